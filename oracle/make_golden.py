@@ -1,0 +1,236 @@
+"""Pin oracle/sb_oracle.py against the REAL reference and write tests/golden/*.npz.
+
+Runs only in the build container (needs /root/reference).  For every stage of
+the hot path it (1) runs SpeechBrain's own modules on CPU, (2) runs the oracle
+restatement on the same seeded weights / inputs, (3) asserts agreement within
+the stated tolerance and (4) stores inputs, weights and the REFERENCE outputs as
+small fixtures.  The fixtures travel to the GPU box; /root/reference does not.
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz
+
+Test infrastructure only - nothing under speechbrain_amd/ imports this.
+"""
+
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("SB_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, "ref_stubs"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import sb_oracle as O  # noqa: E402
+
+torch.set_num_threads(8)
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def maxdiff(a, b):
+    return float((a - b).abs().max())
+
+
+def check(name, ref, got, tol):
+    d = maxdiff(ref, got)
+    print(f"  {name:40s} max|d| = {d:.3e}  (tol {tol:g})")
+    assert d <= tol, name
+
+
+def np_sd(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+# ---------------------------------------------------------------- Fbank
+def golden_fbank():
+    from speechbrain.lobes.features import Fbank
+    from speechbrain.processing.features import InputNormalization
+
+    print("[fbank]")
+    g = torch.Generator().manual_seed(1234)
+    wav = 0.1 * torch.randn(3, 4000, generator=g)
+    wav[1, 3000:] = 0.0  # zero right-padding like batch_pad_right
+    wav[2] *= torch.linspace(1.0, 1e-3, 4000)  # wide dynamic range -> exercises the top_db floor
+    out = {"wav": wav.numpy()}
+    for tag, n_fft, win in (("L", 512, 32), ("S", 400, 25)):
+        ref = Fbank(n_fft=n_fft, n_mels=80, win_length=win)(wav)
+        cfg = O.FbankCfg(n_fft=n_fft, n_mels=80, win_length_ms=win)
+        got = O.fbank(wav, cfg)
+        check(f"fbank {tag} n_fft={n_fft}", ref, got, 2e-3)
+        out[f"fbank_{tag}"] = ref.numpy()
+    # global input normalisation with fixed stats
+    norm = InputNormalization(norm_type="global")
+    norm.eval()
+    mean = torch.linspace(-60, -20, 80)
+    std = torch.linspace(5, 15, 80)
+    norm.glob_mean, norm.glob_std, norm.count = mean, std, 1
+    x = torch.from_numpy(out["fbank_L"])
+    lens = torch.tensor([1.0, 0.75, 1.0])
+    ref = norm(x, lens)
+    check("input_norm global", ref, O.input_norm_global(x, mean, std), 1e-6)
+    out["norm_mean"], out["norm_std"], out["normed_L"] = mean.numpy(), std.numpy(), ref.numpy()
+    sn = InputNormalization(norm_type="sentence")
+    sn.eval()
+    ref = sn(x, lens)
+    check("input_norm sentence", ref, O.input_norm_sentence(x, lens), 1e-4)
+    out["lens"], out["normed_sentence_L"] = lens.numpy(), ref.numpy()
+    np.savez_compressed(os.path.join(OUT, "fbank.npz"), **out)
+
+
+# ---------------------------------------------------------------- model
+def build_reference(d_model, nhead, d_ffn, n_enc, n_dec, vocab, seed):
+    from speechbrain.lobes.models.convolution import ConvolutionFrontEnd
+    from speechbrain.lobes.models.transformer.TransformerASR import TransformerASR
+    from speechbrain.nnet.linear import Linear
+
+    torch.manual_seed(seed)
+    cnn = ConvolutionFrontEnd(
+        input_shape=(8, 10, 80), num_blocks=2, num_layers_per_block=1, out_channels=(64, 32),
+        kernel_sizes=(3, 3), strides=(2, 2), residuals=(False, False),
+    )
+    tr = TransformerASR(
+        input_size=640, tgt_vocab=vocab, d_model=d_model, nhead=nhead, num_encoder_layers=n_enc,
+        num_decoder_layers=n_dec, d_ffn=d_ffn, dropout=0.1, activation=torch.nn.GELU,
+        encoder_module="conformer", attention_type="RelPosMHAXL", normalize_before=True, causal=False,
+    )
+    ctc_lin = Linear(input_size=d_model, n_neurons=vocab)
+    seq_lin = Linear(input_size=d_model, n_neurons=vocab)
+    mods = torch.nn.ModuleDict({"CNN": cnn, "Transformer": tr, "seq_lin": seq_lin, "ctc_lin": ctc_lin})
+    mods.eval()
+    # random LayerNorm affines / biases so that they are exercised (default init is 1/0)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in mods.named_parameters():
+            if p.dim() == 1 or "norm" in n:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    return mods
+
+
+def golden_model(tag, d_model, nhead, d_ffn, n_enc, n_dec, vocab, B, n_frames, beam, ctc_w, seed=0,
+                 max_ratio=1.0, min_ratio=0.0, eos_thr=False, sharpen=1.0):
+    from speechbrain.decoders import S2STransformerBeamSearcher, S2STransformerGreedySearcher
+    from speechbrain.decoders.scorer import CTCScorer, ScorerBuilder
+
+    print(f"[model {tag}] d={d_model} H={nhead} enc={n_enc} dec={n_dec} V={vocab} B={B} beam={beam} ctc={ctc_w}")
+    mods = build_reference(d_model, nhead, d_ffn, n_enc, n_dec, vocab, seed)
+    if sharpen != 1.0:  # peakier posteriors => EOS and non-trivial beams appear
+        with torch.no_grad():
+            mods["seq_lin"].w.weight.mul_(sharpen)
+            mods["ctc_lin"].w.weight.mul_(sharpen)
+    sd = {k: v.detach().clone() for k, v in mods.state_dict().items()}
+    cfg = O.ModelCfg(d_model=d_model, nhead=nhead, num_encoder_layers=n_enc, num_decoder_layers=n_dec,
+                     d_ffn=d_ffn, vocab=vocab)
+    g = torch.Generator().manual_seed(4321 + seed)
+    feats = torch.randn(B, n_frames, 80, generator=g)
+    wav_lens = torch.linspace(0.6, 1.0, B) if B > 1 else torch.ones(1)
+    out = {"feats": feats.numpy(), "wav_lens": wav_lens.numpy()}
+    with torch.no_grad():
+        cnn_ref = mods["CNN"](feats)
+        check("conv front-end", cnn_ref, O.conv_frontend(feats, sd, "CNN."), 1e-5)
+        enc_ref = mods["Transformer"].encode(cnn_ref, wav_lens)
+        enc_got, layers = O.encode(cnn_ref, wav_lens, sd, cfg, "Transformer.", return_layers=True)
+        check("TransformerASR.encode", enc_ref, enc_got, 2e-5)
+        out["cnn_out"], out["enc_out"] = cnn_ref.numpy(), enc_ref.numpy()
+        out["enc_layer0"] = layers[0].numpy()
+        # full-prefix decode
+        T = enc_ref.shape[1]
+        enc_lens = torch.round(T * wav_lens).int()
+        tgt = torch.randint(0, vocab, (B, 5), generator=g)
+        dec_ref, _ = mods["Transformer"].decode(tgt, enc_ref, enc_lens)
+        check("TransformerASR.decode", dec_ref, O.decode(tgt, enc_ref, enc_lens, sd, cfg, "Transformer."), 2e-5)
+        out["dec_tgt"], out["dec_out"] = tgt.numpy(), dec_ref.numpy()
+
+        # greedy
+        gs = S2STransformerGreedySearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                          min_decode_ratio=min_ratio, max_decode_ratio=max_ratio)
+        hyps_r, lens_r, scores_r, lp_r = gs(enc_ref, wav_lens)
+        sc = O.SearchCfg(beam=1, min_decode_ratio=min_ratio, max_decode_ratio=max_ratio)
+        hyps_o, lens_o, scores_o, lp_o = O.greedy_search(enc_ref, wav_lens, sd, cfg, sc)
+        assert hyps_r == hyps_o, (hyps_r, hyps_o)
+        check("greedy scores", scores_r.squeeze(1), scores_o, 1e-4)
+        print("  greedy hyps lens:", [len(h) for h in hyps_r])
+        out["greedy_hyps"] = np.array([h + [-1] * (64 - len(h)) for h in hyps_r], dtype=np.int64)
+        out["greedy_scores"] = scores_r.squeeze(1).numpy()
+
+        # beam search (+ CTC)
+        scorer = None
+        if ctc_w > 0:
+            scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)],
+                                   weights={"ctc": ctc_w})
+        bs = S2STransformerBeamSearcher(
+            modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=min_ratio,
+            max_decode_ratio=max_ratio, beam_size=beam, using_eos_threshold=eos_thr, length_normalization=True,
+            scorer=scorer,
+        )
+        hyps_r, lens_r, scores_r, lp_r = bs(enc_ref.clone(), wav_lens)
+        sc = O.SearchCfg(beam=beam, ctc_weight=ctc_w, min_decode_ratio=min_ratio, max_decode_ratio=max_ratio,
+                         using_eos_threshold=eos_thr)
+        tr = O.SearchTrace()
+        hyps_o, lens_o, scores_o, lp_o = O.beam_search(enc_ref, wav_lens, sd, cfg, sc, trace=tr)
+        print("  beam hyps lens:", [len(h) for h in hyps_r], "steps:", len(tr.tokens))
+        assert hyps_r == hyps_o, (hyps_r, hyps_o)
+        check("beam best scores", scores_r, scores_o, 1e-4)
+        check("beam lens", lens_r, lens_o, 1e-6)
+        for a, b in zip(lp_r, lp_o):
+            check("beam best log_probs", a[: b.numel()], b, 1e-4)
+            break
+        out["beam_hyps"] = np.array([h + [-1] * (64 - len(h)) for h in hyps_r], dtype=np.int64)
+        out["beam_scores"], out["beam_lens"] = scores_r.numpy(), lens_r.numpy()
+        out["beam_step0_am"] = tr.am_log_probs[0].numpy()
+        if ctc_w > 0:
+            out["beam_step0_ctc"] = tr.ctc_scores[0].numpy()
+            out["beam_step1_ctc"] = tr.ctc_scores[1].numpy()
+            out["beam_step1_tok"] = tr.tokens[0].numpy()
+        # beam = 1 through the beam searcher (north-star "greedy beam=1")
+        bs1 = S2STransformerBeamSearcher(
+            modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=min_ratio,
+            max_decode_ratio=max_ratio, beam_size=1, using_eos_threshold=False, length_normalization=True)
+        hyps1_r, _, s1_r, _ = bs1(enc_ref.clone(), wav_lens)
+        hyps1_o, _, s1_o, _ = O.beam_search(enc_ref, wav_lens, sd, cfg,
+                                            O.SearchCfg(beam=1, min_decode_ratio=min_ratio, max_decode_ratio=max_ratio))
+        assert hyps1_r == hyps1_o
+        out["beam1_hyps"] = np.array([h + [-1] * (64 - len(h)) for h in hyps1_r], dtype=np.int64)
+        out["beam1_scores"] = s1_r.numpy()
+    out["cfg"] = np.array([d_model, nhead, d_ffn, n_enc, n_dec, vocab, beam, int(eos_thr)], dtype=np.int64)
+    out["cfgf"] = np.array([ctc_w, max_ratio, min_ratio], dtype=np.float64)
+    for k, v in np_sd(sd).items():
+        out["sd/" + k] = v
+    path = os.path.join(OUT, f"model_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# ---------------------------------------------------------------- init parity
+def golden_init_fingerprint():
+    """Same-seed construction fingerprint of the reference Conformer-S, so that the
+    product's constructors can be checked to draw identical weights (host logic)."""
+    print("[init fingerprint]")
+    torch.manual_seed(0)
+    from speechbrain.lobes.models.transformer.TransformerASR import TransformerASR
+
+    tr = TransformerASR(input_size=640, tgt_vocab=100, d_model=48, nhead=4, num_encoder_layers=2,
+                        num_decoder_layers=2, d_ffn=96, activation=torch.nn.GELU, encoder_module="conformer",
+                        attention_type="RelPosMHAXL", normalize_before=True, causal=False)
+    fp = {k: np.array([float(v.double().sum()), float(v.double().abs().sum()), v.numel()])
+          for k, v in tr.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "init_fingerprint.npz"), **fp)
+    print(f"  {len(fp)} tensors")
+
+
+if __name__ == "__main__":
+    golden_fbank()
+    # tiny model, EOS reachable (sharpened heads), CTC on
+    golden_model("tiny_ctc", d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=2, vocab=40, B=3, n_frames=61,
+                 beam=4, ctc_w=0.4, sharpen=6.0, max_ratio=1.0)
+    # tiny model without scorer, eos threshold on, min_decode_ratio > 0
+    golden_model("tiny_noctc", d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=2, vocab=40, B=2, n_frames=45,
+                 beam=3, ctc_w=0.0, sharpen=6.0, eos_thr=True, min_ratio=0.2, seed=1)
+    # odd head_dim (Conformer-S like: Dh = 36) and B = 1
+    golden_model("dh36", d_model=72, nhead=2, d_ffn=96, n_enc=1, n_dec=1, vocab=30, B=1, n_frames=37,
+                 beam=2, ctc_w=0.4, sharpen=4.0, seed=2)
+    golden_init_fingerprint()
+    print("OK")
