@@ -1,0 +1,114 @@
+/* sbk.h -- C ABI of libsbk_hip.so, the MI355X (gfx950) kernels behind the
+ * SpeechBrain EncoderDecoderASR hot path.
+ *
+ * The reference (speechbrain v1.1.0) is pure Python: it has no FFI/plugin
+ * registry; each entry point below replaces the ATen call(s) made by the cited
+ * reference function (paths relative to /root/reference/speechbrain).  The
+ * reference-side binding (a ctypes stub per module) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is DEVICE memory owned by the caller (PyTorch-allocated);
+ *    the library never allocates, frees or retains pointers past the call;
+ *  - tensors are row-major contiguous fp32 unless stated; lengths are int32;
+ *  - calls are asynchronous on `stream` (a hipStream_t) and never synchronise;
+ *  - return 0 on success, a negative errno-style code for bad arguments
+ *    (SBK_EINVAL = -22), a positive hipError_t if a launch failed;
+ *    sbk_last_error() returns the thread-local message of the last failure;
+ *  - re-entrant; one host thread per process per GPU is the intended use.
+ */
+#ifndef SBK_H_
+#define SBK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBK_ABI_VERSION 1
+
+typedef void* sbk_stream_t; /* hipStream_t */
+
+int sbk_abi_version(void);
+const char* sbk_last_error(void);
+
+/* ---- activations understood by fused epilogues --------------------------- */
+enum { SBK_ACT_NONE = 0, SBK_ACT_SWISH = 1, SBK_ACT_GELU = 2, SBK_ACT_RELU = 3, SBK_ACT_LEAKY_RELU = 4 };
+
+/* ---- a2-a5: Fbank -------------------------------------------------------
+ * Replaces lobes/features.py:147-169 (Fbank.forward) = processing/features.py
+ * :141-188 (STFT -> torch.stft), :341-378 (spectral_magnitude, power=1),
+ * :512-586 (Filterbank.forward matmul) and :736-759 (_amplitude_to_DB with the
+ * per-utterance max - top_db floor).
+ *   wav      [B,N]            waveforms (zero right-padded)
+ *   window   [n_fft]          analysis window, already centred in n_fft
+ *   twiddle  [n_fft,2]        (cos, -sin)(2 pi m / n_fft), m = 0..n_fft-1
+ *   radices  [n_radix]        host int array, product = n_fft, each in {2,3,4,5}
+ *   mel_w    [nnz], mel_ptr [n_mels+1], mel_bin [n_mels]: CSR-by-filter form of
+ *            the [n_stft,n_mels] filter matrix (each filter = one contiguous
+ *            run of bins starting at mel_bin[m], weights mel_w[mel_ptr[m]..])
+ *   out      [B,T,n_mels]     T = 1 + N/hop
+ *   tile_max [B,ntiles]       workspace, ntiles = ceil(T/4)
+ *   norm_mean/norm_std [n_mels] or NULL: fuse InputNormalization(global, eval)
+ *            (processing/features.py:1404-1455) into the dB pass.
+ */
+int sbk_fbank_f32(const float* wav, const float* window, const float* twiddle, const int32_t* radices,
+                  int n_radix, const float* mel_w, const int32_t* mel_ptr, const int32_t* mel_bin, float* out,
+                  float* tile_max, int B, int N, int n_fft, int hop, int n_mels, int nnz, float amin, float top_db,
+                  const float* norm_mean, const float* norm_std, float norm_eps, sbk_stream_t stream);
+
+/* a6: InputNormalization.forward, eval, norm_type="global" (features.py:1404-1455):
+ * y = (x - mean[c]) / max(std[c], eps), x [rows, C]. */
+int sbk_input_norm_global_f32(const float* x, const float* mean, const float* std, float* y, int rows, int C,
+                              float eps, sbk_stream_t stream);
+
+/* ---- dense contraction ---------------------------------------------------
+ * C[M,N] = epilogue(A[M,K] . W[N,K]^T): replaces every F.linear / 1x1 Conv1d on
+ * the path (nnet/linear.py:44-91, attention.py:623,915-947, Conformer.py
+ * :129,155, Transformer.py decoder projections).  fp32 MFMA (exact f32 fma).
+ *   v = acc + bias[n] (bias may be NULL); v = act(v);
+ *   if seq_len: rows are [batch][rows_per_seq] and v = 0 for row-in-seq >= seq_len[batch]
+ *               (ConvolutionModule's masked_fill_ of padded frames, Conformer.py:327-328)
+ *   C = (residual ? residual[m,n] : 0) + alpha * v
+ * lda / ldw / ldc / ldr are row strides in elements. */
+int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual,
+                    int ldr, float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
+                    int rows_per_seq, sbk_stream_t stream);
+
+/* ---- LayerNorm over the last dimension (nnet/normalization.py:185-242,
+ * torch.nn.LayerNorm at Conformer.py:126,152,426,437): y = act(LN(x)), x [rows,d]. */
+int sbk_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int rows, int d, float eps,
+                      int act, sbk_stream_t stream);
+
+/* ---- a7: one ConvolutionFrontEnd block (lobes/models/convolution.py:311-317):
+ * reflect-pad(1) + Conv2d(3x3, stride 2, bias) (nnet/CNN.py:654-751) ->
+ * LayerNorm over (F',C') eps (nnet/normalization.py:185-242) -> LeakyReLU(slope).
+ *   x [B,Tin,Fin,Cin] -> y [B,Tout,Fout,Cout], Tout = (Tin-1)/2+1, Fout = (Fin-1)/2+1
+ *   wt [Cin*9, Cout] = conv.weight[Cout,Cin,kF,kT] re-laid-out as row (ci*3+kf)*3+kt
+ *   gamma/beta [Fout*Cout] */
+int sbk_conv_block_f32(const float* x, const float* wt, const float* bias, const float* gamma, const float* beta,
+                       float* y, int B, int Tin, int Fin, int Cin, int Cout, float eps, float slope,
+                       sbk_stream_t stream);
+
+/* ---- a12: RelPosMHAXL core (nnet/attention.py:555-742 minus the two Linear layers):
+ *   qkv  [B,T,H,3*Dh] = F.linear(x, in_proj_weight) viewed per head as (q|k|v) (:623-626)
+ *   pos  [2T-1,H*Dh]  = linear_pos(RelPosEncXL(T))                            (:655)
+ *   bias_u/bias_v [H*Dh]: pos_bias_u/v storage read as (H,Dh)                  (:660-664)
+ *   key_len [B] int32 or NULL: keys >= key_len[b] are masked (key_padding_mask)
+ *   out  [B,T,H*Dh]   context before out_proj;  attn [B,H,T,T] or NULL (attention weights)
+ *   scale = 1/sqrt(embed_dim) (:521).  Dh in {8,16,32,36,64}; T up to ~1100 (LDS strip). */
+int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
+                             const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,
+                             float scale, sbk_stream_t stream);
+
+/* ---- a13: middle of ConvolutionModule (Conformer.py:315-330): GLU over channels of the
+ * pointwise-conv output followed by the depthwise Conv1d (kernel ksize, zero padding
+ * (ksize-1)/2, groups = d) + bias.   h [B,T,2d] -> y [B,T,d];  w [d,ksize]; bias [d]. */
+int sbk_glu_dwconv_f32(const float* h, const float* w, const float* bias, float* y, int B, int T, int d, int ksize,
+                       sbk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBK_H_ */

@@ -1,0 +1,183 @@
+// Fused STFT -> power -> mel -> dB (-> top_db floor -> global norm)   (sbk_fbank_f32)
+//
+// Roofline: HBM.  Algorithmic traffic per audio-second (16 kHz, 80 mels, hop
+// 160): 64 000 B of samples in + 32 032 B of features out (+ the same 32 KB
+// re-read/re-written by the floor pass, L2-resident for LibriSpeech-length
+// utterances).  Nothing else touches HBM: frames are cut straight out of the
+// waveform (each sample is fetched ~n_fft/hop times, all but the first from
+// L1/L2), the FFT runs entirely in LDS, and the twiddle table and the
+// compacted mel filterbank are LDS-staged once per workgroup.
+//
+// Kernel 1: one wavefront per frame (4 frames per 256-thread workgroup).
+//   Stockham autosort FFT, mixed radix {2,3,4,5} so that both recipe sizes
+//   (n_fft = 512 = 4^4*2 and n_fft = 400 = 5*5*4*4) stay in LDS; power
+//   spectrum; triangular filters as contiguous bin runs (CSR by filter);
+//   10*log10(max(.,amin)); per-tile max for the per-utterance floor.
+// Kernel 2: floor at (utterance max - top_db) and optional (x-mean)/std.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxRadix = 12;
+struct Radices {
+  int n;
+  int r[kMaxRadix];
+};
+
+struct FbankArgs {
+  const float* wav;
+  const float* window;
+  const float* twiddle;
+  const float* mel_w;
+  const int32_t* mel_ptr;
+  const int32_t* mel_bin;
+  float* out;
+  float* tile_max;
+  int B, N, T, n_fft, hop, n_mels, nnz, ntiles;
+  float amin;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+__global__ void __launch_bounds__(256) fbank_frames_kernel(FbankArgs a, Radices rad) {
+  SBK_DYN_LDS(float, lds);
+  const int n_fft = a.n_fft, n_stft = a.n_fft / 2 + 1;
+  float2* tw = reinterpret_cast<float2*>(lds);                    // [n_fft]
+  float2* bufs = tw + n_fft;                                      // [4 waves][2][n_fft]
+  float* pw = reinterpret_cast<float*>(bufs + 4 * 2 * n_fft);     // [4 waves][n_stft]
+  float* melw = pw + 4 * n_stft;                                  // [nnz]
+  float* wmax = melw + a.nnz;                                     // [4]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 4 + wave;
+
+  for (int i = tid; i < n_fft; i += 256) tw[i] = make_float2(a.twiddle[2 * i], a.twiddle[2 * i + 1]);
+  for (int i = tid; i < a.nnz; i += 256) melw[i] = a.mel_w[i];
+
+  float2* cur = bufs + (wave * 2 + 0) * n_fft;
+  float2* nxt = bufs + (wave * 2 + 1) * n_fft;
+  {  // cut the (centre-padded) frame out of the waveform and window it
+    const float* w = a.wav + (size_t)b * a.N;
+    const long base = (long)t * a.hop - n_fft / 2;
+    for (int n = lane; n < n_fft; n += 64) {
+      const long idx = base + n;
+      const float x = (t < a.T && idx >= 0 && idx < a.N) ? w[idx] : 0.0f;
+      cur[n] = make_float2(x * a.window[n], 0.0f);
+    }
+  }
+  __syncthreads();
+
+  int Ns = 1;
+  for (int p = 0; p < rad.n; ++p) {
+    const int R = rad.r[p];
+    const int nb = n_fft / R;          // butterflies in this pass
+    const int tstep = n_fft / (Ns * R);  // twiddle stride of this pass
+    const int rstep = n_fft / R;       // stride of the R-point DFT's own roots
+    for (int j = lane; j < nb; j += 64) {
+      const int k = j % Ns;
+      float2 v[5];
+      for (int q = 0; q < R; ++q) v[q] = cmul(cur[j + q * nb], tw[k * q * tstep]);
+      const int dst = (j / Ns) * Ns * R + k;
+      for (int u = 0; u < R; ++u) {
+        float2 acc = v[0];
+        for (int q = 1; q < R; ++q) {
+          const float2 c = cmul(v[q], tw[((u * q) % R) * rstep]);
+          acc.x += c.x;
+          acc.y += c.y;
+        }
+        nxt[dst + u * Ns] = acc;
+      }
+    }
+    __syncthreads();
+    float2* tmp = cur;
+    cur = nxt;
+    nxt = tmp;
+    Ns *= R;
+  }
+
+  float* mypw = pw + wave * n_stft;
+  for (int f = lane; f < n_stft; f += 64) mypw[f] = cur[f].x * cur[f].x + cur[f].y * cur[f].y;
+  __syncthreads();
+
+  float mx = -INFINITY;
+  for (int m = lane; m < a.n_mels; m += 64) {
+    const int p0 = a.mel_ptr[m], p1 = a.mel_ptr[m + 1], f0 = a.mel_bin[m];
+    float acc = 0.0f;
+    for (int i = p0; i < p1; ++i) acc = fmaf(mypw[f0 + (i - p0)], melw[i], acc);
+    const float db = 10.0f * log10f(fmaxf(acc, a.amin));
+    if (t < a.T) {
+      a.out[((size_t)b * a.T + t) * a.n_mels + m] = db;
+      mx = fmaxf(mx, db);
+    }
+  }
+  mx = sbk::wave_max(mx);
+  if (lane == 0) wmax[wave] = mx;
+  __syncthreads();
+  if (tid == 0) a.tile_max[(size_t)b * a.ntiles + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+}
+
+__global__ void __launch_bounds__(256) fbank_floor_norm_kernel(float* __restrict__ x, const float* __restrict__ tile_max,
+                                                               int ntiles, long per_utt, int n_mels, float top_db,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ sd, float eps) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  float mx = -INFINITY;
+  for (int i = tid; i < ntiles; i += 256) mx = fmaxf(mx, tile_max[(size_t)b * ntiles + i]);
+  mx = sbk::wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  const float floor_db = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - top_db;
+  float* xb = x + (size_t)b * per_utt;
+  for (long i = (long)blockIdx.x * 256 + tid; i < per_utt; i += (long)gridDim.x * 256) {
+    float v = fmaxf(xb[i], floor_db);
+    if (mean) {
+      const int m = (int)(i % n_mels);
+      v = (v - mean[m]) / fmaxf(sd[m], eps);
+    }
+    xb[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int sbk_fbank_f32(const float* wav, const float* window, const float* twiddle, const int32_t* radices,
+                             int n_radix, const float* mel_w, const int32_t* mel_ptr, const int32_t* mel_bin,
+                             float* out, float* tile_max, int B, int N, int n_fft, int hop, int n_mels, int nnz,
+                             float amin, float top_db, const float* norm_mean, const float* norm_std, float norm_eps,
+                             sbk_stream_t stream) {
+  SBK_REQUIRE(wav && window && twiddle && radices && mel_w && mel_ptr && mel_bin && out && tile_max,
+              "fbank: null operand");
+  SBK_REQUIRE(B >= 0 && N >= 0 && n_fft >= 2 && hop > 0 && n_mels > 0 && nnz >= 0, "fbank: bad shape");
+  SBK_REQUIRE(n_radix > 0 && n_radix <= kMaxRadix, "fbank: %d FFT passes", n_radix);
+  SBK_REQUIRE((norm_mean == nullptr) == (norm_std == nullptr), "fbank: need both mean and std or neither");
+  Radices rad;
+  rad.n = n_radix;
+  long prod = 1;
+  for (int i = 0; i < n_radix; ++i) {
+    rad.r[i] = radices[i];
+    SBK_REQUIRE(radices[i] >= 2 && radices[i] <= 5, "fbank: radix %d unsupported (n_fft must factor into 2,3,4,5)",
+                radices[i]);
+    prod *= radices[i];
+  }
+  SBK_REQUIRE(prod == n_fft, "fbank: radices do not multiply to n_fft=%d", n_fft);
+  if (B == 0) return 0;
+  const int T = 1 + N / hop;
+  const int ntiles = sbk::cdiv(T, 4);
+  const int n_stft = n_fft / 2 + 1;
+  const size_t lds = (size_t)n_fft * 8 + (size_t)4 * 2 * n_fft * 8 + (size_t)4 * n_stft * 4 + (size_t)nnz * 4 + 16;
+  SBK_REQUIRE(lds <= 160 * 1024, "fbank: n_fft=%d needs %zu B of LDS", n_fft, lds);
+  FbankArgs a{wav, window, twiddle, mel_w, mel_ptr, mel_bin, out, tile_max, B, N, T, n_fft, hop, n_mels, nnz, ntiles, amin};
+  hipStream_t st = sbk::as_stream(stream);
+  SBK_LAUNCH(fbank_frames_kernel, dim3(ntiles, B), dim3(256), lds, st, a, rad);
+  int rc = sbk::launch_status("sbk_fbank_f32/frames");
+  if (rc) return rc;
+  const long per_utt = (long)T * n_mels;
+  const int gx = (int)((per_utt + 2047) / 2048 < 1 ? 1 : (per_utt + 2047) / 2048);
+  SBK_LAUNCH(fbank_floor_norm_kernel, dim3(gx, B), dim3(256), 0, st, out, tile_max, ntiles, per_utt, n_mels, top_db,
+             norm_mean, norm_std, norm_eps);
+  return sbk::launch_status("sbk_fbank_f32/floor");
+}

@@ -1,0 +1,176 @@
+// fp32 MFMA GEMM  C[M,N] = epilogue(A[M,K] . W[N,K]^T)   (sbk_gemm_nt_f32)
+//
+// Roofline: MFMA fp32 (v_mfma_f32_32x32x2_f32, 157 TFLOP/s dense on MI355X).
+// One workgroup owns a BM x BN tile of C; its waves each own a WM x WN
+// sub-tile made of 32x32 MFMA accumulators.  A and W panels are staged through
+// LDS as [rows][BK+1] (odd pitch => the 32 lanes of an MFMA operand read hit 32
+// distinct banks), loaded from HBM as 16-byte vectors along K (both operands
+// are K-contiguous, so every global load is a full 128-byte line per 8 lanes).
+// The epilogue (bias, activation, scaled residual) runs on the accumulators in
+// registers and writes 128-byte rows (32 lanes x 4 B) per store instruction.
+#include "common.h"
+
+namespace {
+
+using sbk::f32x16;
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case SBK_ACT_SWISH: return v / (1.0f + expf(-v));
+    case SBK_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case SBK_ACT_RELU: return v > 0.0f ? v : 0.0f;
+    case SBK_ACT_LEAKY_RELU: return v > 0.0f ? v : 0.01f * v;
+    default: return v;
+  }
+}
+
+struct GemmArgs {
+  const float* A;
+  const float* W;
+  const float* bias;
+  const float* R;
+  float* C;
+  int lda, ldw, ldr, ldc, M, N, K, act;
+  float alpha;
+  const int32_t* seq_len;  // optional: rows are [batch][rows_per_seq]; rows >= seq_len[batch] produce v = 0
+  int rows_per_seq;
+};
+
+// Stage a [ROWS x BK] panel of a K-contiguous matrix into LDS (pitch BK+1).
+template <int ROWS, int BK, int NT, bool VEC>
+__device__ __forceinline__ void stage_panel(float (*dst)[BK + 1], const float* __restrict__ src, int ld, int row0,
+                                            int nrows, int k0, int K, int tid) {
+  if (VEC) {
+    constexpr int V = BK / 4;  // float4 slots per row
+    for (int s = tid; s < ROWS * V; s += NT) {
+      const int r = s / V, c = (s % V) * 4;
+      const int gr = row0 + r, gk = k0 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < nrows) {
+        const float* p = src + (size_t)gr * ld + gk;
+        if (gk + 3 < K) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (gk < K) v.x = p[0];
+          if (gk + 1 < K) v.y = p[1];
+          if (gk + 2 < K) v.z = p[2];
+        }
+      }
+      dst[r][c] = v.x;
+      dst[r][c + 1] = v.y;
+      dst[r][c + 2] = v.z;
+      dst[r][c + 3] = v.w;
+    }
+  } else {
+    for (int s = tid; s < ROWS * BK; s += NT) {
+      const int r = s / BK, c = s % BK;
+      const int gr = row0 + r, gk = k0 + c;
+      dst[r][c] = (gr < nrows && gk < K) ? src[(size_t)gr * ld + gk] : 0.0f;
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool VEC>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(GemmArgs g) {
+  constexpr int WAVES_N = BN / WN;
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  __shared__ float As[BM][BK + 1];
+  __shared__ float Ws[BN][BK + 1];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int lrow = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    stage_panel<BM, BK, NT, VEC>(As, g.A, g.lda, m0, g.M, k0, g.K, tid);
+    stage_panel<BN, BK, NT, VEC>(Ws, g.W, g.ldw, n0, g.N, k0, g.K, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[wm0 + i * 32 + lrow][kk + lk];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Ws[wn0 + j * 32 + lrow][kk + lk];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x2(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn0 + j * 32 + lrow;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        float v = apply_act(acc[i][j][r] + bv, g.act) * g.alpha;
+        if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
+        if (g.R) v += g.R[(size_t)row * g.ldr + col];
+        g.C[(size_t)row * g.ldc + col] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
+  dim3 grid(sbk::cdiv(g.N, BN), sbk::cdiv(g.M, BM));
+  dim3 block((BM / WM) * (BN / WN) * 64);
+  if (vec) {
+    SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, true>), grid, block, 0, st, g);
+  } else {
+    SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, false>), grid, block, 0, st, g);
+  }
+  return sbk::launch_status("sbk_gemm_nt_f32");
+}
+
+}  // namespace
+
+namespace sbk {
+// Internal C++ entry shared with the fused pipelines (decoder step, encoder).
+int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
+            int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st) {
+  if (M == 0 || N == 0) return 0;
+  GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
+  const bool vec = (lda % 4 == 0) && (ldw % 4 == 0) && aligned16(A) && aligned16(W);
+  // Tile choice: keep >= ~1 workgroup per CU where the problem allows it.
+  const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
+  const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
+  if (tiles128 >= 384) return launch_gemm<128, 128, 32, 64, 64>(g, vec, st);
+  if (tiles64 >= 256 || M > 256) return launch_gemm<64, 64, 32, 32, 32>(g, vec, st);
+  return launch_gemm<32, 64, 32, 32, 32>(g, vec, st);
+}
+}  // namespace sbk
+
+extern "C" int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
+                               const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
+                               float alpha, const int32_t* seq_len, int rows_per_seq, sbk_stream_t stream) {
+  SBK_REQUIRE(A && W && C, "gemm: null operand");
+  SBK_REQUIRE(M >= 0 && N >= 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+  SBK_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dimension smaller than the row");
+  SBK_REQUIRE(!residual || ldr >= N, "gemm: residual stride");
+  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm: unknown activation %d", act);
+  SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm: seq_len given without rows_per_seq");
+  return sbk::gemm_nt(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq,
+                      sbk::as_stream(stream));
+}

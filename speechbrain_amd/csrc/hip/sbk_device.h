@@ -1,0 +1,61 @@
+// Device-side vocabulary for the gfx950 kernels (wave64, MFMA, LDS).
+//
+// Every kernel in csrc/ is written against the handful of names declared here
+// so that the source reads as plain CDNA4 HIP.  (tools/kernel_emu/ ships a
+// header of the same name that gives these names host semantics, so kernels
+// can be single-stepped on a CPU during development; it is test tooling and is
+// never on the include path of the shipped library.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sbk {
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// D(32x32) += A(32x2) * B(2x32).  Lane l supplies A[l&31][l>>5], B[l>>5][l&31];
+// acc[r] is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].  Exact f32 fma chain.
+__device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+}
+// D(16x16) += A(16x4) * B(4x16).  Lane l supplies A[l&15][l>>4], B[l>>4][l&15];
+// acc[r] is D[(l>>4)*4 + r][l&15].
+__device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, kWave); }
+__device__ __forceinline__ int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, kWave); }
+__device__ __forceinline__ float shfl(float v, int lane) { return __shfl(v, lane, kWave); }
+__device__ __forceinline__ int shfl(int v, int lane) { return __shfl(v, lane, kWave); }
+
+// Orders this wave's LDS traffic in program order (the hardware already runs a
+// wave's DS instructions in order; this pins the compiler's schedule).
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
+  return v;
+}
+
+}  // namespace sbk
+
+// Dynamic LDS window of the launching workgroup.
+#define SBK_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+
+// Raise a kernel's dynamic-LDS window above the 64 KiB default (gfx950 has 160 KiB per CU).
+#define SBK_ALLOW_DYN_LDS(kernel, bytes) \
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+
+// kernel<<<grid, block, lds_bytes, stream>>>(args...)
+#define SBK_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \
+  hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, __VA_ARGS__)

@@ -1,0 +1,17 @@
+// C++-level entry points shared between translation units (the fused pipelines
+// call the same launchers the C ABI exposes, without re-validating arguments).
+#pragma once
+#include "common.h"
+
+namespace sbk {
+int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
+            int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq,
+            hipStream_t st);
+int layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int d, float eps, int act,
+              hipStream_t st);
+int relpos_attention(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
+                     const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh, float scale,
+                     hipStream_t st);
+int glu_dwconv(const float* h, const float* w, const float* bias, float* y, int B, int T, int d, int ksize,
+               hipStream_t st);
+}  // namespace sbk

@@ -1,0 +1,139 @@
+// Row-wise normalisation kernels (HBM-bound; one wavefront per row).
+//
+//  sbk_layernorm_f32        y = act(LayerNorm(x))  over the last dimension
+//  sbk_input_norm_global_f32 y = (x - mean[c]) / max(std[c], eps)
+//
+// A row of d floats (d <= a few thousand on this path) is read by the 64 lanes
+// of one wave with 16-byte loads, reduced with wave shuffles (no LDS, no
+// barrier) and written once: 2*d*4 bytes of HBM traffic per row.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float act_f(float v, int act) {
+  if (act == SBK_ACT_SWISH) return v / (1.0f + expf(-v));
+  if (act == SBK_ACT_LEAKY_RELU) return v > 0.0f ? v : 0.01f * v;
+  if (act == SBK_ACT_RELU) return v > 0.0f ? v : 0.0f;
+  return v;
+}
+
+// MAXV = float4 slots kept in registers per lane (d <= 256*MAXV).
+template <int MAXV>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        int rows, int d, float eps, int act) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool live = row < rows;
+  const int r = live ? row : rows - 1;  // idle waves shadow the last row so shuffles stay full-width
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)r * d);
+  const int nv = d >> 2;
+  float4 v[MAXV];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = sbk::wave_sum(s) / (float)d;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + dd * dd);
+    }
+  }
+  const float rstd = rsqrtf(sbk::wave_sum(q) / (float)d + eps);
+  if (!live) return;
+  float4* yr = reinterpret_cast<float4*>(y + (size_t)row * d);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float4 g = g4[c], b = b4[c];
+      float4 o;
+      o.x = act_f((v[i].x - mean) * rstd * g.x + b.x, act);
+      o.y = act_f((v[i].y - mean) * rstd * g.y + b.y, act);
+      o.z = act_f((v[i].z - mean) * rstd * g.z + b.z, act);
+      o.w = act_f((v[i].w - mean) * rstd * g.w + b.w, act);
+      yr[c] = o;
+    }
+  }
+}
+
+// Any d (scalar loads, three passes over an L1/L2-resident row).
+__global__ void __launch_bounds__(256) layernorm_generic_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ y,
+                                                                int rows, int d, float eps, int act) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool live = row < rows;
+  const int r = live ? row : rows - 1;
+  const float* xr = x + (size_t)r * d;
+  float s = 0.0f;
+  for (int c = lane; c < d; c += 64) s += xr[c];
+  const float mean = sbk::wave_sum(s) / (float)d;
+  float q = 0.0f;
+  for (int c = lane; c < d; c += 64) {
+    const float a = xr[c] - mean;
+    q += a * a;
+  }
+  const float rstd = rsqrtf(sbk::wave_sum(q) / (float)d + eps);
+  if (!live) return;
+  float* yr = y + (size_t)row * d;
+  for (int c = lane; c < d; c += 64) yr[c] = act_f((xr[c] - mean) * rstd * gamma[c] + beta[c], act);
+}
+
+__global__ void __launch_bounds__(256) input_norm_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ sd, float* __restrict__ y,
+                                                         long n, int C, float eps) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    y[i] = (x[i] - mean[c]) / fmaxf(sd[c], eps);
+  }
+}
+
+}  // namespace
+
+namespace sbk {
+int layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int d, float eps, int act,
+              hipStream_t st) {
+  if (rows == 0) return 0;
+  dim3 grid(cdiv(rows, 4)), block(256);
+  const bool vec = (d % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta);
+  if (vec && d <= 256 * 1) {
+    SBK_LAUNCH((layernorm_kernel<1>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, act);
+  } else if (vec && d <= 256 * 2) {
+    SBK_LAUNCH((layernorm_kernel<2>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, act);
+  } else if (vec && d <= 256 * 4) {
+    SBK_LAUNCH((layernorm_kernel<4>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, act);
+  } else {
+    SBK_LAUNCH(layernorm_generic_kernel, grid, block, 0, st, x, gamma, beta, y, rows, d, eps, act);
+  }
+  return launch_status("sbk_layernorm_f32");
+}
+}  // namespace sbk
+
+extern "C" int sbk_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int rows, int d,
+                                 float eps, int act, sbk_stream_t stream) {
+  SBK_REQUIRE(x && gamma && beta && y, "layernorm: null operand");
+  SBK_REQUIRE(rows >= 0 && d > 0, "layernorm: bad shape rows=%d d=%d", rows, d);
+  return sbk::layernorm(x, gamma, beta, y, rows, d, eps, act, sbk::as_stream(stream));
+}
+
+extern "C" int sbk_input_norm_global_f32(const float* x, const float* mean, const float* std, float* y, int rows,
+                                         int C, float eps, sbk_stream_t stream) {
+  SBK_REQUIRE(x && mean && std && y, "input_norm: null operand");
+  SBK_REQUIRE(rows >= 0 && C > 0, "input_norm: bad shape");
+  const long n = (long)rows * C;
+  if (n == 0) return 0;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  SBK_LAUNCH(input_norm_kernel, dim3(blocks), dim3(256), 0, sbk::as_stream(stream), x, mean, std, y, n, C, eps);
+  return sbk::launch_status("sbk_input_norm_global_f32");
+}

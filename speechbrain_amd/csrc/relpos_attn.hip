@@ -1,0 +1,233 @@
+// Fused relative-position self-attention (RelPosMHAXL, Transformer-XL style)
+//                                                      (sbk_relpos_attention_f32)
+//   out = softmax( (q+u)K^T s + shift((q+v)P^T s) , keys < key_len ) V
+//
+// Roofline: MFMA fp32 (three 32x32 contractions per key tile: AC, BD x2, then
+// P.V).  HBM traffic is the fused minimum: q/k/v are read from the interleaved
+// in_proj output [B,T,H,(q|k|v)] exactly as the projection GEMM wrote it, the
+// context is written as [B,T,H*Dh] for out_proj; the [T,2T-1] position-score
+// matrix and the [T,T] score matrix of the reference never exist in HBM.
+//
+// One workgroup = one (batch, head, 32-query tile); its 4 waves split the key
+// tiles.  The relative shift is done in registers: for a 32x32 (query,key)
+// tile the needed position rows are the 63 consecutive rows
+// r = T-1-i+j, so the wave computes G = (Q+v) P[rbase..rbase+63]^T with two
+// MFMA column tiles and every lane adds its G[i][r] straight into
+// S[i][j = r + i - 31 + j0] (each S element is touched by exactly one lane).
+// The whole score strip S[32][T] lives in LDS (T <= ~1100), so the softmax is
+// the exact two-pass form (max, exp, sum, divide) of the reference.
+//
+// MFMA operand trick: the two k-slices of v_mfma_f32_32x32x2 are fed from the
+// two halves of the head dimension (k=0 -> columns [0,Dh/2), k=1 -> [Dh/2,Dh))
+// so each lane's K / P operand is one contiguous Dh/2-float run of a single
+// row: vector loads straight from HBM/L2 into registers, no LDS staging.
+#include "common.h"
+
+namespace {
+
+using sbk::f32x16;
+
+struct AttnArgs {
+  const float* qkv;       // [B,T,H,3*DH]
+  const float* pos;       // [2T-1, H*DH]  = linear_pos(RelPosEncXL table)
+  const float* bias_u;    // [H*DH]  (pos_bias_u storage viewed as (H,DH))
+  const float* bias_v;
+  const int32_t* key_len; // [B] or null
+  float* out;             // [B,T,H*DH]
+  float* attn;            // [B,H,T,T] or null
+  int B, T, H, SP;
+  float scale;
+};
+
+template <int N>
+__device__ __forceinline__ void load_run(float (&dst)[N], const float* __restrict__ p) {
+  if constexpr (N % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      const float4 v = reinterpret_cast<const float4*>(p)[i];
+      dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+    }
+  } else if constexpr (N % 2 == 0) {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+      const float2 v = reinterpret_cast<const float2*>(p)[i];
+      dst[2 * i] = v.x; dst[2 * i + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) dst[i] = p[i];
+  }
+}
+
+template <int DH>
+__global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
+  constexpr int DH2 = DH / 2;
+  constexpr int QP = DH + 1;             // LDS pitch of the Q tiles (odd)
+  constexpr int NC = (DH + 31) / 32;     // 32-wide column tiles of the context
+  constexpr int NPART = 4 / NC;          // waves sharing one column tile in P.V
+  SBK_DYN_LDS(float, lds);
+  float* Qu = lds;                       // [32][QP]   (q + u) * scale
+  float* Qv = Qu + 32 * QP;              // [32][QP]   (q + v) * scale
+  float* red = Qv + 32 * QP;             // [3][32][33] partial contexts
+  float* S = red + 3 * 32 * 33;          // [32][SP]   scores -> probabilities
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & 31, half = lane >> 5;
+  const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int T = a.T, SP = a.SP, d = a.H * DH;
+  const size_t row3 = (size_t)3 * d;
+  const float* qkv_b = a.qkv + (size_t)b * T * row3 + (size_t)h * 3 * DH;
+
+  for (int idx = tid; idx < 32 * DH; idx += 256) {
+    const int i = idx / DH, c = idx % DH;
+    const int row = min(i0 + i, T - 1);
+    const float q = qkv_b[(size_t)row * row3 + c];
+    Qu[i * QP + c] = (q + a.bias_u[h * DH + c]) * a.scale;
+    Qv[i * QP + c] = (q + a.bias_v[h * DH + c]) * a.scale;
+  }
+  __syncthreads();
+
+  // ---- phase 1: S = AC + shifted BD, key tiles round-robin over the waves
+  const int nkt = (T + 31) / 32;
+  for (int kt = wave; kt < nkt; kt += 4) {
+    const int j0 = kt * 32;
+    float breg[DH2];
+    f32x16 acc;
+    {  // AC = (Q+u) K^T
+      const int krow = min(j0 + jl, T - 1);
+      load_run<DH2>(breg, qkv_b + (size_t)krow * row3 + DH + half * DH2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < DH2; ++s) acc = sbk::mfma_32x32x2(Qu[jl * QP + s + half * DH2], breg[s], acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        S[i * SP + j0 + jl] = acc[r];
+      }
+    }
+    sbk::wave_sync();
+    const int rbase = (T - 1) - i0 - 31 + j0;
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {  // BD: G = (Q+v) P[rbase + 32*pt ...]^T, added along the skew
+      const int rl = pt * 32 + jl;
+      const int prow = min(max(rbase + rl, 0), 2 * T - 2);
+      load_run<DH2>(breg, a.pos + (size_t)prow * d + h * DH + half * DH2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < DH2; ++s) acc = sbk::mfma_32x32x2(Qv[jl * QP + s + half * DH2], breg[s], acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int jloc = rl + i - 31;
+        if (jloc >= 0 && jloc < 32) S[i * SP + j0 + jloc] += acc[r];
+      }
+    }
+    sbk::wave_sync();
+  }
+  __syncthreads();
+
+  // ---- phase 2: exact softmax over valid keys, 8 rows per wave
+  int klen = T;
+  if (a.key_len) klen = min(max(a.key_len[b], 1), T);
+  const int kend = nkt * 32;
+  for (int ii = 0; ii < 8; ++ii) {
+    const int i = wave * 8 + ii;
+    float* Srow = S + i * SP;
+    float m = -INFINITY;
+    for (int j = lane; j < klen; j += 64) m = fmaxf(m, Srow[j]);
+    m = sbk::wave_max(m);
+    float sum = 0.0f;
+    for (int j = lane; j < klen; j += 64) {
+      const float e = expf(Srow[j] - m);
+      Srow[j] = e;
+      sum += e;
+    }
+    sum = sbk::wave_sum(sum);
+    for (int j = lane; j < kend; j += 64) Srow[j] = j < klen ? Srow[j] / sum : 0.0f;
+    if (a.attn && i0 + i < T) {
+      float* arow = a.attn + (((size_t)b * a.H + h) * T + (i0 + i)) * T;
+      for (int j = lane; j < T; j += 64) arow[j] = Srow[j];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: context = P . V ; wave -> (column tile, key range)
+  {
+    const int ct = wave % NC, part = wave / NC;
+    const int kspan = (klen + 1) & ~1;
+    int chunk = (kspan + NPART - 1) / NPART;
+    chunk = (chunk + 1) & ~1;
+    const int t_begin = min(part * chunk, kspan), t_end = min(t_begin + chunk, kspan);
+    const int col = ct * 32 + jl;
+    const bool col_ok = col < DH;
+    const float* vbase = qkv_b + 2 * DH + (col_ok ? col : 0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int t0 = t_begin; t0 < t_end; t0 += 2) {
+      const int t = t0 + half;
+      const float pv = S[jl * SP + t];
+      const float vv = col_ok ? vbase[(size_t)min(t, T - 1) * row3] : 0.0f;
+      acc = sbk::mfma_32x32x2(pv, vv, acc);
+    }
+    if (part > 0) {
+      float* dst = red + ((part - 1) * NC + ct) * 32 * 33;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + jl] = acc[r];
+    }
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r];
+        for (int p = 1; p < NPART; ++p) v += red[(((p - 1) * NC + ct) * 32 + i) * 33 + jl];
+        if (col_ok && i0 + i < T) a.out[((size_t)b * T + i0 + i) * d + h * DH + col] = v;
+      }
+    }
+  }
+}
+
+template <int DH>
+int launch_attn(const AttnArgs& a, hipStream_t st) {
+  const size_t lds = ((size_t)2 * 32 * (DH + 1) + 3 * 32 * 33 + (size_t)32 * a.SP) * sizeof(float);
+  if (lds > 160 * 1024) return sbk::fail(SBK_EINVAL, "relpos_attention: T=%d needs %zu B of LDS (max 160 KiB)", a.T, lds);
+  if (lds > 64 * 1024) {
+    hipError_t e = SBK_ALLOW_DYN_LDS((relpos_attn_kernel<DH>), lds);
+    if (e != hipSuccess) return sbk::fail((int)e, "relpos_attention: cannot raise the LDS window to %zu B", lds);
+  }
+  SBK_LAUNCH((relpos_attn_kernel<DH>), dim3((a.T + 31) / 32, a.H, a.B), dim3(256), lds, st, a);
+  return sbk::launch_status("sbk_relpos_attention_f32");
+}
+
+}  // namespace
+
+namespace sbk {
+int relpos_attention(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
+                     const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh, float scale,
+                     hipStream_t st) {
+  if (B == 0 || T == 0) return 0;
+  const int SP = ((T + 31) / 32) * 32 + 1;  // odd pitch: the 32 rows of a P.V operand read hit 32 banks
+  AttnArgs a{qkv, pos, bias_u, bias_v, key_len, out, attn, B, T, H, SP, scale};
+  switch (Dh) {
+    case 64: return launch_attn<64>(a, st);
+    case 36: return launch_attn<36>(a, st);
+    case 32: return launch_attn<32>(a, st);
+    case 16: return launch_attn<16>(a, st);
+    case 8: return launch_attn<8>(a, st);
+    default: return fail(SBK_EINVAL, "relpos_attention: head_dim %d not instantiated (8,16,32,36,64)", Dh);
+  }
+}
+}  // namespace sbk
+
+extern "C" int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
+                                        const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,
+                                        float scale, sbk_stream_t stream) {
+  SBK_REQUIRE(qkv && pos && bias_u && bias_v && out, "relpos_attention: null operand");
+  SBK_REQUIRE(B >= 0 && T >= 0 && H > 0 && Dh > 0, "relpos_attention: bad shape");
+  SBK_REQUIRE(sbk::aligned16(qkv) && sbk::aligned16(pos), "relpos_attention: operands must be 16-byte aligned");
+  return sbk::relpos_attention(qkv, pos, bias_u, bias_v, key_len, out, attn, B, T, H, Dh, scale,
+                               sbk::as_stream(stream));
+}

@@ -1,0 +1,139 @@
+"""Per-kernel parity: every C-ABI op vs the fp32 oracle / a plain torch fp32 restatement.
+
+Each test runs twice: on the CPU emulator of the kernel sources (not gpu) and on
+the MI355X through libsbk_hip.so (``-m gpu``).  Tolerances are absolute fp32.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sb_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _md(a, b):
+    return float((a.cpu() - b.cpu()).abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 50, 36), (33, 130, 64), (200, 96, 72), (320, 64, 32), (300, 20, 34),
+                                   (1000, 300, 128)])
+def test_gemm_bias_act_residual(backend, M, N, K):
+    nat, dev = backend
+    g = torch.Generator().manual_seed(M * 7 + N)
+    # asymmetric operands: catches row/column swaps in the MFMA C layout
+    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01
+    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    for act, fn in ((nat.ACT_NONE, lambda v: v), (nat.ACT_SWISH, F.silu), (nat.ACT_GELU, F.gelu)):
+        out = nat.gemm_nt(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=act, alpha=0.5)
+        ref = r + 0.5 * fn(a.double() @ w.double().t() + b).float()
+        scale = float((a.abs() @ w.abs().t()).max())
+        assert _md(out, ref) <= 2e-6 * scale + 1e-5
+
+
+def test_gemm_row_mask(backend):
+    nat, dev = backend
+    a, w, r = torch.randn(14, 16), torch.randn(12, 16), torch.randn(14, 12)
+    sl = torch.tensor([7, 3], dtype=torch.int32)
+    out = nat.gemm_nt(a.to(dev), w.to(dev), None, r.to(dev), seq_len=sl.to(dev), rows_per_seq=7)
+    ref = a @ w.t()
+    ref[10:] = 0
+    assert _md(out, ref + r) <= 1e-5
+
+
+@pytest.mark.parametrize("d", [32, 144, 512, 640, 2560, 37])
+def test_layernorm(backend, d):
+    nat, dev = backend
+    x, g, b = torch.randn(13, d) * 3 + 1, torch.randn(d), torch.randn(d)
+    out = nat.layernorm(x.to(dev), g.to(dev), b.to(dev), 1e-5)
+    assert _md(out, F.layer_norm(x, (d,), g, b, 1e-5)) <= 1e-5
+    out = nat.layernorm(x.to(dev), g.to(dev), b.to(dev), 1e-6, act=nat.ACT_SWISH)
+    assert _md(out, F.silu(F.layer_norm(x, (d,), g, b, 1e-6))) <= 1e-5
+
+
+def test_fbank_golden(backend):
+    """Fbank vs the REFERENCE's outputs (tests/golden/fbank.npz).  Tolerance 1e-3 dB."""
+    nat, dev = backend
+    from speechbrain_amd.processing.features import FbankFrontend
+
+    g = np.load(os.path.join(GOLD, "fbank.npz"))
+    wav = torch.from_numpy(g["wav"]).to(dev)
+    for tag, n_fft, win in (("L", 512, 32), ("S", 400, 25)):
+        fe = FbankFrontend(n_fft=n_fft, n_mels=80, win_length=win).to(dev)
+        assert _md(fe(wav), torch.from_numpy(g["fbank_" + tag])) <= 1e-3
+    fe = FbankFrontend(n_fft=512, n_mels=80, win_length=32).to(dev)
+    out = fe(wav, torch.from_numpy(g["norm_mean"]).to(dev), torch.from_numpy(g["norm_std"]).to(dev))
+    assert _md(out, torch.from_numpy(g["normed_L"])) <= 2e-4
+
+
+def test_fbank_known_answers(backend):
+    """Reference unit tests for the filterbank (tests/unittests/test_features.py:57-84):
+    silence -> exactly -100 dB; batch invariance."""
+    nat, dev = backend
+    from speechbrain_amd.processing.features import FbankFrontend
+
+    fe = FbankFrontend(n_fft=400, n_mels=40).to(dev)
+    out = fe(torch.zeros(2, 1600, device=dev))
+    assert out.shape == (2, 11, 40)
+    assert torch.all(out.cpu() == -100.0)
+    wav = torch.rand(1, 3200, generator=torch.Generator().manual_seed(3))
+    one = fe(wav.to(dev))
+    rep = fe(wav.repeat(3, 1).to(dev))
+    assert _md(rep[2], one[0]) <= 8e-5
+
+
+def test_conv_frontend_golden(backend):
+    nat, dev = backend
+    g = np.load(os.path.join(GOLD, "model_tiny_ctc.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    h = torch.from_numpy(g["feats"]).unsqueeze(-1).contiguous().to(dev)
+    for i in range(2):
+        w = sd[f"CNN.convblock_{i}.convs.conv_0.conv.weight"]
+        wt = w.permute(1, 2, 3, 0).reshape(-1, w.shape[0]).contiguous()
+        h = nat.conv_block(h, wt.to(dev), sd[f"CNN.convblock_{i}.convs.conv_0.conv.bias"].to(dev),
+                           sd[f"CNN.convblock_{i}.convs.norm_0.norm.weight"].reshape(-1).contiguous().to(dev),
+                           sd[f"CNN.convblock_{i}.convs.norm_0.norm.bias"].reshape(-1).contiguous().to(dev), w.shape[0])
+    assert _md(h, torch.from_numpy(g["cnn_out"])) <= 2e-5
+
+
+@pytest.mark.parametrize("B,T,H,Dh,lens", [(2, 45, 4, 8, [45, 30]), (1, 70, 2, 36, [70]), (2, 33, 2, 64, [33, 20]),
+                                           (1, 100, 1, 16, None), (1, 40, 2, 32, [17]), (2, 251, 2, 64, [251, 129])])
+def test_relpos_attention(backend, B, T, H, Dh, lens):
+    nat, dev = backend
+    d = H * Dh
+    g = torch.Generator().manual_seed(T + Dh)
+    x = torch.randn(B, T, d, generator=g)
+    sd = {"in_proj_weight": torch.randn(3 * d, d, generator=g) / math.sqrt(d),
+          "pos_bias_u": torch.randn(Dh, H, generator=g) * 0.3, "pos_bias_v": torch.randn(Dh, H, generator=g) * 0.3,
+          "linear_pos.weight": torch.randn(d, d, generator=g) / math.sqrt(d), "out_proj.weight": torch.eye(d),
+          "out_proj.bias": torch.zeros(d)}
+    pos = O.relpos_table(T, d)
+    kl = kp = None
+    if lens is not None:
+        kl = torch.tensor(lens, dtype=torch.int32)
+        kp = ~O.length_to_mask(kl, T)
+    ref = O.relpos_mha(x, pos, sd, "", H, kp)
+    qkv = nat.gemm_nt(x.to(dev), sd["in_proj_weight"].to(dev))
+    P = nat.gemm_nt(pos.to(dev), sd["linear_pos.weight"].to(dev))
+    out, attn = nat.relpos_attention(qkv, P, sd["pos_bias_u"].reshape(-1).contiguous().to(dev),
+                                     sd["pos_bias_v"].reshape(-1).contiguous().to(dev),
+                                     None if kl is None else kl.to(dev), H, 1 / math.sqrt(d), want_attn=True)
+    assert _md(out, ref) <= 5e-6
+    assert float((attn.sum(-1) - 1).abs().max()) <= 1e-5
+    if lens is not None:  # masked keys carry exactly zero weight
+        for b, n in enumerate(lens):
+            assert float(attn[b, :, :, n:].abs().max()) == 0.0 if n < T else True
+
+
+@pytest.mark.parametrize("B,T,d,ks", [(2, 50, 32, 31), (1, 70, 72, 31), (1, 33, 144, 7)])
+def test_glu_dwconv(backend, B, T, d, ks):
+    nat, dev = backend
+    h, w, b = torch.randn(B, T, 2 * d), torch.randn(d, ks) * 0.2, torch.randn(d)
+    ref = F.conv1d(F.glu(h.transpose(1, 2), dim=1), w.unsqueeze(1), b, padding=(ks - 1) // 2, groups=d).transpose(1, 2)
+    assert _md(nat.glu_dwconv(h.to(dev), w.to(dev), b.to(dev), ks), ref) <= 1e-5

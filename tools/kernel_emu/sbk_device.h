@@ -1,0 +1,153 @@
+// Host-side stand-in for csrc/hip/sbk_device.h  --  TEST TOOLING ONLY.
+//
+// Gives the device vocabulary (threadIdx, __shared__, __syncthreads, wave
+// shuffles, f32 MFMA, SBK_LAUNCH ...) host semantics so the very same kernel
+// sources can be compiled with g++ and single-stepped / unit-tested on a CPU
+// box without a GPU.  Each workgroup runs as a set of cooperative fibers on
+// one OS thread (so `static thread_local` storage behaves like LDS); waves are
+// groups of 64 consecutive fibers that rendezvous for shuffles and MFMA.
+//
+// This is NOT a product path: the shipped library (libsbk_hip.so) is built from
+// csrc/hip/sbk_device.h by hipcc only, and speechbrain_amd.native refuses to
+// run without it.  The emulator library is loaded only by tests that ask for it
+// explicitly (tests/emu_utils.py).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipPeekAtLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+enum { hipMemcpyDeviceToDevice = 3, hipMemcpyDeviceToHost = 2, hipMemcpyHostToDevice = 1 };
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+
+namespace sbk_emu {
+struct ThreadCtx {
+  dim3 tid, bid, bdim, gdim;
+  int lin, lane, wave;
+};
+ThreadCtx& cur();
+void block_barrier();
+void wave_barrier();
+float* wave_buf(int which);  // 64-float exchange buffers of the current wave (which = 0,1)
+void* dyn_lds();
+void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds_bytes);
+}  // namespace sbk_emu
+
+#define threadIdx (sbk_emu::cur().tid)
+#define blockIdx (sbk_emu::cur().bid)
+#define blockDim (sbk_emu::cur().bdim)
+#define gridDim (sbk_emu::cur().gdim)
+static inline void __syncthreads() { sbk_emu::block_barrier(); }
+
+using std::max;
+using std::min;
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+
+namespace sbk {
+constexpr int kWave = 64;
+struct f32x16 {
+  float v[16];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+struct f32x4 {
+  float v[4];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+
+static inline f32x16 mfma_32x32x2(float a, float b, f32x16 acc) {
+  const int l = sbk_emu::cur().lane;
+  float* A = sbk_emu::wave_buf(0);
+  float* B = sbk_emu::wave_buf(1);
+  A[l] = a;
+  B[l] = b;
+  sbk_emu::wave_barrier();
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+    float c = acc[r];
+    for (int k = 0; k < 2; ++k) c = fmaf(A[row + 32 * k], B[col + 32 * k], c);
+    acc[r] = c;
+  }
+  sbk_emu::wave_barrier();
+  return acc;
+}
+static inline f32x4 mfma_16x16x4(float a, float b, f32x4 acc) {
+  const int l = sbk_emu::cur().lane;
+  float* A = sbk_emu::wave_buf(0);
+  float* B = sbk_emu::wave_buf(1);
+  A[l] = a;
+  B[l] = b;
+  sbk_emu::wave_barrier();
+  for (int r = 0; r < 4; ++r) {
+    const int row = (l >> 4) * 4 + r, col = l & 15;
+    float c = acc[r];
+    for (int k = 0; k < 4; ++k) c = fmaf(A[row + 16 * k], B[col + 16 * k], c);
+    acc[r] = c;
+  }
+  sbk_emu::wave_barrier();
+  return acc;
+}
+template <typename T>
+static inline T shfl_idx_(T v, int src) {
+  const int l = sbk_emu::cur().lane;
+  float* X = sbk_emu::wave_buf(0);
+  static_assert(sizeof(T) == 4, "32-bit shuffles only");
+  memcpy(&X[l], &v, 4);
+  sbk_emu::wave_barrier();
+  T r;
+  memcpy(&r, &X[src & 63], 4);
+  sbk_emu::wave_barrier();
+  return r;
+}
+static inline float shfl_xor(float v, int m) { return shfl_idx_(v, sbk_emu::cur().lane ^ m); }
+static inline int shfl_xor(int v, int m) { return shfl_idx_(v, sbk_emu::cur().lane ^ m); }
+static inline float shfl(float v, int lane) { return shfl_idx_(v, lane); }
+static inline int shfl(int v, int lane) { return shfl_idx_(v, lane); }
+static inline void wave_sync() { sbk_emu::wave_barrier(); }
+static inline float wave_sum(float v) {
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+  return v;
+}
+static inline float wave_max(float v) {
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
+  return v;
+}
+}  // namespace sbk
+
+#define SBK_DYN_LDS(type, name) type* name = reinterpret_cast<type*>(sbk_emu::dyn_lds())
+#define SBK_ALLOW_DYN_LDS(kernel, bytes) ((void)(bytes), 0)
+#define SBK_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \
+  sbk_emu::launch([=]() { kernel(__VA_ARGS__); }, grid, block, lds_bytes)
