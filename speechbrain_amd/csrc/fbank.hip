@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(256) fbank_frames_kernel(FbankArgs a, Radices 
     const int p0 = a.mel_ptr[m], p1 = a.mel_ptr[m + 1], f0 = a.mel_bin[m];
     float acc = 0.0f;
     for (int i = p0; i < p1; ++i) acc = fmaf(mypw[f0 + (i - p0)], melw[i], acc);
-    const float db = 10.0f * log10f(fmaxf(acc, a.amin));
+    // log10 in f64: correctly rounded to f32 (silence must give exactly 10*log10(amin) like the reference)
+    const float db = 10.0f * (float)log10((double)fmaxf(acc, a.amin));
     if (t < a.T) {
       a.out[((size_t)b * a.T + t) * a.n_mels + m] = db;
       mx = fmaxf(mx, db);

@@ -1,0 +1,74 @@
+"""speechbrain.lobes.models.convolution mirror: ConvolutionFrontEnd / ConvBlock (convolution.py:116-320)."""
+from typing import List
+
+import torch
+
+from speechbrain_amd import native
+from speechbrain_amd.nnet.CNN import Conv2d
+from speechbrain_amd.nnet.normalization import LayerNorm
+
+
+class _NamedChildren(torch.nn.ModuleDict):
+    pass
+
+
+class ConvBlock(torch.nn.Module):
+    """conv(3x3, stride s, reflect 'same') -> LayerNorm(F',C') -> LeakyReLU -> Dropout, one HIP launch."""
+
+    def __init__(self, num_layers, out_channels, input_shape, kernel_size=3, stride=1, dilation=1, residual=False,
+                 conv_module=Conv2d, activation=torch.nn.LeakyReLU, norm=LayerNorm, dropout=0.1, conv_bias=True,
+                 padding="same", conv_init=None):
+        super().__init__()
+        if num_layers != 1 or residual or dilation != 1 or kernel_size != 3 or stride != 2 or padding != "same":
+            raise NotImplementedError("MI355X ConvBlock implements the ASR recipe shape: one 3x3 stride-2 layer")
+        if conv_module is not Conv2d or norm is not LayerNorm or activation is not torch.nn.LeakyReLU:
+            raise NotImplementedError("ConvBlock is fused for Conv2d + LayerNorm + LeakyReLU")
+        B, T, F = input_shape[0], input_shape[1], input_shape[2]
+        cin = 1 if len(input_shape) == 3 else input_shape[3]
+        self.out_shape = (B, (T - 1) // 2 + 1, (F - 1) // 2 + 1, out_channels)
+        self.convs = _NamedChildren()
+        self.convs["conv_0"] = Conv2d(out_channels, kernel_size, in_channels=cin, stride=stride, bias=conv_bias,
+                                      conv_init=conv_init)
+        self.convs["norm_0"] = LayerNorm(input_shape=self.out_shape)
+        self.convs["act_0"] = activation()
+        self.convs["dropout_0"] = torch.nn.Dropout(dropout)
+        self._wt_cache = None
+
+    def _wt(self):
+        w = self.convs["conv_0"].conv.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._wt_cache is None or self._wt_cache[0] != key:
+            # [Cout,Cin,kF,kT] -> [(ci,kf,kt), Cout]: coalesced across output channels in the kernel
+            self._wt_cache = (key, w.detach().permute(1, 2, 3, 0).reshape(-1, w.shape[0]).contiguous())
+        return self._wt_cache[1]
+
+    def forward(self, x):
+        if x.dim() == 3:
+            x = x.unsqueeze(-1)
+        conv, norm = self.convs["conv_0"], self.convs["norm_0"]
+        return native.conv_block(x.contiguous(), self._wt(), conv.conv.bias, norm.norm.weight.reshape(-1),
+                                 norm.norm.bias.reshape(-1), conv.out_channels, eps=norm.eps,
+                                 slope=self.convs["act_0"].negative_slope)
+
+
+class ConvolutionFrontEnd(torch.nn.ModuleDict):
+    """Stack of ConvBlocks, [B,T,F] -> [B,T',F',C]; children are named convblock_{i} as in the reference."""
+
+    def __init__(self, input_shape, num_blocks=3, num_layers_per_block=5, out_channels: List[int] = [128, 256, 512],
+                 kernel_sizes: List[int] = [3, 3, 3], strides: List[int] = [1, 2, 2], dilations: List[int] = [1, 1, 1],
+                 residuals: List[bool] = [True, True, True], conv_module=Conv2d, activation=torch.nn.LeakyReLU,
+                 norm=LayerNorm, dropout=0.1, conv_bias=True, padding="same", conv_init=None):
+        super().__init__()
+        shape = tuple(input_shape)
+        for i in range(num_blocks):
+            block = ConvBlock(num_layers=num_layers_per_block, out_channels=out_channels[i], input_shape=shape,
+                              kernel_size=kernel_sizes[i], stride=strides[i], dilation=dilations[i],
+                              residual=residuals[i], conv_module=conv_module, activation=activation, norm=norm,
+                              dropout=dropout, conv_bias=conv_bias, padding=padding, conv_init=conv_init)
+            self[f"convblock_{i}"] = block
+            shape = block.out_shape
+
+    def forward(self, x):
+        for block in self.values():
+            x = block(x)
+        return x

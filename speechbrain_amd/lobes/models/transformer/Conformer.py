@@ -1,0 +1,132 @@
+"""speechbrain.lobes.models.transformer.Conformer mirror (Conformer.py:75-778), offline path.
+
+ConvolutionModule / ConformerEncoderLayer / ConformerEncoder keep the reference's constructors,
+forward signatures and state_dict keys.  Per layer the work is 17 HIP launches: every LayerNorm
+is one row kernel, every Linear / pointwise conv one MFMA GEMM with bias + activation + (scaled)
+residual fused in the epilogue, attention and GLU+depthwise-conv one fused kernel each.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from speechbrain_amd import native
+from speechbrain_amd.nnet.activations import Swish
+from speechbrain_amd.nnet.attention import PositionalwiseFeedForward, RelPosMHAXL, _act_code
+from speechbrain_amd.nnet.normalization import LayerNorm
+
+
+class ConvolutionModule(nn.Module):
+    """LN -> pointwise(d->2d) -> GLU -> depthwise(k) -> LN -> act -> Linear(d->d) -> mask (Conformer.py:75-330)."""
+
+    def __init__(self, input_size, kernel_size=31, bias=True, activation=Swish, dropout=0.0, causal=False, dilation=1):
+        super().__init__()
+        if causal or dilation != 1 or not bias:
+            raise NotImplementedError("causal / dilated / bias-free ConvolutionModule is not on the offline ASR path")
+        self.kernel_size, self.causal, self.dilation = kernel_size, causal, dilation
+        self.padding = (kernel_size - 1) // 2
+        self.layer_norm = nn.LayerNorm(input_size)
+        self.bottleneck = nn.Sequential(nn.Conv1d(input_size, 2 * input_size, kernel_size=1, stride=1, bias=bias),
+                                        nn.GLU(dim=1))
+        self.conv = nn.Conv1d(input_size, input_size, kernel_size=kernel_size, stride=1, padding=self.padding,
+                              dilation=dilation, groups=input_size, bias=bias)
+        self.after_conv = nn.Sequential(nn.LayerNorm(input_size), activation(), nn.Linear(input_size, input_size, bias=bias),
+                                        nn.Dropout(dropout))
+        self.act_code = _act_code(self.after_conv[1])
+
+    def forward(self, x, mask: Optional[torch.Tensor] = None, dynchunktrain_config=None, residual=None, key_len=None):
+        """x [B,T,d]; mask [B,T,1] True = padded (reference surface) or key_len int32 [B]."""
+        if dynchunktrain_config is not None:
+            raise NotImplementedError("dynamic chunk convolution (streaming) is outside the offline ASR path")
+        B, T, d = x.shape
+        if key_len is None and mask is not None:
+            key_len = (~mask.reshape(B, T)).sum(-1, dtype=torch.int32)
+        h = native.layernorm(x.contiguous(), self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        pw = self.bottleneck[0]
+        h = native.gemm_nt(h, pw.weight.reshape(2 * d, d), pw.bias)
+        h = native.glu_dwconv(h, self.conv.weight.reshape(d, self.kernel_size), self.conv.bias, self.kernel_size)
+        ln = self.after_conv[0]
+        h = native.layernorm(h, ln.weight, ln.bias, ln.eps, act=self.act_code)
+        lin = self.after_conv[2]
+        return native.gemm_nt(h, lin.weight, lin.bias, residual=residual, seq_len=key_len, rows_per_seq=T)
+
+
+class ConformerEncoderLayer(nn.Module):
+    """Conformer.py:333-499: x + FFN/2 -> MHSA -> Conv -> LN(x + FFN/2)."""
+
+    def __init__(self, d_model, d_ffn, nhead, kernel_size=31, kdim=None, vdim=None, activation=Swish, bias=True,
+                 dropout=0.0, causal=False, attention_type="RelPosMHAXL"):
+        super().__init__()
+        if attention_type != "RelPosMHAXL":
+            raise NotImplementedError(f"attention_type={attention_type}: this round implements RelPosMHAXL")
+        self.mha_layer = RelPosMHAXL(num_heads=nhead, embed_dim=d_model, dropout=dropout, mask_pos_future=causal)
+        self.convolution_module = ConvolutionModule(d_model, kernel_size, bias, activation, dropout, causal=causal)
+        self.ffn_module1 = nn.Sequential(
+            nn.LayerNorm(d_model),
+            PositionalwiseFeedForward(d_ffn=d_ffn, input_size=d_model, dropout=dropout, activation=activation),
+            nn.Dropout(dropout))
+        self.ffn_module2 = nn.Sequential(
+            nn.LayerNorm(d_model),
+            PositionalwiseFeedForward(d_ffn=d_ffn, input_size=d_model, dropout=dropout, activation=activation),
+            nn.Dropout(dropout))
+        self.norm1 = LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
+        self.drop = nn.Dropout(dropout)
+        self.collect_attention = False  # attention maps are opt-in (they are [B,H,T,T] of HBM traffic)
+
+    def _ffn(self, mod, x):
+        ln, ffn = mod[0], mod[1]
+        h = native.layernorm(x, ln.weight, ln.bias, ln.eps)
+        return ffn(h, residual=x, alpha=0.5)
+
+    def forward(self, x, src_mask=None, src_key_padding_mask=None, pos_embs=None, dynchunktrain_config=None,
+                key_len=None):
+        if src_mask is not None or dynchunktrain_config is not None:
+            raise NotImplementedError("src_mask / dynamic chunk training belong to the streaming path")
+        if key_len is None and src_key_padding_mask is not None:
+            key_len = (~src_key_padding_mask).sum(-1, dtype=torch.int32)
+        x = self._ffn(self.ffn_module1, x.contiguous())
+        h = native.layernorm(x, self.norm1.norm.weight, self.norm1.norm.bias, self.norm1.eps)
+        x, attn = self.mha_layer.core(h, pos_embs.reshape(-1, x.shape[-1]), key_len, residual=x,
+                                      want_attn=self.collect_attention)
+        x = self.convolution_module(x, residual=x, key_len=key_len)
+        y = self._ffn(self.ffn_module2, x)
+        return native.layernorm(y, self.norm2.norm.weight, self.norm2.norm.bias, self.norm2.eps), attn
+
+
+class ConformerEncoder(nn.Module):
+    """Conformer.py:589-778."""
+
+    def __init__(self, num_layers, d_model, d_ffn, nhead, kernel_size=31, kdim=None, vdim=None, activation=Swish,
+                 bias=True, dropout=0.0, causal=False, attention_type="RelPosMHAXL", output_hidden_states=False,
+                 layerdrop_prob=0.0):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            ConformerEncoderLayer(d_ffn=d_ffn, nhead=nhead, d_model=d_model, kdim=kdim, vdim=vdim, dropout=dropout,
+                                  activation=activation, kernel_size=kernel_size, bias=bias, causal=causal,
+                                  attention_type=attention_type)
+            for _ in range(num_layers)])
+        self.norm = LayerNorm(d_model, eps=1e-6)
+        self.layerdrop_prob = layerdrop_prob
+        self.attention_type = attention_type
+        self.output_hidden_states = output_hidden_states
+
+    def forward(self, src, src_mask=None, src_key_padding_mask=None, pos_embs=None, dynchunktrain_config=None):
+        if self.attention_type == "RelPosMHAXL" and pos_embs is None:
+            raise ValueError("RelPosMHAXL needs positional embeddings")
+        key_len = None
+        if src_key_padding_mask is not None:
+            key_len = (~src_key_padding_mask).sum(-1, dtype=torch.int32)
+        output = src
+        attention_lst = []
+        hidden = [output] if self.output_hidden_states else None
+        for layer in self.layers:
+            output, attention = layer(output, src_mask=src_mask, pos_embs=pos_embs, key_len=key_len,
+                                      dynchunktrain_config=dynchunktrain_config)
+            attention_lst.append(attention)
+            if hidden is not None:
+                hidden.append(output)
+        output = self.norm(output)
+        if hidden is not None:
+            return output, attention_lst, hidden
+        return output, attention_lst

@@ -1,0 +1,134 @@
+"""speechbrain.lobes.models.transformer.Transformer mirror: the pieces TransformerASR is built from
+(Transformer.py:35-1068).  The decoder classes are parameter holders with the reference's names;
+their arithmetic is the fused KV-cached decode step in csrc/decoder.hip."""
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from speechbrain_amd.nnet.activations import Swish
+from speechbrain_amd.nnet.attention import MultiheadAttention, PositionalwiseFeedForward, RelPosEncXL
+from speechbrain_amd.nnet.embedding import Embedding
+from speechbrain_amd.nnet.normalization import LayerNorm
+
+
+class PositionalEncoding(nn.Module):
+    """Absolute sinusoidal table, buffer ``pe`` [1,max_len,d] (Transformer.py:252-303)."""
+
+    def __init__(self, input_size, max_len=2500):
+        super().__init__()
+        if input_size % 2 != 0:
+            raise ValueError(f"Cannot use sin/cos positional encoding with odd channels (got channels={input_size})")
+        self.max_len = max_len
+        pe = torch.zeros(self.max_len, input_size, requires_grad=False)
+        positions = torch.arange(0, self.max_len).unsqueeze(1).float()
+        denominator = torch.exp(torch.arange(0, input_size, 2).float() * -(math.log(10000.0) / input_size))
+        pe[:, 0::2] = torch.sin(positions * denominator)
+        pe[:, 1::2] = torch.cos(positions * denominator)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+    def forward(self, x):
+        return self.pe[:, : x.size(1)].clone().detach()
+
+
+class NormalizedEmbedding(nn.Module):
+    """emb(x) * sqrt(d_model) (Transformer.py:966-995); the scaling is fused into the decode step."""
+
+    def __init__(self, d_model, vocab):
+        super().__init__()
+        self.emb = Embedding(num_embeddings=vocab, embedding_dim=d_model, blank_id=0)
+        self.d_model = d_model
+
+
+class TransformerDecoderLayer(nn.Module):
+    """Transformer.py:659-834 (regularMHA): holder of self_attn / multihead_attn / pos_ffn / norm1-3."""
+
+    def __init__(self, d_ffn, nhead, d_model, kdim=None, vdim=None, dropout=0.0, activation=nn.ReLU,
+                 normalize_before=False, attention_type="regularMHA", causal=None):
+        super().__init__()
+        if attention_type != "regularMHA":
+            raise NotImplementedError("the ASR decoder always uses regularMHA (Transformer.py:232)")
+        self.nhead = nhead
+        self.self_attn = MultiheadAttention(nhead=nhead, d_model=d_model, kdim=kdim, vdim=vdim, dropout=dropout)
+        self.multihead_attn = MultiheadAttention(nhead=nhead, d_model=d_model, kdim=kdim, vdim=vdim, dropout=dropout)
+        self.pos_ffn = PositionalwiseFeedForward(d_ffn=d_ffn, input_size=d_model, dropout=dropout, activation=activation)
+        self.norm1 = LayerNorm(d_model, eps=1e-6)
+        self.norm2 = LayerNorm(d_model, eps=1e-6)
+        self.norm3 = LayerNorm(d_model, eps=1e-6)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        self.normalize_before = normalize_before
+
+
+class TransformerDecoder(nn.Module):
+    """Transformer.py:843-963."""
+
+    def __init__(self, num_layers, nhead, d_ffn, d_model, kdim=None, vdim=None, dropout=0.0, activation=nn.ReLU,
+                 normalize_before=False, causal=False, attention_type="regularMHA"):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            TransformerDecoderLayer(d_ffn=d_ffn, nhead=nhead, d_model=d_model, kdim=kdim, vdim=vdim, dropout=dropout,
+                                    activation=activation, normalize_before=normalize_before, causal=causal,
+                                    attention_type=attention_type)
+            for _ in range(num_layers)])
+        self.norm = LayerNorm(d_model, eps=1e-6)
+
+
+class TransformerInterface(nn.Module):
+    """Transformer.py:35-250, restricted to encoder_module="conformer" + RelPosMHAXL."""
+
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, d_ffn=2048, dropout=0.1,
+                 activation=nn.ReLU, custom_src_module=None, custom_tgt_module=None,
+                 positional_encoding="fixed_abs_sine", normalize_before=True, kernel_size: int = 31, bias: bool = True,
+                 encoder_module: str = "transformer", conformer_activation=Swish, branchformer_activation=nn.GELU,
+                 attention_type: str = "regularMHA", max_length: int = 2500, causal: bool = False,
+                 encoder_kdim: Optional[int] = None, encoder_vdim: Optional[int] = None,
+                 decoder_kdim: Optional[int] = None, decoder_vdim: Optional[int] = None, csgu_linear_units: int = 3072,
+                 gate_activation=nn.Identity, use_linear_after_conv: bool = False, output_hidden_states=False,
+                 layerdrop_prob=0.0):
+        super().__init__()
+        from speechbrain_amd.lobes.models.transformer.Conformer import ConformerEncoder
+
+        self.causal, self.attention_type = causal, attention_type
+        self.positional_encoding_type = positional_encoding
+        self.output_hidden_states, self.layerdrop_prob = output_hidden_states, layerdrop_prob
+        assert positional_encoding in ["fixed_abs_sine", None]
+        assert num_encoder_layers + num_decoder_layers > 0
+        if encoder_module != "conformer" or attention_type != "RelPosMHAXL" or causal:
+            raise NotImplementedError(
+                "this round implements encoder_module='conformer' with attention_type='RelPosMHAXL', causal=False")
+        if positional_encoding == "fixed_abs_sine":
+            self.positional_encoding = PositionalEncoding(d_model, max_length)
+        self.positional_encoding = RelPosEncXL(d_model)  # overrides, as in the reference (:165-170)
+        self.positional_encoding_decoder = PositionalEncoding(d_model, max_length)
+        if num_encoder_layers > 0:
+            self.encoder = ConformerEncoder(nhead=nhead, num_layers=num_encoder_layers, d_ffn=d_ffn, d_model=d_model,
+                                            dropout=dropout, activation=conformer_activation, kernel_size=kernel_size,
+                                            bias=bias, causal=causal, attention_type=attention_type,
+                                            output_hidden_states=output_hidden_states, layerdrop_prob=layerdrop_prob)
+            assert normalize_before, "normalize_before must be True for Conformer"
+        if num_decoder_layers > 0:
+            self.decoder = TransformerDecoder(num_layers=num_decoder_layers, nhead=nhead, d_ffn=d_ffn, d_model=d_model,
+                                              dropout=dropout, activation=activation,
+                                              normalize_before=normalize_before, causal=True,
+                                              attention_type="regularMHA")
+
+
+def get_lookahead_mask(padded_input):
+    """Transformer.py:1037-1068 (kept for API completeness; the decode kernels are causal by construction)."""
+    seq_len = padded_input.shape[1]
+    mask = (torch.triu(torch.ones((seq_len, seq_len), device=padded_input.device)) == 1).transpose(0, 1)
+    return mask.float().masked_fill(mask == 0, float("-inf")).masked_fill(mask == 1, 0.0).detach()
+
+
+def get_key_padding_mask(padded_input, pad_idx):
+    """Transformer.py:998-1034."""
+    if len(padded_input.shape) == 4:
+        bz, time, ch1, ch2 = padded_input.shape
+        padded_input = padded_input.reshape(bz, time, ch1 * ch2)
+    key_padded_mask = padded_input.eq(pad_idx)
+    if len(padded_input.shape) > 2:
+        key_padded_mask = key_padded_mask.float().prod(dim=-1).bool()
+    return key_padded_mask.detach()
