@@ -108,6 +108,70 @@ int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bi
 int sbk_glu_dwconv_f32(const float* h, const float* w, const float* bias, float* y, int B, int T, int d, int ksize,
                        sbk_stream_t stream);
 
+/* log_softmax(x / temperature) * weight over the last dimension, x [rows,V] (seq2seq.py:1933). */
+int sbk_log_softmax_f32(const float* x, float* out, int rows, int V, float temperature, float weight,
+                        sbk_stream_t stream);
+
+/* ---- a15-a21: the searchers ----------------------------------------------
+ * Weights of TransformerASR's decoder (Transformer.py:659-963) + embedding + seq_lin, by the
+ * reference's state_dict names (all device pointers, fp32):
+ *   layers[l]: norm{1,2,3}.norm.{weight,bias}; self_attn.att / multihead_attn.att
+ *              {in_proj_weight [3d,d], in_proj_bias [3d], out_proj.weight [d,d], out_proj.bias};
+ *              pos_ffn.ffn.{0,3}.{weight,bias}                                              */
+typedef struct {
+  const float *ln1_g, *ln1_b, *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b;
+  const float *ln2_g, *ln2_b, *ca_in_w, *ca_in_b, *ca_out_w, *ca_out_b;
+  const float *ln3_g, *ln3_b, *ff1_w, *ff1_b, *ff2_w, *ff2_b;
+} sbk_decoder_layer;
+
+typedef struct {
+  const sbk_decoder_layer* layers; /* HOST array of n_layers entries */
+  const float* emb;                /* custom_tgt_module.layers.0.emb.Embedding.weight [V,d] */
+  const float* pe;                 /* positional_encoding_decoder.pe [max_len,d] */
+  const float *final_ln_g, *final_ln_b; /* decoder.norm.norm */
+  const float *seq_w, *seq_b;      /* seq_lin.w [V,d],[V] (may be NULL for sbk_decoder_prefix_f32) */
+  int32_t d_model, nhead, d_ffn, n_layers, vocab, max_len, ffn_act;
+  float ln_eps;
+} sbk_decoder_weights;
+
+/* S2SBeamSearcher options (seq2seq.py:752-768) after the host resolved ratios to step counts
+ * (min/max_steps = int(T * ratio), :1336-1338) and scorer weights (ctc_weight; attn weight is
+ * 1 - ctc_weight when a CTC scorer is present, :803-804). */
+typedef struct {
+  int32_t bos, eos, blank, beam, min_steps, max_steps;
+  int32_t length_normalization, using_eos_threshold, check_every;
+  float ctc_weight, temperature, eos_threshold, minus_inf;
+} sbk_search_config;
+
+/* S2STransformerBeamSearcher.forward (seq2seq.py:1632-1723, :1853-1934) with an optional full
+ * CTC scorer (scorer.py:108-255,1221-1315; ctc.py:26-295).
+ *   enc [B,T,d], enc_len [B] = round(T * wav_len); ctc_w [V,d], ctc_b [V] (NULL when ctc_weight = 0)
+ *   out_tokens [B,max_steps] (best hypothesis, EOS stripped, zero padded), out_len [B],
+ *   out_score [B], out_logp [B,max_steps]
+ *   host_flag: pinned HOST int32 used to poll the stop rule every cfg->check_every steps (the
+ *              only points where this call synchronises the stream); NULL => run max_steps.
+ *   steps_run: HOST int32 out. */
+size_t sbk_beam_search_workspace_bytes(const sbk_decoder_weights* W, const sbk_search_config* cfg, int B, int T);
+int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_search_config* cfg, const float* enc,
+                        const int32_t* enc_len, const float* ctc_w, const float* ctc_b, void* workspace,
+                        size_t workspace_bytes, int32_t* out_tokens, int32_t* out_len, float* out_score,
+                        float* out_logp, int32_t* host_flag, int32_t* steps_run, int B, int T, sbk_stream_t stream);
+
+/* S2STransformerGreedySearcher.forward (seq2seq.py:176-367, temperature 0): per-step arg-max.
+ *   out_tokens [B,max_steps] (EOS-latched), out_scores [B,max_steps] (log-prob of the arg-max, 0 after the end) */
+size_t sbk_greedy_search_workspace_bytes(const sbk_decoder_weights* W, int B, int T, int max_steps);
+int sbk_greedy_search_f32(const sbk_decoder_weights* W, const float* enc, const int32_t* enc_len, void* workspace,
+                          size_t workspace_bytes, int32_t* out_tokens, float* out_scores, int32_t* host_flag,
+                          int32_t* steps_run, int B, int T, int min_steps, int max_steps, int bos, int eos,
+                          int check_every, sbk_stream_t stream);
+
+/* TransformerASR.decode (TransformerASR.py:426-473) through the KV-cached step:
+ * tokens [n,L] int32, enc [n,T,d], enc_len [n] -> pred [n,L,d] (decoder.norm output). */
+size_t sbk_decoder_prefix_workspace_bytes(const sbk_decoder_weights* W, int n, int T, int L);
+int sbk_decoder_prefix_f32(const sbk_decoder_weights* W, const int32_t* tokens, const float* enc,
+                           const int32_t* enc_len, void* workspace, size_t workspace_bytes, float* pred, int n, int T,
+                           int L, sbk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

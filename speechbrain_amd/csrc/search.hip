@@ -1,0 +1,668 @@
+// S2STransformerBeamSearcher / S2STransformerGreedySearcher on the device.
+//
+// Replaces decoders/seq2seq.py:711-1749 (S2SBeamSearcher.forward and helpers),
+// :1853-1934 (S2STransformerBeamSearcher), :176-367 (greedy), scorer.py:1221-1315
+// (ScorerBuilder with one full CTC scorer) and TransformerASR.decode
+// (TransformerASR.py:426-473).  The whole search runs inside ONE C-ABI call: the
+// host loop only enqueues kernels; beam bookkeeping (length-normalised top-k over
+// beam*V, predecessor gathers, EOS harvesting, finished-hypothesis lists) lives in
+// device memory, so there is no per-step host synchronisation.  The reference's
+// stop rule ("every utterance has beam_size finished hypotheses") is polled every
+// `check_every` steps through one 4-byte async copy; running past that point
+// cannot change the result because full lists accept no further hypotheses.
+#include <limits.h>
+
+#include "common.h"
+#include "internal.h"
+
+namespace sbk {
+// decoder.hip / ctc_prefix.hip
+int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,
+              hipStream_t st);
+int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t* kv_slot, float* out, int n, int d,
+                   int H, int step, int nslot, int Lmax, hipStream_t st);
+int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, int B, int T, int d, int H,
+                    int beam, hipStream_t st);
+int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st);
+int ctc_prepare(float* x, const int32_t* enc_len, float* phi, float* psi_prev, int B, int T, int V, int beam, int blank,
+                hipStream_t st);
+int ctc_score_step(const float* x, const float* phi, const float* psi_prev, const int32_t* last_tok,
+                   const int32_t* enc_len, const float* am, float* comb, float* psi, int B, int T, int V, int beam,
+                   int prefix_len, int blank, int eos, float weight, int eos_floor, int use_thr, float thr,
+                   float minus_inf, const float* am_max, hipStream_t st);
+int ctc_advance(const float* x, const float* phi_old, const float* psi, const int32_t* parent, const int32_t* token,
+                const int32_t* parent_last_tok, float* phi_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
+                int prefix_len, int blank, hipStream_t st);
+int am_only(const float* am, float* comb, int n_bh, int V, int eos, int eos_floor, int use_thr, float thr,
+            float minus_inf, const float* am_max, hipStream_t st);
+int row_max(const float* x, float* out, int rows, int V, hipStream_t st);
+}  // namespace sbk
+
+namespace {
+
+constexpr int kMaxBeam = 16;
+
+// ---------------------------------------------------------------- top-k over beam*V per utterance
+struct Cand {
+  float v;
+  int i;
+};
+__device__ __forceinline__ bool better(float v, int i, float v2, int i2) { return v > v2 || (v == v2 && i < i2); }
+
+__global__ void __launch_bounds__(256) beam_topk_kernel(const float* __restrict__ comb, const float* __restrict__ seq,
+                                                        float* __restrict__ out_val, int32_t* __restrict__ out_idx,
+                                                        int V, int beam, float norm) {
+  __shared__ float lv[256][kMaxBeam];
+  __shared__ int li[256][kMaxBeam];
+  __shared__ float wv[4];
+  __shared__ int wi[4];
+  __shared__ int win;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int total = beam * V;
+  float vals[kMaxBeam];
+  int ids[kMaxBeam];
+#pragma unroll
+  for (int s = 0; s < kMaxBeam; ++s) {
+    vals[s] = -INFINITY;
+    ids[s] = INT_MAX;
+  }
+  const float* cb = comb + (size_t)b * total;
+  for (int e = tid; e < total; e += 256) {
+    const float v = seq[b * beam + e / V] + cb[e];
+    const float vn = norm > 0.0f ? v / norm : v;  // length normalisation divides, like seq2seq.py:1232-1233
+    if (vn != vn) continue;
+    if (better(vn, e, vals[kMaxBeam - 1], ids[kMaxBeam - 1])) {
+      float cv = vn;
+      int ci = e;
+#pragma unroll
+      for (int s = 0; s < kMaxBeam; ++s) {
+        if (better(cv, ci, vals[s], ids[s])) {
+          const float tv = vals[s];
+          const int ti = ids[s];
+          vals[s] = cv;
+          ids[s] = ci;
+          cv = tv;
+          ci = ti;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < kMaxBeam; ++s) {
+    lv[tid][s] = vals[s];
+    li[tid][s] = ids[s];
+  }
+  __syncthreads();
+  int hp = 0;
+  for (int r = 0; r < beam; ++r) {
+    float v = hp < kMaxBeam ? lv[tid][hp] : -INFINITY;
+    int i = hp < kMaxBeam ? li[tid][hp] : INT_MAX;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float ov = sbk::shfl_xor(v, m);
+      const int oi = sbk::shfl_xor(i, m);
+      if (better(ov, oi, v, i)) {
+        v = ov;
+        i = oi;
+      }
+    }
+    if ((tid & 63) == 0) {
+      wv[tid >> 6] = v;
+      wi[tid >> 6] = i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float bv = wv[0];
+      int bi = wi[0];
+      for (int w = 1; w < 4; ++w)
+        if (better(wv[w], wi[w], bv, bi)) {
+          bv = wv[w];
+          bi = wi[w];
+        }
+      win = bi;
+      out_val[b * beam + r] = bv;
+      out_idx[b * beam + r] = bi == INT_MAX ? 0 : bi;
+    }
+    __syncthreads();
+    if (hp < kMaxBeam && li[tid][hp] == win && win != INT_MAX) ++hp;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- beam bookkeeping
+struct BeamState {
+  // double-buffered per-hypothesis tables, [n_bh][Lmax]
+  int32_t* seq[2];
+  float* lp[2];
+  int32_t* kv_slot[2];
+  int32_t* tokens[2];   // [n_bh] input token of the next / current step
+  float* seq_scores;    // [n_bh]
+  float* cand_val;      // [n_bh] normalised top-k scores of the current step
+  int32_t* cand_idx;    // [n_bh] index into beam*V
+  int32_t* parent;      // [n_bh]
+  // finished hypotheses, [B][beam]...
+  int32_t* fin_count;   // [B]
+  int32_t* fin_seq;     // [B][beam][Lmax]
+  float* fin_lp;        // [B][beam][Lmax]
+  int32_t* fin_len;     // [B][beam]
+  float* fin_score;     // [B][beam]
+  int32_t* n_full;      // [1] utterances whose finished list is full
+};
+
+__global__ void beam_init_kernel(BeamState s, int B, int beam, int bos) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n == 0) *s.n_full = 0;
+  if (n < B) s.fin_count[n] = 0;
+  if (n >= B * beam) return;
+  s.tokens[0][n] = bos;
+  s.seq_scores[n] = (n % beam == 0) ? 0.0f : -INFINITY;  // seq2seq.py:880-884
+}
+
+__global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const float* __restrict__ am, int cur, int step,
+                                                          int V, int beam, int Lmax, int eos, int length_norm) {
+  __shared__ int h_src[kMaxBeam];
+  __shared__ int h_dst[kMaxBeam];
+  __shared__ int h_n;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nxt = cur ^ 1;
+  for (int idx = tid; idx < beam * (step + 1); idx += 256) {
+    const int j = idx / (step + 1), p = idx % (step + 1);
+    const int n = b * beam + j;
+    const int cand = s.cand_idx[n];
+    const int pred = b * beam + cand / V, tok = cand % V;
+    const size_t o = (size_t)n * Lmax + p, po = (size_t)pred * Lmax + p;
+    if (p < step) {
+      s.seq[nxt][o] = s.seq[cur][po];
+      s.lp[nxt][o] = s.lp[cur][po];
+      s.kv_slot[nxt][o] = s.kv_slot[cur][po];
+    } else {
+      s.seq[nxt][o] = tok;
+      s.lp[nxt][o] = am[(size_t)pred * V + tok];  // pre-scorer AM log-prob (seq2seq.py:1547,1187-1189)
+      s.kv_slot[nxt][o] = pred;                   // this step's K/V were written at slot = parent index
+      s.tokens[nxt][n] = tok;
+      s.parent[n] = pred;
+    }
+  }
+  if (tid == 0) {  // EOS harvest, first come in beam order, at most `beam` per utterance (seq2seq.py:1371-1416)
+    int cnt = s.fin_count[b], nh = 0;
+    const int before = cnt;
+    for (int j = 0; j < beam; ++j) {
+      const int n = b * beam + j;
+      const int tok = s.cand_idx[n] % V;
+      const float score = s.cand_val[n];
+      if (tok == eos && cnt < beam) {
+        h_src[nh] = j;
+        h_dst[nh] = cnt;
+        ++nh;
+        s.fin_len[b * beam + cnt] = step + 1;
+        s.fin_score[b * beam + cnt] = score;
+        ++cnt;
+      }
+      s.seq_scores[n] = tok == eos ? -INFINITY : (length_norm ? score * (float)(step + 1) : score);
+    }
+    s.fin_count[b] = cnt;
+    h_n = nh;
+    if (cnt == beam && before < beam) atomicAdd(s.n_full, 1);
+  }
+  __syncthreads();
+  for (int k = 0; k < h_n; ++k) {
+    const int n = b * beam + h_src[k];
+    const int cand = s.cand_idx[n];
+    const int pred = b * beam + cand / V, tok = cand % V;
+    const size_t fo = ((size_t)b * beam + h_dst[k]) * Lmax;
+    for (int p = tid; p <= step; p += 256) {
+      s.fin_seq[fo + p] = p < step ? s.seq[cur][(size_t)pred * Lmax + p] : tok;
+      s.fin_lp[fo + p] = p < step ? s.lp[cur][(size_t)pred * Lmax + p] : am[(size_t)pred * V + tok];
+    }
+  }
+}
+
+// Fill unfinished lists with the alive hypotheses (seq2seq.py:1600-1630), pick the best finished
+// hypothesis per utterance (:1418-1476, topk = 1) and strip its last token (:1461 + undo_padding).
+__global__ void __launch_bounds__(256) beam_finalize_kernel(BeamState s, int cur, int steps_done, int beam, int Lmax,
+                                                            int32_t* __restrict__ out_tok, int32_t* __restrict__ out_len,
+                                                            float* __restrict__ out_score, float* __restrict__ out_lp) {
+  __shared__ int best;
+  __shared__ int best_from_alive;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int cnt = s.fin_count[b];
+    float bv = -INFINITY;
+    int bi = -1, alive_j = -1;
+    for (int f = 0; f < cnt; ++f)
+      if (bi < 0 || s.fin_score[b * beam + f] > bv) {
+        bv = s.fin_score[b * beam + f];
+        bi = f;
+      }
+    if (steps_done > 0) {
+      for (int j = 0; j < beam && cnt < beam; ++j, ++cnt) {
+        const float sc = s.cand_val[b * beam + j];
+        if (bi < 0 || sc > bv) {
+          bv = sc;
+          bi = cnt;
+          alive_j = j;
+        }
+      }
+    }
+    best = bi;
+    best_from_alive = alive_j;
+    out_score[b] = bi < 0 ? 0.0f : bv;
+    int len = 0;
+    if (bi >= 0) len = (alive_j >= 0 ? steps_done : s.fin_len[b * beam + bi]) - 1;
+    out_len[b] = len < 0 ? 0 : len;
+  }
+  __syncthreads();
+  const int len = out_len[b];
+  for (int p = tid; p < Lmax; p += 256) {
+    int tok = 0;
+    float lp = 0.0f;
+    if (best >= 0 && p <= len) {  // log-probs keep the stripped position too, like the reference
+      if (best_from_alive >= 0) {
+        const size_t o = ((size_t)b * beam + best_from_alive) * Lmax + p;
+        tok = s.seq[cur][o];
+        lp = s.lp[cur][o];
+      } else {
+        const size_t o = ((size_t)b * beam + best) * Lmax + p;
+        tok = s.fin_seq[o];
+        lp = s.fin_lp[o];
+      }
+    }
+    out_tok[(size_t)b * Lmax + p] = p < len ? tok : 0;
+    out_lp[(size_t)b * Lmax + p] = lp;
+  }
+}
+
+// ---------------------------------------------------------------- greedy helpers
+__global__ void __launch_bounds__(256) greedy_pick_kernel(const float* __restrict__ logits, int32_t* __restrict__ tok_out,
+                                                          int32_t* __restrict__ ended, int32_t* __restrict__ hyp,
+                                                          float* __restrict__ score, int32_t* __restrict__ n_ended,
+                                                          int V, int k, int Lmax, int eos) {
+  __shared__ float wv[4];
+  __shared__ int wi[4];
+  __shared__ float red[4];
+  __shared__ float row_lse;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const float* x = logits + (size_t)i * V;
+  float v = -INFINITY;
+  int a = INT_MAX;
+  for (int c = tid; c < V; c += 256)
+    if (better(x[c], c, v, a)) {
+      v = x[c];
+      a = c;
+    }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float ov = sbk::shfl_xor(v, m);
+    const int oi = sbk::shfl_xor(a, m);
+    if (better(ov, oi, v, a)) {
+      v = ov;
+      a = oi;
+    }
+  }
+  if ((tid & 63) == 0) {
+    wv[tid >> 6] = v;
+    wi[tid >> 6] = a;
+  }
+  __syncthreads();
+  float bv = wv[0];
+  int bi = wi[0];
+  for (int w = 1; w < 4; ++w)
+    if (better(wv[w], wi[w], bv, bi)) {
+      bv = wv[w];
+      bi = wi[w];
+    }
+  // log-softmax value of the arg-max: max - logsumexp
+  float se = 0.0f;
+  for (int c = tid; c < V; c += 256) se += expf(x[c] - bv);
+  se = sbk::wave_sum(se);
+  if ((tid & 63) == 0) red[tid >> 6] = se;
+  __syncthreads();
+  if (tid == 0) {
+    row_lse = logf((red[0] + red[1]) + (red[2] + red[3]));
+    const int was = ended[i];
+    const int now = was | (bi == eos);
+    if (now && !was) atomicAdd(n_ended, 1);
+    ended[i] = now;
+    // after the end (and on the eos step itself) the reference reports eos with score 0 (seq2seq.py:262-275)
+    hyp[(size_t)i * Lmax + k] = now ? eos : bi;
+    score[(size_t)i * Lmax + k] = now ? 0.0f : -row_lse;
+    tok_out[i] = now ? eos : bi;
+  }
+}
+
+__global__ void greedy_init_kernel(int32_t* tok, int32_t* ended, int32_t* n_ended, int32_t* kv_slot, int n, int Lmax,
+                                   int bos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *n_ended = 0;
+  if (i >= n) return;
+  tok[i] = bos;
+  ended[i] = 0;
+  for (int p = 0; p < Lmax; ++p) kv_slot[(size_t)i * Lmax + p] = i;
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int d, long dst_stride) {
+  const int i = blockIdx.x;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) dst[(size_t)i * dst_stride + c] = src[(size_t)i * d + c];
+}
+
+// ---------------------------------------------------------------- workspace carving
+struct Carver {
+  char* p;
+  size_t used;
+  bool dry;
+  template <typename T>
+  T* take(size_t n) {
+    const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+    T* r = dry ? nullptr : reinterpret_cast<T*>(p + used);
+    used += bytes;
+    return r;
+  }
+};
+
+struct DecoderBufs {
+  float *x, *h, *qkv, *ctx, *q, *ff, *logits;
+  float* ckv[64];
+  float *kcache[64], *vcache[64];
+};
+
+void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int n, int B, int T, int Lmax) {
+  const int dm = W->d_model;
+  d.x = c.take<float>((size_t)n * dm);
+  d.h = c.take<float>((size_t)n * dm);
+  d.qkv = c.take<float>((size_t)n * 3 * dm);
+  d.ctx = c.take<float>((size_t)n * dm);
+  d.q = c.take<float>((size_t)n * dm);
+  d.ff = c.take<float>((size_t)n * W->d_ffn);
+  d.logits = c.take<float>((size_t)n * W->vocab);
+  for (int l = 0; l < W->n_layers; ++l) {
+    d.ckv[l] = c.take<float>((size_t)B * T * 2 * dm);
+    d.kcache[l] = c.take<float>((size_t)Lmax * n * dm);
+    d.vcache[l] = c.take<float>((size_t)Lmax * n * dm);
+  }
+}
+
+#define SBK_TRY(expr)        \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__) return rc__;   \
+  } while (0)
+
+// Project the encoder memory to the cross-attention K/V of every layer, once per batch.
+int project_memory(const sbk_decoder_weights* W, const DecoderBufs& d, const float* enc, int B, int T,
+                   hipStream_t st) {
+  const int dm = W->d_model;
+  for (int l = 0; l < W->n_layers; ++l) {
+    const sbk_decoder_layer& L = W->layers[l];
+    SBK_TRY(sbk::gemm_nt(enc, dm, L.ca_in_w + (size_t)dm * dm, dm, L.ca_in_b + dm, nullptr, 0, d.ckv[l], 2 * dm,
+                         B * T, 2 * dm, dm, SBK_ACT_NONE, 1.0f, nullptr, 0, st));
+  }
+  return 0;
+}
+
+// One decoder step for n = B*beam hypotheses at position `step`; leaves the final-LayerNorm
+// output in d.h and (when want_logits) seq_lin logits in d.logits.
+int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32_t* tokens, const int32_t* kv_slot,
+                 const int32_t* enc_len, int step, int n, int B, int T, int beam, int Lmax, bool want_logits,
+                 hipStream_t st) {
+  const int dm = W->d_model, H = W->nhead;
+  SBK_TRY(sbk::embed_pos(tokens, W->emb, W->pe + (size_t)step * dm, d.x, n, dm, sqrtf((float)dm), st));
+  for (int l = 0; l < W->n_layers; ++l) {
+    const sbk_decoder_layer& L = W->layers[l];
+    SBK_TRY(sbk::layernorm(d.x, L.ln1_g, L.ln1_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
+    SBK_TRY(sbk::gemm_nt(d.h, dm, L.sa_in_w, dm, L.sa_in_b, nullptr, 0, d.qkv, 3 * dm, n, 3 * dm, dm, SBK_ACT_NONE, 1.0f,
+                         nullptr, 0, st));
+    SBK_TRY(sbk::self_attn_step(d.qkv, d.kcache[l], d.vcache[l], kv_slot, d.ctx, n, dm, H, step, n, Lmax, st));
+    SBK_TRY(sbk::gemm_nt(d.ctx, dm, L.sa_out_w, dm, L.sa_out_b, d.x, dm, d.x, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
+                         0, st));
+    SBK_TRY(sbk::layernorm(d.x, L.ln2_g, L.ln2_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
+    SBK_TRY(sbk::gemm_nt(d.h, dm, L.ca_in_w, dm, L.ca_in_b, nullptr, 0, d.q, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr, 0,
+                         st));
+    SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, B, T, dm, H, beam, st));
+    SBK_TRY(sbk::gemm_nt(d.ctx, dm, L.ca_out_w, dm, L.ca_out_b, d.x, dm, d.x, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
+                         0, st));
+    SBK_TRY(sbk::layernorm(d.x, L.ln3_g, L.ln3_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
+    SBK_TRY(sbk::gemm_nt(d.h, dm, L.ff1_w, dm, L.ff1_b, nullptr, 0, d.ff, W->d_ffn, n, W->d_ffn, dm, W->ffn_act, 1.0f,
+                         nullptr, 0, st));
+    SBK_TRY(sbk::gemm_nt(d.ff, W->d_ffn, L.ff2_w, W->d_ffn, L.ff2_b, d.x, dm, d.x, dm, n, dm, W->d_ffn, SBK_ACT_NONE, 1.0f,
+                         nullptr, 0, st));
+  }
+  SBK_TRY(sbk::layernorm(d.x, W->final_ln_g, W->final_ln_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
+  if (want_logits)
+    SBK_TRY(sbk::gemm_nt(d.h, dm, W->seq_w, dm, W->seq_b, nullptr, 0, d.logits, W->vocab, n, W->vocab, dm, SBK_ACT_NONE,
+                         1.0f, nullptr, 0, st));
+  return 0;
+}
+
+int check_weights(const sbk_decoder_weights* W) {
+  SBK_REQUIRE(W && W->layers && W->emb && W->pe && W->final_ln_g && W->final_ln_b, "decoder weights: null pointer");
+  SBK_REQUIRE(W->n_layers > 0 && W->n_layers <= 64 && W->d_model > 0 && W->nhead > 0 && W->d_model % W->nhead == 0,
+              "decoder weights: bad shape");
+  return 0;
+}
+
+struct BeamBufs {
+  BeamState s;
+  float *am, *comb, *psi, *am_max, *ctc_x, *phi[2], *psi_prev[2];
+};
+
+void carve_beam(Carver& c, BeamBufs& b, int B, int beam, int T, int V, int Lmax, bool ctc) {
+  const size_t n = (size_t)B * beam;
+  for (int k = 0; k < 2; ++k) {
+    b.s.seq[k] = c.take<int32_t>(n * Lmax);
+    b.s.lp[k] = c.take<float>(n * Lmax);
+    b.s.kv_slot[k] = c.take<int32_t>(n * Lmax);
+    b.s.tokens[k] = c.take<int32_t>(n);
+  }
+  b.s.seq_scores = c.take<float>(n);
+  b.s.cand_val = c.take<float>(n);
+  b.s.cand_idx = c.take<int32_t>(n);
+  b.s.parent = c.take<int32_t>(n);
+  b.s.fin_count = c.take<int32_t>(B);
+  b.s.fin_seq = c.take<int32_t>(n * Lmax);
+  b.s.fin_lp = c.take<float>(n * Lmax);
+  b.s.fin_len = c.take<int32_t>(n);
+  b.s.fin_score = c.take<float>(n);
+  b.s.n_full = c.take<int32_t>(64);
+  b.am = c.take<float>(n * V);
+  b.comb = c.take<float>(n * V);
+  b.am_max = c.take<float>(n);
+  if (ctc) {
+    b.psi = c.take<float>(n * V);
+    b.ctc_x = c.take<float>((size_t)B * T * V);
+    for (int k = 0; k < 2; ++k) {
+      b.phi[k] = c.take<float>(n * T * 2);
+      b.psi_prev[k] = c.take<float>(n);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t sbk_beam_search_workspace_bytes(const sbk_decoder_weights* W, const sbk_search_config* cfg, int B,
+                                                  int T) {
+  if (!W || !cfg) return 0;
+  Carver c{nullptr, 0, true};
+  DecoderBufs d;
+  BeamBufs bb;
+  const int Lmax = cfg->max_steps > 0 ? cfg->max_steps : 1;
+  carve_decoder(c, d, W, B * cfg->beam, B, T, Lmax);
+  carve_beam(c, bb, B, cfg->beam, T, W->vocab, Lmax, cfg->ctc_weight > 0.0f);
+  return c.used + 256;
+}
+
+extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_search_config* cfg, const float* enc,
+                                   const int32_t* enc_len, const float* ctc_w, const float* ctc_b, void* workspace,
+                                   size_t workspace_bytes, int32_t* out_tokens, int32_t* out_len, float* out_score,
+                                   float* out_logp, int32_t* host_flag, int32_t* steps_run, int B, int T,
+                                   sbk_stream_t stream) {
+  SBK_TRY(check_weights(W));
+  SBK_REQUIRE(cfg && enc && enc_len && workspace && out_tokens && out_len && out_score && out_logp, "beam_search: null");
+  SBK_REQUIRE(W->seq_w && W->seq_b, "beam_search: seq_lin weights missing");
+  SBK_REQUIRE(cfg->beam >= 1 && cfg->beam <= kMaxBeam, "beam_search: beam %d outside [1,%d]", cfg->beam, kMaxBeam);
+  SBK_REQUIRE(cfg->max_steps <= W->max_len, "beam_search: %d steps exceed the positional table (%d)", cfg->max_steps,
+              W->max_len);
+  const bool ctc = cfg->ctc_weight > 0.0f;
+  SBK_REQUIRE(!ctc || (ctc_w && ctc_b), "beam_search: ctc_weight > 0 needs the ctc_lin weights");
+  SBK_REQUIRE(!ctc || (cfg->bos != cfg->eos && cfg->bos != cfg->blank && cfg->eos != cfg->blank),
+              "Set blank, eos and bos to different indexes for joint ATT/CTC or CTC decoding");
+  SBK_REQUIRE(workspace_bytes >= sbk_beam_search_workspace_bytes(W, cfg, B, T), "beam_search: workspace too small");
+  SBK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "beam_search: workspace must be 256-byte aligned");
+  hipStream_t st = sbk::as_stream(stream);
+  const int beam = cfg->beam, V = W->vocab, n = B * beam, dm = W->d_model;
+  const int Lmax = cfg->max_steps > 0 ? cfg->max_steps : 1;
+  if (steps_run) *steps_run = 0;
+  if (B == 0) return 0;
+
+  Carver c{static_cast<char*>(workspace), 0, false};
+  DecoderBufs d;
+  BeamBufs bb;
+  carve_decoder(c, d, W, n, B, T, Lmax);
+  carve_beam(c, bb, B, beam, T, V, Lmax, ctc);
+
+  SBK_TRY(project_memory(W, d, enc, B, T, st));
+  if (ctc) {  // CTCScorer.reset_mem (scorer.py:239-255): log_softmax(ctc_lin(enc)), then the frame mask
+    SBK_TRY(sbk::gemm_nt(enc, dm, ctc_w, dm, ctc_b, nullptr, 0, bb.ctc_x, V, B * T, V, dm, SBK_ACT_NONE, 1.0f, nullptr, 0, st));
+    SBK_TRY(sbk::log_softmax_rows(bb.ctc_x, bb.ctc_x, B * T, V, 1.0f, 1.0f, st));
+    SBK_TRY(sbk::ctc_prepare(bb.ctc_x, enc_len, bb.phi[0], bb.psi_prev[0], B, T, V, beam, cfg->blank, st));
+  }
+  SBK_LAUNCH(beam_init_kernel, dim3(sbk::cdiv(n > B ? n : B, 256)), dim3(256), 0, st, bb.s, B, beam, cfg->bos);
+  SBK_TRY(sbk::launch_status("beam_init"));
+
+  const float attn_w = ctc ? 1.0f - cfg->ctc_weight : 1.0f;  // seq2seq.py:803-804
+  int cur = 0, steps = 0;
+  for (int step = 0; step < cfg->max_steps; ++step) {
+    SBK_TRY(decoder_step(W, d, bb.s.tokens[cur], bb.s.kv_slot[cur], enc_len, step, n, B, T, beam, Lmax, true, st));
+    SBK_TRY(sbk::log_softmax_rows(d.logits, bb.am, n, V, cfg->temperature, attn_w, st));
+    if (cfg->using_eos_threshold) SBK_TRY(sbk::row_max(bb.am, bb.am_max, n, V, st));
+    const int eos_floor = step < cfg->min_steps;
+    if (ctc) {
+      SBK_TRY(sbk::ctc_score_step(bb.ctc_x, bb.phi[cur], bb.psi_prev[cur], bb.s.tokens[cur], enc_len, bb.am, bb.comb,
+                                  bb.psi, B, T, V, beam, step, cfg->blank, cfg->eos, cfg->ctc_weight, eos_floor,
+                                  cfg->using_eos_threshold, cfg->eos_threshold, cfg->minus_inf, bb.am_max, st));
+    } else {
+      SBK_TRY(sbk::am_only(bb.am, bb.comb, n, V, cfg->eos, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
+                           cfg->minus_inf, bb.am_max, st));
+    }
+    const float norm = cfg->length_normalization ? (float)(step + 1) : 0.0f;
+    SBK_LAUNCH(beam_topk_kernel, dim3(B), dim3(256), 0, st, (const float*)bb.comb, (const float*)bb.s.seq_scores,
+               bb.s.cand_val, bb.s.cand_idx, V, beam, norm);
+    SBK_TRY(sbk::launch_status("beam_topk"));
+    SBK_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 0, st, bb.s, (const float*)bb.am, cur, step, V, beam, Lmax,
+               cfg->eos, cfg->length_normalization);
+    SBK_TRY(sbk::launch_status("beam_update"));
+    if (ctc)
+      SBK_TRY(sbk::ctc_advance(bb.ctc_x, bb.phi[cur], bb.psi, bb.s.parent, bb.s.tokens[cur ^ 1], bb.s.tokens[cur],
+                               bb.phi[cur ^ 1], bb.psi_prev[cur ^ 1], n, T, V, beam, step, cfg->blank, st));
+    cur ^= 1;
+    steps = step + 1;
+    if (host_flag && cfg->check_every > 0 && (steps % cfg->check_every == 0) && steps < cfg->max_steps) {
+      hipMemcpyAsync(host_flag, bb.s.n_full, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+      hipStreamSynchronize(st);
+      if (*host_flag >= B) break;
+    }
+  }
+  if (steps_run) *steps_run = steps;
+  SBK_LAUNCH(beam_finalize_kernel, dim3(B), dim3(256), 0, st, bb.s, cur, steps, beam, Lmax, out_tokens, out_len,
+             out_score, out_logp);
+  return sbk::launch_status("beam_finalize");
+}
+
+// Teacher-forced run of the KV-cached decoder over a given prefix: the TransformerASR.decode
+// surface (TransformerASR.py:426-473).  tokens [n,L] -> pred [n,L,d] (final LayerNorm output).
+extern "C" size_t sbk_decoder_prefix_workspace_bytes(const sbk_decoder_weights* W, int n, int T, int L) {
+  if (!W) return 0;
+  Carver c{nullptr, 0, true};
+  DecoderBufs d;
+  carve_decoder(c, d, W, n, n, T, L);
+  c.take<int32_t>((size_t)n * L);  // kv_slot
+  c.take<int32_t>((size_t)n);      // tok column
+  c.take<int32_t>(64 + 2 * (size_t)n);
+  return c.used + 256;
+}
+
+__global__ void gather_col_kernel(const int32_t* __restrict__ tokens, int32_t* __restrict__ col, int n, int L, int p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) col[i] = tokens[(size_t)i * L + p];
+}
+
+extern "C" int sbk_decoder_prefix_f32(const sbk_decoder_weights* W, const int32_t* tokens, const float* enc,
+                                      const int32_t* enc_len, void* workspace, size_t workspace_bytes, float* pred,
+                                      int n, int T, int L, sbk_stream_t stream) {
+  SBK_TRY(check_weights(W));
+  SBK_REQUIRE(tokens && enc && enc_len && workspace && pred, "decoder_prefix: null");
+  SBK_REQUIRE(L <= W->max_len, "decoder_prefix: prefix longer than the positional table");
+  SBK_REQUIRE(workspace_bytes >= sbk_decoder_prefix_workspace_bytes(W, n, T, L), "decoder_prefix: workspace too small");
+  hipStream_t st = sbk::as_stream(stream);
+  if (n == 0 || L == 0) return 0;
+  Carver c{static_cast<char*>(workspace), 0, false};
+  DecoderBufs d;
+  carve_decoder(c, d, W, n, n, T, L);
+  int32_t* kv_slot = c.take<int32_t>((size_t)n * L);
+  int32_t* col = c.take<int32_t>((size_t)n);
+  int32_t* misc = c.take<int32_t>(64 + 2 * (size_t)n);
+  SBK_TRY(project_memory(W, d, enc, n, T, st));
+  SBK_LAUNCH(greedy_init_kernel, dim3(sbk::cdiv(n, 256)), dim3(256), 0, st, misc + 64, misc + 64 + n, misc, kv_slot, n, L, 0);
+  SBK_TRY(sbk::launch_status("prefix_init"));
+  for (int p = 0; p < L; ++p) {
+    SBK_LAUNCH(gather_col_kernel, dim3(sbk::cdiv(n, 256)), dim3(256), 0, st, tokens, col, n, L, p);
+    SBK_TRY(decoder_step(W, d, col, kv_slot, enc_len, p, n, n, T, 1, L, false, st));
+    SBK_LAUNCH(copy_rows_kernel, dim3(n), dim3(256), 0, st, (const float*)d.h, pred + (size_t)p * W->d_model, n,
+               W->d_model, (long)L * W->d_model);
+    SBK_TRY(sbk::launch_status("prefix_copy"));
+  }
+  return 0;
+}
+
+// S2STransformerGreedySearcher (seq2seq.py:176-367, temperature 0).
+extern "C" size_t sbk_greedy_search_workspace_bytes(const sbk_decoder_weights* W, int B, int T, int max_steps) {
+  if (!W) return 0;
+  Carver c{nullptr, 0, true};
+  DecoderBufs d;
+  const int L = max_steps > 0 ? max_steps : 1;
+  carve_decoder(c, d, W, B, B, T, L);
+  c.take<int32_t>((size_t)B * L);
+  c.take<int32_t>(64 + 2 * (size_t)B);
+  return c.used + 256;
+}
+
+extern "C" int sbk_greedy_search_f32(const sbk_decoder_weights* W, const float* enc, const int32_t* enc_len,
+                                     void* workspace, size_t workspace_bytes, int32_t* out_tokens, float* out_scores,
+                                     int32_t* host_flag, int32_t* steps_run, int B, int T, int min_steps, int max_steps,
+                                     int bos, int eos, int check_every, sbk_stream_t stream) {
+  SBK_TRY(check_weights(W));
+  SBK_REQUIRE(enc && enc_len && workspace && out_tokens && out_scores && W->seq_w && W->seq_b, "greedy_search: null");
+  SBK_REQUIRE(max_steps <= W->max_len, "greedy_search: too many steps for the positional table");
+  SBK_REQUIRE(workspace_bytes >= sbk_greedy_search_workspace_bytes(W, B, T, max_steps), "greedy: workspace too small");
+  hipStream_t st = sbk::as_stream(stream);
+  if (steps_run) *steps_run = 0;
+  const int L = max_steps > 0 ? max_steps : 1;
+  if (B == 0) return 0;
+  Carver c{static_cast<char*>(workspace), 0, false};
+  DecoderBufs d;
+  carve_decoder(c, d, W, B, B, T, L);
+  int32_t* kv_slot = c.take<int32_t>((size_t)B * L);
+  int32_t* misc = c.take<int32_t>(64 + 2 * (size_t)B);
+  int32_t *n_ended = misc, *tok = misc + 64, *ended = misc + 64 + B;
+  SBK_TRY(project_memory(W, d, enc, B, T, st));
+  SBK_LAUNCH(greedy_init_kernel, dim3(sbk::cdiv(B, 256)), dim3(256), 0, st, tok, ended, n_ended, kv_slot, B, L, bos);
+  SBK_TRY(sbk::launch_status("greedy_init"));
+  hipMemsetAsync(out_tokens, 0, (size_t)B * L * sizeof(int32_t), st);
+  hipMemsetAsync(out_scores, 0, (size_t)B * L * sizeof(float), st);
+  int k = 0;
+  for (int step = min_steps; step < max_steps; ++step, ++k) {  // positions count from 0 (seq2seq.py:227)
+    SBK_TRY(decoder_step(W, d, tok, kv_slot, enc_len, k, B, B, T, 1, L, true, st));
+    SBK_LAUNCH(greedy_pick_kernel, dim3(B), dim3(256), 0, st, (const float*)d.logits, tok, ended, out_tokens,
+               out_scores, n_ended, W->vocab, k, L, eos);
+    SBK_TRY(sbk::launch_status("greedy_pick"));
+    if (host_flag && check_every > 0 && ((k + 1) % check_every == 0)) {
+      hipMemcpyAsync(host_flag, n_ended, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+      hipStreamSynchronize(st);
+      if (*host_flag >= B) {
+        ++k;
+        break;
+      }
+    }
+  }
+  if (steps_run) *steps_run = k;
+  return 0;
+}

@@ -27,6 +27,26 @@ class SbkError(RuntimeError):
     pass
 
 
+class DecoderLayer(ctypes.Structure):  # sbk_decoder_layer
+    _fields_ = [(n, c_void_p) for n in (
+        "ln1_g", "ln1_b", "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ln2_g", "ln2_b", "ca_in_w", "ca_in_b",
+        "ca_out_w", "ca_out_b", "ln3_g", "ln3_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b")]
+
+
+class DecoderWeights(ctypes.Structure):  # sbk_decoder_weights
+    _fields_ = [("layers", POINTER(DecoderLayer)), ("emb", c_void_p), ("pe", c_void_p), ("final_ln_g", c_void_p),
+                ("final_ln_b", c_void_p), ("seq_w", c_void_p), ("seq_b", c_void_p), ("d_model", c_int32),
+                ("nhead", c_int32), ("d_ffn", c_int32), ("n_layers", c_int32), ("vocab", c_int32),
+                ("max_len", c_int32), ("ffn_act", c_int32), ("ln_eps", c_float)]
+
+
+class SearchConfig(ctypes.Structure):  # sbk_search_config
+    _fields_ = [("bos", c_int32), ("eos", c_int32), ("blank", c_int32), ("beam", c_int32), ("min_steps", c_int32),
+                ("max_steps", c_int32), ("length_normalization", c_int32), ("using_eos_threshold", c_int32),
+                ("check_every", c_int32), ("ctc_weight", c_float), ("temperature", c_float),
+                ("eos_threshold", c_float), ("minus_inf", c_float)]
+
+
 def _declare(lib):
     p, i, f = c_void_p, c_int, c_float
     sig = {
@@ -39,6 +59,15 @@ def _declare(lib):
         "sbk_relpos_attention_f32": ([p, p, p, p, p, p, p, i, i, i, i, f, p], c_int),
         "sbk_glu_dwconv_f32": ([p, p, p, p, i, i, i, i, p], c_int),
         "sbk_layernorm_f32": ([p, p, p, p, i, i, f, i, p], c_int),
+        "sbk_log_softmax_f32": ([p, p, i, i, f, f, p], c_int),
+        "sbk_beam_search_workspace_bytes": ([POINTER(DecoderWeights), POINTER(SearchConfig), i, i], ctypes.c_size_t),
+        "sbk_beam_search_f32": ([POINTER(DecoderWeights), POINTER(SearchConfig), p, p, p, p, p, ctypes.c_size_t, p, p,
+                                 p, p, p, POINTER(c_int32), i, i, p], c_int),
+        "sbk_greedy_search_workspace_bytes": ([POINTER(DecoderWeights), i, i, i], ctypes.c_size_t),
+        "sbk_greedy_search_f32": ([POINTER(DecoderWeights), p, p, p, ctypes.c_size_t, p, p, p, POINTER(c_int32), i, i,
+                                   i, i, i, i, i, p], c_int),
+        "sbk_decoder_prefix_workspace_bytes": ([POINTER(DecoderWeights), i, i, i], ctypes.c_size_t),
+        "sbk_decoder_prefix_f32": ([POINTER(DecoderWeights), p, p, p, p, ctypes.c_size_t, p, i, i, i, p], c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -218,3 +247,138 @@ def glu_dwconv(h, w, bias, ksize):
     _chk(lib.sbk_glu_dwconv_f32(_p(h), _p(w), _p(bias), _p(y), B, T, d2 // 2, int(ksize), _stream(h)),
          "sbk_glu_dwconv_f32")
     return y
+
+
+# ------------------------------------------------------------------ decoder / searchers
+class DecoderHandle:
+    """Device pointers of a TransformerASR decoder (+ seq_lin) laid out as sbk_decoder_weights.
+    Holds references to the parameter tensors so the pointers stay valid."""
+
+    def __init__(self, model, seq_lin=None):
+        dec = model.decoder
+        self.keep = []
+        layers = (DecoderLayer * len(dec.layers))()
+
+        def ptr(t):
+            t = t.detach()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            _dev_ok(t)
+            _f32(t)
+            self.keep.append(t)
+            return t.data_ptr()
+
+        act = None
+        for l, L in enumerate(dec.layers):
+            o = layers[l]
+            o.ln1_g, o.ln1_b = ptr(L.norm1.norm.weight), ptr(L.norm1.norm.bias)
+            o.sa_in_w, o.sa_in_b = ptr(L.self_attn.att.in_proj_weight), ptr(L.self_attn.att.in_proj_bias)
+            o.sa_out_w, o.sa_out_b = ptr(L.self_attn.att.out_proj.weight), ptr(L.self_attn.att.out_proj.bias)
+            o.ln2_g, o.ln2_b = ptr(L.norm2.norm.weight), ptr(L.norm2.norm.bias)
+            o.ca_in_w, o.ca_in_b = ptr(L.multihead_attn.att.in_proj_weight), ptr(L.multihead_attn.att.in_proj_bias)
+            o.ca_out_w, o.ca_out_b = ptr(L.multihead_attn.att.out_proj.weight), ptr(L.multihead_attn.att.out_proj.bias)
+            o.ln3_g, o.ln3_b = ptr(L.norm3.norm.weight), ptr(L.norm3.norm.bias)
+            o.ff1_w, o.ff1_b = ptr(L.pos_ffn.ffn[0].weight), ptr(L.pos_ffn.ffn[0].bias)
+            o.ff2_w, o.ff2_b = ptr(L.pos_ffn.ffn[3].weight), ptr(L.pos_ffn.ffn[3].bias)
+            act = L.pos_ffn.act_code
+            if not L.normalize_before:
+                raise NotImplementedError("post-norm decoder layers are not on the Conformer ASR path")
+        self.layers = layers
+        W = DecoderWeights()
+        W.layers = ctypes.cast(layers, POINTER(DecoderLayer))
+        emb = model.custom_tgt_module.layers[0].emb.Embedding.weight
+        pe = model.positional_encoding_decoder.pe
+        W.emb, W.pe = ptr(emb), ptr(pe.reshape(pe.shape[-2], pe.shape[-1]))
+        W.final_ln_g, W.final_ln_b = ptr(dec.norm.norm.weight), ptr(dec.norm.norm.bias)
+        if seq_lin is not None:
+            W.seq_w, W.seq_b = ptr(seq_lin.w.weight), ptr(seq_lin.w.bias)
+        W.d_model, W.nhead = emb.shape[1], dec.layers[0].nhead
+        W.d_ffn, W.n_layers = dec.layers[0].pos_ffn.ffn[0].weight.shape[0], len(dec.layers)
+        W.vocab = seq_lin.w.weight.shape[0] if seq_lin is not None else emb.shape[0]
+        W.max_len, W.ffn_act, W.ln_eps = pe.shape[-2], act, dec.norm.eps
+        self.W = W
+        self.device = emb.device
+        self.key = tuple((t.data_ptr(), t._version) for t in self.keep)
+
+    def stale(self, model, seq_lin):
+        try:
+            return DecoderHandle(model, seq_lin).key != self.key
+        except Exception:
+            return True
+
+
+def _host_flag(device):
+    t = torch.zeros(1, dtype=torch.int32)
+    return t.pin_memory() if device.type == "cuda" else t
+
+
+def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=None, ctc_b=None):
+    """Returns (tokens [B,max_steps] int32, lens [B] int32, scores [B], log_probs [B,max_steps], steps_run)."""
+    lib = load()
+    _dev_ok(enc, enc_len, ctc_w, ctc_b)
+    _f32(enc)
+    B, T, _ = enc.shape
+    dev = enc.device
+    L = max(int(cfg.max_steps), 1)
+    nbytes = lib.sbk_beam_search_workspace_bytes(ctypes.byref(handle.W), ctypes.byref(cfg), B, T)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    out_tok = torch.zeros(B, L, dtype=torch.int32, device=dev)
+    out_len = torch.zeros(B, dtype=torch.int32, device=dev)
+    out_score = torch.zeros(B, dtype=torch.float32, device=dev)
+    out_lp = torch.zeros(B, L, dtype=torch.float32, device=dev)
+    flag = _host_flag(dev)
+    steps = c_int32(0)
+    _chk(lib.sbk_beam_search_f32(ctypes.byref(handle.W), ctypes.byref(cfg), _p(enc), _p(enc_len), _p(ctc_w), _p(ctc_b),
+                                 c_void_p(ws.data_ptr() + off), nbytes, _p(out_tok), _p(out_len), _p(out_score),
+                                 _p(out_lp), c_void_p(flag.data_ptr()), ctypes.byref(steps), B, T, _stream(enc)),
+         "sbk_beam_search_f32")
+    return out_tok, out_len, out_score, out_lp, steps.value
+
+
+def greedy_search(handle: DecoderHandle, enc, enc_len, min_steps, max_steps, bos, eos, check_every=8):
+    """Returns (tokens [B,max_steps] int32 (EOS-latched), scores [B,max_steps], steps_run)."""
+    lib = load()
+    _dev_ok(enc, enc_len)
+    B, T, _ = enc.shape
+    dev = enc.device
+    L = max(int(max_steps), 1)
+    nbytes = lib.sbk_greedy_search_workspace_bytes(ctypes.byref(handle.W), B, T, max_steps)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    out_tok = torch.zeros(B, L, dtype=torch.int32, device=dev)
+    out_sc = torch.zeros(B, L, dtype=torch.float32, device=dev)
+    flag = _host_flag(dev)
+    steps = c_int32(0)
+    _chk(lib.sbk_greedy_search_f32(ctypes.byref(handle.W), _p(enc), _p(enc_len), c_void_p(ws.data_ptr() + off), nbytes,
+                                   _p(out_tok), _p(out_sc), c_void_p(flag.data_ptr()), ctypes.byref(steps), B, T,
+                                   int(min_steps), int(max_steps), int(bos), int(eos), int(check_every), _stream(enc)),
+         "sbk_greedy_search_f32")
+    return out_tok, out_sc, steps.value
+
+
+def decoder_prefix(handle: DecoderHandle, tokens, enc, enc_len):
+    """tokens [n,L] int32, enc [n,T,d] -> decoder.norm output [n,L,d] (KV-cached, teacher forced)."""
+    lib = load()
+    _dev_ok(tokens, enc, enc_len)
+    n, L = tokens.shape
+    T = enc.shape[1]
+    nbytes = lib.sbk_decoder_prefix_workspace_bytes(ctypes.byref(handle.W), n, T, L)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=enc.device)
+    off = (-ws.data_ptr()) % 256
+    pred = torch.empty(n, L, handle.W.d_model, dtype=torch.float32, device=enc.device)
+    _chk(lib.sbk_decoder_prefix_f32(ctypes.byref(handle.W), _p(tokens), _p(enc), _p(enc_len),
+                                    c_void_p(ws.data_ptr() + off), nbytes, _p(pred), n, T, L, _stream(enc)),
+         "sbk_decoder_prefix_f32")
+    return pred
+
+
+def log_softmax(x, temperature=1.0, weight=1.0):
+    lib = load()
+    V = x.shape[-1]
+    x2 = x.reshape(-1, V)
+    _dev_ok(x2)
+    out = torch.empty_like(x)
+    _chk(lib.sbk_log_softmax_f32(_p(x2), _p(out), x2.shape[0], V, float(temperature), float(weight), _stream(x2)),
+         "sbk_log_softmax_f32")
+    return out
