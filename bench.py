@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py -- audio-sec/s of the EncoderDecoderASR hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 8 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], "Full Conformer-L enc-dec + S2STransformerBeamSearcher
+beam=10, LibriSpeech-shape synthetic"): Conformer-L (d 512, 12 enc / 6 dec layers, 5000 tokens,
+RelPosMHAXL), beam 10 + CTC weight 0.4 (the recipe's valid_search), seeded random weights,
+synthetic 16 kHz audio 0.1*randn, utterance durations U(5,30) s (seed 1234), duration-sorted
+batches of 32.  One "step" = one batch through Fbank -> norm -> CNN -> Conformer encoder -> beam
+search -> token ids on the host.  Random weights never emit EOS, so the number of decoding steps is
+fixed through max_decode_ratio to round(4 tokens/s * seconds).
+Waveforms are resident in HBM when the timed region starts.  fp32 arithmetic throughout.
+
+One JSON line on rank 0: metric / value (total unpadded audio seconds of all ranks / max-over-ranks
+wall time) plus "roofline" (dominant kernel, from HIP-event timing of every launch during an
+instrumented repetition of the same steps) and "cpu_baseline" (the oracle port of the reference's
+PyTorch-CPU path, timed here on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
+MFMA_KERNELS = ("gemm_nt", "relpos_attention")
+TOKENS_PER_SECOND = 4.0
+
+
+def make_batches(n_batches, batch, seed, sr=16000, lo=5.0, hi=30.0):
+    """Duration-sorted batches of synthetic audio: list of (wavs [B,N] cpu, rel_lens [B], seconds list)."""
+    g = torch.Generator().manual_seed(seed)
+    dur = (lo + (hi - lo) * torch.rand(n_batches * batch, generator=g)).sort().values
+    out = []
+    for i in range(n_batches):
+        d = dur[i * batch:(i + 1) * batch]
+        n = (d * sr).round().long()
+        N = int(n.max())
+        wav = 0.1 * torch.randn(batch, N, generator=g)
+        for r in range(batch):
+            wav[r, int(n[r]):] = 0.0
+        out.append((wav, n.float() / N, (n.float() / sr).tolist()))
+    return out
+
+
+def frames_after_frontend(n_samples):
+    t = 1 + n_samples // 160
+    t = (t - 1) // 2 + 1
+    return (t - 1) // 2 + 1
+
+
+def set_decode_steps(asr, n_samples):
+    """Fix the decode length to round(4 tok/s * padded seconds) through max_decode_ratio."""
+    T = frames_after_frontend(n_samples)
+    steps = max(1, int(round(TOKENS_PER_SECOND * n_samples / 16000.0)))
+    asr.mods.decoder.max_decode_ratio = (steps + 0.5) / T
+    return steps
+
+
+def run_step(asr, wav, lens):
+    set_decode_steps(asr, wav.shape[1])
+    words, toks = asr.transcribe_batch(wav, lens)
+    return toks
+
+
+def cpu_baseline(asr, seconds=6.0, batch=2):
+    """Oracle port of the reference's CPU path (no KV cache, Python-loop CTC scorer) on a bounded sample."""
+    from oracle import sb_oracle as O
+    from speechbrain_amd.inference.builders import oracle_state_dict
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = oracle_state_dict(asr)
+    fc = O.FbankCfg(n_fft=512, n_mels=80, win_length_ms=32)
+    mc = O.ModelCfg()
+    n = int(seconds * 16000)
+    wav = 0.1 * torch.randn(batch, n, generator=torch.Generator().manual_seed(99))
+    lens = torch.ones(batch)
+    T = frames_after_frontend(n)
+    steps = max(1, int(round(TOKENS_PER_SECOND * seconds)))
+    sc = O.SearchCfg(beam=10, ctc_weight=0.4, max_decode_ratio=(steps + 0.5) / T)
+    t0 = time.time()
+    with torch.no_grad():
+        enc = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
+        O.beam_search(enc, lens, sd, mc, sc)
+    dt = time.time() - t0
+    return {"value": round(batch * seconds / dt, 3), "unit": "audio-sec/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{batch} x {seconds:g} s utterance, Conformer-L beam 10 + CTC 0.4, {steps} decode steps, "
+                                      f"oracle/sb_oracle.py (torch-CPU fp32) in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--latency-runs", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from speechbrain_amd import native
+    from speechbrain_amd.inference.builders import build_asr
+
+    native.load()
+    asr = build_asr("L", vocab=5000, seed=0, beam_size=10, ctc_weight=0.4, device=str(dev))
+    asr.mods.decoder.check_every = 0  # fixed-length decoding: no stop-rule polling, fully asynchronous
+
+    # every rank owns K (+W) batches: weak scaling, per-GPU work fixed as N grows
+    pool = make_batches(args.steps, args.batch, seed=1234 + rank)
+    pool_dev = [(w.to(dev), l.to(dev), s) for w, l, s in pool]
+    warm_dev = [pool_dev[-1]] * args.warmup  # the longest batch: sizes every allocation before the timed region
+    audio_sec = sum(sum(s) for _, _, s in pool)
+
+    for w, l, _ in warm_dev:
+        run_step(asr, w, l)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    results = []
+    for k, (w, l, _) in enumerate(pool_dev):
+        hyps = run_step(asr, w, l)
+        results.extend((k * args.batch + i, h) for i, h in enumerate(hyps))
+    if world > 1:  # token ids to rank 0: the path's only collective
+        width = int(round(TOKENS_PER_SECOND * 30.0)) + 8  # same shape on every rank (durations <= 30 s)
+        buf = torch.zeros(len(results), width + 1, dtype=torch.int32, device=dev)
+        for r, (_, h) in enumerate(results):
+            buf[r, 0] = len(h)
+            buf[r, 1:1 + len(h)] = torch.tensor(h, dtype=torch.int32)
+        gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, gathered, dst=0)
+    barrier()
+    dt = time.perf_counter() - t0
+    stats = torch.tensor([dt, audio_sec], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, total_audio = float(tmax[0]), float(tsum[1])
+    else:
+        total_audio = audio_sec
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "audio-sec/s decoded (node), Conformer-L beam=10", "value": round(total_audio / dt, 2),
+            "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Conformer-L enc-dec (RelPosMHAXL, 12+6 layers, d=512, V=5000) + "
+                                   "S2STransformerBeamSearcher beam=10 + CTC 0.4; 16 kHz 0.1*randn audio, durations "
+                                   "U(5,30) s, duration-sorted batches; decode steps = round(4 tok/s * seconds)",
+                       "batch": args.batch, "utterances_per_gpu": args.steps * args.batch,
+                       "audio_seconds_total": round(total_audio, 1), "weights": "random init, torch.manual_seed(0)",
+                       "parallelism": f"replicas x{world}, utterance sharding, gather of token ids only"},
+        }
+
+    # ---- p50 per-utterance latency (B = 1, 10 s), rank 0 only
+    if rank == 0 and args.latency_runs > 0:
+        w1 = (0.1 * torch.randn(1, 160000, generator=torch.Generator().manual_seed(5))).to(dev)
+        l1 = torch.ones(1, device=dev)
+        run_step(asr, w1, l1)
+        lat = []
+        for _ in range(args.latency_runs):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            run_step(asr, w1, l1)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t)
+        lat.sort()
+        out["p50_latency_ms"] = round(1000.0 * lat[len(lat) // 2], 2)
+        out["config"]["latency_case"] = "B=1, 10 s utterance, 40 decode steps"
+
+    # ---- roofline of the dominant kernel: HIP events around every launch, same steps repeated
+    if rank == 0 and not args.no_roofline:
+        native.prof_reset()
+        native.prof_enable(True)
+        for w, l, _ in pool_dev:
+            run_step(asr, w, l)
+        torch.cuda.synchronize()
+        native.prof_enable(False)
+        rep = native.prof_report()
+        native.prof_reset()
+        total_ms = sum(v["ms"] for v in rep.values()) or 1.0
+        name, top = max(rep.items(), key=lambda kv: kv[1]["ms"])
+        mfma = name.startswith(MFMA_KERNELS)
+        avg_ms = top["ms"] / top["count"]
+        if mfma:
+            ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4)}
+        else:
+            ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 4)}
+        roof.update({"traffic": None, "kernel": name, "launches": top["count"], "avg_launch_ms": round(avg_ms, 4),
+                     "share_of_gpu_time": round(top["ms"] / total_ms, 3)})
+        out["roofline"] = roof
+        out["kernel_breakdown_ms"] = {k: round(v["ms"], 2) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(asr)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,6 +33,12 @@ typedef void* sbk_stream_t; /* hipStream_t */
 int sbk_abi_version(void);
 const char* sbk_last_error(void);
 
+/* Per-launch timing with HIP events recorded on each launch's own stream (bench.py's roofline
+ * leg).  sbk_prof_report writes "name count total_ms algorithmic_flops algorithmic_bytes" lines. */
+void sbk_prof_enable(int on);
+void sbk_prof_reset(void);
+size_t sbk_prof_report(char* buf, size_t cap);
+
 /* ---- activations understood by fused epilogues --------------------------- */
 enum { SBK_ACT_NONE = 0, SBK_ACT_SWISH = 1, SBK_ACT_GELU = 2, SBK_ACT_RELU = 3, SBK_ACT_LEAKY_RELU = 4 };
 
@@ -147,7 +153,8 @@ typedef struct {
  * CTC scorer (scorer.py:108-255,1221-1315; ctc.py:26-295).
  *   enc [B,T,d], enc_len [B] = round(T * wav_len); ctc_w [V,d], ctc_b [V] (NULL when ctc_weight = 0)
  *   out_tokens [B,max_steps] (best hypothesis, EOS stripped, zero padded), out_len [B],
- *   out_score [B], out_logp [B,max_steps]
+ *   out_score [B], out_logp [B,max_steps]; out_max_len [1] (device, may be NULL): length of the
+ *   longest finished hypothesis in the batch = pad width the reference divides lengths by (:1461)
  *   host_flag: pinned HOST int32 used to poll the stop rule every cfg->check_every steps (the
  *              only points where this call synchronises the stream); NULL => run max_steps.
  *   steps_run: HOST int32 out. */
@@ -155,7 +162,8 @@ size_t sbk_beam_search_workspace_bytes(const sbk_decoder_weights* W, const sbk_s
 int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_search_config* cfg, const float* enc,
                         const int32_t* enc_len, const float* ctc_w, const float* ctc_b, void* workspace,
                         size_t workspace_bytes, int32_t* out_tokens, int32_t* out_len, float* out_score,
-                        float* out_logp, int32_t* host_flag, int32_t* steps_run, int B, int T, sbk_stream_t stream);
+                        float* out_logp, int32_t* out_max_len, int32_t* host_flag, int32_t* steps_run, int B, int T,
+                        sbk_stream_t stream);
 
 /* S2STransformerGreedySearcher.forward (seq2seq.py:176-367, temperature 0): per-step arg-max.
  *   out_tokens [B,max_steps] (EOS-latched), out_scores [B,max_steps] (log-prob of the arg-max, 0 after the end) */

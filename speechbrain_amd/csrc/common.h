@@ -11,6 +11,15 @@ int fail(int code, const char* fmt, ...);
 // Returns 0 or the hipError_t of the launch that just happened (and records it).
 int launch_status(const char* what);
 
+// Optional per-launch timing with HIP events on the launch stream (sbk_prof_* in include/sbk.h).
+// Costs nothing when disabled.  `flops` / `bytes` are the ALGORITHMIC work of the launch.
+struct ProfScope {
+  ProfScope(const char* name, double flops, double bytes, hipStream_t st);
+  ~ProfScope();
+  int slot;
+  hipStream_t st;
+};
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline hipStream_t as_stream(sbk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -112,6 +112,8 @@ extern "C" int sbk_conv_block_f32(const float* x, const float* wt, const float* 
   SBK_REQUIRE(lds <= 64 * 1024, "conv_block: input patch of %zu B does not fit the LDS window", lds);
   if (B == 0) return 0;
   ConvArgs a{x, wt, bias, gamma, beta, y, B, Tin, Fin, Cin, Tout, Fout, Cout, eps, slope};
+  sbk::ProfScope prof(Cin == 1 ? "conv_block_cin1" : "conv_block", 2.0 * 9 * Cin * (double)B * Tout * Fout * Cout,
+                      4.0 * B * ((double)Tin * Fin * Cin + (double)Tout * Fout * Cout), sbk::as_stream(stream));
   SBK_LAUNCH(conv_block_kernel, dim3(Tout, B), dim3(256), lds, sbk::as_stream(stream), a);
   return sbk::launch_status("sbk_conv_block_f32");
 }

@@ -63,6 +63,7 @@ int glu_dwconv(const float* h, const float* w, const float* bias, float* y, int 
                hipStream_t st) {
   if (B == 0 || T == 0) return 0;
   dim3 grid(cdiv(T, kTT), cdiv(d, kCT), B), block(256);
+  ProfScope prof("glu_dwconv", (2.0 * ksize + 4.0) * B * T * d, 12.0 * B * T * d, st);
   switch (ksize) {
     case 31: SBK_LAUNCH((glu_dwconv_kernel<31>), grid, block, 0, st, h, w, bias, y, T, d); break;
     case 15: SBK_LAUNCH((glu_dwconv_kernel<15>), grid, block, 0, st, h, w, bias, y, T, d); break;

@@ -222,6 +222,7 @@ int ctc_score_step(const float* x, const float* phi, const float* psi_prev, cons
                    float minus_inf, const float* am_max, hipStream_t st) {
   CtcStepArgs a{x, phi, psi_prev, last_tok, enc_len, am, comb, psi, B, T, V, beam, prefix_len, blank, eos, weight,
                 eos_floor, use_thr, thr, minus_inf, am_max};
+  ProfScope prof("ctc_score_step", 10.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 12.0 * B * beam * V, st);
   SBK_LAUNCH(ctc_score_step_kernel, dim3(cdiv(V, 256), B), dim3(256), 0, st, a);
   return launch_status("ctc_score_step");
 }
@@ -229,6 +230,7 @@ int ctc_score_step(const float* x, const float* phi, const float* psi_prev, cons
 int ctc_advance(const float* x, const float* phi_old, const float* psi, const int32_t* parent, const int32_t* token,
                 const int32_t* parent_last_tok, float* phi_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
                 int prefix_len, int blank, hipStream_t st) {
+  ProfScope prof("ctc_advance", 10.0 * n_bh * T, 16.0 * n_bh * T, st);
   SBK_LAUNCH(ctc_advance_kernel, dim3(cdiv(n_bh, 64)), dim3(64), 0, st, x, phi_old, psi, parent, token,
              parent_last_tok, phi_new, psi_prev_new, n_bh, T, V, beam, prefix_len, blank);
   return launch_status("ctc_advance");

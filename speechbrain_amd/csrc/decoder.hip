@@ -184,6 +184,7 @@ int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
     hipError_t e = SBK_ALLOW_DYN_LDS((cross_attn_step_kernel<DH>), lds);
     if (e != hipSuccess) return sbk::fail((int)e, "cross_attn: cannot raise the LDS window");
   }
+  sbk::ProfScope prof("cross_attn_step", 4.0 * a.B * a.beam * (double)a.T * a.d, 8.0 * a.B * (double)a.T * a.d, st);
   SBK_LAUNCH((cross_attn_step_kernel<DH>), dim3(sbk::cdiv(a.beam, kQT), a.H, a.B), dim3(256), lds, st, a);
   return sbk::launch_status("cross_attn_step");
 }
@@ -219,6 +220,7 @@ namespace sbk {
 int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,
               hipStream_t st) {
   if (n == 0) return 0;
+  ProfScope prof("embed_pos", 2.0 * n * d, 8.0 * n * d, st);
   SBK_LAUNCH(embed_pos_kernel, dim3(n), dim3(256), 0, st, tok, emb, pe_row, x, n, d, scale);
   return launch_status("embed_pos");
 }
@@ -229,6 +231,7 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
   SelfAttnArgs a{qkv, kcache, vcache, kv_slot, out, n, d, H, d / H, step, nslot, Lmax, 1.0f / sqrtf((float)(d / H))};
   const size_t lds = (size_t)4 * (((Lmax + 63) / 64) * 64) * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "self_attn_step: Lmax=%d too long for the LDS window", Lmax);
+  ProfScope prof("self_attn_step", 4.0 * n * d * (step + 1), 8.0 * n * d * (step + 1), st);
   SBK_LAUNCH(self_attn_step_kernel, dim3(cdiv(n * H, 4)), dim3(256), lds, st, a);
   return launch_status("self_attn_step");
 }
@@ -250,6 +253,7 @@ int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, flo
 
 int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st) {
   if (rows == 0) return 0;
+  ProfScope prof("log_softmax", 4.0 * rows * V, 8.0 * rows * V, st);
   SBK_LAUNCH(log_softmax_row_kernel, dim3(rows), dim3(256), 0, st, x, out, V, 1.0f / temperature, weight);
   return launch_status("log_softmax_rows");
 }

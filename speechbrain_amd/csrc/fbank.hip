@@ -173,6 +173,7 @@ extern "C" int sbk_fbank_f32(const float* wav, const float* window, const float*
   SBK_REQUIRE(lds <= 160 * 1024, "fbank: n_fft=%d needs %zu B of LDS", n_fft, lds);
   FbankArgs a{wav, window, twiddle, mel_w, mel_ptr, mel_bin, out, tile_max, B, N, T, n_fft, hop, n_mels, nnz, ntiles, amin};
   hipStream_t st = sbk::as_stream(stream);
+  sbk::ProfScope prof("fbank", 5.0 * n_fft * 9.0 * B * T, 4.0 * ((double)B * N + 3.0 * B * T * n_mels), st);
   SBK_LAUNCH(fbank_frames_kernel, dim3(ntiles, B), dim3(256), lds, st, a, rad);
   int rc = sbk::launch_status("sbk_fbank_f32/frames");
   if (rc) return rc;

@@ -136,6 +136,8 @@ template <int BM, int BN, int BK, int WM, int WN>
 int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
   dim3 grid(sbk::cdiv(g.N, BN), sbk::cdiv(g.M, BM));
   dim3 block((BM / WM) * (BN / WN) * 64);
+  static const char* kName = BM == 128 ? "gemm_nt_128x128" : (BM == 64 ? "gemm_nt_64x64" : "gemm_nt_32x64");
+  sbk::ProfScope prof(kName, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N), st);
   if (vec) {
     SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, true>), grid, block, 0, st, g);
   } else {

@@ -106,6 +106,7 @@ int layernorm(const float* x, const float* gamma, const float* beta, float* y, i
               hipStream_t st) {
   if (rows == 0) return 0;
   dim3 grid(cdiv(rows, 4)), block(256);
+  ProfScope prof("layernorm", 8.0 * rows * d, 8.0 * rows * d, st);
   const bool vec = (d % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta);
   if (vec && d <= 256 * 1) {
     SBK_LAUNCH((layernorm_kernel<1>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, act);

@@ -198,6 +198,8 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
     hipError_t e = SBK_ALLOW_DYN_LDS((relpos_attn_kernel<DH>), lds);
     if (e != hipSuccess) return sbk::fail((int)e, "relpos_attention: cannot raise the LDS window to %zu B", lds);
   }
+  sbk::ProfScope prof("relpos_attention", 6.0 * a.B * a.H * (double)a.T * a.T * DH,
+                      4.0 * a.B * a.T * (4.0 * a.H * DH) + 4.0 * (2.0 * a.T - 1) * a.H * DH, st);
   SBK_LAUNCH((relpos_attn_kernel<DH>), dim3((a.T + 31) / 32, a.H, a.B), dim3(256), lds, st, a);
   return sbk::launch_status("sbk_relpos_attention_f32");
 }

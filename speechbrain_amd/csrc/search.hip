@@ -151,7 +151,10 @@ struct BeamState {
 
 __global__ void beam_init_kernel(BeamState s, int B, int beam, int bos) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n == 0) *s.n_full = 0;
+  if (n == 0) {
+    s.n_full[0] = 0;
+    s.n_full[1] = 0;  // longest finished hypothesis (pad width of the reference's top_hyps tensor)
+  }
   if (n < B) s.fin_count[n] = 0;
   if (n >= B * beam) return;
   s.tokens[0][n] = bos;
@@ -244,6 +247,10 @@ __global__ void __launch_bounds__(256) beam_finalize_kernel(BeamState s, int cur
         }
       }
     }
+    int longest = 0;  // over ALL finished entries of this utterance, filled ones included
+    for (int f = 0; f < s.fin_count[b]; ++f) longest = max(longest, s.fin_len[b * beam + f]);
+    if (steps_done > 0 && s.fin_count[b] < beam) longest = max(longest, steps_done);
+    atomicMax(&s.n_full[1], longest);
     best = bi;
     best_from_alive = alive_j;
     out_score[b] = bi < 0 ? 0.0f : bv;
@@ -381,6 +388,12 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
   }
 }
 
+#define SBK_HIP(expr)                                                              \
+  do {                                                                             \
+    hipError_t e__ = (expr);                                                       \
+    if (e__ != hipSuccess) return sbk::fail((int)e__, "%s: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+
 #define SBK_TRY(expr)        \
   do {                       \
     int rc__ = (expr);       \
@@ -493,8 +506,8 @@ extern "C" size_t sbk_beam_search_workspace_bytes(const sbk_decoder_weights* W, 
 extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_search_config* cfg, const float* enc,
                                    const int32_t* enc_len, const float* ctc_w, const float* ctc_b, void* workspace,
                                    size_t workspace_bytes, int32_t* out_tokens, int32_t* out_len, float* out_score,
-                                   float* out_logp, int32_t* host_flag, int32_t* steps_run, int B, int T,
-                                   sbk_stream_t stream) {
+                                   float* out_logp, int32_t* out_max_len, int32_t* host_flag, int32_t* steps_run,
+                                   int B, int T, sbk_stream_t stream) {
   SBK_TRY(check_weights(W));
   SBK_REQUIRE(cfg && enc && enc_len && workspace && out_tokens && out_len && out_score && out_logp, "beam_search: null");
   SBK_REQUIRE(W->seq_w && W->seq_b, "beam_search: seq_lin weights missing");
@@ -544,11 +557,17 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
                            cfg->minus_inf, bb.am_max, st));
     }
     const float norm = cfg->length_normalization ? (float)(step + 1) : 0.0f;
-    SBK_LAUNCH(beam_topk_kernel, dim3(B), dim3(256), 0, st, (const float*)bb.comb, (const float*)bb.s.seq_scores,
+    {
+      sbk::ProfScope prof("beam_topk", 2.0 * n * V, 4.0 * n * V, st);
+      SBK_LAUNCH(beam_topk_kernel, dim3(B), dim3(256), 0, st, (const float*)bb.comb, (const float*)bb.s.seq_scores,
                bb.s.cand_val, bb.s.cand_idx, V, beam, norm);
+    }
     SBK_TRY(sbk::launch_status("beam_topk"));
-    SBK_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 0, st, bb.s, (const float*)bb.am, cur, step, V, beam, Lmax,
-               cfg->eos, cfg->length_normalization);
+    {
+      sbk::ProfScope prof("beam_update", 0.0, 24.0 * n * (step + 1), st);
+      SBK_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 0, st, bb.s, (const float*)bb.am, cur, step, V, beam, Lmax,
+                 cfg->eos, cfg->length_normalization);
+    }
     SBK_TRY(sbk::launch_status("beam_update"));
     if (ctc)
       SBK_TRY(sbk::ctc_advance(bb.ctc_x, bb.phi[cur], bb.psi, bb.s.parent, bb.s.tokens[cur ^ 1], bb.s.tokens[cur],
@@ -556,15 +575,18 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
     cur ^= 1;
     steps = step + 1;
     if (host_flag && cfg->check_every > 0 && (steps % cfg->check_every == 0) && steps < cfg->max_steps) {
-      hipMemcpyAsync(host_flag, bb.s.n_full, sizeof(int32_t), hipMemcpyDeviceToHost, st);
-      hipStreamSynchronize(st);
+      SBK_HIP(hipMemcpyAsync(host_flag, bb.s.n_full, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SBK_HIP(hipStreamSynchronize(st));
       if (*host_flag >= B) break;
     }
   }
   if (steps_run) *steps_run = steps;
   SBK_LAUNCH(beam_finalize_kernel, dim3(B), dim3(256), 0, st, bb.s, cur, steps, beam, Lmax, out_tokens, out_len,
              out_score, out_logp);
-  return sbk::launch_status("beam_finalize");
+  SBK_TRY(sbk::launch_status("beam_finalize"));
+  if (out_max_len)
+    SBK_HIP(hipMemcpyAsync(out_max_len, bb.s.n_full + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return 0;
 }
 
 // Teacher-forced run of the KV-cached decoder over a given prefix: the TransformerASR.decode
@@ -646,8 +668,8 @@ extern "C" int sbk_greedy_search_f32(const sbk_decoder_weights* W, const float* 
   SBK_TRY(project_memory(W, d, enc, B, T, st));
   SBK_LAUNCH(greedy_init_kernel, dim3(sbk::cdiv(B, 256)), dim3(256), 0, st, tok, ended, n_ended, kv_slot, B, L, bos);
   SBK_TRY(sbk::launch_status("greedy_init"));
-  hipMemsetAsync(out_tokens, 0, (size_t)B * L * sizeof(int32_t), st);
-  hipMemsetAsync(out_scores, 0, (size_t)B * L * sizeof(float), st);
+  SBK_HIP(hipMemsetAsync(out_tokens, 0, (size_t)B * L * sizeof(int32_t), st));
+  SBK_HIP(hipMemsetAsync(out_scores, 0, (size_t)B * L * sizeof(float), st));
   int k = 0;
   for (int step = min_steps; step < max_steps; ++step, ++k) {  // positions count from 0 (seq2seq.py:227)
     SBK_TRY(decoder_step(W, d, tok, kv_slot, enc_len, k, B, B, T, 1, L, true, st));
@@ -655,8 +677,8 @@ extern "C" int sbk_greedy_search_f32(const sbk_decoder_weights* W, const float* 
                out_scores, n_ended, W->vocab, k, L, eos);
     SBK_TRY(sbk::launch_status("greedy_pick"));
     if (host_flag && check_every > 0 && ((k + 1) % check_every == 0)) {
-      hipMemcpyAsync(host_flag, n_ended, sizeof(int32_t), hipMemcpyDeviceToHost, st);
-      hipStreamSynchronize(st);
+      SBK_HIP(hipMemcpyAsync(host_flag, n_ended, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SBK_HIP(hipStreamSynchronize(st));
       if (*host_flag >= B) {
         ++k;
         break;

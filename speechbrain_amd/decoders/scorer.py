@@ -1,0 +1,44 @@
+"""speechbrain.decoders.scorer mirror for the ASR recipe: ScorerBuilder + CTCScorer.
+
+The reference scorer objects carry Python-side state and are called once per decoding step
+(scorer.py:1221-1315, :108-255).  Here they are configuration holders: the CTC prefix scoring
+itself is fused into the device-side search (csrc/ctc_prefix.hip), driven by
+``S2STransformerBeamSearcher``.
+"""
+
+
+class BaseScorerInterface:
+    pass
+
+
+class CTCScorer(BaseScorerInterface):
+    """scorer.py:108-255: ctc_fc = the CTC output Linear; blank_index / eos_index as in the recipe."""
+
+    def __init__(self, ctc_fc, blank_index, eos_index, ctc_window_size=0):
+        if ctc_window_size != 0:
+            raise NotImplementedError("attention-windowed CTC scoring (ctc_window_size > 0) is not implemented")
+        self.ctc_fc, self.blank_index, self.eos_index = ctc_fc, blank_index, eos_index
+        self.ctc_window_size = ctc_window_size
+
+
+_KNOWN = ("ctc", "rnnlm", "transformerlm", "kenlm", "coverage", "length", "huggingfacelm", "basescorerinterface")
+
+
+class ScorerBuilder:
+    """scorer.py:1075-1315.  Supported composition this round: full_scorers=[CTCScorer], as in the
+    recipe's ``valid_search`` (conformer_large.yaml:225-239)."""
+
+    def __init__(self, weights=dict(), full_scorers=list(), partial_scorers=list(), scorer_beam_scale=2):
+        assert len(weights) == len(full_scorers) + len(partial_scorers), "Weights and scorers are not matched."
+        self.scorer_beam_scale = scorer_beam_scale
+        name = lambda impl: impl.__class__.__name__.lower().split("scorer")[0]  # noqa: E731
+        self.weights = {**dict.fromkeys(_KNOWN, 0.0), **weights}
+        self.full_scorers = {name(s): s for s in full_scorers}
+        self.partial_scorers = {name(s): s for s in partial_scorers}
+        unsupported = [k for k in list(self.full_scorers) + list(self.partial_scorers) if k != "ctc"]
+        if unsupported or self.partial_scorers:
+            raise NotImplementedError(
+                f"scorers {unsupported or list(self.partial_scorers)}: this round fuses one full CTC scorer; "
+                "TransformerLM / partial scorers are the next scope row")
+        if not 0.0 <= self.weights["ctc"] <= 1.0:
+            raise ValueError("ctc_weight should not > 1.0 and < 0.0")

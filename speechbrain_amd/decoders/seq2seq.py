@@ -1,0 +1,134 @@
+"""speechbrain.decoders.seq2seq mirror: S2STransformerBeamSearcher / S2STransformerGreedySearcher.
+
+Constructor signatures, ``forward(enc_states, wav_len)`` and return tuples follow the reference
+(decoders/seq2seq.py:711-1934).  One forward = one C-ABI call that runs the whole search on the
+device (csrc/search.hip): KV-cached decoder steps, fused CTC prefix scoring, device-side beam
+bookkeeping; the only device->host traffic is the stop-rule poll and the final token ids.
+"""
+import torch
+
+from speechbrain_amd import native
+
+
+class S2SBaseSearcher(torch.nn.Module):
+    def __init__(self, bos_index, eos_index, min_decode_ratio, max_decode_ratio):
+        super().__init__()
+        self.bos_index, self.eos_index = bos_index, eos_index
+        self.min_decode_ratio, self.max_decode_ratio = min_decode_ratio, max_decode_ratio
+
+    def _handle(self):
+        h = getattr(self, "_dec_handle", None)
+        probe = self.model.decoder.norm.norm.weight
+        if h is None or h.device != probe.device or h.keep[0].data_ptr() != self.model.decoder.layers[0].norm1.norm.weight.data_ptr():
+            h = native.DecoderHandle(self.model, self.fc)
+            self._dec_handle = h
+        return h
+
+    def _steps(self, T):
+        # seq2seq.py:1336-1338 / :218-219
+        return int(T * self.min_decode_ratio), int(T * self.max_decode_ratio)
+
+
+class S2STransformerGreedySearcher(S2SBaseSearcher):
+    """seq2seq.py:330-367 on top of S2SGreedySearcher.forward (:176-327), temperature 0 (arg-max).
+
+    Returns (hyps, top_lengths [B,1], top_scores [B,1,L], None): the reference's fourth output, the
+    full [B,1,L,V] log-probability tensor, is not materialised on the device path."""
+
+    def __init__(self, modules, temperature=0.0, **kwargs):
+        super().__init__(**kwargs)
+        if temperature != 0.0:
+            raise NotImplementedError("sampling (temperature > 0) is not on the ASR inference path")
+        self.model, self.fc, self.temperature = modules[0], modules[1], temperature
+        self.check_every = 8
+
+    @torch.no_grad()
+    def forward(self, enc_states, wav_len, attention_mask=None):
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is a Whisper/LLM decoder feature")
+        B, T, _ = enc_states.shape
+        enc_lens = torch.round(T * wav_len).int().to(enc_states.device)
+        mn, mx = self._steps(T)
+        tok, sc, steps = native.greedy_search(self._handle(), enc_states.contiguous(), enc_lens, mn, mx, self.bos_index,
+                                              self.eos_index, self.check_every)
+        tok, sc = tok[:, :steps].cpu(), sc[:, :steps].cpu()
+        # the reference stops at the first step after which every utterance has ended (:277-278)
+        is_eos = tok == self.eos_index
+        first = torch.where(is_eos.any(1), is_eos.float().argmax(1), torch.full((B,), steps))
+        L = steps if (first == steps).any() else int(first.max()) + 1
+        L = max(L, 1) if steps > 0 else 0
+        tok, sc = tok[:, :L], sc[:, :L]
+        hyps, rel = [], []
+        for b in range(B):
+            n = min(int(first[b]), L)
+            rel.append(n / L if L else 0.0)
+            hyps.append(tok[b, :n].tolist())
+        return hyps, torch.tensor(rel).unsqueeze(1), sc.unsqueeze(1), None
+
+
+class S2STransformerBeamSearcher(S2SBaseSearcher):
+    """seq2seq.py:1853-1934 + S2SBeamSearcher (:711-1749).
+
+    forward(enc_states [B,T',d], wav_len [B]) -> (hyps list[list[int]], best_lens [B], best_scores [B],
+    best_log_probs [B,Lmax])."""
+
+    def __init__(self, modules, temperature=1.0, bos_index=None, eos_index=None, min_decode_ratio=0.0,
+                 max_decode_ratio=1.0, beam_size=None, scorer=None, return_topk=False, topk=1,
+                 using_eos_threshold=True, eos_threshold=1.5, length_normalization=True, using_max_attn_shift=False,
+                 max_attn_shift=60, minus_inf=-1e20):
+        super().__init__(bos_index, eos_index, min_decode_ratio, max_decode_ratio)
+        if return_topk or topk != 1:
+            raise NotImplementedError("return_topk / topk > 1 is not implemented on the device search yet")
+        if using_max_attn_shift:
+            raise NotImplementedError("max_attn_shift applies to RNN attention decoders")
+        self.model, self.fc, self.temperature = modules[0], modules[1], temperature
+        self.beam_size, self.scorer = beam_size, scorer
+        self.return_topk, self.topk = return_topk, topk
+        self.length_normalization = length_normalization
+        self.using_eos_threshold, self.eos_threshold = using_eos_threshold, eos_threshold
+        self.minus_inf = minus_inf
+        self.attn_weight, self.ctc_weight = 1.0, 0.0
+        self.check_every = 8
+        self.blank_index = 0
+        self.ctc_fc = None
+        if scorer is not None:
+            if length_normalization and scorer.weights["length"] > 0.0:
+                raise ValueError("Length normalization is not compatible with length rewarding.")
+            if scorer.weights["ctc"] > 0.0:
+                ctc = {**scorer.full_scorers, **scorer.partial_scorers}["ctc"]
+                if len({bos_index, eos_index, ctc.blank_index}) < 3:
+                    raise ValueError(
+                        "Set blank, eos and bos to different indexes for joint ATT/CTC or CTC decoding")
+                self.ctc_weight = scorer.weights["ctc"]
+                self.attn_weight = 1.0 - self.ctc_weight
+                self.blank_index, self.ctc_fc = ctc.blank_index, ctc.ctc_fc
+        if self.attn_weight <= 0:
+            raise NotImplementedError("pure-CTC beam search (ctc_weight = 1) is not implemented")
+
+    def config(self, T):
+        mn, mx = self._steps(T)
+        return native.SearchConfig(bos=self.bos_index, eos=self.eos_index, blank=self.blank_index, beam=self.beam_size,
+                                   min_steps=mn, max_steps=mx, length_normalization=int(self.length_normalization),
+                                   using_eos_threshold=int(self.using_eos_threshold), check_every=self.check_every,
+                                   ctc_weight=self.ctc_weight, temperature=self.temperature,
+                                   eos_threshold=self.eos_threshold, minus_inf=self.minus_inf)
+
+    @torch.no_grad()
+    def search_device(self, enc_states, wav_len):
+        """Device-resident results: (tokens [B,L] int32, lens [B] int32, scores [B], log_probs [B,L], max_len [1])."""
+        B, T, _ = enc_states.shape
+        enc_lens = torch.round(T * wav_len.to(enc_states.device)).int()
+        cw = cb = None
+        if self.ctc_weight > 0:
+            cw, cb = self.ctc_fc.w.weight, self.ctc_fc.w.bias
+        tok, ln, sc, lp, mxl, steps = native.beam_search(self._handle(), self.config(T), enc_states.contiguous(),
+                                                         enc_lens, cw, cb)
+        return tok, ln, sc, lp, mxl
+
+    @torch.no_grad()
+    def forward(self, enc_states, wav_len):
+        tok, ln, sc, lp, mxl = self.search_device(enc_states, wav_len)
+        tok_h, ln_h, max_len = tok.cpu(), ln.cpu(), max(int(mxl.cpu()), 1)
+        hyps = [tok_h[b, : int(ln_h[b])].tolist() for b in range(tok_h.shape[0])]
+        best_lens = ln_h.float() / max_len  # SpeechBrain relative length (seq2seq.py:1461)
+        return hyps, best_lens.to(enc_states.device), sc, lp[:, :max_len]

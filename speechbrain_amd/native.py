@@ -52,6 +52,9 @@ def _declare(lib):
     sig = {
         "sbk_abi_version": ([], c_int),
         "sbk_last_error": ([], c_char_p),
+        "sbk_prof_enable": ([i], None),
+        "sbk_prof_reset": ([], None),
+        "sbk_prof_report": ([ctypes.c_char_p, ctypes.c_size_t], ctypes.c_size_t),
         "sbk_fbank_f32": ([p, p, p, POINTER(c_int32), i, p, p, p, p, p, i, i, i, i, i, i, f, f, p, p, f, p], c_int),
         "sbk_input_norm_global_f32": ([p, p, p, p, i, i, f, p], c_int),
         "sbk_gemm_nt_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
@@ -62,7 +65,7 @@ def _declare(lib):
         "sbk_log_softmax_f32": ([p, p, i, i, f, f, p], c_int),
         "sbk_beam_search_workspace_bytes": ([POINTER(DecoderWeights), POINTER(SearchConfig), i, i], ctypes.c_size_t),
         "sbk_beam_search_f32": ([POINTER(DecoderWeights), POINTER(SearchConfig), p, p, p, p, p, ctypes.c_size_t, p, p,
-                                 p, p, p, POINTER(c_int32), i, i, p], c_int),
+                                 p, p, p, p, POINTER(c_int32), i, i, p], c_int),
         "sbk_greedy_search_workspace_bytes": ([POINTER(DecoderWeights), i, i, i], ctypes.c_size_t),
         "sbk_greedy_search_f32": ([POINTER(DecoderWeights), p, p, p, ctypes.c_size_t, p, p, p, POINTER(c_int32), i, i,
                                    i, i, i, i, i, p], c_int),
@@ -313,7 +316,8 @@ def _host_flag(device):
 
 
 def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=None, ctc_b=None):
-    """Returns (tokens [B,max_steps] int32, lens [B] int32, scores [B], log_probs [B,max_steps], steps_run)."""
+    """Returns (tokens [B,max_steps] int32, lens [B] int32, scores [B], log_probs [B,max_steps],
+    max_len [1] int32 (longest finished hypothesis), steps_run)."""
     lib = load()
     _dev_ok(enc, enc_len, ctc_w, ctc_b)
     _f32(enc)
@@ -327,13 +331,15 @@ def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=No
     out_len = torch.zeros(B, dtype=torch.int32, device=dev)
     out_score = torch.zeros(B, dtype=torch.float32, device=dev)
     out_lp = torch.zeros(B, L, dtype=torch.float32, device=dev)
+    out_max = torch.zeros(1, dtype=torch.int32, device=dev)
     flag = _host_flag(dev)
     steps = c_int32(0)
     _chk(lib.sbk_beam_search_f32(ctypes.byref(handle.W), ctypes.byref(cfg), _p(enc), _p(enc_len), _p(ctc_w), _p(ctc_b),
                                  c_void_p(ws.data_ptr() + off), nbytes, _p(out_tok), _p(out_len), _p(out_score),
-                                 _p(out_lp), c_void_p(flag.data_ptr()), ctypes.byref(steps), B, T, _stream(enc)),
+                                 _p(out_lp), _p(out_max), c_void_p(flag.data_ptr()), ctypes.byref(steps), B, T,
+                                 _stream(enc)),
          "sbk_beam_search_f32")
-    return out_tok, out_len, out_score, out_lp, steps.value
+    return out_tok, out_len, out_score, out_lp, out_max, steps.value
 
 
 def greedy_search(handle: DecoderHandle, enc, enc_len, min_steps, max_steps, bos, eos, check_every=8):
@@ -381,4 +387,25 @@ def log_softmax(x, temperature=1.0, weight=1.0):
     out = torch.empty_like(x)
     _chk(lib.sbk_log_softmax_f32(_p(x2), _p(out), x2.shape[0], V, float(temperature), float(weight), _stream(x2)),
          "sbk_log_softmax_f32")
+    return out
+
+
+# ------------------------------------------------------------------ HIP-event profiler
+def prof_enable(on: bool):
+    load().sbk_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    load().sbk_prof_reset()
+
+
+def prof_report():
+    """{kernel: dict(count, ms, flops, bytes)} for everything launched since prof_reset()."""
+    lib = load()
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.sbk_prof_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, count, ms, flops, nbytes = line.split()
+        out[name] = dict(count=int(count), ms=float(ms), flops=float(flops), bytes=float(nbytes))
     return out

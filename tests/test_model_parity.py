@@ -1,0 +1,99 @@
+"""Model-level parity through the drop-in module surface (speechbrain_amd.*), against the REFERENCE's
+outputs stored in tests/golden/model_*.npz.  Runs on the CPU emulator of the kernels (not gpu) and on
+the MI355X (``-m gpu``).  Token ids must be bit-exact; floats within the stated fp32 tolerances."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sb_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def build(tag, dev):
+    from speechbrain_amd.inference.builders import build_modules
+
+    g = np.load(os.path.join(GOLD, f"model_{tag}.npz"))
+    d_model, nhead, d_ffn, n_enc, n_dec, vocab, beam, eos_thr = [int(v) for v in g["cfg"]]
+    m = build_modules(dict(d_model=d_model, nhead=nhead, d_ffn=d_ffn, n_enc=n_enc, n_dec=n_dec, n_fft=512,
+                           win_length=32), vocab=vocab)
+    mods = torch.nn.ModuleDict({k: m[k] for k in ("CNN", "Transformer", "seq_lin", "ctc_lin")})
+    mods.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}, strict=True)
+    return g, mods.to(dev).eval()
+
+
+def hyps_of(arr):
+    return [[int(v) for v in row if v >= 0] for row in arr]
+
+
+@pytest.mark.parametrize("tag", ["tiny_ctc", "tiny_noctc", "dh36"])
+def test_golden_model(backend, tag):
+    nat, dev = backend
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, S2STransformerGreedySearcher, ScorerBuilder
+
+    g, mods = build(tag, dev)
+    beam, eos_thr = int(g["cfg"][6]), bool(g["cfg"][7])
+    ctc_w, max_ratio, min_ratio = [float(v) for v in g["cfgf"]]
+    feats, wl = torch.from_numpy(g["feats"]).to(dev), torch.from_numpy(g["wav_lens"]).to(dev)
+    with torch.no_grad():
+        cnn = mods["CNN"](feats)
+        assert float((cnn.cpu() - torch.from_numpy(g["cnn_out"])).abs().max()) <= 2e-5
+        enc = mods["Transformer"].encode(cnn, wl)
+        assert float((enc.cpu() - torch.from_numpy(g["enc_out"])).abs().max()) <= 5e-5
+        enc_ref = torch.from_numpy(g["enc_out"]).to(dev)  # searches start from the reference's encoder output
+        T = enc_ref.shape[1]
+        h = nat.DecoderHandle(mods["Transformer"], mods["seq_lin"])
+        pred = nat.decoder_prefix(h, torch.from_numpy(g["dec_tgt"]).int().to(dev), enc_ref, torch.round(T * wl).int())
+        assert float((pred.cpu() - torch.from_numpy(g["dec_out"])).abs().max()) <= 5e-5
+
+        gs = S2STransformerGreedySearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                          min_decode_ratio=min_ratio, max_decode_ratio=max_ratio)
+        hyps, _, scores, _ = gs(enc_ref, wl)
+        assert hyps == hyps_of(g["greedy_hyps"])
+        assert float((scores[:, 0].cpu() - torch.from_numpy(g["greedy_scores"])[:, : scores.shape[2]]).abs().max()) <= 1e-4
+
+        scorer = None
+        if ctc_w > 0:
+            scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)],
+                                   weights={"ctc": ctc_w})
+        bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                        min_decode_ratio=min_ratio, max_decode_ratio=max_ratio, beam_size=beam,
+                                        using_eos_threshold=eos_thr, length_normalization=True, scorer=scorer)
+        hyps, lens, scores, _ = bs(enc_ref, wl)
+        assert hyps == hyps_of(g["beam_hyps"])
+        assert float((scores.cpu() - torch.from_numpy(g["beam_scores"])).abs().max()) <= 1e-4
+        assert float((lens.cpu() - torch.from_numpy(g["beam_lens"])).abs().max()) <= 1e-6
+
+        bs1 = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                         min_decode_ratio=min_ratio, max_decode_ratio=max_ratio, beam_size=1,
+                                         using_eos_threshold=False, length_normalization=True)
+        hyps1, _, s1, _ = bs1(enc_ref, wl)
+        assert hyps1 == hyps_of(g["beam1_hyps"])
+        assert float((s1.cpu() - torch.from_numpy(g["beam1_scores"])).abs().max()) <= 1e-4
+
+
+def test_waveform_to_tokens_vs_oracle(backend):
+    """EncoderDecoderASR.transcribe_batch on padded waveforms vs the oracle's whole path."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_asr, oracle_state_dict
+
+    tiny = dict(d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=2, n_fft=512, win_length=32)
+    asr = build_asr(tiny, vocab=40, seed=3, beam_size=4, ctc_weight=0.4, device=str(dev))
+    with torch.no_grad():
+        asr.mods.seq_lin.w.weight.mul_(6.0)
+        asr.mods.ctc_lin.w.weight.mul_(6.0)
+    wav = 0.1 * torch.randn(3, 9600, generator=torch.Generator().manual_seed(1234))
+    lens = torch.tensor([1.0, 0.8, 0.6])
+    for i, l in enumerate(lens):
+        wav[i, int(l * 9600):] = 0
+    words, toks = asr.transcribe_batch(wav, lens)
+    sd = oracle_state_dict(asr)
+    fc = O.FbankCfg(n_fft=512, n_mels=80, win_length_ms=32)
+    mc = O.ModelCfg(d_model=32, nhead=4, num_encoder_layers=2, num_decoder_layers=2, d_ffn=64, vocab=40)
+    enc = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
+    assert float((asr.encode_batch(wav, lens).cpu() - enc).abs().max()) <= 5e-5
+    hyps, _, _, _ = O.beam_search(enc, lens, sd, mc, O.SearchCfg(beam=4, ctc_weight=0.4))
+    assert toks == hyps
+    assert words == [" ".join(str(t) for t in h) for h in hyps]

@@ -41,6 +41,11 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 enum { hipMemcpyDeviceToDevice = 3, hipMemcpyDeviceToHost = 2, hipMemcpyHostToDevice = 1 };
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+typedef void* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (void*)1; return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return 0; }
 
 #define __global__
 #define __device__
@@ -72,8 +77,14 @@ using std::max;
 using std::min;
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
-static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
-static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline int atomicMax(int* p, int v) {
+  int o = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (o < v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+  }
+  return o;
+}
+static inline int atomicMaxUnused_(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 
 namespace sbk {
 constexpr int kWave = 64;
