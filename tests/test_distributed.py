@@ -1,0 +1,83 @@
+"""Utterance sharding across ranks (speechbrain_amd/inference/sharded.py) with the gloo backend,
+world_size 2, on CPU -- the same pattern the reference uses (tests/unittests/test_distributed.py:10-23).
+The per-rank worker is a deterministic stand-in: this test covers partitioning, the scatter of padded
+waveforms and the gather of token ids, not the kernels."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from speechbrain_amd.inference.sharded import ShardedTranscriber, assign_batches, batch_cost, plan_batches
+
+
+def fake_transcribe(wavs, lens):
+    """tokens = [number of valid samples // 1000, first sample * 1e3 rounded] -- depends on content and length."""
+    out = []
+    for w, l in zip(wavs, lens):
+        n = int(round(float(l) * w.numel()))
+        out.append([n // 1000, int(round(float(w[0]) * 1000)) % 997, n % 7])
+    return out
+
+
+def make_job(n=23, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(2000, 9000, (n,), generator=g).tolist()
+    return [torch.rand(m, generator=g) for m in lens]
+
+
+def expected(wavs):
+    return [[w.numel() // 1000, int(round(float(w[0]) * 1000)) % 997, w.numel() % 7] for w in wavs]
+
+
+def _worker(rank, world, tmpdir, q):
+    os.environ["RANK"], os.environ["LOCAL_RANK"], os.environ["WORLD_SIZE"] = str(rank), str(rank), str(world)
+    dist.init_process_group("gloo", init_method=f"file://{tmpdir}/sync", rank=rank, world_size=world)
+    try:
+        wavs = make_job() if rank == 0 else None
+        st = ShardedTranscriber(fake_transcribe, "cpu", max_utts=4)
+        local = st.scatter(wavs)
+        n_local = sum(len(ids) for ids, _, _ in local)
+        hyps = st.gather(st.run_local(local))
+        if rank == 0:
+            q.put(("hyps", hyps))
+        q.put(("count", rank, n_local))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_scatter_gather_world2(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    hyps = [g[1] for g in got if g[0] == "hyps"][0]
+    counts = {g[1]: g[2] for g in got if g[0] == "count"}
+    assert hyps == expected(make_job())          # every utterance, in input order, on rank 0
+    assert sum(counts.values()) == 23 and min(counts.values()) >= 6  # both ranks did real work
+
+
+def test_single_process_path():
+    st = ShardedTranscriber(fake_transcribe, "cpu", max_utts=5)
+    wavs = make_job(11, seed=9)
+    assert st.transcribe(wavs) == expected(wavs)
+
+
+def test_planning_properties():
+    n = [int(v) for v in torch.randint(80000, 480000, (200,), generator=torch.Generator().manual_seed(1))]
+    batches = plan_batches(n, max_utts=32, max_padded_samples=32 * 480000)
+    assert sorted(i for b in batches for i in b) == list(range(200))       # a partition
+    assert all(len(b) <= 32 for b in batches)
+    for b in batches:                                                         # duration-sorted buckets: little padding
+        assert max(n[i] for i in b) - min(n[i] for i in b) <= 0.35 * max(n)
+    costs = [batch_cost(n, b) for b in batches]
+    owner = assign_batches(costs, 8)
+    assert sorted(i for o in owner for i in o) == list(range(len(batches)))
+    loads = [sum(costs[i] for i in o) for o in owner]
+    assert max(loads) <= min(loads) + max(costs)                              # LPT balance bound
+    assert plan_batches([], 4) == [] and assign_batches([], 3) == [[], [], []]
