@@ -82,6 +82,13 @@ int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const floa
                     int ldr, float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
                     int rows_per_seq, sbk_stream_t stream);
 
+/* Same contraction for few-row operands (M <= 512: the beams x utterances rows of a decoder step):
+ * waves own 32-column tiles and K slices, partial sums go through `workspace` (floats; the more,
+ * the more K slices, at most 8*M*N is useful) and are combined in a fixed order. */
+int sbk_gemm_nt_splitk_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
+                           const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
+                           float alpha, float* workspace, size_t workspace_floats, sbk_stream_t stream);
+
 /* ---- LayerNorm over the last dimension (nnet/normalization.py:185-242,
  * torch.nn.LayerNorm at Conformer.py:126,152,426,437): y = act(LN(x)), x [rows,d]. */
 int sbk_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int rows, int d, float eps,

@@ -1,79 +1,115 @@
 // CTC prefix scorer (Watanabe et al. 2017, Alg. 2), full-vocabulary mode.
 // Replaces decoders/ctc.py:26-295 (CTCPrefixScore) as driven by scorer.py:108-255.
 //
-// The reference materialises r[T,2,n_bh,V] every step (10 MB per hypothesis) and walks
-// the frames in a Python loop.  Here the state kept per hypothesis is only its own
-// forward variables r[T][2] (plus phi inputs derived from them); one step is
-//   ctc_score_step : thread <-> vocabulary entry c of one utterance, ALL beams of
-//                    the utterance in registers, frames walked sequentially, so the
-//                    emission row x[b,t,:] is read ONCE per step and utterance
-//                    (coalesced along V) -- algorithmic traffic T*V*4 B per utterance
-//                    per step; everything else is transcendental math (about 5
-//                    exp/log per (hypothesis, token, frame)): VALU-bound, not HBM.
-//   ctc_advance    : after the beam top-k picked (parent, token) for each new
-//                    hypothesis, re-run the same recurrence for that single pair to
-//                    obtain the new r[T][2] (the reference gathers it out of the
-//                    materialised tensor, ctc.py:243-295).
-// Numerics follow the reference: finite -1e20 "minus infinity" (ctc.py:53), two-term
-// logsumexp as max + log(exp(a-max)+exp(b-max)).
+// The reference materialises r[T,2,n_bh,V] every step (10 MB per hypothesis), walks the
+// frames in a Python loop and evaluates every recurrence in the log domain (5 exp/log per
+// (hypothesis, token, frame)).  Here
+//  * the state kept per hypothesis is only its own forward variables per frame, stored as
+//    block-floating-point pairs  exp(gamma[t]) = mg * 2^eg  (gamma = log-sum of the
+//    non-blank/blank variables) and  exp(beta[t]) = mb * 2^eb  (beta = blank variable);
+//  * emissions are kept as linear probabilities P[b,t,c] (frames past the utterance end:
+//    P = 0 except column 0 = 1, the linear image of ctc.py:57-61);
+//  * ctc_score_step: thread <-> token c of one utterance, ALL beams of the utterance in
+//    registers, frames walked sequentially; the recurrences
+//        Rnb[t] = (Rnb[t-1] + phi[t-1]) * P_c[t],   Rb[t] = (Rnb[t-1] + Rb[t-1]) * P_blank[t],
+//        Psi   += phi[t-1] * P_c[t]
+//    run on mantissas with a per-thread integer exponent that is re-based with ldexp/frexp
+//    every frame (a scaled forward algorithm with power-of-two scales: exact scaling, no
+//    transcendental in the loop).  The emission row P[b,t,:] is read ONCE per step and
+//    utterance (coalesced along V): algorithmic traffic T*V*4 B per utterance per step.
+//  * ctc_advance: after the beam top-k picked (parent, token) for each new hypothesis, the
+//    same recurrence for that single pair yields the new per-frame state (the reference
+//    gathers it out of the materialised tensor, ctc.py:243-295).
+// Values the reference represents with its finite -1e20 sentinel (ctc.py:53) are exact
+// zeros here and map back to -1e20 whenever a log-domain number leaves the kernels.
 #include "common.h"
 #include "internal.h"
 
 namespace {
 
 constexpr float kNeg = -1e20f;
-constexpr int kBT = 16;  // beams held in registers per thread
+constexpr int kNegE = -(1 << 20);  // exponent of an exact zero
+constexpr int kBT = 16;            // beams held in registers per thread
+constexpr int kHead = 24;          // head-room (bits) kept above the incoming phi term
 
-__device__ __forceinline__ float lse2(float a, float b) {
-  const float m = fmaxf(a, b);
-  return m + logf(expf(a - m) + expf(b - m));
+struct BF {  // exp(gamma) = mg * 2^eg, exp(beta) = mb * 2^eb   (16 bytes per (hypothesis, frame))
+  float mg, mb;
+  int eg, eb;
+};
+
+__device__ __forceinline__ int fexp(float x) { return x > 0.0f ? ilogbf(x) + 1 : 0; }  // x = f * 2^k, f in [0.5,1)
+
+// natural log of m * 2^e (m >= 0) in f64, rounded once
+__device__ __forceinline__ float bf_log(float m, int e) {
+  if (!(m > 0.0f)) return kNeg;
+  const double v = ((double)e + (double)log2f(m)) * 0.69314718055994530942;
+  return v < (double)kNeg ? kNeg : (float)v;
+}
+// block-float image of exp(x), x a natural-log value (<= ~0)
+__device__ __forceinline__ void bf_exp(float x, float* m, int* e) {
+  if (!(x > -1e19f)) {
+    *m = 0.0f;
+    *e = kNegE;
+    return;
+  }
+  const double y = (double)x * 1.44269504088896340736;
+  const double ip = floor(y);
+  *m = exp2f((float)(y - ip));
+  *e = (int)ip;
 }
 
-// x[b,t,c]: frames >= enc_len are -1e20 except column 0 which is 0 (ctc.py:57-61; the
-// reference hard-codes column 0, which is the blank in every recipe).
-__global__ void __launch_bounds__(256) ctc_mask_kernel(float* __restrict__ x, const int32_t* __restrict__ enc_len,
-                                                       int T, int V) {
+// ---- emissions: log_softmax rows -> linear probabilities with the reference's frame mask
+__global__ void __launch_bounds__(256) ctc_emissions_kernel(float* __restrict__ x, float* __restrict__ xb_log,
+                                                            const int32_t* __restrict__ enc_len, int T, int V, int blank) {
   const int b = blockIdx.y, t = blockIdx.x;
-  if (t < enc_len[b]) return;
   float* row = x + ((size_t)b * T + t) * V;
-  for (int c = threadIdx.x; c < V; c += 256) row[c] = c == 0 ? 0.0f : kNeg;
+  const bool pad = t >= enc_len[b];
+  if (threadIdx.x == 0) xb_log[b * T + t] = pad ? (blank == 0 ? 0.0f : kNeg) : row[blank];
+  __syncthreads();
+  for (int c = threadIdx.x; c < V; c += 256) row[c] = pad ? (c == 0 ? 1.0f : 0.0f) : expf(row[c]);
 }
 
-// Initial state (ctc.py:103-116): r[t][nb] = -1e20, r[t][b] = cumsum_t x[b,t,blank], for every beam.
-// phi[n][t] = (logsumexp(r[t]), r[t][b]).
-__global__ void ctc_init_kernel(const float* __restrict__ x, float* __restrict__ phi, float* __restrict__ psi_prev,
-                                int B, int T, int V, int beam, int blank) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  float cum = 0.0f;
-  for (int t = 0; t < T; ++t) {
-    cum += x[((size_t)b * T + t) * V + blank];
-    const float rs = lse2(kNeg, cum);
-    for (int j = 0; j < beam; ++j) {
-      const size_t o = (((size_t)b * beam + j) * T + t) * 2;
-      phi[o] = rs;
-      phi[o + 1] = cum;
+// ---- initial state (ctc.py:103-116): r[t][nb] = -1e20, r[t][b] = cumsum_t x[b,t,blank], for every beam.
+// One workgroup per utterance: the cumulative sum is serial (same order as torch.cumsum), the
+// block-float conversion and the per-beam replication are parallel over frames.
+__global__ void __launch_bounds__(256) ctc_init_kernel(const float* __restrict__ xb_log, BF* __restrict__ st,
+                                                       float* __restrict__ psi_prev, int T, int beam) {
+  SBK_DYN_LDS(float, cum);
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    float c = 0.0f;
+    for (int t = 0; t < T; ++t) {
+      c += xb_log[b * T + t];
+      cum[t] = c;
     }
   }
-  for (int j = 0; j < beam; ++j) psi_prev[b * beam + j] = 0.0f;
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += 256) {
+    BF v;
+    bf_exp(cum[t], &v.mg, &v.eg);
+    v.mb = v.mg;
+    v.eb = v.eg;
+    for (int j = 0; j < beam; ++j) st[((size_t)b * beam + j) * T + t] = v;
+  }
+  if (threadIdx.x < beam) psi_prev[b * beam + threadIdx.x] = 0.0f;
 }
 
 struct CtcStepArgs {
-  const float* x;         // [B,T,V] masked log-posteriors
-  const float* phi;       // [n_bh,T,2] (r_sum, r_blank) of each hypothesis' prefix
-  const float* psi_prev;  // [n_bh]
+  const float* P;           // [B,T,V] masked linear posteriors
+  const BF* st;             // [n_bh,T] state of each hypothesis' prefix
+  const float* psi_prev;    // [n_bh]
   const int32_t* last_tok;  // [n_bh]
   const int32_t* enc_len;   // [B]
-  const float* am;        // [n_bh,V] acoustic-model log-probs (already * attn_weight), or null
-  float* comb;            // [n_bh,V] out: am' + w * (psi - psi_prev)
-  float* psi;             // [n_bh,V] out
+  const float* am;          // [n_bh,V] acoustic-model log-probs (already * attn_weight)
+  float* comb;              // [n_bh,V] out: am' + w * (psi - psi_prev)
+  float* psi;               // [n_bh,V] out
   int B, T, V, beam, prefix_len, blank, eos;
   float weight;
   // modifications of the AM scores applied before the scorer (seq2seq.py:995-1017, scorer.py:1250)
-  int eos_floor;          // 1: step < min_decode_steps -> am[eos] = minus_inf
+  int eos_floor;            // 1: step < min_decode_steps -> am[eos] = minus_inf
   int use_eos_threshold;
   float eos_threshold, minus_inf;
-  const float* am_max;    // [n_bh] max over V of am (only when use_eos_threshold)
+  const float* am_max;      // [n_bh] max over V of am (only when use_eos_threshold)
 };
 
 __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a) {
@@ -83,40 +119,51 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a) {
   const int cc = c_ok ? c : a.V - 1;
   const int T = a.T, V = a.V;
   const int start = a.prefix_len > 1 ? a.prefix_len : 1;
-  const float* xb = a.x + (size_t)b * T * V;
+  const float* Pb = a.P + (size_t)b * T * V;
   const int last_frame = a.enc_len[b] - 1;
 
   for (int j0 = 0; j0 < a.beam; j0 += kBT) {
     const int nb = min(kBT, a.beam - j0);
-    float r_nb[kBT], r_b[kBT], pm[kBT], ps[kBT];
+    float mnb[kBT], mbl[kBT], mps[kBT];
+    int E[kBT], Eps[kBT];
     bool same[kBT];
+    const float p0 = Pb[cc];
 #pragma unroll
     for (int j = 0; j < kBT; ++j) {
-      r_nb[j] = (a.prefix_len == 0) ? xb[cc] : kNeg;  // r[start-1][nb]: x[0] at the first step, else untouched
-      r_b[j] = kNeg;
-      pm[j] = r_nb[j];  // running logsumexp of {psi_init, phix[start..]} as (max, sum)
-      ps[j] = 1.0f;
+      // r[start-1]: x[0] (non-blank) at the very first step, nothing otherwise (ctc.py:168-172)
+      const bool first = a.prefix_len == 0 && p0 > 0.0f;
+      mnb[j] = first ? p0 : 0.0f;
+      mbl[j] = 0.0f;
+      E[j] = first ? 0 : kNegE;
+      mps[j] = mnb[j];  // psi_init = r[start-1][nb]
+      Eps[j] = E[j];
       same[j] = j < nb && a.last_tok[b * a.beam + j0 + j] == cc;
     }
     for (int t = start; t < T; ++t) {
-      const float x_nb = xb[(size_t)t * V + cc];
-      const float x_b = xb[(size_t)t * V + a.blank];
+      const float p_nb = Pb[(size_t)t * V + cc];
+      const float p_b = Pb[(size_t)t * V + a.blank];
 #pragma unroll
       for (int j = 0; j < kBT; ++j) {
         if (j < nb) {
-          const float* ph = a.phi + (((size_t)b * a.beam + j0 + j) * T + (t - 1)) * 2;
-          const float phi_prev = same[j] ? ph[1] : ph[0];
-          const float n_nb = lse2(r_nb[j], phi_prev) + x_nb;
-          const float n_b = lse2(r_nb[j], r_b[j]) + x_b;
-          r_nb[j] = n_nb;
-          r_b[j] = n_b;
-          const float v = phi_prev + x_nb;
-          if (v > pm[j]) {
-            ps[j] = ps[j] * expf(pm[j] - v) + 1.0f;
-            pm[j] = v;
-          } else {
-            ps[j] += expf(v - pm[j]);
-          }
+          const BF s = a.st[((size_t)b * a.beam + j0 + j) * T + (t - 1)];
+          const float mphi = same[j] ? s.mb : s.mg;
+          const int ephi = same[j] ? s.eb : s.eg;
+          // forward variables on the common exponent E2
+          const int E2 = max(E[j], ephi - kHead);
+          const float x_nb = ldexpf(mnb[j], E[j] - E2);
+          const float x_b = ldexpf(mbl[j], E[j] - E2);
+          const float ph = ldexpf(mphi, ephi - E2);
+          const float n_nb = (x_nb + ph) * p_nb;
+          const float n_b = (x_nb + x_b) * p_b;
+          const float sum = n_nb + n_b;
+          const int k = fexp(sum);
+          mnb[j] = ldexpf(n_nb, -k);
+          mbl[j] = ldexpf(n_b, -k);
+          E[j] = sum > 0.0f ? E2 + k : kNegE;
+          // psi += phi[t-1] * P_c[t]
+          const int P2 = max(Eps[j], ephi - kHead);
+          mps[j] = ldexpf(mps[j], Eps[j] - P2) + ldexpf(mphi, ephi - P2) * p_nb;
+          Eps[j] = P2;
         }
       }
     }
@@ -125,55 +172,99 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a) {
     for (int j = 0; j < kBT; ++j) {
       if (j < nb) {
         const int n = b * a.beam + j0 + j;
-        float psi = pm[j] + logf(ps[j]);
-        if (c == a.eos) psi = a.phi[((size_t)n * T + last_frame) * 2];
+        float psi = bf_log(mps[j], Eps[j]);
+        if (c == a.eos) {  // psi[eos] = log-sum of the prefix' own variables at the last frame (ctc.py:232-235)
+          const BF s = a.st[(size_t)n * T + last_frame];
+          psi = bf_log(s.mg, s.eg);
+        }
         if (c == a.blank && a.eos != a.blank) psi = kNeg;
         a.psi[(size_t)n * V + c] = psi;
-        float am = 0.0f;
-        if (a.am) {
-          am = a.am[(size_t)n * V + c];
-          if (c == a.eos) {
-            if (a.eos_floor) am = a.minus_inf;
-            if (a.use_eos_threshold && !(am > a.eos_threshold * a.am_max[n])) am = a.minus_inf;
-          }
-          if (c == a.blank) am = kNeg;
+        float am = a.am[(size_t)n * V + c];
+        if (c == a.eos) {
+          if (a.eos_floor) am = a.minus_inf;
+          if (a.use_eos_threshold && !(am > a.eos_threshold * a.am_max[n])) am = a.minus_inf;
         }
+        if (c == a.blank) am = kNeg;
         a.comb[(size_t)n * V + c] = am + (psi - a.psi_prev[n]) * a.weight;
       }
     }
   }
 }
 
-// New forward variables of hypothesis n = (parent hyp, token) chosen by the beam search.
-__global__ void ctc_advance_kernel(const float* __restrict__ x, const float* __restrict__ phi_old,
-                                   const float* __restrict__ psi, const int32_t* __restrict__ parent,
-                                   const int32_t* __restrict__ token, const int32_t* __restrict__ parent_last_tok,
-                                   float* __restrict__ phi_new, float* __restrict__ psi_prev_new, int n_bh, int T, int V,
-                                   int beam, int prefix_len, int blank) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= n_bh) return;
-  const int b = n / beam, p = parent[n], c = token[n];
-  const float* xb = x + (size_t)b * T * V;
-  const bool same = parent_last_tok[p] == c;
-  const int start = prefix_len > 1 ? prefix_len : 1;
-  float* out = phi_new + (size_t)n * T * 2;
-  float r_nb = (prefix_len == 0) ? xb[c] : kNeg, r_b = kNeg;
-  for (int t = 0; t < start; ++t) {  // frames before `start` keep r = -1e20 (except r[0][nb] at the first step)
-    const float a_nb = (t == start - 1) ? r_nb : kNeg;
-    out[2 * t] = lse2(a_nb, kNeg);
-    out[2 * t + 1] = kNeg;
+// New per-frame state of hypothesis n = (parent hyp, token) chosen by the beam search: one wave per
+// hypothesis; emissions and parent state are prefetched into LDS, lane 0 runs the serial recurrence,
+// all lanes normalise and store.
+struct CtcAdvArgs {
+  const float* P;
+  const BF* st_old;
+  const float* psi;
+  const int32_t* parent;
+  const int32_t* token;
+  const int32_t* parent_last_tok;
+  BF* st_new;
+  float* psi_prev_new;
+  int n_bh, T, V, beam, prefix_len, blank;
+};
+
+__global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
+  SBK_DYN_LDS(float, lds);
+  const int T = a.T;
+  float* pc = lds;              // [T] P[t][token]
+  float* pb = pc + T;           // [T] P[t][blank]
+  float* mph = pb + T;          // [T] phi mantissa
+  int* eph = reinterpret_cast<int*>(mph + T);  // [T] phi exponent
+  float* onb = reinterpret_cast<float*>(eph + T);  // [T] results
+  float* obl = onb + T;
+  int* oe = reinterpret_cast<int*>(obl + T);
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int b = n / a.beam, p = a.parent[n], c = a.token[n];
+  const bool same = a.parent_last_tok[p] == c;
+  const float* Pb = a.P + (size_t)b * T * a.V;
+  for (int t = lane; t < T; t += 64) {
+    pc[t] = Pb[(size_t)t * a.V + c];
+    pb[t] = Pb[(size_t)t * a.V + a.blank];
+    const BF s = a.st_old[(size_t)p * T + t];
+    mph[t] = same ? s.mb : s.mg;
+    eph[t] = same ? s.eb : s.eg;
   }
-  for (int t = start; t < T; ++t) {
-    const float* ph = phi_old + ((size_t)p * T + (t - 1)) * 2;
-    const float phi_prev = same ? ph[1] : ph[0];
-    const float n_nb = lse2(r_nb, phi_prev) + xb[(size_t)t * V + c];
-    const float n_b = lse2(r_nb, r_b) + xb[(size_t)t * V + blank];
-    r_nb = n_nb;
-    r_b = n_b;
-    out[2 * t] = lse2(r_nb, r_b);
-    out[2 * t + 1] = r_b;
+  __syncthreads();
+  if (lane == 0) {
+    const int start = a.prefix_len > 1 ? a.prefix_len : 1;
+    const bool first = a.prefix_len == 0 && pc[0] > 0.0f;
+    float mnb = first ? pc[0] : 0.0f, mbl = 0.0f;
+    int E = first ? 0 : kNegE;
+    for (int t = 0; t < start; ++t) {  // frames before `start` keep r = "minus infinity" (except r[0][nb] at the first step)
+      onb[t] = (t == start - 1) ? mnb : 0.0f;
+      obl[t] = 0.0f;
+      oe[t] = (t == start - 1) ? E : kNegE;
+    }
+    for (int t = start; t < T; ++t) {
+      const int ephi = eph[t - 1];
+      const int E2 = max(E, ephi - kHead);
+      const float x_nb = ldexpf(mnb, E - E2), x_b = ldexpf(mbl, E - E2), ph = ldexpf(mph[t - 1], ephi - E2);
+      const float n_nb = (x_nb + ph) * pc[t], n_b = (x_nb + x_b) * pb[t];
+      const float sum = n_nb + n_b;
+      const int k = fexp(sum);
+      mnb = ldexpf(n_nb, -k);
+      mbl = ldexpf(n_b, -k);
+      E = sum > 0.0f ? E2 + k : kNegE;
+      onb[t] = mnb;
+      obl[t] = mbl;
+      oe[t] = E;
+    }
   }
-  psi_prev_new[n] = psi[(size_t)p * V + c];
+  __syncthreads();
+  for (int t = lane; t < T; t += 64) {
+    BF s;
+    const float g = onb[t] + obl[t];
+    const int kg = fexp(g), kb = fexp(obl[t]);
+    s.mg = g > 0.0f ? ldexpf(g, 1 - kg) : 0.0f;  // mantissa in [1,2)
+    s.eg = g > 0.0f ? oe[t] + kg - 1 : kNegE;
+    s.mb = obl[t] > 0.0f ? ldexpf(obl[t], 1 - kb) : 0.0f;
+    s.eb = obl[t] > 0.0f ? oe[t] + kb - 1 : kNegE;
+    a.st_new[(size_t)n * T + t] = s;
+  }
+  if (lane == 0) a.psi_prev_new[n] = a.psi[(size_t)p * a.V + c];
 }
 
 // Without a CTC scorer: comb = am with the eos modifications only.
@@ -206,33 +297,39 @@ __global__ void __launch_bounds__(256) row_max_kernel(const float* __restrict__ 
 
 namespace sbk {
 
-int ctc_prepare(float* x, const int32_t* enc_len, float* phi, float* psi_prev, int B, int T, int V, int beam, int blank,
-                hipStream_t st) {
-  SBK_LAUNCH(ctc_mask_kernel, dim3(T, B), dim3(256), 0, st, x, enc_len, T, V);
-  int rc = launch_status("ctc_mask");
+size_t ctc_state_floats(int n_bh, int T) { return (size_t)n_bh * T * (sizeof(BF) / sizeof(float)); }
+
+// x: [B,T,V] log_softmax(ctc_lin(enc)) on entry, linear masked posteriors on exit.
+int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, float* psi_prev, int B, int T, int V,
+                int beam, int blank, hipStream_t st) {
+  SBK_LAUNCH(ctc_emissions_kernel, dim3(T, B), dim3(256), 0, st, x, xb_log, enc_len, T, V, blank);
+  int rc = launch_status("ctc_emissions");
   if (rc) return rc;
-  SBK_LAUNCH(ctc_init_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, (const float*)x, phi, psi_prev, B, T, V, beam,
-             blank);
+  SBK_LAUNCH(ctc_init_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float), st, (const float*)xb_log,
+             reinterpret_cast<BF*>(state), psi_prev, T, beam);
   return launch_status("ctc_init");
 }
 
-int ctc_score_step(const float* x, const float* phi, const float* psi_prev, const int32_t* last_tok,
+int ctc_score_step(const float* P, const float* state, const float* psi_prev, const int32_t* last_tok,
                    const int32_t* enc_len, const float* am, float* comb, float* psi, int B, int T, int V, int beam,
                    int prefix_len, int blank, int eos, float weight, int eos_floor, int use_thr, float thr,
                    float minus_inf, const float* am_max, hipStream_t st) {
-  CtcStepArgs a{x, phi, psi_prev, last_tok, enc_len, am, comb, psi, B, T, V, beam, prefix_len, blank, eos, weight,
-                eos_floor, use_thr, thr, minus_inf, am_max};
-  ProfScope prof("ctc_score_step", 10.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 12.0 * B * beam * V, st);
+  CtcStepArgs a{P, reinterpret_cast<const BF*>(state), psi_prev, last_tok, enc_len, am, comb, psi, B, T, V, beam,
+                prefix_len, blank, eos, weight, eos_floor, use_thr, thr, minus_inf, am_max};
+  ProfScope prof("ctc_score_step", 14.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 12.0 * B * beam * V, st);
   SBK_LAUNCH(ctc_score_step_kernel, dim3(cdiv(V, 256), B), dim3(256), 0, st, a);
   return launch_status("ctc_score_step");
 }
 
-int ctc_advance(const float* x, const float* phi_old, const float* psi, const int32_t* parent, const int32_t* token,
-                const int32_t* parent_last_tok, float* phi_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
+int ctc_advance(const float* P, const float* state_old, const float* psi, const int32_t* parent, const int32_t* token,
+                const int32_t* parent_last_tok, float* state_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
                 int prefix_len, int blank, hipStream_t st) {
-  ProfScope prof("ctc_advance", 10.0 * n_bh * T, 16.0 * n_bh * T, st);
-  SBK_LAUNCH(ctc_advance_kernel, dim3(cdiv(n_bh, 64)), dim3(64), 0, st, x, phi_old, psi, parent, token,
-             parent_last_tok, phi_new, psi_prev_new, n_bh, T, V, beam, prefix_len, blank);
+  CtcAdvArgs a{P, reinterpret_cast<const BF*>(state_old), psi, parent, token, parent_last_tok,
+               reinterpret_cast<BF*>(state_new), psi_prev_new, n_bh, T, V, beam, prefix_len, blank};
+  const size_t lds = (size_t)7 * T * sizeof(float);
+  if (lds > 64 * 1024) return fail(SBK_EINVAL, "ctc_advance: T=%d too long for the LDS window", T);
+  ProfScope prof("ctc_advance", 14.0 * n_bh * T, 40.0 * n_bh * T, st);
+  SBK_LAUNCH(ctc_advance_kernel, dim3(n_bh), dim3(64), lds, st, a);
   return launch_status("ctc_advance");
 }
 

@@ -40,9 +40,12 @@ struct SelfAttnArgs {
   float scale;
 };
 
-// one wave per (hypothesis, head)
+// One wave per (hypothesis, head).  The 64 lanes form 4 position groups x 16 lanes; a group's 16
+// lanes read one K (or V) head row as 16-byte pieces (a 256-byte row per load instruction and
+// group, fully coalesced) and several rows are in flight at once, so the walk over the prefix is
+// a handful of dependent round trips instead of one per position.
 __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
-  SBK_DYN_LDS(float, lds);  // [4 waves][Lmax_pad] probabilities
+  SBK_DYN_LDS(float, lds);  // [4 waves][Lmax_pad] scores -> probabilities
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = blockIdx.x * 4 + wave;
   const bool live = item < a.n * a.H;
@@ -53,6 +56,8 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
   const float* q = a.qkv + (size_t)i * 3 * d + h * Dh;
   const float* knew = q + d;
   const float* vnew = q + 2 * d;
+  const int pg = lane >> 4, cq = lane & 15;  // position group, 16-byte piece of the head row
+  const int nchunk = (Dh + 63) / 64;         // 64-float chunks per head row (1 for Dh <= 64)
   // append this token's K/V head slice to the cache (slot = hypothesis index)
   if (live) {
     for (int c = lane; c < Dh; c += 64) {
@@ -61,15 +66,29 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
       a.vcache[o] = vnew[c];
     }
   }
-  // scores: lane <-> position
-  float m = -INFINITY;
-  for (int p = lane; p < L; p += 64) {
-    const float* kp = (p == a.step) ? knew : a.kcache + ((size_t)p * a.nslot + a.kv_slot[(size_t)i * a.Lmax + p]) * d + h * Dh;
+  // scores
+  for (int p0 = 0; p0 < L; p0 += 4) {
+    const int p = p0 + pg;
     float s = 0.0f;
-    for (int c = 0; c < Dh; ++c) s = fmaf(q[c] * a.scale, kp[c], s);
-    prob[p] = s;
-    m = fmaxf(m, s);
+    if (p < L) {
+      const float* kp = (p == a.step) ? knew : a.kcache + ((size_t)p * a.nslot + a.kv_slot[(size_t)i * a.Lmax + p]) * d + h * Dh;
+      for (int ch = 0; ch < nchunk; ++ch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = ch * 64 + cq * 4 + e;
+          if (c < Dh) s = fmaf(q[c] * a.scale, kp[c], s);
+        }
+      }
+    }
+    s += sbk::shfl_xor(s, 1);
+    s += sbk::shfl_xor(s, 2);
+    s += sbk::shfl_xor(s, 4);
+    s += sbk::shfl_xor(s, 8);
+    if (p < L && cq == 0) prob[p] = s;
   }
+  sbk::wave_sync();
+  float m = -INFINITY;
+  for (int p = lane; p < L; p += 64) m = fmaxf(m, prob[p]);
   m = sbk::wave_max(m);
   float sum = 0.0f;
   for (int p = lane; p < L; p += 64) {
@@ -80,14 +99,28 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
   sum = sbk::wave_sum(sum);
   for (int p = lane; p < L; p += 64) prob[p] = prob[p] / sum;
   sbk::wave_sync();
-  // context: lane <-> channel
-  for (int c = lane; c < Dh; c += 64) {
-    float acc = 0.0f;
-    for (int p = 0; p < L; ++p) {
-      const float* vp = (p == a.step) ? vnew : a.vcache + ((size_t)p * a.nslot + a.kv_slot[(size_t)i * a.Lmax + p]) * d + h * Dh;
-      acc = fmaf(prob[p], vp[c], acc);
+  // context: each position group accumulates its positions, then the 4 groups are summed
+  for (int ch = 0; ch < nchunk; ++ch) {
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int p0 = 0; p0 < L; p0 += 4) {
+      const int p = p0 + pg;
+      if (p < L) {
+        const float* vp = (p == a.step) ? vnew : a.vcache + ((size_t)p * a.nslot + a.kv_slot[(size_t)i * a.Lmax + p]) * d + h * Dh;
+        const float w = prob[p];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = ch * 64 + cq * 4 + e;
+          if (c < Dh) acc[e] = fmaf(w, vp[c], acc[e]);
+        }
+      }
     }
-    if (live) a.out[(size_t)i * d + h * Dh + c] = acc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[e] += sbk::shfl_xor(acc[e], 16);
+      acc[e] += sbk::shfl_xor(acc[e], 32);
+      const int c = ch * 64 + cq * 4 + e;
+      if (live && pg == 0 && c < Dh) a.out[(size_t)i * d + h * Dh + c] = acc[e];
+    }
   }
 }
 
@@ -151,17 +184,30 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
     for (int t = lane; t < klen; t += 64) Sr[t] = Sr[t] / sum;
   }
   __syncthreads();
-  // context: wave <-> quarter of the frames, lane <-> channel; V row read once for all beams
+  // context: wave <-> quarter of the frames, lane <-> channel; V row read once for all beams.
+  // Rows are fetched 8 at a time so that 8 loads are in flight per lane.
   {
     float acc[kQT];
 #pragma unroll
     for (int j = 0; j < kQT; ++j) acc[j] = 0.0f;
     const int c = lane;
     if (c < DH) {
-      for (int t = wave; t < klen; t += 4) {
-        const float v = kvb[(size_t)t * 2 * d + d + c];
+      const float* vcol = kvb + d + c;
+      for (int t0 = wave; t0 < klen; t0 += 32) {
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < kQT; ++j) acc[j] = fmaf(S[j * SP + t], v, acc[j]);
+        for (int u = 0; u < 8; ++u) {
+          const int t = t0 + 4 * u;
+          v[u] = t < klen ? vcol[(size_t)t * 2 * d] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = t0 + 4 * u;
+          if (t < klen) {
+#pragma unroll
+            for (int j = 0; j < kQT; ++j) acc[j] = fmaf(S[j * SP + t], v[u], acc[j]);
+          }
+        }
       }
 #pragma unroll
       for (int j = 0; j < kQT; ++j) red[(wave * kQT + j) * DH + c] = acc[j];

@@ -132,6 +132,111 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(Gem
   }
 }
 
+// ---------------------------------------------------------------------------
+// Skinny GEMM for the decoder steps (M = beams x utterances, a few hundred rows).
+// With so few rows an LDS-tiled workgroup grid cannot fill 256 CUs, and the
+// weights (L2/MALL resident) dominate traffic.  Here every WAVE owns one
+// (TM*32) x 32 output tile and one K slice: operands go straight from L2 into
+// registers as 16-byte runs (lane (r, half) reads the `half` side of a 32-float
+// chunk of row r, the two k-slices of the 32x32x2 MFMA are fed from the two
+// halves), there is no LDS and no barrier, and K is split across waves so the
+// grid has a few thousand independent waves.  Split-K partials are combined by
+// a second, deterministic kernel that also applies the epilogue.
+template <int TM>
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __restrict__ partial, int SK, int kper) {
+  constexpr int KC = 32;  // floats per row per chunk (16 per lane half)
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tiles_n = (g.N + 31) / 32, tiles_m = (g.M + TM * 32 - 1) / (TM * 32);
+  if (wid >= tiles_n * tiles_m * SK) return;
+  const int nt = wid % tiles_n, mt = (wid / tiles_n) % tiles_m, ks = wid / (tiles_n * tiles_m);
+  const int r = lane & 31, half = lane >> 5;
+  const int k_begin = ks * kper, k_end = min(g.K, k_begin + kper);
+  const float* wrow = g.W + (size_t)min(nt * 32 + r, g.N - 1) * g.ldw + half * (KC / 2);
+  const float* arow[TM];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) arow[t] = g.A + (size_t)min(mt * TM * 32 + t * 32 + r, g.M - 1) * g.lda + half * (KC / 2);
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+
+  float4 a0[TM][4], w0[4], a1[TM][4], w1[4];
+  auto load = [&](float4 (&a)[TM][4], float4 (&w)[4], int k) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) w[v] = *reinterpret_cast<const float4*>(wrow + k + 4 * v);
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) a[t][v] = *reinterpret_cast<const float4*>(arow[t] + k + 4 * v);
+  };
+  auto compute = [&](const float4 (&a)[TM][4], const float4 (&w)[4]) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t) acc[t] = sbk::mfma_32x32x2(a[t][v].x, w[v].x, acc[t]);
+#pragma unroll
+      for (int t = 0; t < TM; ++t) acc[t] = sbk::mfma_32x32x2(a[t][v].y, w[v].y, acc[t]);
+#pragma unroll
+      for (int t = 0; t < TM; ++t) acc[t] = sbk::mfma_32x32x2(a[t][v].z, w[v].z, acc[t]);
+#pragma unroll
+      for (int t = 0; t < TM; ++t) acc[t] = sbk::mfma_32x32x2(a[t][v].w, w[v].w, acc[t]);
+    }
+  };
+  // register double buffering: the loads of chunk k+1 are in flight under the MFMAs of chunk k
+  load(a0, w0, k_begin);
+  for (int k = k_begin; k < k_end; k += 2 * KC) {
+    if (k + KC < k_end) load(a1, w1, k + KC);
+    compute(a0, w0);
+    if (k + KC < k_end) {
+      if (k + 2 * KC < k_end) load(a0, w0, k + 2 * KC);
+      compute(a1, w1);
+    }
+  }
+
+  const int col = nt * 32 + r;
+  if (col >= g.N) return;
+  if (SK > 1) {
+    float* P = partial + (size_t)ks * g.M * g.N;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = mt * TM * 32 + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+        if (row < g.M) P[(size_t)row * g.N + col] = acc[t][q];
+      }
+    return;
+  }
+  const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = mt * TM * 32 + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+      if (row >= g.M) continue;
+      float v = apply_act(acc[t][q] + bv, g.act) * g.alpha;
+      if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
+      if (g.R) v += g.R[(size_t)row * g.ldr + col];
+      g.C[(size_t)row * g.ldc + col] = v;
+    }
+}
+
+// C = epilogue(sum_ks partial[ks]) ; fixed summation order => run-to-run deterministic.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const float* __restrict__ partial, int SK) {
+  const size_t total = (size_t)g.M * g.N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / g.N), col = (int)(i % g.N);
+    float acc = partial[i];
+    for (int ks = 1; ks < SK; ++ks) acc += partial[(size_t)ks * total + i];
+    float v = apply_act(acc + (g.bias ? g.bias[col] : 0.0f), g.act) * g.alpha;
+    if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
+    if (g.R) v += g.R[(size_t)row * g.ldr + col];
+    g.C[(size_t)row * g.ldc + col] = v;
+  }
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
   dim3 grid(sbk::cdiv(g.N, BN), sbk::cdiv(g.M, BM));
@@ -149,7 +254,39 @@ int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
 }  // namespace
 
 namespace sbk {
+int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
+            int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
 // Internal C++ entry shared with the fused pipelines (decoder step, encoder).
+// Skinny path: M <= 512 rows, K a multiple of 64, 16-byte aligned rows.  `ws` (optional) holds the
+// split-K partials: SK * M * N floats.
+int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
+               int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq,
+               float* ws, size_t ws_floats, hipStream_t st) {
+  if (M == 0 || N == 0) return 0;
+  const bool skinny_ok = M <= 512 && K % 64 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
+  if (!skinny_ok) return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
+  GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
+  const int TM = M > 32 ? 2 : 1;
+  const int tiles = cdiv(N, 32) * cdiv(M, TM * 32);
+  int SK = 1;
+  if (ws) {  // enough independent waves for ~2 per SIMD, at least 64 of K per slice
+    while (K % (SK * 2 * 64) == 0 && tiles * SK < 2048 && (size_t)(SK * 2) * M * N <= ws_floats) SK *= 2;
+  }
+  const int kper = K / SK;
+  ProfScope prof("gemm_skinny", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
+  dim3 grid(cdiv(tiles * SK, 4)), block(256);
+  if (TM == 2) {
+    SBK_LAUNCH((gemm_skinny_kernel<2>), grid, block, 0, st, g, ws, SK, kper);
+  } else {
+    SBK_LAUNCH((gemm_skinny_kernel<1>), grid, block, 0, st, g, ws, SK, kper);
+  }
+  int rc = launch_status("gemm_skinny");
+  if (rc || SK == 1) return rc;
+  const size_t total = (size_t)M * N;
+  SBK_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, g, (const float*)ws, SK);
+  return launch_status("splitk_reduce");
+}
+
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st) {
   if (M == 0 || N == 0) return 0;
@@ -173,6 +310,18 @@ extern "C" int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw,
   SBK_REQUIRE(!residual || ldr >= N, "gemm: residual stride");
   SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm: unknown activation %d", act);
   SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm: seq_len given without rows_per_seq");
-  return sbk::gemm_nt(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq,
-                      sbk::as_stream(stream));
+  return sbk::gemm_nt_ws(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq,
+                         nullptr, 0, sbk::as_stream(stream));
+}
+
+extern "C" int sbk_gemm_nt_splitk_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
+                                      const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
+                                      float alpha, float* workspace, size_t workspace_floats, sbk_stream_t stream) {
+  SBK_REQUIRE(A && W && C, "gemm: null operand");
+  SBK_REQUIRE(M >= 0 && N >= 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+  SBK_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dimension smaller than the row");
+  SBK_REQUIRE(!residual || ldr >= N, "gemm: residual stride");
+  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm: unknown activation %d", act);
+  return sbk::gemm_nt_ws(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, nullptr, 0, workspace,
+                         workspace ? workspace_floats : 0, sbk::as_stream(stream));
 }

@@ -24,8 +24,9 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
 int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, int B, int T, int d, int H,
                     int beam, hipStream_t st);
 int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st);
-int ctc_prepare(float* x, const int32_t* enc_len, float* phi, float* psi_prev, int B, int T, int V, int beam, int blank,
-                hipStream_t st);
+int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, float* psi_prev, int B, int T, int V,
+                int beam, int blank, hipStream_t st);
+size_t ctc_state_floats(int n_bh, int T);
 int ctc_score_step(const float* x, const float* phi, const float* psi_prev, const int32_t* last_tok,
                    const int32_t* enc_len, const float* am, float* comb, float* psi, int B, int T, int V, int beam,
                    int prefix_len, int blank, int eos, float weight, int eos_floor, int use_thr, float thr,
@@ -49,16 +50,18 @@ struct Cand {
 };
 __device__ __forceinline__ bool better(float v, int i, float v2, int i2) { return v > v2 || (v == v2 && i < i2); }
 
-__global__ void __launch_bounds__(256) beam_topk_kernel(const float* __restrict__ comb, const float* __restrict__ seq,
-                                                        float* __restrict__ out_val, int32_t* __restrict__ out_idx,
-                                                        int V, int beam, float norm) {
+// Block-wide selection of the `k` best (value, index) pairs among the candidates a loader yields.
+// Every thread keeps a sorted top-16 list of its strided share (registers), the lists go to LDS and
+// k rounds of a block arg-max over the list heads emit the winners in descending order
+// (ties: lower index first).
+template <typename Load>
+__device__ __forceinline__ void block_topk(int total, int k, float* out_val, int32_t* out_idx, Load load) {
   __shared__ float lv[256][kMaxBeam];
   __shared__ int li[256][kMaxBeam];
   __shared__ float wv[4];
   __shared__ int wi[4];
   __shared__ int win;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int total = beam * V;
+  const int tid = threadIdx.x;
   float vals[kMaxBeam];
   int ids[kMaxBeam];
 #pragma unroll
@@ -66,14 +69,14 @@ __global__ void __launch_bounds__(256) beam_topk_kernel(const float* __restrict_
     vals[s] = -INFINITY;
     ids[s] = INT_MAX;
   }
-  const float* cb = comb + (size_t)b * total;
   for (int e = tid; e < total; e += 256) {
-    const float v = seq[b * beam + e / V] + cb[e];
-    const float vn = norm > 0.0f ? v / norm : v;  // length normalisation divides, like seq2seq.py:1232-1233
+    float vn;
+    int id;
+    load(e, vn, id);
     if (vn != vn) continue;
-    if (better(vn, e, vals[kMaxBeam - 1], ids[kMaxBeam - 1])) {
+    if (better(vn, id, vals[kMaxBeam - 1], ids[kMaxBeam - 1])) {
       float cv = vn;
-      int ci = e;
+      int ci = id;
 #pragma unroll
       for (int s = 0; s < kMaxBeam; ++s) {
         if (better(cv, ci, vals[s], ids[s])) {
@@ -94,7 +97,7 @@ __global__ void __launch_bounds__(256) beam_topk_kernel(const float* __restrict_
   }
   __syncthreads();
   int hp = 0;
-  for (int r = 0; r < beam; ++r) {
+  for (int r = 0; r < k; ++r) {
     float v = hp < kMaxBeam ? lv[tid][hp] : -INFINITY;
     int i = hp < kMaxBeam ? li[tid][hp] : INT_MAX;
 #pragma unroll
@@ -120,13 +123,50 @@ __global__ void __launch_bounds__(256) beam_topk_kernel(const float* __restrict_
           bi = wi[w];
         }
       win = bi;
-      out_val[b * beam + r] = bv;
-      out_idx[b * beam + r] = bi == INT_MAX ? 0 : bi;
+      out_val[r] = bv;
+      out_idx[r] = bi;
     }
     __syncthreads();
     if (hp < kMaxBeam && li[tid][hp] == win && win != INT_MAX) ++hp;
     __syncthreads();
   }
+}
+
+constexpr int kTopkChunks = 16;  // stage-1 workgroups per utterance
+
+// stage 1: grid (chunks, B); each workgroup reduces one contiguous slice of the beam*V candidates
+__global__ void __launch_bounds__(256) beam_topk_stage1_kernel(const float* __restrict__ comb,
+                                                               const float* __restrict__ seq, float* __restrict__ pval,
+                                                               int32_t* __restrict__ pidx, int V, int beam, float norm) {
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int total = beam * V;
+  const int len = (total + kTopkChunks - 1) / kTopkChunks;
+  const int e0 = ch * len, n = max(0, min(len, total - e0));
+  const float* cb = comb + (size_t)b * total;
+  const float* sq = seq + b * beam;
+  block_topk(n, beam, pval + ((size_t)b * kTopkChunks + ch) * kMaxBeam, pidx + ((size_t)b * kTopkChunks + ch) * kMaxBeam,
+             [&](int e, float& v, int& id) {
+               id = e0 + e;
+               const float x = sq[id / V] + cb[id];
+               v = norm > 0.0f ? x / norm : x;  // length normalisation divides, like seq2seq.py:1232-1233
+             });
+}
+
+// stage 2: grid (B); merge the chunk winners
+__global__ void __launch_bounds__(256) beam_topk_stage2_kernel(const float* __restrict__ pval,
+                                                               const int32_t* __restrict__ pidx,
+                                                               float* __restrict__ out_val,
+                                                               int32_t* __restrict__ out_idx, int beam) {
+  const int b = blockIdx.x;
+  const float* pv = pval + (size_t)b * kTopkChunks * kMaxBeam;
+  const int32_t* pi = pidx + (size_t)b * kTopkChunks * kMaxBeam;
+  block_topk(kTopkChunks * kMaxBeam, beam, out_val + b * beam, out_idx + b * beam, [&](int e, float& v, int& id) {
+    const bool ok = (e % kMaxBeam) < beam;
+    v = ok ? pv[e] : -INFINITY;
+    id = ok ? pi[e] : INT_MAX;
+  });
+  __syncthreads();
+  if (threadIdx.x < beam && out_idx[b * beam + threadIdx.x] == INT_MAX) out_idx[b * beam + threadIdx.x] = 0;
 }
 
 // ---------------------------------------------------------------- beam bookkeeping
@@ -368,6 +408,8 @@ struct Carver {
 
 struct DecoderBufs {
   float *x, *h, *qkv, *ctx, *q, *ff, *logits;
+  float* splitk;        // split-K partials of the skinny GEMMs
+  size_t splitk_floats;
   float* ckv[64];
   float *kcache[64], *vcache[64];
 };
@@ -381,6 +423,8 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
   d.q = c.take<float>((size_t)n * dm);
   d.ff = c.take<float>((size_t)n * W->d_ffn);
   d.logits = c.take<float>((size_t)n * W->vocab);
+  d.splitk_floats = (size_t)8 * n * (size_t)(W->d_ffn > 3 * dm ? W->d_ffn : 3 * dm);
+  d.splitk = c.take<float>(d.splitk_floats);
   for (int l = 0; l < W->n_layers; ++l) {
     d.ckv[l] = c.take<float>((size_t)B * T * 2 * dm);
     d.kcache[l] = c.take<float>((size_t)Lmax * n * dm);
@@ -422,27 +466,27 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
     SBK_TRY(sbk::layernorm(d.x, L.ln1_g, L.ln1_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
-    SBK_TRY(sbk::gemm_nt(d.h, dm, L.sa_in_w, dm, L.sa_in_b, nullptr, 0, d.qkv, 3 * dm, n, 3 * dm, dm, SBK_ACT_NONE, 1.0f,
-                         nullptr, 0, st));
+    SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.sa_in_w, dm, L.sa_in_b, nullptr, 0, d.qkv, 3 * dm, n, 3 * dm, dm, SBK_ACT_NONE, 1.0f,
+                         nullptr, 0, d.splitk, d.splitk_floats, st));
     SBK_TRY(sbk::self_attn_step(d.qkv, d.kcache[l], d.vcache[l], kv_slot, d.ctx, n, dm, H, step, n, Lmax, st));
-    SBK_TRY(sbk::gemm_nt(d.ctx, dm, L.sa_out_w, dm, L.sa_out_b, d.x, dm, d.x, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
-                         0, st));
+    SBK_TRY(sbk::gemm_nt_ws(d.ctx, dm, L.sa_out_w, dm, L.sa_out_b, d.x, dm, d.x, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
+                         0, d.splitk, d.splitk_floats, st));
     SBK_TRY(sbk::layernorm(d.x, L.ln2_g, L.ln2_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
-    SBK_TRY(sbk::gemm_nt(d.h, dm, L.ca_in_w, dm, L.ca_in_b, nullptr, 0, d.q, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr, 0,
-                         st));
+    SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.ca_in_w, dm, L.ca_in_b, nullptr, 0, d.q, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr, 0,
+                         d.splitk, d.splitk_floats, st));
     SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, B, T, dm, H, beam, st));
-    SBK_TRY(sbk::gemm_nt(d.ctx, dm, L.ca_out_w, dm, L.ca_out_b, d.x, dm, d.x, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
-                         0, st));
+    SBK_TRY(sbk::gemm_nt_ws(d.ctx, dm, L.ca_out_w, dm, L.ca_out_b, d.x, dm, d.x, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
+                         0, d.splitk, d.splitk_floats, st));
     SBK_TRY(sbk::layernorm(d.x, L.ln3_g, L.ln3_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
-    SBK_TRY(sbk::gemm_nt(d.h, dm, L.ff1_w, dm, L.ff1_b, nullptr, 0, d.ff, W->d_ffn, n, W->d_ffn, dm, W->ffn_act, 1.0f,
-                         nullptr, 0, st));
-    SBK_TRY(sbk::gemm_nt(d.ff, W->d_ffn, L.ff2_w, W->d_ffn, L.ff2_b, d.x, dm, d.x, dm, n, dm, W->d_ffn, SBK_ACT_NONE, 1.0f,
-                         nullptr, 0, st));
+    SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.ff1_w, dm, L.ff1_b, nullptr, 0, d.ff, W->d_ffn, n, W->d_ffn, dm, W->ffn_act, 1.0f,
+                         nullptr, 0, d.splitk, d.splitk_floats, st));
+    SBK_TRY(sbk::gemm_nt_ws(d.ff, W->d_ffn, L.ff2_w, W->d_ffn, L.ff2_b, d.x, dm, d.x, dm, n, dm, W->d_ffn, SBK_ACT_NONE, 1.0f,
+                         nullptr, 0, d.splitk, d.splitk_floats, st));
   }
   SBK_TRY(sbk::layernorm(d.x, W->final_ln_g, W->final_ln_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
   if (want_logits)
-    SBK_TRY(sbk::gemm_nt(d.h, dm, W->seq_w, dm, W->seq_b, nullptr, 0, d.logits, W->vocab, n, W->vocab, dm, SBK_ACT_NONE,
-                         1.0f, nullptr, 0, st));
+    SBK_TRY(sbk::gemm_nt_ws(d.h, dm, W->seq_w, dm, W->seq_b, nullptr, 0, d.logits, W->vocab, n, W->vocab, dm, SBK_ACT_NONE,
+                         1.0f, nullptr, 0, d.splitk, d.splitk_floats, st));
   return 0;
 }
 
@@ -455,7 +499,9 @@ int check_weights(const sbk_decoder_weights* W) {
 
 struct BeamBufs {
   BeamState s;
-  float *am, *comb, *psi, *am_max, *ctc_x, *phi[2], *psi_prev[2];
+  float *am, *comb, *psi, *am_max, *ctc_x, *ctc_xb, *phi[2], *psi_prev[2];
+  float* topk_val;
+  int32_t* topk_idx;
 };
 
 void carve_beam(Carver& c, BeamBufs& b, int B, int beam, int T, int V, int Lmax, bool ctc) {
@@ -479,11 +525,14 @@ void carve_beam(Carver& c, BeamBufs& b, int B, int beam, int T, int V, int Lmax,
   b.am = c.take<float>(n * V);
   b.comb = c.take<float>(n * V);
   b.am_max = c.take<float>(n);
+  b.topk_val = c.take<float>((size_t)B * kTopkChunks * kMaxBeam);
+  b.topk_idx = c.take<int32_t>((size_t)B * kTopkChunks * kMaxBeam);
   if (ctc) {
     b.psi = c.take<float>(n * V);
     b.ctc_x = c.take<float>((size_t)B * T * V);
+    b.ctc_xb = c.take<float>((size_t)B * T);
     for (int k = 0; k < 2; ++k) {
-      b.phi[k] = c.take<float>(n * T * 2);
+      b.phi[k] = c.take<float>(sbk::ctc_state_floats((int)n, T));
       b.psi_prev[k] = c.take<float>(n);
     }
   }
@@ -536,7 +585,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   if (ctc) {  // CTCScorer.reset_mem (scorer.py:239-255): log_softmax(ctc_lin(enc)), then the frame mask
     SBK_TRY(sbk::gemm_nt(enc, dm, ctc_w, dm, ctc_b, nullptr, 0, bb.ctc_x, V, B * T, V, dm, SBK_ACT_NONE, 1.0f, nullptr, 0, st));
     SBK_TRY(sbk::log_softmax_rows(bb.ctc_x, bb.ctc_x, B * T, V, 1.0f, 1.0f, st));
-    SBK_TRY(sbk::ctc_prepare(bb.ctc_x, enc_len, bb.phi[0], bb.psi_prev[0], B, T, V, beam, cfg->blank, st));
+    SBK_TRY(sbk::ctc_prepare(bb.ctc_x, bb.ctc_xb, enc_len, bb.phi[0], bb.psi_prev[0], B, T, V, beam, cfg->blank, st));
   }
   SBK_LAUNCH(beam_init_kernel, dim3(sbk::cdiv(n > B ? n : B, 256)), dim3(256), 0, st, bb.s, B, beam, cfg->bos);
   SBK_TRY(sbk::launch_status("beam_init"));
@@ -559,8 +608,10 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
     const float norm = cfg->length_normalization ? (float)(step + 1) : 0.0f;
     {
       sbk::ProfScope prof("beam_topk", 2.0 * n * V, 4.0 * n * V, st);
-      SBK_LAUNCH(beam_topk_kernel, dim3(B), dim3(256), 0, st, (const float*)bb.comb, (const float*)bb.s.seq_scores,
-               bb.s.cand_val, bb.s.cand_idx, V, beam, norm);
+      SBK_LAUNCH(beam_topk_stage1_kernel, dim3(kTopkChunks, B), dim3(256), 0, st, (const float*)bb.comb,
+                 (const float*)bb.s.seq_scores, bb.topk_val, bb.topk_idx, V, beam, norm);
+      SBK_LAUNCH(beam_topk_stage2_kernel, dim3(B), dim3(256), 0, st, (const float*)bb.topk_val,
+                 (const int32_t*)bb.topk_idx, bb.s.cand_val, bb.s.cand_idx, beam);
     }
     SBK_TRY(sbk::launch_status("beam_topk"));
     {

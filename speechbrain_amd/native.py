@@ -58,6 +58,7 @@ def _declare(lib):
         "sbk_fbank_f32": ([p, p, p, POINTER(c_int32), i, p, p, p, p, p, i, i, i, i, i, i, f, f, p, p, f, p], c_int),
         "sbk_input_norm_global_f32": ([p, p, p, p, i, i, f, p], c_int),
         "sbk_gemm_nt_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
+        "sbk_gemm_nt_splitk_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, ctypes.c_size_t, p], c_int),
         "sbk_conv_block_f32": ([p, p, p, p, p, p, i, i, i, i, i, f, f, p], c_int),
         "sbk_relpos_attention_f32": ([p, p, p, p, p, p, p, i, i, i, i, f, p], c_int),
         "sbk_glu_dwconv_f32": ([p, p, p, p, i, i, i, i, p], c_int),
@@ -168,6 +169,21 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_
     _dev_ok(seq_len)
     _chk(lib.sbk_gemm_nt_f32(_p(a2), K, _p(w), w.stride(0), _p(bias), _p(r2), N, _p(out), N, M, N, K, act,
                              float(alpha), _p(seq_len), int(rows_per_seq), _stream(a2)), "sbk_gemm_nt_f32")
+    return out
+
+
+def gemm_nt_splitk(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, slices=8):
+    """gemm_nt for few-row operands with a caller-provided split-K workspace."""
+    lib = load()
+    K = a.shape[-1]
+    a2 = a.reshape(-1, K)
+    M, N = a2.shape[0], w.shape[0]
+    _dev_ok(a2, w, bias, residual)
+    out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
+    ws = torch.empty(max(1, slices * M * N), dtype=torch.float32, device=a.device)
+    r2 = residual.reshape(-1, N) if residual is not None else None
+    _chk(lib.sbk_gemm_nt_splitk_f32(_p(a2), K, _p(w), w.stride(0), _p(bias), _p(r2), N, _p(out), N, M, N, K, act,
+                                    float(alpha), _p(ws), ws.numel(), _stream(a2)), "sbk_gemm_nt_splitk_f32")
     return out
 
 

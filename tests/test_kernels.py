@@ -37,6 +37,28 @@ def test_gemm_bias_act_residual(backend, M, N, K):
         assert _md(out, ref) <= 2e-6 * scale + 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(320, 96, 128), (40, 70, 64), (512, 33, 192), (20, 130, 512), (320, 512, 2048)])
+def test_gemm_skinny_splitk(backend, M, N, K):
+    """Decoder-step shapes: register-fed skinny kernel, with and without split-K partials."""
+    nat, dev = backend
+    if dev.type == "cpu" and M * N * K > 4e6:
+        pytest.skip("large shape: GPU only")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01
+    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = r + F.gelu(a.double() @ w.double().t() + b).float()
+    scale = float((a.abs() @ w.abs().t()).max())
+    for fn in (lambda: nat.gemm_nt(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_GELU),
+               lambda: nat.gemm_nt_splitk(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_GELU, slices=8),
+               lambda: nat.gemm_nt_splitk(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_GELU, slices=2)):
+        assert _md(fn(), ref) <= 2e-6 * scale + 1e-5
+    x = a.to(dev).clone()  # in-place residual (C aliases R), as the decoder step uses it
+    sq = torch.randn(K, K, generator=g)
+    out = nat.gemm_nt_splitk(x, sq.to(dev), None, x, slices=4)
+    assert _md(out, a + (a.double() @ sq.double().t()).float()) <= 2e-6 * float((a.abs() @ sq.abs().t()).max()) + 1e-5
+
+
 def test_gemm_row_mask(backend):
     nat, dev = backend
     a, w, r = torch.randn(14, 16), torch.randn(12, 16), torch.randn(14, 12)
