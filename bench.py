@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
-MFMA_KERNELS = ("gemm_nt", "relpos_attention")
+MFMA_KERNELS = ("gemm", "relpos_attention")
 TOKENS_PER_SECOND = 4.0
 
 

@@ -9,17 +9,19 @@
 //    non-blank/blank variables) and  exp(beta[t]) = mb * 2^eb  (beta = blank variable);
 //  * emissions are kept as linear probabilities P[b,t,c] (frames past the utterance end:
 //    P = 0 except column 0 = 1, the linear image of ctc.py:57-61);
-//  * ctc_score_step: thread <-> token c of one utterance, ALL beams of the utterance in
-//    registers, frames walked sequentially; the recurrences
-//        Rnb[t] = (Rnb[t-1] + phi[t-1]) * P_c[t],   Rb[t] = (Rnb[t-1] + Rb[t-1]) * P_blank[t],
-//        Psi   += phi[t-1] * P_c[t]
-//    run on mantissas with a per-thread integer exponent that is re-based with ldexp/frexp
-//    every frame (a scaled forward algorithm with power-of-two scales: exact scaling, no
-//    transcendental in the loop).  The emission row P[b,t,:] is read ONCE per step and
-//    utterance (coalesced along V): algorithmic traffic T*V*4 B per utterance per step.
+//  * ctc_score_step: the score of extending prefix g by token c needs only g's state,
+//        psi(g.c) = log( r_init + sum_t phi_g[t-1] * P_c[t] ),
+//    so a thread (<-> token c of one utterance, ALL beams of the utterance in registers) walks the
+//    frames once, accumulating mantissas under a per-thread integer exponent that is re-based with
+//    ldexp (a scaled sum with power-of-two scales: exact scaling, no transcendental in the loop).
+//    The emission row P[b,t,:] is read ONCE per step and utterance (coalesced along V):
+//    algorithmic traffic T*V*4 B per utterance per step.
 //  * ctc_advance: after the beam top-k picked (parent, token) for each new hypothesis, the
-//    same recurrence for that single pair yields the new per-frame state (the reference
-//    gathers it out of the materialised tensor, ctc.py:243-295).
+//    forward recurrences
+//        Rnb[t] = (Rnb[t-1] + phi[t-1]) * P_c[t],   Rb[t] = (Rnb[t-1] + Rb[t-1]) * P_blank[t]
+//    are run for that single pair (block-float, re-normalised with frexp every frame) to obtain
+//    the survivor's per-frame state (the reference gathers it out of the materialised tensor,
+//    ctc.py:243-295).
 // Values the reference represents with its finite -1e20 sentinel (ctc.py:53) are exact
 // zeros here and map back to -1e20 whenever a log-domain number leaves the kernels.
 #include "common.h"
@@ -29,15 +31,12 @@ namespace {
 
 constexpr float kNeg = -1e20f;
 constexpr int kNegE = -(1 << 20);  // exponent of an exact zero
-constexpr int kBT = 16;            // beams held in registers per thread
 constexpr int kHead = 24;          // head-room (bits) kept above the incoming phi term
 
 struct BF {  // exp(gamma) = mg * 2^eg, exp(beta) = mb * 2^eb   (16 bytes per (hypothesis, frame))
   float mg, mb;
   int eg, eb;
 };
-
-__device__ __forceinline__ int fexp(float x) { return x > 0.0f ? ilogbf(x) + 1 : 0; }  // x = f * 2^k, f in [0.5,1)
 
 // natural log of m * 2^e (m >= 0) in f64, rounded once
 __device__ __forceinline__ float bf_log(float m, int e) {
@@ -95,97 +94,91 @@ __global__ void __launch_bounds__(256) ctc_init_kernel(const float* __restrict__
 }
 
 struct CtcStepArgs {
-  const float* P;           // [B,T,V] masked linear posteriors
-  const BF* st;             // [n_bh,T] state of each hypothesis' prefix
-  const float* psi_prev;    // [n_bh]
   const int32_t* last_tok;  // [n_bh]
   const int32_t* enc_len;   // [B]
-  const float* am;          // [n_bh,V] acoustic-model log-probs (already * attn_weight)
-  float* comb;              // [n_bh,V] out: am' + w * (psi - psi_prev)
-  float* psi;               // [n_bh,V] out
   int B, T, V, beam, prefix_len, blank, eos;
   float weight;
   // modifications of the AM scores applied before the scorer (seq2seq.py:995-1017, scorer.py:1250)
   int eos_floor;            // 1: step < min_decode_steps -> am[eos] = minus_inf
   int use_eos_threshold;
   float eos_threshold, minus_inf;
-  const float* am_max;      // [n_bh] max over V of am (only when use_eos_threshold)
 };
 
-__global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a) {
+// P [B,T,V] masked linear posteriors; st [n_bh,T] state of each hypothesis' prefix (uniform per
+// workgroup: fetched through the scalar cache); am [n_bh,V] acoustic log-probs (already * attn
+// weight); outputs comb = am' + w * (psi - psi_prev) and psi, both [n_bh,V].
+template <int NB>
+__global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, const float* __restrict__ P,
+                                                             const BF* __restrict__ st,
+                                                             const float* __restrict__ psi_prev,
+                                                             const float* __restrict__ am,
+                                                             const float* __restrict__ am_max,
+                                                             float* __restrict__ comb, float* __restrict__ psi_out) {
   const int b = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   const bool c_ok = c < a.V;
   const int cc = c_ok ? c : a.V - 1;
   const int T = a.T, V = a.V;
   const int start = a.prefix_len > 1 ? a.prefix_len : 1;
-  const float* Pb = a.P + (size_t)b * T * V;
+  const float* Pb = P + (size_t)b * T * V;
   const int last_frame = a.enc_len[b] - 1;
 
-  for (int j0 = 0; j0 < a.beam; j0 += kBT) {
-    const int nb = min(kBT, a.beam - j0);
-    float mnb[kBT], mbl[kBT], mps[kBT];
-    int E[kBT], Eps[kBT];
-    bool same[kBT];
+  for (int j0 = 0; j0 < a.beam; j0 += NB) {
+    const int nb = min(NB, a.beam - j0);
+    // The prefix score of h = g.c needs only g's state:  psi = log( r_init + sum_t phi_g[t-1] * P_c[t] )
+    // (ctc.py:212-229); the forward variables of h itself are produced later, for the survivors
+    // only, by ctc_advance.  Block-float accumulator: value = mps * 2^Eps.
+    float mps[NB];
+    int Eps[NB];
+    bool same[NB];
     const float p0 = Pb[cc];
 #pragma unroll
-    for (int j = 0; j < kBT; ++j) {
-      // r[start-1]: x[0] (non-blank) at the very first step, nothing otherwise (ctc.py:168-172)
+    for (int j = 0; j < NB; ++j) {
+      // psi_init = r[start-1][nb]: x[0] (non-blank) at the very first step, nothing otherwise (ctc.py:168-172,212)
       const bool first = a.prefix_len == 0 && p0 > 0.0f;
-      mnb[j] = first ? p0 : 0.0f;
-      mbl[j] = 0.0f;
-      E[j] = first ? 0 : kNegE;
-      mps[j] = mnb[j];  // psi_init = r[start-1][nb]
-      Eps[j] = E[j];
+      mps[j] = first ? p0 : 0.0f;
+      Eps[j] = first ? 0 : kNegE;
       same[j] = j < nb && a.last_tok[b * a.beam + j0 + j] == cc;
     }
+    // Rows of the state table used by this beam tile; beams past the tile's end shadow its last
+    // beam (computed redundantly, never stored) so that the frame loop carries no branches.
+    const BF* sb[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) sb[j] = st + ((size_t)b * a.beam + j0 + min(j, nb - 1)) * T;
     for (int t = start; t < T; ++t) {
       const float p_nb = Pb[(size_t)t * V + cc];
-      const float p_b = Pb[(size_t)t * V + a.blank];
+      BF s[NB];
 #pragma unroll
-      for (int j = 0; j < kBT; ++j) {
-        if (j < nb) {
-          const BF s = a.st[((size_t)b * a.beam + j0 + j) * T + (t - 1)];
-          const float mphi = same[j] ? s.mb : s.mg;
-          const int ephi = same[j] ? s.eb : s.eg;
-          // forward variables on the common exponent E2
-          const int E2 = max(E[j], ephi - kHead);
-          const float x_nb = ldexpf(mnb[j], E[j] - E2);
-          const float x_b = ldexpf(mbl[j], E[j] - E2);
-          const float ph = ldexpf(mphi, ephi - E2);
-          const float n_nb = (x_nb + ph) * p_nb;
-          const float n_b = (x_nb + x_b) * p_b;
-          const float sum = n_nb + n_b;
-          const int k = fexp(sum);
-          mnb[j] = ldexpf(n_nb, -k);
-          mbl[j] = ldexpf(n_b, -k);
-          E[j] = sum > 0.0f ? E2 + k : kNegE;
-          // psi += phi[t-1] * P_c[t]
-          const int P2 = max(Eps[j], ephi - kHead);
-          mps[j] = ldexpf(mps[j], Eps[j] - P2) + ldexpf(mphi, ephi - P2) * p_nb;
-          Eps[j] = P2;
-        }
+      for (int j = 0; j < NB; ++j) s[j] = sb[j][t - 1];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        // phi = beta for the token that repeats the prefix' last token, gamma otherwise (ctc.py:175-186)
+        const float mphi = same[j] ? s[j].mb : s[j].mg;
+        const int ephi = same[j] ? s[j].eb : s[j].eg;
+        const int P2 = max(Eps[j], ephi - kHead);
+        mps[j] = fmaf(sbk::fast_ldexp(mphi, ephi - P2), p_nb, sbk::fast_ldexp(mps[j], Eps[j] - P2));
+        Eps[j] = P2;
       }
     }
     if (!c_ok) continue;
 #pragma unroll
-    for (int j = 0; j < kBT; ++j) {
+    for (int j = 0; j < NB; ++j) {
       if (j < nb) {
         const int n = b * a.beam + j0 + j;
         float psi = bf_log(mps[j], Eps[j]);
         if (c == a.eos) {  // psi[eos] = log-sum of the prefix' own variables at the last frame (ctc.py:232-235)
-          const BF s = a.st[(size_t)n * T + last_frame];
+          const BF s = st[(size_t)n * T + last_frame];
           psi = bf_log(s.mg, s.eg);
         }
         if (c == a.blank && a.eos != a.blank) psi = kNeg;
-        a.psi[(size_t)n * V + c] = psi;
-        float am = a.am[(size_t)n * V + c];
+        psi_out[(size_t)n * V + c] = psi;
+        float v = am[(size_t)n * V + c];
         if (c == a.eos) {
-          if (a.eos_floor) am = a.minus_inf;
-          if (a.use_eos_threshold && !(am > a.eos_threshold * a.am_max[n])) am = a.minus_inf;
+          if (a.eos_floor) v = a.minus_inf;
+          if (a.use_eos_threshold && !(v > a.eos_threshold * am_max[n])) v = a.minus_inf;
         }
-        if (c == a.blank) am = kNeg;
-        a.comb[(size_t)n * V + c] = am + (psi - a.psi_prev[n]) * a.weight;
+        if (c == a.blank) v = kNeg;
+        comb[(size_t)n * V + c] = v + (psi - psi_prev[n]) * a.weight;
       }
     }
   }
@@ -241,12 +234,12 @@ __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
     for (int t = start; t < T; ++t) {
       const int ephi = eph[t - 1];
       const int E2 = max(E, ephi - kHead);
-      const float x_nb = ldexpf(mnb, E - E2), x_b = ldexpf(mbl, E - E2), ph = ldexpf(mph[t - 1], ephi - E2);
+      const float x_nb = sbk::fast_ldexp(mnb, E - E2), x_b = sbk::fast_ldexp(mbl, E - E2), ph = sbk::fast_ldexp(mph[t - 1], ephi - E2);
       const float n_nb = (x_nb + ph) * pc[t], n_b = (x_nb + x_b) * pb[t];
       const float sum = n_nb + n_b;
-      const int k = fexp(sum);
-      mnb = ldexpf(n_nb, -k);
-      mbl = ldexpf(n_b, -k);
+      const int k = sbk::frexp_exp(sum);
+      mnb = sbk::fast_ldexp(n_nb, -k);
+      mbl = sbk::fast_ldexp(n_b, -k);
       E = sum > 0.0f ? E2 + k : kNegE;
       onb[t] = mnb;
       obl[t] = mbl;
@@ -257,10 +250,10 @@ __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
   for (int t = lane; t < T; t += 64) {
     BF s;
     const float g = onb[t] + obl[t];
-    const int kg = fexp(g), kb = fexp(obl[t]);
-    s.mg = g > 0.0f ? ldexpf(g, 1 - kg) : 0.0f;  // mantissa in [1,2)
+    const int kg = sbk::frexp_exp(g), kb = sbk::frexp_exp(obl[t]);
+    s.mg = g > 0.0f ? sbk::fast_ldexp(g, 1 - kg) : 0.0f;  // mantissa in [1,2)
     s.eg = g > 0.0f ? oe[t] + kg - 1 : kNegE;
-    s.mb = obl[t] > 0.0f ? ldexpf(obl[t], 1 - kb) : 0.0f;
+    s.mb = obl[t] > 0.0f ? sbk::fast_ldexp(obl[t], 1 - kb) : 0.0f;
     s.eb = obl[t] > 0.0f ? oe[t] + kb - 1 : kNegE;
     a.st_new[(size_t)n * T + t] = s;
   }
@@ -314,10 +307,19 @@ int ctc_score_step(const float* P, const float* state, const float* psi_prev, co
                    const int32_t* enc_len, const float* am, float* comb, float* psi, int B, int T, int V, int beam,
                    int prefix_len, int blank, int eos, float weight, int eos_floor, int use_thr, float thr,
                    float minus_inf, const float* am_max, hipStream_t st) {
-  CtcStepArgs a{P, reinterpret_cast<const BF*>(state), psi_prev, last_tok, enc_len, am, comb, psi, B, T, V, beam,
-                prefix_len, blank, eos, weight, eos_floor, use_thr, thr, minus_inf, am_max};
-  ProfScope prof("ctc_score_step", 14.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 12.0 * B * beam * V, st);
-  SBK_LAUNCH(ctc_score_step_kernel, dim3(cdiv(V, 256), B), dim3(256), 0, st, a);
+  CtcStepArgs a{last_tok, enc_len, B, T, V, beam, prefix_len, blank, eos, weight, eos_floor, use_thr, thr, minus_inf};
+  const BF* sp = reinterpret_cast<const BF*>(state);
+  ProfScope prof("ctc_score_step", 6.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 12.0 * B * beam * V, st);
+  dim3 grid(cdiv(V, 256), B), block(256);
+  if (beam == 1) {
+    SBK_LAUNCH((ctc_score_step_kernel<1>), grid, block, 0, st, a, P, sp, psi_prev, am, am_max, comb, psi);
+  } else if (beam <= 4) {
+    SBK_LAUNCH((ctc_score_step_kernel<4>), grid, block, 0, st, a, P, sp, psi_prev, am, am_max, comb, psi);
+  } else if (beam <= 10) {
+    SBK_LAUNCH((ctc_score_step_kernel<10>), grid, block, 0, st, a, P, sp, psi_prev, am, am_max, comb, psi);
+  } else {
+    SBK_LAUNCH((ctc_score_step_kernel<16>), grid, block, 0, st, a, P, sp, psi_prev, am, am_max, comb, psi);
+  }
   return launch_status("ctc_score_step");
 }
 

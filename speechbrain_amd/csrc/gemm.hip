@@ -135,23 +135,25 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(Gem
 // ---------------------------------------------------------------------------
 // Skinny GEMM for the decoder steps (M = beams x utterances, a few hundred rows).
 // With so few rows an LDS-tiled workgroup grid cannot fill 256 CUs, and the
-// weights (L2/MALL resident) dominate traffic.  Here every WAVE owns one
-// (TM*32) x 32 output tile and one K slice: operands go straight from L2 into
-// registers as 16-byte runs (lane (r, half) reads the `half` side of a 32-float
-// chunk of row r, the two k-slices of the 32x32x2 MFMA are fed from the two
-// halves), there is no LDS and no barrier, and K is split across waves so the
-// grid has a few thousand independent waves.  Split-K partials are combined by
-// a second, deterministic kernel that also applies the epilogue.
+// weights (L2/MALL resident) dominate traffic.  Here a workgroup owns one
+// (TM*32) x 32 output tile and its 4 waves own 4 K slices of it: operands go
+// straight from L2 into registers as 16-byte runs (lane (r, half) reads the
+// `half` side of a 32-float chunk of row r; the two k-slices of the 32x32x2
+// MFMA are fed from the two halves), double-buffered in registers, no LDS and
+// no barrier in the main loop.  The four partial tiles meet in LDS and wave 0
+// applies the epilogue (fixed summation order => run-to-run deterministic).
+// For long K (FFN2) gridDim.y adds a second, global split whose partial tiles
+// are combined by splitk_reduce_kernel.
 template <int TM>
-__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __restrict__ partial, int SK, int kper) {
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __restrict__ partial, int kper) {
   constexpr int KC = 32;  // floats per row per chunk (16 per lane half)
-  const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int tiles_n = (g.N + 31) / 32, tiles_m = (g.M + TM * 32 - 1) / (TM * 32);
-  if (wid >= tiles_n * tiles_m * SK) return;
-  const int nt = wid % tiles_n, mt = (wid / tiles_n) % tiles_m, ks = wid / (tiles_n * tiles_m);
+  __shared__ float red[3][TM][32][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles_n = (g.N + 31) / 32;
+  const int nt = blockIdx.x % tiles_n, mt = blockIdx.x / tiles_n;
   const int r = lane & 31, half = lane >> 5;
-  const int k_begin = ks * kper, k_end = min(g.K, k_begin + kper);
+  const int ks = blockIdx.y * 4 + wave;
+  const int k_begin = min(g.K, ks * kper), k_end = min(g.K, k_begin + kper);
   const float* wrow = g.W + (size_t)min(nt * 32 + r, g.N - 1) * g.ldw + half * (KC / 2);
   const float* arow[TM];
 #pragma unroll
@@ -186,7 +188,7 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __r
     }
   };
   // register double buffering: the loads of chunk k+1 are in flight under the MFMAs of chunk k
-  load(a0, w0, k_begin);
+  if (k_begin < k_end) load(a0, w0, k_begin);
   for (int k = k_begin; k < k_end; k += 2 * KC) {
     if (k + KC < k_end) load(a1, w1, k + KC);
     compute(a0, w0);
@@ -196,30 +198,34 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __r
     }
   }
 
-  const int col = nt * 32 + r;
-  if (col >= g.N) return;
-  if (SK > 1) {
-    float* P = partial + (size_t)ks * g.M * g.N;
+  if (wave > 0) {
 #pragma unroll
     for (int t = 0; t < TM; ++t)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = mt * TM * 32 + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-        if (row < g.M) P[(size_t)row * g.N + col] = acc[t][q];
-      }
-    return;
+      for (int q = 0; q < 16; ++q) red[wave - 1][t][(q & 3) + 8 * (q >> 2) + 4 * half][r] = acc[t][q];
   }
-  const float bv = g.bias ? g.bias[col] : 0.0f;
+  __syncthreads();
+  if (wave > 0) return;
+  const int col = nt * 32 + r;
+  const bool to_partial = gridDim.y > 1;
+  const float bv = (!to_partial && g.bias && col < g.N) ? g.bias[col] : 0.0f;
+  float* P = partial + (size_t)blockIdx.y * g.M * g.N;
 #pragma unroll
   for (int t = 0; t < TM; ++t)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int row = mt * TM * 32 + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-      if (row >= g.M) continue;
-      float v = apply_act(acc[t][q] + bv, g.act) * g.alpha;
-      if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
-      if (g.R) v += g.R[(size_t)row * g.ldr + col];
-      g.C[(size_t)row * g.ldc + col] = v;
+      const int rr = (q & 3) + 8 * (q >> 2) + 4 * half;
+      const int row = mt * TM * 32 + t * 32 + rr;
+      const float sum = ((acc[t][q] + red[0][t][rr][r]) + red[1][t][rr][r]) + red[2][t][rr][r];
+      if (row >= g.M || col >= g.N) continue;
+      if (to_partial) {
+        P[(size_t)row * g.N + col] = sum;
+      } else {
+        float v = apply_act(sum + bv, g.act) * g.alpha;
+        if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
+        if (g.R) v += g.R[(size_t)row * g.ldr + col];
+        g.C[(size_t)row * g.ldc + col] = v;
+      }
     }
 }
 
@@ -263,27 +269,31 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
                int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq,
                float* ws, size_t ws_floats, hipStream_t st) {
   if (M == 0 || N == 0) return 0;
-  const bool skinny_ok = M <= 512 && K % 64 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
+  const bool skinny_ok = M <= 512 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
   if (!skinny_ok) return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
   GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
-  const int TM = M > 32 ? 2 : 1;
+  // 64-row tiles when that still yields >= 256 workgroups, else 32-row tiles
+  const int TM = (M > 32 && cdiv(N, 32) * cdiv(M, 64) >= 256) ? 2 : 1;
   const int tiles = cdiv(N, 32) * cdiv(M, TM * 32);
-  int SK = 1;
-  if (ws) {  // enough independent waves for ~2 per SIMD, at least 64 of K per slice
-    while (K % (SK * 2 * 64) == 0 && tiles * SK < 2048 && (size_t)(SK * 2) * M * N <= ws_floats) SK *= 2;
+  // global split only for long K and only while the partial tiles stay small (<= ws)
+  int SKg = 1;
+  if (ws) {
+    while (K / (4 * SKg) > 128 && K % (4 * SKg * 2 * 32) == 0 && tiles * SKg < 1024 &&
+           (size_t)(SKg * 2) * M * N <= ws_floats)
+      SKg *= 2;
   }
-  const int kper = K / SK;
+  const int kper = cdiv(cdiv(K, 4 * SKg), 32) * 32;
   ProfScope prof("gemm_skinny", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
-  dim3 grid(cdiv(tiles * SK, 4)), block(256);
+  dim3 grid(tiles, SKg), block(256);
   if (TM == 2) {
-    SBK_LAUNCH((gemm_skinny_kernel<2>), grid, block, 0, st, g, ws, SK, kper);
+    SBK_LAUNCH((gemm_skinny_kernel<2>), grid, block, 0, st, g, ws, kper);
   } else {
-    SBK_LAUNCH((gemm_skinny_kernel<1>), grid, block, 0, st, g, ws, SK, kper);
+    SBK_LAUNCH((gemm_skinny_kernel<1>), grid, block, 0, st, g, ws, kper);
   }
   int rc = launch_status("gemm_skinny");
-  if (rc || SK == 1) return rc;
+  if (rc || SKg == 1) return rc;
   const size_t total = (size_t)M * N;
-  SBK_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, g, (const float*)ws, SK);
+  SBK_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, g, (const float*)ws, SKg);
   return launch_status("splitk_reduce");
 }
 

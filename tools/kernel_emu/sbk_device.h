@@ -148,6 +148,12 @@ static inline int shfl_xor(int v, int m) { return shfl_idx_(v, sbk_emu::cur().la
 static inline float shfl(float v, int lane) { return shfl_idx_(v, lane); }
 static inline int shfl(int v, int lane) { return shfl_idx_(v, lane); }
 static inline void wave_sync() { sbk_emu::wave_barrier(); }
+static inline float fast_ldexp(float x, int e) {
+  if (e < -400) return x * 0.0f;
+  if (e > 400) e = 400;
+  return ldexpf(x, e);
+}
+static inline int frexp_exp(float x) { return (x != 0.0f && std::isfinite(x)) ? ilogbf(x) + 1 : 0; }
 static inline float wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
   return v;
