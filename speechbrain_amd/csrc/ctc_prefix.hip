@@ -213,12 +213,26 @@ __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
   const int b = n / a.beam, p = a.parent[n], c = a.token[n];
   const bool same = a.parent_last_tok[p] == c;
   const float* Pb = a.P + (size_t)b * T * a.V;
-  for (int t = lane; t < T; t += 64) {
-    pc[t] = Pb[(size_t)t * a.V + c];
-    pb[t] = Pb[(size_t)t * a.V + a.blank];
-    const BF s = a.st_old[(size_t)p * T + t];
-    mph[t] = same ? s.mb : s.mg;
-    eph[t] = same ? s.eb : s.eg;
+  for (int tb = 0; tb < T; tb += 256) {  // 4 frames per lane per round: 12 loads in flight per lane
+    float vpc[4], vpb[4];
+    BF vs[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = min(tb + u * 64 + lane, T - 1);
+      vpc[u] = Pb[(size_t)t * a.V + c];
+      vpb[u] = Pb[(size_t)t * a.V + a.blank];
+      vs[u] = a.st_old[(size_t)p * T + t];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = tb + u * 64 + lane;
+      if (t < T) {
+        pc[t] = vpc[u];
+        pb[t] = vpb[u];
+        mph[t] = same ? vs[u].mb : vs[u].mg;
+        eph[t] = same ? vs[u].eb : vs[u].eg;
+      }
+    }
   }
   __syncthreads();
   if (lane == 0) {
@@ -231,11 +245,21 @@ __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
       obl[t] = 0.0f;
       oe[t] = (t == start - 1) ? E : kNegE;
     }
+    // serial recurrence; the LDS operands of frame t+1 are requested before frame t is computed
+    float n_pc = start < T ? pc[start] : 0.0f, n_pb = start < T ? pb[start] : 0.0f, n_m = mph[start - 1];
+    int n_e = eph[start - 1];
     for (int t = start; t < T; ++t) {
-      const int ephi = eph[t - 1];
+      const float c_pc = n_pc, c_pb = n_pb, c_m = n_m;
+      const int ephi = n_e;
+      const int tn = min(t + 1, T - 1);
+      n_pc = pc[tn];
+      n_pb = pb[tn];
+      n_m = mph[t];
+      n_e = eph[t];
       const int E2 = max(E, ephi - kHead);
-      const float x_nb = sbk::fast_ldexp(mnb, E - E2), x_b = sbk::fast_ldexp(mbl, E - E2), ph = sbk::fast_ldexp(mph[t - 1], ephi - E2);
-      const float n_nb = (x_nb + ph) * pc[t], n_b = (x_nb + x_b) * pb[t];
+      const float x_nb = sbk::fast_ldexp(mnb, E - E2), x_b = sbk::fast_ldexp(mbl, E - E2);
+      const float ph = sbk::fast_ldexp(c_m, ephi - E2);
+      const float n_nb = (x_nb + ph) * c_pc, n_b = (x_nb + x_b) * c_pb;
       const float sum = n_nb + n_b;
       const int k = sbk::frexp_exp(sum);
       mnb = sbk::fast_ldexp(n_nb, -k);

@@ -42,22 +42,24 @@ struct SelfAttnArgs {
 
 // One wave per (hypothesis, head).  The 64 lanes form 4 position groups x 16 lanes; a group's 16
 // lanes read one K (or V) head row as 16-byte pieces (a 256-byte row per load instruction and
-// group, fully coalesced) and several rows are in flight at once, so the walk over the prefix is
-// a handful of dependent round trips instead of one per position.
+// group, fully coalesced).  The ancestry slots are fetched once into LDS, and rows are requested
+// four position-quads at a time, so the walk over the prefix costs a few dependent round trips
+// instead of two per position.
 __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
-  SBK_DYN_LDS(float, lds);  // [4 waves][Lmax_pad] scores -> probabilities
+  SBK_DYN_LDS(float, lds);  // [4 waves][2][Lmax_pad]: probabilities, slots
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = blockIdx.x * 4 + wave;
   const bool live = item < a.n * a.H;
   const int i = live ? item / a.H : 0, h = live ? item % a.H : 0;
   const int d = a.d, Dh = a.Dh, L = a.step + 1;
   const int lpad = ((a.Lmax + 63) / 64) * 64;
-  float* prob = lds + wave * lpad;
+  float* prob = lds + wave * 2 * lpad;
+  int* slot = reinterpret_cast<int*>(prob + lpad);
   const float* q = a.qkv + (size_t)i * 3 * d + h * Dh;
   const float* knew = q + d;
   const float* vnew = q + 2 * d;
   const int pg = lane >> 4, cq = lane & 15;  // position group, 16-byte piece of the head row
-  const int nchunk = (Dh + 63) / 64;         // 64-float chunks per head row (1 for Dh <= 64)
+  const bool vec = (Dh % 4 == 0) && Dh <= 64;
   // append this token's K/V head slice to the cache (slot = hypothesis index)
   if (live) {
     for (int c = lane; c < Dh; c += 64) {
@@ -66,25 +68,51 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
       a.vcache[o] = vnew[c];
     }
   }
+  for (int p = lane; p < a.step; p += 64) slot[p] = a.kv_slot[(size_t)i * a.Lmax + p];
+  sbk::wave_sync();
+  const size_t head_off = (size_t)h * Dh;
+  auto krow = [&](int p) { return (p == a.step) ? knew : a.kcache + ((size_t)p * a.nslot + slot[p]) * d + head_off; };
+  auto vrow = [&](int p) { return (p == a.step) ? vnew : a.vcache + ((size_t)p * a.nslot + slot[p]) * d + head_off; };
+  const bool piece = vec && cq * 4 < Dh;
+  float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (piece) {
+    q4 = *reinterpret_cast<const float4*>(q + cq * 4);
+    q4.x *= a.scale; q4.y *= a.scale; q4.z *= a.scale; q4.w *= a.scale;
+  }
   // scores
-  for (int p0 = 0; p0 < L; p0 += 4) {
-    const int p = p0 + pg;
-    float s = 0.0f;
-    if (p < L) {
-      const float* kp = (p == a.step) ? knew : a.kcache + ((size_t)p * a.nslot + a.kv_slot[(size_t)i * a.Lmax + p]) * d + h * Dh;
-      for (int ch = 0; ch < nchunk; ++ch) {
+  for (int p0 = 0; p0 < L; p0 += 16) {
+    float sc[4];
+    if (vec) {
+      float4 kv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = ch * 64 + cq * 4 + e;
-          if (c < Dh) s = fmaf(q[c] * a.scale, kp[c], s);
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + 4 * u + pg;
+        kv[u] = (p < L && piece) ? *reinterpret_cast<const float4*>(krow(p) + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sc[u] = (q4.x * kv[u].x + q4.y * kv[u].y) + (q4.z * kv[u].z + q4.w * kv[u].w);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + 4 * u + pg;
+        float s = 0.0f;
+        if (p < L) {
+          const float* kp = krow(p);
+          for (int c = cq; c < Dh; c += 16) s = fmaf(q[c] * a.scale, kp[c], s);
         }
+        sc[u] = s;
       }
     }
-    s += sbk::shfl_xor(s, 1);
-    s += sbk::shfl_xor(s, 2);
-    s += sbk::shfl_xor(s, 4);
-    s += sbk::shfl_xor(s, 8);
-    if (p < L && cq == 0) prob[p] = s;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float s = sc[u];
+      s += sbk::shfl_xor(s, 1);
+      s += sbk::shfl_xor(s, 2);
+      s += sbk::shfl_xor(s, 4);
+      s += sbk::shfl_xor(s, 8);
+      const int p = p0 + 4 * u + pg;
+      if (p < L && cq == 0) prob[p] = s;
+    }
   }
   sbk::wave_sync();
   float m = -INFINITY;
@@ -100,139 +128,202 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
   for (int p = lane; p < L; p += 64) prob[p] = prob[p] / sum;
   sbk::wave_sync();
   // context: each position group accumulates its positions, then the 4 groups are summed
-  for (int ch = 0; ch < nchunk; ++ch) {
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int p0 = 0; p0 < L; p0 += 4) {
-      const int p = p0 + pg;
-      if (p < L) {
-        const float* vp = (p == a.step) ? vnew : a.vcache + ((size_t)p * a.nslot + a.kv_slot[(size_t)i * a.Lmax + p]) * d + h * Dh;
-        const float w = prob[p];
+  if (vec) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p0 = 0; p0 < L; p0 += 16) {
+      float4 vv[4];
+      float w[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = ch * 64 + cq * 4 + e;
-          if (c < Dh) acc[e] = fmaf(w, vp[c], acc[e]);
-        }
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + 4 * u + pg;
+        const bool ok = p < L && piece;
+        vv[u] = ok ? *reinterpret_cast<const float4*>(vrow(p) + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        w[u] = ok ? prob[p] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc.x = fmaf(w[u], vv[u].x, acc.x);
+        acc.y = fmaf(w[u], vv[u].y, acc.y);
+        acc.z = fmaf(w[u], vv[u].z, acc.z);
+        acc.w = fmaf(w[u], vv[u].w, acc.w);
       }
     }
+    float o[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      acc[e] += sbk::shfl_xor(acc[e], 16);
-      acc[e] += sbk::shfl_xor(acc[e], 32);
-      const int c = ch * 64 + cq * 4 + e;
-      if (live && pg == 0 && c < Dh) a.out[(size_t)i * d + h * Dh + c] = acc[e];
+      o[e] += sbk::shfl_xor(o[e], 16);
+      o[e] += sbk::shfl_xor(o[e], 32);
+    }
+    if (live && pg == 0 && piece) *reinterpret_cast<float4*>(a.out + (size_t)i * d + head_off + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+    for (int c0 = 0; c0 < Dh; c0 += 16) {
+      const int c = c0 + cq;
+      float acc = 0.0f;
+      for (int p = pg; p < L; p += 4)
+        if (c < Dh) acc = fmaf(prob[p], vrow(p)[c], acc);
+      acc += sbk::shfl_xor(acc, 16);
+      acc += sbk::shfl_xor(acc, 32);
+      if (live && pg == 0 && c < Dh) a.out[(size_t)i * d + head_off + c] = acc;
     }
   }
 }
 
 // ---------------------------------------------------------------- cross attention, all beams of an utterance
-constexpr int kQT = 16;  // queries (beams) served per workgroup
+constexpr int kQT = 16;   // queries (beams) served per workgroup
+constexpr int kFC = 128;  // memory frames per workgroup (flash-decoding style split of the memory)
 
 struct CrossAttnArgs {
   const float* q;         // [n,d]   n = B*beam, hypothesis i belongs to utterance i / beam
   const float* kv;        // [B,T,2d] per frame: K (d) then V (d), projected once per utterance
   const int32_t* enc_len; // [B]
   float* out;             // [n,d]
-  int B, T, d, H, Dh, beam, SP;
+  float* part;            // [B,H,NS,kQT,DH+2] partial (context, max, sum) when NS > 1
+  int B, T, d, H, Dh, beam, NS;
   float scale;
 };
 
+// grid (NS, H, B x query tiles).  A workgroup scores kFC memory frames against every beam of one
+// (utterance, head): thread <-> (frame, beam parity), the K row is held in registers and reused by
+// the beams; probabilities go through LDS; the context pass reads each V row once for all beams.
+// With NS > 1 the workgroup emits (un-normalised context, running max, sum) and cross_merge_kernel
+// combines the splits exactly like an online softmax.
 template <int DH>
 __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
-  SBK_DYN_LDS(float, lds);
-  float* qs = lds;                    // [kQT][DH]   scaled queries
-  float* S = qs + kQT * DH;           // [kQT][SP]   scores -> probabilities
-  float* red = S + kQT * a.SP;        // [4][kQT][DH] partial contexts
+  __shared__ float qs[kQT][DH];
+  __shared__ float S[kQT][kFC + 1];
+  __shared__ float red[4][kQT][DH];
+  __shared__ float mx[kQT], sm[kQT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q0 = blockIdx.x * kQT, h = blockIdx.y, b = blockIdx.z;
+  const int split = blockIdx.x, h = blockIdx.y;
+  const int qtiles = (a.beam + kQT - 1) / kQT;
+  const int b = blockIdx.z / qtiles, q0 = (blockIdx.z % qtiles) * kQT;
   const int nq = min(kQT, a.beam - q0);
-  const int T = a.T, d = a.d, SP = a.SP;
+  const int T = a.T, d = a.d;
   const int klen = min(max(a.enc_len[b], 1), T);
+  const int per = ((klen + a.NS - 1) / a.NS + 3) & ~3;
+  const int t0 = split * per, t1 = min(klen, t0 + per);
+  const int nf = max(0, t1 - t0);
   const float* kvb = a.kv + (size_t)b * T * 2 * d + h * DH;
 
   for (int idx = tid; idx < kQT * DH; idx += 256) {
     const int j = idx / DH, c = idx % DH;
-    qs[idx] = j < nq ? a.q[((size_t)b * a.beam + q0 + j) * d + h * DH + c] * a.scale : 0.0f;
+    qs[j][c] = j < nq ? a.q[((size_t)b * a.beam + q0 + j) * d + h * DH + c] * a.scale : 0.0f;
   }
   __syncthreads();
-  // scores: thread <-> memory frame, K row held in registers and reused by every beam
-  for (int t = tid; t < klen; t += 256) {
-    float kr[DH];
-    const float* kp = kvb + (size_t)t * 2 * d;
+  // scores: per needs <= kFC (checked by the launcher)
+  {
+    const int f = tid & (kFC - 1), par = tid / kFC;  // 2 threads per frame, beams split by parity
+    if (f < nf) {
+      float kr[DH];
+      const float* kp = kvb + (size_t)(t0 + f) * 2 * d;
 #pragma unroll
-    for (int c = 0; c < DH; ++c) kr[c] = kp[c];
-    for (int j = 0; j < nq; ++j) {
-      float s = 0.0f;
+      for (int c = 0; c < DH; ++c) kr[c] = kp[c];
+      for (int j = par; j < nq; j += 256 / kFC) {
+        float s = 0.0f;
 #pragma unroll
-      for (int c = 0; c < DH; ++c) s = fmaf(qs[j * DH + c], kr[c], s);
-      S[j * SP + t] = s;
+        for (int c = 0; c < DH; ++c) s = fmaf(qs[j][c], kr[c], s);
+        S[j][f] = s;
+      }
     }
   }
   __syncthreads();
-  // softmax over valid frames, one wave per query row
-  for (int j = wave; j < nq; j += 4) {
-    float* Sr = S + j * SP;
+  for (int j = wave; j < nq; j += 4) {  // one wave per query row
     float m = -INFINITY;
-    for (int t = lane; t < klen; t += 64) m = fmaxf(m, Sr[t]);
+    for (int f = lane; f < nf; f += 64) m = fmaxf(m, S[j][f]);
     m = sbk::wave_max(m);
     float sum = 0.0f;
-    for (int t = lane; t < klen; t += 64) {
-      const float e = expf(Sr[t] - m);
-      Sr[t] = e;
+    for (int f = lane; f < nf; f += 64) {
+      const float e = expf(S[j][f] - m);
+      S[j][f] = e;
       sum += e;
     }
     sum = sbk::wave_sum(sum);
-    for (int t = lane; t < klen; t += 64) Sr[t] = Sr[t] / sum;
+    if (a.NS == 1)
+      for (int f = lane; f < nf; f += 64) S[j][f] = S[j][f] / sum;
+    if (lane == 0) {
+      mx[j] = m;
+      sm[j] = sum;
+    }
   }
   __syncthreads();
-  // context: wave <-> quarter of the frames, lane <-> channel; V row read once for all beams.
-  // Rows are fetched 8 at a time so that 8 loads are in flight per lane.
-  {
+  {  // context: wave <-> quarter of the frames, lane <-> channel; 8 V rows in flight per lane
     float acc[kQT];
 #pragma unroll
     for (int j = 0; j < kQT; ++j) acc[j] = 0.0f;
     const int c = lane;
     if (c < DH) {
-      const float* vcol = kvb + d + c;
-      for (int t0 = wave; t0 < klen; t0 += 32) {
+      const float* vcol = kvb + (size_t)t0 * 2 * d + d + c;
+      for (int f0 = wave; f0 < nf; f0 += 32) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int t = t0 + 4 * u;
-          v[u] = t < klen ? vcol[(size_t)t * 2 * d] : 0.0f;
+          const int f = f0 + 4 * u;
+          v[u] = f < nf ? vcol[(size_t)f * 2 * d] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int t = t0 + 4 * u;
-          if (t < klen) {
+          const int f = f0 + 4 * u;
+          if (f < nf) {
 #pragma unroll
-            for (int j = 0; j < kQT; ++j) acc[j] = fmaf(S[j * SP + t], v[u], acc[j]);
+            for (int j = 0; j < kQT; ++j) acc[j] = fmaf(S[j][f], v[u], acc[j]);
           }
         }
       }
 #pragma unroll
-      for (int j = 0; j < kQT; ++j) red[(wave * kQT + j) * DH + c] = acc[j];
+      for (int j = 0; j < kQT; ++j) red[wave][j][c] = acc[j];
     }
   }
   __syncthreads();
   for (int idx = tid; idx < nq * DH; idx += 256) {
     const int j = idx / DH, c = idx % DH;
-    const float v = (red[(0 * kQT + j) * DH + c] + red[(1 * kQT + j) * DH + c]) +
-                    (red[(2 * kQT + j) * DH + c] + red[(3 * kQT + j) * DH + c]);
-    a.out[((size_t)b * a.beam + q0 + j) * d + h * DH + c] = v;
+    const float v = (red[0][j][c] + red[1][j][c]) + (red[2][j][c] + red[3][j][c]);
+    if (a.NS == 1) {
+      a.out[((size_t)b * a.beam + q0 + j) * d + h * DH + c] = v;
+    } else {
+      float* pp = a.part + ((((size_t)b * a.H + h) * a.NS + split) * a.beam + q0 + j) * (DH + 2);
+      pp[c] = v;
+      if (c == 0) {
+        pp[DH] = nf > 0 ? mx[j] : -INFINITY;
+        pp[DH + 1] = nf > 0 ? sm[j] : 0.0f;
+      }
+    }
+  }
+}
+
+// out[i, h*DH + c] = sum_s e^{m_s - M} o_s[c] / sum_s e^{m_s - M} l_s
+__global__ void __launch_bounds__(256) cross_merge_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                          int H, int NS, int beam, int DH, int d) {
+  const int i = blockIdx.x;  // hypothesis
+  const int b = i / beam, j = i % beam;
+  for (int e = threadIdx.x; e < H * DH; e += 256) {
+    const int h = e / DH, c = e % DH;
+    const float* pp = part + ((((size_t)b * H + h) * NS) * beam + j) * (DH + 2);
+    const size_t stride = (size_t)beam * (DH + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < NS; ++s) M = fmaxf(M, pp[s * stride + DH]);
+    float num = 0.0f, den = 0.0f;
+    for (int s = 0; s < NS; ++s) {
+      const float l = pp[s * stride + DH + 1];
+      if (l > 0.0f) {
+        const float w = expf(pp[s * stride + DH] - M);
+        num = fmaf(w, pp[s * stride + c], num);
+        den = fmaf(w, l, den);
+      }
+    }
+    out[(size_t)i * d + h * DH + c] = num / den;
   }
 }
 
 template <int DH>
 int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
-  const size_t lds = ((size_t)kQT * DH + (size_t)kQT * a.SP + (size_t)4 * kQT * DH) * sizeof(float);
-  if (lds > 160 * 1024) return sbk::fail(SBK_EINVAL, "cross_attn: T=%d needs %zu B of LDS", a.T, lds);
-  if (lds > 64 * 1024) {
-    hipError_t e = SBK_ALLOW_DYN_LDS((cross_attn_step_kernel<DH>), lds);
-    if (e != hipSuccess) return sbk::fail((int)e, "cross_attn: cannot raise the LDS window");
-  }
+  const int qtiles = (a.beam + kQT - 1) / kQT;
   sbk::ProfScope prof("cross_attn_step", 4.0 * a.B * a.beam * (double)a.T * a.d, 8.0 * a.B * (double)a.T * a.d, st);
-  SBK_LAUNCH((cross_attn_step_kernel<DH>), dim3(sbk::cdiv(a.beam, kQT), a.H, a.B), dim3(256), lds, st, a);
-  return sbk::launch_status("cross_attn_step");
+  SBK_LAUNCH((cross_attn_step_kernel<DH>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
+  int rc = sbk::launch_status("cross_attn_step");
+  if (rc || a.NS == 1) return rc;
+  SBK_LAUNCH(cross_merge_kernel, dim3(a.B * a.beam), dim3(256), 0, st, (const float*)a.part, a.out, a.H, a.NS, a.beam,
+             DH, a.d);
+  return sbk::launch_status("cross_merge");
 }
 
 // ---------------------------------------------------------------- log-softmax over the vocabulary
@@ -275,18 +366,27 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
                    int H, int step, int nslot, int Lmax, hipStream_t st) {
   if (n == 0) return 0;
   SelfAttnArgs a{qkv, kcache, vcache, kv_slot, out, n, d, H, d / H, step, nslot, Lmax, 1.0f / sqrtf((float)(d / H))};
-  const size_t lds = (size_t)4 * (((Lmax + 63) / 64) * 64) * sizeof(float);
+  const size_t lds = (size_t)8 * (((Lmax + 63) / 64) * 64) * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "self_attn_step: Lmax=%d too long for the LDS window", Lmax);
   ProfScope prof("self_attn_step", 4.0 * n * d * (step + 1), 8.0 * n * d * (step + 1), st);
   SBK_LAUNCH(self_attn_step_kernel, dim3(cdiv(n * H, 4)), dim3(256), lds, st, a);
   return launch_status("self_attn_step");
 }
 
-int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, int B, int T, int d, int H,
-                    int beam, hipStream_t st) {
+// Number of memory splits used for T frames and floats of partial storage they need.
+int cross_attn_splits(int T) { return cdiv(T, kFC); }
+size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam) {
+  const int ns = cross_attn_splits(T);
+  return ns > 1 ? (size_t)B * H * ns * beam * (Dh + 2) : 0;
+}
+
+int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, float* part, int B, int T,
+                    int d, int H, int beam, hipStream_t st) {
   if (B == 0) return 0;
   const int Dh = d / H;
-  CrossAttnArgs a{q, kv, enc_len, out, B, T, d, H, Dh, beam, T + 1, 1.0f / sqrtf((float)Dh)};
+  const int NS = cross_attn_splits(T);
+  if (NS > 1 && !part) return fail(SBK_EINVAL, "cross_attn_step: T=%d needs a partial buffer", T);
+  CrossAttnArgs a{q, kv, enc_len, out, part, B, T, d, H, Dh, beam, NS, 1.0f / sqrtf((float)Dh)};
   switch (Dh) {
     case 64: return launch_cross<64>(a, st);
     case 36: return launch_cross<36>(a, st);

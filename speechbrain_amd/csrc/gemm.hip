@@ -144,65 +144,59 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(Gem
 // applies the epilogue (fixed summation order => run-to-run deterministic).
 // For long K (FFN2) gridDim.y adds a second, global split whose partial tiles
 // are combined by splitk_reduce_kernel.
-template <int TM>
-__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __restrict__ partial, int kper) {
+template <int NCH>  // 32-float K chunks fetched per batch (all of them in flight together)
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __restrict__ partial, int kper,
+                                                          int tiles_m, int tiles_n) {
   constexpr int KC = 32;  // floats per row per chunk (16 per lane half)
-  __shared__ float red[3][TM][32][33];
+  __shared__ float red[3][32][33];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tiles_n = (g.N + 31) / 32;
-  const int nt = blockIdx.x % tiles_n, mt = blockIdx.x / tiles_n;
+  // XCD-aware tile order: workgroup id = 8*q + x runs on XCD x (observed round-robin), so give XCD x
+  // the column tiles nt = x (mod 8): every weight row is then fetched into ONE XCD's L2 only.
+  int nt, mt;
+  {
+    const int id = blockIdx.x, x = id & 7, q = id >> 3;
+    const int nt8 = (tiles_n + 7) / 8;  // column tiles per XCD (last group may be ragged)
+    mt = q % tiles_m;
+    nt = x + 8 * (q / tiles_m);
+    if (q / tiles_m >= nt8 || nt >= tiles_n) return;  // uniform per workgroup: no barrier is skipped by a subset
+  }
   const int r = lane & 31, half = lane >> 5;
   const int ks = blockIdx.y * 4 + wave;
   const int k_begin = min(g.K, ks * kper), k_end = min(g.K, k_begin + kper);
   const float* wrow = g.W + (size_t)min(nt * 32 + r, g.N - 1) * g.ldw + half * (KC / 2);
-  const float* arow[TM];
-#pragma unroll
-  for (int t = 0; t < TM; ++t) arow[t] = g.A + (size_t)min(mt * TM * 32 + t * 32 + r, g.M - 1) * g.lda + half * (KC / 2);
+  const float* arow = g.A + (size_t)min(mt * 32 + r, g.M - 1) * g.lda + half * (KC / 2);
 
-  f32x16 acc[TM];
+  f32x16 acc;
 #pragma unroll
-  for (int t = 0; t < TM; ++t)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
 
-  float4 a0[TM][4], w0[4], a1[TM][4], w1[4];
-  auto load = [&](float4 (&a)[TM][4], float4 (&w)[4], int k) {
+  for (int k0 = k_begin; k0 < k_end; k0 += NCH * KC) {
+    float4 a[NCH][4], w[NCH][4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) w[v] = *reinterpret_cast<const float4*>(wrow + k + 4 * v);
+    for (int c = 0; c < NCH; ++c) {
+      const int k = min(k0 + c * KC, g.K - KC);  // chunks past the slice end re-read a valid chunk and are skipped below
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
+      for (int v = 0; v < 4; ++v) w[c][v] = *reinterpret_cast<const float4*>(wrow + k + 4 * v);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) a[t][v] = *reinterpret_cast<const float4*>(arow[t] + k + 4 * v);
-  };
-  auto compute = [&](const float4 (&a)[TM][4], const float4 (&w)[4]) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-#pragma unroll
-      for (int t = 0; t < TM; ++t) acc[t] = sbk::mfma_32x32x2(a[t][v].x, w[v].x, acc[t]);
-#pragma unroll
-      for (int t = 0; t < TM; ++t) acc[t] = sbk::mfma_32x32x2(a[t][v].y, w[v].y, acc[t]);
-#pragma unroll
-      for (int t = 0; t < TM; ++t) acc[t] = sbk::mfma_32x32x2(a[t][v].z, w[v].z, acc[t]);
-#pragma unroll
-      for (int t = 0; t < TM; ++t) acc[t] = sbk::mfma_32x32x2(a[t][v].w, w[v].w, acc[t]);
+      for (int v = 0; v < 4; ++v) a[c][v] = *reinterpret_cast<const float4*>(arow + k + 4 * v);
     }
-  };
-  // register double buffering: the loads of chunk k+1 are in flight under the MFMAs of chunk k
-  if (k_begin < k_end) load(a0, w0, k_begin);
-  for (int k = k_begin; k < k_end; k += 2 * KC) {
-    if (k + KC < k_end) load(a1, w1, k + KC);
-    compute(a0, w0);
-    if (k + KC < k_end) {
-      if (k + 2 * KC < k_end) load(a0, w0, k + 2 * KC);
-      compute(a1, w1);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (k0 + c * KC < k_end) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          acc = sbk::mfma_32x32x2(a[c][v].x, w[c][v].x, acc);
+          acc = sbk::mfma_32x32x2(a[c][v].y, w[c][v].y, acc);
+          acc = sbk::mfma_32x32x2(a[c][v].z, w[c][v].z, acc);
+          acc = sbk::mfma_32x32x2(a[c][v].w, w[c][v].w, acc);
+        }
+      }
     }
   }
 
   if (wave > 0) {
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) red[wave - 1][t][(q & 3) + 8 * (q >> 2) + 4 * half][r] = acc[t][q];
+    for (int q = 0; q < 16; ++q) red[wave - 1][(q & 3) + 8 * (q >> 2) + 4 * half][r] = acc[q];
   }
   __syncthreads();
   if (wave > 0) return;
@@ -211,22 +205,20 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __r
   const float bv = (!to_partial && g.bias && col < g.N) ? g.bias[col] : 0.0f;
   float* P = partial + (size_t)blockIdx.y * g.M * g.N;
 #pragma unroll
-  for (int t = 0; t < TM; ++t)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int rr = (q & 3) + 8 * (q >> 2) + 4 * half;
-      const int row = mt * TM * 32 + t * 32 + rr;
-      const float sum = ((acc[t][q] + red[0][t][rr][r]) + red[1][t][rr][r]) + red[2][t][rr][r];
-      if (row >= g.M || col >= g.N) continue;
-      if (to_partial) {
-        P[(size_t)row * g.N + col] = sum;
-      } else {
-        float v = apply_act(sum + bv, g.act) * g.alpha;
-        if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
-        if (g.R) v += g.R[(size_t)row * g.ldr + col];
-        g.C[(size_t)row * g.ldc + col] = v;
-      }
+  for (int q = 0; q < 16; ++q) {
+    const int rr = (q & 3) + 8 * (q >> 2) + 4 * half;
+    const int row = mt * 32 + rr;
+    const float sum = ((acc[q] + red[0][rr][r]) + red[1][rr][r]) + red[2][rr][r];
+    if (row >= g.M || col >= g.N) continue;
+    if (to_partial) {
+      P[(size_t)row * g.N + col] = sum;
+    } else {
+      float v = apply_act(sum + bv, g.act) * g.alpha;
+      if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
+      if (g.R) v += g.R[(size_t)row * g.ldr + col];
+      g.C[(size_t)row * g.ldc + col] = v;
     }
+  }
 }
 
 // C = epilogue(sum_ks partial[ks]) ; fixed summation order => run-to-run deterministic.
@@ -272,23 +264,23 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   const bool skinny_ok = M <= 512 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
   if (!skinny_ok) return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
   GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
-  // 64-row tiles when that still yields >= 256 workgroups, else 32-row tiles
-  const int TM = (M > 32 && cdiv(N, 32) * cdiv(M, 64) >= 256) ? 2 : 1;
-  const int tiles = cdiv(N, 32) * cdiv(M, TM * 32);
-  // global split only for long K and only while the partial tiles stay small (<= ws)
+  const int tiles_m = cdiv(M, 32), tiles_n = cdiv(N, 32);
+  // a second, global K split when the tile grid alone leaves SIMDs idle (needs `ws` for the partial tiles)
   int SKg = 1;
   if (ws) {
-    while (K / (4 * SKg) > 128 && K % (4 * SKg * 2 * 32) == 0 && tiles * SKg < 1024 &&
+    while (K / (4 * SKg) > 32 && K % (4 * SKg * 2 * 32) == 0 && tiles_m * tiles_n * SKg < 512 &&
            (size_t)(SKg * 2) * M * N <= ws_floats)
       SKg *= 2;
   }
   const int kper = cdiv(cdiv(K, 4 * SKg), 32) * 32;
   ProfScope prof("gemm_skinny", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
-  dim3 grid(tiles, SKg), block(256);
-  if (TM == 2) {
-    SBK_LAUNCH((gemm_skinny_kernel<2>), grid, block, 0, st, g, ws, kper);
+  dim3 grid(8 * tiles_m * cdiv(tiles_n, 8), SKg), block(256);
+  if (kper >= 128) {
+    SBK_LAUNCH((gemm_skinny_kernel<4>), grid, block, 0, st, g, ws, kper, tiles_m, tiles_n);
+  } else if (kper >= 64) {
+    SBK_LAUNCH((gemm_skinny_kernel<2>), grid, block, 0, st, g, ws, kper, tiles_m, tiles_n);
   } else {
-    SBK_LAUNCH((gemm_skinny_kernel<1>), grid, block, 0, st, g, ws, kper);
+    SBK_LAUNCH((gemm_skinny_kernel<1>), grid, block, 0, st, g, ws, kper, tiles_m, tiles_n);
   }
   int rc = launch_status("gemm_skinny");
   if (rc || SKg == 1) return rc;

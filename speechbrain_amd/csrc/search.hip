@@ -21,8 +21,9 @@ int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* 
               hipStream_t st);
 int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t* kv_slot, float* out, int n, int d,
                    int H, int step, int nslot, int Lmax, hipStream_t st);
-int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, int B, int T, int d, int H,
-                    int beam, hipStream_t st);
+int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, float* part, int B, int T,
+                    int d, int H, int beam, hipStream_t st);
+size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam);
 int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st);
 int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, float* psi_prev, int B, int T, int V,
                 int beam, int blank, hipStream_t st);
@@ -410,6 +411,7 @@ struct DecoderBufs {
   float *x, *h, *qkv, *ctx, *q, *ff, *logits;
   float* splitk;        // split-K partials of the skinny GEMMs
   size_t splitk_floats;
+  float* xpart;         // cross-attention split partials
   float* ckv[64];
   float *kcache[64], *vcache[64];
 };
@@ -425,6 +427,7 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
   d.logits = c.take<float>((size_t)n * W->vocab);
   d.splitk_floats = (size_t)8 * n * (size_t)(W->d_ffn > 3 * dm ? W->d_ffn : 3 * dm);
   d.splitk = c.take<float>(d.splitk_floats);
+  d.xpart = c.take<float>(sbk::cross_attn_partial_floats(B, T, W->nhead, dm / W->nhead, n / (B > 0 ? B : 1)) + 64);
   for (int l = 0; l < W->n_layers; ++l) {
     d.ckv[l] = c.take<float>((size_t)B * T * 2 * dm);
     d.kcache[l] = c.take<float>((size_t)Lmax * n * dm);
@@ -474,7 +477,7 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
     SBK_TRY(sbk::layernorm(d.x, L.ln2_g, L.ln2_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
     SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.ca_in_w, dm, L.ca_in_b, nullptr, 0, d.q, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr, 0,
                          d.splitk, d.splitk_floats, st));
-    SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, B, T, dm, H, beam, st));
+    SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, d.xpart, B, T, dm, H, beam, st));
     SBK_TRY(sbk::gemm_nt_ws(d.ctx, dm, L.ca_out_w, dm, L.ca_out_b, d.x, dm, d.x, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
                          0, d.splitk, d.splitk_floats, st));
     SBK_TRY(sbk::layernorm(d.x, L.ln3_g, L.ln3_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));

@@ -97,3 +97,22 @@ def test_waveform_to_tokens_vs_oracle(backend):
     hyps, _, _, _ = O.beam_search(enc, lens, sd, mc, O.SearchCfg(beam=4, ctc_weight=0.4))
     assert toks == hyps
     assert words == [" ".join(str(t) for t in h) for h in hyps]
+
+
+def test_decoder_long_memory_and_prefix(backend):
+    """KV-cached decoder vs the oracle's full-prefix decode with a memory longer than one
+    cross-attention split (T' > 128 frames) and a prefix longer than one self-attention batch."""
+    nat, dev = backend
+    g, mods = build("tiny_ctc", dev)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    d_model, nhead, d_ffn, n_enc, n_dec, vocab = [int(v) for v in g["cfg"][:6]]
+    cfg = O.ModelCfg(d_model=d_model, nhead=nhead, num_encoder_layers=n_enc, num_decoder_layers=n_dec, d_ffn=d_ffn,
+                     vocab=vocab)
+    gen = torch.Generator().manual_seed(77)
+    enc = torch.randn(2, 300, d_model, generator=gen)
+    enc_len = torch.tensor([300, 170], dtype=torch.int32)
+    tgt = torch.randint(0, vocab, (2, 21), generator=gen)
+    ref = O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")
+    h = nat.DecoderHandle(mods["Transformer"], mods["seq_lin"])
+    pred = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev))
+    assert float((pred.cpu() - ref).abs().max()) <= 5e-5
