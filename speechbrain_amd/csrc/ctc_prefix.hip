@@ -10,12 +10,15 @@
 //  * emissions are kept as linear probabilities P[b,t,c] (frames past the utterance end:
 //    P = 0 except column 0 = 1, the linear image of ctc.py:57-61);
 //  * ctc_score_step: the score of extending prefix g by token c needs only g's state,
-//        psi(g.c) = log( r_init + sum_t phi_g[t-1] * P_c[t] ),
-//    so a thread (<-> token c of one utterance, ALL beams of the utterance in registers) walks the
-//    frames once, accumulating mantissas under a per-thread integer exponent that is re-based with
-//    ldexp (a scaled sum with power-of-two scales: exact scaling, no transcendental in the loop).
+//        psi(g.c) = log( r_init + sum_t phi_g[t-1] * P_c[t] ),   phi = gamma (beta if c repeats g's last token)
+//    i.e. a [beams x T] . [T x V] product per utterance with an enormous dynamic range along T.
+//    The state tables therefore also carry the phi values pre-scaled per 32-frame segment
+//    (value * 2^-segment_exponent, exact power-of-two scaling); a thread (<-> token c of one
+//    utterance, ALL beams in registers) does ONE fma per (beam, frame) and folds each segment's
+//    partial sum into a block-float accumulator.  The repeated-token entries (one per
+//    hypothesis) are recomputed from the beta table by ctc_same_token_kernel.
 //    The emission row P[b,t,:] is read ONCE per step and utterance (coalesced along V):
-//    algorithmic traffic T*V*4 B per utterance per step.
+//    algorithmic traffic T*V*4 B per utterance per step -- the kernel is HBM/L2-bound.
 //  * ctc_advance: after the beam top-k picked (parent, token) for each new hypothesis, the
 //    forward recurrences
 //        Rnb[t] = (Rnb[t-1] + phi[t-1]) * P_c[t],   Rb[t] = (Rnb[t-1] + Rb[t-1]) * P_blank[t]
@@ -57,6 +60,34 @@ __device__ __forceinline__ void bf_exp(float x, float* m, int* e) {
   *e = (int)ip;
 }
 
+// Segment-scaled phi tables used by ctc_score_step: for hypothesis h and frame t,
+//   sg[h][t] = exp(gamma_h[t]) * 2^-seg_e[h][t/32],  sb[h][t] = exp(beta_h[t]) * 2^-seg_e[h][t/32]
+// with seg_e = the largest exponent inside the segment (so every entry is < 2).
+constexpr int kSeg = 32;
+__device__ __forceinline__ int nseg_of(int T) { return (T + kSeg - 1) / kSeg; }
+
+// One wave converts the BF rows of one hypothesis (already in global memory / LDS as `row`) into the
+// scaled tables.  `row(t)` returns the BF of frame t.
+template <typename Row>
+__device__ __forceinline__ void build_segment_tables(Row row, int T, int lane, float* __restrict__ sg,
+                                                     float* __restrict__ sb, int* __restrict__ se) {
+  const int nseg = nseg_of(T);
+  for (int s0 = 0; s0 < nseg; s0 += 2) {  // two 32-frame segments per pass: lanes 0-31 and 32-63
+    const int seg = s0 + (lane >> 5);
+    const int t = seg * kSeg + (lane & 31);
+    BF v{0.0f, 0.0f, kNegE, kNegE};
+    if (seg < nseg && t < T) v = row(t);
+    int e = max(v.mg > 0.0f ? v.eg : kNegE, v.mb > 0.0f ? v.eb : kNegE);
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) e = max(e, sbk::shfl_xor(e, m));  // max within the 32-lane half
+    if (seg < nseg && t < T) {
+      sg[t] = sbk::fast_ldexp(v.mg, v.eg - e);
+      sb[t] = sbk::fast_ldexp(v.mb, v.eb - e);
+    }
+    if (seg < nseg && (lane & 31) == 0) se[seg] = e;
+  }
+}
+
 // ---- emissions: log_softmax rows -> linear probabilities with the reference's frame mask
 __global__ void __launch_bounds__(256) ctc_emissions_kernel(float* __restrict__ x, float* __restrict__ xb_log,
                                                             const int32_t* __restrict__ enc_len, int T, int V, int blank) {
@@ -72,9 +103,12 @@ __global__ void __launch_bounds__(256) ctc_emissions_kernel(float* __restrict__ 
 // One workgroup per utterance: the cumulative sum is serial (same order as torch.cumsum), the
 // block-float conversion and the per-beam replication are parallel over frames.
 __global__ void __launch_bounds__(256) ctc_init_kernel(const float* __restrict__ xb_log, BF* __restrict__ st,
-                                                       float* __restrict__ psi_prev, int T, int beam) {
+                                                       float* __restrict__ sg, float* __restrict__ sb,
+                                                       int* __restrict__ se, float* __restrict__ psi_prev, int T,
+                                                       int beam) {
   SBK_DYN_LDS(float, cum);
   const int b = blockIdx.x;
+  const int nseg = nseg_of(T);
   if (threadIdx.x == 0) {
     float c = 0.0f;
     for (int t = 0; t < T; ++t) {
@@ -91,6 +125,14 @@ __global__ void __launch_bounds__(256) ctc_init_kernel(const float* __restrict__
     for (int j = 0; j < beam; ++j) st[((size_t)b * beam + j) * T + t] = v;
   }
   if (threadIdx.x < beam) psi_prev[b * beam + threadIdx.x] = 0.0f;
+  __syncthreads();
+  // scaled tables: wave w builds beams w, w+4, ... from the rows just written by this workgroup
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < beam; j += 4) {
+    const size_t n = (size_t)b * beam + j;
+    const BF* rowp = st + n * T;
+    build_segment_tables([&](int t) { return rowp[t]; }, T, lane, sg + n * T, sb + n * T, se + n * nseg);
+  }
 }
 
 struct CtcStepArgs {
@@ -104,12 +146,13 @@ struct CtcStepArgs {
   float eos_threshold, minus_inf;
 };
 
-// P [B,T,V] masked linear posteriors; st [n_bh,T] state of each hypothesis' prefix (uniform per
-// workgroup: fetched through the scalar cache); am [n_bh,V] acoustic log-probs (already * attn
-// weight); outputs comb = am' + w * (psi - psi_prev) and psi, both [n_bh,V].
+// P [B,T,V] masked linear posteriors; sg [n_bh,T] / se [n_bh,nseg] segment-scaled gamma tables
+// (uniform per workgroup: fetched through the scalar cache); am [n_bh,V] acoustic log-probs
+// (already * attn weight); outputs comb = am' + w * (psi - psi_prev) and psi, both [n_bh,V].
 template <int NB>
 __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, const float* __restrict__ P,
-                                                             const BF* __restrict__ st,
+                                                             const BF* __restrict__ st, const float* __restrict__ sg,
+                                                             const int* __restrict__ se,
                                                              const float* __restrict__ psi_prev,
                                                              const float* __restrict__ am,
                                                              const float* __restrict__ am_max,
@@ -119,18 +162,16 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   const bool c_ok = c < a.V;
   const int cc = c_ok ? c : a.V - 1;
   const int T = a.T, V = a.V;
+  const int nseg = nseg_of(T);
   const int start = a.prefix_len > 1 ? a.prefix_len : 1;
   const float* Pb = P + (size_t)b * T * V;
   const int last_frame = a.enc_len[b] - 1;
 
   for (int j0 = 0; j0 < a.beam; j0 += NB) {
     const int nb = min(NB, a.beam - j0);
-    // The prefix score of h = g.c needs only g's state:  psi = log( r_init + sum_t phi_g[t-1] * P_c[t] )
-    // (ctc.py:212-229); the forward variables of h itself are produced later, for the survivors
-    // only, by ctc_advance.  Block-float accumulator: value = mps * 2^Eps.
+    // block-float accumulator: value = mps * 2^Eps
     float mps[NB];
     int Eps[NB];
-    bool same[NB];
     const float p0 = Pb[cc];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -138,25 +179,35 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
       const bool first = a.prefix_len == 0 && p0 > 0.0f;
       mps[j] = first ? p0 : 0.0f;
       Eps[j] = first ? 0 : kNegE;
-      same[j] = j < nb && a.last_tok[b * a.beam + j0 + j] == cc;
     }
-    // Rows of the state table used by this beam tile; beams past the tile's end shadow its last
-    // beam (computed redundantly, never stored) so that the frame loop carries no branches.
-    const BF* sb[NB];
+    // beams past the tile's end shadow its last beam (computed redundantly, never stored)
+    const float* grow[NB];
+    const int* erow[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) sb[j] = st + ((size_t)b * a.beam + j0 + min(j, nb - 1)) * T;
-    for (int t = start; t < T; ++t) {
-      const float p_nb = Pb[(size_t)t * V + cc];
-      BF s[NB];
+    for (int j = 0; j < NB; ++j) {
+      const size_t n = (size_t)b * a.beam + j0 + min(j, nb - 1);
+      grow[j] = sg + n * T;
+      erow[j] = se + n * nseg;
+    }
+    // phi[t-1] * P[t]: frame t uses table entry t-1, so segment s of the TABLE covers frames s*32+1 ...
+    for (int s0 = (start - 1) / kSeg; s0 < nseg; ++s0) {
+      float part[NB];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) s[j] = sb[j][t - 1];
+      for (int j = 0; j < NB; ++j) part[j] = 0.0f;
+      const int u_lo = max(s0 * kSeg, start - 1), u_hi = min((s0 + 1) * kSeg, T - 1);  // table indices u = t-1
+      for (int u = u_lo; u < u_hi; ++u) {
+        const float p_nb = Pb[(size_t)(u + 1) * V + cc];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) part[j] = fmaf(grow[j][u], p_nb, part[j]);
+      }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        // phi = beta for the token that repeats the prefix' last token, gamma otherwise (ctc.py:175-186)
-        const float mphi = same[j] ? s[j].mb : s[j].mg;
-        const int ephi = same[j] ? s[j].eb : s[j].eg;
-        const int P2 = max(Eps[j], ephi - kHead);
-        mps[j] = fmaf(sbk::fast_ldexp(mphi, ephi - P2), p_nb, sbk::fast_ldexp(mps[j], Eps[j] - P2));
+        const int es = erow[j][s0];
+        const int k = sbk::frexp_exp(part[j]);
+        const int ep = part[j] > 0.0f ? es + k : kNegE;
+        const float mp = sbk::fast_ldexp(part[j], -k);
+        const int P2 = max(Eps[j], ep);
+        mps[j] = sbk::fast_ldexp(mps[j], Eps[j] - P2) + sbk::fast_ldexp(mp, ep - P2);
         Eps[j] = P2;
       }
     }
@@ -184,6 +235,49 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   }
 }
 
+// The one token per hypothesis that repeats the prefix' last token uses phi = beta instead of
+// gamma (ctc.py:175-186): recompute that entry.  One wave per hypothesis, lanes over frames.
+__global__ void __launch_bounds__(64) ctc_same_token_kernel(CtcStepArgs a, const float* __restrict__ P,
+                                                            const float* __restrict__ sb, const int* __restrict__ se,
+                                                            const float* __restrict__ psi_prev,
+                                                            const float* __restrict__ am,
+                                                            const float* __restrict__ am_max,
+                                                            float* __restrict__ comb, float* __restrict__ psi_out) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int b = n / a.beam, c = a.last_tok[n];
+  const int T = a.T, V = a.V, nseg = nseg_of(T);
+  if (c == a.eos || c == a.blank || c < 0 || c >= V) return;  // those entries are overridden anyway
+  const int start = a.prefix_len > 1 ? a.prefix_len : 1;
+  const float* Pb = P + (size_t)b * T * V;
+  // per-lane block-float partial over its frames, then a wave reduction on a common exponent
+  float m = 0.0f;
+  int E = kNegE;
+  if (lane == 0 && a.prefix_len == 0 && Pb[c] > 0.0f) {
+    m = Pb[c];
+    E = 0;
+  }
+  for (int u = start - 1 + lane; u < T - 1; u += 64) {
+    const float term = sb[(size_t)n * T + u] * Pb[(size_t)(u + 1) * V + c];
+    const int k = sbk::frexp_exp(term);
+    const int et = term > 0.0f ? se[(size_t)n * nseg + u / kSeg] + k : kNegE;
+    const float mt = sbk::fast_ldexp(term, -k);
+    const int E2 = max(E, et);
+    m = sbk::fast_ldexp(m, E - E2) + sbk::fast_ldexp(mt, et - E2);
+    E = E2;
+  }
+  int Emax = E;
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) Emax = max(Emax, sbk::shfl_xor(Emax, k));
+  float v = sbk::fast_ldexp(m, E - Emax);
+  v = sbk::wave_sum(v);
+  if (lane == 0) {
+    const float psi = bf_log(v, Emax);
+    psi_out[(size_t)n * V + c] = psi;
+    float x = am[(size_t)n * V + c];
+    comb[(size_t)n * V + c] = x + (psi - psi_prev[n]) * a.weight;
+  }
+}
+
 // New per-frame state of hypothesis n = (parent hyp, token) chosen by the beam search: one wave per
 // hypothesis; emissions and parent state are prefetched into LDS, lane 0 runs the serial recurrence,
 // all lanes normalise and store.
@@ -195,6 +289,9 @@ struct CtcAdvArgs {
   const int32_t* token;
   const int32_t* parent_last_tok;
   BF* st_new;
+  float* sg_new;
+  float* sb_new;
+  int* se_new;
   float* psi_prev_new;
   int n_bh, T, V, beam, prefix_len, blank;
 };
@@ -271,16 +368,26 @@ __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
     }
   }
   __syncthreads();
-  for (int t = lane; t < T; t += 64) {
-    BF s;
-    const float g = onb[t] + obl[t];
-    const int kg = sbk::frexp_exp(g), kb = sbk::frexp_exp(obl[t]);
-    s.mg = g > 0.0f ? sbk::fast_ldexp(g, 1 - kg) : 0.0f;  // mantissa in [1,2)
-    s.eg = g > 0.0f ? oe[t] + kg - 1 : kNegE;
-    s.mb = obl[t] > 0.0f ? sbk::fast_ldexp(obl[t], 1 - kb) : 0.0f;
-    s.eb = obl[t] > 0.0f ? oe[t] + kb - 1 : kNegE;
-    a.st_new[(size_t)n * T + t] = s;
+  BF* bfrow = reinterpret_cast<BF*>(pc);  // reuse the (now dead) input area: 4 floats per frame
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    BF s{0.0f, 0.0f, kNegE, kNegE};
+    if (t < T) {
+      const float g = onb[t] + obl[t];
+      const int kg = sbk::frexp_exp(g), kb = sbk::frexp_exp(obl[t]);
+      s.mg = g > 0.0f ? sbk::fast_ldexp(g, 1 - kg) : 0.0f;  // mantissa in [1,2)
+      s.eg = g > 0.0f ? oe[t] + kg - 1 : kNegE;
+      s.mb = obl[t] > 0.0f ? sbk::fast_ldexp(obl[t], 1 - kb) : 0.0f;
+      s.eb = obl[t] > 0.0f ? oe[t] + kb - 1 : kNegE;
+      a.st_new[(size_t)n * T + t] = s;
+    }
+    __syncthreads();  // everyone has read onb/obl/oe of this round before pc.. is overwritten
+    if (t < T) bfrow[t] = s;
   }
+  __syncthreads();
+  const int nseg = nseg_of(T);
+  build_segment_tables([&](int t) { return bfrow[t]; }, T, lane, a.sg_new + (size_t)n * T, a.sb_new + (size_t)n * T,
+                       a.se_new + (size_t)n * nseg);
   if (lane == 0) a.psi_prev_new[n] = a.psi[(size_t)p * a.V + c];
 }
 
@@ -314,7 +421,25 @@ __global__ void __launch_bounds__(256) row_max_kernel(const float* __restrict__ 
 
 namespace sbk {
 
-size_t ctc_state_floats(int n_bh, int T) { return (size_t)n_bh * T * (sizeof(BF) / sizeof(float)); }
+namespace {
+struct StateView {
+  BF* st;
+  float* sg;
+  float* sb;
+  int* se;
+};
+StateView view(float* base, int n_bh, int T) {
+  StateView v;
+  v.st = reinterpret_cast<BF*>(base);
+  v.sg = base + (size_t)4 * n_bh * T;
+  v.sb = v.sg + (size_t)n_bh * T;
+  v.se = reinterpret_cast<int*>(v.sb + (size_t)n_bh * T);
+  return v;
+}
+}  // namespace
+
+// floats of one CTC state buffer: BF rows + the two segment-scaled tables + segment exponents
+size_t ctc_state_floats(int n_bh, int T) { return (size_t)6 * n_bh * T + (size_t)n_bh * ((T + kSeg - 1) / kSeg) + 16; }
 
 // x: [B,T,V] log_softmax(ctc_lin(enc)) on entry, linear masked posteriors on exit.
 int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, float* psi_prev, int B, int T, int V,
@@ -322,8 +447,9 @@ int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, f
   SBK_LAUNCH(ctc_emissions_kernel, dim3(T, B), dim3(256), 0, st, x, xb_log, enc_len, T, V, blank);
   int rc = launch_status("ctc_emissions");
   if (rc) return rc;
-  SBK_LAUNCH(ctc_init_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float), st, (const float*)xb_log,
-             reinterpret_cast<BF*>(state), psi_prev, T, beam);
+  StateView v = view(state, B * beam, T);
+  SBK_LAUNCH(ctc_init_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float), st, (const float*)xb_log, v.st, v.sg, v.sb,
+             v.se, psi_prev, T, beam);
   return launch_status("ctc_init");
 }
 
@@ -332,29 +458,39 @@ int ctc_score_step(const float* P, const float* state, const float* psi_prev, co
                    int prefix_len, int blank, int eos, float weight, int eos_floor, int use_thr, float thr,
                    float minus_inf, const float* am_max, hipStream_t st) {
   CtcStepArgs a{last_tok, enc_len, B, T, V, beam, prefix_len, blank, eos, weight, eos_floor, use_thr, thr, minus_inf};
-  const BF* sp = reinterpret_cast<const BF*>(state);
-  ProfScope prof("ctc_score_step", 6.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 12.0 * B * beam * V, st);
+  const StateView v = view(const_cast<float*>(state), B * beam, T);
+  ProfScope prof("ctc_score_step", 2.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 12.0 * B * beam * V, st);
   dim3 grid(cdiv(V, 256), B), block(256);
   if (beam == 1) {
-    SBK_LAUNCH((ctc_score_step_kernel<1>), grid, block, 0, st, a, P, sp, psi_prev, am, am_max, comb, psi);
+    SBK_LAUNCH((ctc_score_step_kernel<1>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg,
+               (const int*)v.se, psi_prev, am, am_max, comb, psi);
   } else if (beam <= 4) {
-    SBK_LAUNCH((ctc_score_step_kernel<4>), grid, block, 0, st, a, P, sp, psi_prev, am, am_max, comb, psi);
+    SBK_LAUNCH((ctc_score_step_kernel<4>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg,
+               (const int*)v.se, psi_prev, am, am_max, comb, psi);
   } else if (beam <= 10) {
-    SBK_LAUNCH((ctc_score_step_kernel<10>), grid, block, 0, st, a, P, sp, psi_prev, am, am_max, comb, psi);
+    SBK_LAUNCH((ctc_score_step_kernel<10>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg,
+               (const int*)v.se, psi_prev, am, am_max, comb, psi);
   } else {
-    SBK_LAUNCH((ctc_score_step_kernel<16>), grid, block, 0, st, a, P, sp, psi_prev, am, am_max, comb, psi);
+    SBK_LAUNCH((ctc_score_step_kernel<16>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg,
+               (const int*)v.se, psi_prev, am, am_max, comb, psi);
   }
-  return launch_status("ctc_score_step");
+  int rc = launch_status("ctc_score_step");
+  if (rc) return rc;
+  SBK_LAUNCH(ctc_same_token_kernel, dim3(B * beam), dim3(64), 0, st, a, P, (const float*)v.sb, (const int*)v.se, psi_prev,
+             am, am_max, comb, psi);
+  return launch_status("ctc_same_token");
 }
 
 int ctc_advance(const float* P, const float* state_old, const float* psi, const int32_t* parent, const int32_t* token,
                 const int32_t* parent_last_tok, float* state_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
                 int prefix_len, int blank, hipStream_t st) {
-  CtcAdvArgs a{P, reinterpret_cast<const BF*>(state_old), psi, parent, token, parent_last_tok,
-               reinterpret_cast<BF*>(state_new), psi_prev_new, n_bh, T, V, beam, prefix_len, blank};
+  const StateView vo = view(const_cast<float*>(state_old), n_bh, T);
+  const StateView vn = view(state_new, n_bh, T);
+  CtcAdvArgs a{P, vo.st, psi, parent, token, parent_last_tok, vn.st, vn.sg, vn.sb, vn.se, psi_prev_new, n_bh, T, V, beam,
+               prefix_len, blank};
   const size_t lds = (size_t)7 * T * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "ctc_advance: T=%d too long for the LDS window", T);
-  ProfScope prof("ctc_advance", 14.0 * n_bh * T, 40.0 * n_bh * T, st);
+  ProfScope prof("ctc_advance", 14.0 * n_bh * T, 64.0 * n_bh * T, st);
   SBK_LAUNCH(ctc_advance_kernel, dim3(n_bh), dim3(64), lds, st, a);
   return launch_status("ctc_advance");
 }

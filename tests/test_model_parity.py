@@ -116,3 +116,28 @@ def test_decoder_long_memory_and_prefix(backend):
     h = nat.DecoderHandle(mods["Transformer"], mods["seq_lin"])
     pred = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev))
     assert float((pred.cpu() - ref).abs().max()) <= 5e-5
+
+
+def test_beam_search_long_memory_vs_oracle(backend):
+    """Beam 4 + CTC over a 150-frame memory (several 32-frame CTC segments, two cross-attention
+    splits, one padded utterance) against the oracle's search: token ids exact, scores 1e-4."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
+
+    g, mods = build("tiny_ctc", dev)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    d_model, nhead, d_ffn, n_enc, n_dec, vocab = [int(v) for v in g["cfg"][:6]]
+    cfg = O.ModelCfg(d_model=d_model, nhead=nhead, num_encoder_layers=n_enc, num_decoder_layers=n_dec, d_ffn=d_ffn,
+                     vocab=vocab)
+    enc = torch.randn(2, 150, d_model, generator=torch.Generator().manual_seed(5)) * 2.0
+    wl = torch.tensor([1.0, 0.62])
+    ratio = 14.5 / 150
+    hyps_ref, lens_ref, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=4, ctc_weight=0.4, max_decode_ratio=ratio))
+    scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)], weights={"ctc": 0.4})
+    bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                    min_decode_ratio=0.0, max_decode_ratio=ratio, beam_size=4,
+                                    using_eos_threshold=False, length_normalization=True, scorer=scorer)
+    hyps, lens, sc, _ = bs(enc.to(dev), wl.to(dev))
+    assert hyps == hyps_ref
+    assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
+    assert float((lens.cpu() - lens_ref).abs().max()) <= 1e-6

@@ -1,0 +1,44 @@
+"""Isolated kernel timings on the MI355X (back-to-back launches between two events)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from speechbrain_amd import native as nat
+
+dev = torch.device("cuda:0")
+nat.load()
+
+
+def timeit(fn, n=200, warm=20):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1000.0  # us
+
+
+def gemm_case(M, N, K, slices):
+    a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
+    ws = torch.empty(max(1, slices * M * N), device=dev)
+    out = torch.empty(M, N, device=dev)
+    lib = nat.load()
+    def f():
+        lib.sbk_gemm_nt_splitk_f32(nat._p(a), K, nat._p(w), K, nat._p(b), None, N, nat._p(out), N, M, N, K, 0, 1.0,
+                                   nat._p(ws) if slices else None, ws.numel() if slices else 0, nat._stream(a))
+    us = timeit(f)
+    print(f"gemm M={M} N={N} K={K} slices={slices}: {us:8.2f} us  {2.0*M*N*K/us/1e6:7.2f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    print("launch overhead (empty-ish layernorm 4 rows):", end=" ")
+    x = torch.randn(4, 512, device=dev); g = torch.ones(512, device=dev); bb = torch.zeros(512, device=dev)
+    print(f"{timeit(lambda: nat.layernorm(x, g, bb, 1e-5)):.2f} us")
+    for (M, N, K) in [(320, 512, 512), (320, 1536, 512), (320, 2048, 512), (320, 512, 2048), (320, 5000, 512)]:
+        for sl in (0, 8):
+            gemm_case(M, N, K, sl)
+    for (M, N, K) in [(8032, 512, 512), (8032, 2048, 512), (8032, 512, 2048), (24032, 2048, 512), (24032, 5000, 512)]:
+        gemm_case(M, N, K, 0)
