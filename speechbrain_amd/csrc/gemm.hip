@@ -268,7 +268,8 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   // a second, global K split when the tile grid alone leaves SIMDs idle (needs `ws` for the partial tiles)
   int SKg = 1;
   if (ws) {
-    while (K / (4 * SKg) > 32 && K % (4 * SKg * 2 * 32) == 0 && tiles_m * tiles_n * SKg < 512 &&
+    // (only worth the extra reduce launch for long K: K = 512 slices are 128 deep already)
+    while (K / (4 * SKg) > 128 && K % (4 * SKg * 2 * 32) == 0 && tiles_m * tiles_n * SKg < 1024 &&
            (size_t)(SKg * 2) * M * N <= ws_floats)
       SKg *= 2;
   }
