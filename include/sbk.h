@@ -64,6 +64,22 @@ int sbk_fbank_f32(const float* wav, const float* window, const float* twiddle, c
                   float* tile_max, int B, int N, int n_fft, int hop, int n_mels, int nnz, float amin, float top_db,
                   const float* norm_mean, const float* norm_std, float norm_eps, sbk_stream_t stream);
 
+/* a2: STFT.forward (processing/features.py:141-188): [B,N] -> spec [B,T,n_fft/2+1,2] (re, im);
+ * window / twiddle / radices as for sbk_fbank_f32. */
+int sbk_stft_f32(const float* wav, const float* window, const float* twiddle, const int32_t* radices, int n_radix,
+                 float* spec, int B, int N, int n_fft, int hop, sbk_stream_t stream);
+
+/* a3: spectral_magnitude (processing/features.py:341-378): out[i] = (re^2 + im^2)^power over n complex
+ * values (eps added first when power < 1), optionally log(. + eps). */
+int sbk_spectral_magnitude_f32(const float* stft, float* out, long n, float power, int take_log, float eps,
+                               sbk_stream_t stream);
+
+/* a4: Filterbank._amplitude_to_DB (processing/features.py:736-759), in place on x [B,per_utt]:
+ * multiplier*log10(max(x,amin)) - db_offset, then floor at (per-utterance max - top_db).
+ * tile_max: workspace [B,64]. */
+int sbk_amplitude_to_db_f32(float* x, float* tile_max, int B, long per_utt, float multiplier, float amin,
+                            float db_offset, float top_db, sbk_stream_t stream);
+
 /* a6: InputNormalization.forward, eval, norm_type="global" (features.py:1404-1455):
  * y = (x - mean[c]) / max(std[c], eps), x [rows, C]. */
 int sbk_input_norm_global_f32(const float* x, const float* mean, const float* std, float* y, int rows, int C,

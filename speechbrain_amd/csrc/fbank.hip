@@ -35,6 +35,7 @@ struct FbankArgs {
   float* tile_max;
   int B, N, T, n_fft, hop, n_mels, nnz, ntiles;
   float amin;
+  float* spec;  // optional [B,T,n_fft/2+1,2] complex STFT output (STFT.forward); when set, the mel stage is skipped
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -98,6 +99,13 @@ __global__ void __launch_bounds__(256) fbank_frames_kernel(FbankArgs a, Radices 
     Ns *= R;
   }
 
+  if (a.spec) {  // plain STFT: (re, im) per bin, no mel stage (uniform branch)
+    if (t < a.T) {
+      float2* dst = reinterpret_cast<float2*>(a.spec) + ((size_t)b * a.T + t) * n_stft;
+      for (int f = lane; f < n_stft; f += 64) dst[f] = cur[f];
+    }
+    return;
+  }
   float* mypw = pw + wave * n_stft;
   for (int f = lane; f < n_stft; f += 64) mypw[f] = cur[f].x * cur[f].x + cur[f].y * cur[f].y;
   __syncthreads();
@@ -171,7 +179,7 @@ extern "C" int sbk_fbank_f32(const float* wav, const float* window, const float*
   const int n_stft = n_fft / 2 + 1;
   const size_t lds = (size_t)n_fft * 8 + (size_t)4 * 2 * n_fft * 8 + (size_t)4 * n_stft * 4 + (size_t)nnz * 4 + 16;
   SBK_REQUIRE(lds <= 160 * 1024, "fbank: n_fft=%d needs %zu B of LDS", n_fft, lds);
-  FbankArgs a{wav, window, twiddle, mel_w, mel_ptr, mel_bin, out, tile_max, B, N, T, n_fft, hop, n_mels, nnz, ntiles, amin};
+  FbankArgs a{wav, window, twiddle, mel_w, mel_ptr, mel_bin, out, tile_max, B, N, T, n_fft, hop, n_mels, nnz, ntiles, amin, nullptr};
   hipStream_t st = sbk::as_stream(stream);
   sbk::ProfScope prof("fbank", 5.0 * n_fft * 9.0 * B * T, 4.0 * ((double)B * N + 3.0 * B * T * n_mels), st);
   SBK_LAUNCH(fbank_frames_kernel, dim3(ntiles, B), dim3(256), lds, st, a, rad);
@@ -182,4 +190,87 @@ extern "C" int sbk_fbank_f32(const float* wav, const float* window, const float*
   SBK_LAUNCH(fbank_floor_norm_kernel, dim3(gx, B), dim3(256), 0, st, out, tile_max, ntiles, per_utt, n_mels, top_db,
              norm_mean, norm_std, norm_eps);
   return sbk::launch_status("sbk_fbank_f32/floor");
+}
+
+
+// STFT.forward (processing/features.py:141-188): [B,N] -> [B,T,n_fft/2+1,2] (re, im).
+extern "C" int sbk_stft_f32(const float* wav, const float* window, const float* twiddle, const int32_t* radices,
+                            int n_radix, float* spec, int B, int N, int n_fft, int hop, sbk_stream_t stream) {
+  SBK_REQUIRE(wav && window && twiddle && radices && spec, "stft: null operand");
+  SBK_REQUIRE(B >= 0 && N >= 0 && n_fft >= 2 && hop > 0, "stft: bad shape");
+  SBK_REQUIRE(n_radix > 0 && n_radix <= kMaxRadix, "stft: %d FFT passes", n_radix);
+  Radices rad;
+  rad.n = n_radix;
+  long prod = 1;
+  for (int i = 0; i < n_radix; ++i) {
+    rad.r[i] = radices[i];
+    SBK_REQUIRE(radices[i] >= 2 && radices[i] <= 5, "stft: radix %d unsupported", radices[i]);
+    prod *= radices[i];
+  }
+  SBK_REQUIRE(prod == n_fft, "stft: radices do not multiply to n_fft=%d", n_fft);
+  if (B == 0) return 0;
+  const int T = 1 + N / hop, ntiles = sbk::cdiv(T, 4), n_stft = n_fft / 2 + 1;
+  const size_t lds = (size_t)n_fft * 8 + (size_t)4 * 2 * n_fft * 8 + (size_t)4 * n_stft * 4 + 16;
+  SBK_REQUIRE(lds <= 160 * 1024, "stft: n_fft=%d needs %zu B of LDS", n_fft, lds);
+  FbankArgs a{wav, window, twiddle, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, T, n_fft, hop, 0, 0, ntiles, 0.0f, spec};
+  SBK_LAUNCH(fbank_frames_kernel, dim3(ntiles, B), dim3(256), lds, sbk::as_stream(stream), a, rad);
+  return sbk::launch_status("sbk_stft_f32");
+}
+
+namespace {
+// spectral_magnitude (processing/features.py:341-378): (re^2 + im^2) ^ power, optional log.
+__global__ void __launch_bounds__(256) spectral_magnitude_kernel(const float2* __restrict__ x, float* __restrict__ y,
+                                                                 long n, float power, int take_log, float eps) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = x[i].x * x[i].x + x[i].y * x[i].y;
+    if (power < 1.0f) v = v + eps;  // the reference adds eps before a fractional power
+    if (power != 1.0f) v = powf(v, power);
+    y[i] = take_log ? logf(v + eps) : v;
+  }
+}
+
+// _amplitude_to_DB (processing/features.py:736-759): 10*log10(max(x,amin)) then the per-utterance floor.
+__global__ void __launch_bounds__(256) to_db_kernel(float* __restrict__ x, float* __restrict__ tile_max, long per_utt,
+                                                    float mult, float amin, float db_offset) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  float* xb = x + (size_t)b * per_utt;
+  float mx = -INFINITY;
+  for (long i = (long)blockIdx.x * 256 + tid; i < per_utt; i += (long)gridDim.x * 256) {
+    const float v = mult * (float)log10((double)fmaxf(xb[i], amin)) - db_offset;
+    xb[i] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = sbk::wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  if (tid == 0) tile_max[(size_t)b * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+}  // namespace
+
+extern "C" int sbk_spectral_magnitude_f32(const float* stft, float* out, long n, float power, int take_log, float eps,
+                                          sbk_stream_t stream) {
+  SBK_REQUIRE(stft && out && n >= 0, "spectral_magnitude: bad arguments");
+  if (n == 0) return 0;
+  const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  SBK_LAUNCH(spectral_magnitude_kernel, dim3(blocks), dim3(256), 0, sbk::as_stream(stream),
+             reinterpret_cast<const float2*>(stft), out, n, power, take_log, eps);
+  return sbk::launch_status("sbk_spectral_magnitude_f32");
+}
+
+// In place: x [B, per_utt] linear filterbank energies -> dB with the per-utterance (max - top_db) floor.
+// tile_max: workspace [B, 64].
+extern "C" int sbk_amplitude_to_db_f32(float* x, float* tile_max, int B, long per_utt, float multiplier, float amin,
+                                       float db_offset, float top_db, sbk_stream_t stream) {
+  SBK_REQUIRE(x && tile_max && B >= 0 && per_utt > 0, "amplitude_to_db: bad arguments");
+  if (B == 0) return 0;
+  hipStream_t st = sbk::as_stream(stream);
+  const int nt = 64;
+  SBK_LAUNCH(to_db_kernel, dim3(nt, B), dim3(256), 0, st, x, tile_max, per_utt, multiplier, amin, db_offset);
+  int rc = sbk::launch_status("sbk_amplitude_to_db_f32/db");
+  if (rc) return rc;
+  const int gx = (int)((per_utt + 2047) / 2048 < 1 ? 1 : (per_utt + 2047) / 2048);
+  SBK_LAUNCH(fbank_floor_norm_kernel, dim3(gx, B), dim3(256), 0, st, x, (const float*)tile_max, nt, per_utt, 1, top_db,
+             (const float*)nullptr, (const float*)nullptr, 0.0f);
+  return sbk::launch_status("sbk_amplitude_to_db_f32/floor");
 }

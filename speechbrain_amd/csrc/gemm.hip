@@ -261,7 +261,7 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
                int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq,
                float* ws, size_t ws_floats, hipStream_t st) {
   if (M == 0 || N == 0) return 0;
-  const bool skinny_ok = M <= 512 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
+  const bool skinny_ok = (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < 256) && M <= 4096 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
   if (!skinny_ok) return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
   GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
   const int tiles_m = cdiv(M, 32), tiles_n = cdiv(N, 32);

@@ -425,7 +425,7 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
   d.q = c.take<float>((size_t)n * dm);
   d.ff = c.take<float>((size_t)n * W->d_ffn);
   d.logits = c.take<float>((size_t)n * W->vocab);
-  d.splitk_floats = (size_t)8 * n * (size_t)(W->d_ffn > 3 * dm ? W->d_ffn : 3 * dm);
+  d.splitk_floats = (size_t)4 * n * (size_t)dm;  // global split-K is used for the long-K FFN2 only
   d.splitk = c.take<float>(d.splitk_floats);
   d.xpart = c.take<float>(sbk::cross_attn_partial_floats(B, T, W->nhead, dm / W->nhead, n / (B > 0 ? B : 1)) + 64);
   for (int l = 0; l < W->n_layers; ++l) {

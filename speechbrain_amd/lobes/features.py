@@ -1,7 +1,7 @@
 """speechbrain.lobes.features mirror: Fbank (lobes/features.py:38-173)."""
 import torch
 
-from speechbrain_amd.processing.features import FbankFrontend
+from speechbrain_amd.processing.features import STFT, FbankFrontend, Filterbank, spectral_magnitude
 
 
 class Fbank(torch.nn.Module):
@@ -16,8 +16,20 @@ class Fbank(torch.nn.Module):
         if deltas or context or requires_grad or filter_shape != "triangular" or param_rand_factor != 0.0:
             raise NotImplementedError("only plain frozen triangular Fbank is on the MI355X ASR path")
         self.deltas, self.context, self.requires_grad = deltas, context, requires_grad
-        self.compute_fbanks = FbankFrontend(sample_rate=sample_rate, win_length=win_length, hop_length=hop_length,
-                                            n_fft=n_fft, n_mels=n_mels, f_min=f_min, f_max=f_max)
+        if f_max is None:
+            f_max = sample_rate / 2
+        # the reference's stages, available stand-alone (same attribute names: lobes/features.py:117-145) ...
+        self.compute_STFT = STFT(sample_rate=sample_rate, n_fft=n_fft, win_length=win_length, hop_length=hop_length)
+        self.compute_fbanks = Filterbank(sample_rate=sample_rate, n_fft=n_fft, n_mels=n_mels, f_min=f_min,
+                                         f_max=f_max, freeze=not requires_grad, filter_shape=filter_shape,
+                                         param_change_factor=param_change_factor, param_rand_factor=param_rand_factor)
+        # ... and the fused single-pass kernel that forward() uses
+        self.fused = FbankFrontend(sample_rate=sample_rate, win_length=win_length, hop_length=hop_length,
+                                   n_fft=n_fft, n_mels=n_mels, f_min=f_min, f_max=f_max)
 
     def forward(self, wav):
-        return self.compute_fbanks(wav)
+        return self.fused(wav)
+
+    def forward_staged(self, wav):
+        """STFT -> spectral_magnitude -> Filterbank exactly as the reference composes them (:147-169)."""
+        return self.compute_fbanks(spectral_magnitude(self.compute_STFT(wav)))

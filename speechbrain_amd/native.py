@@ -56,6 +56,9 @@ def _declare(lib):
         "sbk_prof_reset": ([], None),
         "sbk_prof_report": ([ctypes.c_char_p, ctypes.c_size_t], ctypes.c_size_t),
         "sbk_fbank_f32": ([p, p, p, POINTER(c_int32), i, p, p, p, p, p, i, i, i, i, i, i, f, f, p, p, f, p], c_int),
+        "sbk_stft_f32": ([p, p, p, POINTER(c_int32), i, p, i, i, i, i, p], c_int),
+        "sbk_spectral_magnitude_f32": ([p, p, ctypes.c_long, f, i, f, p], c_int),
+        "sbk_amplitude_to_db_f32": ([p, p, i, ctypes.c_long, f, f, f, f, p], c_int),
         "sbk_input_norm_global_f32": ([p, p, p, p, i, i, f, p], c_int),
         "sbk_gemm_nt_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_splitk_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, ctypes.c_size_t, p], c_int),
@@ -227,6 +230,42 @@ def fbank(wav, window, twiddle, radices, mel_w, mel_ptr, mel_bin, n_fft, hop, n_
                            _p(out), _p(tile_max), B, N, n_fft, hop, n_mels, mel_w.numel(), float(amin), float(top_db),
                            _p(norm_mean), _p(norm_std), float(norm_eps), _stream(wav)), "sbk_fbank_f32")
     return out
+
+
+def stft(wav, window, twiddle, radices, n_fft, hop):
+    """[B,N] -> complex STFT [B,T,n_fft/2+1,2]."""
+    lib = load()
+    _dev_ok(wav, window, twiddle)
+    _f32(wav)
+    B, N = wav.shape
+    T = 1 + N // hop
+    spec = torch.empty(B, T, n_fft // 2 + 1, 2, dtype=torch.float32, device=wav.device)
+    rad = (c_int32 * len(radices))(*radices)
+    _chk(lib.sbk_stft_f32(_p(wav), _p(window), _p(twiddle), rad, len(radices), _p(spec), B, N, n_fft, hop, _stream(wav)),
+         "sbk_stft_f32")
+    return spec
+
+
+def spectral_magnitude(stft_t, power=1.0, log=False, eps=1e-14):
+    lib = load()
+    _dev_ok(stft_t)
+    _f32(stft_t)
+    out = torch.empty(stft_t.shape[:-1], dtype=torch.float32, device=stft_t.device)
+    _chk(lib.sbk_spectral_magnitude_f32(_p(stft_t), _p(out), out.numel(), float(power), int(bool(log)), float(eps),
+                                        _stream(stft_t)), "sbk_spectral_magnitude_f32")
+    return out
+
+
+def amplitude_to_db(x, multiplier, amin, db_offset, top_db):
+    """In place on x [B, ...]: dB conversion + per-utterance floor."""
+    lib = load()
+    _dev_ok(x)
+    _f32(x)
+    B = x.shape[0]
+    tile_max = torch.empty(B, 64, dtype=torch.float32, device=x.device)
+    _chk(lib.sbk_amplitude_to_db_f32(_p(x), _p(tile_max), B, x[0].numel(), float(multiplier), float(amin),
+                                     float(db_offset), float(top_db), _stream(x)), "sbk_amplitude_to_db_f32")
+    return x
 
 
 def conv_block(x, wt, bias, gamma, beta, cout, eps=1e-5, slope=0.01):

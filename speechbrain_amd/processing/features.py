@@ -42,6 +42,72 @@ def make_padding_mask(x, lengths=None, length_dim=1, eps=1e-6):
     return mask
 
 
+class STFT(torch.nn.Module):
+    """processing/features.py:58-188: [B,N] -> [B,T,n_fft/2+1,2] (re, im).  Same constructor as the
+    reference; the periodic Hamming window / centred constant padding / one-sided unnormalised
+    transform used by the ASR recipes run in the in-LDS FFT kernel (csrc/fbank.hip)."""
+
+    def __init__(self, sample_rate, win_length=25, hop_length=10, n_fft=400, window_fn=torch.hamming_window,
+                 normalized_stft=False, center=True, pad_mode="constant", onesided=True):
+        super().__init__()
+        if normalized_stft or not center or pad_mode != "constant" or not onesided:
+            raise NotImplementedError("only the recipe configuration (center, constant pad, onesided) is implemented")
+        self.sample_rate, self.n_fft = sample_rate, n_fft
+        self.win_length = int(round((sample_rate / 1000.0) * win_length))
+        self.hop_length = int(round((sample_rate / 1000.0) * hop_length))
+        self.normalized_stft, self.center, self.pad_mode, self.onesided = normalized_stft, center, pad_mode, onesided
+        window = window_fn(self.win_length)
+        self.register_buffer("window", window, persistent=False)
+        padded = window
+        if self.win_length < n_fft:
+            left = (n_fft - self.win_length) // 2
+            padded = torch.nn.functional.pad(window, (left, n_fft - self.win_length - left))
+        m = torch.arange(n_fft, dtype=torch.float64) * (2.0 * math.pi / n_fft)
+        self.register_buffer("_window_fft", padded.float().contiguous(), persistent=False)
+        self.register_buffer("_twiddle", torch.stack([torch.cos(m), -torch.sin(m)], dim=1).float().contiguous(),
+                             persistent=False)
+        self.radices = factor_radices(n_fft)
+
+    def forward(self, x):
+        if x.dim() != 2:
+            raise NotImplementedError("multi-channel input is not on the ASR path")
+        return native.stft(x.float().contiguous(), self._window_fft, self._twiddle, self.radices, self.n_fft,
+                           self.hop_length)
+
+
+def spectral_magnitude(stft, power: float = 1, log: bool = False, eps: float = 1e-14):
+    """processing/features.py:341-378: (re^2 + im^2)^power (+ optional log)."""
+    return native.spectral_magnitude(stft.contiguous(), power, log, eps)
+
+
+class Filterbank(torch.nn.Module):
+    """processing/features.py:381-759, frozen triangular filters: spectrogram [B,T,n_stft] -> fbanks
+    [B,T,n_mels] = dB(spectrogram @ filter matrix) with the per-utterance top_db floor."""
+
+    def __init__(self, n_mels=40, log_mel=True, filter_shape="triangular", f_min=0, f_max=8000, n_fft=400,
+                 sample_rate=16000, power_spectrogram=2, amin=1e-10, ref_value=1.0, top_db=80.0,
+                 param_change_factor=1.0, param_rand_factor=0.0, freeze=True):
+        super().__init__()
+        if filter_shape != "triangular" or not freeze or param_rand_factor != 0.0:
+            raise NotImplementedError("only frozen triangular filters are on the ASR path")
+        self.n_mels, self.log_mel, self.n_fft, self.sample_rate = n_mels, log_mel, n_fft, sample_rate
+        self.amin, self.ref_value, self.top_db = amin, ref_value, top_db
+        self.n_stft = n_fft // 2 + 1
+        self.db_multiplier = math.log10(max(amin, ref_value))
+        self.multiplier = 10 if power_spectrogram == 2 else 20
+        fb = FbankFrontend._filter_matrix(n_fft, n_mels, f_min, f_max, sample_rate)
+        self.register_buffer("fbank_matrix_t", fb.t().contiguous(), persistent=False)  # [n_mels, n_stft]: GEMM weight
+
+    def forward(self, spectrogram):
+        if spectrogram.dim() != 3:
+            raise NotImplementedError("multi-channel spectrograms are not on the ASR path")
+        fbanks = native.gemm_nt(spectrogram.contiguous(), self.fbank_matrix_t)
+        if self.log_mel:
+            fbanks = native.amplitude_to_db(fbanks, self.multiplier, self.amin, self.multiplier * self.db_multiplier,
+                                            self.top_db)
+        return fbanks
+
+
 class FbankFrontend(torch.nn.Module):
     """STFT -> |.|^2 -> triangular mel filterbank -> dB with top_db floor, one fused launch pair.
 

@@ -54,3 +54,26 @@ def test_fft_radix_plans():
     for n in (512, 400, 256, 480, 1024):
         r = factor_radices(n)
         assert all(x in (2, 3, 4, 5) for x in r) and int(np.prod(r)) == n
+
+
+def test_speechbrain_import_shim():
+    import importlib
+    import sys
+
+    import speechbrain_amd.compat as compat
+
+    assert "speechbrain" not in sys.modules
+    try:
+        compat.install()
+        fbank_cls = importlib.import_module("speechbrain.lobes.features").Fbank
+        from speechbrain_amd.lobes.features import Fbank
+
+        assert fbank_cls is Fbank
+        from speechbrain.lobes.models.transformer.TransformerASR import TransformerASR  # noqa: F401
+        from speechbrain.decoders import S2STransformerBeamSearcher  # noqa: F401
+        from speechbrain.inference.ASR import EncoderDecoderASR  # noqa: F401
+        from speechbrain.nnet.attention import RelPosMHAXL  # noqa: F401
+        from speechbrain.processing.features import STFT, Filterbank, InputNormalization, spectral_magnitude  # noqa: F401
+    finally:
+        for k in [k for k in sys.modules if k == "speechbrain" or k.startswith("speechbrain.")]:
+            del sys.modules[k]

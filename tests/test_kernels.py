@@ -159,3 +159,25 @@ def test_glu_dwconv(backend, B, T, d, ks):
     h, w, b = torch.randn(B, T, 2 * d), torch.randn(d, ks) * 0.2, torch.randn(d)
     ref = F.conv1d(F.glu(h.transpose(1, 2), dim=1), w.unsqueeze(1), b, padding=(ks - 1) // 2, groups=d).transpose(1, 2)
     assert _md(nat.glu_dwconv(h.to(dev), w.to(dev), b.to(dev), ks), ref) <= 1e-5
+
+
+def test_staged_features_match_fused_and_reference(backend):
+    """STFT -> spectral_magnitude -> Filterbank (the reference's composition, lobes/features.py:147-169)
+    vs the fused kernel and vs the reference golden; spectral_magnitude doctest (features.py:365-367)."""
+    nat, dev = backend
+    from speechbrain_amd.lobes.features import Fbank
+    from speechbrain_amd.processing.features import STFT, spectral_magnitude
+
+    g = np.load(os.path.join(GOLD, "fbank.npz"))
+    wav = torch.from_numpy(g["wav"]).to(dev)
+    fb = Fbank(n_fft=512, n_mels=80, win_length=32).to(dev)
+    staged, fused = fb.forward_staged(wav), fb(wav)
+    assert _md(staged, torch.from_numpy(g["fbank_L"])) <= 1e-3
+    assert _md(staged, fused) <= 1e-3
+    stft = STFT(sample_rate=16000).to(dev)(torch.randn(10, 16000, generator=torch.Generator().manual_seed(1)).to(dev))
+    assert stft.shape == (10, 101, 201, 2)  # doctest shape, features.py:99-106
+    ref = torch.view_as_real(torch.stft(torch.randn(10, 16000, generator=torch.Generator().manual_seed(1)), 400, 160, 400,
+                                        torch.hamming_window(400), True, "constant", False, True,
+                                        return_complex=True)).transpose(2, 1)
+    assert _md(stft, ref) <= 2e-4
+    assert _md(spectral_magnitude(torch.tensor([[3.0, 4.0]]).to(dev), power=0.5), torch.tensor([5.0])) <= 1e-6
