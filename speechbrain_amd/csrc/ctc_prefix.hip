@@ -153,10 +153,7 @@ template <int NB>
 __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, const float* __restrict__ P,
                                                              const BF* __restrict__ st, const float* __restrict__ sg,
                                                              const int* __restrict__ se,
-                                                             const float* __restrict__ psi_prev,
-                                                             const float* __restrict__ am,
-                                                             const float* __restrict__ am_max,
-                                                             float* __restrict__ comb, float* __restrict__ psi_out) {
+                                                             float* __restrict__ psi_out) {
   const int b = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   const bool c_ok = c < a.V;
@@ -229,13 +226,6 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
         }
         if (c == a.blank && a.eos != a.blank) psi = kNeg;
         psi_out[(size_t)n * V + c] = psi;
-        float v = am[(size_t)n * V + c];
-        if (c == a.eos) {
-          if (a.eos_floor) v = a.minus_inf;
-          if (a.use_eos_threshold && !(v > a.eos_threshold * am_max[n])) v = a.minus_inf;
-        }
-        if (c == a.blank) v = kNeg;
-        comb[(size_t)n * V + c] = v + (psi - psi_prev[n]) * a.weight;
       }
     }
   }
@@ -245,10 +235,7 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
 // gamma (ctc.py:175-186): recompute that entry.  One wave per hypothesis, lanes over frames.
 __global__ void __launch_bounds__(64) ctc_same_token_kernel(CtcStepArgs a, const float* __restrict__ P,
                                                             const float* __restrict__ sb, const int* __restrict__ se,
-                                                            const float* __restrict__ psi_prev,
-                                                            const float* __restrict__ am,
-                                                            const float* __restrict__ am_max,
-                                                            float* __restrict__ comb, float* __restrict__ psi_out) {
+                                                            float* __restrict__ psi_out) {
   const int n = blockIdx.x, lane = threadIdx.x;
   const int b = n / a.beam, c = a.last_tok[n];
   const int T = a.T, V = a.V, nseg = nseg_of(T);
@@ -276,12 +263,25 @@ __global__ void __launch_bounds__(64) ctc_same_token_kernel(CtcStepArgs a, const
   for (int k = 32; k >= 1; k >>= 1) Emax = max(Emax, sbk::shfl_xor(Emax, k));
   float v = sbk::fast_ldexp(m, E - Emax);
   v = sbk::wave_sum(v);
-  if (lane == 0) {
-    const float psi = bf_log(v, Emax);
-    psi_out[(size_t)n * V + c] = psi;
-    float x = am[(size_t)n * V + c];
-    comb[(size_t)n * V + c] = x + (psi - psi_prev[n]) * a.weight;
+  if (lane == 0) psi_out[(size_t)n * V + c] = bf_log(v, Emax);
+}
+
+// comb = am' + w * (psi - psi_prev): the scorer combination of scorer.py:1248-1253 with the AM
+// modifications applied first (eos floor / eos threshold, seq2seq.py:995-1017; blank column, scorer.py:1250).
+__global__ void __launch_bounds__(256) ctc_combine_kernel(CtcStepArgs a, const float* __restrict__ am,
+                                                          const float* __restrict__ am_max,
+                                                          const float* __restrict__ psi,
+                                                          const float* __restrict__ psi_prev, float* __restrict__ comb) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.V) return;
+  float v = am[(size_t)n * a.V + c];
+  if (c == a.eos) {
+    if (a.eos_floor) v = a.minus_inf;
+    if (a.use_eos_threshold && !(v > a.eos_threshold * am_max[n])) v = a.minus_inf;
   }
+  if (c == a.blank) v = kNeg;
+  comb[(size_t)n * a.V + c] = v + (psi[(size_t)n * a.V + c] - psi_prev[n]) * a.weight;
 }
 
 // New per-frame state of hypothesis n = (parent hyp, token) chosen by the beam search: one wave per
@@ -459,32 +459,34 @@ int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, f
   return launch_status("ctc_init");
 }
 
-int ctc_score_step(const float* P, const float* state, const float* psi_prev, const int32_t* last_tok,
-                   const int32_t* enc_len, const float* am, float* comb, float* psi, int B, int T, int V, int beam,
-                   int prefix_len, int blank, int eos, float weight, int eos_floor, int use_thr, float thr,
-                   float minus_inf, const float* am_max, hipStream_t st) {
-  CtcStepArgs a{last_tok, enc_len, B, T, V, beam, prefix_len, blank, eos, weight, eos_floor, use_thr, thr, minus_inf};
+// psi[n,c] for every hypothesis / token (needs only the CTC state: can run beside the decoder step)
+int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, const int32_t* enc_len, float* psi, int B,
+                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st) {
+  CtcStepArgs a{last_tok, enc_len, B, T, V, beam, prefix_len, blank, eos, 0.0f, 0, 0, 0.0f, 0.0f};
   const StateView v = view(const_cast<float*>(state), B * beam, T);
-  ProfScope prof("ctc_score_step", 2.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 12.0 * B * beam * V, st);
+  ProfScope prof("ctc_score_step", 2.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 4.0 * B * beam * V, st);
   dim3 grid(cdiv(V, 256), B), block(256);
   if (beam == 1) {
-    SBK_LAUNCH((ctc_score_step_kernel<1>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg,
-               (const int*)v.se, psi_prev, am, am_max, comb, psi);
+    SBK_LAUNCH((ctc_score_step_kernel<1>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
   } else if (beam <= 4) {
-    SBK_LAUNCH((ctc_score_step_kernel<4>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg,
-               (const int*)v.se, psi_prev, am, am_max, comb, psi);
+    SBK_LAUNCH((ctc_score_step_kernel<4>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
   } else if (beam <= 10) {
-    SBK_LAUNCH((ctc_score_step_kernel<10>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg,
-               (const int*)v.se, psi_prev, am, am_max, comb, psi);
+    SBK_LAUNCH((ctc_score_step_kernel<10>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
   } else {
-    SBK_LAUNCH((ctc_score_step_kernel<16>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg,
-               (const int*)v.se, psi_prev, am, am_max, comb, psi);
+    SBK_LAUNCH((ctc_score_step_kernel<16>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
   }
   int rc = launch_status("ctc_score_step");
   if (rc) return rc;
-  SBK_LAUNCH(ctc_same_token_kernel, dim3(B * beam), dim3(64), 0, st, a, P, (const float*)v.sb, (const int*)v.se, psi_prev,
-             am, am_max, comb, psi);
+  SBK_LAUNCH(ctc_same_token_kernel, dim3(B * beam), dim3(64), 0, st, a, P, (const float*)v.sb, (const int*)v.se, psi);
   return launch_status("ctc_same_token");
+}
+
+int ctc_combine(const float* am, const float* am_max, const float* psi, const float* psi_prev, float* comb, int n_bh,
+                int V, int blank, int eos, float weight, int eos_floor, int use_thr, float thr, float minus_inf,
+                hipStream_t st) {
+  CtcStepArgs a{nullptr, nullptr, 0, 0, V, 0, 0, blank, eos, weight, eos_floor, use_thr, thr, minus_inf};
+  SBK_LAUNCH(ctc_combine_kernel, dim3(cdiv(V, 256), n_bh), dim3(256), 0, st, a, am, am_max, psi, psi_prev, comb);
+  return launch_status("ctc_combine");
 }
 
 int ctc_advance(const float* P, const float* state_old, const float* psi, const int32_t* parent, const int32_t* token,

@@ -28,10 +28,11 @@ int log_softmax_rows(const float* x, float* out, int rows, int V, float temperat
 int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, float* psi_prev, int B, int T, int V,
                 int beam, int blank, hipStream_t st);
 size_t ctc_state_floats(int n_bh, int T);
-int ctc_score_step(const float* x, const float* phi, const float* psi_prev, const int32_t* last_tok,
-                   const int32_t* enc_len, const float* am, float* comb, float* psi, int B, int T, int V, int beam,
-                   int prefix_len, int blank, int eos, float weight, int eos_floor, int use_thr, float thr,
-                   float minus_inf, const float* am_max, hipStream_t st);
+int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, const int32_t* enc_len, float* psi, int B,
+                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st);
+int ctc_combine(const float* am, const float* am_max, const float* psi, const float* psi_prev, float* comb, int n_bh,
+                int V, int blank, int eos, float weight, int eos_floor, int use_thr, float thr, float minus_inf,
+                hipStream_t st);
 int ctc_advance(const float* x, const float* phi_old, const float* psi, const int32_t* parent, const int32_t* token,
                 const int32_t* parent_last_tok, float* phi_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
                 int prefix_len, int blank, hipStream_t st);
@@ -41,6 +42,24 @@ int row_max(const float* x, float* out, int rows, int V, hipStream_t st);
 }  // namespace sbk
 
 namespace {
+
+// The CTC scorer's work of a step (psi of every candidate, then the survivors' new state) depends
+// only on the beam bookkeeping, not on the decoder step: it runs on a helper stream beside the
+// decoder GEMMs and is joined just before the scores are combined.
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+SideStream* side_stream() {
+  static thread_local SideStream ss;  // one per host thread (= per concurrent search)
+  if (!ss.s) {
+    if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess)
+      return nullptr;
+  }
+  return &ss;
+}
 
 constexpr int kMaxBeam = 16;
 
@@ -594,6 +613,17 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   SBK_TRY(sbk::launch_status("beam_init"));
 
   const float attn_w = ctc ? 1.0f - cfg->ctc_weight : 1.0f;  // seq2seq.py:803-804
+  SideStream* side = ctc ? side_stream() : nullptr;
+  hipStream_t cst = side ? side->s : st;  // stream of the CTC work
+  if (ctc) {
+    if (side) {
+      SBK_HIP(hipEventRecord(side->fork, st));
+      SBK_HIP(hipStreamWaitEvent(cst, side->fork, 0));
+    }
+    SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[0], bb.s.tokens[0], enc_len, bb.psi, B, T, V, beam, 0, cfg->blank,
+                              cfg->eos, cst));
+    if (side) SBK_HIP(hipEventRecord(side->join, cst));
+  }
   int cur = 0, steps = 0;
   for (int step = 0; step < cfg->max_steps; ++step) {
     SBK_TRY(decoder_step(W, d, bb.s.tokens[cur], bb.s.kv_slot[cur], enc_len, step, n, B, T, beam, Lmax, true, st));
@@ -601,9 +631,10 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
     if (cfg->using_eos_threshold) SBK_TRY(sbk::row_max(bb.am, bb.am_max, n, V, st));
     const int eos_floor = step < cfg->min_steps;
     if (ctc) {
-      SBK_TRY(sbk::ctc_score_step(bb.ctc_x, bb.phi[cur], bb.psi_prev[cur], bb.s.tokens[cur], enc_len, bb.am, bb.comb,
-                                  bb.psi, B, T, V, beam, step, cfg->blank, cfg->eos, cfg->ctc_weight, eos_floor,
-                                  cfg->using_eos_threshold, cfg->eos_threshold, cfg->minus_inf, bb.am_max, st));
+      if (side) SBK_HIP(hipStreamWaitEvent(st, side->join, 0));  // psi of this step is ready
+      SBK_TRY(sbk::ctc_combine(bb.am, bb.am_max, bb.psi, bb.psi_prev[cur], bb.comb, n, V, cfg->blank, cfg->eos,
+                               cfg->ctc_weight, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
+                               cfg->minus_inf, st));
     } else {
       SBK_TRY(sbk::am_only(bb.am, bb.comb, n, V, cfg->eos, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
                            cfg->minus_inf, bb.am_max, st));
@@ -623,9 +654,17 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
                  cfg->eos, cfg->length_normalization);
     }
     SBK_TRY(sbk::launch_status("beam_update"));
-    if (ctc)
+    if (ctc && step + 1 < cfg->max_steps) {  // survivors' CTC state, then the next step's psi -- beside the next decoder step
+      if (side) {
+        SBK_HIP(hipEventRecord(side->fork, st));
+        SBK_HIP(hipStreamWaitEvent(cst, side->fork, 0));
+      }
       SBK_TRY(sbk::ctc_advance(bb.ctc_x, bb.phi[cur], bb.psi, bb.s.parent, bb.s.tokens[cur ^ 1], bb.s.tokens[cur],
-                               bb.phi[cur ^ 1], bb.psi_prev[cur ^ 1], n, T, V, beam, step, cfg->blank, st));
+                               bb.phi[cur ^ 1], bb.psi_prev[cur ^ 1], n, T, V, beam, step, cfg->blank, cst));
+      SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[cur ^ 1], bb.s.tokens[cur ^ 1], enc_len, bb.psi, B, T, V, beam, step + 1,
+                                cfg->blank, cfg->eos, cst));
+      if (side) SBK_HIP(hipEventRecord(side->join, cst));
+    }
     cur ^= 1;
     steps = step + 1;
     if (host_flag && cfg->check_every > 0 && (steps % cfg->check_every == 0) && steps < cfg->max_steps) {
@@ -634,6 +673,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
       if (*host_flag >= B) break;
     }
   }
+  if (side) SBK_HIP(hipStreamWaitEvent(st, side->join, 0));  // nothing of this call outlives it on the helper stream
   if (steps_run) *steps_run = steps;
   SBK_LAUNCH(beam_finalize_kernel, dim3(B), dim3(256), 0, st, bb.s, cur, steps, beam, Lmax, out_tokens, out_len,
              out_score, out_logp);
