@@ -169,6 +169,9 @@ typedef struct {
 typedef struct {
   int32_t bos, eos, blank, beam, min_steps, max_steps;
   int32_t length_normalization, using_eos_threshold, check_every;
+  int32_t overlap_ctc; /* 1: run the CTC scorer on a library-owned helper stream beside the decoder step
+                          (lowest single-batch latency); 0: everything on `stream` (best when the caller
+                          already keeps several batches in flight on different streams) */
   float ctc_weight, temperature, eos_threshold, minus_inf;
 } sbk_search_config;
 

@@ -5,7 +5,8 @@
 // sub-tile made of 32x32 MFMA accumulators.  A and W panels are staged through
 // LDS as [rows][BK+1] (odd pitch => the 32 lanes of an MFMA operand read hit 32
 // distinct banks), loaded from HBM as 16-byte vectors along K (both operands
-// are K-contiguous, so every global load is a full 128-byte line per 8 lanes).
+// are K-contiguous, so every global load is a full 128-byte line per 8 lanes)
+// into registers one K tile ahead, so HBM latency hides under the MFMAs.
 // The epilogue (bias, activation, scaled residual) runs on the accumulators in
 // registers and writes 128-byte rows (32 lanes x 4 B) per store instruction.
 #include "common.h"
@@ -36,39 +37,51 @@ struct GemmArgs {
   int rows_per_seq;
 };
 
-// Stage a [ROWS x BK] panel of a K-contiguous matrix into LDS (pitch BK+1).
-template <int ROWS, int BK, int NT, bool VEC>
-__device__ __forceinline__ void stage_panel(float (*dst)[BK + 1], const float* __restrict__ src, int ld, int row0,
-                                            int nrows, int k0, int K, int tid) {
-  if (VEC) {
-    constexpr int V = BK / 4;  // float4 slots per row
-    for (int s = tid; s < ROWS * V; s += NT) {
-      const int r = s / V, c = (s % V) * 4;
-      const int gr = row0 + r, gk = k0 + c;
+// Register-staged panel: global -> registers (issued early, in flight under the MFMAs of the previous
+// K tile) -> LDS [rows][BK+1].
+template <int ROWS, int BK, int NT>
+struct PanelStage {
+  static constexpr int V = BK / 4;                       // float4 slots per row
+  static constexpr int PER = (ROWS * V + NT - 1) / NT;   // float4 slots per thread
+  float4 r[PER];
+
+  template <bool VEC>
+  __device__ __forceinline__ void fetch(const float* __restrict__ src, int ld, int row0, int nrows, int k0, int K,
+                                        int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int s = tid + i * NT;
+      const int rr = s / V, c = (s % V) * 4;
+      const int gr = row0 + rr, gk = k0 + c;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < nrows) {
+      if (s < ROWS * V && gr < nrows) {
         const float* p = src + (size_t)gr * ld + gk;
-        if (gk + 3 < K) {
+        if (VEC && gk + 3 < K) {
           v = *reinterpret_cast<const float4*>(p);
         } else {
           if (gk < K) v.x = p[0];
           if (gk + 1 < K) v.y = p[1];
           if (gk + 2 < K) v.z = p[2];
+          if (gk + 3 < K) v.w = p[3];
         }
       }
-      dst[r][c] = v.x;
-      dst[r][c + 1] = v.y;
-      dst[r][c + 2] = v.z;
-      dst[r][c + 3] = v.w;
-    }
-  } else {
-    for (int s = tid; s < ROWS * BK; s += NT) {
-      const int r = s / BK, c = s % BK;
-      const int gr = row0 + r, gk = k0 + c;
-      dst[r][c] = (gr < nrows && gk < K) ? src[(size_t)gr * ld + gk] : 0.0f;
+      r[i] = v;
     }
   }
-}
+  __device__ __forceinline__ void commit(float (*dst)[BK + 1], int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int s = tid + i * NT;
+      if (s < ROWS * V) {
+        const int rr = s / V, c = (s % V) * 4;
+        dst[rr][c] = r[i].x;
+        dst[rr][c + 1] = r[i].y;
+        dst[rr][c + 2] = r[i].z;
+        dst[rr][c + 3] = r[i].w;
+      }
+    }
+  }
+};
 
 template <int BM, int BN, int BK, int WM, int WN, bool VEC>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(GemmArgs g) {
@@ -81,7 +94,19 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(Gem
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order (workgroup id % 8 = XCD): each XCD walks a contiguous range of tiles, so the
+  // A row panel shared by neighbouring tiles is fetched into one L2 instead of eight.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int id = by * gx + bx;
+    if (nwg % 8 == 0) {
+      const int swz = (id % 8) * (nwg / 8) + id / 8;
+      bx = swz % gx;
+      by = swz / gx;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   const int lrow = lane & 31, lk = lane >> 5;
 
   f32x16 acc[TM][TN];
@@ -92,10 +117,18 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(Gem
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  PanelStage<BM, BK, NT> pa;
+  PanelStage<BN, BK, NT> pw;
+  pa.template fetch<VEC>(g.A, g.lda, m0, g.M, 0, g.K, tid);
+  pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, 0, g.K, tid);
   for (int k0 = 0; k0 < g.K; k0 += BK) {
-    stage_panel<BM, BK, NT, VEC>(As, g.A, g.lda, m0, g.M, k0, g.K, tid);
-    stage_panel<BN, BK, NT, VEC>(Ws, g.W, g.ldw, n0, g.N, k0, g.K, tid);
+    pa.commit(As, tid);
+    pw.commit(Ws, tid);
     __syncthreads();
+    if (k0 + BK < g.K) {  // next K tile: loads fly while this tile is multiplied
+      pa.template fetch<VEC>(g.A, g.lda, m0, g.M, k0 + BK, g.K, tid);
+      pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, k0 + BK, g.K, tid);
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];

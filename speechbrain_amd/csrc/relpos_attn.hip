@@ -91,15 +91,23 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
   const int nkt = (T + 31) / 32;
   for (int kt = wave; kt < nkt; kt += 4) {
     const int j0 = kt * 32;
-    float breg[DH2];
+    // all three operand runs of this key tile (K, P[rbase..], P[rbase+32..]) are requested up front,
+    // so their latency is paid once per tile and overlaps the first MFMA chain
+    float kreg[DH2], p0reg[DH2], p1reg[DH2];
+    const int rbase = (T - 1) - i0 - 31 + j0;
+    {
+      const int krow = min(j0 + jl, T - 1);
+      load_run<DH2>(kreg, qkv_b + (size_t)krow * row3 + DH + half * DH2);
+      const int prow0 = min(max(rbase + jl, 0), 2 * T - 2), prow1 = min(max(rbase + 32 + jl, 0), 2 * T - 2);
+      load_run<DH2>(p0reg, a.pos + (size_t)prow0 * d + h * DH + half * DH2);
+      load_run<DH2>(p1reg, a.pos + (size_t)prow1 * d + h * DH + half * DH2);
+    }
     f32x16 acc;
     {  // AC = (Q+u) K^T
-      const int krow = min(j0 + jl, T - 1);
-      load_run<DH2>(breg, qkv_b + (size_t)krow * row3 + DH + half * DH2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-      for (int s = 0; s < DH2; ++s) acc = sbk::mfma_32x32x2(Qu[jl * QP + s + half * DH2], breg[s], acc);
+      for (int s = 0; s < DH2; ++s) acc = sbk::mfma_32x32x2(Qu[jl * QP + s + half * DH2], kreg[s], acc);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -107,16 +115,14 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
       }
     }
     sbk::wave_sync();
-    const int rbase = (T - 1) - i0 - 31 + j0;
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {  // BD: G = (Q+v) P[rbase + 32*pt ...]^T, added along the skew
       const int rl = pt * 32 + jl;
-      const int prow = min(max(rbase + rl, 0), 2 * T - 2);
-      load_run<DH2>(breg, a.pos + (size_t)prow * d + h * DH + half * DH2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-      for (int s = 0; s < DH2; ++s) acc = sbk::mfma_32x32x2(Qv[jl * QP + s + half * DH2], breg[s], acc);
+      for (int s = 0; s < DH2; ++s)
+        acc = sbk::mfma_32x32x2(Qv[jl * QP + s + half * DH2], pt == 0 ? p0reg[s] : p1reg[s], acc);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -166,11 +172,17 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    for (int t0 = t_begin; t0 < t_end; t0 += 2) {
-      const int t = t0 + half;
-      const float pv = S[jl * SP + t];
-      const float vv = col_ok ? vbase[(size_t)min(t, T - 1) * row3] : 0.0f;
-      acc = sbk::mfma_32x32x2(pv, vv, acc);
+    for (int t0 = t_begin; t0 < t_end; t0 += 16) {  // 8 k-steps per round: 8 V loads in flight per lane
+      float pv[8], vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + 2 * u + half;
+        const bool ok = t0 + 2 * u < t_end;
+        vv[u] = (ok && col_ok) ? vbase[(size_t)min(t, T - 1) * row3] : 0.0f;
+        pv[u] = ok ? S[jl * SP + min(t, SP - 1)] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = sbk::mfma_32x32x2(pv[u], vv[u], acc);
     }
     if (part > 0) {
       float* dst = red + ((part - 1) * NC + ct) * 32 * 33;

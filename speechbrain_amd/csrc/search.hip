@@ -613,7 +613,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   SBK_TRY(sbk::launch_status("beam_init"));
 
   const float attn_w = ctc ? 1.0f - cfg->ctc_weight : 1.0f;  // seq2seq.py:803-804
-  SideStream* side = ctc ? side_stream() : nullptr;
+  SideStream* side = (ctc && cfg->overlap_ctc) ? side_stream() : nullptr;
   hipStream_t cst = side ? side->s : st;  // stream of the CTC work
   if (ctc) {
     if (side) {

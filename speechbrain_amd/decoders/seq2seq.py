@@ -89,6 +89,7 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
         self.minus_inf = minus_inf
         self.attn_weight, self.ctc_weight = 1.0, 0.0
         self.check_every = 8
+        self.overlap_ctc = True  # CTC scorer on a helper stream beside the decoder step (see include/sbk.h)
         self.blank_index = 0
         self.ctc_fc = None
         if scorer is not None:
@@ -110,6 +111,7 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
         return native.SearchConfig(bos=self.bos_index, eos=self.eos_index, blank=self.blank_index, beam=self.beam_size,
                                    min_steps=mn, max_steps=mx, length_normalization=int(self.length_normalization),
                                    using_eos_threshold=int(self.using_eos_threshold), check_every=self.check_every,
+                                   overlap_ctc=int(self.overlap_ctc),
                                    ctc_weight=self.ctc_weight, temperature=self.temperature,
                                    eos_threshold=self.eos_threshold, minus_inf=self.minus_inf)
 

@@ -43,7 +43,7 @@ class DecoderWeights(ctypes.Structure):  # sbk_decoder_weights
 class SearchConfig(ctypes.Structure):  # sbk_search_config
     _fields_ = [("bos", c_int32), ("eos", c_int32), ("blank", c_int32), ("beam", c_int32), ("min_steps", c_int32),
                 ("max_steps", c_int32), ("length_normalization", c_int32), ("using_eos_threshold", c_int32),
-                ("check_every", c_int32), ("ctc_weight", c_float), ("temperature", c_float),
+                ("check_every", c_int32), ("overlap_ctc", c_int32), ("ctc_weight", c_float), ("temperature", c_float),
                 ("eos_threshold", c_float), ("minus_inf", c_float)]
 
 
