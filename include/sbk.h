@@ -169,9 +169,10 @@ typedef struct {
 typedef struct {
   int32_t bos, eos, blank, beam, min_steps, max_steps;
   int32_t length_normalization, using_eos_threshold, check_every;
-  int32_t overlap_ctc; /* 1: run the CTC scorer on a library-owned helper stream beside the decoder step
-                          (lowest single-batch latency); 0: everything on `stream` (best when the caller
-                          already keeps several batches in flight on different streams) */
+  int32_t overlap_ctc; /* bit 0: the survivors' CTC state update runs on a library-owned helper stream beside
+                          the next decoder step; bit 1: so does the full-vocabulary CTC score pass (lowest
+                          single-batch latency; costs throughput when the caller already keeps several
+                          batches in flight on different streams); 0: everything on `stream` */
   float ctc_weight, temperature, eos_threshold, minus_inf;
 } sbk_search_config;
 

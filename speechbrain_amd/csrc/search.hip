@@ -613,16 +613,18 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   SBK_TRY(sbk::launch_status("beam_init"));
 
   const float attn_w = ctc ? 1.0f - cfg->ctc_weight : 1.0f;  // seq2seq.py:803-804
+  // overlap_ctc bit 0: survivors' CTC state (ctc_advance: one wave per hypothesis, latency-bound) on the
+  // helper stream beside the next decoder step; bit 1: the full-vocabulary psi pass there as well.
   SideStream* side = (ctc && cfg->overlap_ctc) ? side_stream() : nullptr;
-  hipStream_t cst = side ? side->s : st;  // stream of the CTC work
-  if (ctc) {
-    if (side) {
-      SBK_HIP(hipEventRecord(side->fork, st));
-      SBK_HIP(hipStreamWaitEvent(cst, side->fork, 0));
-    }
+  const bool psi_aside = side && (cfg->overlap_ctc & 2);
+  hipStream_t cst = side ? side->s : st;      // stream of ctc_advance
+  hipStream_t pst = psi_aside ? side->s : st;  // stream of ctc_psi_step
+  if (ctc && psi_aside) {
+    SBK_HIP(hipEventRecord(side->fork, st));
+    SBK_HIP(hipStreamWaitEvent(cst, side->fork, 0));
     SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[0], bb.s.tokens[0], enc_len, bb.psi, B, T, V, beam, 0, cfg->blank,
-                              cfg->eos, cst));
-    if (side) SBK_HIP(hipEventRecord(side->join, cst));
+                              cfg->eos, pst));
+    SBK_HIP(hipEventRecord(side->join, cst));
   }
   int cur = 0, steps = 0;
   for (int step = 0; step < cfg->max_steps; ++step) {
@@ -631,7 +633,10 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
     if (cfg->using_eos_threshold) SBK_TRY(sbk::row_max(bb.am, bb.am_max, n, V, st));
     const int eos_floor = step < cfg->min_steps;
     if (ctc) {
-      if (side) SBK_HIP(hipStreamWaitEvent(st, side->join, 0));  // psi of this step is ready
+      if (side && (psi_aside || step > 0)) SBK_HIP(hipStreamWaitEvent(st, side->join, 0));  // helper-stream work done
+      if (!psi_aside)
+        SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[cur], bb.s.tokens[cur], enc_len, bb.psi, B, T, V, beam, step,
+                                  cfg->blank, cfg->eos, st));
       SBK_TRY(sbk::ctc_combine(bb.am, bb.am_max, bb.psi, bb.psi_prev[cur], bb.comb, n, V, cfg->blank, cfg->eos,
                                cfg->ctc_weight, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
                                cfg->minus_inf, st));
@@ -661,8 +666,9 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
       }
       SBK_TRY(sbk::ctc_advance(bb.ctc_x, bb.phi[cur], bb.psi, bb.s.parent, bb.s.tokens[cur ^ 1], bb.s.tokens[cur],
                                bb.phi[cur ^ 1], bb.psi_prev[cur ^ 1], n, T, V, beam, step, cfg->blank, cst));
-      SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[cur ^ 1], bb.s.tokens[cur ^ 1], enc_len, bb.psi, B, T, V, beam, step + 1,
-                                cfg->blank, cfg->eos, cst));
+      if (psi_aside)
+        SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[cur ^ 1], bb.s.tokens[cur ^ 1], enc_len, bb.psi, B, T, V, beam,
+                                  step + 1, cfg->blank, cfg->eos, pst));
       if (side) SBK_HIP(hipEventRecord(side->join, cst));
     }
     cur ^= 1;

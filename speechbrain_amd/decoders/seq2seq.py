@@ -89,7 +89,7 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
         self.minus_inf = minus_inf
         self.attn_weight, self.ctc_weight = 1.0, 0.0
         self.check_every = 8
-        self.overlap_ctc = True  # CTC scorer on a helper stream beside the decoder step (see include/sbk.h)
+        self.overlap_ctc = 3  # CTC scorer on a helper stream beside the decoder step (bit mask, see include/sbk.h)
         self.blank_index = 0
         self.ctc_fc = None
         if scorer is not None:

@@ -137,7 +137,9 @@ def test_beam_search_long_memory_vs_oracle(backend):
     bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
                                     min_decode_ratio=0.0, max_decode_ratio=ratio, beam_size=4,
                                     using_eos_threshold=False, length_normalization=True, scorer=scorer)
-    hyps, lens, sc, _ = bs(enc.to(dev), wl.to(dev))
-    assert hyps == hyps_ref
-    assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
-    assert float((lens.cpu() - lens_ref).abs().max()) <= 1e-6
+    for overlap in (3, 1, 0):  # helper-stream modes of the CTC scorer must not change the result
+        bs.overlap_ctc = overlap
+        hyps, lens, sc, _ = bs(enc.to(dev), wl.to(dev))
+        assert hyps == hyps_ref
+        assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
+        assert float((lens.cpu() - lens_ref).abs().max()) <= 1e-6
