@@ -38,6 +38,10 @@ const char* sbk_last_error(void);
 void sbk_prof_enable(int on);
 void sbk_prof_reset(void);
 size_t sbk_prof_report(char* buf, size_t cap);
+/* mean microseconds per launch of C[M,N] = A[M,K].W[N,K]^T over `iters` back-to-back launches
+ * (tools/microbench.py; synchronises the stream). us_per_launch is a HOST pointer. */
+int sbk_prof_gemm_repeat_f32(const float* A, const float* W, float* C, int M, int N, int K, float* workspace,
+                             size_t workspace_floats, int iters, float* us_per_launch, sbk_stream_t stream);
 
 /* ---- activations understood by fused epilogues --------------------------- */
 enum { SBK_ACT_NONE = 0, SBK_ACT_SWISH = 1, SBK_ACT_GELU = 2, SBK_ACT_RELU = 3, SBK_ACT_LEAKY_RELU = 4 };

@@ -205,79 +205,72 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
   const int nf = max(0, t1 - t0);
   const float* kvb = a.kv + (size_t)b * T * 2 * d + h * DH;
 
-  // Every global load of the workgroup is requested up front: the K row of this thread's frame and
-  // the V elements of this lane's channel for the wave's 32 frames (frames f = wave + 4*u).  The
-  // memory latency is then paid once, under the query staging, instead of once per phase.
-  const int f = tid & (kFC - 1), par = tid / kFC;  // scores: 2 threads per frame, beams split by parity
-  float kr[DH];
-  if (f < nf) {
-    const float* kp = kvb + (size_t)(t0 + f) * 2 * d;
-#pragma unroll
-    for (int c = 0; c < DH; ++c) kr[c] = kp[c];
-  }
-  constexpr int VPL = kFC / 4;  // frames per wave
-  float vreg[VPL];
-  {
-    const int c = lane < DH ? lane : 0;
-    const float* vcol = kvb + (size_t)t0 * 2 * d + d + c;
-#pragma unroll
-    for (int u = 0; u < VPL; ++u) {
-      const int fr = wave + 4 * u;
-      vreg[u] = (fr < nf && lane < DH) ? vcol[(size_t)fr * 2 * d] : 0.0f;
-    }
-  }
   for (int idx = tid; idx < kQT * DH; idx += 256) {
     const int j = idx / DH, c = idx % DH;
     qs[j][c] = j < nq ? a.q[((size_t)b * a.beam + q0 + j) * d + h * DH + c] * a.scale : 0.0f;
   }
   __syncthreads();
-  if (f < nf) {
-    for (int j = par; j < nq; j += 256 / kFC) {
-      float s = 0.0f;
+  // scores: per needs <= kFC (checked by the launcher)
+  {
+    const int f = tid & (kFC - 1), par = tid / kFC;  // 2 threads per frame, beams split by parity
+    if (f < nf) {
+      float kr[DH];
+      const float* kp = kvb + (size_t)(t0 + f) * 2 * d;
 #pragma unroll
-      for (int c = 0; c < DH; ++c) s = fmaf(qs[j][c], kr[c], s);
-      S[j][f] = s;
+      for (int c = 0; c < DH; ++c) kr[c] = kp[c];
+      for (int j = par; j < nq; j += 256 / kFC) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) s = fmaf(qs[j][c], kr[c], s);
+        S[j][f] = s;
+      }
     }
   }
   __syncthreads();
-  for (int j = wave; j < kQT; j += 4) {  // one wave per query row (rows past nq are zero-filled)
-    if (j < nq) {
-      float m = -INFINITY;
-      for (int ff = lane; ff < nf; ff += 64) m = fmaxf(m, S[j][ff]);
-      m = sbk::wave_max(m);
-      float sum = 0.0f;
-      for (int ff = lane; ff < nf; ff += 64) {
-        const float e = expf(S[j][ff] - m);
-        S[j][ff] = e;
-        sum += e;
-      }
-      sum = sbk::wave_sum(sum);
-      if (a.NS == 1)
-        for (int ff = lane; ff < nf; ff += 64) S[j][ff] = S[j][ff] / sum;
-      if (lane == 0) {
-        mx[j] = m;
-        sm[j] = sum;
-      }
-    } else {
-      for (int ff = lane; ff < kFC; ff += 64) S[j][ff] = 0.0f;
+  for (int j = wave; j < nq; j += 4) {  // one wave per query row
+    float m = -INFINITY;
+    for (int f = lane; f < nf; f += 64) m = fmaxf(m, S[j][f]);
+    m = sbk::wave_max(m);
+    float sum = 0.0f;
+    for (int f = lane; f < nf; f += 64) {
+      const float e = expf(S[j][f] - m);
+      S[j][f] = e;
+      sum += e;
+    }
+    sum = sbk::wave_sum(sum);
+    if (a.NS == 1)
+      for (int f = lane; f < nf; f += 64) S[j][f] = S[j][f] / sum;
+    if (lane == 0) {
+      mx[j] = m;
+      sm[j] = sum;
     }
   }
   __syncthreads();
-  {  // context from the prefetched V registers: wave <-> quarter of the frames, lane <-> channel
+  {  // context: wave <-> quarter of the frames, lane <-> channel; 8 V rows in flight per lane
     float acc[kQT];
 #pragma unroll
     for (int j = 0; j < kQT; ++j) acc[j] = 0.0f;
+    const int c = lane;
+    if (c < DH) {
+      const float* vcol = kvb + (size_t)t0 * 2 * d + d + c;
+      for (int f0 = wave; f0 < nf; f0 += 32) {
+        float v[8];
 #pragma unroll
-    for (int u = 0; u < VPL; ++u) {
-      const int fr = wave + 4 * u;
-      if (fr < nf) {
+        for (int u = 0; u < 8; ++u) {
+          const int f = f0 + 4 * u;
+          v[u] = f < nf ? vcol[(size_t)f * 2 * d] : 0.0f;
+        }
 #pragma unroll
-        for (int j = 0; j < kQT; ++j) acc[j] = fmaf(S[j][fr], vreg[u], acc[j]);
+        for (int u = 0; u < 8; ++u) {
+          const int f = f0 + 4 * u;
+          if (f < nf) {
+#pragma unroll
+            for (int j = 0; j < kQT; ++j) acc[j] = fmaf(S[j][f], v[u], acc[j]);
+          }
+        }
       }
-    }
-    if (lane < DH) {
 #pragma unroll
-      for (int j = 0; j < kQT; ++j) red[wave][j][lane] = acc[j];
+      for (int j = 0; j < kQT; ++j) red[wave][j][c] = acc[j];
     }
   }
   __syncthreads();

@@ -361,3 +361,29 @@ extern "C" int sbk_gemm_nt_splitk_f32(const float* A, int lda, const float* W, i
   return sbk::gemm_nt_ws(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, nullptr, 0, workspace,
                          workspace ? workspace_floats : 0, sbk::as_stream(stream));
 }
+
+
+// Measurement helper: `iters` back-to-back launches of the same contraction between two events on
+// `stream` (host launch overhead amortised); returns the mean time per launch in microseconds.
+extern "C" int sbk_prof_gemm_repeat_f32(const float* A, const float* W, float* C, int M, int N, int K, float* workspace,
+                                        size_t workspace_floats, int iters, float* us_per_launch,
+                                        sbk_stream_t stream) {
+  SBK_REQUIRE(A && W && C && us_per_launch && iters > 0, "gemm_repeat: bad arguments");
+  hipStream_t st = sbk::as_stream(stream);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return sbk::fail(1, "event create");
+  int rc = 0;
+  for (int i = 0; i < 3 && !rc; ++i)
+    rc = sbk::gemm_nt_ws(A, K, W, K, nullptr, nullptr, 0, C, N, M, N, K, SBK_ACT_NONE, 1.0f, nullptr, 0, workspace,
+                         workspace_floats, st);
+  (void)hipEventRecord(e0, st);
+  for (int i = 0; i < iters && !rc; ++i)
+    rc = sbk::gemm_nt_ws(A, K, W, K, nullptr, nullptr, 0, C, N, M, N, K, SBK_ACT_NONE, 1.0f, nullptr, 0, workspace,
+                         workspace_floats, st);
+  (void)hipEventRecord(e1, st);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.0f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *us_per_launch = ms * 1000.0f / iters;
+  return rc;
+}

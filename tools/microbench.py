@@ -1,5 +1,5 @@
 """Isolated kernel timings on the MI355X (back-to-back launches between two events)."""
-import sys, os, time
+import ctypes, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from speechbrain_amd import native as nat
@@ -22,15 +22,15 @@ def timeit(fn, n=200, warm=20):
 
 
 def gemm_case(M, N, K, slices):
-    a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
+    a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev)
     ws = torch.empty(max(1, slices * M * N), device=dev)
     out = torch.empty(M, N, device=dev)
     lib = nat.load()
-    def f():
-        lib.sbk_gemm_nt_splitk_f32(nat._p(a), K, nat._p(w), K, nat._p(b), None, N, nat._p(out), N, M, N, K, 0, 1.0,
-                                   nat._p(ws) if slices else None, ws.numel() if slices else 0, nat._stream(a))
-    us = timeit(f)
-    print(f"gemm M={M} N={N} K={K} slices={slices}: {us:8.2f} us  {2.0*M*N*K/us/1e6:7.2f} TFLOP/s", flush=True)
+    us = ctypes.c_float(0)
+    rc = lib.sbk_prof_gemm_repeat_f32(nat._p(a), nat._p(w), nat._p(out), M, N, K, nat._p(ws) if slices else None,
+                                      ws.numel() if slices else 0, 200, ctypes.byref(us), nat._stream(a))
+    assert rc == 0
+    print(f"gemm M={M} N={N} K={K} slices={slices}: {us.value:8.2f} us  {2.0*M*N*K/us.value/1e6:7.2f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":
