@@ -64,13 +64,17 @@ __device__ __forceinline__ void bf_exp(float x, float* m, int* e) {
 //   sg[h][t] = exp(gamma_h[t]) * 2^-seg_e[h][t/32],  sb[h][t] = exp(beta_h[t]) * 2^-seg_e[h][t/32]
 // with seg_e = the largest exponent inside the segment (so every entry is < 2).
 constexpr int kSeg = 32;
-__device__ __forceinline__ int nseg_of(int T) { return (T + kSeg - 1) / kSeg; }
+__device__ __host__ __forceinline__ int nseg_of(int T) { return (T + kSeg - 1) / kSeg; }
+__device__ __host__ __forceinline__ int beam_pitch(int beam) { return (beam + 3) & ~3; }
 
 // One wave converts the BF rows of one hypothesis (already in global memory / LDS as `row`) into the
 // scaled tables.  `row(t)` returns the BF of frame t.
+// sg / se are written with stride `bp` (the gamma table is stored [utterance][frame][beam], beam
+// fastest and padded to a multiple of 4, so that the score kernel fetches all beams of a frame with
+// a few wide scalar loads); sb is a plain per-hypothesis row.
 template <typename Row>
 __device__ __forceinline__ void build_segment_tables(Row row, int T, int lane, float* __restrict__ sg,
-                                                     float* __restrict__ sb, int* __restrict__ se) {
+                                                     float* __restrict__ sb, int* __restrict__ se, int bp) {
   const int nseg = nseg_of(T);
   for (int s0 = 0; s0 < nseg; s0 += 2) {  // two 32-frame segments per pass: lanes 0-31 and 32-63
     const int seg = s0 + (lane >> 5);
@@ -81,10 +85,10 @@ __device__ __forceinline__ void build_segment_tables(Row row, int T, int lane, f
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1) e = max(e, sbk::shfl_xor(e, m));  // max within the 32-lane half
     if (seg < nseg && t < T) {
-      sg[t] = sbk::fast_ldexp(v.mg, v.eg - e);
+      sg[(size_t)t * bp] = sbk::fast_ldexp(v.mg, v.eg - e);
       sb[t] = sbk::fast_ldexp(v.mb, v.eb - e);
     }
-    if (seg < nseg && (lane & 31) == 0) se[seg] = e;
+    if (seg < nseg && (lane & 31) == 0) se[(size_t)seg * bp] = e;
   }
 }
 
@@ -131,7 +135,9 @@ __global__ void __launch_bounds__(256) ctc_init_kernel(const float* __restrict__
   for (int j = wave; j < beam; j += 4) {
     const size_t n = (size_t)b * beam + j;
     const BF* rowp = st + n * T;
-    build_segment_tables([&](int t) { return rowp[t]; }, T, lane, sg + n * T, sb + n * T, se + n * nseg);
+    const int bp = beam_pitch(beam);
+    build_segment_tables([&](int t) { return rowp[t]; }, T, lane, sg + (size_t)b * T * bp + j, sb + n * T,
+                         se + (size_t)b * nseg * bp + j, bp);
   }
 }
 
@@ -178,14 +184,12 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
       Eps[j] = first ? 0 : kNegE;
     }
     // beams past the tile's end shadow its last beam (computed redundantly, never stored)
-    const float* grow[NB];
-    const int* erow[NB];
+    const int bp = beam_pitch(a.beam);
+    const float* sgb = sg + (size_t)b * T * bp;
+    const int* seb = se + (size_t)b * nseg * bp;
+    int jj[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const size_t n = (size_t)b * a.beam + j0 + min(j, nb - 1);
-      grow[j] = sg + n * T;
-      erow[j] = se + n * nseg;
-    }
+    for (int j = 0; j < NB; ++j) jj[j] = j0 + min(j, nb - 1);
     // phi[t-1] * P[t]: frame t uses table entry t-1, so segment s of the TABLE covers frames s*32+1 ...
     for (int s0 = (start - 1) / kSeg; s0 < nseg; ++s0) {
       float part[NB];
@@ -198,14 +202,14 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
         for (int q = 0; q < 8; ++q) p_nb[q] = (u0 + q < u_hi) ? Pb[(size_t)(u0 + q + 1) * V + cc] : 0.0f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const int u = min(u0 + q, u_hi - 1);
+          const float* grow = sgb + (size_t)min(u0 + q, u_hi - 1) * bp;  // all beams of one frame: contiguous, uniform
 #pragma unroll
-          for (int j = 0; j < NB; ++j) part[j] = fmaf(grow[j][u], p_nb[q], part[j]);
+          for (int j = 0; j < NB; ++j) part[j] = fmaf(grow[jj[j]], p_nb[q], part[j]);
         }
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int es = erow[j][s0];
+        const int es = seb[(size_t)s0 * bp + jj[j]];
         const int k = sbk::frexp_exp(part[j]);
         const int ep = part[j] > 0.0f ? es + k : kNegE;
         const float mp = sbk::fast_ldexp(part[j], -k);
@@ -252,7 +256,7 @@ __global__ void __launch_bounds__(64) ctc_same_token_kernel(CtcStepArgs a, const
   for (int u = start - 1 + lane; u < T - 1; u += 64) {
     const float term = sb[(size_t)n * T + u] * Pb[(size_t)(u + 1) * V + c];
     const int k = sbk::frexp_exp(term);
-    const int et = term > 0.0f ? se[(size_t)n * nseg + u / kSeg] + k : kNegE;
+    const int et = term > 0.0f ? se[((size_t)b * nseg + u / kSeg) * beam_pitch(a.beam) + n % a.beam] + k : kNegE;
     const float mt = sbk::fast_ldexp(term, -k);
     const int E2 = max(E, et);
     m = sbk::fast_ldexp(m, E - E2) + sbk::fast_ldexp(mt, et - E2);
@@ -392,8 +396,9 @@ __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
   }
   __syncthreads();
   const int nseg = nseg_of(T);
-  build_segment_tables([&](int t) { return bfrow[t]; }, T, lane, a.sg_new + (size_t)n * T, a.sb_new + (size_t)n * T,
-                       a.se_new + (size_t)n * nseg);
+  const int bp = beam_pitch(a.beam);
+  build_segment_tables([&](int t) { return bfrow[t]; }, T, lane, a.sg_new + (size_t)b * T * bp + n % a.beam,
+                       a.sb_new + (size_t)n * T, a.se_new + (size_t)b * nseg * bp + n % a.beam, bp);
   if (lane == 0) a.psi_prev_new[n] = a.psi[(size_t)p * a.V + c];
 }
 
@@ -434,18 +439,22 @@ struct StateView {
   float* sb;
   int* se;
 };
-StateView view(float* base, int n_bh, int T) {
+StateView view(float* base, int B, int beam, int T) {
+  const size_t n_bh = (size_t)B * beam, bp = beam_pitch(beam);
   StateView v;
   v.st = reinterpret_cast<BF*>(base);
-  v.sg = base + (size_t)4 * n_bh * T;
-  v.sb = v.sg + (size_t)n_bh * T;
-  v.se = reinterpret_cast<int*>(v.sb + (size_t)n_bh * T);
+  v.sg = base + 4 * n_bh * T;
+  v.sb = v.sg + (size_t)B * T * bp;
+  v.se = reinterpret_cast<int*>(v.sb + n_bh * T);
   return v;
 }
 }  // namespace
 
 // floats of one CTC state buffer: BF rows + the two segment-scaled tables + segment exponents
-size_t ctc_state_floats(int n_bh, int T) { return (size_t)6 * n_bh * T + (size_t)n_bh * ((T + kSeg - 1) / kSeg) + 16; }
+size_t ctc_state_floats(int B, int beam, int T) {
+  const size_t n_bh = (size_t)B * beam, bp = beam_pitch(beam);
+  return 4 * n_bh * T + (size_t)B * T * bp + n_bh * T + (size_t)B * nseg_of(T) * bp + 16;
+}
 
 // x: [B,T,V] log_softmax(ctc_lin(enc)) on entry, linear masked posteriors on exit.
 int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, float* psi_prev, int B, int T, int V,
@@ -453,7 +462,7 @@ int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, f
   SBK_LAUNCH(ctc_emissions_kernel, dim3(T, B), dim3(256), 0, st, x, xb_log, enc_len, T, V, blank);
   int rc = launch_status("ctc_emissions");
   if (rc) return rc;
-  StateView v = view(state, B * beam, T);
+  StateView v = view(state, B, beam, T);
   SBK_LAUNCH(ctc_init_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float), st, (const float*)xb_log, v.st, v.sg, v.sb,
              v.se, psi_prev, T, beam);
   return launch_status("ctc_init");
@@ -463,7 +472,7 @@ int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, f
 int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, const int32_t* enc_len, float* psi, int B,
                  int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st) {
   CtcStepArgs a{last_tok, enc_len, B, T, V, beam, prefix_len, blank, eos, 0.0f, 0, 0, 0.0f, 0.0f};
-  const StateView v = view(const_cast<float*>(state), B * beam, T);
+  const StateView v = view(const_cast<float*>(state), B, beam, T);
   ProfScope prof("ctc_score_step", 2.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 4.0 * B * beam * V, st);
   dim3 grid(cdiv(V, 256), B), block(256);
   if (beam == 1) {
@@ -492,8 +501,8 @@ int ctc_combine(const float* am, const float* am_max, const float* psi, const fl
 int ctc_advance(const float* P, const float* state_old, const float* psi, const int32_t* parent, const int32_t* token,
                 const int32_t* parent_last_tok, float* state_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
                 int prefix_len, int blank, hipStream_t st) {
-  const StateView vo = view(const_cast<float*>(state_old), n_bh, T);
-  const StateView vn = view(state_new, n_bh, T);
+  const StateView vo = view(const_cast<float*>(state_old), n_bh / beam, beam, T);
+  const StateView vn = view(state_new, n_bh / beam, beam, T);
   CtcAdvArgs a{P, vo.st, psi, parent, token, parent_last_tok, vn.st, vn.sg, vn.sb, vn.se, psi_prev_new, n_bh, T, V, beam,
                prefix_len, blank};
   const size_t lds = (size_t)7 * T * sizeof(float);

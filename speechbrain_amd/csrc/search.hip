@@ -27,7 +27,7 @@ size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam);
 int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st);
 int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, float* psi_prev, int B, int T, int V,
                 int beam, int blank, hipStream_t st);
-size_t ctc_state_floats(int n_bh, int T);
+size_t ctc_state_floats(int B, int beam, int T);
 int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, const int32_t* enc_len, float* psi, int B,
                  int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st);
 int ctc_combine(const float* am, const float* am_max, const float* psi, const float* psi_prev, float* comb, int n_bh,
@@ -554,7 +554,7 @@ void carve_beam(Carver& c, BeamBufs& b, int B, int beam, int T, int V, int Lmax,
     b.ctc_x = c.take<float>((size_t)B * T * V);
     b.ctc_xb = c.take<float>((size_t)B * T);
     for (int k = 0; k < 2; ++k) {
-      b.phi[k] = c.take<float>(sbk::ctc_state_floats((int)n, T));
+      b.phi[k] = c.take<float>(sbk::ctc_state_floats(B, beam, T));
       b.psi_prev[k] = c.take<float>(n);
     }
   }
