@@ -190,32 +190,48 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
     int jj[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) jj[j] = j0 + min(j, nb - 1);
-    // phi[t-1] * P[t]: frame t uses table entry t-1, so segment s of the TABLE covers frames s*32+1 ...
-    for (int s0 = (start - 1) / kSeg; s0 < nseg; ++s0) {
-      float part[NB];
+    // phi[t-1] * P[t]: frame t uses table entry u = t-1.  The frames are walked in chunks of 16 table
+    // entries (two per 32-entry scale segment); the emission values of the NEXT chunk are requested
+    // before the current chunk is accumulated, so two chunks (32 rows) are always in flight per lane.
+    constexpr int CH = 16;
+    const int u_begin = start - 1, u_end = T - 1;
+    auto fetch = [&](float (&buf)[CH], int cb) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j) part[j] = 0.0f;
-      const int u_lo = max(s0 * kSeg, start - 1), u_hi = min((s0 + 1) * kSeg, T - 1);  // table indices u = t-1
-      for (int u0 = u_lo; u0 < u_hi; u0 += 8) {  // 8 emission rows in flight per lane (16 measured slower: registers)
-        float p_nb[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) p_nb[q] = (u0 + q < u_hi) ? Pb[(size_t)(u0 + q + 1) * V + cc] : 0.0f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float* grow = sgb + (size_t)min(u0 + q, u_hi - 1) * bp;  // all beams of one frame: contiguous, uniform
-#pragma unroll
-          for (int j = 0; j < NB; ++j) part[j] = fmaf(grow[jj[j]], p_nb[q], part[j]);
-        }
+      for (int q = 0; q < CH; ++q) {
+        const int u = cb + q;
+        buf[q] = (u >= u_begin && u < u_end) ? Pb[(size_t)(u + 1) * V + cc] : 0.0f;
       }
+    };
+    float part[NB];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const int es = seb[(size_t)s0 * bp + jj[j]];
-        const int k = sbk::frexp_exp(part[j]);
-        const int ep = part[j] > 0.0f ? es + k : kNegE;
-        const float mp = sbk::fast_ldexp(part[j], -k);
-        const int P2 = max(Eps[j], ep);
-        mps[j] = sbk::fast_ldexp(mps[j], Eps[j] - P2) + sbk::fast_ldexp(mp, ep - P2);
-        Eps[j] = P2;
+    for (int j = 0; j < NB; ++j) part[j] = 0.0f;
+    float nxt[CH];
+    int cb = (u_begin / CH) * CH;
+    if (cb < u_end) fetch(nxt, cb);
+    for (; cb < u_end; cb += CH) {
+      float cur[CH];
+#pragma unroll
+      for (int q = 0; q < CH; ++q) cur[q] = nxt[q];
+      if (cb + CH < u_end) fetch(nxt, cb + CH);
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const float* grow = sgb + (size_t)min(cb + q, u_end - 1) * bp;  // all beams of one frame: contiguous, uniform
+#pragma unroll
+        for (int j = 0; j < NB; ++j) part[j] = fmaf(grow[jj[j]], cur[q], part[j]);
+      }
+      if (((cb + CH) % kSeg) == 0 || cb + CH >= u_end) {  // end of a scale segment: fold into the block-float sum
+        const int s0 = cb / kSeg;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int es = seb[(size_t)s0 * bp + jj[j]];
+          const int k = sbk::frexp_exp(part[j]);
+          const int ep = part[j] > 0.0f ? es + k : kNegE;
+          const float mp = sbk::fast_ldexp(part[j], -k);
+          const int P2 = max(Eps[j], ep);
+          mps[j] = sbk::fast_ldexp(mps[j], Eps[j] - P2) + sbk::fast_ldexp(mp, ep - P2);
+          Eps[j] = P2;
+          part[j] = 0.0f;
+        }
       }
     }
     if (!c_ok) continue;
@@ -451,6 +467,9 @@ StateView view(float* base, int B, int beam, int T) {
 }  // namespace
 
 // floats of one CTC state buffer: BF rows + the two segment-scaled tables + segment exponents
+int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, const int32_t* enc_len, float* psi, int B,
+                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st);
+
 size_t ctc_state_floats(int B, int beam, int T) {
   const size_t n_bh = (size_t)B * beam, bp = beam_pitch(beam);
   return 4 * n_bh * T + (size_t)B * T * bp + n_bh * T + (size_t)B * nseg_of(T) * bp + 16;
@@ -525,3 +544,30 @@ int row_max(const float* x, float* out, int rows, int V, hipStream_t st) {
 }
 
 }  // namespace sbk
+
+
+// Measurement helper (tools/microbench.py): `iters` back-to-back ctc_psi_step launches on a freshly
+// initialised state; mean microseconds per launch.  `work` >= ctc_state_floats + B*T + n_bh floats.
+extern "C" int sbk_prof_ctc_psi_repeat_f32(float* P_logsoftmax, const int32_t* enc_len, const int32_t* last_tok,
+                                           float* psi, float* work, int B, int T, int V, int beam, int prefix_len,
+                                           int iters, float* us_per_launch, sbk_stream_t stream) {
+  SBK_REQUIRE(P_logsoftmax && enc_len && last_tok && psi && work && us_per_launch && iters > 0, "psi_repeat: bad arguments");
+  hipStream_t st = sbk::as_stream(stream);
+  float* state = work;
+  float* xb = work + sbk::ctc_state_floats(B, beam, T);
+  float* psi_prev = xb + (size_t)B * T;
+  int rc = sbk::ctc_prepare(P_logsoftmax, xb, enc_len, state, psi_prev, B, T, V, beam, 0, st);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return sbk::fail(1, "event create");
+  for (int i = 0; i < 2 && !rc; ++i)
+    rc = sbk::ctc_psi_step(P_logsoftmax, state, last_tok, enc_len, psi, B, T, V, beam, prefix_len, 0, 2, st);
+  (void)hipEventRecord(e0, st);
+  for (int i = 0; i < iters && !rc; ++i)
+    rc = sbk::ctc_psi_step(P_logsoftmax, state, last_tok, enc_len, psi, B, T, V, beam, prefix_len, 0, 2, st);
+  (void)hipEventRecord(e1, st);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.0f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *us_per_launch = ms * 1000.0f / iters;
+  return rc;
+}

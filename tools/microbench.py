@@ -33,7 +33,24 @@ def gemm_case(M, N, K, slices):
     print(f"gemm M={M} N={N} K={K} slices={slices}: {us.value:8.2f} us  {2.0*M*N*K/us.value/1e6:7.2f} TFLOP/s", flush=True)
 
 
+def ctc_case(B, T, V, beam, prefix_len):
+    x = torch.log_softmax(torch.randn(B, T, V, device=dev), -1)
+    enc_len = torch.full((B,), T, dtype=torch.int32, device=dev)
+    last = torch.randint(3, V, (B * beam,), dtype=torch.int32, device=dev)
+    psi = torch.empty(B * beam, V, device=dev)
+    work = torch.empty(8 * B * beam * T + B * T + B * beam + 4096, device=dev)
+    us = ctypes.c_float(0)
+    rc = nat.load().sbk_prof_ctc_psi_repeat_f32(nat._p(x), nat._p(enc_len), nat._p(last), nat._p(psi), nat._p(work), B, T,
+                                                V, beam, prefix_len, 20, ctypes.byref(us), nat._stream(x))
+    assert rc == 0, nat.load().sbk_last_error()
+    print(f"ctc_psi B={B} T={T} V={V} beam={beam}: {us.value:8.1f} us  {4.0*B*T*V/us.value/1e3:7.1f} GB/s", flush=True)
+
+
 if __name__ == "__main__":
+    if "--ctc" in sys.argv:
+        for (B, T) in [(32, 251), (32, 440), (32, 751), (8, 440)]:
+            ctc_case(B, T, 5000, 10, 5)
+        sys.exit(0)
     print("launch overhead (empty-ish layernorm 4 rows):", end=" ")
     x = torch.randn(4, 512, device=dev); g = torch.ones(512, device=dev); bb = torch.zeros(512, device=dev)
     print(f"{timeit(lambda: nat.layernorm(x, g, bb, 1e-5)):.2f} us")
