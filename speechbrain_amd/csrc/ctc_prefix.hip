@@ -65,7 +65,7 @@ __device__ __forceinline__ void bf_exp(float x, float* m, int* e) {
 // with seg_e = the largest exponent inside the segment (so every entry is < 2).
 constexpr int kSeg = 32;
 __device__ __host__ __forceinline__ int nseg_of(int T) { return (T + kSeg - 1) / kSeg; }
-__device__ __host__ __forceinline__ int beam_pitch(int beam) { return (beam + 3) & ~3; }
+__device__ __host__ __forceinline__ int beam_pitch(int) { return 16; }  // table row pitch (max beam), 4 float4 per frame
 
 // One wave converts the BF rows of one hypothesis (already in global memory / LDS as `row`) into the
 // scaled tables.  `row(t)` returns the BF of frame t.
@@ -160,6 +160,9 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
                                                              const BF* __restrict__ st, const float* __restrict__ sg,
                                                              const int* __restrict__ se,
                                                              float* __restrict__ psi_out) {
+  constexpr int BP = 16;               // table row pitch
+  constexpr int NV = (NB + 3) / 4;     // float4 per frame actually consumed
+  SBK_DYN_LDS(float, lds);
   const int b = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   const bool c_ok = c < a.V;
@@ -169,84 +172,93 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   const int start = a.prefix_len > 1 ? a.prefix_len : 1;
   const float* Pb = P + (size_t)b * T * V;
   const int last_frame = a.enc_len[b] - 1;
+  // the utterance's scaled gamma table [T][16] and segment exponents [nseg][16] -> LDS (coalesced copy);
+  // every lane then reads the same address per frame (broadcast, conflict-free)
+  float* tab = lds;
+  int* segs = reinterpret_cast<int*>(lds + (size_t)T * BP);
+  {
+    const float4* src = reinterpret_cast<const float4*>(sg + (size_t)b * T * BP);
+    float4* dst = reinterpret_cast<float4*>(tab);
+    for (int i = threadIdx.x; i < T * (BP / 4); i += 256) dst[i] = src[i];
+    const int* es = se + (size_t)b * nseg * BP;
+    for (int i = threadIdx.x; i < nseg * BP; i += 256) segs[i] = es[i];
+  }
+  __syncthreads();
 
-  for (int j0 = 0; j0 < a.beam; j0 += NB) {
-    const int nb = min(NB, a.beam - j0);
-    // block-float accumulator: value = mps * 2^Eps
-    float mps[NB];
-    int Eps[NB];
-    const float p0 = Pb[cc];
+  // The prefix score of h = g.c needs only g's state:  psi = log( r_init + sum_t phi_g[t-1] * P_c[t] )
+  // (ctc.py:212-229).  Block-float accumulator per beam: value = mps * 2^Eps.  (beam <= NB; table
+  // columns past `beam` are zero, so the surplus accumulators idle harmlessly.)
+  float mps[NB];
+  int Eps[NB];
+  const float p0 = Pb[cc];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      // psi_init = r[start-1][nb]: x[0] (non-blank) at the very first step, nothing otherwise (ctc.py:168-172,212)
-      const bool first = a.prefix_len == 0 && p0 > 0.0f;
-      mps[j] = first ? p0 : 0.0f;
-      Eps[j] = first ? 0 : kNegE;
+  for (int j = 0; j < NB; ++j) {
+    // psi_init = r[start-1][nb]: x[0] (non-blank) at the very first step, nothing otherwise (ctc.py:168-172,212)
+    const bool first = a.prefix_len == 0 && p0 > 0.0f;
+    mps[j] = first ? p0 : 0.0f;
+    Eps[j] = first ? 0 : kNegE;
+  }
+  // phi[t-1] * P[t]: frame t uses table entry u = t-1.  Chunks of 16 table entries (two per 32-entry
+  // scale segment); the emission values of the NEXT chunk are requested before the current chunk is
+  // accumulated, so two chunks (32 rows) are in flight per lane.
+  constexpr int CH = 16;
+  const int u_begin = start - 1, u_end = T - 1;
+  auto fetch = [&](float (&buf)[CH], int cb) {
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int u = cb + q;
+      buf[q] = (u >= u_begin && u < u_end) ? Pb[(size_t)(u + 1) * V + cc] : 0.0f;
     }
-    // beams past the tile's end shadow its last beam (computed redundantly, never stored)
-    const int bp = beam_pitch(a.beam);
-    const float* sgb = sg + (size_t)b * T * bp;
-    const int* seb = se + (size_t)b * nseg * bp;
-    int jj[NB];
+  };
+  float part[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) jj[j] = j0 + min(j, nb - 1);
-    // phi[t-1] * P[t]: frame t uses table entry u = t-1.  The frames are walked in chunks of 16 table
-    // entries (two per 32-entry scale segment); the emission values of the NEXT chunk are requested
-    // before the current chunk is accumulated, so two chunks (32 rows) are always in flight per lane.
-    constexpr int CH = 16;
-    const int u_begin = start - 1, u_end = T - 1;
-    auto fetch = [&](float (&buf)[CH], int cb) {
+  for (int j = 0; j < NB; ++j) part[j] = 0.0f;
+  float nxt[CH];
+  int cb = (u_begin / CH) * CH;
+  if (cb < u_end) fetch(nxt, cb);
+  for (; cb < u_end; cb += CH) {
+    float cur[CH];
 #pragma unroll
-      for (int q = 0; q < CH; ++q) {
-        const int u = cb + q;
-        buf[q] = (u >= u_begin && u < u_end) ? Pb[(size_t)(u + 1) * V + cc] : 0.0f;
+    for (int q = 0; q < CH; ++q) cur[q] = nxt[q];
+    if (cb + CH < u_end) fetch(nxt, cb + CH);
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const float4* row = reinterpret_cast<const float4*>(tab + (size_t)min(cb + q, u_end - 1) * BP);
+      float g[NV * 4];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const float4 t4 = row[v];
+        g[4 * v] = t4.x; g[4 * v + 1] = t4.y; g[4 * v + 2] = t4.z; g[4 * v + 3] = t4.w;
       }
-    };
-    float part[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) part[j] = 0.0f;
-    float nxt[CH];
-    int cb = (u_begin / CH) * CH;
-    if (cb < u_end) fetch(nxt, cb);
-    for (; cb < u_end; cb += CH) {
-      float cur[CH];
+      for (int j = 0; j < NB; ++j) part[j] = fmaf(g[j], cur[q], part[j]);
+    }
+    if (((cb + CH) % kSeg) == 0 || cb + CH >= u_end) {  // end of a scale segment: fold into the block-float sum
+      const int* es = segs + (cb / kSeg) * BP;
 #pragma unroll
-      for (int q = 0; q < CH; ++q) cur[q] = nxt[q];
-      if (cb + CH < u_end) fetch(nxt, cb + CH);
-#pragma unroll
-      for (int q = 0; q < CH; ++q) {
-        const float* grow = sgb + (size_t)min(cb + q, u_end - 1) * bp;  // all beams of one frame: contiguous, uniform
-#pragma unroll
-        for (int j = 0; j < NB; ++j) part[j] = fmaf(grow[jj[j]], cur[q], part[j]);
-      }
-      if (((cb + CH) % kSeg) == 0 || cb + CH >= u_end) {  // end of a scale segment: fold into the block-float sum
-        const int s0 = cb / kSeg;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          const int es = seb[(size_t)s0 * bp + jj[j]];
-          const int k = sbk::frexp_exp(part[j]);
-          const int ep = part[j] > 0.0f ? es + k : kNegE;
-          const float mp = sbk::fast_ldexp(part[j], -k);
-          const int P2 = max(Eps[j], ep);
-          mps[j] = sbk::fast_ldexp(mps[j], Eps[j] - P2) + sbk::fast_ldexp(mp, ep - P2);
-          Eps[j] = P2;
-          part[j] = 0.0f;
-        }
+      for (int j = 0; j < NB; ++j) {
+        const int k = sbk::frexp_exp(part[j]);
+        const int ep = part[j] > 0.0f ? es[j] + k : kNegE;
+        const float mp = sbk::fast_ldexp(part[j], -k);
+        const int P2 = max(Eps[j], ep);
+        mps[j] = sbk::fast_ldexp(mps[j], Eps[j] - P2) + sbk::fast_ldexp(mp, ep - P2);
+        Eps[j] = P2;
+        part[j] = 0.0f;
       }
     }
-    if (!c_ok) continue;
+  }
+  if (!c_ok) return;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      if (j < nb) {
-        const int n = b * a.beam + j0 + j;
-        float psi = bf_log(mps[j], Eps[j]);
-        if (c == a.eos) {  // psi[eos] = log-sum of the prefix' own variables at the last frame (ctc.py:232-235)
-          const BF s = st[(size_t)n * T + last_frame];
-          psi = bf_log(s.mg, s.eg);
-        }
-        if (c == a.blank && a.eos != a.blank) psi = kNeg;
-        psi_out[(size_t)n * V + c] = psi;
+  for (int j = 0; j < NB; ++j) {
+    if (j < a.beam) {
+      const int n = b * a.beam + j;
+      float psi = bf_log(mps[j], Eps[j]);
+      if (c == a.eos) {  // psi[eos] = log-sum of the prefix' own variables at the last frame (ctc.py:232-235)
+        const BF s = st[(size_t)n * T + last_frame];
+        psi = bf_log(s.mg, s.eg);
       }
+      if (c == a.blank && a.eos != a.blank) psi = kNeg;
+      psi_out[(size_t)n * V + c] = psi;
     }
   }
 }
@@ -482,6 +494,8 @@ int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, f
   int rc = launch_status("ctc_emissions");
   if (rc) return rc;
   StateView v = view(state, B, beam, T);
+  // columns past `beam` of the [frame][16] tables are never written afterwards and must read as zero
+  if (hipMemsetAsync(v.sg, 0, (size_t)B * T * 16 * sizeof(float), st) != hipSuccess) return fail(1, "ctc: memset");
   SBK_LAUNCH(ctc_init_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float), st, (const float*)xb_log, v.st, v.sg, v.sb,
              v.se, psi_prev, T, beam);
   return launch_status("ctc_init");
@@ -494,14 +508,16 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
   const StateView v = view(const_cast<float*>(state), B, beam, T);
   ProfScope prof("ctc_score_step", 2.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 4.0 * B * beam * V, st);
   dim3 grid(cdiv(V, 256), B), block(256);
+  const size_t lds = ((size_t)T * 16 + (size_t)((T + kSeg - 1) / kSeg) * 16) * sizeof(float);
+  if (lds > 64 * 1024) return fail(SBK_EINVAL, "ctc_psi_step: T=%d too long for the LDS window", T);
   if (beam == 1) {
-    SBK_LAUNCH((ctc_score_step_kernel<1>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
+    SBK_LAUNCH((ctc_score_step_kernel<1>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
   } else if (beam <= 4) {
-    SBK_LAUNCH((ctc_score_step_kernel<4>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
+    SBK_LAUNCH((ctc_score_step_kernel<4>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
   } else if (beam <= 10) {
-    SBK_LAUNCH((ctc_score_step_kernel<10>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
+    SBK_LAUNCH((ctc_score_step_kernel<10>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
   } else {
-    SBK_LAUNCH((ctc_score_step_kernel<16>), grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
+    SBK_LAUNCH((ctc_score_step_kernel<16>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
   }
   int rc = launch_status("ctc_score_step");
   if (rc) return rc;

@@ -607,6 +607,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   if (ctc) {  // CTCScorer.reset_mem (scorer.py:239-255): log_softmax(ctc_lin(enc)), then the frame mask
     SBK_TRY(sbk::gemm_nt(enc, dm, ctc_w, dm, ctc_b, nullptr, 0, bb.ctc_x, V, B * T, V, dm, SBK_ACT_NONE, 1.0f, nullptr, 0, st));
     SBK_TRY(sbk::log_softmax_rows(bb.ctc_x, bb.ctc_x, B * T, V, 1.0f, 1.0f, st));
+    SBK_HIP(hipMemsetAsync(bb.phi[1], 0, sbk::ctc_state_floats(B, beam, T) * sizeof(float), st));  // zero table padding
     SBK_TRY(sbk::ctc_prepare(bb.ctc_x, bb.ctc_xb, enc_len, bb.phi[0], bb.psi_prev[0], B, T, V, beam, cfg->blank, st));
   }
   SBK_LAUNCH(beam_init_kernel, dim3(sbk::cdiv(n > B ? n : B, 256)), dim3(256), 0, st, bb.s, B, beam, cfg->bos);
