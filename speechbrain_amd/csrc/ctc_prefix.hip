@@ -22,9 +22,9 @@
 //  * ctc_advance: after the beam top-k picked (parent, token) for each new hypothesis, the
 //    forward recurrences
 //        Rnb[t] = (Rnb[t-1] + phi[t-1]) * P_c[t],   Rb[t] = (Rnb[t-1] + Rb[t-1]) * P_blank[t]
-//    are run for that single pair (block-float, re-normalised with frexp every frame) to obtain
-//    the survivor's per-frame state (the reference gathers it out of the materialised tensor,
-//    ctc.py:243-295).
+//    are evaluated for that single pair as a wave-parallel prefix scan over per-frame affine maps
+//    (block-float) to obtain the survivor's per-frame state (the reference gathers it out of the
+//    materialised tensor, ctc.py:243-295).
 // Values the reference represents with its finite -1e20 sentinel (ctc.py:53) are exact
 // zeros here and map back to -1e20 whenever a log-domain number leaves the kernels.
 #include "common.h"
@@ -316,6 +316,90 @@ __global__ void __launch_bounds__(256) ctc_combine_kernel(CtcStepArgs a, const f
   comb[(size_t)n * a.V + c] = v + (psi[(size_t)n * a.V + c] - psi_prev[n]) * a.weight;
 }
 
+// ---- the forward recurrence as a prefix scan ---------------------------------------------------
+// One frame maps the state s = (Rnb, Rb) to  s' = A s + v  with  A = [[pc,0],[pb,pb]],  v = (pc*phi, 0).
+// Such affine maps compose associatively (lower-triangular A stays lower-triangular), so the T-step
+// recurrence becomes: each lane composes the maps of its own run of frames, a 6-step wave scan
+// composes the lane maps, and each lane replays its run from the scanned prefix.  Maps and states
+// are block-float: (a, c, d) * 2^ea, (v0, v1) * 2^ev, (nb, bl) * 2^e -- exact power-of-two scaling.
+struct AMap {
+  float a, c, d, v0, v1;
+  int ea, ev;
+};
+struct AState {
+  float nb, bl;
+  int e;
+};
+__device__ __forceinline__ void norm2(float& x, float& y, int& e) {
+  const float m = fmaxf(x, y);
+  const int k = sbk::frexp_exp(m);
+  x = sbk::fast_ldexp(x, -k);
+  y = sbk::fast_ldexp(y, -k);
+  e = m > 0.0f ? e + k : kNegE;
+}
+__device__ __forceinline__ void norm3(float& x, float& y, float& z, int& e) {
+  const float m = fmaxf(fmaxf(x, y), z);
+  const int k = sbk::frexp_exp(m);
+  x = sbk::fast_ldexp(x, -k);
+  y = sbk::fast_ldexp(y, -k);
+  z = sbk::fast_ldexp(z, -k);
+  e = m > 0.0f ? e + k : kNegE;
+}
+__device__ __forceinline__ int clamp_e(int e) { return max(e, kNegE); }
+// s' = M s
+__device__ __forceinline__ AState apply_map(const AMap& m, const AState& s) {
+  // A s has exponent ea + e; v has exponent ev
+  const int e1 = clamp_e(m.ea + s.e), e2 = m.ev;
+  const int E = max(e1, e2);
+  const float x = sbk::fast_ldexp(m.a * s.nb, e1 - E) + sbk::fast_ldexp(m.v0, e2 - E);
+  const float y = sbk::fast_ldexp(m.c * s.nb + m.d * s.bl, e1 - E) + sbk::fast_ldexp(m.v1, e2 - E);
+  AState r{x, y, E};
+  norm2(r.nb, r.bl, r.e);
+  return r;
+}
+// (m2 after m1)
+__device__ __forceinline__ AMap compose(const AMap& m2, const AMap& m1) {
+  AMap r;
+  r.a = m2.a * m1.a;
+  r.d = m2.d * m1.d;
+  r.c = m2.c * m1.a + m2.d * m1.c;
+  r.ea = clamp_e(m2.ea + m1.ea);
+  norm3(r.a, r.c, r.d, r.ea);
+  const int e1 = clamp_e(m2.ea + m1.ev), e2 = m2.ev;
+  const int E = max(e1, e2);
+  r.v0 = sbk::fast_ldexp(m2.a * m1.v0, e1 - E) + sbk::fast_ldexp(m2.v0, e2 - E);
+  r.v1 = sbk::fast_ldexp(m2.c * m1.v0 + m2.d * m1.v1, e1 - E) + sbk::fast_ldexp(m2.v1, e2 - E);
+  r.ev = E;
+  norm2(r.v0, r.v1, r.ev);
+  return r;
+}
+__device__ __forceinline__ AMap frame_map(float pc, float pb, float mphi, int ephi) {
+  AMap m;
+  m.a = pc;
+  m.c = pb;
+  m.d = pb;
+  m.ea = 0;
+  norm3(m.a, m.c, m.d, m.ea);
+  m.v0 = pc * mphi;
+  m.v1 = 0.0f;
+  m.ev = ephi;
+  norm2(m.v0, m.v1, m.ev);
+  return m;
+}
+__device__ __forceinline__ AMap identity_map() { return AMap{1.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0, kNegE}; }
+__device__ __forceinline__ AMap shfl_up_map(const AMap& m, int delta, int lane) {
+  const int src = max(lane - delta, 0);
+  AMap r;
+  r.a = sbk::shfl(m.a, src);
+  r.c = sbk::shfl(m.c, src);
+  r.d = sbk::shfl(m.d, src);
+  r.v0 = sbk::shfl(m.v0, src);
+  r.v1 = sbk::shfl(m.v1, src);
+  r.ea = sbk::shfl(m.ea, src);
+  r.ev = sbk::shfl(m.ev, src);
+  return r;
+}
+
 // New per-frame state of hypothesis n = (parent hyp, token) chosen by the beam search: one wave per
 // hypothesis; emissions and parent state are prefetched into LDS, lane 0 runs the serial recurrence,
 // all lanes normalise and store.
@@ -370,39 +454,37 @@ __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
     }
   }
   __syncthreads();
-  if (lane == 0) {
+  {
     const int start = a.prefix_len > 1 ? a.prefix_len : 1;
     const bool first = a.prefix_len == 0 && pc[0] > 0.0f;
-    float mnb = first ? pc[0] : 0.0f, mbl = 0.0f;
-    int E = first ? 0 : kNegE;
-    for (int t = 0; t < start; ++t) {  // frames before `start` keep r = "minus infinity" (except r[0][nb] at the first step)
-      onb[t] = (t == start - 1) ? mnb : 0.0f;
+    AState s0{first ? pc[0] : 0.0f, 0.0f, first ? 0 : kNegE};  // r[start-1]
+    norm2(s0.nb, s0.bl, s0.e);
+    for (int t = lane; t < start; t += 64) {  // frames before `start` keep r = "minus infinity" (except r[0][nb] at the first step)
+      onb[t] = (t == start - 1) ? s0.nb : 0.0f;
       obl[t] = 0.0f;
-      oe[t] = (t == start - 1) ? E : kNegE;
+      oe[t] = (t == start - 1) ? s0.e : kNegE;
     }
-    // serial recurrence; the LDS operands of frame t+1 are requested before frame t is computed
-    float n_pc = start < T ? pc[start] : 0.0f, n_pb = start < T ? pb[start] : 0.0f, n_m = mph[start - 1];
-    int n_e = eph[start - 1];
-    for (int t = start; t < T; ++t) {
-      const float c_pc = n_pc, c_pb = n_pb, c_m = n_m;
-      const int ephi = n_e;
-      const int tn = min(t + 1, T - 1);
-      n_pc = pc[tn];
-      n_pb = pb[tn];
-      n_m = mph[t];
-      n_e = eph[t];
-      const int E2 = max(E, ephi - kHead);
-      const float x_nb = sbk::fast_ldexp(mnb, E - E2), x_b = sbk::fast_ldexp(mbl, E - E2);
-      const float ph = sbk::fast_ldexp(c_m, ephi - E2);
-      const float n_nb = (x_nb + ph) * c_pc, n_b = (x_nb + x_b) * c_pb;
-      const float sum = n_nb + n_b;
-      const int k = sbk::frexp_exp(sum);
-      mnb = sbk::fast_ldexp(n_nb, -k);
-      mbl = sbk::fast_ldexp(n_b, -k);
-      E = sum > 0.0f ? E2 + k : kNegE;
-      onb[t] = mnb;
-      obl[t] = mbl;
-      oe[t] = E;
+    // lane l owns frames [f0, f1)
+    const int nfr = max(T - start, 0);
+    const int fpl = (nfr + 63) / 64;
+    const int f0 = min(start + lane * fpl, T), f1 = min(f0 + fpl, T);
+    AMap mine = identity_map();
+    for (int t = f0; t < f1; ++t) mine = compose(frame_map(pc[t], pb[t], mph[t - 1], eph[t - 1]), mine);
+    // inclusive scan of the lane maps (Hillis-Steele)
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const AMap other = shfl_up_map(mine, dlt, lane);
+      if (lane >= dlt) mine = compose(mine, other);
+    }
+    // exclusive prefix = the scanned map of lane-1; replay this lane's frames from it
+    AMap pre = shfl_up_map(mine, 1, lane);
+    if (lane == 0) pre = identity_map();
+    AState st = apply_map(pre, s0);
+    for (int t = f0; t < f1; ++t) {
+      st = apply_map(frame_map(pc[t], pb[t], mph[t - 1], eph[t - 1]), st);
+      onb[t] = st.nb;
+      obl[t] = st.bl;
+      oe[t] = st.e;
     }
   }
   __syncthreads();
