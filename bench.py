@@ -94,7 +94,7 @@ class StreamWorkers:
         self.streams = [torch.cuda.Stream(dev) for _ in range(n)]
         self.decoders = [copy.copy(asr.mods.decoder) for _ in range(n)]
         for d in self.decoders:  # with several batches in flight the GPU is already shared; keep each search on one stream
-            d.overlap_ctc = 3 if n == 1 else 1
+            d.overlap_ctc = 3 if n == 1 else 0
         self.pool = ThreadPoolExecutor(n)
 
     def _work(self, slot, items):
