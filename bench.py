@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--latency-runs", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=2, help="independent batches in flight per GPU")
+    ap.add_argument("--streams", type=int, default=3, help="independent batches in flight per GPU")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()

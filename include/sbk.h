@@ -43,6 +43,8 @@ size_t sbk_prof_report(char* buf, size_t cap);
 int sbk_prof_gemm_repeat_f32(const float* A, const float* W, float* C, int M, int N, int K, float* workspace,
                              size_t workspace_floats, int iters, float* us_per_launch, sbk_stream_t stream);
 
+/* tuning knobs for experiments (key 1: K chunks per fetch batch of the skinny GEMM, 0 = automatic) */
+void sbk_prof_set_knob(int key, int value);
 /* same for the CTC prefix-score pass (x: [B,T,V] log-softmax rows, converted in place; work: scratch) */
 int sbk_prof_ctc_psi_repeat_f32(float* x, const int32_t* enc_len, const int32_t* last_tok, float* psi, float* work,
                                 int B, int T, int V, int beam, int prefix_len, int iters, float* us_per_launch,

@@ -285,6 +285,8 @@ int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
 }  // namespace
 
 namespace sbk {
+int g_skinny_nch = 0;  // tuning knob (0 = automatic): K chunks fetched per batch by the skinny kernel
+int g_skinny_off = 0;  // tuning knob: 1 = route few-row GEMMs to the LDS-tiled kernels
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
 // Internal C++ entry shared with the fused pipelines (decoder step, encoder).
@@ -295,7 +297,7 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
                float* ws, size_t ws_floats, hipStream_t st) {
   if (M == 0 || N == 0) return 0;
   const bool skinny_ok = (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < 256) && M <= 4096 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
-  if (!skinny_ok) return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
+  if (!skinny_ok || g_skinny_off) return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
   GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
   const int tiles_m = cdiv(M, 32), tiles_n = cdiv(N, 32);
   // a second, global K split when the tile grid alone leaves SIMDs idle (needs `ws` for the partial tiles)
@@ -309,9 +311,10 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   const int kper = cdiv(cdiv(K, 4 * SKg), 32) * 32;
   ProfScope prof("gemm_skinny", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
   dim3 grid(8 * tiles_m * cdiv(tiles_n, 8), SKg), block(256);
-  if (kper >= 128) {
+  const int nch = g_skinny_nch ? g_skinny_nch : (kper >= 128 ? 4 : (kper >= 64 ? 2 : 1));
+  if (nch >= 4) {
     SBK_LAUNCH((gemm_skinny_kernel<4>), grid, block, 0, st, g, ws, kper, tiles_m, tiles_n);
-  } else if (kper >= 64) {
+  } else if (nch >= 2) {
     SBK_LAUNCH((gemm_skinny_kernel<2>), grid, block, 0, st, g, ws, kper, tiles_m, tiles_n);
   } else {
     SBK_LAUNCH((gemm_skinny_kernel<1>), grid, block, 0, st, g, ws, kper, tiles_m, tiles_n);
@@ -386,4 +389,9 @@ extern "C" int sbk_prof_gemm_repeat_f32(const float* A, const float* W, float* C
   (void)hipEventElapsedTime(&ms, e0, e1);
   *us_per_launch = ms * 1000.0f / iters;
   return rc;
+}
+
+extern "C" void sbk_prof_set_knob(int key, int value) {
+  if (key == 1) sbk::g_skinny_nch = value;
+  if (key == 2) sbk::g_skinny_off = value;
 }

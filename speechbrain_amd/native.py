@@ -56,6 +56,7 @@ def _declare(lib):
         "sbk_prof_reset": ([], None),
         "sbk_prof_report": ([ctypes.c_char_p, ctypes.c_size_t], ctypes.c_size_t),
         "sbk_prof_ctc_psi_repeat_f32": ([p, p, p, p, p, i, i, i, i, i, i, POINTER(c_float), p], c_int),
+        "sbk_prof_set_knob": ([i, i], None),
         "sbk_prof_gemm_repeat_f32": ([p, p, p, i, i, i, p, ctypes.c_size_t, i, POINTER(c_float), p], c_int),
         "sbk_fbank_f32": ([p, p, p, POINTER(c_int32), i, p, p, p, p, p, i, i, i, i, i, i, f, f, p, p, f, p], c_int),
         "sbk_stft_f32": ([p, p, p, POINTER(c_int32), i, p, i, i, i, i, p], c_int),

@@ -54,8 +54,19 @@ if __name__ == "__main__":
     print("launch overhead (empty-ish layernorm 4 rows):", end=" ")
     x = torch.randn(4, 512, device=dev); g = torch.ones(512, device=dev); bb = torch.zeros(512, device=dev)
     print(f"{timeit(lambda: nat.layernorm(x, g, bb, 1e-5)):.2f} us")
-    for (M, N, K) in [(320, 512, 512), (320, 1536, 512), (320, 2048, 512), (320, 512, 2048), (320, 5000, 512)]:
-        for sl in (0, 8):
-            gemm_case(M, N, K, sl)
+    for nch in (2,):
+        print("skinny chunks per batch =", nch)
+        nat.load().sbk_prof_set_knob(1, nch)
+        for (M, N, K) in [(320, 512, 512), (320, 1536, 512), (320, 2048, 512), (320, 512, 2048), (320, 5000, 512)]:
+            gemm_case(M, N, K, 8)
+    nat.load().sbk_prof_set_knob(1, 0)
+    print("LDS-tiled kernels for the same shapes")
+    nat.load().sbk_prof_set_knob(2, 1)
+    for (M, N, K) in [(320, 512, 512), (320, 1536, 512), (320, 2048, 512), (320, 512, 2048), (320, 5000, 512), (640, 2048, 512), (640, 5000, 512)]:
+        gemm_case(M, N, K, 8)
+    nat.load().sbk_prof_set_knob(2, 0)
+    for (M, N, K) in [(640, 2048, 512), (640, 5000, 512)]:
+        gemm_case(M, N, K, 8)
+    sys.exit(0)
     for (M, N, K) in [(8032, 512, 512), (8032, 2048, 512), (8032, 512, 2048), (24032, 2048, 512), (24032, 5000, 512)]:
         gemm_case(M, N, K, 0)
