@@ -47,6 +47,12 @@ def ctc_case(B, T, V, beam, prefix_len):
 
 
 if __name__ == "__main__":
+    if "--pmc-workload" in sys.argv:  # short, single-stream: the kernels whose HBM traffic is read from PMC counters
+        for (M, N, K) in [(320, 512, 512), (320, 1536, 512), (320, 2048, 512), (320, 512, 2048), (320, 5000, 512),
+                          (8032, 2048, 512), (8032, 512, 2048)]:
+            gemm_case(M, N, K, 8)
+        ctc_case(32, 440, 5000, 10, 5)
+        sys.exit(0)
     if "--ctc" in sys.argv:
         for (B, T) in [(32, 251), (32, 440), (32, 751), (8, 440)]:
             ctc_case(B, T, 5000, 10, 5)

@@ -3,7 +3,7 @@
 # prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc never combined with other traces
 # than --kernel-trace).  Output: gpurun_out/pmc_fetch_*.csv, gpurun_out/pmc_write_*.csv
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-CMD="python $PWD/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-roofline --latency-runs 0"
+CMD="python $PWD/tools/microbench.py --pmc-workload"
 (cd /tmp && rm -rf /tmp/pmc1 && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc1 -o f -- $CMD > $OLDPWD/gpurun_out/pmc_fetch.log 2>&1)
 (cd /tmp && rm -rf /tmp/pmc2 && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc2 -o w -- $CMD > $OLDPWD/gpurun_out/pmc_write.log 2>&1)
 find /tmp/pmc1 -name "*counter_collection.csv" -exec cp {} gpurun_out/pmc_fetch_counters.csv \;
