@@ -313,7 +313,16 @@ def main():
             ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4)}
-        roof.update({"traffic": None, "kernel": name, "launches": top["count"], "avg_launch_ms": round(avg_ms, 4),
+        traffic = None
+        try:  # HBM bytes per launch from the PMC counters, collected in their own rocprofv3 --pmc passes (tools/run_pmc.sh)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = next((k for k in pmc if not k.startswith("_") and name.startswith(k)), None)
+            if key:
+                traffic = pmc[key]["bytes_per_launch"]
+                roof["traffic_note"] = f"{pmc[key]['note']}; algorithmic {pmc[key]['algorithmic_bytes_per_launch']} B/launch"
+        except Exception:
+            pass
+        roof.update({"traffic": traffic, "kernel": name, "launches": top["count"], "avg_launch_ms": round(avg_ms, 4),
                      "share_of_gpu_time": round(top["ms"] / total_ms, 3)})
         out["roofline"] = roof
         out["kernel_breakdown_ms"] = {k: round(v["ms"], 2) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}
