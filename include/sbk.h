@@ -116,6 +116,13 @@ int sbk_gemm_nt_splitk_f32(const float* A, int lda, const float* W, int ldw, con
                            const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
                            float alpha, float* workspace, size_t workspace_floats, sbk_stream_t stream);
 
+/* LayerNorm fused into the few-row contraction: C = epilogue(LN(A) . W^T + b) with gamma/beta pre-folded
+ * by the caller: Wf[n,k] = W[n,k]*gamma[k], bf[n] = b[n] + sum_k W[n,k]*beta[k].  K in {128,256,512},
+ * M <= 512 (SBK_EINVAL otherwise). */
+int sbk_gemm_ln_nt_f32(const float* A, int lda, const float* Wf, int ldw, const float* bf, const float* residual,
+                       int ldr, float* C, int ldc, int M, int N, int K, float eps, int act, float alpha,
+                       sbk_stream_t stream);
+
 /* ---- LayerNorm over the last dimension (nnet/normalization.py:185-242,
  * torch.nn.LayerNorm at Conformer.py:126,152,426,437): y = act(LN(x)), x [rows,d]. */
 int sbk_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int rows, int d, float eps,
@@ -162,6 +169,9 @@ typedef struct {
   const float *ln1_g, *ln1_b, *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b;
   const float *ln2_g, *ln2_b, *ca_in_w, *ca_in_b, *ca_out_w, *ca_out_b;
   const float *ln3_g, *ln3_b, *ff1_w, *ff1_b, *ff2_w, *ff2_b;
+  /* optional (NULL = unused): the three LayerNorm-fed projections with gamma/beta folded in
+   * (Wf = W*gamma[k], bf = b + W.beta): self-attention in_proj, cross-attention q rows, ffn.0 */
+  const float *sa_in_wf, *sa_in_bf, *ca_q_wf, *ca_q_bf, *ff1_wf, *ff1_bf;
 } sbk_decoder_layer;
 
 typedef struct {
@@ -170,6 +180,7 @@ typedef struct {
   const float* pe;                 /* positional_encoding_decoder.pe [max_len,d] */
   const float *final_ln_g, *final_ln_b; /* decoder.norm.norm */
   const float *seq_w, *seq_b;      /* seq_lin.w [V,d],[V] (may be NULL for sbk_decoder_prefix_f32) */
+  const float *seq_wf, *seq_bf;    /* optional: seq_lin with decoder.norm folded in (see sbk_decoder_layer) */
   int32_t d_model, nhead, d_ffn, n_layers, vocab, max_len, ffn_act;
   float ln_eps;
 } sbk_decoder_weights;

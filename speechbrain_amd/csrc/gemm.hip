@@ -254,6 +254,97 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __r
   }
 }
 
+// LayerNorm fused into the skinny GEMM:  C = epilogue( LN(A) . W^T ) for K = NCH*128 (one fetch batch
+// per wave, so the workgroup's four waves hold complete rows of A in registers).  gamma/beta are
+// pre-folded into the operands by the caller:  Wf[n,k] = W[n,k]*gamma[k],  bf[n] = b[n] + sum_k W[n,k]*beta[k],
+// hence  LN(x).W^T + b = rstd * ((x - mean) . Wf^T) + bf.  Row statistics are the two-pass form of
+// csrc/norm.hip (mean, then sum of squared deviations), reduced across the waves through LDS.
+template <int NCH>
+__global__ void __launch_bounds__(256) gemm_skinny_ln_kernel(GemmArgs g, float eps, int tiles_m, int tiles_n) {
+  constexpr int KC = 32;
+  __shared__ float red[3][32][33];
+  __shared__ float stat[2][4][32];
+  __shared__ float rstd_s[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int nt, mt;
+  {
+    const int id = blockIdx.x, x = id & 7, q = id >> 3;
+    const int nt8 = (tiles_n + 7) / 8;
+    mt = q % tiles_m;
+    nt = x + 8 * (q / tiles_m);
+    if (q / tiles_m >= nt8 || nt >= tiles_n) return;
+  }
+  const int r = lane & 31, half = lane >> 5;
+  const int k_begin = wave * NCH * KC;  // K == 4 * NCH * KC
+  const float* wrow = g.W + (size_t)min(nt * 32 + r, g.N - 1) * g.ldw + half * (KC / 2);
+  const float* arow = g.A + (size_t)min(mt * 32 + r, g.M - 1) * g.lda + half * (KC / 2);
+  float4 a[NCH][4], w[NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = k_begin + c * KC;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) w[c][v] = *reinterpret_cast<const float4*>(wrow + k + 4 * v);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a[c][v] = *reinterpret_cast<const float4*>(arow + k + 4 * v);
+  }
+  // mean over the full row: lane partial -> both halves -> the four waves
+  float s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s += (a[c][v].x + a[c][v].y) + (a[c][v].z + a[c][v].w);
+  s += sbk::shfl_xor(s, 32);
+  if (half == 0) stat[0][wave][r] = s;
+  __syncthreads();
+  const float mean = ((stat[0][0][r] + stat[0][1][r]) + (stat[0][2][r] + stat[0][3][r])) / (float)g.K;
+  float q2 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      a[c][v].x -= mean; a[c][v].y -= mean; a[c][v].z -= mean; a[c][v].w -= mean;
+      q2 += (a[c][v].x * a[c][v].x + a[c][v].y * a[c][v].y) + (a[c][v].z * a[c][v].z + a[c][v].w * a[c][v].w);
+    }
+  q2 += sbk::shfl_xor(q2, 32);
+  if (half == 0) stat[1][wave][r] = q2;
+
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      acc = sbk::mfma_32x32x2(a[c][v].x, w[c][v].x, acc);
+      acc = sbk::mfma_32x32x2(a[c][v].y, w[c][v].y, acc);
+      acc = sbk::mfma_32x32x2(a[c][v].z, w[c][v].z, acc);
+      acc = sbk::mfma_32x32x2(a[c][v].w, w[c][v].w, acc);
+    }
+  if (wave > 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[wave - 1][(q & 3) + 8 * (q >> 2) + 4 * half][r] = acc[q];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  if (half == 0) {
+    const float var = ((stat[1][0][r] + stat[1][1][r]) + (stat[1][2][r] + stat[1][3][r])) / (float)g.K;
+    rstd_s[r] = rsqrtf(var + eps);
+  }
+  sbk::wave_sync();
+  const int col = nt * 32 + r;
+  const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.0f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int rr = (q & 3) + 8 * (q >> 2) + 4 * half;
+    const int row = mt * 32 + rr;
+    const float sum = ((acc[q] + red[0][rr][r]) + red[1][rr][r]) + red[2][rr][r];
+    if (row >= g.M || col >= g.N) continue;
+    float v = apply_act(sum * rstd_s[rr] + bv, g.act) * g.alpha;
+    if (g.R) v += g.R[(size_t)row * g.ldr + col];
+    g.C[(size_t)row * g.ldc + col] = v;
+  }
+}
+
 // C = epilogue(sum_ks partial[ks]) ; fixed summation order => run-to-run deterministic.
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const float* __restrict__ partial, int SK) {
   const size_t total = (size_t)g.M * g.N;
@@ -326,6 +417,28 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   return launch_status("splitk_reduce");
 }
 
+// C = epilogue(LN(A) . Wf^T + bf) with gamma/beta pre-folded into (Wf, bf); returns -1 when the shape is
+// not eligible (the caller then runs LayerNorm + gemm_nt_ws with the unfolded weights).
+int gemm_ln_nt(const float* A, int lda, const float* Wf, int ldw, const float* bf, const float* R, int ldr, float* C,
+               int ldc, int M, int N, int K, float eps, int act, float alpha, hipStream_t st) {
+  if (M == 0 || N == 0) return 0;
+  const bool ok = (K == 512 || K == 256 || K == 128) && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < 256) &&
+                  M <= 4096 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(Wf) && !g_skinny_off;
+  if (!ok) return -1;
+  GemmArgs g{A, Wf, bf, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, nullptr, 1};
+  const int tiles_m = cdiv(M, 32), tiles_n = cdiv(N, 32);
+  ProfScope prof("gemm_skinny_ln", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
+  dim3 grid(8 * tiles_m * cdiv(tiles_n, 8)), block(256);
+  if (K == 512) {
+    SBK_LAUNCH((gemm_skinny_ln_kernel<4>), grid, block, 0, st, g, eps, tiles_m, tiles_n);
+  } else if (K == 256) {
+    SBK_LAUNCH((gemm_skinny_ln_kernel<2>), grid, block, 0, st, g, eps, tiles_m, tiles_n);
+  } else {
+    SBK_LAUNCH((gemm_skinny_ln_kernel<1>), grid, block, 0, st, g, eps, tiles_m, tiles_n);
+  }
+  return launch_status("gemm_skinny_ln");
+}
+
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st) {
   if (M == 0 || N == 0) return 0;
@@ -351,6 +464,17 @@ extern "C" int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw,
   SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm: seq_len given without rows_per_seq");
   return sbk::gemm_nt_ws(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq,
                          nullptr, 0, sbk::as_stream(stream));
+}
+
+extern "C" int sbk_gemm_ln_nt_f32(const float* A, int lda, const float* Wf, int ldw, const float* bf,
+                                  const float* residual, int ldr, float* C, int ldc, int M, int N, int K, float eps,
+                                  int act, float alpha, sbk_stream_t stream) {
+  SBK_REQUIRE(A && Wf && C, "gemm_ln: null operand");
+  SBK_REQUIRE(M >= 0 && N >= 0 && K > 0 && lda >= K && ldw >= K && ldc >= N, "gemm_ln: bad shape");
+  const int rc = sbk::gemm_ln_nt(A, lda, Wf, ldw, bf, residual, ldr, C, ldc, M, N, K, eps, act, alpha,
+                                 sbk::as_stream(stream));
+  if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_ln: shape M=%d N=%d K=%d not eligible for the fused kernel", M, N, K);
+  return rc;
 }
 
 extern "C" int sbk_gemm_nt_splitk_f32(const float* A, int lda, const float* W, int ldw, const float* bias,

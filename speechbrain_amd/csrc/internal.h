@@ -10,6 +10,8 @@ int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
 int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
                int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, float* ws,
                size_t ws_floats, hipStream_t st);
+int gemm_ln_nt(const float* A, int lda, const float* Wf, int ldw, const float* bf, const float* R, int ldr, float* C,
+               int ldc, int M, int N, int K, float eps, int act, float alpha, hipStream_t st);
 int layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int d, float eps, int act,
               hipStream_t st);
 int relpos_attention(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,

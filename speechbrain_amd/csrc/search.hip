@@ -487,28 +487,51 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
   SBK_TRY(sbk::embed_pos(tokens, W->emb, W->pe + (size_t)step * dm, d.x, n, dm, sqrtf((float)dm), st));
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
-    SBK_TRY(sbk::layernorm(d.x, L.ln1_g, L.ln1_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
-    SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.sa_in_w, dm, L.sa_in_b, nullptr, 0, d.qkv, 3 * dm, n, 3 * dm, dm, SBK_ACT_NONE, 1.0f,
-                         nullptr, 0, d.splitk, d.splitk_floats, st));
+    int frc = L.sa_in_wf ? sbk::gemm_ln_nt(d.x, dm, L.sa_in_wf, dm, L.sa_in_bf, nullptr, 0, d.qkv, 3 * dm, n, 3 * dm, dm,
+                                           W->ln_eps, SBK_ACT_NONE, 1.0f, st)
+                         : -1;
+    if (frc > 0 || frc < -1) return frc;
+    if (frc == -1) {
+      SBK_TRY(sbk::layernorm(d.x, L.ln1_g, L.ln1_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
+      SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.sa_in_w, dm, L.sa_in_b, nullptr, 0, d.qkv, 3 * dm, n, 3 * dm, dm, SBK_ACT_NONE,
+                              1.0f, nullptr, 0, d.splitk, d.splitk_floats, st));
+    }
     SBK_TRY(sbk::self_attn_step(d.qkv, d.kcache[l], d.vcache[l], kv_slot, d.ctx, n, dm, H, step, n, Lmax, st));
     SBK_TRY(sbk::gemm_nt_ws(d.ctx, dm, L.sa_out_w, dm, L.sa_out_b, d.x, dm, d.x, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
                          0, d.splitk, d.splitk_floats, st));
-    SBK_TRY(sbk::layernorm(d.x, L.ln2_g, L.ln2_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
-    SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.ca_in_w, dm, L.ca_in_b, nullptr, 0, d.q, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr, 0,
-                         d.splitk, d.splitk_floats, st));
+    frc = L.ca_q_wf ? sbk::gemm_ln_nt(d.x, dm, L.ca_q_wf, dm, L.ca_q_bf, nullptr, 0, d.q, dm, n, dm, dm, W->ln_eps,
+                                      SBK_ACT_NONE, 1.0f, st)
+                    : -1;
+    if (frc > 0 || frc < -1) return frc;
+    if (frc == -1) {
+      SBK_TRY(sbk::layernorm(d.x, L.ln2_g, L.ln2_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
+      SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.ca_in_w, dm, L.ca_in_b, nullptr, 0, d.q, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
+                              0, d.splitk, d.splitk_floats, st));
+    }
     SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, d.xpart, B, T, dm, H, beam, st));
     SBK_TRY(sbk::gemm_nt_ws(d.ctx, dm, L.ca_out_w, dm, L.ca_out_b, d.x, dm, d.x, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
                          0, d.splitk, d.splitk_floats, st));
-    SBK_TRY(sbk::layernorm(d.x, L.ln3_g, L.ln3_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
-    SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.ff1_w, dm, L.ff1_b, nullptr, 0, d.ff, W->d_ffn, n, W->d_ffn, dm, W->ffn_act, 1.0f,
-                         nullptr, 0, d.splitk, d.splitk_floats, st));
+    frc = L.ff1_wf ? sbk::gemm_ln_nt(d.x, dm, L.ff1_wf, dm, L.ff1_bf, nullptr, 0, d.ff, W->d_ffn, n, W->d_ffn, dm, W->ln_eps,
+                                     W->ffn_act, 1.0f, st)
+                   : -1;
+    if (frc > 0 || frc < -1) return frc;
+    if (frc == -1) {
+      SBK_TRY(sbk::layernorm(d.x, L.ln3_g, L.ln3_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
+      SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.ff1_w, dm, L.ff1_b, nullptr, 0, d.ff, W->d_ffn, n, W->d_ffn, dm, W->ffn_act, 1.0f,
+                              nullptr, 0, d.splitk, d.splitk_floats, st));
+    }
     SBK_TRY(sbk::gemm_nt_ws(d.ff, W->d_ffn, L.ff2_w, W->d_ffn, L.ff2_b, d.x, dm, d.x, dm, n, dm, W->d_ffn, SBK_ACT_NONE, 1.0f,
                          nullptr, 0, d.splitk, d.splitk_floats, st));
+  }
+  if (want_logits && W->seq_wf) {  // final LayerNorm fused into seq_lin
+    const int frc = sbk::gemm_ln_nt(d.x, dm, W->seq_wf, dm, W->seq_bf, nullptr, 0, d.logits, W->vocab, n, W->vocab, dm,
+                                    W->ln_eps, SBK_ACT_NONE, 1.0f, st);
+    if (frc != -1) return frc;
   }
   SBK_TRY(sbk::layernorm(d.x, W->final_ln_g, W->final_ln_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
   if (want_logits)
     SBK_TRY(sbk::gemm_nt_ws(d.h, dm, W->seq_w, dm, W->seq_b, nullptr, 0, d.logits, W->vocab, n, W->vocab, dm, SBK_ACT_NONE,
-                         1.0f, nullptr, 0, d.splitk, d.splitk_floats, st));
+                            1.0f, nullptr, 0, d.splitk, d.splitk_floats, st));
   return 0;
 }
 

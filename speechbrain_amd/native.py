@@ -30,12 +30,14 @@ class SbkError(RuntimeError):
 class DecoderLayer(ctypes.Structure):  # sbk_decoder_layer
     _fields_ = [(n, c_void_p) for n in (
         "ln1_g", "ln1_b", "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ln2_g", "ln2_b", "ca_in_w", "ca_in_b",
-        "ca_out_w", "ca_out_b", "ln3_g", "ln3_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b")]
+        "ca_out_w", "ca_out_b", "ln3_g", "ln3_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b", "sa_in_wf", "sa_in_bf", "ca_q_wf",
+        "ca_q_bf", "ff1_wf", "ff1_bf")]
 
 
 class DecoderWeights(ctypes.Structure):  # sbk_decoder_weights
     _fields_ = [("layers", POINTER(DecoderLayer)), ("emb", c_void_p), ("pe", c_void_p), ("final_ln_g", c_void_p),
-                ("final_ln_b", c_void_p), ("seq_w", c_void_p), ("seq_b", c_void_p), ("d_model", c_int32),
+                ("final_ln_b", c_void_p), ("seq_w", c_void_p), ("seq_b", c_void_p), ("seq_wf", c_void_p),
+                ("seq_bf", c_void_p), ("d_model", c_int32),
                 ("nhead", c_int32), ("d_ffn", c_int32), ("n_layers", c_int32), ("vocab", c_int32),
                 ("max_len", c_int32), ("ffn_act", c_int32), ("ln_eps", c_float)]
 
@@ -64,6 +66,7 @@ def _declare(lib):
         "sbk_amplitude_to_db_f32": ([p, p, i, ctypes.c_long, f, f, f, f, p], c_int),
         "sbk_input_norm_global_f32": ([p, p, p, p, i, i, f, p], c_int),
         "sbk_gemm_nt_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
+        "sbk_gemm_ln_nt_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, f, i, f, p], c_int),
         "sbk_gemm_nt_splitk_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, ctypes.c_size_t, p], c_int),
         "sbk_conv_block_f32": ([p, p, p, p, p, p, i, i, i, i, i, f, f, p], c_int),
         "sbk_relpos_attention_f32": ([p, p, p, p, p, p, p, i, i, i, i, f, p], c_int),
@@ -193,6 +196,20 @@ def gemm_nt_splitk(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, slic
     return out
 
 
+def gemm_ln_nt(a, wf, bf, eps, residual=None, act=ACT_NONE, alpha=1.0):
+    """LN(a) @ W^T + b with gamma/beta pre-folded into (wf, bf) (see include/sbk.h)."""
+    lib = load()
+    K = a.shape[-1]
+    a2 = a.reshape(-1, K)
+    M, N = a2.shape[0], wf.shape[0]
+    _dev_ok(a2, wf, bf, residual)
+    out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
+    r2 = residual.reshape(-1, N) if residual is not None else None
+    _chk(lib.sbk_gemm_ln_nt_f32(_p(a2), K, _p(wf), K, _p(bf), _p(r2), N, _p(out), N, M, N, K, float(eps), act,
+                                float(alpha), _stream(a2)), "sbk_gemm_ln_nt_f32")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, act=ACT_NONE, out=None):
     """LayerNorm over the trailing gamma.numel() elements of every row."""
     lib = load()
@@ -315,9 +332,10 @@ class DecoderHandle:
     """Device pointers of a TransformerASR decoder (+ seq_lin) laid out as sbk_decoder_weights.
     Holds references to the parameter tensors so the pointers stay valid."""
 
-    def __init__(self, model, seq_lin=None):
+    def __init__(self, model, seq_lin=None, fold=True):
         dec = model.decoder
         self.keep = []
+        fold = fold and dec.norm.norm.weight.shape[0] in (128, 256, 512)  # shapes the fused kernel takes
         layers = (DecoderLayer * len(dec.layers))()
 
         def ptr(t):
@@ -341,6 +359,15 @@ class DecoderHandle:
             o.ln3_g, o.ln3_b = ptr(L.norm3.norm.weight), ptr(L.norm3.norm.bias)
             o.ff1_w, o.ff1_b = ptr(L.pos_ffn.ffn[0].weight), ptr(L.pos_ffn.ffn[0].bias)
             o.ff2_w, o.ff2_b = ptr(L.pos_ffn.ffn[3].weight), ptr(L.pos_ffn.ffn[3].bias)
+            if fold:  # LayerNorm folded into the projection it feeds (fused kernel, csrc/gemm.hip)
+                dm = L.norm1.norm.weight.shape[0]
+                o.sa_in_wf, o.sa_in_bf = map(ptr, _fold_ln(L.self_attn.att.in_proj_weight, L.self_attn.att.in_proj_bias,
+                                                            L.norm1.norm.weight, L.norm1.norm.bias))
+                o.ca_q_wf, o.ca_q_bf = map(ptr, _fold_ln(L.multihead_attn.att.in_proj_weight[:dm],
+                                                          L.multihead_attn.att.in_proj_bias[:dm], L.norm2.norm.weight,
+                                                          L.norm2.norm.bias))
+                o.ff1_wf, o.ff1_bf = map(ptr, _fold_ln(L.pos_ffn.ffn[0].weight, L.pos_ffn.ffn[0].bias,
+                                                        L.norm3.norm.weight, L.norm3.norm.bias))
             act = L.pos_ffn.act_code
             if not L.normalize_before:
                 raise NotImplementedError("post-norm decoder layers are not on the Conformer ASR path")
@@ -353,6 +380,9 @@ class DecoderHandle:
         W.final_ln_g, W.final_ln_b = ptr(dec.norm.norm.weight), ptr(dec.norm.norm.bias)
         if seq_lin is not None:
             W.seq_w, W.seq_b = ptr(seq_lin.w.weight), ptr(seq_lin.w.bias)
+            if fold:
+                W.seq_wf, W.seq_bf = map(ptr, _fold_ln(seq_lin.w.weight, seq_lin.w.bias, dec.norm.norm.weight,
+                                                        dec.norm.norm.bias))
         W.d_model, W.nhead = emb.shape[1], dec.layers[0].nhead
         W.d_ffn, W.n_layers = dec.layers[0].pos_ffn.ffn[0].weight.shape[0], len(dec.layers)
         W.vocab = seq_lin.w.weight.shape[0] if seq_lin is not None else emb.shape[0]
@@ -366,6 +396,14 @@ class DecoderHandle:
             return DecoderHandle(model, seq_lin).key != self.key
         except Exception:
             return True
+
+
+def _fold_ln(w, b, gamma, beta):
+    """(Wf, bf) with a preceding LayerNorm's affine folded in: Wf = W*gamma[k], bf = b + W.beta (fp64, rounded once)."""
+    w64, g64, be64 = w.detach().double(), gamma.detach().double(), beta.detach().double()
+    wf = (w64 * g64[None, :]).float().contiguous()
+    bf = (b.detach().double() + w64 @ be64).float().contiguous()
+    return wf, bf
 
 
 def _host_flag(device):

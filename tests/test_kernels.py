@@ -181,3 +181,18 @@ def test_staged_features_match_fused_and_reference(backend):
                                         return_complex=True)).transpose(2, 1)
     assert _md(stft, ref) <= 2e-4
     assert _md(spectral_magnitude(torch.tensor([[3.0, 4.0]]).to(dev), power=0.5), torch.tensor([5.0])) <= 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(320, 96, 128), (40, 70, 256), (300, 64, 512), (33, 130, 512)])
+def test_gemm_layernorm_fused(backend, M, N, K):
+    """LayerNorm folded into the few-row GEMM (decoder projections): vs F.layer_norm + F.linear."""
+    nat, dev = backend
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g) * 2.0 + 0.7 + torch.arange(M)[:, None] * 0.01
+    w, b = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    gamma, beta = 1.0 + 0.2 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = r + F.gelu(F.linear(F.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-6), w.double(), b.double())).float()
+    wf, bf = nat._fold_ln(w, b, gamma, beta)
+    out = nat.gemm_ln_nt(x.to(dev), wf.to(dev), bf.to(dev), 1e-6, residual=r.to(dev), act=nat.ACT_GELU)
+    assert _md(out, ref) <= 2e-5

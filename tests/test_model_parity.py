@@ -143,3 +143,41 @@ def test_beam_search_long_memory_vs_oracle(backend):
         assert hyps == hyps_ref
         assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
         assert float((lens.cpu() - lens_ref).abs().max()) <= 1e-6
+
+
+def test_decoder_with_fused_layernorm_vs_oracle(backend):
+    """d_model = 128 is eligible for the LayerNorm-fused projection kernel (the 32/72-wide golden models
+    are not): decoder outputs and a CTC beam search against the oracle."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
+    from speechbrain_amd.inference.builders import build_modules
+
+    m = build_modules(dict(d_model=128, nhead=4, d_ffn=256, n_enc=1, n_dec=2, n_fft=512, win_length=32), vocab=60, seed=5)
+    mods = torch.nn.ModuleDict({k: m[k] for k in ("CNN", "Transformer", "seq_lin", "ctc_lin")})
+    gen = torch.Generator().manual_seed(9)
+    with torch.no_grad():  # non-trivial LayerNorm affines and peaked heads
+        for name, p in mods.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+        mods["seq_lin"].w.weight.mul_(5.0)
+        mods["ctc_lin"].w.weight.mul_(5.0)
+    sd = {k: v.detach().clone() for k, v in mods.state_dict().items()}
+    mods = mods.to(dev).eval()
+    cfg = O.ModelCfg(d_model=128, nhead=4, num_encoder_layers=1, num_decoder_layers=2, d_ffn=256, vocab=60)
+    enc = torch.randn(2, 40, 128, generator=gen)
+    wl = torch.tensor([1.0, 0.7])
+    enc_len = torch.round(40 * wl).int()
+    tgt = torch.randint(0, 60, (2, 7), generator=gen)
+    h = nat.DecoderHandle(mods["Transformer"], mods["seq_lin"])
+    assert h.W.seq_wf and h.layers[0].sa_in_wf  # the folded operands exist for this width
+    pred = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev))
+    assert float((pred.cpu() - O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")).abs().max()) <= 5e-5
+    ratio = 10.5 / 40
+    hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=4, ctc_weight=0.4, max_decode_ratio=ratio))
+    scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)], weights={"ctc": 0.4})
+    bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                    min_decode_ratio=0.0, max_decode_ratio=ratio, beam_size=4,
+                                    using_eos_threshold=False, length_normalization=True, scorer=scorer)
+    hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))
+    assert hyps == hyps_ref
+    assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
