@@ -97,21 +97,31 @@ class StreamWorkers:
             d.overlap_ctc = 3 if n == 1 else 0
         self.pool = ThreadPoolExecutor(n)
 
-    def _work(self, slot, items):
+    def _work(self, slot, queue, batches):
         out = []
         with torch.cuda.stream(self.streams[slot]):
-            for k, (w, l) in items:
+            while True:
+                try:
+                    k = queue.get_nowait()
+                except Exception:
+                    break
+                w, l = batches[k]
                 out.append((k, run_step(self.asr, w, l, self.decoders[slot])))
             self.streams[slot].synchronize()
         return out
 
     def run(self, batches):
-        """batches: list of (wav, lens) on the device -> list of token lists, in order."""
+        """batches: list of (wav, lens) on the device -> list of token lists, in order.  Workers pull
+        from one queue, longest batch first, so the streams finish together."""
+        import queue as _q
+
         cur = torch.cuda.current_stream()
         for s in self.streams:
             s.wait_stream(cur)
-        shares = [[(k, b) for k, b in enumerate(batches) if k % self.n == slot] for slot in range(self.n)]
-        futs = [self.pool.submit(self._work, slot, share) for slot, share in enumerate(shares) if share]
+        q = _q.Queue()
+        for k in sorted(range(len(batches)), key=lambda i: -batches[i][0].numel()):
+            q.put(k)
+        futs = [self.pool.submit(self._work, slot, q, batches) for slot in range(min(self.n, len(batches)))]
         res = {}
         for f in futs:
             for k, toks in f.result():
