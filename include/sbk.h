@@ -185,6 +185,34 @@ typedef struct {
   float ln_eps;
 } sbk_decoder_weights;
 
+/* ---- a20: TransformerLM (lobes/models/transformer/TransformerLM.py:22-187; encoder-only, regularMHA,
+ * fixed_abs_sine positions, no embedding_proj) used as a full scorer (decoders/scorer.py:413-577).
+ * By the reference's state_dict names (device pointers, fp32):
+ *   layers[l]: encoder.layers.l.self_att.att.{in_proj_weight [3d,d], in_proj_bias, out_proj.weight, out_proj.bias};
+ *              norm1.norm / norm2.norm; pos_ffn.ffn.{0,3}.w.{weight,bias}
+ *   emb = custom_src_module.emb.Embedding.weight [V,d]; pe = positional_encoding.pe [max_len,d];
+ *   final_ln = encoder.norm.norm; out0 / out_ln / out2 = output_proj.layers.{0,1,2}              */
+typedef struct {
+  const float *in_w, *in_b, *out_w, *out_b, *ln1_g, *ln1_b;
+  const float *ff1_w, *ff1_b, *ff2_w, *ff2_b, *ln2_g, *ln2_b;
+} sbk_lm_layer;
+
+typedef struct {
+  const sbk_lm_layer* layers; /* HOST array of n_layers entries */
+  const float *emb, *pe, *final_ln_g, *final_ln_b;
+  const float *out0_w, *out0_b, *out_ln_g, *out_ln_b, *out2_w, *out2_b;
+  int32_t d_model, nhead, d_ffn, n_layers, vocab, max_len, ffn_act;
+  int32_t normalize_before; /* Transformer.py:452-480: pre-norm (1) or post-norm (0) layers */
+  int32_t pad_idx;          /* keys whose token equals pad_idx are masked (TransformerLM.py:165-187; 0) */
+  float ln_eps;             /* 1e-6 everywhere in TransformerLM */
+} sbk_lm_weights;
+
+/* TransformerLM.forward (TransformerLM.py:116-158) through the KV-cached step:
+ * tokens [n,L] int32 -> logits [n,L,V]. */
+size_t sbk_lm_prefix_workspace_bytes(const sbk_lm_weights* LM, int n, int L);
+int sbk_lm_prefix_f32(const sbk_lm_weights* LM, const int32_t* tokens, void* workspace, size_t workspace_bytes,
+                      float* logits, int n, int L, sbk_stream_t stream);
+
 /* S2SBeamSearcher options (seq2seq.py:752-768) after the host resolved ratios to step counts
  * (min/max_steps = int(T * ratio), :1336-1338) and scorer weights (ctc_weight; attn weight is
  * 1 - ctc_weight when a CTC scorer is present, :803-804). */
@@ -196,6 +224,11 @@ typedef struct {
                           single-batch latency; costs throughput when the caller already keeps several
                           batches in flight on different streams); 0: everything on `stream` */
   float ctc_weight, temperature, eos_threshold, minus_inf;
+  /* optional TransformerLM full scorer, scored BEFORE the CTC scorer like the recipe's
+   * full_scorers=[transformerlm, ctc] (scorer.py:1246-1253): log_probs += lm_weight *
+   * log_softmax(LM(prefix) / lm_temperature).  lm = NULL or lm_weight = 0: no LM. */
+  float lm_weight, lm_temperature;
+  const sbk_lm_weights* lm;
 } sbk_search_config;
 
 /* S2STransformerBeamSearcher.forward (seq2seq.py:1632-1723, :1853-1934) with an optional full

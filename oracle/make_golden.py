@@ -204,6 +204,84 @@ def golden_model(tag, d_model, nhead, d_ffn, n_enc, n_dec, vocab, B, n_frames, b
     print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+# ---------------------------------------------------------------- TransformerLM scorer (a20)
+def golden_lm(tag, normalize_before, ctc_w, lm_w, lm_temp, seed, beam=4, B=3, n_frames=61, vocab=40,
+              lm_d=32, lm_heads=4, lm_ffn=64, lm_layers=2):
+    from speechbrain.decoders import S2STransformerBeamSearcher
+    from speechbrain.decoders.scorer import CTCScorer, ScorerBuilder, TransformerLMScorer
+    from speechbrain.lobes.models.transformer.TransformerLM import TransformerLM
+
+    print(f"[lm {tag}] normalize_before={normalize_before} ctc={ctc_w} lm={lm_w} T={lm_temp}")
+    mods = build_reference(32, 4, 64, 2, 2, vocab, seed)
+    with torch.no_grad():
+        mods["seq_lin"].w.weight.mul_(6.0)
+        mods["ctc_lin"].w.weight.mul_(6.0)
+    torch.manual_seed(seed + 100)
+    lm = TransformerLM(vocab=vocab, d_model=lm_d, nhead=lm_heads, num_encoder_layers=lm_layers, num_decoder_layers=0,
+                       d_ffn=lm_ffn, dropout=0.0, activation=torch.nn.GELU, normalize_before=normalize_before)
+    lm.eval()
+    g = torch.Generator().manual_seed(seed + 2)
+    with torch.no_grad():
+        for n, p in lm.named_parameters():
+            if p.dim() == 1 or "norm" in n:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+        lm.output_proj.layers[2].w.weight.mul_(4.0)  # a language model with opinions
+    sd = {k: v.detach().clone() for k, v in mods.state_dict().items()}
+    sd.update({"LM." + k: v.detach().clone() for k, v in lm.state_dict().items()})
+    cfg = O.ModelCfg(d_model=32, nhead=4, num_encoder_layers=2, num_decoder_layers=2, d_ffn=64, vocab=vocab)
+    lcfg = O.LMCfg(vocab=vocab, d_model=lm_d, nhead=lm_heads, num_encoder_layers=lm_layers, d_ffn=lm_ffn,
+                   normalize_before=normalize_before)
+    g = torch.Generator().manual_seed(4321 + seed)
+    feats = torch.randn(B, n_frames, 80, generator=g)
+    wav_lens = torch.linspace(0.6, 1.0, B)
+    out = {"wav_lens": wav_lens.numpy()}
+    with torch.no_grad():
+        enc_ref = mods["Transformer"].encode(mods["CNN"](feats), wav_lens)
+        out["enc_out"] = enc_ref.numpy()
+        # TransformerLM.forward on prefixes holding pad tokens (key padding mask of index 0)
+        toks = torch.randint(1, vocab, (5, 9), generator=g)
+        toks[1, 3] = 0
+        toks[2, 5:7] = 0
+        toks[4, 8] = 0
+        ref = lm(toks)
+        check("TransformerLM.forward", ref, O.lm_forward(toks, sd, lcfg, "LM."), 2e-5)
+        out["lm_tokens"], out["lm_logits"] = toks.numpy(), ref.numpy()
+
+        full = [TransformerLMScorer(language_model=lm, temperature=lm_temp)]
+        weights = {"transformerlm": lm_w}
+        if ctc_w > 0:
+            full.append(CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2))
+            weights["ctc"] = ctc_w
+        bs = S2STransformerBeamSearcher(
+            modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=0.0,
+            max_decode_ratio=1.0, beam_size=beam, using_eos_threshold=False, length_normalization=True,
+            temperature=1.15, scorer=ScorerBuilder(full_scorers=full, weights=weights),
+        )
+        hyps_r, lens_r, scores_r, lp_r = bs(enc_ref.clone(), wav_lens)
+        sc = O.SearchCfg(beam=beam, ctc_weight=ctc_w, temperature=1.15, lm_weight=lm_w, lm_temperature=lm_temp)
+        tr = O.SearchTrace()
+        hyps_o, lens_o, scores_o, lp_o = O.beam_search(enc_ref, wav_lens, sd, cfg, sc, trace=tr, lm_cfg=lcfg)
+        print("  beam hyps lens:", [len(h) for h in hyps_r], "steps:", len(tr.tokens))
+        assert hyps_r == hyps_o, (hyps_r, hyps_o)
+        check("beam best scores", scores_r, scores_o, 1e-4)
+        check("beam lens", lens_r, lens_o, 1e-6)
+        # the LM must matter: the same search without it picks something else
+        hyps_n, _, _, _ = O.beam_search(enc_ref, wav_lens, sd, cfg,
+                                        O.SearchCfg(beam=beam, ctc_weight=ctc_w, temperature=1.15))
+        print("  hyps differ from the no-LM search:", hyps_n != hyps_r)
+        out["beam_hyps"] = np.array([h + [-1] * (64 - len(h)) for h in hyps_r], dtype=np.int64)
+        out["beam_scores"], out["beam_lens"] = scores_r.numpy(), lens_r.numpy()
+        out["beam_step0_lm"] = tr.lm_log_probs[0].numpy()
+    out["cfg"] = np.array([32, 4, 64, 2, 2, vocab, beam, 0], dtype=np.int64)
+    out["lm_cfg"] = np.array([lm_d, lm_heads, lm_ffn, lm_layers, int(normalize_before)], dtype=np.int64)
+    out["cfgf"] = np.array([ctc_w, 1.0, 0.0, lm_w, lm_temp, 1.15], dtype=np.float64)
+    for k, v in np_sd(sd).items():
+        out["sd/" + k] = v
+    path = os.path.join(OUT, f"model_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 # ---------------------------------------------------------------- init parity
 def golden_init_fingerprint():
     """Same-seed construction fingerprint of the reference Conformer-S, so that the
@@ -222,6 +300,10 @@ def golden_init_fingerprint():
 
 
 if __name__ == "__main__":
+    if "--lm-only" in sys.argv:
+        golden_lm("tiny_lm_ctc", normalize_before=False, ctc_w=0.4, lm_w=0.6, lm_temp=1.15, seed=3)
+        golden_lm("tiny_lm_prenorm", normalize_before=True, ctc_w=0.0, lm_w=0.5, lm_temp=1.0, seed=4, beam=3, B=2)
+        sys.exit(0)
     golden_fbank()
     # tiny model, EOS reachable (sharpened heads), CTC on
     golden_model("tiny_ctc", d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=2, vocab=40, B=3, n_frames=61,
@@ -232,5 +314,7 @@ if __name__ == "__main__":
     # odd head_dim (Conformer-S like: Dh = 36) and B = 1
     golden_model("dh36", d_model=72, nhead=2, d_ffn=96, n_enc=1, n_dec=1, vocab=30, B=1, n_frames=37,
                  beam=2, ctc_w=0.4, sharpen=4.0, seed=2)
+    golden_lm("tiny_lm_ctc", normalize_before=False, ctc_w=0.4, lm_w=0.6, lm_temp=1.15, seed=3)
+    golden_lm("tiny_lm_prenorm", normalize_before=True, ctc_w=0.0, lm_w=0.5, lm_temp=1.0, seed=4, beam=3, B=2)
     golden_init_fingerprint()
     print("OK")

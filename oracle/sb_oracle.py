@@ -92,6 +92,22 @@ class SearchCfg:
     using_eos_threshold: bool = False
     eos_threshold: float = 1.5
     minus_inf: float = -1e20
+    lm_weight: float = 0.0  # ScorerBuilder weights["transformerlm"] (scorer.py:1163-1200)
+    lm_temperature: float = 1.0  # TransformerLMScorer.temperature (scorer.py:504-508)
+
+
+@dataclass
+class LMCfg:
+    """TransformerLM.py:68-85 arguments on the path (encoder-only, regularMHA)."""
+
+    vocab: int = 5000
+    d_model: int = 768
+    nhead: int = 12
+    num_encoder_layers: int = 12
+    d_ffn: int = 3072
+    normalize_before: bool = False
+    activation: str = "gelu"
+    pad_idx: int = 0
 
 
 # --------------------------------------------------------------------------
@@ -374,6 +390,41 @@ def decode(tgt: Tensor, enc_out: Tensor, enc_len: Optional[Tensor], sd: SD, cfg:
 
 
 # --------------------------------------------------------------------------
+# a20: TransformerLM (full scorer of the test-time search)
+# --------------------------------------------------------------------------
+def lm_forward(tokens: Tensor, sd: SD, cfg: LMCfg, pfx: str = "") -> Tensor:
+    """TransformerLM.forward (TransformerLM.py:116-158): tokens [n,L] -> logits [n,L,V].
+
+    make_masks (:165-187): causal mask + key padding mask of tokens == pad_idx (0).
+    NormalizedEmbedding*sqrt(d) + absolute PE; TransformerEncoderLayer x N
+    (Transformer.py:427-481, post-norm unless normalize_before) with regularMHA;
+    TransformerEncoder's final LayerNorm (:620-624); output_proj = Linear ->
+    LayerNorm(eps 1e-6) -> Linear (TransformerLM.py:104-108).
+    """
+    n, L = tokens.shape
+    d = cfg.d_model
+    act = {"gelu": F.gelu, "relu": F.relu}[cfg.activation]
+    causal = torch.full((L, L), float("-inf")).triu(1)
+    key_pad = tokens.long() == cfg.pad_idx
+    x = F.embedding(tokens.long(), sd[pfx + "custom_src_module.emb.Embedding.weight"]) * math.sqrt(d)
+    x = x + abs_pos_encoding(L, d)[None]
+    for l in range(cfg.num_encoder_layers):
+        p = f"{pfx}encoder.layers.{l}."
+        if cfg.normalize_before:
+            h = _ln(x, sd, p + "norm1.norm.", 1e-6)
+            x = x + _mha(h, h, sd, p + "self_att.", cfg.nhead, attn_mask=causal, key_pad=key_pad)
+            h = _ln(x, sd, p + "norm2.norm.", 1e-6)
+            x = x + _ffn(h, sd, p + "pos_ffn.", act)
+        else:
+            x = _ln(x + _mha(x, x, sd, p + "self_att.", cfg.nhead, attn_mask=causal, key_pad=key_pad), sd, p + "norm1.norm.", 1e-6)
+            x = _ln(x + _ffn(x, sd, p + "pos_ffn.", act), sd, p + "norm2.norm.", 1e-6)
+    x = _ln(x, sd, pfx + "encoder.norm.norm.", 1e-6)
+    x = F.linear(x, sd[pfx + "output_proj.layers.0.w.weight"], sd[pfx + "output_proj.layers.0.w.bias"])
+    x = _ln(x, sd, pfx + "output_proj.layers.1.norm.", 1e-6)
+    return F.linear(x, sd[pfx + "output_proj.layers.2.w.weight"], sd[pfx + "output_proj.layers.2.w.bias"])
+
+
+# --------------------------------------------------------------------------
 # a14, a19: CTC prefix scorer (Watanabe et al. 2017, Alg. 2)
 # --------------------------------------------------------------------------
 class CTCPrefixScorer:
@@ -453,13 +504,15 @@ class SearchTrace:
 
     am_log_probs: List[Tensor] = field(default_factory=list)  # attn_weight * log_softmax, [n_bh,V]
     ctc_scores: List[Tensor] = field(default_factory=list)
+    lm_log_probs: List[Tensor] = field(default_factory=list)
     tokens: List[Tensor] = field(default_factory=list)
     preds: List[Tensor] = field(default_factory=list)
     scores: List[Tensor] = field(default_factory=list)
 
 
 def beam_search(enc: Tensor, wav_len: Tensor, sd: SD, cfg: ModelCfg, sc: SearchCfg, pfx: str = "Transformer.",
-                seq_lin: str = "seq_lin.w.", ctc_lin: str = "ctc_lin.w.", trace: Optional[SearchTrace] = None):
+                seq_lin: str = "seq_lin.w.", ctc_lin: str = "ctc_lin.w.", trace: Optional[SearchTrace] = None,
+                lm_cfg: Optional[LMCfg] = None, lm_pfx: str = "LM."):
     """S2SBeamSearcher.forward (decoders/seq2seq.py:1632-1723) specialised to
     S2STransformerBeamSearcher (:1853-1934) with an optional full CTC scorer
     (scorer.py:1221-1268).  Returns (hyps, best_lens, best_scores, best_log_probs).
@@ -509,6 +562,12 @@ def beam_search(enc: Tensor, wav_len: Tensor, sd: SD, cfg: ModelCfg, sc: SearchC
             mx = lp.max(dim=-1).values
             keep = lp[:, sc.eos] > sc.eos_threshold * mx
             lp[:, sc.eos] = torch.where(keep, lp[:, sc.eos], torch.full_like(mx, sc.minus_inf))
+        if lm_cfg is not None and sc.lm_weight != 0.0:  # TransformerLMScorer.score (scorer.py:510-543), first full scorer
+            lm_logits = lm_forward(memory, sd, lm_cfg, lm_pfx)
+            lm_lp = F.log_softmax(lm_logits / sc.lm_temperature, dim=-1)[:, -1, :]
+            lp = lp + lm_lp * sc.lm_weight
+            if trace is not None:
+                trace.lm_log_probs.append(lm_lp.clone())
         if ctc is not None:
             lp[:, sc.blank] = CTCPrefixScorer.NEG  # scorer.py:1248-1253
             ctc_sc, ctc_full = ctc.step(tok, ctc_state, beam)

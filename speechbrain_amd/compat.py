@@ -13,7 +13,7 @@ import types
 _MODULES = [
     "processing", "processing.features", "lobes", "lobes.features", "lobes.models", "lobes.models.convolution",
     "lobes.models.transformer", "lobes.models.transformer.Conformer", "lobes.models.transformer.Transformer",
-    "lobes.models.transformer.TransformerASR", "nnet", "nnet.attention", "nnet.activations", "nnet.CNN",
+    "lobes.models.transformer.TransformerASR", "lobes.models.transformer.TransformerLM", "nnet", "nnet.attention", "nnet.activations", "nnet.CNN",
     "nnet.containers", "nnet.embedding", "nnet.linear", "nnet.normalization", "decoders", "decoders.seq2seq",
     "decoders.scorer", "decoders.utils", "inference", "inference.ASR", "inference.interfaces", "utils",
     "utils.data_utils",

@@ -303,7 +303,8 @@ __global__ void __launch_bounds__(64) ctc_same_token_kernel(CtcStepArgs a, const
 __global__ void __launch_bounds__(256) ctc_combine_kernel(CtcStepArgs a, const float* __restrict__ am,
                                                           const float* __restrict__ am_max,
                                                           const float* __restrict__ psi,
-                                                          const float* __restrict__ psi_prev, float* __restrict__ comb) {
+                                                          const float* __restrict__ psi_prev, float* __restrict__ comb,
+                                                          const float* __restrict__ extra) {
   const int n = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= a.V) return;
@@ -312,6 +313,7 @@ __global__ void __launch_bounds__(256) ctc_combine_kernel(CtcStepArgs a, const f
     if (a.eos_floor) v = a.minus_inf;
     if (a.use_eos_threshold && !(v > a.eos_threshold * am_max[n])) v = a.minus_inf;
   }
+  if (extra) v += extra[(size_t)n * a.V + c];  // full scorers listed before "ctc" (already weighted)
   if (c == a.blank) v = kNeg;
   comb[(size_t)n * a.V + c] = v + (psi[(size_t)n * a.V + c] - psi_prev[n]) * a.weight;
 }
@@ -515,7 +517,8 @@ __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
 // Without a CTC scorer: comb = am with the eos modifications only.
 __global__ void __launch_bounds__(256) am_only_kernel(const float* __restrict__ am, float* __restrict__ comb, int V,
                                                       int eos, int eos_floor, int use_thr, float thr, float minus_inf,
-                                                      const float* __restrict__ am_max) {
+                                                      const float* __restrict__ am_max,
+                                                      const float* __restrict__ extra) {
   const int n = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= V) return;
@@ -524,6 +527,7 @@ __global__ void __launch_bounds__(256) am_only_kernel(const float* __restrict__ 
     if (eos_floor) v = minus_inf;
     if (use_thr && !(v > thr * am_max[n])) v = minus_inf;
   }
+  if (extra) v += extra[(size_t)n * V + c];
   comb[(size_t)n * V + c] = v;
 }
 
@@ -609,9 +613,9 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
 
 int ctc_combine(const float* am, const float* am_max, const float* psi, const float* psi_prev, float* comb, int n_bh,
                 int V, int blank, int eos, float weight, int eos_floor, int use_thr, float thr, float minus_inf,
-                hipStream_t st) {
+                const float* extra, hipStream_t st) {
   CtcStepArgs a{nullptr, nullptr, 0, 0, V, 0, 0, blank, eos, weight, eos_floor, use_thr, thr, minus_inf};
-  SBK_LAUNCH(ctc_combine_kernel, dim3(cdiv(V, 256), n_bh), dim3(256), 0, st, a, am, am_max, psi, psi_prev, comb);
+  SBK_LAUNCH(ctc_combine_kernel, dim3(cdiv(V, 256), n_bh), dim3(256), 0, st, a, am, am_max, psi, psi_prev, comb, extra);
   return launch_status("ctc_combine");
 }
 
@@ -630,9 +634,9 @@ int ctc_advance(const float* P, const float* state_old, const float* psi, const 
 }
 
 int am_only(const float* am, float* comb, int n_bh, int V, int eos, int eos_floor, int use_thr, float thr,
-            float minus_inf, const float* am_max, hipStream_t st) {
+            float minus_inf, const float* am_max, const float* extra, hipStream_t st) {
   SBK_LAUNCH(am_only_kernel, dim3(cdiv(V, 256), n_bh), dim3(256), 0, st, am, comb, V, eos, eos_floor, use_thr, thr,
-             minus_inf, am_max);
+             minus_inf, am_max, extra);
   return launch_status("am_only");
 }
 

@@ -38,6 +38,11 @@ struct SelfAttnArgs {
   float* out;              // [n,d]
   int n, d, H, Dh, step, nslot, Lmax;
   float scale;
+  // optional key padding mask (TransformerLM.make_masks, TransformerLM.py:165-187): key position p is
+  // masked when the token fed at p equals pad_idx.  That token is key_tok[i*key_stride + p - key_shift]
+  // (key_first for p < key_shift).  NULL = no mask.
+  const int32_t* key_tok;
+  int key_stride, key_shift, key_first, pad_idx;
 };
 
 // One wave per (hypothesis, head).  The 64 lanes form 4 position groups x 16 lanes; a group's 16
@@ -111,7 +116,13 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
       s += sbk::shfl_xor(s, 4);
       s += sbk::shfl_xor(s, 8);
       const int p = p0 + 4 * u + pg;
-      if (p < L && cq == 0) prob[p] = s;
+      if (p < L && cq == 0) {
+        if (a.key_tok) {
+          const int tk = p < a.key_shift ? a.key_first : a.key_tok[(size_t)i * a.key_stride + p - a.key_shift];
+          if (tk == a.pad_idx) s = -INFINITY;
+        }
+        prob[p] = s;
+      }
     }
   }
   sbk::wave_sync();
@@ -363,9 +374,11 @@ int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* 
 }
 
 int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t* kv_slot, float* out, int n, int d,
-                   int H, int step, int nslot, int Lmax, hipStream_t st) {
+                   int H, int step, int nslot, int Lmax, hipStream_t st, const int32_t* key_tok, int key_stride,
+                   int key_shift, int key_first, int pad_idx) {
   if (n == 0) return 0;
-  SelfAttnArgs a{qkv, kcache, vcache, kv_slot, out, n, d, H, d / H, step, nslot, Lmax, 1.0f / sqrtf((float)(d / H))};
+  SelfAttnArgs a{qkv, kcache, vcache, kv_slot, out, n, d, H, d / H, step, nslot, Lmax, 1.0f / sqrtf((float)(d / H)),
+                 key_tok, key_stride, key_shift, key_first, pad_idx};
   const size_t lds = (size_t)8 * (((Lmax + 63) / 64) * 64) * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "self_attn_step: Lmax=%d too long for the LDS window", Lmax);
   ProfScope prof("self_attn_step", 4.0 * n * d * (step + 1), 8.0 * n * d * (step + 1), st);

@@ -20,7 +20,8 @@ namespace sbk {
 int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,
               hipStream_t st);
 int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t* kv_slot, float* out, int n, int d,
-                   int H, int step, int nslot, int Lmax, hipStream_t st);
+                   int H, int step, int nslot, int Lmax, hipStream_t st, const int32_t* key_tok = nullptr,
+                   int key_stride = 0, int key_shift = 0, int key_first = 0, int pad_idx = 0);
 int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, float* part, int B, int T,
                     int d, int H, int beam, hipStream_t st);
 size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam);
@@ -32,12 +33,12 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
                  int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st);
 int ctc_combine(const float* am, const float* am_max, const float* psi, const float* psi_prev, float* comb, int n_bh,
                 int V, int blank, int eos, float weight, int eos_floor, int use_thr, float thr, float minus_inf,
-                hipStream_t st);
+                const float* extra, hipStream_t st);
 int ctc_advance(const float* x, const float* phi_old, const float* psi, const int32_t* parent, const int32_t* token,
                 const int32_t* parent_last_tok, float* phi_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
                 int prefix_len, int blank, hipStream_t st);
 int am_only(const float* am, float* comb, int n_bh, int V, int eos, int eos_floor, int use_thr, float thr,
-            float minus_inf, const float* am_max, hipStream_t st);
+            float minus_inf, const float* am_max, const float* extra, hipStream_t st);
 int row_max(const float* x, float* out, int rows, int V, hipStream_t st);
 }  // namespace sbk
 
@@ -535,6 +536,84 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
   return 0;
 }
 
+// ---------------------------------------------------------------- TransformerLM scorer (a20)
+struct LmBufs {
+  float *x, *t, *h, *qkv, *ctx, *ff, *logits;
+  float* splitk;
+  size_t splitk_floats;
+  float *kcache[64], *vcache[64];
+};
+
+void carve_lm(Carver& c, LmBufs& d, const sbk_lm_weights* LM, int n, int Lmax) {
+  const int dm = LM->d_model;
+  d.x = c.take<float>((size_t)n * dm);
+  d.t = c.take<float>((size_t)n * dm);
+  d.h = c.take<float>((size_t)n * dm);
+  d.qkv = c.take<float>((size_t)n * 3 * dm);
+  d.ctx = c.take<float>((size_t)n * dm);
+  d.ff = c.take<float>((size_t)n * LM->d_ffn);
+  d.logits = c.take<float>((size_t)n * LM->vocab);
+  d.splitk_floats = (size_t)4 * n * (size_t)dm;
+  d.splitk = c.take<float>(d.splitk_floats);
+  for (int l = 0; l < LM->n_layers; ++l) {
+    d.kcache[l] = c.take<float>((size_t)Lmax * n * dm);
+    d.vcache[l] = c.take<float>((size_t)Lmax * n * dm);
+  }
+}
+
+int check_lm(const sbk_lm_weights* LM) {
+  SBK_REQUIRE(LM && LM->layers && LM->emb && LM->pe && LM->final_ln_g && LM->final_ln_b && LM->out0_w && LM->out0_b &&
+                  LM->out_ln_g && LM->out_ln_b && LM->out2_w && LM->out2_b,
+              "lm weights: null pointer");
+  SBK_REQUIRE(LM->n_layers > 0 && LM->n_layers <= 64 && LM->d_model > 0 && LM->nhead > 0 &&
+                  LM->d_model % LM->nhead == 0 && LM->vocab > 0,
+              "lm weights: bad shape");
+  return 0;
+}
+
+// One TransformerLM step for n hypotheses at position `step` (TransformerLM.forward restricted to the
+// newest position; earlier positions' K/V sit in the slot-addressed cache shared with the decoder's
+// ancestry table).  Leaves output_proj logits in d.logits.
+int lm_step(const sbk_lm_weights* LM, const LmBufs& d, const int32_t* tokens, const int32_t* kv_slot,
+            const int32_t* key_tok, int key_stride, int key_shift, int key_first, int step, int n, int Lmax,
+            hipStream_t st) {
+  const int dm = LM->d_model, H = LM->nhead, ff = LM->d_ffn;
+  const float eps = LM->ln_eps;
+  auto gemm = [&](const float* A, int lda, const float* Wt, const float* b, const float* R, float* C, int N, int K,
+                  int act) {
+    return sbk::gemm_nt_ws(A, lda, Wt, K, b, R, R ? N : 0, C, N, n, N, K, act, 1.0f, nullptr, 0, d.splitk,
+                           d.splitk_floats, st);
+  };
+  SBK_TRY(sbk::embed_pos(tokens, LM->emb, LM->pe + (size_t)step * dm, d.x, n, dm, sqrtf((float)dm), st));
+  for (int l = 0; l < LM->n_layers; ++l) {
+    const sbk_lm_layer& L = LM->layers[l];
+    if (LM->normalize_before) {  // Transformer.py:452-480 with normalize_before
+      SBK_TRY(sbk::layernorm(d.x, L.ln1_g, L.ln1_b, d.h, n, dm, eps, SBK_ACT_NONE, st));
+      SBK_TRY(gemm(d.h, dm, L.in_w, L.in_b, nullptr, d.qkv, 3 * dm, dm, SBK_ACT_NONE));
+      SBK_TRY(sbk::self_attn_step(d.qkv, d.kcache[l], d.vcache[l], kv_slot, d.ctx, n, dm, H, step, n, Lmax, st, key_tok,
+                                  key_stride, key_shift, key_first, LM->pad_idx));
+      SBK_TRY(gemm(d.ctx, dm, L.out_w, L.out_b, d.x, d.x, dm, dm, SBK_ACT_NONE));
+      SBK_TRY(sbk::layernorm(d.x, L.ln2_g, L.ln2_b, d.h, n, dm, eps, SBK_ACT_NONE, st));
+      SBK_TRY(gemm(d.h, dm, L.ff1_w, L.ff1_b, nullptr, d.ff, ff, dm, LM->ffn_act));
+      SBK_TRY(gemm(d.ff, ff, L.ff2_w, L.ff2_b, d.x, d.x, dm, ff, SBK_ACT_NONE));
+    } else {  // post-norm
+      SBK_TRY(gemm(d.x, dm, L.in_w, L.in_b, nullptr, d.qkv, 3 * dm, dm, SBK_ACT_NONE));
+      SBK_TRY(sbk::self_attn_step(d.qkv, d.kcache[l], d.vcache[l], kv_slot, d.ctx, n, dm, H, step, n, Lmax, st, key_tok,
+                                  key_stride, key_shift, key_first, LM->pad_idx));
+      SBK_TRY(gemm(d.ctx, dm, L.out_w, L.out_b, d.x, d.t, dm, dm, SBK_ACT_NONE));
+      SBK_TRY(sbk::layernorm(d.t, L.ln1_g, L.ln1_b, d.x, n, dm, eps, SBK_ACT_NONE, st));
+      SBK_TRY(gemm(d.x, dm, L.ff1_w, L.ff1_b, nullptr, d.ff, ff, dm, LM->ffn_act));
+      SBK_TRY(gemm(d.ff, ff, L.ff2_w, L.ff2_b, d.x, d.t, dm, ff, SBK_ACT_NONE));
+      SBK_TRY(sbk::layernorm(d.t, L.ln2_g, L.ln2_b, d.x, n, dm, eps, SBK_ACT_NONE, st));
+    }
+  }
+  SBK_TRY(sbk::layernorm(d.x, LM->final_ln_g, LM->final_ln_b, d.h, n, dm, eps, SBK_ACT_NONE, st));
+  SBK_TRY(gemm(d.h, dm, LM->out0_w, LM->out0_b, nullptr, d.t, dm, dm, SBK_ACT_NONE));
+  SBK_TRY(sbk::layernorm(d.t, LM->out_ln_g, LM->out_ln_b, d.h, n, dm, eps, SBK_ACT_NONE, st));
+  SBK_TRY(gemm(d.h, dm, LM->out2_w, LM->out2_b, nullptr, d.logits, LM->vocab, dm, SBK_ACT_NONE));
+  return 0;
+}
+
 int check_weights(const sbk_decoder_weights* W) {
   SBK_REQUIRE(W && W->layers && W->emb && W->pe && W->final_ln_g && W->final_ln_b, "decoder weights: null pointer");
   SBK_REQUIRE(W->n_layers > 0 && W->n_layers <= 64 && W->d_model > 0 && W->nhead > 0 && W->d_model % W->nhead == 0,
@@ -594,6 +673,10 @@ extern "C" size_t sbk_beam_search_workspace_bytes(const sbk_decoder_weights* W, 
   const int Lmax = cfg->max_steps > 0 ? cfg->max_steps : 1;
   carve_decoder(c, d, W, B * cfg->beam, B, T, Lmax);
   carve_beam(c, bb, B, cfg->beam, T, W->vocab, Lmax, cfg->ctc_weight > 0.0f);
+  if (cfg->lm && cfg->lm_weight != 0.0f) {
+    LmBufs lb;
+    carve_lm(c, lb, cfg->lm, B * cfg->beam, Lmax);
+  }
   return c.used + 256;
 }
 
@@ -625,6 +708,16 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   BeamBufs bb;
   carve_decoder(c, d, W, n, B, T, Lmax);
   carve_beam(c, bb, B, beam, T, V, Lmax, ctc);
+  const sbk_lm_weights* LM = (cfg->lm && cfg->lm_weight != 0.0f) ? cfg->lm : nullptr;
+  LmBufs lb;
+  if (LM) {
+    SBK_TRY(check_lm(LM));
+    SBK_REQUIRE(LM->vocab == V, "beam_search: the LM scores %d tokens, the decoder %d", LM->vocab, V);
+    SBK_REQUIRE(cfg->max_steps <= LM->max_len, "beam_search: %d steps exceed the LM positional table", cfg->max_steps);
+    SBK_REQUIRE(cfg->lm_temperature > 0.0f, "beam_search: lm_temperature must be positive");
+    carve_lm(c, lb, LM, n, Lmax);
+  }
+  const float* extra = LM ? lb.logits : nullptr;  // weighted LM log-probs of the step
 
   SBK_TRY(project_memory(W, d, enc, B, T, st));
   if (ctc) {  // CTCScorer.reset_mem (scorer.py:239-255): log_softmax(ctc_lin(enc)), then the frame mask
@@ -656,6 +749,10 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
     SBK_TRY(sbk::log_softmax_rows(d.logits, bb.am, n, V, cfg->temperature, attn_w, st));
     if (cfg->using_eos_threshold) SBK_TRY(sbk::row_max(bb.am, bb.am_max, n, V, st));
     const int eos_floor = step < cfg->min_steps;
+    if (LM) {  // TransformerLMScorer.score (scorer.py:510-543): the prefix is the decoder's own token history
+      SBK_TRY(lm_step(LM, lb, bb.s.tokens[cur], bb.s.kv_slot[cur], bb.s.seq[cur], Lmax, 1, cfg->bos, step, n, Lmax, st));
+      SBK_TRY(sbk::log_softmax_rows(lb.logits, lb.logits, n, V, cfg->lm_temperature, cfg->lm_weight, st));
+    }
     if (ctc) {
       if (side && (psi_aside || step > 0)) SBK_HIP(hipStreamWaitEvent(st, side->join, 0));  // helper-stream work done
       if (!psi_aside)
@@ -663,10 +760,10 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
                                   cfg->blank, cfg->eos, st));
       SBK_TRY(sbk::ctc_combine(bb.am, bb.am_max, bb.psi, bb.psi_prev[cur], bb.comb, n, V, cfg->blank, cfg->eos,
                                cfg->ctc_weight, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
-                               cfg->minus_inf, st));
+                               cfg->minus_inf, extra, st));
     } else {
       SBK_TRY(sbk::am_only(bb.am, bb.comb, n, V, cfg->eos, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
-                           cfg->minus_inf, bb.am_max, st));
+                           cfg->minus_inf, bb.am_max, extra, st));
     }
     const float norm = cfg->length_normalization ? (float)(step + 1) : 0.0f;
     {
@@ -755,6 +852,44 @@ extern "C" int sbk_decoder_prefix_f32(const sbk_decoder_weights* W, const int32_
     SBK_LAUNCH(copy_rows_kernel, dim3(n), dim3(256), 0, st, (const float*)d.h, pred + (size_t)p * W->d_model, n,
                W->d_model, (long)L * W->d_model);
     SBK_TRY(sbk::launch_status("prefix_copy"));
+  }
+  return 0;
+}
+
+// TransformerLM.forward (TransformerLM.py:116-158) through the KV-cached step.
+extern "C" size_t sbk_lm_prefix_workspace_bytes(const sbk_lm_weights* LM, int n, int L) {
+  if (!LM) return 0;
+  Carver c{nullptr, 0, true};
+  LmBufs d;
+  carve_lm(c, d, LM, n, L > 0 ? L : 1);
+  c.take<int32_t>((size_t)n * (L > 0 ? L : 1));
+  c.take<int32_t>((size_t)n);
+  c.take<int32_t>(64 + 2 * (size_t)n);
+  return c.used + 256;
+}
+
+extern "C" int sbk_lm_prefix_f32(const sbk_lm_weights* LM, const int32_t* tokens, void* workspace,
+                                 size_t workspace_bytes, float* logits, int n, int L, sbk_stream_t stream) {
+  SBK_TRY(check_lm(LM));
+  SBK_REQUIRE(tokens && workspace && logits, "lm_prefix: null");
+  SBK_REQUIRE(L <= LM->max_len, "lm_prefix: prefix longer than the positional table");
+  SBK_REQUIRE(workspace_bytes >= sbk_lm_prefix_workspace_bytes(LM, n, L), "lm_prefix: workspace too small");
+  hipStream_t st = sbk::as_stream(stream);
+  if (n == 0 || L == 0) return 0;
+  Carver c{static_cast<char*>(workspace), 0, false};
+  LmBufs d;
+  carve_lm(c, d, LM, n, L);
+  int32_t* kv_slot = c.take<int32_t>((size_t)n * L);
+  int32_t* col = c.take<int32_t>((size_t)n);
+  int32_t* misc = c.take<int32_t>(64 + 2 * (size_t)n);
+  SBK_LAUNCH(greedy_init_kernel, dim3(sbk::cdiv(n, 256)), dim3(256), 0, st, misc + 64, misc + 64 + n, misc, kv_slot, n, L, 0);
+  SBK_TRY(sbk::launch_status("lm_prefix_init"));
+  for (int p = 0; p < L; ++p) {
+    SBK_LAUNCH(gather_col_kernel, dim3(sbk::cdiv(n, 256)), dim3(256), 0, st, tokens, col, n, L, p);
+    SBK_TRY(lm_step(LM, d, col, kv_slot, tokens, L, 0, 0, p, n, L, st));
+    SBK_LAUNCH(copy_rows_kernel, dim3(n), dim3(256), 0, st, (const float*)d.logits, logits + (size_t)p * LM->vocab, n,
+               LM->vocab, (long)L * LM->vocab);
+    SBK_TRY(sbk::launch_status("lm_prefix_copy"));
   }
   return 0;
 }

@@ -1,3 +1,3 @@
-"""speechbrain.decoders mirror (ASR searchers + CTC scorer only)."""
-from speechbrain_amd.decoders.scorer import CTCScorer, ScorerBuilder  # noqa: F401
+"""speechbrain.decoders mirror (ASR searchers + CTC / TransformerLM scorers)."""
+from speechbrain_amd.decoders.scorer import CTCScorer, ScorerBuilder, TransformerLMScorer  # noqa: F401
 from speechbrain_amd.decoders.seq2seq import S2STransformerBeamSearcher, S2STransformerGreedySearcher  # noqa: F401

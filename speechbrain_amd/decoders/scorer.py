@@ -1,4 +1,4 @@
-"""speechbrain.decoders.scorer mirror for the ASR recipe: ScorerBuilder + CTCScorer.
+"""speechbrain.decoders.scorer mirror for the ASR recipe: ScorerBuilder + CTCScorer + TransformerLMScorer.
 
 The reference scorer objects carry Python-side state and are called once per decoding step
 (scorer.py:1221-1315, :108-255).  Here they are configuration holders: the CTC prefix scoring
@@ -21,12 +21,24 @@ class CTCScorer(BaseScorerInterface):
         self.ctc_window_size = ctc_window_size
 
 
+class TransformerLMScorer(BaseScorerInterface):
+    """scorer.py:413-577: language_model = a TransformerLM; temperature divides its logits before the
+    log-softmax.  The reference re-runs the LM over the whole prefix every step (:538-543); the device
+    search keeps a per-hypothesis K/V cache instead (csrc/search.hip:lm_step)."""
+
+    def __init__(self, language_model, temperature=1.0):
+        self.lm = language_model
+        self.lm.eval()
+        self.temperature = temperature
+
+
 _KNOWN = ("ctc", "rnnlm", "transformerlm", "kenlm", "coverage", "length", "huggingfacelm", "basescorerinterface")
 
 
 class ScorerBuilder:
-    """scorer.py:1075-1315.  Supported composition this round: full_scorers=[CTCScorer], as in the
-    recipe's ``valid_search`` (conformer_large.yaml:225-239)."""
+    """scorer.py:1075-1315.  Supported compositions: full_scorers drawn from {CTCScorer,
+    TransformerLMScorer} -- the recipe's ``valid_search`` ([ctc]) and ``test_search``
+    ([transformerlm, ctc]) (conformer_large.yaml:215-239)."""
 
     def __init__(self, weights=dict(), full_scorers=list(), partial_scorers=list(), scorer_beam_scale=2):
         assert len(weights) == len(full_scorers) + len(partial_scorers), "Weights and scorers are not matched."
@@ -35,10 +47,10 @@ class ScorerBuilder:
         self.weights = {**dict.fromkeys(_KNOWN, 0.0), **weights}
         self.full_scorers = {name(s): s for s in full_scorers}
         self.partial_scorers = {name(s): s for s in partial_scorers}
-        unsupported = [k for k in list(self.full_scorers) + list(self.partial_scorers) if k != "ctc"]
+        unsupported = [k for k in list(self.full_scorers) + list(self.partial_scorers) if k not in ("ctc", "transformerlm")]
         if unsupported or self.partial_scorers:
             raise NotImplementedError(
-                f"scorers {unsupported or list(self.partial_scorers)}: this round fuses one full CTC scorer; "
-                "TransformerLM / partial scorers are the next scope row")
+                f"scorers {unsupported or list(self.partial_scorers)}: the device search fuses the full CTC and "
+                "TransformerLM scorers; RNNLM / KenLM / coverage / length / partial scorers are not implemented")
         if not 0.0 <= self.weights["ctc"] <= 1.0:
             raise ValueError("ctc_weight should not > 1.0 and < 0.0")

@@ -5,6 +5,8 @@ Constructor signatures, ``forward(enc_states, wav_len)`` and return tuples follo
 device (csrc/search.hip): KV-cached decoder steps, fused CTC prefix scoring, device-side beam
 bookkeeping; the only device->host traffic is the stop-rule poll and the final token ids.
 """
+import ctypes
+
 import torch
 
 from speechbrain_amd import native
@@ -92,7 +94,11 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
         self.overlap_ctc = 3  # CTC scorer on a helper stream beside the decoder step (bit mask, see include/sbk.h)
         self.blank_index = 0
         self.ctc_fc = None
+        self.lm, self.lm_weight, self.lm_temperature = None, 0.0, 1.0
         if scorer is not None:
+            if scorer.weights["transformerlm"] != 0.0 and "transformerlm" in scorer.full_scorers:
+                lms = scorer.full_scorers["transformerlm"]
+                self.lm, self.lm_weight, self.lm_temperature = lms.lm, scorer.weights["transformerlm"], lms.temperature
             if length_normalization and scorer.weights["length"] > 0.0:
                 raise ValueError("Length normalization is not compatible with length rewarding.")
             if scorer.weights["ctc"] > 0.0:
@@ -108,7 +114,12 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
 
     def config(self, T):
         mn, mx = self._steps(T)
-        return native.SearchConfig(bos=self.bos_index, eos=self.eos_index, blank=self.blank_index, beam=self.beam_size,
+        lm = {}
+        if self.lm is not None:
+            self._lm_handle = self.lm.handle()  # keeps the pointed-to weight table alive during the call
+            lm = dict(lm=ctypes.pointer(self._lm_handle.W), lm_weight=self.lm_weight,
+                      lm_temperature=self.lm_temperature)
+        return native.SearchConfig(**lm, bos=self.bos_index, eos=self.eos_index, blank=self.blank_index, beam=self.beam_size,
                                    min_steps=mn, max_steps=mx, length_normalization=int(self.length_normalization),
                                    using_eos_threshold=int(self.using_eos_threshold), check_every=self.check_every,
                                    overlap_ctc=int(self.overlap_ctc),

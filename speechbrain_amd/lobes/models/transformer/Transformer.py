@@ -41,6 +41,46 @@ class NormalizedEmbedding(nn.Module):
         self.d_model = d_model
 
 
+class TransformerEncoderLayer(nn.Module):
+    """Transformer.py:306-481 (regularMHA + regularFFN): holder of self_att / pos_ffn / norm1-2.  The
+    arithmetic on the path is the KV-cached TransformerLM step in csrc/search.hip (lm_step)."""
+
+    def __init__(self, d_ffn, nhead, d_model, kdim=None, vdim=None, dropout=0.0, activation=nn.ReLU,
+                 normalize_before=False, attention_type="regularMHA", ffn_type="regularFFN",
+                 ffn_cnn_kernel_size_list=[3, 3], causal=False):
+        super().__init__()
+        if attention_type != "regularMHA" or ffn_type != "regularFFN":
+            raise NotImplementedError("TransformerEncoderLayer: only regularMHA + regularFFN (the TransformerLM "
+                                      "configuration) is implemented")
+        self.nhead = nhead
+        self.self_att = MultiheadAttention(nhead=nhead, d_model=d_model, dropout=dropout, kdim=kdim, vdim=vdim)
+        self.pos_ffn = PositionalwiseFeedForward(d_ffn=d_ffn, input_size=d_model, dropout=dropout, activation=activation)
+        self.norm1 = LayerNorm(d_model, eps=1e-6)
+        self.norm2 = LayerNorm(d_model, eps=1e-6)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.normalize_before = normalize_before
+
+
+class TransformerEncoder(nn.Module):
+    """Transformer.py:484-640: N encoder layers + final LayerNorm(eps 1e-6)."""
+
+    def __init__(self, num_layers, nhead, d_ffn, input_shape=None, d_model=None, kdim=None, vdim=None, dropout=0.0,
+                 activation=nn.ReLU, normalize_before=False, causal=False, layerdrop_prob=0.0,
+                 attention_type="regularMHA", ffn_type="regularFFN", ffn_cnn_kernel_size_list=[3, 3],
+                 output_hidden_states=False):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            TransformerEncoderLayer(d_ffn=d_ffn, nhead=nhead, d_model=d_model, kdim=kdim, vdim=vdim, dropout=dropout,
+                                    activation=activation, normalize_before=normalize_before, causal=causal,
+                                    attention_type=attention_type, ffn_type=ffn_type,
+                                    ffn_cnn_kernel_size_list=ffn_cnn_kernel_size_list)
+            for _ in range(num_layers)])
+        self.norm = LayerNorm(d_model, eps=1e-6)
+        self.layerdrop_prob = layerdrop_prob
+        self.output_hidden_states = output_hidden_states
+
+
 class TransformerDecoderLayer(nn.Module):
     """Transformer.py:659-834 (regularMHA): holder of self_attn / multihead_attn / pos_ffn / norm1-3."""
 
@@ -77,7 +117,8 @@ class TransformerDecoder(nn.Module):
 
 
 class TransformerInterface(nn.Module):
-    """Transformer.py:35-250, restricted to encoder_module="conformer" + RelPosMHAXL."""
+    """Transformer.py:35-250: encoder_module="conformer" + RelPosMHAXL (TransformerASR) or
+    encoder_module="transformer" + regularMHA (TransformerLM)."""
 
     def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, d_ffn=2048, dropout=0.1,
                  activation=nn.ReLU, custom_src_module=None, custom_tgt_module=None,
@@ -96,14 +137,26 @@ class TransformerInterface(nn.Module):
         self.output_hidden_states, self.layerdrop_prob = output_hidden_states, layerdrop_prob
         assert positional_encoding in ["fixed_abs_sine", None]
         assert num_encoder_layers + num_decoder_layers > 0
-        if encoder_module != "conformer" or attention_type != "RelPosMHAXL" or causal:
+        lm_like = encoder_module == "transformer" and attention_type == "regularMHA"
+        if not lm_like and (encoder_module != "conformer" or attention_type != "RelPosMHAXL" or causal):
             raise NotImplementedError(
-                "this round implements encoder_module='conformer' with attention_type='RelPosMHAXL', causal=False")
+                "implemented: encoder_module='conformer' with attention_type='RelPosMHAXL', causal=False (ASR) and "
+                "encoder_module='transformer' with attention_type='regularMHA' (TransformerLM)")
         if positional_encoding == "fixed_abs_sine":
             self.positional_encoding = PositionalEncoding(d_model, max_length)
-        self.positional_encoding = RelPosEncXL(d_model)  # overrides, as in the reference (:165-170)
-        self.positional_encoding_decoder = PositionalEncoding(d_model, max_length)
-        if num_encoder_layers > 0:
+        if attention_type == "RelPosMHAXL":
+            self.positional_encoding = RelPosEncXL(d_model)  # overrides, as in the reference (:165-170)
+            self.positional_encoding_decoder = PositionalEncoding(d_model, max_length)
+        if num_encoder_layers > 0 and lm_like:
+            if custom_src_module is not None:
+                self.custom_src_module = custom_src_module(d_model)
+            self.encoder = TransformerEncoder(nhead=nhead, num_layers=num_encoder_layers, d_ffn=d_ffn, d_model=d_model,
+                                              dropout=dropout, activation=activation,
+                                              normalize_before=normalize_before, causal=causal,
+                                              attention_type=attention_type, kdim=encoder_kdim, vdim=encoder_vdim,
+                                              output_hidden_states=output_hidden_states,
+                                              layerdrop_prob=layerdrop_prob)
+        elif num_encoder_layers > 0:
             self.encoder = ConformerEncoder(nhead=nhead, num_layers=num_encoder_layers, d_ffn=d_ffn, d_model=d_model,
                                             dropout=dropout, activation=conformer_activation, kernel_size=kernel_size,
                                             bias=bias, causal=causal, attention_type=attention_type,

@@ -42,11 +42,24 @@ class DecoderWeights(ctypes.Structure):  # sbk_decoder_weights
                 ("max_len", c_int32), ("ffn_act", c_int32), ("ln_eps", c_float)]
 
 
+class LMLayer(ctypes.Structure):  # sbk_lm_layer
+    _fields_ = [(n, c_void_p) for n in ("in_w", "in_b", "out_w", "out_b", "ln1_g", "ln1_b", "ff1_w", "ff1_b", "ff2_w",
+                                        "ff2_b", "ln2_g", "ln2_b")]
+
+
+class LMWeights(ctypes.Structure):  # sbk_lm_weights
+    _fields_ = [("layers", POINTER(LMLayer))] + [(n, c_void_p) for n in (
+        "emb", "pe", "final_ln_g", "final_ln_b", "out0_w", "out0_b", "out_ln_g", "out_ln_b", "out2_w", "out2_b")] + [
+        (n, c_int32) for n in ("d_model", "nhead", "d_ffn", "n_layers", "vocab", "max_len", "ffn_act",
+                               "normalize_before", "pad_idx")] + [("ln_eps", c_float)]
+
+
 class SearchConfig(ctypes.Structure):  # sbk_search_config
     _fields_ = [("bos", c_int32), ("eos", c_int32), ("blank", c_int32), ("beam", c_int32), ("min_steps", c_int32),
                 ("max_steps", c_int32), ("length_normalization", c_int32), ("using_eos_threshold", c_int32),
                 ("check_every", c_int32), ("overlap_ctc", c_int32), ("ctc_weight", c_float), ("temperature", c_float),
-                ("eos_threshold", c_float), ("minus_inf", c_float)]
+                ("eos_threshold", c_float), ("minus_inf", c_float), ("lm_weight", c_float), ("lm_temperature", c_float),
+                ("lm", POINTER(LMWeights))]
 
 
 def _declare(lib):
@@ -81,6 +94,8 @@ def _declare(lib):
                                    i, i, i, i, i, p], c_int),
         "sbk_decoder_prefix_workspace_bytes": ([POINTER(DecoderWeights), i, i, i], ctypes.c_size_t),
         "sbk_decoder_prefix_f32": ([POINTER(DecoderWeights), p, p, p, p, ctypes.c_size_t, p, i, i, i, p], c_int),
+        "sbk_lm_prefix_workspace_bytes": ([POINTER(LMWeights), i, i], ctypes.c_size_t),
+        "sbk_lm_prefix_f32": ([POINTER(LMWeights), p, p, ctypes.c_size_t, p, i, i, p], c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -396,6 +411,71 @@ class DecoderHandle:
             return DecoderHandle(model, seq_lin).key != self.key
         except Exception:
             return True
+
+
+class LMHandle:
+    """Device pointers of a TransformerLM laid out as sbk_lm_weights (keeps the tensors alive)."""
+
+    def __init__(self, lm):
+        self.keep = []
+
+        def ptr(t):
+            t = t.detach()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            _dev_ok(t)
+            _f32(t)
+            self.keep.append(t)
+            return t.data_ptr()
+
+        enc = lm.encoder
+        layers = (LMLayer * len(enc.layers))()
+        for l, L in enumerate(enc.layers):
+            o = layers[l]
+            o.in_w, o.in_b = ptr(L.self_att.att.in_proj_weight), ptr(L.self_att.att.in_proj_bias)
+            o.out_w, o.out_b = ptr(L.self_att.att.out_proj.weight), ptr(L.self_att.att.out_proj.bias)
+            o.ln1_g, o.ln1_b = ptr(L.norm1.norm.weight), ptr(L.norm1.norm.bias)
+            o.ff1_w, o.ff1_b = ptr(L.pos_ffn.ffn[0].weight), ptr(L.pos_ffn.ffn[0].bias)
+            o.ff2_w, o.ff2_b = ptr(L.pos_ffn.ffn[3].weight), ptr(L.pos_ffn.ffn[3].bias)
+            o.ln2_g, o.ln2_b = ptr(L.norm2.norm.weight), ptr(L.norm2.norm.bias)
+        self.layers = layers
+        W = LMWeights()
+        W.layers = ctypes.cast(layers, POINTER(LMLayer))
+        emb = lm.custom_src_module.emb.Embedding.weight
+        pe = lm.positional_encoding.pe
+        W.emb, W.pe = ptr(emb), ptr(pe.reshape(pe.shape[-2], pe.shape[-1]))
+        W.final_ln_g, W.final_ln_b = ptr(enc.norm.norm.weight), ptr(enc.norm.norm.bias)
+        o0, oln, o2 = lm.output_proj.layers[0], lm.output_proj.layers[1], lm.output_proj.layers[2]
+        W.out0_w, W.out0_b = ptr(o0.w.weight), ptr(o0.w.bias)
+        W.out_ln_g, W.out_ln_b = ptr(oln.norm.weight), ptr(oln.norm.bias)
+        W.out2_w, W.out2_b = ptr(o2.w.weight), ptr(o2.w.bias)
+        W.d_model, W.nhead = emb.shape[1], enc.layers[0].nhead
+        W.d_ffn, W.n_layers, W.vocab = enc.layers[0].pos_ffn.ffn[0].weight.shape[0], len(enc.layers), o2.w.weight.shape[0]
+        W.max_len, W.ffn_act = pe.shape[-2], enc.layers[0].pos_ffn.act_code
+        W.normalize_before, W.pad_idx, W.ln_eps = int(enc.layers[0].normalize_before), 0, enc.norm.eps
+        self.W = W
+        self.device = emb.device
+        self.key = tuple((t.data_ptr(), t._version) for t in self.keep)
+
+    def stale(self, lm):
+        try:
+            return LMHandle(lm).key != self.key
+        except Exception:
+            return True
+
+
+def lm_prefix(handle: "LMHandle", tokens):
+    """TransformerLM.forward: tokens [n,L] int32 -> logits [n,L,V] (KV-cached, causal, pad-0 keys masked)."""
+    lib = load()
+    _dev_ok(tokens)
+    n, L = tokens.shape
+    nbytes = lib.sbk_lm_prefix_workspace_bytes(ctypes.byref(handle.W), n, L)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=tokens.device)
+    off = (-ws.data_ptr()) % 256
+    out = torch.empty(n, L, handle.W.vocab, dtype=torch.float32, device=tokens.device)
+    _chk(lib.sbk_lm_prefix_f32(ctypes.byref(handle.W), _p(tokens), c_void_p(ws.data_ptr() + off), nbytes, _p(out), n, L,
+                               _stream(tokens)), "sbk_lm_prefix_f32")
+    return out
 
 
 def _fold_ln(w, b, gamma, beta):

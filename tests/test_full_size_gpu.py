@@ -89,6 +89,55 @@ def test_conformer_l_decoder_logprobs_and_search_vs_oracle():
     assert float((scores.cpu() - scores_ref).abs().max()) <= 1e-3
 
 
+def test_recipe_lm_scorer_search_vs_oracle():
+    """a20 at recipe size: Conformer-L + TransformerLM (12 x 768, 12 heads, d_ffn 3072, GELU, post-norm,
+    LM temperature 1.15, lm_weight 0.6) + CTC 0.4 (conformer_large.yaml:166-223 ``test_search`` scorers,
+    beam 10): LM logits within 2e-3 on a fixed prefix, then bit-exact token ids vs the oracle."""
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder, TransformerLMScorer
+    from speechbrain_amd.inference.builders import oracle_state_dict
+    from speechbrain_amd.lobes.models.transformer.TransformerLM import TransformerLM
+
+    asr = _asr("L", beam_size=10, ctc_weight=0.4)
+    fc, mc = _oracle_cfg("L")
+    torch.manual_seed(11)
+    lm = TransformerLM(vocab=5000, d_model=768, nhead=12, num_encoder_layers=12, num_decoder_layers=0, d_ffn=3072,
+                       dropout=0.0, activation=torch.nn.GELU, normalize_before=False).cuda().eval()
+    with torch.no_grad():
+        asr.mods.seq_lin.w.weight.mul_(8.0)
+        asr.mods.ctc_lin.w.weight.mul_(8.0)
+        lm.output_proj.layers[2].w.weight.mul_(4.0)
+    lcfg = O.LMCfg(vocab=5000, d_model=768, nhead=12, num_encoder_layers=12, d_ffn=3072)
+    sd = oracle_state_dict(asr)
+    sd.update({"LM." + k: v.detach().cpu() for k, v in lm.state_dict().items()})
+    toks = torch.randint(1, 5000, (3, 14), generator=torch.Generator().manual_seed(5))
+    toks[1, 4] = 0  # a masked key
+    ref = O.lm_forward(toks, sd, lcfg, "LM.")
+    got = lm(toks.cuda()).cpu()
+    assert float((got - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()) / 10)
+    n = 3 * 16000
+    wav = 0.1 * torch.randn(2, n, generator=torch.Generator().manual_seed(4))
+    lens = torch.tensor([1.0, 0.7])
+    wav[1, int(0.7 * n):] = 0
+    enc_ref = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
+    T = enc_ref.shape[1]
+    scorer = ScorerBuilder(full_scorers=[TransformerLMScorer(language_model=lm, temperature=1.15),
+                                         CTCScorer(ctc_fc=asr.mods.ctc_lin, blank_index=0, eos_index=2)],
+                           weights={"transformerlm": 0.6, "ctc": 0.4})
+    bs = S2STransformerBeamSearcher(modules=[asr.mods.transformer, asr.mods.seq_lin], bos_index=1, eos_index=2,
+                                    min_decode_ratio=0.0, max_decode_ratio=10.5 / T, beam_size=10,
+                                    using_eos_threshold=False, length_normalization=True, temperature=1.15,
+                                    scorer=scorer)
+    hyps, _, scores, _ = bs(enc_ref.cuda(), lens.cuda())
+    hyps_ref, _, scores_ref, _ = O.beam_search(
+        enc_ref, lens, sd, mc, O.SearchCfg(beam=10, ctc_weight=0.4, max_decode_ratio=10.5 / T, temperature=1.15,
+                                           lm_weight=0.6, lm_temperature=1.15), lm_cfg=lcfg)
+    assert hyps == hyps_ref
+    assert float((scores.cpu() - scores_ref).abs().max()) <= 2e-3
+    hyps_nolm, _, _, _ = O.beam_search(enc_ref, lens, sd, mc, O.SearchCfg(beam=10, ctc_weight=0.4,
+                                                                           max_decode_ratio=10.5 / T, temperature=1.15))
+    assert hyps_nolm != hyps_ref  # the LM is not a no-op in this test
+
+
 def test_greedy_beam1_bit_exact_tokens_conformer_l():
     """North-star: bit-exact token ids at greedy / beam = 1 (peaked heads, see above)."""
     from speechbrain_amd.decoders import S2STransformerBeamSearcher, S2STransformerGreedySearcher

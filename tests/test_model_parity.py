@@ -181,3 +181,52 @@ def test_decoder_with_fused_layernorm_vs_oracle(backend):
     hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))
     assert hyps == hyps_ref
     assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
+
+
+def build_lm(g, dev):
+    from speechbrain_amd.lobes.models.transformer.TransformerLM import TransformerLM
+
+    lm_d, lm_heads, lm_ffn, lm_layers, pre = [int(v) for v in g["lm_cfg"]]
+    lm = TransformerLM(vocab=int(g["cfg"][5]), d_model=lm_d, nhead=lm_heads, num_encoder_layers=lm_layers,
+                       num_decoder_layers=0, d_ffn=lm_ffn, dropout=0.0, activation=torch.nn.GELU,
+                       normalize_before=bool(pre))
+    lm.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/LM.")}, strict=True)
+    return lm.to(dev).eval()
+
+
+@pytest.mark.parametrize("tag", ["tiny_lm_ctc", "tiny_lm_prenorm"])
+def test_golden_transformerlm_scorer(backend, tag):
+    """a20: TransformerLM.forward and the [transformerlm, ctc] / [transformerlm] searches against the
+    reference's outputs (post-norm and pre-norm LM layers, pad-0 key masking, LM temperature)."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import (CTCScorer, S2STransformerBeamSearcher, ScorerBuilder,
+                                          TransformerLMScorer)
+    from speechbrain_amd.inference.builders import build_modules
+
+    g = np.load(os.path.join(GOLD, f"model_{tag}.npz"))
+    d_model, nhead, d_ffn, n_enc, n_dec, vocab, beam, _ = [int(v) for v in g["cfg"]]
+    ctc_w, _, _, lm_w, lm_temp, temp = [float(v) for v in g["cfgf"]]
+    m = build_modules(dict(d_model=d_model, nhead=nhead, d_ffn=d_ffn, n_enc=n_enc, n_dec=n_dec, n_fft=512,
+                           win_length=32), vocab=vocab)
+    mods = torch.nn.ModuleDict({k: m[k] for k in ("CNN", "Transformer", "seq_lin", "ctc_lin")})
+    mods.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files
+                          if k.startswith("sd/") and not k.startswith("sd/LM.")}, strict=True)
+    mods = mods.to(dev).eval()
+    lm = build_lm(g, dev)
+    with torch.no_grad():
+        logits = lm(torch.from_numpy(g["lm_tokens"]).to(dev))
+        assert float((logits.cpu() - torch.from_numpy(g["lm_logits"])).abs().max()) <= 1e-4
+        full, weights = [TransformerLMScorer(language_model=lm, temperature=lm_temp)], {"transformerlm": lm_w}
+        if ctc_w > 0:
+            full.append(CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2))
+            weights["ctc"] = ctc_w
+        bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                        min_decode_ratio=0.0, max_decode_ratio=1.0, beam_size=beam,
+                                        using_eos_threshold=False, length_normalization=True, temperature=temp,
+                                        scorer=ScorerBuilder(full_scorers=full, weights=weights))
+        enc = torch.from_numpy(g["enc_out"]).to(dev)
+        wl = torch.from_numpy(g["wav_lens"]).to(dev)
+        hyps, lens, scores, _ = bs(enc, wl)
+        assert hyps == hyps_of(g["beam_hyps"])
+        assert float((scores.cpu() - torch.from_numpy(g["beam_scores"])).abs().max()) <= 1e-4
+        assert float((lens.cpu() - torch.from_numpy(g["beam_lens"])).abs().max()) <= 1e-6
