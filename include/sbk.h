@@ -149,6 +149,14 @@ int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bi
                              const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,
                              float scale, sbk_stream_t stream);
 
+/* ---- RoPEMHA core (nnet/attention.py:1167-1392): what sits between in_proj and out_proj.
+ *   out = softmax( rot(q) rot(k)^T scale , keys < key_len ) v,  scale = 1/sqrt(embed_dim) (:1272)
+ *   qkv as for sbk_relpos_attention_f32; cosines / sines [table_rows >= T, Dh] = the buffers of
+ *   PrecomputedRoPESinusoids (:955-1053): rot(x)[c] = x[c]*cos[t][c] + x[c^1]*sines[t][c]. */
+int sbk_rope_attention_f32(const float* qkv, const float* cosines, const float* sines, const int32_t* key_len,
+                           float* out, float* attn, int B, int T, int H, int Dh, int table_rows, float scale,
+                           sbk_stream_t stream);
+
 /* ---- a13: middle of ConvolutionModule (Conformer.py:315-330): GLU over channels of the
  * pointwise-conv output followed by the depthwise Conv1d (kernel ksize, zero padding
  * (ksize-1)/2, groups = d) + bias.   h [B,T,2d] -> y [B,T,d];  w [d,ksize]; bias [d]. */

@@ -82,7 +82,7 @@ def golden_fbank():
 
 
 # ---------------------------------------------------------------- model
-def build_reference(d_model, nhead, d_ffn, n_enc, n_dec, vocab, seed):
+def build_reference(d_model, nhead, d_ffn, n_enc, n_dec, vocab, seed, attention_type="RelPosMHAXL"):
     from speechbrain.lobes.models.convolution import ConvolutionFrontEnd
     from speechbrain.lobes.models.transformer.TransformerASR import TransformerASR
     from speechbrain.nnet.linear import Linear
@@ -95,7 +95,7 @@ def build_reference(d_model, nhead, d_ffn, n_enc, n_dec, vocab, seed):
     tr = TransformerASR(
         input_size=640, tgt_vocab=vocab, d_model=d_model, nhead=nhead, num_encoder_layers=n_enc,
         num_decoder_layers=n_dec, d_ffn=d_ffn, dropout=0.1, activation=torch.nn.GELU,
-        encoder_module="conformer", attention_type="RelPosMHAXL", normalize_before=True, causal=False,
+        encoder_module="conformer", attention_type=attention_type, normalize_before=True, causal=False,
     )
     ctc_lin = Linear(input_size=d_model, n_neurons=vocab)
     seq_lin = Linear(input_size=d_model, n_neurons=vocab)
@@ -204,6 +204,59 @@ def golden_model(tag, d_model, nhead, d_ffn, n_enc, n_dec, vocab, B, n_frames, b
     print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+# ---------------------------------------------------------------- RoPEMHA encoder (the current recipe's attention)
+def golden_rope(tag, d_model, nhead, seed, B=3, n_frames=61, vocab=40, beam=4, ctc_w=0.4):
+    from speechbrain.decoders import S2STransformerBeamSearcher
+    from speechbrain.decoders.scorer import CTCScorer, ScorerBuilder
+
+    print(f"[rope {tag}] d={d_model} H={nhead}")
+    mods = build_reference(d_model, nhead, 64, 2, 2, vocab, seed, attention_type="RoPEMHA")
+    with torch.no_grad():
+        mods["seq_lin"].w.weight.mul_(6.0)
+        mods["ctc_lin"].w.weight.mul_(6.0)
+    sd = {k: v.detach().clone() for k, v in mods.state_dict().items()}
+    cfg = O.ModelCfg(d_model=d_model, nhead=nhead, num_encoder_layers=2, num_decoder_layers=2, d_ffn=64, vocab=vocab,
+                     attention_type="RoPEMHA")
+    g = torch.Generator().manual_seed(4321 + seed)
+    feats = torch.randn(B, n_frames, 80, generator=g)
+    wav_lens = torch.linspace(0.6, 1.0, B) if B > 1 else torch.ones(1)
+    out = {"feats": feats.numpy(), "wav_lens": wav_lens.numpy()}
+    with torch.no_grad():
+        cnn_ref = mods["CNN"](feats)
+        enc_ref = mods["Transformer"].encode(cnn_ref, wav_lens)
+        enc_got, layers = O.encode(cnn_ref, wav_lens, sd, cfg, "Transformer.", return_layers=True)
+        check("TransformerASR.encode (RoPEMHA)", enc_ref, enc_got, 2e-5)
+        out["cnn_out"], out["enc_out"] = cnn_ref.numpy(), enc_ref.numpy()
+        # the attention module alone, with and without padding
+        mha = mods["Transformer"].encoder.layers[0].mha_layer
+        x = torch.randn(B, 50, d_model, generator=g)
+        pad = ~O.length_to_mask(torch.tensor([50, 33, 17][:B]), 50)
+        ref, _ = mha(x, x, x, key_padding_mask=pad)
+        got = O.rope_mha(x, sd, "Transformer.encoder.layers.0.mha_layer.", nhead, pad)
+        check("RoPEMHA.forward", ref, got, 1e-5)
+        out["mha_x"], out["mha_len"], out["mha_out"] = x.numpy(), np.array([50, 33, 17][:B]), ref.numpy()
+        scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)],
+                               weights={"ctc": ctc_w})
+        bs = S2STransformerBeamSearcher(
+            modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=0.0,
+            max_decode_ratio=1.0, beam_size=beam, using_eos_threshold=False, length_normalization=True, scorer=scorer)
+        hyps_r, lens_r, scores_r, _ = bs(enc_ref.clone(), wav_lens)
+        hyps_o, lens_o, scores_o, _ = O.beam_search(enc_ref, wav_lens, sd, cfg, O.SearchCfg(beam=beam, ctc_weight=ctc_w))
+        assert hyps_r == hyps_o
+        check("beam best scores", scores_r, scores_o, 1e-4)
+        out["beam_hyps"] = np.array([h + [-1] * (64 - len(h)) for h in hyps_r], dtype=np.int64)
+        out["beam_scores"] = scores_r.numpy()
+    out["cfg"] = np.array([d_model, nhead, 64, 2, 2, vocab, beam, 0], dtype=np.int64)
+    out["cfgf"] = np.array([ctc_w, 1.0, 0.0], dtype=np.float64)
+    for k, v in np_sd(sd).items():
+        if k.endswith(".pe"):
+            continue  # sinusoid buffers: regenerated by the constructors (checked in tests/test_host_logic.py)
+        out["sd/" + k] = v
+    path = os.path.join(OUT, f"model_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 # ---------------------------------------------------------------- TransformerLM scorer (a20)
 def golden_lm(tag, normalize_before, ctc_w, lm_w, lm_temp, seed, beam=4, B=3, n_frames=61, vocab=40,
               lm_d=32, lm_heads=4, lm_ffn=64, lm_layers=2):
@@ -300,6 +353,10 @@ def golden_init_fingerprint():
 
 
 if __name__ == "__main__":
+    if "--rope-only" in sys.argv:
+        golden_rope("rope", d_model=32, nhead=4, seed=5)
+        golden_rope("rope_dh36", d_model=72, nhead=2, seed=6, B=2)
+        sys.exit(0)
     if "--lm-only" in sys.argv:
         golden_lm("tiny_lm_ctc", normalize_before=False, ctc_w=0.4, lm_w=0.6, lm_temp=1.15, seed=3)
         golden_lm("tiny_lm_prenorm", normalize_before=True, ctc_w=0.0, lm_w=0.5, lm_temp=1.0, seed=4, beam=3, B=2)
@@ -316,5 +373,7 @@ if __name__ == "__main__":
                  beam=2, ctc_w=0.4, sharpen=4.0, seed=2)
     golden_lm("tiny_lm_ctc", normalize_before=False, ctc_w=0.4, lm_w=0.6, lm_temp=1.15, seed=3)
     golden_lm("tiny_lm_prenorm", normalize_before=True, ctc_w=0.0, lm_w=0.5, lm_temp=1.0, seed=4, beam=3, B=2)
+    golden_rope("rope", d_model=32, nhead=4, seed=5)
+    golden_rope("rope_dh36", d_model=72, nhead=2, seed=6, B=2)
     golden_init_fingerprint()
     print("OK")

@@ -74,6 +74,7 @@ class ModelCfg:
     vocab: int = 5000
     kernel_size: int = 31
     input_size: int = 640
+    attention_type: str = "RelPosMHAXL"  # or "RoPEMHA" (conformer_large.yaml:158 of the current recipe)
 
 
 @dataclass
@@ -265,6 +266,38 @@ def relpos_mha(x: Tensor, pos: Tensor, sd: SD, pfx: str, H: int, key_pad: Option
     return F.linear(o, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"])
 
 
+def rope_tables(T: int, Dh: int):
+    """PrecomputedRoPESinusoids (nnet/attention.py:955-1053): cosines, signed sines [T,Dh]."""
+    angles = torch.exp(torch.arange(0, Dh, 2, dtype=torch.float32) * -(math.log(10000.0) / Dh))
+    ta = torch.outer(torch.arange(0, T, dtype=torch.float32), angles)
+    cos = torch.stack([torch.cos(ta)] * 2, dim=-1).reshape(T, Dh)
+    sin = torch.stack([torch.sin(ta)] * 2, dim=-1).reshape(T, Dh)
+    sin = ((-1) ** torch.arange(Dh, dtype=torch.float32)) * -sin
+    return cos, sin
+
+
+def rope_rotate(x: Tensor) -> Tensor:
+    """_rope_rotate (attention.py:1167-1188): x [B,T,H,Dh], pairs (2i, 2i+1) rotated by t * theta_i."""
+    _, T, _, Dh = x.shape
+    cos, sin = rope_tables(T, Dh)
+    swap = torch.arange(Dh).view(-1, 2).flip(-1).reshape(-1)
+    return x * cos.unsqueeze(1) + x[..., swap] * sin.unsqueeze(1)
+
+
+def rope_mha(x: Tensor, sd: SD, pfx: str, H: int, key_pad: Optional[Tensor]) -> Tensor:
+    """RoPEMHA.forward, self-attention branch (attention.py:1284-1392): bias-free stacked in_proj viewed
+    per head as (q|k|v), rotary q/k, scale 1/sqrt(embed_dim) (:1272), key padding mask, out_proj."""
+    B, T, E = x.shape
+    Dh = E // H
+    q, k, v = F.linear(x, sd[pfx + "in_proj_weight"]).view(B, T, H, 3 * Dh).chunk(3, dim=-1)
+    q, k = rope_rotate(q), rope_rotate(k)
+    sc = torch.einsum("bihd,bjhd->bhij", q, k) * (1.0 / math.sqrt(E))
+    if key_pad is not None:
+        sc = sc.masked_fill(key_pad.view(B, 1, 1, T), float("-inf"))
+    o = torch.einsum("bhij,bjhd->bihd", F.softmax(sc, dim=-1), v).reshape(B, T, E)
+    return F.linear(o, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"])
+
+
 def _ffn(x: Tensor, sd: SD, pfx: str, act) -> Tensor:
     """PositionalwiseFeedForward (attention.py:915-947)."""
     h = act(F.linear(x, sd[pfx + "ffn.0.weight"], sd[pfx + "ffn.0.bias"]))
@@ -291,10 +324,14 @@ def conv_module(x: Tensor, sd: SD, pfx: str, pad_mask: Optional[Tensor], ksize: 
 
 
 def conformer_layer(x, pos, sd, pfx, H, key_pad, ksize):
-    """ConformerEncoderLayer.forward (Conformer.py:451-499)."""
+    """ConformerEncoderLayer.forward (Conformer.py:451-499); pos = None selects RoPEMHA (:414-419)."""
     x = x + 0.5 * _ffn(_ln(x, sd, pfx + "ffn_module1.0.", 1e-5), sd, pfx + "ffn_module1.1.", F.silu)
     skip = x
-    x = relpos_mha(_ln(x, sd, pfx + "norm1.norm.", 1e-5), pos, sd, pfx + "mha_layer.", H, key_pad) + skip
+    h = _ln(x, sd, pfx + "norm1.norm.", 1e-5)
+    if pos is None:
+        x = rope_mha(h, sd, pfx + "mha_layer.", H, key_pad) + skip
+    else:
+        x = relpos_mha(h, pos, sd, pfx + "mha_layer.", H, key_pad) + skip
     x = x + conv_module(x, sd, pfx + "convolution_module.", key_pad, ksize)
     y = x + 0.5 * _ffn(_ln(x, sd, pfx + "ffn_module2.0.", 1e-5), sd, pfx + "ffn_module2.1.", F.silu)
     return _ln(y, sd, pfx + "norm2.norm.", 1e-5)
@@ -320,7 +357,7 @@ def encode(src: Tensor, wav_lens: Optional[Tensor], sd: SD, cfg: ModelCfg, pfx: 
     if wav_lens is not None:
         key_pad = ~length_to_mask(torch.round(wav_lens * T), T)
     x = F.linear(src, sd[pfx + "custom_src_module.layers.0.w.weight"], sd[pfx + "custom_src_module.layers.0.w.bias"])
-    pos = relpos_table(T, cfg.d_model)
+    pos = None if cfg.attention_type == "RoPEMHA" else relpos_table(T, cfg.d_model)  # TransformerASR.py:519-528
     layers = []
     for l in range(cfg.num_encoder_layers):
         x = conformer_layer(x, pos, sd, f"{pfx}encoder.layers.{l}.", cfg.nhead, key_pad, cfg.kernel_size)

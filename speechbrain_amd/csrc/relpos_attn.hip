@@ -59,7 +59,12 @@ __device__ __forceinline__ void load_run(float (&dst)[N], const float* __restric
   }
 }
 
-template <int DH>
+// ROPE = true is RoPEMHA (nnet/attention.py:1167-1392): no position-score term; q and k are rotated
+// pair-wise by the angle of their own frame on the way into the MFMA operands (a.pos = cosines
+// [>=T][DH], a.bias_u = signed sines [>=T][DH] of PrecomputedRoPESinusoids, attention.py:955-1053;
+// x'[c] = x[c]*cos[t][c] + x[c^1]*sin[t][c]).  The rotation pairs (2i, 2i+1) never straddle the two
+// halves of the head dimension, so the half-split operand runs rotate in registers.
+template <int DH, bool ROPE>
 __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
   constexpr int DH2 = DH / 2;
   constexpr int QP = DH + 1;             // LDS pitch of the Q tiles (odd)
@@ -82,8 +87,13 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
     const int i = idx / DH, c = idx % DH;
     const int row = min(i0 + i, T - 1);
     const float q = qkv_b[(size_t)row * row3 + c];
-    Qu[i * QP + c] = (q + a.bias_u[h * DH + c]) * a.scale;
-    Qv[i * QP + c] = (q + a.bias_v[h * DH + c]) * a.scale;
+    if constexpr (ROPE) {
+      const float qs = qkv_b[(size_t)row * row3 + (c ^ 1)];
+      Qu[i * QP + c] = (q * a.pos[(size_t)row * DH + c] + qs * a.bias_u[(size_t)row * DH + c]) * a.scale;
+    } else {
+      Qu[i * QP + c] = (q + a.bias_u[h * DH + c]) * a.scale;
+      Qv[i * QP + c] = (q + a.bias_v[h * DH + c]) * a.scale;
+    }
   }
   __syncthreads();
 
@@ -98,9 +108,20 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
     {
       const int krow = min(j0 + jl, T - 1);
       load_run<DH2>(kreg, qkv_b + (size_t)krow * row3 + DH + half * DH2);
-      const int prow0 = min(max(rbase + jl, 0), 2 * T - 2), prow1 = min(max(rbase + 32 + jl, 0), 2 * T - 2);
-      load_run<DH2>(p0reg, a.pos + (size_t)prow0 * d + h * DH + half * DH2);
-      load_run<DH2>(p1reg, a.pos + (size_t)prow1 * d + h * DH + half * DH2);
+      if constexpr (ROPE) {  // p0reg / p1reg carry this frame's cosines / sines
+        load_run<DH2>(p0reg, a.pos + (size_t)krow * DH + half * DH2);
+        load_run<DH2>(p1reg, a.bias_u + (size_t)krow * DH + half * DH2);
+#pragma unroll
+        for (int s2 = 0; s2 < DH2; s2 += 2) {
+          const float k0 = kreg[s2], k1 = kreg[s2 + 1];
+          kreg[s2] = k0 * p0reg[s2] + k1 * p1reg[s2];
+          kreg[s2 + 1] = k1 * p0reg[s2 + 1] + k0 * p1reg[s2 + 1];
+        }
+      } else {
+        const int prow0 = min(max(rbase + jl, 0), 2 * T - 2), prow1 = min(max(rbase + 32 + jl, 0), 2 * T - 2);
+        load_run<DH2>(p0reg, a.pos + (size_t)prow0 * d + h * DH + half * DH2);
+        load_run<DH2>(p1reg, a.pos + (size_t)prow1 * d + h * DH + half * DH2);
+      }
     }
     f32x16 acc;
     {  // AC = (Q+u) K^T
@@ -115,6 +136,7 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
       }
     }
     sbk::wave_sync();
+    if constexpr (!ROPE) {
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {  // BD: G = (Q+v) P[rbase + 32*pt ...]^T, added along the skew
       const int rl = pt * 32 + jl;
@@ -131,6 +153,7 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
       }
     }
     sbk::wave_sync();
+    }
   }
   __syncthreads();
 
@@ -202,18 +225,18 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
   }
 }
 
-template <int DH>
+template <int DH, bool ROPE>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
   const size_t lds = ((size_t)2 * 32 * (DH + 1) + 3 * 32 * 33 + (size_t)32 * a.SP) * sizeof(float);
   if (lds > 160 * 1024) return sbk::fail(SBK_EINVAL, "relpos_attention: T=%d needs %zu B of LDS (max 160 KiB)", a.T, lds);
   if (lds > 64 * 1024) {
-    hipError_t e = SBK_ALLOW_DYN_LDS((relpos_attn_kernel<DH>), lds);
+    hipError_t e = SBK_ALLOW_DYN_LDS((relpos_attn_kernel<DH, ROPE>), lds);
     if (e != hipSuccess) return sbk::fail((int)e, "relpos_attention: cannot raise the LDS window to %zu B", lds);
   }
-  sbk::ProfScope prof("relpos_attention", 6.0 * a.B * a.H * (double)a.T * a.T * DH,
+  sbk::ProfScope prof(ROPE ? "rope_attention" : "relpos_attention", (ROPE ? 4.0 : 6.0) * a.B * a.H * (double)a.T * a.T * DH,
                       4.0 * a.B * a.T * (4.0 * a.H * DH) + 4.0 * (2.0 * a.T - 1) * a.H * DH, st);
-  SBK_LAUNCH((relpos_attn_kernel<DH>), dim3((a.T + 31) / 32, a.H, a.B), dim3(256), lds, st, a);
-  return sbk::launch_status("sbk_relpos_attention_f32");
+  SBK_LAUNCH((relpos_attn_kernel<DH, ROPE>), dim3((a.T + 31) / 32, a.H, a.B), dim3(256), lds, st, a);
+  return sbk::launch_status(ROPE ? "sbk_rope_attention_f32" : "sbk_relpos_attention_f32");
 }
 
 }  // namespace
@@ -226,15 +249,41 @@ int relpos_attention(const float* qkv, const float* pos, const float* bias_u, co
   const int SP = ((T + 31) / 32) * 32 + 1;  // odd pitch: the 32 rows of a P.V operand read hit 32 banks
   AttnArgs a{qkv, pos, bias_u, bias_v, key_len, out, attn, B, T, H, SP, scale};
   switch (Dh) {
-    case 64: return launch_attn<64>(a, st);
-    case 36: return launch_attn<36>(a, st);
-    case 32: return launch_attn<32>(a, st);
-    case 16: return launch_attn<16>(a, st);
-    case 8: return launch_attn<8>(a, st);
+    case 64: return launch_attn<64, false>(a, st);
+    case 36: return launch_attn<36, false>(a, st);
+    case 32: return launch_attn<32, false>(a, st);
+    case 16: return launch_attn<16, false>(a, st);
+    case 8: return launch_attn<8, false>(a, st);
     default: return fail(SBK_EINVAL, "relpos_attention: head_dim %d not instantiated (8,16,32,36,64)", Dh);
   }
 }
+
+int rope_attention(const float* qkv, const float* cosines, const float* sines, const int32_t* key_len, float* out,
+                   float* attn, int B, int T, int H, int Dh, float scale, hipStream_t st) {
+  if (B == 0 || T == 0) return 0;
+  const int SP = ((T + 31) / 32) * 32 + 1;
+  AttnArgs a{qkv, cosines, sines, nullptr, key_len, out, attn, B, T, H, SP, scale};
+  switch (Dh) {
+    case 64: return launch_attn<64, true>(a, st);
+    case 36: return launch_attn<36, true>(a, st);
+    case 32: return launch_attn<32, true>(a, st);
+    case 16: return launch_attn<16, true>(a, st);
+    case 8: return launch_attn<8, true>(a, st);
+    default: return fail(SBK_EINVAL, "rope_attention: head_dim %d not instantiated (8,16,32,36,64)", Dh);
+  }
+}
 }  // namespace sbk
+
+extern "C" int sbk_rope_attention_f32(const float* qkv, const float* cosines, const float* sines,
+                                      const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,
+                                      int table_rows, float scale, sbk_stream_t stream) {
+  SBK_REQUIRE(qkv && cosines && sines && out, "rope_attention: null operand");
+  SBK_REQUIRE(B >= 0 && T >= 0 && H > 0 && Dh > 0 && Dh % 2 == 0, "rope_attention: bad shape");
+  SBK_REQUIRE(table_rows >= T, "rope_attention: the sinusoid tables hold %d rows, T = %d", table_rows, T);
+  SBK_REQUIRE(sbk::aligned16(qkv) && sbk::aligned16(cosines) && sbk::aligned16(sines),
+              "rope_attention: operands must be 16-byte aligned");
+  return sbk::rope_attention(qkv, cosines, sines, key_len, out, attn, B, T, H, Dh, scale, sbk::as_stream(stream));
+}
 
 extern "C" int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                                         const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,

@@ -35,7 +35,8 @@ def build_modules(size="L", vocab=5000, seed=0, **override):
     transformer = TransformerASR(input_size=640, tgt_vocab=vocab, d_model=cfg["d_model"], nhead=cfg["nhead"],
                                  num_encoder_layers=cfg["n_enc"], num_decoder_layers=cfg["n_dec"], d_ffn=cfg["d_ffn"],
                                  dropout=0.1, activation=torch.nn.GELU, encoder_module="conformer",
-                                 attention_type="RelPosMHAXL", normalize_before=True, causal=False)
+                                 attention_type=cfg.get("attention_type", "RelPosMHAXL"), normalize_before=True,
+                                 causal=False)
     ctc_lin = Linear(input_size=cfg["d_model"], n_neurons=vocab)
     seq_lin = Linear(input_size=cfg["d_model"], n_neurons=vocab)
     normalize = InputNormalization(norm_type="global", update_until_epoch=4)

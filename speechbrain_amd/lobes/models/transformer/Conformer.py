@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from speechbrain_amd import native
 from speechbrain_amd.nnet.activations import Swish
-from speechbrain_amd.nnet.attention import PositionalwiseFeedForward, RelPosMHAXL, _act_code
+from speechbrain_amd.nnet.attention import PositionalwiseFeedForward, RelPosMHAXL, RoPEMHA, _act_code
 from speechbrain_amd.nnet.normalization import LayerNorm
 
 
@@ -57,9 +57,13 @@ class ConformerEncoderLayer(nn.Module):
     def __init__(self, d_model, d_ffn, nhead, kernel_size=31, kdim=None, vdim=None, activation=Swish, bias=True,
                  dropout=0.0, causal=False, attention_type="RelPosMHAXL"):
         super().__init__()
-        if attention_type != "RelPosMHAXL":
-            raise NotImplementedError(f"attention_type={attention_type}: this round implements RelPosMHAXL")
-        self.mha_layer = RelPosMHAXL(num_heads=nhead, embed_dim=d_model, dropout=dropout, mask_pos_future=causal)
+        if attention_type == "RelPosMHAXL":
+            self.mha_layer = RelPosMHAXL(num_heads=nhead, embed_dim=d_model, dropout=dropout, mask_pos_future=causal)
+        elif attention_type == "RoPEMHA":
+            self.mha_layer = RoPEMHA(num_heads=nhead, embed_dim=d_model, dropout=dropout)
+        else:
+            raise NotImplementedError(f"attention_type={attention_type}: RelPosMHAXL and RoPEMHA are implemented")
+        self.attention_type = attention_type
         self.convolution_module = ConvolutionModule(d_model, kernel_size, bias, activation, dropout, causal=causal)
         self.ffn_module1 = nn.Sequential(
             nn.LayerNorm(d_model),
@@ -87,8 +91,11 @@ class ConformerEncoderLayer(nn.Module):
             key_len = (~src_key_padding_mask).sum(-1, dtype=torch.int32)
         x = self._ffn(self.ffn_module1, x.contiguous())
         h = native.layernorm(x, self.norm1.norm.weight, self.norm1.norm.bias, self.norm1.eps)
-        x, attn = self.mha_layer.core(h, pos_embs.reshape(-1, x.shape[-1]), key_len, residual=x,
-                                      want_attn=self.collect_attention)
+        if self.attention_type == "RoPEMHA":
+            x, attn = self.mha_layer.core(h, key_len, residual=x, want_attn=self.collect_attention)
+        else:
+            x, attn = self.mha_layer.core(h, pos_embs.reshape(-1, x.shape[-1]), key_len, residual=x,
+                                          want_attn=self.collect_attention)
         x = self.convolution_module(x, residual=x, key_len=key_len)
         y = self._ffn(self.ffn_module2, x)
         return native.layernorm(y, self.norm2.norm.weight, self.norm2.norm.bias, self.norm2.eps), attn

@@ -138,14 +138,16 @@ class TransformerInterface(nn.Module):
         assert positional_encoding in ["fixed_abs_sine", None]
         assert num_encoder_layers + num_decoder_layers > 0
         lm_like = encoder_module == "transformer" and attention_type == "regularMHA"
-        if not lm_like and (encoder_module != "conformer" or attention_type != "RelPosMHAXL" or causal):
+        if not lm_like and (encoder_module != "conformer" or attention_type not in ("RelPosMHAXL", "RoPEMHA") or causal):
             raise NotImplementedError(
-                "implemented: encoder_module='conformer' with attention_type='RelPosMHAXL', causal=False (ASR) and "
-                "encoder_module='transformer' with attention_type='regularMHA' (TransformerLM)")
+                "implemented: encoder_module='conformer' with attention_type='RelPosMHAXL' | 'RoPEMHA', causal=False "
+                "(ASR) and encoder_module='transformer' with attention_type='regularMHA' (TransformerLM)")
         if positional_encoding == "fixed_abs_sine":
             self.positional_encoding = PositionalEncoding(d_model, max_length)
         if attention_type == "RelPosMHAXL":
             self.positional_encoding = RelPosEncXL(d_model)  # overrides, as in the reference (:165-170)
+            self.positional_encoding_decoder = PositionalEncoding(d_model, max_length)
+        if attention_type == "RoPEMHA":  # Transformer.py:171-174
             self.positional_encoding_decoder = PositionalEncoding(d_model, max_length)
         if num_encoder_layers > 0 and lm_like:
             if custom_src_module is not None:

@@ -80,7 +80,8 @@ class TransformerASR(TransformerInterface):
         src_key_padding_mask, _, src_mask, _ = make_transformer_src_tgt_masks(src, None, wav_len, pad_idx=pad_idx,
                                                                                causal=self.causal)
         src = self.custom_src_module(src)
-        pos_embs_source = self.positional_encoding(src)
+        # RoPEMHA rotates q/k inside the attention kernel; RelPosMHAXL takes the sinusoid table (:519-528)
+        pos_embs_source = None if self.attention_type == "RoPEMHA" else self.positional_encoding(src)
         outputs = self.encoder(src=src, src_mask=src_mask, src_key_padding_mask=src_key_padding_mask,
                                pos_embs=pos_embs_source)
         if self.output_hidden_states:

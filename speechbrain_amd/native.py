@@ -83,6 +83,7 @@ def _declare(lib):
         "sbk_gemm_nt_splitk_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, ctypes.c_size_t, p], c_int),
         "sbk_conv_block_f32": ([p, p, p, p, p, p, i, i, i, i, i, f, f, p], c_int),
         "sbk_relpos_attention_f32": ([p, p, p, p, p, p, p, i, i, i, i, f, p], c_int),
+        "sbk_rope_attention_f32": ([p, p, p, p, p, p, i, i, i, i, i, f, p], c_int),
         "sbk_glu_dwconv_f32": ([p, p, p, p, i, i, i, i, p], c_int),
         "sbk_layernorm_f32": ([p, p, p, p, i, i, f, i, p], c_int),
         "sbk_log_softmax_f32": ([p, p, i, i, f, f, p], c_int),
@@ -327,6 +328,20 @@ def relpos_attention(qkv, pos, bias_u, bias_v, key_len, H, scale, want_attn=Fals
     attn = torch.empty(B, H, T, T, dtype=torch.float32, device=qkv.device) if want_attn else None
     _chk(lib.sbk_relpos_attention_f32(_p(qkv), _p(pos), _p(bias_u), _p(bias_v), _p(key_len), _p(out), _p(attn), B, T,
                                       H, d // H, float(scale), _stream(qkv)), "sbk_relpos_attention_f32")
+    return out, attn
+
+
+def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False):
+    """qkv [B,T,3*d] (per-head interleaved), cosines / sines [rows >= T, Dh] -> context [B,T,d]."""
+    lib = load()
+    _dev_ok(qkv, cosines, sines, key_len)
+    _f32(qkv)
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    out = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
+    attn = torch.empty(B, H, T, T, dtype=torch.float32, device=qkv.device) if want_attn else None
+    _chk(lib.sbk_rope_attention_f32(_p(qkv), _p(cosines), _p(sines), _p(key_len), _p(out), _p(attn), B, T, H, d // H,
+                                    cosines.shape[0], float(scale), _stream(qkv)), "sbk_rope_attention_f32")
     return out, attn
 
 

@@ -51,6 +51,26 @@ def test_encoder_vs_oracle(size, B, sec):
     assert float((enc - ref).abs().max()) <= 2e-4
 
 
+def test_rope_conformer_l_encoder_vs_oracle():
+    """Conformer-L with attention_type=RoPEMHA (the in-tree conformer_large.yaml:158): encoder output
+    within 2e-4 of the oracle, with padding."""
+    import dataclasses
+
+    from speechbrain_amd.inference.builders import oracle_state_dict
+
+    asr = _asr("L", attention_type="RoPEMHA")
+    n = 6 * 16000
+    wav = 0.1 * torch.randn(2, n, generator=torch.Generator().manual_seed(1234))
+    lens = torch.tensor([1.0, 0.55])
+    wav[1, int(0.55 * n):] = 0
+    fc, mc = _oracle_cfg("L")
+    mc = dataclasses.replace(mc, attention_type="RoPEMHA")
+    sd = oracle_state_dict(asr)
+    enc = asr.encode_batch(wav, lens).cpu()
+    ref = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
+    assert float((enc - ref).abs().max()) <= 2e-4
+
+
 def test_conformer_l_decoder_logprobs_and_search_vs_oracle():
     """Conformer-L, beam 10 + CTC 0.4: first-step log-probs within 1e-4, then (with peaked output
     heads so that fp32 noise cannot flip a near-tie, SURVEY 7 hard-part 1) bit-exact token ids and

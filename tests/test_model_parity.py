@@ -230,3 +230,40 @@ def test_golden_transformerlm_scorer(backend, tag):
         assert hyps == hyps_of(g["beam_hyps"])
         assert float((scores.cpu() - torch.from_numpy(g["beam_scores"])).abs().max()) <= 1e-4
         assert float((lens.cpu() - torch.from_numpy(g["beam_lens"])).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("tag", ["rope", "rope_dh36"])
+def test_golden_rope_conformer(backend, tag):
+    """RoPEMHA encoder (attention_type of the current conformer_large.yaml) against the reference's
+    outputs: the attention module with padding, the whole encoder, then beam search + CTC."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
+    from speechbrain_amd.inference.builders import build_modules
+
+    g = np.load(os.path.join(GOLD, f"model_{tag}.npz"))
+    d_model, nhead, d_ffn, n_enc, n_dec, vocab, beam, _ = [int(v) for v in g["cfg"]]
+    m = build_modules(dict(d_model=d_model, nhead=nhead, d_ffn=d_ffn, n_enc=n_enc, n_dec=n_dec, n_fft=512,
+                           win_length=32, attention_type="RoPEMHA"), vocab=vocab)
+    mods = torch.nn.ModuleDict({k: m[k] for k in ("CNN", "Transformer", "seq_lin", "ctc_lin")})
+    res = mods.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}, strict=False)
+    assert not res.unexpected_keys and all(k.endswith(".pe") for k in res.missing_keys)
+    mods = mods.to(dev).eval()
+    wl = torch.from_numpy(g["wav_lens"]).to(dev)
+    with torch.no_grad():
+        mha = mods["Transformer"].encoder.layers[0].mha_layer
+        x = torch.from_numpy(g["mha_x"]).to(dev)
+        T = x.shape[1]
+        pad = (torch.arange(T)[None, :] >= torch.from_numpy(g["mha_len"])[:, None]).to(dev)
+        out, none = mha(x, x, x, key_padding_mask=pad)
+        assert none is None
+        assert float((out.cpu() - torch.from_numpy(g["mha_out"])).abs().max()) <= 2e-5
+        enc = mods["Transformer"].encode(torch.from_numpy(g["cnn_out"]).to(dev), wl)
+        assert float((enc.cpu() - torch.from_numpy(g["enc_out"])).abs().max()) <= 5e-5
+        scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)],
+                               weights={"ctc": float(g["cfgf"][0])})
+        bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                        min_decode_ratio=0.0, max_decode_ratio=1.0, beam_size=beam,
+                                        using_eos_threshold=False, length_normalization=True, scorer=scorer)
+        hyps, _, scores, _ = bs(torch.from_numpy(g["enc_out"]).to(dev), wl)
+        assert hyps == hyps_of(g["beam_hyps"])
+        assert float((scores.cpu() - torch.from_numpy(g["beam_scores"])).abs().max()) <= 1e-4
