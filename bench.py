@@ -193,6 +193,10 @@ def main():
     ap.add_argument("--latency-runs", type=int, default=5)
     ap.add_argument("--streams", type=int, default=3, help="independent batches in flight per GPU")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--attention", default="RelPosMHAXL", choices=["RelPosMHAXL", "RoPEMHA"],
+                    help="encoder attention (RelPosMHAXL = BASELINE.json's config; RoPEMHA = the in-tree recipe)")
+    ap.add_argument("--lm", action="store_true",
+                    help="add the recipe's TransformerLM scorer (12 x 768, weight 0.6, T=1.15): test_search at beam 10")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -222,7 +226,23 @@ def main():
     from speechbrain_amd.inference.builders import build_asr
 
     native.load()
-    asr = build_asr("L", vocab=5000, seed=0, beam_size=10, ctc_weight=0.4, device=str(dev))
+    asr = build_asr("L", vocab=5000, seed=0, beam_size=10, ctc_weight=0.4, device=str(dev),
+                    attention_type=args.attention)
+    if args.lm:  # conformer_large.yaml:166-223: full_scorers=[transformerlm, ctc], lm_weight 0.6, temperature 1.15
+        from speechbrain_amd.decoders import (CTCScorer, S2STransformerBeamSearcher, ScorerBuilder,
+                                              TransformerLMScorer)
+        from speechbrain_amd.lobes.models.transformer.TransformerLM import TransformerLM
+
+        torch.manual_seed(1)
+        lm = TransformerLM(vocab=5000, d_model=768, nhead=12, num_encoder_layers=12, num_decoder_layers=0, d_ffn=3072,
+                           dropout=0.0, activation=torch.nn.GELU, normalize_before=False).to(dev).eval()
+        scorer = ScorerBuilder(full_scorers=[TransformerLMScorer(language_model=lm, temperature=1.15),
+                                             CTCScorer(ctc_fc=asr.mods.ctc_lin, blank_index=0, eos_index=2)],
+                               weights={"transformerlm": 0.6, "ctc": 0.4})
+        asr.mods.decoder = S2STransformerBeamSearcher(
+            modules=[asr.mods.transformer, asr.mods.seq_lin], bos_index=1, eos_index=2, min_decode_ratio=0.0,
+            max_decode_ratio=1.0, beam_size=10, using_eos_threshold=False, length_normalization=True,
+            temperature=1.15, scorer=scorer)
     asr.mods.decoder.check_every = 0  # fixed-length decoding: no stop-rule polling, fully asynchronous
 
     # every rank owns K (+W) batches: weak scaling, per-GPU work fixed as N grows
@@ -275,8 +295,10 @@ def main():
             "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Conformer-L enc-dec (RelPosMHAXL, 12+6 layers, d=512, V=5000) + "
-                                   "S2STransformerBeamSearcher beam=10 + CTC 0.4; 16 kHz 0.1*randn audio, durations "
+            "config": {"workload": f"Conformer-L enc-dec ({args.attention}, 12+6 layers, d=512, V=5000) + "
+                                   "S2STransformerBeamSearcher beam=10 + CTC 0.4"
+                                   + (" + TransformerLM 12x768 scorer 0.6" if args.lm else "")
+                                   + "; 16 kHz 0.1*randn audio, durations "
                                    "U(5,30) s, duration-sorted batches; decode steps = round(4 tok/s * seconds)",
                        "batch": args.batch, "utterances_per_gpu": args.steps * args.batch,
                        "audio_seconds_total": round(total_audio, 1), "weights": "random init, torch.manual_seed(0)",
