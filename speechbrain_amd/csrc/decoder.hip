@@ -301,6 +301,142 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
   }
 }
 
+// Same work, laid out for HBM streaming (head_dim 64 / 32 / 16): the K/V rows of a (utterance, head)
+// are 4*DH-byte runs 8*d bytes apart, re-read from HBM every step (B*T'*2d*4 B per layer: 115 MB at
+// B=64 -- far beyond L2).  Here LPR = DH/4 lanes read one row as 16-byte pieces, so a wave instruction
+// covers 64/LPR whole rows, and a wave requests ALL K and V rows of its 32 frames before any arithmetic
+// (16 KB in flight per wave, the workgroup's whole 64 KB chunk at once).  Scores are 4-wide partial
+// dots reduced over the LPR lanes by shuffles; the context pass keeps a float4 per beam and folds the
+// row groups by shuffles, then the 4 waves through LDS.
+template <int DH>
+__global__ void __launch_bounds__(256) cross_attn_rows_kernel(CrossAttnArgs a) {
+  constexpr int LPR = DH / 4, RPI = 64 / LPR, U = 32 / RPI;
+  static_assert(kFC == 128 && LPR * 4 == DH && RPI * LPR == 64 && U * RPI == 32, "cross_attn_rows: layout");
+  __shared__ float S[kQT][kFC + 1];
+  __shared__ float red[4][kQT][DH];
+  __shared__ float mx[kQT], sm[kQT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x, h = blockIdx.y;
+  const int qtiles = (a.beam + kQT - 1) / kQT;
+  const int b = blockIdx.z / qtiles, q0 = (blockIdx.z % qtiles) * kQT;
+  const int nq = min(kQT, a.beam - q0);
+  const int T = a.T, d = a.d;
+  const int klen = min(max(a.enc_len[b], 1), T);
+  const int per = ((klen + a.NS - 1) / a.NS + 3) & ~3;
+  const int t0 = split * per, t1 = min(klen, t0 + per);
+  const int nf = max(0, t1 - t0);
+  const int rg = lane / LPR, cq = lane % LPR;
+  const float* kvb = a.kv + (size_t)b * T * 2 * d + h * DH + cq * 4;
+
+  float4 k4[U], v4[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int f = wave * 32 + u * RPI + rg;
+    const float* row = kvb + (size_t)(t0 + min(f, max(nf - 1, 0))) * 2 * d;
+    const bool ok = f < nf;
+    k4[u] = ok ? *reinterpret_cast<const float4*>(row) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v4[u] = ok ? *reinterpret_cast<const float4*>(row + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  {
+    float4 q4[kQT];
+#pragma unroll
+    for (int j = 0; j < kQT; ++j) {
+      q4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < nq) {
+        q4[j] = *reinterpret_cast<const float4*>(a.q + ((size_t)b * a.beam + q0 + j) * d + h * DH + cq * 4);
+        q4[j].x *= a.scale; q4[j].y *= a.scale; q4[j].z *= a.scale; q4[j].w *= a.scale;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = wave * 32 + u * RPI + rg;
+#pragma unroll
+      for (int j = 0; j < kQT; ++j) {
+        if (j < nq) {
+          float p = fmaf(q4[j].x, k4[u].x, fmaf(q4[j].y, k4[u].y, fmaf(q4[j].z, k4[u].z, q4[j].w * k4[u].w)));
+#pragma unroll
+          for (int m = 1; m < LPR; m <<= 1) p += sbk::shfl_xor(p, m);
+          if (cq == 0 && f < nf) S[j][f] = p;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = wave; j < nq; j += 4) {  // one wave per query row
+    float m = -INFINITY;
+    for (int f = lane; f < nf; f += 64) m = fmaxf(m, S[j][f]);
+    m = sbk::wave_max(m);
+    float sum = 0.0f;
+    for (int f = lane; f < nf; f += 64) {
+      const float e = expf(S[j][f] - m);
+      S[j][f] = e;
+      sum += e;
+    }
+    sum = sbk::wave_sum(sum);
+    if (a.NS == 1)
+      for (int f = lane; f < nf; f += 64) S[j][f] = S[j][f] / sum;
+    if (lane == 0) {
+      mx[j] = m;
+      sm[j] = sum;
+    }
+  }
+  __syncthreads();
+  {
+    float4 acc[kQT];
+#pragma unroll
+    for (int j = 0; j < kQT; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = wave * 32 + u * RPI + rg;
+      if (f < nf) {
+#pragma unroll
+        for (int j = 0; j < kQT; ++j) {
+          if (j < nq) {
+            const float p = S[j][f];
+            acc[j].x = fmaf(p, v4[u].x, acc[j].x);
+            acc[j].y = fmaf(p, v4[u].y, acc[j].y);
+            acc[j].z = fmaf(p, v4[u].z, acc[j].z);
+            acc[j].w = fmaf(p, v4[u].w, acc[j].w);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kQT; ++j) {
+      if (j < nq) {
+#pragma unroll
+        for (int m = LPR; m < 64; m <<= 1) {
+          acc[j].x += sbk::shfl_xor(acc[j].x, m);
+          acc[j].y += sbk::shfl_xor(acc[j].y, m);
+          acc[j].z += sbk::shfl_xor(acc[j].z, m);
+          acc[j].w += sbk::shfl_xor(acc[j].w, m);
+        }
+        if (rg == 0) {
+          red[wave][j][cq * 4] = acc[j].x;
+          red[wave][j][cq * 4 + 1] = acc[j].y;
+          red[wave][j][cq * 4 + 2] = acc[j].z;
+          red[wave][j][cq * 4 + 3] = acc[j].w;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < nq * DH; idx += 256) {
+    const int j = idx / DH, c = idx % DH;
+    const float v = (red[0][j][c] + red[1][j][c]) + (red[2][j][c] + red[3][j][c]);
+    if (a.NS == 1) {
+      a.out[((size_t)b * a.beam + q0 + j) * d + h * DH + c] = v;
+    } else {
+      float* pp = a.part + ((((size_t)b * a.H + h) * a.NS + split) * a.beam + q0 + j) * (DH + 2);
+      pp[c] = v;
+      if (c == 0) {
+        pp[DH] = nf > 0 ? mx[j] : -INFINITY;
+        pp[DH + 1] = nf > 0 ? sm[j] : 0.0f;
+      }
+    }
+  }
+}
+
 // out[i, h*DH + c] = sum_s e^{m_s - M} o_s[c] / sum_s e^{m_s - M} l_s
 __global__ void __launch_bounds__(256) cross_merge_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int H, int NS, int beam, int DH, int d) {
@@ -329,7 +465,15 @@ template <int DH>
 int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
   const int qtiles = (a.beam + kQT - 1) / kQT;
   sbk::ProfScope prof("cross_attn_step", 4.0 * a.B * a.beam * (double)a.T * a.d, 8.0 * a.B * (double)a.T * a.d, st);
-  SBK_LAUNCH((cross_attn_step_kernel<DH>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
+  if constexpr (DH == 64 || DH == 32 || DH == 16) {
+    if (sbk::g_cross_rows && (a.d % 4) == 0 && sbk::aligned16(a.kv) && sbk::aligned16(a.q)) {
+      SBK_LAUNCH((cross_attn_rows_kernel<DH>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
+    } else {
+      SBK_LAUNCH((cross_attn_step_kernel<DH>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
+    }
+  } else {
+    SBK_LAUNCH((cross_attn_step_kernel<DH>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
+  }
   int rc = sbk::launch_status("cross_attn_step");
   if (rc || a.NS == 1) return rc;
   SBK_LAUNCH(cross_merge_kernel, dim3(a.B * a.beam), dim3(256), 0, st, (const float*)a.part, a.out, a.H, a.NS, a.beam,
@@ -364,6 +508,7 @@ __global__ void __launch_bounds__(256) log_softmax_row_kernel(const float* __res
 }  // namespace
 
 namespace sbk {
+int g_cross_rows = 1;  // tuning knob (sbk_prof_set_knob key 4): row-coalesced cross-attention kernel
 
 int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,
               hipStream_t st) {

@@ -10,6 +10,7 @@
 // The epilogue (bias, activation, scaled residual) runs on the accumulators in
 // registers and writes 128-byte rows (32 lanes x 4 B) per store instruction.
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -387,7 +388,10 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
                int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq,
                float* ws, size_t ws_floats, hipStream_t st) {
   if (M == 0 || N == 0) return 0;
-  const bool skinny_ok = (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < 256) && M <= 4096 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
+  // (measured, tools/microbench.py --attn --gemm: from ~1.9 M outputs with a short K the LDS-tiled kernels win:
+  //  M=1280 N=1536 41.6 -> 27.6 us, M=640 N=5000 63 -> 46 us; a long K still needs the split of the skinny path)
+  const bool big_short = (long)M * N >= 1900000 && K <= 512;
+  const bool skinny_ok = !big_short && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < 256) && M <= 4096 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
   if (!skinny_ok || g_skinny_off) return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
   GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
   const int tiles_m = cdiv(M, 32), tiles_n = cdiv(N, 32);
@@ -423,7 +427,7 @@ int gemm_ln_nt(const float* A, int lda, const float* Wf, int ldw, const float* b
                int ldc, int M, int N, int K, float eps, int act, float alpha, hipStream_t st) {
   if (M == 0 || N == 0) return 0;
   const bool ok = (K == 512 || K == 256 || K == 128) && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < 256) &&
-                  M <= 4096 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(Wf) && !g_skinny_off;
+                  M <= 4096 && (long)M * N < 1900000 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(Wf) && !g_skinny_off;
   if (!ok) return -1;
   GemmArgs g{A, Wf, bf, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, nullptr, 1};
   const int tiles_m = cdiv(M, 32), tiles_n = cdiv(N, 32);
@@ -518,4 +522,6 @@ extern "C" int sbk_prof_gemm_repeat_f32(const float* A, const float* W, float* C
 extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 1) sbk::g_skinny_nch = value;
   if (key == 2) sbk::g_skinny_off = value;
+  if (key == 3) sbk::g_attn_prefetch = value;
+  if (key == 4) sbk::g_cross_rows = value;
 }

@@ -22,6 +22,7 @@
 // so each lane's K / P operand is one contiguous Dh/2-float run of a single
 // row: vector loads straight from HBM/L2 into registers, no LDS staging.
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -64,17 +65,20 @@ __device__ __forceinline__ void load_run(float (&dst)[N], const float* __restric
 // [>=T][DH], a.bias_u = signed sines [>=T][DH] of PrecomputedRoPESinusoids, attention.py:955-1053;
 // x'[c] = x[c]*cos[t][c] + x[c^1]*sin[t][c]).  The rotation pairs (2i, 2i+1) never straddle the two
 // halves of the head dimension, so the half-split operand runs rotate in registers.
-template <int DH, bool ROPE>
-__global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
+// NW = waves per workgroup (4 or 8).  The score strip pins one workgroup per CU once T' > ~350, so 8 waves
+// put two on every SIMD behind the same strip: one wave's operand loads hide behind the other's MFMA chain.
+template <int DH, bool ROPE, bool PF, int NW>
+__global__ void __launch_bounds__(NW * 64) relpos_attn_kernel(AttnArgs a) {
   constexpr int DH2 = DH / 2;
   constexpr int QP = DH + 1;             // LDS pitch of the Q tiles (odd)
   constexpr int NC = (DH + 31) / 32;     // 32-wide column tiles of the context
-  constexpr int NPART = 4 / NC;          // waves sharing one column tile in P.V
+  constexpr int NPART = NW / NC;         // waves sharing one column tile in P.V
+  constexpr int NT = NW * 64;
   SBK_DYN_LDS(float, lds);
   float* Qu = lds;                       // [32][QP]   (q + u) * scale
   float* Qv = Qu + 32 * QP;              // [32][QP]   (q + v) * scale
-  float* red = Qv + 32 * QP;             // [3][32][33] partial contexts
-  float* S = red + 3 * 32 * 33;          // [32][SP]   scores -> probabilities
+  float* red = Qv + 32 * QP;             // [NW-NC][32][33] partial contexts
+  float* S = red + (NW - NC) * 32 * 33;  // [32][SP]   scores -> probabilities
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jl = lane & 31, half = lane >> 5;
@@ -83,7 +87,7 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
   const size_t row3 = (size_t)3 * d;
   const float* qkv_b = a.qkv + (size_t)b * T * row3 + (size_t)h * 3 * DH;
 
-  for (int idx = tid; idx < 32 * DH; idx += 256) {
+  for (int idx = tid; idx < 32 * DH; idx += NT) {
     const int i = idx / DH, c = idx % DH;
     const int row = min(i0 + i, T - 1);
     const float q = qkv_b[(size_t)row * row3 + c];
@@ -97,30 +101,32 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
   }
   __syncthreads();
 
-  // ---- phase 1: S = AC + shifted BD, key tiles round-robin over the waves
+  // ---- phase 1: S = AC + shifted BD, key tiles round-robin over the waves.  The operand runs of a
+  // wave's NEXT key tile (K, P[rbase..], P[rbase+32..]; for RoPE: K, cosines, sines) are requested
+  // before the MFMA chains of the current one, so their latency hides behind ~100 MFMAs.
   const int nkt = (T + 31) / 32;
-  for (int kt = wave; kt < nkt; kt += 4) {
+  auto fetch = [&](int kt, float (&kr)[DH2], float (&q0)[DH2], float (&q1)[DH2]) {
     const int j0 = kt * 32;
-    // all three operand runs of this key tile (K, P[rbase..], P[rbase+32..]) are requested up front,
-    // so their latency is paid once per tile and overlaps the first MFMA chain
-    float kreg[DH2], p0reg[DH2], p1reg[DH2];
-    const int rbase = (T - 1) - i0 - 31 + j0;
-    {
-      const int krow = min(j0 + jl, T - 1);
-      load_run<DH2>(kreg, qkv_b + (size_t)krow * row3 + DH + half * DH2);
-      if constexpr (ROPE) {  // p0reg / p1reg carry this frame's cosines / sines
-        load_run<DH2>(p0reg, a.pos + (size_t)krow * DH + half * DH2);
-        load_run<DH2>(p1reg, a.bias_u + (size_t)krow * DH + half * DH2);
+    const int krow = min(j0 + jl, T - 1);
+    load_run<DH2>(kr, qkv_b + (size_t)krow * row3 + DH + half * DH2);
+    if constexpr (ROPE) {
+      load_run<DH2>(q0, a.pos + (size_t)krow * DH + half * DH2);
+      load_run<DH2>(q1, a.bias_u + (size_t)krow * DH + half * DH2);
+    } else {
+      const int rbase = (T - 1) - i0 - 31 + j0;
+      const int prow0 = min(max(rbase + jl, 0), 2 * T - 2), prow1 = min(max(rbase + 32 + jl, 0), 2 * T - 2);
+      load_run<DH2>(q0, a.pos + (size_t)prow0 * d + h * DH + half * DH2);
+      load_run<DH2>(q1, a.pos + (size_t)prow1 * d + h * DH + half * DH2);
+    }
+  };
+  auto score_tile = [&](int kt, float (&kreg)[DH2], float (&p0reg)[DH2], float (&p1reg)[DH2]) {
+    const int j0 = kt * 32;
+    if constexpr (ROPE) {  // p0reg / p1reg carry this frame's cosines / sines
 #pragma unroll
-        for (int s2 = 0; s2 < DH2; s2 += 2) {
-          const float k0 = kreg[s2], k1 = kreg[s2 + 1];
-          kreg[s2] = k0 * p0reg[s2] + k1 * p1reg[s2];
-          kreg[s2 + 1] = k1 * p0reg[s2 + 1] + k0 * p1reg[s2 + 1];
-        }
-      } else {
-        const int prow0 = min(max(rbase + jl, 0), 2 * T - 2), prow1 = min(max(rbase + 32 + jl, 0), 2 * T - 2);
-        load_run<DH2>(p0reg, a.pos + (size_t)prow0 * d + h * DH + half * DH2);
-        load_run<DH2>(p1reg, a.pos + (size_t)prow1 * d + h * DH + half * DH2);
+      for (int s2 = 0; s2 < DH2; s2 += 2) {
+        const float k0 = kreg[s2], k1 = kreg[s2 + 1];
+        kreg[s2] = k0 * p0reg[s2] + k1 * p1reg[s2];
+        kreg[s2 + 1] = k1 * p0reg[s2 + 1] + k0 * p1reg[s2 + 1];
       }
     }
     f32x16 acc;
@@ -138,31 +144,50 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
     sbk::wave_sync();
     if constexpr (!ROPE) {
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {  // BD: G = (Q+v) P[rbase + 32*pt ...]^T, added along the skew
-      const int rl = pt * 32 + jl;
+      for (int pt = 0; pt < 2; ++pt) {  // BD: G = (Q+v) P[rbase + 32*pt ...]^T, added along the skew
+        const int rl = pt * 32 + jl;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-      for (int s = 0; s < DH2; ++s)
-        acc = sbk::mfma_32x32x2(Qv[jl * QP + s + half * DH2], pt == 0 ? p0reg[s] : p1reg[s], acc);
+        for (int s = 0; s < DH2; ++s)
+          acc = sbk::mfma_32x32x2(Qv[jl * QP + s + half * DH2], pt == 0 ? p0reg[s] : p1reg[s], acc);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int jloc = rl + i - 31;
-        if (jloc >= 0 && jloc < 32) S[i * SP + j0 + jloc] += acc[r];
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int jloc = rl + i - 31;
+          if (jloc >= 0 && jloc < 32) S[i * SP + j0 + jloc] += acc[r];
+        }
+      }
+      sbk::wave_sync();
+    }
+  };
+  if constexpr (PF) {
+    float kA[DH2], pA0[DH2], pA1[DH2], kB[DH2], pB0[DH2], pB1[DH2];
+    if (wave < nkt) fetch(wave, kA, pA0, pA1);
+    for (int kt = wave; kt < nkt; kt += 2 * NW) {
+      const bool more = kt + NW < nkt;
+      if (more) fetch(kt + NW, kB, pB0, pB1);
+      score_tile(kt, kA, pA0, pA1);
+      if (more) {
+        if (kt + 2 * NW < nkt) fetch(kt + 2 * NW, kA, pA0, pA1);
+        score_tile(kt + NW, kB, pB0, pB1);
       }
     }
-    sbk::wave_sync();
+  } else {
+    float kA[DH2], pA0[DH2], pA1[DH2];
+    for (int kt = wave; kt < nkt; kt += NW) {
+      fetch(kt, kA, pA0, pA1);
+      score_tile(kt, kA, pA0, pA1);
     }
   }
   __syncthreads();
 
-  // ---- phase 2: exact softmax over valid keys, 8 rows per wave
+  // ---- phase 2: exact softmax over valid keys, 32 / NW rows per wave
   int klen = T;
   if (a.key_len) klen = min(max(a.key_len[b], 1), T);
   const int kend = nkt * 32;
-  for (int ii = 0; ii < 8; ++ii) {
-    const int i = wave * 8 + ii;
+  for (int ii = 0; ii < 32 / NW; ++ii) {
+    const int i = wave * (32 / NW) + ii;
     float* Srow = S + i * SP;
     float m = -INFINITY;
     for (int j = lane; j < klen; j += 64) m = fmaxf(m, Srow[j]);
@@ -195,8 +220,9 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    for (int t0 = t_begin; t0 < t_end; t0 += 16) {  // 8 k-steps per round: 8 V loads in flight per lane
-      float pv[8], vv[8];
+    // 8 k-steps per round (8 V loads in flight per lane); the next round's operands are requested
+    // before the current round's MFMAs
+    auto fetch_pv = [&](int t0, float (&pv)[8], float (&vv)[8]) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int t = t0 + 2 * u + half;
@@ -204,8 +230,16 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
         vv[u] = (ok && col_ok) ? vbase[(size_t)min(t, T - 1) * row3] : 0.0f;
         pv[u] = ok ? S[jl * SP + min(t, SP - 1)] : 0.0f;
       }
+    };
+    float pvA[8], vvA[8], pvB[8], vvB[8];
+    fetch_pv(t_begin, pvA, vvA);
+    for (int t0 = t_begin; t0 < t_end; t0 += 32) {
+      fetch_pv(t0 + 16, pvB, vvB);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc = sbk::mfma_32x32x2(pv[u], vv[u], acc);
+      for (int u = 0; u < 8; ++u) acc = sbk::mfma_32x32x2(pvA[u], vvA[u], acc);
+      fetch_pv(t0 + 32, pvA, vvA);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = sbk::mfma_32x32x2(pvB[u], vvB[u], acc);
     }
     if (part > 0) {
       float* dst = red + ((part - 1) * NC + ct) * 32 * 33;
@@ -225,23 +259,44 @@ __global__ void __launch_bounds__(256) relpos_attn_kernel(AttnArgs a) {
   }
 }
 
+
+template <int DH, bool ROPE, bool PF, int NW>
+int launch_attn_pf(const AttnArgs& a, hipStream_t st);
+
 template <int DH, bool ROPE>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
-  const size_t lds = ((size_t)2 * 32 * (DH + 1) + 3 * 32 * 33 + (size_t)32 * a.SP) * sizeof(float);
+  // Schedule (measured on MI355X, tools/microbench.py --attn, B=64 T'=440 Dh=64): once the score strip
+  // pins one workgroup per CU (> 80 KB of LDS), 8 waves per workgroup are 1.43x (RelPos) / 1.28x (RoPE)
+  // faster than 4; prefetching the next key tile's operands helps only RoPE (1.18x more; RelPos spills).
+  // sbk_prof_set_knob key 3 overrides: bit 0 prefetch on, bit 1 force 4 waves, bit 2 force 8 waves.
+  const int k = sbk::g_attn_prefetch;
+  const size_t lds4 = ((size_t)2 * 32 * (DH + 1) + 3 * 32 * 33 + (size_t)32 * a.SP) * sizeof(float);
+  const bool eight = (k & 4) ? true : ((k & 2) ? false : lds4 > 80 * 1024);
+  const bool pf = k ? (k & 1) : (ROPE && eight);
+  if (eight) return pf ? launch_attn_pf<DH, ROPE, true, 8>(a, st) : launch_attn_pf<DH, ROPE, false, 8>(a, st);
+  return pf ? launch_attn_pf<DH, ROPE, true, 4>(a, st) : launch_attn_pf<DH, ROPE, false, 4>(a, st);
+}
+
+template <int DH, bool ROPE, bool PF, int NW>
+int launch_attn_pf(const AttnArgs& a, hipStream_t st) {
+  constexpr int NCt = (DH + 31) / 32;
+  const size_t lds = ((size_t)2 * 32 * (DH + 1) + (NW - NCt) * 32 * 33 + (size_t)32 * a.SP) * sizeof(float);
   if (lds > 160 * 1024) return sbk::fail(SBK_EINVAL, "relpos_attention: T=%d needs %zu B of LDS (max 160 KiB)", a.T, lds);
   if (lds > 64 * 1024) {
-    hipError_t e = SBK_ALLOW_DYN_LDS((relpos_attn_kernel<DH, ROPE>), lds);
+    hipError_t e = SBK_ALLOW_DYN_LDS((relpos_attn_kernel<DH, ROPE, PF, NW>), lds);
     if (e != hipSuccess) return sbk::fail((int)e, "relpos_attention: cannot raise the LDS window to %zu B", lds);
   }
   sbk::ProfScope prof(ROPE ? "rope_attention" : "relpos_attention", (ROPE ? 4.0 : 6.0) * a.B * a.H * (double)a.T * a.T * DH,
                       4.0 * a.B * a.T * (4.0 * a.H * DH) + 4.0 * (2.0 * a.T - 1) * a.H * DH, st);
-  SBK_LAUNCH((relpos_attn_kernel<DH, ROPE>), dim3((a.T + 31) / 32, a.H, a.B), dim3(256), lds, st, a);
+  SBK_LAUNCH((relpos_attn_kernel<DH, ROPE, PF, NW>), dim3((a.T + 31) / 32, a.H, a.B), dim3(NW * 64), lds, st, a);
   return sbk::launch_status(ROPE ? "sbk_rope_attention_f32" : "sbk_relpos_attention_f32");
 }
 
 }  // namespace
 
 namespace sbk {
+int g_attn_prefetch = 0;  // tuning knob (sbk_prof_set_knob key 3): phase 1 prefetches the next key tile's operands
+
 int relpos_attention(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                      const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh, float scale,
                      hipStream_t st) {

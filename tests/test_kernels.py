@@ -126,8 +126,10 @@ def test_conv_frontend_golden(backend):
 
 @pytest.mark.parametrize("B,T,H,Dh,lens", [(2, 45, 4, 8, [45, 30]), (1, 70, 2, 36, [70]), (2, 33, 2, 64, [33, 20]),
                                            (1, 100, 1, 16, None), (1, 40, 2, 32, [17]), (2, 251, 2, 64, [251, 129])])
-def test_relpos_attention(backend, B, T, H, Dh, lens):
+@pytest.mark.parametrize("prefetch", [0, 1, 4, 5])
+def test_relpos_attention(backend, B, T, H, Dh, lens, prefetch):
     nat, dev = backend
+    nat.load().sbk_prof_set_knob(3, prefetch)  # both schedules of phase 1 (operand prefetch off / on)
     d = H * Dh
     g = torch.Generator().manual_seed(T + Dh)
     x = torch.randn(B, T, d, generator=g)
@@ -151,6 +153,37 @@ def test_relpos_attention(backend, B, T, H, Dh, lens):
     if lens is not None:  # masked keys carry exactly zero weight
         for b, n in enumerate(lens):
             assert float(attn[b, :, :, n:].abs().max()) == 0.0 if n < T else True
+    nat.load().sbk_prof_set_knob(3, 0)
+
+
+@pytest.mark.parametrize("prefetch", [0, 1, 4, 5])
+@pytest.mark.parametrize("B,T,H,Dh,lens", [(2, 45, 4, 8, [45, 30]), (1, 70, 2, 36, [70]), (2, 133, 2, 64, [133, 20]),
+                                           (1, 300, 1, 32, None)])
+def test_rope_attention(backend, B, T, H, Dh, lens, prefetch):
+    """RoPEMHA (nnet/attention.py:1191-1392) vs the oracle restatement, with key padding."""
+    nat, dev = backend
+    from speechbrain_amd.nnet.attention import PrecomputedRoPESinusoids
+
+    nat.load().sbk_prof_set_knob(3, prefetch)
+    d = H * Dh
+    g = torch.Generator().manual_seed(T + Dh)
+    x = torch.randn(B, T, d, generator=g)
+    sd = {"in_proj_weight": torch.randn(3 * d, d, generator=g) / math.sqrt(d), "out_proj.weight": torch.eye(d),
+          "out_proj.bias": torch.zeros(d)}
+    kl = kp = None
+    if lens is not None:
+        kl = torch.tensor(lens, dtype=torch.int32)
+        kp = ~O.length_to_mask(kl, T)
+    ref = O.rope_mha(x, sd, "", H, kp)
+    tab = PrecomputedRoPESinusoids(512, Dh, torch.float32, "cpu")
+    cos_ref, sin_ref = O.rope_tables(512, Dh)
+    assert torch.equal(tab.cosines, cos_ref) and torch.equal(tab.sines, sin_ref)
+    qkv = nat.gemm_nt(x.to(dev), sd["in_proj_weight"].to(dev))
+    out, attn = nat.rope_attention(qkv, tab.cosines.to(dev), tab.sines.to(dev), None if kl is None else kl.to(dev), H,
+                                   1 / math.sqrt(d), want_attn=True)
+    nat.load().sbk_prof_set_knob(3, 0)
+    assert _md(out, ref) <= 5e-6
+    assert float((attn.sum(-1) - 1).abs().max()) <= 1e-5
 
 
 @pytest.mark.parametrize("B,T,d,ks", [(2, 50, 32, 31), (1, 70, 72, 31), (1, 33, 144, 7)])

@@ -267,3 +267,44 @@ def test_golden_rope_conformer(backend, tag):
         hyps, _, scores, _ = bs(torch.from_numpy(g["enc_out"]).to(dev), wl)
         assert hyps == hyps_of(g["beam_hyps"])
         assert float((scores.cpu() - torch.from_numpy(g["beam_scores"])).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("nhead", [2, 4, 8])
+@pytest.mark.parametrize("rows", [1, 0])
+def test_cross_attention_kernel_variants(backend, nhead, rows):
+    """Both cross-attention kernels (row-coalesced for head_dim 64/32/16, frame-per-thread otherwise) over a
+    memory of several splits with ragged lengths, through the KV-cached decoder vs the oracle."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_modules
+
+    m = build_modules(dict(d_model=128, nhead=nhead, d_ffn=128, n_enc=1, n_dec=1, n_fft=512, win_length=32), vocab=30,
+                      seed=nhead)
+    mods = torch.nn.ModuleDict({k: m[k] for k in ("CNN", "Transformer", "seq_lin", "ctc_lin")})
+    sd = {k: v.detach().clone() for k, v in mods.state_dict().items()}
+    mods = mods.to(dev).eval()
+    cfg = O.ModelCfg(d_model=128, nhead=nhead, num_encoder_layers=1, num_decoder_layers=1, d_ffn=128, vocab=30)
+    gen = torch.Generator().manual_seed(3)
+    enc = torch.randn(3, 300, 128, generator=gen)
+    enc_len = torch.tensor([300, 171, 5], dtype=torch.int32)
+    tgt = torch.randint(0, 30, (3, 4), generator=gen)
+    from speechbrain_amd.decoders import S2STransformerBeamSearcher
+
+    with torch.no_grad():
+        mods["seq_lin"].w.weight.mul_(6.0)
+    sd["seq_lin.w.weight"] = sd["seq_lin.w.weight"] * 6.0
+    wl = enc_len.float() / 300
+    ratio = 6.5 / 300
+    bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                    min_decode_ratio=0.0, max_decode_ratio=ratio, beam_size=5,
+                                    using_eos_threshold=False, length_normalization=True)
+    nat.load().sbk_prof_set_knob(4, rows)
+    try:
+        h = nat.DecoderHandle(mods["Transformer"], mods["seq_lin"])
+        pred = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev))
+        hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))  # several beams per (utterance, head) workgroup
+    finally:
+        nat.load().sbk_prof_set_knob(4, 1)
+    assert float((pred.cpu() - O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")).abs().max()) <= 5e-5
+    hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=5, max_decode_ratio=ratio))
+    assert hyps == hyps_ref
+    assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4

@@ -53,6 +53,35 @@ if __name__ == "__main__":
             gemm_case(M, N, K, 8)
         ctc_case(32, 440, 5000, 10, 5)
         sys.exit(0)
+    if "--attn" in sys.argv:  # encoder attention, both schedules of phase 1
+        import math
+        from speechbrain_amd.nnet.attention import PrecomputedRoPESinusoids
+        H, Dh = 8, 64
+        d = H * Dh
+        tab = PrecomputedRoPESinusoids(1024, Dh, torch.float32, dev)
+        for (B, T) in [(16, 300), (16, 600), (64, 440)]:
+            qkv = torch.randn(B, T, 3 * d, device=dev)
+            P = torch.randn(2 * T - 1, d, device=dev)
+            u = torch.randn(d, device=dev) * 0.1
+            kl = torch.full((B,), T, dtype=torch.int32, device=dev)
+            for pf in (2, 3, 4, 5):  # 2: 4 waves, 3: 4 waves + prefetch, 4: 8 waves, 5: 8 waves + prefetch
+                nat.load().sbk_prof_set_knob(3, pf)
+                t_rel = timeit(lambda: nat.relpos_attention(qkv, P, u, u, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
+                t_rope = timeit(lambda: nat.rope_attention(qkv, tab.cosines, tab.sines, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
+                fl = B * H * T * T * Dh
+                print(f"attn B={B} T={T} knob={pf}: relpos {t_rel:8.1f} us {6.0*fl/t_rel/1e6:6.1f} TF/s | rope {t_rope:8.1f} us {4.0*fl/t_rope/1e6:6.1f} TF/s", flush=True)
+        nat.load().sbk_prof_set_knob(3, 0)
+        if "--gemm" not in sys.argv:
+            sys.exit(0)
+        print("decode-step GEMMs: register-operand 32x32 tiles (skinny) vs LDS-tiled")
+        for M in (320, 640, 1280):
+            for (N, K) in [(512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512)]:
+                nat.load().sbk_prof_set_knob(2, 0)
+                gemm_case(M, N, K, 8)
+                nat.load().sbk_prof_set_knob(2, 1)
+                gemm_case(M, N, K, 8)
+        nat.load().sbk_prof_set_knob(2, 0)
+        sys.exit(0)
     if "--ctc" in sys.argv:
         for (B, T) in [(32, 251), (32, 440), (32, 751), (8, 440)]:
             ctc_case(B, T, 5000, 10, 5)
