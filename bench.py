@@ -197,6 +197,8 @@ def main():
                     help="encoder attention (RelPosMHAXL = BASELINE.json's config; RoPEMHA = the in-tree recipe)")
     ap.add_argument("--lm", action="store_true",
                     help="add the recipe's TransformerLM scorer (12 x 768, weight 0.6, T=1.15): test_search at beam 10")
+    ap.add_argument("--knob", action="append", default=[], metavar="KEY=VALUE",
+                    help="tuning switch passed to sbk_prof_set_knob (A/B measurements only)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -226,6 +228,8 @@ def main():
     from speechbrain_amd.inference.builders import build_asr
 
     native.load()
+    for kv in args.knob:
+        native.load().sbk_prof_set_knob(*[int(v) for v in kv.split("=")])
     asr = build_asr("L", vocab=5000, seed=0, beam_size=10, ctc_weight=0.4, device=str(dev),
                     attention_type=args.attention)
     if args.lm:  # conformer_large.yaml:166-223: full_scorers=[transformerlm, ctc], lm_weight 0.6, temperature 1.15

@@ -311,7 +311,8 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
 template <int DH>
 __global__ void __launch_bounds__(256) cross_attn_rows_kernel(CrossAttnArgs a) {
   constexpr int LPR = DH / 4, RPI = 64 / LPR, U = 32 / RPI;
-  static_assert(kFC == 128 && LPR * 4 == DH && RPI * LPR == 64 && U * RPI == 32, "cross_attn_rows: layout");
+  static_assert(kFC == 128 && LPR * 4 == DH && RPI * LPR == 64 && U * RPI == 32 && (kQT * DH) % 256 == 0, "cross_attn_rows: layout");
+  __shared__ __attribute__((aligned(16))) float qs[kQT][DH];
   __shared__ float S[kQT][kFC + 1];
   __shared__ float red[4][kQT][DH];
   __shared__ float mx[kQT], sm[kQT];
@@ -328,25 +329,36 @@ __global__ void __launch_bounds__(256) cross_attn_rows_kernel(CrossAttnArgs a) {
   const int rg = lane / LPR, cq = lane % LPR;
   const float* kvb = a.kv + (size_t)b * T * 2 * d + h * DH + cq * 4;
 
+  // request order = completion order (vmcnt): queries, then K rows, then V rows, so the score pass can
+  // start while the V rows are still in flight
+  constexpr int QL = kQT * DH / 256;
+  float qv[QL];
+#pragma unroll
+  for (int e = 0; e < QL; ++e) {
+    const int idx = tid + e * 256, j = idx / DH, c = idx % DH;
+    qv[e] = a.q[((size_t)b * a.beam + q0 + min(j, nq - 1)) * d + h * DH + c];  // rows >= nq: duplicates, never used
+  }
   float4 k4[U], v4[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int f = wave * 32 + u * RPI + rg;
-    const float* row = kvb + (size_t)(t0 + min(f, max(nf - 1, 0))) * 2 * d;
-    const bool ok = f < nf;
-    k4[u] = ok ? *reinterpret_cast<const float4*>(row) : make_float4(0.f, 0.f, 0.f, 0.f);
-    v4[u] = ok ? *reinterpret_cast<const float4*>(row + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+    k4[u] = *reinterpret_cast<const float4*>(kvb + (size_t)min(t0 + f, T - 1) * 2 * d);  // rows >= nf: loaded, never used
   }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int f = wave * 32 + u * RPI + rg;
+    v4[u] = *reinterpret_cast<const float4*>(kvb + (size_t)min(t0 + f, T - 1) * 2 * d + d);
+  }
+#pragma unroll
+  for (int e = 0; e < QL; ++e) {
+    const int idx = tid + e * 256;
+    qs[idx / DH][idx % DH] = qv[e] * a.scale;
+  }
+  __syncthreads();
   {
     float4 q4[kQT];
 #pragma unroll
-    for (int j = 0; j < kQT; ++j) {
-      q4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < nq) {
-        q4[j] = *reinterpret_cast<const float4*>(a.q + ((size_t)b * a.beam + q0 + j) * d + h * DH + cq * 4);
-        q4[j].x *= a.scale; q4[j].y *= a.scale; q4[j].z *= a.scale; q4[j].w *= a.scale;
-      }
-    }
+    for (int j = 0; j < kQT; ++j) q4[j] = *reinterpret_cast<const float4*>(&qs[j][cq * 4]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int f = wave * 32 + u * RPI + rg;
@@ -354,8 +366,7 @@ __global__ void __launch_bounds__(256) cross_attn_rows_kernel(CrossAttnArgs a) {
       for (int j = 0; j < kQT; ++j) {
         if (j < nq) {
           float p = fmaf(q4[j].x, k4[u].x, fmaf(q4[j].y, k4[u].y, fmaf(q4[j].z, k4[u].z, q4[j].w * k4[u].w)));
-#pragma unroll
-          for (int m = 1; m < LPR; m <<= 1) p += sbk::shfl_xor(p, m);
+          p = sbk::group_sum<LPR>(p);
           if (cq == 0 && f < nf) S[j][f] = p;
         }
       }

@@ -41,6 +41,23 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ float fast_ldexp(float x, int e) { return __builtin_amdgcn_ldexpf(x, e); }
 __device__ __forceinline__ int frexp_exp(float x) { return __builtin_amdgcn_frexp_expf(x); }
 
+// Sum over aligned groups of G lanes (G = 2, 4, 8, 16), result in every lane of the group, on the VALU
+// through DPP lane selects (quad_perm / row_half_mirror / row_mirror) -- unlike __shfl_xor, which goes
+// through the LDS crossbar (ds_bpermute_b32) and serialises behind the CU's other LDS traffic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "group_sum: group width");
+  if constexpr (G >= 2) v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  if constexpr (G >= 4) v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  if constexpr (G >= 8) v += dpp_move<0x141>(v);  // row_half_mirror
+  if constexpr (G >= 16) v += dpp_move<0x140>(v); // row_mirror
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);

@@ -158,6 +158,15 @@ static inline float fast_ldexp(float x, int e) {
   return ldexpf(x, e);
 }
 static inline int frexp_exp(float x) { return (x != 0.0f && std::isfinite(x)) ? ilogbf(x) + 1 : 0; }
+template <int G>
+static inline float group_sum(float v) {  // same lane selects as the DPP sequence of the device header
+  const int lane = sbk_emu::cur().lane;
+  if (G >= 2) v += shfl_idx_(v, lane ^ 1);
+  if (G >= 4) v += shfl_idx_(v, lane ^ 2);
+  if (G >= 8) v += shfl_idx_(v, (lane & ~7) | (7 - (lane & 7)));
+  if (G >= 16) v += shfl_idx_(v, (lane & ~15) | (15 - (lane & 15)));
+  return v;
+}
 static inline float wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
   return v;
