@@ -185,13 +185,43 @@ constexpr int kFC = 128;  // memory frames per workgroup (flash-decoding style s
 
 struct CrossAttnArgs {
   const float* q;         // [n,d]   n = B*beam, hypothesis i belongs to utterance i / beam
-  const float* kv;        // [B,T,2d] per frame: K (d) then V (d), projected once per utterance
+  const float* kv;        // head_major = 0: [B,T,2d] per frame K (d) then V (d) (the projection GEMM's output);
+                          // head_major = 1: [B,H,T,2*Dh] per (utterance, head) K|V rows back to back, so a
+                          // workgroup's chunk of the memory is ONE contiguous run of HBM
   const int32_t* enc_len; // [B]
   float* out;             // [n,d]
   float* part;            // [B,H,NS,kQT,DH+2] partial (context, max, sum) when NS > 1
   int B, T, d, H, Dh, beam, NS;
   float scale;
+  int head_major;
 };
+
+// element offsets of (utterance b, head h): base of frame 0, frame stride, K -> V distance
+struct KvView {
+  size_t base;
+  int row, voff;
+};
+__device__ __forceinline__ KvView kv_view(const CrossAttnArgs& a, int b, int h, int DH) {
+  if (a.head_major) return {((size_t)b * a.H + h) * a.T * 2 * DH, 2 * DH, DH};
+  return {(size_t)b * a.T * 2 * a.d + (size_t)h * DH, 2 * a.d, a.d};
+}
+
+// [B,T,2d] -> [B,H,T,2*Dh]: once per utterance batch and layer, after the K/V projection GEMM.
+__global__ void __launch_bounds__(256) kv_head_major_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                            int T, int H, int Dh4, long total4) {
+  // one float4 per thread; consecutive threads walk the DESTINATION (fully coalesced writes, 16*Dh-byte read runs)
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total4; o += (long)gridDim.x * 256) {
+    const int c = (int)(o % Dh4);
+    long r = o / Dh4;
+    const int part = (int)(r & 1);
+    r >>= 1;
+    const int t = (int)(r % T);
+    r /= T;
+    const int h = (int)(r % H);
+    const long b = r / H;
+    dst[o] = src[((b * T + t) * 2 + part) * (long)H * Dh4 + (long)h * Dh4 + c];
+  }
+}
 
 // grid (NS, H, B x query tiles).  A workgroup scores kFC memory frames against every beam of one
 // (utterance, head): thread <-> (frame, beam parity), the K row is held in registers and reused by
@@ -214,7 +244,8 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
   const int per = ((klen + a.NS - 1) / a.NS + 3) & ~3;
   const int t0 = split * per, t1 = min(klen, t0 + per);
   const int nf = max(0, t1 - t0);
-  const float* kvb = a.kv + (size_t)b * T * 2 * d + h * DH;
+  const KvView kvv = kv_view(a, b, h, DH);
+  const float* kvb = a.kv + kvv.base;
 
   for (int idx = tid; idx < kQT * DH; idx += 256) {
     const int j = idx / DH, c = idx % DH;
@@ -226,7 +257,7 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
     const int f = tid & (kFC - 1), par = tid / kFC;  // 2 threads per frame, beams split by parity
     if (f < nf) {
       float kr[DH];
-      const float* kp = kvb + (size_t)(t0 + f) * 2 * d;
+      const float* kp = kvb + (size_t)(t0 + f) * kvv.row;
 #pragma unroll
       for (int c = 0; c < DH; ++c) kr[c] = kp[c];
       for (int j = par; j < nq; j += 256 / kFC) {
@@ -263,13 +294,13 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
     for (int j = 0; j < kQT; ++j) acc[j] = 0.0f;
     const int c = lane;
     if (c < DH) {
-      const float* vcol = kvb + (size_t)t0 * 2 * d + d + c;
+      const float* vcol = kvb + (size_t)t0 * kvv.row + kvv.voff + c;
       for (int f0 = wave; f0 < nf; f0 += 32) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int f = f0 + 4 * u;
-          v[u] = f < nf ? vcol[(size_t)f * 2 * d] : 0.0f;
+          v[u] = f < nf ? vcol[(size_t)f * kvv.row] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -327,7 +358,8 @@ __global__ void __launch_bounds__(256) cross_attn_rows_kernel(CrossAttnArgs a) {
   const int t0 = split * per, t1 = min(klen, t0 + per);
   const int nf = max(0, t1 - t0);
   const int rg = lane / LPR, cq = lane % LPR;
-  const float* kvb = a.kv + (size_t)b * T * 2 * d + h * DH + cq * 4;
+  const KvView kvv = kv_view(a, b, h, DH);
+  const float* kvb = a.kv + kvv.base + cq * 4;
 
   // request order = completion order (vmcnt): queries, then K rows, then V rows, so the score pass can
   // start while the V rows are still in flight
@@ -342,12 +374,12 @@ __global__ void __launch_bounds__(256) cross_attn_rows_kernel(CrossAttnArgs a) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int f = wave * 32 + u * RPI + rg;
-    k4[u] = *reinterpret_cast<const float4*>(kvb + (size_t)min(t0 + f, T - 1) * 2 * d);  // rows >= nf: loaded, never used
+    k4[u] = *reinterpret_cast<const float4*>(kvb + (size_t)min(t0 + f, T - 1) * kvv.row);  // rows >= nf: loaded, never used
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int f = wave * 32 + u * RPI + rg;
-    v4[u] = *reinterpret_cast<const float4*>(kvb + (size_t)min(t0 + f, T - 1) * 2 * d + d);
+    v4[u] = *reinterpret_cast<const float4*>(kvb + (size_t)min(t0 + f, T - 1) * kvv.row + kvv.voff);
   }
 #pragma unroll
   for (int e = 0; e < QL; ++e) {
@@ -520,6 +552,7 @@ __global__ void __launch_bounds__(256) log_softmax_row_kernel(const float* __res
 
 namespace sbk {
 int g_cross_rows = 1;  // tuning knob (sbk_prof_set_knob key 4): row-coalesced cross-attention kernel
+int g_kv_head_major = 1;  // tuning knob (key 5): cross K/V stored [B,H,T,2*Dh] instead of [B,T,2d]
 
 int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,
               hipStream_t st) {
@@ -549,13 +582,26 @@ size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam) {
   return ns > 1 ? (size_t)B * H * ns * beam * (Dh + 2) : 0;
 }
 
+// [B,T,2d] (projection output) -> [B,H,T,2*Dh] (what cross_attn_step streams when head_major = 1)
+int kv_head_major(const float* src, float* dst, int B, int T, int d, int H, hipStream_t st) {
+  const int Dh = d / H;
+  if (B == 0 || T == 0) return 0;
+  if (Dh % 4 != 0 || !aligned16(src) || !aligned16(dst)) return fail(SBK_EINVAL, "kv_head_major: head_dim %d / alignment", Dh);
+  const long total4 = (long)B * T * 2 * d / 4;
+  ProfScope prof("kv_head_major", 0.0, 8.0 * B * (double)T * 2 * d, st);
+  const long blocks = (total4 + 255) / 256;
+  SBK_LAUNCH(kv_head_major_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st,
+             reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), T, H, Dh / 4, total4);
+  return launch_status("kv_head_major");
+}
+
 int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, float* part, int B, int T,
-                    int d, int H, int beam, hipStream_t st) {
+                    int d, int H, int beam, hipStream_t st, int head_major) {
   if (B == 0) return 0;
   const int Dh = d / H;
   const int NS = cross_attn_splits(T);
   if (NS > 1 && !part) return fail(SBK_EINVAL, "cross_attn_step: T=%d needs a partial buffer", T);
-  CrossAttnArgs a{q, kv, enc_len, out, part, B, T, d, H, Dh, beam, NS, 1.0f / sqrtf((float)Dh)};
+  CrossAttnArgs a{q, kv, enc_len, out, part, B, T, d, H, Dh, beam, NS, 1.0f / sqrtf((float)Dh), head_major};
   switch (Dh) {
     case 64: return launch_cross<64>(a, st);
     case 36: return launch_cross<36>(a, st);

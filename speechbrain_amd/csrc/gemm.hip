@@ -524,4 +524,5 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 2) sbk::g_skinny_off = value;
   if (key == 3) sbk::g_attn_prefetch = value;
   if (key == 4) sbk::g_cross_rows = value;
+  if (key == 5) sbk::g_kv_head_major = value;
 }

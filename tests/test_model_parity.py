@@ -270,8 +270,8 @@ def test_golden_rope_conformer(backend, tag):
 
 
 @pytest.mark.parametrize("nhead", [2, 4, 8])
-@pytest.mark.parametrize("rows", [1, 0])
-def test_cross_attention_kernel_variants(backend, nhead, rows):
+@pytest.mark.parametrize("rows,head_major", [(1, 1), (0, 1), (1, 0), (0, 0)])
+def test_cross_attention_kernel_variants(backend, nhead, rows, head_major):
     """Both cross-attention kernels (row-coalesced for head_dim 64/32/16, frame-per-thread otherwise) over a
     memory of several splits with ragged lengths, through the KV-cached decoder vs the oracle."""
     nat, dev = backend
@@ -298,12 +298,14 @@ def test_cross_attention_kernel_variants(backend, nhead, rows):
                                     min_decode_ratio=0.0, max_decode_ratio=ratio, beam_size=5,
                                     using_eos_threshold=False, length_normalization=True)
     nat.load().sbk_prof_set_knob(4, rows)
+    nat.load().sbk_prof_set_knob(5, head_major)  # cross K/V as [B,H,T,2*Dh] or as the projection wrote them
     try:
         h = nat.DecoderHandle(mods["Transformer"], mods["seq_lin"])
         pred = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev))
         hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))  # several beams per (utterance, head) workgroup
     finally:
         nat.load().sbk_prof_set_knob(4, 1)
+        nat.load().sbk_prof_set_knob(5, 1)
     assert float((pred.cpu() - O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")).abs().max()) <= 5e-5
     hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=5, max_decode_ratio=ratio))
     assert hyps == hyps_ref
