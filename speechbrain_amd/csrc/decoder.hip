@@ -551,8 +551,11 @@ __global__ void __launch_bounds__(256) log_softmax_row_kernel(const float* __res
 }  // namespace
 
 namespace sbk {
-int g_cross_rows = 1;  // tuning knob (sbk_prof_set_knob key 4): row-coalesced cross-attention kernel
-int g_kv_head_major = 1;  // tuning knob (key 5): cross K/V stored [B,H,T,2*Dh] instead of [B,T,2d]
+// Measured alternatives kept behind sbk_prof_set_knob (Conformer-L, B=64, MI355X; cross_attn_step total per
+// 8 batches): frame-per-thread kernel 247 ms with either layout; row-coalesced kernel 336 ms on [B,T,2d],
+// 306 ms on head-major [B,H,T,2*Dh].  The step is not HBM-bound at these sizes, so the defaults stay 0.
+int g_cross_rows = 0;     // key 4: row-coalesced cross-attention kernel
+int g_kv_head_major = 0;  // key 5: cross K/V stored [B,H,T,2*Dh] instead of [B,T,2d]
 
 int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,
               hipStream_t st) {

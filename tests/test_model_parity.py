@@ -304,8 +304,8 @@ def test_cross_attention_kernel_variants(backend, nhead, rows, head_major):
         pred = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev))
         hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))  # several beams per (utterance, head) workgroup
     finally:
-        nat.load().sbk_prof_set_knob(4, 1)
-        nat.load().sbk_prof_set_knob(5, 1)
+        nat.load().sbk_prof_set_knob(4, 0)
+        nat.load().sbk_prof_set_knob(5, 0)
     assert float((pred.cpu() - O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")).abs().max()) <= 5e-5
     hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=5, max_decode_ratio=ratio))
     assert hyps == hyps_ref
