@@ -335,6 +335,230 @@ def golden_lm(tag, normalize_before, ctc_w, lm_w, lm_temp, seed, beam=4, B=3, n_
     print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+# ---------------------------------------------------------------- a pretrained model directory (from_hparams)
+PRETRAINED_YAML = """# Layout of speechbrain/asr-conformer-transformerlm-librispeech's hyperparams.yaml, tiny sizes.
+sample_rate: 16000
+n_fft: 400
+n_mels: 80
+
+d_model: 32
+nhead: 4
+num_encoder_layers: 2
+num_decoder_layers: 2
+d_ffn: 64
+transformer_dropout: 0.0
+activation: !name:torch.nn.GELU
+output_neurons: 40
+
+blank_index: 0
+bos_index: 1
+eos_index: 2
+
+min_decode_ratio: 0.0
+max_decode_ratio: 1.0
+test_beam_size: 20
+lm_weight: 0.60
+ctc_weight_decode: 0.40
+
+CNN: !new:speechbrain.lobes.models.convolution.ConvolutionFrontEnd
+    input_shape: (8, 10, 80)
+    num_blocks: 2
+    num_layers_per_block: 1
+    out_channels: (64, 32)
+    kernel_sizes: (3, 3)
+    strides: (2, 2)
+    residuals: (False, False)
+
+Transformer: !new:speechbrain.lobes.models.transformer.TransformerASR.TransformerASR
+    input_size: 640
+    tgt_vocab: !ref <output_neurons>
+    d_model: !ref <d_model>
+    nhead: !ref <nhead>
+    num_encoder_layers: !ref <num_encoder_layers>
+    num_decoder_layers: !ref <num_decoder_layers>
+    d_ffn: !ref <d_ffn>
+    dropout: !ref <transformer_dropout>
+    activation: !ref <activation>
+    encoder_module: conformer
+    attention_type: RelPosMHAXL
+    normalize_before: True
+    causal: False
+
+ctc_lin: !new:speechbrain.nnet.linear.Linear
+    input_size: !ref <d_model>
+    n_neurons: !ref <output_neurons>
+
+seq_lin: !new:speechbrain.nnet.linear.Linear
+    input_size: !ref <d_model>
+    n_neurons: !ref <output_neurons>
+
+lm_model: !new:speechbrain.lobes.models.transformer.TransformerLM.TransformerLM
+    vocab: !ref <output_neurons>
+    d_model: 48
+    nhead: 4
+    num_encoder_layers: 2
+    num_decoder_layers: 0
+    d_ffn: 96
+    dropout: 0.0
+    activation: !name:torch.nn.GELU
+    normalize_before: False
+
+transformerlm_scorer: !new:speechbrain.decoders.scorer.TransformerLMScorer
+    language_model: !ref <lm_model>
+    temperature: 1.15
+
+ctc_scorer: !new:speechbrain.decoders.scorer.CTCScorer
+    eos_index: !ref <eos_index>
+    blank_index: !ref <blank_index>
+    ctc_fc: !ref <ctc_lin>
+
+scorer: !new:speechbrain.decoders.scorer.ScorerBuilder
+    full_scorers: [!ref <transformerlm_scorer>, !ref <ctc_scorer>]
+    weights:
+        transformerlm: !ref <lm_weight>
+        ctc: !ref <ctc_weight_decode>
+
+decoder: !new:speechbrain.decoders.S2STransformerBeamSearcher
+    modules: [!ref <Transformer>, !ref <seq_lin>]
+    bos_index: !ref <bos_index>
+    eos_index: !ref <eos_index>
+    min_decode_ratio: !ref <min_decode_ratio>
+    max_decode_ratio: !ref <max_decode_ratio>
+    beam_size: !ref <test_beam_size>
+    temperature: 1.15
+    using_eos_threshold: False
+    length_normalization: True
+    scorer: !ref <scorer>
+
+log_softmax: !new:torch.nn.LogSoftmax
+    dim: -1
+
+normalizer: !new:speechbrain.processing.features.InputNormalization
+    norm_type: global
+
+compute_features: !new:speechbrain.lobes.features.Fbank
+    sample_rate: !ref <sample_rate>
+    n_fft: !ref <n_fft>
+    n_mels: !ref <n_mels>
+
+tokenizer: !new:sentencepiece.SentencePieceProcessor
+
+Tencoder: !new:speechbrain.lobes.models.transformer.TransformerASR.EncoderWrapper
+    transformer: !ref <Transformer>
+
+encoder: !new:speechbrain.nnet.containers.LengthsCapableSequential
+    input_shape: [null, null, !ref <n_mels>]
+    compute_features: !ref <compute_features>
+    normalize: !ref <normalizer>
+    cnn: !ref <CNN>
+    transformer_encoder: !ref <Tencoder>
+
+asr_model: !new:torch.nn.ModuleList
+    - [!ref <CNN>, !ref <Transformer>, !ref <seq_lin>, !ref <ctc_lin>]
+
+modules:
+    pre_transformer: !ref <CNN>
+    transformer: !ref <Transformer>
+    seq_lin: !ref <seq_lin>
+    ctc_lin: !ref <ctc_lin>
+    normalizer: !ref <normalizer>
+    encoder: !ref <encoder>
+    compute_features: !ref <compute_features>
+    model: !ref <asr_model>
+    lm_model: !ref <lm_model>
+    decoder: !ref <decoder>
+
+pretrainer: !new:speechbrain.utils.parameter_transfer.Pretrainer
+    loadables:
+        normalizer: !ref <normalizer>
+        asr: !ref <asr_model>
+        lm: !ref <lm_model>
+        tokenizer: !ref <tokenizer>
+"""
+
+
+def golden_pretrained():
+    """A model directory in the reference's HuggingFace layout (hyperparams.yaml + asr/lm/normalizer/tokenizer
+    checkpoints written with the reference's own savers) and what the reference's EncoderDecoderASR
+    transcribes from it: the fixture of the from_hparams drop-in test."""
+    import sentencepiece as spm
+    from speechbrain.decoders import S2STransformerBeamSearcher
+    from speechbrain.decoders.scorer import CTCScorer, ScorerBuilder, TransformerLMScorer
+    from speechbrain.inference.ASR import EncoderDecoderASR
+    from speechbrain.lobes.features import Fbank
+    from speechbrain.lobes.models.transformer.TransformerASR import EncoderWrapper
+    from speechbrain.lobes.models.transformer.TransformerLM import TransformerLM
+    from speechbrain.nnet.containers import LengthsCapableSequential
+    from speechbrain.processing.features import InputNormalization
+
+    print("[pretrained dir]")
+    out_dir = os.path.join(OUT, "pretrained_tiny")
+    os.makedirs(out_dir, exist_ok=True)
+    mods = build_reference(32, 4, 64, 2, 2, 40, seed=7)
+    with torch.no_grad():
+        mods["seq_lin"].w.weight.mul_(6.0)
+        mods["ctc_lin"].w.weight.mul_(6.0)
+    torch.manual_seed(107)
+    lm = TransformerLM(vocab=40, d_model=48, nhead=4, num_encoder_layers=2, num_decoder_layers=0, d_ffn=96,
+                       dropout=0.0, activation=torch.nn.GELU, normalize_before=False).eval()
+    with torch.no_grad():
+        lm.output_proj.layers[2].w.weight.mul_(4.0)
+    # tokenizer: a 40-piece unigram model trained on a synthetic corpus
+    words = ["speech", "brain", "wave", "front", "beam", "search", "frame", "token", "mel", "filter", "bank", "conformer",
+             "quick", "jumps", "lazy", "dog", "vex", "zygote", "hq"]
+    g = torch.Generator().manual_seed(99)
+    corpus = os.path.join(out_dir, "_corpus.txt")
+    with open(corpus, "w") as f:
+        for _ in range(400):
+            f.write(" ".join(words[int(i)] for i in torch.randint(0, len(words), (6,), generator=g)) + "\n")
+    spm.SentencePieceTrainer.train(input=corpus, model_prefix=os.path.join(out_dir, "_spm"), vocab_size=40,
+                                   model_type="unigram", unk_id=0, bos_id=1, eos_id=2, pad_id=-1,
+                                   character_coverage=1.0, hard_vocab_limit=False, minloglevel=2)
+    os.replace(os.path.join(out_dir, "_spm.model"), os.path.join(out_dir, "tokenizer.ckpt"))
+    for leftover in ("_spm.vocab", "_corpus.txt"):
+        os.remove(os.path.join(out_dir, leftover))
+    tok = spm.SentencePieceProcessor()
+    tok.load(os.path.join(out_dir, "tokenizer.ckpt"))
+    # normalisation statistics as a trained model would carry them
+    norm = InputNormalization(norm_type="global")
+    norm.glob_mean = -30.0 + 5.0 * torch.randn(80, generator=g)
+    norm.glob_std = 8.0 + torch.rand(80, generator=g)
+    norm.count = 1000
+    norm._save(os.path.join(out_dir, "normalizer.ckpt"))
+    asr_model = torch.nn.ModuleList([mods["CNN"], mods["Transformer"], mods["seq_lin"], mods["ctc_lin"]])
+    torch.save(asr_model.state_dict(), os.path.join(out_dir, "asr.ckpt"))
+    torch.save(lm.state_dict(), os.path.join(out_dir, "lm.ckpt"))
+    with open(os.path.join(out_dir, "hyperparams.yaml"), "w") as f:
+        f.write(PRETRAINED_YAML)
+
+    # the reference pipeline, wired exactly as the YAML describes
+    feats = Fbank(sample_rate=16000, n_fft=400, n_mels=80)
+    encoder = LengthsCapableSequential(input_shape=[None, None, 80], compute_features=feats, normalize=norm,
+                                       cnn=mods["CNN"], transformer_encoder=EncoderWrapper(mods["Transformer"]))
+    scorer = ScorerBuilder(full_scorers=[TransformerLMScorer(language_model=lm, temperature=1.15),
+                                         CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)],
+                           weights={"transformerlm": 0.6, "ctc": 0.4})
+    decoder = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                         min_decode_ratio=0.0, max_decode_ratio=1.0, beam_size=20, temperature=1.15,
+                                         using_eos_threshold=False, length_normalization=True, scorer=scorer)
+    asr = EncoderDecoderASR(modules={"encoder": encoder, "decoder": decoder, "transformer": mods["Transformer"]},
+                            hparams={"tokenizer": tok}, run_opts={"device": "cpu"})
+    wav = 0.1 * torch.randn(3, 12000, generator=g)
+    lens = torch.tensor([1.0, 0.8, 0.55])
+    for i in range(3):
+        wav[i, int(lens[i] * 12000):] = 0
+    with torch.no_grad():
+        words_ref, tokens_ref = asr.transcribe_batch(wav, lens)
+        enc_ref = asr.encode_batch(wav, lens)
+    print("  tokens:", [len(t) for t in tokens_ref], "words[0]:", repr(words_ref[0][:60]))
+    np.savez_compressed(os.path.join(OUT, "pretrained_tiny_expected.npz"), wav=wav.numpy(), lens=lens.numpy(),
+                        enc_out=enc_ref.numpy(),
+                        tokens=np.array([t + [-1] * (64 - len(t)) for t in tokens_ref], dtype=np.int64),
+                        words=np.array(words_ref))
+    size = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
+    print(f"  wrote {out_dir} ({size / 1024:.0f} KiB)")
+
+
 # ---------------------------------------------------------------- init parity
 def golden_init_fingerprint():
     """Same-seed construction fingerprint of the reference Conformer-S, so that the
@@ -353,6 +577,9 @@ def golden_init_fingerprint():
 
 
 if __name__ == "__main__":
+    if "--pretrained-only" in sys.argv:
+        golden_pretrained()
+        sys.exit(0)
     if "--rope-only" in sys.argv:
         golden_rope("rope", d_model=32, nhead=4, seed=5)
         golden_rope("rope_dh36", d_model=72, nhead=2, seed=6, B=2)
@@ -375,5 +602,6 @@ if __name__ == "__main__":
     golden_lm("tiny_lm_prenorm", normalize_before=True, ctc_w=0.0, lm_w=0.5, lm_temp=1.0, seed=4, beam=3, B=2)
     golden_rope("rope", d_model=32, nhead=4, seed=5)
     golden_rope("rope_dh36", d_model=72, nhead=2, seed=6, B=2)
+    golden_pretrained()
     golden_init_fingerprint()
     print("OK")

@@ -65,7 +65,7 @@ __device__ __forceinline__ void bf_exp(float x, float* m, int* e) {
 // with seg_e = the largest exponent inside the segment (so every entry is < 2).
 constexpr int kSeg = 32;
 __device__ __host__ __forceinline__ int nseg_of(int T) { return (T + kSeg - 1) / kSeg; }
-__device__ __host__ __forceinline__ int beam_pitch(int) { return 16; }  // table row pitch (max beam), 4 float4 per frame
+__device__ __host__ __forceinline__ int beam_pitch(int beam) { return 16 * ((beam + 15) / 16); }  // table row pitch: beams in tiles of 16 (4 float4 per frame and tile)
 
 // One wave converts the BF rows of one hypothesis (already in global memory / LDS as `row`) into the
 // scaled tables.  `row(t)` returns the BF of frame t.
@@ -160,10 +160,11 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
                                                              const BF* __restrict__ st, const float* __restrict__ sg,
                                                              const int* __restrict__ se,
                                                              float* __restrict__ psi_out) {
-  constexpr int BP = 16;               // table row pitch
+  constexpr int BP = 16;               // LDS row pitch = one tile of 16 beams (blockIdx.z selects the tile)
   constexpr int NV = (NB + 3) / 4;     // float4 per frame actually consumed
   SBK_DYN_LDS(float, lds);
   const int b = blockIdx.y;
+  const int j0 = blockIdx.z * BP, bp = beam_pitch(a.beam);
   const int c = blockIdx.x * 256 + threadIdx.x;
   const bool c_ok = c < a.V;
   const int cc = c_ok ? c : a.V - 1;
@@ -177,11 +178,11 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   float* tab = lds;
   int* segs = reinterpret_cast<int*>(lds + (size_t)T * BP);
   {
-    const float4* src = reinterpret_cast<const float4*>(sg + (size_t)b * T * BP);
     float4* dst = reinterpret_cast<float4*>(tab);
-    for (int i = threadIdx.x; i < T * (BP / 4); i += 256) dst[i] = src[i];
-    const int* es = se + (size_t)b * nseg * BP;
-    for (int i = threadIdx.x; i < nseg * BP; i += 256) segs[i] = es[i];
+    for (int i = threadIdx.x; i < T * (BP / 4); i += 256)
+      dst[i] = *reinterpret_cast<const float4*>(sg + ((size_t)b * T + i / (BP / 4)) * bp + j0 + 4 * (i % (BP / 4)));
+    const int* es = se + (size_t)b * nseg * bp + j0;
+    for (int i = threadIdx.x; i < nseg * BP; i += 256) segs[i] = es[(size_t)(i / BP) * bp + i % BP];
   }
   __syncthreads();
 
@@ -250,8 +251,8 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   if (!c_ok) return;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    if (j < a.beam) {
-      const int n = b * a.beam + j;
+    if (j0 + j < a.beam) {
+      const int n = b * a.beam + j0 + j;
       float psi = bf_log(mps[j], Eps[j]);
       if (c == a.eos) {  // psi[eos] = log-sum of the prefix' own variables at the last frame (ctc.py:232-235)
         const BF s = st[(size_t)n * T + last_frame];
@@ -581,7 +582,7 @@ int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, f
   if (rc) return rc;
   StateView v = view(state, B, beam, T);
   // columns past `beam` of the [frame][16] tables are never written afterwards and must read as zero
-  if (hipMemsetAsync(v.sg, 0, (size_t)B * T * 16 * sizeof(float), st) != hipSuccess) return fail(1, "ctc: memset");
+  if (hipMemsetAsync(v.sg, 0, (size_t)B * T * beam_pitch(beam) * sizeof(float), st) != hipSuccess) return fail(1, "ctc: memset");
   SBK_LAUNCH(ctc_init_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float), st, (const float*)xb_log, v.st, v.sg, v.sb,
              v.se, psi_prev, T, beam);
   return launch_status("ctc_init");
@@ -593,7 +594,7 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
   CtcStepArgs a{last_tok, enc_len, B, T, V, beam, prefix_len, blank, eos, 0.0f, 0, 0, 0.0f, 0.0f};
   const StateView v = view(const_cast<float*>(state), B, beam, T);
   ProfScope prof("ctc_score_step", 2.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 4.0 * B * beam * V, st);
-  dim3 grid(cdiv(V, 256), B), block(256);
+  dim3 grid(cdiv(V, 256), B, beam_pitch(beam) / 16), block(256);  // z: tiles of 16 beams (P is re-read per tile)
   const size_t lds = ((size_t)T * 16 + (size_t)((T + kSeg - 1) / kSeg) * 16) * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "ctc_psi_step: T=%d too long for the LDS window", T);
   if (beam == 1) {

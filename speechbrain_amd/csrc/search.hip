@@ -63,7 +63,8 @@ SideStream* side_stream() {
   return &ss;
 }
 
-constexpr int kMaxBeam = 16;
+constexpr int kMaxBeam = 16;        // per-thread list length of the two-stage top-k
+constexpr int kMaxBeamLarge = 128;  // radix-select top-k (beam_topk_large_kernel) above that
 
 // ---------------------------------------------------------------- top-k over beam*V per utterance
 struct Cand {
@@ -191,6 +192,161 @@ __global__ void __launch_bounds__(256) beam_topk_stage2_kernel(const float* __re
   if (threadIdx.x < beam && out_idx[b * beam + threadIdx.x] == INT_MAX) out_idx[b * beam + threadIdx.x] = 0;
 }
 
+// Beams wider than the per-thread lists (the recipe's test_search uses beam 66): exact radix select.
+// One workgroup of 1024 threads per utterance: four 8-bit passes over the order-preserving integer
+// image of the candidate scores find the beam-th largest key, a fifth pass collects the winners
+// (ties on the threshold: lowest candidate index first, in index order), and a bitonic sort in LDS
+// emits them in descending order.
+__device__ __forceinline__ unsigned order_key(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void __launch_bounds__(1024) beam_topk_large_kernel(const float* __restrict__ comb,
+                                                               const float* __restrict__ seq,
+                                                               float* __restrict__ out_val,
+                                                               int32_t* __restrict__ out_idx, int V, int beam,
+                                                               float norm) {
+  __shared__ int hist[256];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_remaining, s_count, s_eq_base;
+  __shared__ int scan[1024];
+  __shared__ float wv[kMaxBeamLarge];
+  __shared__ int wi[kMaxBeamLarge];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int total = beam * V;
+  const float* cb = comb + (size_t)b * total;
+  const float* sq = seq + b * beam;
+  auto value = [&](int e) {
+    const float x = sq[e / V] + cb[e];
+    const float v = norm > 0.0f ? x / norm : x;
+    return v != v ? -INFINITY : v;  // NaN never wins (the small-beam path skips them as well)
+  };
+  if (tid == 0) {
+    s_prefix = 0u;
+    s_remaining = beam;
+  }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    for (int e = tid; e < total; e += 1024) {
+      const unsigned k = order_key(value(e));
+      if (pass == 0 || (k >> (shift + 8)) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int rem = s_remaining, d = 255;
+      for (; d > 0; --d) {
+        if (hist[d] >= rem) break;
+        rem -= hist[d];
+      }
+      s_remaining = rem;  // how many keys with this digit (and prefix) are still needed
+      s_prefix = (prefix << 8) | (unsigned)d;
+    }
+    __syncthreads();
+  }
+  const unsigned thr = s_prefix;  // key of the beam-th largest candidate
+  const int need_eq = s_remaining;
+  if (tid == 0) {
+    s_count = 0;
+    s_eq_base = 0;
+  }
+  for (int i = tid; i < kMaxBeamLarge; i += 1024) {
+    wv[i] = -INFINITY;
+    wi[i] = INT_MAX;
+  }
+  __syncthreads();
+  // winners above the threshold in any order; threshold ties listed (normally exactly one element)
+  __shared__ int s_ties;
+  if (tid == 0) s_ties = 0;
+  __syncthreads();
+  for (int e = tid; e < total; e += 1024) {
+    const float v = value(e);
+    const unsigned k = order_key(v);
+    if (k > thr) {
+      const int slot = atomicAdd(&s_count, 1);
+      if (slot < kMaxBeamLarge) {
+        wv[slot] = v;
+        wi[slot] = e;
+      }
+    } else if (k == thr) {
+      const int t = atomicAdd(&s_ties, 1);
+      if (t < 1024) scan[t] = e;
+    }
+  }
+  __syncthreads();
+  const int n_ties = s_ties;
+  if (n_ties <= 1024) {  // ties resolve to the lowest candidate indices: rank each tie among the ties
+    if (tid < n_ties) {
+      const int e = scan[tid];
+      int rank = 0;
+      for (int q = 0; q < n_ties; ++q) rank += scan[q] < e;
+      if (rank < need_eq) {
+        const int slot = atomicAdd(&s_count, 1);
+        if (slot < kMaxBeamLarge) {
+          wv[slot] = value(e);
+          wi[slot] = e;
+        }
+      }
+    }
+    __syncthreads();
+  } else {  // a sea of equal keys (e.g. -inf candidates of dead beams): ordered sweep with a block scan
+    __syncthreads();
+    for (int e0 = 0; e0 < total; e0 += 1024) {
+      const int e = e0 + tid;
+      const int is_eq = (e < total && order_key(value(e)) == thr) ? 1 : 0;
+      scan[tid] = is_eq;
+      __syncthreads();
+      for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan of the tie flags
+        const int add = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
+      }
+      const int eq_rank = s_eq_base + scan[tid] - is_eq;
+      if (is_eq && eq_rank < need_eq) {
+        const int slot = atomicAdd(&s_count, 1);
+        if (slot < kMaxBeamLarge) {
+          wv[slot] = value(e);
+          wi[slot] = e;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) s_eq_base += scan[1023];
+      __syncthreads();
+      if (s_eq_base >= need_eq) break;
+    }
+    __syncthreads();
+  }
+  // bitonic sort of the kMaxBeamLarge slots, descending by (value, then lower index)
+  for (int size = 2; size <= kMaxBeamLarge; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (tid < kMaxBeamLarge) {
+        const int partner = tid ^ stride;
+        if (partner > tid) {
+          const bool desc = (tid & size) == 0;
+          const bool first_better = better(wv[tid], wi[tid], wv[partner], wi[partner]);
+          if (desc != first_better) {
+            const float tv = wv[tid];
+            const int ti = wi[tid];
+            wv[tid] = wv[partner];
+            wi[tid] = wi[partner];
+            wv[partner] = tv;
+            wi[partner] = ti;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < beam) {
+    out_val[b * beam + tid] = wv[tid];
+    out_idx[b * beam + tid] = wi[tid] == INT_MAX ? 0 : wi[tid];
+  }
+}
+
 // ---------------------------------------------------------------- beam bookkeeping
 struct BeamState {
   // double-buffered per-hypothesis tables, [n_bh][Lmax]
@@ -225,8 +381,8 @@ __global__ void beam_init_kernel(BeamState s, int B, int beam, int bos) {
 
 __global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const float* __restrict__ am, int cur, int step,
                                                           int V, int beam, int Lmax, int eos, int length_norm) {
-  __shared__ int h_src[kMaxBeam];
-  __shared__ int h_dst[kMaxBeam];
+  __shared__ int h_src[kMaxBeamLarge];
+  __shared__ int h_dst[kMaxBeamLarge];
   __shared__ int h_n;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int nxt = cur ^ 1;
@@ -695,7 +851,8 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   SBK_TRY(check_weights(W));
   SBK_REQUIRE(cfg && enc && enc_len && workspace && out_tokens && out_len && out_score && out_logp, "beam_search: null");
   SBK_REQUIRE(W->seq_w && W->seq_b, "beam_search: seq_lin weights missing");
-  SBK_REQUIRE(cfg->beam >= 1 && cfg->beam <= kMaxBeam, "beam_search: beam %d outside [1,%d]", cfg->beam, kMaxBeam);
+  SBK_REQUIRE(cfg->beam >= 1 && cfg->beam <= kMaxBeamLarge, "beam_search: beam %d outside [1,%d]", cfg->beam,
+              kMaxBeamLarge);
   SBK_REQUIRE(cfg->max_steps <= W->max_len, "beam_search: %d steps exceed the positional table (%d)", cfg->max_steps,
               W->max_len);
   const bool ctc = cfg->ctc_weight > 0.0f;
@@ -773,7 +930,11 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
                            cfg->minus_inf, bb.am_max, extra, st));
     }
     const float norm = cfg->length_normalization ? (float)(step + 1) : 0.0f;
-    {
+    if (beam > kMaxBeam) {
+      sbk::ProfScope prof("beam_topk_large", 10.0 * n * V, 20.0 * n * V, st);
+      SBK_LAUNCH(beam_topk_large_kernel, dim3(B), dim3(1024), 0, st, (const float*)bb.comb,
+                 (const float*)bb.s.seq_scores, bb.s.cand_val, bb.s.cand_idx, V, beam, norm);
+    } else {
       sbk::ProfScope prof("beam_topk", 2.0 * n * V, 4.0 * n * V, st);
       SBK_LAUNCH(beam_topk_stage1_kernel, dim3(kTopkChunks, B), dim3(256), 0, st, (const float*)bb.comb,
                  (const float*)bb.s.seq_scores, bb.topk_val, bb.topk_idx, V, beam, norm);

@@ -1,6 +1,8 @@
 """speechbrain.inference.interfaces mirror: the slice of ``Pretrained`` that EncoderDecoderASR needs
-(inference/interfaces.py:216-489).  Construction from modules=/hparams= dicts is supported; the
-HyperPyYAML / HuggingFace fetching front-end (from_hparams) is outside this round's scope."""
+(inference/interfaces.py:216-489).  Construction from modules=/hparams= dicts and ``from_hparams`` on a LOCAL
+model directory (hyperparams.yaml + *.ckpt, the layout of the reference's HuggingFace model cards) are
+supported; fetching from HuggingFace / URLs is not (no network on the box)."""
+import os
 import types
 import wave
 
@@ -67,7 +69,26 @@ class Pretrained(torch.nn.Module):
         return self.audio_normalizer(sig, sr).to(self.device)
 
     @classmethod
-    def from_hparams(cls, *args, **kwargs):
-        raise NotImplementedError(
-            "from_hparams needs HyperPyYAML + checkpoint fetching, which is outside this round's scope; build the "
-            "modules (speechbrain_amd.inference.builders) and call cls(modules=..., hparams=...)")
+    def from_hparams(cls, source, hparams_file="hyperparams.yaml", pymodule_file="custom.py", overrides=None,
+                     savedir=None, run_opts=None, freeze_params=True, **kwargs):
+        """inference/interfaces.py:455-489 + utils/fetching / parameter_transfer for a local ``source`` directory:
+        build every object of ``<source>/<hparams_file>`` (``speechbrain.*`` classes are served by
+        ``speechbrain_amd.*``), run its ``pretrainer`` over ``<source>/<name>.ckpt`` and wrap ``modules``."""
+        from speechbrain_amd.utils.hpyaml import load_hyperpyyaml
+
+        source = str(source)
+        path = os.path.join(source, hparams_file)
+        if not os.path.isfile(path):
+            raise FileNotFoundError(
+                f"from_hparams: '{path}' not found. `source` must be a local model directory (hyperparams.yaml + "
+                "checkpoints); HuggingFace ids / URLs are not fetched on the MI355X path.")
+        if os.path.isfile(os.path.join(source, pymodule_file)):
+            raise NotImplementedError(f"from_hparams: custom python modules ({pymodule_file}) are not executed")
+        with open(path, encoding="utf-8") as f:
+            hparams = load_hyperpyyaml(f, overrides)
+        pretrainer = hparams.get("pretrainer")
+        if pretrainer is not None:
+            pretrainer.set_collect_in(savedir)
+            pretrainer.collect_files(default_source=source)
+            pretrainer.load_collected()
+        return cls(hparams["modules"], hparams, run_opts=run_opts, freeze_params=freeze_params, **kwargs)

@@ -94,3 +94,22 @@ class TransformerASR(TransformerInterface):
         if tgt is not None:
             raise NotImplementedError("teacher-forced forward (training) is outside the inference path")
         return self.encode(src, wav_len, pad_idx)
+
+
+class EncoderWrapper(nn.Module):
+    """TransformerASR.py:678-726: ``forward`` = ``transformer.encode`` (so the encoder can sit inside a
+    ``LengthsCapableSequential``).  As in the reference, ``forward`` takes ``wav_lens`` -- not ``lengths`` --
+    so a LengthsCapableSequential calls it WITHOUT lengths and the encoder then runs unmasked (:711-714)."""
+
+    def __init__(self, transformer, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.transformer = transformer
+
+    def forward(self, x, wav_lens=None, pad_idx=0, **kwargs):
+        return self.transformer.encode(x, wav_lens, pad_idx, **kwargs)
+
+    def forward_streaming(self, x, context):
+        raise NotImplementedError("streaming (dynamic chunk) encoding is outside the offline path")
+
+    def make_streaming_context(self, *args, **kwargs):
+        raise NotImplementedError("streaming (dynamic chunk) encoding is outside the offline path")

@@ -310,3 +310,51 @@ def test_cross_attention_kernel_variants(backend, nhead, rows, head_major):
     hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=5, max_decode_ratio=ratio))
     assert hyps == hyps_ref
     assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("beam,ctc_w", [(20, 0.4), (33, 0.0), (17, 0.4)])
+def test_wide_beam_vs_oracle(backend, beam, ctc_w):
+    """beam > 16 (the recipe's test_search uses 66): radix-select top-k + CTC tables in tiles of 16 beams."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
+
+    g, mods = build("tiny_ctc", dev)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    d_model, nhead, d_ffn, n_enc, n_dec, vocab = [int(v) for v in g["cfg"][:6]]
+    cfg = O.ModelCfg(d_model=d_model, nhead=nhead, num_encoder_layers=n_enc, num_decoder_layers=n_dec, d_ffn=d_ffn,
+                     vocab=vocab)
+    enc, wl = torch.from_numpy(g["enc_out"]), torch.from_numpy(g["wav_lens"])
+    scorer = None
+    if ctc_w > 0:
+        scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)],
+                               weights={"ctc": ctc_w})
+    bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                    min_decode_ratio=0.0, max_decode_ratio=1.0, beam_size=beam,
+                                    using_eos_threshold=False, length_normalization=True, scorer=scorer)
+    hyps, lens, scores, _ = bs(enc.to(dev), wl.to(dev))
+    hyps_ref, lens_ref, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=beam, ctc_weight=ctc_w))
+    assert hyps == hyps_ref
+    assert float((scores.cpu() - sc_ref).abs().max()) <= 1e-4
+    assert float((lens.cpu() - lens_ref).abs().max()) <= 1e-6
+
+
+def test_from_hparams_local_model_directory(backend):
+    """EncoderDecoderASR.from_hparams on a model directory in the reference's HuggingFace layout
+    (tests/golden/pretrained_tiny: hyperparams.yaml written for ``speechbrain.*`` classes + asr / lm /
+    normalizer / tokenizer checkpoints saved by the reference's own savers, oracle/make_golden.py):
+    the transcription must equal what the reference's EncoderDecoderASR produced from the same files
+    (beam 20 > 16, TransformerLM + CTC scorers, SentencePiece detokenisation)."""
+    nat, dev = backend
+    from speechbrain_amd.inference.ASR import EncoderDecoderASR
+
+    exp = np.load(os.path.join(GOLD, "pretrained_tiny_expected.npz"))
+    asr = EncoderDecoderASR.from_hparams(source=os.path.join(GOLD, "pretrained_tiny"), run_opts={"device": str(dev)})
+    assert type(asr.mods.decoder).__module__.startswith("speechbrain_amd.")
+    wav, lens = torch.from_numpy(exp["wav"]), torch.from_numpy(exp["lens"])
+    enc = asr.encode_batch(wav, lens)
+    assert float((enc.cpu() - torch.from_numpy(exp["enc_out"])).abs().max()) <= 5e-5
+    words, tokens = asr.transcribe_batch(wav, lens)
+    assert tokens == hyps_of(exp["tokens"])
+    assert words == [str(w) for w in exp["words"]]
+    with pytest.raises(FileNotFoundError):
+        EncoderDecoderASR.from_hparams(source="speechbrain/asr-conformer-transformerlm-librispeech")
