@@ -237,13 +237,16 @@ typedef struct {
    * log_softmax(LM(prefix) / lm_temperature).  lm = NULL or lm_weight = 0: no LM. */
   float lm_weight, lm_temperature;
   const sbk_lm_weights* lm;
+  int32_t topk; /* 0 / 1: the best hypothesis per utterance (last token stripped); > 1: return_topk
+                   (seq2seq.py:757-760,1712) -- the outputs hold `topk` rows per utterance in descending
+                   score order and keep their last token, like the reference's padded topk_hyps */
 } sbk_search_config;
 
 /* S2STransformerBeamSearcher.forward (seq2seq.py:1632-1723, :1853-1934) with an optional full
  * CTC scorer (scorer.py:108-255,1221-1315; ctc.py:26-295).
  *   enc [B,T,d], enc_len [B] = round(T * wav_len); ctc_w [V,d], ctc_b [V] (NULL when ctc_weight = 0)
- *   out_tokens [B,max_steps] (best hypothesis, EOS stripped, zero padded), out_len [B],
- *   out_score [B], out_logp [B,max_steps]; out_max_len [1] (device, may be NULL): length of the
+ *   out_tokens [B*topk,max_steps] (topk = 1: best hypothesis, EOS stripped, zero padded), out_len [B*topk]
+ *   (= token count - 1), out_score [B*topk], out_logp [B*topk,max_steps]; out_max_len [1] (device, may be NULL): length of the
  *   longest finished hypothesis in the batch = pad width the reference divides lengths by (:1461)
  *   host_flag: pinned HOST int32 used to poll the stop rule every cfg->check_every steps (the
  *              only points where this call synchronises the stream); NULL => run max_steps.

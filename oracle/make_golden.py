@@ -185,6 +185,22 @@ def golden_model(tag, d_model, nhead, d_ffn, n_enc, n_dec, vocab, B, n_frames, b
             out["beam_step0_ctc"] = tr.ctc_scores[0].numpy()
             out["beam_step1_ctc"] = tr.ctc_scores[1].numpy()
             out["beam_step1_tok"] = tr.tokens[0].numpy()
+        if tag == "tiny_ctc":  # return_topk (seq2seq.py:757-760,1712-1713): padded [B,topk,L] tensors
+            bsk = S2STransformerBeamSearcher(
+                modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=min_ratio,
+                max_decode_ratio=max_ratio, beam_size=beam, using_eos_threshold=eos_thr, length_normalization=True,
+                scorer=scorer, return_topk=True, topk=3)
+            k_hyps, k_lens, k_scores, k_lps = bsk(enc_ref.clone(), wav_lens)
+            o_hyps, o_lens, o_scores, o_lps = O.beam_search(
+                enc_ref, wav_lens, sd, cfg, O.SearchCfg(beam=beam, ctc_weight=ctc_w, min_decode_ratio=min_ratio,
+                                                        max_decode_ratio=max_ratio, using_eos_threshold=eos_thr,
+                                                        return_topk=True, topk=3))
+            assert torch.equal(k_hyps, o_hyps), (k_hyps, o_hyps)
+            check("topk scores", k_scores, o_scores, 1e-4)
+            check("topk lens", k_lens, o_lens, 1e-6)
+            check("topk log_probs", k_lps, o_lps, 1e-4)
+            out["topk_hyps"], out["topk_lens"] = k_hyps.numpy(), k_lens.numpy()
+            out["topk_scores"], out["topk_lps"] = k_scores.numpy(), k_lps.numpy()
         # beam = 1 through the beam searcher (north-star "greedy beam=1")
         bs1 = S2STransformerBeamSearcher(
             modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=min_ratio,
@@ -577,6 +593,10 @@ def golden_init_fingerprint():
 
 
 if __name__ == "__main__":
+    if "--tiny-ctc-only" in sys.argv:
+        golden_model("tiny_ctc", d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=2, vocab=40, B=3, n_frames=61,
+                     beam=4, ctc_w=0.4, sharpen=6.0, max_ratio=1.0)
+        sys.exit(0)
     if "--pretrained-only" in sys.argv:
         golden_pretrained()
         sys.exit(0)

@@ -93,6 +93,8 @@ class SearchCfg:
     using_eos_threshold: bool = False
     eos_threshold: float = 1.5
     minus_inf: float = -1e20
+    topk: int = 1  # with return_topk (seq2seq.py:757-760): the searcher returns padded [B,topk,...] tensors
+    return_topk: bool = False
     lm_weight: float = 0.0  # ScorerBuilder weights["transformerlm"] (scorer.py:1163-1200)
     lm_temperature: float = 1.0  # TransformerLMScorer.temperature (scorer.py:504-508)
 
@@ -636,10 +638,25 @@ def beam_search(enc: Tensor, wav_len: Tensor, sd: SD, cfg: ModelCfg, sc: SearchC
     if not all(len(f) == beam for f in finished):  # seq2seq.py:1600-1630
         harvest(torch.full((n_bh,), sc.eos, dtype=torch.long), scores)
 
-    # _get_topk_prediction (:1418-1476) with topk = 1
-    hyps, lens, best_scores, best_lps = [], [], [], []
     flat = [h for f in finished for h in f]
     max_len = max(h[0].numel() for h in flat)
+    if sc.return_topk:  # _get_topk_prediction (:1418-1476): padded tensors, sequences keep their last token
+        K = sc.topk
+        t_hyps = torch.zeros(B, K, max_len, dtype=torch.long)
+        t_lps = torch.zeros(B, K, max_len)
+        t_lens, t_scores = torch.zeros(B, K), torch.zeros(B, K)
+        for b in range(B):
+            sc_b = torch.stack([h[2] for h in finished[b]])
+            top = sc_b.topk(K)
+            for r, j in enumerate(top.indices.tolist()):
+                seq, lps, s = finished[b][j]
+                t_hyps[b, r, : seq.numel()] = seq
+                t_lps[b, r, : lps.numel()] = lps
+                t_lens[b, r] = (seq.numel() - 1) / max_len
+                t_scores[b, r] = s
+        return t_hyps, t_lens, t_scores, t_lps
+    # _get_topk_prediction (:1418-1476) with topk = 1
+    hyps, lens, best_scores, best_lps = [], [], [], []
     for b in range(B):
         sc_b = torch.stack([h[2] for h in finished[b]])
         j = int(sc_b.topk(1).indices[0])

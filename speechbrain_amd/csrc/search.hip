@@ -438,62 +438,69 @@ __global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const flo
   }
 }
 
-// Fill unfinished lists with the alive hypotheses (seq2seq.py:1600-1630), pick the best finished
-// hypothesis per utterance (:1418-1476, topk = 1) and strip its last token (:1461 + undo_padding).
+// Fill unfinished lists with the alive hypotheses (seq2seq.py:1600-1630) and emit the `topk` best
+// finished hypotheses per utterance in descending score order (:1418-1476).  topk = 1: the last token
+// is stripped (:1461 + undo_padding) and the row zero padded; topk > 1 (return_topk): rows keep their
+// last token like the reference's padded topk_hyps tensor.  out_len = token count - 1 either way.
 __global__ void __launch_bounds__(256) beam_finalize_kernel(BeamState s, int cur, int steps_done, int beam, int Lmax,
-                                                            int32_t* __restrict__ out_tok, int32_t* __restrict__ out_len,
-                                                            float* __restrict__ out_score, float* __restrict__ out_lp) {
-  __shared__ int best;
-  __shared__ int best_from_alive;
+                                                            int topk, int32_t* __restrict__ out_tok,
+                                                            int32_t* __restrict__ out_len, float* __restrict__ out_score,
+                                                            float* __restrict__ out_lp) {
+  __shared__ float e_score[kMaxBeamLarge];
+  __shared__ int e_src[kMaxBeamLarge];   // >= 0: finished slot f;  < 0: alive hypothesis -(j+1)
+  __shared__ int sel[kMaxBeamLarge];
+  __shared__ int n_entries;
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) {
     int cnt = s.fin_count[b];
-    float bv = -INFINITY;
-    int bi = -1, alive_j = -1;
-    for (int f = 0; f < cnt; ++f)
-      if (bi < 0 || s.fin_score[b * beam + f] > bv) {
-        bv = s.fin_score[b * beam + f];
-        bi = f;
-      }
+    for (int f = 0; f < cnt; ++f) {
+      e_score[f] = s.fin_score[b * beam + f];
+      e_src[f] = f;
+    }
+    int longest = 0;  // over ALL final entries of this utterance, filled ones included
+    for (int f = 0; f < cnt; ++f) longest = max(longest, s.fin_len[b * beam + f]);
     if (steps_done > 0) {
+      if (cnt < beam) longest = max(longest, steps_done);
       for (int j = 0; j < beam && cnt < beam; ++j, ++cnt) {
-        const float sc = s.cand_val[b * beam + j];
-        if (bi < 0 || sc > bv) {
-          bv = sc;
-          bi = cnt;
-          alive_j = j;
-        }
+        e_score[cnt] = s.cand_val[b * beam + j];
+        e_src[cnt] = -(j + 1);
       }
     }
-    int longest = 0;  // over ALL finished entries of this utterance, filled ones included
-    for (int f = 0; f < s.fin_count[b]; ++f) longest = max(longest, s.fin_len[b * beam + f]);
-    if (steps_done > 0 && s.fin_count[b] < beam) longest = max(longest, steps_done);
     atomicMax(&s.n_full[1], longest);
-    best = bi;
-    best_from_alive = alive_j;
-    out_score[b] = bi < 0 ? 0.0f : bv;
-    int len = 0;
-    if (bi >= 0) len = (alive_j >= 0 ? steps_done : s.fin_len[b * beam + bi]) - 1;
-    out_len[b] = len < 0 ? 0 : len;
+    n_entries = cnt;
+    for (int r = 0; r < topk; ++r) {  // selection in descending score order; ties: first entry first
+      int bi = -1;
+      for (int e = 0; e < cnt; ++e) {
+        bool used = false;
+        for (int q = 0; q < r; ++q) used |= sel[q] == e;
+        if (!used && (bi < 0 || e_score[e] > e_score[bi])) bi = e;
+      }
+      sel[r] = bi;
+    }
   }
   __syncthreads();
-  const int len = out_len[b];
-  for (int p = tid; p < Lmax; p += 256) {
-    int tok = 0;
-    float lp = 0.0f;
-    if (best >= 0 && p <= len) {  // log-probs keep the stripped position too, like the reference
-      if (best_from_alive >= 0) {
-        const size_t o = ((size_t)b * beam + best_from_alive) * Lmax + p;
-        tok = s.seq[cur][o];
-        lp = s.lp[cur][o];
-      } else {
-        const size_t o = ((size_t)b * beam + best) * Lmax + p;
-        tok = s.fin_seq[o];
-        lp = s.fin_lp[o];
-      }
+  for (int r = 0; r < topk; ++r) {
+    const int e = sel[r];
+    const size_t row = (size_t)b * topk + r;
+    int ntok = 0;
+    if (e >= 0) ntok = e_src[e] < 0 ? steps_done : s.fin_len[b * beam + e_src[e]];
+    const int len = ntok > 0 ? ntok - 1 : 0;
+    if (tid == 0) {
+      out_score[row] = e >= 0 ? e_score[e] : 0.0f;
+      out_len[row] = len;
     }
-    out_tok[(size_t)b * Lmax + p] = p < len ? tok : 0;
-    out_lp[(size_t)b * Lmax + p] = lp;
+    for (int p = tid; p < Lmax; p += 256) {
+      int tok = 0;
+      float lp = 0.0f;
+      if (e >= 0 && p < ntok) {  // log-probs keep the stripped position too, like the reference
+        const size_t o = e_src[e] < 0 ? ((size_t)b * beam + (-e_src[e] - 1)) * Lmax + p
+                                      : ((size_t)b * beam + e_src[e]) * Lmax + p;
+        tok = e_src[e] < 0 ? s.seq[cur][o] : s.fin_seq[o];
+        lp = e_src[e] < 0 ? s.lp[cur][o] : s.fin_lp[o];
+      }
+      out_tok[row * Lmax + p] = (topk > 1 ? p < ntok : p < len) ? tok : 0;
+      out_lp[row * Lmax + p] = lp;
+    }
   }
 }
 
@@ -856,6 +863,8 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   SBK_REQUIRE(cfg->max_steps <= W->max_len, "beam_search: %d steps exceed the positional table (%d)", cfg->max_steps,
               W->max_len);
   const bool ctc = cfg->ctc_weight > 0.0f;
+  const int topk = cfg->topk > 1 ? cfg->topk : 1;
+  SBK_REQUIRE(topk <= cfg->beam, "beam_search: topk %d exceeds the beam %d", topk, cfg->beam);
   SBK_REQUIRE(!ctc || (ctc_w && ctc_b), "beam_search: ctc_weight > 0 needs the ctc_lin weights");
   SBK_REQUIRE(!ctc || (cfg->bos != cfg->eos && cfg->bos != cfg->blank && cfg->eos != cfg->blank),
               "Set blank, eos and bos to different indexes for joint ATT/CTC or CTC decoding");
@@ -970,7 +979,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   }
   if (side) SBK_HIP(hipStreamWaitEvent(st, side->join, 0));  // nothing of this call outlives it on the helper stream
   if (steps_run) *steps_run = steps;
-  SBK_LAUNCH(beam_finalize_kernel, dim3(B), dim3(256), 0, st, bb.s, cur, steps, beam, Lmax, out_tokens, out_len,
+  SBK_LAUNCH(beam_finalize_kernel, dim3(B), dim3(256), 0, st, bb.s, cur, steps, beam, Lmax, topk, out_tokens, out_len,
              out_score, out_logp);
   SBK_TRY(sbk::launch_status("beam_finalize"));
   if (out_max_len)

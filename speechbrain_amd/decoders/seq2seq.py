@@ -79,8 +79,8 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
                  using_eos_threshold=True, eos_threshold=1.5, length_normalization=True, using_max_attn_shift=False,
                  max_attn_shift=60, minus_inf=-1e20):
         super().__init__(bos_index, eos_index, min_decode_ratio, max_decode_ratio)
-        if return_topk or topk != 1:
-            raise NotImplementedError("return_topk / topk > 1 is not implemented on the device search yet")
+        if topk < 1 or (beam_size is not None and topk > beam_size):
+            raise ValueError("topk must lie in [1, beam_size]")
         if using_max_attn_shift:
             raise NotImplementedError("max_attn_shift applies to RNN attention decoders")
         self.model, self.fc, self.temperature = modules[0], modules[1], temperature
@@ -119,7 +119,7 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
             self._lm_handle = self.lm.handle()  # keeps the pointed-to weight table alive during the call
             lm = dict(lm=ctypes.pointer(self._lm_handle.W), lm_weight=self.lm_weight,
                       lm_temperature=self.lm_temperature)
-        return native.SearchConfig(**lm, bos=self.bos_index, eos=self.eos_index, blank=self.blank_index, beam=self.beam_size,
+        return native.SearchConfig(**lm, topk=self.topk if self.return_topk else 1, bos=self.bos_index, eos=self.eos_index, blank=self.blank_index, beam=self.beam_size,
                                    min_steps=mn, max_steps=mx, length_normalization=int(self.length_normalization),
                                    using_eos_threshold=int(self.using_eos_threshold), check_every=self.check_every,
                                    overlap_ctc=int(self.overlap_ctc),
@@ -141,6 +141,10 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
     @torch.no_grad()
     def forward(self, enc_states, wav_len):
         tok, ln, sc, lp, mxl = self.search_device(enc_states, wav_len)
+        if self.return_topk:  # padded tensors [B,topk,max_len] (seq2seq.py:1712-1713)
+            B, K, max_len = enc_states.shape[0], self.topk, max(int(mxl.cpu()), 1)
+            return (tok[:, :max_len].reshape(B, K, max_len).long(), ln.float().reshape(B, K) / max_len,
+                    sc.reshape(B, K), lp[:, :max_len].reshape(B, K, max_len))
         tok_h, ln_h, max_len = tok.cpu(), ln.cpu(), max(int(mxl.cpu()), 1)
         hyps = [tok_h[b, : int(ln_h[b])].tolist() for b in range(tok_h.shape[0])]
         best_lens = ln_h.float() / max_len  # SpeechBrain relative length (seq2seq.py:1461)

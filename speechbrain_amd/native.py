@@ -59,7 +59,7 @@ class SearchConfig(ctypes.Structure):  # sbk_search_config
                 ("max_steps", c_int32), ("length_normalization", c_int32), ("using_eos_threshold", c_int32),
                 ("check_every", c_int32), ("overlap_ctc", c_int32), ("ctc_weight", c_float), ("temperature", c_float),
                 ("eos_threshold", c_float), ("minus_inf", c_float), ("lm_weight", c_float), ("lm_temperature", c_float),
-                ("lm", POINTER(LMWeights))]
+                ("lm", POINTER(LMWeights)), ("topk", c_int32)]
 
 
 def _declare(lib):
@@ -515,13 +515,14 @@ def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=No
     B, T, _ = enc.shape
     dev = enc.device
     L = max(int(cfg.max_steps), 1)
+    K = max(int(cfg.topk), 1)  # rows per utterance (return_topk)
     nbytes = lib.sbk_beam_search_workspace_bytes(ctypes.byref(handle.W), ctypes.byref(cfg), B, T)
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
-    out_tok = torch.zeros(B, L, dtype=torch.int32, device=dev)
-    out_len = torch.zeros(B, dtype=torch.int32, device=dev)
-    out_score = torch.zeros(B, dtype=torch.float32, device=dev)
-    out_lp = torch.zeros(B, L, dtype=torch.float32, device=dev)
+    out_tok = torch.zeros(B * K, L, dtype=torch.int32, device=dev)
+    out_len = torch.zeros(B * K, dtype=torch.int32, device=dev)
+    out_score = torch.zeros(B * K, dtype=torch.float32, device=dev)
+    out_lp = torch.zeros(B * K, L, dtype=torch.float32, device=dev)
     out_max = torch.zeros(1, dtype=torch.int32, device=dev)
     flag = _host_flag(dev)
     steps = c_int32(0)

@@ -66,6 +66,17 @@ def test_golden_model(backend, tag):
         assert float((scores.cpu() - torch.from_numpy(g["beam_scores"])).abs().max()) <= 1e-4
         assert float((lens.cpu() - torch.from_numpy(g["beam_lens"])).abs().max()) <= 1e-6
 
+        if "topk_hyps" in g.files:  # return_topk: padded [B,topk,L] tensors in descending score order
+            bsk = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                             min_decode_ratio=min_ratio, max_decode_ratio=max_ratio, beam_size=beam,
+                                             using_eos_threshold=eos_thr, length_normalization=True, scorer=scorer,
+                                             return_topk=True, topk=3)
+            k_hyps, k_lens, k_scores, k_lps = bsk(enc_ref, wl)
+            assert torch.equal(k_hyps.cpu(), torch.from_numpy(g["topk_hyps"]))
+            assert float((k_lens.cpu() - torch.from_numpy(g["topk_lens"])).abs().max()) <= 1e-6
+            assert float((k_scores.cpu() - torch.from_numpy(g["topk_scores"])).abs().max()) <= 1e-4
+            assert float((k_lps.cpu() - torch.from_numpy(g["topk_lps"])).abs().max()) <= 1e-4
+
         bs1 = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
                                          min_decode_ratio=min_ratio, max_decode_ratio=max_ratio, beam_size=1,
                                          using_eos_threshold=False, length_normalization=True)
