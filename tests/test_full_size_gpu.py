@@ -158,6 +158,51 @@ def test_recipe_lm_scorer_search_vs_oracle():
     assert hyps_nolm != hyps_ref  # the LM is not a no-op in this test
 
 
+def test_recipe_test_search_beam66_vs_oracle():
+    """The recipe's test_search at full width (conformer_large.yaml:241-251: beam 66, TransformerLM 0.6 +
+    CTC 0.4, temperature 1.15) on Conformer-L: radix-select top-k, CTC tables in 5 tiles of 16 beams,
+    LM K/V cache for 66 hypotheses -- bit-exact token ids and the top-3 list vs the oracle."""
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder, TransformerLMScorer
+    from speechbrain_amd.inference.builders import oracle_state_dict
+    from speechbrain_amd.lobes.models.transformer.TransformerLM import TransformerLM
+
+    asr = _asr("L", beam_size=10, ctc_weight=0.4)
+    fc, mc = _oracle_cfg("L")
+    torch.manual_seed(12)
+    lm = TransformerLM(vocab=5000, d_model=768, nhead=12, num_encoder_layers=12, num_decoder_layers=0, d_ffn=3072,
+                       dropout=0.0, activation=torch.nn.GELU, normalize_before=False).cuda().eval()
+    with torch.no_grad():
+        asr.mods.seq_lin.w.weight.mul_(8.0)
+        asr.mods.ctc_lin.w.weight.mul_(8.0)
+        lm.output_proj.layers[2].w.weight.mul_(4.0)
+    lcfg = O.LMCfg(vocab=5000, d_model=768, nhead=12, num_encoder_layers=12, d_ffn=3072)
+    sd = oracle_state_dict(asr)
+    sd.update({"LM." + k: v.detach().cpu() for k, v in lm.state_dict().items()})
+    n = 2 * 16000
+    wav = 0.1 * torch.randn(1, n, generator=torch.Generator().manual_seed(8))
+    lens = torch.ones(1)
+    enc_ref = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
+    T = enc_ref.shape[1]
+    scorer = ScorerBuilder(full_scorers=[TransformerLMScorer(language_model=lm, temperature=1.15),
+                                         CTCScorer(ctc_fc=asr.mods.ctc_lin, blank_index=0, eos_index=2)],
+                           weights={"transformerlm": 0.6, "ctc": 0.4})
+    kw = dict(modules=[asr.mods.transformer, asr.mods.seq_lin], bos_index=1, eos_index=2, min_decode_ratio=0.0,
+              max_decode_ratio=6.5 / T, beam_size=66, using_eos_threshold=False, length_normalization=True,
+              temperature=1.15, scorer=scorer)
+    hyps, _, scores, _ = S2STransformerBeamSearcher(**kw)(enc_ref.cuda(), lens.cuda())
+    ocfg = O.SearchCfg(beam=66, ctc_weight=0.4, max_decode_ratio=6.5 / T, temperature=1.15, lm_weight=0.6,
+                       lm_temperature=1.15)
+    hyps_ref, _, scores_ref, _ = O.beam_search(enc_ref, lens, sd, mc, ocfg, lm_cfg=lcfg)
+    assert hyps == hyps_ref
+    assert float((scores.cpu() - scores_ref).abs().max()) <= 2e-3
+    import dataclasses
+    k_hyps, _, k_scores, _ = S2STransformerBeamSearcher(**kw, return_topk=True, topk=3)(enc_ref.cuda(), lens.cuda())
+    o_hyps, _, o_scores, _ = O.beam_search(enc_ref, lens, sd, mc, dataclasses.replace(ocfg, return_topk=True, topk=3),
+                                           lm_cfg=lcfg)
+    assert torch.equal(k_hyps.cpu(), o_hyps)
+    assert float((k_scores.cpu() - o_scores).abs().max()) <= 2e-3
+
+
 def test_greedy_beam1_bit_exact_tokens_conformer_l():
     """North-star: bit-exact token ids at greedy / beam = 1 (peaked heads, see above)."""
     from speechbrain_amd.decoders import S2STransformerBeamSearcher, S2STransformerGreedySearcher
