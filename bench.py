@@ -8,7 +8,7 @@ Workload (BASELINE.json configs[2], "Full Conformer-L enc-dec + S2STransformerBe
 beam=10, LibriSpeech-shape synthetic"): Conformer-L (d 512, 12 enc / 6 dec layers, 5000 tokens,
 RelPosMHAXL), beam 10 + CTC weight 0.4 (the recipe's valid_search), seeded random weights,
 synthetic 16 kHz audio 0.1*randn, utterance durations U(5,30) s (seed 1234), duration-sorted
-batches of 64 utterances (sized for 288 GB of HBM; --batch 32 gives the recipe-sized batches), a
+batches of 128 utterances (sized for 288 GB of HBM; --batch 32 gives the recipe-sized batches), a
 few batches in flight on separate HIP streams (--streams).  One "step" = one batch through
 Fbank -> norm -> CNN -> Conformer encoder -> beam search -> token ids on the host.  Random weights never emit EOS, so the number of decoding steps is
 fixed through max_decode_ratio to round(4 tokens/s * seconds).
@@ -185,9 +185,9 @@ def cpu_baseline(asr, seconds=6.0, batch=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per duration-sorted batch (32 = the recipe-sized batches)")
+    ap.add_argument("--batch", type=int, default=128, help="utterances per duration-sorted batch (32 = the recipe-sized batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--latency-runs", type=int, default=5)
