@@ -364,7 +364,9 @@ template <int BM, int BN, int BK, int WM, int WN>
 int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
   dim3 grid(sbk::cdiv(g.N, BN), sbk::cdiv(g.M, BM));
   dim3 block((BM / WM) * (BN / WN) * 64);
-  static const char* kName = BM == 128 ? "gemm_nt_128x128" : (BM == 64 ? "gemm_nt_64x64" : "gemm_nt_32x64");
+  static const char* kName = (BM == 256 && BN == 128) ? (WM == 128 ? "gemm_nt_256x128w" : "gemm_nt_256x128")
+                             : (BM == 128 && BN == 256) ? "gemm_nt_128x256"
+                             : BM == 128 ? "gemm_nt_128x128" : (BM == 64 ? "gemm_nt_64x64" : "gemm_nt_32x64");
   sbk::ProfScope prof(kName, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N), st);
   if (vec) {
     SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, true>), grid, block, 0, st, g);
@@ -379,6 +381,8 @@ int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
 namespace sbk {
 int g_skinny_nch = 0;  // tuning knob (0 = automatic): K chunks fetched per batch by the skinny kernel
 int g_skinny_off = 0;  // tuning knob: 1 = route few-row GEMMs to the LDS-tiled kernels
+int g_gemm_tile = 0;   // tuning knob (key 6) for the large-M path: 0 = 128x128, 1 = 256x128 (8 waves of 64x64),
+                       // 2 = 128x256 (8 waves), 3 = 256x128 (4 waves of 128x64)
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
 // Internal C++ entry shared with the fused pipelines (decoder step, encoder).
@@ -451,6 +455,10 @@ int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
   // Tile choice: keep >= ~1 workgroup per CU where the problem allows it.
   const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
   const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
+  const bool big = tiles128 >= 768 || (g_gemm_tile & 16);  // +16: take the variant at any size (tests)
+  if (big && (g_gemm_tile & 15) == 1) return launch_gemm<256, 128, 32, 64, 64>(g, vec, st);
+  if (big && (g_gemm_tile & 15) == 2) return launch_gemm<128, 256, 32, 64, 64>(g, vec, st);
+  if (big && (g_gemm_tile & 15) == 3) return launch_gemm<256, 128, 32, 128, 64>(g, vec, st);
   if (tiles128 >= 384) return launch_gemm<128, 128, 32, 64, 64>(g, vec, st);
   if (tiles64 >= 256 || M > 256) return launch_gemm<64, 64, 32, 32, 32>(g, vec, st);
   return launch_gemm<32, 64, 32, 32, 32>(g, vec, st);
@@ -525,4 +533,5 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 3) sbk::g_attn_prefetch = value;
   if (key == 4) sbk::g_cross_rows = value;
   if (key == 5) sbk::g_kv_head_major = value;
+  if (key == 6) sbk::g_gemm_tile = value;
 }

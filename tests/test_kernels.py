@@ -37,6 +37,25 @@ def test_gemm_bias_act_residual(backend, M, N, K):
         assert _md(out, ref) <= 2e-6 * scale + 1e-5
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_gemm_large_tile_variants(backend, tile):
+    """The 256x128 / 128x256 tilings of the large-M path (tuning knob 6), forced at a small ragged shape."""
+    nat, dev = backend
+    M, N, K = 5000, 300, 72  # > 4096 rows: past the skinny path; ragged in every dimension
+    g = torch.Generator().manual_seed(tile)
+    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.001
+    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = r + 0.5 * F.silu(a.double() @ w.double().t() + b).float()
+    scale = float((a.abs() @ w.abs().t()).max())
+    nat.load().sbk_prof_set_knob(6, 16 + tile)
+    try:
+        out = nat.gemm_nt(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_SWISH, alpha=0.5)
+    finally:
+        nat.load().sbk_prof_set_knob(6, 0)
+    assert _md(out, ref) <= 2e-6 * scale + 1e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(320, 96, 128), (40, 70, 64), (512, 33, 192), (20, 130, 512), (320, 512, 2048)])
 def test_gemm_skinny_splitk(backend, M, N, K):
     """Decoder-step shapes: register-fed skinny kernel, with and without split-K partials."""
@@ -150,6 +169,11 @@ def test_relpos_attention(backend, B, T, H, Dh, lens, prefetch):
                                      None if kl is None else kl.to(dev), H, 1 / math.sqrt(d), want_attn=True)
     assert _md(out, ref) <= 5e-6
     assert float((attn.sum(-1) - 1).abs().max()) <= 1e-5
+    # without the weights output the strip-free (online-softmax) kernel runs
+    out2, none = nat.relpos_attention(qkv, P, sd["pos_bias_u"].reshape(-1).contiguous().to(dev),
+                                      sd["pos_bias_v"].reshape(-1).contiguous().to(dev),
+                                      None if kl is None else kl.to(dev), H, 1 / math.sqrt(d), want_attn=False)
+    assert none is None and _md(out2, ref) <= 5e-6
     if lens is not None:  # masked keys carry exactly zero weight
         for b, n in enumerate(lens):
             assert float(attn[b, :, :, n:].abs().max()) == 0.0 if n < T else True
@@ -181,8 +205,11 @@ def test_rope_attention(backend, B, T, H, Dh, lens, prefetch):
     qkv = nat.gemm_nt(x.to(dev), sd["in_proj_weight"].to(dev))
     out, attn = nat.rope_attention(qkv, tab.cosines.to(dev), tab.sines.to(dev), None if kl is None else kl.to(dev), H,
                                    1 / math.sqrt(d), want_attn=True)
+    out2, _ = nat.rope_attention(qkv, tab.cosines.to(dev), tab.sines.to(dev), None if kl is None else kl.to(dev), H,
+                                 1 / math.sqrt(d), want_attn=False)  # strip-free kernel
     nat.load().sbk_prof_set_knob(3, 0)
     assert _md(out, ref) <= 5e-6
+    assert _md(out2, ref) <= 5e-6
     assert float((attn.sum(-1) - 1).abs().max()) <= 1e-5
 
 

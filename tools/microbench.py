@@ -64,7 +64,7 @@ if __name__ == "__main__":
             P = torch.randn(2 * T - 1, d, device=dev)
             u = torch.randn(d, device=dev) * 0.1
             kl = torch.full((B,), T, dtype=torch.int32, device=dev)
-            for pf in (2, 3, 4, 5):  # 2: 4 waves, 3: 4 waves + prefetch, 4: 8 waves, 5: 8 waves + prefetch
+            for pf in (0, 8):  # 0: strip-free online-softmax kernel; 8: score-strip kernel (default schedule)
                 nat.load().sbk_prof_set_knob(3, pf)
                 t_rel = timeit(lambda: nat.relpos_attention(qkv, P, u, u, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
                 t_rope = timeit(lambda: nat.rope_attention(qkv, tab.cosines, tab.sines, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
@@ -81,6 +81,15 @@ if __name__ == "__main__":
                 nat.load().sbk_prof_set_knob(2, 1)
                 gemm_case(M, N, K, 8)
         nat.load().sbk_prof_set_knob(2, 0)
+        sys.exit(0)
+    if "--enc-gemm" in sys.argv:  # encoder GEMM shapes (M = B*T'), tile variants of the large-M path
+        for tile in (0, 1, 2, 3):
+            nat.load().sbk_prof_set_knob(6, tile)
+            print("tile variant", tile)
+            for (M, N, K) in [(16384, 2048, 512), (16384, 512, 2048), (56064, 2048, 512), (56064, 512, 2048),
+                              (56064, 1536, 512), (56064, 512, 512), (56064, 1024, 512)]:
+                gemm_case(M, N, K, 0)
+        nat.load().sbk_prof_set_knob(6, 0)
         sys.exit(0)
     if "--ctc" in sys.argv:
         for (B, T) in [(32, 251), (32, 440), (32, 751), (8, 440)]:
