@@ -155,7 +155,7 @@ struct CtcStepArgs {
 // P [B,T,V] masked linear posteriors; sg [n_bh,T] / se [n_bh,nseg] segment-scaled gamma tables
 // (uniform per workgroup: fetched through the scalar cache); am [n_bh,V] acoustic log-probs
 // (already * attn weight); outputs comb = am' + w * (psi - psi_prev) and psi, both [n_bh,V].
-template <int NB>
+template <int NB, int TPT>  // beams per tile in registers; tokens per thread (each table read feeds NB*TPT FMAs)
 __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, const float* __restrict__ P,
                                                              const BF* __restrict__ st, const float* __restrict__ sg,
                                                              const int* __restrict__ se,
@@ -165,10 +165,15 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   SBK_DYN_LDS(float, lds);
   const int b = blockIdx.y;
   const int j0 = blockIdx.z * BP, bp = beam_pitch(a.beam);
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const bool c_ok = c < a.V;
-  const int cc = c_ok ? c : a.V - 1;
   const int T = a.T, V = a.V;
+  int c[TPT], cc[TPT];
+  bool c_ok[TPT];
+#pragma unroll
+  for (int k = 0; k < TPT; ++k) {
+    c[k] = (blockIdx.x * TPT + k) * 256 + threadIdx.x;
+    c_ok[k] = c[k] < V;
+    cc[k] = c_ok[k] ? c[k] : V - 1;
+  }
   const int nseg = nseg_of(T);
   const int start = a.prefix_len > 1 ? a.prefix_len : 1;
   const float* Pb = P + (size_t)b * T * V;
@@ -187,40 +192,46 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   __syncthreads();
 
   // The prefix score of h = g.c needs only g's state:  psi = log( r_init + sum_t phi_g[t-1] * P_c[t] )
-  // (ctc.py:212-229).  Block-float accumulator per beam: value = mps * 2^Eps.  (beam <= NB; table
+  // (ctc.py:212-229).  Block-float accumulator per (token, beam): value = mps * 2^Eps.  (beam <= NB; table
   // columns past `beam` are zero, so the surplus accumulators idle harmlessly.)
-  float mps[NB];
-  int Eps[NB];
-  const float p0 = Pb[cc];
+  float mps[TPT][NB];
+  int Eps[TPT][NB];
+  float part[TPT][NB];
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    // psi_init = r[start-1][nb]: x[0] (non-blank) at the very first step, nothing otherwise (ctc.py:168-172,212)
-    const bool first = a.prefix_len == 0 && p0 > 0.0f;
-    mps[j] = first ? p0 : 0.0f;
-    Eps[j] = first ? 0 : kNegE;
+  for (int k = 0; k < TPT; ++k) {
+    const float p0 = Pb[cc[k]];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      // psi_init = r[start-1][nb]: x[0] (non-blank) at the very first step, nothing otherwise (ctc.py:168-172,212)
+      const bool first = a.prefix_len == 0 && p0 > 0.0f;
+      mps[k][j] = first ? p0 : 0.0f;
+      Eps[k][j] = first ? 0 : kNegE;
+      part[k][j] = 0.0f;
+    }
   }
-  // phi[t-1] * P[t]: frame t uses table entry u = t-1.  Chunks of 16 table entries (two per 32-entry
-  // scale segment); the emission values of the NEXT chunk are requested before the current chunk is
-  // accumulated, so two chunks (32 rows) are in flight per lane.
-  constexpr int CH = 16;
+  // phi[t-1] * P[t]: frame t uses table entry u = t-1.  Chunks of CH table entries; the emission values of
+  // the NEXT chunk are requested before the current chunk is accumulated (two chunks in flight per lane).
+  constexpr int CH = 16 / TPT < 8 ? 8 : 16 / TPT;
+  static_assert(kSeg % CH == 0, "ctc_score_step: chunks must tile a scale segment");
   const int u_begin = start - 1, u_end = T - 1;
-  auto fetch = [&](float (&buf)[CH], int cb) {
+  auto fetch = [&](float (&buf)[TPT][CH], int cb) {
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
       const int u = cb + q;
-      buf[q] = (u >= u_begin && u < u_end) ? Pb[(size_t)(u + 1) * V + cc] : 0.0f;
+      const bool ok = u >= u_begin && u < u_end;
+#pragma unroll
+      for (int k = 0; k < TPT; ++k) buf[k][q] = ok ? Pb[(size_t)(u + 1) * V + cc[k]] : 0.0f;
     }
   };
-  float part[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) part[j] = 0.0f;
-  float nxt[CH];
+  float nxt[TPT][CH];
   int cb = (u_begin / CH) * CH;
   if (cb < u_end) fetch(nxt, cb);
   for (; cb < u_end; cb += CH) {
-    float cur[CH];
+    float cur[TPT][CH];
 #pragma unroll
-    for (int q = 0; q < CH; ++q) cur[q] = nxt[q];
+    for (int k = 0; k < TPT; ++k)
+#pragma unroll
+      for (int q = 0; q < CH; ++q) cur[k][q] = nxt[k][q];
     if (cb + CH < u_end) fetch(nxt, cb + CH);
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
@@ -232,34 +243,41 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
         g[4 * v] = t4.x; g[4 * v + 1] = t4.y; g[4 * v + 2] = t4.z; g[4 * v + 3] = t4.w;
       }
 #pragma unroll
-      for (int j = 0; j < NB; ++j) part[j] = fmaf(g[j], cur[q], part[j]);
+      for (int k = 0; k < TPT; ++k)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) part[k][j] = fmaf(g[j], cur[k][q], part[k][j]);
     }
     if (((cb + CH) % kSeg) == 0 || cb + CH >= u_end) {  // end of a scale segment: fold into the block-float sum
       const int* es = segs + (cb / kSeg) * BP;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const int k = sbk::frexp_exp(part[j]);
-        const int ep = part[j] > 0.0f ? es[j] + k : kNegE;
-        const float mp = sbk::fast_ldexp(part[j], -k);
-        const int P2 = max(Eps[j], ep);
-        mps[j] = sbk::fast_ldexp(mps[j], Eps[j] - P2) + sbk::fast_ldexp(mp, ep - P2);
-        Eps[j] = P2;
-        part[j] = 0.0f;
-      }
+      for (int k = 0; k < TPT; ++k)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int kx = sbk::frexp_exp(part[k][j]);
+          const int ep = part[k][j] > 0.0f ? es[j] + kx : kNegE;
+          const float mp = sbk::fast_ldexp(part[k][j], -kx);
+          const int P2 = max(Eps[k][j], ep);
+          mps[k][j] = sbk::fast_ldexp(mps[k][j], Eps[k][j] - P2) + sbk::fast_ldexp(mp, ep - P2);
+          Eps[k][j] = P2;
+          part[k][j] = 0.0f;
+        }
     }
   }
-  if (!c_ok) return;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    if (j0 + j < a.beam) {
-      const int n = b * a.beam + j0 + j;
-      float psi = bf_log(mps[j], Eps[j]);
-      if (c == a.eos) {  // psi[eos] = log-sum of the prefix' own variables at the last frame (ctc.py:232-235)
-        const BF s = st[(size_t)n * T + last_frame];
-        psi = bf_log(s.mg, s.eg);
+  for (int k = 0; k < TPT; ++k) {
+    if (!c_ok[k]) continue;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (j0 + j < a.beam) {
+        const int n = b * a.beam + j0 + j;
+        float psi = bf_log(mps[k][j], Eps[k][j]);
+        if (c[k] == a.eos) {  // psi[eos] = log-sum of the prefix' own variables at the last frame (ctc.py:232-235)
+          const BF s = st[(size_t)n * T + last_frame];
+          psi = bf_log(s.mg, s.eg);
+        }
+        if (c[k] == a.blank && a.eos != a.blank) psi = kNeg;
+        psi_out[(size_t)n * V + c[k]] = psi;
       }
-      if (c == a.blank && a.eos != a.blank) psi = kNeg;
-      psi_out[(size_t)n * V + c] = psi;
     }
   }
 }
@@ -546,6 +564,7 @@ __global__ void __launch_bounds__(256) row_max_kernel(const float* __restrict__ 
 }  // namespace
 
 namespace sbk {
+int g_ctc_tpt = 2;  // tuning knob (sbk_prof_set_knob key 7): vocabulary entries per thread in ctc_score_step (1 or 2)
 
 namespace {
 struct StateView {
@@ -594,18 +613,30 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
   CtcStepArgs a{last_tok, enc_len, B, T, V, beam, prefix_len, blank, eos, 0.0f, 0, 0, 0.0f, 0.0f};
   const StateView v = view(const_cast<float*>(state), B, beam, T);
   ProfScope prof("ctc_score_step", 2.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 4.0 * B * beam * V, st);
-  dim3 grid(cdiv(V, 256), B, beam_pitch(beam) / 16), block(256);  // z: tiles of 16 beams (P is re-read per tile)
+  const int tpt = g_ctc_tpt;
+  dim3 grid(cdiv(V, 256 * tpt), B, beam_pitch(beam) / 16), block(256);  // z: tiles of 16 beams (P is re-read per tile)
   const size_t lds = ((size_t)T * 16 + (size_t)((T + kSeg - 1) / kSeg) * 16) * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "ctc_psi_step: T=%d too long for the LDS window", T);
+#define SBK_CTC_LAUNCH(NB)                                                                                              \
+  do {                                                                                                                  \
+    if (tpt == 2) {                                                                                                     \
+      SBK_LAUNCH((ctc_score_step_kernel<NB, 2>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg,       \
+                 (const int*)v.se, psi);                                                                                \
+    } else {                                                                                                            \
+      SBK_LAUNCH((ctc_score_step_kernel<NB, 1>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg,       \
+                 (const int*)v.se, psi);                                                                                \
+    }                                                                                                                   \
+  } while (0)
   if (beam == 1) {
-    SBK_LAUNCH((ctc_score_step_kernel<1>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
+    SBK_CTC_LAUNCH(1);
   } else if (beam <= 4) {
-    SBK_LAUNCH((ctc_score_step_kernel<4>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
+    SBK_CTC_LAUNCH(4);
   } else if (beam <= 10) {
-    SBK_LAUNCH((ctc_score_step_kernel<10>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
+    SBK_CTC_LAUNCH(10);
   } else {
-    SBK_LAUNCH((ctc_score_step_kernel<16>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
+    SBK_CTC_LAUNCH(16);
   }
+#undef SBK_CTC_LAUNCH
   int rc = launch_status("ctc_score_step");
   if (rc) return rc;
   SBK_LAUNCH(ctc_same_token_kernel, dim3(B * beam), dim3(64), 0, st, a, P, (const float*)v.sb, (const int*)v.se, psi);

@@ -480,6 +480,132 @@ __global__ void __launch_bounds__(256) cross_attn_rows_kernel(CrossAttnArgs a) {
   }
 }
 
+// MFMA formulation (head_dim 64 / 32): the frame-per-thread kernel above spends its time in the LDS pipe
+// (one broadcast read of q per FMA in the score pass, one read of every probability per beam and
+// frame in the context pass).  Here the score tile S[32 frames x 32 beams] = K . q^T is one chain of
+// v_mfma_f32_32x32x2 per wave with BOTH operands in registers (lane (r, half) holds the `half` side of
+// frame row r / of beam row r -- the same contiguous-run trick as csrc/gemm.hip), and the context
+// P . V feeds P from LDS once per MFMA step (16 frames x 32 beams per read) and V straight from L2 in
+// 128-byte rows.  Up to 32 beams per workgroup.
+constexpr int kQT2 = 32;
+
+template <int DH>
+__global__ void __launch_bounds__(256) cross_attn_mfma_kernel(CrossAttnArgs a) {
+  constexpr int DH2 = DH / 2, NC = DH / 32, NPART = 4 / NC;
+  static_assert(DH == 64 || DH == 32, "cross_attn_mfma: head_dim");
+  __shared__ float S[kQT2][kFC + 1];
+  __shared__ float red[3][kQT2][33];
+  __shared__ float mx[kQT2], sm[kQT2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & 31, half = lane >> 5;
+  const int split = blockIdx.x, h = blockIdx.y;
+  const int qtiles = (a.beam + kQT2 - 1) / kQT2;
+  const int b = blockIdx.z / qtiles, q0 = (blockIdx.z % qtiles) * kQT2;
+  const int nq = min(kQT2, a.beam - q0);
+  const int T = a.T, d = a.d;
+  const int klen = min(max(a.enc_len[b], 1), T);
+  const int per = ((klen + a.NS - 1) / a.NS + 3) & ~3;
+  const int t0 = split * per, t1 = min(klen, t0 + per);
+  const int nf = max(0, t1 - t0);
+  const KvView kvv = kv_view(a, b, h, DH);
+  const float* kvb = a.kv + kvv.base;
+
+  {  // scores of this wave's 32 frames against all beams
+    float kreg[DH2], qreg[DH2];
+    const int f = wave * 32 + jl;
+    const float* kp = kvb + (size_t)min(t0 + f, T - 1) * kvv.row + half * DH2;
+    const float* qp = a.q + ((size_t)b * a.beam + q0 + min(jl, nq - 1)) * d + h * DH + half * DH2;
+#pragma unroll
+    for (int s4 = 0; s4 < DH2; s4 += 4) {
+      const float4 kv4 = *reinterpret_cast<const float4*>(kp + s4);
+      const float4 qv4 = *reinterpret_cast<const float4*>(qp + s4);
+      kreg[s4] = kv4.x; kreg[s4 + 1] = kv4.y; kreg[s4 + 2] = kv4.z; kreg[s4 + 3] = kv4.w;
+      qreg[s4] = qv4.x; qreg[s4 + 1] = qv4.y; qreg[s4 + 2] = qv4.z; qreg[s4 + 3] = qv4.w;
+    }
+    const float qs = jl < nq ? a.scale : 0.0f;
+    sbk::f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < DH2; ++s) acc = sbk::mfma_32x32x2(kreg[s], qreg[s] * qs, acc);
+    // acc[r] = S[frame wave*32 + i(r)][beam jl]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int fr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (jl < nq && fr < nf) S[jl][fr] = acc[r];
+    }
+  }
+  __syncthreads();
+  for (int j = wave; j < nq; j += 4) {  // one wave per query row
+    float m = -INFINITY;
+    for (int f = lane; f < nf; f += 64) m = fmaxf(m, S[j][f]);
+    m = sbk::wave_max(m);
+    float sum = 0.0f;
+    for (int f = lane; f < nf; f += 64) {
+      const float e = expf(S[j][f] - m);
+      S[j][f] = e;
+      sum += e;
+    }
+    sum = sbk::wave_sum(sum);
+    if (a.NS == 1)
+      for (int f = lane; f < nf; f += 64) S[j][f] = S[j][f] / sum;
+    if (lane == 0) {
+      mx[j] = m;
+      sm[j] = sum;
+    }
+  }
+  __syncthreads();
+  {  // context: wave -> (32-column tile ct, frame range part)
+    const int ct = wave % NC, part = wave / NC;
+    const int span = kFC / NPART;
+    const int f_begin = part * span, f_end = min(nf, f_begin + span);
+    const float* vbase = kvb + kvv.voff + ct * 32 + jl;
+    sbk::f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+    for (int f0 = f_begin; f0 < f_end; f0 += 16) {  // 8 k-steps per round, their V rows requested together
+      float pv[8], vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = f0 + 2 * u + half;
+        const bool ok = f < f_end;
+        vv[u] = ok ? vbase[(size_t)min(t0 + f, T - 1) * kvv.row] : 0.0f;
+        pv[u] = (ok && jl < nq) ? S[jl][f] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o = sbk::mfma_32x32x2(pv[u], vv[u], o);
+    }
+    // o[r] = ctx[beam i(r)][column ct*32 + jl] over this wave's frames
+    if (part > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(part - 1) * NC + ct][(r & 3) + 8 * (r >> 2) + 4 * half][jl] = o[r];
+    }
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = o[r];
+#pragma unroll
+        for (int p = 1; p < NPART; ++p) v += red[(p - 1) * NC + ct][j][jl];
+        if (j < nq) {
+          const int c = ct * 32 + jl;
+          if (a.NS == 1) {
+            a.out[((size_t)b * a.beam + q0 + j) * d + h * DH + c] = v;
+          } else {
+            float* pp = a.part + ((((size_t)b * a.H + h) * a.NS + split) * a.beam + q0 + j) * (DH + 2);
+            pp[c] = v;
+            if (c == 0) {
+              pp[DH] = nf > 0 ? mx[j] : -INFINITY;
+              pp[DH + 1] = nf > 0 ? sm[j] : 0.0f;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // out[i, h*DH + c] = sum_s e^{m_s - M} o_s[c] / sum_s e^{m_s - M} l_s
 __global__ void __launch_bounds__(256) cross_merge_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int H, int NS, int beam, int DH, int d) {
@@ -508,8 +634,19 @@ template <int DH>
 int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
   const int qtiles = (a.beam + kQT - 1) / kQT;
   sbk::ProfScope prof("cross_attn_step", 4.0 * a.B * a.beam * (double)a.T * a.d, 8.0 * a.B * (double)a.T * a.d, st);
+  if constexpr (DH == 64 || DH == 32) {
+    if (sbk::g_cross_rows == 2 && (a.d % 4) == 0 && sbk::aligned16(a.kv) && sbk::aligned16(a.q)) {
+      const int qt2 = (a.beam + kQT2 - 1) / kQT2;
+      SBK_LAUNCH((cross_attn_mfma_kernel<DH>), dim3(a.NS, a.H, a.B * qt2), dim3(256), 0, st, a);
+      int rc2 = sbk::launch_status("cross_attn_step");
+      if (rc2 || a.NS == 1) return rc2;
+      SBK_LAUNCH(cross_merge_kernel, dim3(a.B * a.beam), dim3(256), 0, st, (const float*)a.part, a.out, a.H, a.NS,
+                 a.beam, DH, a.d);
+      return sbk::launch_status("cross_merge");
+    }
+  }
   if constexpr (DH == 64 || DH == 32 || DH == 16) {
-    if (sbk::g_cross_rows && (a.d % 4) == 0 && sbk::aligned16(a.kv) && sbk::aligned16(a.q)) {
+    if (sbk::g_cross_rows == 1 && (a.d % 4) == 0 && sbk::aligned16(a.kv) && sbk::aligned16(a.q)) {
       SBK_LAUNCH((cross_attn_rows_kernel<DH>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
     } else {
       SBK_LAUNCH((cross_attn_step_kernel<DH>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
@@ -554,7 +691,7 @@ namespace sbk {
 // Measured alternatives kept behind sbk_prof_set_knob (Conformer-L, B=64, MI355X; cross_attn_step total per
 // 8 batches): frame-per-thread kernel 247 ms with either layout; row-coalesced kernel 336 ms on [B,T,2d],
 // 306 ms on head-major [B,H,T,2*Dh].  The step is not HBM-bound at these sizes, so the defaults stay 0.
-int g_cross_rows = 0;     // key 4: row-coalesced cross-attention kernel
+int g_cross_rows = 2;     // key 4: 0 frame-per-thread kernel, 1 row-coalesced kernel, 2 MFMA kernel (head_dim 64 / 32)
 int g_kv_head_major = 0;  // key 5: cross K/V stored [B,H,T,2*Dh] instead of [B,T,2d]
 
 int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,

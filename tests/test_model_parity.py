@@ -281,10 +281,11 @@ def test_golden_rope_conformer(backend, tag):
 
 
 @pytest.mark.parametrize("nhead", [2, 4, 8])
-@pytest.mark.parametrize("rows,head_major", [(1, 1), (0, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("rows,head_major", [(2, 0), (2, 1), (1, 1), (0, 1), (1, 0), (0, 0)])
 def test_cross_attention_kernel_variants(backend, nhead, rows, head_major):
-    """Both cross-attention kernels (row-coalesced for head_dim 64/32/16, frame-per-thread otherwise) over a
-    memory of several splits with ragged lengths, through the KV-cached decoder vs the oracle."""
+    """The three cross-attention kernels (2: MFMA for head_dim 64/32, 1: row-coalesced for 64/32/16, 0:
+    frame-per-thread) and both K/V layouts over a memory of several splits with ragged lengths, through
+    the KV-cached decoder and a 5-beam search vs the oracle."""
     nat, dev = backend
     from speechbrain_amd.inference.builders import build_modules
 
@@ -315,7 +316,7 @@ def test_cross_attention_kernel_variants(backend, nhead, rows, head_major):
         pred = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev))
         hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))  # several beams per (utterance, head) workgroup
     finally:
-        nat.load().sbk_prof_set_knob(4, 0)
+        nat.load().sbk_prof_set_knob(4, 2)
         nat.load().sbk_prof_set_knob(5, 0)
     assert float((pred.cpu() - O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")).abs().max()) <= 5e-5
     hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=5, max_decode_ratio=ratio))
@@ -369,3 +370,25 @@ def test_from_hparams_local_model_directory(backend):
     assert words == [str(w) for w in exp["words"]]
     with pytest.raises(FileNotFoundError):
         EncoderDecoderASR.from_hparams(source="speechbrain/asr-conformer-transformerlm-librispeech")
+
+
+@pytest.mark.parametrize("tpt", [1, 2])
+def test_ctc_score_tokens_per_thread(backend, tpt):
+    """ctc_score_step with 1 and 2 vocabulary entries per thread (tuning knob 7): golden CTC beam search."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
+
+    g, mods = build("tiny_ctc", dev)
+    beam, ctc_w = int(g["cfg"][6]), float(g["cfgf"][0])
+    scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)],
+                           weights={"ctc": ctc_w})
+    bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                    min_decode_ratio=0.0, max_decode_ratio=1.0, beam_size=beam,
+                                    using_eos_threshold=False, length_normalization=True, scorer=scorer)
+    nat.load().sbk_prof_set_knob(7, tpt)
+    try:
+        hyps, _, scores, _ = bs(torch.from_numpy(g["enc_out"]).to(dev), torch.from_numpy(g["wav_lens"]).to(dev))
+    finally:
+        nat.load().sbk_prof_set_knob(7, 2)
+    assert hyps == hyps_of(g["beam_hyps"])
+    assert float((scores.cpu() - torch.from_numpy(g["beam_scores"])).abs().max()) <= 1e-4
