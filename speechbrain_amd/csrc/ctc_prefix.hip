@@ -155,6 +155,8 @@ struct CtcStepArgs {
 // P [B,T,V] masked linear posteriors; sg [n_bh,T] / se [n_bh,nseg] segment-scaled gamma tables
 // (uniform per workgroup: fetched through the scalar cache); am [n_bh,V] acoustic log-probs
 // (already * attn weight); outputs comb = am' + w * (psi - psi_prev) and psi, both [n_bh,V].
+// TPT = 4 takes FOUR CONSECUTIVE vocabulary entries per thread and reads the emissions as float4 (needs V % 4 == 0);
+// TPT = 1 / 2 take entries 256 apart with scalar loads.
 template <int NB, int TPT>  // beams per tile in registers; tokens per thread (each table read feeds NB*TPT FMAs)
 __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, const float* __restrict__ P,
                                                              const BF* __restrict__ st, const float* __restrict__ sg,
@@ -170,10 +172,11 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   bool c_ok[TPT];
 #pragma unroll
   for (int k = 0; k < TPT; ++k) {
-    c[k] = (blockIdx.x * TPT + k) * 256 + threadIdx.x;
+    c[k] = TPT == 4 ? (blockIdx.x * 256 + threadIdx.x) * 4 + k : (blockIdx.x * TPT + k) * 256 + threadIdx.x;
     c_ok[k] = c[k] < V;
     cc[k] = c_ok[k] ? c[k] : V - 1;
   }
+  const int c4 = c_ok[0] ? c[0] : V - 4;  // TPT = 4: base of this thread's float4 (V % 4 == 0)
   const int nseg = nseg_of(T);
   const int start = a.prefix_len > 1 ? a.prefix_len : 1;
   const float* Pb = P + (size_t)b * T * V;
@@ -219,8 +222,14 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
     for (int q = 0; q < CH; ++q) {
       const int u = cb + q;
       const bool ok = u >= u_begin && u < u_end;
+      if constexpr (TPT == 4) {
+        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v4 = *reinterpret_cast<const float4*>(Pb + (size_t)(u + 1) * V + c4);
+        buf[0][q] = v4.x; buf[1][q] = v4.y; buf[2][q] = v4.z; buf[3][q] = v4.w;
+      } else {
 #pragma unroll
-      for (int k = 0; k < TPT; ++k) buf[k][q] = ok ? Pb[(size_t)(u + 1) * V + cc[k]] : 0.0f;
+        for (int k = 0; k < TPT; ++k) buf[k][q] = ok ? Pb[(size_t)(u + 1) * V + cc[k]] : 0.0f;
+      }
     }
   };
   float nxt[TPT][CH];
@@ -564,7 +573,7 @@ __global__ void __launch_bounds__(256) row_max_kernel(const float* __restrict__ 
 }  // namespace
 
 namespace sbk {
-int g_ctc_tpt = 2;  // tuning knob (sbk_prof_set_knob key 7): vocabulary entries per thread in ctc_score_step (1 or 2)
+int g_ctc_tpt = 1;  // tuning knob (sbk_prof_set_knob key 7): vocabulary entries per thread in ctc_score_step (1, 2, 4)
 
 namespace {
 struct StateView {
@@ -613,13 +622,16 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
   CtcStepArgs a{last_tok, enc_len, B, T, V, beam, prefix_len, blank, eos, 0.0f, 0, 0, 0.0f, 0.0f};
   const StateView v = view(const_cast<float*>(state), B, beam, T);
   ProfScope prof("ctc_score_step", 2.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 4.0 * B * beam * V, st);
-  const int tpt = g_ctc_tpt;
+  const int tpt = (g_ctc_tpt == 4 && (V % 4 != 0 || !aligned16(P))) ? 1 : g_ctc_tpt;
   dim3 grid(cdiv(V, 256 * tpt), B, beam_pitch(beam) / 16), block(256);  // z: tiles of 16 beams (P is re-read per tile)
   const size_t lds = ((size_t)T * 16 + (size_t)((T + kSeg - 1) / kSeg) * 16) * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "ctc_psi_step: T=%d too long for the LDS window", T);
 #define SBK_CTC_LAUNCH(NB)                                                                                              \
   do {                                                                                                                  \
-    if (tpt == 2) {                                                                                                     \
+    if (tpt == 4) {                                                                                                     \
+      SBK_LAUNCH((ctc_score_step_kernel<NB, 4>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg,       \
+                 (const int*)v.se, psi);                                                                                \
+    } else if (tpt == 2) {                                                                                              \
       SBK_LAUNCH((ctc_score_step_kernel<NB, 2>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg,       \
                  (const int*)v.se, psi);                                                                                \
     } else {                                                                                                            \

@@ -690,8 +690,8 @@ __global__ void __launch_bounds__(256) log_softmax_row_kernel(const float* __res
 namespace sbk {
 // Measured alternatives kept behind sbk_prof_set_knob (Conformer-L, B=64, MI355X; cross_attn_step total per
 // 8 batches): frame-per-thread kernel 247 ms with either layout; row-coalesced kernel 336 ms on [B,T,2d],
-// 306 ms on head-major [B,H,T,2*Dh].  The step is not HBM-bound at these sizes, so the defaults stay 0.
-int g_cross_rows = 2;     // key 4: 0 frame-per-thread kernel, 1 row-coalesced kernel, 2 MFMA kernel (head_dim 64 / 32)
+// 306 ms on head-major [B,H,T,2*Dh]; at B=128 the MFMA formulation took 371 ms vs 301 ms.  The defaults stay 0.
+int g_cross_rows = 0;     // key 4: 0 frame-per-thread kernel, 1 row-coalesced kernel, 2 MFMA kernel (head_dim 64 / 32)
 int g_kv_head_major = 0;  // key 5: cross K/V stored [B,H,T,2*Dh] instead of [B,T,2d]
 
 int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,

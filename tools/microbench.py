@@ -91,6 +91,15 @@ if __name__ == "__main__":
                 gemm_case(M, N, K, 0)
         nat.load().sbk_prof_set_knob(6, 0)
         sys.exit(0)
+    if "--copy" in sys.argv:  # what a plain streaming kernel reaches on this box (calibrates the HBM rooflines)
+        for mb in (256, 1024, 4096):
+            x = torch.empty(mb * 1024 * 1024 // 4, device=dev).normal_()
+            y = torch.empty_like(x)
+            t_copy = timeit(lambda: y.copy_(x), n=20, warm=3)
+            t_read = timeit(lambda: x.sum(), n=20, warm=3)
+            print(f"copy {mb} MiB: {2 * x.numel() * 4 / t_copy / 1e6:7.2f} TB/s (read+write) | "
+                  f"sum-reduce read {x.numel() * 4 / t_read / 1e6:7.2f} TB/s", flush=True)
+        sys.exit(0)
     if "--ctc" in sys.argv:
         for (B, T) in [(32, 251), (32, 440), (32, 751), (8, 440)]:
             ctc_case(B, T, 5000, 10, 5)
