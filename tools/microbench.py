@@ -21,14 +21,14 @@ def timeit(fn, n=200, warm=20):
     return e0.elapsed_time(e1) / n * 1000.0  # us
 
 
-def gemm_case(M, N, K, slices):
+def gemm_case(M, N, K, slices, iters=200):
     a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev)
     ws = torch.empty(max(1, slices * M * N), device=dev)
     out = torch.empty(M, N, device=dev)
     lib = nat.load()
     us = ctypes.c_float(0)
     rc = lib.sbk_prof_gemm_repeat_f32(nat._p(a), nat._p(w), nat._p(out), M, N, K, nat._p(ws) if slices else None,
-                                      ws.numel() if slices else 0, 200, ctypes.byref(us), nat._stream(a))
+                                      ws.numel() if slices else 0, iters, ctypes.byref(us), nat._stream(a))
     assert rc == 0
     print(f"gemm M={M} N={N} K={K} slices={slices}: {us.value:8.2f} us  {2.0*M*N*K/us.value/1e6:7.2f} TFLOP/s", flush=True)
 
@@ -48,10 +48,15 @@ def ctc_case(B, T, V, beam, prefix_len):
 
 if __name__ == "__main__":
     if "--pmc-workload" in sys.argv:  # short, single-stream: the kernels whose HBM traffic is read from PMC counters
-        for (M, N, K) in [(320, 512, 512), (320, 1536, 512), (320, 2048, 512), (320, 512, 2048), (320, 5000, 512),
-                          (8032, 2048, 512), (8032, 512, 2048)]:
-            gemm_case(M, N, K, 8)
-        ctc_case(32, 440, 5000, 10, 5)
+        # encoder GEMMs of one Conformer-L layer at the bench's batch (M = 128 utterances x 438 frames)
+        for (M, N, K) in [(56064, 1536, 512), (56064, 512, 512), (56064, 2048, 512), (56064, 512, 2048),
+                          (56064, 2048, 512), (56064, 512, 2048), (56064, 1024, 512), (56064, 512, 512)]:
+            gemm_case(M, N, K, 0, iters=10)
+        # decode-step GEMMs at M = 128 x beam 10
+        for (M, N, K) in [(1280, 1536, 512), (1280, 512, 512), (1280, 512, 512), (1280, 512, 512), (1280, 2048, 512),
+                          (1280, 512, 2048), (1280, 5000, 512)]:
+            gemm_case(M, N, K, 8, iters=20)
+        ctc_case(128, 440, 5000, 10, 5)
         sys.exit(0)
     if "--attn" in sys.argv:  # encoder attention, both schedules of phase 1
         import math
