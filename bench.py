@@ -274,10 +274,11 @@ def main():
         results.extend((k * args.batch + i, h) for i, h in enumerate(hyps))
     if world > 1:  # token ids to rank 0: the path's only collective
         width = int(round(TOKENS_PER_SECOND * 30.0)) + 8  # same shape on every rank (durations <= 30 s)
-        buf = torch.zeros(len(results), width + 1, dtype=torch.int32, device=dev)
+        host = torch.zeros(len(results), width + 1, dtype=torch.int32)
         for r, (_, h) in enumerate(results):
-            buf[r, 0] = len(h)
-            buf[r, 1:1 + len(h)] = torch.tensor(h, dtype=torch.int32)
+            host[r, 0] = len(h)
+            host[r, 1:1 + len(h)] = torch.tensor(h, dtype=torch.int32)
+        buf = host.to(dev)  # one copy: [utterances, 1 + width] token ids of this rank
         gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
         dist.gather(buf, gathered, dst=0)
     barrier()
