@@ -625,18 +625,23 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
   const int tpt = (g_ctc_tpt == 4 && (V % 4 != 0 || !aligned16(P))) ? 1 : g_ctc_tpt;
   dim3 grid(cdiv(V, 256 * tpt), B, beam_pitch(beam) / 16), block(256);  // z: tiles of 16 beams (P is re-read per tile)
   const size_t lds = ((size_t)T * 16 + (size_t)((T + kSeg - 1) / kSeg) * 16) * sizeof(float);
-  if (lds > 64 * 1024) return fail(SBK_EINVAL, "ctc_psi_step: T=%d too long for the LDS window", T);
+  if (lds > 160 * 1024) return fail(SBK_EINVAL, "ctc_psi_step: T=%d frames need %zu B of LDS (max 160 KiB)", T, lds);
+  // utterances beyond ~39 s (T' > 990) need more than the default 64 KiB dynamic-LDS window
+#define SBK_CTC_LAUNCH_ONE(NB, TP)                                                                                      \
+  do {                                                                                                                  \
+    if (lds > 64 * 1024 && SBK_ALLOW_DYN_LDS((ctc_score_step_kernel<NB, TP>), lds) != hipSuccess)                        \
+      return fail(SBK_EINVAL, "ctc_psi_step: cannot raise the LDS window to %zu B", lds);                               \
+    SBK_LAUNCH((ctc_score_step_kernel<NB, TP>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg,        \
+               (const int*)v.se, psi);                                                                                  \
+  } while (0)
 #define SBK_CTC_LAUNCH(NB)                                                                                              \
   do {                                                                                                                  \
     if (tpt == 4) {                                                                                                     \
-      SBK_LAUNCH((ctc_score_step_kernel<NB, 4>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg,       \
-                 (const int*)v.se, psi);                                                                                \
+      SBK_CTC_LAUNCH_ONE(NB, 4);                                                                                        \
     } else if (tpt == 2) {                                                                                              \
-      SBK_LAUNCH((ctc_score_step_kernel<NB, 2>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg,       \
-                 (const int*)v.se, psi);                                                                                \
+      SBK_CTC_LAUNCH_ONE(NB, 2);                                                                                        \
     } else {                                                                                                            \
-      SBK_LAUNCH((ctc_score_step_kernel<NB, 1>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg,       \
-                 (const int*)v.se, psi);                                                                                \
+      SBK_CTC_LAUNCH_ONE(NB, 1);                                                                                        \
     }                                                                                                                   \
   } while (0)
   if (beam == 1) {
@@ -649,6 +654,7 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
     SBK_CTC_LAUNCH(16);
   }
 #undef SBK_CTC_LAUNCH
+#undef SBK_CTC_LAUNCH_ONE
   int rc = launch_status("ctc_score_step");
   if (rc) return rc;
   SBK_LAUNCH(ctc_same_token_kernel, dim3(B * beam), dim3(64), 0, st, a, P, (const float*)v.sb, (const int*)v.se, psi);

@@ -392,3 +392,28 @@ def test_ctc_score_tokens_per_thread(backend, tpt):
         nat.load().sbk_prof_set_knob(7, 1)
     assert hyps == hyps_of(g["beam_hyps"])
     assert float((scores.cpu() - torch.from_numpy(g["beam_scores"])).abs().max()) <= 1e-4
+
+
+def test_long_utterance_search_vs_oracle(backend):
+    """A 44 s utterance (T' = 1100 encoder frames): CTC tables beyond the default 64 KiB LDS window,
+    9 cross-attention splits -- beam search + CTC vs the oracle."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
+
+    g, mods = build("tiny_ctc", dev)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    d_model, nhead, d_ffn, n_enc, n_dec, vocab = [int(v) for v in g["cfg"][:6]]
+    cfg = O.ModelCfg(d_model=d_model, nhead=nhead, num_encoder_layers=n_enc, num_decoder_layers=n_dec, d_ffn=d_ffn,
+                     vocab=vocab)
+    enc = torch.randn(2, 1100, d_model, generator=torch.Generator().manual_seed(21))
+    wl = torch.tensor([1.0, 0.93])
+    ratio = 5.5 / 1100
+    scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)],
+                           weights={"ctc": 0.4})
+    bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                    min_decode_ratio=0.0, max_decode_ratio=ratio, beam_size=4,
+                                    using_eos_threshold=False, length_normalization=True, scorer=scorer)
+    hyps, _, scores, _ = bs(enc.to(dev), wl.to(dev))
+    hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=4, ctc_weight=0.4, max_decode_ratio=ratio))
+    assert hyps == hyps_ref
+    assert float((scores.cpu() - sc_ref).abs().max()) <= 1e-4
