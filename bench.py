@@ -91,7 +91,7 @@ class StreamWorkers:
         import copy
         from concurrent.futures import ThreadPoolExecutor
 
-        self.asr, self.n = asr, n
+        self.asr, self.n, self.dev = asr, n, dev
         self.streams = [torch.cuda.Stream(dev) for _ in range(n)]
         self.decoders = [copy.copy(asr.mods.decoder) for _ in range(n)]
         for d in self.decoders:  # with several batches in flight the GPU is already shared; keep each search on one stream
@@ -100,6 +100,7 @@ class StreamWorkers:
 
     def _work(self, slot, queue, batches):
         out = []
+        torch.cuda.set_device(self.dev)  # the current device is per host thread: rank r's workers launch on GPU r
         with torch.cuda.stream(self.streams[slot]):
             while True:
                 try:
