@@ -12,7 +12,7 @@ export TMPDIR=/tmp
   echo "== bench"; timeout 900 python bench.py --steps ${BENCH_STEPS:-6} --warmup 1 --verbose ${BENCH_ARGS:-} 2>&1 | tail -12
 } > gpurun_out/round.log 2>&1
 if [ "${PROFILE:-1}" = "1" ]; then
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r1 -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-roofline --latency-runs 0 > "$OLDPWD/gpurun_out/rocprof_run.log" 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r1 -- python "$OLDPWD/bench.py" --steps ${BENCH_STEPS:-6} --warmup 1 --streams 1 --no-cpu-baseline --no-roofline --latency-runs 0 > "$OLDPWD/gpurun_out/rocprof_run.log" 2>&1)
   find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/ \; 2>/dev/null
   ls -la /tmp/prof >> gpurun_out/rocprof_run.log 2>&1; find /tmp/prof | head -20 >> gpurun_out/rocprof_run.log
 fi
