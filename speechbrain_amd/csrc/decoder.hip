@@ -247,6 +247,23 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
   const KvView kvv = kv_view(a, b, h, DH);
   const float* kvb = a.kv + kvv.base;
 
+  // Every global operand of the workgroup is requested before the first barrier -- the K row of this
+  // thread's frame and the V values of this lane's channel for the wave's 32 frames -- so the phases
+  // below share ONE memory round trip (they used to pay one each: q, K, then four rounds of V).
+  const int f = tid & (kFC - 1), par = tid / kFC;  // 2 threads per frame, beams split by parity
+  float kr[DH];
+  {
+    const float* kp = kvb + (size_t)min(t0 + f, T - 1) * kvv.row;  // frames >= nf: loaded, never used
+#pragma unroll
+    for (int c = 0; c < DH; ++c) kr[c] = kp[c];
+  }
+  constexpr int VF = kFC / 4;  // frames per wave in the context pass (wave, wave + 4, ...)
+  float vpre[VF];
+  {
+    const float* vcol = kvb + kvv.voff + min(lane, DH - 1);
+#pragma unroll
+    for (int i = 0; i < VF; ++i) vpre[i] = vcol[(size_t)min(t0 + wave + 4 * i, T - 1) * kvv.row];
+  }
   for (int idx = tid; idx < kQT * DH; idx += 256) {
     const int j = idx / DH, c = idx % DH;
     qs[j][c] = j < nq ? a.q[((size_t)b * a.beam + q0 + j) * d + h * DH + c] * a.scale : 0.0f;
@@ -254,12 +271,7 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
   __syncthreads();
   // scores: per needs <= kFC (checked by the launcher)
   {
-    const int f = tid & (kFC - 1), par = tid / kFC;  // 2 threads per frame, beams split by parity
     if (f < nf) {
-      float kr[DH];
-      const float* kp = kvb + (size_t)(t0 + f) * kvv.row;
-#pragma unroll
-      for (int c = 0; c < DH; ++c) kr[c] = kp[c];
       for (int j = par; j < nq; j += 256 / kFC) {
         float s = 0.0f;
 #pragma unroll
@@ -288,27 +300,18 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
     }
   }
   __syncthreads();
-  {  // context: wave <-> quarter of the frames, lane <-> channel; 8 V rows in flight per lane
+  {  // context: wave <-> frames wave, wave + 4, ...; lane <-> channel; V already in registers
     float acc[kQT];
 #pragma unroll
     for (int j = 0; j < kQT; ++j) acc[j] = 0.0f;
     const int c = lane;
     if (c < DH) {
-      const float* vcol = kvb + (size_t)t0 * kvv.row + kvv.voff + c;
-      for (int f0 = wave; f0 < nf; f0 += 32) {
-        float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int f = f0 + 4 * u;
-          v[u] = f < nf ? vcol[(size_t)f * kvv.row] : 0.0f;
-        }
+      for (int i = 0; i < VF; ++i) {
+        const int fr = wave + 4 * i;
+        if (fr < nf) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int f = f0 + 4 * u;
-          if (f < nf) {
-#pragma unroll
-            for (int j = 0; j < kQT; ++j) acc[j] = fmaf(S[j][f], v[u], acc[j]);
-          }
+          for (int j = 0; j < kQT; ++j) acc[j] = fmaf(S[j][fr], vpre[i], acc[j]);
         }
       }
 #pragma unroll
@@ -510,6 +513,21 @@ __global__ void __launch_bounds__(256) cross_attn_mfma_kernel(CrossAttnArgs a) {
   const KvView kvv = kv_view(a, b, h, DH);
   const float* kvb = a.kv + kvv.base;
 
+  // context work of this wave: (32-column tile ct, frame range part).  Its V operands -- one value per
+  // lane and k-step -- are requested NOW, together with the K and q runs of the score pass, so the whole
+  // workgroup pays one memory round trip instead of one per phase.
+  constexpr int SPAN = kFC / NPART, VSTEPS = SPAN / 2;
+  const int ct = wave % NC, part = wave / NC;
+  const int f_begin = part * SPAN, f_end = min(nf, f_begin + SPAN);
+  float vall[VSTEPS];
+  {
+    const float* vbase = kvb + kvv.voff + ct * 32 + jl;
+#pragma unroll
+    for (int u = 0; u < VSTEPS; ++u) {
+      const int f = f_begin + 2 * u + half;
+      vall[u] = vbase[(size_t)min(t0 + f, T - 1) * kvv.row];  // rows >= f_end: loaded, multiplied by p = 0
+    }
+  }
   {  // scores of this wave's 32 frames against all beams
     float kreg[DH2], qreg[DH2];
     const int f = wave * 32 + jl;
@@ -555,25 +573,16 @@ __global__ void __launch_bounds__(256) cross_attn_mfma_kernel(CrossAttnArgs a) {
     }
   }
   __syncthreads();
-  {  // context: wave -> (32-column tile ct, frame range part)
-    const int ct = wave % NC, part = wave / NC;
-    const int span = kFC / NPART;
-    const int f_begin = part * span, f_end = min(nf, f_begin + span);
-    const float* vbase = kvb + kvv.voff + ct * 32 + jl;
+  {  // context: P (LDS) . V (registers since the top of the kernel)
     sbk::f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.0f;
-    for (int f0 = f_begin; f0 < f_end; f0 += 16) {  // 8 k-steps per round, their V rows requested together
-      float pv[8], vv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int f = f0 + 2 * u + half;
-        const bool ok = f < f_end;
-        vv[u] = ok ? vbase[(size_t)min(t0 + f, T - 1) * kvv.row] : 0.0f;
-        pv[u] = (ok && jl < nq) ? S[jl][f] : 0.0f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) o = sbk::mfma_32x32x2(pv[u], vv[u], o);
+    for (int u = 0; u < VSTEPS; ++u) {
+      const int f = f_begin + 2 * u + half;
+      const float pv = (f < f_end && jl < nq) ? S[jl][f] : 0.0f;
+      const float vv = f < f_end ? vall[u] : 0.0f;
+      o = sbk::mfma_32x32x2(pv, vv, o);
     }
     // o[r] = ctx[beam i(r)][column ct*32 + jl] over this wave's frames
     if (part > 0) {
