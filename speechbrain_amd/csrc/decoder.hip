@@ -247,23 +247,6 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
   const KvView kvv = kv_view(a, b, h, DH);
   const float* kvb = a.kv + kvv.base;
 
-  // Every global operand of the workgroup is requested before the first barrier -- the K row of this
-  // thread's frame and the V values of this lane's channel for the wave's 32 frames -- so the phases
-  // below share ONE memory round trip (they used to pay one each: q, K, then four rounds of V).
-  const int f = tid & (kFC - 1), par = tid / kFC;  // 2 threads per frame, beams split by parity
-  float kr[DH];
-  {
-    const float* kp = kvb + (size_t)min(t0 + f, T - 1) * kvv.row;  // frames >= nf: loaded, never used
-#pragma unroll
-    for (int c = 0; c < DH; ++c) kr[c] = kp[c];
-  }
-  constexpr int VF = kFC / 4;  // frames per wave in the context pass (wave, wave + 4, ...)
-  float vpre[VF];
-  {
-    const float* vcol = kvb + kvv.voff + min(lane, DH - 1);
-#pragma unroll
-    for (int i = 0; i < VF; ++i) vpre[i] = vcol[(size_t)min(t0 + wave + 4 * i, T - 1) * kvv.row];
-  }
   for (int idx = tid; idx < kQT * DH; idx += 256) {
     const int j = idx / DH, c = idx % DH;
     qs[j][c] = j < nq ? a.q[((size_t)b * a.beam + q0 + j) * d + h * DH + c] * a.scale : 0.0f;
@@ -271,7 +254,12 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
   __syncthreads();
   // scores: per needs <= kFC (checked by the launcher)
   {
+    const int f = tid & (kFC - 1), par = tid / kFC;  // 2 threads per frame, beams split by parity
     if (f < nf) {
+      float kr[DH];
+      const float* kp = kvb + (size_t)(t0 + f) * kvv.row;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) kr[c] = kp[c];
       for (int j = par; j < nq; j += 256 / kFC) {
         float s = 0.0f;
 #pragma unroll
@@ -300,18 +288,27 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
     }
   }
   __syncthreads();
-  {  // context: wave <-> frames wave, wave + 4, ...; lane <-> channel; V already in registers
+  {  // context: wave <-> quarter of the frames, lane <-> channel; 8 V rows in flight per lane
     float acc[kQT];
 #pragma unroll
     for (int j = 0; j < kQT; ++j) acc[j] = 0.0f;
     const int c = lane;
     if (c < DH) {
+      const float* vcol = kvb + (size_t)t0 * kvv.row + kvv.voff + c;
+      for (int f0 = wave; f0 < nf; f0 += 32) {
+        float v[8];
 #pragma unroll
-      for (int i = 0; i < VF; ++i) {
-        const int fr = wave + 4 * i;
-        if (fr < nf) {
+        for (int u = 0; u < 8; ++u) {
+          const int f = f0 + 4 * u;
+          v[u] = f < nf ? vcol[(size_t)f * kvv.row] : 0.0f;
+        }
 #pragma unroll
-          for (int j = 0; j < kQT; ++j) acc[j] = fmaf(S[j][fr], vpre[i], acc[j]);
+        for (int u = 0; u < 8; ++u) {
+          const int f = f0 + 4 * u;
+          if (f < nf) {
+#pragma unroll
+            for (int j = 0; j < kQT; ++j) acc[j] = fmaf(S[j][f], v[u], acc[j]);
+          }
         }
       }
 #pragma unroll
@@ -515,7 +512,8 @@ __global__ void __launch_bounds__(256) cross_attn_mfma_kernel(CrossAttnArgs a) {
 
   // context work of this wave: (32-column tile ct, frame range part).  Its V operands -- one value per
   // lane and k-step -- are requested NOW, together with the K and q runs of the score pass, so the whole
-  // workgroup pays one memory round trip instead of one per phase.
+  // workgroup pays one memory round trip instead of one per phase (371 -> 315 ms at B=128; the same
+  // hoisting made the frame-per-thread kernel slower, 303 -> 353 ms, and was not kept there).
   constexpr int SPAN = kFC / NPART, VSTEPS = SPAN / 2;
   const int ct = wave % NC, part = wave / NC;
   const int f_begin = part * SPAN, f_end = min(nf, f_begin + SPAN);
@@ -699,7 +697,7 @@ __global__ void __launch_bounds__(256) log_softmax_row_kernel(const float* __res
 namespace sbk {
 // Measured alternatives kept behind sbk_prof_set_knob (Conformer-L, B=64, MI355X; cross_attn_step total per
 // 8 batches): frame-per-thread kernel 247 ms with either layout; row-coalesced kernel 336 ms on [B,T,2d],
-// 306 ms on head-major [B,H,T,2*Dh]; at B=128 the MFMA formulation took 371 ms vs 301 ms.  The defaults stay 0.
+// 306 ms on head-major [B,H,T,2*Dh]; at B=128 the MFMA formulation takes 315 ms vs 303 ms.  The defaults stay 0.
 int g_cross_rows = 0;     // key 4: 0 frame-per-thread kernel, 1 row-coalesced kernel, 2 MFMA kernel (head_dim 64 / 32)
 int g_kv_head_major = 0;  // key 5: cross K/V stored [B,H,T,2*Dh] instead of [B,T,2d]
 
