@@ -394,7 +394,7 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   if (M == 0 || N == 0) return 0;
   // (measured, tools/microbench.py --attn --gemm: from ~1.9 M outputs with a short K the LDS-tiled kernels win:
   //  M=1280 N=1536 41.6 -> 27.6 us, M=640 N=5000 63 -> 46 us; a long K still needs the split of the skinny path)
-  const bool big_short = (long)M * N >= 1900000 && K <= 512;
+  const bool big_short = (long)M * N >= 1900000 && K <= 1024;  // (K = 768: the TransformerLM scorer's projections)
   const bool skinny_ok = !big_short && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < 256) && M <= 4096 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
   if (!skinny_ok || g_skinny_off) return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
   GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};

@@ -321,25 +321,38 @@ __global__ void __launch_bounds__(256, 2) relpos_flash_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[ct][r] = 0.0f;
 
+  // The position rows a key tile needs are r = rbase .. rbase+63 with rbase = T-1-i0-31+j0, so the upper
+  // half of one tile's rows is the lower half of the next tile's: G = (Q+v) P[rbase+32 ..]^T is computed
+  // ONCE and carried in registers to the next tile (one new 32-MFMA chain and one new P run per tile).
+  f32x16 gprev;
+  if constexpr (!ROPE) {
+    float p0reg[DH2];
+    const int prow0 = min(max((T - 1) - i0 - 31 + jl, 0), 2 * T - 2);
+    load_run<DH2>(p0reg, a.pos + (size_t)prow0 * d + h * DH + half * DH2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gprev[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < DH2; ++s) gprev = sbk::mfma_32x32x2(qv[s], p0reg[s], gprev);
+  }
   for (int kt = 0; kt < nkt; ++kt) {
     const int j0 = kt * 32;
-    float kreg[DH2], p0reg[DH2], p1reg[DH2];
+    float kreg[DH2], p1reg[DH2];
     {
       const int krow = min(j0 + jl, T - 1);
       load_run<DH2>(kreg, qkv_b + (size_t)krow * row3 + DH + half * DH2);
       if constexpr (ROPE) {
-        load_run<DH2>(p0reg, a.pos + (size_t)krow * DH + half * DH2);
+        float csreg[DH2];
+        load_run<DH2>(csreg, a.pos + (size_t)krow * DH + half * DH2);
         load_run<DH2>(p1reg, a.bias_u + (size_t)krow * DH + half * DH2);
 #pragma unroll
         for (int s2 = 0; s2 < DH2; s2 += 2) {
           const float k0 = kreg[s2], k1 = kreg[s2 + 1];
-          kreg[s2] = k0 * p0reg[s2] + k1 * p1reg[s2];
-          kreg[s2 + 1] = k1 * p0reg[s2 + 1] + k0 * p1reg[s2 + 1];
+          kreg[s2] = k0 * csreg[s2] + k1 * p1reg[s2];
+          kreg[s2 + 1] = k1 * csreg[s2 + 1] + k0 * p1reg[s2 + 1];
         }
       } else {
         const int rbase = (T - 1) - i0 - 31 + j0;
-        const int prow0 = min(max(rbase + jl, 0), 2 * T - 2), prow1 = min(max(rbase + 32 + jl, 0), 2 * T - 2);
-        load_run<DH2>(p0reg, a.pos + (size_t)prow0 * d + h * DH + half * DH2);
+        const int prow1 = min(max(rbase + 32 + jl, 0), 2 * T - 2);
         load_run<DH2>(p1reg, a.pos + (size_t)prow1 * d + h * DH + half * DH2);
       }
     }
@@ -365,19 +378,20 @@ __global__ void __launch_bounds__(256, 2) relpos_flash_kernel(AttnArgs a) {
     sbk::wave_sync();
     if constexpr (!ROPE) {
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < DH2; ++s) acc = sbk::mfma_32x32x2(qv[s], p1reg[s], acc);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {  // lower rows: carried from the previous tile; upper rows: just computed
         const int rl = pt * 32 + jl;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < DH2; ++s) acc = sbk::mfma_32x32x2(qv[s], pt == 0 ? p0reg[s] : p1reg[s], acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
           const int jloc = rl + i - 31;
-          if (jloc >= 0 && jloc < 32) S[i][jloc] += acc[r];
+          if (jloc >= 0 && jloc < 32) S[i][jloc] += pt == 0 ? gprev[r] : acc[r];
         }
       }
+      gprev = acc;
       sbk::wave_sync();
     }
     // online softmax: lane = (row jl, columns half*16 .. half*16+15)
