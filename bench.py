@@ -66,9 +66,11 @@ def set_decode_steps(asr, n_samples):
     return steps
 
 
-def run_step(asr, wav, lens, decoder=None):
+def run_step(asr, wav, lens, decoder=None, dec_stream=None):
     """One batch through the whole path.  `decoder` = a per-worker shallow copy of the searcher (shares
-    the weights; carries its own max_decode_ratio so that concurrent workers do not race on it)."""
+    the weights; carries its own max_decode_ratio so that concurrent workers do not race on it).
+    `dec_stream` = a HIGH-priority stream for the search: its short dependent kernels then get workgroup
+    slots ahead of the other workers' encoder GEMMs, which fill the gaps instead of queueing in front."""
     if decoder is None:
         set_decode_steps(asr, wav.shape[1])
         words, toks = asr.transcribe_batch(wav, lens)
@@ -78,7 +80,15 @@ def run_step(asr, wav, lens, decoder=None):
     decoder.max_decode_ratio = (steps + 0.5) / T
     with torch.no_grad():
         enc = asr.encode_batch(wav, lens)
-        toks, _, _, _ = decoder(enc, lens)
+        if dec_stream is None:
+            toks, _, _, _ = decoder(enc, lens)
+        else:
+            cur = torch.cuda.current_stream()
+            dec_stream.wait_stream(cur)
+            with torch.cuda.stream(dec_stream):
+                toks, _, _, _ = decoder(enc, lens)  # ends with the token ids on the host: dec_stream is drained
+            enc.record_stream(dec_stream)
+            cur.wait_stream(dec_stream)
     return toks
 
 
@@ -87,12 +97,14 @@ class StreamWorkers:
     release the GIL).  The decode steps of one batch are short, dependent kernels that cannot fill
     256 CUs; overlapping a few batches does."""
 
-    def __init__(self, asr, n, dev):
+    def __init__(self, asr, n, dev, prioritise_search=True):
         import copy
         from concurrent.futures import ThreadPoolExecutor
 
         self.asr, self.n, self.dev = asr, n, dev
         self.streams = [torch.cuda.Stream(dev) for _ in range(n)]
+        self.dec_streams = [torch.cuda.Stream(dev, priority=-1) if (prioritise_search and n > 1) else None
+                            for _ in range(n)]
         self.decoders = [copy.copy(asr.mods.decoder) for _ in range(n)]
         for d in self.decoders:  # with several batches in flight the GPU is already shared; keep each search on one stream
             d.overlap_ctc = 3 if n == 1 else 0
@@ -108,7 +120,7 @@ class StreamWorkers:
                 except Exception:
                     break
                 w, l = batches[k]
-                out.append((k, run_step(self.asr, w, l, self.decoders[slot])))
+                out.append((k, run_step(self.asr, w, l, self.decoders[slot], self.dec_streams[slot])))
             self.streams[slot].synchronize()
         return out
 
@@ -198,6 +210,8 @@ def main():
                     help="encoder attention (RelPosMHAXL = BASELINE.json's config; RoPEMHA = the in-tree recipe)")
     ap.add_argument("--lm", action="store_true",
                     help="add the recipe's TransformerLM scorer (12 x 768, weight 0.6, T=1.15): test_search at beam 10")
+    ap.add_argument("--no-search-priority", action="store_true",
+                    help="run each worker's search on its normal-priority stream (A/B of the stream priorities)")
     ap.add_argument("--knob", action="append", default=[], metavar="KEY=VALUE",
                     help="tuning switch passed to sbk_prof_set_knob (A/B measurements only)")
     ap.add_argument("--verbose", action="store_true")
@@ -257,7 +271,7 @@ def main():
     audio_sec = sum(sum(s) for _, _, s in pool)
 
     note(f"model built; {args.steps} batches resident; warm-up")
-    workers = StreamWorkers(asr, max(1, args.streams), dev)
+    workers = StreamWorkers(asr, max(1, args.streams), dev, prioritise_search=not args.no_search_priority)
     for w, l, _ in warm_dev:
         workers.run([(w, l)] * workers.n)  # every worker stream sizes its allocations on the longest batch
     note("timed region")
