@@ -9,7 +9,7 @@ beam=10, LibriSpeech-shape synthetic"): Conformer-L (d 512, 12 enc / 6 dec layer
 RelPosMHAXL), beam 10 + CTC weight 0.4 (the recipe's valid_search), seeded random weights,
 synthetic 16 kHz audio 0.1*randn, utterance durations U(5,30) s (seed 1234), duration-sorted
 batches of 128 utterances (sized for 288 GB of HBM; --batch 32 gives the recipe-sized batches), a
-few batches in flight on separate HIP streams (--streams).  One "step" = one batch through
+few batches in flight on separate HIP streams (--streams), each search on a high-priority stream.  One "step" = one batch through
 Fbank -> norm -> CNN -> Conformer encoder -> beam search -> token ids on the host.  Random weights never emit EOS, so the number of decoding steps is
 fixed through max_decode_ratio to round(4 tokens/s * seconds).
 Waveforms are resident in HBM when the timed region starts.  fp32 arithmetic throughout.
