@@ -66,81 +66,18 @@ def set_decode_steps(asr, n_samples):
     return steps
 
 
-def run_step(asr, wav, lens, decoder=None, dec_stream=None):
-    """One batch through the whole path.  `decoder` = a per-worker shallow copy of the searcher (shares
-    the weights; carries its own max_decode_ratio so that concurrent workers do not race on it).
-    `dec_stream` = a HIGH-priority stream for the search: its short dependent kernels then get workgroup
-    slots ahead of the other workers' encoder GEMMs, which fill the gaps instead of queueing in front."""
-    if decoder is None:
-        set_decode_steps(asr, wav.shape[1])
-        words, toks = asr.transcribe_batch(wav, lens)
-        return toks
-    T = frames_after_frontend(wav.shape[1])
-    steps = max(1, int(round(TOKENS_PER_SECOND * wav.shape[1] / 16000.0)))
-    decoder.max_decode_ratio = (steps + 0.5) / T
-    with torch.no_grad():
-        enc = asr.encode_batch(wav, lens)
-        if dec_stream is None:
-            toks, _, _, _ = decoder(enc, lens)
-        else:
-            cur = torch.cuda.current_stream()
-            dec_stream.wait_stream(cur)
-            with torch.cuda.stream(dec_stream):
-                toks, _, _, _ = decoder(enc, lens)  # ends with the token ids on the host: dec_stream is drained
-            enc.record_stream(dec_stream)
-            cur.wait_stream(dec_stream)
+def run_step(asr, wav, lens):
+    """One batch through the whole path on the current stream (latency case, instrumented pass)."""
+    set_decode_steps(asr, wav.shape[1])
+    words, toks = asr.transcribe_batch(wav, lens)
     return toks
 
 
-class StreamWorkers:
-    """Independent batches in flight on separate HIP streams (one host thread each; the C-ABI calls
-    release the GIL).  The decode steps of one batch are short, dependent kernels that cannot fill
-    256 CUs; overlapping a few batches does."""
-
-    def __init__(self, asr, n, dev, prioritise_search=True):
-        import copy
-        from concurrent.futures import ThreadPoolExecutor
-
-        self.asr, self.n, self.dev = asr, n, dev
-        self.streams = [torch.cuda.Stream(dev) for _ in range(n)]
-        self.dec_streams = [torch.cuda.Stream(dev, priority=-1) if (prioritise_search and n > 1) else None
-                            for _ in range(n)]
-        self.decoders = [copy.copy(asr.mods.decoder) for _ in range(n)]
-        for d in self.decoders:  # with several batches in flight the GPU is already shared; keep each search on one stream
-            d.overlap_ctc = 3 if n == 1 else 0
-        self.pool = ThreadPoolExecutor(n)
-
-    def _work(self, slot, queue, batches):
-        out = []
-        torch.cuda.set_device(self.dev)  # the current device is per host thread: rank r's workers launch on GPU r
-        with torch.cuda.stream(self.streams[slot]):
-            while True:
-                try:
-                    k = queue.get_nowait()
-                except Exception:
-                    break
-                w, l = batches[k]
-                out.append((k, run_step(self.asr, w, l, self.decoders[slot], self.dec_streams[slot])))
-            self.streams[slot].synchronize()
-        return out
-
-    def run(self, batches):
-        """batches: list of (wav, lens) on the device -> list of token lists, in order.  Workers pull
-        from one queue, longest batch first, so the streams finish together."""
-        import queue as _q
-
-        cur = torch.cuda.current_stream()
-        for s in self.streams:
-            s.wait_stream(cur)
-        q = _q.Queue()
-        for k in sorted(range(len(batches)), key=lambda i: -batches[i][0].numel()):
-            q.put(k)
-        futs = [self.pool.submit(self._work, slot, q, batches) for slot in range(min(self.n, len(batches)))]
-        res = {}
-        for f in futs:
-            for k, toks in f.result():
-                res[k] = toks
-        return [res[k] for k in range(len(batches))]
+def fixed_decode_length(searcher, wavs):
+    """`prepare` hook of ConcurrentTranscriber: decode steps = round(4 tok/s * padded seconds)."""
+    T = frames_after_frontend(wavs.shape[1])
+    steps = max(1, int(round(TOKENS_PER_SECOND * wavs.shape[1] / 16000.0)))
+    searcher.max_decode_ratio = (steps + 0.5) / T
 
 
 def cpu_threads():
@@ -271,9 +208,11 @@ def main():
     audio_sec = sum(sum(s) for _, _, s in pool)
 
     note(f"model built; {args.steps} batches resident; warm-up")
-    workers = StreamWorkers(asr, max(1, args.streams), dev, prioritise_search=not args.no_search_priority)
-    for w, l, _ in warm_dev:
-        workers.run([(w, l)] * workers.n)  # every worker stream sizes its allocations on the longest batch
+    from speechbrain_amd.inference.streams import ConcurrentTranscriber
+
+    workers = ConcurrentTranscriber(asr, streams=max(1, args.streams), prioritise_search=not args.no_search_priority)
+    for w, l, _ in warm_dev:  # every worker stream sizes its allocations on the longest batch
+        workers.transcribe_batches([(w, l)] * workers.n, prepare=fixed_decode_length)
     note("timed region")
 
     def barrier():
@@ -285,7 +224,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     results = []
-    for k, hyps in enumerate(workers.run([(w, l) for w, l, _ in pool_dev])):
+    for k, hyps in enumerate(workers.transcribe_batches([(w, l) for w, l, _ in pool_dev], prepare=fixed_decode_length)):
         results.extend((k * args.batch + i, h) for i, h in enumerate(hyps))
     if world > 1:  # token ids to rank 0: the path's only collective
         width = int(round(TOKENS_PER_SECOND * 30.0)) + 8  # same shape on every rank (durations <= 30 s)

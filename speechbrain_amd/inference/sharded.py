@@ -65,9 +65,11 @@ class ShardedTranscriber:
     """
 
     def __init__(self, transcribe_batch: Callable, device, max_utts: int = 32, max_padded_samples: Optional[int] = None,
-                 group=None):
+                 group=None, concurrent=None):
+        """``concurrent`` (optional): a ``speechbrain_amd.inference.streams.ConcurrentTranscriber``; the rank's
+        batches then run several at a time on separate HIP streams instead of one after the other."""
         self.fn, self.device, self.max_utts, self.max_padded = transcribe_batch, torch.device(device), max_utts, max_padded_samples
-        self.group = group
+        self.group, self.concurrent = group, concurrent
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -114,6 +116,10 @@ class ShardedTranscriber:
     # -- run + gather ------------------------------------------------------------
     def run_local(self, local):
         out = []
+        if self.concurrent is not None and len(local) > 1:
+            for (ids, _, _), hyps in zip(local, self.concurrent.transcribe_batches([(x, l) for _, x, l in local])):
+                out.extend(zip(ids, hyps))
+            return out
         for ids, x, lens in local:
             hyps = self.fn(x, lens)
             out.extend(zip(ids, hyps))
@@ -130,11 +136,12 @@ class ShardedTranscriber:
         dist.all_gather(all_cnt, cnt, group=self.group)
         rows = int(max(c[0] for c in all_cnt))
         W = int(max(c[1] for c in all_cnt))
-        buf = torch.full((max(rows, 1), W + 2), -1, dtype=torch.int32, device=self.device)
+        host = torch.full((max(rows, 1), W + 2), -1, dtype=torch.int32)
         for r, (i, h) in enumerate(results):
-            buf[r, 0], buf[r, 1] = i, len(h)
+            host[r, 0], host[r, 1] = i, len(h)
             if h:
-                buf[r, 2: 2 + len(h)] = torch.tensor(h, dtype=torch.int32, device=self.device)
+                host[r, 2: 2 + len(h)] = torch.tensor(h, dtype=torch.int32)
+        buf = host.to(self.device)  # one copy to the device before the collective
         gathered = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == 0 else None
         dist.gather(buf, gathered, dst=0, group=self.group)
         if self.rank != 0:

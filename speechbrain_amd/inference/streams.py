@@ -1,0 +1,92 @@
+"""Several utterance batches in flight on one MI355X.
+
+The search half of ``EncoderDecoderASR.transcribe_batch`` is a chain of ~65 short, dependent kernels
+per decoding step that cannot fill 256 CUs, while the encoder half is a few large GEMMs.  Running a
+handful of independent batches concurrently -- one host thread per batch in flight (the C-ABI calls
+release the GIL), the encoder on a normal-priority HIP stream and the search on a HIGH-priority one --
+lets the encoder GEMMs of one batch fill the gaps of another batch's search without queueing in front
+of its latency-critical kernels.  No state is shared between batches (utterances are
+independent), so the results are identical to sequential ``transcribe_batch`` calls.
+"""
+import copy
+import queue
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+
+class ConcurrentTranscriber:
+    """``transcribe_batches([(wavs, wav_lens), ...]) -> [token lists per batch]`` with up to ``streams``
+    batches in flight.  ``prepare(searcher, wavs)`` (optional) may adjust the per-worker copy of the
+    searcher before a batch (e.g. its decode-length ratios); the copies share the model weights."""
+
+    def __init__(self, asr, streams: int = 6, prioritise_search: bool = True):
+        self.asr, self.n, self.device = asr, max(1, int(streams)), asr.device
+        if self.device.type != "cuda":
+            self.n = 1
+        self.searchers = [copy.copy(asr.mods.decoder) for _ in range(self.n)]
+        for s in self.searchers:  # several batches already share the GPU: keep each search on one stream
+            if hasattr(s, "overlap_ctc"):
+                s.overlap_ctc = 3 if self.n == 1 else 0
+        if self.device.type == "cuda":
+            self.enc_streams = [torch.cuda.Stream(self.device) for _ in range(self.n)]
+            self.dec_streams = [torch.cuda.Stream(self.device, priority=-1) if (prioritise_search and self.n > 1) else None
+                                for _ in range(self.n)]
+        self.pool = ThreadPoolExecutor(self.n)
+
+    def _one(self, slot: int, wavs, wav_lens, prepare: Optional[Callable]):
+        searcher = self.searchers[slot]
+        if prepare is not None:
+            prepare(searcher, wavs)
+        with torch.no_grad():
+            wav_lens = wav_lens.to(self.device)
+            enc = self.asr.encode_batch(wavs, wav_lens)
+            dec_stream = self.dec_streams[slot] if self.device.type == "cuda" else None
+            if dec_stream is None:
+                toks, _, _, _ = searcher(enc, wav_lens)
+            else:
+                cur = torch.cuda.current_stream()
+                dec_stream.wait_stream(cur)
+                with torch.cuda.stream(dec_stream):
+                    toks, _, _, _ = searcher(enc, wav_lens)  # returns host token lists: dec_stream is drained
+                enc.record_stream(dec_stream)
+                cur.wait_stream(dec_stream)
+        return toks
+
+    def _work(self, slot: int, todo: "queue.Queue", batches, prepare):
+        out = []
+        if self.device.type != "cuda":
+            while True:
+                try:
+                    k = todo.get_nowait()
+                except queue.Empty:
+                    return out
+                out.append((k, self._one(slot, *batches[k], prepare)))
+        torch.cuda.set_device(self.device)  # the current device is per host thread
+        with torch.cuda.stream(self.enc_streams[slot]):
+            while True:
+                try:
+                    k = todo.get_nowait()
+                except queue.Empty:
+                    break
+                out.append((k, self._one(slot, *batches[k], prepare)))
+            self.enc_streams[slot].synchronize()
+        return out
+
+    def transcribe_batches(self, batches: Sequence[Tuple[torch.Tensor, torch.Tensor]],
+                           prepare: Optional[Callable] = None) -> List[list]:
+        """Workers pull from one queue, largest batch first, so that they finish together."""
+        if self.device.type == "cuda":
+            cur = torch.cuda.current_stream(self.device)
+            for s in self.enc_streams:
+                s.wait_stream(cur)
+        todo: "queue.Queue" = queue.Queue()
+        for k in sorted(range(len(batches)), key=lambda i: -batches[i][0].numel()):
+            todo.put(k)
+        futs = [self.pool.submit(self._work, slot, todo, batches, prepare) for slot in range(min(self.n, len(batches)))]
+        res = {}
+        for f in futs:
+            for k, toks in f.result():
+                res[k] = toks
+        return [res[k] for k in range(len(batches))]

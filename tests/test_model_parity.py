@@ -417,3 +417,32 @@ def test_long_utterance_search_vs_oracle(backend):
     hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=4, ctc_weight=0.4, max_decode_ratio=ratio))
     assert hyps == hyps_ref
     assert float((scores.cpu() - sc_ref).abs().max()) <= 1e-4
+
+
+def test_concurrent_transcriber_matches_sequential(backend):
+    """Several batches in flight (one host thread + normal / high-priority HIP streams per batch on the GPU;
+    sequential on the CPU emulator) give exactly the token ids of one-at-a-time transcribe_batch calls."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_asr
+    from speechbrain_amd.inference.streams import ConcurrentTranscriber
+
+    tiny = dict(d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=2, n_fft=512, win_length=32)
+    asr = build_asr(tiny, vocab=40, seed=3, beam_size=4, ctc_weight=0.4, device=str(dev), max_decode_ratio=0.5)
+    with torch.no_grad():
+        asr.mods.seq_lin.w.weight.mul_(6.0)
+        asr.mods.ctc_lin.w.weight.mul_(6.0)
+    gen = torch.Generator().manual_seed(5)
+    batches = []
+    for n, b in ((6400, 2), (9600, 3), (4800, 1), (8000, 2), (7200, 2)):
+        wav = 0.1 * torch.randn(b, n, generator=gen)
+        lens = torch.linspace(0.7, 1.0, b)
+        for i in range(b):
+            wav[i, int(lens[i] * n):] = 0
+        batches.append((wav.to(dev), lens.to(dev)))
+    ref = [asr.transcribe_batch(w, l)[1] for w, l in batches]
+    got = ConcurrentTranscriber(asr, streams=3).transcribe_batches(batches)
+    assert got == ref
+    seen = []
+    got2 = ConcurrentTranscriber(asr, streams=2, prioritise_search=False).transcribe_batches(
+        batches, prepare=lambda searcher, wavs: seen.append(wavs.shape[1]))
+    assert got2 == ref and sorted(seen) == sorted(w.shape[1] for w, _ in batches)
