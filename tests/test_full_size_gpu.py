@@ -252,3 +252,34 @@ def test_properties_at_bench_shape():
     for i in (0, 17, 31):
         w1, t1 = asr.transcribe_batch(wav[i:i + 1], lens[i:i + 1])
         assert t1[0] == toks[i]
+
+
+def test_batches_in_flight_match_sequential_conformer_l():
+    """The bench's execution mode at full model size: six batches in flight (host threads, normal- and
+    high-priority HIP streams, per-thread helper streams) must give exactly the token ids of sequential
+    transcribe_batch calls, and the same ids again on a second concurrent run (no cross-stream races)."""
+    from speechbrain_amd.inference.streams import ConcurrentTranscriber
+
+    asr = _asr("L", beam_size=10, ctc_weight=0.4)
+    asr.mods.decoder.check_every = 0
+    g = torch.Generator().manual_seed(33)
+    batches = []
+    for k, (B, sec) in enumerate([(24, 9.0), (16, 14.0), (32, 6.0), (8, 20.0), (16, 11.0), (24, 7.5), (12, 16.0)]):
+        n = int(sec * 16000)
+        wav = 0.1 * torch.randn(B, n, generator=g)
+        lens = torch.linspace(0.6, 1.0, B)
+        for i in range(B):
+            wav[i, int(lens[i] * n):] = 0
+        batches.append((wav.cuda(), lens.cuda()))
+
+    def fix_len(searcher, wavs):
+        T = ((1 + wavs.shape[1] // 160 - 1) // 2 + 1 - 1) // 2 + 1
+        searcher.max_decode_ratio = 20.5 / T
+
+    ref = []
+    for w, l in batches:
+        fix_len(asr.mods.decoder, w)
+        ref.append(asr.transcribe_batch(w, l)[1])
+    ct = ConcurrentTranscriber(asr, streams=6)
+    assert ct.transcribe_batches(batches, prepare=fix_len) == ref
+    assert ct.transcribe_batches(batches, prepare=fix_len) == ref
