@@ -240,6 +240,10 @@ typedef struct {
   int32_t topk; /* 0 / 1: the best hypothesis per utterance (last token stripped); > 1: return_topk
                    (seq2seq.py:757-760,1712) -- the outputs hold `topk` rows per utterance in descending
                    score order and keep their last token, like the reference's padded topk_hyps */
+  int32_t graph_mode; /* 0: one launch list per step; 1: the step counter lives in device memory and two
+                         consecutive steps are captured once into a hipGraph and replayed (single-stream
+                         latency; ignored with overlap_ctc, profiling or T > 900); 2: device-side counter
+                         with plain launches (what 1 falls back to) */
 } sbk_search_config;
 
 /* S2STransformerBeamSearcher.forward (seq2seq.py:1632-1723, :1853-1934) with an optional full

@@ -54,6 +54,8 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
+bool prof_enabled() { return g_prof_on; }
+
 ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t s) : slot(-1), st(s) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -20,6 +20,8 @@ struct ProfScope {
   hipStream_t st;
 };
 
+bool prof_enabled();  // per-launch timing is on (sbk_prof_enable)
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline hipStream_t as_stream(sbk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

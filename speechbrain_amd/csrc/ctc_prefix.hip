@@ -150,6 +150,8 @@ struct CtcStepArgs {
   int eos_floor;            // 1: step < min_decode_steps -> am[eos] = minus_inf
   int use_eos_threshold;
   float eos_threshold, minus_inf;
+  const int32_t* step_ptr;  // non-null: prefix_len / eos_floor come from the device-side step counter
+  int min_steps;
 };
 
 // P [B,T,V] masked linear posteriors; sg [n_bh,T] / se [n_bh,nseg] segment-scaled gamma tables
@@ -165,6 +167,7 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   constexpr int BP = 16;               // LDS row pitch = one tile of 16 beams (blockIdx.z selects the tile)
   constexpr int NV = (NB + 3) / 4;     // float4 per frame actually consumed
   SBK_DYN_LDS(float, lds);
+  if (a.step_ptr) a.prefix_len = a.step_ptr[0];
   const int b = blockIdx.y;
   const int j0 = blockIdx.z * BP, bp = beam_pitch(a.beam);
   const int T = a.T, V = a.V;
@@ -297,6 +300,7 @@ __global__ void __launch_bounds__(64) ctc_same_token_kernel(CtcStepArgs a, const
                                                             const float* __restrict__ sb, const int* __restrict__ se,
                                                             float* __restrict__ psi_out) {
   const int n = blockIdx.x, lane = threadIdx.x;
+  if (a.step_ptr) a.prefix_len = a.step_ptr[0];
   const int b = n / a.beam, c = a.last_tok[n];
   const int T = a.T, V = a.V, nseg = nseg_of(T);
   if (c == a.eos || c == a.blank || c < 0 || c >= V) return;  // those entries are overridden anyway
@@ -338,7 +342,7 @@ __global__ void __launch_bounds__(256) ctc_combine_kernel(CtcStepArgs a, const f
   if (c >= a.V) return;
   float v = am[(size_t)n * a.V + c];
   if (c == a.eos) {
-    if (a.eos_floor) v = a.minus_inf;
+    if (a.step_ptr ? a.step_ptr[0] < a.min_steps : a.eos_floor) v = a.minus_inf;
     if (a.use_eos_threshold && !(v > a.eos_threshold * am_max[n])) v = a.minus_inf;
   }
   if (extra) v += extra[(size_t)n * a.V + c];  // full scorers listed before "ctc" (already weighted)
@@ -446,10 +450,12 @@ struct CtcAdvArgs {
   int* se_new;
   float* psi_prev_new;
   int n_bh, T, V, beam, prefix_len, blank;
+  const int32_t* step_ptr;
 };
 
 __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
   SBK_DYN_LDS(float, lds);
+  if (a.step_ptr) a.prefix_len = a.step_ptr[0];
   const int T = a.T;
   float* pc = lds;              // [T] P[t][token]
   float* pb = pc + T;           // [T] P[t][blank]
@@ -546,13 +552,14 @@ __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
 __global__ void __launch_bounds__(256) am_only_kernel(const float* __restrict__ am, float* __restrict__ comb, int V,
                                                       int eos, int eos_floor, int use_thr, float thr, float minus_inf,
                                                       const float* __restrict__ am_max,
-                                                      const float* __restrict__ extra) {
+                                                      const float* __restrict__ extra,
+                                                      const int32_t* __restrict__ step_ptr, int min_steps) {
   const int n = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= V) return;
   float v = am[(size_t)n * V + c];
   if (c == eos) {
-    if (eos_floor) v = minus_inf;
+    if (step_ptr ? step_ptr[0] < min_steps : eos_floor) v = minus_inf;
     if (use_thr && !(v > thr * am_max[n])) v = minus_inf;
   }
   if (extra) v += extra[(size_t)n * V + c];
@@ -619,7 +626,7 @@ int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, f
 // psi[n,c] for every hypothesis / token (needs only the CTC state: can run beside the decoder step)
 int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, const int32_t* enc_len, float* psi, int B,
                  int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st) {
-  CtcStepArgs a{last_tok, enc_len, B, T, V, beam, prefix_len, blank, eos, 0.0f, 0, 0, 0.0f, 0.0f};
+  CtcStepArgs a{last_tok, enc_len, B, T, V, beam, prefix_len, blank, eos, 0.0f, 0, 0, 0.0f, 0.0f, g_step_ptr, 0};
   const StateView v = view(const_cast<float*>(state), B, beam, T);
   ProfScope prof("ctc_score_step", 2.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 4.0 * B * beam * V, st);
   const int tpt = (g_ctc_tpt == 4 && (V % 4 != 0 || !aligned16(P))) ? 1 : g_ctc_tpt;
@@ -664,7 +671,8 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
 int ctc_combine(const float* am, const float* am_max, const float* psi, const float* psi_prev, float* comb, int n_bh,
                 int V, int blank, int eos, float weight, int eos_floor, int use_thr, float thr, float minus_inf,
                 const float* extra, hipStream_t st) {
-  CtcStepArgs a{nullptr, nullptr, 0, 0, V, 0, 0, blank, eos, weight, eos_floor, use_thr, thr, minus_inf};
+  CtcStepArgs a{nullptr, nullptr, 0, 0, V, 0, 0, blank, eos, weight, eos_floor, use_thr, thr, minus_inf, g_step_ptr,
+                g_step_min_steps};
   SBK_LAUNCH(ctc_combine_kernel, dim3(cdiv(V, 256), n_bh), dim3(256), 0, st, a, am, am_max, psi, psi_prev, comb, extra);
   return launch_status("ctc_combine");
 }
@@ -675,7 +683,7 @@ int ctc_advance(const float* P, const float* state_old, const float* psi, const 
   const StateView vo = view(const_cast<float*>(state_old), n_bh / beam, beam, T);
   const StateView vn = view(state_new, n_bh / beam, beam, T);
   CtcAdvArgs a{P, vo.st, psi, parent, token, parent_last_tok, vn.st, vn.sg, vn.sb, vn.se, psi_prev_new, n_bh, T, V, beam,
-               prefix_len, blank};
+               prefix_len, blank, g_step_ptr};
   const size_t lds = (size_t)7 * T * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "ctc_advance: T=%d too long for the LDS window", T);
   ProfScope prof("ctc_advance", 14.0 * n_bh * T, 64.0 * n_bh * T, st);
@@ -685,8 +693,10 @@ int ctc_advance(const float* P, const float* state_old, const float* psi, const 
 
 int am_only(const float* am, float* comb, int n_bh, int V, int eos, int eos_floor, int use_thr, float thr,
             float minus_inf, const float* am_max, const float* extra, hipStream_t st) {
+  const int32_t* sp = g_step_ptr;  // locals: launch arguments must not name the thread_locals themselves
+  const int min_steps = g_step_min_steps;
   SBK_LAUNCH(am_only_kernel, dim3(cdiv(V, 256), n_bh), dim3(256), 0, st, am, comb, V, eos, eos_floor, use_thr, thr,
-             minus_inf, am_max, extra);
+             minus_inf, am_max, extra, sp, min_steps);
   return launch_status("am_only");
 }
 

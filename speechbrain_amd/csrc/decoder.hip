@@ -23,8 +23,10 @@ namespace {
 // ---------------------------------------------------------------- embedding
 __global__ void __launch_bounds__(256) embed_pos_kernel(const int32_t* __restrict__ tok, const float* __restrict__ emb,
                                                         const float* __restrict__ pe_row, float* __restrict__ x,
-                                                        int n, int d, float scale) {
+                                                        int n, int d, float scale,
+                                                        const int32_t* __restrict__ step_ptr) {
   const int i = blockIdx.x;
+  if (step_ptr) pe_row += (size_t)step_ptr[0] * d;  // pe_row = row 0 of the table in that mode
   const float* e = emb + (size_t)tok[i] * d;
   for (int c = threadIdx.x; c < d; c += 256) x[(size_t)i * d + c] = e[c] * scale + pe_row[c];
 }
@@ -38,6 +40,7 @@ struct SelfAttnArgs {
   float* out;              // [n,d]
   int n, d, H, Dh, step, nslot, Lmax;
   float scale;
+  const int32_t* step_ptr;  // non-null: the position comes from the device-side step counter
   // optional key padding mask (TransformerLM.make_masks, TransformerLM.py:165-187): key position p is
   // masked when the token fed at p equals pad_idx.  That token is key_tok[i*key_stride + p - key_shift]
   // (key_first for p < key_shift).  NULL = no mask.
@@ -52,6 +55,7 @@ struct SelfAttnArgs {
 // instead of two per position.
 __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
   SBK_DYN_LDS(float, lds);  // [4 waves][2][Lmax_pad]: probabilities, slots
+  if (a.step_ptr) a.step = a.step_ptr[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = blockIdx.x * 4 + wave;
   const bool live = item < a.n * a.H;
@@ -695,6 +699,9 @@ __global__ void __launch_bounds__(256) log_softmax_row_kernel(const float* __res
 }  // namespace
 
 namespace sbk {
+thread_local const int32_t* g_step_ptr = nullptr;
+thread_local int g_step_min_steps = 0;
+
 // Measured alternatives kept behind sbk_prof_set_knob (Conformer-L, B=64, MI355X; cross_attn_step total per
 // 8 batches): frame-per-thread kernel 247 ms with either layout; row-coalesced kernel 336 ms on [B,T,2d],
 // 306 ms on head-major [B,H,T,2*Dh]; at B=128 the MFMA formulation takes 315 ms vs 303 ms.  The defaults stay 0.
@@ -705,7 +712,8 @@ int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* 
               hipStream_t st) {
   if (n == 0) return 0;
   ProfScope prof("embed_pos", 2.0 * n * d, 8.0 * n * d, st);
-  SBK_LAUNCH(embed_pos_kernel, dim3(n), dim3(256), 0, st, tok, emb, pe_row, x, n, d, scale);
+  const int32_t* sp = g_step_ptr;  // a local: launch arguments must not name the thread_local itself
+  SBK_LAUNCH(embed_pos_kernel, dim3(n), dim3(256), 0, st, tok, emb, pe_row, x, n, d, scale, sp);
   return launch_status("embed_pos");
 }
 
@@ -714,7 +722,7 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
                    int key_shift, int key_first, int pad_idx) {
   if (n == 0) return 0;
   SelfAttnArgs a{qkv, kcache, vcache, kv_slot, out, n, d, H, d / H, step, nslot, Lmax, 1.0f / sqrtf((float)(d / H)),
-                 key_tok, key_stride, key_shift, key_first, pad_idx};
+                 g_step_ptr, key_tok, key_stride, key_shift, key_first, pad_idx};
   const size_t lds = (size_t)8 * (((Lmax + 63) / 64) * 64) * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "self_attn_step: Lmax=%d too long for the LDS window", Lmax);
   ProfScope prof("self_attn_step", 4.0 * n * d * (step + 1), 8.0 * n * d * (step + 1), st);

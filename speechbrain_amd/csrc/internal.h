@@ -7,6 +7,11 @@ namespace sbk {
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq,
             hipStream_t st);
+// Device-resident step counter of the search running on this host thread (nullptr: the step is the
+// launch argument).  When set, every step-dependent kernel reads the step from it, so that the launches
+// of one decoding step are identical for every step and can be replayed from a captured hipGraph.
+extern thread_local const int32_t* g_step_ptr;
+extern thread_local int g_step_min_steps;  // min_decode_steps of that search (eos floor: step < min_steps)
 extern int g_attn_prefetch;
 extern int g_cross_rows;
 extern int g_kv_head_major;

@@ -160,7 +160,9 @@ constexpr int kTopkChunks = 16;  // stage-1 workgroups per utterance
 // stage 1: grid (chunks, B); each workgroup reduces one contiguous slice of the beam*V candidates
 __global__ void __launch_bounds__(256) beam_topk_stage1_kernel(const float* __restrict__ comb,
                                                                const float* __restrict__ seq, float* __restrict__ pval,
-                                                               int32_t* __restrict__ pidx, int V, int beam, float norm) {
+                                                               int32_t* __restrict__ pidx, int V, int beam, float norm,
+                                                               const int32_t* __restrict__ step_ptr) {
+  if (step_ptr && norm > 0.0f) norm = (float)(step_ptr[0] + 1);  // length normalisation by the device-side step
   const int b = blockIdx.y, ch = blockIdx.x;
   const int total = beam * V;
   const int len = (total + kTopkChunks - 1) / kTopkChunks;
@@ -206,7 +208,8 @@ __global__ void __launch_bounds__(1024) beam_topk_large_kernel(const float* __re
                                                                const float* __restrict__ seq,
                                                                float* __restrict__ out_val,
                                                                int32_t* __restrict__ out_idx, int V, int beam,
-                                                               float norm) {
+                                                               float norm, const int32_t* __restrict__ step_ptr) {
+  if (step_ptr && norm > 0.0f) norm = (float)(step_ptr[0] + 1);
   __shared__ int hist[256];
   __shared__ unsigned s_prefix;
   __shared__ int s_remaining, s_count, s_eq_base;
@@ -367,6 +370,8 @@ struct BeamState {
   int32_t* n_full;      // [1] utterances whose finished list is full
 };
 
+__global__ void step_inc_kernel(int32_t* step) { step[0] += 1; }
+
 __global__ void beam_init_kernel(BeamState s, int B, int beam, int bos) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n == 0) {
@@ -380,7 +385,9 @@ __global__ void beam_init_kernel(BeamState s, int B, int beam, int bos) {
 }
 
 __global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const float* __restrict__ am, int cur, int step,
-                                                          int V, int beam, int Lmax, int eos, int length_norm) {
+                                                          int V, int beam, int Lmax, int eos, int length_norm,
+                                                          const int32_t* __restrict__ step_ptr) {
+  if (step_ptr) step = step_ptr[0];
   __shared__ int h_src[kMaxBeamLarge];
   __shared__ int h_dst[kMaxBeamLarge];
   __shared__ int h_n;
@@ -916,8 +923,11 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
                               cfg->eos, pst));
     SBK_HIP(hipEventRecord(side->join, cst));
   }
-  int cur = 0, steps = 0;
-  for (int step = 0; step < cfg->max_steps; ++step) {
+  // One decoding step as a list of launches.  `counter` = true: the step number lives in device memory
+  // (bb.s.n_full[2]; every step-dependent kernel reads it, sbk::g_step_ptr), `step` is then only a
+  // placeholder 0 and the launches are identical for every step -- what a captured hipGraph needs.
+  int32_t* step_dev = bb.s.n_full + 2;
+  auto issue_step = [&](int step, int cur, bool counter) -> int {
     SBK_TRY(decoder_step(W, d, bb.s.tokens[cur], bb.s.kv_slot[cur], enc_len, step, n, B, T, beam, Lmax, true, st));
     SBK_TRY(sbk::log_softmax_rows(d.logits, bb.am, n, V, cfg->temperature, attn_w, st));
     if (cfg->using_eos_threshold) SBK_TRY(sbk::row_max(bb.am, bb.am_max, n, V, st));
@@ -939,14 +949,15 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
                            cfg->minus_inf, bb.am_max, extra, st));
     }
     const float norm = cfg->length_normalization ? (float)(step + 1) : 0.0f;
+    const int32_t* sp = sbk::g_step_ptr;  // a local: launch arguments must not name the thread_local itself
     if (beam > kMaxBeam) {
       sbk::ProfScope prof("beam_topk_large", 10.0 * n * V, 20.0 * n * V, st);
       SBK_LAUNCH(beam_topk_large_kernel, dim3(B), dim3(1024), 0, st, (const float*)bb.comb,
-                 (const float*)bb.s.seq_scores, bb.s.cand_val, bb.s.cand_idx, V, beam, norm);
+                 (const float*)bb.s.seq_scores, bb.s.cand_val, bb.s.cand_idx, V, beam, norm, sp);
     } else {
       sbk::ProfScope prof("beam_topk", 2.0 * n * V, 4.0 * n * V, st);
       SBK_LAUNCH(beam_topk_stage1_kernel, dim3(kTopkChunks, B), dim3(256), 0, st, (const float*)bb.comb,
-                 (const float*)bb.s.seq_scores, bb.topk_val, bb.topk_idx, V, beam, norm);
+                 (const float*)bb.s.seq_scores, bb.topk_val, bb.topk_idx, V, beam, norm, sp);
       SBK_LAUNCH(beam_topk_stage2_kernel, dim3(B), dim3(256), 0, st, (const float*)bb.topk_val,
                  (const int32_t*)bb.topk_idx, bb.s.cand_val, bb.s.cand_idx, beam);
     }
@@ -954,10 +965,12 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
     {
       sbk::ProfScope prof("beam_update", 0.0, 24.0 * n * (step + 1), st);
       SBK_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 0, st, bb.s, (const float*)bb.am, cur, step, V, beam, Lmax,
-                 cfg->eos, cfg->length_normalization);
+                 cfg->eos, cfg->length_normalization, sp);
     }
     SBK_TRY(sbk::launch_status("beam_update"));
-    if (ctc && step + 1 < cfg->max_steps) {  // survivors' CTC state, then the next step's psi -- beside the next decoder step
+    // survivors' CTC state, then the next step's psi -- beside the next decoder step (with a device-side
+    // counter the last step cannot be told apart: its update is computed and never read)
+    if (ctc && (counter || step + 1 < cfg->max_steps)) {
       if (side) {
         SBK_HIP(hipEventRecord(side->fork, st));
         SBK_HIP(hipStreamWaitEvent(cst, side->fork, 0));
@@ -969,12 +982,77 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
                                   step + 1, cfg->blank, cfg->eos, pst));
       if (side) SBK_HIP(hipEventRecord(side->join, cst));
     }
-    cur ^= 1;
-    steps = step + 1;
-    if (host_flag && cfg->check_every > 0 && (steps % cfg->check_every == 0) && steps < cfg->max_steps) {
-      SBK_HIP(hipMemcpyAsync(host_flag, bb.s.n_full, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      SBK_HIP(hipStreamSynchronize(st));
-      if (*host_flag >= B) break;
+    if (counter) {
+      SBK_LAUNCH(step_inc_kernel, dim3(1), dim3(1), 0, st, step_dev);
+      SBK_TRY(sbk::launch_status("step_inc"));
+    }
+    return 0;
+  };
+  auto poll_full = [&](int steps_done) -> int {  // 1: every utterance has its beam of finished hypotheses
+    if (!(host_flag && cfg->check_every > 0 && (steps_done % cfg->check_every == 0) && steps_done < cfg->max_steps)) return 0;
+    if (hipMemcpyAsync(host_flag, bb.s.n_full, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return -1;
+    return *host_flag >= B ? 1 : 0;
+  };
+
+  int cur = 0, steps = 0;
+  // graph_mode 1: two consecutive steps (the double-buffered tables flip back after two) are captured once
+  // into a hipGraph and replayed; 2: the same device-side step counter with plain launches (tests, fallback).
+  int graph_mode = cfg->graph_mode;
+  if (graph_mode && (side || sbk::prof_enabled() || T > 900 || cfg->max_steps < 2)) graph_mode = 0;
+  if (graph_mode) {
+    struct Scope {  // the step source is per host thread; never leave it set
+      ~Scope() {
+        sbk::g_step_ptr = nullptr;
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+      }
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+    } scope;
+    SBK_HIP(hipMemsetAsync(step_dev, 0, sizeof(int32_t), st));
+    sbk::g_step_ptr = step_dev;
+    sbk::g_step_min_steps = cfg->min_steps;
+    if (graph_mode == 1) {
+      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        int rc = issue_step(0, 0, true);
+        if (!rc) rc = issue_step(0, 1, true);
+        const hipError_t e = hipStreamEndCapture(st, &scope.graph);
+        if (rc) return rc;
+        if (e != hipSuccess || hipGraphInstantiate(&scope.exec, scope.graph, nullptr, nullptr, 0) != hipSuccess) {
+          scope.exec = nullptr;  // replay unavailable: plain launches below
+          (void)hipGetLastError();
+        }
+      }
+    }
+    const int pairs = cfg->max_steps / 2;
+    bool done = false;
+    for (int p = 0; p < pairs && !done; ++p) {
+      if (scope.exec) {
+        SBK_HIP(hipGraphLaunch(scope.exec, st));
+      } else {
+        SBK_TRY(issue_step(0, 0, true));
+        SBK_TRY(issue_step(0, 1, true));
+      }
+      steps += 2;
+      const int r = poll_full(steps);  // (running a step past the stop point cannot change the result)
+      if (r < 0) return sbk::fail(1, "beam_search: stop-rule poll failed");
+      done = r == 1;
+    }
+    if (!done && (cfg->max_steps & 1)) {
+      SBK_TRY(issue_step(0, 0, true));
+      ++steps;
+    }
+    cur = steps & 1;
+  } else {
+    for (int step = 0; step < cfg->max_steps; ++step) {
+      SBK_TRY(issue_step(step, cur, false));
+      cur ^= 1;
+      steps = step + 1;
+      const int r = poll_full(steps);
+      if (r < 0) return sbk::fail(1, "beam_search: stop-rule poll failed");
+      if (r == 1) break;
     }
   }
   if (side) SBK_HIP(hipStreamWaitEvent(st, side->join, 0));  // nothing of this call outlives it on the helper stream

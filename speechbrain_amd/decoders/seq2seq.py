@@ -92,6 +92,7 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
         self.attn_weight, self.ctc_weight = 1.0, 0.0
         self.check_every = 8
         self.overlap_ctc = 3  # CTC scorer on a helper stream beside the decoder step (bit mask, see include/sbk.h)
+        self.graph_mode = 0   # 1: replay two decoding steps from a captured hipGraph (needs overlap_ctc = 0)
         self.blank_index = 0
         self.ctc_fc = None
         self.lm, self.lm_weight, self.lm_temperature = None, 0.0, 1.0
@@ -119,7 +120,8 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
             self._lm_handle = self.lm.handle()  # keeps the pointed-to weight table alive during the call
             lm = dict(lm=ctypes.pointer(self._lm_handle.W), lm_weight=self.lm_weight,
                       lm_temperature=self.lm_temperature)
-        return native.SearchConfig(**lm, topk=self.topk if self.return_topk else 1, bos=self.bos_index, eos=self.eos_index, blank=self.blank_index, beam=self.beam_size,
+        return native.SearchConfig(**lm, topk=self.topk if self.return_topk else 1, graph_mode=int(self.graph_mode),
+                                   bos=self.bos_index, eos=self.eos_index, blank=self.blank_index, beam=self.beam_size,
                                    min_steps=mn, max_steps=mx, length_normalization=int(self.length_normalization),
                                    using_eos_threshold=int(self.using_eos_threshold), check_every=self.check_every,
                                    overlap_ctc=int(self.overlap_ctc),

@@ -59,7 +59,7 @@ class SearchConfig(ctypes.Structure):  # sbk_search_config
                 ("max_steps", c_int32), ("length_normalization", c_int32), ("using_eos_threshold", c_int32),
                 ("check_every", c_int32), ("overlap_ctc", c_int32), ("ctc_weight", c_float), ("temperature", c_float),
                 ("eos_threshold", c_float), ("minus_inf", c_float), ("lm_weight", c_float), ("lm_temperature", c_float),
-                ("lm", POINTER(LMWeights)), ("topk", c_int32)]
+                ("lm", POINTER(LMWeights)), ("topk", c_int32), ("graph_mode", c_int32)]
 
 
 def _declare(lib):

@@ -446,3 +446,45 @@ def test_concurrent_transcriber_matches_sequential(backend):
     got2 = ConcurrentTranscriber(asr, streams=2, prioritise_search=False).transcribe_batches(
         batches, prepare=lambda searcher, wavs: seen.append(wavs.shape[1]))
     assert got2 == ref and sorted(seen) == sorted(w.shape[1] for w, _ in batches)
+
+
+@pytest.mark.parametrize("tag", ["tiny_ctc", "tiny_noctc", "tiny_lm_ctc"])
+@pytest.mark.parametrize("graph_mode", [1, 2])
+def test_device_side_step_counter_and_graph_replay(backend, tag, graph_mode):
+    """graph_mode 2: the step number lives in device memory (every step-dependent kernel reads it);
+    graph_mode 1: two steps captured into a hipGraph and replayed (on the CPU emulator the capture is
+    unavailable and the library falls back to mode 2).  Results must equal the reference goldens."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import (CTCScorer, S2STransformerBeamSearcher, ScorerBuilder,
+                                          TransformerLMScorer)
+    from speechbrain_amd.inference.builders import build_modules
+
+    g = np.load(os.path.join(GOLD, f"model_{tag}.npz"))
+    d_model, nhead, d_ffn, n_enc, n_dec, vocab, beam, eos_thr = [int(v) for v in g["cfg"]]
+    cf = [float(v) for v in g["cfgf"]]
+    ctc_w, max_ratio, min_ratio = cf[0], cf[1], cf[2]
+    m = build_modules(dict(d_model=d_model, nhead=nhead, d_ffn=d_ffn, n_enc=n_enc, n_dec=n_dec, n_fft=512,
+                           win_length=32), vocab=vocab)
+    mods = torch.nn.ModuleDict({k: m[k] for k in ("CNN", "Transformer", "seq_lin", "ctc_lin")})
+    mods.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files
+                          if k.startswith("sd/") and not k.startswith("sd/LM.")}, strict=True)
+    mods = mods.to(dev).eval()
+    full, weights, temp = [], {}, 1.0
+    if "lm_cfg" in g.files:
+        full.append(TransformerLMScorer(language_model=build_lm(g, dev), temperature=cf[4]))
+        weights["transformerlm"], temp = cf[3], cf[5]
+    if ctc_w > 0:
+        full.append(CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2))
+        weights["ctc"] = ctc_w
+    scorer = ScorerBuilder(full_scorers=full, weights=weights) if full else None
+    bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                    min_decode_ratio=min_ratio, max_decode_ratio=max_ratio, beam_size=beam,
+                                    using_eos_threshold=bool(eos_thr), length_normalization=True, temperature=temp,
+                                    scorer=scorer)
+    bs.overlap_ctc, bs.graph_mode = 0, graph_mode
+    for check_every in (8, 1, 0):
+        bs.check_every = check_every
+        hyps, lens, scores, _ = bs(torch.from_numpy(g["enc_out"]).to(dev), torch.from_numpy(g["wav_lens"]).to(dev))
+        assert hyps == hyps_of(g["beam_hyps"])
+        assert float((scores.cpu() - torch.from_numpy(g["beam_scores"])).abs().max()) <= 1e-4
+        assert float((lens.cpu() - torch.from_numpy(g["beam_lens"])).abs().max()) <= 1e-6

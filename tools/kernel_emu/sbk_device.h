@@ -42,6 +42,17 @@ enum { hipMemcpyDeviceToDevice = 3, hipMemcpyDeviceToHost = 2, hipMemcpyHostToDe
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 typedef void* hipEvent_t;
+// hipGraph: not emulated -- capture reports failure, the callers fall back to plain launches
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+typedef void* hipGraphNode_t;
+enum { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return 1; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return 1; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, hipGraphNode_t*, char*, size_t) { *e = nullptr; return 1; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 1; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return 0; }
+static inline hipError_t hipGraphDestroy(hipGraph_t) { return 0; }
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)2; return 0; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*)1; return 0; }
