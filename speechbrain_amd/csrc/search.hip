@@ -1024,6 +1024,8 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
           scope.exec = nullptr;  // replay unavailable: plain launches below
           (void)hipGetLastError();
         }
+      } else {
+        (void)hipGetLastError();  // e.g. the legacy default stream cannot capture: plain launches below
       }
     }
     const int pairs = cfg->max_steps / 2;

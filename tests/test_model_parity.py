@@ -482,9 +482,16 @@ def test_device_side_step_counter_and_graph_replay(backend, tag, graph_mode):
                                     using_eos_threshold=bool(eos_thr), length_normalization=True, temperature=temp,
                                     scorer=scorer)
     bs.overlap_ctc, bs.graph_mode = 0, graph_mode
+    import contextlib
+    # capture needs a real stream (the legacy default stream cannot be captured; the library then falls back)
+    side = torch.cuda.stream(torch.cuda.Stream(dev)) if dev.type == "cuda" else contextlib.nullcontext()
     for check_every in (8, 1, 0):
         bs.check_every = check_every
-        hyps, lens, scores, _ = bs(torch.from_numpy(g["enc_out"]).to(dev), torch.from_numpy(g["wav_lens"]).to(dev))
+        with side:
+            hyps, lens, scores, _ = bs(torch.from_numpy(g["enc_out"]).to(dev), torch.from_numpy(g["wav_lens"]).to(dev))
+        if dev.type == "cuda" and check_every == 8:  # and once on the default stream: silent fallback to plain launches
+            hyps_d, _, _, _ = bs(torch.from_numpy(g["enc_out"]).to(dev), torch.from_numpy(g["wav_lens"]).to(dev))
+            assert hyps_d == hyps
         assert hyps == hyps_of(g["beam_hyps"])
         assert float((scores.cpu() - torch.from_numpy(g["beam_scores"])).abs().max()) <= 1e-4
         assert float((lens.cpu() - torch.from_numpy(g["beam_lens"])).abs().max()) <= 1e-6
