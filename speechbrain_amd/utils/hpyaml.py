@@ -12,6 +12,7 @@ Module paths that start with ``speechbrain.`` are resolved inside ``speechbrain_
 drop-in: a YAML written for the reference builds the MI355X modules.
 """
 import ast
+import builtins
 import copy
 import functools
 import importlib
@@ -37,6 +38,8 @@ def resolve_name(path: str):
     if path == "speechbrain" or path.startswith("speechbrain."):
         path = "speechbrain_amd" + path[len("speechbrain"):]
     parts = path.split(".")
+    if len(parts) == 1 and hasattr(builtins, path):
+        return getattr(builtins, path)
     for cut in range(len(parts), 0, -1):
         try:
             obj = importlib.import_module(".".join(parts[:cut]))

@@ -77,3 +77,89 @@ def test_speechbrain_import_shim():
     finally:
         for k in [k for k in sys.modules if k == "speechbrain" or k.startswith("speechbrain.")]:
             del sys.modules[k]
+
+
+def test_hyperpyyaml_subset_loader():
+    """utils/hpyaml.py: the HyperPyYAML features inference hyperparams.yaml files use."""
+    from speechbrain_amd.utils.hpyaml import load_hyperpyyaml
+
+    text = """
+d_model: 32
+half: !ref <d_model> // 2
+ratio: !ref <d_model> * 1.5
+folder: out
+save: !ref <folder>/save/<d_model>
+act: !name:torch.nn.GELU
+leaky: !name:torch.nn.functional.leaky_relu
+    negative_slope: 0.2
+shape: (8, 10, 80)
+quoted: "(1, 2)"
+lin: !new:speechbrain.nnet.linear.Linear
+    input_size: !ref <d_model>
+    n_neurons: 7
+pair: [!ref <lin>, !ref <lin>]
+ml: !new:torch.nn.ModuleList
+    - [!ref <lin>]
+cp: !copy <lin>
+sm: !new:torch.nn.LogSoftmax
+    dim: -1
+nested:
+    a: !ref <lin>
+    b: [1, 2.5, null, true]
+pick: !ref <nested[b][1]>
+applied: !apply:max
+    - 3
+    - 9
+"""
+    h = load_hyperpyyaml(text)
+    assert h["half"] == 16 and h["ratio"] == 48.0 and h["save"] == "out/save/32"
+    assert h["act"] is torch.nn.GELU and h["shape"] == (8, 10, 80) and h["quoted"] == "(1, 2)"
+    assert float(h["leaky"](torch.tensor(-1.0))) == pytest.approx(-0.2)
+    assert type(h["lin"]).__module__ == "speechbrain_amd.nnet.linear"  # speechbrain.* is served by speechbrain_amd.*
+    assert h["pair"][0] is h["lin"] and h["pair"][1] is h["lin"] and h["ml"][0] is h["lin"] and h["nested"]["a"] is h["lin"]
+    assert h["cp"] is not h["lin"] and torch.equal(h["cp"].w.weight, h["lin"].w.weight)
+    assert h["nested"]["b"] == [1, 2.5, None, True] and h["pick"] == 2.5 and h["applied"] == 9
+    assert load_hyperpyyaml(text, overrides={"d_model": 64})["lin"].w.weight.shape == (7, 64)
+    assert load_hyperpyyaml(text, overrides="d_model: 16")["half"] == 8
+    with pytest.raises(ValueError):
+        load_hyperpyyaml("x: !PLACEHOLDER\n")
+    assert load_hyperpyyaml("x: !PLACEHOLDER\ny: !ref <x>", overrides={"x": 3})["y"] == 3
+    with pytest.raises(KeyError):
+        load_hyperpyyaml("y: !ref <missing>")
+    with pytest.raises(ValueError):
+        load_hyperpyyaml("a: !ref <b>\nb: !ref <a>")
+    with pytest.raises(ImportError):
+        load_hyperpyyaml("x: !new:speechbrain.lobes.models.ECAPA_TDNN.ECAPA_TDNN")  # outside the path
+    with pytest.raises(NotImplementedError):
+        load_hyperpyyaml("x: !include:other.yaml")
+
+
+def test_pretrainer_local_sources(tmp_path):
+    """utils/parameter_transfer.py: default <source>/<name>.ckpt, explicit paths, conditions, hooks, errors."""
+    from speechbrain_amd.nnet.linear import Linear
+    from speechbrain_amd.processing.features import InputNormalization
+    from speechbrain_amd.utils.parameter_transfer import Pretrainer
+
+    src = Linear(input_size=4, n_neurons=3)
+    torch.save(src.state_dict(), tmp_path / "lin.ckpt")
+    other = tmp_path / "elsewhere"
+    other.mkdir()
+    norm_src = InputNormalization(norm_type="global")
+    norm_src.glob_mean, norm_src.glob_std, norm_src.count = torch.arange(5.0), torch.ones(5) * 2, 7
+    norm_src._save(other / "stats.ckpt")
+    lin, norm, skipped, hooked = Linear(input_size=4, n_neurons=3), InputNormalization(norm_type="global"), Linear(input_size=4, n_neurons=3), {}
+    pt = Pretrainer(loadables={"lin": lin, "norm": norm, "skipped": skipped, "hooked": hooked},
+                    paths={"norm": str(other / "stats.ckpt"), "hooked": str(tmp_path / "lin.ckpt")},
+                    conditions={"skipped": False}, custom_hooks={"hooked": lambda obj, path: obj.update(path=str(path))})
+    assert Pretrainer.split_path("a/b/c.ckpt") == ("a/b", "c.ckpt") and Pretrainer.split_path("c.ckpt") == ("./", "c.ckpt")
+    with pytest.raises(RuntimeError):
+        pt.load_collected()  # before collect_files
+    got = pt.collect_files(default_source=str(tmp_path))
+    assert set(got) == {"lin", "norm", "hooked"}
+    pt.load_collected()
+    assert torch.equal(lin.w.weight, src.w.weight) and torch.equal(norm.glob_mean, torch.arange(5.0)) and norm.count == 7
+    assert hooked["path"].endswith("lin.ckpt")
+    with pytest.raises(FileNotFoundError):
+        Pretrainer(loadables={"absent": lin}).collect_files(default_source=str(tmp_path))
+    with pytest.raises(ValueError):
+        Pretrainer(loadables={"nopath": lin}).collect_files()
