@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
