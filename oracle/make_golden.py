@@ -567,8 +567,24 @@ def golden_pretrained():
         words_ref, tokens_ref = asr.transcribe_batch(wav, lens)
         enc_ref = asr.encode_batch(wav, lens)
     print("  tokens:", [len(t) for t in tokens_ref], "words[0]:", repr(words_ref[0][:60]))
+    # transcribe_file (inference/ASR.py:96-117): a mono and a stereo 16-bit PCM file written with the stdlib
+    import wave
+
+    file_words = {}
+    for name, ch in (("sample_mono.wav", 1), ("sample_stereo.wav", 2)):
+        pcm = (0.3 * torch.randn(14000, ch, generator=g)).clamp(-1, 1).mul(32767).round().to(torch.int16)
+        path = os.path.join(OUT, name)
+        with wave.open(path, "wb") as f:
+            f.setnchannels(ch)
+            f.setsampwidth(2)
+            f.setframerate(16000)
+            f.writeframes(pcm.numpy().astype("<i2").tobytes())
+        with torch.no_grad():
+            file_words[name] = asr.transcribe_file(path)
+        print("  transcribe_file", name, "->", repr(file_words[name][:50]))
     np.savez_compressed(os.path.join(OUT, "pretrained_tiny_expected.npz"), wav=wav.numpy(), lens=lens.numpy(),
-                        enc_out=enc_ref.numpy(),
+                        enc_out=enc_ref.numpy(), file_names=np.array(list(file_words)),
+                        file_words=np.array(list(file_words.values())),
                         tokens=np.array([t + [-1] * (64 - len(t)) for t in tokens_ref], dtype=np.int64),
                         words=np.array(words_ref))
     size = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))

@@ -368,6 +368,9 @@ def test_from_hparams_local_model_directory(backend):
     words, tokens = asr.transcribe_batch(wav, lens)
     assert tokens == hyps_of(exp["tokens"])
     assert words == [str(w) for w in exp["words"]]
+    # transcribe_file (inference/ASR.py:96-117): 16-bit PCM mono and stereo (channel mean) wav files
+    for name, ref_words in zip(exp["file_names"], exp["file_words"]):
+        assert asr.transcribe_file(os.path.join(GOLD, str(name))) == str(ref_words)
     with pytest.raises(FileNotFoundError):
         EncoderDecoderASR.from_hparams(source="speechbrain/asr-conformer-transformerlm-librispeech")
 
