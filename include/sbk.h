@@ -14,7 +14,9 @@
  *  - return 0 on success, a negative errno-style code for bad arguments
  *    (SBK_EINVAL = -22), a positive hipError_t if a launch failed;
  *    sbk_last_error() returns the thread-local message of the last failure;
- *  - re-entrant; one host thread per process per GPU is the intended use.
+ *  - a call whose batch dimension is 0 returns 0 without touching its data pointers (they may be NULL);
+ *  - re-entrant: concurrent calls from several host threads (one stream each) are supported; the
+ *    searchers keep their per-call state in the caller's workspace and a per-thread helper stream.
  */
 #ifndef SBK_H_
 #define SBK_H_

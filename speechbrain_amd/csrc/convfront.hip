@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(256) conv_block_kernel(ConvArgs a) {
 extern "C" int sbk_conv_block_f32(const float* x, const float* wt, const float* bias, const float* gamma,
                                   const float* beta, float* y, int B, int Tin, int Fin, int Cin, int Cout, float eps,
                                   float slope, sbk_stream_t stream) {
+  if (B == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(x && wt && bias && gamma && beta && y, "conv_block: null operand");
   SBK_REQUIRE(B >= 0 && Tin >= 2 && Fin >= 2 && Cin >= 1 && Cout >= 1, "conv_block: bad shape");
   const int Tout = (Tin - 1) / 2 + 1, Fout = (Fin - 1) / 2 + 1;  // floor((n + 2 - 3) / 2) + 1

@@ -77,6 +77,7 @@ int glu_dwconv(const float* h, const float* w, const float* bias, float* y, int 
 
 extern "C" int sbk_glu_dwconv_f32(const float* h, const float* w, const float* bias, float* y, int B, int T, int d,
                                   int ksize, sbk_stream_t stream) {
+  if (B == 0 || T == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(h && w && bias && y, "glu_dwconv: null operand");
   SBK_REQUIRE(B >= 0 && T >= 0 && d > 0, "glu_dwconv: bad shape");
   return sbk::glu_dwconv(h, w, bias, y, B, T, d, ksize, sbk::as_stream(stream));

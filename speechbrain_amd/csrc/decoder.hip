@@ -778,6 +778,7 @@ int log_softmax_rows(const float* x, float* out, int rows, int V, float temperat
 
 extern "C" int sbk_log_softmax_f32(const float* x, float* out, int rows, int V, float temperature, float weight,
                                    sbk_stream_t stream) {
+  if (rows == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(x && out && rows >= 0 && V > 0 && temperature > 0.0f, "log_softmax: bad arguments");
   return sbk::log_softmax_rows(x, out, rows, V, temperature, weight, sbk::as_stream(stream));
 }

@@ -158,6 +158,7 @@ extern "C" int sbk_fbank_f32(const float* wav, const float* window, const float*
                              float* out, float* tile_max, int B, int N, int n_fft, int hop, int n_mels, int nnz,
                              float amin, float top_db, const float* norm_mean, const float* norm_std, float norm_eps,
                              sbk_stream_t stream) {
+  if (B == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(wav && window && twiddle && radices && mel_w && mel_ptr && mel_bin && out && tile_max,
               "fbank: null operand");
   SBK_REQUIRE(B >= 0 && N >= 0 && n_fft >= 2 && hop > 0 && n_mels > 0 && nnz >= 0, "fbank: bad shape");
@@ -196,6 +197,7 @@ extern "C" int sbk_fbank_f32(const float* wav, const float* window, const float*
 // STFT.forward (processing/features.py:141-188): [B,N] -> [B,T,n_fft/2+1,2] (re, im).
 extern "C" int sbk_stft_f32(const float* wav, const float* window, const float* twiddle, const int32_t* radices,
                             int n_radix, float* spec, int B, int N, int n_fft, int hop, sbk_stream_t stream) {
+  if (B == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(wav && window && twiddle && radices && spec, "stft: null operand");
   SBK_REQUIRE(B >= 0 && N >= 0 && n_fft >= 2 && hop > 0, "stft: bad shape");
   SBK_REQUIRE(n_radix > 0 && n_radix <= kMaxRadix, "stft: %d FFT passes", n_radix);

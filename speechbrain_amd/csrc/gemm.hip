@@ -468,6 +468,7 @@ int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
 extern "C" int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
                                const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
                                float alpha, const int32_t* seq_len, int rows_per_seq, sbk_stream_t stream) {
+  if (M == 0 || N == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(A && W && C, "gemm: null operand");
   SBK_REQUIRE(M >= 0 && N >= 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   SBK_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dimension smaller than the row");
@@ -481,6 +482,7 @@ extern "C" int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw,
 extern "C" int sbk_gemm_ln_nt_f32(const float* A, int lda, const float* Wf, int ldw, const float* bf,
                                   const float* residual, int ldr, float* C, int ldc, int M, int N, int K, float eps,
                                   int act, float alpha, sbk_stream_t stream) {
+  if (M == 0 || N == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(A && Wf && C, "gemm_ln: null operand");
   SBK_REQUIRE(M >= 0 && N >= 0 && K > 0 && lda >= K && ldw >= K && ldc >= N, "gemm_ln: bad shape");
   const int rc = sbk::gemm_ln_nt(A, lda, Wf, ldw, bf, residual, ldr, C, ldc, M, N, K, eps, act, alpha,
@@ -492,6 +494,7 @@ extern "C" int sbk_gemm_ln_nt_f32(const float* A, int lda, const float* Wf, int 
 extern "C" int sbk_gemm_nt_splitk_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
                                       const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
                                       float alpha, float* workspace, size_t workspace_floats, sbk_stream_t stream) {
+  if (M == 0 || N == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(A && W && C, "gemm: null operand");
   SBK_REQUIRE(M >= 0 && N >= 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   SBK_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dimension smaller than the row");

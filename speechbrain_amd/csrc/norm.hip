@@ -123,6 +123,7 @@ int layernorm(const float* x, const float* gamma, const float* beta, float* y, i
 
 extern "C" int sbk_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int rows, int d,
                                  float eps, int act, sbk_stream_t stream) {
+  if (rows == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(x && gamma && beta && y, "layernorm: null operand");
   SBK_REQUIRE(rows >= 0 && d > 0, "layernorm: bad shape rows=%d d=%d", rows, d);
   return sbk::layernorm(x, gamma, beta, y, rows, d, eps, act, sbk::as_stream(stream));
@@ -130,6 +131,7 @@ extern "C" int sbk_layernorm_f32(const float* x, const float* gamma, const float
 
 extern "C" int sbk_input_norm_global_f32(const float* x, const float* mean, const float* std, float* y, int rows,
                                          int C, float eps, sbk_stream_t stream) {
+  if (rows == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(x && mean && std && y, "input_norm: null operand");
   SBK_REQUIRE(rows >= 0 && C > 0, "input_norm: bad shape");
   const long n = (long)rows * C;

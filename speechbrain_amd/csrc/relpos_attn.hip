@@ -527,6 +527,7 @@ int rope_attention(const float* qkv, const float* cosines, const float* sines, c
 extern "C" int sbk_rope_attention_f32(const float* qkv, const float* cosines, const float* sines,
                                       const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,
                                       int table_rows, float scale, sbk_stream_t stream) {
+  if (B == 0 || T == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(qkv && cosines && sines && out, "rope_attention: null operand");
   SBK_REQUIRE(B >= 0 && T >= 0 && H > 0 && Dh > 0 && Dh % 2 == 0, "rope_attention: bad shape");
   SBK_REQUIRE(table_rows >= T, "rope_attention: the sinusoid tables hold %d rows, T = %d", table_rows, T);
@@ -538,6 +539,7 @@ extern "C" int sbk_rope_attention_f32(const float* qkv, const float* cosines, co
 extern "C" int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                                         const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,
                                         float scale, sbk_stream_t stream) {
+  if (B == 0 || T == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(qkv && pos && bias_u && bias_v && out, "relpos_attention: null operand");
   SBK_REQUIRE(B >= 0 && T >= 0 && H > 0 && Dh > 0, "relpos_attention: bad shape");
   SBK_REQUIRE(sbk::aligned16(qkv) && sbk::aligned16(pos), "relpos_attention: operands must be 16-byte aligned");

@@ -863,6 +863,10 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
                                    float* out_logp, int32_t* out_max_len, int32_t* host_flag, int32_t* steps_run,
                                    int B, int T, sbk_stream_t stream) {
   SBK_TRY(check_weights(W));
+  if (B == 0) {  // empty batch: nothing to launch, the data pointers may be NULL
+    if (steps_run) *steps_run = 0;
+    return 0;
+  }
   SBK_REQUIRE(cfg && enc && enc_len && workspace && out_tokens && out_len && out_score && out_logp, "beam_search: null");
   SBK_REQUIRE(W->seq_w && W->seq_b, "beam_search: seq_lin weights missing");
   SBK_REQUIRE(cfg->beam >= 1 && cfg->beam <= kMaxBeamLarge, "beam_search: beam %d outside [1,%d]", cfg->beam,
@@ -1089,6 +1093,7 @@ extern "C" int sbk_decoder_prefix_f32(const sbk_decoder_weights* W, const int32_
                                       const int32_t* enc_len, void* workspace, size_t workspace_bytes, float* pred,
                                       int n, int T, int L, sbk_stream_t stream) {
   SBK_TRY(check_weights(W));
+  if (n == 0 || L == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(tokens && enc && enc_len && workspace && pred, "decoder_prefix: null");
   SBK_REQUIRE(L <= W->max_len, "decoder_prefix: prefix longer than the positional table");
   SBK_REQUIRE(workspace_bytes >= sbk_decoder_prefix_workspace_bytes(W, n, T, L), "decoder_prefix: workspace too small");
@@ -1128,6 +1133,7 @@ extern "C" size_t sbk_lm_prefix_workspace_bytes(const sbk_lm_weights* LM, int n,
 extern "C" int sbk_lm_prefix_f32(const sbk_lm_weights* LM, const int32_t* tokens, void* workspace,
                                  size_t workspace_bytes, float* logits, int n, int L, sbk_stream_t stream) {
   SBK_TRY(check_lm(LM));
+  if (n == 0 || L == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(tokens && workspace && logits, "lm_prefix: null");
   SBK_REQUIRE(L <= LM->max_len, "lm_prefix: prefix longer than the positional table");
   SBK_REQUIRE(workspace_bytes >= sbk_lm_prefix_workspace_bytes(LM, n, L), "lm_prefix: workspace too small");
@@ -1168,6 +1174,10 @@ extern "C" int sbk_greedy_search_f32(const sbk_decoder_weights* W, const float* 
                                      int32_t* host_flag, int32_t* steps_run, int B, int T, int min_steps, int max_steps,
                                      int bos, int eos, int check_every, sbk_stream_t stream) {
   SBK_TRY(check_weights(W));
+  if (B == 0) {  // empty batch: nothing to launch, the data pointers may be NULL
+    if (steps_run) *steps_run = 0;
+    return 0;
+  }
   SBK_REQUIRE(enc && enc_len && workspace && out_tokens && out_scores && W->seq_w && W->seq_b, "greedy_search: null");
   SBK_REQUIRE(max_steps <= W->max_len, "greedy_search: too many steps for the positional table");
   SBK_REQUIRE(workspace_bytes >= sbk_greedy_search_workspace_bytes(W, B, T, max_steps), "greedy: workspace too small");

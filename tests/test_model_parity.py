@@ -498,3 +498,37 @@ def test_device_side_step_counter_and_graph_replay(backend, tag, graph_mode):
         assert hyps == hyps_of(g["beam_hyps"])
         assert float((scores.cpu() - torch.from_numpy(g["beam_scores"])).abs().max()) <= 1e-4
         assert float((lens.cpu() - torch.from_numpy(g["beam_lens"])).abs().max()) <= 1e-6
+
+
+def test_degenerate_inputs(backend):
+    """Empty batch, a single very short utterance (T' = 3 encoder frames), batch of one, all-padding tails:
+    the path returns the shapes the reference would and never faults."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_asr, oracle_state_dict
+
+    tiny = dict(d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=2, n_fft=512, win_length=32)
+    asr = build_asr(tiny, vocab=40, seed=3, beam_size=4, ctc_weight=0.4, device=str(dev))
+    # empty batch through every kernel entry that takes a batch dimension
+    assert nat.gemm_nt(torch.zeros(0, 32, device=dev), torch.zeros(8, 32, device=dev)).shape == (0, 8)
+    assert nat.layernorm(torch.zeros(0, 32, device=dev), torch.ones(32, device=dev), torch.zeros(32, device=dev), 1e-5).shape == (0, 32)
+    enc0 = torch.zeros(0, 7, 32, device=dev)
+    hyps, lens, scores, lp = asr.mods.decoder(enc0, torch.zeros(0, device=dev))
+    assert hyps == [] and lens.numel() == 0 and scores.numel() == 0
+    # 0.07 s of audio -> 8 feature frames -> T' = 2; still decodes (max_decode_ratio 1.0 -> 2 steps)
+    wav = 0.1 * torch.randn(1, 1120, generator=torch.Generator().manual_seed(2))
+    words, toks = asr.transcribe_batch(wav, torch.ones(1))
+    sd = oracle_state_dict(asr)
+    fc = O.FbankCfg(n_fft=512, n_mels=80, win_length_ms=32)
+    mc = O.ModelCfg(d_model=32, nhead=4, num_encoder_layers=2, num_decoder_layers=2, d_ffn=64, vocab=40)
+    enc = O.encode_batch(wav, torch.ones(1), sd, fc, mc, torch.zeros(80), torch.ones(80))
+    assert enc.shape[1] == 2
+    hyps_ref, _, _, _ = O.beam_search(enc, torch.ones(1), sd, mc, O.SearchCfg(beam=4, ctc_weight=0.4))
+    assert toks == hyps_ref
+    # an utterance that is almost entirely padding inside a batch
+    wav2 = 0.1 * torch.randn(2, 8000, generator=torch.Generator().manual_seed(3))
+    lens2 = torch.tensor([1.0, 0.05])
+    wav2[1, 400:] = 0
+    words2, toks2 = asr.transcribe_batch(wav2, lens2)
+    enc2 = O.encode_batch(wav2, lens2, sd, fc, mc, torch.zeros(80), torch.ones(80))
+    hyps2, _, _, _ = O.beam_search(enc2, lens2, sd, mc, O.SearchCfg(beam=4, ctc_weight=0.4))
+    assert toks2 == hyps2
