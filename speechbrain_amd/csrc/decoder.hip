@@ -232,10 +232,10 @@ __global__ void __launch_bounds__(256) kv_head_major_kernel(const float4* __rest
 // the beams; probabilities go through LDS; the context pass reads each V row once for all beams.
 // With NS > 1 the workgroup emits (un-normalised context, running max, sum) and cross_merge_kernel
 // combines the splits exactly like an online softmax.
-template <int DH>
+template <int DH, int FC>  // FC = memory frames per workgroup (128 or 256)
 __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
   __shared__ float qs[kQT][DH];
-  __shared__ float S[kQT][kFC + 1];
+  __shared__ float S[kQT][FC + 1];
   __shared__ float red[4][kQT][DH];
   __shared__ float mx[kQT], sm[kQT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -256,15 +256,15 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
     qs[j][c] = j < nq ? a.q[((size_t)b * a.beam + q0 + j) * d + h * DH + c] * a.scale : 0.0f;
   }
   __syncthreads();
-  // scores: per needs <= kFC (checked by the launcher)
+  // scores: per needs <= FC (the launcher chooses NS accordingly)
   {
-    const int f = tid & (kFC - 1), par = tid / kFC;  // 2 threads per frame, beams split by parity
+    const int f = tid & (FC - 1), par = tid / FC;  // 256 / FC threads per frame, beams split between them
     if (f < nf) {
       float kr[DH];
       const float* kp = kvb + (size_t)(t0 + f) * kvv.row;
 #pragma unroll
       for (int c = 0; c < DH; ++c) kr[c] = kp[c];
-      for (int j = par; j < nq; j += 256 / kFC) {
+      for (int j = par; j < nq; j += 256 / FC) {
         float s = 0.0f;
 #pragma unroll
         for (int c = 0; c < DH; ++c) s = fmaf(qs[j][c], kr[c], s);
@@ -642,6 +642,15 @@ __global__ void __launch_bounds__(256) cross_merge_kernel(const float* __restric
 }
 
 template <int DH>
+void launch_frames(const CrossAttnArgs& a, int qtiles, hipStream_t st) {
+  if (a.NS * kFC >= a.T) {  // splits of <= 128 frames
+    SBK_LAUNCH((cross_attn_step_kernel<DH, kFC>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
+  } else {                  // splits of <= 256 frames (sbk_prof_set_knob key 8)
+    SBK_LAUNCH((cross_attn_step_kernel<DH, 2 * kFC>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
+  }
+}
+
+template <int DH>
 int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
   const int qtiles = (a.beam + kQT - 1) / kQT;
   sbk::ProfScope prof("cross_attn_step", 4.0 * a.B * a.beam * (double)a.T * a.d, 8.0 * a.B * (double)a.T * a.d, st);
@@ -660,10 +669,10 @@ int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
     if (sbk::g_cross_rows == 1 && (a.d % 4) == 0 && sbk::aligned16(a.kv) && sbk::aligned16(a.q)) {
       SBK_LAUNCH((cross_attn_rows_kernel<DH>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
     } else {
-      SBK_LAUNCH((cross_attn_step_kernel<DH>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
+      launch_frames<DH>(a, qtiles, st);
     }
   } else {
-    SBK_LAUNCH((cross_attn_step_kernel<DH>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
+    launch_frames<DH>(a, qtiles, st);
   }
   int rc = sbk::launch_status("cross_attn_step");
   if (rc || a.NS == 1) return rc;
@@ -731,7 +740,8 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
 }
 
 // Number of memory splits used for T frames and floats of partial storage they need.
-int cross_attn_splits(int T) { return cdiv(T, kFC); }
+int g_cross_fc256 = 0;  // tuning knob (key 8): 256 memory frames per workgroup for the frame-per-thread kernel
+int cross_attn_splits(int T) { return cdiv(T, kFC); }  // (sizes the partial buffer: never fewer than this many needed)
 size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam) {
   const int ns = cross_attn_splits(T);
   return ns > 1 ? (size_t)B * H * ns * beam * (Dh + 2) : 0;
@@ -754,7 +764,7 @@ int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, flo
                     int d, int H, int beam, hipStream_t st, int head_major) {
   if (B == 0) return 0;
   const int Dh = d / H;
-  const int NS = cross_attn_splits(T);
+  const int NS = (g_cross_fc256 && g_cross_rows == 0) ? cdiv(T, 2 * kFC) : cross_attn_splits(T);
   if (NS > 1 && !part) return fail(SBK_EINVAL, "cross_attn_step: T=%d needs a partial buffer", T);
   CrossAttnArgs a{q, kv, enc_len, out, part, B, T, d, H, Dh, beam, NS, 1.0f / sqrtf((float)Dh), head_major};
   switch (Dh) {

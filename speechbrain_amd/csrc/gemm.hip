@@ -538,4 +538,5 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 5) sbk::g_kv_head_major = value;
   if (key == 6) sbk::g_gemm_tile = value;
   if (key == 7) sbk::g_ctc_tpt = value;
+  if (key == 8) sbk::g_cross_fc256 = value;
 }
