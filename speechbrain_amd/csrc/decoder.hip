@@ -198,6 +198,7 @@ struct CrossAttnArgs {
   int B, T, d, H, Dh, beam, NS;
   float scale;
   int head_major;
+  int fc;  // memory frames per workgroup of the frame-per-thread kernel (64, 128 or 256)
 };
 
 // element offsets of (utterance b, head h): base of frame 0, frame stride, K -> V distance
@@ -643,10 +644,12 @@ __global__ void __launch_bounds__(256) cross_merge_kernel(const float* __restric
 
 template <int DH>
 void launch_frames(const CrossAttnArgs& a, int qtiles, hipStream_t st) {
-  if (a.NS * kFC >= a.T) {  // splits of <= 128 frames
+  if (a.fc == 64) {
+    SBK_LAUNCH((cross_attn_step_kernel<DH, 64>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
+  } else if (a.fc == 256) {
+    SBK_LAUNCH((cross_attn_step_kernel<DH, 256>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
+  } else {
     SBK_LAUNCH((cross_attn_step_kernel<DH, kFC>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
-  } else {                  // splits of <= 256 frames (sbk_prof_set_knob key 8)
-    SBK_LAUNCH((cross_attn_step_kernel<DH, 2 * kFC>), dim3(a.NS, a.H, a.B * qtiles), dim3(256), 0, st, a);
   }
 }
 
@@ -740,8 +743,8 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
 }
 
 // Number of memory splits used for T frames and floats of partial storage they need.
-int g_cross_fc256 = 0;  // tuning knob (key 8): 256 memory frames per workgroup for the frame-per-thread kernel
-int cross_attn_splits(int T) { return cdiv(T, kFC); }  // (sizes the partial buffer: never fewer than this many needed)
+int g_cross_fc256 = 0;  // tuning knob (key 8): memory frames per workgroup of the frame-per-thread kernel: 0 = 128, 1 = 256, 2 = 64
+int cross_attn_splits(int T) { return cdiv(T, 64); }  // sizes the partial buffer for the finest split
 size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam) {
   const int ns = cross_attn_splits(T);
   return ns > 1 ? (size_t)B * H * ns * beam * (Dh + 2) : 0;
@@ -764,9 +767,10 @@ int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, flo
                     int d, int H, int beam, hipStream_t st, int head_major) {
   if (B == 0) return 0;
   const int Dh = d / H;
-  const int NS = (g_cross_fc256 && g_cross_rows == 0) ? cdiv(T, 2 * kFC) : cross_attn_splits(T);
+  const int fc = g_cross_rows != 0 ? kFC : (g_cross_fc256 == 1 ? 256 : (g_cross_fc256 == 2 ? 64 : kFC));
+  const int NS = cdiv(T, fc);
   if (NS > 1 && !part) return fail(SBK_EINVAL, "cross_attn_step: T=%d needs a partial buffer", T);
-  CrossAttnArgs a{q, kv, enc_len, out, part, B, T, d, H, Dh, beam, NS, 1.0f / sqrtf((float)Dh), head_major};
+  CrossAttnArgs a{q, kv, enc_len, out, part, B, T, d, H, Dh, beam, NS, 1.0f / sqrtf((float)Dh), head_major, fc};
   switch (Dh) {
     case 64: return launch_cross<64>(a, st);
     case 36: return launch_cross<36>(a, st);

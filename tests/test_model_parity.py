@@ -281,7 +281,7 @@ def test_golden_rope_conformer(backend, tag):
 
 
 @pytest.mark.parametrize("nhead", [2, 4, 8])
-@pytest.mark.parametrize("rows,head_major", [(2, 0), (2, 1), (1, 1), (0, 1), (1, 0), (0, 0), (3, 0)])
+@pytest.mark.parametrize("rows,head_major", [(2, 0), (2, 1), (1, 1), (0, 1), (1, 0), (0, 0), (3, 0), (4, 0)])
 def test_cross_attention_kernel_variants(backend, nhead, rows, head_major):
     """The three cross-attention kernels (2: MFMA for head_dim 64/32, 1: row-coalesced for 64/32/16, 0:
     frame-per-thread) and both K/V layouts over a memory of several splits with ragged lengths, through
@@ -309,8 +309,8 @@ def test_cross_attention_kernel_variants(backend, nhead, rows, head_major):
     bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
                                     min_decode_ratio=0.0, max_decode_ratio=ratio, beam_size=5,
                                     using_eos_threshold=False, length_normalization=True)
-    nat.load().sbk_prof_set_knob(4, rows % 3)    # 3 = the frame-per-thread kernel with 256-frame splits
-    nat.load().sbk_prof_set_knob(8, int(rows == 3))
+    nat.load().sbk_prof_set_knob(4, rows if rows < 3 else 0)  # 3 / 4 = the frame-per-thread kernel with 256- / 64-frame splits
+    nat.load().sbk_prof_set_knob(8, {3: 1, 4: 2}.get(rows, 0))
     nat.load().sbk_prof_set_knob(5, head_major)  # cross K/V as [B,H,T,2*Dh] or as the projection wrote them
     try:
         h = nat.DecoderHandle(mods["Transformer"], mods["seq_lin"])
