@@ -135,13 +135,13 @@ def cpu_baseline(asr, seconds=6.0, batch=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=128, help="utterances per duration-sorted batch (32 = the recipe-sized batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--latency-runs", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=6, help="independent batches in flight per GPU")
+    ap.add_argument("--streams", type=int, default=8, help="independent batches in flight per GPU")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--attention", default="RelPosMHAXL", choices=["RelPosMHAXL", "RoPEMHA"],
                     help="encoder attention (RelPosMHAXL = BASELINE.json's config; RoPEMHA = the in-tree recipe)")
