@@ -168,12 +168,15 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # SBK_BENCH_FORCE_DIST=1 (with torchrun --nproc-per-node 1): run the RCCL leg -- process group, gather,
+    # all-reduce, barrier -- on a single GPU, to check the N > 1 code path where only one GPU is available
+    dist_on = world > 1 or (os.environ.get("SBK_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    if world > 1:
+    if dist_on:
         dist.init_process_group("nccl", device_id=dev)
 
     from speechbrain_amd import native
@@ -217,7 +220,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -226,19 +229,16 @@ def main():
     results = []
     for k, hyps in enumerate(workers.transcribe_batches([(w, l) for w, l, _ in pool_dev], prepare=fixed_decode_length)):
         results.extend((k * args.batch + i, h) for i, h in enumerate(hyps))
-    if world > 1:  # token ids to rank 0: the path's only collective
+    if dist_on:  # token ids to rank 0: the path's only collective
         width = int(round(TOKENS_PER_SECOND * 30.0)) + 8  # same shape on every rank (durations <= 30 s)
-        host = torch.zeros(len(results), width + 1, dtype=torch.int32)
-        for r, (_, h) in enumerate(results):
-            host[r, 0] = len(h)
-            host[r, 1:1 + len(h)] = torch.tensor(h, dtype=torch.int32)
+        host = torch.tensor([[len(h)] + list(h) + [0] * (width - len(h)) for _, h in results], dtype=torch.int32)
         buf = host.to(dev)  # one copy: [utterances, 1 + width] token ids of this rank
         gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
         dist.gather(buf, gathered, dst=0)
     barrier()
     dt = time.perf_counter() - t0
     stats = torch.tensor([dt, audio_sec], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = stats.clone()
@@ -337,7 +337,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

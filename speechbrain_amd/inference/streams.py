@@ -21,7 +21,7 @@ class ConcurrentTranscriber:
     batches in flight.  ``prepare(searcher, wavs)`` (optional) may adjust the per-worker copy of the
     searcher before a batch (e.g. its decode-length ratios); the copies share the model weights."""
 
-    def __init__(self, asr, streams: int = 6, prioritise_search: bool = True):
+    def __init__(self, asr, streams: int = 8, prioritise_search: bool = True):
         self.asr, self.n, self.device = asr, max(1, int(streams)), asr.device
         if self.device.type != "cuda":
             self.n = 1
