@@ -1,17 +1,19 @@
 #!/usr/bin/env python
 """bench.py -- audio-sec/s of the EncoderDecoderASR hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 8 --warmup 1
+    python bench.py --gpus 1 --steps 16 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[2], "Full Conformer-L enc-dec + S2STransformerBeamSearcher
 beam=10, LibriSpeech-shape synthetic"): Conformer-L (d 512, 12 enc / 6 dec layers, 5000 tokens,
 RelPosMHAXL), beam 10 + CTC weight 0.4 (the recipe's valid_search), seeded random weights,
 synthetic 16 kHz audio 0.1*randn, utterance durations U(5,30) s (seed 1234), duration-sorted
-batches of 128 utterances (sized for 288 GB of HBM; --batch 32 gives the recipe-sized batches), a
-few batches in flight on separate HIP streams (--streams), each search on a high-priority stream.  One "step" = one batch through
-Fbank -> norm -> CNN -> Conformer encoder -> beam search -> token ids on the host.  Random weights never emit EOS, so the number of decoding steps is
-fixed through max_decode_ratio to round(4 tokens/s * seconds).
+batches of 128 utterances (sized for 288 GB of HBM; --batch 32 gives the recipe-sized batches),
+--streams batches in flight through speechbrain_amd.inference.streams.ConcurrentTranscriber (one
+host thread per batch in flight, the encoder on a normal- and the search on a high-priority HIP
+stream).  One "step" = one batch through Fbank -> norm -> CNN -> Conformer encoder -> beam search ->
+token ids on the host.  Random weights never emit EOS, so the number of decoding steps is fixed
+through max_decode_ratio to round(4 tokens/s * seconds).
 Waveforms are resident in HBM when the timed region starts.  fp32 arithmetic throughout.
 
 One JSON line on rank 0: metric / value (total unpadded audio seconds of all ranks / max-over-ranks
