@@ -112,10 +112,10 @@ def cpu_baseline_subprocess(timeout_s=240):
 def cpu_baseline(asr, seconds=6.0, batch=2):
     """Oracle port of the reference's CPU path (no KV cache, Python-loop CTC scorer) on a bounded sample."""
     from oracle import sb_oracle as O
-    from speechbrain_amd.inference.builders import oracle_state_dict
+    from speechbrain_amd.inference.builders import flat_state_dict
 
     torch.set_num_threads(cpu_threads())
-    sd = oracle_state_dict(asr)
+    sd = flat_state_dict(asr)
     fc = O.FbankCfg(n_fft=512, n_mels=80, win_length_ms=32)
     mc = O.ModelCfg()
     n = int(seconds * 16000)

@@ -71,8 +71,8 @@ def build_asr(size="L", vocab=5000, seed=0, beam_size=10, ctc_weight=0.4, max_de
     return asr
 
 
-def oracle_state_dict(asr):
-    """Flat state_dict with the key prefixes oracle/sb_oracle.py expects (CNN. / Transformer. / seq_lin. / ctc_lin.)."""
+def flat_state_dict(asr):
+    """One flat state_dict of the ASR modules under the prefixes CNN. / Transformer. / seq_lin. / ctc_lin. (CPU tensors)."""
     sd = {}
     for pfx, mod in (("CNN.", asr.mods.encoder["model"]), ("Transformer.", asr.mods.transformer),
                      ("seq_lin.", asr.mods.seq_lin), ("ctc_lin.", asr.mods.ctc_lin)):

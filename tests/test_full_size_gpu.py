@@ -33,7 +33,7 @@ def _oracle_cfg(size):
 def test_encoder_vs_oracle(size, B, sec):
     """configs[1]-shaped (Conformer-S, 10 s) and Conformer-L encoders: Fbank within 1e-3 dB,
     encoder output within 2e-4 absolute (fp32; oracle self-noise is 2e-6)."""
-    from speechbrain_amd.inference.builders import oracle_state_dict
+    from speechbrain_amd.inference.builders import flat_state_dict
 
     asr = _asr(size)
     n = int(sec * 16000)
@@ -42,7 +42,7 @@ def test_encoder_vs_oracle(size, B, sec):
     for i in range(B):
         wav[i, int(lens[i] * n):] = 0
     fc, mc = _oracle_cfg(size)
-    sd = oracle_state_dict(asr)
+    sd = flat_state_dict(asr)
     feats = asr.mods.encoder["compute_features"](wav.cuda())
     assert float((feats.cpu() - O.fbank(wav, fc)).abs().max()) <= 1e-3
     enc = asr.encode_batch(wav, lens).cpu()
@@ -56,7 +56,7 @@ def test_rope_conformer_l_encoder_vs_oracle():
     within 2e-4 of the oracle, with padding."""
     import dataclasses
 
-    from speechbrain_amd.inference.builders import oracle_state_dict
+    from speechbrain_amd.inference.builders import flat_state_dict
 
     asr = _asr("L", attention_type="RoPEMHA")
     n = 6 * 16000
@@ -65,7 +65,7 @@ def test_rope_conformer_l_encoder_vs_oracle():
     wav[1, int(0.55 * n):] = 0
     fc, mc = _oracle_cfg("L")
     mc = dataclasses.replace(mc, attention_type="RoPEMHA")
-    sd = oracle_state_dict(asr)
+    sd = flat_state_dict(asr)
     enc = asr.encode_batch(wav, lens).cpu()
     ref = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
     assert float((enc - ref).abs().max()) <= 2e-4
@@ -76,7 +76,7 @@ def test_conformer_l_decoder_logprobs_and_search_vs_oracle():
     heads so that fp32 noise cannot flip a near-tie, SURVEY 7 hard-part 1) bit-exact token ids and
     scores within 1e-3 against the oracle's full-prefix / Python-loop CTC search."""
     from speechbrain_amd import native
-    from speechbrain_amd.inference.builders import oracle_state_dict
+    from speechbrain_amd.inference.builders import flat_state_dict
 
     asr = _asr("L", beam_size=10, ctc_weight=0.4)
     fc, mc = _oracle_cfg("L")
@@ -87,7 +87,7 @@ def test_conformer_l_decoder_logprobs_and_search_vs_oracle():
     wav = 0.1 * torch.randn(2, n, generator=torch.Generator().manual_seed(4))
     lens = torch.tensor([1.0, 0.7])
     wav[1, int(0.7 * n):] = 0
-    sd = oracle_state_dict(asr)
+    sd = flat_state_dict(asr)
     enc_ref = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
     T = enc_ref.shape[1]
     enc_lens = torch.round(T * lens).int()
@@ -114,7 +114,7 @@ def test_recipe_lm_scorer_search_vs_oracle():
     LM temperature 1.15, lm_weight 0.6) + CTC 0.4 (conformer_large.yaml:166-223 ``test_search`` scorers,
     beam 10): LM logits within 2e-3 on a fixed prefix, then bit-exact token ids vs the oracle."""
     from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder, TransformerLMScorer
-    from speechbrain_amd.inference.builders import oracle_state_dict
+    from speechbrain_amd.inference.builders import flat_state_dict
     from speechbrain_amd.lobes.models.transformer.TransformerLM import TransformerLM
 
     asr = _asr("L", beam_size=10, ctc_weight=0.4)
@@ -127,7 +127,7 @@ def test_recipe_lm_scorer_search_vs_oracle():
         asr.mods.ctc_lin.w.weight.mul_(8.0)
         lm.output_proj.layers[2].w.weight.mul_(4.0)
     lcfg = O.LMCfg(vocab=5000, d_model=768, nhead=12, num_encoder_layers=12, d_ffn=3072)
-    sd = oracle_state_dict(asr)
+    sd = flat_state_dict(asr)
     sd.update({"LM." + k: v.detach().cpu() for k, v in lm.state_dict().items()})
     toks = torch.randint(1, 5000, (3, 14), generator=torch.Generator().manual_seed(5))
     toks[1, 4] = 0  # a masked key
@@ -163,7 +163,7 @@ def test_recipe_test_search_beam66_vs_oracle():
     CTC 0.4, temperature 1.15) on Conformer-L: radix-select top-k, CTC tables in 5 tiles of 16 beams,
     LM K/V cache for 66 hypotheses -- bit-exact token ids and the top-3 list vs the oracle."""
     from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder, TransformerLMScorer
-    from speechbrain_amd.inference.builders import oracle_state_dict
+    from speechbrain_amd.inference.builders import flat_state_dict
     from speechbrain_amd.lobes.models.transformer.TransformerLM import TransformerLM
 
     asr = _asr("L", beam_size=10, ctc_weight=0.4)
@@ -176,7 +176,7 @@ def test_recipe_test_search_beam66_vs_oracle():
         asr.mods.ctc_lin.w.weight.mul_(8.0)
         lm.output_proj.layers[2].w.weight.mul_(4.0)
     lcfg = O.LMCfg(vocab=5000, d_model=768, nhead=12, num_encoder_layers=12, d_ffn=3072)
-    sd = oracle_state_dict(asr)
+    sd = flat_state_dict(asr)
     sd.update({"LM." + k: v.detach().cpu() for k, v in lm.state_dict().items()})
     n = 2 * 16000
     wav = 0.1 * torch.randn(1, n, generator=torch.Generator().manual_seed(8))
@@ -206,7 +206,7 @@ def test_recipe_test_search_beam66_vs_oracle():
 def test_greedy_beam1_bit_exact_tokens_conformer_l():
     """North-star: bit-exact token ids at greedy / beam = 1 (peaked heads, see above)."""
     from speechbrain_amd.decoders import S2STransformerBeamSearcher, S2STransformerGreedySearcher
-    from speechbrain_amd.inference.builders import oracle_state_dict
+    from speechbrain_amd.inference.builders import flat_state_dict
 
     asr = _asr("L", beam_size=1, ctc_weight=0.0)
     fc, mc = _oracle_cfg("L")
@@ -216,7 +216,7 @@ def test_greedy_beam1_bit_exact_tokens_conformer_l():
     wav = 0.1 * torch.randn(2, n, generator=torch.Generator().manual_seed(8))
     lens = torch.tensor([1.0, 0.8])
     wav[1, int(0.8 * n):] = 0
-    sd = oracle_state_dict(asr)
+    sd = flat_state_dict(asr)
     enc_ref = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
     T = enc_ref.shape[1]
     ratio = 20.5 / T

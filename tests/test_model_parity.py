@@ -88,7 +88,7 @@ def test_golden_model(backend, tag):
 def test_waveform_to_tokens_vs_oracle(backend):
     """EncoderDecoderASR.transcribe_batch on padded waveforms vs the oracle's whole path."""
     nat, dev = backend
-    from speechbrain_amd.inference.builders import build_asr, oracle_state_dict
+    from speechbrain_amd.inference.builders import build_asr, flat_state_dict
 
     tiny = dict(d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=2, n_fft=512, win_length=32)
     asr = build_asr(tiny, vocab=40, seed=3, beam_size=4, ctc_weight=0.4, device=str(dev))
@@ -100,7 +100,7 @@ def test_waveform_to_tokens_vs_oracle(backend):
     for i, l in enumerate(lens):
         wav[i, int(l * 9600):] = 0
     words, toks = asr.transcribe_batch(wav, lens)
-    sd = oracle_state_dict(asr)
+    sd = flat_state_dict(asr)
     fc = O.FbankCfg(n_fft=512, n_mels=80, win_length_ms=32)
     mc = O.ModelCfg(d_model=32, nhead=4, num_encoder_layers=2, num_decoder_layers=2, d_ffn=64, vocab=40)
     enc = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
@@ -506,7 +506,7 @@ def test_degenerate_inputs(backend):
     """Empty batch, a single very short utterance (T' = 3 encoder frames), batch of one, all-padding tails:
     the path returns the shapes the reference would and never faults."""
     nat, dev = backend
-    from speechbrain_amd.inference.builders import build_asr, oracle_state_dict
+    from speechbrain_amd.inference.builders import build_asr, flat_state_dict
 
     tiny = dict(d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=2, n_fft=512, win_length=32)
     asr = build_asr(tiny, vocab=40, seed=3, beam_size=4, ctc_weight=0.4, device=str(dev))
@@ -519,7 +519,7 @@ def test_degenerate_inputs(backend):
     # 0.07 s of audio -> 8 feature frames -> T' = 2; still decodes (max_decode_ratio 1.0 -> 2 steps)
     wav = 0.1 * torch.randn(1, 1120, generator=torch.Generator().manual_seed(2))
     words, toks = asr.transcribe_batch(wav, torch.ones(1))
-    sd = oracle_state_dict(asr)
+    sd = flat_state_dict(asr)
     fc = O.FbankCfg(n_fft=512, n_mels=80, win_length_ms=32)
     mc = O.ModelCfg(d_model=32, nhead=4, num_encoder_layers=2, num_decoder_layers=2, d_ffn=64, vocab=40)
     enc = O.encode_batch(wav, torch.ones(1), sd, fc, mc, torch.zeros(80), torch.ones(80))
