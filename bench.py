@@ -326,6 +326,10 @@ def main():
             if key:
                 traffic = pmc[key]["bytes_per_launch"]
                 roof["traffic_note"] = f"{pmc[key]['note']}; algorithmic {pmc[key]['algorithmic_bytes_per_launch']} B/launch"
+            busy = {k: v["mfma_busy"] for k, v in pmc.get("_mfma_busy", {}).items()
+                    if not k.startswith("_") and k.startswith(name)}
+            if busy:  # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x active cycles), from its own --pmc pass
+                roof["mfma_busy_pmc"] = busy
         except Exception:
             pass
         roof.update({"traffic": traffic, "kernel": name, "launches": top["count"], "avg_launch_ms": round(avg_ms, 4),
