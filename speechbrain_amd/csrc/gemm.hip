@@ -89,14 +89,8 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(Gem
   constexpr int WAVES_N = BN / WN;
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr int TM = WM / 32, TN = WN / 32;
-  // two LDS stages of the A / W panels: the next K tile is committed to the other stage while this one
-  // is being multiplied, so ONE barrier per K tile orders everything (PMC: with a single stage and two
-  // barriers 20 % of the wave time of the 128x128 kernel was parked on s_waitcnt / barriers)
-  SBK_DYN_LDS(float, lds);
-  typedef float(*Panel)[BK + 1];
-  constexpr int kStage = (BM + BN) * (BK + 1);  // floats per stage: A panel, then W panel
-  auto a_panel = [&](int stage) { return reinterpret_cast<Panel>(lds + stage * kStage); };
-  auto w_panel = [&](int stage) { return reinterpret_cast<Panel>(lds + stage * kStage + BM * (BK + 1)); };
+  __shared__ float As[BM][BK + 1];
+  __shared__ float Ws[BN][BK + 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -128,35 +122,27 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(Gem
   PanelStage<BN, BK, NT> pw;
   pa.template fetch<VEC>(g.A, g.lda, m0, g.M, 0, g.K, tid);
   pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, 0, g.K, tid);
-  pa.commit(a_panel(0), tid);
-  pw.commit(w_panel(0), tid);
-  __syncthreads();
-  int cur = 0;
   for (int k0 = 0; k0 < g.K; k0 += BK) {
-    const bool more = k0 + BK < g.K;
-    if (more) {  // next K tile: loads fly while this tile is multiplied
+    pa.commit(As, tid);
+    pw.commit(Ws, tid);
+    __syncthreads();
+    if (k0 + BK < g.K) {  // next K tile: loads fly while this tile is multiplied
       pa.template fetch<VEC>(g.A, g.lda, m0, g.M, k0 + BK, g.K, tid);
       pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, k0 + BK, g.K, tid);
     }
-    const Panel Ac = a_panel(cur), Wc = w_panel(cur);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = Ac[wm0 + i * 32 + lrow][kk + lk];
+      for (int i = 0; i < TM; ++i) a[i] = As[wm0 + i * 32 + lrow][kk + lk];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Wc[wn0 + j * 32 + lrow][kk + lk];
+      for (int j = 0; j < TN; ++j) b[j] = Ws[wn0 + j * 32 + lrow][kk + lk];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x2(a[i], b[j], acc[i][j]);
     }
-    if (more) {  // the other stage was last read one iteration ago, before the previous barrier
-      pa.commit(a_panel(cur ^ 1), tid);
-      pw.commit(w_panel(cur ^ 1), tid);
-    }
     __syncthreads();
-    cur ^= 1;
   }
 
   // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -382,15 +368,10 @@ int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
                              : (BM == 128 && BN == 256) ? "gemm_nt_128x256"
                              : BM == 128 ? "gemm_nt_128x128" : (BM == 64 ? "gemm_nt_64x64" : "gemm_nt_32x64");
   sbk::ProfScope prof(kName, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N), st);
-  constexpr size_t kLds = (size_t)2 * (BM + BN) * (BK + 1) * sizeof(float);  // two stages of both panels
   if (vec) {
-    if (kLds > 64 * 1024 && SBK_ALLOW_DYN_LDS((gemm_nt_kernel<BM, BN, BK, WM, WN, true>), kLds) != hipSuccess)
-      return sbk::fail(SBK_EINVAL, "gemm: cannot raise the LDS window to %zu B", kLds);
-    SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, true>), grid, block, kLds, st, g);
+    SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, true>), grid, block, 0, st, g);
   } else {
-    if (kLds > 64 * 1024 && SBK_ALLOW_DYN_LDS((gemm_nt_kernel<BM, BN, BK, WM, WN, false>), kLds) != hipSuccess)
-      return sbk::fail(SBK_EINVAL, "gemm: cannot raise the LDS window to %zu B", kLds);
-    SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, false>), grid, block, kLds, st, g);
+    SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, false>), grid, block, 0, st, g);
   }
   return sbk::launch_status("sbk_gemm_nt_f32");
 }
