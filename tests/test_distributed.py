@@ -81,3 +81,66 @@ def test_planning_properties():
     loads = [sum(costs[i] for i in o) for o in owner]
     assert max(loads) <= min(loads) + max(costs)                              # LPT balance bound
     assert plan_batches([], 4) == [] and assign_batches([], 3) == [[], [], []]
+
+
+def _tiny_asr():
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from emu_utils import attach
+
+    attach()  # CPU kernel emulator (test tooling): the product itself has no CPU path
+    from speechbrain_amd.inference.builders import build_asr
+
+    tiny = dict(d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=2, n_fft=512, win_length=32)
+    asr = build_asr(tiny, vocab=40, seed=3, beam_size=3, ctc_weight=0.4, device="cpu", max_decode_ratio=0.4)
+    with torch.no_grad():
+        asr.mods.seq_lin.w.weight.mul_(6.0)
+        asr.mods.ctc_lin.w.weight.mul_(6.0)
+    return asr
+
+
+def _asr_job():
+    g = torch.Generator().manual_seed(11)
+    return [0.1 * torch.randn(int(n), generator=g) for n in torch.randint(3000, 8000, (9,), generator=g)]
+
+
+def _worker_asr(rank, world, tmpdir, q):
+    os.environ["RANK"], os.environ["LOCAL_RANK"], os.environ["WORLD_SIZE"] = str(rank), str(rank), str(world)
+    dist.init_process_group("gloo", init_method=f"file://{tmpdir}/sync", rank=rank, world_size=world)
+    try:
+        from speechbrain_amd.inference.streams import ConcurrentTranscriber
+
+        asr = _tiny_asr()
+        st = ShardedTranscriber(lambda w, l: asr.transcribe_batch(w, l)[1], "cpu", max_utts=2,
+                                concurrent=ConcurrentTranscriber(asr, streams=3))
+        hyps = st.transcribe(_asr_job() if rank == 0 else None)
+        if rank == 0:
+            q.put(hyps)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_asr_world2_matches_single_process(tmp_path):
+    """The whole multi-rank path with the real modules (tiny Conformer on the CPU kernel emulator): rank 0
+    scatters padded waveforms, both ranks transcribe their batches through ConcurrentTranscriber, token ids
+    are gathered -- and equal a plain single-process transcription of the same batches."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_asr, args=(r, 2, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    hyps = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    from speechbrain_amd.inference.sharded import pad_batch
+
+    asr = _tiny_asr()
+    wavs = _asr_job()
+    ref = [None] * len(wavs)
+    for b in plan_batches([w.numel() for w in wavs], max_utts=2):
+        x, lens = pad_batch(wavs, b)
+        for i, h in zip(b, asr.transcribe_batch(x, lens)[1]):
+            ref[i] = h
+    assert hyps == ref
