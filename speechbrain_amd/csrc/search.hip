@@ -2,8 +2,8 @@
 //
 // Replaces decoders/seq2seq.py:711-1749 (S2SBeamSearcher.forward and helpers),
 // :1853-1934 (S2STransformerBeamSearcher), :176-367 (greedy), scorer.py:1221-1315
-// (ScorerBuilder with one full CTC scorer) and TransformerASR.decode
-// (TransformerASR.py:426-473).  The whole search runs inside ONE C-ABI call: the
+// (ScorerBuilder with the full CTC and / or TransformerLM scorers, scorer.py:413-577) and
+// TransformerASR.decode (TransformerASR.py:426-473).  The whole search runs inside ONE C-ABI call: the
 // host loop only enqueues kernels; beam bookkeeping (length-normalised top-k over
 // beam*V, predecessor gathers, EOS harvesting, finished-hypothesis lists) lives in
 // device memory, so there is no per-step host synchronisation.  The reference's
