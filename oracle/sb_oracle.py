@@ -3,8 +3,8 @@
 This file is a functional (state_dict in, tensors out) restatement, in plain
 fp32 PyTorch-CPU ops, of the algorithm SpeechBrain's own modules run for the
 path  STFT/Fbank -> InputNormalization -> ConvolutionFrontEnd -> TransformerASR
-.encode (Conformer, RelPosMHAXL) -> S2STransformer{Beam,Greedy}Searcher
-(+ CTCScorer / CTCPrefixScore).
+.encode (Conformer, RelPosMHAXL or RoPEMHA) -> S2STransformer{Beam,Greedy}Searcher
+(+ CTCScorer / CTCPrefixScore, TransformerLMScorer / TransformerLM, return_topk).
 
 * It is the checker, never the product: only ``tests/``,
   ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
