@@ -3,11 +3,53 @@
 model directory (hyperparams.yaml + *.ckpt, the layout of the reference's HuggingFace model cards) are
 supported; fetching from HuggingFace / URLs is not (no network on the box)."""
 import os
+import struct
 import types
-import wave
 
 import numpy as np
 import torch
+
+
+def read_wav(path):
+    """RIFF/WAVE reader for the formats libsndfile (the reference's ``soundfile`` backend,
+    dataio/audio_io.py:141-209) decodes to float32 the same way: integer PCM of 8 / 16 / 24 / 32 bits scaled by
+    2^(bits-1) (8-bit is unsigned with a 128 offset), IEEE float 32 / 64 as is; plain and WAVE_FORMAT_EXTENSIBLE
+    headers.  Returns (float32 array [frames, channels], sample_rate)."""
+    with open(str(path), "rb") as f:
+        data = f.read()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file (only wav files are read by the built-in loader)")
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        tag, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if tag == b"fmt ":
+            code, ch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
+            if code == 0xFFFE and len(body) >= 26:  # WAVE_FORMAT_EXTENSIBLE: the real code leads the sub-format GUID
+                code = struct.unpack("<H", body[24:26])[0]
+            fmt = (code, ch, sr, bits)
+        elif tag == b"data":
+            pcm = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None:
+        raise ValueError(f"{path}: missing fmt or data chunk")
+    code, ch, sr, bits = fmt
+    if code == 1 and bits == 8:
+        x = (np.frombuffer(pcm, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif code == 1 and bits == 16:
+        x = np.frombuffer(pcm, dtype="<i2").astype(np.float32) / 32768.0
+    elif code == 1 and bits == 24:
+        b = np.frombuffer(pcm[: len(pcm) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        x = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
+    elif code == 1 and bits == 32:
+        x = (np.frombuffer(pcm, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    elif code == 3 and bits in (32, 64):
+        x = np.frombuffer(pcm, dtype="<f4" if bits == 32 else "<f8").astype(np.float32)
+    else:
+        raise NotImplementedError(f"{path}: wav format code {code} with {bits} bits is not read by the built-in loader")
+    n = x.size // ch * ch
+    return x[:n].reshape(-1, ch), sr
 
 
 class AudioNormalizer:
@@ -57,15 +99,12 @@ class Pretrained(torch.nn.Module):
                 p.requires_grad = False
 
     def load_audio(self, path, savedir=None):
-        """PCM16 wav -> float32 [time] in [-1,1) (soundfile's float convention), mono."""
-        with wave.open(str(path), "rb") as f:
-            if f.getsampwidth() != 2:
-                raise NotImplementedError("only 16-bit PCM wav files are read by the built-in loader")
-            sr, ch = f.getframerate(), f.getnchannels()
-            pcm = np.frombuffer(f.readframes(f.getnframes()), dtype="<i2")
-        sig = torch.from_numpy(pcm.astype(np.float32) / 32768.0)
-        if ch > 1:
-            sig = sig.view(-1, ch)
+        """wav file -> float32 [time] (soundfile's float convention), channels averaged
+        (inference/interfaces.py:343-358 + dataio/preprocess.py:49-84)."""
+        x, sr = read_wav(path)
+        sig = torch.from_numpy(np.ascontiguousarray(x))
+        if sig.shape[1] == 1:
+            sig = sig[:, 0]
         return self.audio_normalizer(sig, sr).to(self.device)
 
     @classmethod

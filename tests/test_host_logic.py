@@ -164,3 +164,50 @@ def test_pretrainer_local_sources(tmp_path):
         Pretrainer(loadables={"absent": lin}).collect_files(default_source=str(tmp_path))
     with pytest.raises(ValueError):
         Pretrainer(loadables={"nopath": lin}).collect_files()
+
+
+def test_wav_reader_formats(tmp_path):
+    """inference/interfaces.py:read_wav -- the sample formats libsndfile converts to float the same way."""
+    import struct
+
+    from speechbrain_amd.inference.interfaces import read_wav
+
+    rng = np.random.default_rng(0)
+    ref = np.clip(rng.normal(0, 0.3, (1000, 2)), -0.99, 0.99)
+
+    def write(name, code, bits, payload, extensible=False):
+        ch, sr = 2, 16000
+        block = ch * bits // 8
+        fmt = struct.pack("<HHIIHH", 0xFFFE if extensible else code, ch, sr, sr * block, block, bits)
+        if extensible:
+            fmt += struct.pack("<HHI", 22, bits, 3) + struct.pack("<H", code) + b"\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71"
+        chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"LIST" + struct.pack("<I", 3) + b"abc\x00"
+        chunks += b"data" + struct.pack("<I", len(payload)) + payload
+        path = tmp_path / name
+        path.write_bytes(b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks)
+        return path
+
+    i16 = np.round(ref * 32767).astype("<i2")
+    x, sr = read_wav(write("p16.wav", 1, 16, i16.tobytes()))
+    assert sr == 16000 and x.shape == (1000, 2) and np.array_equal(x, i16.astype(np.float32) / 32768.0)
+    x, _ = read_wav(write("p16x.wav", 1, 16, i16.tobytes(), extensible=True))
+    assert np.array_equal(x, i16.astype(np.float32) / 32768.0)
+    u8 = np.round(ref * 127 + 128).astype(np.uint8)
+    x, _ = read_wav(write("p8.wav", 1, 8, u8.tobytes()))
+    assert np.array_equal(x, (u8.astype(np.float32) - 128) / 128)
+    i32 = np.round(ref * 2147483000).astype("<i4")
+    x, _ = read_wav(write("p32.wav", 1, 32, i32.tobytes()))
+    assert np.allclose(x, i32 / 2147483648.0, atol=1e-7)
+    i24 = np.round(ref * 8388607).astype(np.int32)
+    b24 = np.stack([(i24 >> s) & 0xFF for s in (0, 8, 16)], axis=-1).astype(np.uint8)
+    x, _ = read_wav(write("p24.wav", 1, 24, b24.tobytes()))
+    assert np.array_equal(x, i24.astype(np.float32) / 8388608.0)
+    f32 = ref.astype("<f4")
+    x, _ = read_wav(write("f32.wav", 3, 32, f32.tobytes()))
+    assert np.array_equal(x, f32)
+    with pytest.raises(ValueError):
+        bad = tmp_path / "bad.wav"
+        bad.write_bytes(b"OggS" + b"\x00" * 40)
+        read_wav(bad)
+    with pytest.raises(NotImplementedError):
+        read_wav(write("adpcm.wav", 2, 4, b"\x00" * 64))
