@@ -55,6 +55,12 @@ int sbk_prof_ctc_psi_repeat_f32(float* x, const int32_t* enc_len, const int32_t*
 /* ---- activations understood by fused epilogues --------------------------- */
 enum { SBK_ACT_NONE = 0, SBK_ACT_SWISH = 1, SBK_ACT_GELU = 2, SBK_ACT_RELU = 3, SBK_ACT_LEAKY_RELU = 4 };
 
+/* ---- a1: PCM16 frames -> float32 mono.  Replaces the sample conversion of audio_io.load (dataio/audio_io.py
+ * :141-209: soundfile's float32 convention, sample / 32768) and AudioNormalizer's channel mean
+ * (dataio/preprocess.py:76-84) for waveforms that are kept / shipped as int16 (inference/sharded.py scatters
+ * them that way: half the xGMI and PCIe bytes of fp32).  pcm [frames, channels] interleaved -> out [frames]. */
+int sbk_pcm16_to_f32(const int16_t* pcm, float* out, long frames, int channels, sbk_stream_t stream);
+
 /* ---- a2-a5: Fbank -------------------------------------------------------
  * Replaces lobes/features.py:147-169 (Fbank.forward) = processing/features.py
  * :141-188 (STFT -> torch.stft), :341-378 (spectral_magnitude, power=1),

@@ -608,7 +608,48 @@ def golden_init_fingerprint():
     print(f"  {len(fp)} tensors")
 
 
+def golden_wer():
+    """ErrorRateStats (utils/metric_stats.py:206, utils/edit_distance.py) on random token sequences with random
+    edits: per-utterance insertions / deletions / substitutions, the alignment op strings and the summary of the
+    REFERENCE -- the Kaldi-style tie-breaking is what a restatement most easily gets wrong."""
+    print("== WER (ErrorRateStats)")
+    from speechbrain.utils.metric_stats import ErrorRateStats
+
+    g = torch.Generator().manual_seed(77)
+    refs, hyps = [], []
+    for i in range(60):
+        n = int(torch.randint(0, 14, (1,), generator=g))
+        ref = torch.randint(3, 9, (n,), generator=g).tolist()  # small alphabet: many ties
+        hyp = list(ref)
+        for _ in range(int(torch.randint(0, 6, (1,), generator=g))):
+            kind = int(torch.randint(0, 3, (1,), generator=g))
+            pos = int(torch.randint(0, len(hyp) + 1, (1,), generator=g))
+            if kind == 0:
+                hyp.insert(pos, int(torch.randint(3, 9, (1,), generator=g)))
+            elif kind == 1 and hyp:
+                del hyp[min(pos, len(hyp) - 1)]
+            elif hyp:
+                hyp[min(pos, len(hyp) - 1)] = int(torch.randint(3, 9, (1,), generator=g))
+        refs.append(ref)
+        hyps.append(hyp)
+    stats = ErrorRateStats()
+    ids = [f"u{i}" for i in range(len(refs))]
+    stats.append(ids, [[str(t) for t in h] for h in hyps], [[str(t) for t in r] for r in refs])
+    summ = stats.summarize()
+    pad = lambda seqs: np.array([s + [-1] * (20 - len(s)) for s in seqs], dtype=np.int64)  # noqa: E731
+    out = {"refs": pad(refs), "hyps": pad(hyps),
+           "ins_del_sub": np.array([[d["insertions"], d["deletions"], d["substitutions"]] for d in stats.scores]),
+           "utt_wer": np.array([d["WER"] for d in stats.scores]),
+           "ops": np.array(["".join(op for op, _, _ in d["alignment"]) for d in stats.scores]),
+           "summary_keys": np.array(sorted(summ)), "summary_vals": np.array([float(summ[k]) for k in sorted(summ)])}
+    np.savez_compressed(os.path.join(OUT, "wer.npz"), **out)
+    print(f"  WER {summ['WER']:.3f} over {summ['num_scored_tokens']} tokens, {len(refs)} utterances")
+
+
 if __name__ == "__main__":
+    if "--wer-only" in sys.argv:
+        golden_wer()
+        sys.exit(0)
     if "--tiny-ctc-only" in sys.argv:
         golden_model("tiny_ctc", d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=2, vocab=40, B=3, n_frames=61,
                      beam=4, ctc_w=0.4, sharpen=6.0, max_ratio=1.0)
@@ -640,4 +681,5 @@ if __name__ == "__main__":
     golden_rope("rope_dh36", d_model=72, nhead=2, seed=6, B=2)
     golden_pretrained()
     golden_init_fingerprint()
+    golden_wer()
     print("OK")

@@ -16,7 +16,7 @@ _MODULES = [
     "lobes.models.transformer.TransformerASR", "lobes.models.transformer.TransformerLM", "nnet", "nnet.attention", "nnet.activations", "nnet.CNN",
     "nnet.containers", "nnet.embedding", "nnet.linear", "nnet.normalization", "decoders", "decoders.seq2seq",
     "decoders.scorer", "decoders.utils", "inference", "inference.ASR", "inference.interfaces", "utils",
-    "utils.data_utils",
+    "utils.data_utils", "utils.parameter_transfer", "utils.metric_stats", "utils.edit_distance",
 ]
 
 

@@ -248,7 +248,46 @@ __global__ void __launch_bounds__(256) to_db_kernel(float* __restrict__ x, float
   __syncthreads();
   if (tid == 0) tile_max[(size_t)b * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
+
+// a1: PCM16 frames -> float32 mono, the soundfile convention the reference loads with (sample / 32768,
+// dataio/audio_io.py:141-209) followed by AudioNormalizer's channel mean (dataio/preprocess.py:76-84).
+// Streaming: 2*channels bytes in, 4 bytes out per frame; 8 frames per thread.
+__global__ void __launch_bounds__(256) pcm16_to_f32_kernel(const int16_t* __restrict__ pcm, float* __restrict__ out,
+                                                           long frames, int channels) {
+  const float inv = 1.0f / 32768.0f;
+  for (long f0 = ((long)blockIdx.x * 256 + threadIdx.x) * 8; f0 < frames; f0 += (long)gridDim.x * 256 * 8) {
+    if (channels == 1 && f0 + 8 <= frames && (reinterpret_cast<uintptr_t>(pcm + f0) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(out + f0) & 15) == 0) {
+      const int4 raw = *reinterpret_cast<const int4*>(pcm + f0);  // 8 samples in one 16-byte load
+      const int w[4] = {raw.x, raw.y, raw.z, raw.w};
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[2 * k] = (float)(int16_t)(w[k] & 0xFFFF) * inv;
+        v[2 * k + 1] = (float)(int16_t)((unsigned)w[k] >> 16) * inv;
+      }
+      *reinterpret_cast<float4*>(out + f0) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(out + f0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      for (long f = f0; f < f0 + 8 && f < frames; ++f) {
+        float acc = 0.0f;
+        for (int c = 0; c < channels; ++c) acc += (float)pcm[f * channels + c] * inv;  // exact: |pcm| < 2^15
+        out[f] = channels == 1 ? acc : acc / (float)channels;  // torch.mean over the channel axis
+      }
+    }
+  }
+}
 }  // namespace
+
+extern "C" int sbk_pcm16_to_f32(const int16_t* pcm, float* out, long frames, int channels, sbk_stream_t stream) {
+  if (frames == 0) return 0;
+  SBK_REQUIRE(pcm && out && frames > 0 && channels >= 1, "pcm16_to_f32: bad arguments");
+  const long groups = (frames + 2047) / 2048;
+  const int blocks = (int)(groups < 8192 ? groups : 8192);
+  sbk::ProfScope prof("pcm16_to_f32", 0.0, (2.0 * channels + 4.0) * (double)frames, sbk::as_stream(stream));
+  SBK_LAUNCH(pcm16_to_f32_kernel, dim3(blocks), dim3(256), 0, sbk::as_stream(stream), pcm, out, frames, channels);
+  return sbk::launch_status("sbk_pcm16_to_f32");
+}
 
 extern "C" int sbk_spectral_magnitude_f32(const float* stft, float* out, long n, float power, int take_log, float eps,
                                           sbk_stream_t stream) {

@@ -19,9 +19,10 @@ class S2SBaseSearcher(torch.nn.Module):
         self.min_decode_ratio, self.max_decode_ratio = min_decode_ratio, max_decode_ratio
 
     def _handle(self):
+        """Weight table for the C ABI; rebuilt when any source parameter moved OR was updated in place
+        (the table holds LayerNorm-folded copies of the projections)."""
         h = getattr(self, "_dec_handle", None)
-        probe = self.model.decoder.norm.norm.weight
-        if h is None or h.device != probe.device or h.keep[0].data_ptr() != self.model.decoder.layers[0].norm1.norm.weight.data_ptr():
+        if h is None or h.stale(self.model, self.fc):
             h = native.DecoderHandle(self.model, self.fc)
             self._dec_handle = h
         return h
@@ -147,7 +148,9 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
             B, K, max_len = enc_states.shape[0], self.topk, max(int(mxl.cpu()), 1)
             return (tok[:, :max_len].reshape(B, K, max_len).long(), ln.float().reshape(B, K) / max_len,
                     sc.reshape(B, K), lp[:, :max_len].reshape(B, K, max_len))
-        tok_h, ln_h, max_len = tok.cpu(), ln.cpu(), max(int(mxl.cpu()), 1)
-        hyps = [tok_h[b, : int(ln_h[b])].tolist() for b in range(tok_h.shape[0])]
+        B, L = tok.shape
+        packed = torch.cat([tok.reshape(-1), ln, mxl]).cpu()  # one device->host copy (and the call's only sync)
+        tok_h, ln_h, max_len = packed[: B * L].reshape(B, L), packed[B * L: B * L + B], max(int(packed[-1]), 1)
+        hyps = [tok_h[b, : int(ln_h[b])].tolist() for b in range(B)]
         best_lens = ln_h.float() / max_len  # SpeechBrain relative length (seq2seq.py:1461)
         return hyps, best_lens.to(enc_states.device), sc, lp[:, :max_len]

@@ -3,9 +3,15 @@
 The path has no cross-utterance state at inference, so utterances shard embarrassingly: one
 process per GPU, each with a full model replica.  Rank 0 owns the job: it sorts utterances by
 duration, forms length-bucketed batches (cf. DynamicBatchSampler, dataio/sampler.py:321),
-assigns batches to ranks longest-processing-time-first, SCATTERS the padded waveforms (RCCL
-scatter over xGMI when the backend is "nccl"; gloo in the CPU tests) and GATHERS the token ids.
-Those two collectives are the only communication; nothing is exchanged while decoding.
+assigns batches to ranks longest-processing-time-first, SCATTERS the padded waveforms (grouped
+point-to-point sends, one per peer = one per xGMI link, RCCL when the backend is "nccl"; gloo in
+the CPU tests) and GATHERS the token ids.  Those two exchanges are the only communication;
+nothing is exchanged while decoding.
+
+Waveforms travel in the dtype they are given in: int16 PCM (what a wav file holds; 2 bytes per
+sample on PCIe and xGMI, converted with sbk_pcm16_to_f32 on the receiving GPU -- the reference's
+``sample / 32768`` load convention, dataio/audio_io.py:141-209) or float32.  Nothing is
+quantised on the way.
 """
 from __future__ import annotations
 
@@ -17,7 +23,8 @@ import torch.distributed as dist
 
 def plan_batches(n_samples: Sequence[int], max_utts: int = 32, max_padded_samples: Optional[int] = None) -> List[List[int]]:
     """Duration-sorted batches: consecutive runs of the length-sorted utterances, at most
-    ``max_utts`` each and (optionally) at most ``max_padded_samples`` of padded audio."""
+    ``max_utts`` each and (optionally) at most ``max_padded_samples`` of padded audio
+    (``max_batch_length`` of the reference's DynamicBatchSampler, in samples)."""
     order = sorted(range(len(n_samples)), key=lambda i: (n_samples[i], i))
     batches, cur = [], []
     for i in order:
@@ -48,10 +55,16 @@ def assign_batches(costs: Sequence[float], world: int) -> List[List[int]]:
     return out
 
 
-def pad_batch(wavs: Sequence[torch.Tensor], idx: Sequence[int]):
-    """batch_pad_right (utils/data_utils.py:459-519): zero right-padding, relative lengths."""
+def pad_batch(wavs: Sequence[torch.Tensor], idx: Sequence[int], out: Optional[torch.Tensor] = None):
+    """batch_pad_right (utils/data_utils.py:459-519): zero right-padding, relative lengths.  Keeps the
+    waveforms' dtype (float32 or int16 PCM); ``out``: optional preallocated [len(idx) * n_max] slab."""
     n = max(wavs[i].numel() for i in idx)
-    out = torch.zeros(len(idx), n, dtype=torch.float32)
+    dtype = wavs[idx[0]].dtype
+    if out is None:
+        out = torch.zeros(len(idx), n, dtype=dtype)
+    else:
+        out = out.view(len(idx), n)
+        out.zero_()
     for r, i in enumerate(idx):
         out[r, : wavs[i].numel()] = wavs[i]
     return out, torch.tensor([wavs[i].numel() / n for i in idx], dtype=torch.float32)
@@ -65,63 +78,99 @@ class ShardedTranscriber:
     """
 
     def __init__(self, transcribe_batch: Callable, device, max_utts: int = 32, max_padded_samples: Optional[int] = None,
-                 group=None, concurrent=None):
+                 group=None, concurrent=None, prepare: Optional[Callable] = None):
         """``concurrent`` (optional): a ``speechbrain_amd.inference.streams.ConcurrentTranscriber``; the rank's
-        batches then run several at a time on separate HIP streams instead of one after the other."""
+        batches then run several at a time on separate HIP streams instead of one after the other (``prepare`` is
+        handed to it)."""
         self.fn, self.device, self.max_utts, self.max_padded = transcribe_batch, torch.device(device), max_utts, max_padded_samples
-        self.group, self.concurrent = group, concurrent
+        self.group, self.concurrent, self.prepare = group, concurrent, prepare
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.last_plan = None  # rank 0: {"batches": ..., "owner": ..., "bytes_sent": ...} of the last scatter
 
     # -- scatter -----------------------------------------------------------------
-    def scatter(self, wavs: Optional[Sequence[torch.Tensor]]):
-        """Rank 0 passes the waveforms; every rank returns its local list of
-        (global utterance ids, padded batch on device, relative lengths)."""
+    def _stage(self, wavs, batches, which):
+        """One rank's batches as ONE host slab (pinned when the target is a GPU: asynchronous H2D) + metadata."""
+        dtype = wavs[batches[which[0]][0]].dtype if which else torch.float32
+        sizes = [len(batches[b]) * max(wavs[i].numel() for i in batches[b]) for b in which]
+        slab = torch.empty(sum(sizes), dtype=dtype, pin_memory=self.device.type == "cuda")
+        meta, off = [], 0
+        for b, cnt in zip(which, sizes):
+            x, lens = pad_batch(wavs, batches[b], out=slab[off: off + cnt])
+            meta.append((batches[b], tuple(x.shape), lens.tolist()))
+            off += cnt
+        return slab, meta
+
+    def plan(self, wavs: Optional[Sequence[torch.Tensor]]):
+        """Rank 0 (host work only): sort by duration, bucket, assign longest-processing-time-first and pad every
+        rank's batches into one pinned host slab.  Other ranks pass None and get None."""
+        if self.rank != 0:
+            return None
+        n = [w.numel() for w in wavs]
+        batches = plan_batches(n, self.max_utts, self.max_padded)
+        owner = assign_batches([batch_cost(n, b) for b in batches], self.world)
+        dtype = wavs[0].dtype if len(wavs) else torch.float32
+        slabs, metas = [], []
+        for r in range(self.world):
+            slab, meta = self._stage(wavs, batches, owner[r])
+            slabs.append(slab)
+            metas.append((str(dtype), slab.numel(), meta))
+        self.last_plan = {"batches": batches, "owner": owner,
+                          "bytes_sent": sum(s.numel() * s.element_size() for s in slabs[1:])}
+        return {"slabs": slabs, "metas": metas}
+
+    def distribute(self, plan):
+        """The scatter proper: per-rank metadata (pickled, small) + each rank's slab.  Every rank returns its local
+        list of (global utterance ids, padded batch on device [B,N] in the input dtype, relative lengths [B])."""
         if self.world == 1:
-            n = [w.numel() for w in wavs]
-            batches = plan_batches(n, self.max_utts, self.max_padded)
-            return [(b,) + tuple(t.to(self.device) for t in pad_batch(wavs, b)) for b in batches]
-        meta: List = [None] * self.world
-        payloads: List[torch.Tensor] = []
-        if self.rank == 0:
-            n = [w.numel() for w in wavs]
-            batches = plan_batches(n, self.max_utts, self.max_padded)
-            owner = assign_batches([batch_cost(n, b) for b in batches], self.world)
-            flat = []
-            for r in range(self.world):
-                m, parts = [], []
-                for bi in owner[r]:
-                    x, lens = pad_batch(wavs, batches[bi])
-                    m.append((batches[bi], tuple(x.shape), lens.tolist()))
-                    parts.append(x.reshape(-1))
-                meta[r] = m
-                flat.append(torch.cat(parts) if parts else torch.zeros(0))
-            width = max(1, max(f.numel() for f in flat))
-            payloads = [torch.nn.functional.pad(f, (0, width - f.numel())).to(self.device) for f in flat]
-            sizes = [width]
+            _, _, my_meta = plan["metas"][0]
+            recv = plan["slabs"][0].to(self.device, non_blocking=True)
         else:
-            sizes = [None]
-        dist.broadcast_object_list(sizes, src=0, group=self.group)
-        my_meta = [None]
-        dist.scatter_object_list(my_meta, meta if self.rank == 0 else None, src=0, group=self.group)
-        recv = torch.empty(sizes[0], dtype=torch.float32, device=self.device)
-        dist.scatter(recv, payloads if self.rank == 0 else None, src=0, group=self.group)
+            mine = [None]
+            dist.scatter_object_list(mine, plan["metas"] if self.rank == 0 else None, src=0, group=self.group)
+            dtype_name, count, my_meta = mine[0]
+            dtype = {"torch.int16": torch.int16, "torch.float32": torch.float32}[dtype_name]
+            if self.rank == 0:
+                # exact-size sends, one per peer, posted together: RCCL runs them as one group (each peer is its
+                # own xGMI link); rank 0's own share is a plain host-to-device copy
+                staged = [s.to(self.device, non_blocking=True) for s in plan["slabs"]]
+                ops = [dist.P2POp(dist.isend, staged[r], r, self.group) for r in range(1, self.world) if staged[r].numel()]
+                for w in (dist.batch_isend_irecv(ops) if ops else []):
+                    w.wait()
+                recv = staged[0]
+            else:
+                recv = torch.empty(count, dtype=dtype, device=self.device)
+                if count:
+                    for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, recv, 0, self.group)]):
+                        w.wait()
         local, off = [], 0
-        for ids, shape, lens in my_meta[0]:
+        for ids, shape, lens in my_meta:
             cnt = shape[0] * shape[1]
             local.append((ids, recv[off: off + cnt].view(shape), torch.tensor(lens, dtype=torch.float32, device=self.device)))
             off += cnt
         return local
 
+    def scatter(self, wavs: Optional[Sequence[torch.Tensor]]):
+        """Rank 0 passes the waveforms (1-D float32 or int16 PCM tensors): plan + distribute."""
+        return self.distribute(self.plan(wavs))
+
     # -- run + gather ------------------------------------------------------------
+    def _floats(self, x):
+        if x.dtype == torch.int16:
+            from speechbrain_amd import native
+
+            return native.pcm16_to_f32(x)
+        return x
+
     def run_local(self, local):
         out = []
         if self.concurrent is not None and len(local) > 1:
-            for (ids, _, _), hyps in zip(local, self.concurrent.transcribe_batches([(x, l) for _, x, l in local])):
+            hyps_per_batch = self.concurrent.transcribe_batches([(x, l) for _, x, l in local], prepare=self.prepare)
+            for (ids, _, _), hyps in zip(local, hyps_per_batch):
                 out.extend(zip(ids, hyps))
             return out
         for ids, x, lens in local:
-            hyps = self.fn(x, lens)
+            hyps = self.fn(self._floats(x), lens)
             out.extend(zip(ids, hyps))
         return out
 

@@ -40,7 +40,14 @@ class ConcurrentTranscriber:
         if prepare is not None:
             prepare(searcher, wavs)
         with torch.no_grad():
-            wav_lens = wav_lens.to(self.device)
+            # host batches (pinned memory: the copy is asynchronous) go to the device on THIS worker's stream, so
+            # the transfer of one batch overlaps the kernels of the batches in flight on the other streams
+            wavs = wavs.to(self.device, non_blocking=True)
+            wav_lens = wav_lens.to(self.device, non_blocking=True)
+            if wavs.dtype == torch.int16:  # PCM as shipped by ShardedTranscriber.scatter / read from a wav file
+                from speechbrain_amd import native
+
+                wavs = native.pcm16_to_f32(wavs)
             enc = self.asr.encode_batch(wavs, wav_lens)
             dec_stream = self.dec_streams[slot] if self.device.type == "cuda" else None
             if dec_stream is None:

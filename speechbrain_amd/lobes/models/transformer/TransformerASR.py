@@ -27,7 +27,9 @@ def make_transformer_src_tgt_masks(src, tgt=None, wav_len=None, pad_idx=0, causa
     src_key_padding_mask = None
     if wav_len is not None:
         abs_len = torch.round(wav_len * src.shape[1])
-        src_key_padding_mask = ~length_to_mask(abs_len).bool()
+        # max_len = T: what the mask is combined with; equal to the reference's abs_len.max() whenever the
+        # longest item fills the batch (batch_pad_right), and it keeps the encoder free of a host sync
+        src_key_padding_mask = ~length_to_mask(abs_len, max_len=src.shape[1]).bool()
     return src_key_padding_mask, None, None, None
 
 

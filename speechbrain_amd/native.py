@@ -20,7 +20,6 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsbk_hip.so")
 ACT_NONE, ACT_SWISH, ACT_GELU, ACT_RELU, ACT_LEAKY_RELU = 0, 1, 2, 3, 4
 
 _lib = None
-_host_tensors_ok = False  # flipped only by tests that attach the kernel emulator
 
 
 class SbkError(RuntimeError):
@@ -73,6 +72,7 @@ def _declare(lib):
         "sbk_prof_ctc_psi_repeat_f32": ([p, p, p, p, p, i, i, i, i, i, i, POINTER(c_float), p], c_int),
         "sbk_prof_set_knob": ([i, i], None),
         "sbk_prof_gemm_repeat_f32": ([p, p, p, i, i, i, p, ctypes.c_size_t, i, POINTER(c_float), p], c_int),
+        "sbk_pcm16_to_f32": ([p, p, ctypes.c_long, i, p], c_int),
         "sbk_fbank_f32": ([p, p, p, POINTER(c_int32), i, p, p, p, p, p, i, i, i, i, i, i, f, f, p, p, f, p], c_int),
         "sbk_stft_f32": ([p, p, p, POINTER(c_int32), i, p, i, i, i, i, p], c_int),
         "sbk_spectral_magnitude_f32": ([p, p, ctypes.c_long, f, i, f, p], c_int),
@@ -127,20 +127,6 @@ def load(path: Optional[str] = None):
     return lib
 
 
-def _attach_for_tests(path: str):
-    """Tests only: point the binding at the CPU kernel emulator build of the same sources."""
-    global _lib, _host_tensors_ok
-    _lib = None
-    load(path)
-    _host_tensors_ok = True
-
-
-def _detach_for_tests():
-    global _lib, _host_tensors_ok
-    _lib = None
-    _host_tensors_ok = False
-
-
 def _chk(rc: int, what: str):
     if rc != 0:
         raise SbkError(f"{what} failed (rc={rc}): {_lib.sbk_last_error().decode()}")
@@ -150,7 +136,7 @@ def _dev_ok(*ts):
     for t in ts:
         if t is None:
             continue
-        if not t.is_cuda and not _host_tensors_ok:
+        if not t.is_cuda:
             raise SbkError(
                 "speechbrain_amd ops run on an MI355X (HIP) device only; got a CPU tensor. "
                 "Move the module and inputs to 'cuda' (there is no CPU fallback)."
@@ -248,6 +234,20 @@ def input_norm_global(x, mean, std, eps):
     out = torch.empty_like(x)
     _chk(lib.sbk_input_norm_global_f32(_p(x2), _p(mean), _p(std), _p(out), x2.shape[0], C, float(eps), _stream(x2)),
          "sbk_input_norm_global_f32")
+    return out
+
+
+def pcm16_to_f32(pcm: torch.Tensor, channels: int = 1, out=None):
+    """int16 PCM (any shape; interleaved channels last when channels > 1) -> float32 sample / 32768, channel mean."""
+    lib = load()
+    _dev_ok(pcm)
+    if pcm.dtype != torch.int16:
+        raise SbkError(f"expected int16 PCM, got {pcm.dtype}")
+    shape = pcm.shape if channels == 1 else pcm.shape[:-1]
+    frames = pcm.numel() // channels
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=pcm.device)
+    _chk(lib.sbk_pcm16_to_f32(_p(pcm), _p(out), frames, int(channels), _stream(pcm)), "sbk_pcm16_to_f32")
     return out
 
 
@@ -419,13 +419,22 @@ class DecoderHandle:
         W.max_len, W.ffn_act, W.ln_eps = pe.shape[-2], act, dec.norm.eps
         self.W = W
         self.device = emb.device
-        self.key = tuple((t.data_ptr(), t._version) for t in self.keep)
+        self.key = self.source_key(model, seq_lin)
 
-    def stale(self, model, seq_lin):
-        try:
-            return DecoderHandle(model, seq_lin).key != self.key
-        except Exception:
-            return True
+    @staticmethod
+    def source_key(model, seq_lin=None):
+        """(data_ptr, _version) of every tensor the handle was derived from -- the folded LayerNorm copies go
+        stale when a source parameter is updated IN PLACE (load_state_dict, Pretrainer, copy_), which keeps
+        data_ptr and bumps _version.  Cheap: no handle is built."""
+        src = list(model.decoder.parameters())
+        src.append(model.custom_tgt_module.layers[0].emb.Embedding.weight)
+        src.append(model.positional_encoding_decoder.pe)
+        if seq_lin is not None:
+            src.extend(seq_lin.parameters())
+        return tuple((t.data_ptr(), t._version) for t in src)
+
+    def stale(self, model, seq_lin=None):
+        return self.source_key(model, seq_lin) != self.key
 
 
 class LMHandle:
@@ -470,13 +479,15 @@ class LMHandle:
         W.normalize_before, W.pad_idx, W.ln_eps = int(enc.layers[0].normalize_before), 0, enc.norm.eps
         self.W = W
         self.device = emb.device
-        self.key = tuple((t.data_ptr(), t._version) for t in self.keep)
+        self.key = self.source_key(lm)
+
+    @staticmethod
+    def source_key(lm):
+        """(data_ptr, _version) of every source tensor (see DecoderHandle.source_key)."""
+        return tuple((t.data_ptr(), t._version) for t in list(lm.parameters()) + [lm.positional_encoding.pe])
 
     def stale(self, lm):
-        try:
-            return LMHandle(lm).key != self.key
-        except Exception:
-            return True
+        return self.source_key(lm) != self.key
 
 
 def lm_prefix(handle: "LMHandle", tokens):

@@ -5,8 +5,11 @@ distribution and is not required here).
 Supported: ``!new:`` (mapping = kwargs, sequence = positional, empty = no arguments), ``!name:``
 (callable, partial when arguments are given), ``!apply:``, ``!ref <key>`` (same object instance for every
 reference, ``<key[sub]>`` indexing, string interpolation, simple arithmetic), ``!copy <key>``, ``!tuple``,
-implicit ``(a, b)`` tuples, ``!PLACEHOLDER``, anchors/aliases, and ``overrides`` (dict or YAML text).
-Not supported (raises): ``!include:``, ``!module:``/``!import:`` side-effect tags.
+implicit ``(a, b)`` tuples, ``!PLACEHOLDER``, anchors/aliases, and ``overrides`` (dict or YAML text, merged
+recursively: ``{"decoder": {"beam_size": 5}}`` changes one argument of the ``decoder`` object).
+Not supported (raises): ``!include:``, ``!module:``/``!import:`` side-effect tags; YAML merge keys (``<<``) are
+not expanded.  ``!name:`` without arguments yields the bare callable (hyperpyyaml wraps it in a partial with no
+arguments; calling either is the same).
 
 Module paths that start with ``speechbrain.`` are resolved inside ``speechbrain_amd`` -- that is the whole
 drop-in: a YAML written for the reference builds the MI355X modules.
@@ -190,8 +193,43 @@ class _Builder:
         return self._plain(node)
 
 
+def _as_node(value):
+    """A python override value as a YAML node (so it is built like text that had been in the file)."""
+    return yaml.compose(yaml.safe_dump(value, default_flow_style=True), Loader=yaml.SafeLoader)
+
+
+def _merge_overrides(node, overrides, direct):
+    """hyperpyyaml's recursive_update on the composed tree: a dict override of a mapping (a plain dict or the
+    argument mapping of a !new:/!name:/!apply: object) changes only the named sub-keys; anything else replaces
+    the node.  Values that YAML cannot express (live objects) stay in `direct` and replace whole top-level keys."""
+    for name, value in overrides.items():
+        slot = next((i for i, (k, _) in enumerate(node.value) if k.value == str(name)), None)
+        if slot is None:
+            key = yaml.ScalarNode("tag:yaml.org,2002:str", str(name))
+            try:
+                node.value.append((key, _as_node(value)))
+            except yaml.YAMLError:
+                if direct is None:
+                    raise
+                direct[name] = value
+            continue
+        key, child = node.value[slot]
+        if isinstance(value, dict) and isinstance(child, yaml.MappingNode):
+            _merge_overrides(child, value, None)
+            continue
+        try:
+            new = _as_node(value)
+        except yaml.YAMLError:
+            if direct is None:
+                raise ValueError(f"hyperparams: the override of '{name}' is not expressible as YAML") from None
+            direct[name] = value
+            continue
+        node.value[slot] = (key, new)
+
+
 def load_hyperpyyaml(stream, overrides=None):
-    """YAML text or file object -> dict of top-level keys with every object constructed."""
+    """YAML text or file object -> dict of top-level keys with every object constructed.  ``overrides`` (dict or
+    YAML text) are merged recursively into the tree before anything is built, like hyperpyyaml does."""
     text = stream if isinstance(stream, str) else stream.read()
     if isinstance(overrides, str):
         overrides = yaml.safe_load(overrides) or {}
@@ -200,7 +238,9 @@ def load_hyperpyyaml(stream, overrides=None):
         return {}
     if not isinstance(root, yaml.MappingNode):
         raise ValueError("hyperparams: the top level must be a mapping")
-    b = _Builder(root, dict(overrides or {}))
+    direct = {}
+    _merge_overrides(root, dict(overrides or {}), direct)
+    b = _Builder(root, direct)
     out = {}
     for k, v in root.value:
         name = k.value

@@ -11,15 +11,36 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+_strict_dev_ok = None
+
+
+def _contiguous_only(*ts):
+    """Stand-in for native._dev_ok while the emulator is attached: host tensors are what it takes."""
+    from speechbrain_amd import native
+
+    for t in ts:
+        if t is not None and not t.is_contiguous():
+            raise native.SbkError("non-contiguous tensor passed to a kernel")
+
+
 def attach():
+    """Point the binding at the emulator build.  The hook lives HERE, not in the product: the shipped
+    native.py has no switch that accepts host tensors."""
+    global _strict_dev_ok
     from tools.kernel_emu.build_emu import build
     from speechbrain_amd import native
 
-    native._attach_for_tests(build())
+    native._lib = None
+    native.load(build())
+    if _strict_dev_ok is None:
+        _strict_dev_ok = native._dev_ok
+    native._dev_ok = _contiguous_only
     return native
 
 
 def detach():
     from speechbrain_amd import native
 
-    native._detach_for_tests()
+    native._lib = None
+    if _strict_dev_ok is not None:
+        native._dev_ok = _strict_dev_ok

@@ -35,7 +35,9 @@ def test_header_symbols_exported(lib_path):
 def test_binding_covers_header(lib_path):
     from speechbrain_amd import native
 
-    native._detach_for_tests()
+    import emu_utils
+
+    emu_utils.detach()
     native.load()
     assert set(declared_symbols()) == set(native.EXPORTS)
 
@@ -53,7 +55,9 @@ def test_product_refuses_cpu_tensors(lib_path):
 
     from speechbrain_amd import native
 
-    native._detach_for_tests()
+    import emu_utils
+
+    emu_utils.detach()
     native.load()
     with pytest.raises(native.SbkError):
         native.gemm_nt(torch.zeros(4, 4), torch.zeros(4, 4))

@@ -4,6 +4,7 @@ The per-rank worker is a deterministic stand-in: this test covers partitioning, 
 waveforms and the gather of token ids, not the kernels."""
 import os
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -100,12 +101,15 @@ def _tiny_asr():
     return asr
 
 
-def _asr_job():
+def _asr_job(pcm=False):
     g = torch.Generator().manual_seed(11)
-    return [0.1 * torch.randn(int(n), generator=g) for n in torch.randint(3000, 8000, (9,), generator=g)]
+    wavs = [0.1 * torch.randn(int(n), generator=g) for n in torch.randint(3000, 8000, (9,), generator=g)]
+    if pcm:  # what a 16-bit wav file holds
+        wavs = [(w * 32768.0).round().clamp(-32768, 32767).to(torch.int16) for w in wavs]
+    return wavs
 
 
-def _worker_asr(rank, world, tmpdir, q):
+def _worker_asr(rank, world, tmpdir, q, pcm=False):
     os.environ["RANK"], os.environ["LOCAL_RANK"], os.environ["WORLD_SIZE"] = str(rank), str(rank), str(world)
     dist.init_process_group("gloo", init_method=f"file://{tmpdir}/sync", rank=rank, world_size=world)
     try:
@@ -114,33 +118,38 @@ def _worker_asr(rank, world, tmpdir, q):
         asr = _tiny_asr()
         st = ShardedTranscriber(lambda w, l: asr.transcribe_batch(w, l)[1], "cpu", max_utts=2,
                                 concurrent=ConcurrentTranscriber(asr, streams=3))
-        hyps = st.transcribe(_asr_job() if rank == 0 else None)
+        hyps = st.transcribe(_asr_job(pcm) if rank == 0 else None)
         if rank == 0:
-            q.put(hyps)
+            q.put((hyps, st.last_plan["bytes_sent"]))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_asr_world2_matches_single_process(tmp_path):
+@pytest.mark.parametrize("pcm", [False, True])
+def test_sharded_asr_world2_matches_single_process(tmp_path, pcm):
     """The whole multi-rank path with the real modules (tiny Conformer on the CPU kernel emulator): rank 0
     scatters padded waveforms, both ranks transcribe their batches through ConcurrentTranscriber, token ids
     are gathered -- and equal a plain single-process transcription of the same batches."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_asr, args=(r, 2, str(tmp_path), q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_asr, args=(r, 2, str(tmp_path), q, pcm)) for r in range(2)]
     for p in procs:
         p.start()
-    hyps = q.get(timeout=300)
+    hyps, bytes_sent = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     from speechbrain_amd.inference.sharded import pad_batch
 
     asr = _tiny_asr()
-    wavs = _asr_job()
+    wavs = _asr_job(pcm)
     ref = [None] * len(wavs)
     for b in plan_batches([w.numel() for w in wavs], max_utts=2):
         x, lens = pad_batch(wavs, b)
+        if pcm:  # int16 PCM travels as int16 (2 bytes per sample) and becomes sample / 32768 on the receiving rank
+            x = x.float() / 32768.0
         for i, h in zip(b, asr.transcribe_batch(x, lens)[1]):
             ref[i] = h
     assert hyps == ref
+    sent_samples = bytes_sent // (2 if pcm else 4)
+    assert 0 < sent_samples <= sum(w.numel() for w in wavs) * 1.3  # exact-size sends: no padding to the widest rank

@@ -14,7 +14,9 @@ def _asr(size, **kw):
     from speechbrain_amd import native
     from speechbrain_amd.inference.builders import build_asr
 
-    native._detach_for_tests()
+    import emu_utils
+
+    emu_utils.detach()
     native.load()
     return build_asr(size, device="cuda:0", **kw)
 

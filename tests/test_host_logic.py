@@ -75,6 +75,10 @@ def test_speechbrain_import_shim():
         from speechbrain.inference.ASR import EncoderDecoderASR  # noqa: F401
         from speechbrain.nnet.attention import RelPosMHAXL  # noqa: F401
         from speechbrain.processing.features import STFT, Filterbank, InputNormalization, spectral_magnitude  # noqa: F401
+        from speechbrain.utils.parameter_transfer import Pretrainer  # noqa: F401
+        from speechbrain.utils.metric_stats import ErrorRateStats  # noqa: F401
+        for sub in compat._MODULES:  # every mirrored module resolves through the shim, to the same object
+            assert importlib.import_module(f"speechbrain.{sub}") is importlib.import_module(f"speechbrain_amd.{sub}")
     finally:
         for k in [k for k in sys.modules if k == "speechbrain" or k.startswith("speechbrain.")]:
             del sys.modules[k]
@@ -122,6 +126,14 @@ applied: !apply:max
     assert h["nested"]["b"] == [1, 2.5, None, True] and h["pick"] == 2.5 and h["applied"] == 9
     assert load_hyperpyyaml(text, overrides={"d_model": 64})["lin"].w.weight.shape == (7, 64)
     assert load_hyperpyyaml(text, overrides="d_model: 16")["half"] == 8
+    # nested overrides change ONE argument of an object / one sub-key of a mapping (hyperpyyaml recursive_update)
+    h2 = load_hyperpyyaml(text, overrides={"lin": {"n_neurons": 9}, "nested": {"b": [5, 6]}, "sm": {"dim": 0}})
+    assert h2["lin"].w.weight.shape == (9, 32) and h2["pair"][0] is h2["lin"]
+    assert h2["nested"]["b"] == [5, 6] and h2["pick"] == 6 and h2["nested"]["a"] is h2["lin"] and h2["sm"].dim == 0
+    assert load_hyperpyyaml(text, overrides="lin: {n_neurons: 3}")["lin"].w.weight.shape == (3, 32)
+    live = torch.nn.Identity()  # a live object replaces the whole key
+    assert load_hyperpyyaml(text, overrides={"sm": live, "extra": 4})["sm"] is live
+    assert load_hyperpyyaml(text, overrides={"extra": 4})["extra"] == 4
     with pytest.raises(ValueError):
         load_hyperpyyaml("x: !PLACEHOLDER\n")
     assert load_hyperpyyaml("x: !PLACEHOLDER\ny: !ref <x>", overrides={"x": 3})["y"] == 3

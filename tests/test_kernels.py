@@ -256,3 +256,21 @@ def test_gemm_layernorm_fused(backend, M, N, K):
     wf, bf = nat._fold_ln(w, b, gamma, beta)
     out = nat.gemm_ln_nt(x.to(dev), wf.to(dev), bf.to(dev), 1e-6, residual=r.to(dev), act=nat.ACT_GELU)
     assert _md(out, ref) <= 2e-5
+
+
+@pytest.mark.parametrize("frames,channels", [(0, 1), (5, 1), (4099, 1), (16384, 1), (1001, 2), (37, 3)])
+def test_pcm16_to_f32(backend, frames, channels):
+    """a1: int16 PCM -> float32 sample/32768 (soundfile's convention) + channel mean; bit-exact (the values are
+    dyadic rationals), including the vector path, its ragged tail and an unaligned start."""
+    nat, dev = backend
+    g = torch.Generator().manual_seed(frames + channels)
+    pcm = torch.randint(-32768, 32768, (frames + 3, channels), generator=g, dtype=torch.int32).to(torch.int16)
+    if frames:
+        pcm[0, 0], pcm[-1, -1] = -32768, 32767
+    for off in (0, 3):  # off = 3: pointer not 16-byte aligned
+        x = pcm[off: off + frames].contiguous() if off == 0 else pcm.reshape(-1)[off * channels:][: frames * channels].reshape(frames, channels)
+        xd = pcm.to(dev).reshape(-1)[off * channels:][: frames * channels].reshape(frames, channels)
+        out = nat.pcm16_to_f32(xd.squeeze(-1) if channels == 1 else xd, channels)
+        ref = torch.mean(x.float() / 32768.0, dim=1)
+        assert out.shape == (frames,)
+        assert torch.equal(out.cpu(), ref)

@@ -534,3 +534,34 @@ def test_degenerate_inputs(backend):
     enc2 = O.encode_batch(wav2, lens2, sd, fc, mc, torch.zeros(80), torch.ones(80))
     hyps2, _, _, _ = O.beam_search(enc2, lens2, sd, mc, O.SearchCfg(beam=4, ctc_weight=0.4))
     assert toks2 == hyps2
+
+
+def test_in_place_weight_update_rebuilds_the_decoder_handle(backend):
+    """the searcher caches LayerNorm-folded copies of the projections; an in-place update of the
+    source parameters (load_state_dict keeps data_ptr, bumps _version) must invalidate them."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_asr
+
+    tiny = dict(d_model=128, nhead=4, d_ffn=128, n_enc=1, n_dec=2, n_fft=512, win_length=32)
+
+    def make(seed):
+        asr = build_asr(tiny, vocab=40, seed=seed, beam_size=3, ctc_weight=0.3, device=str(dev))
+        with torch.no_grad():  # peaked heads: the comparison below is on token ids
+            asr.mods.seq_lin.w.weight.mul_(8.0)
+            asr.mods.ctc_lin.w.weight.mul_(8.0)
+        return asr
+
+    wav = 0.1 * torch.randn(2, 6400, generator=torch.Generator().manual_seed(3))
+    lens = torch.tensor([1.0, 0.8])
+    a, b = make(5), make(6)
+    _, toks_a = a.transcribe_batch(wav, lens)
+    _, toks_b = b.transcribe_batch(wav, lens)
+    assert toks_a != toks_b
+    h0 = a.mods.decoder._handle()
+    assert a.mods.decoder._handle() is h0  # unchanged weights: the cached table is reused
+    for name in ("transformer", "seq_lin", "ctc_lin"):
+        a.mods[name].load_state_dict(b.mods[name].state_dict())
+    a.mods.encoder["model"].load_state_dict(b.mods.encoder["model"].state_dict())
+    _, toks_a2 = a.transcribe_batch(wav, lens)
+    assert a.mods.decoder._handle() is not h0
+    assert toks_a2 == toks_b
