@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SBK_ABI_VERSION 1
+#define SBK_ABI_VERSION 2
 
 typedef void* sbk_stream_t; /* hipStream_t */
 
@@ -248,6 +248,14 @@ typedef struct {
   int32_t topk; /* 0 / 1: the best hypothesis per utterance (last token stripped); > 1: return_topk
                    (seq2seq.py:757-760,1712) -- the outputs hold `topk` rows per utterance in descending
                    score order and keep their last token, like the reference's padded topk_hyps */
+  /* Grouped search (optional, NULL = the scalar min_steps / max_steps for everybody): DEVICE int32 [B] arrays with
+   * every utterance's own min / max decode steps.  Several independent batches of the reference -- each with its own
+   * padded T and hence its own int(T * ratio) step limits (seq2seq.py:1336-1338) -- can then share ONE search: their
+   * rows are stacked (enc zero-padded to the longest T; frames beyond enc_len are never read), max_steps is the
+   * largest limit, and an utterance simply stops taking part after its own last step.  Results per utterance are
+   * those of the separate searches; what changes is that the decoder GEMMs see the rows of all batches at once. */
+  const int32_t* utt_min_steps;
+  const int32_t* utt_max_steps;
   int32_t graph_mode; /* 0: one launch list per step; 1: the step counter lives in device memory and two
                          consecutive steps are captured once into a hipGraph and replayed (single-stream
                          latency; ignored with overlap_ctc, profiling or T > 900); 2: device-side counter
@@ -267,8 +275,8 @@ size_t sbk_beam_search_workspace_bytes(const sbk_decoder_weights* W, const sbk_s
 int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_search_config* cfg, const float* enc,
                         const int32_t* enc_len, const float* ctc_w, const float* ctc_b, void* workspace,
                         size_t workspace_bytes, int32_t* out_tokens, int32_t* out_len, float* out_score,
-                        float* out_logp, int32_t* out_max_len, int32_t* host_flag, int32_t* steps_run, int B, int T,
-                        sbk_stream_t stream);
+                        float* out_logp, int32_t* out_max_len, int32_t* out_longest, int32_t* host_flag,
+                        int32_t* steps_run, int B, int T, sbk_stream_t stream);
 
 /* S2STransformerGreedySearcher.forward (seq2seq.py:176-367, temperature 0): per-step arg-max.
  *   out_tokens [B,max_steps] (EOS-latched), out_scores [B,max_steps] (log-prob of the arg-max, 0 after the end) */

@@ -152,6 +152,9 @@ struct CtcStepArgs {
   float eos_threshold, minus_inf;
   const int32_t* step_ptr;  // non-null: prefix_len / eos_floor come from the device-side step counter
   int min_steps;
+  // grouped search: per-utterance min_decode_steps (overrides eos_floor / min_steps); row n belongs to utterance n / beam
+  const int32_t* utt_min;
+  int utt_beam, step;
 };
 
 // P [B,T,V] masked linear posteriors; sg [n_bh,T] / se [n_bh,nseg] segment-scaled gamma tables
@@ -342,7 +345,9 @@ __global__ void __launch_bounds__(256) ctc_combine_kernel(CtcStepArgs a, const f
   if (c >= a.V) return;
   float v = am[(size_t)n * a.V + c];
   if (c == a.eos) {
-    if (a.step_ptr ? a.step_ptr[0] < a.min_steps : a.eos_floor) v = a.minus_inf;
+    const int step = a.step_ptr ? a.step_ptr[0] : a.step;
+    const bool floor = a.utt_min ? step < a.utt_min[n / a.utt_beam] : (a.step_ptr ? step < a.min_steps : a.eos_floor);
+    if (floor) v = a.minus_inf;
     if (a.use_eos_threshold && !(v > a.eos_threshold * am_max[n])) v = a.minus_inf;
   }
   if (extra) v += extra[(size_t)n * a.V + c];  // full scorers listed before "ctc" (already weighted)
@@ -553,13 +558,15 @@ __global__ void __launch_bounds__(256) am_only_kernel(const float* __restrict__ 
                                                       int eos, int eos_floor, int use_thr, float thr, float minus_inf,
                                                       const float* __restrict__ am_max,
                                                       const float* __restrict__ extra,
-                                                      const int32_t* __restrict__ step_ptr, int min_steps) {
+                                                      const int32_t* __restrict__ step_ptr, int min_steps,
+                                                      const int32_t* __restrict__ utt_min, int beam, int step) {
   const int n = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= V) return;
   float v = am[(size_t)n * V + c];
   if (c == eos) {
-    if (step_ptr ? step_ptr[0] < min_steps : eos_floor) v = minus_inf;
+    if (step_ptr) step = step_ptr[0];
+    if (utt_min ? step < utt_min[n / beam] : (step_ptr ? step < min_steps : eos_floor)) v = minus_inf;
     if (use_thr && !(v > thr * am_max[n])) v = minus_inf;
   }
   if (extra) v += extra[(size_t)n * V + c];
@@ -670,9 +677,9 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
 
 int ctc_combine(const float* am, const float* am_max, const float* psi, const float* psi_prev, float* comb, int n_bh,
                 int V, int blank, int eos, float weight, int eos_floor, int use_thr, float thr, float minus_inf,
-                const float* extra, hipStream_t st) {
+                const float* extra, hipStream_t st, const int32_t* utt_min, int beam, int step) {
   CtcStepArgs a{nullptr, nullptr, 0, 0, V, 0, 0, blank, eos, weight, eos_floor, use_thr, thr, minus_inf, g_step_ptr,
-                g_step_min_steps};
+                g_step_min_steps, utt_min, beam > 0 ? beam : 1, step};
   SBK_LAUNCH(ctc_combine_kernel, dim3(cdiv(V, 256), n_bh), dim3(256), 0, st, a, am, am_max, psi, psi_prev, comb, extra);
   return launch_status("ctc_combine");
 }
@@ -692,11 +699,12 @@ int ctc_advance(const float* P, const float* state_old, const float* psi, const 
 }
 
 int am_only(const float* am, float* comb, int n_bh, int V, int eos, int eos_floor, int use_thr, float thr,
-            float minus_inf, const float* am_max, const float* extra, hipStream_t st) {
+            float minus_inf, const float* am_max, const float* extra, hipStream_t st, const int32_t* utt_min, int beam,
+            int step) {
   const int32_t* sp = g_step_ptr;  // locals: launch arguments must not name the thread_locals themselves
   const int min_steps = g_step_min_steps;
   SBK_LAUNCH(am_only_kernel, dim3(cdiv(V, 256), n_bh), dim3(256), 0, st, am, comb, V, eos, eos_floor, use_thr, thr,
-             minus_inf, am_max, extra, sp, min_steps);
+             minus_inf, am_max, extra, sp, min_steps, utt_min, beam > 0 ? beam : 1, step);
   return launch_status("am_only");
 }
 

@@ -69,6 +69,14 @@ struct PanelStage {
       r[i] = v;
     }
   }
+  // [rows][BK+4] layout: one 16-byte LDS store per slot (rows stay 16-byte aligned: (BK+4)*4 is a multiple of 16)
+  __device__ __forceinline__ void commit_vec(float (*dst)[BK + 4], int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int s = tid + i * NT;
+      if (s < ROWS * V) *reinterpret_cast<float4*>(&dst[s / V][(s % V) * 4]) = r[i];
+    }
+  }
   __device__ __forceinline__ void commit(float (*dst)[BK + 1], int tid) const {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -166,6 +174,160 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(Gem
   }
 }
 
+// Same tiling with 16-byte LDS traffic.  The two k-slices of v_mfma_f32_32x32x2 need not be neighbours in
+// memory: any pairing of k values is a valid contraction as long as A and W use the same one.  Lane half
+// `lk` therefore owns the contiguous run [lk*BK/2, (lk+1)*BK/2) of a K tile and MFMA number j multiplies
+// k = j (lanes 0-31) with k = BK/2 + j (lanes 32-63): every operand fetch is a ds_read_b128 of four
+// consecutive k (4x fewer LDS instructions than scalar reads at pitch BK+1) and every panel store a
+// ds_write_b128.  Pitch BK+4 floats: the 16-lane groups of a b128 read (MI355X_MICROARCH.md, LDS table) land
+// on 16 distinct 4-bank groups because (BK+4)/4 is odd; the 8-lane groups of a b128 write cover one row.
+template <int BM, int BN, int BK, int WM, int WN, bool VEC>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_v4_kernel(GemmArgs g) {
+  constexpr int WAVES_N = BN / WN;
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(((BK + 4) / 4) % 2 == 1 && BK % 8 == 0, "pitch (BK+4)/4 must be odd");
+  __shared__ __attribute__((aligned(16))) float As[BM][BK + 4];
+  __shared__ __attribute__((aligned(16))) float Ws[BN][BK + 4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {  // XCD-aware tile order, as in gemm_nt_kernel
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int id = by * gx + bx;
+    if (nwg % 8 == 0) {
+      const int swz = (id % 8) * (nwg / 8) + id / 8;
+      bx = swz % gx;
+      by = swz / gx;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int lrow = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  PanelStage<BM, BK, NT> pa;
+  PanelStage<BN, BK, NT> pw;
+  pa.template fetch<VEC>(g.A, g.lda, m0, g.M, 0, g.K, tid);
+  pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, 0, g.K, tid);
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    pa.commit_vec(As, tid);
+    pw.commit_vec(Ws, tid);
+    __syncthreads();
+    if (k0 + BK < g.K) {  // next K tile: loads fly while this tile is multiplied
+      pa.template fetch<VEC>(g.A, g.lda, m0, g.M, k0 + BK, g.K, tid);
+      pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, k0 + BK, g.K, tid);
+    }
+#pragma unroll
+    for (int kv = 0; kv < BK / 2; kv += 4) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(&As[wm0 + i * 32 + lrow][lk * (BK / 2) + kv]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(&Ws[wn0 + j * 32 + lrow][lk * (BK / 2) + kv]);
+      // k-major order: consecutive MFMAs go to DIFFERENT accumulators (a same-accumulator pair with anything
+      // scheduled in between stalls, MI355X_MICROARCH.md per-instruction table)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float av = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
+            const float bw = e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w;
+            acc[i][j] = sbk::mfma_32x32x2(av, bw, acc[i][j]);
+          }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn0 + j * 32 + lrow;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        float v = apply_act(acc[i][j][r] + bv, g.act) * g.alpha;
+        if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
+        if (g.R) v += g.R[(size_t)row * g.ldr + col];
+        g.C[(size_t)row * g.ldc + col] = v;
+      }
+    }
+  }
+}
+
+// Epilogue of a 32x32 register tile held by ONE wave (lane: column r, rows (q&3) + 8*(q>>2) + 4*half): straight-line
+// code -- the residual rows / sequence lengths are requested together, the activation is chosen by ONE uniform
+// switch outside the per-row work, and the sixteen row stores are issued back to back (a branchy per-row loop makes
+// the compiler drain the memory counter before every store: sixteen serialized round trips on a 5 us kernel).
+__device__ __forceinline__ void tile_epilogue_32x32(const GemmArgs& g, float (&v)[16], int mt, int nt, int r, int half) {
+  const int col = nt * 32 + r;
+  const bool col_ok = col < g.N;
+  const float bv = (g.bias && col_ok) ? g.bias[col] : 0.0f;
+  float res[16];
+  int len[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+    const bool live = col_ok && row < g.M;
+    res[q] = (live && g.R) ? g.R[(size_t)row * g.ldr + col] : 0.0f;
+    len[q] = (live && g.seq_len) ? g.seq_len[row / g.rows_per_seq] : 0x7fffffff;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] += bv;
+  switch (g.act) {  // uniform
+    case SBK_ACT_SWISH:
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = v[q] / (1.0f + expf(-v[q]));
+      break;
+    case SBK_ACT_GELU:
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = 0.5f * v[q] * (1.0f + erff(v[q] * 0.70710678118654752440f));
+      break;
+    case SBK_ACT_RELU:
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.0f;
+      break;
+    case SBK_ACT_LEAKY_RELU:
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.01f * v[q];
+      break;
+    default: break;
+  }
+  if (g.seq_len) {  // uniform
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+      v[q] = (row % g.rows_per_seq) >= len[q] ? 0.0f : v[q] * g.alpha;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] *= g.alpha;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] += res[q];
+  sbk::sched_fence();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+    if (col_ok && row < g.M) g.C[(size_t)row * g.ldc + col] = v[q];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Skinny GEMM for the decoder steps (M = beams x utterances, a few hundred rows).
 // With so few rows an LDS-tiled workgroup grid cannot fill 256 CUs, and the
@@ -255,6 +417,75 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __r
   }
 }
 
+// The same contraction when a wave's K slice is exactly ONE fetch batch (kper == NCH*32: K = 512 with the four
+// waves, K = 2048 with the four-way global split, ...).  No loop and no predicates: all 8*NCH 16-byte loads of a
+// lane are issued back to back (the sched_barrier keeps the compiler from sinking them next to their MFMAs --
+// in the looped kernel above it pairs every four MFMAs with a fresh load round trip, which makes a 128-deep
+// slice cost ~16 dependent L2 latencies), then the MFMA chain runs off registers.
+template <int NCH>
+__global__ void __launch_bounds__(256) gemm_skinny_flat_kernel(GemmArgs g, float* __restrict__ partial, int tiles_m,
+                                                               int tiles_n) {
+  constexpr int KC = 32;
+  __shared__ float red[3][32][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int nt, mt;
+  {
+    const int id = blockIdx.x, x = id & 7, q = id >> 3;
+    const int nt8 = (tiles_n + 7) / 8;
+    mt = q % tiles_m;
+    nt = x + 8 * (q / tiles_m);
+    if (q / tiles_m >= nt8 || nt >= tiles_n) return;
+  }
+  const int r = lane & 31, half = lane >> 5;
+  const int k_begin = (blockIdx.y * 4 + wave) * NCH * KC;
+  const float* wrow = g.W + (size_t)min(nt * 32 + r, g.N - 1) * g.ldw + half * (KC / 2) + k_begin;
+  const float* arow = g.A + (size_t)min(mt * 32 + r, g.M - 1) * g.lda + half * (KC / 2) + k_begin;
+  float4 a[NCH][4], w[NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) w[c][v] = *reinterpret_cast<const float4*>(wrow + c * KC + 4 * v);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a[c][v] = *reinterpret_cast<const float4*>(arow + c * KC + 4 * v);
+  }
+  sbk::sched_fence();
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      acc = sbk::mfma_32x32x2(a[c][v].x, w[c][v].x, acc);
+      acc = sbk::mfma_32x32x2(a[c][v].y, w[c][v].y, acc);
+      acc = sbk::mfma_32x32x2(a[c][v].z, w[c][v].z, acc);
+      acc = sbk::mfma_32x32x2(a[c][v].w, w[c][v].w, acc);
+    }
+  if (wave > 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[wave - 1][(q & 3) + 8 * (q >> 2) + 4 * half][r] = acc[q];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int rr = (q & 3) + 8 * (q >> 2) + 4 * half;
+    v[q] = ((acc[q] + red[0][rr][r]) + red[1][rr][r]) + red[2][rr][r];
+  }
+  if (gridDim.y > 1) {  // partial tile of a global K split: combined by splitk_reduce_kernel
+    float* P = partial + (size_t)blockIdx.y * g.M * g.N;
+    const int col = nt * 32 + r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+      if (row < g.M && col < g.N) P[(size_t)row * g.N + col] = v[q];
+    }
+    return;
+  }
+  tile_epilogue_32x32(g, v, mt, nt, r, half);
+}
+
 // LayerNorm fused into the skinny GEMM:  C = epilogue( LN(A) . W^T ) for K = NCH*128 (one fetch batch
 // per wave, so the workgroup's four waves hold complete rows of A in registers).  gamma/beta are
 // pre-folded into the operands by the caller:  Wf[n,k] = W[n,k]*gamma[k],  bf[n] = b[n] + sum_k W[n,k]*beta[k],
@@ -280,14 +511,16 @@ __global__ void __launch_bounds__(256) gemm_skinny_ln_kernel(GemmArgs g, float e
   const float* wrow = g.W + (size_t)min(nt * 32 + r, g.N - 1) * g.ldw + half * (KC / 2);
   const float* arow = g.A + (size_t)min(mt * 32 + r, g.M - 1) * g.lda + half * (KC / 2);
   float4 a[NCH][4], w[NCH][4];
+  // the activation rows first: the row statistics below wait for them only, the weight loads stay in flight
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int k = k_begin + c * KC;
+  for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) w[c][v] = *reinterpret_cast<const float4*>(wrow + k + 4 * v);
+    for (int v = 0; v < 4; ++v) a[c][v] = *reinterpret_cast<const float4*>(arow + k_begin + c * KC + 4 * v);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) a[c][v] = *reinterpret_cast<const float4*>(arow + k + 4 * v);
-  }
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) w[c][v] = *reinterpret_cast<const float4*>(wrow + k_begin + c * KC + 4 * v);
+  sbk::sched_fence();
   // mean over the full row: lane partial -> both halves -> the four waves
   float s = 0.0f;
 #pragma unroll
@@ -332,18 +565,13 @@ __global__ void __launch_bounds__(256) gemm_skinny_ln_kernel(GemmArgs g, float e
     rstd_s[r] = rsqrtf(var + eps);
   }
   sbk::wave_sync();
-  const int col = nt * 32 + r;
-  const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.0f;
+  float v[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int rr = (q & 3) + 8 * (q >> 2) + 4 * half;
-    const int row = mt * 32 + rr;
-    const float sum = ((acc[q] + red[0][rr][r]) + red[1][rr][r]) + red[2][rr][r];
-    if (row >= g.M || col >= g.N) continue;
-    float v = apply_act(sum * rstd_s[rr] + bv, g.act) * g.alpha;
-    if (g.R) v += g.R[(size_t)row * g.ldr + col];
-    g.C[(size_t)row * g.ldc + col] = v;
+    v[q] = (((acc[q] + red[0][rr][r]) + red[1][rr][r]) + red[2][rr][r]) * rstd_s[rr];
   }
+  tile_epilogue_32x32(g, v, mt, nt, r, half);
 }
 
 // C = epilogue(sum_ks partial[ks]) ; fixed summation order => run-to-run deterministic.
@@ -360,6 +588,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const fl
   }
 }
 
+}  // namespace
+namespace sbk {
+int g_gemm_vec_lds = 0;  // tuning knob (key 9): 1 = the 16-byte LDS operand variant (gemm_nt_v4_kernel)
+}
+namespace {
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
   dim3 grid(sbk::cdiv(g.N, BN), sbk::cdiv(g.M, BM));
@@ -368,10 +601,16 @@ int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
                              : (BM == 128 && BN == 256) ? "gemm_nt_128x256"
                              : BM == 128 ? "gemm_nt_128x128" : (BM == 64 ? "gemm_nt_64x64" : "gemm_nt_32x64");
   sbk::ProfScope prof(kName, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N), st);
-  if (vec) {
-    SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, true>), grid, block, 0, st, g);
+  if (!sbk::g_gemm_vec_lds) {  // default: scalar LDS operand reads at pitch BK+1 (measured faster)
+    if (vec) {
+      SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, true>), grid, block, 0, st, g);
+    } else {
+      SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, false>), grid, block, 0, st, g);
+    }
+  } else if (vec) {
+    SBK_LAUNCH((gemm_nt_v4_kernel<BM, BN, BK, WM, WN, true>), grid, block, 0, st, g);
   } else {
-    SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, false>), grid, block, 0, st, g);
+    SBK_LAUNCH((gemm_nt_v4_kernel<BM, BN, BK, WM, WN, false>), grid, block, 0, st, g);
   }
   return sbk::launch_status("sbk_gemm_nt_f32");
 }
@@ -381,8 +620,9 @@ int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
 namespace sbk {
 int g_skinny_nch = 0;  // tuning knob (0 = automatic): K chunks fetched per batch by the skinny kernel
 int g_skinny_off = 0;  // tuning knob: 1 = route few-row GEMMs to the LDS-tiled kernels
+int g_skinny_looped = 0;  // tuning knob (key 10): 1 = always the looped skinny kernel (the round-1 schedule)
 int g_gemm_tile = 0;   // tuning knob (key 6) for the large-M path: 0 = 128x128, 1 = 256x128 (8 waves of 64x64),
-                       // 2 = 128x256 (8 waves), 3 = 256x128 (4 waves of 128x64)
+                       // 2 = 128x256 (8 waves), 3 = 256x128 (4 waves of 128x64), 4 = 128x128 with 64-deep K tiles
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
 // Internal C++ entry shared with the fused pipelines (decoder step, encoder).
@@ -411,7 +651,16 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   ProfScope prof("gemm_skinny", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
   dim3 grid(8 * tiles_m * cdiv(tiles_n, 8), SKg), block(256);
   const int nch = g_skinny_nch ? g_skinny_nch : (kper >= 128 ? 4 : (kper >= 64 ? 2 : 1));
-  if (nch >= 4) {
+  const bool flat = !g_skinny_looped && K == 4 * SKg * kper && (kper == 128 || kper == 64 || kper == 32);
+  if (flat) {  // one fetch batch per wave: every load in flight before the first MFMA
+    if (kper == 128) {
+      SBK_LAUNCH((gemm_skinny_flat_kernel<4>), grid, block, 0, st, g, ws, tiles_m, tiles_n);
+    } else if (kper == 64) {
+      SBK_LAUNCH((gemm_skinny_flat_kernel<2>), grid, block, 0, st, g, ws, tiles_m, tiles_n);
+    } else {
+      SBK_LAUNCH((gemm_skinny_flat_kernel<1>), grid, block, 0, st, g, ws, tiles_m, tiles_n);
+    }
+  } else if (nch >= 4) {
     SBK_LAUNCH((gemm_skinny_kernel<4>), grid, block, 0, st, g, ws, kper, tiles_m, tiles_n);
   } else if (nch >= 2) {
     SBK_LAUNCH((gemm_skinny_kernel<2>), grid, block, 0, st, g, ws, kper, tiles_m, tiles_n);
@@ -459,6 +708,7 @@ int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
   if (big && (g_gemm_tile & 15) == 1) return launch_gemm<256, 128, 32, 64, 64>(g, vec, st);
   if (big && (g_gemm_tile & 15) == 2) return launch_gemm<128, 256, 32, 64, 64>(g, vec, st);
   if (big && (g_gemm_tile & 15) == 3) return launch_gemm<256, 128, 32, 128, 64>(g, vec, st);
+  if (big && (g_gemm_tile & 15) == 4) return launch_gemm<128, 128, 64, 64, 64>(g, vec, st);  // one barrier pair per 128 MFMAs
   if (tiles128 >= 384) return launch_gemm<128, 128, 32, 64, 64>(g, vec, st);
   if (tiles64 >= 256 || M > 256) return launch_gemm<64, 64, 32, 32, 32>(g, vec, st);
   return launch_gemm<32, 64, 32, 32, 32>(g, vec, st);
@@ -539,4 +789,6 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 6) sbk::g_gemm_tile = value;
   if (key == 7) sbk::g_ctc_tpt = value;
   if (key == 8) sbk::g_cross_fc256 = value;
+  if (key == 9) sbk::g_gemm_vec_lds = value;
+  if (key == 10) sbk::g_skinny_looped = value;
 }

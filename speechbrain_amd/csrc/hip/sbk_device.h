@@ -36,6 +36,10 @@ __device__ __forceinline__ int shfl(int v, int lane) { return __shfl(v, lane, kW
 // wave's DS instructions in order; this pins the compiler's schedule).
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
+// Scheduling fence for the compiler: nothing is moved across it (keeps a block of loads issued ahead of
+// the arithmetic that consumes them instead of sunk next to each use).
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 // x * 2^e and the exponent k of x = f * 2^k, f in [0.5,1) (0 for x = 0): single VALU instructions
 // (v_ldexp_f32 / v_frexp_exp_i32_f32) without the libm special-case wrappers.
 __device__ __forceinline__ float fast_ldexp(float x, int e) { return __builtin_amdgcn_ldexpf(x, e); }

@@ -34,12 +34,13 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
                  int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st);
 int ctc_combine(const float* am, const float* am_max, const float* psi, const float* psi_prev, float* comb, int n_bh,
                 int V, int blank, int eos, float weight, int eos_floor, int use_thr, float thr, float minus_inf,
-                const float* extra, hipStream_t st);
+                const float* extra, hipStream_t st, const int32_t* utt_min = nullptr, int beam = 1, int step = 0);
 int ctc_advance(const float* x, const float* phi_old, const float* psi, const int32_t* parent, const int32_t* token,
                 const int32_t* parent_last_tok, float* phi_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
                 int prefix_len, int blank, hipStream_t st);
 int am_only(const float* am, float* comb, int n_bh, int V, int eos, int eos_floor, int use_thr, float thr,
-            float minus_inf, const float* am_max, const float* extra, hipStream_t st);
+            float minus_inf, const float* am_max, const float* extra, hipStream_t st, const int32_t* utt_min = nullptr,
+            int beam = 1, int step = 0);
 int row_max(const float* x, float* out, int rows, int V, hipStream_t st);
 }  // namespace sbk
 
@@ -161,9 +162,12 @@ constexpr int kTopkChunks = 16;  // stage-1 workgroups per utterance
 __global__ void __launch_bounds__(256) beam_topk_stage1_kernel(const float* __restrict__ comb,
                                                                const float* __restrict__ seq, float* __restrict__ pval,
                                                                int32_t* __restrict__ pidx, int V, int beam, float norm,
-                                                               const int32_t* __restrict__ step_ptr) {
+                                                               const int32_t* __restrict__ step_ptr, int step,
+                                                               const int32_t* __restrict__ utt_max) {
   if (step_ptr && norm > 0.0f) norm = (float)(step_ptr[0] + 1);  // length normalisation by the device-side step
+  if (step_ptr) step = step_ptr[0];
   const int b = blockIdx.y, ch = blockIdx.x;
+  if (utt_max && step >= utt_max[b]) return;  // this utterance's search has ended: its candidates stay frozen
   const int total = beam * V;
   const int len = (total + kTopkChunks - 1) / kTopkChunks;
   const int e0 = ch * len, n = max(0, min(len, total - e0));
@@ -181,8 +185,12 @@ __global__ void __launch_bounds__(256) beam_topk_stage1_kernel(const float* __re
 __global__ void __launch_bounds__(256) beam_topk_stage2_kernel(const float* __restrict__ pval,
                                                                const int32_t* __restrict__ pidx,
                                                                float* __restrict__ out_val,
-                                                               int32_t* __restrict__ out_idx, int beam) {
+                                                               int32_t* __restrict__ out_idx, int beam,
+                                                               const int32_t* __restrict__ step_ptr, int step,
+                                                               const int32_t* __restrict__ utt_max) {
   const int b = blockIdx.x;
+  if (step_ptr) step = step_ptr[0];
+  if (utt_max && step >= utt_max[b]) return;
   const float* pv = pval + (size_t)b * kTopkChunks * kMaxBeam;
   const int32_t* pi = pidx + (size_t)b * kTopkChunks * kMaxBeam;
   block_topk(kTopkChunks * kMaxBeam, beam, out_val + b * beam, out_idx + b * beam, [&](int e, float& v, int& id) {
@@ -208,8 +216,11 @@ __global__ void __launch_bounds__(1024) beam_topk_large_kernel(const float* __re
                                                                const float* __restrict__ seq,
                                                                float* __restrict__ out_val,
                                                                int32_t* __restrict__ out_idx, int V, int beam,
-                                                               float norm, const int32_t* __restrict__ step_ptr) {
+                                                               float norm, const int32_t* __restrict__ step_ptr,
+                                                               int step, const int32_t* __restrict__ utt_max) {
   if (step_ptr && norm > 0.0f) norm = (float)(step_ptr[0] + 1);
+  if (step_ptr) step = step_ptr[0];
+  if (utt_max && step >= utt_max[blockIdx.x]) return;  // uniform per workgroup
   __shared__ int hist[256];
   __shared__ unsigned s_prefix;
   __shared__ int s_remaining, s_count, s_eq_base;
@@ -386,13 +397,32 @@ __global__ void beam_init_kernel(BeamState s, int B, int beam, int bos) {
 
 __global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const float* __restrict__ am, int cur, int step,
                                                           int V, int beam, int Lmax, int eos, int length_norm,
-                                                          const int32_t* __restrict__ step_ptr) {
+                                                          const int32_t* __restrict__ step_ptr,
+                                                          const int32_t* __restrict__ utt_max) {
   if (step_ptr) step = step_ptr[0];
   __shared__ int h_src[kMaxBeamLarge];
   __shared__ int h_dst[kMaxBeamLarge];
   __shared__ int h_n;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int nxt = cur ^ 1;
+  if (utt_max && step >= utt_max[b]) {
+    // grouped search: this utterance ran its own number of steps already.  Its hypotheses, scores and finished
+    // list stay as they were; only the double-buffered tables are carried over to the other buffer.
+    // (The rows keep going through the decoder step with the others -- their results are ignored -- so the
+    // ancestry table must stay addressable: position `step` points at the row's own slot.)
+    for (int idx = tid; idx < beam * (step + 1); idx += 256) {
+      const int j = idx / (step + 1), p = idx % (step + 1);
+      const size_t o = ((size_t)b * beam + j) * Lmax + p;
+      s.seq[nxt][o] = p < step ? s.seq[cur][o] : 0;
+      s.lp[nxt][o] = p < step ? s.lp[cur][o] : 0.0f;
+      s.kv_slot[nxt][o] = p < step ? s.kv_slot[cur][o] : b * beam + j;
+    }
+    if (tid < beam) {
+      s.tokens[nxt][b * beam + tid] = s.tokens[cur][b * beam + tid];
+      s.parent[b * beam + tid] = b * beam + tid;
+    }
+    return;
+  }
   for (int idx = tid; idx < beam * (step + 1); idx += 256) {
     const int j = idx / (step + 1), p = idx % (step + 1);
     const int n = b * beam + j;
@@ -452,7 +482,10 @@ __global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const flo
 __global__ void __launch_bounds__(256) beam_finalize_kernel(BeamState s, int cur, int steps_done, int beam, int Lmax,
                                                             int topk, int32_t* __restrict__ out_tok,
                                                             int32_t* __restrict__ out_len, float* __restrict__ out_score,
-                                                            float* __restrict__ out_lp) {
+                                                            float* __restrict__ out_lp,
+                                                            const int32_t* __restrict__ utt_max,
+                                                            int32_t* __restrict__ out_longest) {
+  if (utt_max) steps_done = min(steps_done, utt_max[blockIdx.x]);  // grouped search: this utterance's own step count
   __shared__ float e_score[kMaxBeamLarge];
   __shared__ int e_src[kMaxBeamLarge];   // >= 0: finished slot f;  < 0: alive hypothesis -(j+1)
   __shared__ int sel[kMaxBeamLarge];
@@ -474,6 +507,7 @@ __global__ void __launch_bounds__(256) beam_finalize_kernel(BeamState s, int cur
       }
     }
     atomicMax(&s.n_full[1], longest);
+    if (out_longest) out_longest[b] = longest;
     n_entries = cnt;
     for (int r = 0; r < topk; ++r) {  // selection in descending score order; ties: first entry first
       int bi = -1;
@@ -860,8 +894,8 @@ extern "C" size_t sbk_beam_search_workspace_bytes(const sbk_decoder_weights* W, 
 extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_search_config* cfg, const float* enc,
                                    const int32_t* enc_len, const float* ctc_w, const float* ctc_b, void* workspace,
                                    size_t workspace_bytes, int32_t* out_tokens, int32_t* out_len, float* out_score,
-                                   float* out_logp, int32_t* out_max_len, int32_t* host_flag, int32_t* steps_run,
-                                   int B, int T, sbk_stream_t stream) {
+                                   float* out_logp, int32_t* out_max_len, int32_t* out_longest, int32_t* host_flag,
+                                   int32_t* steps_run, int B, int T, sbk_stream_t stream) {
   SBK_TRY(check_weights(W));
   if (B == 0) {  // empty batch: nothing to launch, the data pointers may be NULL
     if (steps_run) *steps_run = 0;
@@ -947,29 +981,30 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
                                   cfg->blank, cfg->eos, st));
       SBK_TRY(sbk::ctc_combine(bb.am, bb.am_max, bb.psi, bb.psi_prev[cur], bb.comb, n, V, cfg->blank, cfg->eos,
                                cfg->ctc_weight, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
-                               cfg->minus_inf, extra, st));
+                               cfg->minus_inf, extra, st, cfg->utt_min_steps, beam, step));
     } else {
       SBK_TRY(sbk::am_only(bb.am, bb.comb, n, V, cfg->eos, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
-                           cfg->minus_inf, bb.am_max, extra, st));
+                           cfg->minus_inf, bb.am_max, extra, st, cfg->utt_min_steps, beam, step));
     }
     const float norm = cfg->length_normalization ? (float)(step + 1) : 0.0f;
     const int32_t* sp = sbk::g_step_ptr;  // a local: launch arguments must not name the thread_local itself
+    const int32_t* umax = cfg->utt_max_steps;
     if (beam > kMaxBeam) {
       sbk::ProfScope prof("beam_topk_large", 10.0 * n * V, 20.0 * n * V, st);
       SBK_LAUNCH(beam_topk_large_kernel, dim3(B), dim3(1024), 0, st, (const float*)bb.comb,
-                 (const float*)bb.s.seq_scores, bb.s.cand_val, bb.s.cand_idx, V, beam, norm, sp);
+                 (const float*)bb.s.seq_scores, bb.s.cand_val, bb.s.cand_idx, V, beam, norm, sp, step, umax);
     } else {
       sbk::ProfScope prof("beam_topk", 2.0 * n * V, 4.0 * n * V, st);
       SBK_LAUNCH(beam_topk_stage1_kernel, dim3(kTopkChunks, B), dim3(256), 0, st, (const float*)bb.comb,
-                 (const float*)bb.s.seq_scores, bb.topk_val, bb.topk_idx, V, beam, norm, sp);
+                 (const float*)bb.s.seq_scores, bb.topk_val, bb.topk_idx, V, beam, norm, sp, step, umax);
       SBK_LAUNCH(beam_topk_stage2_kernel, dim3(B), dim3(256), 0, st, (const float*)bb.topk_val,
-                 (const int32_t*)bb.topk_idx, bb.s.cand_val, bb.s.cand_idx, beam);
+                 (const int32_t*)bb.topk_idx, bb.s.cand_val, bb.s.cand_idx, beam, sp, step, umax);
     }
     SBK_TRY(sbk::launch_status("beam_topk"));
     {
       sbk::ProfScope prof("beam_update", 0.0, 24.0 * n * (step + 1), st);
       SBK_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 0, st, bb.s, (const float*)bb.am, cur, step, V, beam, Lmax,
-                 cfg->eos, cfg->length_normalization, sp);
+                 cfg->eos, cfg->length_normalization, sp, umax);
     }
     SBK_TRY(sbk::launch_status("beam_update"));
     // survivors' CTC state, then the next step's psi -- beside the next decoder step (with a device-side
@@ -1064,7 +1099,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   if (side) SBK_HIP(hipStreamWaitEvent(st, side->join, 0));  // nothing of this call outlives it on the helper stream
   if (steps_run) *steps_run = steps;
   SBK_LAUNCH(beam_finalize_kernel, dim3(B), dim3(256), 0, st, bb.s, cur, steps, beam, Lmax, topk, out_tokens, out_len,
-             out_score, out_logp);
+             out_score, out_logp, cfg->utt_max_steps, out_longest);
   SBK_TRY(sbk::launch_status("beam_finalize"));
   if (out_max_len)
     SBK_HIP(hipMemcpyAsync(out_max_len, bb.s.n_full + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, st));

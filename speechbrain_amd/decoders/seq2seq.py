@@ -142,6 +142,55 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
         return tok, ln, sc, lp, mxl
 
     @torch.no_grad()
+    def forward_group(self, items, ratios=None):
+        """Several independent batches in ONE device search.
+
+        ``items``: list of (enc_states [B_g,T_g,d], wav_len [B_g]); ``ratios`` (optional): per batch
+        (min_decode_ratio, max_decode_ratio), default the searcher's own.  Returns the list of ``forward`` results,
+        one per batch.  Every batch keeps its own semantics -- its own padded length T_g, hence its own step limits
+        int(T_g * ratio) (seq2seq.py:1336-1338) and its own length normaliser for ``best_lens`` -- but the decoder
+        step runs over the rows of all batches at once (csrc/search.hip, ``utt_max_steps``): with recipe-sized
+        batches the per-step GEMMs otherwise see a few hundred rows and cannot fill the chip."""
+        if self.return_topk:
+            raise NotImplementedError("forward_group returns the best hypothesis per utterance (return_topk = False)")
+        if len(items) == 1 and ratios is None:
+            return [self.forward(*items[0])]
+        dev = items[0][0].device
+        ratios = ratios or [(self.min_decode_ratio, self.max_decode_ratio)] * len(items)
+        Bs = [e.shape[0] for e, _ in items]
+        Tmax, d = max(e.shape[1] for e, _ in items), items[0][0].shape[2]
+        enc = torch.zeros(sum(Bs), Tmax, d, dtype=torch.float32, device=dev)  # frames past enc_len are never read
+        lens, mins, maxs, off = [], [], [], 0
+        for (e, wl), (r_min, r_max), B in zip(items, ratios, Bs):
+            T = e.shape[1]
+            enc[off: off + B, :T] = e
+            lens.append(torch.round(T * wl.to(dev)).int())
+            mins += [int(T * r_min)] * B
+            maxs += [int(T * r_max)] * B
+            off += B
+        enc_lens = torch.cat(lens)
+        limits = torch.tensor([mins, maxs], dtype=torch.int32).to(dev, non_blocking=True)
+        cfg = self.config(Tmax)
+        cfg.min_steps, cfg.max_steps = min(mins), max(maxs)
+        cw = cb = None
+        if self.ctc_weight > 0:
+            cw, cb = self.ctc_fc.w.weight, self.ctc_fc.w.bias
+        tok, ln, sc, lp, _, _, longest = native.beam_search(self._handle(), cfg, enc, enc_lens, cw, cb,
+                                                            utt_min_steps=limits[0].contiguous(),
+                                                            utt_max_steps=limits[1].contiguous(), want_longest=True)
+        n, L = tok.shape
+        packed = torch.cat([tok.reshape(-1), ln, longest]).cpu()  # one device->host copy
+        tok_h, ln_h, longest_h = packed[: n * L].reshape(n, L), packed[n * L: n * L + n], packed[n * L + n:]
+        out, off = [], 0
+        for B in Bs:
+            max_len = max(int(longest_h[off: off + B].max()), 1)  # this batch's pad width (seq2seq.py:1461)
+            hyps = [tok_h[b, : int(ln_h[b])].tolist() for b in range(off, off + B)]
+            out.append((hyps, (ln_h[off: off + B].float() / max_len).to(dev), sc[off: off + B],
+                        lp[off: off + B, :max_len]))
+            off += B
+        return out
+
+    @torch.no_grad()
     def forward(self, enc_states, wav_len):
         tok, ln, sc, lp, mxl = self.search_device(enc_states, wav_len)
         if self.return_topk:  # padded tensors [B,topk,max_len] (seq2seq.py:1712-1713)

@@ -21,8 +21,12 @@ class ConcurrentTranscriber:
     batches in flight.  ``prepare(searcher, wavs)`` (optional) may adjust the per-worker copy of the
     searcher before a batch (e.g. its decode-length ratios); the copies share the model weights."""
 
-    def __init__(self, asr, streams: int = 8, prioritise_search: bool = True):
+    def __init__(self, asr, streams: int = 8, prioritise_search: bool = True, group: int = 1):
+        """``group`` > 1: a worker takes up to that many batches (neighbours in the duration order), encodes them one
+        after the other and decodes them in ONE grouped search (``S2STransformerBeamSearcher.forward_group``): every
+        batch keeps its own padding and step limits, the decoder step sees the rows of all of them."""
         self.asr, self.n, self.device = asr, max(1, int(streams)), asr.device
+        self.group = max(1, int(group))
         if self.device.type != "cuda":
             self.n = 1
         self.searchers = [copy.copy(asr.mods.decoder) for _ in range(self.n)]
@@ -61,23 +65,67 @@ class ConcurrentTranscriber:
                 cur.wait_stream(dec_stream)
         return toks
 
+    def _many(self, slot: int, ks, batches, prepare: Optional[Callable]):
+        """Encode the batches `ks` one after the other, decode them in one grouped search."""
+        searcher = self.searchers[slot]
+        items, ratios = [], []
+        with torch.no_grad():
+            for k in ks:
+                wavs, wav_lens = batches[k]
+                if prepare is not None:
+                    prepare(searcher, wavs)
+                ratios.append((searcher.min_decode_ratio, searcher.max_decode_ratio))
+                wavs = wavs.to(self.device, non_blocking=True)
+                wav_lens = wav_lens.to(self.device, non_blocking=True)
+                if wavs.dtype == torch.int16:
+                    from speechbrain_amd import native
+
+                    wavs = native.pcm16_to_f32(wavs)
+                items.append((self.asr.encode_batch(wavs, wav_lens), wav_lens))
+            dec_stream = self.dec_streams[slot] if self.device.type == "cuda" else None
+            if dec_stream is None:
+                res = searcher.forward_group(items, ratios)
+            else:
+                cur = torch.cuda.current_stream()
+                dec_stream.wait_stream(cur)
+                with torch.cuda.stream(dec_stream):
+                    res = searcher.forward_group(items, ratios)  # returns host token lists: dec_stream is drained
+                for enc, _ in items:
+                    enc.record_stream(dec_stream)
+                cur.wait_stream(dec_stream)
+        return [(k, r[0]) for k, r in zip(ks, res)]
+
     def _work(self, slot: int, todo: "queue.Queue", batches, prepare):
         out = []
+
+        def take():
+            ks = []
+            while len(ks) < self.group:
+                try:
+                    ks.append(todo.get_nowait())
+                except queue.Empty:
+                    break
+            return ks
+
+        def run(ks):
+            if len(ks) > 1 and hasattr(self.searchers[slot], "forward_group"):
+                out.extend(self._many(slot, ks, batches, prepare))
+            else:
+                out.extend((k, self._one(slot, *batches[k], prepare)) for k in ks)
+
         if self.device.type != "cuda":
             while True:
-                try:
-                    k = todo.get_nowait()
-                except queue.Empty:
+                ks = take()
+                if not ks:
                     return out
-                out.append((k, self._one(slot, *batches[k], prepare)))
+                run(ks)
         torch.cuda.set_device(self.device)  # the current device is per host thread
         with torch.cuda.stream(self.enc_streams[slot]):
             while True:
-                try:
-                    k = todo.get_nowait()
-                except queue.Empty:
+                ks = take()
+                if not ks:
                     break
-                out.append((k, self._one(slot, *batches[k], prepare)))
+                run(ks)
             self.enc_streams[slot].synchronize()
         return out
 
@@ -91,7 +139,8 @@ class ConcurrentTranscriber:
         todo: "queue.Queue" = queue.Queue()
         for k in sorted(range(len(batches)), key=lambda i: -batches[i][0].numel()):
             todo.put(k)
-        futs = [self.pool.submit(self._work, slot, todo, batches, prepare) for slot in range(min(self.n, len(batches)))]
+        n_workers = min(self.n, (len(batches) + self.group - 1) // self.group)
+        futs = [self.pool.submit(self._work, slot, todo, batches, prepare) for slot in range(max(1, n_workers))]
         res = {}
         for f in futs:
             for k, toks in f.result():

@@ -58,7 +58,8 @@ class SearchConfig(ctypes.Structure):  # sbk_search_config
                 ("max_steps", c_int32), ("length_normalization", c_int32), ("using_eos_threshold", c_int32),
                 ("check_every", c_int32), ("overlap_ctc", c_int32), ("ctc_weight", c_float), ("temperature", c_float),
                 ("eos_threshold", c_float), ("minus_inf", c_float), ("lm_weight", c_float), ("lm_temperature", c_float),
-                ("lm", POINTER(LMWeights)), ("topk", c_int32), ("graph_mode", c_int32)]
+                ("lm", POINTER(LMWeights)), ("topk", c_int32), ("utt_min_steps", c_void_p),
+                ("utt_max_steps", c_void_p), ("graph_mode", c_int32)]
 
 
 def _declare(lib):
@@ -89,7 +90,7 @@ def _declare(lib):
         "sbk_log_softmax_f32": ([p, p, i, i, f, f, p], c_int),
         "sbk_beam_search_workspace_bytes": ([POINTER(DecoderWeights), POINTER(SearchConfig), i, i], ctypes.c_size_t),
         "sbk_beam_search_f32": ([POINTER(DecoderWeights), POINTER(SearchConfig), p, p, p, p, p, ctypes.c_size_t, p, p,
-                                 p, p, p, p, POINTER(c_int32), i, i, p], c_int),
+                                 p, p, p, p, p, POINTER(c_int32), i, i, p], c_int),
         "sbk_greedy_search_workspace_bytes": ([POINTER(DecoderWeights), i, i, i], ctypes.c_size_t),
         "sbk_greedy_search_f32": ([POINTER(DecoderWeights), p, p, p, ctypes.c_size_t, p, p, p, POINTER(c_int32), i, i,
                                    i, i, i, i, i, p], c_int),
@@ -121,7 +122,7 @@ def load(path: Optional[str] = None):
         )
     lib = ctypes.CDLL(path)
     EXPORTS = tuple(_declare(lib).keys())
-    if lib.sbk_abi_version() != 1:
+    if lib.sbk_abi_version() != 2:
         raise SbkError(f"ABI version mismatch: {lib.sbk_abi_version()}")
     _lib = lib
     return lib
@@ -517,11 +518,15 @@ def _host_flag(device):
     return t.pin_memory() if device.type == "cuda" else t
 
 
-def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=None, ctc_b=None):
+def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=None, ctc_b=None, utt_min_steps=None,
+                utt_max_steps=None, want_longest=False):
     """Returns (tokens [B,max_steps] int32, lens [B] int32, scores [B], log_probs [B,max_steps],
-    max_len [1] int32 (longest finished hypothesis), steps_run)."""
+    max_len [1] int32 (longest finished hypothesis), steps_run) -- plus longest [B] int32 with ``want_longest``.
+    ``utt_min_steps`` / ``utt_max_steps`` (int32 [B] on the device): per-utterance step limits of a grouped search."""
     lib = load()
-    _dev_ok(enc, enc_len, ctc_w, ctc_b)
+    _dev_ok(enc, enc_len, ctc_w, ctc_b, utt_min_steps, utt_max_steps)
+    cfg.utt_min_steps = utt_min_steps.data_ptr() if utt_min_steps is not None else None
+    cfg.utt_max_steps = utt_max_steps.data_ptr() if utt_max_steps is not None else None
     _f32(enc)
     B, T, _ = enc.shape
     dev = enc.device
@@ -535,13 +540,16 @@ def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=No
     out_score = torch.zeros(B * K, dtype=torch.float32, device=dev)
     out_lp = torch.zeros(B * K, L, dtype=torch.float32, device=dev)
     out_max = torch.zeros(1, dtype=torch.int32, device=dev)
+    out_longest = torch.zeros(B, dtype=torch.int32, device=dev) if want_longest else None
     flag = _host_flag(dev)
     steps = c_int32(0)
     _chk(lib.sbk_beam_search_f32(ctypes.byref(handle.W), ctypes.byref(cfg), _p(enc), _p(enc_len), _p(ctc_w), _p(ctc_b),
                                  c_void_p(ws.data_ptr() + off), nbytes, _p(out_tok), _p(out_len), _p(out_score),
-                                 _p(out_lp), _p(out_max), c_void_p(flag.data_ptr()), ctypes.byref(steps), B, T,
-                                 _stream(enc)),
+                                 _p(out_lp), _p(out_max), _p(out_longest), c_void_p(flag.data_ptr()),
+                                 ctypes.byref(steps), B, T, _stream(enc)),
          "sbk_beam_search_f32")
+    if want_longest:
+        return out_tok, out_len, out_score, out_lp, out_max, steps.value, out_longest
     return out_tok, out_len, out_score, out_lp, out_max, steps.value
 
 

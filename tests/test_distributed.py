@@ -117,7 +117,7 @@ def _worker_asr(rank, world, tmpdir, q, pcm=False):
 
         asr = _tiny_asr()
         st = ShardedTranscriber(lambda w, l: asr.transcribe_batch(w, l)[1], "cpu", max_utts=2,
-                                concurrent=ConcurrentTranscriber(asr, streams=3))
+                                concurrent=ConcurrentTranscriber(asr, streams=3, group=2 if pcm else 1))
         hyps = st.transcribe(_asr_job(pcm) if rank == 0 else None)
         if rank == 0:
             q.put((hyps, st.last_plan["bytes_sent"]))

@@ -565,3 +565,40 @@ def test_in_place_weight_update_rebuilds_the_decoder_handle(backend):
     _, toks_a2 = a.transcribe_batch(wav, lens)
     assert a.mods.decoder._handle() is not h0
     assert toks_a2 == toks_b
+
+
+@pytest.mark.parametrize("ctc_weight", [0.4, 0.0])
+def test_grouped_search_equals_separate_searches(backend, ctc_weight):
+    """forward_group: several batches (own padded length, own step limits, EOS reachable) in ONE device search give
+    every batch exactly what its own search gives -- the basis for running recipe-sized batches with full GEMMs."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_asr
+
+    tiny = dict(d_model=32, nhead=4, d_ffn=64, n_enc=1, n_dec=2, n_fft=512, win_length=32)
+    asr = build_asr(tiny, vocab=30, seed=21, beam_size=4, ctc_weight=ctc_weight, device=str(dev), using_eos_threshold=True)
+    with torch.no_grad():
+        asr.mods.seq_lin.w.weight.mul_(7.0)
+        asr.mods.ctc_lin.w.weight.mul_(7.0)
+        asr.mods.seq_lin.w.bias[2] += 6.0  # EOS (index 2) within reach: some hypotheses end before the step limit
+    g = torch.Generator().manual_seed(17)
+    shapes = [(3, 9600, (0.0, 0.5)), (2, 5120, (0.2, 1.0)), (1, 12800, (0.0, 0.3)), (2, 7040, (0.0, 0.9))]
+    items, ratios = [], []
+    dec = asr.mods.decoder
+    for B, N, r in shapes:
+        wav = 0.1 * torch.randn(B, N, generator=g)
+        lens = torch.linspace(0.7, 1.0, B)
+        items.append((asr.encode_batch(wav, lens), lens.to(dev)))
+        ratios.append(r)
+    separate = []
+    for (enc, wl), (r_min, r_max) in zip(items, ratios):
+        dec.min_decode_ratio, dec.max_decode_ratio = r_min, r_max
+        separate.append(dec(enc, wl))
+    grouped = dec.forward_group(items, ratios)
+    assert len(grouped) == len(separate)
+    for (h_g, l_g, s_g, p_g), (h_s, l_s, s_s, p_s) in zip(grouped, separate):
+        assert h_g == h_s
+        assert float((l_g.cpu() - l_s.cpu()).abs().max()) <= 1e-6
+        assert float((s_g.cpu() - s_s.cpu()).abs().max()) <= 2e-5
+        assert p_g.shape == p_s.shape and float((p_g.cpu() - p_s.cpu()).abs().max()) <= 2e-5
+    early = [len(h) < int(items[i][0].shape[1] * ratios[i][1]) - 1 for i, res in enumerate(separate) for h in res[0]]
+    assert any(early), "the case should contain hypotheses that end through EOS before the step limit"

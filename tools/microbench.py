@@ -88,13 +88,32 @@ if __name__ == "__main__":
         nat.load().sbk_prof_set_knob(2, 0)
         sys.exit(0)
     if "--enc-gemm" in sys.argv:  # encoder GEMM shapes (M = B*T'), tile variants of the large-M path
-        for tile in (0, 1, 2, 3):
+        for tile, vec in ((0, 0), (0, 1), (4, 1)):
             nat.load().sbk_prof_set_knob(6, tile)
-            print("tile variant", tile)
+            nat.load().sbk_prof_set_knob(9, vec)
+            print("tile variant", tile, "16-byte LDS operands" if vec else "scalar LDS operands")
             for (M, N, K) in [(16384, 2048, 512), (16384, 512, 2048), (56064, 2048, 512), (56064, 512, 2048),
                               (56064, 1536, 512), (56064, 512, 512), (56064, 1024, 512)]:
                 gemm_case(M, N, K, 0)
         nat.load().sbk_prof_set_knob(6, 0)
+        print("decode-step shapes through the tiled kernels (knob 2 = 1), scalar vs 16-byte LDS operands")
+        nat.load().sbk_prof_set_knob(2, 1)
+        for vec in (0, 1):
+            nat.load().sbk_prof_set_knob(9, vec)
+            for M in (320, 1280):
+                for (N, K) in [(512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512)]:
+                    gemm_case(M, N, K, 0)
+        nat.load().sbk_prof_set_knob(2, 0)
+        nat.load().sbk_prof_set_knob(9, 0)
+        sys.exit(0)
+    if "--skinny" in sys.argv:  # decode-step GEMMs on the register-operand path: looped (round 1) vs flat schedule
+        for looped in (1, 0):
+            nat.load().sbk_prof_set_knob(10, looped)
+            print("skinny schedule:", "looped" if looped else "flat (all loads up front)")
+            for M in (320, 640, 1280):
+                for (N, K) in [(512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512)]:
+                    gemm_case(M, N, K, 8)
+        nat.load().sbk_prof_set_knob(10, 0)
         sys.exit(0)
     if "--copy" in sys.argv:  # what a plain streaming kernel reaches on this box (calibrates the HBM rooflines)
         for mb in (256, 1024, 4096):
