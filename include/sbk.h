@@ -152,10 +152,14 @@ int sbk_conv_block_f32(const float* x, const float* wt, const float* bias, const
  *   bias_u/bias_v [H*Dh]: pos_bias_u/v storage read as (H,Dh)                  (:660-664)
  *   key_len [B] int32 or NULL: keys >= key_len[b] are masked (key_padding_mask)
  *   out  [B,T,H*Dh]   context before out_proj;  attn [B,H,T,T] or NULL (attention weights)
- *   scale = 1/sqrt(embed_dim) (:521).  Dh in {8,16,32,36,64}; T up to ~1100 (LDS strip). */
+ *   scale = 1/sqrt(embed_dim) (:521).  Dh in {8,16,32,36,64}; T up to ~1100 (LDS strip) when attn is requested.
+ *   chunk_size > 0: the Dynamic Chunk attention mask of make_transformer_src_mask (TransformerASR.py:47-103) --
+ *   query i (chunk c = i / chunk_size) sees the keys [max(0, (c - left_chunks) * chunk_size), (c + 1) * chunk_size);
+ *   left_chunks < 0: unlimited left context; chunk_size = 0: no mask.  Rows without any allowed key give a zero
+ *   context (the post-softmax masked_fill of :713-728). */
 int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                              const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,
-                             float scale, sbk_stream_t stream);
+                             float scale, int chunk_size, int left_chunks, sbk_stream_t stream);
 
 /* ---- RoPEMHA core (nnet/attention.py:1167-1392): what sits between in_proj and out_proj.
  *   out = softmax( rot(q) rot(k)^T scale , keys < key_len ) v,  scale = 1/sqrt(embed_dim) (:1272)
@@ -163,13 +167,15 @@ int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bi
  *   PrecomputedRoPESinusoids (:955-1053): rot(x)[c] = x[c]*cos[t][c] + x[c^1]*sines[t][c]. */
 int sbk_rope_attention_f32(const float* qkv, const float* cosines, const float* sines, const int32_t* key_len,
                            float* out, float* attn, int B, int T, int H, int Dh, int table_rows, float scale,
-                           sbk_stream_t stream);
+                           int chunk_size, int left_chunks, sbk_stream_t stream);
 
 /* ---- a13: middle of ConvolutionModule (Conformer.py:315-330): GLU over channels of the
  * pointwise-conv output followed by the depthwise Conv1d (kernel ksize, zero padding
- * (ksize-1)/2, groups = d) + bias.   h [B,T,2d] -> y [B,T,d];  w [d,ksize]; bias [d]. */
+ * (ksize-1)/2, groups = d) + bias.   h [B,T,2d] -> y [B,T,d];  w [d,ksize]; bias [d].
+ * chunk_size > 0: Dynamic Chunk Convolution (Conformer.py:190-313) -- an output frame of chunk c = t / chunk_size sees
+ * its past across chunk borders but zeros instead of every frame >= (c + 1) * chunk_size. */
 int sbk_glu_dwconv_f32(const float* h, const float* w, const float* bias, float* y, int B, int T, int d, int ksize,
-                       sbk_stream_t stream);
+                       int chunk_size, sbk_stream_t stream);
 
 /* log_softmax(x / temperature) * weight over the last dimension, x [rows,V] (seq2seq.py:1933). */
 int sbk_log_softmax_f32(const float* x, float* out, int rows, int V, float temperature, float weight,

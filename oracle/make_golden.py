@@ -608,6 +608,131 @@ def golden_init_fingerprint():
     print(f"  {len(fp)} tensors")
 
 
+def golden_streaming():
+    """Dynamic Chunk (masked) and streaming (chunk-by-chunk) Conformer encoder of the REFERENCE:
+    TransformerASR.encode(dynchunktrain_config=...) and encode_streaming over the same input, for a limited and an
+    unlimited left context, a length that is not a multiple of the chunk and a padded batch; plus the layer-level
+    case of the reference's own tests/unittests/test_conformer.py:5-98 (masked == streaming)."""
+    print("== streaming / dynamic chunk")
+    from speechbrain.lobes.models.transformer.Conformer import ConformerEncoderLayer
+    from speechbrain.lobes.models.transformer.TransformerASR import TransformerASR, make_transformer_src_mask
+    from speechbrain.nnet.attention import RelPosEncXL
+    from speechbrain.utils.dynamic_chunk_training import DynChunkTrainConfig
+
+    out = {}
+    # (1) the reference's unit test, values stored
+    torch.manual_seed(1337)
+    layer = ConformerEncoderLayer(d_model=16, d_ffn=32, nhead=1, kernel_size=5).eval()
+    pos = RelPosEncXL(16)
+    x = torch.randn(1, 24, 16)
+    cfg = DynChunkTrainConfig(chunk_size=8, left_context_size=1)
+    with torch.no_grad():
+        masked, _ = layer(x, src_mask=make_transformer_src_mask(x, dynchunktrain_config=cfg), pos_embs=pos(x),
+                          dynchunktrain_config=cfg)
+        ctx = layer.make_streaming_context(8)
+        chunks = []
+        for i in range(3):
+            c = x[:, 8 * i: 8 * i + 8]
+            n = 8 + (0 if ctx.mha_left_context is None else ctx.mha_left_context.size(1))
+            chunks.append(layer.forward_streaming(c, ctx, pos_embs=pos(torch.empty(1, n, 16)))[0])
+        stream = torch.cat(chunks, 1)
+    print(f"  reference layer test: mean |masked - streaming| = {float((masked - stream).abs().mean()):.2e}")
+    assert float((masked - stream).abs().mean()) < 1e-6
+    out.update({"layer/x": x.numpy(), "layer/masked": masked.numpy(), "layer/stream": stream.numpy()})
+    out.update({"layer/sd/" + k: v.numpy() for k, v in layer.state_dict().items()})
+
+    # (2) TransformerASR level
+    for tag, att, cs, lc, T, ks in (("a", "RelPosMHAXL", 8, 1, 29, 15), ("b", "RelPosMHAXL", 6, None, 20, 7),
+                                    ("c", "RoPEMHA", 4, 2, 19, 7)):
+        torch.manual_seed(101 + cs)
+        tr = TransformerASR(input_size=40, tgt_vocab=30, d_model=32, nhead=4, num_encoder_layers=2,
+                            num_decoder_layers=0, d_ffn=64, dropout=0.0, activation=torch.nn.GELU,
+                            encoder_module="conformer", attention_type=att, normalize_before=True, causal=False,
+                            kernel_size=ks).eval()
+        g = torch.Generator().manual_seed(5 + cs)
+        src = torch.randn(2, T, 40, generator=g)
+        wl = torch.tensor([1.0, 0.7])
+        cfg = DynChunkTrainConfig(chunk_size=cs, left_context_size=lc)
+        with torch.no_grad():
+            masked = tr.encode(src, wl, dynchunktrain_config=cfg)
+            masked_nopad = tr.encode(src, None, dynchunktrain_config=cfg)
+            res = {"src": src.numpy(), "wav_len": wl.numpy(), "masked": masked.numpy(), "masked_nopad": masked_nopad.numpy(),
+                   "cfg": np.array([cs, -1 if lc is None else lc, ks]), "att": np.array(att),
+                   "src_mask": make_transformer_src_mask(src, dynchunktrain_config=cfg).numpy()}
+            if lc is not None:  # (the reference's streaming context needs a finite left context)
+                ctx = tr.make_streaming_context(cfg)
+                pieces = [tr.encode_streaming(src[:, t0: t0 + cs], ctx) for t0 in range(0, T, cs)]
+                stream = torch.cat(pieces, 1)
+                print(f"  {tag}: max |masked_nopad - streaming| = {float((masked_nopad - stream).abs().max()):.2e}")
+                res["stream"] = stream.numpy()
+        out.update({f"{tag}/{k}": v for k, v in res.items()})
+        # (the sinusoid tables are deterministic buffers: not stored)
+        out.update({f"{tag}/sd/{k}": v.numpy() for k, v in tr.state_dict().items() if not k.endswith(".pe")})
+    # (3) StreamingFeatureWrapper around Fbank -> ConvolutionFrontEnd (lobes/features.py:505-670): chunked waveform in,
+    # the same frames out as the offline pipeline (up to the padding the wrapper documents)
+    from speechbrain.lobes.features import Fbank, StreamingFeatureWrapper
+    from speechbrain.lobes.models.convolution import ConvolutionFrontEnd
+    from speechbrain.utils.filter_analysis import stack_filter_properties
+
+    torch.manual_seed(77)
+    fb = Fbank(sample_rate=16000, n_fft=512, n_mels=80, win_length=32)
+    cnn = ConvolutionFrontEnd(input_shape=(8, 10, 80), num_blocks=2, num_layers_per_block=1, out_channels=(8, 4),
+                              kernel_sizes=(3, 3), strides=(2, 2), residuals=(False, False)).eval()
+    pipe = torch.nn.Sequential(fb, cnn)
+    props = stack_filter_properties([fb, cnn])
+    wrap = StreamingFeatureWrapper(pipe, props)
+    wav = 0.1 * torch.randn(2, 640 * 20, generator=torch.Generator().manual_seed(3))
+    chunk = 640 * 4  # 4 output frames per chunk (stride 640 samples)
+    with torch.no_grad():
+        ctx = wrap.make_streaming_context()
+        pieces = [wrap(wav[:, t0: t0 + chunk], ctx) for t0 in range(0, wav.shape[1], chunk)]
+    feats = torch.cat(pieces, 1)
+    print(f"  feature wrapper: window {props.window_size} stride {props.stride}, padding {wrap.get_required_padding()}, "
+          f"{feats.shape[1]} frames")
+    out.update({"fw/wav": wav.numpy(), "fw/feats": feats.numpy(), "fw/props": np.array([props.window_size, props.stride,
+               wrap.get_required_padding(), wrap.get_output_count_per_pad_frame(),
+               wrap.get_recommended_final_chunk_count(chunk)])})
+    out.update({"fw/sd/" + k: v.numpy() for k, v in cnn.state_dict().items()})
+    # (4) StreamingASR.encode_chunk of the REFERENCE (inference/ASR.py:1254-1300) over a chunked waveform
+    from speechbrain.inference.ASR import StreamingASR
+    from speechbrain.lobes.models.transformer.TransformerASR import EncoderWrapper
+    from speechbrain.nnet.containers import LengthsCapableSequential
+    from speechbrain.nnet.linear import Linear
+    from speechbrain.processing.features import InputNormalization
+
+    torch.manual_seed(91)
+    fb = Fbank(sample_rate=16000, n_fft=512, n_mels=80, win_length=32)
+    norm = InputNormalization(norm_type="global", update_until_epoch=4)
+    cnn = ConvolutionFrontEnd(input_shape=(8, 10, 80), num_blocks=2, num_layers_per_block=1, out_channels=(8, 4),
+                              kernel_sizes=(3, 3), strides=(2, 2), residuals=(False, False))
+    tr = TransformerASR(input_size=80, tgt_vocab=30, d_model=32, nhead=4, num_encoder_layers=2, num_decoder_layers=0,
+                        d_ffn=64, dropout=0.0, activation=torch.nn.GELU, encoder_module="conformer",
+                        attention_type="RelPosMHAXL", normalize_before=True, causal=False, kernel_size=7)
+    proj = Linear(input_size=32, n_neurons=30)
+    front = LengthsCapableSequential(input_shape=[None, None], compute_features=fb, normalize=norm, model=cnn)
+    norm.glob_mean, norm.glob_std, norm.count = torch.linspace(-50, -20, 80), torch.linspace(8, 12, 80), 1
+    wrapper = StreamingFeatureWrapper(front, stack_filter_properties([fb, cnn])).eval()  # (a YAML lists these under modules)
+    asr = StreamingASR(modules={"enc": EncoderWrapper(tr), "proj_enc": proj},
+                       hparams={"fea_streaming_extractor": wrapper, "make_decoder_streaming_context": lambda: None,
+                                "decoding_function": lambda x, ctx: [t.argmax(-1).tolist() for t in x],
+                                "make_tokenizer_streaming_context": lambda: None,
+                                "tokenizer_decode_streaming": lambda tok, ids, ctx: " ".join(map(str, ids)),
+                                "tokenizer": None}, run_opts={"device": "cpu"})
+    cfg = DynChunkTrainConfig(chunk_size=4, left_context_size=2)
+    n = asr.get_chunk_size_frames(cfg)
+    wav = 0.1 * torch.randn(2, n * 5, generator=torch.Generator().manual_seed(8))
+    sctx = asr.make_streaming_context(cfg)
+    encs = [asr.encode_chunk(sctx, wav[:, t0: t0 + n]) for t0 in range(0, wav.shape[1], n)]
+    enc_all = torch.cat(encs, 1)
+    print(f"  StreamingASR: chunk = {n} samples, {enc_all.shape[1]} frames over {len(encs)} chunks")
+    out.update({"asr/wav": wav.numpy(), "asr/enc": enc_all.numpy(), "asr/chunk": np.array([n]),
+                "asr/mean": norm.glob_mean.numpy(), "asr/std": norm.glob_std.numpy()})
+    out.update({"asr/sd_cnn/" + k: v.numpy() for k, v in cnn.state_dict().items()})
+    out.update({"asr/sd_tr/" + k: v.numpy() for k, v in tr.state_dict().items() if not k.endswith(".pe")})
+    out.update({"asr/sd_proj/" + k: v.numpy() for k, v in proj.state_dict().items()})
+    np.savez_compressed(os.path.join(OUT, "streaming.npz"), **out)
+
+
 def golden_wer():
     """ErrorRateStats (utils/metric_stats.py:206, utils/edit_distance.py) on random token sequences with random
     edits: per-utterance insertions / deletions / substitutions, the alignment op strings and the summary of the
@@ -650,6 +775,9 @@ if __name__ == "__main__":
     if "--wer-only" in sys.argv:
         golden_wer()
         sys.exit(0)
+    if "--streaming-only" in sys.argv:
+        golden_streaming()
+        sys.exit(0)
     if "--tiny-ctc-only" in sys.argv:
         golden_model("tiny_ctc", d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=2, vocab=40, B=3, n_frames=61,
                      beam=4, ctc_w=0.4, sharpen=6.0, max_ratio=1.0)
@@ -682,4 +810,5 @@ if __name__ == "__main__":
     golden_pretrained()
     golden_init_fingerprint()
     golden_wer()
+    golden_streaming()
     print("OK")

@@ -17,6 +17,7 @@ _MODULES = [
     "nnet.containers", "nnet.embedding", "nnet.linear", "nnet.normalization", "decoders", "decoders.seq2seq",
     "decoders.scorer", "decoders.utils", "inference", "inference.ASR", "inference.interfaces", "utils",
     "utils.data_utils", "utils.parameter_transfer", "utils.metric_stats", "utils.edit_distance",
+    "utils.dynamic_chunk_training", "utils.filter_analysis",
 ]
 
 

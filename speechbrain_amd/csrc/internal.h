@@ -26,7 +26,7 @@ int layernorm(const float* x, const float* gamma, const float* beta, float* y, i
               hipStream_t st);
 int relpos_attention(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                      const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh, float scale,
-                     hipStream_t st);
+                     hipStream_t st, int chunk = 0, int left = -1);
 int glu_dwconv(const float* h, const float* w, const float* bias, float* y, int B, int T, int d, int ksize,
-               hipStream_t st);
+               hipStream_t st, int chunk = 0);
 }  // namespace sbk

@@ -38,7 +38,21 @@ struct AttnArgs {
   float* attn;            // [B,H,T,T] or null
   int B, T, H, SP;
   float scale;
+  // Dynamic Chunk attention mask (TransformerASR.py:47-103, make_transformer_src_mask): chunk > 0 restricts query i
+  // (chunk c = i / chunk) to the keys [max(0, (c - left) * chunk), (c + 1) * chunk); left < 0 = unlimited left context.
+  int chunk, left;
 };
+
+// allowed key range [lo, hi) of query row i under the chunk mask and the key padding length
+__device__ __forceinline__ void key_range(const AttnArgs& a, int i, int klen, int& lo, int& hi) {
+  lo = 0;
+  hi = klen;
+  if (a.chunk > 0) {
+    const int c = i / a.chunk;
+    hi = min((c + 1) * a.chunk, klen);
+    if (a.left >= 0) lo = max(0, (c - a.left) * a.chunk);
+  }
+}
 
 template <int N>
 __device__ __forceinline__ void load_run(float (&dst)[N], const float* __restrict__ p) {
@@ -189,17 +203,20 @@ __global__ void __launch_bounds__(NW * 64) relpos_attn_kernel(AttnArgs a) {
   for (int ii = 0; ii < 32 / NW; ++ii) {
     const int i = wave * (32 / NW) + ii;
     float* Srow = S + i * SP;
+    int lo, hi;
+    key_range(a, min(i0 + i, T - 1), klen, lo, hi);
     float m = -INFINITY;
-    for (int j = lane; j < klen; j += 64) m = fmaxf(m, Srow[j]);
+    for (int j = lo + lane; j < hi; j += 64) m = fmaxf(m, Srow[j]);
     m = sbk::wave_max(m);
     float sum = 0.0f;
-    for (int j = lane; j < klen; j += 64) {
+    for (int j = lo + lane; j < hi; j += 64) {
       const float e = expf(Srow[j] - m);
       Srow[j] = e;
       sum += e;
     }
     sum = sbk::wave_sum(sum);
-    for (int j = lane; j < kend; j += 64) Srow[j] = j < klen ? Srow[j] / sum : 0.0f;
+    // (a row whose keys are all masked gets zero weights, like the reference's post-softmax masked_fill, :713-728)
+    for (int j = lane; j < kend; j += 64) Srow[j] = (j >= lo && j < hi) ? Srow[j] / sum : 0.0f;
     if (a.attn && i0 + i < T) {
       float* arow = a.attn + (((size_t)b * a.H + h) * T + (i0 + i)) * T;
       for (int j = lane; j < T; j += 64) arow[j] = Srow[j];
@@ -314,6 +331,13 @@ __global__ void __launch_bounds__(256, 2) relpos_flash_kernel(AttnArgs a) {
   int klen = T;
   if (a.key_len) klen = min(max(a.key_len[b], 1), T);
   const int nkt = (klen + 31) / 32;
+  int lo_row, hi_row;  // allowed keys of query row jl
+  key_range(a, min(i0 + jl, T - 1), klen, lo_row, hi_row);
+  int kt_begin = 0, kt_end = nkt;  // key tiles any row of this query tile may see
+  if (a.chunk > 0) {
+    kt_end = min(nkt, ((min(i0 + 31, T - 1) / a.chunk + 1) * a.chunk + 31) / 32);
+    if (a.left >= 0) kt_begin = max(0, (i0 / a.chunk - a.left) * a.chunk) / 32;
+  }
   float m_run = -INFINITY, l_run = 0.0f;  // of query row jl (both half-waves carry the same values)
   f32x16 o[NC];
 #pragma unroll
@@ -327,14 +351,14 @@ __global__ void __launch_bounds__(256, 2) relpos_flash_kernel(AttnArgs a) {
   f32x16 gprev;
   if constexpr (!ROPE) {
     float p0reg[DH2];
-    const int prow0 = min(max((T - 1) - i0 - 31 + jl, 0), 2 * T - 2);
+    const int prow0 = min(max((T - 1) - i0 - 31 + kt_begin * 32 + jl, 0), 2 * T - 2);
     load_run<DH2>(p0reg, a.pos + (size_t)prow0 * d + h * DH + half * DH2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) gprev[r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < DH2; ++s) gprev = sbk::mfma_32x32x2(qv[s], p0reg[s], gprev);
   }
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int j0 = kt * 32;
     float kreg[DH2], p1reg[DH2];
     {
@@ -400,16 +424,16 @@ __global__ void __launch_bounds__(256, 2) relpos_flash_kernel(AttnArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int c = half * 16 + q;
-      sv[q] = (j0 + c < klen) ? S[jl][c] : -INFINITY;
+      sv[q] = (j0 + c >= lo_row && j0 + c < hi_row) ? S[jl][c] : -INFINITY;
       mx = fmaxf(mx, sv[q]);
     }
     mx = fmaxf(mx, sbk::shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);  // finite: key j0 < klen is never masked
-    const float alpha = expf(m_run - m_new);
+    const float m_new = fmaxf(m_run, mx);  // -inf while the row has not met an allowed key yet (chunk mask)
+    const float alpha = m_new == -INFINITY ? 1.0f : expf(m_run - m_new);
     float sum = 0.0f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const float pq = expf(sv[q] - m_new);
+      const float pq = sv[q] == -INFINITY ? 0.0f : expf(sv[q] - m_new);
       S[jl][half * 16 + q] = pq;
       sum += pq;
     }
@@ -437,7 +461,7 @@ __global__ void __launch_bounds__(256, 2) relpos_flash_kernel(AttnArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-    const float inv = 1.0f / rv[i];
+    const float inv = rv[i] > 0.0f ? 1.0f / rv[i] : 0.0f;  // no allowed key at all: zero context (attention.py:713-728)
 #pragma unroll
     for (int ct = 0; ct < NC; ++ct) {
       const int col = ct * 32 + jl;
@@ -494,10 +518,10 @@ int g_attn_prefetch = 0;  // tuning knob (sbk_prof_set_knob key 3): phase 1 pref
 
 int relpos_attention(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                      const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh, float scale,
-                     hipStream_t st) {
+                     hipStream_t st, int chunk, int left) {
   if (B == 0 || T == 0) return 0;
   const int SP = ((T + 31) / 32) * 32 + 1;  // odd pitch: the 32 rows of a P.V operand read hit 32 banks
-  AttnArgs a{qkv, pos, bias_u, bias_v, key_len, out, attn, B, T, H, SP, scale};
+  AttnArgs a{qkv, pos, bias_u, bias_v, key_len, out, attn, B, T, H, SP, scale, chunk, left};
   switch (Dh) {
     case 64: return launch_attn<64, false>(a, st);
     case 36: return launch_attn<36, false>(a, st);
@@ -509,10 +533,10 @@ int relpos_attention(const float* qkv, const float* pos, const float* bias_u, co
 }
 
 int rope_attention(const float* qkv, const float* cosines, const float* sines, const int32_t* key_len, float* out,
-                   float* attn, int B, int T, int H, int Dh, float scale, hipStream_t st) {
+                   float* attn, int B, int T, int H, int Dh, float scale, hipStream_t st, int chunk, int left) {
   if (B == 0 || T == 0) return 0;
   const int SP = ((T + 31) / 32) * 32 + 1;
-  AttnArgs a{qkv, cosines, sines, nullptr, key_len, out, attn, B, T, H, SP, scale};
+  AttnArgs a{qkv, cosines, sines, nullptr, key_len, out, attn, B, T, H, SP, scale, chunk, left};
   switch (Dh) {
     case 64: return launch_attn<64, true>(a, st);
     case 36: return launch_attn<36, true>(a, st);
@@ -526,23 +550,27 @@ int rope_attention(const float* qkv, const float* cosines, const float* sines, c
 
 extern "C" int sbk_rope_attention_f32(const float* qkv, const float* cosines, const float* sines,
                                       const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,
-                                      int table_rows, float scale, sbk_stream_t stream) {
+                                      int table_rows, float scale, int chunk_size, int left_chunks,
+                                      sbk_stream_t stream) {
   if (B == 0 || T == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(qkv && cosines && sines && out, "rope_attention: null operand");
   SBK_REQUIRE(B >= 0 && T >= 0 && H > 0 && Dh > 0 && Dh % 2 == 0, "rope_attention: bad shape");
   SBK_REQUIRE(table_rows >= T, "rope_attention: the sinusoid tables hold %d rows, T = %d", table_rows, T);
   SBK_REQUIRE(sbk::aligned16(qkv) && sbk::aligned16(cosines) && sbk::aligned16(sines),
               "rope_attention: operands must be 16-byte aligned");
-  return sbk::rope_attention(qkv, cosines, sines, key_len, out, attn, B, T, H, Dh, scale, sbk::as_stream(stream));
+  SBK_REQUIRE(chunk_size >= 0, "rope_attention: negative chunk size");
+  return sbk::rope_attention(qkv, cosines, sines, key_len, out, attn, B, T, H, Dh, scale, sbk::as_stream(stream),
+                             chunk_size, left_chunks);
 }
 
 extern "C" int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                                         const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,
-                                        float scale, sbk_stream_t stream) {
+                                        float scale, int chunk_size, int left_chunks, sbk_stream_t stream) {
   if (B == 0 || T == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(qkv && pos && bias_u && bias_v && out, "relpos_attention: null operand");
   SBK_REQUIRE(B >= 0 && T >= 0 && H > 0 && Dh > 0, "relpos_attention: bad shape");
   SBK_REQUIRE(sbk::aligned16(qkv) && sbk::aligned16(pos), "relpos_attention: operands must be 16-byte aligned");
+  SBK_REQUIRE(chunk_size >= 0, "relpos_attention: negative chunk size");
   return sbk::relpos_attention(qkv, pos, bias_u, bias_v, key_len, out, attn, B, T, H, Dh, scale,
-                               sbk::as_stream(stream));
+                               sbk::as_stream(stream), chunk_size, left_chunks);
 }

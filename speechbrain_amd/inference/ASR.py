@@ -45,3 +45,92 @@ class EncoderDecoderASR(Pretrained):
 
     def forward(self, wavs, wav_lens):
         return self.transcribe_batch(wavs, wav_lens)
+
+
+# ---------------------------------------------------------------------------------------------- streaming
+from dataclasses import dataclass  # noqa: E402
+from itertools import chain  # noqa: E402
+from typing import Any, List, Optional  # noqa: E402
+
+
+def split_fixed_chunks(x, chunk_size, dim=-1):
+    """utils/streaming.py split_fixed_chunks: consecutive chunks of `chunk_size` along `dim` (the last may be short)."""
+    n = x.shape[dim]
+    return [x.narrow(dim, t0, min(chunk_size, n - t0)) for t0 in range(0, n, chunk_size)]
+
+
+@dataclass
+class ASRStreamingContext:
+    """inference/ASR.py:948-975: the mutable state of one streaming session."""
+
+    config: Any                              # DynChunkTrainConfig; fixed for the session
+    fea_extractor_context: Any
+    encoder_context: Any
+    decoder_context: Any
+    tokenizer_context: Optional[List[Any]]   # one per batch item, created at the first decode
+
+
+class StreamingASR(Pretrained):
+    """Chunk-by-chunk ASR (inference/ASR.py:978-1363): ``hparams.fea_streaming_extractor`` (a
+    StreamingFeatureWrapper) -> ``mods.enc.forward_streaming`` (Conformer with left-context caches) ->
+    ``mods.proj_enc`` -> ``hparams.decoding_function``.  The decoder of the reference's streaming models is a
+    transducer search, which is a different model family; any callable ``decoding_function(x, decoder_context) ->
+    list[list[int]]`` plugs in (e.g. a greedy CTC decoder over ``proj_enc``'s output)."""
+
+    HPARAMS_NEEDED = ["fea_streaming_extractor", "make_decoder_streaming_context", "decoding_function",
+                      "make_tokenizer_streaming_context", "tokenizer_decode_streaming"]
+    MODULES_NEEDED = ["enc", "proj_enc"]
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.filter_props = self.hparams.fea_streaming_extractor.properties
+
+    def make_streaming_context(self, dynchunktrain_config):
+        return ASRStreamingContext(
+            config=dynchunktrain_config,
+            fea_extractor_context=self.hparams.fea_streaming_extractor.make_streaming_context(),
+            encoder_context=self.mods.enc.make_streaming_context(dynchunktrain_config),
+            decoder_context=self.hparams.make_decoder_streaming_context(), tokenizer_context=None)
+
+    def get_chunk_size_frames(self, dynchunktrain_config) -> int:
+        """Input samples per chunk, as the reference computes it (:1236-1252)."""
+        return (self.filter_props.stride - 1) * dynchunktrain_config.chunk_size
+
+    @torch.no_grad()
+    def encode_chunk(self, context: ASRStreamingContext, chunk, chunk_len=None):
+        if chunk_len is None:
+            chunk_len = torch.ones((chunk.size(0),))
+        chunk, chunk_len = chunk.float().to(self.device), chunk_len.to(self.device)
+        assert chunk.shape[-1] <= self.get_chunk_size_frames(context.config)
+        x = self.hparams.fea_streaming_extractor(chunk, context=context.fea_extractor_context, lengths=chunk_len)
+        x = self.mods.enc.forward_streaming(x, context.encoder_context)
+        return self.mods.proj_enc(x)
+
+    @torch.no_grad()
+    def decode_chunk(self, context: ASRStreamingContext, x):
+        tokens = self.hparams.decoding_function(x, context.decoder_context)
+        if context.tokenizer_context is None:
+            context.tokenizer_context = [self.hparams.make_tokenizer_streaming_context() for _ in range(len(tokens))]
+        words = [self.hparams.tokenizer_decode_streaming(self.hparams.tokenizer, cur, context.tokenizer_context[i])
+                 for i, cur in enumerate(tokens)]
+        return words, tokens
+
+    def transcribe_chunk(self, context: ASRStreamingContext, chunk, chunk_len=None):
+        words, _ = self.decode_chunk(context, self.encode_chunk(context, chunk, chunk_len))
+        return words
+
+    def transcribe_file_streaming(self, path, dynchunktrain_config, use_torchaudio_streaming: bool = True, **kwargs):
+        """Yields the text of every chunk.  The file is read with the built-in wav reader and cut into chunks
+        (the reference's ffmpeg-backed ``torchaudio.io.StreamReader`` is not part of this package; the chunks and
+        therefore the results are the same)."""
+        chunk_size = self.get_chunk_size_frames(dynchunktrain_config)
+        chunks = split_fixed_chunks(self.load_audio(path, **kwargs).unsqueeze(0), chunk_size)
+        rel_length = torch.tensor([1.0])
+        context = self.make_streaming_context(dynchunktrain_config)
+        n_final = self.hparams.fea_streaming_extractor.get_recommended_final_chunk_count(chunk_size)
+        final_chunks = [torch.zeros((1, chunk_size), device=self.device)] * n_final
+        for chunk in chain(chunks, final_chunks):
+            yield self.transcribe_chunk(context, chunk, rel_length)[0]
+
+    def transcribe_file(self, path, dynchunktrain_config, use_torchaudio_streaming: bool = True):
+        return "".join(self.transcribe_file_streaming(path, dynchunktrain_config, use_torchaudio_streaming))

@@ -1,11 +1,13 @@
-"""speechbrain.lobes.models.transformer.Conformer mirror (Conformer.py:75-778), offline path.
+"""speechbrain.lobes.models.transformer.Conformer mirror (Conformer.py:30-848): offline, Dynamic Chunk (masked) and
+streaming (chunk-by-chunk with left-context caches) paths.
 
 ConvolutionModule / ConformerEncoderLayer / ConformerEncoder keep the reference's constructors,
 forward signatures and state_dict keys.  Per layer the work is 17 HIP launches: every LayerNorm
 is one row kernel, every Linear / pointwise conv one MFMA GEMM with bias + activation + (scaled)
 residual fused in the epilogue, attention and GLU+depthwise-conv one fused kernel each.
 """
-from typing import Optional
+from dataclasses import dataclass
+from typing import List, Optional
 
 import torch
 import torch.nn as nn
@@ -14,6 +16,23 @@ from speechbrain_amd import native
 from speechbrain_amd.nnet.activations import Swish
 from speechbrain_amd.nnet.attention import PositionalwiseFeedForward, RelPosMHAXL, RoPEMHA, _act_code
 from speechbrain_amd.nnet.normalization import LayerNorm
+
+
+@dataclass
+class ConformerEncoderLayerStreamingContext:
+    """Conformer.py:30-58: per-layer state carried across chunks."""
+
+    mha_left_context_size: int
+    mha_left_context: Optional[torch.Tensor] = None      # inputs of the MHA for the last <= size frames
+    dcconv_left_context: Optional[torch.Tensor] = None   # inputs of the conv module for the last `padding` frames
+
+
+@dataclass
+class ConformerEncoderStreamingContext:
+    """Conformer.py:61-72."""
+
+    dynchunktrain_config: object
+    layers: List[ConformerEncoderLayerStreamingContext]
 
 
 class ConvolutionModule(nn.Module):
@@ -35,16 +54,18 @@ class ConvolutionModule(nn.Module):
         self.act_code = _act_code(self.after_conv[1])
 
     def forward(self, x, mask: Optional[torch.Tensor] = None, dynchunktrain_config=None, residual=None, key_len=None):
-        """x [B,T,d]; mask [B,T,1] True = padded (reference surface) or key_len int32 [B]."""
-        if dynchunktrain_config is not None:
-            raise NotImplementedError("dynamic chunk convolution (streaming) is outside the offline ASR path")
+        """x [B,T,d]; mask [B,T,1] True = padded (reference surface) or key_len int32 [B].  With
+        ``dynchunktrain_config`` the depthwise conv is the Dynamic Chunk Convolution (Conformer.py:190-313): frames
+        see their past across chunk borders and zeros beyond the end of their own chunk."""
         B, T, d = x.shape
+        chunk_size = int(dynchunktrain_config.chunk_size) if dynchunktrain_config is not None else 0
         if key_len is None and mask is not None:
             key_len = (~mask.reshape(B, T)).sum(-1, dtype=torch.int32)
         h = native.layernorm(x.contiguous(), self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
         pw = self.bottleneck[0]
         h = native.gemm_nt(h, pw.weight.reshape(2 * d, d), pw.bias)
-        h = native.glu_dwconv(h, self.conv.weight.reshape(d, self.kernel_size), self.conv.bias, self.kernel_size)
+        h = native.glu_dwconv(h, self.conv.weight.reshape(d, self.kernel_size), self.conv.bias, self.kernel_size,
+                              chunk_size)
         ln = self.after_conv[0]
         h = native.layernorm(h, ln.weight, ln.bias, ln.eps, act=self.act_code)
         lin = self.after_conv[2]
@@ -85,20 +106,50 @@ class ConformerEncoderLayer(nn.Module):
 
     def forward(self, x, src_mask=None, src_key_padding_mask=None, pos_embs=None, dynchunktrain_config=None,
                 key_len=None):
-        if src_mask is not None or dynchunktrain_config is not None:
-            raise NotImplementedError("src_mask / dynamic chunk training belong to the streaming path")
+        """``src_mask`` is taken to be make_transformer_src_mask(dynchunktrain_config) (TransformerASR.py:47-103): the
+        attention kernel gets the chunk geometry instead of a [T,T] tensor; other masks are not supported."""
+        if src_mask is not None and dynchunktrain_config is None:
+            raise NotImplementedError("src_mask without dynchunktrain_config (causal masks) is a training-time feature")
         if key_len is None and src_key_padding_mask is not None:
             key_len = (~src_key_padding_mask).sum(-1, dtype=torch.int32)
+        chunk = dynchunktrain_config.kernel_args() if dynchunktrain_config is not None else (0, -1)
         x = self._ffn(self.ffn_module1, x.contiguous())
-        h = native.layernorm(x, self.norm1.norm.weight, self.norm1.norm.bias, self.norm1.eps)
-        if self.attention_type == "RoPEMHA":
-            x, attn = self.mha_layer.core(h, key_len, residual=x, want_attn=self.collect_attention)
-        else:
-            x, attn = self.mha_layer.core(h, pos_embs.reshape(-1, x.shape[-1]), key_len, residual=x,
-                                          want_attn=self.collect_attention)
-        x = self.convolution_module(x, residual=x, key_len=key_len)
+        x, attn = self._mha(x, pos_embs, key_len, chunk)
+        x = self.convolution_module(x, residual=x, key_len=key_len, dynchunktrain_config=dynchunktrain_config)
         y = self._ffn(self.ffn_module2, x)
         return native.layernorm(y, self.norm2.norm.weight, self.norm2.norm.bias, self.norm2.eps), attn
+
+    def _mha(self, x, pos_embs, key_len, chunk=(0, -1)):
+        """x + MHA(norm1(x))."""
+        h = native.layernorm(x, self.norm1.norm.weight, self.norm1.norm.bias, self.norm1.eps)
+        if self.attention_type == "RoPEMHA":
+            return self.mha_layer.core(h, key_len, residual=x, want_attn=self.collect_attention, chunk=chunk)
+        return self.mha_layer.core(h, pos_embs.reshape(-1, x.shape[-1]), key_len, residual=x,
+                                   want_attn=self.collect_attention, chunk=chunk)
+
+    def forward_streaming(self, x, context: ConformerEncoderLayerStreamingContext, pos_embs=None):
+        """One chunk through the layer with the left-context caches of ``context`` (Conformer.py:501-586): the MHA
+        runs unmasked over (cached inputs | chunk), the convolution module over (cached inputs | chunk), and the
+        outputs of the cached frames are dropped."""
+        orig_len = x.shape[-2]
+        x = self._ffn(self.ffn_module1, x.contiguous())
+        if context.mha_left_context is not None:
+            x = torch.cat((context.mha_left_context, x), dim=1)
+        if context.mha_left_context_size > 0:
+            context.mha_left_context = x[..., -context.mha_left_context_size:, :]
+        x, attn = self._mha(x.contiguous(), pos_embs, None)
+        x = x[..., -orig_len:, :]
+        if context.dcconv_left_context is not None:
+            x = torch.cat((context.dcconv_left_context, x), dim=1)
+        context.dcconv_left_context = x[..., -self.convolution_module.padding:, :]
+        x = x.contiguous()
+        x = self.convolution_module(x, residual=x)
+        x = x[..., -orig_len:, :].contiguous()
+        y = self._ffn(self.ffn_module2, x)
+        return native.layernorm(y, self.norm2.norm.weight, self.norm2.norm.bias, self.norm2.eps), attn
+
+    def make_streaming_context(self, mha_left_context_size: int):
+        return ConformerEncoderLayerStreamingContext(mha_left_context_size=mha_left_context_size)
 
 
 class ConformerEncoder(nn.Module):
@@ -137,3 +188,20 @@ class ConformerEncoder(nn.Module):
         if hidden is not None:
             return output, attention_lst, hidden
         return output, attention_lst
+
+    def forward_streaming(self, src, context: ConformerEncoderStreamingContext, pos_embs=None):
+        """Conformer.py:780-828."""
+        if self.attention_type == "RelPosMHAXL" and pos_embs is None:
+            raise ValueError("RelPosMHAXL needs positional embeddings")
+        output, attention_lst = src, []
+        for i, layer in enumerate(self.layers):
+            output, attention = layer.forward_streaming(output, pos_embs=pos_embs, context=context.layers[i])
+            attention_lst.append(attention)
+        return self.norm(output), attention_lst
+
+    def make_streaming_context(self, dynchunktrain_config):
+        """Conformer.py:830-848."""
+        return ConformerEncoderStreamingContext(
+            dynchunktrain_config=dynchunktrain_config,
+            layers=[layer.make_streaming_context(mha_left_context_size=dynchunktrain_config.left_context_size_frames())
+                    for layer in self.layers])

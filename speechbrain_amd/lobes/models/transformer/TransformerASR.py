@@ -1,5 +1,7 @@
-"""speechbrain.lobes.models.transformer.TransformerASR mirror (TransformerASR.py:106-675), offline path."""
-from typing import Optional
+"""speechbrain.lobes.models.transformer.TransformerASR mirror (TransformerASR.py:29-726): offline, Dynamic Chunk and
+streaming encoders."""
+from dataclasses import dataclass
+from typing import Any, Optional
 
 import torch
 import torch.nn as nn
@@ -19,18 +21,45 @@ def length_to_mask(length, max_len=None, dtype=None, device=None):
     return torch.as_tensor(mask, dtype=dtype or length.dtype, device=device or length.device)
 
 
+@dataclass
+class TransformerASRStreamingContext:
+    """TransformerASR.py:29-44."""
+
+    dynchunktrain_config: Any
+    encoder_context: Any
+
+
+def make_transformer_src_mask(src, causal: bool = False, dynchunktrain_config=None):
+    """The [T,T] boolean Dynamic Chunk mask (True = masked) of TransformerASR.py:47-103.  The attention kernels take
+    the chunk geometry directly (csrc/relpos_attn.hip key_range); this tensor exists for the reference's call
+    surface and for tests."""
+    if causal:
+        raise NotImplementedError("causal (look-ahead) masks are a training-time feature")
+    if dynchunktrain_config is None:
+        return None
+    T, cs = src.size(1), dynchunktrain_config.chunk_size
+    idx = torch.arange(T, device=src.device)
+    chunk_end = (idx // cs + 1) * cs
+    mask = idx[None] >= chunk_end[:, None]
+    if not dynchunktrain_config.is_infinite_left_context():
+        chunk_lo = chunk_end - cs * (dynchunktrain_config.left_context_size + 1)
+        mask = mask | (idx[None] < chunk_lo[:, None])
+    return mask
+
+
 def make_transformer_src_tgt_masks(src, tgt=None, wav_len=None, pad_idx=0, causal: bool = False,
                                    dynchunktrain_config=None):
-    """TransformerASR.py:106-164 for the offline encoder: only the key-padding mask is non-trivial."""
-    if causal or dynchunktrain_config is not None or tgt is not None:
-        raise NotImplementedError("causal / chunked / teacher-forced masks are outside the inference path")
+    """TransformerASR.py:106-164 for the encoder side: key-padding mask + (optional) Dynamic Chunk mask."""
+    if causal or tgt is not None:
+        raise NotImplementedError("causal / teacher-forced masks are outside the inference path")
     src_key_padding_mask = None
     if wav_len is not None:
         abs_len = torch.round(wav_len * src.shape[1])
         # max_len = T: what the mask is combined with; equal to the reference's abs_len.max() whenever the
         # longest item fills the batch (batch_pad_right), and it keeps the encoder free of a host sync
         src_key_padding_mask = ~length_to_mask(abs_len, max_len=src.shape[1]).bool()
-    return src_key_padding_mask, None, None, None
+    src_mask = make_transformer_src_mask(src, causal=causal, dynchunktrain_config=dynchunktrain_config)
+    return src_key_padding_mask, None, src_mask, None
 
 
 class TransformerASR(TransformerInterface):
@@ -73,19 +102,18 @@ class TransformerASR(TransformerInterface):
                 torch.nn.init.xavier_normal_(p)
 
     def encode(self, src, wav_len=None, pad_idx=0, dynchunktrain_config=None):
-        """[B,T',F',C] or [B,T',F] -> [B,T',d] (TransformerASR.py:475-544)."""
-        if dynchunktrain_config is not None:
-            raise NotImplementedError("dynamic chunk training / streaming is outside the offline path")
+        """[B,T',F',C] or [B,T',F] -> [B,T',d] (TransformerASR.py:475-544).  ``dynchunktrain_config``: chunked
+        attention + Dynamic Chunk Convolution (what a streaming-capable model is trained and evaluated with)."""
         if src.dim() == 4:
             bz, t, ch1, ch2 = src.shape
             src = src.reshape(bz, t, ch1 * ch2)
-        src_key_padding_mask, _, src_mask, _ = make_transformer_src_tgt_masks(src, None, wav_len, pad_idx=pad_idx,
-                                                                               causal=self.causal)
+        src_key_padding_mask, _, src_mask, _ = make_transformer_src_tgt_masks(
+            src, None, wav_len, pad_idx=pad_idx, causal=self.causal, dynchunktrain_config=dynchunktrain_config)
         src = self.custom_src_module(src)
         # RoPEMHA rotates q/k inside the attention kernel; RelPosMHAXL takes the sinusoid table (:519-528)
         pos_embs_source = None if self.attention_type == "RoPEMHA" else self.positional_encoding(src)
         outputs = self.encoder(src=src, src_mask=src_mask, src_key_padding_mask=src_key_padding_mask,
-                               pos_embs=pos_embs_source)
+                               pos_embs=pos_embs_source, dynchunktrain_config=dynchunktrain_config)
         if self.output_hidden_states:
             encoder_out, _, hidden_states = outputs
             return encoder_out, hidden_states
@@ -96,6 +124,30 @@ class TransformerASR(TransformerInterface):
         if tgt is not None:
             raise NotImplementedError("teacher-forced forward (training) is outside the inference path")
         return self.encode(src, wav_len, pad_idx)
+
+    def encode_streaming(self, src, context: TransformerASRStreamingContext):
+        """One chunk [B,chunk,F(,C)] -> [B,chunk,d] (TransformerASR.py:546-640); ``context`` is mutated."""
+        if src.dim() == 4:
+            bz, t, ch1, ch2 = src.shape
+            src = src.reshape(bz, t, ch1 * ch2)
+        # the relative-position table must span the cached left context as well (:611-622)
+        known_left_context = context.encoder_context.layers[0].mha_left_context
+        n_pos = src.shape[-2] + (0 if known_left_context is None else known_left_context.shape[-2])
+        src = self.custom_src_module(src)
+        pos_embs_source = None
+        if self.attention_type == "RelPosMHAXL":
+            pos_embs_source = self.positional_encoding.make_pe(n_pos)
+        elif self.attention_type != "RoPEMHA":
+            raise NotImplementedError("streaming: RelPosMHAXL and RoPEMHA encoders are implemented")
+        encoder_out, _ = self.encoder.forward_streaming(src=src, pos_embs=pos_embs_source,
+                                                        context=context.encoder_context)
+        return encoder_out
+
+    def make_streaming_context(self, dynchunktrain_config, encoder_kwargs={}):
+        """TransformerASR.py:642-670."""
+        return TransformerASRStreamingContext(
+            dynchunktrain_config=dynchunktrain_config,
+            encoder_context=self.encoder.make_streaming_context(dynchunktrain_config, **encoder_kwargs))
 
 
 class EncoderWrapper(nn.Module):
@@ -111,7 +163,9 @@ class EncoderWrapper(nn.Module):
         return self.transformer.encode(x, wav_lens, pad_idx, **kwargs)
 
     def forward_streaming(self, x, context):
-        raise NotImplementedError("streaming (dynamic chunk) encoding is outside the offline path")
+        """TransformerASR.py:716-720."""
+        return self.transformer.encode_streaming(x, context)
 
     def make_streaming_context(self, *args, **kwargs):
-        raise NotImplementedError("streaming (dynamic chunk) encoding is outside the offline path")
+        """TransformerASR.py:722-726."""
+        return self.transformer.make_streaming_context(*args, **kwargs)

@@ -83,9 +83,9 @@ def _declare(lib):
         "sbk_gemm_ln_nt_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, f, i, f, p], c_int),
         "sbk_gemm_nt_splitk_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, ctypes.c_size_t, p], c_int),
         "sbk_conv_block_f32": ([p, p, p, p, p, p, i, i, i, i, i, f, f, p], c_int),
-        "sbk_relpos_attention_f32": ([p, p, p, p, p, p, p, i, i, i, i, f, p], c_int),
-        "sbk_rope_attention_f32": ([p, p, p, p, p, p, i, i, i, i, i, f, p], c_int),
-        "sbk_glu_dwconv_f32": ([p, p, p, p, i, i, i, i, p], c_int),
+        "sbk_relpos_attention_f32": ([p, p, p, p, p, p, p, i, i, i, i, f, i, i, p], c_int),
+        "sbk_rope_attention_f32": ([p, p, p, p, p, p, i, i, i, i, i, f, i, i, p], c_int),
+        "sbk_glu_dwconv_f32": ([p, p, p, p, i, i, i, i, i, p], c_int),
         "sbk_layernorm_f32": ([p, p, p, p, i, i, f, i, p], c_int),
         "sbk_log_softmax_f32": ([p, p, i, i, f, f, p], c_int),
         "sbk_beam_search_workspace_bytes": ([POINTER(DecoderWeights), POINTER(SearchConfig), i, i], ctypes.c_size_t),
@@ -318,8 +318,9 @@ def conv_block(x, wt, bias, gamma, beta, cout, eps=1e-5, slope=0.01):
     return y
 
 
-def relpos_attention(qkv, pos, bias_u, bias_v, key_len, H, scale, want_attn=False):
-    """qkv [B,T,3*d] (per-head interleaved), pos [2T-1,d] -> context [B,T,d] (+ weights [B,H,T,T])."""
+def relpos_attention(qkv, pos, bias_u, bias_v, key_len, H, scale, want_attn=False, chunk_size=0, left_chunks=-1):
+    """qkv [B,T,3*d] (per-head interleaved), pos [2T-1,d] -> context [B,T,d] (+ weights [B,H,T,T]).
+    ``chunk_size`` > 0: Dynamic Chunk mask (``left_chunks`` < 0 = unlimited left context)."""
     lib = load()
     _dev_ok(qkv, pos, bias_u, bias_v, key_len)
     _f32(qkv)
@@ -328,11 +329,12 @@ def relpos_attention(qkv, pos, bias_u, bias_v, key_len, H, scale, want_attn=Fals
     out = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
     attn = torch.empty(B, H, T, T, dtype=torch.float32, device=qkv.device) if want_attn else None
     _chk(lib.sbk_relpos_attention_f32(_p(qkv), _p(pos), _p(bias_u), _p(bias_v), _p(key_len), _p(out), _p(attn), B, T,
-                                      H, d // H, float(scale), _stream(qkv)), "sbk_relpos_attention_f32")
+                                      H, d // H, float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
+         "sbk_relpos_attention_f32")
     return out, attn
 
 
-def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False):
+def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False, chunk_size=0, left_chunks=-1):
     """qkv [B,T,3*d] (per-head interleaved), cosines / sines [rows >= T, Dh] -> context [B,T,d]."""
     lib = load()
     _dev_ok(qkv, cosines, sines, key_len)
@@ -342,18 +344,19 @@ def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False):
     out = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
     attn = torch.empty(B, H, T, T, dtype=torch.float32, device=qkv.device) if want_attn else None
     _chk(lib.sbk_rope_attention_f32(_p(qkv), _p(cosines), _p(sines), _p(key_len), _p(out), _p(attn), B, T, H, d // H,
-                                    cosines.shape[0], float(scale), _stream(qkv)), "sbk_rope_attention_f32")
+                                    cosines.shape[0], float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
+         "sbk_rope_attention_f32")
     return out, attn
 
 
-def glu_dwconv(h, w, bias, ksize):
-    """h [B,T,2d] -> depthwise_conv(GLU(h)) [B,T,d]; w [d,ksize]."""
+def glu_dwconv(h, w, bias, ksize, chunk_size=0):
+    """h [B,T,2d] -> depthwise_conv(GLU(h)) [B,T,d]; w [d,ksize]; ``chunk_size`` > 0: Dynamic Chunk Convolution."""
     lib = load()
     _dev_ok(h, w, bias)
     _f32(h)
     B, T, d2 = h.shape
     y = torch.empty(B, T, d2 // 2, dtype=torch.float32, device=h.device)
-    _chk(lib.sbk_glu_dwconv_f32(_p(h), _p(w), _p(bias), _p(y), B, T, d2 // 2, int(ksize), _stream(h)),
+    _chk(lib.sbk_glu_dwconv_f32(_p(h), _p(w), _p(bias), _p(y), B, T, d2 // 2, int(ksize), int(chunk_size), _stream(h)),
          "sbk_glu_dwconv_f32")
     return y
 

@@ -68,6 +68,15 @@ class STFT(torch.nn.Module):
                              persistent=False)
         self.radices = factor_radices(n_fft)
 
+    def get_filter_properties(self):
+        """processing/features.py:190-199."""
+        from speechbrain_amd.utils.filter_analysis import FilterProperties
+
+        if not self.center:
+            raise ValueError("ValueProperties cannot model a non-centered STFT, as it assumes either centering or "
+                             "causality")
+        return FilterProperties(window_size=self.win_length, stride=self.hop_length)
+
     def forward(self, x):
         if x.dim() != 2:
             raise NotImplementedError("multi-channel input is not on the ASR path")

@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of batches in flight x hardware queues (GPU_MAX_HW_QUEUES) on the bench; CASES = lines of "ENV|ARGS"
+# A/B of workers x group (and env settings) on the bench; CASES = lines of "ENV|ARGS"
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
-show='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["config"].get("batch"), d["config"].get("batches_in_flight_per_gpu"))'
+show='import sys,json; d=json.loads(sys.stdin.read()); c=d["config"]; print(d["value"], d["ms_per_step"], c.get("max_batch"), c.get("workers_per_gpu"), c.get("batches_per_grouped_search"))'
 while IFS='|' read -r envs line; do
   [ -z "$line" ] && continue
   echo "== env[$envs] bench $line"
-  env $envs timeout 600 python bench.py --warmup 1 --no-cpu-baseline --no-roofline --latency-runs 0 $line 2>&1 | grep '^{' | tee -a gpurun_out/streams_ab.jsonl | python -c "$show"
+  env $envs timeout 600 python bench.py --warmup 1 --no-cpu-baseline --no-roofline --no-extras --latency-runs 0 $line 2> gpurun_out/ab_last.err | grep '^{' | tee -a gpurun_out/streams_ab.jsonl | python -c "$show" || tail -5 gpurun_out/ab_last.err
 done <<< "$CASES"
