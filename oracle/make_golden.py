@@ -582,6 +582,17 @@ def golden_pretrained():
         with torch.no_grad():
             file_words[name] = asr.transcribe_file(path)
         print("  transcribe_file", name, "->", repr(file_words[name][:50]))
+    # BASELINE.json configs[0]: the reference's OWN sample wav (tests/samples/ASR/spk1_snt1.wav, 2.87 s, 16 kHz PCM16)
+    # through transcribe_file.  The GPU box has no /root/reference, so the audio travels as a fixture next to what
+    # the reference transcribes from it.
+    import shutil
+
+    ref_wav = os.path.join(REF, "tests", "samples", "ASR", "spk1_snt1.wav")
+    shutil.copyfile(ref_wav, os.path.join(OUT, "ref_spk1_snt1.wav"))
+    os.chmod(os.path.join(OUT, "ref_spk1_snt1.wav"), 0o644)
+    with torch.no_grad():
+        file_words["ref_spk1_snt1.wav"] = asr.transcribe_file(os.path.join(OUT, "ref_spk1_snt1.wav"))
+    print("  transcribe_file ref_spk1_snt1.wav ->", repr(file_words["ref_spk1_snt1.wav"][:60]))
     np.savez_compressed(os.path.join(OUT, "pretrained_tiny_expected.npz"), wav=wav.numpy(), lens=lens.numpy(),
                         enc_out=enc_ref.numpy(), file_names=np.array(list(file_words)),
                         file_words=np.array(list(file_words.values())),

@@ -53,16 +53,25 @@ def read_wav(path):
 
 
 class AudioNormalizer:
-    """dataio/preprocess.py:8-84 for the already-16-kHz case: channel mean; resampling is identity when
-    the rates agree (augment/time_domain.py:576-577) and unsupported otherwise."""
+    """dataio/preprocess.py:8-84: resample to the model's rate (identity when the rates agree,
+    augment/time_domain.py:576-577; otherwise the windowed-sinc resampler of ``augment.time_domain.Resample``, one
+    cached per source rate like the reference's ``_cached_resample``) and average the channels."""
 
     def __init__(self, sample_rate=16000, mix="avg-to-mono"):
+        if mix not in ("avg-to-mono", "keep"):
+            raise ValueError(f"Unexpected mixing configuration {mix}")
         self.sample_rate, self.mix = sample_rate, mix
+        self._resamplers = {}
 
     def __call__(self, audio, sample_rate):
+        """audio [time] or [time, channels] -> [time] (mono) at ``self.sample_rate``."""
         if sample_rate != self.sample_rate:
-            raise NotImplementedError(f"resampling {sample_rate} -> {self.sample_rate} Hz is not implemented")
-        if audio.dim() == 2:
+            from speechbrain_amd.augment.time_domain import Resample
+
+            if sample_rate not in self._resamplers:
+                self._resamplers[sample_rate] = Resample(sample_rate, self.sample_rate)
+            audio = self._resamplers[sample_rate](audio.unsqueeze(0)).squeeze(0)
+        if audio.dim() == 2 and self.mix == "avg-to-mono":
             audio = audio.mean(dim=1)
         return audio
 
