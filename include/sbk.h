@@ -83,6 +83,17 @@ int sbk_fbank_f32(const float* wav, const float* window, const float* twiddle, c
                   float* tile_max, int B, int N, int n_fft, int hop, int n_mels, int nnz, float amin, float top_db,
                   const float* norm_mean, const float* norm_std, float norm_eps, sbk_stream_t stream);
 
+/* ---- SURVEY 8f / BASELINE.json configs[4]: the log-mel front-end of WhisperASR, integrations/huggingface/whisper.py
+ * :276-316 (`log_mel_spectrogram`, adapted there from openai/whisper audio.py): torch.stft(audio, n_fft = 400, hop = 160,
+ * hann_window, centre + REFLECT padding) -> last frame dropped -> power -> mel filters (the HF feature extractor's
+ * slaney filters, CSR as for sbk_fbank_f32) -> log10(max(., 1e-10)) -> max(., max over the WHOLE BATCH - 8) -> (. + 4)/4.
+ *   wav [B,N] (pad_or_trim'ed to 480000 by the caller) -> out [B, n_mels, N/hop] (mel-major, the encoder Conv1d's layout)
+ *   tmp [B, N/hop, n_mels] and tile_max [B * ceil(N/hop/4)]: workspaces. */
+int sbk_whisper_log_mel_f32(const float* wav, const float* window, const float* twiddle, const int32_t* radices,
+                            int n_radix, const float* mel_w, const int32_t* mel_ptr, const int32_t* mel_bin, float* tmp,
+                            float* tile_max, float* out, int B, int N, int n_fft, int hop, int n_mels, int nnz,
+                            sbk_stream_t stream);
+
 /* a2: STFT.forward (processing/features.py:141-188): [B,N] -> spec [B,T,n_fft/2+1,2] (re, im);
  * window / twiddle / radices as for sbk_fbank_f32. */
 int sbk_stft_f32(const float* wav, const float* window, const float* twiddle, const int32_t* radices, int n_radix,

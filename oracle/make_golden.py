@@ -744,6 +744,35 @@ def golden_streaming():
     np.savez_compressed(os.path.join(OUT, "streaming.npz"), **out)
 
 
+def golden_whisper():
+    """The log-mel front-end of the reference's Whisper wrapper (integrations/huggingface/whisper.py:276-350), run
+    as the reference code itself: the class needs a HuggingFace download to construct, so the two methods are
+    called on a bare object carrying the attributes they read (_n_fft, _hop_length, _mel_filters)."""
+    print("== Whisper log-mel")
+    import types
+
+    from speechbrain.integrations.huggingface.whisper import Whisper
+    from transformers import WhisperFeatureExtractor
+
+    g = torch.Generator().manual_seed(31)
+    n_samples = 32000  # 2 s "chunks" keep the fixture small; the arithmetic does not depend on the length
+    wav = torch.stack([0.3 * torch.randn(24000, generator=g), 0.01 * torch.randn(24000, generator=g)])
+    wav[1, 20000:] = 0
+    out = {"wav": wav.numpy(), "n_samples": np.array(n_samples)}
+    for n_mels in (80, 128):
+        fe = WhisperFeatureExtractor(feature_size=n_mels)
+        filters = torch.as_tensor(fe.mel_filters, dtype=torch.float32)
+        if filters.shape[0] != n_mels:
+            filters = filters.T
+        obj = types.SimpleNamespace(_n_fft=fe.n_fft, _hop_length=fe.hop_length, _mel_filters=filters)
+        padded = Whisper.pad_or_trim(obj, wav, length=n_samples)
+        mel = Whisper.log_mel_spectrogram(obj, padded)
+        print(f"  n_mels {n_mels}: {tuple(mel.shape)}, range [{float(mel.min()):.3f}, {float(mel.max()):.3f}]")
+        out[f"mel{n_mels}"] = mel.numpy()
+        out[f"filters{n_mels}"] = filters.numpy()
+    np.savez_compressed(os.path.join(OUT, "whisper_logmel.npz"), **out)
+
+
 def golden_wer():
     """ErrorRateStats (utils/metric_stats.py:206, utils/edit_distance.py) on random token sequences with random
     edits: per-utterance insertions / deletions / substitutions, the alignment op strings and the summary of the
@@ -786,6 +815,9 @@ if __name__ == "__main__":
     if "--wer-only" in sys.argv:
         golden_wer()
         sys.exit(0)
+    if "--whisper-only" in sys.argv:
+        golden_whisper()
+        sys.exit(0)
     if "--streaming-only" in sys.argv:
         golden_streaming()
         sys.exit(0)
@@ -822,4 +854,5 @@ if __name__ == "__main__":
     golden_init_fingerprint()
     golden_wer()
     golden_streaming()
+    golden_whisper()
     print("OK")

@@ -36,6 +36,8 @@ struct FbankArgs {
   int B, N, T, n_fft, hop, n_mels, nnz, ntiles;
   float amin;
   float* spec;  // optional [B,T,n_fft/2+1,2] complex STFT output (STFT.forward); when set, the mel stage is skipped
+  int reflect;     // 1: torch.stft's default reflect padding of the centred frames (Whisper); 0: zero padding (Fbank)
+  float log_mult;  // 10 (dB, Fbank) or 1 (plain log10, Whisper)
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -64,7 +66,11 @@ __global__ void __launch_bounds__(256) fbank_frames_kernel(FbankArgs a, Radices 
     const float* w = a.wav + (size_t)b * a.N;
     const long base = (long)t * a.hop - n_fft / 2;
     for (int n = lane; n < n_fft; n += 64) {
-      const long idx = base + n;
+      long idx = base + n;
+      if (a.reflect) {  // mirror without repeating the edge sample: x[-k] = x[k], x[N-1+k] = x[N-1-k]
+        if (idx < 0) idx = -idx;
+        if (idx >= a.N) idx = 2 * ((long)a.N - 1) - idx;
+      }
       const float x = (t < a.T && idx >= 0 && idx < a.N) ? w[idx] : 0.0f;
       cur[n] = make_float2(x * a.window[n], 0.0f);
     }
@@ -116,7 +122,7 @@ __global__ void __launch_bounds__(256) fbank_frames_kernel(FbankArgs a, Radices 
     float acc = 0.0f;
     for (int i = p0; i < p1; ++i) acc = fmaf(mypw[f0 + (i - p0)], melw[i], acc);
     // log10 in f64: correctly rounded to f32 (silence must give exactly 10*log10(amin) like the reference)
-    const float db = 10.0f * (float)log10((double)fmaxf(acc, a.amin));
+    const float db = a.log_mult * (float)log10((double)fmaxf(acc, a.amin));
     if (t < a.T) {
       a.out[((size_t)b * a.T + t) * a.n_mels + m] = db;
       mx = fmaxf(mx, db);
@@ -151,6 +157,35 @@ __global__ void __launch_bounds__(256) fbank_floor_norm_kernel(float* __restrict
   }
 }
 
+
+// Whisper's dynamic-range step (integrations/huggingface/whisper.py:312-314, openai/whisper audio.py): floor at
+// (max over the WHOLE BATCH - 8), then (x + 4) / 4; written mel-major [B, n_mels, T] as the encoder's Conv1d reads it.
+// x [B,T,M] is the frames kernel's output, tile_max its [B*ntiles] per-tile maxima.
+__global__ void __launch_bounds__(256) whisper_floor_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ tile_max, int n_tile_max,
+                                                            float* __restrict__ out, int T, int M) {
+  __shared__ float red[4];
+  __shared__ float tile[32][33];
+  const int tid = threadIdx.x;
+  float mx = -INFINITY;
+  for (int i = tid; i < n_tile_max; i += 256) mx = fmaxf(mx, tile_max[i]);
+  mx = sbk::wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  const float floor_v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - 8.0f;
+  // 32 x 32 (frame, mel) tile transposed through LDS: coalesced reads along mel, coalesced writes along time
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int c = tid & 31, r0 = tid >> 5;
+  for (int r = r0; r < 32; r += 8) {
+    const int t = t0 + r, m = m0 + c;
+    tile[r][c] = (t < T && m < M) ? x[((size_t)b * T + t) * M + m] : 0.0f;
+  }
+  __syncthreads();
+  for (int r = r0; r < 32; r += 8) {
+    const int m = m0 + r, t = t0 + c;
+    if (m < M && t < T) out[((size_t)b * M + m) * T + t] = (fmaxf(tile[c][r], floor_v) + 4.0f) / 4.0f;
+  }
+}
 }  // namespace
 
 extern "C" int sbk_fbank_f32(const float* wav, const float* window, const float* twiddle, const int32_t* radices,
@@ -180,7 +215,8 @@ extern "C" int sbk_fbank_f32(const float* wav, const float* window, const float*
   const int n_stft = n_fft / 2 + 1;
   const size_t lds = (size_t)n_fft * 8 + (size_t)4 * 2 * n_fft * 8 + (size_t)4 * n_stft * 4 + (size_t)nnz * 4 + 16;
   SBK_REQUIRE(lds <= 160 * 1024, "fbank: n_fft=%d needs %zu B of LDS", n_fft, lds);
-  FbankArgs a{wav, window, twiddle, mel_w, mel_ptr, mel_bin, out, tile_max, B, N, T, n_fft, hop, n_mels, nnz, ntiles, amin, nullptr};
+  FbankArgs a{wav, window, twiddle, mel_w, mel_ptr, mel_bin, out, tile_max, B, N, T, n_fft, hop, n_mels, nnz, ntiles, amin, nullptr,
+              0, 10.0f};
   hipStream_t st = sbk::as_stream(stream);
   sbk::ProfScope prof("fbank", 5.0 * n_fft * 9.0 * B * T, 4.0 * ((double)B * N + 3.0 * B * T * n_mels), st);
   SBK_LAUNCH(fbank_frames_kernel, dim3(ntiles, B), dim3(256), lds, st, a, rad);
@@ -314,4 +350,46 @@ extern "C" int sbk_amplitude_to_db_f32(float* x, float* tile_max, int B, long pe
   SBK_LAUNCH(fbank_floor_norm_kernel, dim3(gx, B), dim3(256), 0, st, x, (const float*)tile_max, nt, per_utt, 1, top_db,
              (const float*)nullptr, (const float*)nullptr, 0.0f);
   return sbk::launch_status("sbk_amplitude_to_db_f32/floor");
+}
+
+
+// Whisper log-mel front-end (integrations/huggingface/whisper.py:276-316 `log_mel_spectrogram`):
+//   torch.stft(audio, n_fft, hop, hann_window(n_fft), center=True, reflect padding) -> drop the last frame ->
+//   |.|^2 -> mel filters -> log10(max(., 1e-10)) -> max(., batch max - 8) -> (. + 4) / 4       [B, n_mels, N/hop]
+// window / twiddle / radices / CSR mel filters as for sbk_fbank_f32; tmp [B,T,n_mels] and tile_max [B*ceil(T/4)]
+// are workspaces.
+extern "C" int sbk_whisper_log_mel_f32(const float* wav, const float* window, const float* twiddle,
+                                       const int32_t* radices, int n_radix, const float* mel_w, const int32_t* mel_ptr,
+                                       const int32_t* mel_bin, float* tmp, float* tile_max, float* out, int B, int N,
+                                       int n_fft, int hop, int n_mels, int nnz, sbk_stream_t stream) {
+  if (B == 0) return 0;
+  SBK_REQUIRE(wav && window && twiddle && radices && mel_w && mel_ptr && mel_bin && tmp && tile_max && out,
+              "whisper_log_mel: null operand");
+  SBK_REQUIRE(N >= n_fft / 2 + 1 && n_fft >= 2 && hop > 0 && n_mels > 0 && nnz >= 0 && N / hop >= 1,
+              "whisper_log_mel: bad shape (reflect padding needs N > n_fft/2)");
+  SBK_REQUIRE(n_radix > 0 && n_radix <= kMaxRadix, "whisper_log_mel: %d FFT passes", n_radix);
+  Radices rad;
+  rad.n = n_radix;
+  long prod = 1;
+  for (int i = 0; i < n_radix; ++i) {
+    rad.r[i] = radices[i];
+    SBK_REQUIRE(radices[i] >= 2 && radices[i] <= 5, "whisper_log_mel: radix %d unsupported", radices[i]);
+    prod *= radices[i];
+  }
+  SBK_REQUIRE(prod == n_fft, "whisper_log_mel: radices do not multiply to n_fft=%d", n_fft);
+  const int T = N / hop;  // 1 + N/hop centred frames, minus the last one (stft[..., :-1])
+  const int ntiles = sbk::cdiv(T, 4);
+  const int n_stft = n_fft / 2 + 1;
+  const size_t lds = (size_t)n_fft * 8 + (size_t)4 * 2 * n_fft * 8 + (size_t)4 * n_stft * 4 + (size_t)nnz * 4 + 16;
+  SBK_REQUIRE(lds <= 160 * 1024, "whisper_log_mel: n_fft=%d needs %zu B of LDS", n_fft, lds);
+  FbankArgs a{wav, window, twiddle, mel_w, mel_ptr, mel_bin, tmp, tile_max, B, N, T, n_fft, hop, n_mels, nnz, ntiles, 1e-10f,
+              nullptr, 1, 1.0f};
+  hipStream_t st = sbk::as_stream(stream);
+  sbk::ProfScope prof("whisper_log_mel", 5.0 * n_fft * 9.0 * B * T, 4.0 * ((double)B * N + 3.0 * B * T * n_mels), st);
+  SBK_LAUNCH(fbank_frames_kernel, dim3(ntiles, B), dim3(256), lds, st, a, rad);
+  int rc = sbk::launch_status("sbk_whisper_log_mel_f32/frames");
+  if (rc) return rc;
+  SBK_LAUNCH(whisper_floor_kernel, dim3(sbk::cdiv(T, 32), sbk::cdiv(n_mels, 32), B), dim3(256), 0, st, (const float*)tmp,
+             (const float*)tile_max, B * ntiles, out, T, n_mels);
+  return sbk::launch_status("sbk_whisper_log_mel_f32/floor");
 }

@@ -75,6 +75,7 @@ def _declare(lib):
         "sbk_prof_gemm_repeat_f32": ([p, p, p, i, i, i, p, ctypes.c_size_t, i, POINTER(c_float), p], c_int),
         "sbk_pcm16_to_f32": ([p, p, ctypes.c_long, i, p], c_int),
         "sbk_fbank_f32": ([p, p, p, POINTER(c_int32), i, p, p, p, p, p, i, i, i, i, i, i, f, f, p, p, f, p], c_int),
+        "sbk_whisper_log_mel_f32": ([p, p, p, POINTER(c_int32), i, p, p, p, p, p, p, i, i, i, i, i, i, p], c_int),
         "sbk_stft_f32": ([p, p, p, POINTER(c_int32), i, p, i, i, i, i, p], c_int),
         "sbk_spectral_magnitude_f32": ([p, p, ctypes.c_long, f, i, f, p], c_int),
         "sbk_amplitude_to_db_f32": ([p, p, i, ctypes.c_long, f, f, f, f, p], c_int),
@@ -266,6 +267,23 @@ def fbank(wav, window, twiddle, radices, mel_w, mel_ptr, mel_bin, n_fft, hop, n_
     _chk(lib.sbk_fbank_f32(_p(wav), _p(window), _p(twiddle), rad, len(radices), _p(mel_w), _p(mel_ptr), _p(mel_bin),
                            _p(out), _p(tile_max), B, N, n_fft, hop, n_mels, mel_w.numel(), float(amin), float(top_db),
                            _p(norm_mean), _p(norm_std), float(norm_eps), _stream(wav)), "sbk_fbank_f32")
+    return out
+
+
+def whisper_log_mel(wav, window, twiddle, radices, mel_w, mel_ptr, mel_bin, n_fft, hop, n_mels):
+    """[B,N] waveforms -> Whisper log-mel [B, n_mels, N // hop] (see include/sbk.h)."""
+    lib = load()
+    _dev_ok(wav, window, twiddle, mel_w, mel_ptr, mel_bin)
+    _f32(wav)
+    B, N = wav.shape
+    T = N // hop
+    tmp = torch.empty(B, T, n_mels, dtype=torch.float32, device=wav.device)
+    tile_max = torch.empty(B * ((T + 3) // 4), dtype=torch.float32, device=wav.device)
+    out = torch.empty(B, n_mels, T, dtype=torch.float32, device=wav.device)
+    rad = (c_int32 * len(radices))(*radices)
+    _chk(lib.sbk_whisper_log_mel_f32(_p(wav), _p(window), _p(twiddle), rad, len(radices), _p(mel_w), _p(mel_ptr),
+                                     _p(mel_bin), _p(tmp), _p(tile_max), _p(out), B, N, n_fft, hop, n_mels,
+                                     mel_w.numel(), _stream(wav)), "sbk_whisper_log_mel_f32")
     return out
 
 

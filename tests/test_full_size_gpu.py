@@ -285,3 +285,42 @@ def test_batches_in_flight_match_sequential_conformer_l():
     ct = ConcurrentTranscriber(asr, streams=6)
     assert ct.transcribe_batches(batches, prepare=fix_len) == ref
     assert ct.transcribe_batches(batches, prepare=fix_len) == ref
+
+
+def test_conformer_l_unscaled_weights_token_equality_where_margin_allows():
+    """UNSCALED random-init Conformer-L (flat posteriors).  The HIP greedy search picks
+    a token per step; the oracle, teacher-forced on the same prefix, gives the full-prefix log-probs.  Wherever the
+    oracle's own top-1 / top-2 margin exceeds the measured log-prob error, the HIP token MUST be the oracle's
+    arg-max (a near-tie may legitimately fall either way); the log-prob of the picked token must agree within 1e-4."""
+    from speechbrain_amd.inference.builders import flat_state_dict
+
+    asr = _asr("L", greedy=True)
+    fc, mc = _oracle_cfg("L")
+    n = 4 * 16000
+    wav = 0.1 * torch.randn(2, n, generator=torch.Generator().manual_seed(21))
+    lens = torch.tensor([1.0, 0.8])
+    wav[1, int(0.8 * n):] = 0
+    sd = flat_state_dict(asr)
+    enc_ref = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
+    T = enc_ref.shape[1]
+    steps = 14
+    asr.mods.decoder.max_decode_ratio = (steps + 0.5) / T
+    hyps, _, scores, _ = asr.mods.decoder(enc_ref.cuda(), lens.cuda())
+    enc_lens = torch.round(T * lens).int()
+    checked = skipped = 0
+    worst = 0.0
+    for b, hyp in enumerate(hyps):
+        prefix = torch.tensor([[1] + hyp[:-1]]) if len(hyp) > 1 else torch.tensor([[1]])
+        dec = O.decode(prefix, enc_ref[b: b + 1], enc_lens[b: b + 1], sd, mc, "Transformer.")
+        lp = torch.log_softmax(torch.nn.functional.linear(dec, sd["seq_lin.w.weight"], sd["seq_lin.w.bias"]), -1)[0]
+        for t, tok in enumerate(hyp[: lp.shape[0]]):
+            top2 = lp[t].topk(2).values
+            err = abs(float(scores[b, 0, t]) - float(lp[t, tok]))
+            worst = max(worst, err)
+            if float(top2[0] - top2[1]) > 5e-4:  # comfortably above the measured error (asserted below)
+                assert tok == int(lp[t].argmax()), (b, t, tok, int(lp[t].argmax()))
+                checked += 1
+            else:
+                skipped += 1
+    assert worst <= 1e-4, worst
+    assert checked >= 10, (checked, skipped)  # the margin rule must not make the test vacuous

@@ -274,3 +274,27 @@ def test_pcm16_to_f32(backend, frames, channels):
         ref = torch.mean(x.float() / 32768.0, dim=1)
         assert out.shape == (frames,)
         assert torch.equal(out.cpu(), ref)
+
+
+def test_documented_capacity_limits_are_reported(backend):
+    """include/sbk.h: the attention-weights (strip) kernel keeps a [32][T] score strip in LDS -- beyond the 160 KiB
+    window the call must fail with SBK_EINVAL and a message, not crash or compute garbage; the strip-free kernel
+    (no weights requested) has no such limit."""
+    nat, dev = backend
+    g = torch.Generator().manual_seed(1)
+    B, T, H, Dh = 1, 1400, 1, 8
+    d = H * Dh
+    qkv = torch.randn(B, T, 3 * d, generator=g).to(dev)
+    pos = torch.randn(2 * T - 1, d, generator=g).to(dev)
+    u = torch.zeros(d).to(dev)
+    with pytest.raises(nat.SbkError, match="LDS"):
+        nat.relpos_attention(qkv, pos, u, u, None, H, 0.3, want_attn=True)
+    ctx, attn = nat.relpos_attention(qkv[:, :96].contiguous(), pos[T - 96: T + 95].contiguous(), u, u, None, H, 0.3,
+                                     want_attn=True)
+    assert attn.shape == (1, 1, 96, 96) and bool(torch.isfinite(ctx).all())
+    # unsupported head size / kernel size: reported, with the instantiated values named
+    with pytest.raises(nat.SbkError, match="head_dim"):
+        nat.relpos_attention(torch.zeros(1, 4, 3 * 24).to(dev), torch.zeros(7, 24).to(dev), torch.zeros(24).to(dev),
+                             torch.zeros(24).to(dev), None, 1, 0.3)
+    with pytest.raises(nat.SbkError, match="kernel size"):
+        nat.glu_dwconv(torch.zeros(1, 8, 16).to(dev), torch.zeros(8, 9).to(dev), torch.zeros(8).to(dev), 9)

@@ -1,0 +1,62 @@
+"""WhisperASR front-end (SURVEY 8f / BASELINE.json configs[4]): pad_or_trim + log_mel_spectrogram of
+integrations/huggingface/whisper.py:276-350 on the HIP kernel, against (a) the reference's own function run here
+(tests/golden/whisper_logmel.npz, oracle/make_golden.py --whisper-only) and (b) a plain torch fp32 restatement on
+fresh inputs.  The reference has no unit test for Whisper: parity is pinned by running the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "whisper_logmel.npz")
+
+
+def torch_log_mel(audio, filters, n_fft=400, hop=160):
+    stft = torch.stft(audio, n_fft, hop, window=torch.hann_window(n_fft), return_complex=True)
+    mel = filters @ (stft[..., :-1].abs() ** 2)
+    log_spec = torch.clamp(mel, min=1e-10).log10()
+    log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
+    return (log_spec + 4.0) / 4.0
+
+
+def test_slaney_filters_match_transformers():
+    tf_audio = pytest.importorskip("transformers.audio_utils")
+    from speechbrain_amd.integrations.huggingface.whisper import slaney_mel_filters
+
+    for n_mels in (80, 128):
+        ref = tf_audio.mel_filter_bank(num_frequency_bins=201, num_mel_filters=n_mels, min_frequency=0.0,
+                                       max_frequency=8000.0, sampling_rate=16000, norm="slaney", mel_scale="slaney")
+        assert float(np.abs(slaney_mel_filters(n_mels).numpy() - ref.astype(np.float32)).max()) <= 1e-7
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_log_mel_matches_reference_golden(backend, n_mels):
+    nat, dev = backend
+    from speechbrain_amd.integrations.huggingface.whisper import WhisperLogMel
+
+    g = np.load(GOLD)
+    fe = WhisperLogMel(n_mels=n_mels, n_samples=int(g["n_samples"]), mel_filters=g[f"filters{n_mels}"]).to(dev)
+    wav = torch.from_numpy(g["wav"]).to(dev)
+    out = fe(wav)
+    ref = torch.from_numpy(g[f"mel{n_mels}"])
+    assert out.shape == ref.shape
+    assert float((out.cpu() - ref).abs().max()) <= 2e-4  # log10 of fp32 power sums; the floor is batch-global
+    # trimming and the raw (un-padded) path
+    long_wav = torch.cat([wav, wav], dim=1)
+    assert torch.equal(fe.pad_or_trim(long_wav).cpu(), fe.pad_or_trim(wav.repeat(1, 2)).cpu())
+    assert fe.pad_or_trim(long_wav).shape[1] == int(g["n_samples"])
+
+
+def test_log_mel_vs_torch_restatement(backend):
+    """Fresh seeded input incl. silence (the 1e-10 clamp) and a loud utterance that sets the batch-wide floor."""
+    nat, dev = backend
+    from speechbrain_amd.integrations.huggingface.whisper import WhisperLogMel
+
+    fe = WhisperLogMel(n_mels=80, n_samples=16000).to(dev)
+    g = torch.Generator().manual_seed(5)
+    wav = torch.stack([0.5 * torch.randn(16000, generator=g), 1e-3 * torch.randn(16000, generator=g), torch.zeros(16000)])
+    out = fe(wav.to(dev)).cpu()
+    ref = torch_log_mel(wav, fe._mel_filters.cpu())
+    assert out.shape == (3, 80, 100)
+    assert float((out - ref).abs().max()) <= 2e-4
+    assert float(out[2].max()) == pytest.approx(float(ref[2].max()), abs=1e-6)  # silence sits exactly on the floor
