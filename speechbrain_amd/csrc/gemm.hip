@@ -69,6 +69,16 @@ struct PanelStage {
       r[i] = v;
     }
   }
+  // Unpredicated fetch for K % BK == 0 and 16-byte aligned rows: row indices are clamped instead of masked, so the
+  // loads carry no control dependence and a ring of several stages stays in flight across the barriers.
+  __device__ __forceinline__ void fetch_fast(const float* __restrict__ src, int ld, int row0, int nrows, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int s = min(tid + i * NT, ROWS * V - 1);
+      const int gr = min(row0 + s / V, nrows - 1);
+      r[i] = *reinterpret_cast<const float4*>(src + (size_t)gr * ld + k0 + (s % V) * 4);
+    }
+  }
   // [rows][BK+4] layout: one 16-byte LDS store per slot (rows stay 16-byte aligned: (BK+4)*4 is a multiple of 16)
   __device__ __forceinline__ void commit_vec(float (*dst)[BK + 4], int tid) const {
 #pragma unroll
@@ -171,6 +181,103 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(Gem
         g.C[(size_t)row * g.ldc + col] = v;
       }
     }
+  }
+}
+
+// The 64x64 tile with a register ring DEPTH K-tiles deep.  On the decode-step shapes (M = 1-5 K rows, K = 512) a
+// workgroup grid is one or two tiles per CU, nothing else hides the L2 latency of the next panel, and the plain
+// kernel above pays ~1 us per 32-deep K tile (measured: 18 us for M = 1280, N = 512, K = 512, the same for M = 320).
+// Here the loads of tiles k+1 .. k+DEPTH-1 are in flight while tile k is multiplied.  The ring is kept in flight by
+// loads the compiler does not count (SBK_LOAD16_ASYNC / SBK_LOADS_WAIT, sbk_device.h): written with plain loads, hipcc's
+// waitcnt pass drains the ring to vmcnt(0..3) at every stage (checked in the ISA).  Needs K % 32 == 0 and 16-byte
+// aligned rows; rows are clamped instead of predicated so every load is unconditional.
+template <int DEPTH>
+__global__ void __launch_bounds__(256) gemm_nt_pipe_kernel(GemmArgs g) {
+  constexpr int BM = 64, BN = 64, BK = 32;
+  __shared__ float As[BM][BK + 1];
+  __shared__ float Ws[BN][BK + 1];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int id = by * gx + bx;
+    if (nwg % 8 == 0) {
+      const int swz = (id % 8) * (nwg / 8) + id / 8;
+      bx = swz % gx;
+      by = swz / gx;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int lrow = lane & 31, lk = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+  // thread -> two 16-byte slots of each 64 x 32 panel: rows tid/8 and tid/8 + 32, k offset (tid % 8) * 4
+  const int prow = tid >> 3, pk = (tid & 7) * 4;
+  const float* a0 = g.A + (size_t)min(m0 + prow, g.M - 1) * g.lda + pk;
+  const float* a1 = g.A + (size_t)min(m0 + prow + 32, g.M - 1) * g.lda + pk;
+  const float* w0 = g.W + (size_t)min(n0 + prow, g.N - 1) * g.ldw + pk;
+  const float* w1 = g.W + (size_t)min(n0 + prow + 32, g.N - 1) * g.ldw + pk;
+  sbk::f32x4 ring[DEPTH][4];
+  const int nk = g.K / BK;
+#pragma unroll
+  for (int s = 0; s < DEPTH; ++s) {
+    if (s < nk) {
+      SBK_LOAD16_ASYNC(ring[s][0], a0 + s * BK);
+      SBK_LOAD16_ASYNC(ring[s][1], a1 + s * BK);
+      SBK_LOAD16_ASYNC(ring[s][2], w0 + s * BK);
+      SBK_LOAD16_ASYNC(ring[s][3], w1 + s * BK);
+    }
+  }
+  for (int kt = 0; kt < nk; kt += DEPTH) {
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) {
+      const int k = kt + s;
+      if (k < nk) {  // uniform
+        // loads issued after stage k's: the refills of the DEPTH-1 stages before it, as far as tiles exist
+        const int younger = min(DEPTH - 1, nk - 1 - k);
+        if (younger >= 3 && DEPTH >= 4) {
+          SBK_LOADS_WAIT(12, ring[s][0], ring[s][1], ring[s][2], ring[s][3]);
+        } else if (younger == 2 && DEPTH >= 3) {
+          SBK_LOADS_WAIT(8, ring[s][0], ring[s][1], ring[s][2], ring[s][3]);
+        } else if (younger == 1) {
+          SBK_LOADS_WAIT(4, ring[s][0], ring[s][1], ring[s][2], ring[s][3]);
+        } else {
+          SBK_LOADS_WAIT(0, ring[s][0], ring[s][1], ring[s][2], ring[s][3]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const sbk::f32x4 v = ring[s][e];
+          float* dst = (e < 2 ? &As[prow + (e & 1) * 32][pk] : &Ws[prow + (e & 1) * 32][pk]);
+          dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        }
+        __syncthreads();
+        if (k + DEPTH < nk) {
+          SBK_LOAD16_ASYNC(ring[s][0], a0 + (k + DEPTH) * BK);
+          SBK_LOAD16_ASYNC(ring[s][1], a1 + (k + DEPTH) * BK);
+          SBK_LOAD16_ASYNC(ring[s][2], w0 + (k + DEPTH) * BK);
+          SBK_LOAD16_ASYNC(ring[s][3], w1 + (k + DEPTH) * BK);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) acc = sbk::mfma_32x32x2(As[wm0 + lrow][kk + lk], Ws[wn0 + lrow][kk + lk], acc);
+        __syncthreads();
+      }
+    }
+  }
+  const int col = n0 + wn0 + lrow;
+  if (col >= g.N) return;
+  const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+    if (row >= g.M) continue;
+    float v = apply_act(acc[r] + bv, g.act) * g.alpha;
+    if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
+    if (g.R) v += g.R[(size_t)row * g.ldr + col];
+    g.C[(size_t)row * g.ldc + col] = v;
   }
 }
 
@@ -591,6 +698,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const fl
 }  // namespace
 namespace sbk {
 int g_gemm_vec_lds = 0;  // tuning knob (key 9): 1 = the 16-byte LDS operand variant (gemm_nt_v4_kernel)
+int g_gemm_pipe = 0;     // tuning knob (key 11): register-ring depth of the 64x64 / 32x64 tiles (0 = no ring)
 }
 namespace {
 template <int BM, int BN, int BK, int WM, int WN>
@@ -601,6 +709,18 @@ int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
                              : (BM == 128 && BN == 256) ? "gemm_nt_128x256"
                              : BM == 128 ? "gemm_nt_128x128" : (BM == 64 ? "gemm_nt_64x64" : "gemm_nt_32x64");
   sbk::ProfScope prof(kName, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N), st);
+  if constexpr (BM == 64 && BN == 64) {  // knob 11: register-ring depth of the pipelined variant (0 = plain kernel)
+    if (sbk::g_gemm_pipe > 0 && vec && g.K % BK == 0 && g.K >= 2 * BK) {
+      if (sbk::g_gemm_pipe >= 4) {
+        SBK_LAUNCH((gemm_nt_pipe_kernel<4>), grid, block, 0, st, g);
+      } else if (sbk::g_gemm_pipe == 3) {
+        SBK_LAUNCH((gemm_nt_pipe_kernel<3>), grid, block, 0, st, g);
+      } else {
+        SBK_LAUNCH((gemm_nt_pipe_kernel<2>), grid, block, 0, st, g);
+      }
+      return sbk::launch_status("sbk_gemm_nt_f32");
+    }
+  }
   if (!sbk::g_gemm_vec_lds) {  // default: scalar LDS operand reads at pitch BK+1 (measured faster)
     if (vec) {
       SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, true>), grid, block, 0, st, g);
@@ -634,7 +754,9 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   if (M == 0 || N == 0) return 0;
   // (measured, tools/microbench.py --attn --gemm: from ~1.9 M outputs with a short K the LDS-tiled kernels win:
   //  M=1280 N=1536 41.6 -> 27.6 us, M=640 N=5000 63 -> 46 us; a long K still needs the split of the skinny path)
-  const bool big_short = (long)M * N >= 1900000 && K <= 1024;  // (K = 768: the TransformerLM scorer's projections)
+  // (knob 11 > 0: the register-ring 64x64 tiles take every mid-M shape -- grouped searches run M = 1-5 K rows)
+  const bool mid_pipe = g_gemm_pipe > 0 && M >= 640 && K % 32 == 0 && (long)cdiv(M, 128) * cdiv(N, 128) < 384;
+  const bool big_short = mid_pipe || ((long)M * N >= 1900000 && K <= 1024);  // (K = 768: the TransformerLM scorer's projections)
   const bool skinny_ok = !big_short && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < 256) && M <= 4096 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
   if (!skinny_ok || g_skinny_off) return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
   GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
@@ -680,7 +802,8 @@ int gemm_ln_nt(const float* A, int lda, const float* Wf, int ldw, const float* b
                int ldc, int M, int N, int K, float eps, int act, float alpha, hipStream_t st) {
   if (M == 0 || N == 0) return 0;
   const bool ok = (K == 512 || K == 256 || K == 128) && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < 256) &&
-                  M <= 4096 && (long)M * N < 1900000 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(Wf) && !g_skinny_off;
+                  M <= 4096 && (long)M * N < 1900000 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(Wf) &&
+                  !g_skinny_off && !(g_gemm_pipe > 0 && M >= 640);
   if (!ok) return -1;
   GemmArgs g{A, Wf, bf, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, nullptr, 1};
   const int tiles_m = cdiv(M, 32), tiles_n = cdiv(N, 32);
@@ -710,6 +833,7 @@ int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
   if (big && (g_gemm_tile & 15) == 3) return launch_gemm<256, 128, 32, 128, 64>(g, vec, st);
   if (big && (g_gemm_tile & 15) == 4) return launch_gemm<128, 128, 64, 64, 64>(g, vec, st);  // one barrier pair per 128 MFMAs
   if (tiles128 >= 384) return launch_gemm<128, 128, 32, 64, 64>(g, vec, st);
+  if (g_gemm_pipe > 0 && M >= 64 && vec && K % 32 == 0) return launch_gemm<64, 64, 32, 32, 32>(g, vec, st);
   if (tiles64 >= 256 || M > 256) return launch_gemm<64, 64, 32, 32, 32>(g, vec, st);
   return launch_gemm<32, 64, 32, 32, 32>(g, vec, st);
 }
@@ -791,4 +915,5 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 8) sbk::g_cross_fc256 = value;
   if (key == 9) sbk::g_gemm_vec_lds = value;
   if (key == 10) sbk::g_skinny_looped = value;
+  if (key == 11) sbk::g_gemm_pipe = value;
 }

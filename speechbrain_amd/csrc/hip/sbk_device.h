@@ -40,6 +40,16 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // the arithmetic that consumes them instead of sunk next to each use).
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
+// Loads the compiler does NOT count (cdna_hip_programming.md 5.7 form ii): a 16-byte global load whose completion is
+// awaited by loads_wait<N>() -- "at most N of this wave's vector-memory loads still outstanding" -- naming the
+// registers that become readable.  hipcc's own s_waitcnt pass collapses a register ring that is several K tiles deep
+// to vmcnt(0..3) inside a loop, i.e. back to one tile in flight; with these the ring really stays in flight across
+// barriers.  Rule for users: between load16_async and the matching loads_wait the wave issues no other VMEM load.
+// (macros: the operands must be plain local lvalues -- hipcc cannot tie an asm operand through a reference)
+#define SBK_LOAD16_ASYNC(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#define SBK_LOADS_WAIT(N, a, b, c, d) \
+  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
+
 // x * 2^e and the exponent k of x = f * 2^k, f in [0.5,1) (0 for x = 0): single VALU instructions
 // (v_ldexp_f32 / v_frexp_exp_i32_f32) without the libm special-case wrappers.
 __device__ __forceinline__ float fast_ldexp(float x, int e) { return __builtin_amdgcn_ldexpf(x, e); }

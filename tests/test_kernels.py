@@ -298,3 +298,25 @@ def test_documented_capacity_limits_are_reported(backend):
                              torch.zeros(24).to(dev), None, 1, 0.3)
     with pytest.raises(nat.SbkError, match="kernel size"):
         nat.glu_dwconv(torch.zeros(1, 8, 16).to(dev), torch.zeros(8, 9).to(dev), torch.zeros(8).to(dev), 9)
+
+
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_gemm_register_ring_variants(backend, depth):
+    """The pipelined 64x64 / 32x64 tiles (tuning knob 11): K a multiple of the 32-deep tile, ragged M and N, a K
+    that is not a multiple of depth * 32, bias + GELU + scaled residual."""
+    nat, dev = backend
+    g = torch.Generator().manual_seed(depth)
+    nat.load().sbk_prof_set_knob(2, 1)   # route away from the register-operand path
+    nat.load().sbk_prof_set_knob(11, depth)
+    try:
+        for (M, N, K) in [(300, 100, 160), (70, 130, 64), (1000, 96, 224)]:
+            a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01
+            w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
+            b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+            out = nat.gemm_nt(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_GELU, alpha=0.5)
+            ref = r + 0.5 * F.gelu(a.double() @ w.double().t() + b).float()
+            scale = float((a.abs() @ w.abs().t()).max())
+            assert _md(out, ref) <= 2e-6 * scale + 1e-5
+    finally:
+        nat.load().sbk_prof_set_knob(11, 0)
+        nat.load().sbk_prof_set_knob(2, 0)

@@ -164,7 +164,9 @@ static inline int shfl_xor(int v, int m) { return shfl_idx_(v, sbk_emu::cur().la
 static inline float shfl(float v, int lane) { return shfl_idx_(v, lane); }
 static inline int shfl(int v, int lane) { return shfl_idx_(v, lane); }
 static inline void wave_sync() { sbk_emu::wave_barrier(); }
-static inline void sched_fence() {}  // a hint to the device compiler's scheduler; nothing to do on the host
+static inline void sched_fence() {}
+#define SBK_LOAD16_ASYNC(dst, ptr) ((dst) = *reinterpret_cast<const sbk::f32x4*>(ptr))
+#define SBK_LOADS_WAIT(N, a, b, c, d) ((void)0)  // a hint to the device compiler's scheduler; nothing to do on the host
 static inline float fast_ldexp(float x, int e) {
   if (e < -400) return x * 0.0f;
   if (e > 400) e = 400;

@@ -106,6 +106,17 @@ if __name__ == "__main__":
         nat.load().sbk_prof_set_knob(2, 0)
         nat.load().sbk_prof_set_knob(9, 0)
         sys.exit(0)
+    if "--pipe" in sys.argv:  # mid-M decode GEMMs on the 64x64 tiles: register-ring depth 0 (plain) / 2 / 3 / 4
+        nat.load().sbk_prof_set_knob(2, 1)
+        for depth in (0, 2, 3, 4):
+            nat.load().sbk_prof_set_knob(11, depth)
+            print("64x64 tiles, ring depth", depth)
+            for M in (320, 1280, 2560, 5120):
+                for (N, K) in [(512, 512), (1536, 512), (2048, 512), (512, 2048)]:
+                    gemm_case(M, N, K, 0)
+        nat.load().sbk_prof_set_knob(11, 0)
+        nat.load().sbk_prof_set_knob(2, 0)
+        sys.exit(0)
     if "--skinny" in sys.argv:  # decode-step GEMMs on the register-operand path: looped (round 1) vs flat schedule
         for looped in (1, 0):
             nat.load().sbk_prof_set_knob(10, looped)
