@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--group", type=int, default=0,
                     help="batches decoded together in one grouped search per worker (0: automatic -- enough recipe-sized "
                          "batches to give the decoder step ~256 utterances)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="arithmetic of the headline run: fp32 = the parity path (default); bf16 = bf16 operands / fp32 "
+                         "accumulation in the encoder GEMMs (opt-in fast path; reported as a secondary value otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip configs[1] (Conformer-S encoder) and the second run")
@@ -263,6 +266,7 @@ def main():
             max_decode_ratio=1.0, beam_size=10, using_eos_threshold=False, length_normalization=True,
             temperature=1.15, scorer=scorer)
     asr.mods.decoder.check_every = 0  # fixed-length decoding: no stop-rule polling, fully asynchronous
+    asr.eval_precision = args.precision
 
     def transcribe_one(w, l):
         return asr.transcribe_batch(w, l)[1]
@@ -326,7 +330,8 @@ def main():
             "metric": "audio-sec/s decoded (node), Conformer-L beam=10", "value": round(total_audio / dt, 2),
             "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate (encoder GEMMs); f32 elsewhere",
+            "data": "synthetic",
             "config": {"workload": f"Conformer-L enc-dec ({args.attention}, 12+6 layers, d=512, V=5000) + "
                                    "S2STransformerBeamSearcher beam=10 + CTC 0.4"
                                    + (" + TransformerLM 12x768 scorer 0.6" if args.lm else "")
@@ -350,6 +355,21 @@ def main():
         out[f"ms_per_step_batch{args.second_batch}"] = round(1000.0 * dt2 / max(args.steps, 1), 3)
         out["config"][f"workers_x_group_batch{args.second_batch}"] = [info2["streams"], info2["group"]]
         note(f"second run ({args.second_batch}-utterance batches): {dt2:.3f} s")
+
+    # ---- the opt-in bf16 encoder GEMMs on the same job + token agreement with the fp32 run (N = 1)
+    if world == 1 and not dist_on and not args.no_extras and args.precision == "fp32":
+        from speechbrain_amd.utils.metric_stats import token_error_rate
+
+        asr.eval_precision = "bf16"
+        dt3, hyps3, _, _ = timed_run(args.max_batch, *auto(args.max_batch))
+        asr.eval_precision = "fp32"
+        ter = token_error_rate(hyps3, hyps)
+        out["value_encoder_gemms_bf16"] = round(total_audio / dt3, 2)
+        out["bf16_vs_fp32_token_error_rate_percent"] = round(ter["WER"], 3)
+        out["config"]["bf16_note"] = ("opt-in (run_opts precision='bf16'): encoder GEMM operands rounded to bf16, fp32 accumulation, "
+                                      "everything else fp32; token error rate of its hypotheses against the fp32 run's on the "
+                                      "same utterances (random-init weights: flat posteriors amplify every perturbation)")
+        note(f"bf16 encoder GEMMs: {dt3:.3f} s, token error rate vs fp32 {ter['WER']:.2f} %")
 
     # ---- p50 per-utterance latency (B = 1, 10 s; pinned host waveform -> token ids on the host), rank 0 only
     if rank == 0 and args.latency_runs > 0:

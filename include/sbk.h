@@ -128,6 +128,17 @@ int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const floa
                     int ldr, float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
                     int rows_per_seq, sbk_stream_t stream);
 
+/* ---- bf16-operand fast entry points ("fp32 parity entry points plus bf16 ... fast entry points").
+ * C = epilogue(bf16(A) . Wb^T) with fp32 accumulation on v_mfma_f32_32x32x16_bf16: A [M,K] stays fp32 in memory and is
+ * rounded to bf16 (nearest even) inside the kernel, Wb [N,K] holds the weights as bf16 bits (sbk_f32_to_bf16, once per
+ * model), bias / activation / residual / row mask exactly as sbk_gemm_nt_f32.  Opt-in (run_opts precision="bf16",
+ * cf. utils/run_opts.py:114-115 / utils/autocast.py): NOT the parity path -- products carry 8 mantissa bits, see
+ * DESIGN.md for the stated tolerance and the token-agreement rate.  K % 8 == 0, ldw % 8 == 0, lda % 4 == 0. */
+int sbk_f32_to_bf16(const float* x, uint16_t* y, long n, sbk_stream_t stream);
+int sbk_gemm_nt_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, const float* bias, const float* residual,
+                     int ldr, float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
+                     int rows_per_seq, sbk_stream_t stream);
+
 /* Same contraction for few-row operands (M <= 512: the beams x utterances rows of a decoder step):
  * waves own 32-column tiles and K slices, partial sums go through `workspace` (floats; the more,
  * the more K slices, at most 8*M*N is useful) and are combined in a fixed order. */

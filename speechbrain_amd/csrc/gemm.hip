@@ -69,16 +69,6 @@ struct PanelStage {
       r[i] = v;
     }
   }
-  // Unpredicated fetch for K % BK == 0 and 16-byte aligned rows: row indices are clamped instead of masked, so the
-  // loads carry no control dependence and a ring of several stages stays in flight across the barriers.
-  __device__ __forceinline__ void fetch_fast(const float* __restrict__ src, int ld, int row0, int nrows, int k0, int tid) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int s = min(tid + i * NT, ROWS * V - 1);
-      const int gr = min(row0 + s / V, nrows - 1);
-      r[i] = *reinterpret_cast<const float4*>(src + (size_t)gr * ld + k0 + (s % V) * 4);
-    }
-  }
   // [rows][BK+4] layout: one 16-byte LDS store per slot (rows stay 16-byte aligned: (BK+4)*4 is a multiple of 16)
   __device__ __forceinline__ void commit_vec(float (*dst)[BK + 4], int tid) const {
 #pragma unroll
@@ -181,103 +171,6 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(Gem
         g.C[(size_t)row * g.ldc + col] = v;
       }
     }
-  }
-}
-
-// The 64x64 tile with a register ring DEPTH K-tiles deep.  On the decode-step shapes (M = 1-5 K rows, K = 512) a
-// workgroup grid is one or two tiles per CU, nothing else hides the L2 latency of the next panel, and the plain
-// kernel above pays ~1 us per 32-deep K tile (measured: 18 us for M = 1280, N = 512, K = 512, the same for M = 320).
-// Here the loads of tiles k+1 .. k+DEPTH-1 are in flight while tile k is multiplied.  The ring is kept in flight by
-// loads the compiler does not count (SBK_LOAD16_ASYNC / SBK_LOADS_WAIT, sbk_device.h): written with plain loads, hipcc's
-// waitcnt pass drains the ring to vmcnt(0..3) at every stage (checked in the ISA).  Needs K % 32 == 0 and 16-byte
-// aligned rows; rows are clamped instead of predicated so every load is unconditional.
-template <int DEPTH>
-__global__ void __launch_bounds__(256) gemm_nt_pipe_kernel(GemmArgs g) {
-  constexpr int BM = 64, BN = 64, BK = 32;
-  __shared__ float As[BM][BK + 1];
-  __shared__ float Ws[BN][BK + 1];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
-    const int id = by * gx + bx;
-    if (nwg % 8 == 0) {
-      const int swz = (id % 8) * (nwg / 8) + id / 8;
-      bx = swz % gx;
-      by = swz / gx;
-    }
-  }
-  const int m0 = by * BM, n0 = bx * BN;
-  const int lrow = lane & 31, lk = lane >> 5;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-
-  // thread -> two 16-byte slots of each 64 x 32 panel: rows tid/8 and tid/8 + 32, k offset (tid % 8) * 4
-  const int prow = tid >> 3, pk = (tid & 7) * 4;
-  const float* a0 = g.A + (size_t)min(m0 + prow, g.M - 1) * g.lda + pk;
-  const float* a1 = g.A + (size_t)min(m0 + prow + 32, g.M - 1) * g.lda + pk;
-  const float* w0 = g.W + (size_t)min(n0 + prow, g.N - 1) * g.ldw + pk;
-  const float* w1 = g.W + (size_t)min(n0 + prow + 32, g.N - 1) * g.ldw + pk;
-  sbk::f32x4 ring[DEPTH][4];
-  const int nk = g.K / BK;
-#pragma unroll
-  for (int s = 0; s < DEPTH; ++s) {
-    if (s < nk) {
-      SBK_LOAD16_ASYNC(ring[s][0], a0 + s * BK);
-      SBK_LOAD16_ASYNC(ring[s][1], a1 + s * BK);
-      SBK_LOAD16_ASYNC(ring[s][2], w0 + s * BK);
-      SBK_LOAD16_ASYNC(ring[s][3], w1 + s * BK);
-    }
-  }
-  for (int kt = 0; kt < nk; kt += DEPTH) {
-#pragma unroll
-    for (int s = 0; s < DEPTH; ++s) {
-      const int k = kt + s;
-      if (k < nk) {  // uniform
-        // loads issued after stage k's: the refills of the DEPTH-1 stages before it, as far as tiles exist
-        const int younger = min(DEPTH - 1, nk - 1 - k);
-        if (younger >= 3 && DEPTH >= 4) {
-          SBK_LOADS_WAIT(12, ring[s][0], ring[s][1], ring[s][2], ring[s][3]);
-        } else if (younger == 2 && DEPTH >= 3) {
-          SBK_LOADS_WAIT(8, ring[s][0], ring[s][1], ring[s][2], ring[s][3]);
-        } else if (younger == 1) {
-          SBK_LOADS_WAIT(4, ring[s][0], ring[s][1], ring[s][2], ring[s][3]);
-        } else {
-          SBK_LOADS_WAIT(0, ring[s][0], ring[s][1], ring[s][2], ring[s][3]);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const sbk::f32x4 v = ring[s][e];
-          float* dst = (e < 2 ? &As[prow + (e & 1) * 32][pk] : &Ws[prow + (e & 1) * 32][pk]);
-          dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
-        }
-        __syncthreads();
-        if (k + DEPTH < nk) {
-          SBK_LOAD16_ASYNC(ring[s][0], a0 + (k + DEPTH) * BK);
-          SBK_LOAD16_ASYNC(ring[s][1], a1 + (k + DEPTH) * BK);
-          SBK_LOAD16_ASYNC(ring[s][2], w0 + (k + DEPTH) * BK);
-          SBK_LOAD16_ASYNC(ring[s][3], w1 + (k + DEPTH) * BK);
-        }
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) acc = sbk::mfma_32x32x2(As[wm0 + lrow][kk + lk], Ws[wn0 + lrow][kk + lk], acc);
-        __syncthreads();
-      }
-    }
-  }
-  const int col = n0 + wn0 + lrow;
-  if (col >= g.N) return;
-  const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-    if (row >= g.M) continue;
-    float v = apply_act(acc[r] + bv, g.act) * g.alpha;
-    if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
-    if (g.R) v += g.R[(size_t)row * g.ldr + col];
-    g.C[(size_t)row * g.ldc + col] = v;
   }
 }
 
@@ -433,6 +326,135 @@ __device__ __forceinline__ void tile_epilogue_32x32(const GemmArgs& g, float (&v
     const int row = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
     if (col_ok && row < g.M) g.C[(size_t)row * g.ldc + col] = v[q];
   }
+}
+
+// ---------------------------------------------------------------------------
+// bf16-operand fast path (sbk_gemm_nt_bf16, SURVEY 8b "fast entry points"): C = epilogue(bf16(A) . Wb^T) with fp32
+// accumulation on v_mfma_f32_32x32x16_bf16 (16x the f32 matrix rate).  A stays fp32 in HBM -- every kernel around
+// the contraction (LayerNorm, attention, GLU/conv, residual stream) is the fp32 one -- and is rounded to bf16 (RNE) on
+// its way into LDS; Wb is the weight matrix converted once by the caller.  Same 128x128 tiling, XCD-aware order and
+// epilogue as the f32 kernel; LDS rows are 32 bf16 + 8 pad (80 B: the 16-lane groups of a ds_read_b128 hit 16
+// distinct 4-bank groups), each operand fragment is one ds_read_b128 of 8 consecutive k.  With the MFMA work cut
+// 16x the kernel is bound by the fp32 A / C traffic (4 B per element each), not by the matrix pipe.
+struct GemmBf16Args {
+  const float* A;
+  const unsigned short* W;  // [N,K] bf16 bits
+  const float* bias;
+  const float* R;
+  float* C;
+  int lda, ldw, ldr, ldc, M, N, K, act;
+  float alpha;
+  const int32_t* seq_len;
+  int rows_per_seq;
+};
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) gemm_nt_bf16_kernel(GemmBf16Args g) {
+  constexpr int BK = 32, PITCH = BK + 8;  // bf16 elements per LDS row
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int APER = BM * BK / 4 / 256;  // float4 slots of the A panel per thread
+  constexpr int WPER = BN * BK / 8 / 256;  // 16-byte (8 x bf16) slots of the W panel per thread
+  static_assert(APER >= 1 && WPER >= 1, "tile too small for 256 threads");
+  __shared__ __attribute__((aligned(16))) unsigned short As[BM][PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned short Ws[BN][PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int id = by * gx + bx;
+    if (nwg % 8 == 0) {
+      const int swz = (id % 8) * (nwg / 8) + id / 8;
+      bx = swz % gx;
+      by = swz / gx;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int lrow = lane & 31, kh = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  float4 ra[APER];
+  uint4 rw[WPER];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < APER; ++i) {
+      const int s = tid + i * 256, rr = s / (BK / 4), c = (s % (BK / 4)) * 4;
+      const int gr = m0 + rr, gk = k0 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < g.M && gk < g.K) v = *reinterpret_cast<const float4*>(g.A + (size_t)gr * g.lda + gk);  // K % 8 == 0
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WPER; ++i) {
+      const int s = tid + i * 256, rr = s / (BK / 8), c = (s % (BK / 8)) * 8;
+      const int gr = n0 + rr, gk = k0 + c;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (gr < g.N && gk < g.K) v = *reinterpret_cast<const uint4*>(g.W + (size_t)gr * g.ldw + gk);
+      rw[i] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < APER; ++i) {
+      const int s = tid + i * 256, rr = s / (BK / 4), c = (s % (BK / 4)) * 4;
+      uint2 p;
+      p.x = (unsigned)sbk::f32_to_bf16(ra[i].x) | ((unsigned)sbk::f32_to_bf16(ra[i].y) << 16);
+      p.y = (unsigned)sbk::f32_to_bf16(ra[i].z) | ((unsigned)sbk::f32_to_bf16(ra[i].w) << 16);
+      *reinterpret_cast<uint2*>(&As[rr][c]) = p;
+    }
+#pragma unroll
+    for (int i = 0; i < WPER; ++i) {
+      const int s = tid + i * 256, rr = s / (BK / 8), c = (s % (BK / 8)) * 8;
+      *reinterpret_cast<uint4*>(&Ws[rr][c]) = rw[i];
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    commit();
+    __syncthreads();
+    if (k0 + BK < g.K) fetch(k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      sbk::bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const sbk::bf16x8*>(&As[wm0 + i * 32 + lrow][ks + kh * 8]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const sbk::bf16x8*>(&Ws[wn0 + j * 32 + lrow][ks + kh * 8]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn0 + j * 32 + lrow;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row >= g.M) continue;
+        float v = apply_act(acc[i][j][r] + bv, g.act) * g.alpha;
+        if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
+        if (g.R) v += g.R[(size_t)row * g.ldr + col];
+        g.C[(size_t)row * g.ldc + col] = v;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = sbk::f32_to_bf16(x[i]);
 }
 
 // ---------------------------------------------------------------------------
@@ -593,6 +615,94 @@ __global__ void __launch_bounds__(256) gemm_skinny_flat_kernel(GemmArgs g, float
   tile_epilogue_32x32(g, v, mt, nt, r, half);
 }
 
+// 64 x 64 tile of the same scheme for M >= ~600 rows (a 128-utterance batch, or a grouped search over several
+// recipe-sized batches): the four waves still split K four ways and hold their whole slice in registers, but each
+// owns a 2 x 2 block of 32x32 accumulators.  Per MFMA that halves the bytes pulled from L2 (the 32x32 kernel moves
+// 128 KB per workgroup for 64 MFMAs per wave and is bound by that traffic from ~500 workgroups on: measured 2.2 us
+// per extra 100 workgroups), and the four accumulator chains are independent, so no MFMA waits on its predecessor.
+template <int NCH>
+__global__ void __launch_bounds__(256) gemm_skinny_flat64_kernel(GemmArgs g, float* __restrict__ partial, int tiles_m,
+                                                                 int tiles_n) {
+  constexpr int KC = 32;
+  __shared__ float red[4][4][32][33];  // [wave][sub-tile][row][col]: partial tiles of the four K slices
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int nt, mt;
+  {
+    const int id = blockIdx.x, x = id & 7, q = id >> 3;
+    const int nt8 = (tiles_n + 7) / 8;
+    mt = q % tiles_m;
+    nt = x + 8 * (q / tiles_m);
+    if (q / tiles_m >= nt8 || nt >= tiles_n) return;
+  }
+  const int r = lane & 31, half = lane >> 5;
+  const int k_begin = (blockIdx.y * 4 + wave) * NCH * KC;
+  const float* arow[2];
+  const float* wrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    arow[i] = g.A + (size_t)min(mt * 64 + i * 32 + r, g.M - 1) * g.lda + half * (KC / 2) + k_begin;
+    wrow[i] = g.W + (size_t)min(nt * 64 + i * 32 + r, g.N - 1) * g.ldw + half * (KC / 2) + k_begin;
+  }
+  float4 a[2][NCH][4], w[2][NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) w[i][c][v] = *reinterpret_cast<const float4*>(wrow[i] + c * KC + 4 * v);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) a[i][c][v] = *reinterpret_cast<const float4*>(arow[i] + c * KC + 4 * v);
+    }
+  sbk::sched_fence();
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float av = e == 0 ? a[i][c][v].x : e == 1 ? a[i][c][v].y : e == 2 ? a[i][c][v].z : a[i][c][v].w;
+            const float wv = e == 0 ? w[j][c][v].x : e == 1 ? w[j][c][v].y : e == 2 ? w[j][c][v].z : w[j][c][v].w;
+            acc[i][j] = sbk::mfma_32x32x2(av, wv, acc[i][j]);
+          }
+  // every wave publishes its four partial sub-tiles; wave s then owns sub-tile s = 2*i + j (fixed summation order)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) red[wave][2 * i + j][(q & 3) + 8 * (q >> 2) + 4 * half][r] = acc[i][j][q];
+  __syncthreads();
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int rr = (q & 3) + 8 * (q >> 2) + 4 * half;
+    v[q] = ((red[0][wave][rr][r] + red[1][wave][rr][r]) + red[2][wave][rr][r]) + red[3][wave][rr][r];
+  }
+  const int sub_m = mt * 2 + (wave >> 1), sub_n = nt * 2 + (wave & 1);  // this wave's 32x32 tile in 32-row/col units
+  if (gridDim.y > 1) {
+    float* P = partial + (size_t)blockIdx.y * g.M * g.N;
+    const int col = sub_n * 32 + r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = sub_m * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+      if (row < g.M && col < g.N) P[(size_t)row * g.N + col] = v[q];
+    }
+    return;
+  }
+  tile_epilogue_32x32(g, v, sub_m, sub_n, r, half);
+}
+
 // LayerNorm fused into the skinny GEMM:  C = epilogue( LN(A) . W^T ) for K = NCH*128 (one fetch batch
 // per wave, so the workgroup's four waves hold complete rows of A in registers).  gamma/beta are
 // pre-folded into the operands by the caller:  Wf[n,k] = W[n,k]*gamma[k],  bf[n] = b[n] + sum_k W[n,k]*beta[k],
@@ -698,7 +808,6 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const fl
 }  // namespace
 namespace sbk {
 int g_gemm_vec_lds = 0;  // tuning knob (key 9): 1 = the 16-byte LDS operand variant (gemm_nt_v4_kernel)
-int g_gemm_pipe = 0;     // tuning knob (key 11): register-ring depth of the 64x64 / 32x64 tiles (0 = no ring)
 }
 namespace {
 template <int BM, int BN, int BK, int WM, int WN>
@@ -709,18 +818,6 @@ int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
                              : (BM == 128 && BN == 256) ? "gemm_nt_128x256"
                              : BM == 128 ? "gemm_nt_128x128" : (BM == 64 ? "gemm_nt_64x64" : "gemm_nt_32x64");
   sbk::ProfScope prof(kName, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N), st);
-  if constexpr (BM == 64 && BN == 64) {  // knob 11: register-ring depth of the pipelined variant (0 = plain kernel)
-    if (sbk::g_gemm_pipe > 0 && vec && g.K % BK == 0 && g.K >= 2 * BK) {
-      if (sbk::g_gemm_pipe >= 4) {
-        SBK_LAUNCH((gemm_nt_pipe_kernel<4>), grid, block, 0, st, g);
-      } else if (sbk::g_gemm_pipe == 3) {
-        SBK_LAUNCH((gemm_nt_pipe_kernel<3>), grid, block, 0, st, g);
-      } else {
-        SBK_LAUNCH((gemm_nt_pipe_kernel<2>), grid, block, 0, st, g);
-      }
-      return sbk::launch_status("sbk_gemm_nt_f32");
-    }
-  }
   if (!sbk::g_gemm_vec_lds) {  // default: scalar LDS operand reads at pitch BK+1 (measured faster)
     if (vec) {
       SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, true>), grid, block, 0, st, g);
@@ -741,6 +838,9 @@ namespace sbk {
 int g_skinny_nch = 0;  // tuning knob (0 = automatic): K chunks fetched per batch by the skinny kernel
 int g_skinny_off = 0;  // tuning knob: 1 = route few-row GEMMs to the LDS-tiled kernels
 int g_skinny_looped = 0;  // tuning knob (key 10): 1 = always the looped skinny kernel (the round-1 schedule)
+int g_flat64_min_rows = 600;  // tuning knob (key 11): from this many rows on the register-operand path uses 64x64 tiles
+int g_skinny_reach = 0;   // tuning knob (key 12): 1 = the register-operand path also takes the mid-M shapes that go to
+                          // the LDS-tiled kernels by default (M*N >= 1.9 M with K <= 1024)
 int g_gemm_tile = 0;   // tuning knob (key 6) for the large-M path: 0 = 128x128, 1 = 256x128 (8 waves of 64x64),
                        // 2 = 128x256 (8 waves), 3 = 256x128 (4 waves of 128x64), 4 = 128x128 with 64-deep K tiles
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
@@ -754,10 +854,8 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   if (M == 0 || N == 0) return 0;
   // (measured, tools/microbench.py --attn --gemm: from ~1.9 M outputs with a short K the LDS-tiled kernels win:
   //  M=1280 N=1536 41.6 -> 27.6 us, M=640 N=5000 63 -> 46 us; a long K still needs the split of the skinny path)
-  // (knob 11 > 0: the register-ring 64x64 tiles take every mid-M shape -- grouped searches run M = 1-5 K rows)
-  const bool mid_pipe = g_gemm_pipe > 0 && M >= 640 && K % 32 == 0 && (long)cdiv(M, 128) * cdiv(N, 128) < 384;
-  const bool big_short = mid_pipe || ((long)M * N >= 1900000 && K <= 1024);  // (K = 768: the TransformerLM scorer's projections)
-  const bool skinny_ok = !big_short && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < 256) && M <= 4096 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
+  const bool big_short = !g_skinny_reach && (long)M * N >= 1900000 && K <= 1024;  // (K = 768: the TransformerLM scorer's projections)
+  const bool skinny_ok = !big_short && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < (g_skinny_reach ? 2048 : 256)) && M <= (g_skinny_reach ? 8192 : 4096) && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
   if (!skinny_ok || g_skinny_off) return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
   GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
   const int tiles_m = cdiv(M, 32), tiles_n = cdiv(N, 32);
@@ -774,7 +872,15 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   dim3 grid(8 * tiles_m * cdiv(tiles_n, 8), SKg), block(256);
   const int nch = g_skinny_nch ? g_skinny_nch : (kper >= 128 ? 4 : (kper >= 64 ? 2 : 1));
   const bool flat = !g_skinny_looped && K == 4 * SKg * kper && (kper == 128 || kper == 64 || kper == 32);
-  if (flat) {  // one fetch batch per wave: every load in flight before the first MFMA
+  if (flat && (kper == 128 || kper == 64) && M >= g_flat64_min_rows) {  // 2 x 2 accumulators per wave (see the kernel)
+    const int tm64 = cdiv(M, 64), tn64 = cdiv(N, 64);
+    dim3 grid64(8 * tm64 * cdiv(tn64, 8), SKg);
+    if (kper == 128) {
+      SBK_LAUNCH((gemm_skinny_flat64_kernel<4>), grid64, block, 0, st, g, ws, tm64, tn64);
+    } else {
+      SBK_LAUNCH((gemm_skinny_flat64_kernel<2>), grid64, block, 0, st, g, ws, tm64, tn64);
+    }
+  } else if (flat) {  // one fetch batch per wave: every load in flight before the first MFMA
     if (kper == 128) {
       SBK_LAUNCH((gemm_skinny_flat_kernel<4>), grid, block, 0, st, g, ws, tiles_m, tiles_n);
     } else if (kper == 64) {
@@ -803,7 +909,7 @@ int gemm_ln_nt(const float* A, int lda, const float* Wf, int ldw, const float* b
   if (M == 0 || N == 0) return 0;
   const bool ok = (K == 512 || K == 256 || K == 128) && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < 256) &&
                   M <= 4096 && (long)M * N < 1900000 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(Wf) &&
-                  !g_skinny_off && !(g_gemm_pipe > 0 && M >= 640);
+                  !g_skinny_off;
   if (!ok) return -1;
   GemmArgs g{A, Wf, bf, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, nullptr, 1};
   const int tiles_m = cdiv(M, 32), tiles_n = cdiv(N, 32);
@@ -833,7 +939,6 @@ int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
   if (big && (g_gemm_tile & 15) == 3) return launch_gemm<256, 128, 32, 128, 64>(g, vec, st);
   if (big && (g_gemm_tile & 15) == 4) return launch_gemm<128, 128, 64, 64, 64>(g, vec, st);  // one barrier pair per 128 MFMAs
   if (tiles128 >= 384) return launch_gemm<128, 128, 32, 64, 64>(g, vec, st);
-  if (g_gemm_pipe > 0 && M >= 64 && vec && K % 32 == 0) return launch_gemm<64, 64, 32, 32, 32>(g, vec, st);
   if (tiles64 >= 256 || M > 256) return launch_gemm<64, 64, 32, 32, 32>(g, vec, st);
   return launch_gemm<32, 64, 32, 32, 32>(g, vec, st);
 }
@@ -915,5 +1020,41 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 8) sbk::g_cross_fc256 = value;
   if (key == 9) sbk::g_gemm_vec_lds = value;
   if (key == 10) sbk::g_skinny_looped = value;
-  if (key == 11) sbk::g_gemm_pipe = value;
+  if (key == 11) sbk::g_flat64_min_rows = value;
+  if (key == 12) sbk::g_skinny_reach = value;
+}
+
+
+// ---- bf16-operand fast entry points ---------------------------------------------------------------
+extern "C" int sbk_f32_to_bf16(const float* x, uint16_t* y, long n, sbk_stream_t stream) {
+  if (n == 0) return 0;
+  SBK_REQUIRE(x && y && n > 0, "f32_to_bf16: bad arguments");
+  const long blocks = (n + 255) / 256;
+  SBK_LAUNCH(f32_to_bf16_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, sbk::as_stream(stream), x,
+             reinterpret_cast<unsigned short*>(y), n);
+  return sbk::launch_status("sbk_f32_to_bf16");
+}
+
+extern "C" int sbk_gemm_nt_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, const float* bias,
+                                const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
+                                float alpha, const int32_t* seq_len, int rows_per_seq, sbk_stream_t stream) {
+  if (M == 0 || N == 0) return 0;
+  SBK_REQUIRE(A && Wb && C, "gemm_bf16: null operand");
+  SBK_REQUIRE(M >= 0 && N >= 0 && K > 0 && K % 8 == 0, "gemm_bf16: bad shape M=%d N=%d K=%d (K must be a multiple of 8)", M, N, K);
+  SBK_REQUIRE(lda >= K && ldw >= K && ldc >= N && lda % 4 == 0 && ldw % 8 == 0, "gemm_bf16: leading dimensions");
+  SBK_REQUIRE(sbk::aligned16(A) && sbk::aligned16(Wb), "gemm_bf16: operands must be 16-byte aligned");
+  SBK_REQUIRE(!residual || ldr >= N, "gemm_bf16: residual stride");
+  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_bf16: unknown activation %d", act);
+  SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm_bf16: seq_len given without rows_per_seq");
+  GemmBf16Args g{A, reinterpret_cast<const unsigned short*>(Wb), bias, residual, C, lda, ldw, ldr, ldc, M, N, K, act, alpha,
+                 seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
+  hipStream_t st = sbk::as_stream(stream);
+  const long tiles128 = (long)sbk::cdiv(M, 128) * sbk::cdiv(N, 128);
+  sbk::ProfScope prof("gemm_nt_bf16", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N) + 2.0 * (double)N * K, st);
+  if (tiles128 >= 256) {
+    SBK_LAUNCH((gemm_nt_bf16_kernel<128, 128>), dim3(sbk::cdiv(N, 128), sbk::cdiv(M, 128)), dim3(256), 0, st, g);
+  } else {
+    SBK_LAUNCH((gemm_nt_bf16_kernel<64, 64>), dim3(sbk::cdiv(N, 64), sbk::cdiv(M, 64)), dim3(256), 0, st, g);
+  }
+  return sbk::launch_status("sbk_gemm_nt_bf16");
 }

@@ -27,6 +27,20 @@ __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
 }
 
+// bf16 operands: 8 per lane (4 VGPRs).  D(32x32) += A(32x16) * B(16x32), fp32 accumulate; lane l supplies row / column
+// l&31 and the k block l>>5 (8 consecutive k each); acc layout as for mfma_32x32x2.  2.5 PFLOP/s dense on MI355X.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+// fp32 -> bf16 bits, round to nearest even (NaN stays NaN: the quiet bit survives the truncation)
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, kWave); }
 __device__ __forceinline__ int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, kWave); }
 __device__ __forceinline__ float shfl(float v, int lane) { return __shfl(v, lane, kWave); }
@@ -39,16 +53,6 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // Scheduling fence for the compiler: nothing is moved across it (keeps a block of loads issued ahead of
 // the arithmetic that consumes them instead of sunk next to each use).
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
-
-// Loads the compiler does NOT count (cdna_hip_programming.md 5.7 form ii): a 16-byte global load whose completion is
-// awaited by loads_wait<N>() -- "at most N of this wave's vector-memory loads still outstanding" -- naming the
-// registers that become readable.  hipcc's own s_waitcnt pass collapses a register ring that is several K tiles deep
-// to vmcnt(0..3) inside a loop, i.e. back to one tile in flight; with these the ring really stays in flight across
-// barriers.  Rule for users: between load16_async and the matching loads_wait the wave issues no other VMEM load.
-// (macros: the operands must be plain local lvalues -- hipcc cannot tie an asm operand through a reference)
-#define SBK_LOAD16_ASYNC(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
-#define SBK_LOADS_WAIT(N, a, b, c, d) \
-  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
 
 // x * 2^e and the exponent k of x = f * 2^k, f in [0.5,1) (0 for x = 0): single VALU instructions
 // (v_ldexp_f32 / v_frexp_exp_i32_f32) without the libm special-case wrappers.

@@ -28,11 +28,14 @@ class EncoderDecoderASR(Pretrained):
         return words[0]
 
     def encode_batch(self, wavs, wav_lens):
+        from speechbrain_amd import native
+
         wavs = wavs.float()
         wavs, wav_lens = wavs.to(self.device), wav_lens.to(self.device)
-        encoder_out = self.mods.encoder(wavs, wav_lens)
+        encoder_out = self.mods.encoder(wavs, wav_lens)  # Fbank / normalisation / CNN: always fp32
         if self.transformer_beam_search:
-            encoder_out = self.mods.transformer.encode(encoder_out, wav_lens)
+            with native.precision_scope(self.eval_precision):
+                encoder_out = self.mods.transformer.encode(encoder_out, wav_lens)
         return encoder_out
 
     def transcribe_batch(self, wavs, wav_lens):

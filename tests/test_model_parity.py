@@ -602,3 +602,27 @@ def test_grouped_search_equals_separate_searches(backend, ctc_weight):
         assert p_g.shape == p_s.shape and float((p_g.cpu() - p_s.cpu()).abs().max()) <= 2e-5
     early = [len(h) < int(items[i][0].shape[1] * ratios[i][1]) - 1 for i, res in enumerate(separate) for h in res[0]]
     assert any(early), "the case should contain hypotheses that end through EOS before the step limit"
+
+
+def test_bf16_precision_is_opt_in_and_close(backend):
+    """run_opts precision="bf16": the encoder's large GEMMs take bf16 operands (fp32 accumulation); the default stays
+    the fp32 parity path bit for bit.  Stated tolerance for this tiny model: encoder output within 5e-2 absolute of
+    the fp32 path (LayerNorm-ed activations of unit scale, 8-bit mantissas through 2 layers)."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_asr
+
+    tiny = dict(d_model=64, nhead=4, d_ffn=128, n_enc=2, n_dec=1, n_fft=512, win_length=32)
+    a32 = build_asr(tiny, vocab=30, seed=2, beam_size=2, ctc_weight=0.3, device=str(dev))
+    a16 = build_asr(tiny, vocab=30, seed=2, beam_size=2, ctc_weight=0.3, device=str(dev))
+    a16.eval_precision = "bf16"
+    wav = 0.1 * torch.randn(3, 48000, generator=torch.Generator().manual_seed(8))  # 3 x 76 frames = 228 >= 256? no:
+    wav = torch.cat([wav, wav], dim=0)                                              # 6 x 76 = 456 rows -> bf16 kernel
+    lens = torch.ones(6)
+    e32, e32b, e16 = a32.encode_batch(wav, lens), a32.encode_batch(wav, lens), a16.encode_batch(wav, lens)
+    assert torch.equal(e32, e32b)
+    d = float((e32 - e16).abs().max())
+    assert 0.0 < d <= 5e-2, d
+    assert nat.precision() == "fp32"  # the scope does not leak
+    with pytest.raises(NotImplementedError):
+        build_asr(tiny, vocab=30, seed=2, device=str(dev)).__class__(modules=dict(a32.mods), hparams={"tokenizer": None},
+                                                                     run_opts={"device": str(dev), "precision": "fp8"})

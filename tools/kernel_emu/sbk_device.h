@@ -28,6 +28,9 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
@@ -131,6 +134,41 @@ static inline f32x16 mfma_32x32x2(float a, float b, f32x16 acc) {
   sbk_emu::wave_barrier();
   return acc;
 }
+struct __attribute__((aligned(16))) bf16x8 {
+  unsigned short v[8];
+};
+static inline unsigned short f32_to_bf16(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+static inline float bf16_to_f32_(unsigned short h) {
+  const unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 acc) {
+  const int l = sbk_emu::cur().lane;
+  float* A = sbk_emu::wave_buf(0);  // [lane][8]
+  float* B = sbk_emu::wave_buf(1);
+  for (int e = 0; e < 8; ++e) {
+    A[l * 8 + e] = bf16_to_f32_(a.v[e]);
+    B[l * 8 + e] = bf16_to_f32_(b.v[e]);
+  }
+  sbk_emu::wave_barrier();
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+    float c = acc[r];
+    for (int kb = 0; kb < 2; ++kb)
+      for (int e = 0; e < 8; ++e) c = fmaf(A[(row + 32 * kb) * 8 + e], B[(col + 32 * kb) * 8 + e], c);
+    acc[r] = c;
+  }
+  sbk_emu::wave_barrier();
+  return acc;
+}
 static inline f32x4 mfma_16x16x4(float a, float b, f32x4 acc) {
   const int l = sbk_emu::cur().lane;
   float* A = sbk_emu::wave_buf(0);
@@ -165,8 +203,6 @@ static inline float shfl(float v, int lane) { return shfl_idx_(v, lane); }
 static inline int shfl(int v, int lane) { return shfl_idx_(v, lane); }
 static inline void wave_sync() { sbk_emu::wave_barrier(); }
 static inline void sched_fence() {}
-#define SBK_LOAD16_ASYNC(dst, ptr) ((dst) = *reinterpret_cast<const sbk::f32x4*>(ptr))
-#define SBK_LOADS_WAIT(N, a, b, c, d) ((void)0)  // a hint to the device compiler's scheduler; nothing to do on the host
 static inline float fast_ldexp(float x, int e) {
   if (e < -400) return x * 0.0f;
   if (e > 400) e = 400;

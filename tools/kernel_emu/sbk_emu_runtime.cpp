@@ -64,7 +64,7 @@ struct BlockRun {
   int wave_count[kMaxThreads / 64] = {0};
   unsigned wave_gen[kMaxThreads / 64] = {0};
   int wave_live[kMaxThreads / 64] = {0};
-  float wbuf[kMaxThreads / 64][2][64];
+  float wbuf[kMaxThreads / 64][2][512];
   std::vector<char> dyn;
   unsigned long progress = 0;  // bumped on every barrier arrival / fiber exit (deadlock detection)
   ~BlockRun() {

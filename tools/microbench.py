@@ -106,16 +106,27 @@ if __name__ == "__main__":
         nat.load().sbk_prof_set_knob(2, 0)
         nat.load().sbk_prof_set_knob(9, 0)
         sys.exit(0)
-    if "--pipe" in sys.argv:  # mid-M decode GEMMs on the 64x64 tiles: register-ring depth 0 (plain) / 2 / 3 / 4
-        nat.load().sbk_prof_set_knob(2, 1)
-        for depth in (0, 2, 3, 4):
-            nat.load().sbk_prof_set_knob(11, depth)
-            print("64x64 tiles, ring depth", depth)
-            for M in (320, 1280, 2560, 5120):
-                for (N, K) in [(512, 512), (1536, 512), (2048, 512), (512, 2048)]:
-                    gemm_case(M, N, K, 0)
-        nat.load().sbk_prof_set_knob(11, 0)
-        nat.load().sbk_prof_set_knob(2, 0)
+    if "--pmc-decode" in sys.argv:  # short: the decode-step GEMM variants whose wave-level counters are read from PMC passes
+        for (knobs, tag) in (((12, 1, 11, 100000), "flat32"), ((12, 1, 11, 600), "flat64"), ((2, 1, 12, 0), "tiled")):
+            for i in range(0, len(knobs), 2):
+                nat.load().sbk_prof_set_knob(knobs[i], knobs[i + 1])
+            print("variant", tag)
+            for (M, N, K) in [(320, 512, 512), (1280, 512, 512), (1280, 2048, 512), (2560, 512, 512)]:
+                gemm_case(M, N, K, 8, iters=5)
+            nat.load().sbk_prof_set_knob(2, 0)
+        nat.load().sbk_prof_set_knob(11, 600)
+        nat.load().sbk_prof_set_knob(12, 0)
+        sys.exit(0)
+    if "--flat64" in sys.argv:  # register-operand path: 32x32 tiles vs 64x64 tiles (2x2 accumulators), reach on
+        nat.load().sbk_prof_set_knob(12, 1)
+        for min_rows in (100000, 600):
+            nat.load().sbk_prof_set_knob(11, min_rows)
+            print("register-operand path,", "32x32 tiles" if min_rows > 10000 else "64x64 tiles from 600 rows")
+            for M in (640, 1280, 2560, 5120):
+                for (N, K) in [(512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512)]:
+                    gemm_case(M, N, K, 8)
+        nat.load().sbk_prof_set_knob(11, 600)
+        nat.load().sbk_prof_set_knob(12, 0)
         sys.exit(0)
     if "--skinny" in sys.argv:  # decode-step GEMMs on the register-operand path: looped (round 1) vs flat schedule
         for looped in (1, 0):
