@@ -317,8 +317,8 @@ def main():
         return dt, hyps, local, info
 
     def auto(max_batch):
-        group = args.group or max(1, 256 // max_batch)
-        return args.streams or (6 if group > 1 else 8), group
+        # measured (tools/ab_cases.txt sweeps, profiles/r02_*): 8 workers; 4 recipe-sized batches per grouped search
+        return args.streams or 8, args.group or max(1, 128 // max_batch)
 
     dt, hyps, local_batches, info = timed_run(args.max_batch, *auto(args.max_batch))
     note(f"timed region done: {dt:.3f} s")
@@ -404,10 +404,11 @@ def main():
         note("instrumented repetition (HIP events)")
         native.prof_reset()
         native.prof_enable(True)
-        rep_audio = 0.0
-        for ids, w, l in local_batches:
-            run_step(asr, w, l)
-            rep_audio += sum(seconds[i] for i in ids)
+        # the same batches, grouped as in the timed region, on ONE worker stream (every launch between two events)
+        one = ConcurrentTranscriber(asr, streams=1, prioritise_search=False, group=auto(args.max_batch)[1])
+        one.transcribe_batches([(w, l) for _, w, l in local_batches], prepare=fixed_decode_length)
+        one.pool.shutdown(wait=True)
+        rep_audio = sum(seconds[i] for ids, _, _ in local_batches for i in ids)
         torch.cuda.synchronize()
         native.prof_enable(False)
         rep = native.prof_report()

@@ -5,7 +5,7 @@
 //   embed_pos        x = emb[tok]*sqrt(d) + pe[step]                        (HBM-bound gather)
 //   self_attn_step   causal MHA of the new token over its own prefix; K/V of
 //                    earlier positions live in a slot-addressed cache
-//                    [pos][slot][d] and are reached through the per-hypothesis
+//                    [slot][pos][d] and are reached through the per-hypothesis
 //                    ancestry table kv_slot[hyp][pos] (beam reordering moves
 //                    4-byte slot ids, never K/V rows)
 //   cross_attn_step  MHA over the encoder memory; the K/V projections of the
@@ -34,7 +34,8 @@ __global__ void __launch_bounds__(256) embed_pos_kernel(const int32_t* __restric
 // ---------------------------------------------------------------- self attention, one new token
 struct SelfAttnArgs {
   const float* qkv;        // [n,3d] stacked (q | k | v) for the new token
-  float* kcache;           // [Lmax][nslot][d]
+  float* kcache;           // [nslot][Lmax][d]: slot-major, so the prefix of a hypothesis (its ancestors are the
+                           // beams of its own utterance) lives in a few MB instead of one row per 2.6 MB stride
   float* vcache;
   const int32_t* kv_slot;  // [n][Lmax]: slot holding position p of hypothesis i (p < step)
   float* out;              // [n,d]
@@ -46,6 +47,9 @@ struct SelfAttnArgs {
   // (key_first for p < key_shift).  NULL = no mask.
   const int32_t* key_tok;
   int key_stride, key_shift, key_first, pad_idx;
+  int group;  // > 1: hypotheses come in groups of `group` beams of one utterance -- the waves of a workgroup then
+              // take different BEAMS of the same (utterance, head): beams share most of their ancestry, so the
+              // workgroup's waves read the same cache rows at the same time (one trip to HBM, the rest from L1/L2)
 };
 
 // One wave per (hypothesis, head).  The 64 lanes form 4 position groups x 16 lanes; a group's 16
@@ -59,7 +63,12 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = blockIdx.x * 4 + wave;
   const bool live = item < a.n * a.H;
-  const int i = live ? item / a.H : 0, h = live ? item % a.H : 0;
+  int i = live ? item / a.H : 0, h = live ? item % a.H : 0;
+  if (live && a.group > 1) {  // item = ((utterance * H + head) * group + beam)
+    const int per = a.H * a.group, u = item / per, rem = item % per;
+    h = rem / a.group;
+    i = u * a.group + rem % a.group;
+  }
   const int d = a.d, Dh = a.Dh, L = a.step + 1;
   const int lpad = ((a.Lmax + 63) / 64) * 64;
   float* prob = lds + wave * 2 * lpad;
@@ -72,7 +81,7 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
   // append this token's K/V head slice to the cache (slot = hypothesis index)
   if (live) {
     for (int c = lane; c < Dh; c += 64) {
-      const size_t o = ((size_t)a.step * a.nslot + i) * d + h * Dh + c;
+      const size_t o = ((size_t)i * a.Lmax + a.step) * d + h * Dh + c;
       a.kcache[o] = knew[c];
       a.vcache[o] = vnew[c];
     }
@@ -80,8 +89,8 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
   for (int p = lane; p < a.step; p += 64) slot[p] = a.kv_slot[(size_t)i * a.Lmax + p];
   sbk::wave_sync();
   const size_t head_off = (size_t)h * Dh;
-  auto krow = [&](int p) { return (p == a.step) ? knew : a.kcache + ((size_t)p * a.nslot + slot[p]) * d + head_off; };
-  auto vrow = [&](int p) { return (p == a.step) ? vnew : a.vcache + ((size_t)p * a.nslot + slot[p]) * d + head_off; };
+  auto krow = [&](int p) { return (p == a.step) ? knew : a.kcache + ((size_t)slot[p] * a.Lmax + p) * d + head_off; };
+  auto vrow = [&](int p) { return (p == a.step) ? vnew : a.vcache + ((size_t)slot[p] * a.Lmax + p) * d + head_off; };
   const bool piece = vec && cq * 4 < Dh;
   float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (piece) {
@@ -618,6 +627,110 @@ __global__ void __launch_bounds__(256) cross_attn_mfma_kernel(CrossAttnArgs a) {
   }
 }
 
+// Streaming formulation for d = 512 (Conformer-L: 8 heads x 64): ONE WAVE walks a run of memory frames by itself --
+// no LDS, no barrier.  A frame's K row (all heads, 2 KB) is one fully coalesced wave load of 32 bytes per lane, so
+// lane l owns channels 8l .. 8l+7 = head l/8; it keeps the matching 8 channels of every beam's query and context in
+// registers (the queries sit in a per-wave LDS slab).  Per frame and beam: 8 FMAs, a 3-step DPP sum over the 8 lanes of
+// the head, and -- once per 2 frames -- one flash-style rescale (running max / sum per beam, replicated in the head's
+// lanes).  K and V of the next 2 frames (8 KB per wave) are requested before the current 2 are consumed.  Partials go through the same
+// (context, max, sum) buffer as the other variants and are combined by cross_merge_kernel.
+template <int NQ>
+__global__ void __launch_bounds__(256) cross_attn_stream_kernel(CrossAttnArgs a, int fpw) {
+  __shared__ __attribute__((aligned(16))) float qs[4][NQ][512];  // each wave's own queries (scaled), 20 KB per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw = blockIdx.x * 4 + wave;
+  const int qtiles = (a.beam + NQ - 1) / NQ;
+  const int item = gw / a.NS, split = gw % a.NS;
+  const int b = item / qtiles, q0 = (item % qtiles) * NQ;
+  if (b >= a.B) return;  // whole wave; nothing below synchronises across waves
+  const int nq = min(NQ, a.beam - q0);
+  const int d = a.d, T = a.T, DH = a.Dh;
+  const int klen = min(max(a.enc_len[b], 1), T);
+  const int t0 = split * fpw, t1 = min(klen, t0 + fpw);
+  const int h = (lane * 8) / DH, c0 = (lane * 8) % DH;
+
+  float acc[NQ][8], m[NQ], l[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const float* qp = a.q + ((size_t)b * a.beam + q0 + min(j, nq - 1)) * d + lane * 8;
+    float4 x0 = *reinterpret_cast<const float4*>(qp), x1 = *reinterpret_cast<const float4*>(qp + 4);
+    x0.x *= a.scale; x0.y *= a.scale; x0.z *= a.scale; x0.w *= a.scale;
+    x1.x *= a.scale; x1.y *= a.scale; x1.z *= a.scale; x1.w *= a.scale;
+    *reinterpret_cast<float4*>(&qs[wave][j][lane * 8]) = x0;
+    *reinterpret_cast<float4*>(&qs[wave][j][lane * 8 + 4]) = x1;
+    m[j] = -INFINITY;
+    l[j] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[j][e] = 0.0f;
+  }
+  sbk::wave_sync();
+  const float* kvb = a.kv + (size_t)b * T * 2 * d + lane * 8;
+  // two register buffers of two frames each (K and V, 8 channels per lane): one is consumed while the other lands
+  float4 bufK[2][2][2], bufV[2][2][2];
+  auto fetch = [&](int t, int which) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float* row = kvb + (size_t)min(t + u, T - 1) * 2 * d;  // frames >= t1: loaded, weighted 0
+      bufK[which][u][0] = *reinterpret_cast<const float4*>(row);
+      bufK[which][u][1] = *reinterpret_cast<const float4*>(row + 4);
+      bufV[which][u][0] = *reinterpret_cast<const float4*>(row + d);
+      bufV[which][u][1] = *reinterpret_cast<const float4*>(row + d + 4);
+    }
+  };
+  auto consume = [&](int t, int which) {
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const float4 qa = *reinterpret_cast<const float4*>(&qs[wave][j][lane * 8]);
+      const float4 qb = *reinterpret_cast<const float4*>(&qs[wave][j][lane * 8 + 4]);
+      float sc[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float4 ka = bufK[which][u][0], kb = bufK[which][u][1];
+        float p = qa.x * ka.x;
+        p = fmaf(qa.y, ka.y, p); p = fmaf(qa.z, ka.z, p); p = fmaf(qa.w, ka.w, p);
+        p = fmaf(qb.x, kb.x, p); p = fmaf(qb.y, kb.y, p); p = fmaf(qb.z, kb.z, p); p = fmaf(qb.w, kb.w, p);
+        p = sbk::group_sum<8>(p);  // the 8 lanes of this head (DH = 64)
+        sc[u] = (t + u < t1) ? p : -INFINITY;
+      }
+      const float mn = fmaxf(m[j], fmaxf(sc[0], sc[1]));  // finite: frame t is valid
+      const float al = expf(m[j] - mn), w0 = expf(sc[0] - mn), w1 = expf(sc[1] - mn);
+      l[j] = fmaf(l[j], al, w0 + w1);
+      m[j] = mn;
+      const float4 va0 = bufV[which][0][0], vb0 = bufV[which][0][1], va1 = bufV[which][1][0], vb1 = bufV[which][1][1];
+      acc[j][0] = fmaf(w1, va1.x, fmaf(w0, va0.x, acc[j][0] * al));
+      acc[j][1] = fmaf(w1, va1.y, fmaf(w0, va0.y, acc[j][1] * al));
+      acc[j][2] = fmaf(w1, va1.z, fmaf(w0, va0.z, acc[j][2] * al));
+      acc[j][3] = fmaf(w1, va1.w, fmaf(w0, va0.w, acc[j][3] * al));
+      acc[j][4] = fmaf(w1, vb1.x, fmaf(w0, vb0.x, acc[j][4] * al));
+      acc[j][5] = fmaf(w1, vb1.y, fmaf(w0, vb0.y, acc[j][5] * al));
+      acc[j][6] = fmaf(w1, vb1.z, fmaf(w0, vb0.z, acc[j][6] * al));
+      acc[j][7] = fmaf(w1, vb1.w, fmaf(w0, vb0.w, acc[j][7] * al));
+    }
+  };
+  if (t0 < t1) fetch(t0, 0);
+  for (int t = t0; t < t1; t += 4) {
+    if (t + 2 < t1) fetch(t + 2, 1);
+    consume(t, 0);
+    if (t + 2 < t1) {
+      if (t + 4 < t1) fetch(t + 4, 0);
+      consume(t + 2, 1);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    if (j < nq) {
+      float* pp = a.part + ((((size_t)b * a.H + h) * a.NS + split) * a.beam + q0 + j) * (DH + 2);
+#pragma unroll
+      for (int e = 0; e < 8; e += 2)  // rows of DH + 2 floats are 8-byte, not 16-byte, aligned
+        *reinterpret_cast<float2*>(pp + c0 + e) = make_float2(acc[j][e], acc[j][e + 1]);
+      if (c0 == 0) {
+        pp[DH] = m[j];
+        pp[DH + 1] = l[j];
+      }
+    }
+  }
+}
+
 // out[i, h*DH + c] = sum_s e^{m_s - M} o_s[c] / sum_s e^{m_s - M} l_s
 __global__ void __launch_bounds__(256) cross_merge_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int H, int NS, int beam, int DH, int d) {
@@ -657,6 +770,34 @@ template <int DH>
 int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
   const int qtiles = (a.beam + kQT - 1) / kQT;
   sbk::ProfScope prof("cross_attn_step", 4.0 * a.B * a.beam * (double)a.T * a.d, 8.0 * a.B * (double)a.T * a.d, st);
+  if constexpr (DH == 64) {
+    // streaming variant (one wave per run of frames, no LDS): d = 512 with 16-byte aligned rows, row-major K/V
+    if ((sbk::g_cross_rows == 3 || sbk::g_cross_rows == 4) && a.d == 512 && !a.head_major && a.part &&
+        sbk::aligned16(a.kv) && sbk::aligned16(a.q) && (reinterpret_cast<uintptr_t>(a.part) & 7) == 0) {
+      // knob 4 = 3: all (<= 10) beams in one wave (288 registers, one wave per SIMD); 4: five beams per wave, two
+      // waves share a run of frames through L1/L2 (half the registers, three waves per SIMD)
+      const int NQ = sbk::g_cross_rows == 3 ? 10 : 5;
+      const int qt = (a.beam + NQ - 1) / NQ;
+      // frames per wave: >= ~4 waves per CU where the batch allows it, 16 .. 64 frames, multiple of 4
+      long total = (long)a.B * qt * a.T;
+      int fpw = (int)(total / 1024);
+      fpw = fpw < 16 ? 16 : (fpw > 64 ? 64 : fpw);
+      fpw = (fpw + 3) & ~3;
+      CrossAttnArgs b = a;
+      b.NS = sbk::cdiv(a.T, fpw);
+      const int waves = a.B * qt * b.NS;
+      if (NQ == 10) {
+        SBK_LAUNCH((cross_attn_stream_kernel<10>), dim3(sbk::cdiv(waves, 4)), dim3(256), 0, st, b, fpw);
+      } else {
+        SBK_LAUNCH((cross_attn_stream_kernel<5>), dim3(sbk::cdiv(waves, 4)), dim3(256), 0, st, b, fpw);
+      }
+      int rc3 = sbk::launch_status("cross_attn_step");
+      if (rc3) return rc3;
+      SBK_LAUNCH(cross_merge_kernel, dim3(a.B * a.beam), dim3(256), 0, st, (const float*)b.part, b.out, b.H, b.NS,
+                 b.beam, DH, b.d);
+      return sbk::launch_status("cross_merge");
+    }
+  }
   if constexpr (DH == 64 || DH == 32) {
     if (sbk::g_cross_rows == 2 && (a.d % 4) == 0 && sbk::aligned16(a.kv) && sbk::aligned16(a.q)) {
       const int qt2 = (a.beam + kQT2 - 1) / kQT2;
@@ -731,10 +872,11 @@ int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* 
 
 int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t* kv_slot, float* out, int n, int d,
                    int H, int step, int nslot, int Lmax, hipStream_t st, const int32_t* key_tok, int key_stride,
-                   int key_shift, int key_first, int pad_idx) {
+                   int key_shift, int key_first, int pad_idx, int group) {
   if (n == 0) return 0;
+  if (group < 1 || n % group != 0 || g_self_group_off) group = 1;
   SelfAttnArgs a{qkv, kcache, vcache, kv_slot, out, n, d, H, d / H, step, nslot, Lmax, 1.0f / sqrtf((float)(d / H)),
-                 g_step_ptr, key_tok, key_stride, key_shift, key_first, pad_idx};
+                 g_step_ptr, key_tok, key_stride, key_shift, key_first, pad_idx, group};
   const size_t lds = (size_t)8 * (((Lmax + 63) / 64) * 64) * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "self_attn_step: Lmax=%d too long for the LDS window", Lmax);
   ProfScope prof("self_attn_step", 4.0 * n * d * (step + 1), 8.0 * n * d * (step + 1), st);
@@ -743,8 +885,10 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
 }
 
 // Number of memory splits used for T frames and floats of partial storage they need.
+int g_self_group_off = 0;  // tuning knob (key 13): 1 = self-attention waves of a workgroup take 4 heads of one hypothesis
+                           // (the round-1 mapping) instead of 4 beams of one (utterance, head)
 int g_cross_fc256 = 0;  // tuning knob (key 8): memory frames per workgroup of the frame-per-thread kernel: 0 = 128, 1 = 256, 2 = 64
-int cross_attn_splits(int T) { return cdiv(T, 64); }  // sizes the partial buffer for the finest split
+int cross_attn_splits(int T) { return cdiv(T, 16); }  // sizes the partial buffer for the finest split (16-frame runs)
 size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam) {
   const int ns = cross_attn_splits(T);
   return ns > 1 ? (size_t)B * H * ns * beam * (Dh + 2) : 0;

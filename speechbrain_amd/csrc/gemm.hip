@@ -38,238 +38,6 @@ struct GemmArgs {
   int rows_per_seq;
 };
 
-// Register-staged panel: global -> registers (issued early, in flight under the MFMAs of the previous
-// K tile) -> LDS [rows][BK+1].
-template <int ROWS, int BK, int NT>
-struct PanelStage {
-  static constexpr int V = BK / 4;                       // float4 slots per row
-  static constexpr int PER = (ROWS * V + NT - 1) / NT;   // float4 slots per thread
-  float4 r[PER];
-
-  template <bool VEC>
-  __device__ __forceinline__ void fetch(const float* __restrict__ src, int ld, int row0, int nrows, int k0, int K,
-                                        int tid) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int s = tid + i * NT;
-      const int rr = s / V, c = (s % V) * 4;
-      const int gr = row0 + rr, gk = k0 + c;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (s < ROWS * V && gr < nrows) {
-        const float* p = src + (size_t)gr * ld + gk;
-        if (VEC && gk + 3 < K) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (gk < K) v.x = p[0];
-          if (gk + 1 < K) v.y = p[1];
-          if (gk + 2 < K) v.z = p[2];
-          if (gk + 3 < K) v.w = p[3];
-        }
-      }
-      r[i] = v;
-    }
-  }
-  // [rows][BK+4] layout: one 16-byte LDS store per slot (rows stay 16-byte aligned: (BK+4)*4 is a multiple of 16)
-  __device__ __forceinline__ void commit_vec(float (*dst)[BK + 4], int tid) const {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int s = tid + i * NT;
-      if (s < ROWS * V) *reinterpret_cast<float4*>(&dst[s / V][(s % V) * 4]) = r[i];
-    }
-  }
-  __device__ __forceinline__ void commit(float (*dst)[BK + 1], int tid) const {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int s = tid + i * NT;
-      if (s < ROWS * V) {
-        const int rr = s / V, c = (s % V) * 4;
-        dst[rr][c] = r[i].x;
-        dst[rr][c + 1] = r[i].y;
-        dst[rr][c + 2] = r[i].z;
-        dst[rr][c + 3] = r[i].w;
-      }
-    }
-  }
-};
-
-template <int BM, int BN, int BK, int WM, int WN, bool VEC>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(GemmArgs g) {
-  constexpr int WAVES_N = BN / WN;
-  constexpr int NT = (BM / WM) * (BN / WN) * 64;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  __shared__ float As[BM][BK + 1];
-  __shared__ float Ws[BN][BK + 1];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-  // XCD-aware tile order (workgroup id % 8 = XCD): each XCD walks a contiguous range of tiles, so the
-  // A row panel shared by neighbouring tiles is fetched into one L2 instead of eight.
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
-    const int id = by * gx + bx;
-    if (nwg % 8 == 0) {
-      const int swz = (id % 8) * (nwg / 8) + id / 8;
-      bx = swz % gx;
-      by = swz / gx;
-    }
-  }
-  const int m0 = by * BM, n0 = bx * BN;
-  const int lrow = lane & 31, lk = lane >> 5;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  PanelStage<BM, BK, NT> pa;
-  PanelStage<BN, BK, NT> pw;
-  pa.template fetch<VEC>(g.A, g.lda, m0, g.M, 0, g.K, tid);
-  pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, 0, g.K, tid);
-  for (int k0 = 0; k0 < g.K; k0 += BK) {
-    pa.commit(As, tid);
-    pw.commit(Ws, tid);
-    __syncthreads();
-    if (k0 + BK < g.K) {  // next K tile: loads fly while this tile is multiplied
-      pa.template fetch<VEC>(g.A, g.lda, m0, g.M, k0 + BK, g.K, tid);
-      pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, k0 + BK, g.K, tid);
-    }
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[wm0 + i * 32 + lrow][kk + lk];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Ws[wn0 + j * 32 + lrow][kk + lk];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x2(a[i], b[j], acc[i][j]);
-    }
-    __syncthreads();
-  }
-
-  // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn0 + j * 32 + lrow;
-    if (col >= g.N) continue;
-    const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= g.M) continue;
-        float v = apply_act(acc[i][j][r] + bv, g.act) * g.alpha;
-        if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
-        if (g.R) v += g.R[(size_t)row * g.ldr + col];
-        g.C[(size_t)row * g.ldc + col] = v;
-      }
-    }
-  }
-}
-
-// Same tiling with 16-byte LDS traffic.  The two k-slices of v_mfma_f32_32x32x2 need not be neighbours in
-// memory: any pairing of k values is a valid contraction as long as A and W use the same one.  Lane half
-// `lk` therefore owns the contiguous run [lk*BK/2, (lk+1)*BK/2) of a K tile and MFMA number j multiplies
-// k = j (lanes 0-31) with k = BK/2 + j (lanes 32-63): every operand fetch is a ds_read_b128 of four
-// consecutive k (4x fewer LDS instructions than scalar reads at pitch BK+1) and every panel store a
-// ds_write_b128.  Pitch BK+4 floats: the 16-lane groups of a b128 read (MI355X_MICROARCH.md, LDS table) land
-// on 16 distinct 4-bank groups because (BK+4)/4 is odd; the 8-lane groups of a b128 write cover one row.
-template <int BM, int BN, int BK, int WM, int WN, bool VEC>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_v4_kernel(GemmArgs g) {
-  constexpr int WAVES_N = BN / WN;
-  constexpr int NT = (BM / WM) * (BN / WN) * 64;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  static_assert(((BK + 4) / 4) % 2 == 1 && BK % 8 == 0, "pitch (BK+4)/4 must be odd");
-  __shared__ __attribute__((aligned(16))) float As[BM][BK + 4];
-  __shared__ __attribute__((aligned(16))) float Ws[BN][BK + 4];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-  int bx = blockIdx.x, by = blockIdx.y;
-  {  // XCD-aware tile order, as in gemm_nt_kernel
-    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
-    const int id = by * gx + bx;
-    if (nwg % 8 == 0) {
-      const int swz = (id % 8) * (nwg / 8) + id / 8;
-      bx = swz % gx;
-      by = swz / gx;
-    }
-  }
-  const int m0 = by * BM, n0 = bx * BN;
-  const int lrow = lane & 31, lk = lane >> 5;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  PanelStage<BM, BK, NT> pa;
-  PanelStage<BN, BK, NT> pw;
-  pa.template fetch<VEC>(g.A, g.lda, m0, g.M, 0, g.K, tid);
-  pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, 0, g.K, tid);
-  for (int k0 = 0; k0 < g.K; k0 += BK) {
-    pa.commit_vec(As, tid);
-    pw.commit_vec(Ws, tid);
-    __syncthreads();
-    if (k0 + BK < g.K) {  // next K tile: loads fly while this tile is multiplied
-      pa.template fetch<VEC>(g.A, g.lda, m0, g.M, k0 + BK, g.K, tid);
-      pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, k0 + BK, g.K, tid);
-    }
-#pragma unroll
-    for (int kv = 0; kv < BK / 2; kv += 4) {
-      float4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(&As[wm0 + i * 32 + lrow][lk * (BK / 2) + kv]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(&Ws[wn0 + j * 32 + lrow][lk * (BK / 2) + kv]);
-      // k-major order: consecutive MFMAs go to DIFFERENT accumulators (a same-accumulator pair with anything
-      // scheduled in between stalls, MI355X_MICROARCH.md per-instruction table)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const float av = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
-            const float bw = e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w;
-            acc[i][j] = sbk::mfma_32x32x2(av, bw, acc[i][j]);
-          }
-    }
-    __syncthreads();
-  }
-
-  // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn0 + j * 32 + lrow;
-    if (col >= g.N) continue;
-    const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= g.M) continue;
-        float v = apply_act(acc[i][j][r] + bv, g.act) * g.alpha;
-        if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
-        if (g.R) v += g.R[(size_t)row * g.ldr + col];
-        g.C[(size_t)row * g.ldc + col] = v;
-      }
-    }
-  }
-}
-
 // Epilogue of a 32x32 register tile held by ONE wave (lane: column r, rows (q&3) + 8*(q>>2) + 4*half): straight-line
 // code -- the residual rows / sequence lengths are requested together, the activation is chosen by ONE uniform
 // switch outside the per-row work, and the sixteen row stores are issued back to back (a branchy per-row loop makes
@@ -455,6 +223,259 @@ __global__ void __launch_bounds__(256) gemm_nt_bf16_kernel(GemmBf16Args g) {
 
 __global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = sbk::f32_to_bf16(x[i]);
+}
+
+// Register-staged panel: global -> registers (issued early, in flight under the MFMAs of the previous
+// K tile) -> LDS [rows][BK+1].
+template <int ROWS, int BK, int NT>
+struct PanelStage {
+  static constexpr int V = BK / 4;                       // float4 slots per row
+  static constexpr int PER = (ROWS * V + NT - 1) / NT;   // float4 slots per thread
+  float4 r[PER];
+
+  template <bool VEC>
+  __device__ __forceinline__ void fetch(const float* __restrict__ src, int ld, int row0, int nrows, int k0, int K,
+                                        int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int s = tid + i * NT;
+      const int rr = s / V, c = (s % V) * 4;
+      const int gr = row0 + rr, gk = k0 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (s < ROWS * V && gr < nrows) {
+        const float* p = src + (size_t)gr * ld + gk;
+        if (VEC && gk + 3 < K) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (gk < K) v.x = p[0];
+          if (gk + 1 < K) v.y = p[1];
+          if (gk + 2 < K) v.z = p[2];
+          if (gk + 3 < K) v.w = p[3];
+        }
+      }
+      r[i] = v;
+    }
+  }
+  // Interior tiles (whole panel inside the matrix, K % BK == 0, 16-byte aligned rows): no predicates at all.  The
+  // predicated form above costs a branch + mask sequence per load (~150 instructions per K tile and wave).
+  __device__ __forceinline__ void fetch_interior(const float* __restrict__ src, int ld, int row0, int k0, int tid) {
+    static_assert((ROWS * V) % NT == 0, "fetch_interior: the panel must divide evenly over the threads");
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int s = tid + i * NT;
+      r[i] = *reinterpret_cast<const float4*>(src + (size_t)(row0 + s / V) * ld + k0 + (s % V) * 4);
+    }
+  }
+  // [rows][BK+4] layout: one 16-byte LDS store per slot (rows stay 16-byte aligned: (BK+4)*4 is a multiple of 16)
+  __device__ __forceinline__ void commit_vec(float (*dst)[BK + 4], int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int s = tid + i * NT;
+      if (s < ROWS * V) *reinterpret_cast<float4*>(&dst[s / V][(s % V) * 4]) = r[i];
+    }
+  }
+  __device__ __forceinline__ void commit(float (*dst)[BK + 1], int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int s = tid + i * NT;
+      if ((ROWS * V) % NT == 0 || s < ROWS * V) {  // evenly divided panels: every slot exists (no mask, no branch)
+        const int rr = s / V, c = (s % V) * 4;
+        dst[rr][c] = r[i].x;
+        dst[rr][c + 1] = r[i].y;
+        dst[rr][c + 2] = r[i].z;
+        dst[rr][c + 3] = r[i].w;
+      }
+    }
+  }
+};
+
+template <int BM, int BN, int BK, int WM, int WN, bool VEC>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(GemmArgs g) {
+  constexpr int WAVES_N = BN / WN;
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  __shared__ float As[BM][BK + 1];
+  __shared__ float Ws[BN][BK + 1];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  // XCD-aware tile order (workgroup id % 8 = XCD): each XCD walks a contiguous range of tiles, so the
+  // A row panel shared by neighbouring tiles is fetched into one L2 instead of eight.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int id = by * gx + bx;
+    if (nwg % 8 == 0) {
+      const int swz = (id % 8) * (nwg / 8) + id / 8;
+      bx = swz % gx;
+      by = swz / gx;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int lrow = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  PanelStage<BM, BK, NT> pa;
+  PanelStage<BN, BK, NT> pw;
+  // (uniform per workgroup) interior tile: unpredicated panel loads
+  const bool interior = VEC && m0 + BM <= g.M && n0 + BN <= g.N && (g.K % BK) == 0 && (BM * (BK / 4)) % NT == 0 &&
+                        (BN * (BK / 4)) % NT == 0;
+  auto fetch = [&](int k0) {
+    if constexpr ((BM * (BK / 4)) % NT == 0 && (BN * (BK / 4)) % NT == 0) {
+      if (interior) {
+        pa.fetch_interior(g.A, g.lda, m0, k0, tid);
+        pw.fetch_interior(g.W, g.ldw, n0, k0, tid);
+        return;
+      }
+    }
+    pa.template fetch<VEC>(g.A, g.lda, m0, g.M, k0, g.K, tid);
+    pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, k0, g.K, tid);
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    pa.commit(As, tid);
+    pw.commit(Ws, tid);
+    __syncthreads();
+    if (k0 + BK < g.K) fetch(k0 + BK);  // next K tile: loads fly while this tile is multiplied
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[wm0 + i * 32 + lrow][kk + lk];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Ws[wn0 + j * 32 + lrow][kk + lk];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x2(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5).  (The batched straight-line epilogue of
+  // the register-operand kernels was tried here: it costs registers -- 3 -> 2 waves per SIMD -- and 17 % throughput.)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn0 + j * 32 + lrow;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        float v = apply_act(acc[i][j][r] + bv, g.act) * g.alpha;
+        if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
+        if (g.R) v += g.R[(size_t)row * g.ldr + col];
+        g.C[(size_t)row * g.ldc + col] = v;
+      }
+    }
+  }
+}
+
+// Same tiling with 16-byte LDS traffic.  The two k-slices of v_mfma_f32_32x32x2 need not be neighbours in
+// memory: any pairing of k values is a valid contraction as long as A and W use the same one.  Lane half
+// `lk` therefore owns the contiguous run [lk*BK/2, (lk+1)*BK/2) of a K tile and MFMA number j multiplies
+// k = j (lanes 0-31) with k = BK/2 + j (lanes 32-63): every operand fetch is a ds_read_b128 of four
+// consecutive k (4x fewer LDS instructions than scalar reads at pitch BK+1) and every panel store a
+// ds_write_b128.  Pitch BK+4 floats: the 16-lane groups of a b128 read (MI355X_MICROARCH.md, LDS table) land
+// on 16 distinct 4-bank groups because (BK+4)/4 is odd; the 8-lane groups of a b128 write cover one row.
+template <int BM, int BN, int BK, int WM, int WN, bool VEC>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_v4_kernel(GemmArgs g) {
+  constexpr int WAVES_N = BN / WN;
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(((BK + 4) / 4) % 2 == 1 && BK % 8 == 0, "pitch (BK+4)/4 must be odd");
+  __shared__ __attribute__((aligned(16))) float As[BM][BK + 4];
+  __shared__ __attribute__((aligned(16))) float Ws[BN][BK + 4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {  // XCD-aware tile order, as in gemm_nt_kernel
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int id = by * gx + bx;
+    if (nwg % 8 == 0) {
+      const int swz = (id % 8) * (nwg / 8) + id / 8;
+      bx = swz % gx;
+      by = swz / gx;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int lrow = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  PanelStage<BM, BK, NT> pa;
+  PanelStage<BN, BK, NT> pw;
+  pa.template fetch<VEC>(g.A, g.lda, m0, g.M, 0, g.K, tid);
+  pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, 0, g.K, tid);
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    pa.commit_vec(As, tid);
+    pw.commit_vec(Ws, tid);
+    __syncthreads();
+    if (k0 + BK < g.K) {  // next K tile: loads fly while this tile is multiplied
+      pa.template fetch<VEC>(g.A, g.lda, m0, g.M, k0 + BK, g.K, tid);
+      pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, k0 + BK, g.K, tid);
+    }
+#pragma unroll
+    for (int kv = 0; kv < BK / 2; kv += 4) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(&As[wm0 + i * 32 + lrow][lk * (BK / 2) + kv]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(&Ws[wn0 + j * 32 + lrow][lk * (BK / 2) + kv]);
+      // k-major order: consecutive MFMAs go to DIFFERENT accumulators (a same-accumulator pair with anything
+      // scheduled in between stalls, MI355X_MICROARCH.md per-instruction table)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float av = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
+            const float bw = e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w;
+            acc[i][j] = sbk::mfma_32x32x2(av, bw, acc[i][j]);
+          }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn0 + j * 32 + lrow;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        float v = apply_act(acc[i][j][r] + bv, g.act) * g.alpha;
+        if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
+        if (g.R) v += g.R[(size_t)row * g.ldr + col];
+        g.C[(size_t)row * g.ldc + col] = v;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -838,7 +859,8 @@ namespace sbk {
 int g_skinny_nch = 0;  // tuning knob (0 = automatic): K chunks fetched per batch by the skinny kernel
 int g_skinny_off = 0;  // tuning knob: 1 = route few-row GEMMs to the LDS-tiled kernels
 int g_skinny_looped = 0;  // tuning knob (key 10): 1 = always the looped skinny kernel (the round-1 schedule)
-int g_flat64_min_rows = 600;  // tuning knob (key 11): from this many rows on the register-operand path uses 64x64 tiles
+int g_flat64_min_rows = 1 << 30;  // tuning knob (key 11): from this many rows on the register-operand path uses 64x64 tiles
+                                  // (off by default: measured slower in situ, 29 vs 23 us at M = 1280)
 int g_skinny_reach = 0;   // tuning knob (key 12): 1 = the register-operand path also takes the mid-M shapes that go to
                           // the LDS-tiled kernels by default (M*N >= 1.9 M with K <= 1024)
 int g_gemm_tile = 0;   // tuning knob (key 6) for the large-M path: 0 = 128x128, 1 = 256x128 (8 waves of 64x64),
@@ -1022,6 +1044,7 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 10) sbk::g_skinny_looped = value;
   if (key == 11) sbk::g_flat64_min_rows = value;
   if (key == 12) sbk::g_skinny_reach = value;
+  if (key == 13) sbk::g_self_group_off = value;
 }
 
 

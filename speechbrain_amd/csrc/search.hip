@@ -21,7 +21,7 @@ int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* 
               hipStream_t st);
 int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t* kv_slot, float* out, int n, int d,
                    int H, int step, int nslot, int Lmax, hipStream_t st, const int32_t* key_tok = nullptr,
-                   int key_stride = 0, int key_shift = 0, int key_first = 0, int pad_idx = 0);
+                   int key_stride = 0, int key_shift = 0, int key_first = 0, int pad_idx = 0, int group = 1);
 int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, float* part, int B, int T,
                     int d, int H, int beam, hipStream_t st, int head_major);
 int kv_head_major(const float* src, float* dst, int B, int T, int d, int H, hipStream_t st);
@@ -708,7 +708,8 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
       SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.sa_in_w, dm, L.sa_in_b, nullptr, 0, d.qkv, 3 * dm, n, 3 * dm, dm, SBK_ACT_NONE,
                               1.0f, nullptr, 0, d.splitk, d.splitk_floats, st));
     }
-    SBK_TRY(sbk::self_attn_step(d.qkv, d.kcache[l], d.vcache[l], kv_slot, d.ctx, n, dm, H, step, n, Lmax, st));
+    SBK_TRY(sbk::self_attn_step(d.qkv, d.kcache[l], d.vcache[l], kv_slot, d.ctx, n, dm, H, step, n, Lmax, st, nullptr, 0, 0,
+                                0, 0, beam));
     SBK_TRY(sbk::gemm_nt_ws(d.ctx, dm, L.sa_out_w, dm, L.sa_out_b, d.x, dm, d.x, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
                          0, d.splitk, d.splitk_floats, st));
     frc = L.ca_q_wf ? sbk::gemm_ln_nt(d.x, dm, L.ca_q_wf, dm, L.ca_q_bf, nullptr, 0, d.q, dm, n, dm, dm, W->ln_eps,

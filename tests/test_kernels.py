@@ -310,10 +310,12 @@ def test_gemm_skinny_flat64(backend, M, N, K):
     w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
     b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
     nat.load().sbk_prof_set_knob(12, 1)
+    nat.load().sbk_prof_set_knob(11, 600)
     try:
         out = nat.gemm_nt_splitk(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_GELU, alpha=0.5)
     finally:
         nat.load().sbk_prof_set_knob(12, 0)
+        nat.load().sbk_prof_set_knob(11, 1 << 30)
     ref = r + 0.5 * F.gelu(a.double() @ w.double().t() + b).float()
     scale = float((a.abs() @ w.abs().t()).max())
     assert _md(out, ref) <= 2e-6 * scale + 1e-5

@@ -626,3 +626,29 @@ def test_bf16_precision_is_opt_in_and_close(backend):
     with pytest.raises(NotImplementedError):
         build_asr(tiny, vocab=30, seed=2, device=str(dev)).__class__(modules=dict(a32.mods), hparams={"tokenizer": None},
                                                                      run_opts={"device": str(dev), "precision": "fp8"})
+
+
+@pytest.mark.parametrize("variant", [3, 4])
+def test_cross_attention_streaming_variant_matches_default(backend, variant):
+    """csrc/decoder.hip cross_attn_stream_kernel (tuning knob 4 = 3; d_model = 512 only): one wave per run of memory
+    frames with an online softmax must give the search the default kernel gives (ragged lengths, several splits)."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_asr
+
+    cfg = dict(d_model=512, nhead=8, d_ffn=64, n_enc=1, n_dec=1, n_fft=512, win_length=32)
+    asr = build_asr(cfg, vocab=24, seed=13, beam_size=3, ctc_weight=0.0, device=str(dev), max_decode_ratio=0.12)
+    with torch.no_grad():
+        asr.mods.seq_lin.w.weight.mul_(8.0)
+    wav = 0.1 * torch.randn(2, 28800, generator=torch.Generator().manual_seed(2))  # 46 frames after the front-end
+    lens = torch.tensor([1.0, 0.62])
+    enc = asr.encode_batch(wav, lens)
+    dec = asr.mods.decoder
+    base = dec(enc, lens.to(dev))
+    nat.load().sbk_prof_set_knob(4, variant)
+    try:
+        alt = dec(enc, lens.to(dev))
+    finally:
+        nat.load().sbk_prof_set_knob(4, 0)
+    assert alt[0] == base[0]
+    assert float((alt[2].cpu() - base[2].cpu()).abs().max()) <= 2e-5
+    assert float((alt[3].cpu() - base[3].cpu()).abs().max()) <= 2e-5

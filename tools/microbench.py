@@ -114,7 +114,7 @@ if __name__ == "__main__":
             for (M, N, K) in [(320, 512, 512), (1280, 512, 512), (1280, 2048, 512), (2560, 512, 512)]:
                 gemm_case(M, N, K, 8, iters=5)
             nat.load().sbk_prof_set_knob(2, 0)
-        nat.load().sbk_prof_set_knob(11, 600)
+        nat.load().sbk_prof_set_knob(11, 1 << 30)
         nat.load().sbk_prof_set_knob(12, 0)
         sys.exit(0)
     if "--flat64" in sys.argv:  # register-operand path: 32x32 tiles vs 64x64 tiles (2x2 accumulators), reach on
@@ -125,7 +125,7 @@ if __name__ == "__main__":
             for M in (640, 1280, 2560, 5120):
                 for (N, K) in [(512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512)]:
                     gemm_case(M, N, K, 8)
-        nat.load().sbk_prof_set_knob(11, 600)
+        nat.load().sbk_prof_set_knob(11, 1 << 30)
         nat.load().sbk_prof_set_knob(12, 0)
         sys.exit(0)
     if "--skinny" in sys.argv:  # decode-step GEMMs on the register-operand path: looped (round 1) vs flat schedule
