@@ -149,7 +149,21 @@ __global__ void __launch_bounds__(256) gemm_nt_bf16_kernel(GemmBf16Args g) {
 
   float4 ra[APER];
   uint4 rw[WPER];
+  const bool interior = m0 + BM <= g.M && n0 + BN <= g.N && (g.K % BK) == 0;  // uniform: unpredicated panel loads
   auto fetch = [&](int k0) {
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < APER; ++i) {
+        const int s = tid + i * 256;
+        ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + s / (BK / 4)) * g.lda + k0 + (s % (BK / 4)) * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < WPER; ++i) {
+        const int s = tid + i * 256;
+        rw[i] = *reinterpret_cast<const uint4*>(g.W + (size_t)(n0 + s / (BK / 8)) * g.ldw + k0 + (s % (BK / 8)) * 8);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < APER; ++i) {
       const int s = tid + i * 256, rr = s / (BK / 4), c = (s % (BK / 4)) * 4;

@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
     echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
   fi
   if [ "${BENCH:-1}" = "1" ]; then
-    echo "== bench"; timeout 1200 python bench.py --steps ${BENCH_STEPS:-16} --warmup 1 --verbose ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -5 gpurun_out/bench.err; cat gpurun_out/bench.json
+    echo "== bench"; timeout 1200 python bench.py --gpus 1 --steps ${BENCH_STEPS:-20} --warmup ${BENCH_WARMUP:-5} --verbose ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -5 gpurun_out/bench.err; cat gpurun_out/bench.json
   fi
   if [ -n "${FORCE_DIST:-}" ]; then
     echo "== bench, RCCL leg forced on one GPU"
@@ -24,6 +24,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 if [ -n "${STATS_ARGS:-}" ]; then
   # single-stream rocprofv3 kernel statistics (true kernel durations, no HIP-event overhead)
   (cd /tmp && rm -rf /tmp/prof2 && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof2 -o st -- python "$OLDPWD/bench.py" --no-cpu-baseline --no-roofline --no-extras --latency-runs 0 --streams 1 $STATS_ARGS > "$OLDPWD/gpurun_out/stats_run.log" 2>&1)
+  d=$(find /tmp/prof2 -name "*domain_stats.csv" | head -1); [ -n "$d" ] && cp "$d" gpurun_out/${STATS_NAME:-stats}_domain_stats.csv
   f=$(find /tmp/prof2 -name "*kernel_stats.csv" | head -1); echo "stats file: $f"; tail -1 gpurun_out/stats_run.log
   [ -n "$f" ] && cp "$f" gpurun_out/${STATS_NAME:-stats}_kernel_stats.csv && head -40 "$f" | cut -c1-200
 fi
