@@ -208,6 +208,8 @@ def main():
                     help="encoder attention (RelPosMHAXL = BASELINE.json's config; RoPEMHA = the in-tree recipe)")
     ap.add_argument("--lm", action="store_true",
                     help="add the recipe's TransformerLM scorer (12 x 768, weight 0.6, T=1.15): test_search at beam 10")
+    ap.add_argument("--no-group-encoder", action="store_true",
+                    help="encode the batches of a group one by one instead of in one encoder pass over all their rows (A/B)")
     ap.add_argument("--no-search-priority", action="store_true",
                     help="run each worker's search on its normal-priority stream (A/B of the stream priorities)")
     ap.add_argument("--knob", action="append", default=[], metavar="KEY=VALUE",
@@ -285,6 +287,7 @@ def main():
     def timed_run(max_batch, streams, group):
         """Warm-up + the timed scatter -> transcribe -> gather of the whole job at one batch size."""
         workers = ConcurrentTranscriber(asr, streams=streams, prioritise_search=not args.no_search_priority, group=group)
+        workers.group_encoder = not args.no_group_encoder
         st = ShardedTranscriber(transcribe_one, dev, max_utts=max_batch, concurrent=workers, prepare=fixed_decode_length)
         # W untimed steps through the same path (communicators, allocator pools); the longest utterances first, and
         # every worker stream sizes its allocations on the longest batch
@@ -406,6 +409,7 @@ def main():
         native.prof_enable(True)
         # the same batches, grouped as in the timed region, on ONE worker stream (every launch between two events)
         one = ConcurrentTranscriber(asr, streams=1, prioritise_search=False, group=auto(args.max_batch)[1])
+        one.group_encoder = not args.no_group_encoder
         one.transcribe_batches([(w, l) for _, w, l in local_batches], prepare=fixed_decode_length)
         one.pool.shutdown(wait=True)
         rep_audio = sum(seconds[i] for ids, _, _ in local_batches for i in ids)

@@ -38,6 +38,23 @@ class EncoderDecoderASR(Pretrained):
                 encoder_out = self.mods.transformer.encode(encoder_out, wav_lens)
         return encoder_out
 
+    def encode_group(self, batches):
+        """``encode_batch`` of several independently padded batches [(wavs, wav_lens), ...] -> [encoder_out, ...].
+        The feature front-end runs batch by batch; the Conformer encoder runs once over the rows of all of them
+        (TransformerASR.encode_group), so its GEMMs are large enough to fill the chip even with recipe-sized
+        batches.  Results equal ``encode_batch`` batch by batch."""
+        from speechbrain_amd import native
+
+        if not (self.transformer_beam_search and hasattr(self.mods.transformer, "encode_group")):
+            return [self.encode_batch(w, l) for w, l in batches]
+        feats, lens = [], []
+        for wavs, wav_lens in batches:
+            wavs, wav_lens = wavs.float().to(self.device), wav_lens.to(self.device)
+            feats.append(self.mods.encoder(wavs, wav_lens))
+            lens.append(wav_lens)
+        with native.precision_scope(self.eval_precision):
+            return self.mods.transformer.encode_group(feats, lens)
+
     def transcribe_batch(self, wavs, wav_lens):
         with torch.no_grad():
             wav_lens = wav_lens.to(self.device)

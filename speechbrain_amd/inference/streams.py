@@ -27,6 +27,7 @@ class ConcurrentTranscriber:
         batch keeps its own padding and step limits, the decoder step sees the rows of all of them."""
         self.asr, self.n, self.device = asr, max(1, int(streams)), asr.device
         self.group = max(1, int(group))
+        self.group_encoder = True  # a group's batches also share one encoder pass (A/B switch)
         if self.device.type != "cuda":
             self.n = 1
         self.searchers = [copy.copy(asr.mods.decoder) for _ in range(self.n)]
@@ -68,7 +69,7 @@ class ConcurrentTranscriber:
     def _many(self, slot: int, ks, batches, prepare: Optional[Callable]):
         """Encode the batches `ks` one after the other, decode them in one grouped search."""
         searcher = self.searchers[slot]
-        items, ratios = [], []
+        items, ratios, dev_batches = [], [], []
         with torch.no_grad():
             for k in ks:
                 wavs, wav_lens = batches[k]
@@ -81,7 +82,12 @@ class ConcurrentTranscriber:
                     from speechbrain_amd import native
 
                     wavs = native.pcm16_to_f32(wavs)
-                items.append((self.asr.encode_batch(wavs, wav_lens), wav_lens))
+                dev_batches.append((wavs, wav_lens))
+            if self.group_encoder and hasattr(self.asr, "encode_group"):
+                encs = self.asr.encode_group(dev_batches)  # one encoder pass over the rows of all the batches
+            else:
+                encs = [self.asr.encode_batch(w, l) for w, l in dev_batches]
+            items = [(e, l) for e, (_, l) in zip(encs, dev_batches)]
             dec_stream = self.dec_streams[slot] if self.device.type == "cuda" else None
             if dec_stream is None:
                 res = searcher.forward_group(items, ratios)

@@ -71,6 +71,29 @@ class ConvolutionModule(nn.Module):
         lin = self.after_conv[2]
         return native.gemm_nt(h, lin.weight, lin.bias, residual=residual, seq_len=key_len, rows_per_seq=T)
 
+    def forward_group(self, x, segs, dynchunktrain_config=None):
+        """x + module(x) over several independently padded batches laid end to end: x [M,d], segs = [(row0, B, T,
+        key_len, pos0)].  LayerNorms and the bottleneck run once over all rows; the depthwise convolution and the
+        length-masked output projection once per batch."""
+        d = x.shape[-1]
+        chunk_size = int(dynchunktrain_config.chunk_size) if dynchunktrain_config is not None else 0
+        h = native.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        pw = self.bottleneck[0]
+        h = native.gemm_nt(h, pw.weight.reshape(2 * d, d), pw.bias)
+        g = torch.empty_like(x)
+        w = self.conv.weight.reshape(d, self.kernel_size)
+        for row0, B, T, _, _ in segs:
+            native.glu_dwconv(h[row0: row0 + B * T].view(B, T, 2 * d), w, self.conv.bias, self.kernel_size, chunk_size,
+                              out=g[row0: row0 + B * T].view(B, T, d))
+        ln = self.after_conv[0]
+        g = native.layernorm(g, ln.weight, ln.bias, ln.eps, act=self.act_code)
+        lin = self.after_conv[2]
+        out = torch.empty_like(x)
+        for row0, B, T, key_len, _ in segs:
+            rows = slice(row0, row0 + B * T)
+            native.gemm_nt(g[rows], lin.weight, lin.bias, residual=x[rows], out=out[rows], seq_len=key_len, rows_per_seq=T)
+        return out
+
 
 class ConformerEncoderLayer(nn.Module):
     """Conformer.py:333-499: x + FFN/2 -> MHSA -> Conv -> LN(x + FFN/2)."""
@@ -126,6 +149,22 @@ class ConformerEncoderLayer(nn.Module):
             return self.mha_layer.core(h, key_len, residual=x, want_attn=self.collect_attention, chunk=chunk)
         return self.mha_layer.core(h, pos_embs.reshape(-1, x.shape[-1]), key_len, residual=x,
                                    want_attn=self.collect_attention, chunk=chunk)
+
+    def forward_group(self, x, pos2d, segs, dynchunktrain_config=None):
+        """``forward`` over several independently padded batches laid end to end (x [M,d], pos2d the batches' position
+        tables end to end, segs = [(row0, B, T, key_len, pos0)]): every row-wise launch (LayerNorms, projections,
+        feed-forward) covers all the batches at once -- large GEMMs whose tiles fill the chip -- and only the two
+        kernels that see the time axis (attention, depthwise convolution) run per batch."""
+        chunk = dynchunktrain_config.kernel_args() if dynchunktrain_config is not None else (0, -1)
+        x = self._ffn(self.ffn_module1, x)
+        h = native.layernorm(x, self.norm1.norm.weight, self.norm1.norm.bias, self.norm1.eps)
+        if self.attention_type == "RoPEMHA":
+            x = self.mha_layer.core_group(h, segs, residual=x, chunk=chunk)
+        else:
+            x = self.mha_layer.core_group(h, pos2d, segs, residual=x, chunk=chunk)
+        x = self.convolution_module.forward_group(x, segs, dynchunktrain_config=dynchunktrain_config)
+        y = self._ffn(self.ffn_module2, x)
+        return native.layernorm(y, self.norm2.norm.weight, self.norm2.norm.bias, self.norm2.eps)
 
     def forward_streaming(self, x, context: ConformerEncoderLayerStreamingContext, pos_embs=None):
         """One chunk through the layer with the left-context caches of ``context`` (Conformer.py:501-586): the MHA
@@ -188,6 +227,15 @@ class ConformerEncoder(nn.Module):
         if hidden is not None:
             return output, attention_lst, hidden
         return output, attention_lst
+
+    def forward_group(self, x, pos2d, segs, dynchunktrain_config=None):
+        """The layers + final norm over several independently padded batches laid end to end (see
+        ConformerEncoderLayer.forward_group); returns [M,d]."""
+        if self.attention_type == "RelPosMHAXL" and pos2d is None:
+            raise ValueError("RelPosMHAXL needs positional embeddings")
+        for layer in self.layers:
+            x = layer.forward_group(x, pos2d, segs, dynchunktrain_config=dynchunktrain_config)
+        return self.norm(x)
 
     def forward_streaming(self, src, context: ConformerEncoderStreamingContext, pos_embs=None):
         """Conformer.py:780-828."""

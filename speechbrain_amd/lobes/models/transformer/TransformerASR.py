@@ -120,6 +120,29 @@ class TransformerASR(TransformerInterface):
         encoder_out, _ = outputs
         return encoder_out
 
+    def encode_group(self, srcs, wav_lens, dynchunktrain_config=None):
+        """``encode`` of several independently padded batches at once: srcs = [[B_i,T_i,F(,C)], ...], wav_lens =
+        [[B_i], ...] -> [[B_i,T_i,d], ...].  The batches' rows are laid end to end so that every projection,
+        feed-forward and LayerNorm of the encoder is ONE launch over all of them; each batch keeps its own padded
+        length, key lengths and position table (results equal ``encode`` batch by batch)."""
+        if not hasattr(self.encoder, "forward_group") or self.output_hidden_states:
+            return [self.encode(s, l, dynchunktrain_config=dynchunktrain_config) for s, l in zip(srcs, wav_lens)]
+        flat, segs, tables, row0, pos0 = [], [], [], 0, 0
+        for src, wav_len in zip(srcs, wav_lens):
+            B, T = src.shape[0], src.shape[1]
+            key_len = None
+            if wav_len is not None:  # make_transformer_src_tgt_masks: abs_len = round(wav_len * T)
+                key_len = torch.round(wav_len * T).to(torch.int32).clamp_(max=T)
+            segs.append((row0, B, T, key_len, pos0))
+            flat.append(src.reshape(B * T, -1))
+            if self.attention_type != "RoPEMHA":
+                tables.append(self.positional_encoding.make_pe(T).reshape(2 * T - 1, -1))
+            row0, pos0 = row0 + B * T, pos0 + 2 * T - 1
+        x = self.custom_src_module(torch.cat(flat, dim=0))
+        pos2d = torch.cat(tables, dim=0) if tables else None
+        y = self.encoder.forward_group(x, pos2d, segs, dynchunktrain_config=dynchunktrain_config)
+        return [y[r0: r0 + B * T].view(B, T, -1) for r0, B, T, _, _ in segs]
+
     def forward(self, src, tgt=None, wav_len=None, pad_idx=0):
         if tgt is not None:
             raise NotImplementedError("teacher-forced forward (training) is outside the inference path")

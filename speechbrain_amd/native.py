@@ -201,8 +201,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_
     K = a.shape[-1]
     a2 = a.reshape(-1, K)
     M, N = a2.shape[0], w.shape[0]
-    if out is None and precision() == "bf16" and M >= 256 and K % 8 == 0 and w.is_contiguous():
-        return gemm_nt_bf16(a, w, bias, residual, act, alpha, seq_len, rows_per_seq)  # opt-in fast path
+    if precision() == "bf16" and M >= 256 and K % 8 == 0 and w.is_contiguous():
+        return gemm_nt_bf16(a, w, bias, residual, act, alpha, seq_len, rows_per_seq, out=out)  # opt-in fast path
     _dev_ok(a2, w, bias, residual)
     _f32(a2), _f32(w)
     if out is None:
@@ -235,19 +235,21 @@ def bf16_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def gemm_nt_bf16(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, seq_len=None,
-                 rows_per_seq=0):
+                 rows_per_seq=0, out=None):
     """gemm_nt with bf16 operands / fp32 accumulation (opt-in fast path; `w` is the fp32 parameter, its bf16 image is
     cached).  Falls back to the fp32 kernel for shapes the bf16 kernel does not take (K % 8 != 0)."""
     K = a.shape[-1]
     if K % 8 != 0:
-        return gemm_nt(a, w, bias, residual, act, alpha, seq_len=seq_len, rows_per_seq=rows_per_seq)
+        with precision_scope("fp32"):
+            return gemm_nt(a, w, bias, residual, act, alpha, out=out, seq_len=seq_len, rows_per_seq=rows_per_seq)
     lib = load()
     a2 = a.reshape(-1, K)
     M, N = a2.shape[0], w.shape[0]
     wb = bf16_weight(w)
     _dev_ok(a2, wb, bias, residual, seq_len)
     _f32(a2)
-    out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
     _chk(lib.sbk_gemm_nt_bf16(_p(a2), K, _p(wb), K, _p(bias), _p(r2), N, _p(out), N, M, N, K, act, float(alpha),
                               _p(seq_len), int(rows_per_seq), _stream(a2)), "sbk_gemm_nt_bf16")
@@ -405,15 +407,18 @@ def conv_block(x, wt, bias, gamma, beta, cout, eps=1e-5, slope=0.01):
     return y
 
 
-def relpos_attention(qkv, pos, bias_u, bias_v, key_len, H, scale, want_attn=False, chunk_size=0, left_chunks=-1):
+def relpos_attention(qkv, pos, bias_u, bias_v, key_len, H, scale, want_attn=False, chunk_size=0, left_chunks=-1,
+                     out=None):
     """qkv [B,T,3*d] (per-head interleaved), pos [2T-1,d] -> context [B,T,d] (+ weights [B,H,T,T]).
-    ``chunk_size`` > 0: Dynamic Chunk mask (``left_chunks`` < 0 = unlimited left context)."""
+    ``chunk_size`` > 0: Dynamic Chunk mask (``left_chunks`` < 0 = unlimited left context).  ``out``: optional
+    contiguous [B,T,d] destination."""
     lib = load()
-    _dev_ok(qkv, pos, bias_u, bias_v, key_len)
+    _dev_ok(qkv, pos, bias_u, bias_v, key_len, out)
     _f32(qkv)
     B, T, d3 = qkv.shape
     d = d3 // 3
-    out = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
+    if out is None:
+        out = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
     attn = torch.empty(B, H, T, T, dtype=torch.float32, device=qkv.device) if want_attn else None
     _chk(lib.sbk_relpos_attention_f32(_p(qkv), _p(pos), _p(bias_u), _p(bias_v), _p(key_len), _p(out), _p(attn), B, T,
                                       H, d // H, float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
@@ -421,14 +426,15 @@ def relpos_attention(qkv, pos, bias_u, bias_v, key_len, H, scale, want_attn=Fals
     return out, attn
 
 
-def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False, chunk_size=0, left_chunks=-1):
+def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False, chunk_size=0, left_chunks=-1, out=None):
     """qkv [B,T,3*d] (per-head interleaved), cosines / sines [rows >= T, Dh] -> context [B,T,d]."""
     lib = load()
-    _dev_ok(qkv, cosines, sines, key_len)
+    _dev_ok(qkv, cosines, sines, key_len, out)
     _f32(qkv)
     B, T, d3 = qkv.shape
     d = d3 // 3
-    out = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
+    if out is None:
+        out = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
     attn = torch.empty(B, H, T, T, dtype=torch.float32, device=qkv.device) if want_attn else None
     _chk(lib.sbk_rope_attention_f32(_p(qkv), _p(cosines), _p(sines), _p(key_len), _p(out), _p(attn), B, T, H, d // H,
                                     cosines.shape[0], float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
@@ -436,13 +442,13 @@ def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False, chun
     return out, attn
 
 
-def glu_dwconv(h, w, bias, ksize, chunk_size=0):
+def glu_dwconv(h, w, bias, ksize, chunk_size=0, out=None):
     """h [B,T,2d] -> depthwise_conv(GLU(h)) [B,T,d]; w [d,ksize]; ``chunk_size`` > 0: Dynamic Chunk Convolution."""
     lib = load()
-    _dev_ok(h, w, bias)
+    _dev_ok(h, w, bias, out)
     _f32(h)
     B, T, d2 = h.shape
-    y = torch.empty(B, T, d2 // 2, dtype=torch.float32, device=h.device)
+    y = out if out is not None else torch.empty(B, T, d2 // 2, dtype=torch.float32, device=h.device)
     _chk(lib.sbk_glu_dwconv_f32(_p(h), _p(w), _p(bias), _p(y), B, T, d2 // 2, int(ksize), int(chunk_size), _stream(h)),
          "sbk_glu_dwconv_f32")
     return y

@@ -604,6 +604,39 @@ def test_grouped_search_equals_separate_searches(backend, ctc_weight):
     assert any(early), "the case should contain hypotheses that end through EOS before the step limit"
 
 
+@pytest.mark.parametrize("attention", ["RelPosMHAXL", "RoPEMHA"])
+def test_grouped_encoder_equals_batch_by_batch(backend, attention):
+    """encode_group: the Conformer encoder over the rows of several independently padded batches laid end to end (one
+    launch per projection / feed-forward / LayerNorm for all of them; attention and depthwise convolution per batch)
+    gives every batch what encode_batch gives it.  Tolerance 2e-5: a GEMM over more rows may take another tile
+    schedule (same products, another summation order)."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_asr
+
+    tiny = dict(d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=1, n_fft=512, win_length=32)
+    asr = build_asr(tiny, vocab=30, seed=23, beam_size=2, ctc_weight=0.3, device=str(dev), attention_type=attention)
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for B, N in [(3, 9600), (2, 5120), (1, 12800), (2, 7040)]:
+        batches.append((0.1 * torch.randn(B, N, generator=g), torch.linspace(0.6, 1.0, B) if B > 1 else torch.ones(1)))
+    with torch.no_grad():
+        one_by_one = [asr.encode_batch(w, l) for w, l in batches]
+        together = asr.encode_group(batches)
+    assert len(together) == len(one_by_one)
+    for a, b in zip(together, one_by_one):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-5
+    # and through the workers: grouped encoder + grouped search against plain sequential calls
+    from speechbrain_amd.inference.streams import ConcurrentTranscriber
+
+    seq = [asr.transcribe_batch(w, l)[1] for w, l in batches]
+    workers = ConcurrentTranscriber(asr, streams=1, group=4)
+    assert workers.group_encoder
+    got = workers.transcribe_batches(batches)
+    workers.pool.shutdown(wait=True)
+    assert got == seq
+
+
 def test_bf16_precision_is_opt_in_and_close(backend):
     """run_opts precision="bf16": the encoder's large GEMMs take bf16 operands (fp32 accumulation); the default stays
     the fp32 parity path bit for bit.  Stated tolerance for this tiny model: encoder output within 5e-2 absolute of
