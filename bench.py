@@ -16,12 +16,15 @@ utterances ("duration-sorted batches of <= 32 utts"); `value` is meas
 utterances are then run again as 128-utterance batches (sized for 288 GB of HBM) and reported as
 `value_batch128`.  Per rank the batches run through ConcurrentTranscriber: --streams worker threads (encoder on a
 normal-, search on a high-priority HIP stream), each encoding --group batches one after the other and decoding them
-in ONE grouped search (every batch keeps its own padding and step limits; the decoder step sees all their rows).
+in ONE grouped search (every batch keeps its own padding and step limits; the decoder step sees all their rows);
+the Conformer encoder likewise runs once over the rows of the group's batches (row-wise launches shared, attention and
+depthwise convolution per batch).
 
 The timed region is the real sharded path (speechbrain_amd.inference.sharded.ShardedTranscriber): rank 0 holds the
 whole job as padded int16 batches in pinned host memory (planning -- duration sort, bucketing, longest-processing-
 time-first assignment, padding -- is host preparation and is reported as `prep_s`); the clock then covers
-host->device copies, the scatter of every other rank's share (grouped point-to-point sends over xGMI), PCM->float,
+host->device copies, the scatter of every other rank's share (streamed: one point-to-point send per batch over the
+peer's xGMI link, so a rank starts on its first batch while the rest is on its way), PCM->float,
 Fbank -> norm -> CNN -> Conformer encoder -> beam search on every rank, and the gather of the token ids to rank 0
 (token-id lists on the host).  With --gpus N each rank gets K steps of work (weak scaling): the job is N*K*128
 utterances.  At N = 1 the same code runs without the two exchanges.
@@ -344,7 +347,7 @@ def main():
                        "utterances_total": n_utts, "batches_total": info["n_batches"],
                        "audio_seconds_total": round(total_audio, 1), "weights": "random init, torch.manual_seed(0)",
                        "parallelism": f"replicas x{world}; rank 0 plans (duration sort, buckets, LPT) and holds the job in "
-                                      "pinned host memory; timed: H2D + scatter of int16 PCM (grouped P2P, RCCL/xGMI) -> "
+                                      "pinned host memory; timed: H2D + streamed scatter of int16 PCM (one P2P send per batch, RCCL/xGMI) -> "
                                       "transcribe -> gather of token ids",
                        "bytes_scattered": info["bytes_scattered"], "prep_s": info["prep_s"],
                        "workers_per_gpu": info["streams"], "batches_per_grouped_search": info["group"],
@@ -410,9 +413,9 @@ def main():
         # the same batches, grouped as in the timed region, on ONE worker stream (every launch between two events)
         one = ConcurrentTranscriber(asr, streams=1, prioritise_search=False, group=auto(args.max_batch)[1])
         one.group_encoder = not args.no_group_encoder
-        one.transcribe_batches([(w, l) for _, w, l in local_batches], prepare=fixed_decode_length)
+        one.transcribe_batches([(t[1], t[2]) for t in local_batches], prepare=fixed_decode_length)
         one.pool.shutdown(wait=True)
-        rep_audio = sum(seconds[i] for ids, _, _ in local_batches for i in ids)
+        rep_audio = sum(seconds[i] for t in local_batches for i in t[0])
         torch.cuda.synchronize()
         native.prof_enable(False)
         rep = native.prof_report()

@@ -3,10 +3,11 @@
 The path has no cross-utterance state at inference, so utterances shard embarrassingly: one
 process per GPU, each with a full model replica.  Rank 0 owns the job: it sorts utterances by
 duration, forms length-bucketed batches (cf. DynamicBatchSampler, dataio/sampler.py:321),
-assigns batches to ranks longest-processing-time-first, SCATTERS the padded waveforms (grouped
-point-to-point sends, one per peer = one per xGMI link, RCCL when the backend is "nccl"; gloo in
-the CPU tests) and GATHERS the token ids.  Those two exchanges are the only communication;
-nothing is exchanged while decoding.
+assigns batches to ranks longest-processing-time-first, SCATTERS the padded waveforms (streamed:
+one exact-size point-to-point send per batch, round-robin over the peers = over the xGMI links,
+RCCL when the backend is "nccl"; gloo in the CPU tests -- a rank starts on its first batch while
+the rest is still on its way) and GATHERS the token ids.  Those two exchanges are the only
+communication; nothing is exchanged while decoding.
 
 Waveforms travel in the dtype they are given in: int16 PCM (what a wav file holds; 2 bytes per
 sample on PCIe and xGMI, converted with sbk_pcm16_to_f32 on the receiving GPU -- the reference's
@@ -111,7 +112,11 @@ class ShardedTranscriber:
         owner = assign_batches([batch_cost(n, b) for b in batches], self.world)
         dtype = wavs[0].dtype if len(wavs) else torch.float32
         slabs, metas = [], []
+        def padded(b):
+            return len(batches[b]) * max(n[i] for i in batches[b])
+
         for r in range(self.world):
+            owner[r].sort(key=lambda b: (-padded(b), b))  # the order the rank's workers take them in (largest first)
             slab, meta = self._stage(wavs, batches, owner[r])
             slabs.append(slab)
             metas.append((str(dtype), slab.numel(), meta))
@@ -120,34 +125,62 @@ class ShardedTranscriber:
         return {"slabs": slabs, "metas": metas}
 
     def distribute(self, plan):
-        """The scatter proper: per-rank metadata (pickled, small) + each rank's slab.  Every rank returns its local
-        list of (global utterance ids, padded batch on device [B,N] in the input dtype, relative lengths [B])."""
+        """The scatter proper, streamed batch by batch.  Every rank returns its local list of (global utterance ids,
+        padded batch on device [B,N] in the input dtype, relative lengths [B], ready) where ``ready()`` -- called
+        on the stream (and host thread) that is about to read the batch -- orders that stream after the batch's
+        arrival.  Rank 0 walks the batches round-robin over the ranks in the order the ranks will run them: one
+        host-to-device copy per batch on a copy stream, followed (for a peer's batch) by an exact-size point-to-point
+        send over that peer's xGMI link (RCCL; gloo in the CPU tests).  Nobody waits for the whole job: a rank
+        starts transcribing when its first batch has landed, and rank 0's PCIe traffic overlaps everyone's compute.
+        The per-rank metadata (pickled, small) travels first."""
+        cuda = self.device.type == "cuda"
         if self.world == 1:
-            _, _, my_meta = plan["metas"][0]
-            recv = plan["slabs"][0].to(self.device, non_blocking=True)
+            dtype_name, count, my_meta = plan["metas"][0]
         else:
             mine = [None]
             dist.scatter_object_list(mine, plan["metas"] if self.rank == 0 else None, src=0, group=self.group)
             dtype_name, count, my_meta = mine[0]
-            dtype = {"torch.int16": torch.int16, "torch.float32": torch.float32}[dtype_name]
-            if self.rank == 0:
-                # exact-size sends, one per peer, posted together: RCCL runs them as one group (each peer is its
-                # own xGMI link); rank 0's own share is a plain host-to-device copy
-                staged = [s.to(self.device, non_blocking=True) for s in plan["slabs"]]
-                ops = [dist.P2POp(dist.isend, staged[r], r, self.group) for r in range(1, self.world) if staged[r].numel()]
-                for w in (dist.batch_isend_irecv(ops) if ops else []):
-                    w.wait()
-                recv = staged[0]
-            else:
-                recv = torch.empty(count, dtype=dtype, device=self.device)
-                if count:
-                    for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, recv, 0, self.group)]):
-                        w.wait()
-        local, off = [], 0
-        for ids, shape, lens in my_meta:
-            cnt = shape[0] * shape[1]
-            local.append((ids, recv[off: off + cnt].view(shape), torch.tensor(lens, dtype=torch.float32, device=self.device)))
-            off += cnt
+        dtype = {"torch.int16": torch.int16, "torch.float32": torch.float32}[dtype_name]
+        self._pending = []  # (work, tensor) of sends in flight: kept until gather()
+
+        def waiter(work):
+            return work.wait  # NCCL: the calling thread's current stream waits; gloo: the host waits
+
+        local = []
+        if self.rank == 0:
+            copy_stream = torch.cuda.Stream(self.device) if cuda else None
+            cursors = [0] * self.world
+            metas = [m[2] for m in plan["metas"]]
+            order = list(range(1, self.world)) + [0]  # the peers' batches go out before rank 0 stages its own
+            for j in range(max(len(m) for m in metas)):
+                for r in order:
+                    if j >= len(metas[r]):
+                        continue
+                    ids, shape, lens = metas[r][j]
+                    cnt = shape[0] * shape[1]
+                    host = plan["slabs"][r][cursors[r]: cursors[r] + cnt]
+                    cursors[r] += cnt
+                    if cuda:
+                        with torch.cuda.stream(copy_stream):
+                            chunk = host.to(self.device, non_blocking=True)
+                            if r != 0:
+                                self._pending.append((dist.isend(chunk, r, group=self.group), chunk))
+                            else:
+                                ev = torch.cuda.Event()
+                                ev.record(copy_stream)
+                    else:
+                        chunk = host
+                        if r != 0:
+                            self._pending.append((dist.isend(chunk, r, group=self.group), chunk))
+                    if r == 0:
+                        ready = (lambda e=ev: torch.cuda.current_stream().wait_event(e)) if cuda else None
+                        local.append((ids, chunk.view(shape), torch.tensor(lens, dtype=torch.float32, device=self.device),
+                                      ready))
+        else:
+            for ids, shape, lens in my_meta:
+                buf = torch.empty(shape, dtype=dtype, device=self.device)
+                work = dist.irecv(buf, 0, group=self.group)
+                local.append((ids, buf, torch.tensor(lens, dtype=torch.float32, device=self.device), waiter(work)))
         return local
 
     def scatter(self, wavs: Optional[Sequence[torch.Tensor]]):
@@ -165,17 +198,27 @@ class ShardedTranscriber:
     def run_local(self, local):
         out = []
         if self.concurrent is not None and len(local) > 1:
-            hyps_per_batch = self.concurrent.transcribe_batches([(x, l) for _, x, l in local], prepare=self.prepare)
-            for (ids, _, _), hyps in zip(local, hyps_per_batch):
-                out.extend(zip(ids, hyps))
+            hyps_per_batch = self.concurrent.transcribe_batches([(t[1], t[2]) for t in local], prepare=self.prepare,
+                                                                ready=[t[3] if len(t) > 3 else None for t in local])
+            for t, hyps in zip(local, hyps_per_batch):
+                out.extend(zip(t[0], hyps))
             return out
-        for ids, x, lens in local:
+        for t in local:
+            ids, x, lens = t[0], t[1], t[2]
+            if len(t) > 3 and t[3] is not None:
+                t[3]()
             hyps = self.fn(self._floats(x), lens)
             out.extend(zip(ids, hyps))
         return out
 
+    def _drain_sends(self):
+        for work, _ in getattr(self, "_pending", []):
+            work.wait()
+        self._pending = []
+
     def gather(self, results, n_total: Optional[int] = None):
         """results: list of (utterance id, token list) -> on rank 0 the hypotheses in input order."""
+        self._drain_sends()
         if self.world == 1:
             table = dict(results)
             return [table[i] for i in range(len(table))]

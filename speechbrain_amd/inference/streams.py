@@ -40,10 +40,12 @@ class ConcurrentTranscriber:
                                 for _ in range(self.n)]
         self.pool = ThreadPoolExecutor(self.n)
 
-    def _one(self, slot: int, wavs, wav_lens, prepare: Optional[Callable]):
+    def _one(self, slot: int, wavs, wav_lens, prepare: Optional[Callable], ready: Optional[Callable] = None):
         searcher = self.searchers[slot]
         if prepare is not None:
             prepare(searcher, wavs)
+        if ready is not None:
+            ready()  # the batch may still be on its way (ShardedTranscriber.distribute): order this stream after it
         with torch.no_grad():
             # host batches (pinned memory: the copy is asynchronous) go to the device on THIS worker's stream, so
             # the transfer of one batch overlaps the kernels of the batches in flight on the other streams
@@ -66,8 +68,8 @@ class ConcurrentTranscriber:
                 cur.wait_stream(dec_stream)
         return toks
 
-    def _many(self, slot: int, ks, batches, prepare: Optional[Callable]):
-        """Encode the batches `ks` one after the other, decode them in one grouped search."""
+    def _many(self, slot: int, ks, batches, prepare: Optional[Callable], ready=None):
+        """Encode the batches `ks` together (or one after the other), decode them in one grouped search."""
         searcher = self.searchers[slot]
         items, ratios, dev_batches = [], [], []
         with torch.no_grad():
@@ -76,6 +78,8 @@ class ConcurrentTranscriber:
                 if prepare is not None:
                     prepare(searcher, wavs)
                 ratios.append((searcher.min_decode_ratio, searcher.max_decode_ratio))
+                if ready is not None and ready[k] is not None:
+                    ready[k]()
                 wavs = wavs.to(self.device, non_blocking=True)
                 wav_lens = wav_lens.to(self.device, non_blocking=True)
                 if wavs.dtype == torch.int16:
@@ -101,7 +105,7 @@ class ConcurrentTranscriber:
                 cur.wait_stream(dec_stream)
         return [(k, r[0]) for k, r in zip(ks, res)]
 
-    def _work(self, slot: int, todo: "queue.Queue", batches, prepare):
+    def _work(self, slot: int, todo: "queue.Queue", batches, prepare, ready=None):
         out = []
 
         def take():
@@ -115,9 +119,9 @@ class ConcurrentTranscriber:
 
         def run(ks):
             if len(ks) > 1 and hasattr(self.searchers[slot], "forward_group"):
-                out.extend(self._many(slot, ks, batches, prepare))
+                out.extend(self._many(slot, ks, batches, prepare, ready))
             else:
-                out.extend((k, self._one(slot, *batches[k], prepare)) for k in ks)
+                out.extend((k, self._one(slot, *batches[k], prepare, ready[k] if ready is not None else None)) for k in ks)
 
         if self.device.type != "cuda":
             while True:
@@ -136,8 +140,9 @@ class ConcurrentTranscriber:
         return out
 
     def transcribe_batches(self, batches: Sequence[Tuple[torch.Tensor, torch.Tensor]],
-                           prepare: Optional[Callable] = None) -> List[list]:
-        """Workers pull from one queue, largest batch first, so that they finish together."""
+                           prepare: Optional[Callable] = None, ready: Optional[Sequence] = None) -> List[list]:
+        """Workers pull from one queue, largest batch first, so that they finish together.  ``ready[k]`` (optional):
+        called by the worker, on its stream, before it touches batch k (a batch that is still being received)."""
         if self.device.type == "cuda":
             cur = torch.cuda.current_stream(self.device)
             for s in self.enc_streams:
@@ -146,7 +151,7 @@ class ConcurrentTranscriber:
         for k in sorted(range(len(batches)), key=lambda i: -batches[i][0].numel()):
             todo.put(k)
         n_workers = min(self.n, (len(batches) + self.group - 1) // self.group)
-        futs = [self.pool.submit(self._work, slot, todo, batches, prepare) for slot in range(max(1, n_workers))]
+        futs = [self.pool.submit(self._work, slot, todo, batches, prepare, ready) for slot in range(max(1, n_workers))]
         res = {}
         for f in futs:
             for k, toks in f.result():

@@ -38,7 +38,7 @@ def _worker(rank, world, tmpdir, q):
         wavs = make_job() if rank == 0 else None
         st = ShardedTranscriber(fake_transcribe, "cpu", max_utts=4)
         local = st.scatter(wavs)
-        n_local = sum(len(ids) for ids, _, _ in local)
+        n_local = sum(len(t[0]) for t in local)
         hyps = st.gather(st.run_local(local))
         if rank == 0:
             q.put(("hyps", hyps))
@@ -47,20 +47,22 @@ def _worker(rank, world, tmpdir, q):
         dist.destroy_process_group()
 
 
-def test_scatter_gather_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_scatter_gather_world2(tmp_path, world):
+    """Streamed scatter (one send per batch, round-robin over the peers) + gather, 2 and 3 ranks."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, str(tmp_path), q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, str(tmp_path), q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(3)]
+    got = [q.get(timeout=120) for _ in range(world + 1)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     hyps = [g[1] for g in got if g[0] == "hyps"][0]
     counts = {g[1]: g[2] for g in got if g[0] == "count"}
     assert hyps == expected(make_job())          # every utterance, in input order, on rank 0
-    assert sum(counts.values()) == 23 and min(counts.values()) >= 6  # both ranks did real work
+    assert sum(counts.values()) == 23 and min(counts.values()) >= 4  # every rank did real work
 
 
 def test_single_process_path():
