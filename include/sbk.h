@@ -115,6 +115,16 @@ int sbk_amplitude_to_db_f32(float* x, float* tile_max, int B, long per_utt, floa
 int sbk_input_norm_global_f32(const float* x, const float* mean, const float* std, float* y, int rows, int C,
                               float eps, sbk_stream_t stream);
 
+/* a6: InputNormalization.forward with norm_type="sentence" (per_batch = 0: mean / std of each utterance's own
+ * valid frames, features.py:1432-1433,1482-1490) or "batch" (per_batch = 1: of all valid frames of the batch, variance
+ * clamped at eps, :1434-1436; gaussian_statistics :997-1089).  x, y [B,T,C]; n_valid[b] = number of unpadded frames
+ * (make_padding_mask :1535-1613: frames t < lengths[b]*T - 1e-6).  Two-pass moments as in the reference; every frame,
+ * padded ones included, is normalised unless avoid_padding_norm (then padded frames pass through, :1451-1453).
+ * workspace: sbk_input_norm_stats_workspace_bytes(B, C) bytes. */
+size_t sbk_input_norm_stats_workspace_bytes(int B, int C);
+int sbk_input_norm_stats_f32(const float* x, const int32_t* n_valid, float* y, float* workspace, int B, int T, int C,
+                             int per_batch, int std_norm, float eps, int avoid_padding_norm, sbk_stream_t stream);
+
 /* ---- dense contraction ---------------------------------------------------
  * C[M,N] = epilogue(A[M,K] . W[N,K]^T): replaces every F.linear / 1x1 Conv1d on
  * the path (nnet/linear.py:44-91, attention.py:623,915-947, Conformer.py

@@ -811,7 +811,34 @@ def golden_wer():
     print(f"  WER {summ['WER']:.3f} over {summ['num_scored_tokens']} tokens, {len(refs)} utterances")
 
 
+def golden_input_norm():
+    """InputNormalization with norm_type "sentence" / "batch" (processing/features.py:1404-1455): the statistics are
+    those of the input itself, over the unpadded frames; std_norm on / off, avoid_padding_norm on / off."""
+    print("== InputNormalization sentence / batch")
+    from speechbrain.processing.features import InputNormalization
+
+    g = torch.Generator().manual_seed(31)
+    x = 3.0 * torch.randn(4, 57, 20, generator=g) + torch.linspace(-5, 5, 20)
+    x[1] *= 0.1
+    lengths = torch.tensor([1.0, 0.72, 0.35, 0.5])
+    out = {"x": x.numpy(), "lengths": lengths.numpy()}
+    for norm_type in ("sentence", "batch"):
+        for std_norm in (True, False):
+            for avoid in (False, True):
+                m = InputNormalization(norm_type=norm_type, std_norm=std_norm, avoid_padding_norm=avoid).eval()
+                with torch.no_grad():
+                    y = m(x, lengths)
+                out[f"y_{norm_type}_{int(std_norm)}_{int(avoid)}"] = y.numpy()
+    with torch.no_grad():
+        out["y_sentence_nolen"] = InputNormalization(norm_type="sentence").eval()(x).numpy()
+    np.savez_compressed(os.path.join(OUT, "input_norm.npz"), **out)
+    print("  cases:", len(out) - 2)
+
+
 if __name__ == "__main__":
+    if "--input-norm-only" in sys.argv:
+        golden_input_norm()
+        sys.exit(0)
     if "--wer-only" in sys.argv:
         golden_wer()
         sys.exit(0)
@@ -855,4 +882,5 @@ if __name__ == "__main__":
     golden_wer()
     golden_streaming()
     golden_whisper()
+    golden_input_norm()
     print("OK")

@@ -2,6 +2,7 @@
 //
 //  sbk_layernorm_f32        y = act(LayerNorm(x))  over the last dimension
 //  sbk_input_norm_global_f32 y = (x - mean[c]) / max(std[c], eps)
+//  sbk_input_norm_stats_f32  the same with the mean / std of the utterance ("sentence") or of the batch ("batch")
 //
 // A row of d floats (d <= a few thousand on this path) is read by the 64 lanes
 // of one wave with 16-byte loads, reduced with wave shuffles (no LDS, no
@@ -99,6 +100,98 @@ __global__ void __launch_bounds__(256) input_norm_kernel(const float* __restrict
   }
 }
 
+// ---- InputNormalization with statistics of the input itself (norm_type "sentence" / "batch") -------------------
+// x [B,T,C]; n_valid[b] frames of utterance b count.  Two-pass moments like the reference (mean first, then the mean
+// of squared deviations), reduced in a fixed order: S time-splits per utterance write partial sums that every
+// consumer adds up in the same order, so the result does not depend on the launch schedule.
+constexpr int NORM_SPLITS = 8;
+
+// part[b][split][c] = sum over the split's valid frames of  x - centre[c]  (squared when `centred`)
+//   centred = 0: plain sums (first pass);  centred = 1: squared deviations from the mean of the first pass
+//   per_batch: the mean is that of the whole batch (all utterances' valid frames) instead of utterance b's own
+__global__ void __launch_bounds__(256) norm_partial_kernel(const float* __restrict__ x, const int* __restrict__ n_valid,
+                                                           const float* __restrict__ sums, float* __restrict__ part,
+                                                           int B, int T, int C, int centred, int per_batch) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.x, split = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = n_valid[b] < T ? n_valid[b] : T;
+  const int per = (T + NORM_SPLITS - 1) / NORM_SPLITS;
+  const int t0 = split * per, t1 = (t0 + per < n) ? t0 + per : n;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
+    float centre = 0.0f;
+    if (centred && c < C) {
+      float tot = 0.0f;
+      long cnt = 0;
+      if (per_batch) {
+        for (int u = 0; u < B; ++u) {
+          for (int k = 0; k < NORM_SPLITS; ++k) tot += sums[((size_t)u * NORM_SPLITS + k) * C + c];
+          cnt += n_valid[u] < T ? n_valid[u] : T;
+        }
+      } else {
+        for (int k = 0; k < NORM_SPLITS; ++k) tot += sums[((size_t)b * NORM_SPLITS + k) * C + c];
+        cnt = n;
+      }
+      centre = tot / (float)cnt;
+    }
+    float acc = 0.0f;
+    if (c < C) {
+      for (int t = t0 + wave; t < t1; t += 4) {
+        const float v = x[((size_t)b * T + t) * C + c] - centre;
+        acc += centred ? v * v : v;
+      }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < C)
+      part[((size_t)b * NORM_SPLITS + split) * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict__ x, const int* __restrict__ n_valid,
+                                                         const float* __restrict__ sums, const float* __restrict__ sq,
+                                                         float* __restrict__ y, int B, int T, int C, int per_batch,
+                                                         int std_norm, float eps, int avoid_padding) {
+  SBK_DYN_LDS(float, stat);  // mean[C], std[C] of this block's utterance
+  const int b = blockIdx.x;
+  const int n = n_valid[b] < T ? n_valid[b] : T;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float tot = 0.0f, dev = 0.0f;
+    long cnt = 0;
+    if (per_batch) {
+      for (int u = 0; u < B; ++u) {
+        for (int k = 0; k < NORM_SPLITS; ++k) {
+          tot += sums[((size_t)u * NORM_SPLITS + k) * C + c];
+          dev += sq[((size_t)u * NORM_SPLITS + k) * C + c];
+        }
+        cnt += n_valid[u] < T ? n_valid[u] : T;
+      }
+    } else {
+      for (int k = 0; k < NORM_SPLITS; ++k) {
+        tot += sums[((size_t)b * NORM_SPLITS + k) * C + c];
+        dev += sq[((size_t)b * NORM_SPLITS + k) * C + c];
+      }
+      cnt = n;
+    }
+    const float var = dev / (float)cnt;
+    stat[c] = tot / (float)cnt;
+    // features.py:1437-1440: "batch" clamps the variance at eps before the root, "sentence" takes the root as it is
+    stat[C + c] = std_norm ? sqrtf(per_batch ? fmaxf(var, eps) : var) : 1.0f;
+  }
+  __syncthreads();
+  const int per = (T + gridDim.y - 1) / gridDim.y;
+  const int t0 = blockIdx.y * per, t1 = (t0 + per < T) ? t0 + per : T;
+  const size_t base = (size_t)b * T * C;
+  for (size_t i = (size_t)t0 * C + threadIdx.x; i < (size_t)t1 * C; i += blockDim.x) {
+    const int c = (int)(i % C);
+    const bool pad = avoid_padding && (int)(i / C) >= n;  // padded frames: mean 0, std 1 (features.py:1451-1453)
+    const float m = pad ? 0.0f : stat[c];
+    const float sd = pad ? 1.0f : stat[C + c];
+    y[base + i] = (x[base + i] - m) / fmaxf(sd, eps);
+  }
+}
+
 }  // namespace
 
 namespace sbk {
@@ -127,6 +220,31 @@ extern "C" int sbk_layernorm_f32(const float* x, const float* gamma, const float
   SBK_REQUIRE(x && gamma && beta && y, "layernorm: null operand");
   SBK_REQUIRE(rows >= 0 && d > 0, "layernorm: bad shape rows=%d d=%d", rows, d);
   return sbk::layernorm(x, gamma, beta, y, rows, d, eps, act, sbk::as_stream(stream));
+}
+
+extern "C" size_t sbk_input_norm_stats_workspace_bytes(int B, int C) {
+  return (size_t)2 * (B > 0 ? B : 0) * NORM_SPLITS * (C > 0 ? C : 0) * sizeof(float);
+}
+
+extern "C" int sbk_input_norm_stats_f32(const float* x, const int32_t* n_valid, float* y, float* workspace, int B, int T,
+                                        int C, int per_batch, int std_norm, float eps, int avoid_padding_norm,
+                                        sbk_stream_t stream) {
+  if (B == 0 || T == 0) return 0;  // empty batch: nothing to launch
+  SBK_REQUIRE(x && n_valid && y && workspace, "input_norm_stats: null operand");
+  SBK_REQUIRE(B > 0 && T > 0 && C > 0 && C <= 4096, "input_norm_stats: bad shape B=%d T=%d C=%d", B, T, C);
+  hipStream_t st = sbk::as_stream(stream);
+  float* sums = workspace;
+  float* sq = workspace + (size_t)B * NORM_SPLITS * C;
+  const double bytes = 4.0 * B * (double)T * C;
+  {
+    sbk::ProfScope prof("input_norm_stats", 0.0, 4.0 * bytes, st);
+    SBK_LAUNCH(norm_partial_kernel, dim3(B, NORM_SPLITS), dim3(256), 0, st, x, n_valid, sums, sums, B, T, C, 0, per_batch);
+    SBK_LAUNCH(norm_partial_kernel, dim3(B, NORM_SPLITS), dim3(256), 0, st, x, n_valid, sums, sq, B, T, C, 1, per_batch);
+    const int ysplit = T >= 512 ? 16 : (T >= 64 ? 4 : 1);
+    SBK_LAUNCH(norm_apply_kernel, dim3(B, ysplit), dim3(256), 2 * C * sizeof(float), st, x, n_valid, sums, sq, y, B, T, C,
+               per_batch, std_norm, eps, avoid_padding_norm);
+  }
+  return sbk::launch_status("sbk_input_norm_stats_f32");
 }
 
 extern "C" int sbk_input_norm_global_f32(const float* x, const float* mean, const float* std, float* y, int rows,

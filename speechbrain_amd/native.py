@@ -82,6 +82,8 @@ def _declare(lib):
         "sbk_spectral_magnitude_f32": ([p, p, ctypes.c_long, f, i, f, p], c_int),
         "sbk_amplitude_to_db_f32": ([p, p, i, ctypes.c_long, f, f, f, f, p], c_int),
         "sbk_input_norm_global_f32": ([p, p, p, p, i, i, f, p], c_int),
+        "sbk_input_norm_stats_workspace_bytes": ([i, i], ctypes.c_size_t),
+        "sbk_input_norm_stats_f32": ([p, p, p, p, i, i, i, i, i, f, i, p], c_int),
         "sbk_gemm_nt_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_f32_to_bf16": ([p, p, ctypes.c_long, p], c_int),
         "sbk_gemm_nt_bf16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
@@ -296,6 +298,21 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         out = torch.empty_like(x)
     _chk(lib.sbk_layernorm_f32(_p(x2), _p(gamma), _p(beta), _p(out), x2.shape[0], d, float(eps), act, _stream(x2)),
          "sbk_layernorm_f32")
+    return out
+
+
+def input_norm_stats(x, n_valid, per_batch, std_norm, eps, avoid_padding_norm=False):
+    """x [B,T,C] normalised with the mean / std of each utterance's valid frames (per_batch False: norm_type
+    "sentence") or of all valid frames of the batch ("batch"); n_valid int32 [B]."""
+    lib = load()
+    _dev_ok(x, n_valid)
+    _f32(x)
+    B, T, C = x.shape
+    out = torch.empty_like(x)
+    ws = torch.empty(max(1, lib.sbk_input_norm_stats_workspace_bytes(B, C) // 4), dtype=torch.float32, device=x.device)
+    _chk(lib.sbk_input_norm_stats_f32(_p(x), _p(n_valid), _p(out), _p(ws), B, T, C, int(bool(per_batch)),
+                                      int(bool(std_norm)), float(eps), int(bool(avoid_padding_norm)), _stream(x)),
+         "sbk_input_norm_stats_f32")
     return out
 
 

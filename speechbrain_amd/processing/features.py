@@ -211,10 +211,20 @@ class InputNormalization(torch.nn.Module):
         self.count = 0
 
     def forward(self, x, lengths=None, epoch=None):
+        if self.norm_type in ("sentence", "batch"):  # statistics of the input itself: the same in train and eval
+            if x.dim() != 3 or self.length_dim != 1:
+                raise NotImplementedError("sentence / batch normalisation of [batch, time, channel] inputs is implemented")
+            T = x.shape[1]
+            if lengths is None:
+                n_valid = torch.full((x.shape[0],), T, dtype=torch.int32, device=x.device)
+            else:  # make_padding_mask (features.py:1603-1606): frame t is valid iff t < lengths * T - 1e-6
+                n_valid = torch.ceil(lengths.to(x.device) * T - 1e-6).clamp_(0, T).to(torch.int32)
+            return native.input_norm_stats(x.contiguous(), n_valid, self.norm_type == "batch", self.std_norm,
+                                           self.epsilon, self.avoid_padding_norm)
         if self.training:
             raise NotImplementedError("statistic updates (training) are outside the MI355X inference path")
-        if self.norm_type != "global" or self.avoid_padding_norm:
-            raise NotImplementedError("only eval-mode global normalisation is on the ASR inference path")
+        if self.avoid_padding_norm:
+            raise NotImplementedError("avoid_padding_norm with global statistics is not on the ASR inference path")
         if self.glob_mean.numel() == 0:
             raise RuntimeError("InputNormalization has no statistics loaded (glob_mean/glob_std)")
         if self.glob_mean.device != x.device:

@@ -276,6 +276,37 @@ def test_pcm16_to_f32(backend, frames, channels):
         assert torch.equal(out.cpu(), ref)
 
 
+def test_input_normalization_sentence_and_batch(backend):
+    """a6: InputNormalization norm_type "sentence" / "batch" against the reference's outputs (tests/golden/
+    input_norm.npz, oracle/make_golden.py:golden_input_norm): statistics over the unpadded frames only, two-pass
+    moments, std_norm on / off, avoid_padding_norm on / off, no lengths.  Tolerance 2e-5 relative to the value
+    scale (a different fp32 summation order over up to 57 x 4 frames)."""
+    nat, dev = backend
+    from speechbrain_amd.processing.features import InputNormalization
+
+    gold = np.load(os.path.join(GOLD, "input_norm.npz"))
+    x, lengths = torch.from_numpy(gold["x"]).to(dev), torch.from_numpy(gold["lengths"]).to(dev)
+    for norm_type in ("sentence", "batch"):
+        for std_norm in (True, False):
+            for avoid in (False, True):
+                m = InputNormalization(norm_type=norm_type, std_norm=std_norm, avoid_padding_norm=avoid).eval()
+                y = m(x, lengths).cpu()
+                ref = torch.from_numpy(gold[f"y_{norm_type}_{int(std_norm)}_{int(avoid)}"])
+                assert float((y - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (norm_type, std_norm, avoid)
+    y = InputNormalization(norm_type="sentence").eval()(x).cpu()
+    ref = torch.from_numpy(gold["y_sentence_nolen"])
+    assert float((y - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    # a long utterance exercises every time split and the 16-way apply grid
+    g = torch.Generator().manual_seed(2)
+    xl = torch.randn(2, 1500, 80, generator=g) * 4.0 + 1.0
+    ll = torch.tensor([1.0, 0.61])
+    yl = InputNormalization(norm_type="sentence").eval()(xl.to(dev), ll.to(dev)).cpu()
+    for b, n in enumerate((1500, 915)):
+        mean = xl[b, :n].double().mean(0)
+        std = (xl[b, :n].double() - mean).square().mean(0).sqrt()
+        assert float((yl[b] - ((xl[b].double() - mean) / std).float()).abs().max()) <= 1e-4
+
+
 def test_documented_capacity_limits_are_reported(backend):
     """include/sbk.h: the attention-weights (strip) kernel keeps a [32][T] score strip in LDS -- beyond the 160 KiB
     window the call must fail with SBK_EINVAL and a message, not crash or compute garbage; the strip-free kernel
