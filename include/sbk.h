@@ -133,7 +133,10 @@ int sbk_input_norm_stats_f32(const float* x, const int32_t* n_valid, float* y, f
  *   if seq_len: rows are [batch][rows_per_seq] and v = 0 for row-in-seq >= seq_len[batch]
  *               (ConvolutionModule's masked_fill_ of padded frames, Conformer.py:327-328)
  *   C = (residual ? residual[m,n] : 0) + alpha * v
- * lda / ldw / ldc / ldr are row strides in elements. */
+ * lda / ldw / ldc / ldr are row strides in elements.  lda < K is allowed (A is read-only): consecutive rows then
+ * overlap -- a window of K floats sliding by lda over a time-major signal, which is how the Conv1d layers of the
+ * Whisper encoder (kernel 3, stride 1 / 2; transformers modeling_whisper.WhisperEncoder, called at
+ * integrations/huggingface/whisper.py:372) run as GEMMs without an im2col copy; A must hold (M-1)*lda + K floats. */
 int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual,
                     int ldr, float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
                     int rows_per_seq, sbk_stream_t stream);

@@ -811,6 +811,64 @@ def golden_wer():
     print(f"  WER {summ['WER']:.3f} over {summ['num_scored_tokens']} tokens, {len(refs)} utterances")
 
 
+def golden_whisper_model():
+    """BASELINE.json configs[4] / SURVEY 8f.5: a tiny random Whisper (HuggingFace layout: config.json, model.safetensors,
+    preprocessor_config.json under tests/golden/whisper_tiny/) through the REFERENCE's wrapper
+    (integrations/huggingface/whisper.py): _get_mel -> forward_encoder (last state and all hidden states) and
+    forward_decoder logits for a token prefix (the wrapper's own method, bound to a tokenizer-free instance)."""
+    print("== Whisper encoder / decoder (tiny random model through the reference wrapper)")
+    import shutil
+    import tempfile
+    import types
+
+    from transformers import WhisperConfig, WhisperFeatureExtractor
+    from transformers import WhisperModel as HFWhisperModel
+
+    from speechbrain.integrations.huggingface.whisper import Whisper
+
+    d = os.path.join(OUT, "whisper_tiny")
+    shutil.rmtree(d, ignore_errors=True)
+    cfg = WhisperConfig(vocab_size=100, num_mel_bins=80, d_model=128, encoder_layers=2, encoder_attention_heads=2,
+                        encoder_ffn_dim=160, decoder_layers=2, decoder_attention_heads=2, decoder_ffn_dim=160,
+                        max_source_positions=50, max_target_positions=24, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                        decoder_start_token_id=3, suppress_tokens=None, begin_suppress_tokens=None)
+    torch.manual_seed(11)
+    hf = HFWhisperModel(cfg).eval()
+    with torch.no_grad():  # non-trivial LayerNorm / bias parameters
+        for n, p_ in hf.named_parameters():
+            if n.endswith("layer_norm.weight"):
+                p_.add_(0.2 * torch.randn_like(p_))
+            elif n.endswith("bias"):
+                p_.add_(0.1 * torch.randn_like(p_))
+    hf.save_pretrained(d, safe_serialization=True)
+    WhisperFeatureExtractor(feature_size=80, sampling_rate=16000, hop_length=160, chunk_length=1, n_fft=400).save_pretrained(d)
+    for f in os.listdir(d):
+        os.chmod(os.path.join(d, f), 0o644)
+    with tempfile.TemporaryDirectory() as tmp:
+        ref = Whisper(d, tmp, encoder_only=True, freeze=True).eval()
+        ref_all = Whisper(d, tmp, encoder_only=True, freeze=True, output_all_hiddens=True).eval()
+    g = torch.Generator().manual_seed(12)
+    wav = torch.stack([0.3 * torch.randn(16000, generator=g), 0.05 * torch.randn(16000, generator=g),
+                       torch.cat([0.2 * torch.randn(9000, generator=g), torch.zeros(7000)])])
+    with torch.no_grad():
+        # (_get_mel always pads to 30 s -- pad_or_trim's default is the module constant N_SAMPLES, whisper.py:318 --
+        # so the tiny model, whose encoder takes 1 s, gets its mel through the two calls _get_mel makes)
+        mel = ref.log_mel_spectrogram(ref.pad_or_trim(wav, 16000))
+        enc = ref.forward_encoder(mel)
+        enc_all = ref_all.forward_encoder(mel)
+    # decoder: the wrapper's forward_decoder on an instance that holds the full model but no tokenizer
+    holder = types.SimpleNamespace(model=hf, output_attentions=False)
+    tokens = torch.randint(3, 100, (3, 7), generator=g)
+    tokens[:, 0] = 3
+    with torch.no_grad():
+        logits, attn, _ = Whisper.forward_decoder(holder, enc, tokens)
+    assert attn is None
+    np.savez_compressed(os.path.join(OUT, "whisper_model.npz"), wav=wav.numpy(), mel=mel.numpy(), enc=enc.numpy(),
+                        enc_all=enc_all.numpy(), tokens=tokens.numpy(), logits=logits.numpy())
+    print("  mel", tuple(mel.shape), "enc", tuple(enc.shape), "enc_all", tuple(enc_all.shape), "logits", tuple(logits.shape),
+          "|enc| max", float(enc.abs().max()), "|logits| max", float(logits.abs().max()))
+
+
 def golden_input_norm():
     """InputNormalization with norm_type "sentence" / "batch" (processing/features.py:1404-1455): the statistics are
     those of the input itself, over the unpadded frames; std_norm on / off, avoid_padding_norm on / off."""
@@ -836,6 +894,9 @@ def golden_input_norm():
 
 
 if __name__ == "__main__":
+    if "--whisper-model-only" in sys.argv:
+        golden_whisper_model()
+        sys.exit(0)
     if "--input-norm-only" in sys.argv:
         golden_input_norm()
         sys.exit(0)
@@ -883,4 +944,5 @@ if __name__ == "__main__":
     golden_streaming()
     golden_whisper()
     golden_input_norm()
+    golden_whisper_model()
     print("OK")

@@ -986,7 +986,8 @@ extern "C" int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw,
   if (M == 0 || N == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(A && W && C, "gemm: null operand");
   SBK_REQUIRE(M >= 0 && N >= 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
-  SBK_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dimension smaller than the row");
+  // lda < K is allowed: rows of A then overlap (a strided window over a time-major signal = a 1-D convolution read in place)
+  SBK_REQUIRE(lda > 0 && ldw >= K && ldc >= N, "gemm: leading dimension smaller than the row");
   SBK_REQUIRE(!residual || ldr >= N, "gemm: residual stride");
   SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm: unknown activation %d", act);
   SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm: seq_len given without rows_per_seq");
@@ -1078,7 +1079,7 @@ extern "C" int sbk_gemm_nt_bf16(const float* A, int lda, const uint16_t* Wb, int
   if (M == 0 || N == 0) return 0;
   SBK_REQUIRE(A && Wb && C, "gemm_bf16: null operand");
   SBK_REQUIRE(M >= 0 && N >= 0 && K > 0 && K % 8 == 0, "gemm_bf16: bad shape M=%d N=%d K=%d (K must be a multiple of 8)", M, N, K);
-  SBK_REQUIRE(lda >= K && ldw >= K && ldc >= N && lda % 4 == 0 && ldw % 8 == 0, "gemm_bf16: leading dimensions");
+  SBK_REQUIRE(lda > 0 && ldw >= K && ldc >= N && lda % 4 == 0 && ldw % 8 == 0, "gemm_bf16: leading dimensions");
   SBK_REQUIRE(sbk::aligned16(A) && sbk::aligned16(Wb), "gemm_bf16: operands must be 16-byte aligned");
   SBK_REQUIRE(!residual || ldr >= N, "gemm_bf16: residual stride");
   SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_bf16: unknown activation %d", act);

@@ -95,3 +95,276 @@ class WhisperLogMel(torch.nn.Module):
 
     def forward(self, wav):
         return self.log_mel_spectrogram(self.pad_or_trim(wav))
+
+
+# ------------------------------------------------------------------------------------------- encoder / decoder
+# The reference wraps HuggingFace's WhisperModel (whisper.py:59-117; encoder call :372-374, decoder call :417-436).
+# Here the same parameters (HF state_dict names, so HF / SpeechBrain checkpoints load unchanged) drive the MI355X
+# kernels: the two input convolutions are GEMMs over an in-place strided window of the time-major signal, attention is
+# the flash kernel of the Conformer encoder with an identity rotation, every Linear / LayerNorm / GELU is the fused
+# GEMM / row kernel of the rest of the path.
+import json  # noqa: E402
+import os  # noqa: E402
+
+from torch import nn  # noqa: E402
+
+
+class _Attention(nn.Module):
+    """Parameter holder with HF's names (modeling_whisper.WhisperAttention): k_proj has no bias."""
+
+    def __init__(self, d, heads):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.head_dim = d, heads, d // heads
+        assert self.head_dim * heads == d
+        self.k_proj = nn.Linear(d, d, bias=False)
+        self.v_proj = nn.Linear(d, d)
+        self.q_proj = nn.Linear(d, d)
+        self.out_proj = nn.Linear(d, d)
+
+    def stacked(self, interleave_heads):
+        """(in_proj weight [3d,d], bias [3d]) of the three projections, cached until a parameter changes.
+        interleave_heads: rows ordered [head][q|k|v][head_dim] (what the encoder attention kernel reads in place);
+        otherwise [q|k|v][d] (torch.nn.MultiheadAttention's in_proj layout, read by the decoder kernels)."""
+        ps = (self.q_proj.weight, self.q_proj.bias, self.k_proj.weight, self.v_proj.weight, self.v_proj.bias)
+        key = (interleave_heads,) + tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_stack_key", None) != key:
+            with torch.no_grad():
+                zero = torch.zeros_like(self.q_proj.bias)
+                w = torch.stack([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])       # [3,d,d]
+                b = torch.stack([self.q_proj.bias, zero, self.v_proj.bias])                          # [3,d]
+                if interleave_heads:
+                    H, Dh, d = self.num_heads, self.head_dim, self.embed_dim
+                    w = w.view(3, H, Dh, d).permute(1, 0, 2, 3)
+                    b = b.view(3, H, Dh).permute(1, 0, 2)
+                self._stack = (w.reshape(3 * self.embed_dim, self.embed_dim).contiguous(), b.reshape(-1).contiguous())
+            self._stack_key = key
+        return self._stack
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, d, heads, ffn):
+        super().__init__()
+        self.self_attn = _Attention(d, heads)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, ffn)
+        self.fc2 = nn.Linear(ffn, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+class _DecoderLayer(nn.Module):
+    def __init__(self, d, heads, ffn):
+        super().__init__()
+        self.self_attn = _Attention(d, heads)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.encoder_attn = _Attention(d, heads)
+        self.encoder_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, ffn)
+        self.fc2 = nn.Linear(ffn, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+def _identity_rotation(rows, head_dim, device):
+    """cos = 1, sin = 0: the rotary attention kernel then computes plain scaled-dot-product attention."""
+    key = (head_dim, str(device))
+    have = _identity_rotation.cache.get(key)
+    if have is None or have[0].shape[0] < rows:
+        n = 1 << max(rows - 1, 1).bit_length()
+        have = (torch.ones(n, head_dim, device=device), torch.zeros(n, head_dim, device=device))
+        _identity_rotation.cache[key] = have
+    return have
+
+
+_identity_rotation.cache = {}
+
+
+class WhisperEncoder(nn.Module):
+    """modeling_whisper.WhisperEncoder: conv1(k3,s1)+GELU -> conv2(k3,s2)+GELU -> + embed_positions -> pre-norm
+    layers (MHA without masks, GELU feed-forward) -> layer_norm."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        d = cfg["d_model"]
+        self.num_mel_bins, self.max_source_positions = cfg["num_mel_bins"], cfg["max_source_positions"]
+        self.conv1 = nn.Conv1d(self.num_mel_bins, d, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv1d(d, d, kernel_size=3, stride=2, padding=1)
+        self.embed_positions = nn.Embedding(self.max_source_positions, d)
+        self.layers = nn.ModuleList([_EncoderLayer(d, cfg["encoder_attention_heads"], cfg["encoder_ffn_dim"])
+                                     for _ in range(cfg["encoder_layers"])])
+        self.layer_norm = nn.LayerNorm(d)
+
+    def _conv_weight(self, conv):
+        """[out, in, 3] -> [out, 3*in] with the tap as the slow index: one row of the strided window."""
+        key = (conv.weight.data_ptr(), conv.weight._version)
+        if getattr(conv, "_gemm_key", None) != key:
+            with torch.no_grad():
+                conv._gemm_w = conv.weight.permute(0, 2, 1).reshape(conv.weight.shape[0], -1).contiguous()
+            conv._gemm_key = key
+        return conv._gemm_w
+
+    def forward(self, input_features, output_hidden_states=False):
+        """input_features [B, n_mels, 2 * max_source_positions] -> last hidden state [B, max_source_positions, d]
+        (and, if asked, the tuple of hidden states: embeddings, every layer's output, the last one normalised --
+        HF's convention, which ``forward_encoder`` of the reference stacks)."""
+        B, C, T = input_features.shape
+        expected = 2 * self.max_source_positions
+        if T != expected or C != self.num_mel_bins:
+            raise ValueError(f"Whisper expects the mel input features to be [B, {self.num_mel_bins}, {expected}], "
+                             f"but found {tuple(input_features.shape)}. Pad or trim the audio to the model's chunk length.")
+        d = self.conv1.out_channels
+        dev = input_features.device
+        # time-major copy with one zero frame on either side (the convolutions' padding)
+        xp = torch.zeros(B, T + 2, C, dtype=torch.float32, device=dev)
+        xp[:, 1: T + 1] = input_features.transpose(1, 2)
+        h1 = torch.zeros(B, T + 2, d, dtype=torch.float32, device=dev)  # conv1 output, padded for conv2
+        w1, w2 = self._conv_weight(self.conv1), self._conv_weight(self.conv2)
+        pos = self.embed_positions.weight
+        x = torch.empty(B, T // 2, d, dtype=torch.float32, device=dev)
+        for b in range(B):
+            # frame t of conv1 reads padded frames t .. t+2: 3*C contiguous floats starting at t*C
+            native.gemm_nt_rows(xp[b].reshape(-1), T, 3 * C, C, w1, self.conv1.bias, act=native.ACT_GELU,
+                                out=h1[b, 1: T + 1])
+            # frame t of conv2 (stride 2) reads padded frames 2t .. 2t+2; + positions after the GELU
+            native.gemm_nt_rows(h1[b].reshape(-1), T // 2, 3 * d, 2 * d, w2, self.conv2.bias, residual=pos,
+                                act=native.ACT_GELU, out=x[b])
+        hidden = [x] if output_hidden_states else None
+        Tq = T // 2
+        for layer in self.layers:
+            att = layer.self_attn
+            ln = layer.self_attn_layer_norm
+            h = native.layernorm(x, ln.weight, ln.bias, ln.eps)
+            w_in, b_in = att.stacked(interleave_heads=True)
+            qkv = native.gemm_nt(h, w_in, b_in)
+            cos, sin = _identity_rotation(Tq, att.head_dim, dev)
+            ctx, _ = native.rope_attention(qkv, cos, sin, None, att.num_heads, att.head_dim ** -0.5)
+            x = native.gemm_nt(ctx, att.out_proj.weight, att.out_proj.bias, residual=x)
+            ln = layer.final_layer_norm
+            h = native.layernorm(x, ln.weight, ln.bias, ln.eps)
+            h = native.gemm_nt(h, layer.fc1.weight, layer.fc1.bias, act=native.ACT_GELU)
+            x = native.gemm_nt(h, layer.fc2.weight, layer.fc2.bias, residual=x)
+            if hidden is not None:
+                hidden.append(x)
+        x = native.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        if hidden is not None:
+            hidden[-1] = x
+            return x, tuple(hidden)
+        return x
+
+
+class WhisperDecoder(nn.Module):
+    """Parameter tree of modeling_whisper.WhisperDecoder (embed_tokens, learned embed_positions, pre-norm layers with
+    self- and cross-attention, GELU feed-forward, layer_norm); the arithmetic is the KV-cached decoder step of
+    csrc/decoder.hip, reached through ``Whisper.forward_decoder`` and the Whisper searchers."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        d = cfg["d_model"]
+        self.max_target_positions = cfg["max_target_positions"]
+        self.embed_tokens = nn.Embedding(cfg["vocab_size"], d, padding_idx=cfg.get("pad_token_id"))
+        self.embed_positions = nn.Embedding(self.max_target_positions, d)
+        self.layers = nn.ModuleList([_DecoderLayer(d, cfg["decoder_attention_heads"], cfg["decoder_ffn_dim"])
+                                     for _ in range(cfg["decoder_layers"])])
+        self.layer_norm = nn.LayerNorm(d)
+
+
+class WhisperModel(nn.Module):
+    def __init__(self, cfg, encoder_only=False):
+        super().__init__()
+        self.config = dict(cfg)
+        self.encoder = WhisperEncoder(cfg)
+        self.decoder = None if encoder_only else WhisperDecoder(cfg)
+
+
+def _read_checkpoint(source):
+    """{name: tensor} from a HuggingFace model directory (model.safetensors or pytorch_model.bin)."""
+    st = os.path.join(source, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+
+        return load_file(st)
+    pt = os.path.join(source, "pytorch_model.bin")
+    if os.path.exists(pt):
+        return torch.load(pt, map_location="cpu")
+    raise FileNotFoundError(f"{source}: neither model.safetensors nor pytorch_model.bin (a LOCAL HuggingFace model "
+                            "directory is needed; this package does not download)")
+
+
+class Whisper(WhisperLogMel):
+    """speechbrain.integrations.huggingface.whisper.Whisper (whisper.py:59-665) on the MI355X kernels.
+
+    ``source`` is a LOCAL HuggingFace model directory (config.json, model.safetensors / pytorch_model.bin,
+    preprocessor_config.json, and -- unless ``encoder_only`` -- the tokenizer files); nothing is downloaded.
+    ``forward(wav, decoder_input_ids)``, ``forward_encoder(mel)``, ``forward_decoder(encoder_states,
+    decoder_input_ids)`` keep the reference's signatures and return values (attention maps are not produced:
+    ``output_attentions`` raises)."""
+
+    def __init__(self, source, save_path=None, sampling_rate=16000, encoder_only=False, freeze=False, freeze_encoder=False,
+                 output_attentions=False, output_all_hiddens=False, language=None, task="transcribe"):
+        with open(os.path.join(source, "config.json")) as f:
+            cfg = json.load(f)
+        if cfg.get("activation_function", "gelu") != "gelu":
+            raise NotImplementedError("Whisper with an activation other than GELU")
+        if output_attentions:
+            raise NotImplementedError("attention maps are not produced by the fused decoder kernels")
+        fe = {}
+        pp = os.path.join(source, "preprocessor_config.json")
+        if os.path.exists(pp):
+            with open(pp) as f:
+                fe = json.load(f)
+        n_fft, hop = fe.get("n_fft", N_FFT), fe.get("hop_length", HOP_LENGTH)
+        n_samples = fe.get("n_samples", fe.get("chunk_length", CHUNK_LENGTH) * fe.get("sampling_rate", SAMPLE_RATE))
+        super().__init__(n_mels=cfg["num_mel_bins"], n_fft=n_fft, hop_length=hop, n_samples=n_samples)
+        self.sampling_rate, self.encoder_only, self.freeze, self.freeze_encoder = sampling_rate, encoder_only, freeze, freeze_encoder
+        self.output_attentions, self.output_all_hiddens = output_attentions, output_all_hiddens
+        self.language, self.task = language, task
+        self.model = WhisperModel(cfg, encoder_only=encoder_only)
+        state = _read_checkpoint(source)
+        state = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in state.items()}
+        state = {k: v.float() for k, v in state.items()
+                 if k != "proj_out.weight" and not (encoder_only and k.startswith("decoder."))}
+        self.model.load_state_dict(state, strict=True)
+        self.tokenizer = None
+        if not encoder_only:
+            self.load_tokenizer(source, bos_token="<|startoftranscript|>")
+            if self.tokenizer is not None and self.is_multilingual:
+                self.tokenizer.set_prefix_tokens(language=self.language or "en", task=self.task)
+        for p in self.model.parameters():  # inference path: parameters are constants
+            p.requires_grad_(False)
+
+    def load_tokenizer(self, source, **kwargs):
+        """The HuggingFace tokenizer of the model directory (host-side text processing, as in the reference,
+        huggingface.py:420-430); a directory without tokenizer files leaves ``tokenizer`` None."""
+        if not any(os.path.exists(os.path.join(source, f)) for f in ("tokenizer.json", "vocab.json")):
+            return
+        from transformers import AutoTokenizer
+
+        self.tokenizer = AutoTokenizer.from_pretrained(source, **kwargs)
+
+    @property
+    def is_multilingual(self):
+        """whisper.py:604-607."""
+        return self.model.config["vocab_size"] >= 51865
+
+    def forward(self, wav, decoder_input_ids=None):
+        """whisper.py:212-256: mel -> encoder (-> decoder logits for the given prefix)."""
+        with torch.no_grad():
+            out_encoder = self.forward_encoder(self._get_mel(wav))
+            if self.encoder_only:
+                return out_encoder
+            states = out_encoder[-1] if self.output_all_hiddens else out_encoder
+            logits, attn, _ = self.forward_decoder(states, decoder_input_ids)
+            return out_encoder, logits, attn
+
+    def pad_or_trim(self, array, length: int = N_SAMPLES, axis=-1):
+        """whisper.py:318-350 -- the default length is the 30-second constant, whatever the feature extractor says."""
+        return super().pad_or_trim(array, length, axis)
+
+    def _get_mel(self, wav):
+        """whisper.py:258-274."""
+        return self.log_mel_spectrogram(self.pad_or_trim(wav))
+
+    def forward_encoder(self, mel):
+        """whisper.py:356-378: the last hidden state, or all hidden states stacked [layers+1, B, T', d]."""
+        with torch.no_grad():
+            if self.output_all_hiddens:
+                return torch.stack(self.model.encoder(mel.float().contiguous(), output_hidden_states=True)[1])
+            return self.model.encoder(mel.float().contiguous())

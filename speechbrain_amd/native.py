@@ -216,6 +216,30 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_
     return out
 
 
+def gemm_nt_rows(a_flat: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE,
+                 alpha=1.0, out=None):
+    """gemm_nt whose A operand is M rows of K floats starting every ``lda`` floats in the flat tensor ``a_flat``.
+    ``lda`` < K makes consecutive rows overlap: a strided window over a time-major signal, i.e. a 1-D convolution read
+    in place (no im2col copy).  out [M,N] (contiguous)."""
+    lib = load()
+    N = w.shape[0]
+    if M == 0:
+        return out if out is not None else torch.empty(0, N, dtype=torch.float32, device=a_flat.device)
+    if a_flat.dim() != 1 or a_flat.numel() < (M - 1) * lda + K or w.shape[1] != K:
+        raise SbkError(f"gemm_nt_rows: {M} rows of {K} every {lda} do not fit {tuple(a_flat.shape)} / {tuple(w.shape)}")
+    _dev_ok(a_flat, w, bias, residual, out)
+    _f32(a_flat), _f32(w)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a_flat.device)
+    if precision() == "bf16" and M >= 256 and K % 8 == 0 and lda % 4 == 0:
+        _chk(lib.sbk_gemm_nt_bf16(_p(a_flat), int(lda), _p(bf16_weight(w)), K, _p(bias), _p(residual), N, _p(out), N, M, N, K,
+                                  act, float(alpha), None, 0, _stream(a_flat)), "sbk_gemm_nt_bf16")
+        return out
+    _chk(lib.sbk_gemm_nt_f32(_p(a_flat), int(lda), _p(w), w.stride(0), _p(bias), _p(residual), N, _p(out), N, M, N, K, act,
+                             float(alpha), None, 0, _stream(a_flat)), "sbk_gemm_nt_f32")
+    return out
+
+
 _BF16_WEIGHTS = {}  # (data_ptr, _version, shape) -> bf16 copy of a weight matrix (converted once)
 
 

@@ -60,3 +60,39 @@ def test_log_mel_vs_torch_restatement(backend):
     assert out.shape == (3, 80, 100)
     assert float((out - ref).abs().max()) <= 2e-4
     assert float(out[2].max()) == pytest.approx(float(ref[2].max()), abs=1e-6)  # silence sits exactly on the floor
+
+
+# ------------------------------------------------------------------------------------------- encoder / decoder
+MODEL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "whisper_tiny")
+MODEL_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "whisper_model.npz")
+
+
+def test_whisper_encoder_matches_reference_golden(backend):
+    """forward_encoder (conv1/conv2 as strided-window GEMMs, positions, pre-norm layers with plain MHA on the flash
+    kernel, final norm) against the REFERENCE wrapper's outputs for the tiny random model under tests/golden/
+    whisper_tiny (oracle/make_golden.py:golden_whisper_model).  Tolerance 5e-5 absolute on activations of unit
+    scale (|x| up to 3.7); the mel feeding it is the kernel's own (2e-4, its own test)."""
+    nat, dev = backend
+    from speechbrain_amd.integrations.huggingface.whisper import Whisper
+
+    g = np.load(MODEL_GOLD)
+    w = Whisper(MODEL_DIR, encoder_only=True).to(dev).eval()
+    assert w.tokenizer is None and w.model.decoder is None
+    mel_ref = torch.from_numpy(g["mel"]).to(dev)
+    enc = w.forward_encoder(mel_ref)
+    assert enc.shape == g["enc"].shape
+    assert float((enc.cpu() - torch.from_numpy(g["enc"])).abs().max()) <= 5e-5
+    # all hidden states, stacked as the reference stacks them
+    w.output_all_hiddens = True
+    allh = w.forward_encoder(mel_ref)
+    assert allh.shape == g["enc_all"].shape
+    assert float((allh.cpu() - torch.from_numpy(g["enc_all"])).abs().max()) <= 5e-5
+    w.output_all_hiddens = False
+    # from the waveform: the wrapper's own mel (1-second chunk of this tiny model) -> encoder
+    wav = torch.from_numpy(g["wav"]).to(dev)
+    mel = w.log_mel_spectrogram(w.pad_or_trim(wav, 16000))
+    assert float((mel.cpu() - torch.from_numpy(g["mel"])).abs().max()) <= 2e-4
+    enc2 = w.forward_encoder(mel)
+    assert float((enc2.cpu() - torch.from_numpy(g["enc"])).abs().max()) <= 1e-3
+    with pytest.raises(ValueError):  # _get_mel pads to 30 s like the reference: 3000 frames do not fit this model
+        w(wav)
