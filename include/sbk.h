@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SBK_ABI_VERSION 2
+#define SBK_ABI_VERSION 3
 
 typedef void* sbk_stream_t; /* hipStream_t */
 
@@ -240,6 +240,8 @@ typedef struct {
   const float *seq_wf, *seq_bf;    /* optional: seq_lin with decoder.norm folded in (see sbk_decoder_layer) */
   int32_t d_model, nhead, d_ffn, n_layers, vocab, max_len, ffn_act;
   float ln_eps;
+  float emb_scale; /* multiplier of the token embedding: 0 = sqrt(d_model) (NormalizedEmbedding, nnet/embedding.py);
+                      1 for the Whisper decoder, whose `pe` is its learned embed_positions table */
 } sbk_decoder_weights;
 
 /* ---- a20: TransformerLM (lobes/models/transformer/TransformerLM.py:22-187; encoder-only, regularMHA,
@@ -326,6 +328,23 @@ int sbk_greedy_search_f32(const sbk_decoder_weights* W, const float* enc, const 
                           size_t workspace_bytes, int32_t* out_tokens, float* out_scores, int32_t* host_flag,
                           int32_t* steps_run, int B, int T, int min_steps, int max_steps, int bos, int eos,
                           int check_every, sbk_stream_t stream);
+
+/* S2SWhisperGreedySearcher.forward (seq2seq.py:421-636 on S2SGreedySearcher.forward :176-327, temperature 0) for a
+ * decoder described by sbk_decoder_weights (the Whisper decoder: emb_scale 1, learned positions, GELU, seq_w = the
+ * tied token embedding, seq_b zeros).  prompt [B,P] int32 (device): the initial tokens (:542-573, per-utterance
+ * language token allowed); positions 0..P-2 only fill the KV cache, the last prompt token is the first decoder input.
+ * Step k = 0.. samples arg-max of  logits + logit_bias (+ first_bias at k = 0)  -- [V] additive masks of 0 / -inf
+ * (suppress_tokens :627-629, suppress_blank :619-625), NULL = none -- with the EOS latch, scores and layout of
+ * sbk_greedy_search_f32: out_tokens / out_scores [B,max_new].  out_probe [B] (may be NULL): softmax(logits at prompt
+ * position probe_pos)[probe_token] -- no_speech_probs (:604-612).  enc_len: pass T for every utterance (the Whisper
+ * decoder attends to all encoder frames). */
+size_t sbk_prompted_greedy_search_workspace_bytes(const sbk_decoder_weights* W, int B, int T, int P, int max_new);
+int sbk_prompted_greedy_search_f32(const sbk_decoder_weights* W, const float* enc, const int32_t* enc_len,
+                                   const int32_t* prompt, int P, const float* logit_bias, const float* first_bias,
+                                   void* workspace, size_t workspace_bytes, int32_t* out_tokens, float* out_scores,
+                                   int probe_pos, int probe_token, float* out_probe, int32_t* host_flag,
+                                   int32_t* steps_run, int B, int T, int max_new, int eos, int check_every,
+                                   sbk_stream_t stream);
 
 /* TransformerASR.decode (TransformerASR.py:426-473) through the KV-cached step:
  * tokens [n,L] int32, enc [n,T,d], enc_len [n] -> pred [n,L,d] (decoder.norm output). */

@@ -811,6 +811,12 @@ def golden_wer():
     print(f"  WER {summ['WER']:.3f} over {summ['num_scored_tokens']} tokens, {len(refs)} utterances")
 
 
+EOS_GAIN = 2.6
+# token ids of the stub tokenizer used for the tiny Whisper (vocab 100)
+WHISPER_IDS = {"<|endoftext|>": 2, "<|startoftranscript|>": 3, "<|en|>": 4, "<|fr|>": 5, "<|transcribe|>": 10,
+               "<|translate|>": 11, "<|startoflm|>": 12, "<|startofprev|>": 13, "<|nospeech|>": 14, "<|notimestamps|>": 15}
+
+
 def golden_whisper_model():
     """BASELINE.json configs[4] / SURVEY 8f.5: a tiny random Whisper (HuggingFace layout: config.json, model.safetensors,
     preprocessor_config.json under tests/golden/whisper_tiny/) through the REFERENCE's wrapper
@@ -840,6 +846,8 @@ def golden_whisper_model():
                 p_.add_(0.2 * torch.randn_like(p_))
             elif n.endswith("bias"):
                 p_.add_(0.1 * torch.randn_like(p_))
+        hf.decoder.embed_tokens.weight.mul_(2.2)     # peaked output distributions (tied input / output embedding)
+        hf.decoder.embed_tokens.weight[2] *= EOS_GAIN  # <|endoftext|> within reach for some utterances
     hf.save_pretrained(d, safe_serialization=True)
     WhisperFeatureExtractor(feature_size=80, sampling_rate=16000, hop_length=160, chunk_length=1, n_fft=400).save_pretrained(d)
     for f in os.listdir(d):
@@ -863,8 +871,37 @@ def golden_whisper_model():
     with torch.no_grad():
         logits, attn, _ = Whisper.forward_decoder(holder, enc, tokens)
     assert attn is None
+    # greedy search: the REFERENCE's S2SWhisperGreedySearcher on a model object that carries what the searcher reads
+    # (token ids, tokenizer.prefix_tokens / encode(" "), non_speech_tokens) and the wrapper's own forward_decoder
+    from speechbrain.decoders.seq2seq import S2SWhisperGreedySearcher
+
+    tok = types.SimpleNamespace(prefix_tokens=[3, 4, 10, 15],
+                                encode=lambda text, add_special_tokens=False: {" ": [16]}[text])
+    ids = WHISPER_IDS
+    model = types.SimpleNamespace(
+        model=hf, output_attentions=False, tokenizer=tok, bos=ids["<|startoftranscript|>"], eos=ids["<|endoftext|>"],
+        bos_prev=ids["<|startofprev|>"], bos_lm=ids["<|startoflm|>"], transcribe=ids["<|transcribe|>"],
+        translate=ids["<|translate|>"], no_speech=ids["<|nospeech|>"], non_speech_tokens=(20, 21, 22, 40))
+    model.forward_decoder = types.MethodType(Whisper.forward_decoder, model)
+    searcher = S2SWhisperGreedySearcher(model=model, min_decode_ratio=0.0, max_decode_ratio=1.0)
+    # (random-weight cross-attention averages the audio away: the three utterances differ through their language token)
+    searcher.set_lang_tokens(torch.tensor([ids["<|en|>"], ids["<|fr|>"], 6]))
+    with torch.no_grad():
+        hyps, lens, scores, log_probs = searcher(enc, torch.ones(3))
+    steps = log_probs.shape[2]
+    top2 = log_probs[:, 0].topk(2, dim=-1).values
+    alive = torch.isfinite(top2[..., 0])
+    margin = float((top2[..., 0] - top2[..., 1])[alive].min())
+    print("  greedy: steps", steps, "hyp lengths", [len(h) for h in hyps], "min top-1/top-2 margin", margin,
+          "no_speech_probs", searcher.no_speech_probs)
+    assert margin > 2e-3, "pick another seed: an arg-max of the golden sits within fp32 noise"
+    assert min(len(h) for h in hyps) < steps, "no hypothesis ends through EOS: raise EOS_GAIN"
     np.savez_compressed(os.path.join(OUT, "whisper_model.npz"), wav=wav.numpy(), mel=mel.numpy(), enc=enc.numpy(),
-                        enc_all=enc_all.numpy(), tokens=tokens.numpy(), logits=logits.numpy())
+                        enc_all=enc_all.numpy(), tokens=tokens.numpy(), logits=logits.numpy(),
+                        greedy_hyps=np.array([h + [-1] * (steps - len(h)) for h in hyps]), greedy_lens=lens.numpy(),
+                        greedy_scores=scores.numpy(), greedy_no_speech=np.array(searcher.no_speech_probs),
+                        initial_tokens=np.array(searcher.initial_tokens),
+                        suppress=np.array(searcher.get_tokens_to_suppress))
     print("  mel", tuple(mel.shape), "enc", tuple(enc.shape), "enc_all", tuple(enc_all.shape), "logits", tuple(logits.shape),
           "|enc| max", float(enc.abs().max()), "|logits| max", float(logits.abs().max()))
 

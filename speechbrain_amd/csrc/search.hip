@@ -549,20 +549,26 @@ __global__ void __launch_bounds__(256) beam_finalize_kernel(BeamState s, int cur
 __global__ void __launch_bounds__(256) greedy_pick_kernel(const float* __restrict__ logits, int32_t* __restrict__ tok_out,
                                                           int32_t* __restrict__ ended, int32_t* __restrict__ hyp,
                                                           float* __restrict__ score, int32_t* __restrict__ n_ended,
-                                                          int V, int k, int Lmax, int eos) {
+                                                          int V, int k, int Lmax, int eos,
+                                                          const float* __restrict__ bias1,
+                                                          const float* __restrict__ bias2) {
   __shared__ float wv[4];
   __shared__ int wi[4];
   __shared__ float red[4];
   __shared__ float row_lse;
   const int i = blockIdx.x, tid = threadIdx.x;
   const float* x = logits + (size_t)i * V;
+  // optional additive logit masks (0 / -inf: suppressed tokens never win and drop out of the normaliser)
+  auto at = [&](int c) { return x[c] + (bias1 ? bias1[c] : 0.0f) + (bias2 ? bias2[c] : 0.0f); };
   float v = -INFINITY;
   int a = INT_MAX;
-  for (int c = tid; c < V; c += 256)
-    if (better(x[c], c, v, a)) {
-      v = x[c];
+  for (int c = tid; c < V; c += 256) {
+    const float xc = at(c);
+    if (better(xc, c, v, a)) {
+      v = xc;
       a = c;
     }
+  }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
     const float ov = sbk::shfl_xor(v, m);
@@ -586,7 +592,7 @@ __global__ void __launch_bounds__(256) greedy_pick_kernel(const float* __restric
     }
   // log-softmax value of the arg-max: max - logsumexp
   float se = 0.0f;
-  for (int c = tid; c < V; c += 256) se += expf(x[c] - bv);
+  for (int c = tid; c < V; c += 256) se += expf(at(c) - bv);
   se = sbk::wave_sum(se);
   if ((tid & 63) == 0) red[tid >> 6] = se;
   __syncthreads();
@@ -611,6 +617,27 @@ __global__ void greedy_init_kernel(int32_t* tok, int32_t* ended, int32_t* n_ende
   tok[i] = bos;
   ended[i] = 0;
   for (int p = 0; p < Lmax; ++p) kv_slot[(size_t)i * Lmax + p] = i;
+}
+
+// out[i] = softmax(logits[i])[token]  (S2SWhisperGreedySearcher: no-speech probability at the start-of-transcript position)
+__global__ void __launch_bounds__(256) softmax_prob_kernel(const float* __restrict__ logits, float* __restrict__ out, int V,
+                                                           int token) {
+  __shared__ float red[4];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const float* x = logits + (size_t)i * V;
+  float m = -INFINITY;
+  for (int c = tid; c < V; c += 256) m = fmaxf(m, x[c]);
+  m = sbk::wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.0f;
+  for (int c = tid; c < V; c += 256) se += expf(x[c] - m);
+  se = sbk::wave_sum(se);
+  if ((tid & 63) == 0) red[tid >> 6] = se;
+  __syncthreads();
+  if (tid == 0) out[i] = expf(x[token] - m) / ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 __global__ void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int d, long dst_stride) {
@@ -696,7 +723,8 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
                  const int32_t* enc_len, int step, int n, int B, int T, int beam, int Lmax, bool want_logits,
                  hipStream_t st) {
   const int dm = W->d_model, H = W->nhead;
-  SBK_TRY(sbk::embed_pos(tokens, W->emb, W->pe + (size_t)step * dm, d.x, n, dm, sqrtf((float)dm), st));
+  const float emb_scale = W->emb_scale > 0.0f ? W->emb_scale : sqrtf((float)dm);  // NormalizedEmbedding: sqrt(d_model)
+  SBK_TRY(sbk::embed_pos(tokens, W->emb, W->pe + (size_t)step * dm, d.x, n, dm, emb_scale, st));
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
     int frc = L.sa_in_wf ? sbk::gemm_ln_nt(d.x, dm, L.sa_in_wf, dm, L.sa_in_bf, nullptr, 0, d.qkv, 3 * dm, n, 3 * dm, dm,
@@ -1236,7 +1264,7 @@ extern "C" int sbk_greedy_search_f32(const sbk_decoder_weights* W, const float* 
   for (int step = min_steps; step < max_steps; ++step, ++k) {  // positions count from 0 (seq2seq.py:227)
     SBK_TRY(decoder_step(W, d, tok, kv_slot, enc_len, k, B, B, T, 1, L, true, st));
     SBK_LAUNCH(greedy_pick_kernel, dim3(B), dim3(256), 0, st, (const float*)d.logits, tok, ended, out_tokens,
-               out_scores, n_ended, W->vocab, k, L, eos);
+               out_scores, n_ended, W->vocab, k, L, eos, (const float*)nullptr, (const float*)nullptr);
     SBK_TRY(sbk::launch_status("greedy_pick"));
     if (host_flag && check_every > 0 && ((k + 1) % check_every == 0)) {
       SBK_HIP(hipMemcpyAsync(host_flag, n_ended, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1248,5 +1276,81 @@ extern "C" int sbk_greedy_search_f32(const sbk_decoder_weights* W, const float* 
     }
   }
   if (steps_run) *steps_run = k;
+  return 0;
+}
+
+// S2SWhisperGreedySearcher.forward (seq2seq.py:176-327 + :421-636): a token prompt common in length to the batch
+// primes the KV cache, then arg-max decoding with additive logit masks.
+extern "C" size_t sbk_prompted_greedy_search_workspace_bytes(const sbk_decoder_weights* W, int B, int T, int P,
+                                                             int max_new) {
+  if (!W) return 0;
+  Carver c{nullptr, 0, true};
+  DecoderBufs d;
+  const int L = (P > 0 ? P - 1 : 0) + (max_new > 0 ? max_new : 1);
+  carve_decoder(c, d, W, B, B, T, L);
+  c.take<int32_t>((size_t)B * L);
+  c.take<int32_t>((size_t)B);
+  c.take<int32_t>(64 + 2 * (size_t)B);
+  return c.used + 256;
+}
+
+extern "C" int sbk_prompted_greedy_search_f32(const sbk_decoder_weights* W, const float* enc, const int32_t* enc_len,
+                                              const int32_t* prompt, int P, const float* logit_bias,
+                                              const float* first_bias, void* workspace, size_t workspace_bytes,
+                                              int32_t* out_tokens, float* out_scores, int probe_pos, int probe_token,
+                                              float* out_probe, int32_t* host_flag, int32_t* steps_run, int B, int T,
+                                              int max_new, int eos, int check_every, sbk_stream_t stream) {
+  SBK_TRY(check_weights(W));
+  if (steps_run) *steps_run = 0;
+  if (B == 0 || max_new <= 0) return 0;  // empty batch / nothing to sample: nothing to launch
+  SBK_REQUIRE(enc && enc_len && prompt && workspace && out_tokens && out_scores && W->seq_w && W->seq_b,
+              "prompted_greedy_search: null");
+  SBK_REQUIRE(P >= 1, "prompted_greedy_search: the prompt holds at least the first decoder input token");
+  const int L = P - 1 + max_new;
+  SBK_REQUIRE(L <= W->max_len, "prompted_greedy_search: prompt + new tokens (%d) exceed the positional table (%d)", L,
+              W->max_len);
+  SBK_REQUIRE(!out_probe || (probe_pos >= 0 && probe_pos < P && probe_token >= 0 && probe_token < W->vocab),
+              "prompted_greedy_search: probe position / token out of range");
+  SBK_REQUIRE(workspace_bytes >= sbk_prompted_greedy_search_workspace_bytes(W, B, T, P, max_new),
+              "prompted_greedy_search: workspace too small");
+  hipStream_t st = sbk::as_stream(stream);
+  Carver c{static_cast<char*>(workspace), 0, false};
+  DecoderBufs d;
+  carve_decoder(c, d, W, B, B, T, L);
+  int32_t* kv_slot = c.take<int32_t>((size_t)B * L);
+  int32_t* col = c.take<int32_t>((size_t)B);
+  int32_t* misc = c.take<int32_t>(64 + 2 * (size_t)B);
+  int32_t *n_ended = misc, *tok = misc + 64, *ended = misc + 64 + B;
+  SBK_TRY(project_memory(W, d, enc, B, T, st));
+  SBK_LAUNCH(greedy_init_kernel, dim3(sbk::cdiv(B, 256)), dim3(256), 0, st, tok, ended, n_ended, kv_slot, B, L, 0);
+  SBK_TRY(sbk::launch_status("greedy_init"));
+  SBK_HIP(hipMemsetAsync(out_tokens, 0, (size_t)B * max_new * sizeof(int32_t), st));
+  SBK_HIP(hipMemsetAsync(out_scores, 0, (size_t)B * max_new * sizeof(float), st));
+  for (int p = 0; p + 1 < P; ++p) {  // the prompt but its last token: K/V only (logits where the probe sits)
+    const bool probe = out_probe && p == probe_pos;
+    SBK_LAUNCH(gather_col_kernel, dim3(sbk::cdiv(B, 256)), dim3(256), 0, st, prompt, col, B, P, p);
+    SBK_TRY(decoder_step(W, d, col, kv_slot, enc_len, p, B, B, T, 1, L, probe, st));
+    if (probe) SBK_LAUNCH(softmax_prob_kernel, dim3(B), dim3(256), 0, st, (const float*)d.logits, out_probe, W->vocab, probe_token);
+  }
+  SBK_LAUNCH(gather_col_kernel, dim3(sbk::cdiv(B, 256)), dim3(256), 0, st, prompt, tok, B, P, P - 1);
+  SBK_TRY(sbk::launch_status("prompt"));
+  int k = 0;
+  for (; k < max_new; ++k) {
+    SBK_TRY(decoder_step(W, d, tok, kv_slot, enc_len, P - 1 + k, B, B, T, 1, L, true, st));
+    if (k == 0 && out_probe && probe_pos == P - 1)
+      SBK_LAUNCH(softmax_prob_kernel, dim3(B), dim3(256), 0, st, (const float*)d.logits, out_probe, W->vocab, probe_token);
+    SBK_LAUNCH(greedy_pick_kernel, dim3(B), dim3(256), 0, st, (const float*)d.logits, tok, ended, out_tokens, out_scores,
+               n_ended, W->vocab, k, max_new, eos, logit_bias, k == 0 ? first_bias : (const float*)nullptr);
+    SBK_TRY(sbk::launch_status("greedy_pick"));
+    if (host_flag && check_every > 0 && ((k + 1) % check_every == 0)) {
+      SBK_HIP(hipMemcpyAsync(host_flag, n_ended, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SBK_HIP(hipStreamSynchronize(st));
+      if (*host_flag >= B) {
+        ++k;
+        break;
+      }
+    }
+  }
+  if (steps_run) *steps_run = k < max_new ? k : max_new;
   return 0;
 }

@@ -69,6 +69,127 @@ class S2STransformerGreedySearcher(S2SBaseSearcher):
         return hyps, torch.tensor(rel).unsqueeze(1), sc.unsqueeze(1), None
 
 
+class S2SWhisperGreedySearcher(S2SBaseSearcher):
+    """seq2seq.py:421-636 (on S2SGreedySearcher.forward, :176-327): greedy decoding of a
+    ``speechbrain_amd.integrations.huggingface.whisper.Whisper`` -- initial tokens (prefix / prompt / task /
+    language) prime the device-side KV cache, then arg-max steps with the blank / non-speech / special-token masks,
+    all inside one C-ABI call (sbk_prompted_greedy_search_f32).
+
+    forward(enc_states, wav_len) -> (hyps, top_lengths [B,1], top_scores [B,1,L], None); ``no_speech_probs`` is set as
+    in the reference.  The fourth output of the reference, the full [B,1,L,V] log-probability tensor, is not
+    materialised on the device path."""
+
+    def __init__(self, model, temperature=0.0, use_kv_cache=True, suppress_blank=True, suppress_tokens="-1",
+                 sample_len=None, prefix=None, prompt=None, **kwargs):
+        kwargs.setdefault("min_decode_ratio", 0.0)
+        kwargs.setdefault("max_decode_ratio", 1.0)
+        super().__init__(bos_index=model.bos, eos_index=model.eos, **kwargs)
+        if temperature != 0.0:
+            raise NotImplementedError("sampling (temperature > 0) is not on the ASR inference path")
+        self.model, self.temperature, self.use_kv_cache = model, temperature, use_kv_cache
+        self.suppress_blank, self.suppress_tokens = suppress_blank, suppress_tokens
+        self.prefix, self.prompt = prefix, prompt
+        cfg = model.model.config
+        self.max_attn_tokens = cfg.get("max_length", cfg.get("max_target_positions", 448))
+        self.sample_len = sample_len or self.max_attn_tokens // 2
+        self.no_speech_probs, self.lang_tokens = None, None
+        self.check_every = 8
+        self._refresh()
+
+    def _refresh(self):
+        self.initial_tokens = self._get_initial_tokens()
+        self.sample_begin = len(self.initial_tokens)
+        self.eos_index, self.bos_index = self.model.eos, self.initial_tokens[-1]
+
+    def set_lang_tokens(self, lang_tokens):
+        self.lang_tokens = lang_tokens
+
+    def set_task(self, task):
+        self.model.set_task(task)
+        self._refresh()
+
+    def set_prompt(self, prompt):
+        self.prompt = prompt
+        self._refresh()
+
+    @property
+    def get_tokens_to_suppress(self):
+        """:512-540: the configured list ("-1" = the model's non-speech symbols) plus the task / start tokens."""
+        sup = self.suppress_tokens
+        if isinstance(sup, str):
+            sup = [int(t) for t in sup.split(",")]
+        if sup is None or len(sup) == 0:
+            sup = []
+        elif -1 in sup:
+            sup = [t for t in sup if t >= 0] + list(self.model.non_speech_tokens)
+        sup = list(sup) + [self.model.transcribe, self.model.translate, self.model.bos, self.model.bos_prev, self.model.bos_lm]
+        return tuple(sorted(set(sup)))
+
+    def _get_initial_tokens(self):
+        """:542-573."""
+        tok = self.model.tokenizer
+        tokens = list(tok.prefix_tokens)
+        if self.prefix:
+            pre = tok.encode(" " + self.prefix.strip(), add_special_tokens=False) if isinstance(self.prefix, str) else list(self.prefix)
+            if self.sample_len is not None:
+                pre = pre[-(self.max_attn_tokens // 2 - self.sample_len):]
+            tokens = tokens + pre
+        if self.prompt:
+            pro = tok.encode(" " + self.prompt.strip(), add_special_tokens=False) if isinstance(self.prompt, str) else list(self.prompt)
+            tokens = [self.model.bos_prev] + pro[-(self.max_attn_tokens // 2 - 1):] + tokens
+        return tuple(tokens)
+
+    def _masks(self, V, device):
+        key = (self.get_tokens_to_suppress if self.suppress_tokens else (), self.suppress_blank, self.eos_index, V, str(device))
+        if getattr(self, "_mask_key", None) != key:
+            always = torch.zeros(V)
+            if self.suppress_tokens:
+                always[list(self.get_tokens_to_suppress)] = -float("inf")
+            first = None
+            if self.suppress_blank:  # :619-625: no blank and no EOS as the very first sampled token
+                first = torch.zeros(V)
+                first[list(self.model.tokenizer.encode(" ", add_special_tokens=False)) + [self.eos_index]] = -float("inf")
+                first = first.to(device)
+            self._mask_key, self._mask = key, (always.to(device) if self.suppress_tokens else None, first)
+        return self._mask
+
+    @torch.no_grad()
+    def forward(self, enc_states, wav_len=None, attention_mask=None):
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is an LLM decoder feature")
+        enc = enc_states.float().contiguous()
+        B, T, _ = enc.shape
+        dev = enc.device
+        P = self.sample_begin
+        prompt = torch.tensor([list(self.initial_tokens)] * B, dtype=torch.int32)
+        if self.lang_tokens is not None:  # :586-591: per-utterance language token right after <|startoftranscript|>
+            prompt[:, self.initial_tokens.index(self.model.bos) + 1] = torch.as_tensor(self.lang_tokens).to(torch.int32).cpu()
+        mn, mx = self._steps(T)
+        # the loop of the reference (:230-279) runs steps mn..mx-1 and stops once the token memory holds
+        # max_attn_tokens - sample_begin entries (:633-635); the memory starts with sample_begin - 1 of them
+        max_new = max(0, min(mx - mn, self.max_attn_tokens - 2 * P + 1))
+        if max_new == 0:
+            raise ValueError("the initial tokens leave no room to decode (max_attn_tokens too small)")
+        handle = self.model.decoder_handle()
+        always, first = self._masks(handle.W.vocab, dev)
+        full = torch.full((B,), T, dtype=torch.int32, device=dev)
+        tok, sc, steps, probe = native.prompted_greedy_search(
+            handle, enc, full, prompt.to(dev), max_new, self.eos_index, always, first,
+            probe=(self.initial_tokens.index(self.model.bos), self.model.no_speech), check_every=self.check_every)
+        self.no_speech_probs = probe.cpu().tolist()
+        tok, sc = tok[:, :steps].cpu(), sc[:, :steps].cpu()
+        is_eos = tok == self.eos_index
+        first_eos = torch.where(is_eos.any(1), is_eos.float().argmax(1), torch.full((B,), steps))
+        L = steps if (first_eos == steps).any() else int(first_eos.max()) + 1  # stops once every utterance has ended
+        tok, sc = tok[:, :L], sc[:, :L]
+        hyps, rel = [], []
+        for b in range(B):
+            n = min(int(first_eos[b]), L)
+            rel.append(n / L if L else 0.0)
+            hyps.append(tok[b, :n].tolist())
+        return hyps, torch.tensor(rel).unsqueeze(1), sc.unsqueeze(1), None
+
+
 class S2STransformerBeamSearcher(S2SBaseSearcher):
     """seq2seq.py:1853-1934 + S2SBeamSearcher (:711-1749).
 

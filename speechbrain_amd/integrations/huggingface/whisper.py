@@ -368,3 +368,117 @@ class Whisper(WhisperLogMel):
             if self.output_all_hiddens:
                 return torch.stack(self.model.encoder(mel.float().contiguous(), output_hidden_states=True)[1])
             return self.model.encoder(mel.float().contiguous())
+
+    # ---- decoder -------------------------------------------------------------------------------------------------
+    def decoder_handle(self):
+        """The decoder's weights as the C ABI's sbk_decoder_weights (rebuilt when a parameter changes): q/k/v stacked
+        as one in_proj per attention (k without bias), learned positions as the position table, token embedding
+        unscaled (or * sqrt(d) with ``scale_embedding``) and tied to the output projection."""
+        dec = self.model.decoder
+        if dec is None:
+            raise RuntimeError("this Whisper was built with encoder_only=True")
+        key = tuple((p.data_ptr(), p._version) for p in dec.parameters())
+        h = getattr(self, "_dec_handle", None)
+        if h is None or h.key != key:
+            layers = []
+            for L in dec.layers:
+                layers.append(dict(
+                    ln1=(L.self_attn_layer_norm.weight, L.self_attn_layer_norm.bias), sa_in=L.self_attn.stacked(False),
+                    sa_out=(L.self_attn.out_proj.weight, L.self_attn.out_proj.bias),
+                    ln2=(L.encoder_attn_layer_norm.weight, L.encoder_attn_layer_norm.bias),
+                    ca_in=L.encoder_attn.stacked(False), ca_out=(L.encoder_attn.out_proj.weight, L.encoder_attn.out_proj.bias),
+                    ln3=(L.final_layer_norm.weight, L.final_layer_norm.bias), ff1=(L.fc1.weight, L.fc1.bias),
+                    ff2=(L.fc2.weight, L.fc2.bias)))
+            emb = dec.embed_tokens.weight
+            cfg = self.model.config
+            h = native.DecoderHandle.from_tensors(
+                layers, emb=emb, pe=dec.embed_positions.weight, final_ln=(dec.layer_norm.weight, dec.layer_norm.bias),
+                seq=(emb, torch.zeros(emb.shape[0], device=emb.device)), nhead=cfg["decoder_attention_heads"],
+                ffn_act=native.ACT_GELU, ln_eps=dec.layer_norm.eps,
+                emb_scale=math.sqrt(cfg["d_model"]) if cfg.get("scale_embedding") else 1.0, key=key)
+            self._dec_handle = h
+        return h
+
+    def forward_decoder(self, encoder_states, decoder_input_ids, use_cache=True, past_key_values=None):
+        """whisper.py:380-439: logits [B,L,V] of the decoder for the token prefix (KV-cached inside the call).
+        Returns (logits, None, None): attention maps and the HuggingFace cache object are not produced -- stepwise
+        decoding is what the Whisper searchers do on the device."""
+        if past_key_values is not None:
+            raise NotImplementedError("incremental decoding with a HuggingFace cache object: use the Whisper searchers "
+                                      "(speechbrain_amd.decoders.seq2seq), which keep the KV cache on the device")
+        with torch.no_grad():
+            enc = encoder_states.float().contiguous()
+            B, T, _ = enc.shape
+            ids = decoder_input_ids.to(device=enc.device, dtype=torch.int32).contiguous()
+            full = torch.full((B,), T, dtype=torch.int32, device=enc.device)  # every encoder frame is attended to
+            hidden = native.decoder_prefix(self.decoder_handle(), ids, enc, full)
+            logits = native.gemm_nt(hidden, self.model.decoder.embed_tokens.weight)
+        return logits, None, None
+
+    # ---- token ids (whisper.py:441-616; all read from the tokenizer) ------------------------------------------------
+    def _id(self, token):
+        if self.tokenizer is None:
+            raise RuntimeError("no tokenizer: the model directory holds no tokenizer files (or encoder_only=True)")
+        return self.tokenizer.convert_tokens_to_ids(token)
+
+    @property
+    def transcribe(self):
+        return self._id("<|transcribe|>")
+
+    @property
+    def translate(self):
+        return self._id("<|translate|>")
+
+    @property
+    def bos(self):
+        return self._id("<|startoftranscript|>")
+
+    @property
+    def eos(self):
+        return self._id("<|endoftext|>")
+
+    @property
+    def bos_lm(self):
+        return self._id("<|startoflm|>")
+
+    @property
+    def bos_prev(self):
+        return self._id("<|startofprev|>")
+
+    @property
+    def no_timestamps(self):
+        return self._id("<|notimestamps|>")
+
+    @property
+    def timestamp_begin(self):
+        return self._id("<|0.00|>")
+
+    @property
+    def no_speech(self):
+        return self.no_timestamps - 1
+
+    @property
+    def non_speech_tokens(self):
+        """Token ids of symbols that annotate rather than transcribe (brackets, quotes, note signs, ...): what
+        ``suppress_tokens="-1"`` expands to (whisper.py:463-500, after openai/whisper's tokenizer)."""
+        have = getattr(self, "_non_speech", None)
+        if have is None:
+            enc = lambda s: self.tokenizer.encode(s, add_special_tokens=False)  # noqa: E731
+            single = list('"#()*+/:;<=>@[\\]^_`{|}~「」『』')
+            multi = "<< >> <<< >>> -- --- -( -[ (' (\" (( )) ((( ))) [[ ]] {{ }} ♪♪ ♪♪♪".split()
+            notes = set("♩♪♫♬♭♮♯")  # U+2640..U+267F: their first byte-level token is safe to suppress
+            ids = {enc(" -")[0], enc(" '")[0]}  # a hyphen / apostrophe may join words but not start one
+            for sym in single + multi + sorted(notes):
+                for toks in (enc(sym), enc(" " + sym)):
+                    if len(toks) == 1 or sym in notes:
+                        ids.add(toks[0])
+            have = self._non_speech = tuple(sorted(ids))
+        return have
+
+    def set_language_token(self, language):
+        self.language = language
+        self.tokenizer.set_prefix_tokens(language=language)
+
+    def set_task(self, task):
+        self.task = task
+        self.tokenizer.set_prefix_tokens(task=task)

@@ -40,7 +40,7 @@ class DecoderWeights(ctypes.Structure):  # sbk_decoder_weights
                 ("final_ln_b", c_void_p), ("seq_w", c_void_p), ("seq_b", c_void_p), ("seq_wf", c_void_p),
                 ("seq_bf", c_void_p), ("d_model", c_int32),
                 ("nhead", c_int32), ("d_ffn", c_int32), ("n_layers", c_int32), ("vocab", c_int32),
-                ("max_len", c_int32), ("ffn_act", c_int32), ("ln_eps", c_float)]
+                ("max_len", c_int32), ("ffn_act", c_int32), ("ln_eps", c_float), ("emb_scale", c_float)]
 
 
 class LMLayer(ctypes.Structure):  # sbk_lm_layer
@@ -101,6 +101,9 @@ def _declare(lib):
         "sbk_greedy_search_workspace_bytes": ([POINTER(DecoderWeights), i, i, i], ctypes.c_size_t),
         "sbk_greedy_search_f32": ([POINTER(DecoderWeights), p, p, p, ctypes.c_size_t, p, p, p, POINTER(c_int32), i, i,
                                    i, i, i, i, i, p], c_int),
+        "sbk_prompted_greedy_search_workspace_bytes": ([POINTER(DecoderWeights), i, i, i, i], ctypes.c_size_t),
+        "sbk_prompted_greedy_search_f32": ([POINTER(DecoderWeights), p, p, p, i, p, p, p, ctypes.c_size_t, p, p, i, i, p, p,
+                                            POINTER(c_int32), i, i, i, i, i, p], c_int),
         "sbk_decoder_prefix_workspace_bytes": ([POINTER(DecoderWeights), i, i, i], ctypes.c_size_t),
         "sbk_decoder_prefix_f32": ([POINTER(DecoderWeights), p, p, p, p, ctypes.c_size_t, p, i, i, i, p], c_int),
         "sbk_lm_prefix_workspace_bytes": ([POINTER(LMWeights), i, i], ctypes.c_size_t),
@@ -129,7 +132,7 @@ def load(path: Optional[str] = None):
         )
     lib = ctypes.CDLL(path)
     EXPORTS = tuple(_declare(lib).keys())
-    if lib.sbk_abi_version() != 2:
+    if lib.sbk_abi_version() != 3:
         raise SbkError(f"ABI version mismatch: {lib.sbk_abi_version()}")
     _lib = lib
     return lib
@@ -502,9 +505,39 @@ class DecoderHandle:
 
     def __init__(self, model, seq_lin=None, fold=True):
         dec = model.decoder
+        layers = []
+        for L in dec.layers:
+            if not L.normalize_before:
+                raise NotImplementedError("post-norm decoder layers are not on the Conformer ASR path")
+            layers.append(dict(
+                ln1=(L.norm1.norm.weight, L.norm1.norm.bias), sa_in=(L.self_attn.att.in_proj_weight, L.self_attn.att.in_proj_bias),
+                sa_out=(L.self_attn.att.out_proj.weight, L.self_attn.att.out_proj.bias),
+                ln2=(L.norm2.norm.weight, L.norm2.norm.bias),
+                ca_in=(L.multihead_attn.att.in_proj_weight, L.multihead_attn.att.in_proj_bias),
+                ca_out=(L.multihead_attn.att.out_proj.weight, L.multihead_attn.att.out_proj.bias),
+                ln3=(L.norm3.norm.weight, L.norm3.norm.bias), ff1=(L.pos_ffn.ffn[0].weight, L.pos_ffn.ffn[0].bias),
+                ff2=(L.pos_ffn.ffn[3].weight, L.pos_ffn.ffn[3].bias)))
+        pe = model.positional_encoding_decoder.pe
+        self._build(layers, emb=model.custom_tgt_module.layers[0].emb.Embedding.weight,
+                    pe=pe.reshape(pe.shape[-2], pe.shape[-1]), final_ln=(dec.norm.norm.weight, dec.norm.norm.bias),
+                    seq=(seq_lin.w.weight, seq_lin.w.bias) if seq_lin is not None else None, nhead=dec.layers[0].nhead,
+                    ffn_act=dec.layers[-1].pos_ffn.act_code, ln_eps=dec.norm.eps, emb_scale=0.0, fold=fold)
+        self.key = self.source_key(model, seq_lin)
+
+    @classmethod
+    def from_tensors(cls, layers, emb, pe, final_ln, seq, nhead, ffn_act, ln_eps, emb_scale, fold=True, key=None):
+        """A pre-norm Transformer decoder given as plain tensors: ``layers`` = dicts with ln1 / sa_in / sa_out / ln2 /
+        ca_in / ca_out / ln3 / ff1 / ff2 -> (weight, bias) (in_proj stacked [3d,d] as torch.nn.MultiheadAttention);
+        ``emb_scale`` multiplies the token embedding (0 = sqrt(d_model)); ``seq`` = output projection (weight, bias)."""
+        self = cls.__new__(cls)
+        self._build(layers, emb, pe, final_ln, seq, nhead, ffn_act, ln_eps, emb_scale, fold)
+        self.key = key
+        return self
+
+    def _build(self, layer_specs, emb, pe, final_ln, seq, nhead, ffn_act, ln_eps, emb_scale, fold):
         self.keep = []
-        fold = fold and dec.norm.norm.weight.shape[0] in (128, 256, 512)  # shapes the fused kernel takes
-        layers = (DecoderLayer * len(dec.layers))()
+        fold = fold and final_ln[0].shape[0] in (128, 256, 512)  # shapes the fused kernel takes
+        layers = (DecoderLayer * len(layer_specs))()
 
         def ptr(t):
             t = t.detach()
@@ -515,49 +548,37 @@ class DecoderHandle:
             self.keep.append(t)
             return t.data_ptr()
 
-        act = None
-        for l, L in enumerate(dec.layers):
+        dm = emb.shape[1]
+        for l, S in enumerate(layer_specs):
             o = layers[l]
-            o.ln1_g, o.ln1_b = ptr(L.norm1.norm.weight), ptr(L.norm1.norm.bias)
-            o.sa_in_w, o.sa_in_b = ptr(L.self_attn.att.in_proj_weight), ptr(L.self_attn.att.in_proj_bias)
-            o.sa_out_w, o.sa_out_b = ptr(L.self_attn.att.out_proj.weight), ptr(L.self_attn.att.out_proj.bias)
-            o.ln2_g, o.ln2_b = ptr(L.norm2.norm.weight), ptr(L.norm2.norm.bias)
-            o.ca_in_w, o.ca_in_b = ptr(L.multihead_attn.att.in_proj_weight), ptr(L.multihead_attn.att.in_proj_bias)
-            o.ca_out_w, o.ca_out_b = ptr(L.multihead_attn.att.out_proj.weight), ptr(L.multihead_attn.att.out_proj.bias)
-            o.ln3_g, o.ln3_b = ptr(L.norm3.norm.weight), ptr(L.norm3.norm.bias)
-            o.ff1_w, o.ff1_b = ptr(L.pos_ffn.ffn[0].weight), ptr(L.pos_ffn.ffn[0].bias)
-            o.ff2_w, o.ff2_b = ptr(L.pos_ffn.ffn[3].weight), ptr(L.pos_ffn.ffn[3].bias)
+            o.ln1_g, o.ln1_b = map(ptr, S["ln1"])
+            o.sa_in_w, o.sa_in_b = map(ptr, S["sa_in"])
+            o.sa_out_w, o.sa_out_b = map(ptr, S["sa_out"])
+            o.ln2_g, o.ln2_b = map(ptr, S["ln2"])
+            o.ca_in_w, o.ca_in_b = map(ptr, S["ca_in"])
+            o.ca_out_w, o.ca_out_b = map(ptr, S["ca_out"])
+            o.ln3_g, o.ln3_b = map(ptr, S["ln3"])
+            o.ff1_w, o.ff1_b = map(ptr, S["ff1"])
+            o.ff2_w, o.ff2_b = map(ptr, S["ff2"])
             if fold:  # LayerNorm folded into the projection it feeds (fused kernel, csrc/gemm.hip)
-                dm = L.norm1.norm.weight.shape[0]
-                o.sa_in_wf, o.sa_in_bf = map(ptr, _fold_ln(L.self_attn.att.in_proj_weight, L.self_attn.att.in_proj_bias,
-                                                            L.norm1.norm.weight, L.norm1.norm.bias))
-                o.ca_q_wf, o.ca_q_bf = map(ptr, _fold_ln(L.multihead_attn.att.in_proj_weight[:dm],
-                                                          L.multihead_attn.att.in_proj_bias[:dm], L.norm2.norm.weight,
-                                                          L.norm2.norm.bias))
-                o.ff1_wf, o.ff1_bf = map(ptr, _fold_ln(L.pos_ffn.ffn[0].weight, L.pos_ffn.ffn[0].bias,
-                                                        L.norm3.norm.weight, L.norm3.norm.bias))
-            act = L.pos_ffn.act_code
-            if not L.normalize_before:
-                raise NotImplementedError("post-norm decoder layers are not on the Conformer ASR path")
+                o.sa_in_wf, o.sa_in_bf = map(ptr, _fold_ln(*S["sa_in"], *S["ln1"]))
+                o.ca_q_wf, o.ca_q_bf = map(ptr, _fold_ln(S["ca_in"][0][:dm], S["ca_in"][1][:dm], *S["ln2"]))
+                o.ff1_wf, o.ff1_bf = map(ptr, _fold_ln(*S["ff1"], *S["ln3"]))
         self.layers = layers
         W = DecoderWeights()
         W.layers = ctypes.cast(layers, POINTER(DecoderLayer))
-        emb = model.custom_tgt_module.layers[0].emb.Embedding.weight
-        pe = model.positional_encoding_decoder.pe
-        W.emb, W.pe = ptr(emb), ptr(pe.reshape(pe.shape[-2], pe.shape[-1]))
-        W.final_ln_g, W.final_ln_b = ptr(dec.norm.norm.weight), ptr(dec.norm.norm.bias)
-        if seq_lin is not None:
-            W.seq_w, W.seq_b = ptr(seq_lin.w.weight), ptr(seq_lin.w.bias)
+        W.emb, W.pe = ptr(emb), ptr(pe)
+        W.final_ln_g, W.final_ln_b = map(ptr, final_ln)
+        if seq is not None:
+            W.seq_w, W.seq_b = map(ptr, seq)
             if fold:
-                W.seq_wf, W.seq_bf = map(ptr, _fold_ln(seq_lin.w.weight, seq_lin.w.bias, dec.norm.norm.weight,
-                                                        dec.norm.norm.bias))
-        W.d_model, W.nhead = emb.shape[1], dec.layers[0].nhead
-        W.d_ffn, W.n_layers = dec.layers[0].pos_ffn.ffn[0].weight.shape[0], len(dec.layers)
-        W.vocab = seq_lin.w.weight.shape[0] if seq_lin is not None else emb.shape[0]
-        W.max_len, W.ffn_act, W.ln_eps = pe.shape[-2], act, dec.norm.eps
+                W.seq_wf, W.seq_bf = map(ptr, _fold_ln(seq[0], seq[1], *final_ln))
+        W.d_model, W.nhead = dm, nhead
+        W.d_ffn, W.n_layers = layer_specs[0]["ff1"][0].shape[0], len(layer_specs)
+        W.vocab = seq[0].shape[0] if seq is not None else emb.shape[0]
+        W.max_len, W.ffn_act, W.ln_eps, W.emb_scale = pe.shape[-2], ffn_act, ln_eps, float(emb_scale)
         self.W = W
         self.device = emb.device
-        self.key = self.source_key(model, seq_lin)
 
     @staticmethod
     def source_key(model, seq_lin=None):
@@ -709,6 +730,33 @@ def greedy_search(handle: DecoderHandle, enc, enc_len, min_steps, max_steps, bos
                                    int(min_steps), int(max_steps), int(bos), int(eos), int(check_every), _stream(enc)),
          "sbk_greedy_search_f32")
     return out_tok, out_sc, steps.value
+
+
+def prompted_greedy_search(handle: DecoderHandle, enc, enc_len, prompt, max_new, eos, logit_bias=None, first_bias=None,
+                           probe=None, check_every=8):
+    """S2SWhisperGreedySearcher on the device: prompt [B,P] int32 primes the KV cache, then arg-max decoding with the
+    additive [V] masks.  Returns (tokens [B,max_new] (EOS-latched), scores [B,max_new], steps_run, probe [B] | None);
+    ``probe`` = (prompt position, token): softmax probability of the token at that position."""
+    lib = load()
+    _dev_ok(enc, enc_len, prompt, logit_bias, first_bias)
+    B, T, _ = enc.shape
+    P = prompt.shape[1]
+    dev = enc.device
+    L = max(int(max_new), 1)
+    nbytes = lib.sbk_prompted_greedy_search_workspace_bytes(ctypes.byref(handle.W), B, T, P, int(max_new))
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    out_tok = torch.zeros(B, L, dtype=torch.int32, device=dev)
+    out_sc = torch.zeros(B, L, dtype=torch.float32, device=dev)
+    out_probe = torch.zeros(B, dtype=torch.float32, device=dev) if probe is not None else None
+    flag = _host_flag(dev)
+    steps = c_int32(0)
+    _chk(lib.sbk_prompted_greedy_search_f32(
+        ctypes.byref(handle.W), _p(enc), _p(enc_len), _p(prompt), P, _p(logit_bias), _p(first_bias),
+        c_void_p(ws.data_ptr() + off), nbytes, _p(out_tok), _p(out_sc), int(probe[0]) if probe else 0,
+        int(probe[1]) if probe else 0, _p(out_probe), c_void_p(flag.data_ptr()), ctypes.byref(steps), B, T, int(max_new),
+        int(eos), int(check_every), _stream(enc)), "sbk_prompted_greedy_search_f32")
+    return out_tok, out_sc, steps.value, out_probe
 
 
 def decoder_prefix(handle: DecoderHandle, tokens, enc, enc_len):

@@ -96,3 +96,72 @@ def test_whisper_encoder_matches_reference_golden(backend):
     assert float((enc2.cpu() - torch.from_numpy(g["enc"])).abs().max()) <= 1e-3
     with pytest.raises(ValueError):  # _get_mel pads to 30 s like the reference: 3000 frames do not fit this model
         w(wav)
+
+
+class _StubTokenizer:
+    """The handful of tokenizer calls the Whisper wrapper / searcher make, over the tiny model's 100-token vocabulary
+    (the same ids the golden was generated with: oracle/make_golden.py WHISPER_IDS)."""
+
+    IDS = {"<|endoftext|>": 2, "<|startoftranscript|>": 3, "<|en|>": 4, "<|fr|>": 5, "<|transcribe|>": 10,
+           "<|translate|>": 11, "<|startoflm|>": 12, "<|startofprev|>": 13, "<|nospeech|>": 14, "<|notimestamps|>": 15}
+    prefix_tokens = [3, 4, 10, 15]
+
+    def convert_tokens_to_ids(self, token):
+        return self.IDS[token]
+
+    def encode(self, text, add_special_tokens=False):
+        return {" ": [16]}[text]
+
+
+def _full_whisper(dev):
+    from speechbrain_amd.integrations.huggingface.whisper import Whisper
+
+    w = Whisper(MODEL_DIR).to(dev).eval()
+    assert w.tokenizer is None  # the fixture directory holds no tokenizer files
+    w.tokenizer = _StubTokenizer()
+    w._non_speech = (20, 21, 22, 40)
+    return w
+
+
+def test_whisper_decoder_logits_match_reference_golden(backend):
+    """forward_decoder (teacher-forced prefix through the KV-cached decoder step: learned positions, unscaled tied
+    embedding, k_proj without bias, GELU) against the reference wrapper's logits.  Tolerance 1e-4 on logits up to 2.7."""
+    nat, dev = backend
+    g = np.load(MODEL_GOLD)
+    w = _full_whisper(dev)
+    enc = torch.from_numpy(g["enc"]).to(dev)
+    logits, attn, cache = w.forward_decoder(enc, torch.from_numpy(g["tokens"]).to(dev))
+    assert attn is None and cache is None
+    assert logits.shape == g["logits"].shape
+    assert float((logits.cpu() - torch.from_numpy(g["logits"])).abs().max()) <= 1e-4
+    # forward(): mel -> encoder -> decoder in one call, on a 30-second model this is the reference's entry point;
+    # here it must refuse the 3000-frame mel just like the encoder does
+    with pytest.raises(ValueError):
+        w(torch.from_numpy(g["wav"]).to(dev), torch.from_numpy(g["tokens"]).to(dev))
+
+
+def test_whisper_greedy_searcher_matches_reference_golden(backend):
+    """S2SWhisperGreedySearcher: initial tokens with a per-utterance language token, suppress lists ("-1" + specials,
+    blank and EOS at the first sampled step), EOS latch, stop once every utterance has ended, no_speech_probs --
+    token ids equal the reference's (its own top-1 / top-2 margin is >= 0.1), per-step log-probs within 2e-4."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import S2SWhisperGreedySearcher
+
+    g = np.load(MODEL_GOLD)
+    w = _full_whisper(dev)
+    s = S2SWhisperGreedySearcher(model=w, min_decode_ratio=0.0, max_decode_ratio=1.0)
+    assert list(s.initial_tokens) == g["initial_tokens"].tolist()
+    assert list(s.get_tokens_to_suppress) == g["suppress"].tolist()
+    s.set_lang_tokens(torch.tensor([4, 5, 6]))
+    enc = torch.from_numpy(g["enc"]).to(dev)
+    hyps, lens, scores, _ = s(enc, torch.ones(3))
+    ref_h = [[int(t) for t in row if t >= 0] for row in g["greedy_hyps"]]
+    assert hyps == ref_h
+    assert torch.allclose(lens.reshape(-1), torch.from_numpy(g["greedy_lens"]).reshape(-1).float(), atol=1e-6)
+    assert scores.shape == g["greedy_scores"].shape
+    assert float((scores - torch.from_numpy(g["greedy_scores"])).abs().max()) <= 2e-4
+    assert np.abs(np.array(s.no_speech_probs) - g["greedy_no_speech"]).max() <= 1e-5
+    # without masks the first sampled token may be anything: the masks are what keeps blank / EOS / specials out
+    free = S2SWhisperGreedySearcher(model=w, suppress_blank=False, suppress_tokens=[])
+    h2, _, sc2, _ = free(enc, torch.ones(3))
+    assert sc2.shape[2] >= 1 and all(len(h) <= sc2.shape[2] for h in h2)
