@@ -174,6 +174,37 @@ def self_launch(n):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def whisper_encoder_leg(dev, B=8, reps=3):
+    """log-mel + Whisper encoder (large-v3 shape: 128 mels, 32 layers, d 1280, 20 heads, ffn 5120) on B x 30 s of audio;
+    fp32 and the opt-in bf16 GEMM operands."""
+    from speechbrain_amd import native
+    from speechbrain_amd.integrations.huggingface.whisper import Whisper
+
+    cfg = dict(num_mel_bins=128, d_model=1280, encoder_layers=32, encoder_attention_heads=20, encoder_ffn_dim=5120,
+               max_source_positions=1500, decoder_layers=0, decoder_attention_heads=20, decoder_ffn_dim=5120,
+               vocab_size=51866, max_target_positions=448)
+    w = Whisper.from_config(cfg, encoder_only=True).to(dev).eval()
+    wav = 0.1 * torch.randn(B, 480000, generator=torch.Generator().manual_seed(3))
+    wav = wav.to(dev)
+    res = {"workload": f"log-mel + Whisper large-v3 encoder forward, {B} x 30 s, random weights, one stream"}
+    flops = B * 32 * (1500 * 2.0 * (4 * 1280 * 1280 + 2 * 1280 * 5120) + 4.0 * 1500 * 1500 * 1280) \
+        + B * 2.0 * (3000 * 1280 * 384 + 1500 * 1280 * 3840)
+    for prec in ("fp32", "bf16"):
+        with native.precision_scope(prec):
+            w.forward_encoder(w._get_mel(wav))
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                w.forward_encoder(w._get_mel(wav))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / reps
+        res[prec] = {"ms_per_batch": round(1000.0 * dt, 2), "audio_sec_per_s": round(B * 30.0 / dt, 1),
+                     "tflops": round(flops / dt / 1e12, 1)}
+    del w
+    torch.cuda.empty_cache()
+    return res
+
+
 def roofline_entry(name, v, total_ms):
     avg_ms = v["ms"] / max(v["count"], 1)
     if name.startswith(MFMA_KERNELS):
@@ -404,6 +435,14 @@ def main():
         out["p50_latency_ms"] = min(by_mode.values())
         out["p50_latency_ms_by_mode"] = by_mode
         out["config"]["latency_case"] = "B=1, 10 s utterance, 40 decode steps"
+
+    # ---- BASELINE.json configs[4] (stretch): Whisper large-v3 shaped encoder, random weights, 30-second chunks
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            out["config5_whisper_encoder"] = whisper_encoder_leg(dev)
+        except Exception as e:  # a secondary measurement must not take the headline down
+            out["config5_whisper_encoder"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        note("whisper encoder leg done")
 
     # ---- rooflines: HIP events around every launch, rank 0's batches repeated on one stream
     if rank == 0 and not args.no_roofline:

@@ -67,6 +67,42 @@ class EncoderDecoderASR(Pretrained):
         return self.transcribe_batch(wavs, wav_lens)
 
 
+class WhisperASR(Pretrained):
+    """inference/ASR.py:431-945, the batch entry points: ``mods.whisper`` (integrations.huggingface.whisper.Whisper)
+    and ``mods.decoder`` (a Whisper searcher, e.g. S2SWhisperGreedySearcher).  ``encode_batch`` = log-mel (padded or
+    trimmed to the 30-second chunk) -> Whisper encoder; ``transcribe_batch`` adds the search and the tokenizer's
+    decoding.  File streaming (ffmpeg-backed ``torchaudio.io.StreamReader``) and language identification are not
+    part of this package."""
+
+    HPARAMS_NEEDED = ["language", "sample_rate"]
+    MODULES_NEEDED = ["whisper", "decoder"]
+    TASKS = ["transcribe", "translate", "lang_id"]
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.tokenizer = self.hparams.whisper.tokenizer
+
+    def encode_batch(self, wavs, wav_lens):
+        wavs = wavs.to(device=self.device, dtype=torch.float32)
+        return self.mods.whisper.forward_encoder(self.mods.whisper._get_mel(wavs))
+
+    @torch.no_grad()
+    def transcribe_batch(self, wavs, wav_lens):
+        wav_lens = wav_lens.float().to(self.device)
+        predicted_tokens, _, _, _ = self.mods.decoder(self.encode_batch(wavs, wav_lens), wav_lens)
+        predicted_words = [self.tokenizer.decode(t, skip_special_tokens=True).strip() for t in predicted_tokens]
+        if getattr(self.hparams, "normalized_transcripts", False):
+            predicted_words = [self.tokenizer.normalize(text).split(" ") for text in predicted_words]
+        return predicted_words, predicted_tokens
+
+    def forward(self, wavs, wav_lens):
+        return self.transcribe_batch(wavs, wav_lens)
+
+    def transcribe_file(self, path, *args, **kwargs):
+        raise NotImplementedError("WhisperASR.transcribe_file streams 30-second segments through torchaudio.io; use "
+                                  "transcribe_batch on loaded audio")
+
+
 # ---------------------------------------------------------------------------------------------- streaming
 from dataclasses import dataclass  # noqa: E402
 from itertools import chain  # noqa: E402

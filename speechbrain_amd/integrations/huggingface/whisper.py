@@ -330,6 +330,20 @@ class Whisper(WhisperLogMel):
         for p in self.model.parameters():  # inference path: parameters are constants
             p.requires_grad_(False)
 
+    @classmethod
+    def from_config(cls, cfg, encoder_only=True, seed=0):
+        """A randomly initialised model of the given HuggingFace config dict (benchmarks: no checkpoint on disk)."""
+        self = cls.__new__(cls)
+        WhisperLogMel.__init__(self, n_mels=cfg["num_mel_bins"])
+        self.sampling_rate, self.encoder_only, self.freeze, self.freeze_encoder = SAMPLE_RATE, encoder_only, True, False
+        self.output_attentions, self.output_all_hiddens, self.language, self.task = False, False, None, "transcribe"
+        torch.manual_seed(seed)
+        self.model = WhisperModel(cfg, encoder_only=encoder_only)
+        self.tokenizer = None
+        for p in self.model.parameters():
+            p.requires_grad_(False)
+        return self
+
     def load_tokenizer(self, source, **kwargs):
         """The HuggingFace tokenizer of the model directory (host-side text processing, as in the reference,
         huggingface.py:420-430); a directory without tokenizer files leaves ``tokenizer`` None."""
