@@ -17,8 +17,7 @@ utterances are then run again as 128-utterance batches (sized for 288 GB of HBM)
 `value_batch128`.  Per rank the batches run through ConcurrentTranscriber: --streams worker threads (encoder on a
 normal-, search on a high-priority HIP stream), each encoding --group batches one after the other and decoding them
 in ONE grouped search (every batch keeps its own padding and step limits; the decoder step sees all their rows);
-the Conformer encoder likewise runs once over the rows of the group's batches (row-wise launches shared, attention and
-depthwise convolution per batch).
+with --group-encoder the Conformer encoder likewise runs once over the rows of the group's batches (measured: no gain).
 
 The timed region is the real sharded path (speechbrain_amd.inference.sharded.ShardedTranscriber): rank 0 holds the
 whole job as padded int16 batches in pinned host memory (planning -- duration sort, bucketing, longest-processing-
@@ -242,8 +241,11 @@ def main():
                     help="encoder attention (RelPosMHAXL = BASELINE.json's config; RoPEMHA = the in-tree recipe)")
     ap.add_argument("--lm", action="store_true",
                     help="add the recipe's TransformerLM scorer (12 x 768, weight 0.6, T=1.15): test_search at beam 10")
-    ap.add_argument("--no-group-encoder", action="store_true",
-                    help="encode the batches of a group one by one instead of in one encoder pass over all their rows (A/B)")
+    ap.add_argument("--group-encoder", action="store_true",
+                    help="one encoder pass over the rows of all the batches of a group instead of one per batch (A/B)")
+    ap.add_argument("--graph-mode", type=int, default=0, choices=[0, 1, 2],
+                    help="searches of the timed run: 1 = decoding steps replayed from a captured hipGraph, 2 = device-side "
+                         "step counter with plain launches (A/B; 0 = plain launches)")
     ap.add_argument("--no-search-priority", action="store_true",
                     help="run each worker's search on its normal-priority stream (A/B of the stream priorities)")
     ap.add_argument("--knob", action="append", default=[], metavar="KEY=VALUE",
@@ -321,7 +323,9 @@ def main():
     def timed_run(max_batch, streams, group):
         """Warm-up + the timed scatter -> transcribe -> gather of the whole job at one batch size."""
         workers = ConcurrentTranscriber(asr, streams=streams, prioritise_search=not args.no_search_priority, group=group)
-        workers.group_encoder = not args.no_group_encoder
+        workers.group_encoder = args.group_encoder
+        for srch in workers.searchers:
+            srch.graph_mode = args.graph_mode
         st = ShardedTranscriber(transcribe_one, dev, max_utts=max_batch, concurrent=workers, prepare=fixed_decode_length)
         # W untimed steps through the same path (communicators, allocator pools); the longest utterances first, and
         # every worker stream sizes its allocations on the longest batch
@@ -451,7 +455,7 @@ def main():
         native.prof_enable(True)
         # the same batches, grouped as in the timed region, on ONE worker stream (every launch between two events)
         one = ConcurrentTranscriber(asr, streams=1, prioritise_search=False, group=auto(args.max_batch)[1])
-        one.group_encoder = not args.no_group_encoder
+        one.group_encoder = args.group_encoder
         one.transcribe_batches([(t[1], t[2]) for t in local_batches], prepare=fixed_decode_length)
         one.pool.shutdown(wait=True)
         rep_audio = sum(seconds[i] for t in local_batches for i in t[0])

