@@ -303,6 +303,10 @@ typedef struct {
                          consecutive steps are captured once into a hipGraph and replayed (single-stream
                          latency; ignored with overlap_ctc, profiling or T > 900); 2: device-side counter
                          with plain launches (what 1 falls back to) */
+  int32_t ctc_candidates; /* 0: CTC is a FULL scorer (every token scored, blank column blocked: scorer.py:1280-1285);
+                             k > 0: CTC is a PARTIAL scorer (ScorerBuilder(partial_scorers=[ctc]), :1287-1300): only the
+                             k = int(beam * scorer_beam_scale) best tokens of each hypothesis -- ranked after the eos
+                             rules and the full scorers -- and <eos> get a CTC score, the rest get minus_inf */
 } sbk_search_config;
 
 /* S2STransformerBeamSearcher.forward (seq2seq.py:1632-1723, :1853-1934) with an optional full

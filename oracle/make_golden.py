@@ -201,6 +201,20 @@ def golden_model(tag, d_model, nhead, d_ffn, n_enc, n_dec, vocab, B, n_frames, b
             check("topk log_probs", k_lps, o_lps, 1e-4)
             out["topk_hyps"], out["topk_lens"] = k_hyps.numpy(), k_lens.numpy()
             out["topk_scores"], out["topk_lps"] = k_scores.numpy(), k_lps.numpy()
+        if tag == "tiny_ctc":  # CTC as a PARTIAL scorer (scorer.py:1287-1300): only int(beam * scale) candidates scored
+            for scale in (1.5, 2):
+                pscorer = ScorerBuilder(partial_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)],
+                                        weights={"ctc": ctc_w}, scorer_beam_scale=scale)
+                bsp = S2STransformerBeamSearcher(
+                    modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=min_ratio,
+                    max_decode_ratio=max_ratio, beam_size=beam, using_eos_threshold=eos_thr, length_normalization=True,
+                    scorer=pscorer)
+                p_hyps, p_lens, p_scores, _ = bsp(enc_ref.clone(), wav_lens)
+                key = str(scale).replace(".", "p")
+                out[f"partial{key}_hyps"] = np.array([h + [-1] * (64 - len(h)) for h in p_hyps], dtype=np.int64)
+                out[f"partial{key}_scores"], out[f"partial{key}_lens"] = p_scores.numpy(), p_lens.numpy()
+                print(f"  partial CTC scorer, scale {scale}: lens", [len(h) for h in p_hyps],
+                      "same as full:", p_hyps == hyps_r)
         # beam = 1 through the beam searcher (north-star "greedy beam=1")
         bs1 = S2STransformerBeamSearcher(
             modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=min_ratio,

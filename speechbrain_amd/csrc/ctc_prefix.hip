@@ -573,6 +573,54 @@ __global__ void __launch_bounds__(256) am_only_kernel(const float* __restrict__ 
   comb[(size_t)n * V + c] = v;
 }
 
+// ---- CTC as a PARTIAL scorer (scorer.py:1280-1300, ctc.py:168-262 with `candidates`) -----------------------------------
+// The reference scores only the top `k` tokens of each hypothesis (after the attention log-probs, the eos rules and
+// the full scorers) and gives every other token minus_inf; <eos> always gets its score, blank never does.  Here the
+// dense psi of the full scorer is computed anyway (it is one matrix product), so the partial scorer is a mask:
+// thr[n] = k-th largest entry of row n, found by bisection over the order-preserving integer image of the floats.
+__device__ __forceinline__ unsigned order_key(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void __launch_bounds__(256) row_kth_largest_kernel(const float* __restrict__ x, float* __restrict__ thr, int V,
+                                                              int k) {
+  __shared__ int cnt[4];
+  __shared__ unsigned prefix_s;
+  const float* xr = x + (size_t)blockIdx.x * V;
+  unsigned prefix = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned t = prefix | (1u << bit);
+    int c = 0;
+    for (int i = threadIdx.x; i < V; i += 256) c += order_key(xr[i]) >= t ? 1 : 0;
+    c = (int)sbk::wave_sum((float)c);  // counts <= V < 2^24: exact in fp32
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) prefix_s = ((cnt[0] + cnt[1]) + (cnt[2] + cnt[3])) >= k ? t : prefix;
+    __syncthreads();
+    prefix = prefix_s;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {  // back from the key to the float
+    const unsigned u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+    thr[blockIdx.x] = __uint_as_float(u);
+  }
+}
+
+// comb (= the attention log-probs after the eos rules and the full scorers) += w * (masked psi - psi_prev)
+__global__ void __launch_bounds__(256) ctc_partial_combine_kernel(float* __restrict__ comb, const float* __restrict__ thr,
+                                                                  const float* __restrict__ psi,
+                                                                  const float* __restrict__ psi_prev, int V, int blank,
+                                                                  int eos, float weight, float minus_inf) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= V) return;
+  const float base = comb[(size_t)n * V + c];
+  float p = (base >= thr[n] || c == eos) ? psi[(size_t)n * V + c] : minus_inf;
+  if (c == blank && eos != blank) p = minus_inf;
+  comb[(size_t)n * V + c] = base + (p - psi_prev[n]) * weight;
+}
+
 __global__ void __launch_bounds__(256) row_max_kernel(const float* __restrict__ x, float* __restrict__ out, int V) {
   __shared__ float red[4];
   const float* xr = x + (size_t)blockIdx.x * V;
@@ -706,6 +754,15 @@ int am_only(const float* am, float* comb, int n_bh, int V, int eos, int eos_floo
   SBK_LAUNCH(am_only_kernel, dim3(cdiv(V, 256), n_bh), dim3(256), 0, st, am, comb, V, eos, eos_floor, use_thr, thr,
              minus_inf, am_max, extra, sp, min_steps, utt_min, beam > 0 ? beam : 1, step);
   return launch_status("am_only");
+}
+
+int ctc_partial_combine(float* comb, float* thr, const float* psi, const float* psi_prev, int n_bh, int V, int k, int blank,
+                        int eos, float weight, float minus_inf, hipStream_t st) {
+  const int kk = k < 1 ? 1 : (k > V ? V : k);  // scorer.py:1290-1291
+  SBK_LAUNCH(row_kth_largest_kernel, dim3(n_bh), dim3(256), 0, st, (const float*)comb, thr, V, kk);
+  SBK_LAUNCH(ctc_partial_combine_kernel, dim3(cdiv(V, 256), n_bh), dim3(256), 0, st, comb, (const float*)thr, psi, psi_prev,
+             V, blank, eos, weight, minus_inf);
+  return launch_status("ctc_partial_combine");
 }
 
 int row_max(const float* x, float* out, int rows, int V, hipStream_t st) {

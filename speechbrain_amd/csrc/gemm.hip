@@ -304,7 +304,7 @@ struct PanelStage {
 };
 
 template <int BM, int BN, int BK, int WM, int WN, bool VEC>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g) {
   constexpr int WAVES_N = BN / WN;
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -394,6 +394,32 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(Gem
       }
     }
   }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool VEC>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(GemmArgs g) {
+  gemm_nt_tile<BM, BN, BK, WM, WN, VEC>(g);
+}
+
+// The same tile over one K slice per blockIdx.z: raw partial products to ws[z][M][N] (splitk_reduce_kernel applies the
+// epilogue).  For few-row, long-K shapes (the decoder's second feed-forward projection at ~1 K rows): 64x64 LDS tiles
+// move half the operand bytes of the 32x32 register-operand tiles through L2, and the K split puts 2-3 workgroups on
+// every CU so that their MFMA and load phases overlap.
+template <int BM, int BN, int BK, int WM, int WN, bool VEC>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_splitk_kernel(GemmArgs g, float* __restrict__ ws,
+                                                                                     int kper) {
+  const int z = blockIdx.z;
+  g.A += (size_t)z * kper;
+  g.W += (size_t)z * kper;
+  g.K = (g.K - z * kper) < kper ? (g.K - z * kper) : kper;
+  g.C = ws + (size_t)z * g.M * g.N;
+  g.ldc = g.N;
+  g.bias = nullptr;
+  g.R = nullptr;
+  g.act = SBK_ACT_NONE;
+  g.alpha = 1.0f;
+  g.seq_len = nullptr;
+  gemm_nt_tile<BM, BN, BK, WM, WN, VEC>(g);
 }
 
 // Same tiling with 16-byte LDS traffic.  The two k-slices of v_mfma_f32_32x32x2 need not be neighbours in
@@ -875,6 +901,11 @@ int g_skinny_off = 0;  // tuning knob: 1 = route few-row GEMMs to the LDS-tiled 
 int g_skinny_looped = 0;  // tuning knob (key 10): 1 = always the looped skinny kernel (the round-1 schedule)
 int g_flat64_min_rows = 1 << 30;  // tuning knob (key 11): from this many rows on the register-operand path uses 64x64 tiles
                                   // (off by default: measured slower in situ, 29 vs 23 us at M = 1280)
+int g_tiled_splitk = 256;  // tuning knob (key 14): from this many rows on, K >= 2048 shapes take 64x64 LDS tiles with a
+                           // 4-way K split instead of the register-operand path (0 = off).  Measured (tools/microbench.py
+                           // --ffn2, N = 512, K = 2048): 160 rows 17.9 -> 21.6 us, 320: 24.2 -> 20.1, 1280: 53.0 -> 37.8,
+                           // 2560: 94.4 -> 57.9; N = 768, K = 3072 at 1280 rows: 115.7 -> 63.5
+int g_tiled_splitk_short = 0;  // tuning knob (key 15): K split of the same kernel for 512 <= K < 2048 (0 = not used)
 int g_skinny_reach = 0;   // tuning knob (key 12): 1 = the register-operand path also takes the mid-M shapes that go to
                           // the LDS-tiled kernels by default (M*N >= 1.9 M with K <= 1024)
 int g_gemm_tile = 0;   // tuning knob (key 6) for the large-M path: 0 = 128x128, 1 = 256x128 (8 waves of 64x64),
@@ -894,6 +925,21 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   const bool skinny_ok = !big_short && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < (g_skinny_reach ? 2048 : 256)) && M <= (g_skinny_reach ? 8192 : 4096) && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
   if (!skinny_ok || g_skinny_off) return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
   GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
+  // (K = 768, the TransformerLM scorer's projections: 2-way split, 34.4 -> 24.6 us at 1280 rows; K = 512: no gain)
+  const int short_sk = K < 2048 && (long)M * N < 1900000 ? (g_tiled_splitk_short ? (K >= 512 ? g_tiled_splitk_short : 0) : (K >= 768 && M >= 1024 ? 2 : 0)) : 0;
+  if (g_tiled_splitk && ws && M >= g_tiled_splitk && (K >= 2048 || short_sk) && K % 128 == 0) {  // long K at ~1 K rows: 64x64 LDS tiles, K split 4-way
+    const int SK = short_sk ? short_sk : 4, kper = K / SK;
+    if ((size_t)SK * M * N <= ws_floats) {
+      ProfScope prof("gemm_skinny", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
+      dim3 grid(cdiv(N, 64), cdiv(M, 64), SK), block(256);
+      SBK_LAUNCH((gemm_nt_splitk_kernel<64, 64, 32, 32, 32, true>), grid, block, 0, st, g, ws, kper);
+      int rc = launch_status("gemm_splitk_tiled");
+      if (rc) return rc;
+      const size_t total = (size_t)M * N;
+      SBK_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, g, (const float*)ws, SK);
+      return launch_status("splitk_reduce");
+    }
+  }
   const int tiles_m = cdiv(M, 32), tiles_n = cdiv(N, 32);
   // a second, global K split when the tile grid alone leaves SIMDs idle (needs `ws` for the partial tiles)
   int SKg = 1;
@@ -1059,6 +1105,8 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 10) sbk::g_skinny_looped = value;
   if (key == 11) sbk::g_flat64_min_rows = value;
   if (key == 12) sbk::g_skinny_reach = value;
+  if (key == 14) sbk::g_tiled_splitk = value;
+  if (key == 15) sbk::g_tiled_splitk_short = value;
   if (key == 13) sbk::g_self_group_off = value;
 }
 

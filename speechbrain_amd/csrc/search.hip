@@ -42,6 +42,8 @@ int am_only(const float* am, float* comb, int n_bh, int V, int eos, int eos_floo
             float minus_inf, const float* am_max, const float* extra, hipStream_t st, const int32_t* utt_min = nullptr,
             int beam = 1, int step = 0);
 int row_max(const float* x, float* out, int rows, int V, hipStream_t st);
+int ctc_partial_combine(float* comb, float* thr, const float* psi, const float* psi_prev, int n_bh, int V, int k, int blank,
+                        int eos, float weight, float minus_inf, hipStream_t st);
 }  // namespace sbk
 
 namespace {
@@ -1008,9 +1010,16 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
       if (!psi_aside)
         SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[cur], bb.s.tokens[cur], enc_len, bb.psi, B, T, V, beam, step,
                                   cfg->blank, cfg->eos, st));
-      SBK_TRY(sbk::ctc_combine(bb.am, bb.am_max, bb.psi, bb.psi_prev[cur], bb.comb, n, V, cfg->blank, cfg->eos,
-                               cfg->ctc_weight, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
-                               cfg->minus_inf, extra, st, cfg->utt_min_steps, beam, step));
+      if (cfg->ctc_candidates > 0) {  // CTC as a partial scorer: only the top candidates of every hypothesis are scored
+        SBK_TRY(sbk::am_only(bb.am, bb.comb, n, V, cfg->eos, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
+                             cfg->minus_inf, bb.am_max, extra, st, cfg->utt_min_steps, beam, step));
+        SBK_TRY(sbk::ctc_partial_combine(bb.comb, bb.topk_val, bb.psi, bb.psi_prev[cur], n, V, cfg->ctc_candidates,
+                                         cfg->blank, cfg->eos, cfg->ctc_weight, cfg->minus_inf, st));
+      } else {
+        SBK_TRY(sbk::ctc_combine(bb.am, bb.am_max, bb.psi, bb.psi_prev[cur], bb.comb, n, V, cfg->blank, cfg->eos,
+                                 cfg->ctc_weight, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
+                                 cfg->minus_inf, extra, st, cfg->utt_min_steps, beam, step));
+      }
     } else {
       SBK_TRY(sbk::am_only(bb.am, bb.comb, n, V, cfg->eos, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
                            cfg->minus_inf, bb.am_max, extra, st, cfg->utt_min_steps, beam, step));

@@ -38,7 +38,9 @@ _KNOWN = ("ctc", "rnnlm", "transformerlm", "kenlm", "coverage", "length", "huggi
 class ScorerBuilder:
     """scorer.py:1075-1315.  Supported compositions: full_scorers drawn from {CTCScorer,
     TransformerLMScorer} -- the recipe's ``valid_search`` ([ctc]) and ``test_search``
-    ([transformerlm, ctc]) (conformer_large.yaml:215-239)."""
+    ([transformerlm, ctc]) (conformer_large.yaml:215-239) -- and CTCScorer as the one partial scorer
+    (``partial_scorers=[ctc]``: only the best int(beam_size * scorer_beam_scale) tokens of every hypothesis get a
+    CTC score, :1287-1300)."""
 
     def __init__(self, weights=dict(), full_scorers=list(), partial_scorers=list(), scorer_beam_scale=2):
         assert len(weights) == len(full_scorers) + len(partial_scorers), "Weights and scorers are not matched."
@@ -47,10 +49,11 @@ class ScorerBuilder:
         self.weights = {**dict.fromkeys(_KNOWN, 0.0), **weights}
         self.full_scorers = {name(s): s for s in full_scorers}
         self.partial_scorers = {name(s): s for s in partial_scorers}
-        unsupported = [k for k in list(self.full_scorers) + list(self.partial_scorers) if k not in ("ctc", "transformerlm")]
-        if unsupported or self.partial_scorers:
+        unsupported = [k for k in self.full_scorers if k not in ("ctc", "transformerlm")]
+        unsupported += [k for k in self.partial_scorers if k != "ctc"]
+        if unsupported or ("ctc" in self.full_scorers and "ctc" in self.partial_scorers):
             raise NotImplementedError(
-                f"scorers {unsupported or list(self.partial_scorers)}: the device search fuses the full CTC and "
-                "TransformerLM scorers; RNNLM / KenLM / coverage / length / partial scorers are not implemented")
+                f"scorers {unsupported}: the device search fuses the CTC scorer (full or partial) and the full "
+                "TransformerLM scorer; RNNLM / KenLM / coverage / length scorers are not implemented")
         if not 0.0 <= self.weights["ctc"] <= 1.0:
             raise ValueError("ctc_weight should not > 1.0 and < 0.0")

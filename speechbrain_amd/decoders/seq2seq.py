@@ -217,6 +217,7 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
         self.graph_mode = 0   # 1: replay two decoding steps from a captured hipGraph (needs overlap_ctc = 0)
         self.blank_index = 0
         self.ctc_fc = None
+        self.ctc_candidates = 0  # > 0: CTC is a partial scorer over that many candidates per hypothesis
         self.lm, self.lm_weight, self.lm_temperature = None, 0.0, 1.0
         if scorer is not None:
             if scorer.weights["transformerlm"] != 0.0 and "transformerlm" in scorer.full_scorers:
@@ -232,6 +233,8 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
                 self.ctc_weight = scorer.weights["ctc"]
                 self.attn_weight = 1.0 - self.ctc_weight
                 self.blank_index, self.ctc_fc = ctc.blank_index, ctc.ctc_fc
+                if "ctc" in scorer.partial_scorers:  # scorer.py:1287-1291
+                    self.ctc_candidates = max(1, int(beam_size * scorer.scorer_beam_scale))
         if self.attn_weight <= 0:
             raise NotImplementedError("pure-CTC beam search (ctc_weight = 1) is not implemented")
 
@@ -246,7 +249,7 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
                                    bos=self.bos_index, eos=self.eos_index, blank=self.blank_index, beam=self.beam_size,
                                    min_steps=mn, max_steps=mx, length_normalization=int(self.length_normalization),
                                    using_eos_threshold=int(self.using_eos_threshold), check_every=self.check_every,
-                                   overlap_ctc=int(self.overlap_ctc),
+                                   overlap_ctc=int(self.overlap_ctc), ctc_candidates=int(self.ctc_candidates),
                                    ctc_weight=self.ctc_weight, temperature=self.temperature,
                                    eos_threshold=self.eos_threshold, minus_inf=self.minus_inf)
 

@@ -61,7 +61,7 @@ class SearchConfig(ctypes.Structure):  # sbk_search_config
                 ("check_every", c_int32), ("overlap_ctc", c_int32), ("ctc_weight", c_float), ("temperature", c_float),
                 ("eos_threshold", c_float), ("minus_inf", c_float), ("lm_weight", c_float), ("lm_temperature", c_float),
                 ("lm", POINTER(LMWeights)), ("topk", c_int32), ("utt_min_steps", c_void_p),
-                ("utt_max_steps", c_void_p), ("graph_mode", c_int32)]
+                ("utt_max_steps", c_void_p), ("graph_mode", c_int32), ("ctc_candidates", c_int32)]
 
 
 def _declare(lib):

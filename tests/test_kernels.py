@@ -78,6 +78,27 @@ def test_gemm_skinny_splitk(backend, M, N, K):
     assert _md(out, a + (a.double() @ sq.double().t()).float()) <= 2e-6 * float((a.abs() @ sq.abs().t()).max()) + 1e-5
 
 
+def test_gemm_tiled_splitk_variant(backend):
+    """csrc/gemm.hip gemm_nt_splitk_kernel (tuning knob 14): few rows, long K through 64x64 LDS tiles with a 4-way K
+    split + the fixed-order reduce -- same epilogue (bias, GELU, alpha, residual in place), ragged M and N."""
+    nat, dev = backend
+    M, N, K = 100, 72, 2048
+    g = torch.Generator().manual_seed(14)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g)
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = r + 0.5 * F.gelu(a.double() @ w.double().t() + b).float()
+    scale = float((a.abs() @ w.abs().t()).max())
+    base = nat.gemm_nt_splitk(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_GELU, alpha=0.5, slices=4)
+    nat.load().sbk_prof_set_knob(14, 64)
+    try:
+        out = nat.gemm_nt_splitk(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_GELU, alpha=0.5, slices=4)
+    finally:
+        nat.load().sbk_prof_set_knob(14, 0)
+    assert _md(out, ref) <= 2e-6 * scale + 1e-5
+    assert _md(base, ref) <= 2e-6 * scale + 1e-5
+
+
 def test_gemm_row_mask(backend):
     nat, dev = backend
     a, w, r = torch.randn(14, 16), torch.randn(12, 16), torch.randn(14, 12)

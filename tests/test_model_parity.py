@@ -85,6 +85,32 @@ def test_golden_model(backend, tag):
         assert float((s1.cpu() - torch.from_numpy(g["beam1_scores"])).abs().max()) <= 1e-4
 
 
+@pytest.mark.parametrize("scale,key", [(1.5, "1p5"), (2, "2")])
+def test_golden_partial_ctc_scorer(backend, scale, key):
+    """ScorerBuilder(partial_scorers=[CTCScorer]) (scorer.py:1287-1300, ctc.py:168-262 with candidates): only the
+    int(beam * scorer_beam_scale) best tokens of every hypothesis and <eos> receive a CTC score.  The reference's
+    results (which differ from the full scorer's and between the two scales) must be reproduced exactly."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
+
+    g, mods = build("tiny_ctc", dev)
+    beam, eos_thr = int(g["cfg"][6]), bool(g["cfg"][7])
+    ctc_w, max_ratio, min_ratio = [float(v) for v in g["cfgf"]]
+    wl = torch.from_numpy(g["wav_lens"]).to(dev)
+    enc_ref = torch.from_numpy(g["enc_out"]).to(dev)
+    scorer = ScorerBuilder(partial_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)],
+                           weights={"ctc": ctc_w}, scorer_beam_scale=scale)
+    bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                    min_decode_ratio=min_ratio, max_decode_ratio=max_ratio, beam_size=beam,
+                                    using_eos_threshold=eos_thr, length_normalization=True, scorer=scorer)
+    assert bs.ctc_candidates == int(beam * scale)
+    hyps, lens, scores, _ = bs(enc_ref, wl)
+    assert hyps == hyps_of(g[f"partial{key}_hyps"])
+    assert hyps != hyps_of(g["beam_hyps"])  # (the full scorer decodes something else: the mask matters)
+    assert float((scores.cpu() - torch.from_numpy(g[f"partial{key}_scores"])).abs().max()) <= 1e-4
+    assert float((lens.cpu() - torch.from_numpy(g[f"partial{key}_lens"])).abs().max()) <= 1e-6
+
+
 def test_waveform_to_tokens_vs_oracle(backend):
     """EncoderDecoderASR.transcribe_batch on padded waveforms vs the oracle's whole path."""
     nat, dev = backend

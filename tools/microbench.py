@@ -128,6 +128,24 @@ if __name__ == "__main__":
         nat.load().sbk_prof_set_knob(11, 1 << 30)
         nat.load().sbk_prof_set_knob(12, 0)
         sys.exit(0)
+    if "--ffn2" in sys.argv:  # few rows, K = 2048: register-operand split-K (default) vs 64x64 LDS tiles with a 4-way K split
+        for knob in (0, 1):
+            nat.load().sbk_prof_set_knob(14, knob)
+            print("K = 2048 path:", "64x64 LDS tiles, 4-way K split" if knob else "register-operand tiles")
+            for M in (10, 40, 80, 160, 320, 640, 1280, 2560):
+                gemm_case(M, 512, 2048, 8)
+            gemm_case(1280, 768, 3072, 8)
+        nat.load().sbk_prof_set_knob(14, 0)
+        sys.exit(0)
+    if "--k512" in sys.argv:  # K = 512 decode shapes: register-operand flat schedule vs 64x64 LDS tiles with a 2- / 4-way K split
+        for sk in (0, 2, 4):
+            nat.load().sbk_prof_set_knob(15, sk)
+            print("K = 512 path:", f"64x64 LDS tiles, {sk}-way K split" if sk else "default")
+            for M in (320, 640, 1280, 2560):
+                gemm_case(M, 512, 512, 8)
+            gemm_case(1280, 768, 768, 8)
+        nat.load().sbk_prof_set_knob(15, 0)
+        sys.exit(0)
     if "--skinny" in sys.argv:  # decode-step GEMMs on the register-operand path: looped (round 1) vs flat schedule
         for looped in (1, 0):
             nat.load().sbk_prof_set_knob(10, looped)
