@@ -77,17 +77,18 @@ struct Cand {
 __device__ __forceinline__ bool better(float v, int i, float v2, int i2) { return v > v2 || (v == v2 && i < i2); }
 
 // Block-wide selection of the `k` best (value, index) pairs among the candidates a loader yields.
-// Every thread keeps a sorted top-16 list of its strided share (registers), the lists go to LDS and
-// k rounds of a block arg-max over the list heads emit the winners in descending order
+// Every thread keeps a sorted top-16 list of its strided share (registers); the lists go to LDS, every
+// wave picks the k best of its 64 lists with k shuffle-only arg-max rounds, and the first wave merges
+// the 4 * k wave winners the same way: one barrier in all, winners in descending order
 // (ties: lower index first).
 template <typename Load>
 __device__ __forceinline__ void block_topk(int total, int k, float* out_val, int32_t* out_idx, Load load) {
-  __shared__ float lv[256][kMaxBeam];
-  __shared__ int li[256][kMaxBeam];
-  __shared__ float wv[4];
-  __shared__ int wi[4];
-  __shared__ int win;
-  const int tid = threadIdx.x;
+  // per-thread sorted lists, transposed so that a wave's accesses to one list position are bank-conflict free
+  __shared__ float lv[kMaxBeam][256];
+  __shared__ int li[kMaxBeam][256];
+  __shared__ float wv[4][kMaxBeam];  // each wave's k best, in order
+  __shared__ int wi[4][kMaxBeam];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float vals[kMaxBeam];
   int ids[kMaxBeam];
 #pragma unroll
@@ -118,14 +119,16 @@ __device__ __forceinline__ void block_topk(int total, int k, float* out_val, int
   }
 #pragma unroll
   for (int s = 0; s < kMaxBeam; ++s) {
-    lv[tid][s] = vals[s];
-    li[tid][s] = ids[s];
+    lv[s][tid] = vals[s];
+    li[s][tid] = ids[s];
   }
-  __syncthreads();
+  // every wave selects the k best of its own 64 lists: k wave-wide arg-max rounds, no barrier (a lane reads only
+  // what it wrote); the top k of the workgroup are among the 4 * k wave winners
   int hp = 0;
   for (int r = 0; r < k; ++r) {
-    float v = hp < kMaxBeam ? lv[tid][hp] : -INFINITY;
-    int i = hp < kMaxBeam ? li[tid][hp] : INT_MAX;
+    float v = hp < kMaxBeam ? lv[hp][tid] : -INFINITY;
+    int i = hp < kMaxBeam ? li[hp][tid] : INT_MAX;
+    const int mine = i;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
       const float ov = sbk::shfl_xor(v, m);
@@ -135,26 +138,41 @@ __device__ __forceinline__ void block_topk(int total, int k, float* out_val, int
         i = oi;
       }
     }
-    if ((tid & 63) == 0) {
-      wv[tid >> 6] = v;
-      wi[tid >> 6] = i;
+    if (lane == 0) {
+      wv[wave][r] = v;
+      wi[wave][r] = i;
     }
-    __syncthreads();
-    if (tid == 0) {
-      float bv = wv[0];
-      int bi = wi[0];
-      for (int w = 1; w < 4; ++w)
-        if (better(wv[w], wi[w], bv, bi)) {
-          bv = wv[w];
-          bi = wi[w];
+    if (hp < kMaxBeam && mine == i && i != INT_MAX) ++hp;  // candidate ids are unique: exactly one lane advances
+  }
+  __syncthreads();
+  if (wave == 0) {  // merge the 4 * k <= 64 wave winners: one per lane, k arg-max rounds with removal
+    float v = -INFINITY;
+    int i = INT_MAX;
+    if (lane < 4 * k) {
+      v = wv[lane / k][lane % k];
+      i = wi[lane / k][lane % k];
+    }
+    for (int r = 0; r < k; ++r) {
+      float bv = v;
+      int bi = i;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = sbk::shfl_xor(bv, m);
+        const int oi = sbk::shfl_xor(bi, m);
+        if (better(ov, oi, bv, bi)) {
+          bv = ov;
+          bi = oi;
         }
-      win = bi;
-      out_val[r] = bv;
-      out_idx[r] = bi;
+      }
+      if (lane == 0) {
+        out_val[r] = bv;
+        out_idx[r] = bi;
+      }
+      if (i == bi && bi != INT_MAX) {  // the winner leaves the pool
+        v = -INFINITY;
+        i = INT_MAX;
+      }
     }
-    __syncthreads();
-    if (hp < kMaxBeam && li[tid][hp] == win && win != INT_MAX) ++hp;
-    __syncthreads();
   }
 }
 
