@@ -31,9 +31,10 @@ def _oracle_cfg(size):
     return fc, mc
 
 
-@pytest.mark.parametrize("size,B,sec", [("S", 4, 10.0), ("L", 2, 6.0)])
+@pytest.mark.parametrize("size,B,sec", [("S", 4, 10.0), ("S", 32, 10.0), ("L", 2, 6.0)])
 def test_encoder_vs_oracle(size, B, sec):
-    """configs[1]-shaped (Conformer-S, 10 s) and Conformer-L encoders: Fbank within 1e-3 dB,
+    """configs[1] (Conformer-S, 32 x 10 s -- BASELINE.json's exact shape -- and a 4-utterance cut of it) and
+    Conformer-L encoders: Fbank within 1e-3 dB,
     encoder output within 2e-4 absolute (fp32; oracle self-noise is 2e-6)."""
     from speechbrain_amd.inference.builders import flat_state_dict
 
