@@ -204,6 +204,14 @@ int sbk_rope_attention_f32(const float* qkv, const float* cosines, const float* 
                            float* out, float* attn, int B, int T, int H, int Dh, int table_rows, float scale,
                            int chunk_size, int left_chunks, sbk_stream_t stream);
 
+/* The same attention (no attention-weights output, head_dim 64) on the bf16 matrix cores, for the opt-in reduced-
+ * precision path (run_opts precision="bf16"; the Whisper encoder's MHA at d = 1280 / 20 heads is its main user): q, k,
+ * v and the probabilities are rounded to bf16 into v_mfma_f32_32x32x16_bf16, the scores, the softmax statistics and
+ * the context accumulate in fp32; inputs and output stay fp32 in HBM. */
+int sbk_rope_attention_bf16(const float* qkv, const float* cosines, const float* sines, const int32_t* key_len,
+                            float* out, int B, int T, int H, int Dh, int table_rows, float scale, int chunk_size,
+                            int left_chunks, sbk_stream_t stream);
+
 /* ---- a13: middle of ConvolutionModule (Conformer.py:315-330): GLU over channels of the
  * pointwise-conv output followed by the depthwise Conv1d (kernel ksize, zero padding
  * (ksize-1)/2, groups = d) + bias.   h [B,T,2d] -> y [B,T,d];  w [d,ksize]; bias [d].

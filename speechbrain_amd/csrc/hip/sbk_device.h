@@ -41,6 +41,15 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   return (unsigned short)(u >> 16);
 }
 
+// eight bf16 bit patterns -> one MFMA operand
+using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
+__device__ __forceinline__ bf16x8 pack_bf16x8(const unsigned short (&h)[8]) {
+  u16x8 u;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) u[e] = h[e];
+  return __builtin_bit_cast(bf16x8, u);
+}
+
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, kWave); }
 __device__ __forceinline__ int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, kWave); }
 __device__ __forceinline__ float shfl(float v, int lane) { return __shfl(v, lane, kWave); }

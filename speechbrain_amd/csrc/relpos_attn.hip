@@ -470,10 +470,274 @@ __global__ void __launch_bounds__(256, 2) relpos_flash_kernel(AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Attention without a position-score term (RoPEMHA; plain MHA = an identity rotation table), transposed scores.
+// The wave computes S^T = K Q^T instead of Q K^T: in the MFMA result layout a lane then holds ONE query (its column)
+// and 16 of the tile's 32 keys, so
+//   * the softmax statistics of a query are lane-local (16 registers + one shuffle with the other half-wave),
+//   * the probabilities are already the B operand of the second product O^T = V^T P^T: accumulator register r of
+//     half-wave h holds key (r&3) + 8(r>>2) + 4h, which is exactly the k-slice MFMA number r contracts when V^T is
+//     fed with the same key order -- P never leaves the registers,
+//   * the running rescale exp(m_old - m_new) is one scalar per lane.
+// No LDS, no wave barrier, no workgroup barrier: a wave is one 32-query tile walking the key tiles.
+template <int DH>
+__device__ __forceinline__ void rotate_run(float (&x)[DH / 2], const float* __restrict__ cs, const float* __restrict__ sn) {
+  float c[DH / 2], sg[DH / 2];
+  load_run<DH / 2>(c, cs);
+  load_run<DH / 2>(sg, sn);
+#pragma unroll
+  for (int s2 = 0; s2 < DH / 2; s2 += 2) {
+    const float x0 = x[s2], x1 = x[s2 + 1];
+    x[s2] = x0 * c[s2] + x1 * sg[s2];
+    x[s2 + 1] = x1 * c[s2 + 1] + x0 * sg[s2 + 1];
+  }
+}
+
+template <int DH>
+__global__ void __launch_bounds__(256, 2) rope_flash_t_kernel(AttnArgs a) {
+  constexpr int DH2 = DH / 2;
+  constexpr int NC = (DH + 31) / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & 31, half = lane >> 5;
+  const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+  const int T = a.T, d = a.H * DH;
+  if (i0 >= T) return;
+  const size_t row3 = (size_t)3 * d;
+  const float* qkv_b = a.qkv + (size_t)b * T * row3 + (size_t)h * 3 * DH;
+  const int qrow = min(i0 + jl, T - 1);  // this lane's query (B operand column / output row)
+
+  float qu[DH2];
+  load_run<DH2>(qu, qkv_b + (size_t)qrow * row3 + half * DH2);
+  rotate_run<DH>(qu, a.pos + (size_t)qrow * DH + half * DH2, a.bias_u + (size_t)qrow * DH + half * DH2);
+#pragma unroll
+  for (int s = 0; s < DH2; ++s) qu[s] *= a.scale;
+
+  int klen = T;
+  if (a.key_len) klen = min(max(a.key_len[b], 1), T);
+  const int nkt = (klen + 31) / 32;
+  int lo, hi;  // allowed keys of this lane's query
+  key_range(a, qrow, klen, lo, hi);
+  int kt_begin = 0, kt_end = nkt;
+  if (a.chunk > 0) {
+    kt_end = min(nkt, ((min(i0 + 31, T - 1) / a.chunk + 1) * a.chunk + 31) / 32);
+    if (a.left >= 0) kt_begin = max(0, (i0 / a.chunk - a.left) * a.chunk) / 32;
+  }
+  float m_run = -INFINITY, l_run = 0.0f;
+  f32x16 o[NC];
+#pragma unroll
+  for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[ct][r] = 0.0f;
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int j0 = kt * 32;
+    float kreg[DH2];
+    {
+      const int krow = min(j0 + jl, T - 1);
+      load_run<DH2>(kreg, qkv_b + (size_t)krow * row3 + DH + half * DH2);
+      rotate_run<DH>(kreg, a.pos + (size_t)krow * DH + half * DH2, a.bias_u + (size_t)krow * DH + half * DH2);
+    }
+    f32x16 acc;  // S^T: row = key (r&3) + 8(r>>2) + 4*half of the tile, column = query jl
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < DH2; ++s) acc = sbk::mfma_32x32x2(kreg[s], qu[s], acc);
+    // V^T operand of the second product, in the key order of the accumulator registers (requested before the softmax)
+    float vv[NC][16];
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+      const int col = ct * 32 + jl;
+      const float* vbase = qkv_b + 2 * DH + (col < DH ? col : 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = min(j0 + (r & 3) + 8 * (r >> 2) + 4 * half, T - 1);
+        vv[ct][r] = col < DH ? vbase[(size_t)t * row3] : 0.0f;
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (!(key >= lo && key < hi)) acc[r] = -INFINITY;
+      mx = fmaxf(mx, acc[r]);
+    }
+    mx = fmaxf(mx, sbk::shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = m_new == -INFINITY ? 1.0f : expf(m_run - m_new);
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[r] = acc[r] == -INFINITY ? 0.0f : expf(acc[r] - m_new);
+      sum += acc[r];
+    }
+    sum += sbk::shfl_xor(sum, 32);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct) o[ct] = sbk::mfma_32x32x2(vv[ct][r], acc[r], o[ct]);
+  }
+  // O^T: column = this lane's query, row = channel (r&3) + 8(r>>2) + 4*half + 32*ct
+  if (i0 + jl < T) {
+    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;  // no allowed key at all: zero context
+    float* orow = a.out + ((size_t)b * T + i0 + jl) * d + h * DH;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (c < DH) orow[c] = o[ct][r] * inv;
+      }
+  }
+}
+
+// The same walk with bf16 MFMA operands (v_mfma_f32_32x32x16_bf16: 8 k-values per lane and instruction) for the
+// opt-in reduced-precision path: q, k, v and the probabilities are rounded to bf16 on their way into the matrix
+// cores, scores / softmax statistics / context accumulate in fp32.  head_dim 64: four instructions per score tile and
+// four per context update instead of 32 + 32.
+__global__ void __launch_bounds__(256, 2) rope_flash_t_bf16_kernel(AttnArgs a) {
+  constexpr int DH = 64;
+  using sbk::bf16x8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & 31, half = lane >> 5;
+  const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+  const int T = a.T, d = a.H * DH;
+  if (i0 >= T) return;
+  const size_t row3 = (size_t)3 * d;
+  const float* qkv_b = a.qkv + (size_t)b * T * row3 + (size_t)h * 3 * DH;
+  const int qrow = min(i0 + jl, T - 1);
+
+  // operand chunk of MFMA step t: channels 16t + 8*half .. +7 of a row (rotation pairs stay inside a chunk)
+  auto load_chunks = [&](const float* row, int frame, float scale, bf16x8 (&dst)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c0 = 16 * t + 8 * half;
+      float x[8], cs[8], sn[8];
+      load_run<8>(x, row + c0);
+      load_run<8>(cs, a.pos + (size_t)frame * DH + c0);
+      load_run<8>(sn, a.bias_u + (size_t)frame * DH + c0);
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const float x0 = x[e], x1 = x[e + 1];
+        x[e] = (x0 * cs[e] + x1 * sn[e]) * scale;
+        x[e + 1] = (x1 * cs[e + 1] + x0 * sn[e + 1]) * scale;
+      }
+      unsigned short hb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) hb[e] = sbk::f32_to_bf16(x[e]);
+      dst[t] = sbk::pack_bf16x8(hb);
+    }
+  };
+  bf16x8 qb[4];
+  load_chunks(qkv_b + (size_t)qrow * row3, qrow, a.scale, qb);
+
+  int klen = T;
+  if (a.key_len) klen = min(max(a.key_len[b], 1), T);
+  const int nkt = (klen + 31) / 32;
+  int lo, hi;
+  key_range(a, qrow, klen, lo, hi);
+  int kt_begin = 0, kt_end = nkt;
+  if (a.chunk > 0) {
+    kt_end = min(nkt, ((min(i0 + 31, T - 1) / a.chunk + 1) * a.chunk + 31) / 32);
+    if (a.left >= 0) kt_begin = max(0, (i0 / a.chunk - a.left) * a.chunk) / 32;
+  }
+  float m_run = -INFINITY, l_run = 0.0f;
+  f32x16 o[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[ct][r] = 0.0f;
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int j0 = kt * 32;
+    bf16x8 kb[4];
+    {
+      const int krow = min(j0 + jl, T - 1);
+      load_chunks(qkv_b + (size_t)krow * row3 + DH, krow, 1.0f, kb);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = sbk::mfma_32x32x16_bf16(kb[t], qb[t], acc);
+    // V^T operands: step s contracts the 8 keys the accumulator registers 8s .. 8s+7 of this half-wave belong to
+    bf16x8 vb[2][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float* vbase = qkv_b + 2 * DH + ct * 32 + jl;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        unsigned short hb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = 8 * s + e;
+          const int t = min(j0 + (r & 3) + 8 * (r >> 2) + 4 * half, T - 1);
+          hb[e] = sbk::f32_to_bf16(vbase[(size_t)t * row3]);
+        }
+        vb[ct][s] = sbk::pack_bf16x8(hb);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (!(key >= lo && key < hi)) acc[r] = -INFINITY;
+      mx = fmaxf(mx, acc[r]);
+    }
+    mx = fmaxf(mx, sbk::shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = m_new == -INFINITY ? 1.0f : expf(m_run - m_new);
+    float sum = 0.0f;
+    bf16x8 pb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      unsigned short hb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int r = 8 * s + e;
+        const float pr = acc[r] == -INFINITY ? 0.0f : expf(acc[r] - m_new);
+        sum += pr;
+        hb[e] = sbk::f32_to_bf16(pr);
+      }
+      pb[s] = sbk::pack_bf16x8(hb);
+    }
+    sum += sbk::shfl_xor(sum, 32);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) o[ct] = sbk::mfma_32x32x16_bf16(vb[ct][s], pb[s], o[ct]);
+  }
+  if (i0 + jl < T) {
+    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+    float* orow = a.out + ((size_t)b * T + i0 + jl) * d + h * DH;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) orow[ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = o[ct][r] * inv;
+  }
+}
+
 template <int DH, bool ROPE>
 int launch_flash(const AttnArgs& a, hipStream_t st) {
   sbk::ProfScope prof(ROPE ? "rope_attention" : "relpos_attention", (ROPE ? 4.0 : 6.0) * a.B * a.H * (double)a.T * a.T * DH,
                       4.0 * a.B * a.T * (4.0 * a.H * DH) + 4.0 * (2.0 * a.T - 1) * a.H * DH, st);
+  if constexpr (ROPE) {
+    if (!sbk::g_rope_flash_lds) {  // default: transposed scores, no LDS (knob 16 = 1 keeps the LDS-tile kernel for A/B)
+      SBK_LAUNCH((rope_flash_t_kernel<DH>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+      return sbk::launch_status("sbk_rope_attention_f32");
+    }
+  }
   SBK_LAUNCH((relpos_flash_kernel<DH, ROPE>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   return sbk::launch_status(ROPE ? "sbk_rope_attention_f32" : "sbk_relpos_attention_f32");
 }
@@ -514,6 +778,7 @@ int launch_attn_pf(const AttnArgs& a, hipStream_t st) {
 }  // namespace
 
 namespace sbk {
+int g_rope_flash_lds = 0;  // tuning knob (key 16): 1 = RoPE / plain attention through the LDS-tile flash kernel (round-2 first half)
 int g_attn_prefetch = 0;  // tuning knob (sbk_prof_set_knob key 3): phase 1 prefetches the next key tile's operands
 
 int relpos_attention(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
@@ -561,6 +826,23 @@ extern "C" int sbk_rope_attention_f32(const float* qkv, const float* cosines, co
   SBK_REQUIRE(chunk_size >= 0, "rope_attention: negative chunk size");
   return sbk::rope_attention(qkv, cosines, sines, key_len, out, attn, B, T, H, Dh, scale, sbk::as_stream(stream),
                              chunk_size, left_chunks);
+}
+
+extern "C" int sbk_rope_attention_bf16(const float* qkv, const float* cosines, const float* sines,
+                                       const int32_t* key_len, float* out, int B, int T, int H, int Dh, int table_rows,
+                                       float scale, int chunk_size, int left_chunks, sbk_stream_t stream) {
+  if (B == 0 || T == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
+  SBK_REQUIRE(qkv && cosines && sines && out, "rope_attention_bf16: null operand");
+  SBK_REQUIRE(B >= 0 && T >= 0 && H > 0 && Dh == 64, "rope_attention_bf16: head_dim 64 only (got %d)", Dh);
+  SBK_REQUIRE(table_rows >= T, "rope_attention_bf16: the sinusoid tables hold %d rows, T = %d", table_rows, T);
+  SBK_REQUIRE(sbk::aligned16(qkv) && sbk::aligned16(cosines) && sbk::aligned16(sines),
+              "rope_attention_bf16: operands must be 16-byte aligned");
+  SBK_REQUIRE(chunk_size >= 0, "rope_attention_bf16: negative chunk size");
+  hipStream_t st = sbk::as_stream(stream);
+  AttnArgs a{qkv, cosines, sines, nullptr, key_len, out, nullptr, B, T, H, 0, scale, chunk_size, left_chunks};
+  sbk::ProfScope prof("rope_attention_bf16", 4.0 * B * H * (double)T * T * Dh, 4.0 * B * T * (4.0 * H * Dh), st);
+  SBK_LAUNCH(rope_flash_t_bf16_kernel, dim3((T + 127) / 128, H, B), dim3(256), 0, st, a);
+  return sbk::launch_status("sbk_rope_attention_bf16");
 }
 
 extern "C" int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,

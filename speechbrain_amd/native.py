@@ -92,6 +92,7 @@ def _declare(lib):
         "sbk_conv_block_f32": ([p, p, p, p, p, p, i, i, i, i, i, f, f, p], c_int),
         "sbk_relpos_attention_f32": ([p, p, p, p, p, p, p, i, i, i, i, f, i, i, p], c_int),
         "sbk_rope_attention_f32": ([p, p, p, p, p, p, i, i, i, i, i, f, i, i, p], c_int),
+        "sbk_rope_attention_bf16": ([p, p, p, p, p, i, i, i, i, i, f, i, i, p], c_int),
         "sbk_glu_dwconv_f32": ([p, p, p, p, i, i, i, i, i, p], c_int),
         "sbk_layernorm_f32": ([p, p, p, p, i, i, f, i, p], c_int),
         "sbk_log_softmax_f32": ([p, p, i, i, f, f, p], c_int),
@@ -479,6 +480,11 @@ def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False, chun
     d = d3 // 3
     if out is None:
         out = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
+    if precision() == "bf16" and not want_attn and d // H == 64:  # opt-in: bf16 operands on the matrix cores
+        _chk(lib.sbk_rope_attention_bf16(_p(qkv), _p(cosines), _p(sines), _p(key_len), _p(out), B, T, H, d // H,
+                                         cosines.shape[0], float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
+             "sbk_rope_attention_bf16")
+        return out, None
     attn = torch.empty(B, H, T, T, dtype=torch.float32, device=qkv.device) if want_attn else None
     _chk(lib.sbk_rope_attention_f32(_p(qkv), _p(cosines), _p(sines), _p(key_len), _p(out), _p(attn), B, T, H, d // H,
                                     cosines.shape[0], float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),

@@ -234,6 +234,49 @@ def test_rope_attention(backend, B, T, H, Dh, lens, prefetch):
     assert float((attn.sum(-1) - 1).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("T,lens,chunk", [(45, None, (0, -1)), (70, [70, 33], (0, -1)), (100, [100, 61], (16, 1))])
+def test_rope_attention_kernel_variants(backend, T, lens, chunk):
+    """The transposed-score flash kernel (default; no LDS) against the LDS-tile flash kernel (knob 16) and the strip
+    kernel, and the bf16 matrix-core variant (precision scope "bf16", head_dim 64) against the fp32 result: key padding,
+    Dynamic Chunk mask, ragged last tiles.  bf16 tolerance 3e-2 absolute on contexts of unit scale (8-bit mantissas
+    of q, k, v and the probabilities)."""
+    nat, dev = backend
+    from speechbrain_amd.nnet.attention import PrecomputedRoPESinusoids
+
+    H, Dh = 2, 64
+    d = H * Dh
+    B = 2 if lens else 1
+    g = torch.Generator().manual_seed(T)
+    qkv = torch.randn(B, T, 3 * d, generator=g).to(dev)
+    tab = PrecomputedRoPESinusoids(128, Dh, torch.float32, "cpu")
+    cos, sin = tab.cosines.to(dev), tab.sines.to(dev)
+    kl = None if lens is None else torch.tensor(lens, dtype=torch.int32).to(dev)
+    scale = 1 / math.sqrt(Dh)
+    new, _ = nat.rope_attention(qkv, cos, sin, kl, H, scale, False, chunk[0], chunk[1])
+    strip, _ = nat.rope_attention(qkv, cos, sin, kl, H, scale, True, chunk[0], chunk[1])
+    nat.load().sbk_prof_set_knob(16, 1)
+    try:
+        old, _ = nat.rope_attention(qkv, cos, sin, kl, H, scale, False, chunk[0], chunk[1])
+    finally:
+        nat.load().sbk_prof_set_knob(16, 0)
+    assert _md(new, old.cpu()) <= 5e-6 and _md(new, strip.cpu()) <= 5e-6
+    with nat.precision_scope("bf16"):
+        low, none = nat.rope_attention(qkv, cos, sin, kl, H, scale, False, chunk[0], chunk[1])
+    assert none is None
+    err = _md(low, new.cpu())
+    assert 0.0 < err <= 3e-2, err
+    # plain attention = identity rotation (what the Whisper encoder uses)
+    ones, zeros = torch.ones(128, Dh, device=dev), torch.zeros(128, Dh, device=dev)
+    plain, _ = nat.rope_attention(qkv, ones, zeros, kl, H, scale, False)
+    q, k, v = [t.reshape(B, T, H, Dh).transpose(1, 2).cpu() for t in qkv.reshape(B, T, H, 3, Dh).unbind(3)]
+    sc = (q @ k.transpose(-1, -2)) * scale
+    if lens is not None:
+        for b_, n in enumerate(lens):
+            sc[b_, :, :, n:] = -float("inf")
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B, T, d)
+    assert _md(plain, ref) <= 5e-6
+
+
 @pytest.mark.parametrize("B,T,d,ks", [(2, 50, 32, 31), (1, 70, 72, 31), (1, 33, 144, 7)])
 def test_glu_dwconv(backend, B, T, d, ks):
     nat, dev = backend

@@ -145,6 +145,11 @@ static inline unsigned short f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
+static inline bf16x8 pack_bf16x8(const unsigned short (&h)[8]) {
+  bf16x8 r;
+  memcpy(r.v, h, sizeof(r.v));
+  return r;
+}
 static inline float bf16_to_f32_(unsigned short h) {
   const unsigned u = (unsigned)h << 16;
   float f;

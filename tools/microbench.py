@@ -128,6 +128,23 @@ if __name__ == "__main__":
         nat.load().sbk_prof_set_knob(11, 1 << 30)
         nat.load().sbk_prof_set_knob(12, 0)
         sys.exit(0)
+    if "--attn2" in sys.argv:  # RoPE / plain attention: LDS-tile flash kernel vs transposed-score kernel vs its bf16 variant
+        import math
+        from speechbrain_amd.nnet.attention import PrecomputedRoPESinusoids
+        for (B, T, H) in [(64, 440, 8), (32, 750, 8), (8, 1500, 20)]:
+            Dh = 64
+            qkv = torch.randn(B, T, 3 * H * Dh, device=dev)
+            tab = PrecomputedRoPESinusoids(2048, Dh, torch.float32, dev)
+            fl = 4.0 * B * H * T * T * Dh
+            res = {}
+            for tag, knob, prec in (("lds-tile", 1, "fp32"), ("transposed", 0, "fp32"), ("transposed bf16", 0, "bf16")):
+                nat.load().sbk_prof_set_knob(16, knob)
+                with nat.precision_scope(prec):
+                    t = timeit(lambda: nat.rope_attention(qkv, tab.cosines, tab.sines, None, H, 0.125), n=20, warm=3)
+                res[tag] = f"{t:8.1f} us {fl / t / 1e6:6.1f} TF/s"
+            nat.load().sbk_prof_set_knob(16, 0)
+            print(f"rope attention B={B} T={T} H={H}:", res, flush=True)
+        sys.exit(0)
     if "--ffn2" in sys.argv:  # few rows, K = 2048: register-operand split-K (default) vs 64x64 LDS tiles with a 4-way K split
         for knob in (0, 1):
             nat.load().sbk_prof_set_knob(14, knob)
