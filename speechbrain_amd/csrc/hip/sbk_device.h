@@ -33,12 +33,13 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 acc) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
-// fp32 -> bf16 bits, round to nearest even (NaN stays NaN: the quiet bit survives the truncation)
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950 converts in hardware (v_cvt_pk_bf16_f32, two values per instruction)
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ bf16x8 cvt_bf16x8(const float (&x)[8]) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (__bf16)x[e];
+  return r;
 }
 
 // eight bf16 bit patterns -> one MFMA operand

@@ -627,10 +627,7 @@ __global__ void __launch_bounds__(256, 2) rope_flash_t_bf16_kernel(AttnArgs a) {
         x[e] = (x0 * cs[e] + x1 * sn[e]) * scale;
         x[e + 1] = (x1 * cs[e + 1] + x0 * sn[e + 1]) * scale;
       }
-      unsigned short hb[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) hb[e] = sbk::f32_to_bf16(x[e]);
-      dst[t] = sbk::pack_bf16x8(hb);
+      dst[t] = sbk::cvt_bf16x8(x);
     }
   };
   bf16x8 qb[4];
@@ -672,14 +669,14 @@ __global__ void __launch_bounds__(256, 2) rope_flash_t_bf16_kernel(AttnArgs a) {
       const float* vbase = qkv_b + 2 * DH + ct * 32 + jl;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        unsigned short hb[8];
+        float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int r = 8 * s + e;
           const int t = min(j0 + (r & 3) + 8 * (r >> 2) + 4 * half, T - 1);
-          hb[e] = sbk::f32_to_bf16(vbase[(size_t)t * row3]);
+          x[e] = vbase[(size_t)t * row3];
         }
-        vb[ct][s] = sbk::pack_bf16x8(hb);
+        vb[ct][s] = sbk::cvt_bf16x8(x);
       }
     }
     float mx = -INFINITY;
@@ -696,15 +693,14 @@ __global__ void __launch_bounds__(256, 2) rope_flash_t_bf16_kernel(AttnArgs a) {
     bf16x8 pb[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      unsigned short hb[8];
+      float x[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int r = 8 * s + e;
-        const float pr = acc[r] == -INFINITY ? 0.0f : expf(acc[r] - m_new);
-        sum += pr;
-        hb[e] = sbk::f32_to_bf16(pr);
+        x[e] = acc[r] == -INFINITY ? 0.0f : expf(acc[r] - m_new);
+        sum += x[e];
       }
-      pb[s] = sbk::pack_bf16x8(hb);
+      pb[s] = sbk::cvt_bf16x8(x);
     }
     sum += sbk::shfl_xor(sum, 32);
     l_run = l_run * alpha + sum;

@@ -150,6 +150,11 @@ static inline bf16x8 pack_bf16x8(const unsigned short (&h)[8]) {
   memcpy(r.v, h, sizeof(r.v));
   return r;
 }
+static inline bf16x8 cvt_bf16x8(const float (&x)[8]) {
+  bf16x8 r;
+  for (int e = 0; e < 8; ++e) r.v[e] = f32_to_bf16(x[e]);
+  return r;
+}
 static inline float bf16_to_f32_(unsigned short h) {
   const unsigned u = (unsigned)h << 16;
   float f;
