@@ -199,7 +199,9 @@ int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bi
 /* ---- RoPEMHA core (nnet/attention.py:1167-1392): what sits between in_proj and out_proj.
  *   out = softmax( rot(q) rot(k)^T scale , keys < key_len ) v,  scale = 1/sqrt(embed_dim) (:1272)
  *   qkv as for sbk_relpos_attention_f32; cosines / sines [table_rows >= T, Dh] = the buffers of
- *   PrecomputedRoPESinusoids (:955-1053): rot(x)[c] = x[c]*cos[t][c] + x[c^1]*sines[t][c]. */
+ *   PrecomputedRoPESinusoids (:955-1053): rot(x)[c] = x[c]*cos[t][c] + x[c^1]*sines[t][c].
+ *   cosines = sines = NULL (attn must be NULL too): no rotation, i.e. plain scaled-dot-product self-attention -- the
+ *   Whisper encoder's MHA (transformers WhisperAttention, reached from integrations/huggingface/whisper.py:372). */
 int sbk_rope_attention_f32(const float* qkv, const float* cosines, const float* sines, const int32_t* key_len,
                            float* out, float* attn, int B, int T, int H, int Dh, int table_rows, float scale,
                            int chunk_size, int left_chunks, sbk_stream_t stream);

@@ -506,9 +506,10 @@ __global__ void __launch_bounds__(256, 2) rope_flash_t_kernel(AttnArgs a) {
   const float* qkv_b = a.qkv + (size_t)b * T * row3 + (size_t)h * 3 * DH;
   const int qrow = min(i0 + jl, T - 1);  // this lane's query (B operand column / output row)
 
+  const bool rot = a.pos != nullptr;  // no tables: plain scaled-dot-product attention (uniform for the launch)
   float qu[DH2];
   load_run<DH2>(qu, qkv_b + (size_t)qrow * row3 + half * DH2);
-  rotate_run<DH>(qu, a.pos + (size_t)qrow * DH + half * DH2, a.bias_u + (size_t)qrow * DH + half * DH2);
+  if (rot) rotate_run<DH>(qu, a.pos + (size_t)qrow * DH + half * DH2, a.bias_u + (size_t)qrow * DH + half * DH2);
 #pragma unroll
   for (int s = 0; s < DH2; ++s) qu[s] *= a.scale;
 
@@ -535,7 +536,7 @@ __global__ void __launch_bounds__(256, 2) rope_flash_t_kernel(AttnArgs a) {
     {
       const int krow = min(j0 + jl, T - 1);
       load_run<DH2>(kreg, qkv_b + (size_t)krow * row3 + DH + half * DH2);
-      rotate_run<DH>(kreg, a.pos + (size_t)krow * DH + half * DH2, a.bias_u + (size_t)krow * DH + half * DH2);
+      if (rot) rotate_run<DH>(kreg, a.pos + (size_t)krow * DH + half * DH2, a.bias_u + (size_t)krow * DH + half * DH2);
     }
     f32x16 acc;  // S^T: row = key (r&3) + 8(r>>2) + 4*half of the tile, column = query jl
 #pragma unroll
@@ -617,16 +618,21 @@ __global__ void __launch_bounds__(256, 2) rope_flash_t_bf16_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int c0 = 16 * t + 8 * half;
-      float x[8], cs[8], sn[8];
+      float x[8];
       load_run<8>(x, row + c0);
-      load_run<8>(cs, a.pos + (size_t)frame * DH + c0);
-      load_run<8>(sn, a.bias_u + (size_t)frame * DH + c0);
+      if (a.pos != nullptr) {  // rotary tables given; otherwise plain attention
+        float cs[8], sn[8];
+        load_run<8>(cs, a.pos + (size_t)frame * DH + c0);
+        load_run<8>(sn, a.bias_u + (size_t)frame * DH + c0);
 #pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        const float x0 = x[e], x1 = x[e + 1];
-        x[e] = (x0 * cs[e] + x1 * sn[e]) * scale;
-        x[e + 1] = (x1 * cs[e + 1] + x0 * sn[e + 1]) * scale;
+        for (int e = 0; e < 8; e += 2) {
+          const float x0 = x[e], x1 = x[e + 1];
+          x[e] = x0 * cs[e] + x1 * sn[e];
+          x[e + 1] = x1 * cs[e + 1] + x0 * sn[e + 1];
+        }
       }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] *= scale;
       dst[t] = sbk::cvt_bf16x8(x);
     }
   };
@@ -729,7 +735,7 @@ int launch_flash(const AttnArgs& a, hipStream_t st) {
   sbk::ProfScope prof(ROPE ? "rope_attention" : "relpos_attention", (ROPE ? 4.0 : 6.0) * a.B * a.H * (double)a.T * a.T * DH,
                       4.0 * a.B * a.T * (4.0 * a.H * DH) + 4.0 * (2.0 * a.T - 1) * a.H * DH, st);
   if constexpr (ROPE) {
-    if (!sbk::g_rope_flash_lds) {  // default: transposed scores, no LDS (knob 16 = 1 keeps the LDS-tile kernel for A/B)
+    if (!sbk::g_rope_flash_lds || !a.pos) {  // default: transposed scores, no LDS (knob 16 = 1 keeps the LDS-tile kernel for A/B)
       SBK_LAUNCH((rope_flash_t_kernel<DH>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
       return sbk::launch_status("sbk_rope_attention_f32");
     }
@@ -814,9 +820,10 @@ extern "C" int sbk_rope_attention_f32(const float* qkv, const float* cosines, co
                                       int table_rows, float scale, int chunk_size, int left_chunks,
                                       sbk_stream_t stream) {
   if (B == 0 || T == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
-  SBK_REQUIRE(qkv && cosines && sines && out, "rope_attention: null operand");
+  SBK_REQUIRE(qkv && out && (cosines != nullptr) == (sines != nullptr), "rope_attention: null operand");
+  SBK_REQUIRE(cosines || !attn, "rope_attention: plain attention (no rotary tables) does not return attention weights");
   SBK_REQUIRE(B >= 0 && T >= 0 && H > 0 && Dh > 0 && Dh % 2 == 0, "rope_attention: bad shape");
-  SBK_REQUIRE(table_rows >= T, "rope_attention: the sinusoid tables hold %d rows, T = %d", table_rows, T);
+  SBK_REQUIRE(!cosines || table_rows >= T, "rope_attention: the sinusoid tables hold %d rows, T = %d", table_rows, T);
   SBK_REQUIRE(sbk::aligned16(qkv) && sbk::aligned16(cosines) && sbk::aligned16(sines),
               "rope_attention: operands must be 16-byte aligned");
   SBK_REQUIRE(chunk_size >= 0, "rope_attention: negative chunk size");
@@ -828,9 +835,9 @@ extern "C" int sbk_rope_attention_bf16(const float* qkv, const float* cosines, c
                                        const int32_t* key_len, float* out, int B, int T, int H, int Dh, int table_rows,
                                        float scale, int chunk_size, int left_chunks, sbk_stream_t stream) {
   if (B == 0 || T == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
-  SBK_REQUIRE(qkv && cosines && sines && out, "rope_attention_bf16: null operand");
+  SBK_REQUIRE(qkv && out && (cosines != nullptr) == (sines != nullptr), "rope_attention_bf16: null operand");
   SBK_REQUIRE(B >= 0 && T >= 0 && H > 0 && Dh == 64, "rope_attention_bf16: head_dim 64 only (got %d)", Dh);
-  SBK_REQUIRE(table_rows >= T, "rope_attention_bf16: the sinusoid tables hold %d rows, T = %d", table_rows, T);
+  SBK_REQUIRE(!cosines || table_rows >= T, "rope_attention_bf16: the sinusoid tables hold %d rows, T = %d", table_rows, T);
   SBK_REQUIRE(sbk::aligned16(qkv) && sbk::aligned16(cosines) && sbk::aligned16(sines),
               "rope_attention_bf16: operands must be 16-byte aligned");
   SBK_REQUIRE(chunk_size >= 0, "rope_attention_bf16: negative chunk size");

@@ -101,7 +101,7 @@ class WhisperLogMel(torch.nn.Module):
 # The reference wraps HuggingFace's WhisperModel (whisper.py:59-117; encoder call :372-374, decoder call :417-436).
 # Here the same parameters (HF state_dict names, so HF / SpeechBrain checkpoints load unchanged) drive the MI355X
 # kernels: the two input convolutions are GEMMs over an in-place strided window of the time-major signal, attention is
-# the flash kernel of the Conformer encoder with an identity rotation, every Linear / LayerNorm / GELU is the fused
+# the rotary flash kernel of the Conformer encoder without a rotation table, every Linear / LayerNorm / GELU is the fused
 # GEMM / row kernel of the rest of the path.
 import json  # noqa: E402
 import os  # noqa: E402
@@ -163,20 +163,6 @@ class _DecoderLayer(nn.Module):
         self.final_layer_norm = nn.LayerNorm(d)
 
 
-def _identity_rotation(rows, head_dim, device):
-    """cos = 1, sin = 0: the rotary attention kernel then computes plain scaled-dot-product attention."""
-    key = (head_dim, str(device))
-    have = _identity_rotation.cache.get(key)
-    if have is None or have[0].shape[0] < rows:
-        n = 1 << max(rows - 1, 1).bit_length()
-        have = (torch.ones(n, head_dim, device=device), torch.zeros(n, head_dim, device=device))
-        _identity_rotation.cache[key] = have
-    return have
-
-
-_identity_rotation.cache = {}
-
-
 class WhisperEncoder(nn.Module):
     """modeling_whisper.WhisperEncoder: conv1(k3,s1)+GELU -> conv2(k3,s2)+GELU -> + embed_positions -> pre-norm
     layers (MHA without masks, GELU feed-forward) -> layer_norm."""
@@ -234,8 +220,7 @@ class WhisperEncoder(nn.Module):
             h = native.layernorm(x, ln.weight, ln.bias, ln.eps)
             w_in, b_in = att.stacked(interleave_heads=True)
             qkv = native.gemm_nt(h, w_in, b_in)
-            cos, sin = _identity_rotation(Tq, att.head_dim, dev)
-            ctx, _ = native.rope_attention(qkv, cos, sin, None, att.num_heads, att.head_dim ** -0.5)
+            ctx, _ = native.rope_attention(qkv, None, None, None, att.num_heads, att.head_dim ** -0.5)  # no rotation
             x = native.gemm_nt(ctx, att.out_proj.weight, att.out_proj.bias, residual=x)
             ln = layer.final_layer_norm
             h = native.layernorm(x, ln.weight, ln.bias, ln.eps)

@@ -472,7 +472,8 @@ def relpos_attention(qkv, pos, bias_u, bias_v, key_len, H, scale, want_attn=Fals
 
 
 def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False, chunk_size=0, left_chunks=-1, out=None):
-    """qkv [B,T,3*d] (per-head interleaved), cosines / sines [rows >= T, Dh] -> context [B,T,d]."""
+    """qkv [B,T,3*d] (per-head interleaved), cosines / sines [rows >= T, Dh] -> context [B,T,d].  ``cosines`` =
+    ``sines`` = None: plain scaled-dot-product attention (no rotation; no attention-weights output)."""
     lib = load()
     _dev_ok(qkv, cosines, sines, key_len, out)
     _f32(qkv)
@@ -480,14 +481,15 @@ def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False, chun
     d = d3 // 3
     if out is None:
         out = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
+    rows = cosines.shape[0] if cosines is not None else 0
     if precision() == "bf16" and not want_attn and d // H == 64:  # opt-in: bf16 operands on the matrix cores
         _chk(lib.sbk_rope_attention_bf16(_p(qkv), _p(cosines), _p(sines), _p(key_len), _p(out), B, T, H, d // H,
-                                         cosines.shape[0], float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
+                                         rows, float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
              "sbk_rope_attention_bf16")
         return out, None
     attn = torch.empty(B, H, T, T, dtype=torch.float32, device=qkv.device) if want_attn else None
     _chk(lib.sbk_rope_attention_f32(_p(qkv), _p(cosines), _p(sines), _p(key_len), _p(out), _p(attn), B, T, H, d // H,
-                                    cosines.shape[0], float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
+                                    rows, float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
          "sbk_rope_attention_f32")
     return out, attn
 

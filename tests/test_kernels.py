@@ -265,9 +265,12 @@ def test_rope_attention_kernel_variants(backend, T, lens, chunk):
     assert none is None
     err = _md(low, new.cpu())
     assert 0.0 < err <= 3e-2, err
-    # plain attention = identity rotation (what the Whisper encoder uses)
+    # plain attention: no rotary tables (what the Whisper encoder uses) = an identity rotation
     ones, zeros = torch.ones(128, Dh, device=dev), torch.zeros(128, Dh, device=dev)
-    plain, _ = nat.rope_attention(qkv, ones, zeros, kl, H, scale, False)
+    plain, _ = nat.rope_attention(qkv, None, None, kl, H, scale, False)
+    assert _md(plain, nat.rope_attention(qkv, ones, zeros, kl, H, scale, False)[0].cpu()) <= 1e-6
+    with nat.precision_scope("bf16"):
+        assert _md(nat.rope_attention(qkv, None, None, kl, H, scale, False)[0], plain.cpu()) <= 3e-2
     q, k, v = [t.reshape(B, T, H, Dh).transpose(1, 2).cpu() for t in qkv.reshape(B, T, H, 3, Dh).unbind(3)]
     sc = (q @ k.transpose(-1, -2)) * scale
     if lens is not None:
