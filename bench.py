@@ -243,6 +243,8 @@ def main():
                     help="add the recipe's TransformerLM scorer (12 x 768, weight 0.6, T=1.15): test_search at beam 10")
     ap.add_argument("--group-encoder", action="store_true",
                     help="one encoder pass over the rows of all the batches of a group instead of one per batch (A/B)")
+    ap.add_argument("--overlap-ctc", type=int, default=-1,
+                    help="A/B: overlap_ctc bit mask of the workers' searches (default: 0 with several workers)")
     ap.add_argument("--graph-mode", type=int, default=0, choices=[0, 1, 2],
                     help="searches of the timed run: 1 = decoding steps replayed from a captured hipGraph, 2 = device-side "
                          "step counter with plain launches (A/B; 0 = plain launches)")
@@ -326,6 +328,8 @@ def main():
         workers.group_encoder = args.group_encoder
         for srch in workers.searchers:
             srch.graph_mode = args.graph_mode
+            if args.overlap_ctc >= 0:
+                srch.overlap_ctc = args.overlap_ctc
         st = ShardedTranscriber(transcribe_one, dev, max_utts=max_batch, concurrent=workers, prepare=fixed_decode_length)
         # W untimed steps through the same path (communicators, allocator pools); the longest utterances first, and
         # every worker stream sizes its allocations on the longest batch
