@@ -204,6 +204,37 @@ def whisper_encoder_leg(dev, B=8, reps=3):
     return res
 
 
+def launch_check(args, rank, world):
+    """The launch / exchange plumbing of a measurement without the GPU: same self-launch, same job, same
+    ShardedTranscriber calls; the per-rank transcriber is a stand-in that derives tokens from each waveform."""
+    import torch.distributed as dist
+
+    from speechbrain_amd.inference.sharded import ShardedTranscriber
+
+    if world > 1:
+        dist.init_process_group("gloo")
+
+    def stand_in(wavs, lens):
+        return [[int(round(float(l) * w.numel())) % 1000, int(w[0]) % 997] for w, l in zip(wavs, lens)]
+
+    n_utts = world * args.steps * UTTS_PER_STEP
+    job, seconds = make_job(n_utts) if rank == 0 else (None, None)
+    if rank == 0:  # (float32 copies: widening int16 PCM is a kernel of the GPU path)
+        job = [w.float() for w in job]
+    st = ShardedTranscriber(stand_in, "cpu", max_utts=args.max_batch)
+    t0 = time.perf_counter()
+    local = st.distribute(st.plan(job))
+    hyps = st.gather(st.run_local(local))
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        assert hyps == [[w.numel() % 1000, int(w[0]) % 997] for w in job], "gathered hypotheses do not match the job"
+        print(json.dumps({"launch_check": True, "n_gpus": world, "steps": args.steps, "utterances_total": n_utts,
+                          "batches_total": len(st.last_plan["batches"]), "bytes_scattered": st.last_plan["bytes_sent"],
+                          "ranks_with_work": sum(1 for o in st.last_plan["owner"] if o), "seconds": round(dt, 3)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def roofline_entry(name, v, total_ms):
     avg_ms = v["ms"] / max(v["count"], 1)
     if name.startswith(MFMA_KERNELS):
@@ -252,6 +283,10 @@ def main():
                     help="run each worker's search on its normal-priority stream (A/B of the stream priorities)")
     ap.add_argument("--knob", action="append", default=[], metavar="KEY=VALUE",
                     help="tuning switch passed to sbk_prof_set_knob (A/B measurements only)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU work: launch the N ranks exactly as a measurement would (gloo instead of RCCL), push the "
+                         "synthetic job through plan -> streamed scatter -> a stand-in transcriber -> gather and print the "
+                         "line with n_gpus = N.  What tests/test_distributed.py runs on CPU")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -269,6 +304,9 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.launch_check:
+        launch_check(args, rank, world)
+        return
     # SBK_BENCH_FORCE_DIST=1 (with torchrun --nproc-per-node 1): run the RCCL leg -- process group, scatter metadata,
     # gather, all-reduce, barrier -- on a single GPU, to check the N > 1 code path where only one GPU is available
     dist_on = world > 1 or (os.environ.get("SBK_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)

@@ -155,3 +155,23 @@ def test_sharded_asr_world2_matches_single_process(tmp_path, pcm):
     assert hyps == ref
     sent_samples = bytes_sent // (2 if pcm else 4)
     assert 0 < sent_samples <= sum(w.numel() for w in wavs) * 1.3  # exact-size sends: no padding to the widest rank
+
+
+def test_bench_self_launch_world2():
+    """`python bench.py --gpus 2` with no rendezvous in the environment must start two ranks itself (torch.distributed.run
+    on 127.0.0.1), run the sharded path and print ONE line with n_gpus = 2.  --launch-check keeps everything but the GPU
+    work: gloo instead of RCCL, a stand-in transcriber, the real plan / streamed scatter / gather."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--launch-check"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["utterances_total"] == 256 and rec["ranks_with_work"] == 2
+    assert rec["bytes_scattered"] > 0
