@@ -227,12 +227,14 @@ class InputNormalization(torch.nn.Module):
             raise NotImplementedError("avoid_padding_norm with global statistics is not on the ASR inference path")
         if self.glob_mean.numel() == 0:
             raise RuntimeError("InputNormalization has no statistics loaded (glob_mean/glob_std)")
-        if self.glob_mean.device != x.device:
-            self.glob_mean = self.glob_mean.to(x.device)
-            self.glob_std = self.glob_std.to(x.device)
-        std = self.glob_std if self.std_norm else torch.ones_like(self.glob_mean)
-        return native.input_norm_global(x.contiguous(), self.glob_mean.float().contiguous(),
-                                        std.float().contiguous(), self.epsilon)
+        # (locals: several worker threads may get here at once; none must see one statistic moved and the other not)
+        mean, std = self.glob_mean, self.glob_std
+        if mean.device != x.device or std.device != x.device:
+            mean, std = mean.to(x.device), std.to(x.device)
+            self.glob_mean, self.glob_std = mean, std
+        if not self.std_norm:
+            std = torch.ones_like(mean)
+        return native.input_norm_global(x.contiguous(), mean.float().contiguous(), std.float().contiguous(), self.epsilon)
 
     def _statistics_dict(self):
         return {"count": self.count, "glob_mean": self.glob_mean, "glob_std": self.glob_std}
@@ -244,6 +246,15 @@ class InputNormalization(torch.nn.Module):
         self = super().to(device)
         self.glob_mean = self.glob_mean.to(device)
         self.glob_std = self.glob_std.to(device)
+        return self
+
+    def _apply(self, fn, *args, **kwargs):
+        """The statistics are plain attributes (as in the reference, whose own ``to`` moves them): a parent module's
+        ``.to(device)`` reaches this module only through ``_apply``, so move them here too -- they are then in
+        place before any worker thread runs ``forward``."""
+        super()._apply(fn, *args, **kwargs)
+        if self.glob_mean.numel():
+            self.glob_mean, self.glob_std = fn(self.glob_mean), fn(self.glob_std)
         return self
 
     def _save(self, path):

@@ -343,6 +343,31 @@ def test_pcm16_to_f32(backend, frames, channels):
         assert torch.equal(out.cpu(), ref)
 
 
+def test_input_normalization_statistics_follow_the_parent_module(backend):
+    """Global statistics are plain attributes: moving a PARENT module must move them (no lazy move left for the first,
+    possibly concurrent, forward), and concurrent first calls must agree (the worker threads of ConcurrentTranscriber)."""
+    nat, dev = backend
+    from concurrent.futures import ThreadPoolExecutor
+
+    from speechbrain_amd.processing.features import InputNormalization
+
+    norm = InputNormalization(norm_type="global").eval()
+    norm.glob_mean, norm.glob_std, norm.count = torch.linspace(-1, 1, 20), torch.linspace(0.5, 2, 20), 7
+    parent = torch.nn.Sequential(norm).to(dev)
+    assert parent[0].glob_mean.device.type == dev.type and parent[0].glob_std.device.type == dev.type
+    x = torch.randn(3, 11, 20, generator=torch.Generator().manual_seed(4))
+    ref = (x - torch.linspace(-1, 1, 20)) / torch.linspace(0.5, 2, 20)
+    lazy = InputNormalization(norm_type="global").eval()  # statistics left on the host: first calls race for the move
+    lazy.glob_mean, lazy.glob_std = torch.linspace(-1, 1, 20), torch.linspace(0.5, 2, 20)
+    if dev.type == "cuda":
+        with ThreadPoolExecutor(4) as pool:
+            outs = list(pool.map(lambda _: lazy(x.to(dev)).cpu(), range(8)))
+    else:  # (the CPU kernel emulator runs one launch at a time)
+        outs = [lazy(x.to(dev)).cpu() for _ in range(2)]
+    for o in outs + [parent(x.to(dev)).cpu()]:
+        assert float((o - ref).abs().max()) <= 1e-6
+
+
 def test_input_normalization_sentence_and_batch(backend):
     """a6: InputNormalization norm_type "sentence" / "batch" against the reference's outputs (tests/golden/
     input_norm.npz, oracle/make_golden.py:golden_input_norm): statistics over the unpadded frames only, two-pass
