@@ -1097,6 +1097,7 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 2) sbk::g_skinny_off = value;
   if (key == 3) sbk::g_attn_prefetch = value;
   if (key == 16) sbk::g_rope_flash_lds = value;
+  if (key == 17) sbk::g_relpos_flash_t = value;
   if (key == 4) sbk::g_cross_rows = value;
   if (key == 5) sbk::g_kv_head_major = value;
   if (key == 6) sbk::g_gemm_tile = value;

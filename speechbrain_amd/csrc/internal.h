@@ -14,6 +14,7 @@ extern thread_local const int32_t* g_step_ptr;
 extern thread_local int g_step_min_steps;  // min_decode_steps of that search (eos floor: step < min_steps)
 extern int g_attn_prefetch;
 extern int g_rope_flash_lds;
+extern int g_relpos_flash_t;
 extern int g_cross_rows;
 extern int g_kv_head_major;
 extern int g_ctc_tpt;

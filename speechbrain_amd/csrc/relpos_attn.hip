@@ -597,6 +597,140 @@ __global__ void __launch_bounds__(256, 2) rope_flash_t_kernel(AttnArgs a) {
   }
 }
 
+// RelPosMHAXL with the same transposed scores.  The position term BD[i][j] = (q_i + v) . p[T-1-i+j] is the one thing that
+// cannot stay in registers: G^T[r'][i] = p[rbase + r'] . (q_i + v) comes out of the MFMA with a lane owning one query
+// column, and the row that query needs for key j is r' = 31 - i + j -- a per-lane shift.  So G^T goes through a 64-row
+// ring in LDS (each key tile adds the 32 rows the previous one did not have; 16 stores per lane) and every lane
+// gathers its 16 entries back (pitch 32: the 32 lanes of a half-wave hit 32 different banks).  Scores, softmax,
+// probabilities and the context product are those of rope_flash_t_kernel.
+template <int DH>
+__global__ void __launch_bounds__(256, 2) relpos_flash_t_kernel(AttnArgs a) {
+  constexpr int DH2 = DH / 2;
+  constexpr int NC = (DH + 31) / 32;
+  __shared__ float Gs[4][64][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & 31, half = lane >> 5;
+  const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+  const int T = a.T, d = a.H * DH;
+  if (i0 >= T) return;
+  const size_t row3 = (size_t)3 * d;
+  const float* qkv_b = a.qkv + (size_t)b * T * row3 + (size_t)h * 3 * DH;
+  const int qrow = min(i0 + jl, T - 1);
+  float (*G)[32] = Gs[wave];
+
+  float qu[DH2], qv[DH2];
+  {
+    float qr[DH2], bu[DH2], bv[DH2];
+    load_run<DH2>(qr, qkv_b + (size_t)qrow * row3 + half * DH2);
+    load_run<DH2>(bu, a.bias_u + h * DH + half * DH2);
+    load_run<DH2>(bv, a.bias_v + h * DH + half * DH2);
+#pragma unroll
+    for (int s = 0; s < DH2; ++s) {
+      qu[s] = (qr[s] + bu[s]) * a.scale;
+      qv[s] = (qr[s] + bv[s]) * a.scale;
+    }
+  }
+  int klen = T;
+  if (a.key_len) klen = min(max(a.key_len[b], 1), T);
+  const int nkt = (klen + 31) / 32;
+  int lo, hi;
+  key_range(a, qrow, klen, lo, hi);
+  int kt_begin = 0, kt_end = nkt;
+  if (a.chunk > 0) {
+    kt_end = min(nkt, ((min(i0 + 31, T - 1) / a.chunk + 1) * a.chunk + 31) / 32);
+    if (a.left >= 0) kt_begin = max(0, (i0 / a.chunk - a.left) * a.chunk) / 32;
+  }
+  float m_run = -INFINITY, l_run = 0.0f;
+  f32x16 o[NC];
+#pragma unroll
+  for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[ct][r] = 0.0f;
+
+  // G^T rows [rbase + 32*blk, +32) of the position table against the wave's queries -> ring rows of parity `slot`
+  auto g_block = [&](int first_row, int slot) {
+    float preg[DH2];
+    const int prow = min(max(first_row + jl, 0), 2 * T - 2);
+    load_run<DH2>(preg, a.pos + (size_t)prow * d + h * DH + half * DH2);
+    f32x16 g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < DH2; ++s) g = sbk::mfma_32x32x2(preg[s], qv[s], g);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) G[slot * 32 + (r & 3) + 8 * (r >> 2) + 4 * half][jl] = g[r];
+  };
+  // key tile kt needs rows rbase .. rbase+62 with rbase = T-1-i0-31+32*kt: its lower 32 rows are the upper 32 of tile
+  // kt-1.  Ring slot of the block starting at rbase + 32*m: (kt + m) & 1.
+  g_block((T - 1) - i0 - 31 + 32 * kt_begin, kt_begin & 1);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int j0 = kt * 32;
+    const int rbase = (T - 1) - i0 - 31 + j0;
+    float kreg[DH2];
+    load_run<DH2>(kreg, qkv_b + (size_t)min(j0 + jl, T - 1) * row3 + DH + half * DH2);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < DH2; ++s) acc = sbk::mfma_32x32x2(kreg[s], qu[s], acc);
+    g_block(rbase + 32, (kt + 1) & 1);  // the upper 32 rows (the slot last read two tiles ago)
+    float vv[NC][16];
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+      const int col = ct * 32 + jl;
+      const float* vbase = qkv_b + 2 * DH + (col < DH ? col : 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = min(j0 + (r & 3) + 8 * (r >> 2) + 4 * half, T - 1);
+        vv[ct][r] = col < DH ? vbase[(size_t)t * row3] : 0.0f;
+      }
+    }
+    sbk::wave_sync();  // the ring holds both blocks of this tile
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jc = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int rr = 31 - jl + jc;  // 0 .. 62: row of this tile's window for (query jl, key jc)
+      acc[r] += G[(((kt & 1) + (rr >> 5)) & 1) * 32 + (rr & 31)][jl];
+      const int key = j0 + jc;
+      if (!(key >= lo && key < hi)) acc[r] = -INFINITY;
+      mx = fmaxf(mx, acc[r]);
+    }
+    sbk::wave_sync();  // everybody has read the lower block before the next tile overwrites its slot
+    mx = fmaxf(mx, sbk::shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = m_new == -INFINITY ? 1.0f : expf(m_run - m_new);
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[r] = acc[r] == -INFINITY ? 0.0f : expf(acc[r] - m_new);
+      sum += acc[r];
+    }
+    sum += sbk::shfl_xor(sum, 32);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct) o[ct] = sbk::mfma_32x32x2(vv[ct][r], acc[r], o[ct]);
+  }
+  if (i0 + jl < T) {
+    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+    float* orow = a.out + ((size_t)b * T + i0 + jl) * d + h * DH;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (c < DH) orow[c] = o[ct][r] * inv;
+      }
+  }
+}
+
 // The same walk with bf16 MFMA operands (v_mfma_f32_32x32x16_bf16: 8 k-values per lane and instruction) for the
 // opt-in reduced-precision path: q, k, v and the probabilities are rounded to bf16 on their way into the matrix
 // cores, scores / softmax statistics / context accumulate in fp32.  head_dim 64: four instructions per score tile and
@@ -740,6 +874,12 @@ int launch_flash(const AttnArgs& a, hipStream_t st) {
       return sbk::launch_status("sbk_rope_attention_f32");
     }
   }
+  if constexpr (!ROPE) {
+    if (sbk::g_relpos_flash_t) {  // knob 17: transposed scores, position term through a 64-row LDS ring (not yet measured)
+      SBK_LAUNCH((relpos_flash_t_kernel<DH>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+      return sbk::launch_status("sbk_relpos_attention_f32");
+    }
+  }
   SBK_LAUNCH((relpos_flash_kernel<DH, ROPE>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   return sbk::launch_status(ROPE ? "sbk_rope_attention_f32" : "sbk_relpos_attention_f32");
 }
@@ -780,6 +920,7 @@ int launch_attn_pf(const AttnArgs& a, hipStream_t st) {
 }  // namespace
 
 namespace sbk {
+int g_relpos_flash_t = 0;  // tuning knob (key 17): 1 = RelPosMHAXL through the transposed-score flash kernel
 int g_rope_flash_lds = 0;  // tuning knob (key 16): 1 = RoPE / plain attention through the LDS-tile flash kernel (round-2 first half)
 int g_attn_prefetch = 0;  // tuning knob (sbk_prof_set_knob key 3): phase 1 prefetches the next key tile's operands
 

@@ -201,6 +201,41 @@ def test_relpos_attention(backend, B, T, H, Dh, lens, prefetch):
     nat.load().sbk_prof_set_knob(3, 0)
 
 
+@pytest.mark.parametrize("B,T,H,Dh,lens,chunk", [(2, 45, 4, 8, [45, 30], (0, -1)), (1, 70, 2, 36, [70], (0, -1)),
+                                                 (2, 133, 2, 64, [133, 20], (0, -1)), (1, 100, 1, 16, None, (0, -1)),
+                                                 (2, 251, 2, 64, [251, 129], (16, 2)), (1, 97, 2, 32, [97], (8, -1))])
+def test_relpos_transposed_flash_variant(backend, B, T, H, Dh, lens, chunk):
+    """csrc/relpos_attn.hip relpos_flash_t_kernel (tuning knob 17; prepared, not yet the default): transposed scores with
+    the position term gathered from a 64-row LDS ring must reproduce the default flash kernel and the oracle --
+    key padding, Dynamic Chunk masks, ragged tiles, every instantiated head size."""
+    nat, dev = backend
+    if dev.type == "cuda":
+        pytest.skip("variant validated on the CPU emulator only so far (not measured on the GPU yet)")
+    d = H * Dh
+    g = torch.Generator().manual_seed(T + Dh)
+    x = torch.randn(B, T, d, generator=g)
+    sd = {"in_proj_weight": torch.randn(3 * d, d, generator=g) / math.sqrt(d),
+          "pos_bias_u": torch.randn(Dh, H, generator=g) * 0.3, "pos_bias_v": torch.randn(Dh, H, generator=g) * 0.3,
+          "linear_pos.weight": torch.randn(d, d, generator=g) / math.sqrt(d), "out_proj.weight": torch.eye(d),
+          "out_proj.bias": torch.zeros(d)}
+    pos = O.relpos_table(T, d)
+    kl = None if lens is None else torch.tensor(lens, dtype=torch.int32)
+    qkv = nat.gemm_nt(x.to(dev), sd["in_proj_weight"].to(dev))
+    P = nat.gemm_nt(pos.to(dev), sd["linear_pos.weight"].to(dev))
+    args = (qkv, P, sd["pos_bias_u"].reshape(-1).contiguous().to(dev), sd["pos_bias_v"].reshape(-1).contiguous().to(dev),
+            None if kl is None else kl.to(dev), H, 1 / math.sqrt(d), False, chunk[0], chunk[1])
+    base, _ = nat.relpos_attention(*args)
+    nat.load().sbk_prof_set_knob(17, 1)
+    try:
+        new, _ = nat.relpos_attention(*args)
+    finally:
+        nat.load().sbk_prof_set_knob(17, 0)
+    assert _md(new, base.cpu()) <= 5e-6
+    if chunk[0] == 0:
+        kp = None if kl is None else ~O.length_to_mask(kl, T)
+        assert _md(new, O.relpos_mha(x, pos, sd, "", H, kp)) <= 5e-6
+
+
 @pytest.mark.parametrize("prefetch", [0, 1, 4, 5])
 @pytest.mark.parametrize("B,T,H,Dh,lens", [(2, 45, 4, 8, [45, 30]), (1, 70, 2, 36, [70]), (2, 133, 2, 64, [133, 20]),
                                            (1, 300, 1, 32, None)])
