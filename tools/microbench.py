@@ -128,6 +128,23 @@ if __name__ == "__main__":
         nat.load().sbk_prof_set_knob(11, 1 << 30)
         nat.load().sbk_prof_set_knob(12, 0)
         sys.exit(0)
+    if "--relpos-t" in sys.argv:  # RelPosMHAXL flash kernel: default (score tile through LDS) vs transposed scores (knob 17)
+        import math
+        for (B, T, H) in [(64, 440, 8), (32, 750, 8)]:
+            Dh, d = 64, 8 * 64
+            qkv = torch.randn(B, T, 3 * d, device=dev)
+            P = torch.randn(2 * T - 1, d, device=dev)
+            u, v = torch.randn(d, device=dev) * 0.3, torch.randn(d, device=dev) * 0.3
+            fl = 6.0 * B * H * T * T * Dh
+            res, outs = {}, {}
+            for tag, knob in (("lds-tile", 0), ("transposed", 1)):
+                nat.load().sbk_prof_set_knob(17, knob)
+                outs[tag] = nat.relpos_attention(qkv, P, u, v, None, H, 1 / math.sqrt(d))[0]
+                t = timeit(lambda: nat.relpos_attention(qkv, P, u, v, None, H, 1 / math.sqrt(d)), n=20, warm=3)
+                res[tag] = f"{t:8.1f} us {fl / t / 1e6:6.1f} TF/s"
+            nat.load().sbk_prof_set_knob(17, 0)
+            print(f"relpos attention B={B} T={T} H={H}:", res, "max|diff|", float((outs["lds-tile"] - outs["transposed"]).abs().max()), flush=True)
+        sys.exit(0)
     if "--attn2" in sys.argv:  # RoPE / plain attention: LDS-tile flash kernel vs transposed-score kernel vs its bf16 variant
         import math
         from speechbrain_amd.nnet.attention import PrecomputedRoPESinusoids
