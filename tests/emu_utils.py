@@ -31,7 +31,12 @@ def attach():
     from speechbrain_amd import native
 
     native._lib = None
-    native.load(build())
+    lib = native.load(build())
+    # SBK_TEST_KNOBS="17=1,14=0": run the CPU suite with tuning variants switched on (validation of a prepared kernel
+    # against every model-level golden before it becomes a default)
+    for kv in filter(None, os.environ.get("SBK_TEST_KNOBS", "").split(",")):
+        key, value = kv.split("=")
+        lib.sbk_prof_set_knob(int(key), int(value))
     if _strict_dev_ok is None:
         _strict_dev_ok = native._dev_ok
     native._dev_ok = _contiguous_only
