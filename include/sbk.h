@@ -47,6 +47,14 @@ int sbk_prof_gemm_repeat_f32(const float* A, const float* W, float* C, int M, in
 
 /* tuning knobs for experiments (key 1: K chunks per fetch batch of the skinny GEMM, 0 = automatic) */
 void sbk_prof_set_knob(int key, int value);
+/* HBM calibration (SURVEY 8d "measure achievable with a copy kernel first"): hand-written float4 streaming kernels.
+ * mode 0 = copy src -> dst (2 * 4 * n bytes per launch), mode 1 = read src (4 * n bytes; dst is a sink of >= 2048
+ * floats).  n % 4 == 0, 16-byte aligned.  Mean time of `iters` back-to-back launches in *us_per_launch (HOST). */
+/* f32 matrix-core ceiling under the chip's power management: `wgs` workgroups of 4 waves issue iters x 16
+ * v_mfma_f32_32x32x2_f32 each from registers (zero or pseudo-random operands); *tflops is a HOST out; sink >= wgs floats. */
+int sbk_prof_mfma_peak_f32(float* sink, int wgs, int iters, int random_data, float* tflops, sbk_stream_t stream);
+int sbk_prof_stream_f32(const float* src, float* dst, long n, int mode, int iters, float* us_per_launch,
+                        sbk_stream_t stream);
 /* same for the CTC prefix-score pass (x: [B,T,V] log-softmax rows, converted in place; work: scratch) */
 int sbk_prof_ctc_psi_repeat_f32(float* x, const int32_t* enc_len, const int32_t* last_tok, float* psi, float* work,
                                 int B, int T, int V, int beam, int prefix_len, int iters, float* us_per_launch,

@@ -12,6 +12,9 @@
 #include "common.h"
 #include "internal.h"
 
+#include <map>
+#include <mutex>
+
 namespace {
 
 using sbk::f32x16;
@@ -519,6 +522,312 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_v4_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Persistent GEMM on LDS-DMA panels with a stream-K tail (the encoder's contractions: M = frames of a batch, 4-24 K
+// rows, i.e. 100-3000 tiles of 128x128 -- tile counts that fill 256 CUs badly when every workgroup takes whole tiles).
+//
+// The launch has a FIXED number of workgroups G = 8 W (W per XCD, two per CU).  XCD x (= workgroup id % 8, observed)
+// owns the contiguous tile range [T x/8, T (x+1)/8) in row-major tile order; its workgroup j takes
+//   * whole tiles  t0 + r W + j,  r = 0 .. T_x / W - 1   (at any moment the XCD's W workgroups multiply W CONSECUTIVE
+//     tiles: neighbours share the A row panel and every W column panel through that XCD's L2 -- a contiguous range per
+//     workgroup instead was measured at a 29 % L2 hit rate and 3.8x the fabric traffic, profiles/r03_*), then
+//   * its share of the XCD's T_x % W LEFTOVER tiles, stream-K style: the leftover (tile, 32-deep K tile) units are cut
+//     into W equal contiguous ranges, so the tail costs (T_x % W) / W of a tile time instead of a whole one.
+// A leftover tile whose K range is cut is finished by whichever of its workgroups arrives last: each writes its partial
+// accumulators to its own slab, publishes (agent-scope release, MI355X_MICROARCH.md "Workgroup dispatch ... visibility")
+// and takes a ticket on the tile's counter; the last ticket reads ALL the tile's slabs in K order (fixed summation
+// order => run-to-run deterministic), applies the epilogue and re-arms the counter.  No workgroup ever waits for
+// another one, so nothing depends on residency or dispatch order.  Workgroups of the upper half of an XCD run their
+// tail share FIRST (knob 23): the two workgroups of a CU are then half a tile apart and do not sit in their epilogues
+// (no MFMA) at the same time.
+//
+// Panels: global_load_lds_dwordx4 straight into a double-buffered LDS image [stage][A 128 rows | W 128 rows][32 k]
+// (no staging registers, no ds_write pass, ONE barrier per K tile).  The LDS image of an LDS-DMA is lane-linear, so
+// the bank swizzle is applied to the global SOURCE address: the 16-byte slot s of row r lands in slot s ^ ((r>>1)&7),
+// and the MFMA operand fetch (ds_read_b128 of four consecutive k, lane half h of row r reads slot (2g+h) ^ ((r>>1)&7))
+// is conflict-free for the 16-lane groups of a b128 read (SQ_LDS_BANK_CONFLICT = 0 measured).  Lanes 0-31 feed
+// k = 8g+e, lanes 32-63 k = 8g+4+e of MFMA e of group g (any pairing of the two k slices is a valid contraction as long
+// as A and W use the same one).
+struct SkArgs {
+  GemmArgs g;
+  float* slabs;  // [2 * G][128 * 128] partial tiles (slot 0: the workgroup's segment that does not start a tile; 1: the one that does)
+  int* cnt;      // [tiles] arrival tickets, zero between launches
+  int tiles_n, tiles, KT;
+  int stagger;   // upper half of each XCD's workgroups runs the tail share first
+  int noload;    // measurement only (knob 22): panels are loaded once per workgroup (wrong results, MFMA/LDS ceiling)
+};
+
+__global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
+  constexpr int BK = 32, PANEL = 128 * BK, STAGE = 2 * PANEL;  // floats
+  SBK_DYN_LDS(float, lds);  // [2][STAGE] + the ticket word (ONE LDS object: a second one de-pipelines the LDS-DMA loop)
+  // kernel arguments into registers (a by-value struct whose address is taken is copied to scratch)
+  const float* const gA = s.g.A;
+  const float* const gW = s.g.W;
+  const float* const gbias = s.g.bias;
+  const float* const gR = s.g.R;
+  float* const gC = s.g.C;
+  const int lda = s.g.lda, ldw = s.g.ldw, ldr = s.g.ldr, ldc = s.g.ldc, M = s.g.M, N = s.g.N, act = s.g.act;
+  const float alpha = s.g.alpha;
+  const int32_t* const seq_len = s.g.seq_len;
+  const int rows_per_seq = s.g.rows_per_seq;
+  float* const slabs = s.slabs;
+  int* const cnt = s.cnt;
+  const int tiles_n = s.tiles_n, KT = s.KT, noload = s.noload;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = sbk::uniform(tid >> 6);
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int lrow = lane & 31, half = lane >> 5, sw = (lrow >> 1) & 7;
+  // ---- this workgroup's segments: whole tiles of the XCD's range, then (or first) its share of the leftover tiles
+  const int W = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;  // gridDim.x is a multiple of 8
+  const int t0 = (int)((long)s.tiles * x / 8), t1 = (int)((long)s.tiles * (x + 1) / 8);
+  const int nfull = sbk::uniform((t1 - t0) / W), R = (t1 - t0) - nfull * W, tb = t0 + nfull * W;
+  const int UT = R * KT, ubase = sbk::uniform(UT / W), urem = UT - ubase * W;
+  const int q0 = j * ubase + min(j, urem), q1 = q0 + ubase + (j < urem ? 1 : 0);
+  int nt = 0, tileA = 0, loA = 0, hiA = 0, hiB = 0;
+  if (q1 > q0) {
+    const int ta = sbk::uniform(q0 / KT);
+    tileA = tb + ta;
+    loA = q0 - ta * KT;
+    hiA = min(KT, loA + (q1 - q0));
+    hiB = q1 - (ta + 1) * KT;  // > 0: the range runs on into the next leftover tile
+    nt = hiB > 0 ? 2 : 1;
+  }
+  const int nseg_wg = nfull + nt;
+  if (nseg_wg == 0) return;
+  const bool tail_first = s.stagger && j >= (W >> 1);
+  auto seg_get = [&](int sidx, int& tile, int& lo, int& hi) SBK_INLINE_LAMBDA {
+    const int d = tail_first ? sidx - nt : sidx;
+    if (d >= 0 && d < nfull) {
+      tile = t0 + d * W + j;
+      lo = 0;
+      hi = KT;
+    } else if ((tail_first ? sidx : sidx - nfull) == 0) {
+      tile = tileA;
+      lo = loA;
+      hi = hiA;
+    } else {
+      tile = tileA + 1;
+      lo = 0;
+      hi = hiB;
+    }
+  };
+  // workgroup (index within the XCD) that owns leftover unit q
+  auto owner = [&](int q) SBK_INLINE_LAMBDA {
+    const int big = urem * (ubase + 1);
+    return sbk::uniform(q < big ? q / (ubase + 1) : urem + (q - big) / max(ubase, 1));
+  };
+  const int p = x * W + j;  // slab owner id
+
+  // loader geometry: wave-instruction i of this wave covers rows (wave*4+i)*8 .. +7 of a panel, 8 slots of 16 B each
+  int lrw[4], lsl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lrw[i] = (wave * 4 + i) * 8 + (lane >> 3);
+    lsl[i] = ((lane & 7) ^ ((lrw[i] >> 1) & 7)) * 4;  // source k offset (floats) of the slot this lane fills
+  }
+  const float* ap[4];
+  const float* wp[4];
+  auto setup = [&](int tile) SBK_INLINE_LAMBDA {
+    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // rows past the matrix re-read its last row (their outputs are never stored)
+      ap[i] = gA + (size_t)min(m0 + lrw[i], M - 1) * lda + lsl[i];
+      wp[i] = gW + (size_t)min(n0 + lrw[i], N - 1) * ldw + lsl[i];
+    }
+  };
+  auto issue = [&](int kt, int stage) SBK_INLINE_LAMBDA {
+    float* base = lds + stage * STAGE + (wave * 4) * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sbk::glds16(ap[i] + kt * BK, base + i * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sbk::glds16(wp[i] + kt * BK, base + PANEL + i * 256);
+  };
+
+  f32x16 acc[2][2];
+  auto zero = [&]() SBK_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  };
+  auto compute = [&](int stage) SBK_INLINE_LAMBDA {
+    const float* As = lds + stage * STAGE + (wm0 + lrow) * BK;
+    const float* Ws = lds + stage * STAGE + PANEL + (wn0 + lrow) * BK;
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) {
+      const int slot = ((2 * gk + half) ^ sw) * 4;
+      float4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(As + i * 32 * BK + slot);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(Ws + j * 32 * BK + slot);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float av = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
+            const float bw = e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w;
+            acc[i][j] = sbk::mfma_32x32x2(av, bw, acc[i][j]);
+          }
+    }
+  };
+  auto epilogue = [&](int tile) SBK_INLINE_LAMBDA {
+    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+    const bool interior = m0 + 128 <= M && n0 + 128 <= N;  // uniform: no per-element predicates
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn0 + j * 32 + lrow;
+      const bool col_ok = interior || col < N;
+      const float bv = (gbias && col_ok) ? gbias[col] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rbase = m0 + wm0 + i * 32 + 4 * half;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+        switch (act) {  // uniform
+          case SBK_ACT_SWISH:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+            break;
+          case SBK_ACT_GELU:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752440f));
+            break;
+          case SBK_ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
+            break;
+          case SBK_ACT_LEAKY_RELU:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.01f * v[r];
+            break;
+          default: break;
+        }
+        if (seq_len) {  // uniform
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = min(rbase + (r & 3) + 8 * (r >> 2), M - 1);
+            v[r] = (row % rows_per_seq) >= seq_len[row / rows_per_seq] ? 0.0f : v[r] * alpha;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] *= alpha;
+        }
+        if (interior) {
+          if (gR) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += gR[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * ldr + col];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gC[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * ldc + col] = v[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            if (col_ok && row < M) {
+              if (gR) v[r] += gR[(size_t)row * ldr + col];
+              gC[(size_t)row * ldc + col] = v[r];
+            }
+          }
+        }
+      }
+    }
+  };
+  int* ticket = reinterpret_cast<int*>(lds + 2 * STAGE);
+  // a K range [kt_lo, kt_hi) of `tile` is complete in acc
+  auto finish = [&](int tile, int kt_lo, int kt_hi) SBK_INLINE_LAMBDA {
+    bool store = true;
+    if (kt_lo != 0 || kt_hi != KT) {  // partial: publish the slab, take a ticket; the last ticket sums the tile's slabs
+      const int p_first = owner((tile - tb) * KT), p_last = owner((tile - tb + 1) * KT - 1);
+      const int nseg = p_last - p_first + 1;
+      float4* mine = reinterpret_cast<float4*>(slabs + (size_t)(2 * p + (kt_lo == 0 ? 1 : 0)) * (128 * 128));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4)
+            mine[((wave * 4 + i * 2 + j) * 4 + r4) * 64 + lane] =
+                make_float4(acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]);
+      sbk::vm_drain();
+      __syncthreads();
+      if (tid == 0) {
+        sbk::release_agent();
+        *ticket = sbk::atomic_add_agent(cnt + tile, 1);
+      }
+      __syncthreads();
+      store = sbk::uniform(*ticket) == nseg - 1;
+      __syncthreads();  // (the ticket word is rewritten by the next partial tile)
+      if (store) {
+        if (tid == 0) sbk::acquire_agent();
+        __syncthreads();
+        zero();
+        for (int sgm = 0; sgm < nseg; ++sgm) {  // segment order = K order: the sum does not depend on who arrived last
+          const float4* src =
+              reinterpret_cast<const float4*>(slabs + (size_t)(2 * (x * W + p_first + sgm) + (sgm == 0 ? 1 : 0)) * (128 * 128));
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 v = src[((wave * 4 + i * 2 + j) * 4 + r4) * 64 + lane];
+                acc[i][j][4 * r4] += v.x;
+                acc[i][j][4 * r4 + 1] += v.y;
+                acc[i][j][4 * r4 + 2] += v.z;
+                acc[i][j][4 * r4 + 3] += v.w;
+              }
+        }
+        if (tid == 0) sbk::atomic_store_agent(cnt + tile, 0);  // re-armed for the next launch on this stream
+      }
+    }
+    if (store) epilogue(tile);
+  };
+
+  int sidx = 0, tile, lo, hi, stage = 0;
+  seg_get(0, tile, lo, hi);
+  int kt = lo;
+  setup(tile);
+  issue(kt, 0);
+  zero();
+  sbk::vm_drain();
+  __syncthreads();
+  for (;;) {
+    const bool seg_ends = kt + 1 == hi;
+    const bool has_next = !seg_ends || sidx + 1 < nseg_wg;
+    int ntile = tile, nlo = lo, nhi = hi, nkt = kt + 1;
+    if (seg_ends && has_next) {
+      seg_get(sidx + 1, ntile, nlo, nhi);
+      nkt = nlo;
+    }
+    if (has_next) {  // the next unit's panels fly while this one is multiplied
+      if (seg_ends) setup(ntile);
+      if (!noload) issue(nkt, stage ^ 1);
+    }
+    compute(stage);
+    sbk::vm_drain();   // this wave's share of the next panels has landed ...
+    __syncthreads();   // ... and everybody's; every wave is done reading `stage`
+    if (seg_ends) {
+      finish(tile, lo, hi);
+      zero();
+    }
+    if (!has_next) break;
+    if (seg_ends) {
+      ++sidx;
+      tile = ntile;
+      lo = nlo;
+      hi = nhi;
+    }
+    kt = nkt;
+    stage ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Skinny GEMM for the decoder steps (M = beams x utterances, a few hundred rows).
 // With so few rows an LDS-tiled workgroup grid cannot fill 256 CUs, and the
 // weights (L2/MALL resident) dominate traffic.  Here a workgroup owns one
@@ -912,6 +1221,7 @@ int g_gemm_tile = 0;   // tuning knob (key 6) for the large-M path: 0 = 128x128,
                        // 2 = 128x256 (8 waves), 3 = 256x128 (4 waves of 128x64), 4 = 128x128 with 64-deep K tiles
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
+int sk_route(int M, int N, int K);  // workgroups of the persistent kernel for this shape (0: tile-grid / register-operand paths)
 // Internal C++ entry shared with the fused pipelines (decoder step, encoder).
 // Skinny path: M <= 512 rows, K a multiple of 64, 16-byte aligned rows.  `ws` (optional) holds the
 // split-K partials: SK * M * N floats.
@@ -923,7 +1233,8 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   //  M=1280 N=1536 41.6 -> 27.6 us, M=640 N=5000 63 -> 46 us; a long K still needs the split of the skinny path)
   const bool big_short = !g_skinny_reach && (long)M * N >= 1900000 && K <= 1024;  // (K = 768: the TransformerLM scorer's projections)
   const bool skinny_ok = !big_short && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < (g_skinny_reach ? 2048 : 256)) && M <= (g_skinny_reach ? 8192 : 4096) && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
-  if (!skinny_ok || g_skinny_off) return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
+  if (!skinny_ok || g_skinny_off || (aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && sk_route(M, N, K) > 0))
+    return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
   GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
   // (K = 768, the TransformerLM scorer's projections: 2-way split, 34.4 -> 24.6 us at 1280 rows; K = 512: no gain)
   const int short_sk = K < 2048 && (long)M * N < 1900000 ? (g_tiled_splitk_short ? (K >= 512 ? g_tiled_splitk_short : 0) : (K >= 768 && M >= 1024 ? 2 : 0)) : 0;
@@ -1007,6 +1318,106 @@ int gemm_ln_nt(const float* A, int lda, const float* Wf, int ldw, const float* b
   return launch_status("gemm_skinny_ln");
 }
 
+// ---- stream-K launch: per-stream workspace (slabs + tile tickets), allocated on first use and kept
+int g_sk_mode = 1;        // tuning knob (key 18): 0 = tile-grid kernels only, 1 = routed by shape (sk_route), 2 = always (tests), 3 = always from 8 tiles on (A/B)
+int g_sk_grid = 0;        // tuning knob (key 19): workgroups of a stream-K launch (0 = two per CU)
+int g_sk_noload = 0;      // measurement knob (key 22)
+int g_sk_stagger = 1;     // tuning knob (key 23): upper half of each XCD's workgroups runs its tail share first
+int g_sk_min_units = 4;   // tuning knob (key 21): fewer units per workgroup than this shrinks the grid
+namespace {
+constexpr int kSkMaxGrid = 512, kSkMaxTiles = 1 << 16;
+int sk_cus();
+}
+// Workgroups of the persistent kernel for this shape, 0 = the tile-grid kernels.  Measured on MI355X (tools/microbench.py
+// --sk, profiles/r03_gemm_persistent_sweep.log): the persistent kernel wins once every workgroup gets about a tile's
+// worth of units (T >= W per XCD keeps the leftover share small); two workgroups per CU from ~500 tiles on, one below;
+// narrow short-K shapes (N <= 512, K <= 512: four column tiles, 16 K steps per tile -- the epilogue and the partial
+// tiles weigh most there) stay on the tile grid until ~1500 tiles.
+int sk_route(int M, int N, int K) {
+  if (!g_sk_mode || K % 32 != 0 || K < 64) return 0;
+  const long T = (long)cdiv(M, 128) * cdiv(N, 128), U = T * (K / 32);
+  const int cus = sk_cus();
+  int G = g_sk_grid;
+  if (g_sk_mode == 1) {
+    if (M < 2048) return 0;  // decode-step shapes keep their own paths
+    const bool narrow_short = N <= 512 && K <= 512;
+    if (narrow_short ? T < 6L * cus : U < 16L * cus) return 0;
+    if (!G) G = U >= 32L * cus ? 2 * cus : cus;
+  } else {
+    if (g_sk_mode == 3 && T < 8) return 0;
+    if (!G) G = 2 * cus;
+    if (U / g_sk_min_units < G) G = (int)(U / g_sk_min_units);  // short launches: fewer, longer ranges
+  }
+  if (G > kSkMaxGrid) G = kSkMaxGrid;
+  return G >= 8 ? (G / 8) * 8 : 8;  // W workgroups on each of the 8 XCDs
+}
+namespace {
+struct SkWorkspace {
+  float* slabs;
+  int* cnt;
+};
+std::mutex g_sk_mu;
+std::map<hipStream_t, SkWorkspace> g_sk_ws;
+int g_sk_cus = 0;
+
+// the stream's workspace; false when it does not exist yet and cannot be created now (the stream is capturing)
+bool sk_workspace(hipStream_t st, SkWorkspace* out) {
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  auto it = g_sk_ws.find(st);
+  if (it != g_sk_ws.end()) {
+    *out = it->second;
+    return true;
+  }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+  SkWorkspace w{nullptr, nullptr};
+  if (hipMalloc(reinterpret_cast<void**>(&w.slabs), (size_t)2 * kSkMaxGrid * 128 * 128 * sizeof(float)) != hipSuccess) return false;
+  if (hipMalloc(reinterpret_cast<void**>(&w.cnt), (size_t)kSkMaxTiles * sizeof(int)) != hipSuccess) {
+    (void)hipFree(w.slabs);
+    return false;
+  }
+  // tickets start at zero (ordered before the first launch on this stream) and every launch leaves them at zero
+  if (hipMemsetAsync(w.cnt, 0, (size_t)kSkMaxTiles * sizeof(int), st) != hipSuccess) return false;
+  g_sk_ws[st] = w;
+  *out = w;
+  return true;
+}
+
+int sk_cus() {
+  if (!g_sk_cus) {
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    g_sk_cus = cus > 0 ? cus : 256;
+  }
+  return g_sk_cus;
+}
+
+int launch_sk(const GemmArgs& g, int G, hipStream_t st) {
+  SkArgs s;
+  s.g = g;
+  s.tiles_n = cdiv(g.N, 128);
+  s.tiles = cdiv(g.M, 128) * s.tiles_n;
+  s.KT = g.K / 32;
+  if (s.tiles > kSkMaxTiles || (long)s.tiles * s.KT > (1L << 30)) return -1;
+  SkWorkspace w;
+  if (!sk_workspace(st, &w)) return -1;
+  s.slabs = w.slabs;
+  s.cnt = w.cnt;
+  s.stagger = g_sk_stagger;
+  s.noload = g_sk_noload;
+  const size_t lds = (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float);
+  static bool once = false;
+  if (!once) {
+    (void)SBK_ALLOW_DYN_LDS(gemm_nt_sk_kernel, lds);
+    once = true;
+  }
+  ProfScope prof("gemm_nt_persistent", 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N), st);
+  SBK_LAUNCH(gemm_nt_sk_kernel, dim3((unsigned)G), dim3(256), lds, st, s);
+  return launch_status("sbk_gemm_nt_f32 (stream-K)");
+}
+}  // namespace
+
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st) {
   if (M == 0 || N == 0) return 0;
@@ -1015,6 +1426,13 @@ int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
   // Tile choice: keep >= ~1 workgroup per CU where the problem allows it.
   const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
   const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
+  if (vec) {
+    const int G = sk_route(M, N, K);
+    if (G > 0) {
+      const int rc = launch_sk(g, G, st);
+      if (rc != -1) return rc;  // -1: no workspace for this stream (first use inside a graph capture)
+    }
+  }
   const bool big = tiles128 >= 768 || (g_gemm_tile & 16);  // +16: take the variant at any size (tests)
   if (big && (g_gemm_tile & 15) == 1) return launch_gemm<256, 128, 32, 64, 64>(g, vec, st);
   if (big && (g_gemm_tile & 15) == 2) return launch_gemm<128, 256, 32, 64, 64>(g, vec, st);
@@ -1110,6 +1528,11 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 14) sbk::g_tiled_splitk = value;
   if (key == 15) sbk::g_tiled_splitk_short = value;
   if (key == 13) sbk::g_self_group_off = value;
+  if (key == 18) sbk::g_sk_mode = value;
+  if (key == 19) sbk::g_sk_grid = value;
+  if (key == 21) sbk::g_sk_min_units = value > 0 ? value : 1;
+  if (key == 22) sbk::g_sk_noload = value;
+  if (key == 23) sbk::g_sk_stagger = value;
 }
 
 

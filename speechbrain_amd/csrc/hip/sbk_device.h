@@ -86,6 +86,46 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+
+// ---- direct global -> LDS copies and inter-workgroup hand-offs (MI355X_MICROARCH.md, "Workgroup dispatch ...")
+// 16 bytes per lane from `src` (per-lane global address) to `lds_wave_base + lane*16` (the LDS destination of an
+// LDS-DMA is wave-uniform base + lane*size: global_load_lds_dwordx4).  Asynchronous: counted on vmcnt; the data is
+// ordered for a ds_read only by the issuing wave's s_waitcnt vmcnt + a barrier the reader has passed.
+__device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
+  // Issued from inline asm on purpose: hipcc orders every ds_read behind a builtin LDS-DMA it cannot disambiguate
+  // (s_waitcnt vmcnt(0) in front of the first operand fetch of each K tile, which serialises the load with the MFMAs
+  // it is meant to overlap).  An asm LDS-DMA is outside the compiler's counter bookkeeping: the caller waits
+  // (vm_drain) and barriers before the data is read.  M0 (LDS base of the DMA) is saved and restored.
+  const unsigned dst = __builtin_amdgcn_readfirstlane(
+      (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)lds_wave_base);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(dst)
+      : "memory");
+}
+// a value the caller knows to be the same in every lane, moved to a scalar register (uniform branches, scalar address math)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// every outstanding vector-memory operation of this wave has completed (inline asm: the compiler cannot drop it)
+__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// publish this workgroup's earlier plain stores to every CU of the device (one lane, after a __syncthreads())
+__device__ __forceinline__ void release_agent() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// drop this CU's stale L1 lines before reading what another workgroup published (one lane, then __syncthreads())
+__device__ __forceinline__ void acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ int atomic_add_agent(int* p, int v) {
+  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void atomic_store_agent(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int atomic_load_agent(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
@@ -100,6 +140,8 @@ __device__ __forceinline__ float wave_max(float v) {
 }  // namespace sbk
 
 // Dynamic LDS window of the launching workgroup.
+// lambdas of a kernel body must be inlined (a called lambda takes its captures through scratch memory)
+#define SBK_INLINE_LAMBDA __attribute__((always_inline))
 #define SBK_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 
 // Raise a kernel's dynamic-LDS window above the 64 KiB default (gfx950 has 160 KiB per CU).

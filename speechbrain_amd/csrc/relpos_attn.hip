@@ -875,7 +875,7 @@ int launch_flash(const AttnArgs& a, hipStream_t st) {
     }
   }
   if constexpr (!ROPE) {
-    if (sbk::g_relpos_flash_t) {  // knob 17: transposed scores, position term through a 64-row LDS ring (not yet measured)
+    if (sbk::g_relpos_flash_t) {  // default: transposed scores, position term through a 64-row LDS ring (knob 17 = 0: LDS-tile kernel)
       SBK_LAUNCH((relpos_flash_t_kernel<DH>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
       return sbk::launch_status("sbk_relpos_attention_f32");
     }
@@ -920,7 +920,8 @@ int launch_attn_pf(const AttnArgs& a, hipStream_t st) {
 }  // namespace
 
 namespace sbk {
-int g_relpos_flash_t = 0;  // tuning knob (key 17): 1 = RelPosMHAXL through the transposed-score flash kernel
+int g_relpos_flash_t = 1;  // tuning knob (key 17): 1 (default since round 3) = RelPosMHAXL through the transposed-score flash
+                           // kernel; 0 = the LDS-tile flash kernel (kept for A/B and as the second implementation in tests)
 int g_rope_flash_lds = 0;  // tuning knob (key 16): 1 = RoPE / plain attention through the LDS-tile flash kernel (round-2 first half)
 int g_attn_prefetch = 0;  // tuning knob (sbk_prof_set_knob key 3): phase 1 prefetches the next key tile's operands
 

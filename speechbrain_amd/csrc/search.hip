@@ -15,6 +15,51 @@
 #include "common.h"
 #include "internal.h"
 
+namespace {
+// Stop-rule polling without a pipeline bubble.  Every `check_every` steps the search enqueues a 4-byte device->host
+// copy of its "finished" counter plus an event and goes on enqueuing steps; it reads a copy back once its event has
+// completed.  The host never waits for the NEWEST copy (that would drain the stream: a bubble of one launch chain per
+// poll, round 2's behaviour) -- only for the one issued two polls earlier, which bounds how far the host runs ahead of
+// the device (otherwise it would enqueue every step before the first copy lands and an early stop would save
+// nothing).  A search therefore runs at most ~3 poll intervals past its stop point; running past it cannot change the
+// result (finished lists accept nothing more / outputs are EOS-latched).  One ring per host thread.
+struct AsyncPoll {
+  static constexpr int kRing = 4;
+  int32_t* host = nullptr;  // pinned
+  hipEvent_t ev[kRing] = {};
+  int issued = 0;
+  bool ok = false;
+  bool begin() {
+    if (!ok) {
+      if (hipHostMalloc(reinterpret_cast<void**>(&host), kRing * sizeof(int32_t), 0) != hipSuccess) return false;
+      for (int i = 0; i < kRing; ++i)
+        if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+      ok = true;
+    }
+    for (int j = issued > kRing ? issued - kRing : 0; j < issued; ++j) (void)hipEventSynchronize(ev[j % kRing]);  // a previous search's copies
+    issued = 0;
+    return true;
+  }
+  // 1: the counter has reached `target`; 0: go on; -1: error
+  int poll(const int32_t* counter_dev, int target, hipStream_t st) {
+    const int k = issued % kRing;
+    if (hipMemcpyAsync(host + k, counter_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipEventRecord(ev[k], st) != hipSuccess)
+      return -1;
+    ++issued;
+    if (issued >= 3) {  // bounded run-ahead
+      const int j = (issued - 3) % kRing;
+      if (hipEventSynchronize(ev[j]) != hipSuccess) return -1;
+      if (host[j] >= target) return 1;
+    }
+    for (int q = issued >= 2 ? issued - 2 : 0; q < issued; ++q)
+      if (hipEventQuery(ev[q % kRing]) == hipSuccess && host[q % kRing] >= target) return 1;
+    return 0;
+  }
+};
+thread_local AsyncPoll g_poll;
+}  // namespace
+
 namespace sbk {
 // decoder.hip / ctc_prefix.hip
 int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,
@@ -1083,12 +1128,10 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
     }
     return 0;
   };
+  const bool polling = host_flag && cfg->check_every > 0 && g_poll.begin();
   auto poll_full = [&](int steps_done) -> int {  // 1: every utterance has its beam of finished hypotheses
-    if (!(host_flag && cfg->check_every > 0 && (steps_done % cfg->check_every == 0) && steps_done < cfg->max_steps)) return 0;
-    if (hipMemcpyAsync(host_flag, bb.s.n_full, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-      return -1;
-    return *host_flag >= B ? 1 : 0;
+    if (!(polling && (steps_done % cfg->check_every == 0) && steps_done < cfg->max_steps)) return 0;
+    return g_poll.poll(bb.s.n_full, B, st);
   };
 
   int cur = 0, steps = 0;
@@ -1288,15 +1331,16 @@ extern "C" int sbk_greedy_search_f32(const sbk_decoder_weights* W, const float* 
   SBK_HIP(hipMemsetAsync(out_tokens, 0, (size_t)B * L * sizeof(int32_t), st));
   SBK_HIP(hipMemsetAsync(out_scores, 0, (size_t)B * L * sizeof(float), st));
   int k = 0;
+  const bool polling = host_flag && check_every > 0 && g_poll.begin();
   for (int step = min_steps; step < max_steps; ++step, ++k) {  // positions count from 0 (seq2seq.py:227)
     SBK_TRY(decoder_step(W, d, tok, kv_slot, enc_len, k, B, B, T, 1, L, true, st));
     SBK_LAUNCH(greedy_pick_kernel, dim3(B), dim3(256), 0, st, (const float*)d.logits, tok, ended, out_tokens,
                out_scores, n_ended, W->vocab, k, L, eos, (const float*)nullptr, (const float*)nullptr);
     SBK_TRY(sbk::launch_status("greedy_pick"));
-    if (host_flag && check_every > 0 && ((k + 1) % check_every == 0)) {
-      SBK_HIP(hipMemcpyAsync(host_flag, n_ended, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      SBK_HIP(hipStreamSynchronize(st));
-      if (*host_flag >= B) {
+    if (polling && ((k + 1) % check_every == 0)) {
+      const int r = g_poll.poll(n_ended, B, st);
+      if (r < 0) return sbk::fail(1, "greedy_search: stop-rule poll failed");
+      if (r == 1) {
         ++k;
         break;
       }
@@ -1362,6 +1406,7 @@ extern "C" int sbk_prompted_greedy_search_f32(const sbk_decoder_weights* W, cons
   SBK_LAUNCH(gather_col_kernel, dim3(sbk::cdiv(B, 256)), dim3(256), 0, st, prompt, tok, B, P, P - 1);
   SBK_TRY(sbk::launch_status("prompt"));
   int k = 0;
+  const bool polling = host_flag && check_every > 0 && g_poll.begin();
   for (; k < max_new; ++k) {
     SBK_TRY(decoder_step(W, d, tok, kv_slot, enc_len, P - 1 + k, B, B, T, 1, L, true, st));
     if (k == 0 && out_probe && probe_pos == P - 1)
@@ -1369,10 +1414,10 @@ extern "C" int sbk_prompted_greedy_search_f32(const sbk_decoder_weights* W, cons
     SBK_LAUNCH(greedy_pick_kernel, dim3(B), dim3(256), 0, st, (const float*)d.logits, tok, ended, out_tokens, out_scores,
                n_ended, W->vocab, k, max_new, eos, logit_bias, k == 0 ? first_bias : (const float*)nullptr);
     SBK_TRY(sbk::launch_status("greedy_pick"));
-    if (host_flag && check_every > 0 && ((k + 1) % check_every == 0)) {
-      SBK_HIP(hipMemcpyAsync(host_flag, n_ended, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      SBK_HIP(hipStreamSynchronize(st));
-      if (*host_flag >= B) {
+    if (polling && ((k + 1) % check_every == 0)) {
+      const int r = g_poll.poll(n_ended, B, st);
+      if (r < 0) return sbk::fail(1, "greedy_search: stop-rule poll failed");
+      if (r == 1) {
         ++k;
         break;
       }

@@ -10,6 +10,7 @@ independent), so the results are identical to sequential ``transcribe_batch`` ca
 """
 import copy
 import queue
+import threading
 from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -42,6 +43,7 @@ class ConcurrentTranscriber:
             self.dec_streams = [torch.cuda.Stream(self.device, priority=-1) if (prioritise_search and self.n > 1) else None
                                 for _ in range(self.n)]
         self.pool = ThreadPoolExecutor(self.n)
+        self._take_lock = threading.Lock()
 
     def _one(self, slot: int, wavs, wav_lens, prepare: Optional[Callable], ready: Optional[Callable] = None):
         searcher = self.searchers[slot]
@@ -112,12 +114,16 @@ class ConcurrentTranscriber:
         out = []
 
         def take():
+            # the whole group under one lock: groups are the same runs of the queue order however the workers
+            # interleave, so a grouped search sees the same rows (-> the same kernels, bit-identical results) in
+            # every run of the same job, with one worker or with eight
             ks = []
-            while len(ks) < self.group:
-                try:
-                    ks.append(todo.get_nowait())
-                except queue.Empty:
-                    break
+            with self._take_lock:
+                while len(ks) < self.group:
+                    try:
+                        ks.append(todo.get_nowait())
+                    except queue.Empty:
+                        break
             return ks
 
         def run(ks):

@@ -11,6 +11,7 @@ import contextlib
 import ctypes
 import os
 import threading
+import weakref
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_void_p
 from typing import Optional
 
@@ -74,6 +75,8 @@ def _declare(lib):
         "sbk_prof_report": ([ctypes.c_char_p, ctypes.c_size_t], ctypes.c_size_t),
         "sbk_prof_ctc_psi_repeat_f32": ([p, p, p, p, p, i, i, i, i, i, i, POINTER(c_float), p], c_int),
         "sbk_prof_set_knob": ([i, i], None),
+        "sbk_prof_mfma_peak_f32": ([p, i, i, i, POINTER(c_float), p], c_int),
+        "sbk_prof_stream_f32": ([p, p, ctypes.c_long, i, i, POINTER(c_float), p], c_int),
         "sbk_prof_gemm_repeat_f32": ([p, p, p, i, i, i, p, ctypes.c_size_t, i, POINTER(c_float), p], c_int),
         "sbk_pcm16_to_f32": ([p, p, ctypes.c_long, i, p], c_int),
         "sbk_fbank_f32": ([p, p, p, POINTER(c_int32), i, p, p, p, p, p, i, i, i, i, i, i, f, f, p, p, f, p], c_int),
@@ -244,24 +247,37 @@ def gemm_nt_rows(a_flat: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor
     return out
 
 
-_BF16_WEIGHTS = {}  # (data_ptr, _version, shape) -> bf16 copy of a weight matrix (converted once)
+_BF16_WEIGHTS = {}  # id(weight tensor) -> (weakref to it, _version, bf16 copy): converted once per parameter
+_BF16_LOCK = threading.Lock()
 
 
 def bf16_weight(w: torch.Tensor) -> torch.Tensor:
-    """The bf16 image of a weight matrix for sbk_gemm_nt_bf16, cached until the parameter is replaced or updated."""
-    key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device))
-    hit = _BF16_WEIGHTS.get(key)
-    if hit is None:
-        lib = load()
-        w2 = w.detach().contiguous()
-        _dev_ok(w2)
-        _f32(w2)
-        out = torch.empty(w2.shape, dtype=torch.int16, device=w.device)
-        _chk(lib.sbk_f32_to_bf16(_p(w2), _p(out), w2.numel(), _stream(w2)), "sbk_f32_to_bf16")
-        if len(_BF16_WEIGHTS) > 4096:
-            _BF16_WEIGHTS.clear()
-        hit = _BF16_WEIGHTS[key] = out
-    return hit
+    """The bf16 image of a weight matrix for sbk_gemm_nt_bf16, cached for the lifetime of THAT tensor object: the entry
+    holds a weak reference to its source and is used only while ``ref() is w`` and the version counter is unchanged
+    (a freed model's addresses are commonly handed to the next model of the same shapes by the caching allocator, and
+    load_state_dict leaves ``_version`` alike -- a (data_ptr, version, shape) key would then serve the OLD model's
+    weights).  Entries die with their tensor (weakref callback); insert / evict under a lock (worker threads)."""
+    key = id(w)
+    with _BF16_LOCK:
+        hit = _BF16_WEIGHTS.get(key)
+        if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].device == w.device:
+            return hit[2]
+    lib = load()
+    w2 = w.detach().contiguous()
+    _dev_ok(w2)
+    _f32(w2)
+    out = torch.empty(w2.shape, dtype=torch.int16, device=w.device)
+    _chk(lib.sbk_f32_to_bf16(_p(w2), _p(out), w2.numel(), _stream(w2)), "sbk_f32_to_bf16")
+
+    def _drop(_ref, key=key):
+        with _BF16_LOCK:
+            cur = _BF16_WEIGHTS.get(key)
+            if cur is not None and cur[0] is _ref:
+                del _BF16_WEIGHTS[key]
+
+    with _BF16_LOCK:
+        _BF16_WEIGHTS[key] = (weakref.ref(w, _drop), w._version, out)
+    return out
 
 
 def gemm_nt_bf16(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, seq_len=None,

@@ -31,10 +31,10 @@ def _oracle_cfg(size):
     return fc, mc
 
 
-@pytest.mark.parametrize("size,B,sec", [("S", 4, 10.0), ("S", 32, 10.0), ("L", 2, 6.0)])
+@pytest.mark.parametrize("size,B,sec", [("S", 4, 10.0), ("S", 32, 10.0), ("L", 2, 6.0), ("L", 2, 22.0)])
 def test_encoder_vs_oracle(size, B, sec):
     """configs[1] (Conformer-S, 32 x 10 s -- BASELINE.json's exact shape -- and a 4-utterance cut of it) and
-    Conformer-L encoders: Fbank within 1e-3 dB,
+    Conformer-L encoders (6 s, and 22 s = T' 551: the headline's utterance lengths): Fbank within 1e-3 dB,
     encoder output within 2e-4 absolute (fp32; oracle self-noise is 2e-6)."""
     from speechbrain_amd.inference.builders import flat_state_dict
 
@@ -325,3 +325,117 @@ def test_conformer_l_unscaled_weights_token_equality_where_margin_allows():
                 skipped += 1
     assert worst <= 1e-4, worst
     assert checked >= 10, (checked, skipped)  # the margin rule must not make the test vacuous
+
+
+def _headline_job(durations, seed):
+    """Zero-padded batch of utterances of the given durations (s) + relative lengths, like the bench's batches."""
+    g = torch.Generator().manual_seed(seed)
+    n = int(max(durations) * 16000)
+    wav = torch.zeros(len(durations), n)
+    for i, d in enumerate(durations):
+        wav[i, : int(d * 16000)] = 0.1 * torch.randn(int(d * 16000), generator=g)
+    return wav, torch.tensor([int(d * 16000) / n for d in durations])
+
+
+def test_headline_shape_beam10_ctc_vs_oracle_end_to_end():
+    """the headline's own shape -- Conformer-L, beam 10 + CTC 0.4, utterances of 16-24 s (T' 401-601,
+    64-96 decoding steps at 4 tokens/s, the bench's rule) -- END TO END (waveform -> token ids: Fbank, CNN, encoder,
+    CTC emissions, grouped-search kernels at their long-memory sizes) against the oracle (waveform -> O.encode_batch ->
+    O.beam_search).  Peaked output heads (x8) so that fp32 reassociation cannot flip a near-tie:
+    token ids exact, scores within 2e-3."""
+    from speechbrain_amd.inference.builders import flat_state_dict
+
+    asr = _asr("L", beam_size=10, ctc_weight=0.4)
+    fc, mc = _oracle_cfg("L")
+    with torch.no_grad():
+        asr.mods.seq_lin.w.weight.mul_(8.0)
+        asr.mods.ctc_lin.w.weight.mul_(8.0)
+    wav, lens = _headline_job([24.0, 16.0], seed=41)
+    T = ((1 + wav.shape[1] // 160 - 1) // 2 + 1 - 1) // 2 + 1
+    steps = int(round(4.0 * wav.shape[1] / 16000.0))
+    assert T >= 590 and steps >= 90
+    ratio = (steps + 0.5) / T
+    asr.mods.decoder.max_decode_ratio = ratio
+    sd = flat_state_dict(asr)
+    _, toks = asr.transcribe_batch(wav, lens)
+    enc_ref = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
+    hyps_ref, _, scores_ref, _ = O.beam_search(enc_ref, lens, sd, mc, O.SearchCfg(beam=10, ctc_weight=0.4, max_decode_ratio=ratio))
+    assert [list(t) for t in toks] == [list(h) for h in hyps_ref]
+    assert min(len(t) for t in toks) >= 20  # a degenerate (empty) hypothesis would make the comparison vacuous
+    hyps, _, scores, _ = asr.mods.decoder(asr.encode_batch(wav, lens), lens.cuda())
+    assert float((scores.cpu() - scores_ref).abs().max()) <= 2e-3
+
+
+def test_long_utterance_unscaled_weights_margin_rule():
+    """VERDICT r2 1(a), second half: UNSCALED random-init Conformer-L at a headline length (20 s, T' 501, 80 steps).
+    The HIP greedy search picks a token per step from its own (KV-cached, long-memory) decoder; the oracle, teacher-
+    forced on the same prefix, gives the full-prefix log-probs.  Wherever the oracle's own top-1 / top-2 margin exceeds
+    5e-4 the HIP token must be the oracle's arg-max; the picked token's log-prob agrees within 2e-4 at every step."""
+    from speechbrain_amd.inference.builders import flat_state_dict
+
+    asr = _asr("L", greedy=True)
+    fc, mc = _oracle_cfg("L")
+    wav, lens = _headline_job([20.0], seed=43)
+    sd = flat_state_dict(asr)
+    enc_ref = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
+    enc = asr.encode_batch(wav, lens)
+    assert float((enc.cpu() - enc_ref).abs().max()) <= 2e-4
+    T = enc_ref.shape[1]
+    steps = 80
+    asr.mods.decoder.max_decode_ratio = (steps + 0.5) / T
+    hyps, _, scores, _ = asr.mods.decoder(enc, lens.cuda())
+    hyp = hyps[0]
+    prefix = torch.tensor([[1] + hyp[:-1]])
+    dec = O.decode(prefix, enc_ref, torch.round(T * lens).int(), sd, mc, "Transformer.")
+    lp = torch.log_softmax(torch.nn.functional.linear(dec, sd["seq_lin.w.weight"], sd["seq_lin.w.bias"]), -1)[0]
+    checked, worst = 0, 0.0
+    for t, tok in enumerate(hyp[: lp.shape[0]]):
+        top2 = lp[t].topk(2).values
+        worst = max(worst, abs(float(scores[0, 0, t]) - float(lp[t, tok])))
+        if float(top2[0] - top2[1]) > 5e-4:
+            assert tok == int(lp[t].argmax()), (t, tok, int(lp[t].argmax()))
+            checked += 1
+    assert worst <= 2e-4, worst
+    assert checked >= 40, checked
+
+
+def test_headline_mode_grouped_concurrent_equals_sequential_conformer_l():
+    """the bench's execution mode at full model size -- ConcurrentTranscriber(streams=8, group=4):
+    eight host threads, each encoding four batches and decoding them in ONE grouped search on a high-priority stream --
+    on 16 Conformer-L batches of mixed size and length (5-26 s, decode steps = 4 tokens/s x padded seconds, int16 PCM
+    from pinned host memory as the bench ships it) gives exactly the token ids of sequential, ungrouped
+    transcribe_batch calls (peaked heads: the grouped search runs the decode GEMMs at other row counts, i.e. through
+    other kernels with another summation order), and the same ids again on a second run (no cross-stream races)."""
+    from speechbrain_amd import native
+    from speechbrain_amd.inference.streams import ConcurrentTranscriber
+
+    asr = _asr("L", beam_size=10, ctc_weight=0.4)
+    asr.mods.decoder.check_every = 0
+    with torch.no_grad():
+        asr.mods.seq_lin.w.weight.mul_(8.0)
+        asr.mods.ctc_lin.w.weight.mul_(8.0)
+    g = torch.Generator().manual_seed(57)
+    shapes = [(32, 5.0), (32, 7.5), (24, 9.0), (32, 11.0), (16, 13.0), (32, 15.0), (8, 17.0), (32, 19.0),
+              (24, 21.0), (12, 23.0), (32, 26.0), (32, 6.0), (20, 8.0), (32, 10.0), (4, 12.0), (32, 14.0)]
+    batches = []
+    for B, sec in shapes:
+        n = int(sec * 16000)
+        pcm = (0.1 * torch.randn(B, n, generator=g) * 32768.0).round().clamp(-32768, 32767).to(torch.int16)
+        lens = torch.linspace(0.7, 1.0, B)
+        for i in range(B):
+            pcm[i, int(lens[i] * n):] = 0
+        batches.append((pcm.pin_memory(), lens))
+
+    def fix_len(searcher, wavs):
+        T = ((1 + wavs.shape[1] // 160 - 1) // 2 + 1 - 1) // 2 + 1
+        searcher.max_decode_ratio = (int(round(4.0 * wavs.shape[1] / 16000.0)) + 0.5) / T
+
+    ref = []
+    for w, l in batches:
+        fix_len(asr.mods.decoder, w)
+        ref.append(asr.transcribe_batch(native.pcm16_to_f32(w.cuda()), l.cuda())[1])
+    assert all(len(t) > 0 for r in ref for t in r)
+    ct = ConcurrentTranscriber(asr, streams=8, group=4)
+    got = ct.transcribe_batches(batches, prepare=fix_len)
+    assert got == ref
+    assert ct.transcribe_batches(batches, prepare=fix_len) == ref

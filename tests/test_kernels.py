@@ -205,12 +205,10 @@ def test_relpos_attention(backend, B, T, H, Dh, lens, prefetch):
                                                  (2, 133, 2, 64, [133, 20], (0, -1)), (1, 100, 1, 16, None, (0, -1)),
                                                  (2, 251, 2, 64, [251, 129], (16, 2)), (1, 97, 2, 32, [97], (8, -1))])
 def test_relpos_transposed_flash_variant(backend, B, T, H, Dh, lens, chunk):
-    """csrc/relpos_attn.hip relpos_flash_t_kernel (tuning knob 17; prepared, not yet the default): transposed scores with
-    the position term gathered from a 64-row LDS ring must reproduce the default flash kernel and the oracle --
-    key padding, Dynamic Chunk masks, ragged tiles, every instantiated head size."""
+    """csrc/relpos_attn.hip relpos_flash_t_kernel (the default since round 3; knob 17 = 0 selects the LDS-tile flash
+    kernel it replaced): transposed scores with the position term gathered from a 64-row LDS ring must reproduce the
+    LDS-tile kernel and the oracle -- key padding, Dynamic Chunk masks, ragged tiles, every instantiated head size."""
     nat, dev = backend
-    if dev.type == "cuda":
-        pytest.skip("variant validated on the CPU emulator only so far (not measured on the GPU yet)")
     d = H * Dh
     g = torch.Generator().manual_seed(T + Dh)
     x = torch.randn(B, T, d, generator=g)
@@ -224,12 +222,12 @@ def test_relpos_transposed_flash_variant(backend, B, T, H, Dh, lens, chunk):
     P = nat.gemm_nt(pos.to(dev), sd["linear_pos.weight"].to(dev))
     args = (qkv, P, sd["pos_bias_u"].reshape(-1).contiguous().to(dev), sd["pos_bias_v"].reshape(-1).contiguous().to(dev),
             None if kl is None else kl.to(dev), H, 1 / math.sqrt(d), False, chunk[0], chunk[1])
-    base, _ = nat.relpos_attention(*args)
-    nat.load().sbk_prof_set_knob(17, 1)
+    nat.load().sbk_prof_set_knob(17, 0)
     try:
-        new, _ = nat.relpos_attention(*args)
+        base, _ = nat.relpos_attention(*args)
     finally:
-        nat.load().sbk_prof_set_knob(17, 0)
+        nat.load().sbk_prof_set_knob(17, 1)
+    new, _ = nat.relpos_attention(*args)
     assert _md(new, base.cpu()) <= 5e-6
     if chunk[0] == 0:
         kp = None if kl is None else ~O.length_to_mask(kl, T)
@@ -498,3 +496,47 @@ def test_gemm_bf16_operands(backend, M, N, K):
     full = r + 0.5 * F.silu(a.double() @ w.double().t() + b).float()
     assert _md(out, full) <= 2.0 ** -7 * scale
     assert nat.bf16_weight(w.to(dev)) is nat.bf16_weight(w.to(dev)) or True  # (cache keyed by data_ptr: new tensor, new entry)
+
+
+@pytest.mark.parametrize("M,N,K,grid", [(700, 300, 96, 0), (1000, 130, 64, 24), (257, 128, 640, 8), (520, 260, 128, 40), (2100, 300, 64, 16),
+                                        (4100, 512, 512, 0), (130, 1030, 2048, 0)])
+def test_gemm_stream_k(backend, M, N, K, grid):
+    """The stream-K LDS-DMA kernel (the encoder's contractions), forced at small ragged shapes: tiles cut by the unit
+    ranges of several workgroups (partial slabs + last-arriver reduction), whole tiles, grids that do not divide the
+    work; bias / activation / scaled residual / row mask; run-to-run bit-identical."""
+    nat, dev = backend
+    if dev.type == "cpu" and M * N * K > 6e7:
+        pytest.skip("large shape: GPU only")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01
+    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    scale = float((a.abs() @ w.abs().t()).max())
+    lib = nat.load()
+    lib.sbk_prof_set_knob(18, 2)
+    lib.sbk_prof_set_knob(19, grid)
+    lib.sbk_prof_set_knob(21, 1)
+    try:
+        ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+        out = nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5)
+        ref = r + 0.5 * F.silu(a.double() @ w.double().t() + b).float()
+        assert _md(out, ref) <= 2e-6 * scale + 1e-5
+        for _ in range(3 if dev.type == "cuda" else 1):  # tickets re-armed, same sum order whoever arrives last
+            assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
+        out = nat.gemm_nt(ad, wd, None, None, act=nat.ACT_GELU)
+        assert _md(out, F.gelu(a.double() @ w.double().t()).float()) <= 2e-6 * scale + 1e-5
+        rows = 50 if M % 50 == 0 else M // 7
+        nseq = M // rows
+        lens = torch.tensor([(i * 13) % (rows + 1) for i in range(nseq)], dtype=torch.int32)
+        out = nat.gemm_nt(ad[: nseq * rows], wd, bd, rd[: nseq * rows], seq_len=lens.to(dev), rows_per_seq=rows)
+        keep = (torch.arange(rows)[None, :] < lens[:, None]).reshape(-1, 1)
+        ref = r[: nseq * rows] + torch.where(keep, (a[: nseq * rows].double() @ w.double().t() + b).float(), torch.zeros(()))
+        assert _md(out, ref) <= 2e-6 * scale + 1e-5
+        x = ad[:, :K].clone()
+        if N == K:  # in-place residual
+            out = nat.gemm_nt(x, wd, None, x)
+            assert _md(out, a + (a.double() @ w.double().t()).float()) <= 2e-6 * scale + 1e-5
+    finally:
+        lib.sbk_prof_set_knob(18, 1)
+        lib.sbk_prof_set_knob(19, 0)
+        lib.sbk_prof_set_knob(21, 4)

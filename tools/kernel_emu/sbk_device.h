@@ -44,6 +44,13 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 enum { hipMemcpyDeviceToDevice = 3, hipMemcpyDeviceToHost = 2, hipMemcpyHostToDevice = 1 };
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : 2; }
+static inline hipError_t hipFree(void* p) { free(p); return 0; }
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
+static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return 0; }
+enum { hipDeviceAttributeMultiprocessorCount = 1 };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 16; return 0; }
 typedef void* hipEvent_t;
 // hipGraph: not emulated -- capture reports failure, the callers fall back to plain launches
 typedef void* hipGraph_t;
@@ -61,8 +68,11 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*)1; return 0; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (void*)1; return 0; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return 0; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? 0 : 2; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return 0; }
 
 #define __global__
@@ -229,6 +239,18 @@ static inline float group_sum(float v) {  // same lane selects as the DPP sequen
   if (G >= 16) v += shfl_idx_(v, (lane & ~15) | (15 - (lane & 15)));
   return v;
 }
+
+// LDS-DMA / inter-workgroup hand-off vocabulary (host semantics: workgroups run on OS threads of one process)
+static inline void glds16(const float* src, float* lds_wave_base) {
+  memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * sbk_emu::cur().lane, src, 16);
+}
+static inline int uniform(int v) { return v; }
+static inline void vm_drain() {}
+static inline void release_agent() { __atomic_thread_fence(__ATOMIC_RELEASE); }
+static inline void acquire_agent() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+static inline int atomic_add_agent(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
+static inline void atomic_store_agent(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+static inline int atomic_load_agent(const int* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 static inline float wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
   return v;
@@ -239,6 +261,8 @@ static inline float wave_max(float v) {
 }
 }  // namespace sbk
 
+// lambdas of a kernel body must be inlined (a called lambda takes its captures through scratch memory)
+#define SBK_INLINE_LAMBDA
 #define SBK_DYN_LDS(type, name) type* name = reinterpret_cast<type*>(sbk_emu::dyn_lds())
 #define SBK_ALLOW_DYN_LDS(kernel, bytes) ((void)(bytes), 0)
 #define SBK_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \

@@ -142,7 +142,7 @@ if __name__ == "__main__":
                 outs[tag] = nat.relpos_attention(qkv, P, u, v, None, H, 1 / math.sqrt(d))[0]
                 t = timeit(lambda: nat.relpos_attention(qkv, P, u, v, None, H, 1 / math.sqrt(d)), n=20, warm=3)
                 res[tag] = f"{t:8.1f} us {fl / t / 1e6:6.1f} TF/s"
-            nat.load().sbk_prof_set_knob(17, 0)
+            nat.load().sbk_prof_set_knob(17, 1)
             print(f"relpos attention B={B} T={T} H={H}:", res, "max|diff|", float((outs["lds-tile"] - outs["transposed"]).abs().max()), flush=True)
         sys.exit(0)
     if "--attn2" in sys.argv:  # RoPE / plain attention: LDS-tile flash kernel vs transposed-score kernel vs its bf16 variant
@@ -188,6 +188,96 @@ if __name__ == "__main__":
                 for (N, K) in [(512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512)]:
                     gemm_case(M, N, K, 8)
         nat.load().sbk_prof_set_knob(10, 0)
+        sys.exit(0)
+    if "--stream" in sys.argv:  # hand-written float4 streaming kernels of the library (sbk_prof_stream_f32): the HBM calibration
+        for mb in (64, 256, 1024, 4096):
+            n = mb * 1024 * 1024 // 4
+            x = torch.empty(n, device=dev).normal_()
+            y = torch.empty_like(x)
+            us = ctypes.c_float(0)
+            res = {}
+            for mode, tag, nbytes in ((0, "copy", 8.0 * n), (1, "read", 4.0 * n)):
+                rc = nat.load().sbk_prof_stream_f32(nat._p(x), nat._p(y), n, mode, 20, ctypes.byref(us), nat._stream(x))
+                assert rc == 0
+                res[tag] = f"{us.value:9.1f} us {nbytes / us.value / 1e6:6.2f} TB/s"
+            print(f"stream {mb} MiB:", res, flush=True)
+        sys.exit(0)
+    if "--enc-layer" in sys.argv:  # the Conformer-L encoder in situ (32 utterances x 5 / 10 / 20 / 30 s): per-kernel event times by GEMM routing
+        from speechbrain_amd.inference.builders import build_asr
+        asr = build_asr("L", vocab=5000, seed=0, device="cuda:0")
+        variants = (("tile grid", {18: 0}), ("persistent G=512", {18: 3, 19: 512}), ("persistent G=256", {18: 3, 19: 256}), ("routed (default)", {18: 1, 19: 0}))
+        for sec in (5, 10, 20, 30):
+            wav = (0.1 * torch.randn(32, sec * 16000, generator=torch.Generator().manual_seed(sec))).to(dev)
+            lens = torch.ones(32, device=dev)
+            for tag, knobs in variants:
+                for k, v in knobs.items():
+                    nat.load().sbk_prof_set_knob(k, v)
+                with torch.no_grad():
+                    for _ in range(2):
+                        asr.encode_batch(wav, lens)
+                    torch.cuda.synchronize()
+                    nat.prof_reset(); nat.prof_enable(True)
+                    for _ in range(3):
+                        asr.encode_batch(wav, lens)
+                    torch.cuda.synchronize()
+                    nat.prof_enable(False)
+                rep = nat.prof_report(); nat.prof_reset()
+                gem = {k: v for k, v in rep.items() if k.startswith("gemm")}
+                tot = sum(v["ms"] for v in rep.values())
+                gms, gfl = sum(v["ms"] for v in gem.values()), sum(v["flops"] for v in gem.values())
+                print(f"enc 32x{sec}s {tag:18s}: all kernels {tot / 3:8.2f} ms | GEMMs {gms / 3:8.2f} ms {gfl / gms / 1e9:6.1f} TF/s |",
+                      {k: (round(v["ms"] / 3, 2), round(v["flops"] / v["ms"] / 1e9, 1)) for k, v in gem.items()}, flush=True)
+        nat.load().sbk_prof_set_knob(18, 1); nat.load().sbk_prof_set_knob(19, 0)
+        sys.exit(0)
+    if "--mfma-peak" in sys.argv:  # f32 matrix-core ceiling under DVFS (registers only), then the stream-K GEMM with its panel loads off
+        sink = torch.zeros(4096, device=dev)
+        tf = ctypes.c_float(0)
+        for wgs in (256, 512, 1024):
+            for rnd in (0, 1):
+                rc = nat.load().sbk_prof_mfma_peak_f32(nat._p(sink), wgs, 20000, rnd, ctypes.byref(tf), nat._stream(sink))
+                assert rc == 0
+                print(f"mfma peak: {wgs} workgroups x 4 waves, {'random' if rnd else 'zero'} operands: {tf.value:7.1f} TFLOP/s", flush=True)
+        for tag, knobs in (("stream-K", {18: 1, 22: 0}), ("stream-K, panel loads off (ceiling of the LDS/MFMA loop)", {18: 1, 22: 1}),
+                           ("tile grid", {18: 0, 22: 0})):
+            for k, v in knobs.items():
+                nat.load().sbk_prof_set_knob(k, v)
+            print("variant:", tag, flush=True)
+            for (M, N, K) in [(56064, 2048, 512), (56064, 512, 2048), (56064, 512, 512)]:
+                gemm_case(M, N, K, 0, iters=30)
+        nat.load().sbk_prof_set_knob(22, 0)
+        nat.load().sbk_prof_set_knob(18, 1)
+        print("zero-filled operands (DVFS give-back), stream-K then tile grid")
+        for mode in (1, 0):
+            nat.load().sbk_prof_set_knob(18, mode)
+            for (M, N, K) in [(56064, 2048, 512), (56064, 512, 2048)]:
+                a = torch.zeros(M, K, device=dev); w = torch.zeros(N, K, device=dev); out = torch.empty(M, N, device=dev)
+                us = ctypes.c_float(0)
+                rc = nat.load().sbk_prof_gemm_repeat_f32(nat._p(a), nat._p(w), nat._p(out), M, N, K, None, 0, 30, ctypes.byref(us), nat._stream(a))
+                assert rc == 0
+                print(f"gemm zeros M={M} N={N} K={K}: {us.value:8.2f} us  {2.0*M*N*K/us.value/1e6:7.2f} TFLOP/s", flush=True)
+        nat.load().sbk_prof_set_knob(18, 1)
+        sys.exit(0)
+    if "--sk-pmc" in sys.argv:  # short: the two big-GEMM kernels for a counters pass
+        for mode in (1, 0):
+            nat.load().sbk_prof_set_knob(18, mode)
+            for (M, N, K) in [(56064, 2048, 512), (56064, 512, 2048), (12800, 2048, 512)]:
+                gemm_case(M, N, K, 0, iters=5)
+        nat.load().sbk_prof_set_knob(18, 1)
+        sys.exit(0)
+    if "--sk" in sys.argv:  # encoder GEMM shapes of the bench (M = 32 utterances x T' frames): tile grid vs stream-K
+        shapes = [(M, N, K) for M in (4032, 8000, 12800, 16000, 24032, 56064)
+                  for (N, K) in ((512, 512), (1536, 512), (2048, 512), (512, 2048), (1024, 512))]
+        for tag, knobs in (("tile grid", {18: 0}), ("persistent G=512 stagger", {18: 1, 19: 512, 23: 1}),
+                           ("persistent G=512 no stagger", {18: 1, 19: 512, 23: 0}), ("persistent G=256", {18: 1, 19: 256, 23: 1})):
+            for k, v in knobs.items():
+                nat.load().sbk_prof_set_knob(k, v)
+            print("variant:", tag, flush=True)
+            for (M, N, K) in shapes:
+                gemm_case(M, N, K, 0, iters=50)
+            nat.load().sbk_prof_set_knob(19, 0)
+            nat.load().sbk_prof_set_knob(21, 4)
+            nat.load().sbk_prof_set_knob(23, 1)
+        nat.load().sbk_prof_set_knob(18, 1)
         sys.exit(0)
     if "--copy" in sys.argv:  # what a plain streaming kernel reaches on this box (calibrates the HBM rooflines)
         for mb in (256, 1024, 4096):
