@@ -546,6 +546,7 @@ def main():
         # the same batches, grouped as in the timed region, on ONE worker stream (every launch between two events)
         one = ConcurrentTranscriber(asr, streams=1, prioritise_search=False, group=auto(args.max_batch)[1])
         one.group_encoder = args.group_encoder
+        one.plan_workers = auto(args.max_batch)[0]  # the same groups as the eight workers formed
         seq_out = one.transcribe_batches([(t[1], t[2]) for t in local_batches], prepare=fixed_decode_length)
         one.pool.shutdown(wait=True)
         # parity of the headline's execution mode: the same batches, in the same groups, one after the other on ONE

@@ -732,6 +732,146 @@ __global__ void __launch_bounds__(256) cross_attn_stream_kernel(CrossAttnArgs a,
 }
 
 // out[i, h*DH + c] = sum_s e^{m_s - M} o_s[c] / sum_s e^{m_s - M} l_s
+// ---- cross-attention step on LDS-DMA tiles and the matrix cores (head_dim 64, d <= 640, beam <= 16, row-major K/V).
+// A workgroup = one utterance x one run of frames, ALL heads (wave w = head w): the K|V rows of 16 frames (16 x 8d
+// bytes, contiguous in HBM: one fully sequential stream per workgroup instead of 256-byte pieces 8d bytes apart) go
+// straight into a double-buffered LDS image by global_load_lds_dwordx4 while the previous tile is consumed -- no
+// staging registers, 16 x 8d bytes in flight per CU at all times.  Per tile and head, transposed scores
+// S^T[frame][beam] = K Q^T on v_mfma_f32_16x16x4_f32 (beams padded to 16): in the result layout a lane owns one beam
+// and four frames, so the online-softmax statistics need two cross-lane steps, the probabilities ARE the B operand of
+// O^T[channel][beam] += V^T P^T (k slot g of MFMA i <-> frame 4g+i, V^T read in that order), and the running rescale
+// is one scalar per lane.  LDS image: the 16-byte slot s of frame row R lands in slot s ^ R ^ ((R & 4) << 1) within
+// its 256-byte head segment (swizzle on the global SOURCE address, the image of an LDS-DMA being lane-linear): the
+// ds_read_b128 of the K operand and the ds_read_b32 of the V operand are both conflict-free (checked exhaustively,
+// DESIGN.md).  Partial (context, max, sum) per run of frames -> cross_merge_kernel, as for the other variants.
+// FR = frames per LDS tile: 16, or 8 (half of the MFMA rows idle, half the LDS: two workgroups per CU whose load
+// and compute phases interleave).
+template <int FR>
+__global__ void __launch_bounds__(1024) cross_attn_dma_kernel(CrossAttnArgs a, int chunk) {
+  SBK_DYN_LDS(float, lds);  // [2 stages][FR frames][2d]
+  const int ROW = 2 * a.d, TILE = FR * ROW, H = a.H;
+  const int tid = threadIdx.x, lane = tid & 63, h = sbk::uniform(tid >> 6);  // wave = head
+  const int split = blockIdx.x, b = blockIdx.y;
+  const int nq = a.beam, col = lane & 15, g = lane >> 4;
+  const int klen = min(max(a.enc_len[b], 1), a.T);
+  const int t0 = split * chunk, t1 = min(klen, t0 + chunk);
+  float* pp = a.part ? a.part + ((((size_t)b * H + h) * a.NS + split) * nq + col) * (64 + 2) : nullptr;
+  if (t0 >= t1) {  // (uniform per workgroup) nothing of this run is inside the utterance: an empty partial
+    if (a.NS > 1 && g == 0 && col < nq) {
+      pp[64] = -INFINITY;
+      pp[65] = 0.0f;
+    }
+    return;
+  }
+  const float* kvb = a.kv + (size_t)b * a.T * ROW;
+  float qf[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    qf[i] = col < nq ? a.q[((size_t)b * nq + col) * a.d + h * 64 + 16 * g + i] * a.scale : 0.0f;
+
+  // loader: the H waves share the 16 frame rows of a tile; one wave-instruction moves 1 KB = 4 head segments of a row
+  const int per_row = ROW / 256;             // wave-instructions per frame row
+  const int pieces = FR * per_row;           // per tile
+  const int seg = lane >> 4, slot = lane & 15;
+  auto issue = [&](int tile, int stage) SBK_INLINE_LAMBDA {
+    for (int pc = h; pc < pieces; pc += H) {
+      const int R = pc / per_row, qd = pc - R * per_row;
+      const int frame = min(t0 + tile * FR + R, klen - 1);  // rows past the run re-read a valid row (masked below)
+      const int fsw = R ^ ((R & 4) << 1);
+      sbk::glds16(kvb + (size_t)frame * ROW + (qd * 4 + seg) * 64 + ((slot ^ fsw) & 15) * 4,
+                  lds + stage * TILE + R * ROW + qd * 256);
+    }
+  };
+  sbk::f32x4 o[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[ct][r] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+  const int ntiles = (t1 - t0 + FR - 1) / FR;
+  const int krow = col & (FR - 1);  // (FR = 8: MFMA rows 8-15 repeat rows 0-7 and are masked out of the softmax)
+  const int ksw = krow ^ ((krow & 4) << 1);  // swizzle of this lane's K row
+  issue(0, 0);
+  sbk::vm_drain();
+  __syncthreads();
+  int stage = 0;
+  for (int k = 0; k < ntiles; ++k) {
+    if (k + 1 < ntiles) issue(k + 1, stage ^ 1);
+    const float* Kt = lds + stage * TILE + h * 64;
+    const float* Vt = Kt + a.d;
+    float4 kq[4];
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) kq[jq] = *reinterpret_cast<const float4*>(Kt + krow * ROW + (((4 * g + jq) ^ ksw) & 15) * 4);
+    sbk::f32x4 sc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc[r] = 0.0f;
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {
+      sc = sbk::mfma_16x16x4(kq[jq].x, qf[4 * jq], sc);
+      sc = sbk::mfma_16x16x4(kq[jq].y, qf[4 * jq + 1], sc);
+      sc = sbk::mfma_16x16x4(kq[jq].z, qf[4 * jq + 2], sc);
+      sc = sbk::mfma_16x16x4(kq[jq].w, qf[4 * jq + 3], sc);
+    }
+    // sc[r] = score of (frame t0 + FR k + 4g + r, beam col)
+    const int fb = t0 + k * FR + 4 * g;
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (fb + r >= t1 || 4 * g + r >= FR) sc[r] = -INFINITY;
+      mt = fmaxf(mt, sc[r]);
+    }
+    mt = fmaxf(mt, sbk::shfl_xor(mt, 16));
+    mt = fmaxf(mt, sbk::shfl_xor(mt, 32));
+    const float m_new = fmaxf(m_run, mt);  // finite: frame t0 + 16k is inside the run
+    const float alpha = expf(m_run - m_new);
+    float p[4], ps = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = expf(sc[r] - m_new);
+      ps += p[r];
+    }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[ct][r] *= alpha;
+    // O^T[channel 16ct + 4g' + r][beam] += V^T P^T: k slot g of MFMA i <-> frame row 4g + i
+    const int vsw = (g & 1) << 3;  // (R & 4) << 1 of R = 4g + i (mod FR); the R part of the swizzle is XORed below
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int R = (4 * g + i) & (FR - 1);
+        const float va = Vt[R * ROW + ((((4 * ct + (col >> 2)) ^ R ^ vsw) & 15) << 2) + (col & 3)];
+        o[ct] = sbk::mfma_16x16x4(va, p[i], o[ct]);
+      }
+    sbk::vm_drain();   // this wave's pieces of the next tile have landed ...
+    __syncthreads();   // ... and everybody's; every wave is done with `stage`
+    stage ^= 1;
+  }
+  float l_tot = l_run + sbk::shfl_xor(l_run, 16);
+  l_tot += sbk::shfl_xor(l_tot, 32);
+  if (col >= nq) return;
+  if (a.NS == 1) {
+    float* op = a.out + ((size_t)b * nq + col) * a.d + h * 64;
+    const float inv = 1.0f / l_tot;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) op[16 * ct + 4 * g + r] = o[ct][r] * inv;
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pp[16 * ct + 4 * g + r] = o[ct][r];
+    if (g == 0) {
+      pp[64] = m_run;
+      pp[65] = l_tot;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) cross_merge_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int H, int NS, int beam, int DH, int d) {
   const int i = blockIdx.x;  // hypothesis
@@ -771,6 +911,42 @@ int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
   const int qtiles = (a.beam + kQT - 1) / kQT;
   sbk::ProfScope prof("cross_attn_step", 4.0 * a.B * a.beam * (double)a.T * a.d, 8.0 * a.B * (double)a.T * a.d, st);
   if constexpr (DH == 64) {
+    // default: LDS-DMA tiles + matrix cores (all heads of an utterance per workgroup, sequential HBM stream)
+    // Measured (tools/decode_probe.py, profiles/r03_cross_attention_dma_sweep.log): with four recipe-sized batches per
+    // search (128 utterances x 430 frames) one workgroup per CU streaming ~14 tiles runs the step in 64 us against 92
+    // for the frame-per-thread kernel (3.5 vs 2.45 TB/s incl. the merge); more, shorter workgroups or 8-frame tiles
+    // lose (73 / 92 / 78-95 us), and for a single 32-utterance batch the frame-per-thread kernel wins (38 vs 52 us):
+    // the default (7) takes the LDS-DMA kernel from ~40 K memory frames per search on.
+    const bool dma_auto = sbk::g_cross_rows == 7 && (long)a.B * a.T >= 40000;
+    if ((sbk::g_cross_rows == 5 || sbk::g_cross_rows == 6 || dma_auto) && !a.head_major && a.d <= 640 && a.H * 64 == a.d &&
+        a.beam <= 16 && sbk::aligned16(a.kv) && (a.part || a.T <= 8)) {
+      CrossAttnArgs c = a;
+      const int FR = sbk::g_cross_rows == 6 ? 8 : 16;
+      const int target = dma_auto ? 256 : (sbk::g_cross_fc256 == 1 ? 256 : (sbk::g_cross_fc256 == 2 ? 1024 : 512));
+      int ns = sbk::cdiv(target, a.B);                          // workgroups over the batch ...
+      if (ns > sbk::cdiv(a.T, FR)) ns = sbk::cdiv(a.T, FR);    // ... of at least one tile
+      if (ns > sbk::cdiv(a.T, 16)) ns = sbk::cdiv(a.T, 16);    // (the partial buffer is sized for 16-frame runs)
+      if (ns < 1) ns = 1;
+      const int chunk = sbk::cdiv(sbk::cdiv(a.T, ns), 16) * 16;
+      c.NS = sbk::cdiv(a.T, chunk);
+      const size_t lds = (size_t)2 * FR * 2 * a.d * sizeof(float);
+      static bool once = false;
+      if (!once) {
+        (void)SBK_ALLOW_DYN_LDS(cross_attn_dma_kernel<16>, 160 * 1024);
+        (void)SBK_ALLOW_DYN_LDS(cross_attn_dma_kernel<8>, 160 * 1024);
+        once = true;
+      }
+      if (FR == 16) {
+        SBK_LAUNCH(cross_attn_dma_kernel<16>, dim3(c.NS, a.B), dim3(64 * a.H), lds, st, c, chunk);
+      } else {
+        SBK_LAUNCH(cross_attn_dma_kernel<8>, dim3(c.NS, a.B), dim3(64 * a.H), lds, st, c, chunk);
+      }
+      int rc5 = sbk::launch_status("cross_attn_step");
+      if (rc5 || c.NS == 1) return rc5;
+      SBK_LAUNCH(cross_merge_kernel, dim3(a.B * a.beam), dim3(256), 0, st, (const float*)c.part, c.out, c.H, c.NS,
+                 c.beam, DH, c.d);
+      return sbk::launch_status("cross_merge");
+    }
     // streaming variant (one wave per run of frames, no LDS): d = 512 with 16-byte aligned rows, row-major K/V
     if ((sbk::g_cross_rows == 3 || sbk::g_cross_rows == 4) && a.d == 512 && !a.head_major && a.part &&
         sbk::aligned16(a.kv) && sbk::aligned16(a.q) && (reinterpret_cast<uintptr_t>(a.part) & 7) == 0) {
@@ -858,7 +1034,9 @@ thread_local int g_step_min_steps = 0;
 // Measured alternatives kept behind sbk_prof_set_knob (Conformer-L, B=64, MI355X; cross_attn_step total per
 // 8 batches): frame-per-thread kernel 247 ms with either layout; row-coalesced kernel 336 ms on [B,T,2d],
 // 306 ms on head-major [B,H,T,2*Dh]; at B=128 the MFMA formulation takes 315 ms vs 303 ms.  The defaults stay 0.
-int g_cross_rows = 0;     // key 4: 0 frame-per-thread kernel, 1 row-coalesced kernel, 2 MFMA kernel (head_dim 64 / 32)
+int g_cross_rows = 7;     // key 4: 7 (default) = LDS-DMA / MFMA kernel for large grouped searches, else frame-per-thread;
+                          // 0 frame-per-thread kernel, 1 row-coalesced kernel, 2 MFMA kernel (head_dim 64 / 32), 5 / 6 = the
+                          // LDS-DMA kernel always (16- / 8-frame tiles)
 int g_kv_head_major = 0;  // key 5: cross K/V stored [B,H,T,2*Dh] instead of [B,T,2d]
 
 int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,

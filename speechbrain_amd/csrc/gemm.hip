@@ -1323,6 +1323,7 @@ int g_sk_mode = 1;        // tuning knob (key 18): 0 = tile-grid kernels only, 1
 int g_sk_grid = 0;        // tuning knob (key 19): workgroups of a stream-K launch (0 = two per CU)
 int g_sk_noload = 0;      // measurement knob (key 22)
 int g_sk_stagger = 1;     // tuning knob (key 23): upper half of each XCD's workgroups runs its tail share first
+int g_sk_min_rows = 2048;  // tuning knob (key 24): fewer rows than this never take the persistent kernel in routed mode
 int g_sk_min_units = 4;   // tuning knob (key 21): fewer units per workgroup than this shrinks the grid
 namespace {
 constexpr int kSkMaxGrid = 512, kSkMaxTiles = 1 << 16;
@@ -1332,16 +1333,17 @@ int sk_cus();
 // --sk, profiles/r03_gemm_persistent_sweep.log): the persistent kernel wins once every workgroup gets about a tile's
 // worth of units (T >= W per XCD keeps the leftover share small); two workgroups per CU from ~500 tiles on, one below;
 // narrow short-K shapes (N <= 512, K <= 512: four column tiles, 16 K steps per tile -- the epilogue and the partial
-// tiles weigh most there) stay on the tile grid until ~1500 tiles.
+// tiles weigh most there) stay on the tile grid below ~400 tiles (in situ -- tools/microbench.py --enc-layer,
+// profiles/r03_encoder_in_situ_gemm_routing.log -- the persistent kernel already wins there from 500 tiles on).
 int sk_route(int M, int N, int K) {
   if (!g_sk_mode || K % 32 != 0 || K < 64) return 0;
   const long T = (long)cdiv(M, 128) * cdiv(N, 128), U = T * (K / 32);
   const int cus = sk_cus();
   int G = g_sk_grid;
   if (g_sk_mode == 1) {
-    if (M < 2048) return 0;  // decode-step shapes keep their own paths
+    if (M < g_sk_min_rows) return 0;  // decode-step shapes keep their own paths
     const bool narrow_short = N <= 512 && K <= 512;
-    if (narrow_short ? T < 6L * cus : U < 16L * cus) return 0;
+    if (narrow_short ? 2 * T < 3L * cus : U < 16L * cus) return 0;
     if (!G) G = U >= 32L * cus ? 2 * cus : cus;
   } else {
     if (g_sk_mode == 3 && T < 8) return 0;
@@ -1533,6 +1535,7 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 21) sbk::g_sk_min_units = value > 0 ? value : 1;
   if (key == 22) sbk::g_sk_noload = value;
   if (key == 23) sbk::g_sk_stagger = value;
+  if (key == 24) sbk::g_sk_min_rows = value;
 }
 
 

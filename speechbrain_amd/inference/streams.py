@@ -44,6 +44,8 @@ class ConcurrentTranscriber:
                                 for _ in range(self.n)]
         self.pool = ThreadPoolExecutor(self.n)
         self._take_lock = threading.Lock()
+        self.balance_tail = True
+        self.plan_workers = self.n  # workers the group sizes are planned for (a one-worker replay of an eight-worker job sets 8)
 
     def _one(self, slot: int, wavs, wav_lens, prepare: Optional[Callable], ready: Optional[Callable] = None):
         searcher = self.searchers[slot]
@@ -119,7 +121,13 @@ class ConcurrentTranscriber:
             # every run of the same job, with one worker or with eight
             ks = []
             with self._take_lock:
-                while len(ks) < self.group:
+                # towards the end of the job the groups shrink so that every worker still gets one (the last round of
+                # an 80-batch job would otherwise keep half of the workers idle); the sizes depend only on the number of
+                # batches left, not on who asks
+                want = self.group
+                if self.balance_tail:
+                    want = max(1, min(self.group, -(-todo.qsize() // self.plan_workers)))
+                while len(ks) < want:
                     try:
                         ks.append(todo.get_nowait())
                     except queue.Empty:

@@ -696,8 +696,14 @@ def _fold_ln(w, b, gamma, beta):
 
 
 def _host_flag(device):
-    t = torch.zeros(1, dtype=torch.int32)
-    return t.pin_memory() if device.type == "cuda" else t
+    """A host int32 the C ABI takes as its "stop-rule polling allowed" argument (the library polls through its own
+    pinned ring, csrc/search.hip AsyncPoll).  One per host thread, allocated once: pinning memory per search call costs
+    a driver round trip per call."""
+    t = getattr(_tls, "host_flag", None)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32)
+        _tls.host_flag = t
+    return t
 
 
 def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=None, ctc_b=None, utt_min_steps=None,

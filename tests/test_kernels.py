@@ -540,3 +540,57 @@ def test_gemm_stream_k(backend, M, N, K, grid):
         lib.sbk_prof_set_knob(18, 1)
         lib.sbk_prof_set_knob(19, 0)
         lib.sbk_prof_set_knob(21, 4)
+
+
+@pytest.mark.parametrize("d_model,nhead,B,T,beam_rows", [(128, 2, 3, 150, 4), (256, 4, 2, 75, 10), (128, 2, 1, 20, 1)])
+def test_cross_attention_lds_dma_variant(backend, d_model, nhead, B, T, beam_rows):
+    """csrc/decoder.hip cross_attn_dma_kernel (head_dim 64: LDS-DMA tiles of 16 frames, transposed scores on the matrix
+    cores, online softmax over the runs of the memory) through the KV-cached decoder: teacher-forced decoder outputs
+    must match the frame-per-thread kernel (knob 4 = 0) and the oracle's full-prefix decode -- ragged memory lengths
+    (partial last tile, empty runs past a short utterance), several hypotheses per utterance, a 1-frame-tile memory."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_modules, flat_state_dict
+
+    mods = build_modules(dict(d_model=d_model, nhead=nhead, d_ffn=256, n_enc=1, n_dec=2, n_fft=400, win_length=25), vocab=50, seed=3)
+    tr, seq = mods["Transformer"].to(dev).eval(), mods["seq_lin"].to(dev).eval()
+    sd = {"Transformer." + k: v.detach().cpu() for k, v in tr.state_dict().items()}
+    cfg = O.ModelCfg(d_model=d_model, nhead=nhead, num_encoder_layers=1, num_decoder_layers=2, d_ffn=256, vocab=50)
+    gen = torch.Generator().manual_seed(T)
+    n = B * beam_rows
+    enc_u = torch.randn(B, T, d_model, generator=gen) * 1.5
+    lens_u = torch.tensor([T] + [max(3, (T * (k + 2)) // (k + 4)) for k in range(B - 1)], dtype=torch.int32)
+    # decoder_prefix runs one hypothesis per memory: repeat each utterance for its `beam_rows` hypotheses
+    enc, enc_len = enc_u.repeat_interleave(beam_rows, 0), lens_u.repeat_interleave(beam_rows, 0)
+    tgt = torch.randint(0, 50, (n, 6), generator=gen)
+    ref = O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")
+    h = nat.DecoderHandle(tr, seq)
+    outs = {}
+    for knob in (0, 5, 6):
+        nat.load().sbk_prof_set_knob(4, knob)
+        try:
+            outs[knob] = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev)).cpu()
+        finally:
+            nat.load().sbk_prof_set_knob(4, 7)
+    assert float((outs[0] - ref).abs().max()) <= 5e-5
+    assert float((outs[5] - ref).abs().max()) <= 5e-5
+    assert float((outs[6] - ref).abs().max()) <= 5e-5
+    if beam_rows == 1:
+        return
+    # the search itself (beam_rows hypotheses per utterance share a memory) vs the oracle's search
+    from speechbrain_amd.decoders import S2STransformerBeamSearcher
+
+    sd["seq_lin.w.weight"], sd["seq_lin.w.bias"] = seq.w.weight.detach().cpu() * 4.0, seq.w.bias.detach().cpu()
+    with torch.no_grad():
+        seq.w.weight.mul_(4.0)
+    wl = lens_u.float() / T
+    ratio = 7.5 / T
+    hyps_ref, _, sc_ref, _ = O.beam_search(enc_u, wl, sd, cfg, O.SearchCfg(beam=beam_rows, ctc_weight=0.0, max_decode_ratio=ratio))
+    bs = S2STransformerBeamSearcher(modules=[tr, seq], bos_index=1, eos_index=2, min_decode_ratio=0.0, max_decode_ratio=ratio,
+                                    beam_size=beam_rows, using_eos_threshold=False, length_normalization=True)
+    nat.load().sbk_prof_set_knob(4, 5)
+    try:
+        hyps, _, sc, _ = bs(enc_u.to(dev), wl.to(dev))
+    finally:
+        nat.load().sbk_prof_set_knob(4, 7)
+    assert hyps == hyps_ref
+    assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4

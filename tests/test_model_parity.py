@@ -343,7 +343,7 @@ def test_cross_attention_kernel_variants(backend, nhead, rows, head_major):
         pred = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev))
         hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))  # several beams per (utterance, head) workgroup
     finally:
-        nat.load().sbk_prof_set_knob(4, 0)
+        nat.load().sbk_prof_set_knob(4, 7)
         nat.load().sbk_prof_set_knob(5, 0)
         nat.load().sbk_prof_set_knob(8, 0)
     assert float((pred.cpu() - O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")).abs().max()) <= 5e-5
@@ -723,7 +723,7 @@ def test_cross_attention_streaming_variant_matches_default(backend, variant):
     try:
         alt = dec(enc, lens.to(dev))
     finally:
-        nat.load().sbk_prof_set_knob(4, 0)
+        nat.load().sbk_prof_set_knob(4, 7)
     assert alt[0] == base[0]
     assert float((alt[2].cpu() - base[2].cpu()).abs().max()) <= 2e-5
     assert float((alt[3].cpu() - base[3].cpu()).abs().max()) <= 2e-5

@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 
-def main(path, t_lo_frac=0.0):
+def main(path, t_lo_frac=0.0, t_hi_frac=1.0):
     rows = []
     with open(path, newline="") as f:
         rd = csv.DictReader(f)
@@ -20,6 +20,8 @@ def main(path, t_lo_frac=0.0):
         print(json.dumps({"error": "no kernel rows", "path": path}))
         return
     rows.sort()
+    if t_lo_frac > 0.0 or t_hi_frac < 1.0:  # the kernels between two percentiles of the launch order: the steady state of a timed region
+        rows = rows[int(len(rows) * t_lo_frac): max(int(len(rows) * t_hi_frac), int(len(rows) * t_lo_frac) + 1)]
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     # sweep: time-weighted histogram of the number of kernels in flight
     ev = []
@@ -55,4 +57,4 @@ def main(path, t_lo_frac=0.0):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], *(float(v) for v in sys.argv[2:4]))
