@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SBK_ABI_VERSION 3
+#define SBK_ABI_VERSION 4
 
 typedef void* sbk_stream_t; /* hipStream_t */
 
@@ -325,6 +325,24 @@ typedef struct {
                              k > 0: CTC is a PARTIAL scorer (ScorerBuilder(partial_scorers=[ctc]), :1287-1300): only the
                              k = int(beam * scorer_beam_scale) best tokens of each hypothesis -- ranked after the eos
                              rules and the full scorers -- and <eos> get a CTC score, the rest get minus_inf */
+  /* ---- S2SWhisperBeamSearcher (seq2seq.py:1937-2206) on the same search (ABI 4).  All optional (zero = off):
+   * prompt [B, prompt_len] DEVICE int32: the initial tokens of every utterance (prefix / prompt / sot / language /
+   *   task, :2069-2102; the per-utterance language token allowed, :2113-2119).  Positions 0 .. prompt_len-2 only fill
+   *   the KV cache of every hypothesis (reset_mem), the last prompt token is the first decoder input (= bos) and
+   *   search step s runs at decoder position prompt_len-1+s; prompt_len-1+max_steps <= max_len.  Not with an LM scorer,
+   *   graph_mode or the grouped search.
+   * logit_bias / first_bias [V] DEVICE: additive 0 / -inf masks on the logits of every step / of step 0 only
+   *   (suppress_tokens :2185-2187, suppress_blank :2176-2183).
+   * temperature_post: 1 = log_softmax(logits) / temperature (:2189-2192) instead of log_softmax(logits / temperature).
+   * probe: out_probe [B] DEVICE = softmax(logits at prompt position probe_pos)[probe_token] -- no_speech_probs
+   *   (:2161-2170); out_probe NULL = off. */
+  const int32_t* prompt;
+  int32_t prompt_len;
+  int32_t temperature_post;
+  const float* logit_bias;
+  const float* first_bias;
+  int32_t probe_pos, probe_token;
+  float* out_probe;
 } sbk_search_config;
 
 /* S2STransformerBeamSearcher.forward (seq2seq.py:1632-1723, :1853-1934) with an optional full

@@ -910,7 +910,45 @@ def golden_whisper_model():
           "no_speech_probs", searcher.no_speech_probs)
     assert margin > 2e-3, "pick another seed: an arg-max of the golden sits within fp32 noise"
     assert min(len(h) for h in hyps) < steps, "no hypothesis ends through EOS: raise EOS_GAIN"
+    # beam search: the REFERENCE's S2SWhisperBeamSearcher on the same model object (beam 4; temperature 1 and 0.8 --
+    # the log-probs are divided by it AFTER the softmax --; a prompt; return_topk)
+    from speechbrain.decoders.seq2seq import S2SWhisperBeamSearcher
+
+    beam_out = {}
+    for tag, kw in (("t10", dict(temperature=1.0)), ("t08", dict(temperature=0.8)),
+                    ("prompt", dict(temperature=1.0, prompt=[30, 31, 32])),
+                    ("min6", dict(temperature=1.0, min_decode_ratio=0.12, length_normalization=False)),
+                    ("top3", dict(temperature=1.0, return_topk=True, topk=3))):
+        base = dict(beam_size=4, min_decode_ratio=0.0, max_decode_ratio=1.0, using_eos_threshold=False,
+                    length_normalization=True)
+        base.update(kw)
+        bs = S2SWhisperBeamSearcher(module=[model], **base)
+        # (reset_mem writes the language tokens into a [batch x beam, prompt] memory, seq2seq.py:2104-2121: one per hypothesis)
+        bs.set_lang_tokens(torch.tensor([ids["<|en|>"], ids["<|fr|>"], 6]).repeat_interleave(4))
+        with torch.no_grad():
+            h, bl, bsc, blp = bs(enc, torch.ones(3))
+        if kw.get("return_topk"):
+            beam_out[f"beam_{tag}_hyps"] = h.numpy()
+            beam_out[f"beam_{tag}_lens"] = bl.numpy()
+        else:
+            width = max(len(x) for x in h)
+            beam_out[f"beam_{tag}_hyps"] = np.array([x + [-1] * (width - len(x)) for x in h])
+            beam_out[f"beam_{tag}_lens"] = bl.numpy()
+            beam_out[f"beam_{tag}_init"] = np.array(bs.initial_tokens)
+        beam_out[f"beam_{tag}_scores"] = bsc.numpy()
+        beam_out[f"beam_{tag}_no_speech"] = np.array(bs.no_speech_probs)
+        print("  beam", tag, "hyps", h if not kw.get("return_topk") else h[:, 0].tolist(), "scores", bsc.reshape(-1)[:4].tolist())
+    # language identification: Whisper.detect_language (whisper.py:617-665) bound to the same object
+    model.all_language_tokens, model.all_language_codes = (4, 5, 6, 7), ("en", "fr", "de", "es")
+    model.tokenizer.language = "en"
+    model.model.encoder = hf.encoder
+    with torch.no_grad():
+        lang_tokens, lang_probs = Whisper.detect_language(model, mel)
+    print("  detect_language", lang_tokens.tolist(), [max(p_, key=p_.get) for p_ in lang_probs])
+    beam_out["lang_tokens"] = lang_tokens.numpy()
+    beam_out["lang_probs"] = np.array([[p_[c] for c in model.all_language_codes] for p_ in lang_probs])
     np.savez_compressed(os.path.join(OUT, "whisper_model.npz"), wav=wav.numpy(), mel=mel.numpy(), enc=enc.numpy(),
+                        **beam_out,
                         enc_all=enc_all.numpy(), tokens=tokens.numpy(), logits=logits.numpy(),
                         greedy_hyps=np.array([h + [-1] * (steps - len(h)) for h in hyps]), greedy_lens=lens.numpy(),
                         greedy_scores=scores.numpy(), greedy_no_speech=np.array(searcher.no_speech_probs),
@@ -918,6 +956,41 @@ def golden_whisper_model():
                         suppress=np.array(searcher.get_tokens_to_suppress))
     print("  mel", tuple(mel.shape), "enc", tuple(enc.shape), "enc_all", tuple(enc_all.shape), "logits", tuple(logits.shape),
           "|enc| max", float(enc.abs().max()), "|logits| max", float(logits.abs().max()))
+
+
+def golden_whisper_large_shape():
+    """BASELINE.json configs[4] at the large-v3 SHAPE (d 1280, 20 heads, 128 mel bins, 1500 positions, ffn 5120) with a
+    reduced depth (2 encoder layers): the reference wrapper's log-mel + encoder on a 30-second waveform.  The weights
+    are transformers' own random initialisation under torch.manual_seed(21) (157 MB: not committed -- the test rebuilds
+    them from the seed with the same transformers build, and also compares against that model directly); committed are
+    strided samples of the reference wrapper's mel and encoder output."""
+    print("== Whisper large-v3 shape, 2 encoder layers (reference wrapper)")
+    import tempfile
+
+    from transformers import WhisperConfig, WhisperFeatureExtractor
+    from transformers import WhisperModel as HFWhisperModel
+
+    from speechbrain.integrations.huggingface.whisper import Whisper
+
+    cfg = WhisperConfig(vocab_size=51866, num_mel_bins=128, d_model=1280, encoder_layers=2, encoder_attention_heads=20,
+                        encoder_ffn_dim=5120, decoder_layers=1, decoder_attention_heads=20, decoder_ffn_dim=5120,
+                        max_source_positions=1500, max_target_positions=448)
+    torch.manual_seed(21)
+    hf = HFWhisperModel(cfg).eval()
+    with tempfile.TemporaryDirectory() as d:
+        hf.save_pretrained(d, safe_serialization=True)
+        WhisperFeatureExtractor(feature_size=128).save_pretrained(d)
+        ref = Whisper(d, d, encoder_only=True, freeze=True).eval()
+    g = torch.Generator().manual_seed(22)
+    wav = torch.stack([0.1 * torch.randn(480000, generator=g),
+                       torch.cat([0.05 * torch.randn(300000, generator=g), torch.zeros(180000)])])
+    with torch.no_grad():
+        mel = ref._get_mel(wav)
+        enc = ref.forward_encoder(mel)
+    print("  mel", tuple(mel.shape), "enc", tuple(enc.shape), "|enc| max", float(enc.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "whisper_large_shape.npz"), mel_sample=mel[:, ::8, ::50].numpy(),
+                        enc_sample=enc[:, ::25, ::32].numpy(), enc_absmax=float(enc.abs().max()),
+                        first_param_sum=float(hf.encoder.layers[0].fc1.weight.double().sum()))
 
 
 def golden_input_norm():
@@ -945,6 +1018,9 @@ def golden_input_norm():
 
 
 if __name__ == "__main__":
+    if "--whisper-large-only" in sys.argv:
+        golden_whisper_large_shape()
+        sys.exit(0)
     if "--whisper-model-only" in sys.argv:
         golden_whisper_model()
         sys.exit(0)
@@ -996,4 +1072,5 @@ if __name__ == "__main__":
     golden_whisper()
     golden_input_norm()
     golden_whisper_model()
+    golden_whisper_large_shape()
     print("OK")

@@ -1003,26 +1003,30 @@ int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
 
 // ---------------------------------------------------------------- log-softmax over the vocabulary
 // out[i,c] = w * (x[i,c]/temp - logsumexp(x[i,:]/temp));  one workgroup per row.
+// bias / bias2 (optional, [V]): additive masks on the logits (0 or -inf: suppressed tokens come out as -inf)
 __global__ void __launch_bounds__(256) log_softmax_row_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                              int V, float inv_temp, float w) {
+                                                              int V, float inv_temp, float w,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ bias2) {
   __shared__ float red[4];
   const int tid = threadIdx.x;
   const float* xr = x + (size_t)blockIdx.x * V;
   float* orow = out + (size_t)blockIdx.x * V;
   float m = -INFINITY;
-  for (int c = tid; c < V; c += 256) m = fmaxf(m, xr[c] * inv_temp);
+  auto at = [&](int c) SBK_INLINE_LAMBDA { return (xr[c] + (bias ? bias[c] : 0.0f) + (bias2 ? bias2[c] : 0.0f)) * inv_temp; };
+  for (int c = tid; c < V; c += 256) m = fmaxf(m, at(c));
   m = sbk::wave_max(m);
   if ((tid & 63) == 0) red[tid >> 6] = m;
   __syncthreads();
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
   float s = 0.0f;
-  for (int c = tid; c < V; c += 256) s += expf(xr[c] * inv_temp - m);
+  for (int c = tid; c < V; c += 256) s += expf(at(c) - m);
   s = sbk::wave_sum(s);
   if ((tid & 63) == 0) red[tid >> 6] = s;
   __syncthreads();
   const float lse = m + logf((red[0] + red[1]) + (red[2] + red[3]));
-  for (int c = tid; c < V; c += 256) orow[c] = w * (xr[c] * inv_temp - lse);
+  for (int c = tid; c < V; c += 256) orow[c] = w * (at(c) - lse);
 }
 
 }  // namespace
@@ -1103,10 +1107,11 @@ int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, flo
   }
 }
 
-int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st) {
+int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st,
+                     const float* bias, const float* bias2) {
   if (rows == 0) return 0;
   ProfScope prof("log_softmax", 4.0 * rows * V, 8.0 * rows * V, st);
-  SBK_LAUNCH(log_softmax_row_kernel, dim3(rows), dim3(256), 0, st, x, out, V, 1.0f / temperature, weight);
+  SBK_LAUNCH(log_softmax_row_kernel, dim3(rows), dim3(256), 0, st, x, out, V, 1.0f / temperature, weight, bias, bias2);
   return launch_status("log_softmax_rows");
 }
 
@@ -1116,5 +1121,5 @@ extern "C" int sbk_log_softmax_f32(const float* x, float* out, int rows, int V, 
                                    sbk_stream_t stream) {
   if (rows == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(x && out && rows >= 0 && V > 0 && temperature > 0.0f, "log_softmax: bad arguments");
-  return sbk::log_softmax_rows(x, out, rows, V, temperature, weight, sbk::as_stream(stream));
+  return sbk::log_softmax_rows(x, out, rows, V, temperature, weight, sbk::as_stream(stream), nullptr, nullptr);
 }

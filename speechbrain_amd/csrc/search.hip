@@ -71,7 +71,8 @@ int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, flo
                     int d, int H, int beam, hipStream_t st, int head_major);
 int kv_head_major(const float* src, float* dst, int B, int T, int d, int H, hipStream_t st);
 size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam);
-int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st);
+int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st,
+                     const float* bias = nullptr, const float* bias2 = nullptr);
 int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, float* psi_prev, int B, int T, int V,
                 int beam, int blank, hipStream_t st);
 size_t ctc_state_floats(int B, int beam, int T);
@@ -444,6 +445,7 @@ struct BeamState {
   int32_t* fin_len;     // [B][beam]
   float* fin_score;     // [B][beam]
   int32_t* n_full;      // [1] utterances whose finished list is full
+  int pos_off;          // decoder position of search step 0 (prompt length - 1; 0 without a prompt): kv_slot is indexed by position
 };
 
 __global__ void step_inc_kernel(int32_t* step) { step[0] += 1; }
@@ -458,6 +460,25 @@ __global__ void beam_init_kernel(BeamState s, int B, int beam, int bos) {
   if (n >= B * beam) return;
   s.tokens[0][n] = bos;
   s.seq_scores[n] = (n % beam == 0) ? 0.0f : -INFINITY;  // seq2seq.py:880-884
+}
+
+// prompt positions of the ancestry tables: every hypothesis primed its OWN cache rows with the (per-utterance) prompt
+__global__ void kv_prompt_init_kernel(BeamState s, int n, int Lmax, int pos_off) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * pos_off) return;
+  const int h = i / pos_off, p = i % pos_off;
+  s.kv_slot[0][(size_t)h * Lmax + p] = h;
+  s.kv_slot[1][(size_t)h * Lmax + p] = h;
+}
+// col[h] = prompt[h / beam][p]
+__global__ void prompt_col_kernel(const int32_t* __restrict__ prompt, int32_t* __restrict__ col, int n, int beam, int P, int p) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h < n) col[h] = prompt[(size_t)(h / beam) * P + p];
+}
+// out[b] = probe[b * beam]  (the beams of an utterance share the prompt)
+__global__ void probe_pick_kernel(const float* __restrict__ probe, float* __restrict__ out, int B, int beam) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) out[b] = probe[(size_t)b * beam];
 }
 
 __global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const float* __restrict__ am, int cur, int step,
@@ -480,7 +501,7 @@ __global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const flo
       const size_t o = ((size_t)b * beam + j) * Lmax + p;
       s.seq[nxt][o] = p < step ? s.seq[cur][o] : 0;
       s.lp[nxt][o] = p < step ? s.lp[cur][o] : 0.0f;
-      s.kv_slot[nxt][o] = p < step ? s.kv_slot[cur][o] : b * beam + j;
+      s.kv_slot[nxt][o + s.pos_off] = p < step ? s.kv_slot[cur][o + s.pos_off] : b * beam + j;
     }
     if (tid < beam) {
       s.tokens[nxt][b * beam + tid] = s.tokens[cur][b * beam + tid];
@@ -497,11 +518,11 @@ __global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const flo
     if (p < step) {
       s.seq[nxt][o] = s.seq[cur][po];
       s.lp[nxt][o] = s.lp[cur][po];
-      s.kv_slot[nxt][o] = s.kv_slot[cur][po];
+      s.kv_slot[nxt][o + s.pos_off] = s.kv_slot[cur][po + s.pos_off];
     } else {
       s.seq[nxt][o] = tok;
       s.lp[nxt][o] = am[(size_t)pred * V + tok];  // pre-scorer AM log-prob (seq2seq.py:1547,1187-1189)
-      s.kv_slot[nxt][o] = pred;                   // this step's K/V were written at slot = parent index
+      s.kv_slot[nxt][o + s.pos_off] = pred;       // this step's K/V were written at slot = parent index
       s.tokens[nxt][n] = tok;
       s.parent[n] = pred;
     }
@@ -545,7 +566,7 @@ __global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const flo
 // is stripped (:1461 + undo_padding) and the row zero padded; topk > 1 (return_topk): rows keep their
 // last token like the reference's padded topk_hyps tensor.  out_len = token count - 1 either way.
 __global__ void __launch_bounds__(256) beam_finalize_kernel(BeamState s, int cur, int steps_done, int beam, int Lmax,
-                                                            int topk, int32_t* __restrict__ out_tok,
+                                                            int Lout, int topk, int32_t* __restrict__ out_tok,
                                                             int32_t* __restrict__ out_len, float* __restrict__ out_score,
                                                             float* __restrict__ out_lp,
                                                             const int32_t* __restrict__ utt_max,
@@ -595,7 +616,7 @@ __global__ void __launch_bounds__(256) beam_finalize_kernel(BeamState s, int cur
       out_score[row] = e >= 0 ? e_score[e] : 0.0f;
       out_len[row] = len;
     }
-    for (int p = tid; p < Lmax; p += 256) {
+    for (int p = tid; p < Lout; p += 256) {  // Lout = row pitch of the outputs (max_steps); Lmax = pitch of the tables
       int tok = 0;
       float lp = 0.0f;
       if (e >= 0 && p < ntok) {  // log-probs keep the stripped position too, like the reference
@@ -604,8 +625,8 @@ __global__ void __launch_bounds__(256) beam_finalize_kernel(BeamState s, int cur
         tok = e_src[e] < 0 ? s.seq[cur][o] : s.fin_seq[o];
         lp = e_src[e] < 0 ? s.lp[cur][o] : s.fin_lp[o];
       }
-      out_tok[row * Lmax + p] = (topk > 1 ? p < ntok : p < len) ? tok : 0;
-      out_lp[row * Lmax + p] = lp;
+      out_tok[row * Lout + p] = (topk > 1 ? p < ntok : p < len) ? tok : 0;
+      out_lp[row * Lout + p] = lp;
     }
   }
 }
@@ -975,7 +996,7 @@ extern "C" size_t sbk_beam_search_workspace_bytes(const sbk_decoder_weights* W, 
   Carver c{nullptr, 0, true};
   DecoderBufs d;
   BeamBufs bb;
-  const int Lmax = cfg->max_steps > 0 ? cfg->max_steps : 1;
+  const int Lmax = (cfg->max_steps > 0 ? cfg->max_steps : 1) + (cfg->prompt && cfg->prompt_len > 1 ? cfg->prompt_len - 1 : 0);
   carve_decoder(c, d, W, B * cfg->beam, B, T, Lmax);
   carve_beam(c, bb, B, cfg->beam, T, W->vocab, Lmax, cfg->ctc_weight > 0.0f);
   if (cfg->lm && cfg->lm_weight != 0.0f) {
@@ -999,8 +1020,14 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   SBK_REQUIRE(W->seq_w && W->seq_b, "beam_search: seq_lin weights missing");
   SBK_REQUIRE(cfg->beam >= 1 && cfg->beam <= kMaxBeamLarge, "beam_search: beam %d outside [1,%d]", cfg->beam,
               kMaxBeamLarge);
-  SBK_REQUIRE(cfg->max_steps <= W->max_len, "beam_search: %d steps exceed the positional table (%d)", cfg->max_steps,
-              W->max_len);
+  const int pos_off = cfg->prompt && cfg->prompt_len > 1 ? cfg->prompt_len - 1 : 0;  // decoder position of search step 0
+  SBK_REQUIRE(pos_off + cfg->max_steps <= W->max_len, "beam_search: %d prompt + %d steps exceed the positional table (%d)",
+              pos_off, cfg->max_steps, W->max_len);
+  SBK_REQUIRE(!cfg->prompt || (cfg->prompt_len >= 1 && !(cfg->lm && cfg->lm_weight != 0.0f) && !cfg->utt_max_steps &&
+                               !cfg->utt_min_steps),
+              "beam_search: a token prompt excludes the LM scorer and the grouped search");
+  SBK_REQUIRE(!cfg->out_probe || (cfg->probe_pos >= 0 && cfg->probe_pos <= pos_off && cfg->probe_token >= 0 &&
+                                  cfg->probe_token < W->vocab), "beam_search: probe position / token out of range");
   const bool ctc = cfg->ctc_weight > 0.0f;
   const int topk = cfg->topk > 1 ? cfg->topk : 1;
   SBK_REQUIRE(topk <= cfg->beam, "beam_search: topk %d exceeds the beam %d", topk, cfg->beam);
@@ -1011,7 +1038,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   SBK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "beam_search: workspace must be 256-byte aligned");
   hipStream_t st = sbk::as_stream(stream);
   const int beam = cfg->beam, V = W->vocab, n = B * beam, dm = W->d_model;
-  const int Lmax = cfg->max_steps > 0 ? cfg->max_steps : 1;
+  const int Lmax = (cfg->max_steps > 0 ? cfg->max_steps : 1) + pos_off;
   if (steps_run) *steps_run = 0;
   if (B == 0) return 0;
 
@@ -1038,8 +1065,23 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
     SBK_HIP(hipMemsetAsync(bb.phi[1], 0, sbk::ctc_state_floats(B, beam, T) * sizeof(float), st));  // zero table padding
     SBK_TRY(sbk::ctc_prepare(bb.ctc_x, bb.ctc_xb, enc_len, bb.phi[0], bb.psi_prev[0], B, T, V, beam, cfg->blank, st));
   }
+  bb.s.pos_off = pos_off;
   SBK_LAUNCH(beam_init_kernel, dim3(sbk::cdiv(n > B ? n : B, 256)), dim3(256), 0, st, bb.s, B, beam, cfg->bos);
   SBK_TRY(sbk::launch_status("beam_init"));
+  if (pos_off > 0) {  // S2SWhisperBeamSearcher.reset_mem (seq2seq.py:2104-2121): the prompt but its last token primes the KV cache
+    SBK_LAUNCH(kv_prompt_init_kernel, dim3(sbk::cdiv(n * pos_off, 256)), dim3(256), 0, st, bb.s, n, Lmax, pos_off);
+    for (int p = 0; p < pos_off; ++p) {
+      const bool probe = cfg->out_probe && p == cfg->probe_pos;
+      SBK_LAUNCH(prompt_col_kernel, dim3(sbk::cdiv(n, 256)), dim3(256), 0, st, cfg->prompt, bb.s.tokens[1], n, beam, pos_off + 1, p);
+      SBK_TRY(decoder_step(W, d, bb.s.tokens[1], bb.s.kv_slot[0], enc_len, p, n, B, T, beam, Lmax, probe, st));
+      if (probe) {
+        SBK_LAUNCH(softmax_prob_kernel, dim3(n), dim3(256), 0, st, (const float*)d.logits, bb.am_max, W->vocab, cfg->probe_token);
+        SBK_LAUNCH(probe_pick_kernel, dim3(sbk::cdiv(B, 256)), dim3(256), 0, st, (const float*)bb.am_max, cfg->out_probe, B, beam);
+      }
+    }
+    SBK_LAUNCH(prompt_col_kernel, dim3(sbk::cdiv(n, 256)), dim3(256), 0, st, cfg->prompt, bb.s.tokens[0], n, beam, pos_off + 1, pos_off);
+    SBK_TRY(sbk::launch_status("beam_search prompt"));
+  }
 
   const float attn_w = ctc ? 1.0f - cfg->ctc_weight : 1.0f;  // seq2seq.py:803-804
   // overlap_ctc bit 0: survivors' CTC state (ctc_advance: one wave per hypothesis, latency-bound) on the
@@ -1060,8 +1102,17 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   // placeholder 0 and the launches are identical for every step -- what a captured hipGraph needs.
   int32_t* step_dev = bb.s.n_full + 2;
   auto issue_step = [&](int step, int cur, bool counter) -> int {
-    SBK_TRY(decoder_step(W, d, bb.s.tokens[cur], bb.s.kv_slot[cur], enc_len, step, n, B, T, beam, Lmax, true, st));
-    SBK_TRY(sbk::log_softmax_rows(d.logits, bb.am, n, V, cfg->temperature, attn_w, st));
+    SBK_TRY(decoder_step(W, d, bb.s.tokens[cur], bb.s.kv_slot[cur], enc_len, pos_off + step, n, B, T, beam, Lmax, true, st));
+    if (step == 0 && cfg->out_probe && cfg->probe_pos == pos_off) {  // (the probe sits on the last prompt token)
+      SBK_LAUNCH(softmax_prob_kernel, dim3(n), dim3(256), 0, st, (const float*)d.logits, bb.am_max, W->vocab, cfg->probe_token);
+      SBK_LAUNCH(probe_pick_kernel, dim3(sbk::cdiv(B, 256)), dim3(256), 0, st, (const float*)bb.am_max, cfg->out_probe, B, beam);
+    }
+    if (cfg->temperature_post)  // Whisper: log_softmax(logits + masks) / temperature (seq2seq.py:2176-2192)
+      SBK_TRY(sbk::log_softmax_rows(d.logits, bb.am, n, V, 1.0f, attn_w / cfg->temperature, st, cfg->logit_bias,
+                                    step == 0 ? cfg->first_bias : nullptr));
+    else
+      SBK_TRY(sbk::log_softmax_rows(d.logits, bb.am, n, V, cfg->temperature, attn_w, st, cfg->logit_bias,
+                                    step == 0 ? cfg->first_bias : nullptr));
     if (cfg->using_eos_threshold) SBK_TRY(sbk::row_max(bb.am, bb.am_max, n, V, st));
     const int eos_floor = step < cfg->min_steps;
     if (LM) {  // TransformerLMScorer.score (scorer.py:510-543): the prefix is the decoder's own token history
@@ -1138,7 +1189,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   // graph_mode 1: two consecutive steps (the double-buffered tables flip back after two) are captured once
   // into a hipGraph and replayed; 2: the same device-side step counter with plain launches (tests, fallback).
   int graph_mode = cfg->graph_mode;
-  if (graph_mode && (side || sbk::prof_enabled() || T > 900 || cfg->max_steps < 2)) graph_mode = 0;
+  if (graph_mode && (side || sbk::prof_enabled() || T > 900 || cfg->max_steps < 2 || pos_off > 0 || cfg->first_bias)) graph_mode = 0;
   if (graph_mode) {
     struct Scope {  // the step source is per host thread; never leave it set
       ~Scope() {
@@ -1197,7 +1248,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   }
   if (side) SBK_HIP(hipStreamWaitEvent(st, side->join, 0));  // nothing of this call outlives it on the helper stream
   if (steps_run) *steps_run = steps;
-  SBK_LAUNCH(beam_finalize_kernel, dim3(B), dim3(256), 0, st, bb.s, cur, steps, beam, Lmax, topk, out_tokens, out_len,
+  SBK_LAUNCH(beam_finalize_kernel, dim3(B), dim3(256), 0, st, bb.s, cur, steps, beam, Lmax, Lmax - pos_off, topk, out_tokens, out_len,
              out_score, out_logp, cfg->utt_max_steps, out_longest);
   SBK_TRY(sbk::launch_status("beam_finalize"));
   if (out_max_len)

@@ -1,4 +1,7 @@
 """speechbrain.inference.ASR mirror: EncoderDecoderASR (inference/ASR.py:35-173)."""
+from dataclasses import dataclass as _dataclass
+from typing import Optional as _Optional
+
 import torch
 
 from speechbrain_amd.inference.interfaces import Pretrained
@@ -67,12 +70,27 @@ class EncoderDecoderASR(Pretrained):
         return self.transcribe_batch(wavs, wav_lens)
 
 
+@_dataclass
+class ASRWhisperSegment:
+    """inference/ASR.py:391-428: one chunk of a long-form Whisper transcription."""
+
+    start: float
+    end: float
+    chunk: torch.Tensor
+    lang_id: _Optional[str] = None
+    words: _Optional[str] = None
+    tokens: _Optional[list] = None
+    prompt: _Optional[list] = None
+    avg_log_probs: _Optional[float] = None
+    no_speech_prob: _Optional[float] = None
+
+
 class WhisperASR(Pretrained):
     """inference/ASR.py:431-945, the batch entry points: ``mods.whisper`` (integrations.huggingface.whisper.Whisper)
     and ``mods.decoder`` (a Whisper searcher, e.g. S2SWhisperGreedySearcher).  ``encode_batch`` = log-mel (padded or
     trimmed to the 30-second chunk) -> Whisper encoder; ``transcribe_batch`` adds the search and the tokenizer's
-    decoding.  File streaming (ffmpeg-backed ``torchaudio.io.StreamReader``) and language identification are not
-    part of this package."""
+    decoding; ``detect_language_*``, ``transcribe_file`` / ``transcribe_file_streaming`` (30-second segments, running
+    prompt, no-speech rule) as in the reference, reading the file with the built-in wav reader."""
 
     HPARAMS_NEEDED = ["language", "sample_rate"]
     MODULES_NEEDED = ["whisper", "decoder"]
@@ -98,9 +116,95 @@ class WhisperASR(Pretrained):
     def forward(self, wavs, wav_lens):
         return self.transcribe_batch(wavs, wav_lens)
 
-    def transcribe_file(self, path, *args, **kwargs):
-        raise NotImplementedError("WhisperASR.transcribe_file streams 30-second segments through torchaudio.io; use "
-                                  "transcribe_batch on loaded audio")
+    # ---- language identification (inference/ASR.py:475-560) --------------------------------------------------------
+    @torch.no_grad()
+    def detect_language_file(self, path: str):
+        """Language of an audio file of 30 seconds or less: (language tokens [1], [{code: probability}])."""
+        wavs = self.load_audio(path).float().to(self.device).unsqueeze(0)
+        return self.mods.whisper.detect_language(self.mods.whisper._get_mel(wavs))
+
+    @torch.no_grad()
+    def detect_language_batch(self, wav):
+        return self.mods.whisper.detect_language(self.mods.whisper._get_mel(wav.to(device=self.device, dtype=torch.float32)))
+
+    @torch.no_grad()
+    def _detect_language(self, mel, task):
+        """:541-560: the configured language, or -- when none is set or the task is lang_id -- the detected one, which
+        is also handed to the searcher as the language token of every utterance."""
+        languages = [self.mods.whisper.language] * mel.shape[0]
+        lang_probs = None
+        if self.mods.whisper.language is None or task == "lang_id":
+            lang_tokens, lang_probs = self.mods.whisper.detect_language(mel)
+            languages = [max(probs, key=probs.get) for probs in lang_probs]
+            self.mods.decoder.set_lang_tokens(lang_tokens)
+        return languages, lang_probs
+
+    # ---- long-form transcription (inference/ASR.py:622-840) ------------------------------------------------------
+    @torch.no_grad()
+    def transcribe_file_streaming(self, path, task=None, initial_prompt=None, logprob_threshold=-1.0,
+                                  no_speech_threshold=0.6, condition_on_previous_text=False, verbose=False,
+                                  use_torchaudio_streaming=False, chunk_size=30, **kwargs):
+        """Yields one ``ASRWhisperSegment`` per ``chunk_size``-second segment of the file (tasks ``transcribe``,
+        ``translate``, ``lang_id``): log-mel -> encoder -> language -> search with the running prompt -> the no-speech /
+        average-log-prob skip rule.  The file is read whole with the built-in wav reader and cut into segments (the
+        reference's ffmpeg-backed ``torchaudio.io.StreamReader`` path, ``use_torchaudio_streaming=True``, is not part
+        of this package; the segments and therefore the results are the same)."""
+        if use_torchaudio_streaming:
+            raise NotImplementedError("torchaudio.io.StreamReader (ffmpeg) streaming: pass use_torchaudio_streaming=False")
+        if task is not None:
+            if task not in self.TASKS:
+                raise ValueError(f"Task {task} not supported. Supported tasks are {self.TASKS}")
+            if task != "lang_id":
+                self.mods.decoder.set_task(task)
+        num_frames_per_chunk = chunk_size * self.hparams.sample_rate
+        segments = split_fixed_chunks(self.load_audio(path, **kwargs).unsqueeze(0), num_frames_per_chunk)
+        rel_length = torch.tensor([1.0])
+        all_tokens, prompt_reset_since = [], 0
+        if initial_prompt is not None:
+            all_tokens.extend(self.tokenizer.encode(" " + initial_prompt.strip()))
+        for i, segment in enumerate(segments):
+            segment = segment.to(self.device)
+            mel_segment = self.mods.whisper._get_mel(segment)
+            start, end = i * chunk_size, (i + 1) * chunk_size
+            encoder_out = self.mods.whisper.forward_encoder(mel_segment)
+            languages, _ = self._detect_language(mel_segment, task)
+            if task == "lang_id":
+                yield ASRWhisperSegment(start=start, end=end, chunk=segment, lang_id=languages[0])
+                continue
+            prompt = all_tokens[prompt_reset_since:]
+            self.mods.decoder.set_prompt(prompt)
+            predicted_tokens, _, scores, _ = self.mods.decoder(encoder_out, rel_length)
+            avg_log_probs = scores.sum() / (len(predicted_tokens[0]) + 1)
+            no_speech_prob = self.mods.decoder.no_speech_probs[0]
+            if no_speech_threshold is not None:
+                should_skip = no_speech_prob > no_speech_threshold
+                if logprob_threshold is not None and avg_log_probs > logprob_threshold:
+                    should_skip = False  # confident enough despite the no-speech probability
+                if should_skip:
+                    yield ASRWhisperSegment(start=start, end=end, chunk=segment, lang_id=languages[0], words="", tokens=[],
+                                            prompt=prompt, avg_log_probs=avg_log_probs.item(), no_speech_prob=no_speech_prob)
+                    continue
+            words = [self.tokenizer.decode(t, skip_special_tokens=True).strip() for t in predicted_tokens]
+            yield ASRWhisperSegment(start=start, end=end, chunk=segment, lang_id=languages[0], words=words[0],
+                                    tokens=predicted_tokens[0], prompt=prompt, avg_log_probs=avg_log_probs.item(),
+                                    no_speech_prob=no_speech_prob)
+            all_tokens.extend(predicted_tokens[0])
+            if not condition_on_previous_text or self.mods.decoder.temperature > 0.5:
+                prompt_reset_since = len(all_tokens)
+
+    def transcribe_file(self, path, task=None, initial_prompt=None, logprob_threshold=-1.0, no_speech_threshold=0.6,
+                        condition_on_previous_text=False, verbose=False, use_torchaudio_streaming=False, chunk_size=30,
+                        **kwargs):
+        """The list of ``ASRWhisperSegment`` of the whole file (:790-865)."""
+        results = []
+        for seg in self.transcribe_file_streaming(
+                path, task=task, initial_prompt=initial_prompt, logprob_threshold=logprob_threshold,
+                no_speech_threshold=no_speech_threshold, condition_on_previous_text=condition_on_previous_text,
+                verbose=verbose, use_torchaudio_streaming=use_torchaudio_streaming, chunk_size=chunk_size, **kwargs):
+            results.append(seg)
+            if verbose:
+                print(f"[{seg.start}s --> {seg.end}s] {seg.words if task != 'lang_id' else seg.lang_id}")
+        return results
 
 
 # ---------------------------------------------------------------------------------------------- streaming

@@ -474,6 +474,46 @@ class Whisper(WhisperLogMel):
             have = self._non_speech = tuple(sorted(ids))
         return have
 
+    @property
+    def all_language_tokens(self):
+        """whisper.py:441-453: the language tokens follow <|startoftranscript|> in the vocabulary, in LANGUAGES order."""
+        have = getattr(self, "_lang_tokens", None)
+        if have is None:
+            from transformers.models.whisper.tokenization_whisper import LANGUAGES
+
+            bos = self.tokenizer.convert_tokens_to_ids(self.tokenizer.bos_token)
+            have = self._lang_tokens = tuple(bos + 1 + i for i in range(len(LANGUAGES)))
+        return have
+
+    @property
+    def all_language_codes(self):
+        """whisper.py:455-461."""
+        have = getattr(self, "_lang_codes", None)
+        if have is None:
+            from transformers.models.whisper.tokenization_whisper import LANGUAGES
+
+            have = self._lang_codes = tuple(LANGUAGES.keys())
+        return have
+
+    @torch.no_grad()
+    def detect_language(self, mel):
+        """whisper.py:617-665: one decoder step on <|startoftranscript|>, the logits restricted to the language tokens.
+        Returns (language_tokens [B], list of {code: probability})."""
+        if getattr(self.tokenizer, "language", None) is None:
+            raise ValueError("This model doesn't have language tokens so it can't perform lang id")
+        enc_states = self.model.encoder(mel.float().contiguous())
+        B = mel.shape[0]
+        ids = torch.full((B, 1), self.bos, dtype=torch.int32, device=mel.device)
+        logits = self.forward_decoder(enc_states, ids)[0][:, 0]
+        mask = torch.ones(logits.shape[-1], dtype=torch.bool, device=logits.device)
+        mask[list(self.all_language_tokens)] = False
+        logits = logits.masked_fill(mask, -float("inf"))  # (host-side glue on a [B, V] tensor, like the reference)
+        language_tokens = logits.argmax(dim=-1)
+        probs = logits.softmax(dim=-1).cpu()
+        language_probs = [{c: probs[i, j].item() for j, c in zip(self.all_language_tokens, self.all_language_codes)}
+                          for i in range(B)]
+        return language_tokens, language_probs
+
     def set_language_token(self, language):
         self.language = language
         self.tokenizer.set_prefix_tokens(language=language)

@@ -190,3 +190,80 @@ def test_whisper_asr_interface(backend):
     assert words[0] == " ".join(f"t{t}" for t in ref_h[0])
     enc = asr.encode_batch(torch.from_numpy(g["wav"]), torch.ones(3))
     assert float((enc.cpu() - torch.from_numpy(g["enc"])).abs().max()) <= 1e-3
+
+
+def test_whisper_beam_searcher_matches_reference_golden(backend):
+    """S2SWhisperBeamSearcher (seq2seq.py:1937-2206) on the device search: prompt priming of every hypothesis' KV cache,
+    per-utterance language tokens, suppression masks, log_softmax / temperature, eos rules, return_topk -- token ids
+    equal the reference's, scores within 2e-4, no_speech_probs within 1e-5; temperatures 1 and 0.8, a token prompt,
+    a minimum length without length normalisation, the top-3 lists."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import S2SWhisperBeamSearcher
+
+    g = np.load(MODEL_GOLD)
+    w = _full_whisper(dev)
+    enc = torch.from_numpy(g["enc"]).to(dev)
+    base = dict(beam_size=4, min_decode_ratio=0.0, max_decode_ratio=1.0, using_eos_threshold=False, length_normalization=True)
+    for tag, kw in (("t10", dict(temperature=1.0)), ("t08", dict(temperature=0.8)),
+                    ("prompt", dict(temperature=1.0, prompt=[30, 31, 32])),
+                    ("min6", dict(temperature=1.0, min_decode_ratio=0.12, length_normalization=False))):
+        s = S2SWhisperBeamSearcher(module=[w], **{**base, **kw})
+        assert list(s.initial_tokens) == g[f"beam_{tag}_init"].tolist()
+        s.set_lang_tokens(torch.tensor([4, 5, 6]).repeat_interleave(4))  # one per hypothesis, as the reference takes them
+        hyps, lens, scores, _ = s(enc, torch.ones(3))
+        assert hyps == [[int(t) for t in row if t >= 0] for row in g[f"beam_{tag}_hyps"]], tag
+        assert float((scores.cpu() - torch.from_numpy(g[f"beam_{tag}_scores"])).abs().max()) <= 2e-4, tag
+        assert float((lens.cpu().float() - torch.from_numpy(g[f"beam_{tag}_lens"]).float()).abs().max()) <= 1e-6, tag
+        assert np.abs(np.array(s.no_speech_probs) - g[f"beam_{tag}_no_speech"][::4]).max() <= 1e-5, tag
+        s.set_lang_tokens(torch.tensor([4, 5, 6]))  # one per utterance gives the same search
+        assert s(enc, torch.ones(3))[0] == hyps
+    s = S2SWhisperBeamSearcher(module=[w], **{**base, "temperature": 1.0, "return_topk": True, "topk": 3})
+    s.set_lang_tokens(torch.tensor([4, 5, 6]))
+    k_hyps, k_lens, k_scores, _ = s(enc, torch.ones(3))
+    assert torch.equal(k_hyps.cpu(), torch.from_numpy(g["beam_top3_hyps"]))
+    assert float((k_scores.cpu() - torch.from_numpy(g["beam_top3_scores"])).abs().max()) <= 2e-4
+
+
+def test_whisper_language_identification_and_file_transcription(backend, tmp_path):
+    """Whisper.detect_language (whisper.py:617-665) against the reference's tokens / probabilities, and
+    WhisperASR.detect_language_batch / transcribe_file (inference/ASR.py:475-865): segments of the file, running prompt,
+    lang_id task, the no-speech skip rule."""
+    nat, dev = backend
+    import struct
+    import wave
+
+    from speechbrain_amd.decoders import S2SWhisperBeamSearcher
+    from speechbrain_amd.inference.ASR import ASRWhisperSegment, WhisperASR
+
+    g = np.load(MODEL_GOLD)
+    w = _full_whisper(dev)
+    w.tokenizer.language, w.tokenizer.bos_token = "en", "<|startoftranscript|>"
+    w._lang_tokens, w._lang_codes = (4, 5, 6, 7), ("en", "fr", "de", "es")
+    toks, probs = w.detect_language(torch.from_numpy(g["mel"]).to(dev))
+    assert toks.cpu().tolist() == g["lang_tokens"].tolist()
+    got = np.array([[p[c] for c in w._lang_codes] for p in probs])
+    assert np.abs(got - g["lang_probs"]).max() <= 1e-5
+    # the interface: 1-second "chunks" for the 50-position toy encoder
+    w.tokenizer.decode = lambda t, skip_special_tokens=True: " " + " ".join(f"t{x}" for x in t) + " "
+    w.tokenizer.encode = lambda text, add_special_tokens=False: {" ": [16]}.get(text, [30, 31])
+    w._get_mel = lambda wav: w.log_mel_spectrogram(w.pad_or_trim(wav, 16000))
+    searcher = S2SWhisperBeamSearcher(module=[w], beam_size=4, using_eos_threshold=False)
+    asr = WhisperASR(modules={"whisper": w, "decoder": searcher},
+                     hparams={"language": None, "sample_rate": 16000, "whisper": w}, run_opts={"device": str(dev)})
+    w.language = None  # language unknown: every segment is identified first
+    lt, lp = asr.detect_language_batch(torch.from_numpy(g["wav"]))
+    assert lt.cpu().tolist() == g["lang_tokens"].tolist()
+    path = str(tmp_path / "two_and_a_half_seconds.wav")
+    pcm = (np.concatenate([g["wav"][0], g["wav"][1], g["wav"][2][:8000]]) * 32767 / 2).astype("<i2")
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000); f.writeframes(pcm.tobytes())
+    segs = asr.transcribe_file(path, chunk_size=1, no_speech_threshold=None)
+    assert [type(s) for s in segs] == [ASRWhisperSegment] * 3 and [(s.start, s.end) for s in segs] == [(0, 1), (1, 2), (2, 3)]
+    assert all(s.lang_id == "fr" and s.tokens and s.words == " ".join(f"t{x}" for x in s.tokens) for s in segs)
+    assert segs[0].prompt == [] and all(0.0 <= s.no_speech_prob <= 1.0 for s in segs)
+    ids = asr.transcribe_file(path, task="lang_id", chunk_size=1)
+    assert [s.lang_id for s in ids] == ["fr"] * 3 and ids[0].words is None
+    skipped = asr.transcribe_file(path, chunk_size=1, no_speech_threshold=0.0, logprob_threshold=None)
+    assert all(s.words == "" and s.tokens == [] for s in skipped)  # every segment is above a zero no-speech threshold
+    prompted = asr.transcribe_file(path, chunk_size=1, initial_prompt="hello", no_speech_threshold=None)
+    assert prompted[0].prompt == [30, 31]
