@@ -336,6 +336,11 @@ typedef struct {
    * temperature_post: 1 = log_softmax(logits) / temperature (:2189-2192) instead of log_softmax(logits / temperature).
    * probe: out_probe [B] DEVICE = softmax(logits at prompt position probe_pos)[probe_token] -- no_speech_probs
    *   (:2161-2170); out_probe NULL = off. */
+  int32_t ctc_window_size; /* CTCScorer(ctc_window_size) (scorer.py:183-187): > 0 = the CTC prefix scores of a step are
+                              computed over the frames [min peak - w, max peak + w) only, the peaks being the arg-max over
+                              the decoded positions of the last decoder layer's head-averaged cross-attention, min / max
+                              taken over the whole batch (ctc.py:189-200, as the reference computes them for a
+                              transformer decoder).  Not with the grouped search, graph_mode or overlap_ctc. */
   const int32_t* prompt;
   int32_t prompt_len;
   int32_t temperature_post;

@@ -215,6 +215,19 @@ def golden_model(tag, d_model, nhead, d_ffn, n_enc, n_dec, vocab, B, n_frames, b
                 out[f"partial{key}_scores"], out[f"partial{key}_lens"] = p_scores.numpy(), p_lens.numpy()
                 print(f"  partial CTC scorer, scale {scale}: lens", [len(h) for h in p_hyps],
                       "same as full:", p_hyps == hyps_r)
+        if tag == "tiny_ctc":  # attention-windowed CTC scoring (CTCScorer(ctc_window_size), scorer.py:183-187, ctc.py:189-200)
+            for wsize in (2, 5):
+                wscorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2,
+                                                                ctc_window_size=wsize)], weights={"ctc": ctc_w})
+                bsw = S2STransformerBeamSearcher(
+                    modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=min_ratio,
+                    max_decode_ratio=max_ratio, beam_size=beam, using_eos_threshold=eos_thr, length_normalization=True,
+                    scorer=wscorer)
+                w_hyps, w_lens, w_scores, _ = bsw(enc_ref.clone(), wav_lens)
+                out[f"window{wsize}_hyps"] = np.array([h + [-1] * (64 - len(h)) for h in w_hyps], dtype=np.int64)
+                out[f"window{wsize}_scores"], out[f"window{wsize}_lens"] = w_scores.numpy(), w_lens.numpy()
+                print(f"  CTC window {wsize}: lens", [len(h) for h in w_hyps], "same as unwindowed:", w_hyps == hyps_r,
+                      "scores", w_scores.tolist())
         # beam = 1 through the beam searcher (north-star "greedy beam=1")
         bs1 = S2STransformerBeamSearcher(
             modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=min_ratio,

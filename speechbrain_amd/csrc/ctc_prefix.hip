@@ -155,7 +155,20 @@ struct CtcStepArgs {
   // grouped search: per-utterance min_decode_steps (overrides eos_floor / min_steps); row n belongs to utterance n / beam
   const int32_t* utt_min;
   int utt_beam, step;
+  // attention window (ctc.py:189-200, ctc_window_size > 0): win = {min, max} of the attention peaks of this step
+  // (device memory), frames [max(start, win[0] - window), min(T, win[1] + window)) are scored; NULL = every frame
+  const int32_t* win;
+  int window;
 };
+// scored frame range [start, end) of a step (ctc.py:187-200)
+__device__ __forceinline__ void ctc_frame_range(int prefix_len, int T, const int32_t* win, int window, int* start, int* end) {
+  *start = prefix_len > 1 ? prefix_len : 1;
+  *end = T;
+  if (win) {
+    *start = max(*start, win[0] - window);
+    *end = min(T, win[1] + window);
+  }
+}
 
 // P [B,T,V] masked linear posteriors; sg [n_bh,T] / se [n_bh,nseg] segment-scaled gamma tables
 // (uniform per workgroup: fetched through the scalar cache); am [n_bh,V] acoustic log-probs
@@ -184,7 +197,8 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   }
   const int c4 = c_ok[0] ? c[0] : V - 4;  // TPT = 4: base of this thread's float4 (V % 4 == 0)
   const int nseg = nseg_of(T);
-  const int start = a.prefix_len > 1 ? a.prefix_len : 1;
+  int start, end;
+  ctc_frame_range(a.prefix_len, T, a.win, a.window, &start, &end);
   const float* Pb = P + (size_t)b * T * V;
   const int last_frame = a.enc_len[b] - 1;
   // the utterance's scaled gamma table [T][16] and segment exponents [nseg][16] -> LDS (coalesced copy);
@@ -212,7 +226,7 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       // psi_init = r[start-1][nb]: x[0] (non-blank) at the very first step, nothing otherwise (ctc.py:168-172,212)
-      const bool first = a.prefix_len == 0 && p0 > 0.0f;
+      const bool first = a.prefix_len == 0 && start == 1 && p0 > 0.0f;
       mps[k][j] = first ? p0 : 0.0f;
       Eps[k][j] = first ? 0 : kNegE;
       part[k][j] = 0.0f;
@@ -222,7 +236,7 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   // the NEXT chunk are requested before the current chunk is accumulated (two chunks in flight per lane).
   constexpr int CH = 16 / TPT < 8 ? 8 : 16 / TPT;
   static_assert(kSeg % CH == 0, "ctc_score_step: chunks must tile a scale segment");
-  const int u_begin = start - 1, u_end = T - 1;
+  const int u_begin = start - 1, u_end = end - 1;
   auto fetch = [&](float (&buf)[TPT][CH], int cb) {
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
@@ -307,16 +321,17 @@ __global__ void __launch_bounds__(64) ctc_same_token_kernel(CtcStepArgs a, const
   const int b = n / a.beam, c = a.last_tok[n];
   const int T = a.T, V = a.V, nseg = nseg_of(T);
   if (c == a.eos || c == a.blank || c < 0 || c >= V) return;  // those entries are overridden anyway
-  const int start = a.prefix_len > 1 ? a.prefix_len : 1;
+  int start, end;
+  ctc_frame_range(a.prefix_len, T, a.win, a.window, &start, &end);
   const float* Pb = P + (size_t)b * T * V;
   // per-lane block-float partial over its frames, then a wave reduction on a common exponent
   float m = 0.0f;
   int E = kNegE;
-  if (lane == 0 && a.prefix_len == 0 && Pb[c] > 0.0f) {
+  if (lane == 0 && a.prefix_len == 0 && start == 1 && Pb[c] > 0.0f) {
     m = Pb[c];
     E = 0;
   }
-  for (int u = start - 1 + lane; u < T - 1; u += 64) {
+  for (int u = start - 1 + lane; u < end - 1; u += 64) {
     const float term = sb[(size_t)n * T + u] * Pb[(size_t)(u + 1) * V + c];
     const int k = sbk::frexp_exp(term);
     const int et = term > 0.0f ? se[((size_t)b * nseg + u / kSeg) * beam_pitch(a.beam) + n % a.beam] + k : kNegE;
@@ -456,6 +471,8 @@ struct CtcAdvArgs {
   float* psi_prev_new;
   int n_bh, T, V, beam, prefix_len, blank;
   const int32_t* step_ptr;
+  const int32_t* win;  // attention window of this step (see CtcStepArgs)
+  int window;
 };
 
 __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
@@ -496,19 +513,23 @@ __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
   }
   __syncthreads();
   {
-    const int start = a.prefix_len > 1 ? a.prefix_len : 1;
+    int start, end;
+    ctc_frame_range(a.prefix_len, T, a.win, a.window, &start, &end);
     const bool first = a.prefix_len == 0 && pc[0] > 0.0f;
-    AState s0{first ? pc[0] : 0.0f, 0.0f, first ? 0 : kNegE};  // r[start-1]
-    norm2(s0.nb, s0.bl, s0.e);
-    for (int t = lane; t < start; t += 64) {  // frames before `start` keep r = "minus infinity" (except r[0][nb] at the first step)
-      onb[t] = (t == start - 1) ? s0.nb : 0.0f;
-      obl[t] = 0.0f;
-      oe[t] = (t == start - 1) ? s0.e : kNegE;
-    }
+    AState r0{first ? pc[0] : 0.0f, 0.0f, first ? 0 : kNegE};  // r[0]: x[0][c] at the first step (ctc.py:168-172)
+    norm2(r0.nb, r0.bl, r0.e);
+    const AState zero{0.0f, 0.0f, kNegE};
+    const AState s0 = start == 1 ? r0 : zero;  // r[start-1]: frames outside the recurrence stay "minus infinity"
+    for (int t = lane; t < T; t += 64)
+      if (t < start || t >= end) {  // (an attention window may leave frames on either side untouched)
+        onb[t] = t == 0 ? r0.nb : 0.0f;
+        obl[t] = 0.0f;
+        oe[t] = t == 0 ? r0.e : kNegE;
+      }
     // lane l owns frames [f0, f1)
-    const int nfr = max(T - start, 0);
+    const int nfr = max(end - start, 0);
     const int fpl = (nfr + 63) / 64;
-    const int f0 = min(start + lane * fpl, T), f1 = min(f0 + fpl, T);
+    const int f0 = min(start + lane * fpl, end), f1 = min(f0 + fpl, end);
     AMap mine = identity_map();
     for (int t = f0; t < f1; ++t) mine = compose(frame_map(pc[t], pb[t], mph[t - 1], eph[t - 1]), mine);
     // inclusive scan of the lane maps (Hillis-Steele)
@@ -657,7 +678,7 @@ StateView view(float* base, int B, int beam, int T) {
 
 // floats of one CTC state buffer: BF rows + the two segment-scaled tables + segment exponents
 int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, const int32_t* enc_len, float* psi, int B,
-                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st);
+                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st, const int32_t* win, int window);
 
 size_t ctc_state_floats(int B, int beam, int T) {
   const size_t n_bh = (size_t)B * beam, bp = beam_pitch(beam);
@@ -680,8 +701,10 @@ int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, f
 
 // psi[n,c] for every hypothesis / token (needs only the CTC state: can run beside the decoder step)
 int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, const int32_t* enc_len, float* psi, int B,
-                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st) {
+                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st, const int32_t* win, int window) {
   CtcStepArgs a{last_tok, enc_len, B, T, V, beam, prefix_len, blank, eos, 0.0f, 0, 0, 0.0f, 0.0f, g_step_ptr, 0};
+  a.win = win;
+  a.window = window;
   const StateView v = view(const_cast<float*>(state), B, beam, T);
   ProfScope prof("ctc_score_step", 2.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 4.0 * B * beam * V, st);
   const int tpt = (g_ctc_tpt == 4 && (V % 4 != 0 || !aligned16(P))) ? 1 : g_ctc_tpt;
@@ -734,11 +757,11 @@ int ctc_combine(const float* am, const float* am_max, const float* psi, const fl
 
 int ctc_advance(const float* P, const float* state_old, const float* psi, const int32_t* parent, const int32_t* token,
                 const int32_t* parent_last_tok, float* state_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
-                int prefix_len, int blank, hipStream_t st) {
+                int prefix_len, int blank, hipStream_t st, const int32_t* win, int window) {
   const StateView vo = view(const_cast<float*>(state_old), n_bh / beam, beam, T);
   const StateView vn = view(state_new, n_bh / beam, beam, T);
   CtcAdvArgs a{P, vo.st, psi, parent, token, parent_last_tok, vn.st, vn.sg, vn.sb, vn.se, psi_prev_new, n_bh, T, V, beam,
-               prefix_len, blank, g_step_ptr};
+               prefix_len, blank, g_step_ptr, win, window};
   const size_t lds = (size_t)7 * T * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "ctc_advance: T=%d too long for the LDS window", T);
   ProfScope prof("ctc_advance", 14.0 * n_bh * T, 64.0 * n_bh * T, st);
@@ -787,10 +810,10 @@ extern "C" int sbk_prof_ctc_psi_repeat_f32(float* P_logsoftmax, const int32_t* e
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return sbk::fail(1, "event create");
   for (int i = 0; i < 2 && !rc; ++i)
-    rc = sbk::ctc_psi_step(P_logsoftmax, state, last_tok, enc_len, psi, B, T, V, beam, prefix_len, 0, 2, st);
+    rc = sbk::ctc_psi_step(P_logsoftmax, state, last_tok, enc_len, psi, B, T, V, beam, prefix_len, 0, 2, st, nullptr, 0);
   (void)hipEventRecord(e0, st);
   for (int i = 0; i < iters && !rc; ++i)
-    rc = sbk::ctc_psi_step(P_logsoftmax, state, last_tok, enc_len, psi, B, T, V, beam, prefix_len, 0, 2, st);
+    rc = sbk::ctc_psi_step(P_logsoftmax, state, last_tok, enc_len, psi, B, T, V, beam, prefix_len, 0, 2, st, nullptr, 0);
   (void)hipEventRecord(e1, st);
   (void)hipEventSynchronize(e1);
   float ms = 0.0f;

@@ -1001,6 +1001,52 @@ int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
   return sbk::launch_status("cross_merge");
 }
 
+// ---- head-averaged cross-attention probabilities of ONE decoder layer for the current position: what
+// nn.MultiheadAttention hands back as attention weights (average over heads) and the CTC scorer's attention window
+// reads (decoders/ctc.py:189-200 through scorer.py:183-187).  One workgroup per hypothesis; only run when
+// ctc_window_size > 0.  out [n,T]: frames past the utterance end get exactly 0 (the key padding mask).
+__global__ void __launch_bounds__(256) cross_attn_avg_probs_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                                   const int32_t* __restrict__ enc_len,
+                                                                   float* __restrict__ out, int T, int d, int H, int beam,
+                                                                   float scale) {
+  SBK_DYN_LDS(float, lds);  // acc[T] | sc[T] | red[8]
+  float* acc = lds;
+  float* sc = lds + T;
+  float* red = sc + T;
+  const int n = blockIdx.x, b = n / beam, tid = threadIdx.x, Dh = d / H;
+  const int klen = min(max(enc_len[b], 1), T);
+  const float* kvb = kv + (size_t)b * T * 2 * d;
+  for (int t = tid; t < T; t += 256) acc[t] = 0.0f;
+  for (int h = 0; h < H; ++h) {
+    const float* qh = q + (size_t)n * d + h * Dh;
+    float m = -INFINITY;
+    for (int t = tid; t < klen; t += 256) {
+      const float* kr = kvb + (size_t)t * 2 * d + h * Dh;
+      float s = 0.0f;
+      for (int c = 0; c < Dh; ++c) s = fmaf(qh[c] * scale, kr[c], s);
+      sc[t] = s;
+      m = fmaxf(m, s);
+    }
+    m = sbk::wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.0f;
+    for (int t = tid; t < klen; t += 256) {
+      const float e = expf(sc[t] - m);
+      sc[t] = e;
+      sum += e;
+    }
+    sum = sbk::wave_sum(sum);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    for (int t = tid; t < klen; t += 256) acc[t] += sc[t] / sum;
+    __syncthreads();
+  }
+  for (int t = tid; t < T; t += 256) out[(size_t)n * T + t] = t < klen ? acc[t] / (float)H : 0.0f;
+}
+
 // ---------------------------------------------------------------- log-softmax over the vocabulary
 // out[i,c] = w * (x[i,c]/temp - logsumexp(x[i,:]/temp));  one workgroup per row.
 // bias / bias2 (optional, [V]): additive masks on the logits (0 or -inf: suppressed tokens come out as -inf)
@@ -1105,6 +1151,17 @@ int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, flo
     case 8: return launch_cross<8>(a, st);
     default: return fail(SBK_EINVAL, "cross_attn_step: head_dim %d not instantiated (8,16,32,36,64)", Dh);
   }
+}
+
+int cross_attn_avg_probs(const float* q, const float* kv, const int32_t* enc_len, float* out, int n, int T, int d, int H,
+                         int beam, hipStream_t st) {
+  if (n == 0) return 0;
+  const size_t lds = ((size_t)2 * T + 8) * sizeof(float);
+  if (lds > 64 * 1024) return fail(SBK_EINVAL, "cross_attn_avg_probs: T=%d too long for the LDS window", T);
+  ProfScope prof("cross_attn_probs", 2.0 * n * (double)T * d, 4.0 * (n / beam) * (double)T * d, st);
+  SBK_LAUNCH(cross_attn_avg_probs_kernel, dim3(n), dim3(256), lds, st, q, kv, enc_len, out, T, d, H, beam,
+             1.0f / sqrtf((float)(d / H)));
+  return launch_status("cross_attn_avg_probs");
 }
 
 int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st,

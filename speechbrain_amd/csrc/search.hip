@@ -77,13 +77,16 @@ int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, f
                 int beam, int blank, hipStream_t st);
 size_t ctc_state_floats(int B, int beam, int T);
 int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, const int32_t* enc_len, float* psi, int B,
-                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st);
+                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st, const int32_t* win = nullptr,
+                 int window = 0);
+int cross_attn_avg_probs(const float* q, const float* kv, const int32_t* enc_len, float* out, int n, int T, int d, int H,
+                         int beam, hipStream_t st);
 int ctc_combine(const float* am, const float* am_max, const float* psi, const float* psi_prev, float* comb, int n_bh,
                 int V, int blank, int eos, float weight, int eos_floor, int use_thr, float thr, float minus_inf,
                 const float* extra, hipStream_t st, const int32_t* utt_min = nullptr, int beam = 1, int step = 0);
 int ctc_advance(const float* x, const float* phi_old, const float* psi, const int32_t* parent, const int32_t* token,
                 const int32_t* parent_last_tok, float* phi_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
-                int prefix_len, int blank, hipStream_t st);
+                int prefix_len, int blank, hipStream_t st, const int32_t* win = nullptr, int window = 0);
 int am_only(const float* am, float* comb, int n_bh, int V, int eos, int eos_floor, int use_thr, float thr,
             float minus_inf, const float* am_max, const float* extra, hipStream_t st, const int32_t* utt_min = nullptr,
             int beam = 1, int step = 0);
@@ -952,9 +955,61 @@ struct BeamBufs {
   float *am, *comb, *psi, *am_max, *ctc_x, *ctc_xb, *phi[2], *psi_prev[2];
   float* topk_val;
   int32_t* topk_idx;
+  // attention window of the CTC scorer (ctc_window_size > 0): running arg-max over the decoded positions of the
+  // head-averaged cross-attention, per (hypothesis, frame), double-buffered like the other per-hypothesis tables
+  float* attn_avg;       // [n_bh][T] this step's probabilities
+  float* peak_val[2];    // [n_bh][T]
+  int32_t* peak_pos[2];  // [n_bh][T]
+  int32_t* win;          // [Lmax][2] {min, max} peak of every step
 };
 
-void carve_beam(Carver& c, BeamBufs& b, int B, int beam, int T, int V, int Lmax, bool ctc) {
+// tables of the attention window: new = old[parent], then the new position takes over where its probability is larger
+// (strictly: torch.max returns the FIRST maximum); the step's min / max position over every hypothesis and frame
+__global__ void __launch_bounds__(256) attn_peak_kernel(const float* __restrict__ probs, const float* __restrict__ old_val,
+                                                        const int32_t* __restrict__ old_pos,
+                                                        const int32_t* __restrict__ parent, float* __restrict__ new_val,
+                                                        int32_t* __restrict__ new_pos, int32_t* __restrict__ win, int T,
+                                                        int step) {
+  __shared__ int lo_s[4], hi_s[4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int p = step > 0 ? parent[n] : n;
+  int lo = INT_MAX, hi = INT_MIN;
+  for (int t = tid; t < T; t += 256) {
+    float v = step > 0 ? old_val[(size_t)p * T + t] : -1.0f;
+    int pos = step > 0 ? old_pos[(size_t)p * T + t] : 0;
+    const float a = probs[(size_t)n * T + t];
+    if (a > v) {
+      v = a;
+      pos = step;
+    }
+    new_val[(size_t)n * T + t] = v;
+    new_pos[(size_t)n * T + t] = pos;
+    lo = min(lo, pos);
+    hi = max(hi, pos);
+  }
+  for (int m = 32; m >= 1; m >>= 1) {
+    lo = min(lo, sbk::shfl_xor(lo, m));
+    hi = max(hi, sbk::shfl_xor(hi, m));
+  }
+  if ((tid & 63) == 0) {
+    lo_s[tid >> 6] = lo;
+    hi_s[tid >> 6] = hi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    atomicMin(&win[2 * step], min(min(lo_s[0], lo_s[1]), min(lo_s[2], lo_s[3])));
+    atomicMax(&win[2 * step + 1], max(max(hi_s[0], hi_s[1]), max(hi_s[2], hi_s[3])));
+  }
+}
+__global__ void win_init_kernel(int32_t* win, int steps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < steps) {
+    win[2 * i] = INT_MAX;
+    win[2 * i + 1] = INT_MIN;
+  }
+}
+
+void carve_beam(Carver& c, BeamBufs& b, int B, int beam, int T, int V, int Lmax, bool ctc, int window = 0) {
   const size_t n = (size_t)B * beam;
   for (int k = 0; k < 2; ++k) {
     b.s.seq[k] = c.take<int32_t>(n * Lmax);
@@ -985,6 +1040,14 @@ void carve_beam(Carver& c, BeamBufs& b, int B, int beam, int T, int V, int Lmax,
       b.phi[k] = c.take<float>(sbk::ctc_state_floats(B, beam, T));
       b.psi_prev[k] = c.take<float>(n);
     }
+    if (window > 0) {
+      b.attn_avg = c.take<float>(n * T);
+      for (int k = 0; k < 2; ++k) {
+        b.peak_val[k] = c.take<float>(n * T);
+        b.peak_pos[k] = c.take<int32_t>(n * T);
+      }
+      b.win = c.take<int32_t>((size_t)2 * Lmax);
+    }
   }
 }
 
@@ -998,7 +1061,7 @@ extern "C" size_t sbk_beam_search_workspace_bytes(const sbk_decoder_weights* W, 
   BeamBufs bb;
   const int Lmax = (cfg->max_steps > 0 ? cfg->max_steps : 1) + (cfg->prompt && cfg->prompt_len > 1 ? cfg->prompt_len - 1 : 0);
   carve_decoder(c, d, W, B * cfg->beam, B, T, Lmax);
-  carve_beam(c, bb, B, cfg->beam, T, W->vocab, Lmax, cfg->ctc_weight > 0.0f);
+  carve_beam(c, bb, B, cfg->beam, T, W->vocab, Lmax, cfg->ctc_weight > 0.0f, cfg->ctc_window_size);
   if (cfg->lm && cfg->lm_weight != 0.0f) {
     LmBufs lb;
     carve_lm(c, lb, cfg->lm, B * cfg->beam, Lmax);
@@ -1046,7 +1109,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   DecoderBufs d;
   BeamBufs bb;
   carve_decoder(c, d, W, n, B, T, Lmax);
-  carve_beam(c, bb, B, beam, T, V, Lmax, ctc);
+  carve_beam(c, bb, B, beam, T, V, Lmax, ctc, cfg->ctc_window_size);
   const sbk_lm_weights* LM = (cfg->lm && cfg->lm_weight != 0.0f) ? cfg->lm : nullptr;
   LmBufs lb;
   if (LM) {
@@ -1083,10 +1146,17 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
     SBK_TRY(sbk::launch_status("beam_search prompt"));
   }
 
+  const int window = ctc ? cfg->ctc_window_size : 0;
+  SBK_REQUIRE(window >= 0 && (window == 0 || (!cfg->utt_max_steps && !cfg->utt_min_steps && !d.head_major)),
+              "beam_search: ctc_window_size excludes the grouped search");
+  if (window > 0) {
+    SBK_LAUNCH(win_init_kernel, dim3(sbk::cdiv(Lmax, 256)), dim3(256), 0, st, bb.win, Lmax);
+    SBK_TRY(sbk::launch_status("ctc window"));
+  }
   const float attn_w = ctc ? 1.0f - cfg->ctc_weight : 1.0f;  // seq2seq.py:803-804
   // overlap_ctc bit 0: survivors' CTC state (ctc_advance: one wave per hypothesis, latency-bound) on the
   // helper stream beside the next decoder step; bit 1: the full-vocabulary psi pass there as well.
-  SideStream* side = (ctc && cfg->overlap_ctc) ? side_stream() : nullptr;
+  SideStream* side = (ctc && cfg->overlap_ctc && window == 0) ? side_stream() : nullptr;
   const bool psi_aside = side && (cfg->overlap_ctc & 2);
   hipStream_t cst = side ? side->s : st;      // stream of ctc_advance
   hipStream_t pst = psi_aside ? side->s : st;  // stream of ctc_psi_step
@@ -1119,11 +1189,20 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
       SBK_TRY(lm_step(LM, lb, bb.s.tokens[cur], bb.s.kv_slot[cur], bb.s.seq[cur], Lmax, 1, cfg->bos, step, n, Lmax, st));
       SBK_TRY(sbk::log_softmax_rows(lb.logits, lb.logits, n, V, cfg->lm_temperature, cfg->lm_weight, st));
     }
+    const int32_t* win = nullptr;
+    if (window > 0) {  // attention peaks of this step (the last decoder layer's head-averaged cross-attention)
+      SBK_TRY(sbk::cross_attn_avg_probs(d.q, d.ckv[W->n_layers - 1], enc_len, bb.attn_avg, n, T, dm, W->nhead, beam, st));
+      SBK_LAUNCH(attn_peak_kernel, dim3(n), dim3(256), 0, st, (const float*)bb.attn_avg, (const float*)bb.peak_val[cur],
+                 (const int32_t*)bb.peak_pos[cur], (const int32_t*)bb.s.parent, bb.peak_val[cur ^ 1], bb.peak_pos[cur ^ 1],
+                 bb.win, T, step);
+      SBK_TRY(sbk::launch_status("attn_peak"));
+      win = bb.win + 2 * step;
+    }
     if (ctc) {
       if (side && (psi_aside || step > 0)) SBK_HIP(hipStreamWaitEvent(st, side->join, 0));  // helper-stream work done
       if (!psi_aside)
         SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[cur], bb.s.tokens[cur], enc_len, bb.psi, B, T, V, beam, step,
-                                  cfg->blank, cfg->eos, st));
+                                  cfg->blank, cfg->eos, st, win, window));
       if (cfg->ctc_candidates > 0) {  // CTC as a partial scorer: only the top candidates of every hypothesis are scored
         SBK_TRY(sbk::am_only(bb.am, bb.comb, n, V, cfg->eos, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
                              cfg->minus_inf, bb.am_max, extra, st, cfg->utt_min_steps, beam, step));
@@ -1167,7 +1246,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
         SBK_HIP(hipStreamWaitEvent(cst, side->fork, 0));
       }
       SBK_TRY(sbk::ctc_advance(bb.ctc_x, bb.phi[cur], bb.psi, bb.s.parent, bb.s.tokens[cur ^ 1], bb.s.tokens[cur],
-                               bb.phi[cur ^ 1], bb.psi_prev[cur ^ 1], n, T, V, beam, step, cfg->blank, cst));
+                               bb.phi[cur ^ 1], bb.psi_prev[cur ^ 1], n, T, V, beam, step, cfg->blank, cst, win, window));
       if (psi_aside)
         SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[cur ^ 1], bb.s.tokens[cur ^ 1], enc_len, bb.psi, B, T, V, beam,
                                   step + 1, cfg->blank, cfg->eos, pst));
@@ -1189,7 +1268,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   // graph_mode 1: two consecutive steps (the double-buffered tables flip back after two) are captured once
   // into a hipGraph and replayed; 2: the same device-side step counter with plain launches (tests, fallback).
   int graph_mode = cfg->graph_mode;
-  if (graph_mode && (side || sbk::prof_enabled() || T > 900 || cfg->max_steps < 2 || pos_off > 0 || cfg->first_bias)) graph_mode = 0;
+  if (graph_mode && (side || sbk::prof_enabled() || T > 900 || cfg->max_steps < 2 || pos_off > 0 || cfg->first_bias || window > 0)) graph_mode = 0;
   if (graph_mode) {
     struct Scope {  // the step source is per host thread; never leave it set
       ~Scope() {

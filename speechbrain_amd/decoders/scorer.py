@@ -12,11 +12,13 @@ class BaseScorerInterface:
 
 
 class CTCScorer(BaseScorerInterface):
-    """scorer.py:108-255: ctc_fc = the CTC output Linear; blank_index / eos_index as in the recipe."""
+    """scorer.py:108-255: ctc_fc = the CTC output Linear; blank_index / eos_index as in the recipe;
+    ``ctc_window_size`` > 0 restricts the scored frames of a step to a window around the attention peaks
+    (ctc.py:189-200; csrc/search.hip keeps the running peaks of the last decoder layer's cross-attention)."""
 
     def __init__(self, ctc_fc, blank_index, eos_index, ctc_window_size=0):
-        if ctc_window_size != 0:
-            raise NotImplementedError("attention-windowed CTC scoring (ctc_window_size > 0) is not implemented")
+        if ctc_window_size < 0:
+            raise ValueError("ctc_window_size must be >= 0")
         self.ctc_fc, self.blank_index, self.eos_index = ctc_fc, blank_index, eos_index
         self.ctc_window_size = ctc_window_size
 

@@ -223,6 +223,7 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
         self.blank_index = 0
         self.ctc_fc = None
         self.ctc_candidates = 0  # > 0: CTC is a partial scorer over that many candidates per hypothesis
+        self.ctc_window_size = 0
         self.lm, self.lm_weight, self.lm_temperature = None, 0.0, 1.0
         if scorer is not None:
             if scorer.weights["transformerlm"] != 0.0 and "transformerlm" in scorer.full_scorers:
@@ -238,6 +239,7 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
                 self.ctc_weight = scorer.weights["ctc"]
                 self.attn_weight = 1.0 - self.ctc_weight
                 self.blank_index, self.ctc_fc = ctc.blank_index, ctc.ctc_fc
+                self.ctc_window_size = int(getattr(ctc, "ctc_window_size", 0))
                 if "ctc" in scorer.partial_scorers:  # scorer.py:1287-1291
                     self.ctc_candidates = max(1, int(beam_size * scorer.scorer_beam_scale))
         if self.attn_weight <= 0:
@@ -250,11 +252,13 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
             self._lm_handle = self.lm.handle()  # keeps the pointed-to weight table alive during the call
             lm = dict(lm=ctypes.pointer(self._lm_handle.W), lm_weight=self.lm_weight,
                       lm_temperature=self.lm_temperature)
-        return native.SearchConfig(**lm, topk=self.topk if self.return_topk else 1, graph_mode=int(self.graph_mode),
+        return native.SearchConfig(**lm, topk=self.topk if self.return_topk else 1,
+                                   graph_mode=0 if self.ctc_window_size else int(self.graph_mode),
                                    bos=self.bos_index, eos=self.eos_index, blank=self.blank_index, beam=self.beam_size,
                                    min_steps=mn, max_steps=mx, length_normalization=int(self.length_normalization),
                                    using_eos_threshold=int(self.using_eos_threshold), check_every=self.check_every,
-                                   overlap_ctc=int(self.overlap_ctc), ctc_candidates=int(self.ctc_candidates),
+                                   overlap_ctc=0 if self.ctc_window_size else int(self.overlap_ctc),
+                                   ctc_candidates=int(self.ctc_candidates), ctc_window_size=int(self.ctc_window_size),
                                    ctc_weight=self.ctc_weight, temperature=self.temperature,
                                    eos_threshold=self.eos_threshold, minus_inf=self.minus_inf)
 
@@ -282,6 +286,8 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
         batches the per-step GEMMs otherwise see a few hundred rows and cannot fill the chip."""
         if self.return_topk:
             raise NotImplementedError("forward_group returns the best hypothesis per utterance (return_topk = False)")
+        if self.ctc_window_size and len(items) > 1:
+            raise NotImplementedError("the CTC attention window takes its frame range over the whole batch: no grouped search")
         if len(items) == 1 and ratios is None:
             return [self.forward(*items[0])]
         dev = items[0][0].device

@@ -63,7 +63,7 @@ class SearchConfig(ctypes.Structure):  # sbk_search_config
                 ("eos_threshold", c_float), ("minus_inf", c_float), ("lm_weight", c_float), ("lm_temperature", c_float),
                 ("lm", POINTER(LMWeights)), ("topk", c_int32), ("utt_min_steps", c_void_p),
                 ("utt_max_steps", c_void_p), ("graph_mode", c_int32), ("ctc_candidates", c_int32),
-                ("prompt", c_void_p), ("prompt_len", c_int32), ("temperature_post", c_int32), ("logit_bias", c_void_p),
+                ("ctc_window_size", c_int32), ("prompt", c_void_p), ("prompt_len", c_int32), ("temperature_post", c_int32), ("logit_bias", c_void_p),
                 ("first_bias", c_void_p), ("probe_pos", c_int32), ("probe_token", c_int32), ("out_probe", c_void_p)]
 
 

@@ -111,6 +111,33 @@ def test_golden_partial_ctc_scorer(backend, scale, key):
     assert float((lens.cpu() - torch.from_numpy(g[f"partial{key}_lens"])).abs().max()) <= 1e-6
 
 
+@pytest.mark.parametrize("wsize", [2, 5])
+def test_golden_ctc_attention_window(backend, wsize):
+    """CTCScorer(ctc_window_size=w) (scorer.py:183-187, ctc.py:189-200): the frames scored at a step are those within w
+    of the attention peaks -- arg-max over the decoded positions of the last decoder layer's head-averaged
+    cross-attention, min / max over the whole batch, exactly as the reference evaluates it for a transformer decoder.
+    The reference's own results (window 2 decodes something else than the unwindowed scorer) must be reproduced."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
+
+    g, mods = build("tiny_ctc", dev)
+    beam, eos_thr = int(g["cfg"][6]), bool(g["cfg"][7])
+    ctc_w, max_ratio, min_ratio = [float(v) for v in g["cfgf"]]
+    wl = torch.from_numpy(g["wav_lens"]).to(dev)
+    enc_ref = torch.from_numpy(g["enc_out"]).to(dev)
+    scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2, ctc_window_size=wsize)],
+                           weights={"ctc": ctc_w})
+    bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                    min_decode_ratio=min_ratio, max_decode_ratio=max_ratio, beam_size=beam,
+                                    using_eos_threshold=eos_thr, length_normalization=True, scorer=scorer)
+    hyps, lens, scores, _ = bs(enc_ref, wl)
+    assert hyps == hyps_of(g[f"window{wsize}_hyps"])
+    if wsize == 2:
+        assert hyps != hyps_of(g["beam_hyps"])  # (the window matters)
+    assert float((scores.cpu() - torch.from_numpy(g[f"window{wsize}_scores"])).abs().max()) <= 1e-4
+    assert float((lens.cpu() - torch.from_numpy(g[f"window{wsize}_lens"])).abs().max()) <= 1e-6
+
+
 def test_waveform_to_tokens_vs_oracle(backend):
     """EncoderDecoderASR.transcribe_batch on padded waveforms vs the oracle's whole path."""
     nat, dev = backend

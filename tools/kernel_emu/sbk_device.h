@@ -114,6 +114,12 @@ static inline int atomicMax(int* p, int v) {
   }
   return o;
 }
+static inline int atomicMin(int* p, int v) {
+  int o = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (o > v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+  }
+  return o;
+}
 static inline int atomicMaxUnused_(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 
 namespace sbk {
