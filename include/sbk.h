@@ -160,6 +160,26 @@ int sbk_gemm_nt_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, const
                      int ldr, float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
                      int rows_per_seq, sbk_stream_t stream);
 
+/* The same contraction with fp16 operands (v_mfma_f32_32x32x16_f16; A rounded to nearest even on its way into LDS, Wh =
+ * the weights converted once by sbk_f32_to_f16).  fp16 has 3 more mantissa bits than bf16 and a narrower range
+ * (|x| <= 65504): the tolerance against the fp32 product is 2^-10 relative per operand. */
+int sbk_gemm_nt_f16(const float* A, int lda, const uint16_t* Wh, int ldw, const float* bias, const float* residual,
+                    int ldr, float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
+                    int rows_per_seq, sbk_stream_t stream);
+int sbk_f32_to_f16(const float* x, uint16_t* y, long n, sbk_stream_t stream);
+
+/* fp8 (OCP e4m3fn) operands on v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulation, per-tensor scales:
+ *   C = epilogue( (a_absmax/448 * w_scale) * ( e4m3(A * 448/a_absmax) . Wq^T ) )
+ * Wq [N,K] = e4m3(W / w_scale) (sbk_f32_to_fp8 with mul = 1/w_scale, w_scale = max|W| / 448); a_absmax = DEVICE scalar
+ * max|A| (sbk_absmax_f32: no host round trip).  K % 16 == 0, ldw % 16 == 0.  e4m3 keeps 3 mantissa bits: expect ~2-3 %
+ * relative RMS error against the fp32 product (tests/test_kernels.py states the bound).  The non-scaled fp8 MFMA runs
+ * at the bf16 rate, so with fp32 activations in HBM this path saves only the weights' bytes. */
+int sbk_gemm_nt_fp8(const float* A, int lda, const float* a_absmax, const uint8_t* Wq, int ldw, float w_scale,
+                    const float* bias, const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
+                    float alpha, const int32_t* seq_len, int rows_per_seq, sbk_stream_t stream);
+int sbk_f32_to_fp8(const float* x, uint8_t* y, long n, float mul, sbk_stream_t stream);
+int sbk_absmax_f32(const float* x, long n, float* out, sbk_stream_t stream);
+
 /* Same contraction for few-row operands (M <= 512: the beams x utterances rows of a decoder step):
  * waves own 32-column tiles and K slices, partial sums go through `workspace` (floats; the more,
  * the more K slices, at most 8*M*N is useful) and are combined in a fixed order. */

@@ -14,6 +14,7 @@
 
 #include <map>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -109,7 +110,7 @@ __device__ __forceinline__ void tile_epilogue_32x32(const GemmArgs& g, float (&v
 // 16x the kernel is bound by the fp32 A / C traffic (4 B per element each), not by the matrix pipe.
 struct GemmBf16Args {
   const float* A;
-  const unsigned short* W;  // [N,K] bf16 bits
+  const void* W;  // [N,K] reduced-precision bits: bf16 / fp16 (2 bytes) or fp8 e4m3 (1 byte)
   const float* bias;
   const float* R;
   float* C;
@@ -117,17 +118,27 @@ struct GemmBf16Args {
   float alpha;
   const int32_t* seq_len;
   int rows_per_seq;
+  // fp8 only: A is multiplied by 448 / a_absmax[0] (device scalar) before it is rounded to e4m3, the accumulators by
+  // a_absmax[0] / 448 * w_scale afterwards (w_scale = the weight's own absmax / 448, applied when it was quantised)
+  const float* a_absmax;
+  float w_scale;
 };
 
-template <int BM, int BN>
-__global__ void __launch_bounds__(256) gemm_nt_bf16_kernel(GemmBf16Args g) {
-  constexpr int BK = 32, PITCH = BK + 8;  // bf16 elements per LDS row
+// DT: 0 = bf16, 1 = fp16 (operands 8 x 16 bit per lane), 2 = fp8 e4m3 (8 x 8 bit per lane); all on the
+// 32x32x16 matrix-core shape with fp32 accumulation.
+template <int BM, int BN, int DT>
+__global__ void __launch_bounds__(256) gemm_nt_lp_kernel(GemmBf16Args g) {
+  using Elem = typename std::conditional<DT == 2, unsigned char, unsigned short>::type;
+  constexpr int ES = (int)sizeof(Elem);
+  constexpr int BK = 32, PITCH = BK + 16 / ES;  // elements per LDS row: 16 bytes of padding
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int APER = BM * BK / 4 / 256;  // float4 slots of the A panel per thread
-  constexpr int WPER = BN * BK / 8 / 256;  // 16-byte (8 x bf16) slots of the W panel per thread
-  static_assert(APER >= 1 && WPER >= 1, "tile too small for 256 threads");
-  __shared__ __attribute__((aligned(16))) unsigned short As[BM][PITCH];
-  __shared__ __attribute__((aligned(16))) unsigned short Ws[BN][PITCH];
+  constexpr int APER = BM * BK / 4 / 256;          // float4 slots of the A panel per thread
+  constexpr int WV = 16 / ES;                      // W elements per 16-byte load
+  constexpr int WSLOTS = BN * BK / WV;             // 16-byte slots of the W panel
+  constexpr int WPER = (WSLOTS + 255) / 256;
+  static_assert(APER >= 1, "tile too small for 256 threads");
+  __shared__ __attribute__((aligned(16))) Elem As[BM][PITCH];
+  __shared__ __attribute__((aligned(16))) Elem Ws[BN][PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   int bx = blockIdx.x, by = blockIdx.y;
@@ -142,6 +153,12 @@ __global__ void __launch_bounds__(256) gemm_nt_bf16_kernel(GemmBf16Args g) {
   }
   const int m0 = by * BM, n0 = bx * BN;
   const int lrow = lane & 31, kh = lane >> 5;
+  float a_mul = 1.0f, out_mul = 1.0f;
+  if constexpr (DT == 2) {
+    const float amax = fmaxf(g.a_absmax ? g.a_absmax[0] : 448.0f, 1e-30f);
+    a_mul = 448.0f / amax;
+    out_mul = amax / 448.0f * g.w_scale;
+  }
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -152,51 +169,50 @@ __global__ void __launch_bounds__(256) gemm_nt_bf16_kernel(GemmBf16Args g) {
 
   float4 ra[APER];
   uint4 rw[WPER];
+  const Elem* Wp = reinterpret_cast<const Elem*>(g.W);
   const bool interior = m0 + BM <= g.M && n0 + BN <= g.N && (g.K % BK) == 0;  // uniform: unpredicated panel loads
-  auto fetch = [&](int k0) {
-    if (interior) {
-#pragma unroll
-      for (int i = 0; i < APER; ++i) {
-        const int s = tid + i * 256;
-        ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + s / (BK / 4)) * g.lda + k0 + (s % (BK / 4)) * 4);
-      }
-#pragma unroll
-      for (int i = 0; i < WPER; ++i) {
-        const int s = tid + i * 256;
-        rw[i] = *reinterpret_cast<const uint4*>(g.W + (size_t)(n0 + s / (BK / 8)) * g.ldw + k0 + (s % (BK / 8)) * 8);
-      }
-      return;
-    }
+  auto fetch = [&](int k0) SBK_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < APER; ++i) {
       const int s = tid + i * 256, rr = s / (BK / 4), c = (s % (BK / 4)) * 4;
       const int gr = m0 + rr, gk = k0 + c;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < g.M && gk < g.K) v = *reinterpret_cast<const float4*>(g.A + (size_t)gr * g.lda + gk);  // K % 8 == 0
+      if (interior || (gr < g.M && gk < g.K)) v = *reinterpret_cast<const float4*>(g.A + (size_t)gr * g.lda + gk);  // K % 8 == 0
       ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < WPER; ++i) {
-      const int s = tid + i * 256, rr = s / (BK / 8), c = (s % (BK / 8)) * 8;
+      const int s = tid + i * 256, rr = s / (BK / WV), c = (s % (BK / WV)) * WV;
       const int gr = n0 + rr, gk = k0 + c;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (gr < g.N && gk < g.K) v = *reinterpret_cast<const uint4*>(g.W + (size_t)gr * g.ldw + gk);
+      if (s < WSLOTS && (interior || (gr < g.N && gk < g.K))) v = *reinterpret_cast<const uint4*>(Wp + (size_t)gr * g.ldw + gk);
       rw[i] = v;
     }
   };
-  auto commit = [&]() {
+  auto commit = [&]() SBK_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < APER; ++i) {
       const int s = tid + i * 256, rr = s / (BK / 4), c = (s % (BK / 4)) * 4;
-      uint2 p;
-      p.x = (unsigned)sbk::f32_to_bf16(ra[i].x) | ((unsigned)sbk::f32_to_bf16(ra[i].y) << 16);
-      p.y = (unsigned)sbk::f32_to_bf16(ra[i].z) | ((unsigned)sbk::f32_to_bf16(ra[i].w) << 16);
-      *reinterpret_cast<uint2*>(&As[rr][c]) = p;
+      if constexpr (DT == 0) {
+        uint2 p;
+        p.x = (unsigned)sbk::f32_to_bf16(ra[i].x) | ((unsigned)sbk::f32_to_bf16(ra[i].y) << 16);
+        p.y = (unsigned)sbk::f32_to_bf16(ra[i].z) | ((unsigned)sbk::f32_to_bf16(ra[i].w) << 16);
+        *reinterpret_cast<uint2*>(&As[rr][c]) = p;
+      } else if constexpr (DT == 1) {
+        uint2 p;
+        p.x = (unsigned)sbk::f32_to_f16(ra[i].x) | ((unsigned)sbk::f32_to_f16(ra[i].y) << 16);
+        p.y = (unsigned)sbk::f32_to_f16(ra[i].z) | ((unsigned)sbk::f32_to_f16(ra[i].w) << 16);
+        *reinterpret_cast<uint2*>(&As[rr][c]) = p;
+      } else {
+        const unsigned p = (unsigned)sbk::f32x2_to_fp8(ra[i].x * a_mul, ra[i].y * a_mul) |
+                           ((unsigned)sbk::f32x2_to_fp8(ra[i].z * a_mul, ra[i].w * a_mul) << 16);
+        *reinterpret_cast<unsigned*>(&As[rr][c]) = p;
+      }
     }
 #pragma unroll
     for (int i = 0; i < WPER; ++i) {
-      const int s = tid + i * 256, rr = s / (BK / 8), c = (s % (BK / 8)) * 8;
-      *reinterpret_cast<uint4*>(&Ws[rr][c]) = rw[i];
+      const int s = tid + i * 256, rr = s / (BK / WV), c = (s % (BK / WV)) * WV;
+      if (s < WSLOTS) *reinterpret_cast<uint4*>(&Ws[rr][c]) = rw[i];
     }
   };
   fetch(0);
@@ -206,15 +222,37 @@ __global__ void __launch_bounds__(256) gemm_nt_bf16_kernel(GemmBf16Args g) {
     if (k0 + BK < g.K) fetch(k0 + BK);
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 16) {
-      sbk::bf16x8 a[TM], b[TN];
+      if constexpr (DT == 2) {
+        sbk::fp8x8 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const sbk::bf16x8*>(&As[wm0 + i * 32 + lrow][ks + kh * 8]);
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const sbk::fp8x8*>(&As[wm0 + i * 32 + lrow][ks + kh * 8]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const sbk::bf16x8*>(&Ws[wn0 + j * 32 + lrow][ks + kh * 8]);
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const sbk::fp8x8*>(&Ws[wn0 + j * 32 + lrow][ks + kh * 8]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(a[i], b[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_fp8(a[i], b[j], acc[i][j]);
+      } else if constexpr (DT == 1) {
+        sbk::f16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const sbk::f16x8*>(&As[wm0 + i * 32 + lrow][ks + kh * 8]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const sbk::f16x8*>(&Ws[wn0 + j * 32 + lrow][ks + kh * 8]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_f16(a[i], b[j], acc[i][j]);
+      } else {
+        sbk::bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const sbk::bf16x8*>(&As[wm0 + i * 32 + lrow][ks + kh * 8]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const sbk::bf16x8*>(&Ws[wn0 + j * 32 + lrow][ks + kh * 8]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(a[i], b[j], acc[i][j]);
+      }
     }
     __syncthreads();
   }
@@ -229,7 +267,7 @@ __global__ void __launch_bounds__(256) gemm_nt_bf16_kernel(GemmBf16Args g) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (row >= g.M) continue;
-        float v = apply_act(acc[i][j][r] + bv, g.act) * g.alpha;
+        float v = apply_act(acc[i][j][r] * out_mul + bv, g.act) * g.alpha;
         if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
         if (g.R) v += g.R[(size_t)row * g.ldr + col];
         g.C[(size_t)row * g.ldc + col] = v;
@@ -240,6 +278,22 @@ __global__ void __launch_bounds__(256) gemm_nt_bf16_kernel(GemmBf16Args g) {
 
 __global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = sbk::f32_to_bf16(x[i]);
+}
+__global__ void __launch_bounds__(256) f32_to_f16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = sbk::f32_to_f16(x[i]);
+}
+// y = e4m3(x * mul), two values per thread (n even)
+__global__ void __launch_bounds__(256) f32_to_fp8_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n2,
+                                                         float mul) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256)
+    y[i] = sbk::f32x2_to_fp8(x[2 * i] * mul, x[2 * i + 1] * mul);
+}
+// out[0] = max |x| (non-negative floats order like their bit patterns: atomicMax on the int image; out zeroed by the caller)
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int* __restrict__ out, long n) {
+  float m = 0.0f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  m = sbk::wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (int)__float_as_uint(m));
 }
 
 // Register-staged panel: global -> registers (issued early, in flight under the MFMAs of the previous
@@ -1549,6 +1603,34 @@ extern "C" int sbk_f32_to_bf16(const float* x, uint16_t* y, long n, sbk_stream_t
   return sbk::launch_status("sbk_f32_to_bf16");
 }
 
+namespace {
+int launch_lp(int dt, const float* A, int lda, const void* Wq, int ldw, const float* bias, const float* residual, int ldr,
+              float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq,
+              const float* a_absmax, float w_scale, hipStream_t st) {
+  GemmBf16Args g{A, Wq, bias, residual, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1,
+                 a_absmax, w_scale};
+  const long tiles128 = (long)sbk::cdiv(M, 128) * sbk::cdiv(N, 128);
+  const char* name = dt == 0 ? "gemm_nt_bf16" : (dt == 1 ? "gemm_nt_f16" : "gemm_nt_fp8");
+  sbk::ProfScope prof(name, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N) + (dt == 2 ? 1.0 : 2.0) * (double)N * K, st);
+  const dim3 g128(sbk::cdiv(N, 128), sbk::cdiv(M, 128)), g64(sbk::cdiv(N, 64), sbk::cdiv(M, 64)), block(256);
+#define SBK_LP(DT)                                                           \
+  if (tiles128 >= 256) {                                                     \
+    SBK_LAUNCH((gemm_nt_lp_kernel<128, 128, DT>), g128, block, 0, st, g);    \
+  } else {                                                                   \
+    SBK_LAUNCH((gemm_nt_lp_kernel<64, 64, DT>), g64, block, 0, st, g);       \
+  }
+  if (dt == 0) {
+    SBK_LP(0)
+  } else if (dt == 1) {
+    SBK_LP(1)
+  } else {
+    SBK_LP(2)
+  }
+#undef SBK_LP
+  return sbk::launch_status(name);
+}
+}  // namespace
+
 extern "C" int sbk_gemm_nt_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, const float* bias,
                                 const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
                                 float alpha, const int32_t* seq_len, int rows_per_seq, sbk_stream_t stream) {
@@ -1560,15 +1642,66 @@ extern "C" int sbk_gemm_nt_bf16(const float* A, int lda, const uint16_t* Wb, int
   SBK_REQUIRE(!residual || ldr >= N, "gemm_bf16: residual stride");
   SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_bf16: unknown activation %d", act);
   SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm_bf16: seq_len given without rows_per_seq");
-  GemmBf16Args g{A, reinterpret_cast<const unsigned short*>(Wb), bias, residual, C, lda, ldw, ldr, ldc, M, N, K, act, alpha,
-                 seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
+  return launch_lp(0, A, lda, Wb, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, nullptr, 1.0f,
+                   sbk::as_stream(stream));
+}
+
+extern "C" int sbk_gemm_nt_f16(const float* A, int lda, const uint16_t* Wh, int ldw, const float* bias,
+                               const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
+                               float alpha, const int32_t* seq_len, int rows_per_seq, sbk_stream_t stream) {
+  if (M == 0 || N == 0) return 0;
+  SBK_REQUIRE(A && Wh && C, "gemm_f16: null operand");
+  SBK_REQUIRE(M >= 0 && N >= 0 && K > 0 && K % 8 == 0, "gemm_f16: bad shape M=%d N=%d K=%d (K must be a multiple of 8)", M, N, K);
+  SBK_REQUIRE(lda > 0 && ldw >= K && ldc >= N && lda % 4 == 0 && ldw % 8 == 0, "gemm_f16: leading dimensions");
+  SBK_REQUIRE(sbk::aligned16(A) && sbk::aligned16(Wh), "gemm_f16: operands must be 16-byte aligned");
+  SBK_REQUIRE(!residual || ldr >= N, "gemm_f16: residual stride");
+  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_f16: unknown activation %d", act);
+  SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm_f16: seq_len given without rows_per_seq");
+  return launch_lp(1, A, lda, Wh, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, nullptr, 1.0f,
+                   sbk::as_stream(stream));
+}
+
+extern "C" int sbk_gemm_nt_fp8(const float* A, int lda, const float* a_absmax, const uint8_t* Wq, int ldw, float w_scale,
+                               const float* bias, const float* residual, int ldr, float* C, int ldc, int M, int N, int K,
+                               int act, float alpha, const int32_t* seq_len, int rows_per_seq, sbk_stream_t stream) {
+  if (M == 0 || N == 0) return 0;
+  SBK_REQUIRE(A && Wq && C && a_absmax, "gemm_fp8: null operand");
+  SBK_REQUIRE(M >= 0 && N >= 0 && K > 0 && K % 16 == 0, "gemm_fp8: bad shape M=%d N=%d K=%d (K must be a multiple of 16)", M, N, K);
+  SBK_REQUIRE(lda > 0 && ldw >= K && ldc >= N && lda % 4 == 0 && ldw % 16 == 0, "gemm_fp8: leading dimensions");
+  SBK_REQUIRE(sbk::aligned16(A) && sbk::aligned16(Wq), "gemm_fp8: operands must be 16-byte aligned");
+  SBK_REQUIRE(!residual || ldr >= N, "gemm_fp8: residual stride");
+  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_fp8: unknown activation %d", act);
+  SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm_fp8: seq_len given without rows_per_seq");
+  SBK_REQUIRE(w_scale > 0.0f, "gemm_fp8: w_scale must be positive");
+  return launch_lp(2, A, lda, Wq, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, a_absmax, w_scale,
+                   sbk::as_stream(stream));
+}
+
+extern "C" int sbk_f32_to_f16(const float* x, uint16_t* y, long n, sbk_stream_t stream) {
+  if (n == 0) return 0;
+  SBK_REQUIRE(x && y && n > 0, "f32_to_f16: bad arguments");
+  const long blocks = (n + 255) / 256;
+  SBK_LAUNCH(f32_to_f16_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, sbk::as_stream(stream), x,
+             reinterpret_cast<unsigned short*>(y), n);
+  return sbk::launch_status("sbk_f32_to_f16");
+}
+
+// y = e4m3(x * mul) (OCP e4m3fn, round to nearest even, saturating at +-448); n even
+extern "C" int sbk_f32_to_fp8(const float* x, uint8_t* y, long n, float mul, sbk_stream_t stream) {
+  if (n == 0) return 0;
+  SBK_REQUIRE(x && y && n > 0 && n % 2 == 0, "f32_to_fp8: bad arguments (n must be even)");
+  const long blocks = (n / 2 + 255) / 256;
+  SBK_LAUNCH(f32_to_fp8_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, sbk::as_stream(stream), x,
+             reinterpret_cast<unsigned short*>(y), n / 2, mul);
+  return sbk::launch_status("sbk_f32_to_fp8");
+}
+
+// out[0] = max |x[i]| (device float; the activation scale of sbk_gemm_nt_fp8)
+extern "C" int sbk_absmax_f32(const float* x, long n, float* out, sbk_stream_t stream) {
+  SBK_REQUIRE(x && out && n > 0, "absmax: bad arguments");
   hipStream_t st = sbk::as_stream(stream);
-  const long tiles128 = (long)sbk::cdiv(M, 128) * sbk::cdiv(N, 128);
-  sbk::ProfScope prof("gemm_nt_bf16", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N) + 2.0 * (double)N * K, st);
-  if (tiles128 >= 256) {
-    SBK_LAUNCH((gemm_nt_bf16_kernel<128, 128>), dim3(sbk::cdiv(N, 128), sbk::cdiv(M, 128)), dim3(256), 0, st, g);
-  } else {
-    SBK_LAUNCH((gemm_nt_bf16_kernel<64, 64>), dim3(sbk::cdiv(N, 64), sbk::cdiv(M, 64)), dim3(256), 0, st, g);
-  }
-  return sbk::launch_status("sbk_gemm_nt_bf16");
+  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return sbk::fail(1, "absmax: memset");
+  const long blocks = (n + 255) / 256;
+  SBK_LAUNCH(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, x, reinterpret_cast<int*>(out), n);
+  return sbk::launch_status("sbk_absmax_f32");
 }

@@ -42,6 +42,24 @@ __device__ __forceinline__ bf16x8 cvt_bf16x8(const float (&x)[8]) {
   return r;
 }
 
+// fp16 operands (same shape and lane mapping as the bf16 form), fp32 accumulate
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+__device__ __forceinline__ f32x16 mfma_32x32x16_f16(f16x8 a, f16x8 b, f32x16 acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned short f32_to_f16(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }  // RNE
+// OCP fp8 e4m3 operands: 8 per lane in one 64-bit register, fp32 accumulate (the non-scaled fp8 MFMA runs at the bf16 rate)
+using fp8x8 = long;
+__device__ __forceinline__ f32x16 mfma_32x32x16_fp8(fp8x8 a, fp8x8 b, f32x16 acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, acc, 0, 0, 0);
+}
+// two floats -> two e4m3 bytes (low byte = a), round to nearest even, saturating at +-448 (v_cvt_pk_fp8_f32)
+__device__ __forceinline__ unsigned short f32x2_to_fp8(float a, float b) {
+  a = fminf(fmaxf(a, -448.0f), 448.0f);
+  b = fminf(fmaxf(b, -448.0f), 448.0f);
+  return (unsigned short)(__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffff);
+}
+
 // eight bf16 bit patterns -> one MFMA operand
 using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
 __device__ __forceinline__ bf16x8 pack_bf16x8(const unsigned short (&h)[8]) {

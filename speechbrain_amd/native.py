@@ -92,6 +92,11 @@ def _declare(lib):
         "sbk_gemm_nt_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_f32_to_bf16": ([p, p, ctypes.c_long, p], c_int),
         "sbk_gemm_nt_bf16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
+        "sbk_gemm_nt_f16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
+        "sbk_f32_to_f16": ([p, p, ctypes.c_long, p], c_int),
+        "sbk_gemm_nt_fp8": ([p, i, p, p, i, f, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
+        "sbk_f32_to_fp8": ([p, p, ctypes.c_long, f, p], c_int),
+        "sbk_absmax_f32": ([p, ctypes.c_long, p, p], c_int),
         "sbk_gemm_ln_nt_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, f, i, f, p], c_int),
         "sbk_gemm_nt_splitk_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, ctypes.c_size_t, p], c_int),
         "sbk_conv_block_f32": ([p, p, p, p, p, p, i, i, i, i, i, f, f, p], c_int),
@@ -183,7 +188,8 @@ _tls = threading.local()
 
 
 def precision() -> str:
-    """"fp32" (parity path, default) or "bf16" (opt-in: bf16 operands / fp32 accumulation for the large GEMMs)."""
+    """"fp32" (parity path, default) or an opt-in reduced-precision operand type for the large GEMMs, all with fp32
+    accumulation: "bf16" (also the bf16 attention kernel), "fp16", "fp8" (e4m3, per-tensor scales)."""
     return getattr(_tls, "precision", "fp32")
 
 
@@ -191,8 +197,8 @@ def precision() -> str:
 def precision_scope(p):
     """Per host thread (the batches in flight of ConcurrentTranscriber each carry their own)."""
     p = p or "fp32"
-    if p not in ("fp32", "bf16"):
-        raise NotImplementedError(f"precision {p!r}: 'fp32' (parity) and 'bf16' (fast encoder GEMMs) are implemented")
+    if p not in ("fp32", "bf16", "fp16", "fp8"):
+        raise NotImplementedError(f"precision {p!r}: 'fp32' (parity) or the opt-in 'bf16' / 'fp16' / 'fp8' GEMM operands")
     old = precision()
     _tls.precision = p
     try:
@@ -212,8 +218,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_
     K = a.shape[-1]
     a2 = a.reshape(-1, K)
     M, N = a2.shape[0], w.shape[0]
-    if precision() == "bf16" and M >= 256 and K % 8 == 0 and w.is_contiguous():
-        return gemm_nt_bf16(a, w, bias, residual, act, alpha, seq_len, rows_per_seq, out=out)  # opt-in fast path
+    if precision() != "fp32" and M >= 256 and K % (16 if precision() == "fp8" else 8) == 0 and w.is_contiguous():
+        return gemm_nt_bf16(a, w, bias, residual, act, alpha, seq_len, rows_per_seq, out=out, kind=precision())  # opt-in fast path
     _dev_ok(a2, w, bias, residual)
     _f32(a2), _f32(w)
     if out is None:
@@ -249,27 +255,35 @@ def gemm_nt_rows(a_flat: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor
     return out
 
 
-_BF16_WEIGHTS = {}  # id(weight tensor) -> (weakref to it, _version, bf16 copy): converted once per parameter
+_BF16_WEIGHTS = {}  # (id(weight tensor), kind) -> (weakref to it, _version, reduced-precision copy[, scale])
 _BF16_LOCK = threading.Lock()
 
 
-def bf16_weight(w: torch.Tensor) -> torch.Tensor:
-    """The bf16 image of a weight matrix for sbk_gemm_nt_bf16, cached for the lifetime of THAT tensor object: the entry
-    holds a weak reference to its source and is used only while ``ref() is w`` and the version counter is unchanged
-    (a freed model's addresses are commonly handed to the next model of the same shapes by the caching allocator, and
-    load_state_dict leaves ``_version`` alike -- a (data_ptr, version, shape) key would then serve the OLD model's
-    weights).  Entries die with their tensor (weakref callback); insert / evict under a lock (worker threads)."""
-    key = id(w)
+def lp_weight(w: torch.Tensor, kind: str = "bf16"):
+    """The reduced-precision image of a weight matrix ("bf16" / "fp16": int16 bits; "fp8": (uint8 e4m3 bits, w_scale)),
+    cached for the lifetime of THAT tensor object: the entry holds a weak reference to its source and is used only while
+    ``ref() is w`` and the version counter is unchanged (a freed model's addresses are commonly handed to the next
+    model of the same shapes by the caching allocator, and load_state_dict leaves ``_version`` alike -- a (data_ptr,
+    version, shape) key would then serve the OLD model's weights).  Entries die with their tensor (weakref callback);
+    insert / evict under a lock (worker threads)."""
+    key = (id(w), kind)
     with _BF16_LOCK:
         hit = _BF16_WEIGHTS.get(key)
         if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].device == w.device:
-            return hit[2]
+            return hit[2] if kind != "fp8" else (hit[2], hit[3])
     lib = load()
     w2 = w.detach().contiguous()
     _dev_ok(w2)
     _f32(w2)
-    out = torch.empty(w2.shape, dtype=torch.int16, device=w.device)
-    _chk(lib.sbk_f32_to_bf16(_p(w2), _p(out), w2.numel(), _stream(w2)), "sbk_f32_to_bf16")
+    scale = None
+    if kind == "fp8":
+        scale = max(float(w2.abs().max()), 1e-30) / 448.0  # (once per weight: a host round trip at load time)
+        out = torch.empty(w2.shape, dtype=torch.uint8, device=w.device)
+        _chk(lib.sbk_f32_to_fp8(_p(w2), _p(out), w2.numel(), 1.0 / scale, _stream(w2)), "sbk_f32_to_fp8")
+    else:
+        out = torch.empty(w2.shape, dtype=torch.int16, device=w.device)
+        fn = lib.sbk_f32_to_bf16 if kind == "bf16" else lib.sbk_f32_to_f16
+        _chk(fn(_p(w2), _p(out), w2.numel(), _stream(w2)), "sbk_f32_to_" + kind)
 
     def _drop(_ref, key=key):
         with _BF16_LOCK:
@@ -278,29 +292,43 @@ def bf16_weight(w: torch.Tensor) -> torch.Tensor:
                 del _BF16_WEIGHTS[key]
 
     with _BF16_LOCK:
-        _BF16_WEIGHTS[key] = (weakref.ref(w, _drop), w._version, out)
-    return out
+        _BF16_WEIGHTS[key] = (weakref.ref(w, _drop), w._version, out, scale)
+    return out if kind != "fp8" else (out, scale)
+
+
+def bf16_weight(w: torch.Tensor) -> torch.Tensor:
+    return lp_weight(w, "bf16")
 
 
 def gemm_nt_bf16(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, seq_len=None,
-                 rows_per_seq=0, out=None):
-    """gemm_nt with bf16 operands / fp32 accumulation (opt-in fast path; `w` is the fp32 parameter, its bf16 image is
-    cached).  Falls back to the fp32 kernel for shapes the bf16 kernel does not take (K % 8 != 0)."""
+                 rows_per_seq=0, out=None, kind="bf16"):
+    """gemm_nt with reduced-precision operands / fp32 accumulation (opt-in fast path; `w` is the fp32 parameter, its
+    image of ``kind`` -- "bf16", "fp16" or "fp8" (e4m3 with per-tensor scales: the weight's at conversion time, the
+    activation's max |a| computed on the device per call) -- is cached).  Falls back to the fp32 kernel for shapes the
+    kernels do not take (K % 8 != 0; fp8: K % 16 != 0)."""
     K = a.shape[-1]
-    if K % 8 != 0:
+    if K % (16 if kind == "fp8" else 8) != 0:
         with precision_scope("fp32"):
             return gemm_nt(a, w, bias, residual, act, alpha, out=out, seq_len=seq_len, rows_per_seq=rows_per_seq)
     lib = load()
     a2 = a.reshape(-1, K)
     M, N = a2.shape[0], w.shape[0]
-    wb = bf16_weight(w)
-    _dev_ok(a2, wb, bias, residual, seq_len)
+    _dev_ok(a2, bias, residual, seq_len)
     _f32(a2)
     if out is None:
         out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
-    _chk(lib.sbk_gemm_nt_bf16(_p(a2), K, _p(wb), K, _p(bias), _p(r2), N, _p(out), N, M, N, K, act, float(alpha),
-                              _p(seq_len), int(rows_per_seq), _stream(a2)), "sbk_gemm_nt_bf16")
+    if kind == "fp8":
+        wq, w_scale = lp_weight(w, "fp8")
+        amax = torch.empty(1, dtype=torch.float32, device=a.device)
+        _chk(lib.sbk_absmax_f32(_p(a2), a2.numel(), _p(amax), _stream(a2)), "sbk_absmax_f32")
+        _chk(lib.sbk_gemm_nt_fp8(_p(a2), K, _p(amax), _p(wq), K, float(w_scale), _p(bias), _p(r2), N, _p(out), N, M, N, K,
+                                 act, float(alpha), _p(seq_len), int(rows_per_seq), _stream(a2)), "sbk_gemm_nt_fp8")
+        return out
+    wb = lp_weight(w, kind)
+    fn = lib.sbk_gemm_nt_bf16 if kind == "bf16" else lib.sbk_gemm_nt_f16
+    _chk(fn(_p(a2), K, _p(wb), K, _p(bias), _p(r2), N, _p(out), N, M, N, K, act, float(alpha),
+            _p(seq_len), int(rows_per_seq), _stream(a2)), "sbk_gemm_nt_" + kind)
     return out
 
 

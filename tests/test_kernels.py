@@ -594,3 +594,32 @@ def test_cross_attention_lds_dma_variant(backend, d_model, nhead, B, T, beam_row
         nat.load().sbk_prof_set_knob(4, 7)
     assert hyps == hyps_ref
     assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 50, 48), (300, 130, 64), (5000, 300, 80)])
+def test_gemm_fp16_and_fp8_operands(backend, M, N, K):
+    """sbk_gemm_nt_f16 / sbk_gemm_nt_fp8 (SURVEY 8b "fp16 / fp8 fast entry points"): the kernels must equal the fp32
+    product of the ROUNDED operands to fp32-summation accuracy -- fp16: round to nearest even; fp8: OCP e4m3fn with the
+    per-tensor scales max|x| / 448 (torch.float8_e4m3fn rounds the same way) -- and sit within the stated tolerance of
+    the un-rounded fp32 product: 2^-10 relative per operand for fp16, 4.5 % of the output RMS for e4m3 (3 mantissa bits)."""
+    nat, dev = backend
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.001
+    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.002
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    full = a.double() @ w.double().t()
+    # fp16
+    out = nat.gemm_nt_bf16(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_SWISH, alpha=0.5, kind="fp16")
+    ah, wh = a.half().double(), w.half().double()
+    scale = float((ah.abs() @ wh.abs().t()).max())
+    assert _md(out, r + 0.5 * F.silu(ah @ wh.t() + b).float()) <= 2e-6 * scale + 1e-5
+    assert _md(out, r + 0.5 * F.silu(full + b).float()) <= 2.0 ** -9 * scale
+    # fp8 e4m3, per-tensor scales
+    out8 = nat.gemm_nt_bf16(a.to(dev), w.to(dev), b.to(dev), None, kind="fp8")
+    sa, sw = float(a.abs().max()) / 448.0, float(w.abs().max()) / 448.0
+    a8 = (a / sa).to(torch.float8_e4m3fn).double() * sa
+    w8 = (w / sw).to(torch.float8_e4m3fn).double() * sw
+    ref8 = (a8 @ w8.t() + b).float()
+    assert _md(out8, ref8) <= 2e-6 * float((a8.abs() @ w8.abs().t()).max()) + 1e-4
+    err = (out8.cpu().double() - (full + b)).pow(2).mean().sqrt() / full.pow(2).mean().sqrt()
+    assert float(err) <= 0.045, float(err)

@@ -196,6 +196,109 @@ static inline f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 acc) {
   sbk_emu::wave_barrier();
   return acc;
 }
+// fp16 / fp8 (e4m3, OCP) operand forms: host conversions + the same contraction as the bf16 form
+static inline unsigned short f32_to_f16(float f) {  // round to nearest even
+  unsigned u;
+  memcpy(&u, &f, 4);
+  const unsigned sign = (u >> 16) & 0x8000u;
+  u &= 0x7fffffffu;
+  if (u > 0x7f800000u) return (unsigned short)(sign | 0x7e00u);
+  if (u >= 0x47800000u) return (unsigned short)(sign | 0x7c00u);  // overflow -> inf
+  if (u < 0x38800000u) {  // subnormal half (or zero)
+    if (u < 0x33000000u) return (unsigned short)sign;
+    const int e = (int)(u >> 23);
+    unsigned m = (u & 0x7fffffu) | 0x800000u;
+    const int shift = 126 - e;  // 14 .. 24
+    const unsigned half_m = m >> shift, rem = m & ((1u << shift) - 1), mid = 1u << (shift - 1);
+    unsigned r = half_m + ((rem > mid || (rem == mid && (half_m & 1))) ? 1 : 0);
+    return (unsigned short)(sign | r);
+  }
+  unsigned r = u - 0x38000000u;
+  const unsigned rem = r & 0x1fffu;
+  r >>= 13;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) ++r;
+  return (unsigned short)(sign | r);
+}
+static inline float f16_to_f32_(unsigned short h) {
+  const unsigned sign = ((unsigned)h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ffu;
+  float f;
+  if (e == 0) {
+    f = ldexpf((float)m, -24);
+  } else if (e == 31) {
+    f = m ? NAN : INFINITY;
+  } else {
+    f = ldexpf((float)(m | 0x400u), (int)e - 25);
+  }
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u |= sign;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline float fp8_to_f32_(unsigned char b) {  // e4m3fn: bias 7, no inf, 0x7f = NaN
+  const int s = b >> 7, e = (b >> 3) & 15, m = b & 7;
+  float f = e == 0 ? ldexpf((float)m, -9) : ((e == 15 && m == 7) ? NAN : ldexpf((float)(8 + m), e - 10));
+  return s ? -f : f;
+}
+static inline unsigned char f32_to_fp8_(float x) {  // nearest even, saturating at 448
+  if (x != x) return 0x7f;
+  const unsigned char s = std::signbit(x) ? 0x80 : 0;
+  float a = fabsf(x);
+  if (a > 448.0f) a = 448.0f;
+  unsigned char best = 0;
+  float bd = INFINITY;
+  for (int c = 0; c < 0x7f; ++c) {  // 127 finite magnitudes: exhaustive nearest (ties to the even code)
+    const float d = fabsf(fp8_to_f32_((unsigned char)c) - a);
+    if (d < bd || (d == bd && (c & 1) == 0)) {
+      bd = d;
+      best = (unsigned char)c;
+    }
+  }
+  return s | best;
+}
+static inline unsigned short f32x2_to_fp8(float a, float b) {
+  return (unsigned short)(f32_to_fp8_(a) | ((unsigned)f32_to_fp8_(b) << 8));
+}
+struct __attribute__((aligned(16))) f16x8 {
+  unsigned short v[8];
+};
+typedef long fp8x8;
+template <typename F>
+static inline f32x16 mfma_32x32x16_generic_(const float (&av)[8], const float (&bv)[8], f32x16 acc, F) {
+  const int l = sbk_emu::cur().lane;
+  float* A = sbk_emu::wave_buf(0);
+  float* B = sbk_emu::wave_buf(1);
+  for (int e = 0; e < 8; ++e) {
+    A[l * 8 + e] = av[e];
+    B[l * 8 + e] = bv[e];
+  }
+  sbk_emu::wave_barrier();
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+    float c = acc[r];
+    for (int kb = 0; kb < 2; ++kb)
+      for (int e = 0; e < 8; ++e) c = fmaf(A[(row + 32 * kb) * 8 + e], B[(col + 32 * kb) * 8 + e], c);
+    acc[r] = c;
+  }
+  sbk_emu::wave_barrier();
+  return acc;
+}
+static inline f32x16 mfma_32x32x16_f16(f16x8 a, f16x8 b, f32x16 acc) {
+  float av[8], bv[8];
+  for (int e = 0; e < 8; ++e) {
+    av[e] = f16_to_f32_(a.v[e]);
+    bv[e] = f16_to_f32_(b.v[e]);
+  }
+  return mfma_32x32x16_generic_(av, bv, acc, 0);
+}
+static inline f32x16 mfma_32x32x16_fp8(fp8x8 a, fp8x8 b, f32x16 acc) {
+  float av[8], bv[8];
+  for (int e = 0; e < 8; ++e) {
+    av[e] = fp8_to_f32_((unsigned char)((unsigned long)a >> (8 * e)));
+    bv[e] = fp8_to_f32_((unsigned char)((unsigned long)b >> (8 * e)));
+  }
+  return mfma_32x32x16_generic_(av, bv, acc, 0);
+}
 static inline f32x4 mfma_16x16x4(float a, float b, f32x4 acc) {
   const int l = sbk_emu::cur().lane;
   float* A = sbk_emu::wave_buf(0);
