@@ -28,11 +28,17 @@ Fbank -> norm -> CNN -> Conformer encoder -> beam search on every rank, and the 
 (token-id lists on the host).  With --gpus N each rank gets K steps of work (weak scaling): the job is N*K*128
 utterances.  At N = 1 the same code runs without the two exchanges.
 
+With --job-utts N the job is FIXED at N utterances shared by the ranks (strong scaling, BASELINE.json configs[3]);
+"rccl_world" and "per_rank" (every rank's wall time, audio seconds and batches) make a scaling run auditable.
+"parity_check": the token ids of the timed region (eight concurrent workers, grouped searches) against the same batches
+in the same groups run sequentially on one stream afterwards -- asserted equal.  The searches keep the product's stop
+rule (polled asynchronously every 8 steps).
+
 One JSON line on rank 0: metric / value (total unpadded audio seconds / max-over-ranks wall time) plus
 "roofline" (dominant kernel; HIP-event timing of every launch during an instrumented single-stream repetition of
 the same batches), "roofline_top3", "roofline_end_to_end", "cpu_baseline" (the oracle port of the reference's
-PyTorch-CPU path: warm-up + best of 3 on a 2-utterance slice of the same job), the token error rate of the HIP
-path against the oracle on that slice, p50 single-utterance latency and configs[1] (Conformer-S encoder).
+PyTorch-CPU path on B = 4 x 10 s, BASELINE.md section 3's CPU shape; child process with a timeout and a smaller
+fall-back slice), the token error rate of the HIP path against the oracle on that slice, p50 single-utterance latency and configs[1] (Conformer-S encoder).
 """
 import argparse
 import json
@@ -627,10 +633,10 @@ def main():
         cpu = cpu_baseline_subprocess()
         ref_tokens = cpu.pop("tokens", None)
         out["cpu_baseline"] = cpu
-        if ref_tokens:  # the same 2-utterance batch on the HIP path, scored against the oracle's tokens
+        if ref_tokens:  # the same batch on the HIP path, scored against the oracle's tokens
             from speechbrain_amd.utils.metric_stats import token_error_rate
 
-            w2, l2 = cpu_sample()
+            w2, l2 = cpu_sample(cpu.get("sample_kind", "4x10s"))
             got = run_step(asr, w2.to(dev), l2.to(dev))
             wer = token_error_rate(got, ref_tokens)
             out["token_error_rate_vs_oracle"] = {

@@ -376,8 +376,12 @@ typedef struct {
  *   out_tokens [B*topk,max_steps] (topk = 1: best hypothesis, EOS stripped, zero padded), out_len [B*topk]
  *   (= token count - 1), out_score [B*topk], out_logp [B*topk,max_steps]; out_max_len [1] (device, may be NULL): length of the
  *   longest finished hypothesis in the batch = pad width the reference divides lengths by (:1461)
- *   host_flag: pinned HOST int32 used to poll the stop rule every cfg->check_every steps (the
- *              only points where this call synchronises the stream); NULL => run max_steps.
+ *   host_flag: non-NULL = the stop rule ("every utterance holds `beam` finished hypotheses") is polled every
+ *              cfg->check_every steps; NULL => run max_steps.  The poll is asynchronous since ABI 4: a 4-byte
+ *              device->host copy into a pinned ring of the library plus an event, read back two polls later -- the
+ *              stream is never drained, the host runs at most ~3 poll intervals ahead of the device, and a search
+ *              runs at most that far past its stop point (which cannot change its result).  The pointed-to word
+ *              itself is no longer written.
  *   steps_run: HOST int32 out. */
 size_t sbk_beam_search_workspace_bytes(const sbk_decoder_weights* W, const sbk_search_config* cfg, int B, int T);
 int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_search_config* cfg, const float* enc,

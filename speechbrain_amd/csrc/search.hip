@@ -8,7 +8,8 @@
 // beam*V, predecessor gathers, EOS harvesting, finished-hypothesis lists) lives in
 // device memory, so there is no per-step host synchronisation.  The reference's
 // stop rule ("every utterance has beam_size finished hypotheses") is polled every
-// `check_every` steps through one 4-byte async copy; running past that point
+// `check_every` steps through a 4-byte asynchronous copy that is read back two polls
+// later (AsyncPoll below: the stream is never drained); running past the stop point
 // cannot change the result because full lists accept no further hypotheses.
 #include <limits.h>
 

@@ -242,6 +242,12 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
                 self.ctc_window_size = int(getattr(ctc, "ctc_window_size", 0))
                 if "ctc" in scorer.partial_scorers:  # scorer.py:1287-1291
                     self.ctc_candidates = max(1, int(beam_size * scorer.scorer_beam_scale))
+                    if self.ctc_candidates < beam_size:
+                        # with fewer candidates than beams a NON-candidate token can be selected; the reference then
+                        # advances it with candidate 0's CTC state (score_index -1 -> 0, ctc.py:262-295), the device
+                        # search with its own true state: results would differ
+                        raise NotImplementedError("CTC as a partial scorer needs scorer_beam_scale >= 1 "
+                                                  "(int(beam_size * scorer_beam_scale) candidates >= beam_size)")
         if self.attn_weight <= 0:
             raise NotImplementedError("pure-CTC beam search (ctc_weight = 1) is not implemented")
 

@@ -87,6 +87,7 @@ class ShardedTranscriber:
         self.group, self.concurrent, self.prepare = group, concurrent, prepare
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._copy_stream = None
         self.last_plan = None  # rank 0: {"batches": ..., "owner": ..., "bytes_sent": ...} of the last scatter
 
     # -- scatter -----------------------------------------------------------------
@@ -148,7 +149,9 @@ class ShardedTranscriber:
 
         local = []
         if self.rank == 0:
-            copy_stream = torch.cuda.Stream(self.device) if cuda else None
+            if cuda and getattr(self, "_copy_stream", None) is None:
+                self._copy_stream = torch.cuda.Stream(self.device)  # ONE copy stream per transcriber (not per call)
+            copy_stream = self._copy_stream if cuda else None
             cursors = [0] * self.world
             metas = [m[2] for m in plan["metas"]]
             order = list(range(1, self.world)) + [0]  # the peers' batches go out before rank 0 stages its own
@@ -173,7 +176,14 @@ class ShardedTranscriber:
                         if r != 0:
                             self._pending.append((dist.isend(chunk, r, group=self.group), chunk))
                     if r == 0:
-                        ready = (lambda e=ev: torch.cuda.current_stream().wait_event(e)) if cuda else None
+                        ready = None
+                        if cuda:
+                            def ready(e=ev, c=chunk):
+                                # the consumer's stream waits for the copy AND is recorded as a user of the block, so
+                                # the caching allocator cannot hand it to a later copy while kernels still read it
+                                cur = torch.cuda.current_stream()
+                                cur.wait_event(e)
+                                c.record_stream(cur)
                         local.append((ids, chunk.view(shape), torch.tensor(lens, dtype=torch.float32, device=self.device),
                                       ready))
         else:

@@ -194,8 +194,29 @@ class _Builder:
 
 
 def _as_node(value):
-    """A python override value as a YAML node (so it is built like text that had been in the file)."""
+    """A python override value as a YAML node (so it is built like text that had been in the file).  A string that
+    carries a tag ("!ref <x>", "!new:pkg.Class", "!name:...", "!copy <x>", "!tuple (1, 2)") becomes the TAGGED node it
+    would have been in the file, as hyperpyyaml resolves it, not a quoted plain string."""
+    if isinstance(value, yaml.Node):
+        return value
+    if isinstance(value, str) and value.startswith("!") and not value.startswith("!!"):
+        return yaml.compose(value, Loader=yaml.SafeLoader)
+    if isinstance(value, dict):  # values may themselves carry tags: build the mapping node entry by entry
+        return yaml.MappingNode("tag:yaml.org,2002:map",
+                                [(yaml.ScalarNode("tag:yaml.org,2002:str", str(k)), _as_node(v)) for k, v in value.items()])
+    if isinstance(value, (list, tuple)) and any(isinstance(v, (str, dict, list, tuple)) for v in value):
+        return yaml.SequenceNode("tag:yaml.org,2002:seq", [_as_node(v) for v in value])
     return yaml.compose(yaml.safe_dump(value, default_flow_style=True), Loader=yaml.SafeLoader)
+
+
+def _overrides_from_text(text):
+    """YAML override text -> {top-level key: node}: composed, not loaded, so that tags inside it survive."""
+    root = yaml.compose(text, Loader=yaml.SafeLoader)
+    if root is None:
+        return {}
+    if not isinstance(root, yaml.MappingNode):
+        raise ValueError("hyperparams: overrides must be a mapping")
+    return {k.value: v for k, v in root.value}
 
 
 def _merge_overrides(node, overrides, direct):
@@ -214,6 +235,8 @@ def _merge_overrides(node, overrides, direct):
                 direct[name] = value
             continue
         key, child = node.value[slot]
+        if isinstance(value, yaml.MappingNode) and isinstance(child, yaml.MappingNode) and not (value.tag or "").startswith("!"):
+            value = {k.value: v for k, v in value.value}  # (override text: merge its sub-keys like a dict override)
         if isinstance(value, dict) and isinstance(child, yaml.MappingNode):
             _merge_overrides(child, value, None)
             continue
@@ -232,7 +255,7 @@ def load_hyperpyyaml(stream, overrides=None):
     YAML text) are merged recursively into the tree before anything is built, like hyperpyyaml does."""
     text = stream if isinstance(stream, str) else stream.read()
     if isinstance(overrides, str):
-        overrides = yaml.safe_load(overrides) or {}
+        overrides = _overrides_from_text(overrides)
     root = yaml.compose(text, Loader=yaml.SafeLoader)
     if root is None:
         return {}

@@ -620,6 +620,7 @@ def test_gemm_fp16_and_fp8_operands(backend, M, N, K):
     a8 = (a / sa).to(torch.float8_e4m3fn).double() * sa
     w8 = (w / sw).to(torch.float8_e4m3fn).double() * sw
     ref8 = (a8 @ w8.t() + b).float()
-    assert _md(out8, ref8) <= 2e-6 * float((a8.abs() @ w8.abs().t()).max()) + 1e-4
+    d8 = (out8.cpu().double() - ref8.double())
+    assert float(d8.pow(2).mean().sqrt() / ref8.double().pow(2).mean().sqrt()) <= 1e-3  # (same roundings up to stray ties)
     err = (out8.cpu().double() - (full + b)).pow(2).mean().sqrt() / full.pow(2).mean().sqrt()
     assert float(err) <= 0.045, float(err)
