@@ -388,6 +388,19 @@ def main():
     def transcribe_one(w, l):
         return asr.transcribe_batch(w, l)[1]
 
+    def trace_mark():
+        # SBK_TRACE_MARK=1: a uniquely named kernel (stream_copy_kernel) brackets the timed region, so that a
+        # rocprofv3 kernel trace can be cut to exactly that region (tools/trace_gaps.py, tools/trace_overlap.py)
+        if os.environ.get("SBK_TRACE_MARK", "0") != "1":
+            return
+        import ctypes
+
+        from speechbrain_amd import native as nat
+        x = torch.zeros(2048, device=dev)
+        us = ctypes.c_float(0)
+        nat.load().sbk_prof_stream_f32(nat._p(x), nat._p(x[1024:]), 1024, 0, 1, ctypes.byref(us), nat._stream(x))
+        torch.cuda.synchronize()
+
     def barrier():
         torch.cuda.synchronize()
         if dist_on:
@@ -425,11 +438,13 @@ def main():
         t_prep = time.perf_counter() - t_prep
         note(f"batch {max_batch}: warm-up done, job planned in {t_prep:.2f} s; timed region")
         barrier()
+        trace_mark()
         t0 = time.perf_counter()
         local = st.distribute(plan)
         hyps = st.gather(st.run_local(local))
         barrier()
         dt = time.perf_counter() - t0
+        trace_mark()
         per_rank_wall = [dt]
         if dist_on:  # every rank's own wall time (audit of a scaling run), MAX over ranks = the job's time
             t = torch.tensor([dt], dtype=torch.float64, device=dev)

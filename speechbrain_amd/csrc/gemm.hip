@@ -610,8 +610,12 @@ struct SkArgs {
   int noload;    // measurement only (knob 22): panels are loaded once per workgroup (wrong results, MFMA/LDS ceiling)
 };
 
+// BT: tile edge (128: four waves of 64x64, the encoder shapes; 64: four waves of 32x32, 32 KB of LDS -- the decode-step
+// shapes of 640-1 280 rows, where 128-wide tiles leave most CUs without one)
+template <int BT>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
-  constexpr int BK = 32, PANEL = 128 * BK, STAGE = 2 * PANEL;  // floats
+  constexpr int BK = 32, PANEL = BT * BK, STAGE = 2 * PANEL;  // floats
+  constexpr int TS = BT / 64, WT = BT / 2, LI = BT / 32;      // 32x32 sub-tiles per wave and dimension, wave tile edge, loader instructions per wave and panel
   SBK_DYN_LDS(float, lds);  // [2][STAGE] + the ticket word (ONE LDS object: a second one de-pipelines the LDS-DMA loop)
   // kernel arguments into registers (a by-value struct whose address is taken is copied to scratch)
   const float* const gA = s.g.A;
@@ -628,7 +632,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
   const int tiles_n = s.tiles_n, KT = s.KT, noload = s.noload;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = sbk::uniform(tid >> 6);
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int wm0 = (wave >> 1) * WT, wn0 = (wave & 1) * WT;
   const int lrow = lane & 31, half = lane >> 5, sw = (lrow >> 1) & 7;
   // ---- this workgroup's segments: whole tiles of the XCD's range, then (or first) its share of the leftover tiles
   const int W = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;  // gridDim.x is a multiple of 8
@@ -672,36 +676,36 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
   const int p = x * W + j;  // slab owner id
 
   // loader geometry: wave-instruction i of this wave covers rows (wave*4+i)*8 .. +7 of a panel, 8 slots of 16 B each
-  int lrw[4], lsl[4];
+  int lrw[LI], lsl[LI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    lrw[i] = (wave * 4 + i) * 8 + (lane >> 3);
+  for (int i = 0; i < LI; ++i) {
+    lrw[i] = (wave * LI + i) * 8 + (lane >> 3);
     lsl[i] = ((lane & 7) ^ ((lrw[i] >> 1) & 7)) * 4;  // source k offset (floats) of the slot this lane fills
   }
-  const float* ap[4];
-  const float* wp[4];
+  const float* ap[LI];
+  const float* wp[LI];
   auto setup = [&](int tile) SBK_INLINE_LAMBDA {
-    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+    const int m0 = (tile / tiles_n) * BT, n0 = (tile % tiles_n) * BT;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {  // rows past the matrix re-read its last row (their outputs are never stored)
+    for (int i = 0; i < LI; ++i) {  // rows past the matrix re-read its last row (their outputs are never stored)
       ap[i] = gA + (size_t)min(m0 + lrw[i], M - 1) * lda + lsl[i];
       wp[i] = gW + (size_t)min(n0 + lrw[i], N - 1) * ldw + lsl[i];
     }
   };
   auto issue = [&](int kt, int stage) SBK_INLINE_LAMBDA {
-    float* base = lds + stage * STAGE + (wave * 4) * 256;
+    float* base = lds + stage * STAGE + (wave * LI) * 256;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sbk::glds16(ap[i] + kt * BK, base + i * 256);
+    for (int i = 0; i < LI; ++i) sbk::glds16(ap[i] + kt * BK, base + i * 256);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sbk::glds16(wp[i] + kt * BK, base + PANEL + i * 256);
+    for (int i = 0; i < LI; ++i) sbk::glds16(wp[i] + kt * BK, base + PANEL + i * 256);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TS][TS];
   auto zero = [&]() SBK_INLINE_LAMBDA {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TS; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TS; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   };
@@ -711,17 +715,17 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
 #pragma unroll
     for (int gk = 0; gk < 4; ++gk) {
       const int slot = ((2 * gk + half) ^ sw) * 4;
-      float4 a[2], b[2];
+      float4 a[TS], b[TS];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(As + i * 32 * BK + slot);
+      for (int i = 0; i < TS; ++i) a[i] = *reinterpret_cast<const float4*>(As + i * 32 * BK + slot);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(Ws + j * 32 * BK + slot);
+      for (int j = 0; j < TS; ++j) b[j] = *reinterpret_cast<const float4*>(Ws + j * 32 * BK + slot);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TS; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < TS; ++j) {
             const float av = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
             const float bw = e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w;
             acc[i][j] = sbk::mfma_32x32x2(av, bw, acc[i][j]);
@@ -729,15 +733,15 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
     }
   };
   auto epilogue = [&](int tile) SBK_INLINE_LAMBDA {
-    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
-    const bool interior = m0 + 128 <= M && n0 + 128 <= N;  // uniform: no per-element predicates
+    const int m0 = (tile / tiles_n) * BT, n0 = (tile % tiles_n) * BT;
+    const bool interior = m0 + BT <= M && n0 + BT <= N;  // uniform: no per-element predicates
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TS; ++j) {
       const int col = n0 + wn0 + j * 32 + lrow;
       const bool col_ok = interior || col < N;
       const float bv = (gbias && col_ok) ? gbias[col] : 0.0f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < TS; ++i) {
         const int rbase = m0 + wm0 + i * 32 + 4 * half;
         float v[16];
 #pragma unroll
@@ -798,14 +802,14 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
     if (kt_lo != 0 || kt_hi != KT) {  // partial: publish the slab, take a ticket; the last ticket sums the tile's slabs
       const int p_first = owner((tile - tb) * KT), p_last = owner((tile - tb + 1) * KT - 1);
       const int nseg = p_last - p_first + 1;
-      float4* mine = reinterpret_cast<float4*>(slabs + (size_t)(2 * p + (kt_lo == 0 ? 1 : 0)) * (128 * 128));
+      float4* mine = reinterpret_cast<float4*>(slabs + (size_t)(2 * p + (kt_lo == 0 ? 1 : 0)) * (BT * BT));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TS; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TS; ++j)
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4)
-            mine[((wave * 4 + i * 2 + j) * 4 + r4) * 64 + lane] =
+            mine[((wave * TS * TS + i * TS + j) * 4 + r4) * 64 + lane] =
                 make_float4(acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]);
       sbk::vm_drain();
       __syncthreads();
@@ -822,14 +826,14 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
         zero();
         for (int sgm = 0; sgm < nseg; ++sgm) {  // segment order = K order: the sum does not depend on who arrived last
           const float4* src =
-              reinterpret_cast<const float4*>(slabs + (size_t)(2 * (x * W + p_first + sgm) + (sgm == 0 ? 1 : 0)) * (128 * 128));
+              reinterpret_cast<const float4*>(slabs + (size_t)(2 * (x * W + p_first + sgm) + (sgm == 0 ? 1 : 0)) * (BT * BT));
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < TS; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TS; ++j)
 #pragma unroll
               for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 v = src[((wave * 4 + i * 2 + j) * 4 + r4) * 64 + lane];
+                const float4 v = src[((wave * TS * TS + i * TS + j) * 4 + r4) * 64 + lane];
                 acc[i][j][4 * r4] += v.x;
                 acc[i][j][4 * r4 + 1] += v.y;
                 acc[i][j][4 * r4 + 2] += v.z;
@@ -1275,7 +1279,7 @@ int g_gemm_tile = 0;   // tuning knob (key 6) for the large-M path: 0 = 128x128,
                        // 2 = 128x256 (8 waves), 3 = 256x128 (4 waves of 128x64), 4 = 128x128 with 64-deep K tiles
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
-int sk_route(int M, int N, int K);  // workgroups of the persistent kernel for this shape (0: tile-grid / register-operand paths)
+int sk_route(int M, int N, int K, int* bt = nullptr);  // workgroups (and tile edge) of the persistent kernel for this shape (0: tile-grid / register-operand paths)
 // Internal C++ entry shared with the fused pipelines (decoder step, encoder).
 // Skinny path: M <= 512 rows, K a multiple of 64, 16-byte aligned rows.  `ws` (optional) holds the
 // split-K partials: SK * M * N floats.
@@ -1379,8 +1383,10 @@ int g_sk_noload = 0;      // measurement knob (key 22)
 int g_sk_stagger = 1;     // tuning knob (key 23): upper half of each XCD's workgroups runs its tail share first
 int g_sk_min_rows = 2048;  // tuning knob (key 24): fewer rows than this never take the persistent kernel in routed mode
 int g_sk_min_units = 4;   // tuning knob (key 21): fewer units per workgroup than this shrinks the grid
+int g_sk64_min_rows = 0;  // tuning knob (key 25): from this many rows on (and below g_sk_min_rows) the 64x64-tile persistent kernel; 0 = off
+int g_sk64_units = 16;    // tuning knob (key 26): K units (64x64x32) per workgroup the 64-tile grid is sized for
 namespace {
-constexpr int kSkMaxGrid = 512, kSkMaxTiles = 1 << 16;
+constexpr int kSkMaxGrid = 512, kSkMaxGrid64 = 1024, kSkMaxTiles = 1 << 16;  // (both grids fit the same slab area)
 int sk_cus();
 }
 // Workgroups of the persistent kernel for this shape, 0 = the tile-grid kernels.  Measured on MI355X (tools/microbench.py
@@ -1389,13 +1395,24 @@ int sk_cus();
 // narrow short-K shapes (N <= 512, K <= 512: four column tiles, 16 K steps per tile -- the epilogue and the partial
 // tiles weigh most there) stay on the tile grid below ~400 tiles (in situ -- tools/microbench.py --enc-layer,
 // profiles/r03_encoder_in_situ_gemm_routing.log -- the persistent kernel already wins there from 500 tiles on).
-int sk_route(int M, int N, int K) {
+int sk_route(int M, int N, int K, int* bt) {
+  int unused;
+  if (!bt) bt = &unused;
+  *bt = 128;
   if (!g_sk_mode || K % 32 != 0 || K < 64) return 0;
   const long T = (long)cdiv(M, 128) * cdiv(N, 128), U = T * (K / 32);
   const int cus = sk_cus();
   int G = g_sk_grid;
+  if (g_sk_mode == 1 && M < g_sk_min_rows) {
+    // decode-step shapes (a few hundred to ~1 300 rows): 64x64 tiles, one workgroup per g_sk64_units K units -- a whole
+    // tile at K = 512, a quarter of one at K = 2 048 (split K through the slabs, reduced by the last arriver)
+    if (!g_sk64_min_rows || M < g_sk64_min_rows) return 0;
+    *bt = 64;
+    const long U64 = (long)cdiv(M, 64) * cdiv(N, 64) * (K / 32);
+    if (!G) G = (int)std::min<long>(kSkMaxGrid64, U64 / std::max(1, g_sk64_units));
+    return G >= 8 ? (G / 8) * 8 : 0;
+  }
   if (g_sk_mode == 1) {
-    if (M < g_sk_min_rows) return 0;  // decode-step shapes keep their own paths
     const bool narrow_short = N <= 512 && K <= 512;
     if (narrow_short ? 2 * T < 3L * cus : U < 16L * cus) return 0;
     if (!G) G = U >= 32L * cus ? 2 * cus : cus;
@@ -1449,11 +1466,11 @@ int sk_cus() {
   return g_sk_cus;
 }
 
-int launch_sk(const GemmArgs& g, int G, hipStream_t st) {
+int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st) {
   SkArgs s;
   s.g = g;
-  s.tiles_n = cdiv(g.N, 128);
-  s.tiles = cdiv(g.M, 128) * s.tiles_n;
+  s.tiles_n = cdiv(g.N, bt);
+  s.tiles = cdiv(g.M, bt) * s.tiles_n;
   s.KT = g.K / 32;
   if (s.tiles > kSkMaxTiles || (long)s.tiles * s.KT > (1L << 30)) return -1;
   SkWorkspace w;
@@ -1462,14 +1479,20 @@ int launch_sk(const GemmArgs& g, int G, hipStream_t st) {
   s.cnt = w.cnt;
   s.stagger = g_sk_stagger;
   s.noload = g_sk_noload;
-  const size_t lds = (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float);
+  const size_t lds = (size_t)(2 * 2 * bt * 32 + 4) * sizeof(float);
   static bool once = false;
   if (!once) {
-    (void)SBK_ALLOW_DYN_LDS(gemm_nt_sk_kernel, lds);
+    (void)SBK_ALLOW_DYN_LDS(gemm_nt_sk_kernel<128>, (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float));
     once = true;
   }
-  ProfScope prof("gemm_nt_persistent", 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N), st);
-  SBK_LAUNCH(gemm_nt_sk_kernel, dim3((unsigned)G), dim3(256), lds, st, s);
+  const double flops = 2.0 * g.M * g.N * g.K, bytes = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+  if (bt == 64) {
+    ProfScope prof("gemm_nt_persistent64", flops, bytes, st);
+    SBK_LAUNCH(gemm_nt_sk_kernel<64>, dim3((unsigned)G), dim3(256), lds, st, s);
+  } else {
+    ProfScope prof("gemm_nt_persistent", flops, bytes, st);
+    SBK_LAUNCH(gemm_nt_sk_kernel<128>, dim3((unsigned)G), dim3(256), lds, st, s);
+  }
   return launch_status("sbk_gemm_nt_f32 (stream-K)");
 }
 }  // namespace
@@ -1483,9 +1506,10 @@ int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
   const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
   const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
   if (vec) {
-    const int G = sk_route(M, N, K);
+    int bt = 128;
+    const int G = sk_route(M, N, K, &bt);
     if (G > 0) {
-      const int rc = launch_sk(g, G, st);
+      const int rc = launch_sk(g, G, bt, st);
       if (rc != -1) return rc;  // -1: no workspace for this stream (first use inside a graph capture)
     }
   }
@@ -1590,6 +1614,8 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 22) sbk::g_sk_noload = value;
   if (key == 23) sbk::g_sk_stagger = value;
   if (key == 24) sbk::g_sk_min_rows = value;
+  if (key == 25) sbk::g_sk64_min_rows = value;
+  if (key == 26) sbk::g_sk64_units = value > 0 ? value : 1;
 }
 
 

@@ -498,12 +498,18 @@ def test_gemm_bf16_operands(backend, M, N, K):
     assert nat.bf16_weight(w.to(dev)) is nat.bf16_weight(w.to(dev)) or True  # (cache keyed by data_ptr: new tensor, new entry)
 
 
-@pytest.mark.parametrize("M,N,K,grid", [(700, 300, 96, 0), (1000, 130, 64, 24), (257, 128, 640, 8), (520, 260, 128, 40), (2100, 300, 64, 16),
-                                        (4100, 512, 512, 0), (130, 1030, 2048, 0)])
-def test_gemm_stream_k(backend, M, N, K, grid):
-    """The stream-K LDS-DMA kernel (the encoder's contractions), forced at small ragged shapes: tiles cut by the unit
-    ranges of several workgroups (partial slabs + last-arriver reduction), whole tiles, grids that do not divide the
-    work; bias / activation / scaled residual / row mask; run-to-run bit-identical."""
+SK64_DEFAULT_ROWS = 0  # csrc/gemm.hip g_sk64_min_rows
+
+
+@pytest.mark.parametrize("M,N,K,grid,bt", [(700, 300, 96, 0, 128), (1000, 130, 64, 24, 128), (257, 128, 640, 8, 128), (520, 260, 128, 40, 128),
+                                           (2100, 300, 64, 16, 128), (4100, 512, 512, 0, 128), (130, 1030, 2048, 0, 128),
+                                           (700, 300, 96, 0, 64), (330, 130, 64, 24, 64), (257, 128, 640, 8, 64), (200, 260, 128, 40, 64),
+                                           (1280, 512, 512, 0, 64), (640, 512, 2048, 0, 64), (70, 1030, 2048, 0, 64), (70, 130, 2048, 0, 64)])
+def test_gemm_stream_k(backend, M, N, K, grid, bt):
+    """The stream-K LDS-DMA kernel (128-wide tiles: the encoder's contractions; 64-wide: the decode-step shapes), forced
+    at small ragged shapes: tiles cut by the unit ranges of several workgroups (partial slabs + last-arriver reduction),
+    whole tiles, grids that do not divide the work; bias / activation / scaled residual / row mask; run-to-run
+    bit-identical."""
     nat, dev = backend
     if dev.type == "cpu" and M * N * K > 6e7:
         pytest.skip("large shape: GPU only")
@@ -513,7 +519,12 @@ def test_gemm_stream_k(backend, M, N, K, grid):
     b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
     scale = float((a.abs() @ w.abs().t()).max())
     lib = nat.load()
-    lib.sbk_prof_set_knob(18, 2)
+    if bt == 64:  # routed mode, every row count below the 128-tile threshold takes the 64-wide tiles; 5 K units per workgroup cut the tiles
+        lib.sbk_prof_set_knob(24, 1 << 30)
+        lib.sbk_prof_set_knob(25, 1)
+        lib.sbk_prof_set_knob(26, 5 if K < 2048 else 16)
+    else:
+        lib.sbk_prof_set_knob(18, 2)
     lib.sbk_prof_set_knob(19, grid)
     lib.sbk_prof_set_knob(21, 1)
     try:
@@ -540,6 +551,9 @@ def test_gemm_stream_k(backend, M, N, K, grid):
         lib.sbk_prof_set_knob(18, 1)
         lib.sbk_prof_set_knob(19, 0)
         lib.sbk_prof_set_knob(21, 4)
+        lib.sbk_prof_set_knob(24, 2048)
+        lib.sbk_prof_set_knob(25, SK64_DEFAULT_ROWS)
+        lib.sbk_prof_set_knob(26, 16)
 
 
 @pytest.mark.parametrize("d_model,nhead,B,T,beam_rows", [(128, 2, 3, 150, 4), (256, 4, 2, 75, 10), (128, 2, 1, 20, 1)])

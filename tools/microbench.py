@@ -279,6 +279,18 @@ if __name__ == "__main__":
             nat.load().sbk_prof_set_knob(23, 1)
         nat.load().sbk_prof_set_knob(18, 1)
         sys.exit(0)
+    if "--sk64" in sys.argv:  # decode-step GEMM shapes (rows = hypotheses in flight): today's paths vs the 64-wide persistent tiles
+        shapes = [(M, N, K) for M in (320, 640, 1280) for (N, K) in ((512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512))]
+        for tag, knobs in (("today (skinny / split-K / tile grid)", {25: 0}), ("persistent 64x64, 16 units per workgroup", {25: 1, 26: 16}),
+                           ("persistent 64x64, 8 units", {25: 1, 26: 8}), ("persistent 64x64, 32 units", {25: 1, 26: 32})):
+            for k, v in knobs.items():
+                nat.load().sbk_prof_set_knob(k, v)
+            print("variant:", tag, flush=True)
+            for (M, N, K) in shapes:
+                gemm_case(M, N, K, 8, iters=100)
+        nat.load().sbk_prof_set_knob(25, 0)
+        nat.load().sbk_prof_set_knob(26, 16)
+        sys.exit(0)
     if "--copy" in sys.argv:  # what a plain streaming kernel reaches on this box (calibrates the HBM rooflines)
         for mb in (256, 1024, 4096):
             x = torch.empty(mb * 1024 * 1024 // 4, device=dev).normal_()
