@@ -22,8 +22,9 @@ def main(path, lo=0.3, hi=0.9):
                 continue
     rows.sort()
     marks = [i for i, r in enumerate(rows) if "stream_copy_kernel" in r[2]]
-    if len(marks) >= 2:  # bench.py SBK_TRACE_MARK=1: exactly the timed region
-        rows = rows[marks[0] + 1: marks[1]]
+    if len(marks) >= 2:  # bench.py SBK_TRACE_MARK=1: exactly the timed region (a mark is a few launches of the marker kernel)
+        lo_i = max(range(len(marks) - 1), key=lambda i: marks[i + 1] - marks[i])
+        rows = rows[marks[lo_i] + 1: marks[lo_i + 1]]
     else:
         rows = rows[int(len(rows) * lo): int(len(rows) * hi)]
     span = max(r[1] for r in rows) - rows[0][0]

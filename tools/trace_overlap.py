@@ -21,8 +21,9 @@ def main(path, t_lo_frac=0.0, t_hi_frac=1.0):
         return
     rows.sort()
     marks = [i for i, r in enumerate(rows) if "stream_copy_kernel" in r[3]]
-    if len(marks) >= 2:  # bench.py SBK_TRACE_MARK=1: exactly the timed region
-        rows = rows[marks[0] + 1: marks[1]]
+    if len(marks) >= 2:  # bench.py SBK_TRACE_MARK=1: exactly the timed region (a mark is a few launches of the marker kernel)
+        lo_i = max(range(len(marks) - 1), key=lambda i: marks[i + 1] - marks[i])
+        rows = rows[marks[lo_i] + 1: marks[lo_i + 1]]
     elif t_lo_frac > 0.0 or t_hi_frac < 1.0:  # the kernels between two percentiles of the launch order: the steady state of a timed region
         rows = rows[int(len(rows) * t_lo_frac): max(int(len(rows) * t_hi_frac), int(len(rows) * t_lo_frac) + 1)]
     t0, t1 = rows[0][0], max(r[1] for r in rows)
