@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SBK_ABI_VERSION 4
+#define SBK_ABI_VERSION 5
 
 typedef void* sbk_stream_t; /* hipStream_t */
 
@@ -159,6 +159,23 @@ int sbk_f32_to_bf16(const float* x, uint16_t* y, long n, sbk_stream_t stream);
 int sbk_gemm_nt_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, const float* bias, const float* residual,
                      int ldr, float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
                      int rows_per_seq, sbk_stream_t stream);
+
+/* bf16 activations BETWEEN the bf16 contractions (the Whisper encoder under precision="bf16",
+ * integrations/huggingface/whisper.py:190-232 <- speechbrain/integrations/huggingface/whisper.py:318-353 forward_encoder):
+ * A [M,K] and Wb [N,K] both bf16 in memory (K % 64 == 0, rows 16-byte aligned), panels global -> LDS by LDS-DMA through
+ * a 4-stage pipeline, fp32 accumulation, epilogue as sbk_gemm_nt_f32 (bias, activation, alpha, fp32 residual) written as
+ * fp32 (C) and / or as bf16 (Cb: the next contraction's operand, rounded to nearest even -- the same value the fp32-A
+ * kernel above would round on its way into LDS, so the two paths differ by summation order only).
+ * sbk_layernorm_bf16o / sbk_rope_attention_bf16o are the producers of such operands: LayerNorm / attention context
+ * written as bf16. */
+int sbk_gemm_nt_bf16a(const uint16_t* A, int lda, const uint16_t* Wb, int ldw, const float* bias, const float* residual,
+                      int ldr, float* C, int ldc, uint16_t* Cb, int ldcb, int M, int N, int K, int act, float alpha,
+                      sbk_stream_t stream);
+int sbk_layernorm_bf16o(const float* x, const float* gamma, const float* beta, uint16_t* y, int rows, int d, float eps,
+                        int act, sbk_stream_t stream);
+int sbk_rope_attention_bf16o(const float* qkv, const float* cosines, const float* sines, const int32_t* key_len,
+                             uint16_t* out, int B, int T, int H, int Dh, int table_rows, float scale, int chunk_size,
+                             int left_chunks, sbk_stream_t stream);
 
 /* The same contraction with fp16 operands (v_mfma_f32_32x32x16_f16; A rounded to nearest even on its way into LDS, Wh =
  * the weights converted once by sbk_f32_to_f16).  fp16 has 3 more mantissa bits than bf16 and a narrower range

@@ -897,6 +897,191 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
 // applies the epilogue (fixed summation order => run-to-run deterministic).
 // For long K (FFN2) gridDim.y adds a second, global split whose partial tiles
 // are combined by splitk_reduce_kernel.
+// ---------------------------------------------------------------------------
+// bf16 activations AND bf16 weights (sbk_gemm_nt_bf16a): C = epilogue(A . W^T) with A [M,K] and W [N,K] both bf16 in
+// HBM, fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 and / or bf16 output.  With the operands already rounded
+// the panels go global -> LDS by LDS-DMA exactly like the fp32 persistent kernel's: a 128-byte LDS row is 64 bf16 (a
+// K tile of 64) instead of 32 floats, the same source-side slot swizzle makes the ds_read_b128 operand fetch (8
+// consecutive k of one row = one MFMA operand) conflict-free.  The matrix pipe needs a K tile every 512 cycles per
+// wave (16x the fp32 rate), so the double buffer of the fp32 kernel cannot cover the load latency: NS stages (NS - 1
+// K tiles in flight, s_waitcnt vmcnt(8 x tiles issued after the one needed) -- loads retire in order), one barrier per
+// K tile, one workgroup per CU.  Persistent over whole tiles (XCD-contiguous ranges, the K pipeline runs on across
+// tile boundaries and under the epilogue); no K split -- the shapes that take this path have thousands of tiles.
+struct Bf16DmaArgs {
+  const unsigned short* A;
+  const unsigned short* W;
+  const float* bias;
+  const float* R;      // fp32 residual (optional)
+  float* C;            // fp32 output (optional)
+  unsigned short* Cb;  // bf16 output (optional): the next contraction's operand
+  int lda, ldw, ldr, ldc, ldcb, M, N, K, act;
+  float alpha;
+  int tiles_n, tiles, KT;
+};
+
+template <int NS>
+__global__ void __launch_bounds__(256, 1) gemm_nt_bf16dma_kernel(Bf16DmaArgs s) {
+  constexpr int BKF = 32, PANEL = 128 * BKF, STAGE = 2 * PANEL;  // float units (one unit = two bf16)
+  SBK_DYN_LDS(float, lds);  // [NS][A 128 rows | W 128 rows][64 bf16]
+  const unsigned short* const gA = s.A;
+  const unsigned short* const gW = s.W;
+  const float* const gbias = s.bias;
+  const float* const gR = s.R;
+  float* const gC = s.C;
+  unsigned short* const gCb = s.Cb;
+  const int lda = s.lda, ldw = s.ldw, ldr = s.ldr, ldc = s.ldc, ldcb = s.ldcb, M = s.M, N = s.N, act = s.act;
+  const float alpha = s.alpha;
+  const int tiles_n = s.tiles_n, KT = s.KT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = sbk::uniform(tid >> 6);
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int lrow = lane & 31, half = lane >> 5, sw = (lrow >> 1) & 7;
+  // this workgroup's tiles: every W-th tile of the XCD's contiguous range
+  const int W = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;  // gridDim.x is a multiple of 8
+  const int t0 = (int)((long)s.tiles * x / 8), t1 = (int)((long)s.tiles * (x + 1) / 8);
+  const int ntile = sbk::uniform(t0 + j < t1 ? (t1 - t0 - j + W - 1) / W : 0);
+  if (ntile == 0) return;
+  const int U = ntile * KT;
+
+  int lrw[4], lsl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lrw[i] = (wave * 4 + i) * 8 + (lane >> 3);
+    lsl[i] = ((lane & 7) ^ ((lrw[i] >> 1) & 7)) * 8;  // source k offset (bf16 elements) of the 16-byte slot this lane fills
+  }
+  const unsigned short* ap[4];
+  const unsigned short* wp[4];
+  auto setup = [&](int tile) SBK_INLINE_LAMBDA {
+    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // rows past the matrix re-read its last row (their outputs are never stored)
+      ap[i] = gA + (size_t)min(m0 + lrw[i], M - 1) * lda + lsl[i];
+      wp[i] = gW + (size_t)min(n0 + lrw[i], N - 1) * ldw + lsl[i];
+    }
+  };
+  auto issue = [&](int kt, int stage) SBK_INLINE_LAMBDA {
+    float* base = lds + stage * STAGE + (wave * 4) * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sbk::glds16(reinterpret_cast<const float*>(ap[i] + kt * 64), base + i * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sbk::glds16(reinterpret_cast<const float*>(wp[i] + kt * 64), base + PANEL + i * 256);
+  };
+  f32x16 acc[2][2];
+  auto zero = [&]() SBK_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
+  };
+  auto compute = [&](int stage) SBK_INLINE_LAMBDA {
+    const float* As = lds + stage * STAGE + (wm0 + lrow) * BKF;
+    const float* Ws = lds + stage * STAGE + PANEL + (wn0 + lrow) * BKF;
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) {  // 16 k per step: lanes 0-31 supply k = 16 gk .. +7, lanes 32-63 the next eight
+      const int slot = ((2 * gk + half) ^ sw) * 4;
+      sbk::bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const sbk::bf16x8*>(As + i * 32 * BKF + slot);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) b[jj] = *reinterpret_cast<const sbk::bf16x8*>(Ws + jj * 32 * BKF + slot);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) acc[i][jj] = sbk::mfma_32x32x16_bf16(a[i], b[jj], acc[i][jj]);
+    }
+  };
+  auto epilogue = [&](int tile) SBK_INLINE_LAMBDA {
+    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+    const bool interior = m0 + 128 <= M && n0 + 128 <= N;  // uniform: no per-element predicates
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int col = n0 + wn0 + jj * 32 + lrow;
+      const bool col_ok = interior || col < N;
+      const float bv = (gbias && col_ok) ? gbias[col] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rbase = m0 + wm0 + i * 32 + 4 * half;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[i][jj][r] + bv;
+        switch (act) {  // uniform
+          case SBK_ACT_SWISH:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+            break;
+          case SBK_ACT_GELU:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752440f));
+            break;
+          case SBK_ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
+            break;
+          case SBK_ACT_LEAKY_RELU:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.01f * v[r];
+            break;
+          default: break;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (interior || (col_ok && row < M)) {
+            float o = v[r] * alpha;
+            if (gR) o += gR[(size_t)row * ldr + col];
+            if (gC) gC[(size_t)row * ldc + col] = o;
+            if (gCb) gCb[(size_t)row * ldcb + col] = sbk::f32_to_bf16(o);
+          }
+        }
+      }
+    }
+  };
+
+  // ---- the K pipeline over this workgroup's units (tile ordinal, K tile): `issued` units are in flight or landed
+  int i_ord = 0, i_kt = 0, issued = 0;
+  setup(t0 + j);
+  auto issue_next = [&]() SBK_INLINE_LAMBDA {
+    issue(i_kt, issued % NS);
+    ++issued;
+    if (++i_kt == KT) {
+      i_kt = 0;
+      if (++i_ord < ntile) setup(t0 + j + i_ord * W);
+    }
+  };
+  for (int pre = 0; pre < NS - 1 && issued < U; ++pre) issue_next();
+  zero();
+  int landed = -1, c_ord = 0, c_kt = 0;
+  for (int n = 0; n < U; ++n) {
+    if (n > landed) {  // unit n's panels: everything this wave issued up to it has landed once at most 8 x (units issued after it) loads are in flight
+      const int newer = sbk::uniform(issued - 1 - n);
+      if (newer <= 0) {
+        sbk::vm_drain();
+      } else if (newer == 1) {
+        sbk::vm_wait<8>();
+      } else if (newer == 2) {
+        sbk::vm_wait<16>();
+      } else {
+        sbk::vm_wait<24>();
+      }
+      landed = n;
+    }
+    __syncthreads();  // ... and everybody's share of it; every wave is done with the stage of unit n - 1
+    if (issued < U) issue_next();  // into the stage unit n - 1 occupied
+    compute(n % NS);
+    if (++c_kt == KT) {
+      epilogue(t0 + j + c_ord * W);
+      zero();
+      c_kt = 0;
+      ++c_ord;
+      // the epilogue's own loads / stores are younger than every K tile in flight: the next wait is a full one, after
+      // which all of them have landed
+      landed = n;
+    }
+  }
+}
+
 template <int NCH>  // 32-float K chunks fetched per batch (all of them in flight together)
 __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __restrict__ partial, int kper,
                                                           int tiles_m, int tiles_n) {
@@ -1385,6 +1570,8 @@ int g_sk_min_rows = 2048;  // tuning knob (key 24): fewer rows than this never t
 int g_sk_min_units = 4;   // tuning knob (key 21): fewer units per workgroup than this shrinks the grid
 int g_sk64_min_rows = 0;  // tuning knob (key 25): from this many rows on (and below g_sk_min_rows) the 64x64-tile persistent kernel; 0 = off
 int g_sk64_units = 16;    // tuning knob (key 26): K units (64x64x32) per workgroup the 64-tile grid is sized for
+int g_bf16a_stages = 4;   // tuning knob (key 27): LDS stages of gemm_nt_bf16dma_kernel (3 or 4)
+int g_bf16a_grid = 0;     // tuning knob (key 28): its workgroups (0 = one per CU)
 namespace {
 constexpr int kSkMaxGrid = 512, kSkMaxGrid64 = 1024, kSkMaxTiles = 1 << 16;  // (both grids fit the same slab area)
 int sk_cus();
@@ -1616,6 +1803,8 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 24) sbk::g_sk_min_rows = value;
   if (key == 25) sbk::g_sk64_min_rows = value;
   if (key == 26) sbk::g_sk64_units = value > 0 ? value : 1;
+  if (key == 27) sbk::g_bf16a_stages = value;
+  if (key == 28) sbk::g_bf16a_grid = value;
 }
 
 
@@ -1630,6 +1819,37 @@ extern "C" int sbk_f32_to_bf16(const float* x, uint16_t* y, long n, sbk_stream_t
 }
 
 namespace {
+int launch_bf16dma(const Bf16DmaArgs& a0, hipStream_t st) {
+  Bf16DmaArgs a = a0;
+  a.tiles_n = sbk::cdiv(a.N, 128);
+  a.tiles = sbk::cdiv(a.M, 128) * a.tiles_n;
+  a.KT = a.K / 64;
+  int dev = 0, cus = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (cus <= 0) cus = 256;
+  int G = sbk::g_bf16a_grid > 0 ? sbk::g_bf16a_grid : cus;
+  if (G > a.tiles) G = a.tiles;
+  G = G >= 8 ? (G / 8) * 8 : 8;
+  const int ns = sbk::g_bf16a_stages == 3 ? 3 : 4;
+  const size_t lds = (size_t)ns * 2 * 128 * 32 * sizeof(float);
+  static bool once = false;
+  if (!once) {
+    (void)SBK_ALLOW_DYN_LDS(gemm_nt_bf16dma_kernel<3>, (size_t)3 * 2 * 128 * 32 * sizeof(float));
+    (void)SBK_ALLOW_DYN_LDS(gemm_nt_bf16dma_kernel<4>, (size_t)4 * 2 * 128 * 32 * sizeof(float));
+    once = true;
+  }
+  sbk::ProfScope prof("gemm_nt_bf16a", 2.0 * a.M * a.N * a.K,
+                      2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.C ? 4.0 : 0.0) * a.M * a.N + (a.Cb ? 2.0 : 0.0) * a.M * a.N +
+                          (a.R ? 4.0 : 0.0) * a.M * a.N, st);
+  if (ns == 3) {
+    SBK_LAUNCH(gemm_nt_bf16dma_kernel<3>, dim3((unsigned)G), dim3(256), lds, st, a);
+  } else {
+    SBK_LAUNCH(gemm_nt_bf16dma_kernel<4>, dim3((unsigned)G), dim3(256), lds, st, a);
+  }
+  return sbk::launch_status("sbk_gemm_nt_bf16a");
+}
+
 int launch_lp(int dt, const float* A, int lda, const void* Wq, int ldw, const float* bias, const float* residual, int ldr,
               float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq,
               const float* a_absmax, float w_scale, hipStream_t st) {
@@ -1670,6 +1890,20 @@ extern "C" int sbk_gemm_nt_bf16(const float* A, int lda, const uint16_t* Wb, int
   SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm_bf16: seq_len given without rows_per_seq");
   return launch_lp(0, A, lda, Wb, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, nullptr, 1.0f,
                    sbk::as_stream(stream));
+}
+
+extern "C" int sbk_gemm_nt_bf16a(const uint16_t* A, int lda, const uint16_t* Wb, int ldw, const float* bias,
+                                 const float* residual, int ldr, float* C, int ldc, uint16_t* Cb, int ldcb, int M, int N,
+                                 int K, int act, float alpha, sbk_stream_t stream) {
+  if (M == 0 || N == 0) return 0;
+  SBK_REQUIRE(A && Wb && (C || Cb), "gemm_bf16a: null operand");
+  SBK_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_bf16a: K must be a multiple of 64 (M=%d N=%d K=%d)", M, N, K);
+  SBK_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && sbk::aligned16(A) && sbk::aligned16(Wb),
+              "gemm_bf16a: operand rows must be 16-byte aligned (lda=%d ldw=%d)", lda, ldw);
+  SBK_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N) && (!residual || ldr >= N), "gemm_bf16a: leading dimension smaller than the row");
+  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_bf16a: unknown activation %d", act);
+  Bf16DmaArgs a{A, Wb, bias, residual, C, Cb, lda, ldw, ldr, ldc, ldcb, M, N, K, act, alpha, 0, 0, 0};
+  return launch_bf16dma(a, sbk::as_stream(stream));
 }
 
 extern "C" int sbk_gemm_nt_f16(const float* A, int lda, const uint16_t* Wh, int ldw, const float* bias,

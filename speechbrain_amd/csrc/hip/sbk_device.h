@@ -127,6 +127,12 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // every outstanding vector-memory operation of this wave has completed (inline asm: the compiler cannot drop it)
 __device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// at most N of this wave's vector-memory operations still in flight (they retire in issue order)
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 // publish this workgroup's earlier plain stores to every CU of the device (one lane, after a __syncthreads())
 __device__ __forceinline__ void release_agent() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

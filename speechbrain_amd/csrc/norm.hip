@@ -22,7 +22,8 @@ __device__ __forceinline__ float act_f(float v, int act) {
 template <int MAXV>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
-                                                        int rows, int d, float eps, int act) {
+                                                        unsigned short* __restrict__ yb, int rows, int d, float eps,
+                                                        int act) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const bool live = row < rows;
@@ -62,7 +63,14 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
       o.y = act_f((v[i].y - mean) * rstd * g.y + b.y, act);
       o.z = act_f((v[i].z - mean) * rstd * g.z + b.z, act);
       o.w = act_f((v[i].w - mean) * rstd * g.w + b.w, act);
-      yr[c] = o;
+      if (yb) {  // (uniform) bf16 output: the next contraction's operand, rounded to nearest even
+        uint2 pk;
+        pk.x = (unsigned)sbk::f32_to_bf16(o.x) | ((unsigned)sbk::f32_to_bf16(o.y) << 16);
+        pk.y = (unsigned)sbk::f32_to_bf16(o.z) | ((unsigned)sbk::f32_to_bf16(o.w) << 16);
+        reinterpret_cast<uint2*>(yb + (size_t)row * d)[c] = pk;
+      } else {
+        yr[c] = o;
+      }
     }
   }
 }
@@ -71,7 +79,8 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
 __global__ void __launch_bounds__(256) layernorm_generic_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float* __restrict__ y,
-                                                                int rows, int d, float eps, int act) {
+                                                                unsigned short* __restrict__ yb, int rows, int d,
+                                                                float eps, int act) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const bool live = row < rows;
@@ -88,7 +97,14 @@ __global__ void __launch_bounds__(256) layernorm_generic_kernel(const float* __r
   const float rstd = rsqrtf(sbk::wave_sum(q) / (float)d + eps);
   if (!live) return;
   float* yr = y + (size_t)row * d;
-  for (int c = lane; c < d; c += 64) yr[c] = act_f((xr[c] - mean) * rstd * gamma[c] + beta[c], act);
+  for (int c = lane; c < d; c += 64) {
+    const float o = act_f((xr[c] - mean) * rstd * gamma[c] + beta[c], act);
+    if (yb) {
+      yb[(size_t)row * d + c] = sbk::f32_to_bf16(o);
+    } else {
+      yr[c] = o;
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) input_norm_kernel(const float* __restrict__ x, const float* __restrict__ mean,
@@ -195,22 +211,29 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict
 }  // namespace
 
 namespace sbk {
-int layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int d, float eps, int act,
-              hipStream_t st) {
+int layernorm_any(const float* x, const float* gamma, const float* beta, float* y, unsigned short* yb, int rows, int d,
+                  float eps, int act, hipStream_t st) {
   if (rows == 0) return 0;
   dim3 grid(cdiv(rows, 4)), block(256);
-  ProfScope prof("layernorm", 8.0 * rows * d, 8.0 * rows * d, st);
-  const bool vec = (d % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta);
+  ProfScope prof("layernorm", 8.0 * rows * d, (yb ? 6.0 : 8.0) * rows * d, st);
+  const bool vec = (d % 4 == 0) && aligned16(x) && (yb ? (reinterpret_cast<uintptr_t>(yb) & 7) == 0 : aligned16(y)) &&
+                   aligned16(gamma) && aligned16(beta);
   if (vec && d <= 256 * 1) {
-    SBK_LAUNCH((layernorm_kernel<1>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, act);
+    SBK_LAUNCH((layernorm_kernel<1>), grid, block, 0, st, x, gamma, beta, y, yb, rows, d, eps, act);
   } else if (vec && d <= 256 * 2) {
-    SBK_LAUNCH((layernorm_kernel<2>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, act);
+    SBK_LAUNCH((layernorm_kernel<2>), grid, block, 0, st, x, gamma, beta, y, yb, rows, d, eps, act);
   } else if (vec && d <= 256 * 4) {
-    SBK_LAUNCH((layernorm_kernel<4>), grid, block, 0, st, x, gamma, beta, y, rows, d, eps, act);
+    SBK_LAUNCH((layernorm_kernel<4>), grid, block, 0, st, x, gamma, beta, y, yb, rows, d, eps, act);
+  } else if (vec && d <= 256 * 5) {  // d = 1 280 (Whisper large)
+    SBK_LAUNCH((layernorm_kernel<5>), grid, block, 0, st, x, gamma, beta, y, yb, rows, d, eps, act);
   } else {
-    SBK_LAUNCH(layernorm_generic_kernel, grid, block, 0, st, x, gamma, beta, y, rows, d, eps, act);
+    SBK_LAUNCH(layernorm_generic_kernel, grid, block, 0, st, x, gamma, beta, y, yb, rows, d, eps, act);
   }
   return launch_status("sbk_layernorm_f32");
+}
+int layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int d, float eps, int act,
+              hipStream_t st) {
+  return layernorm_any(x, gamma, beta, y, nullptr, rows, d, eps, act, st);
 }
 }  // namespace sbk
 
@@ -220,6 +243,14 @@ extern "C" int sbk_layernorm_f32(const float* x, const float* gamma, const float
   SBK_REQUIRE(x && gamma && beta && y, "layernorm: null operand");
   SBK_REQUIRE(rows >= 0 && d > 0, "layernorm: bad shape rows=%d d=%d", rows, d);
   return sbk::layernorm(x, gamma, beta, y, rows, d, eps, act, sbk::as_stream(stream));
+}
+
+extern "C" int sbk_layernorm_bf16o(const float* x, const float* gamma, const float* beta, uint16_t* y, int rows, int d,
+                                   float eps, int act, sbk_stream_t stream) {
+  if (rows == 0) return 0;
+  SBK_REQUIRE(x && gamma && beta && y, "layernorm_bf16o: null operand");
+  SBK_REQUIRE(rows >= 0 && d > 0, "layernorm_bf16o: bad shape rows=%d d=%d", rows, d);
+  return sbk::layernorm_any(x, gamma, beta, nullptr, y, rows, d, eps, act, sbk::as_stream(stream));
 }
 
 extern "C" size_t sbk_input_norm_stats_workspace_bytes(int B, int C) {

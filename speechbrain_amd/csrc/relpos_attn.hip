@@ -41,6 +41,7 @@ struct AttnArgs {
   // Dynamic Chunk attention mask (TransformerASR.py:47-103, make_transformer_src_mask): chunk > 0 restricts query i
   // (chunk c = i / chunk) to the keys [max(0, (c - left) * chunk), (c + 1) * chunk); left < 0 = unlimited left context.
   int chunk, left;
+  int out_bf16;  // rope_flash_t_bf16_kernel only: `out` holds bf16 (the next contraction's operand) instead of fp32
 };
 
 // allowed key range [lo, hi) of query row i under the chunk mask and the key padding length
@@ -856,11 +857,24 @@ __global__ void __launch_bounds__(256, 2) rope_flash_t_bf16_kernel(AttnArgs a) {
   }
   if (i0 + jl < T) {
     const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
-    float* orow = a.out + ((size_t)b * T + i0 + jl) * d + h * DH;
+    if (a.out_bf16) {  // (uniform) four consecutive channels per register quad: 8-byte stores
+      unsigned short* orow = reinterpret_cast<unsigned short*>(a.out) + ((size_t)b * T + i0 + jl) * d + h * DH;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) orow[ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = o[ct][r] * inv;
+        for (int q = 0; q < 4; ++q) {
+          uint2 pk;
+          pk.x = (unsigned)sbk::f32_to_bf16(o[ct][4 * q] * inv) | ((unsigned)sbk::f32_to_bf16(o[ct][4 * q + 1] * inv) << 16);
+          pk.y = (unsigned)sbk::f32_to_bf16(o[ct][4 * q + 2] * inv) | ((unsigned)sbk::f32_to_bf16(o[ct][4 * q + 3] * inv) << 16);
+          *reinterpret_cast<uint2*>(orow + ct * 32 + 8 * q + 4 * half) = pk;
+        }
+    } else {
+      float* orow = a.out + ((size_t)b * T + i0 + jl) * d + h * DH;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) orow[ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = o[ct][r] * inv;
+    }
   }
 }
 
@@ -973,9 +987,27 @@ extern "C" int sbk_rope_attention_f32(const float* qkv, const float* cosines, co
                              chunk_size, left_chunks);
 }
 
+namespace {
+int rope_attention_bf16_impl(const float* qkv, const float* cosines, const float* sines, const int32_t* key_len, void* out,
+                             int out_bf16, int B, int T, int H, int Dh, int table_rows, float scale, int chunk_size,
+                             int left_chunks, sbk_stream_t stream);
+}
 extern "C" int sbk_rope_attention_bf16(const float* qkv, const float* cosines, const float* sines,
                                        const int32_t* key_len, float* out, int B, int T, int H, int Dh, int table_rows,
                                        float scale, int chunk_size, int left_chunks, sbk_stream_t stream) {
+  return rope_attention_bf16_impl(qkv, cosines, sines, key_len, out, 0, B, T, H, Dh, table_rows, scale, chunk_size,
+                                  left_chunks, stream);
+}
+extern "C" int sbk_rope_attention_bf16o(const float* qkv, const float* cosines, const float* sines,
+                                        const int32_t* key_len, uint16_t* out, int B, int T, int H, int Dh, int table_rows,
+                                        float scale, int chunk_size, int left_chunks, sbk_stream_t stream) {
+  return rope_attention_bf16_impl(qkv, cosines, sines, key_len, out, 1, B, T, H, Dh, table_rows, scale, chunk_size,
+                                  left_chunks, stream);
+}
+namespace {
+int rope_attention_bf16_impl(const float* qkv, const float* cosines, const float* sines, const int32_t* key_len, void* out,
+                             int out_bf16, int B, int T, int H, int Dh, int table_rows, float scale, int chunk_size,
+                             int left_chunks, sbk_stream_t stream) {
   if (B == 0 || T == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(qkv && out && (cosines != nullptr) == (sines != nullptr), "rope_attention_bf16: null operand");
   SBK_REQUIRE(B >= 0 && T >= 0 && H > 0 && Dh == 64, "rope_attention_bf16: head_dim 64 only (got %d)", Dh);
@@ -984,11 +1016,12 @@ extern "C" int sbk_rope_attention_bf16(const float* qkv, const float* cosines, c
               "rope_attention_bf16: operands must be 16-byte aligned");
   SBK_REQUIRE(chunk_size >= 0, "rope_attention_bf16: negative chunk size");
   hipStream_t st = sbk::as_stream(stream);
-  AttnArgs a{qkv, cosines, sines, nullptr, key_len, out, nullptr, B, T, H, 0, scale, chunk_size, left_chunks};
-  sbk::ProfScope prof("rope_attention_bf16", 4.0 * B * H * (double)T * T * Dh, 4.0 * B * T * (4.0 * H * Dh), st);
+  AttnArgs a{qkv, cosines, sines, nullptr, key_len, reinterpret_cast<float*>(out), nullptr, B, T, H, 0, scale, chunk_size, left_chunks, out_bf16};
+  sbk::ProfScope prof("rope_attention_bf16", 4.0 * B * H * (double)T * T * Dh, 4.0 * B * T * (3.0 * H * Dh) + (out_bf16 ? 2.0 : 4.0) * B * T * H * Dh, st);
   SBK_LAUNCH(rope_flash_t_bf16_kernel, dim3((T + 127) / 128, H, B), dim3(256), 0, st, a);
   return sbk::launch_status("sbk_rope_attention_bf16");
 }
+}  // namespace
 
 extern "C" int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                                         const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,

@@ -163,6 +163,12 @@ class _DecoderLayer(nn.Module):
         self.final_layer_norm = nn.LayerNorm(d)
 
 
+
+def att_ok(layers):
+    """The bf16 attention kernel of the bf16-activation path is instantiated for head_dim 64."""
+    return len(layers) > 0 and all(l.self_attn.head_dim == 64 for l in layers)
+
+
 class WhisperEncoder(nn.Module):
     """modeling_whisper.WhisperEncoder: conv1(k3,s1)+GELU -> conv2(k3,s2)+GELU -> + embed_positions -> pre-norm
     layers (MHA without masks, GELU feed-forward) -> layer_norm."""
@@ -214,11 +220,30 @@ class WhisperEncoder(nn.Module):
                                 act=native.ACT_GELU, out=x[b])
         hidden = [x] if output_hidden_states else None
         Tq = T // 2
+        # precision "bf16": the operands of the four contractions of a layer are WRITTEN as bf16 by their producers
+        # (LayerNorm, attention, the GELU epilogue) and stream global -> LDS by LDS-DMA (native.gemm_nt_bf16a); the
+        # residual stream, the qkv rows and every accumulation stay fp32.  Same roundings as the fp32-activation bf16
+        # kernels, at the points where those round on load.
+        bf16a = (native.precision() == "bf16" and native.BF16_ACTIVATIONS and att_ok(self.layers) and native.bf16a_ok(d)
+                 and native.bf16a_ok(self.layers[0].fc1.out_features))
         for layer in self.layers:
             att = layer.self_attn
             ln = layer.self_attn_layer_norm
-            h = native.layernorm(x, ln.weight, ln.bias, ln.eps)
             w_in, b_in = att.stacked(interleave_heads=True)
+            if bf16a:
+                h = native.layernorm_bf16(x, ln.weight, ln.bias, ln.eps)
+                qkv = native.gemm_nt_bf16a(h, w_in, b_in)
+                ctx, _ = native.rope_attention(qkv, None, None, None, att.num_heads, att.head_dim ** -0.5,
+                                               out_dtype=torch.bfloat16)
+                x = native.gemm_nt_bf16a(ctx, att.out_proj.weight, att.out_proj.bias, residual=x)
+                ln = layer.final_layer_norm
+                h = native.layernorm_bf16(x, ln.weight, ln.bias, ln.eps)
+                h = native.gemm_nt_bf16a(h, layer.fc1.weight, layer.fc1.bias, act=native.ACT_GELU, out_dtype=torch.bfloat16)
+                x = native.gemm_nt_bf16a(h, layer.fc2.weight, layer.fc2.bias, residual=x)
+                if hidden is not None:
+                    hidden.append(x)
+                continue
+            h = native.layernorm(x, ln.weight, ln.bias, ln.eps)
             qkv = native.gemm_nt(h, w_in, b_in)
             ctx, _ = native.rope_attention(qkv, None, None, None, att.num_heads, att.head_dim ** -0.5)  # no rotation
             x = native.gemm_nt(ctx, att.out_proj.weight, att.out_proj.bias, residual=x)

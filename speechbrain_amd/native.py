@@ -93,6 +93,9 @@ def _declare(lib):
         "sbk_f32_to_bf16": ([p, p, ctypes.c_long, p], c_int),
         "sbk_gemm_nt_bf16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_f16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
+        "sbk_gemm_nt_bf16a": ([p, i, p, i, p, p, i, p, i, p, i, i, i, i, i, f, p], c_int),
+        "sbk_layernorm_bf16o": ([p, p, p, p, i, i, f, i, p], c_int),
+        "sbk_rope_attention_bf16o": ([p, p, p, p, p, i, i, i, i, i, f, i, i, p], c_int),
         "sbk_f32_to_f16": ([p, p, ctypes.c_long, p], c_int),
         "sbk_gemm_nt_fp8": ([p, i, p, p, i, f, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_f32_to_fp8": ([p, p, ctypes.c_long, f, p], c_int),
@@ -143,7 +146,7 @@ def load(path: Optional[str] = None):
         )
     lib = ctypes.CDLL(path)
     EXPORTS = tuple(_declare(lib).keys())
-    if lib.sbk_abi_version() != 4:
+    if lib.sbk_abi_version() != 5:
         raise SbkError(f"ABI version mismatch: {lib.sbk_abi_version()}")
     _lib = lib
     return lib
@@ -332,6 +335,51 @@ def gemm_nt_bf16(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act
     return out
 
 
+# precision "bf16": keep the operands of consecutive contractions in bf16 in memory where a model's forward supports it
+# (the Whisper encoder); False = every contraction reads fp32 activations and rounds them on load (A/B, tests)
+BF16_ACTIVATIONS = True
+
+
+def bf16a_ok(K: int) -> bool:
+    """Shapes the bf16-activation contraction (sbk_gemm_nt_bf16a) takes: K a multiple of its 64-deep K tile."""
+    return K % 64 == 0
+
+
+def gemm_nt_bf16a(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0,
+                  out_dtype=torch.float32):
+    """epilogue(a . w^T) with ``a`` ALREADY bf16 in memory (torch.bfloat16 [..., K], written by layernorm_bf16 /
+    rope_attention(out_dtype=bf16) / a previous gemm_nt_bf16a) and the cached bf16 image of the fp32 parameter ``w``;
+    fp32 accumulation, fp32 residual; the result is fp32 or -- ``out_dtype=torch.bfloat16`` -- the next contraction's
+    bf16 operand."""
+    lib = load()
+    K = a.shape[-1]
+    a2 = a.reshape(-1, K)
+    M, N = a2.shape[0], w.shape[0]
+    _dev_ok(a2, bias, residual)
+    if a2.dtype != torch.bfloat16 or not a2.is_contiguous():
+        raise SbkError("gemm_nt_bf16a: the activation operand must be a contiguous torch.bfloat16 tensor")
+    wb = lp_weight(w, "bf16")
+    out = torch.empty(*a.shape[:-1], N, dtype=out_dtype, device=a.device)
+    r2 = residual.reshape(-1, N) if residual is not None else None
+    c32, cb = (out, None) if out_dtype == torch.float32 else (None, out)
+    _chk(lib.sbk_gemm_nt_bf16a(_p(a2), K, _p(wb), K, _p(bias), _p(r2), N, _p(c32), N, _p(cb), N, M, N, K, act,
+                               float(alpha), _stream(a2)), "sbk_gemm_nt_bf16a")
+    return out
+
+
+def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, act=ACT_NONE):
+    """``layernorm`` written as bf16 (round to nearest even): the operand of a following gemm_nt_bf16a."""
+    lib = load()
+    d = gamma.numel()
+    x2 = x.reshape(-1, d)
+    _dev_ok(x2, gamma, beta)
+    _f32(x2)
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _chk(lib.sbk_layernorm_bf16o(_p(x2), _p(gamma), _p(beta), _p(out), x2.shape[0], d, float(eps), act, _stream(x2)),
+         "sbk_layernorm_bf16o")
+    return out
+
+
 def gemm_nt_splitk(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, slices=8):
     """gemm_nt for few-row operands with a caller-provided split-K workspace."""
     lib = load()
@@ -517,7 +565,8 @@ def relpos_attention(qkv, pos, bias_u, bias_v, key_len, H, scale, want_attn=Fals
     return out, attn
 
 
-def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False, chunk_size=0, left_chunks=-1, out=None):
+def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False, chunk_size=0, left_chunks=-1, out=None,
+                   out_dtype=torch.float32):
     """qkv [B,T,3*d] (per-head interleaved), cosines / sines [rows >= T, Dh] -> context [B,T,d].  ``cosines`` =
     ``sines`` = None: plain scaled-dot-product attention (no rotation; no attention-weights output)."""
     lib = load()
@@ -525,9 +574,17 @@ def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False, chun
     _f32(qkv)
     B, T, d3 = qkv.shape
     d = d3 // 3
+    rows = cosines.shape[0] if cosines is not None else 0
+    if out_dtype == torch.bfloat16:  # bf16 operands AND a bf16 context (the operand of the output projection)
+        if want_attn or d // H != 64 or out is not None:
+            raise SbkError("rope_attention: the bf16 context output needs head_dim 64 and no attention-weights output")
+        out = torch.empty(B, T, d, dtype=torch.bfloat16, device=qkv.device)
+        _chk(lib.sbk_rope_attention_bf16o(_p(qkv), _p(cosines), _p(sines), _p(key_len), _p(out), B, T, H, d // H,
+                                          rows, float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
+             "sbk_rope_attention_bf16o")
+        return out, None
     if out is None:
         out = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
-    rows = cosines.shape[0] if cosines is not None else 0
     if precision() == "bf16" and not want_attn and d // H == 64:  # opt-in: bf16 operands on the matrix cores
         _chk(lib.sbk_rope_attention_bf16(_p(qkv), _p(cosines), _p(sines), _p(key_len), _p(out), B, T, H, d // H,
                                          rows, float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),

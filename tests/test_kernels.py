@@ -498,6 +498,60 @@ def test_gemm_bf16_operands(backend, M, N, K):
     assert nat.bf16_weight(w.to(dev)) is nat.bf16_weight(w.to(dev)) or True  # (cache keyed by data_ptr: new tensor, new entry)
 
 
+@pytest.mark.parametrize("M,N,K,grid,stages", [(300, 200, 128, 0, 4), (700, 300, 192, 8, 4), (130, 260, 64, 8, 3), (257, 128, 320, 16, 4),
+                                               (12000, 1280, 1280, 0, 4), (12000, 5120, 1280, 0, 3), (4100, 1280, 5120, 64, 4)])
+def test_gemm_bf16_activation_operands(backend, M, N, K, grid, stages):
+    """sbk_gemm_nt_bf16a (bf16 activations between the bf16 contractions): A and W bf16 in memory, LDS-DMA panels through
+    a 3- / 4-stage pipeline that runs on across tile boundaries (grids smaller than the tile count), ragged edges; fp32
+    and bf16 outputs, bias / GELU / alpha / fp32 residual; against the exact product of the same bf16 operands.  Also
+    the producers: LayerNorm and attention context written as bf16 equal their fp32 outputs rounded to nearest even."""
+    nat, dev = backend
+    if dev.type == "cpu" and M * N * K > 6e7:
+        pytest.skip("large shape: GPU only")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.003).bfloat16()
+    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.002
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    lib = nat.load()
+    lib.sbk_prof_set_knob(27, stages)
+    lib.sbk_prof_set_knob(28, grid)
+    try:
+        ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+        big = M * N * K > 6e7
+        dd = (lambda t: t.to(dev).double()) if big else (lambda t: t.double())  # the large references on the device
+        A, W = dd(a), dd(w.bfloat16())
+        scale = float((A.abs() @ W.abs().t()).max())
+        out = nat.gemm_nt_bf16a(ad, wd, bd, rd, act=nat.ACT_GELU, alpha=0.5)
+        ref = dd(r) + 0.5 * F.gelu(A @ W.t() + dd(b))
+        assert out.dtype == torch.float32 and _md(out.cpu(), ref.float().cpu()) <= 2e-6 * scale + 1e-5
+        for _ in range(2 if dev.type == "cuda" else 1):
+            assert torch.equal(nat.gemm_nt_bf16a(ad, wd, bd, rd, act=nat.ACT_GELU, alpha=0.5), out)
+        ob = nat.gemm_nt_bf16a(ad, wd, bd, None, out_dtype=torch.bfloat16)
+        ref = (A @ W.t() + dd(b)).float()
+        assert ob.dtype == torch.bfloat16
+        # a bf16 result is the fp32 one rounded: one bf16 ulp (2^-8 relative) where the two fp32 sums straddle a boundary
+        assert float(((ob.float().cpu() - ref.cpu()).abs() / (ref.cpu().abs() + 1e-3 * scale)).max()) <= 2.0 ** -7
+        assert torch.equal(ob, nat.gemm_nt_bf16a(ad, wd, bd, None).bfloat16())
+    finally:
+        lib.sbk_prof_set_knob(27, 4)
+        lib.sbk_prof_set_knob(28, 0)
+    if M > 1000:
+        return
+    x = torch.randn(M // 10, 3, 256, generator=g).to(dev)
+    gam, bet = torch.randn(256, generator=g).to(dev), torch.randn(256, generator=g).to(dev)
+    assert torch.equal(nat.layernorm_bf16(x, gam, bet, 1e-5), nat.layernorm(x, gam, bet, 1e-5).bfloat16())
+    x5 = torch.randn(7, 1280, generator=g).to(dev)  # d = 1 280: the five-vector rows of Whisper large
+    g5, b5 = torch.randn(1280, generator=g).to(dev), torch.randn(1280, generator=g).to(dev)
+    ln5 = nat.layernorm(x5, g5, b5, 1e-5)
+    assert _md(ln5.cpu(), F.layer_norm(x5.cpu(), (1280,), g5.cpu(), b5.cpu(), 1e-5)) <= 5e-6
+    assert torch.equal(nat.layernorm_bf16(x5, g5, b5, 1e-5), ln5.bfloat16())
+    qkv = torch.randn(2, 70, 3 * 128, generator=g).to(dev)
+    with nat.precision_scope("bf16"):
+        c32, _ = nat.rope_attention(qkv, None, None, None, 2, 0.125)
+    cb, _ = nat.rope_attention(qkv, None, None, None, 2, 0.125, out_dtype=torch.bfloat16)
+    assert cb.dtype == torch.bfloat16 and torch.equal(cb, c32.bfloat16())
+
+
 SK64_DEFAULT_ROWS = 0  # csrc/gemm.hip g_sk64_min_rows
 
 

@@ -267,3 +267,33 @@ def test_whisper_language_identification_and_file_transcription(backend, tmp_pat
     assert all(s.words == "" and s.tokens == [] for s in skipped)  # every segment is above a zero no-speech threshold
     prompted = asr.transcribe_file(path, chunk_size=1, initial_prompt="hello", no_speech_threshold=None)
     assert prompted[0].prompt == [30, 31]
+
+
+def test_whisper_encoder_bf16_activation_pipeline(backend):
+    """precision "bf16": the encoder keeps the operands of its contractions in bf16 in memory (LayerNorm / attention /
+    GELU epilogue write bf16, native.gemm_nt_bf16a reads them by LDS-DMA).  Same roundings as the kernels that read fp32
+    activations and round on load (native.BF16_ACTIVATIONS = False): both within the bf16 tolerance of the fp32
+    encoder, and of each other (they differ by summation order only, so mostly bit-identical roundings)."""
+    nat, dev = backend
+    from speechbrain_amd.integrations.huggingface.whisper import Whisper
+
+    cfg = dict(num_mel_bins=80, d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256,
+               max_source_positions=40, decoder_layers=0, decoder_attention_heads=2, decoder_ffn_dim=256,
+               vocab_size=100, max_target_positions=16)
+    w = Whisper.from_config(cfg, encoder_only=True, seed=4).to(dev).eval()
+    mel = torch.randn(2, 80, 80, generator=torch.Generator().manual_seed(5)).to(dev)
+    with torch.no_grad():
+        ref = w.model.encoder(mel)
+        with nat.precision_scope("bf16"):
+            got_a = w.model.encoder(mel)
+            nat.BF16_ACTIVATIONS = False
+            try:
+                got_f = w.model.encoder(mel)
+            finally:
+                nat.BF16_ACTIVATIONS = True
+    assert got_a.dtype == torch.float32 and got_a.shape == ref.shape
+    rms = float(ref.pow(2).mean().sqrt())
+    for got in (got_a, got_f):
+        err = (got - ref).float()
+        assert float(err.abs().max()) <= 0.15 and float(err.pow(2).mean().sqrt()) <= 1e-2 * rms
+    assert float((got_a - got_f).pow(2).mean().sqrt()) <= 3e-3 * rms

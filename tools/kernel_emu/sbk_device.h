@@ -355,6 +355,8 @@ static inline void glds16(const float* src, float* lds_wave_base) {
 }
 static inline int uniform(int v) { return v; }
 static inline void vm_drain() {}
+template <int N>
+static inline void vm_wait() {}
 static inline void release_agent() { __atomic_thread_fence(__ATOMIC_RELEASE); }
 static inline void acquire_agent() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
 static inline int atomic_add_agent(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }

@@ -279,6 +279,30 @@ if __name__ == "__main__":
             nat.load().sbk_prof_set_knob(23, 1)
         nat.load().sbk_prof_set_knob(18, 1)
         sys.exit(0)
+    if "--bf16a" in sys.argv:  # bf16 activations + weights through the LDS-DMA pipeline vs the kernel that reads fp32 activations
+        def ev_time(fn, n=20):
+            fn(); fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+        shapes = [(12000, 3840, 1280), (12000, 1280, 1280), (12000, 5120, 1280), (12000, 1280, 5120), (12800, 2048, 512), (12800, 512, 2048), (48000, 1280, 1280)]
+        for (M, N, K) in shapes:
+            a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); ab = a.bfloat16()
+            t_old = ev_time(lambda: nat.gemm_nt_bf16(a, w))
+            line = f"bf16 gemm M={M} N={N} K={K}: fp32-A kernel {t_old:7.1f} us {2.0*M*N*K/t_old/1e6:7.1f} TF/s |"
+            for st, grid in ((4, 0), (3, 0), (4, 128)):
+                nat.load().sbk_prof_set_knob(27, st); nat.load().sbk_prof_set_knob(28, grid)
+                t32 = ev_time(lambda: nat.gemm_nt_bf16a(ab, w))
+                t16 = ev_time(lambda: nat.gemm_nt_bf16a(ab, w, out_dtype=torch.bfloat16))
+                line += f" bf16-A {st} stages grid {grid or 'cus'}: {t32:7.1f} us {2.0*M*N*K/t32/1e6:7.1f} TF/s (bf16 out {t16:7.1f} us {2.0*M*N*K/t16/1e6:7.1f}) |"
+            nat.load().sbk_prof_set_knob(27, 4); nat.load().sbk_prof_set_knob(28, 0)
+            print(line, flush=True)
+        sys.exit(0)
     if "--sk64" in sys.argv:  # decode-step GEMM shapes (rows = hypotheses in flight): today's paths vs the 64-wide persistent tiles
         shapes = [(M, N, K) for M in (320, 640, 1280) for (N, K) in ((512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512))]
         for tag, knobs in (("today (skinny / split-K / tile grid)", {25: 0}), ("persistent 64x64, 16 units per workgroup", {25: 1, 26: 16}),
