@@ -127,7 +127,7 @@ struct GemmBf16Args {
 // DT: 0 = bf16, 1 = fp16 (operands 8 x 16 bit per lane), 2 = fp8 e4m3 (8 x 8 bit per lane); all on the
 // 32x32x16 matrix-core shape with fp32 accumulation.
 template <int BM, int BN, int DT>
-__global__ void __launch_bounds__(256) gemm_nt_lp_kernel(GemmBf16Args g) {
+__global__ void __launch_bounds__(256, 2) gemm_nt_lp_kernel(GemmBf16Args g) {
   using Elem = typename std::conditional<DT == 2, unsigned char, unsigned short>::type;
   constexpr int ES = (int)sizeof(Elem);
   constexpr int BK = 32, PITCH = BK + 16 / ES;  // elements per LDS row: 16 bytes of padding
@@ -454,7 +454,9 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool VEC>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(GemmArgs g) {
+// (two waves per SIMD = a 256-register budget wherever the accumulators fit it: with the 512-register budget of one wave
+// per SIMD the compiler parks the accumulators in AGPRs and copies every one of them in and out around the K loop body)
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM * WN <= 64 * 64) ? 2 : 1) gemm_nt_kernel(GemmArgs g) {
   gemm_nt_tile<BM, BN, BK, WM, WN, VEC>(g);
 }
 
@@ -463,7 +465,7 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_kernel(Gem
 // move half the operand bytes of the 32x32 register-operand tiles through L2, and the K split puts 2-3 workgroups on
 // every CU so that their MFMA and load phases overlap.
 template <int BM, int BN, int BK, int WM, int WN, bool VEC>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_splitk_kernel(GemmArgs g, float* __restrict__ ws,
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM * WN <= 64 * 64) ? 2 : 1) gemm_nt_splitk_kernel(GemmArgs g, float* __restrict__ ws,
                                                                                      int kper) {
   const int z = blockIdx.z;
   g.A += (size_t)z * kper;
@@ -487,7 +489,7 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_splitk_ker
 // ds_write_b128.  Pitch BK+4 floats: the 16-lane groups of a b128 read (MI355X_MICROARCH.md, LDS table) land
 // on 16 distinct 4-bank groups because (BK+4)/4 is odd; the 8-lane groups of a b128 write cover one row.
 template <int BM, int BN, int BK, int WM, int WN, bool VEC>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_nt_v4_kernel(GemmArgs g) {
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM * WN <= 64 * 64) ? 2 : 1) gemm_nt_v4_kernel(GemmArgs g) {
   constexpr int WAVES_N = BN / WN;
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -903,9 +905,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
 // the panels go global -> LDS by LDS-DMA exactly like the fp32 persistent kernel's: a 128-byte LDS row is 64 bf16 (a
 // K tile of 64) instead of 32 floats, the same source-side slot swizzle makes the ds_read_b128 operand fetch (8
 // consecutive k of one row = one MFMA operand) conflict-free.  The matrix pipe needs a K tile every 512 cycles per
-// wave (16x the fp32 rate), so the double buffer of the fp32 kernel cannot cover the load latency: NS stages (NS - 1
-// K tiles in flight, s_waitcnt vmcnt(8 x tiles issued after the one needed) -- loads retire in order), one barrier per
-// K tile, one workgroup per CU.  Persistent over whole tiles (XCD-contiguous ranges, the K pipeline runs on across
+// wave (16x the fp32 rate): NS stages (NS - 1 K tiles in flight, s_waitcnt vmcnt(8 x tiles issued after the one needed)
+// -- loads retire in order), one barrier per K tile; default NS = 2 with two workgroups per CU (see launch_bf16dma).
+// 256-register budget: with 512 the compiler keeps the accumulators in AGPRs and copies all 64 in and out of VGPRs
+// every K tile.  Persistent over whole tiles (XCD-contiguous ranges, the K pipeline runs on across
 // tile boundaries and under the epilogue); no K split -- the shapes that take this path have thousands of tiles.
 struct Bf16DmaArgs {
   const unsigned short* A;
@@ -917,10 +920,11 @@ struct Bf16DmaArgs {
   int lda, ldw, ldr, ldc, ldcb, M, N, K, act;
   float alpha;
   int tiles_n, tiles, KT;
+  int mode;  // measurement only (knob 29): 1 = no MFMA work, 2 = no panel loads after the prologue (wrong results)
 };
 
 template <int NS>
-__global__ void __launch_bounds__(256, 1) gemm_nt_bf16dma_kernel(Bf16DmaArgs s) {
+__global__ void __launch_bounds__(256, 2) gemm_nt_bf16dma_kernel(Bf16DmaArgs s) {
   constexpr int BKF = 32, PANEL = 128 * BKF, STAGE = 2 * PANEL;  // float units (one unit = two bf16)
   SBK_DYN_LDS(float, lds);  // [NS][A 128 rows | W 128 rows][64 bf16]
   const unsigned short* const gA = s.A;
@@ -931,7 +935,7 @@ __global__ void __launch_bounds__(256, 1) gemm_nt_bf16dma_kernel(Bf16DmaArgs s) 
   unsigned short* const gCb = s.Cb;
   const int lda = s.lda, ldw = s.ldw, ldr = s.ldr, ldc = s.ldc, ldcb = s.ldcb, M = s.M, N = s.N, act = s.act;
   const float alpha = s.alpha;
-  const int tiles_n = s.tiles_n, KT = s.KT;
+  const int tiles_n = s.tiles_n, KT = s.KT, mode = s.mode;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = sbk::uniform(tid >> 6);
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
@@ -1043,7 +1047,7 @@ __global__ void __launch_bounds__(256, 1) gemm_nt_bf16dma_kernel(Bf16DmaArgs s) 
   int i_ord = 0, i_kt = 0, issued = 0;
   setup(t0 + j);
   auto issue_next = [&]() SBK_INLINE_LAMBDA {
-    issue(i_kt, issued % NS);
+    if (!(mode & 2) || issued < NS - 1) issue(i_kt, issued % NS);
     ++issued;
     if (++i_kt == KT) {
       i_kt = 0;
@@ -1069,7 +1073,7 @@ __global__ void __launch_bounds__(256, 1) gemm_nt_bf16dma_kernel(Bf16DmaArgs s) 
     }
     __syncthreads();  // ... and everybody's share of it; every wave is done with the stage of unit n - 1
     if (issued < U) issue_next();  // into the stage unit n - 1 occupied
-    compute(n % NS);
+    if (!(mode & 1)) compute(n % NS);
     if (++c_kt == KT) {
       epilogue(t0 + j + c_ord * W);
       zero();
@@ -1083,7 +1087,7 @@ __global__ void __launch_bounds__(256, 1) gemm_nt_bf16dma_kernel(Bf16DmaArgs s) 
 }
 
 template <int NCH>  // 32-float K chunks fetched per batch (all of them in flight together)
-__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __restrict__ partial, int kper,
+__global__ void __launch_bounds__(256, 2) gemm_skinny_kernel(GemmArgs g, float* __restrict__ partial, int kper,
                                                           int tiles_m, int tiles_n) {
   constexpr int KC = 32;  // floats per row per chunk (16 per lane half)
   __shared__ float red[3][32][33];
@@ -1165,7 +1169,7 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g, float* __r
 // in the looped kernel above it pairs every four MFMAs with a fresh load round trip, which makes a 128-deep
 // slice cost ~16 dependent L2 latencies), then the MFMA chain runs off registers.
 template <int NCH>
-__global__ void __launch_bounds__(256) gemm_skinny_flat_kernel(GemmArgs g, float* __restrict__ partial, int tiles_m,
+__global__ void __launch_bounds__(256, 2) gemm_skinny_flat_kernel(GemmArgs g, float* __restrict__ partial, int tiles_m,
                                                                int tiles_n) {
   constexpr int KC = 32;
   __shared__ float red[3][32][33];
@@ -1322,7 +1326,7 @@ __global__ void __launch_bounds__(256) gemm_skinny_flat64_kernel(GemmArgs g, flo
 // hence  LN(x).W^T + b = rstd * ((x - mean) . Wf^T) + bf.  Row statistics are the two-pass form of
 // csrc/norm.hip (mean, then sum of squared deviations), reduced across the waves through LDS.
 template <int NCH>
-__global__ void __launch_bounds__(256) gemm_skinny_ln_kernel(GemmArgs g, float eps, int tiles_m, int tiles_n) {
+__global__ void __launch_bounds__(256, 2) gemm_skinny_ln_kernel(GemmArgs g, float eps, int tiles_m, int tiles_n) {
   constexpr int KC = 32;
   __shared__ float red[3][32][33];
   __shared__ float stat[2][4][32];
@@ -1570,8 +1574,9 @@ int g_sk_min_rows = 2048;  // tuning knob (key 24): fewer rows than this never t
 int g_sk_min_units = 4;   // tuning knob (key 21): fewer units per workgroup than this shrinks the grid
 int g_sk64_min_rows = 0;  // tuning knob (key 25): from this many rows on (and below g_sk_min_rows) the 64x64-tile persistent kernel; 0 = off
 int g_sk64_units = 16;    // tuning knob (key 26): K units (64x64x32) per workgroup the 64-tile grid is sized for
-int g_bf16a_stages = 4;   // tuning knob (key 27): LDS stages of gemm_nt_bf16dma_kernel (3 or 4)
-int g_bf16a_grid = 0;     // tuning knob (key 28): its workgroups (0 = one per CU)
+int g_bf16a_stages = 2;   // tuning knob (key 27): LDS stages of gemm_nt_bf16dma_kernel (2, 3 or 4)
+int g_bf16a_grid = 0;     // tuning knob (key 28): its workgroups (0 = as many as fit: two per CU with 2 stages, one with 3 / 4)
+int g_bf16a_mode = 0;     // measurement knob (key 29)
 namespace {
 constexpr int kSkMaxGrid = 512, kSkMaxGrid64 = 1024, kSkMaxTiles = 1 << 16;  // (both grids fit the same slab area)
 int sk_cus();
@@ -1805,6 +1810,7 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 26) sbk::g_sk64_units = value > 0 ? value : 1;
   if (key == 27) sbk::g_bf16a_stages = value;
   if (key == 28) sbk::g_bf16a_grid = value;
+  if (key == 29) sbk::g_bf16a_mode = value;
 }
 
 
@@ -1824,17 +1830,22 @@ int launch_bf16dma(const Bf16DmaArgs& a0, hipStream_t st) {
   a.tiles_n = sbk::cdiv(a.N, 128);
   a.tiles = sbk::cdiv(a.M, 128) * a.tiles_n;
   a.KT = a.K / 64;
+  a.mode = sbk::g_bf16a_mode;
   int dev = 0, cus = 0;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (cus <= 0) cus = 256;
-  int G = sbk::g_bf16a_grid > 0 ? sbk::g_bf16a_grid : cus;
+  // Measured on MI355X (tools/microbench.py --bf16a, profiles/r03_bf16_activation_gemm.log): two stages and two
+  // workgroups per CU (634-827 TF/s at 12 000 rows) beat three / four stages with one (460-630): a second workgroup's
+  // MFMAs cover the ~100-cycle issue of each LDS-DMA piece better than a deeper pipeline of one wave per SIMD does
+  const int ns = sbk::g_bf16a_stages == 3 ? 3 : (sbk::g_bf16a_stages == 4 ? 4 : 2);
+  int G = sbk::g_bf16a_grid > 0 ? sbk::g_bf16a_grid : (ns == 2 ? 2 * cus : cus);
   if (G > a.tiles) G = a.tiles;
   G = G >= 8 ? (G / 8) * 8 : 8;
-  const int ns = sbk::g_bf16a_stages == 3 ? 3 : 4;
   const size_t lds = (size_t)ns * 2 * 128 * 32 * sizeof(float);
   static bool once = false;
   if (!once) {
+    (void)SBK_ALLOW_DYN_LDS(gemm_nt_bf16dma_kernel<2>, (size_t)2 * 2 * 128 * 32 * sizeof(float));
     (void)SBK_ALLOW_DYN_LDS(gemm_nt_bf16dma_kernel<3>, (size_t)3 * 2 * 128 * 32 * sizeof(float));
     (void)SBK_ALLOW_DYN_LDS(gemm_nt_bf16dma_kernel<4>, (size_t)4 * 2 * 128 * 32 * sizeof(float));
     once = true;
@@ -1842,7 +1853,9 @@ int launch_bf16dma(const Bf16DmaArgs& a0, hipStream_t st) {
   sbk::ProfScope prof("gemm_nt_bf16a", 2.0 * a.M * a.N * a.K,
                       2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.C ? 4.0 : 0.0) * a.M * a.N + (a.Cb ? 2.0 : 0.0) * a.M * a.N +
                           (a.R ? 4.0 : 0.0) * a.M * a.N, st);
-  if (ns == 3) {
+  if (ns == 2) {
+    SBK_LAUNCH(gemm_nt_bf16dma_kernel<2>, dim3((unsigned)G), dim3(256), lds, st, a);
+  } else if (ns == 3) {
     SBK_LAUNCH(gemm_nt_bf16dma_kernel<3>, dim3((unsigned)G), dim3(256), lds, st, a);
   } else {
     SBK_LAUNCH(gemm_nt_bf16dma_kernel<4>, dim3((unsigned)G), dim3(256), lds, st, a);
@@ -1902,7 +1915,7 @@ extern "C" int sbk_gemm_nt_bf16a(const uint16_t* A, int lda, const uint16_t* Wb,
               "gemm_bf16a: operand rows must be 16-byte aligned (lda=%d ldw=%d)", lda, ldw);
   SBK_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N) && (!residual || ldr >= N), "gemm_bf16a: leading dimension smaller than the row");
   SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_bf16a: unknown activation %d", act);
-  Bf16DmaArgs a{A, Wb, bias, residual, C, Cb, lda, ldw, ldr, ldc, ldcb, M, N, K, act, alpha, 0, 0, 0};
+  Bf16DmaArgs a{A, Wb, bias, residual, C, Cb, lda, ldw, ldr, ldc, ldcb, M, N, K, act, alpha, 0, 0, 0, 0};
   return launch_bf16dma(a, sbk::as_stream(stream));
 }
 

@@ -295,12 +295,13 @@ if __name__ == "__main__":
             a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); ab = a.bfloat16()
             t_old = ev_time(lambda: nat.gemm_nt_bf16(a, w))
             line = f"bf16 gemm M={M} N={N} K={K}: fp32-A kernel {t_old:7.1f} us {2.0*M*N*K/t_old/1e6:7.1f} TF/s |"
-            for st, grid in ((4, 0), (3, 0), (4, 128)):
-                nat.load().sbk_prof_set_knob(27, st); nat.load().sbk_prof_set_knob(28, grid)
+            for st, grid, mode in ((4, 0, 0), (2, 512, 0), (2, 768, 0), (4, 0, 1), (4, 0, 2), (2, 512, 1), (2, 512, 2)):
+                for k, v in ((27, st), (28, grid), (29, mode)):
+                    nat.load().sbk_prof_set_knob(k, v)
                 t32 = ev_time(lambda: nat.gemm_nt_bf16a(ab, w))
-                t16 = ev_time(lambda: nat.gemm_nt_bf16a(ab, w, out_dtype=torch.bfloat16))
-                line += f" bf16-A {st} stages grid {grid or 'cus'}: {t32:7.1f} us {2.0*M*N*K/t32/1e6:7.1f} TF/s (bf16 out {t16:7.1f} us {2.0*M*N*K/t16/1e6:7.1f}) |"
-            nat.load().sbk_prof_set_knob(27, 4); nat.load().sbk_prof_set_knob(28, 0)
+                line += f" {st} stages grid {grid or 'cus'} mode {mode}: {t32:7.1f} us {2.0*M*N*K/t32/1e6:7.1f} TF/s |"
+            for k, v in ((27, 2), (28, 0), (29, 0)):
+                nat.load().sbk_prof_set_knob(k, v)
             print(line, flush=True)
         sys.exit(0)
     if "--sk64" in sys.argv:  # decode-step GEMM shapes (rows = hypotheses in flight): today's paths vs the 64-wide persistent tiles
