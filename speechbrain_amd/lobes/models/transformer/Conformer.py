@@ -124,7 +124,13 @@ class ConformerEncoderLayer(nn.Module):
 
     def _ffn(self, mod, x):
         ln, ffn = mod[0], mod[1]
-        h = native.layernorm(x, ln.weight, ln.bias, ln.eps)
+        if (native.precision() == "bf16" and native.BF16_ACTIVATIONS and x.numel() // x.shape[-1] >= 256
+                and native.bf16a_ok(x.shape[-1]) and native.bf16a_ok(ffn.ffn[0].out_features)):
+            # opt-in bf16 operands: LayerNorm writes the first contraction's operand as bf16 (same rounding the fp32-A
+            # kernel applies on load), the feed-forward pair keeps its hidden layer in bf16
+            h = native.layernorm_bf16(x, ln.weight, ln.bias, ln.eps)
+        else:
+            h = native.layernorm(x, ln.weight, ln.bias, ln.eps)
         return ffn(h, residual=x, alpha=0.5)
 
     def forward(self, x, src_mask=None, src_key_padding_mask=None, pos_embs=None, dynchunktrain_config=None,
