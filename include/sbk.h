@@ -176,6 +176,14 @@ int sbk_layernorm_bf16o(const float* x, const float* gamma, const float* beta, u
 int sbk_rope_attention_bf16o(const float* qkv, const float* cosines, const float* sines, const int32_t* key_len,
                              uint16_t* out, int B, int T, int H, int Dh, int table_rows, float scale, int chunk_size,
                              int left_chunks, sbk_stream_t stream);
+/* Plain scaled-dot-product attention with bf16 rows in and out (head_dim 64): qkv [B,T,H,3,64] bf16 as written by
+ * sbk_gemm_nt_bf16a, out [B,T,H*64] bf16; workspace (sbk_attention_bf16io_workspace_bytes) receives the transposed
+ * values.  K rows and V^T rows of a 64-key tile are shared by the 128 queries of a workgroup through LDS (LDS-DMA);
+ * fp32 scores / softmax statistics / context accumulation, probabilities rounded to bf16 as in
+ * sbk_rope_attention_bf16 (nnet/attention.py:941-945 scaled_dot_product_attention of the HF Whisper encoder layer). */
+size_t sbk_attention_bf16io_workspace_bytes(int B, int T, int H);
+int sbk_attention_bf16io(const uint16_t* qkv, const int32_t* key_len, uint16_t* out, uint16_t* workspace, int B, int T,
+                         int H, int Dh, float scale, sbk_stream_t stream);
 
 /* The same contraction with fp16 operands (v_mfma_f32_32x32x16_f16; A rounded to nearest even on its way into LDS, Wh =
  * the weights converted once by sbk_f32_to_f16).  fp16 has 3 more mantissa bits than bf16 and a narrower range

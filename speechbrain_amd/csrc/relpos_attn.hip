@@ -878,6 +878,170 @@ __global__ void __launch_bounds__(256, 2) rope_flash_t_bf16_kernel(AttnArgs a) {
   }
 }
 
+// ---- plain attention on bf16 q / k / v rows shared through LDS (the Whisper encoder under precision "bf16") ------------
+// qkv [B,T,H,3,64] bf16 as written by the bf16-activation QKV contraction; vT [B,H,64,Tp] bf16 = the values transposed
+// (v_transpose_bf16_kernel, Tp = T rounded up to 64, zero padded).  A workgroup = one (utterance, head) and 128 queries
+// (four waves of 32); the K rows and V^T rows of a 64-key tile go global -> LDS by LDS-DMA once per workgroup (double
+// buffer, 128-byte rows, the 16-byte slot s of row r lands in slot s ^ ((r>>1)&7): the ds_read_b128 operand fetch of the
+// GEMM kernels) instead of once per wave from L2.  Scores transposed as in rope_flash_t_kernel: S^T = K Q^T with Q in
+// registers; MFMA row i of a 32-key sub-tile holds key i with bits 2 and 3 swapped, so that the 8 probabilities a lane
+// packs for MFMA step s of the context product belong to the 8 CONSECUTIVE keys 16s + 8*half .. +7 -- one
+// ds_read_b128 of a V^T row.  Online softmax in fp32 (scores scaled after the MFMA), probabilities rounded to bf16,
+// context accumulated in fp32 and written as bf16 (the output projection's operand).
+struct AttnLdsArgs {
+  const unsigned short* qkv;
+  const unsigned short* vT;
+  const int32_t* key_len;
+  unsigned short* out;  // [B,T,H*64] bf16
+  int B, T, Tp, H;
+  float scale;
+};
+
+__global__ void __launch_bounds__(256) v_transpose_bf16_kernel(const unsigned short* __restrict__ qkv,
+                                                               unsigned short* __restrict__ vT, int T, int Tp, int H) {
+  __shared__ unsigned short tile[64][66];
+  const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const size_t row3 = (size_t)3 * H * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int t = e >> 6, c = e & 63;
+    tile[t][c] = t0 + t < T ? qkv[((size_t)b * T + t0 + t) * row3 + (size_t)h * 192 + 128 + c] : (unsigned short)0;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int c = e >> 6, t = e & 63;
+    vT[(((size_t)b * H + h) * 64 + c) * Tp + t0 + t] = tile[t][c];
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) attn_lds_bf16_kernel(AttnLdsArgs a) {
+  using sbk::bf16x8;
+  constexpr int TILE = 64 * 32;  // floats: 64 rows x 128 bytes
+  SBK_DYN_LDS(float, lds);       // [2 stages][K tile | V^T tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = sbk::uniform(tid >> 6);
+  const int jl = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int T = a.T, d = a.H * 64;
+  const int i0 = blockIdx.x * 128 + wave * 32;
+  const size_t row3 = (size_t)3 * d;
+  const unsigned short* qkv_b = a.qkv + (size_t)b * T * row3 + (size_t)h * 192;
+  const unsigned short* vT_b = a.vT + ((size_t)b * a.H + h) * 64 * a.Tp;
+  int klen = T;
+  if (a.key_len) klen = min(max(a.key_len[b], 1), T);
+  const int ntile = (klen + 63) / 64;
+
+  // Q operands: channels 16t + 8*half .. +7 of this lane's query row
+  bf16x8 qb[4];
+  {
+    const unsigned short* qrow = qkv_b + (size_t)min(i0 + jl, T - 1) * row3;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qb[t] = *reinterpret_cast<const bf16x8*>(qrow + 16 * t + 8 * half);
+  }
+  // loader: wave w fills rows 16w .. 16w+15 of the K tile and of the V^T tile (two 8-row pieces each)
+  const int lr = lane >> 3, ls = lane & 7;
+  auto issue = [&](int tile, int stage) SBK_INLINE_LAMBDA {
+    float* base = lds + stage * 2 * TILE;
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+      const int r = wave * 16 + pc * 8 + lr;  // row of the tile: a key (K) / a channel (V^T)
+      const int sl = (ls ^ ((r >> 1) & 7)) * 8;  // source offset (bf16 elements) of the slot this lane fills
+      const int key = min(tile * 64 + r, T - 1);  // keys past the utterance re-read its last row (masked below)
+      sbk::glds16(reinterpret_cast<const float*>(qkv_b + (size_t)key * row3 + 64 + sl), base + (wave * 16 + pc * 8) * 32);
+      sbk::glds16(reinterpret_cast<const float*>(vT_b + (size_t)r * a.Tp + tile * 64 + sl), base + TILE + (wave * 16 + pc * 8) * 32);
+    }
+  };
+  f32x16 o[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[c][r] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+  // MFMA row jl of a score sub-tile = key jl with bits 2 and 3 swapped
+  const int krow = (jl & 19) | ((jl & 4) << 1) | ((jl & 8) >> 1);
+  const int ksw = (krow >> 1) & 7, vsw = (jl >> 1) & 7;  // (rows + 32 have the same swizzle)
+
+  issue(0, 0);
+  sbk::vm_drain();
+  __syncthreads();
+  for (int kt = 0; kt < ntile; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < ntile) issue(kt + 1, stage ^ 1);
+    const float* Kt = lds + stage * 2 * TILE;
+    const float* Vt = Kt + TILE;
+    f32x16 acc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bf16x8 kb = *reinterpret_cast<const bf16x8*>(Kt + (32 * u + krow) * 32 + (((2 * t + half) ^ ksw) << 2));
+        acc[u] = sbk::mfma_32x32x16_bf16(kb, qb[t], acc[u]);
+      }
+    }
+    // acc[u][r]: key 64 kt + 32u + 16 (r>>3) + 8 half + (r&7), query jl
+    float mx = -INFINITY;
+    const bool tail = (kt + 1) * 64 > klen;  // uniform: only the last tile has keys to mask
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[u][r] * a.scale;
+        if (tail && kt * 64 + 32 * u + 16 * (r >> 3) + 8 * half + (r & 7) >= klen) v = -INFINITY;
+        acc[u][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, sbk::shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);  // finite: key 64 kt is inside the utterance
+    const float alpha = expf(m_run - m_new);
+    float sum = 0.0f;
+    bf16x8 pb[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          x[e] = expf(acc[u][8 * s2 + e] - m_new);
+          sum += x[e];
+        }
+        pb[u][s2] = sbk::cvt_bf16x8(x);
+      }
+    sum += sbk::shfl_xor(sum, 32);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[c][r] *= alpha;
+    // O^T[channel 32c + row][query] += V^T[channel][keys 32u + 16s + 8 half .. +7] . P^T
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const bf16x8 vb = *reinterpret_cast<const bf16x8*>(Vt + (32 * c + jl) * 32 + (((4 * u + 2 * s2 + half) ^ vsw) << 2));
+          o[c] = sbk::mfma_32x32x16_bf16(vb, pb[u][s2], o[c]);
+        }
+    sbk::vm_drain();   // this wave's pieces of the next tile have landed ...
+    __syncthreads();   // ... and everybody's; every wave is done with `stage`
+  }
+  if (i0 + jl < T) {
+    const float inv = 1.0f / l_run;
+    unsigned short* orow = a.out + ((size_t)b * T + i0 + jl) * d + h * 64;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint2 pk;
+        pk.x = (unsigned)sbk::f32_to_bf16(o[c][4 * q] * inv) | ((unsigned)sbk::f32_to_bf16(o[c][4 * q + 1] * inv) << 16);
+        pk.y = (unsigned)sbk::f32_to_bf16(o[c][4 * q + 2] * inv) | ((unsigned)sbk::f32_to_bf16(o[c][4 * q + 3] * inv) << 16);
+        *reinterpret_cast<uint2*>(orow + c * 32 + 8 * q + 4 * half) = pk;
+      }
+  }
+}
+
 template <int DH, bool ROPE>
 int launch_flash(const AttnArgs& a, hipStream_t st) {
   sbk::ProfScope prof(ROPE ? "rope_attention" : "relpos_attention", (ROPE ? 4.0 : 6.0) * a.B * a.H * (double)a.T * a.T * DH,
@@ -1022,6 +1186,28 @@ int rope_attention_bf16_impl(const float* qkv, const float* cosines, const float
   return sbk::launch_status("sbk_rope_attention_bf16");
 }
 }  // namespace
+
+extern "C" size_t sbk_attention_bf16io_workspace_bytes(int B, int T, int H) {
+  return (size_t)B * H * 64 * ((T + 63) / 64 * 64) * sizeof(uint16_t);
+}
+extern "C" int sbk_attention_bf16io(const uint16_t* qkv, const int32_t* key_len, uint16_t* out, uint16_t* workspace, int B,
+                                    int T, int H, int Dh, float scale, sbk_stream_t stream) {
+  if (B == 0 || T == 0) return 0;
+  SBK_REQUIRE(qkv && out && workspace, "attention_bf16io: null operand");
+  SBK_REQUIRE(B > 0 && T > 0 && H > 0 && Dh == 64, "attention_bf16io: head_dim 64 only (got %d)", Dh);
+  SBK_REQUIRE(sbk::aligned16(qkv) && sbk::aligned16(workspace) && (reinterpret_cast<uintptr_t>(out) & 7) == 0,
+              "attention_bf16io: operands must be 16-byte aligned");
+  hipStream_t st = sbk::as_stream(stream);
+  const int Tp = (T + 63) / 64 * 64;
+  AttnLdsArgs a{qkv, workspace, key_len, out, B, T, Tp, H, scale};
+  sbk::ProfScope prof("attention_bf16io", 4.0 * B * H * (double)T * T * Dh, 2.0 * B * T * (5.0 * H * Dh) + 2.0 * B * H * 64.0 * Tp, st);
+  SBK_LAUNCH(v_transpose_bf16_kernel, dim3(Tp / 64, H, B), dim3(256), 0, st, qkv, workspace, T, Tp, H);
+  int rc = sbk::launch_status("sbk_attention_bf16io (transpose)");
+  if (rc) return rc;
+  const size_t lds = (size_t)2 * 2 * 64 * 32 * sizeof(float);
+  SBK_LAUNCH(attn_lds_bf16_kernel, dim3((T + 127) / 128, H, B), dim3(256), lds, st, a);
+  return sbk::launch_status("sbk_attention_bf16io");
+}
 
 extern "C" int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                                         const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,

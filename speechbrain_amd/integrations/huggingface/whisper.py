@@ -232,9 +232,8 @@ class WhisperEncoder(nn.Module):
             w_in, b_in = att.stacked(interleave_heads=True)
             if bf16a:
                 h = native.layernorm_bf16(x, ln.weight, ln.bias, ln.eps)
-                qkv = native.gemm_nt_bf16a(h, w_in, b_in)
-                ctx, _ = native.rope_attention(qkv, None, None, None, att.num_heads, att.head_dim ** -0.5,
-                                               out_dtype=torch.bfloat16)
+                qkv = native.gemm_nt_bf16a(h, w_in, b_in, out_dtype=torch.bfloat16)
+                ctx = native.attention_bf16(qkv, None, att.num_heads, att.head_dim ** -0.5)  # K / V^T tiles shared through LDS
                 x = native.gemm_nt_bf16a(ctx, att.out_proj.weight, att.out_proj.bias, residual=x)
                 ln = layer.final_layer_norm
                 h = native.layernorm_bf16(x, ln.weight, ln.bias, ln.eps)

@@ -124,7 +124,7 @@ class ConformerEncoderLayer(nn.Module):
 
     def _ffn(self, mod, x):
         ln, ffn = mod[0], mod[1]
-        if (native.precision() == "bf16" and native.BF16_ACTIVATIONS and x.numel() // x.shape[-1] >= 256
+        if (native.precision() == "bf16" and native.BF16_ACTIVATIONS and x.numel() // x.shape[-1] >= native.BF16A_MIN_ROWS
                 and native.bf16a_ok(x.shape[-1]) and native.bf16a_ok(ffn.ffn[0].out_features)):
             # opt-in bf16 operands: LayerNorm writes the first contraction's operand as bf16 (same rounding the fp32-A
             # kernel applies on load), the feed-forward pair keeps its hidden layer in bf16

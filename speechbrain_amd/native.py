@@ -96,6 +96,8 @@ def _declare(lib):
         "sbk_gemm_nt_bf16a": ([p, i, p, i, p, p, i, p, i, p, i, i, i, i, i, f, p], c_int),
         "sbk_layernorm_bf16o": ([p, p, p, p, i, i, f, i, p], c_int),
         "sbk_rope_attention_bf16o": ([p, p, p, p, p, i, i, i, i, i, f, i, i, p], c_int),
+        "sbk_attention_bf16io_workspace_bytes": ([i, i, i], ctypes.c_size_t),
+        "sbk_attention_bf16io": ([p, p, p, p, i, i, i, i, f, p], c_int),
         "sbk_f32_to_f16": ([p, p, ctypes.c_long, p], c_int),
         "sbk_gemm_nt_fp8": ([p, i, p, p, i, f, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_f32_to_fp8": ([p, p, ctypes.c_long, f, p], c_int),
@@ -338,6 +340,10 @@ def gemm_nt_bf16(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act
 # precision "bf16": keep the operands of consecutive contractions in bf16 in memory where a model's forward supports it
 # (the Whisper encoder); False = every contraction reads fp32 activations and rounds them on load (A/B, tests)
 BF16_ACTIVATIONS = True
+# rows from which the Conformer feed-forward pairs take that path: its 128x128-tile persistent kernel needs a few hundred
+# tiles of a long K loop; measured on MI355X (tools/microbench.py --enc-bf16, profiles/r03_bf16_attention_lds_and_conformer_bf16.log)
+# 32 x 20 s (16 000 rows) encodes in 15.7 instead of 17.0 ms, 32 x 10 s in 9.4 instead of 8.9
+BF16A_MIN_ROWS = 16000
 
 
 def bf16a_ok(K: int) -> bool:
@@ -595,6 +601,22 @@ def rope_attention(qkv, cosines, sines, key_len, H, scale, want_attn=False, chun
                                     rows, float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
          "sbk_rope_attention_f32")
     return out, attn
+
+
+def attention_bf16(qkv: torch.Tensor, key_len, H: int, scale: float):
+    """Plain attention on bf16 rows: qkv [B,T,3*d] torch.bfloat16 (per-head interleaved, written by gemm_nt_bf16a) ->
+    context [B,T,d] torch.bfloat16 (head_dim 64)."""
+    lib = load()
+    _dev_ok(qkv, key_len)
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    if qkv.dtype != torch.bfloat16 or not qkv.is_contiguous() or d // H != 64:
+        raise SbkError("attention_bf16: contiguous torch.bfloat16 qkv rows with head_dim 64")
+    out = torch.empty(B, T, d, dtype=torch.bfloat16, device=qkv.device)
+    ws = torch.empty(lib.sbk_attention_bf16io_workspace_bytes(B, T, H) // 2, dtype=torch.bfloat16, device=qkv.device)
+    _chk(lib.sbk_attention_bf16io(_p(qkv), _p(key_len), _p(out), _p(ws), B, T, H, d // H, float(scale), _stream(qkv)),
+         "sbk_attention_bf16io")
+    return out
 
 
 def glu_dwconv(h, w, bias, ksize, chunk_size=0, out=None):

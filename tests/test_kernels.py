@@ -552,6 +552,37 @@ def test_gemm_bf16_activation_operands(backend, M, N, K, grid, stages):
     assert cb.dtype == torch.bfloat16 and torch.equal(cb, c32.bfloat16())
 
 
+@pytest.mark.parametrize("B,T,H,ragged", [(2, 70, 2, False), (1, 200, 1, True), (2, 129, 3, True), (8, 1500, 20, False)])
+def test_attention_bf16_rows_through_lds(backend, B, T, H, ragged):
+    """sbk_attention_bf16io: plain attention on bf16 q / k / v rows, K and V^T tiles of 64 keys shared by a workgroup's
+    128 queries through LDS (LDS-DMA), keys permuted inside a score sub-tile so that the probabilities feed the context
+    product without a shuffle.  Against fp64 attention on the same bf16 inputs: the only roundings in the kernel are the
+    probabilities' (bf16, 2^-9 relative) and the bf16 output (2^-9); partial last key tile, key lengths, partial last
+    query block; the Whisper large-v3 shape on the GPU."""
+    nat, dev = backend
+    if dev.type == "cpu" and B * H * T * T > 4e5:
+        pytest.skip("large shape: GPU only")
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    d = 64 * H
+    qkv = (torch.randn(B, T, 3 * d, generator=g) * 1.5).bfloat16()
+    lens = torch.tensor([T] + [max(1, (T * (k + 3)) // (k + 5)) for k in range(B - 1)], dtype=torch.int32) if ragged else None
+    out = nat.attention_bf16(qkv.to(dev), lens.to(dev) if ragged else None, H, 0.125)
+    assert out.dtype == torch.bfloat16 and out.shape == (B, T, d)
+    x = qkv.to(dev).double().view(B, T, H, 3, 64)
+    q, k, v = x[:, :, :, 0].transpose(1, 2), x[:, :, :, 1].transpose(1, 2), x[:, :, :, 2].transpose(1, 2)  # [B,H,T,64]
+    sc = q @ k.transpose(-1, -2) * 0.125
+    if ragged:
+        sc = sc.masked_fill(torch.arange(T, device=dev)[None, None, None, :] >= lens.to(dev)[:, None, None, None], float("-inf"))
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B, T, d)
+    err = (out.double() - ref).abs()
+    assert float(err.max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-3, float(err.max())
+    assert float(err.pow(2).mean().sqrt()) <= 4e-3 * float(ref.pow(2).mean().sqrt())
+    # the fp32-row kernel (rounds the same rows on load) agrees to the bf16 output rounding
+    with nat.precision_scope("bf16"):
+        alt, _ = nat.rope_attention(qkv.to(dev).float(), None, None, lens.to(dev) if ragged else None, H, 0.125)
+    assert float((out.float() - alt).abs().max()) <= 2.0 ** -6 * float(ref.abs().max()) + 1e-3
+
+
 SK64_DEFAULT_ROWS = 0  # csrc/gemm.hip g_sk64_min_rows
 
 

@@ -229,6 +229,35 @@ if __name__ == "__main__":
                       {k: (round(v["ms"] / 3, 2), round(v["flops"] / v["ms"] / 1e9, 1)) for k, v in gem.items()}, flush=True)
         nat.load().sbk_prof_set_knob(18, 1); nat.load().sbk_prof_set_knob(19, 0)
         sys.exit(0)
+    if "--enc-bf16" in sys.argv:  # Conformer-L encoder under precision bf16: bf16 activations in memory (feed-forward pairs) vs fp32 activations rounded on load
+        from speechbrain_amd.inference.builders import build_asr
+        asr = build_asr("L", vocab=5000, seed=0, device="cuda:0")
+        asr.eval_precision = "bf16"
+        for sec in (5, 10, 20):
+            wav = (0.1 * torch.randn(32, sec * 16000, generator=torch.Generator().manual_seed(sec))).to(dev)
+            lens = torch.ones(32, device=dev)
+            for flag in (True, False):
+                nat.BF16_ACTIVATIONS = flag
+                with torch.no_grad():
+                    for _ in range(2):
+                        asr.encode_batch(wav, lens)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        asr.encode_batch(wav, lens)
+                    torch.cuda.synchronize()
+                    wall = (time.perf_counter() - t0) / 5
+                    nat.prof_reset(); nat.prof_enable(True)
+                    for _ in range(3):
+                        asr.encode_batch(wav, lens)
+                    torch.cuda.synchronize()
+                    nat.prof_enable(False)
+                rep = nat.prof_report(); nat.prof_reset()
+                tot = sum(v["ms"] for v in rep.values())
+                print(f"enc 32x{sec}s bf16 activations {flag}: wall {1e3 * wall:7.2f} ms, kernel events {tot / 3:7.2f} ms |",
+                      {k: (v["count"] // 3, round(v["ms"] / 3, 2), round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:7]}, flush=True)
+        nat.BF16_ACTIVATIONS = True
+        sys.exit(0)
     if "--mfma-peak" in sys.argv:  # f32 matrix-core ceiling under DVFS (registers only), then the stream-K GEMM with its panel loads off
         sink = torch.zeros(4096, device=dev)
         tf = ctypes.c_float(0)
