@@ -213,9 +213,10 @@ def whisper_encoder_leg(dev, B=8, reps=3):
     wav = 0.1 * torch.randn(B, 480000, generator=torch.Generator().manual_seed(3))
     wav = wav.to(dev)
     res = {"workload": f"log-mel + Whisper large-v3 encoder forward, {B} x 30 s, random weights, one stream",
-           "precisions": "operand type of the GEMMs (fp32 accumulation everywhere): fp32 = parity path; bf16 also uses the bf16 "
-                         "attention kernel; fp16; fp8 = e4m3 with per-tensor scales (activation max |x| found on the device per "
-                         "GEMM).  Activations stay fp32 in HBM, which is what bounds all three"}
+           "precisions": "operand type of the GEMMs (fp32 accumulation everywhere): fp32 = parity path; bf16 = bf16 activations "
+                         "between the contractions (LayerNorm / attention / GELU epilogue write bf16, LDS-DMA bf16 GEMM, "
+                         "attention with K / V^T tiles shared through LDS; residual stream fp32); fp16 and fp8 (e4m3, per-tensor "
+                         "scales, activation max |x| found on the device per GEMM) read fp32 activations and round them on load"}
     flops = B * 32 * (1500 * 2.0 * (4 * 1280 * 1280 + 2 * 1280 * 5120) + 4.0 * 1500 * 1500 * 1280) \
         + B * 2.0 * (3000 * 1280 * 384 + 1500 * 1280 * 3840)
     for prec in ("fp32", "bf16", "fp16", "fp8"):

@@ -614,7 +614,11 @@ struct SkArgs {
 
 // BT: tile edge (128: four waves of 64x64, the encoder shapes; 64: four waves of 32x32, 32 KB of LDS -- the decode-step
 // shapes of 640-1 280 rows, where 128-wide tiles leave most CUs without one)
-template <int BT>
+// IL: the LDS-DMA pieces of the next K tile are issued BETWEEN the MFMA groups of the current one (one A piece and one W
+// piece per group of 4 k) instead of in one block in front of them: a piece keeps its wave's issue port for ~60-150
+// cycles, which a 64-cycle fp32 MFMA in flight covers -- in one block the eight pieces leave the matrix pipe of that
+// wave empty for ~1 000 cycles per K tile (the kernel's time was the SUM of its no-load and load-only times).
+template <int BT, bool IL>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
   constexpr int BK = 32, PANEL = BT * BK, STAGE = 2 * PANEL;  // floats
   constexpr int TS = BT / 64, WT = BT / 2, LI = BT / 32;      // 32x32 sub-tiles per wave and dimension, wave tile edge, loader instructions per wave and panel
@@ -711,9 +715,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   };
-  auto compute = [&](int stage) SBK_INLINE_LAMBDA {
+  auto compute = [&](int stage, bool fly, int nkt) SBK_INLINE_LAMBDA {
     const float* As = lds + stage * STAGE + (wm0 + lrow) * BK;
     const float* Ws = lds + stage * STAGE + PANEL + (wn0 + lrow) * BK;
+    float* nbase = lds + (stage ^ 1) * STAGE + (wave * LI) * 256;
 #pragma unroll
     for (int gk = 0; gk < 4; ++gk) {
       const int slot = ((2 * gk + half) ^ sw) * 4;
@@ -732,6 +737,12 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
             const float bw = e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w;
             acc[i][j] = sbk::mfma_32x32x2(av, bw, acc[i][j]);
           }
+      if constexpr (IL) {
+        if (fly && gk < LI) {  // (uniform) behind this group's MFMAs
+          sbk::glds16(ap[gk] + nkt * BK, nbase + gk * 256);
+          sbk::glds16(wp[gk] + nkt * BK, nbase + PANEL + gk * 256);
+        }
+      }
     }
   };
   auto epilogue = [&](int tile) SBK_INLINE_LAMBDA {
@@ -866,9 +877,9 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
     }
     if (has_next) {  // the next unit's panels fly while this one is multiplied
       if (seg_ends) setup(ntile);
-      if (!noload) issue(nkt, stage ^ 1);
+      if (!IL && !noload) issue(nkt, stage ^ 1);
     }
-    compute(stage);
+    compute(stage, has_next && !noload, nkt);
     sbk::vm_drain();   // this wave's share of the next panels has landed ...
     __syncthreads();   // ... and everybody's; every wave is done reading `stage`
     if (seg_ends) {
@@ -1572,6 +1583,7 @@ int g_sk_noload = 0;      // measurement knob (key 22)
 int g_sk_stagger = 1;     // tuning knob (key 23): upper half of each XCD's workgroups runs its tail share first
 int g_sk_min_rows = 2048;  // tuning knob (key 24): fewer rows than this never take the persistent kernel in routed mode
 int g_sk_min_units = 4;   // tuning knob (key 21): fewer units per workgroup than this shrinks the grid
+int g_sk_interleave = 0;  // tuning knob (key 30): 1 = the next K tile's LDS-DMA pieces are issued between the MFMA groups
 int g_sk64_min_rows = 0;  // tuning knob (key 25): from this many rows on (and below g_sk_min_rows) the 64x64-tile persistent kernel; 0 = off
 int g_sk64_units = 16;    // tuning knob (key 26): K units (64x64x32) per workgroup the 64-tile grid is sized for
 int g_bf16a_stages = 2;   // tuning knob (key 27): LDS stages of gemm_nt_bf16dma_kernel (2, 3 or 4)
@@ -1674,16 +1686,21 @@ int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st) {
   const size_t lds = (size_t)(2 * 2 * bt * 32 + 4) * sizeof(float);
   static bool once = false;
   if (!once) {
-    (void)SBK_ALLOW_DYN_LDS(gemm_nt_sk_kernel<128>, (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float));
+    (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false>), (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float));
+    (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, true>), (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float));
     once = true;
   }
   const double flops = 2.0 * g.M * g.N * g.K, bytes = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
   if (bt == 64) {
     ProfScope prof("gemm_nt_persistent64", flops, bytes, st);
-    SBK_LAUNCH(gemm_nt_sk_kernel<64>, dim3((unsigned)G), dim3(256), lds, st, s);
+    SBK_LAUNCH((gemm_nt_sk_kernel<64, false>), dim3((unsigned)G), dim3(256), lds, st, s);
   } else {
     ProfScope prof("gemm_nt_persistent", flops, bytes, st);
-    SBK_LAUNCH(gemm_nt_sk_kernel<128>, dim3((unsigned)G), dim3(256), lds, st, s);
+    if (g_sk_interleave) {
+      SBK_LAUNCH((gemm_nt_sk_kernel<128, true>), dim3((unsigned)G), dim3(256), lds, st, s);
+    } else {
+      SBK_LAUNCH((gemm_nt_sk_kernel<128, false>), dim3((unsigned)G), dim3(256), lds, st, s);
+    }
   }
   return launch_status("sbk_gemm_nt_f32 (stream-K)");
 }
@@ -1807,6 +1824,7 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 23) sbk::g_sk_stagger = value;
   if (key == 24) sbk::g_sk_min_rows = value;
   if (key == 25) sbk::g_sk64_min_rows = value;
+  if (key == 30) sbk::g_sk_interleave = value;
   if (key == 26) sbk::g_sk64_units = value > 0 ? value : 1;
   if (key == 27) sbk::g_bf16a_stages = value;
   if (key == 28) sbk::g_bf16a_grid = value;

@@ -339,11 +339,12 @@ def gemm_nt_bf16(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act
 
 # precision "bf16": keep the operands of consecutive contractions in bf16 in memory where a model's forward supports it
 # (the Whisper encoder); False = every contraction reads fp32 activations and rounds them on load (A/B, tests)
-BF16_ACTIVATIONS = True
-# rows from which the Conformer feed-forward pairs take that path: its 128x128-tile persistent kernel needs a few hundred
-# tiles of a long K loop; measured on MI355X (tools/microbench.py --enc-bf16, profiles/r03_bf16_attention_lds_and_conformer_bf16.log)
-# 32 x 20 s (16 000 rows) encodes in 15.7 instead of 17.0 ms, 32 x 10 s in 9.4 instead of 8.9
-BF16A_MIN_ROWS = 16000
+BF16_ACTIVATIONS = os.environ.get("SBK_BF16_ACTIVATIONS", "1") != "0"
+# rows from which the Conformer feed-forward pairs take that path.  Measured on MI355X: one stream, 32 x 20 s (16 000 rows)
+# encodes in 15.7 instead of 17.0 ms, 32 x 10 s in 9.4 instead of 8.9 (tools/microbench.py --enc-bf16,
+# profiles/r03_bf16_attention_lds_and_conformer_bf16.log); the eight-worker job of bench.py --precision bf16 runs at
+# 12 093 audio-s/s with every batch on this path, 11 752 from 16 000 rows, 11 887 without (profiles/r03_bf16_bench_leg_ab.log)
+BF16A_MIN_ROWS = int(os.environ.get("SBK_BF16A_MIN_ROWS", "256"))
 
 
 def bf16a_ok(K: int) -> bool:

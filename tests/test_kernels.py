@@ -584,6 +584,7 @@ def test_attention_bf16_rows_through_lds(backend, B, T, H, ragged):
 
 
 SK64_DEFAULT_ROWS = 0  # csrc/gemm.hip g_sk64_min_rows
+SK_INTERLEAVE_DEFAULT = 0  # csrc/gemm.hip g_sk_interleave
 
 
 @pytest.mark.parametrize("M,N,K,grid,bt", [(700, 300, 96, 0, 128), (1000, 130, 64, 24, 128), (257, 128, 640, 8, 128), (520, 260, 128, 40, 128),
@@ -619,6 +620,12 @@ def test_gemm_stream_k(backend, M, N, K, grid, bt):
         assert _md(out, ref) <= 2e-6 * scale + 1e-5
         for _ in range(3 if dev.type == "cuda" else 1):  # tickets re-armed, same sum order whoever arrives last
             assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
+        if bt == 128:  # the other placement of the LDS-DMA pieces (between / in front of the MFMA groups): same arithmetic
+            lib.sbk_prof_set_knob(30, 1 - SK_INTERLEAVE_DEFAULT)
+            try:
+                assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
+            finally:
+                lib.sbk_prof_set_knob(30, SK_INTERLEAVE_DEFAULT)
         out = nat.gemm_nt(ad, wd, None, None, act=nat.ACT_GELU)
         assert _md(out, F.gelu(a.double() @ w.double().t()).float()) <= 2e-6 * scale + 1e-5
         rows = 50 if M % 50 == 0 else M // 7

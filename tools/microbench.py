@@ -296,8 +296,12 @@ if __name__ == "__main__":
     if "--sk" in sys.argv:  # encoder GEMM shapes of the bench (M = 32 utterances x T' frames): tile grid vs stream-K
         shapes = [(M, N, K) for M in (4032, 8000, 12800, 16000, 24032, 56064)
                   for (N, K) in ((512, 512), (1536, 512), (2048, 512), (512, 2048), (1024, 512))]
-        for tag, knobs in (("tile grid", {18: 0}), ("persistent G=512 stagger", {18: 1, 19: 512, 23: 1}),
-                           ("persistent G=512 no stagger", {18: 1, 19: 512, 23: 0}), ("persistent G=256", {18: 1, 19: 256, 23: 1})):
+        variants = (("persistent (routed), pieces in front", {18: 1, 30: 0}), ("persistent (routed), pieces interleaved", {18: 1, 30: 1}))
+        if "--sk-narrow" in sys.argv:  # the narrow short-K shapes on 64-wide persistent tiles
+            shapes = [(M, N, K) for M in (4032, 8000, 12800, 16000, 24032) for (N, K) in ((512, 512), (1024, 512))]
+            variants = (("routed (128-wide tiles / tile grid)", {24: 2048, 25: 0}), ("64-wide tiles, 16 K units per workgroup", {24: 1 << 30, 25: 1, 26: 16}),
+                        ("64-wide tiles, 32 units", {24: 1 << 30, 25: 1, 26: 32}), ("64-wide tiles, 48 units", {24: 1 << 30, 25: 1, 26: 48}))
+        for tag, knobs in variants:
             for k, v in knobs.items():
                 nat.load().sbk_prof_set_knob(k, v)
             print("variant:", tag, flush=True)
@@ -306,7 +310,8 @@ if __name__ == "__main__":
             nat.load().sbk_prof_set_knob(19, 0)
             nat.load().sbk_prof_set_knob(21, 4)
             nat.load().sbk_prof_set_knob(23, 1)
-        nat.load().sbk_prof_set_knob(18, 1)
+        for k, v in ((18, 1), (30, 0), (24, 2048), (25, 0), (26, 16)):
+            nat.load().sbk_prof_set_knob(k, v)
         sys.exit(0)
     if "--bf16a" in sys.argv:  # bf16 activations + weights through the LDS-DMA pipeline vs the kernel that reads fp32 activations
         def ev_time(fn, n=20):
