@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SBK_ABI_VERSION 5
+#define SBK_ABI_VERSION 6
 
 typedef void* sbk_stream_t; /* hipStream_t */
 
@@ -148,6 +148,22 @@ int sbk_input_norm_stats_f32(const float* x, const int32_t* n_valid, float* y, f
 int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual,
                     int ldr, float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
                     int rows_per_seq, sbk_stream_t stream);
+
+/* The SAME fp32 contraction on the bf16 matrix pipe (ABI 6) -- the large encoder contractions of nnet/attention.py:623,
+ * 941-945 (in_proj / out_proj), Conformer.py:129,155 (macaron feed-forward), :230-330 (pointwise convolutions) take this
+ * entry.  An fp32 number is exactly the sum of three bf16 numbers (hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid,
+ * round to nearest even); of the nine partial products of a.w the six of relative size >= 2^-17 are formed exactly on
+ * v_mfma_f32_32x32x16_bf16 (16x the per-cycle rate of v_mfma_f32_32x32x2_f32) and accumulated in fp32, the three
+ * dropped ones are <= 2^-26 |a||w| each, of either sign -- below the rounding of one fp32 multiply-add.  Same result class as
+ * sbk_gemm_nt_f32 (measured against fp64: no larger error than the fp32 MFMA chain), NOT a reduced-precision path.
+ *   sbk_split_bf16x3: W [N,K] fp32 (row stride ldw) -> W3 [N][K/32][3][32] bf16 bits (hi, mid, lo pieces; once per
+ *   weight matrix, 6 bytes per element).  K % 32 == 0.
+ *   sbk_gemm_nt_f32x3: C = epilogue(A . W^T) with A [M,K] fp32 in memory (cut into its pieces in registers), epilogue /
+ *   lda < K / seq_len exactly as sbk_gemm_nt_f32.  K % 32 == 0, K >= 64, lda % 4 == 0, A and W3 16-byte aligned. */
+int sbk_split_bf16x3(const float* W, int ldw, uint16_t* W3, int N, int K, sbk_stream_t stream);
+int sbk_gemm_nt_f32x3(const float* A, int lda, const uint16_t* W3, const float* bias, const float* residual, int ldr,
+                      float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
+                      int rows_per_seq, sbk_stream_t stream);
 
 /* ---- bf16-operand fast entry points ("fp32 parity entry points plus bf16 ... fast entry points").
  * C = epilogue(bf16(A) . Wb^T) with fp32 accumulation on v_mfma_f32_32x32x16_bf16: A [M,K] stays fp32 in memory and is

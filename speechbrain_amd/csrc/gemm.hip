@@ -282,6 +282,24 @@ __global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float* __restric
 __global__ void __launch_bounds__(256) f32_to_f16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = sbk::f32_to_f16(x[i]);
 }
+// W [N][K] fp32 -> [N][K/32][3][32] bf16: the three exact pieces of every element (hi = bf16(x), mid = bf16(x - hi),
+// lo = x - hi - mid, round to nearest even), one 192-byte record per row and 32-deep K tile -- the W operand of gemm_nt_sk_kernel<.., X3>
+__global__ void __launch_bounds__(256) split_bf16x3_kernel(const float* __restrict__ W, int ldw, unsigned short* __restrict__ out,
+                                                           long n, int K) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long row = i / K;
+    const int k = (int)(i - row * K);
+    const float x = W[row * ldw + k];
+    const unsigned short hi = sbk::f32_to_bf16(x);
+    const float r = x - __uint_as_float((unsigned)hi << 16);
+    const unsigned short mid = sbk::f32_to_bf16(r);
+    const float q = r - __uint_as_float((unsigned)mid << 16);  // <= 7 significant bits: a bf16 exactly
+    unsigned short* o = out + (row * (K / 32) + k / 32) * 96 + (k & 31);
+    o[0] = hi;
+    o[32] = mid;
+    o[64] = sbk::f32_to_bf16(q);
+  }
+}
 // y = e4m3(x * mul), two values per thread (n even)
 __global__ void __launch_bounds__(256) f32_to_fp8_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n2,
                                                          float mul) {
@@ -618,10 +636,35 @@ struct SkArgs {
 // piece per group of 4 k) instead of in one block in front of them: a piece keeps its wave's issue port for ~60-150
 // cycles, which a 64-cycle fp32 MFMA in flight covers -- in one block the eight pieces leave the matrix pipe of that
 // wave empty for ~1 000 cycles per K tile (the kernel's time was the SUM of its no-load and load-only times).
-template <int BT, bool IL>
-__global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
-  constexpr int BK = 32, PANEL = BT * BK, STAGE = 2 * PANEL;  // floats
+//
+// X3: the fp32 contraction on the bf16 matrix pipe (sbk_gemm_nt_f32x3).  v_mfma_f32_32x32x16_bf16 delivers 16x the
+// flops of v_mfma_f32_32x32x2_f32 per cycle, and an fp32 number is EXACTLY the sum of three bf16 numbers (hi = bf16(x),
+// mid = bf16(x - hi), lo = x - hi - mid, round to nearest even: the remainders are exact in fp32 and the last one has
+// at most 7 significant bits).  a.w = sum of nine partial products; the six of relative size >= 2^-17 are kept (hi.hi,
+// hi.mid, mid.hi, hi.lo, lo.hi, mid.mid: exact products, fp32 accumulation on the matrix core), the three dropped ones
+// are <= 2^-26 |a||w| each and of either sign (rounded pieces: truncated ones would all carry the product's sign and
+// add up), i.e. below the rounding error of ONE fp32 multiply-add -- measured against fp64 the result
+// is as close as the fp32 MFMA chain's (tests/test_kernels.py::test_gemm_f32x3).  Six bf16 MFMAs replace sixteen
+// fp32-MFMA-equivalents: a 2.67x higher ceiling (2.5 PF/s / 6 = 417 TF/s fp32-equivalent) for the same fp32 result.
+// A stays fp32 in HBM and in LDS (same LDS-DMA image as the fp32 kernel) and is cut into its three pieces in registers
+// after the operand fetch (two ds_read_b128 = 8 consecutive k of a row = one MFMA operand per piece; ~5 VALU
+// instructions per element, which the other wave of the SIMD runs under this wave's MFMAs).  W arrives pre-split
+// (sbk_split_bf16x3: [N][K/32][3 pieces][32 k] bf16, 192 contiguous bytes per row and K tile) and lands in LDS as
+// [128 rows][3 pieces][4 slots of 8 k]; row pitch 192 B, slot s of row r at s ^ ((r>>2)&3) => the 16-lane groups of a
+// ds_read_b128 touch 16 distinct 4-bank groups.
+// MEAS (measurement builds of the X3 loop, wrong results): 2 = no operand split, 4 = the hi.hi products only
+// REGLD (X3): the next K tile's panels travel global -> registers (issued in front of the MFMA loop) -> ds_write_b128 behind it,
+// instead of by LDS-DMA: a DMA piece keeps its wave's issue port for 60-180 cycles (MI355X_MICROARCH.md), ten of them per K
+// tile weigh as much as the tile's 48 bf16 MFMAs; a global_load_dwordx4 + ds_write_b128 pair costs ~30
+template <int BT, bool IL, bool X3, int MEAS = 0, bool REGLD = false>
+__global__ void __launch_bounds__(256, REGLD ? 1 : 2) gemm_nt_sk_kernel(SkArgs s) {
+  static_assert(!X3 || (BT == 128 && !IL), "the split-operand variant: 128-wide tiles, panel loads in one block");
+  constexpr int BK = 32, PANEL = BT * BK, WPITCH = X3 ? 48 : BK, WPANEL = BT * WPITCH, STAGE = PANEL + WPANEL;  // floats
   constexpr int TS = BT / 64, WT = BT / 2, LI = BT / 32;      // 32x32 sub-tiles per wave and dimension, wave tile edge, loader instructions per wave and panel
+  // the wave's sub-tiles: TM x TN of 32 x 32.  X3: one row block x four column blocks (a wave = 32 rows of the tile, all
+  // its 128 columns): every A element is fetched and split by exactly ONE wave (2 x 2 sub-tiles split it twice)
+  constexpr int TM = X3 ? 1 : TS, TN = X3 ? 4 : TS;
+  constexpr int LIW = X3 ? BT * 3 / 64 : LI;                  // ... of the W panel (X3: 12 slots of 16 B per row)
   SBK_DYN_LDS(float, lds);  // [2][STAGE] + the ticket word (ONE LDS object: a second one de-pipelines the LDS-DMA loop)
   // kernel arguments into registers (a by-value struct whose address is taken is copied to scratch)
   const float* const gA = s.g.A;
@@ -638,7 +681,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
   const int tiles_n = s.tiles_n, KT = s.KT, noload = s.noload;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = sbk::uniform(tid >> 6);
-  const int wm0 = (wave >> 1) * WT, wn0 = (wave & 1) * WT;
+  const int wm0 = X3 ? wave * 32 : (wave >> 1) * WT, wn0 = X3 ? 0 : (wave & 1) * WT;
   const int lrow = lane & 31, half = lane >> 5, sw = (lrow >> 1) & 7;
   // ---- this workgroup's segments: whole tiles of the XCD's range, then (or first) its share of the leftover tiles
   const int W = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;  // gridDim.x is a multiple of 8
@@ -688,36 +731,137 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
     lrw[i] = (wave * LI + i) * 8 + (lane >> 3);
     lsl[i] = ((lane & 7) ^ ((lrw[i] >> 1) & 7)) * 4;  // source k offset (floats) of the slot this lane fills
   }
+  // X3: the W panel is [BT rows][12 slots]; lane-linear slot q of the image = row q / 12, position q % 12 = piece * 4 +
+  // (logical slot ^ ((row>>2)&3)); the source is the pre-split matrix [N][KT][3][32 bf16] addressed in float units
+  int wrw[LIW], wsl[LIW];
+  if constexpr (X3) {
+#pragma unroll
+    for (int i = 0; i < LIW; ++i) {
+      const int q = (wave * LIW + i) * 64 + lane;
+      wrw[i] = q / 12;
+      const int pos = q - wrw[i] * 12;
+      wsl[i] = (pos >> 2) * 16 + (((pos & 3) ^ ((wrw[i] >> 2) & 3)) * 4);
+    }
+  }
   const float* ap[LI];
-  const float* wp[LI];
+  const float* wp[LIW];
   auto setup = [&](int tile) SBK_INLINE_LAMBDA {
     const int m0 = (tile / tiles_n) * BT, n0 = (tile % tiles_n) * BT;
 #pragma unroll
-    for (int i = 0; i < LI; ++i) {  // rows past the matrix re-read its last row (their outputs are never stored)
+    for (int i = 0; i < LI; ++i)  // rows past the matrix re-read its last row (their outputs are never stored)
       ap[i] = gA + (size_t)min(m0 + lrw[i], M - 1) * lda + lsl[i];
-      wp[i] = gW + (size_t)min(n0 + lrw[i], N - 1) * ldw + lsl[i];
+    if constexpr (X3) {
+#pragma unroll
+      for (int i = 0; i < LIW; ++i) wp[i] = gW + (size_t)min(n0 + wrw[i], N - 1) * (KT * 48) + wsl[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < LI; ++i) wp[i] = gW + (size_t)min(n0 + lrw[i], N - 1) * ldw + lsl[i];
     }
   };
   auto issue = [&](int kt, int stage) SBK_INLINE_LAMBDA {
     float* base = lds + stage * STAGE + (wave * LI) * 256;
 #pragma unroll
     for (int i = 0; i < LI; ++i) sbk::glds16(ap[i] + kt * BK, base + i * 256);
+    float* wbase = lds + stage * STAGE + PANEL + (wave * LIW) * 256;
 #pragma unroll
-    for (int i = 0; i < LI; ++i) sbk::glds16(wp[i] + kt * BK, base + PANEL + i * 256);
+    for (int i = 0; i < LIW; ++i) sbk::glds16(wp[i] + kt * WPITCH, wbase + i * 256);
+  };
+  float4 stg[REGLD ? LI + LIW : 1];  // (REGLD) the same pieces on their way through registers
+  auto gload = [&](int kt) SBK_INLINE_LAMBDA {
+    if constexpr (REGLD) {
+#pragma unroll
+      for (int i = 0; i < LI; ++i) stg[i] = *reinterpret_cast<const float4*>(ap[i] + kt * BK);
+#pragma unroll
+      for (int i = 0; i < LIW; ++i) stg[LI + i] = *reinterpret_cast<const float4*>(wp[i] + kt * WPITCH);
+    }
+  };
+  auto commit = [&](int stage) SBK_INLINE_LAMBDA {  // lane-linear image, exactly what the LDS-DMA writes
+    if constexpr (REGLD) {
+      float* base = lds + stage * STAGE + (wave * LI) * 256 + lane * 4;
+#pragma unroll
+      for (int i = 0; i < LI; ++i) *reinterpret_cast<float4*>(base + i * 256) = stg[i];
+      float* wbase = lds + stage * STAGE + PANEL + (wave * LIW) * 256 + lane * 4;
+#pragma unroll
+      for (int i = 0; i < LIW; ++i) *reinterpret_cast<float4*>(wbase + i * 256) = stg[LI + i];
+    }
   };
 
-  f32x16 acc[TS][TS];
+  f32x16 acc[TM][TN];
   auto zero = [&]() SBK_INLINE_LAMBDA {
 #pragma unroll
-    for (int i = 0; i < TS; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TS; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   };
   auto compute = [&](int stage, bool fly, int nkt) SBK_INLINE_LAMBDA {
     const float* As = lds + stage * STAGE + (wm0 + lrow) * BK;
-    const float* Ws = lds + stage * STAGE + PANEL + (wn0 + lrow) * BK;
+    const float* Ws = lds + stage * STAGE + PANEL + (wn0 + lrow) * WPITCH;
+    if constexpr (X3) {
+      const int wsw = (lrow >> 2) & 3;
+#pragma unroll
+      for (int gk = 0; gk < 2; ++gk) {  // 16 k per step: lanes 0-31 supply k = 16 gk .. +7, lanes 32-63 the next eight
+        sbk::bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float4 x0 = *reinterpret_cast<const float4*>(As + i * 32 * BK + ((4 * gk + 2 * half) ^ sw) * 4);
+          const float4 x1 = *reinterpret_cast<const float4*>(As + i * 32 * BK + ((4 * gk + 2 * half + 1) ^ sw) * 4);
+          const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+          unsigned h[4], m[4], l[4];
+          if constexpr ((MEAS & 2) != 0) {  // measurement only: no operand split (wrong results)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) h[p] = m[p] = l[p] = __float_as_uint(x[2 * p]) ^ __float_as_uint(x[2 * p + 1]);
+          } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {  // x = hi + mid + lo exactly: 8 significand bits each, remainders exact in fp32
+              h[p] = sbk::bf16_pair(x[2 * p], x[2 * p + 1]);
+              const float r0 = x[2 * p] - __uint_as_float(h[p] << 16), r1 = x[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
+              m[p] = sbk::bf16_pair(r0, r1);
+              l[p] = sbk::bf16_pair(r0 - __uint_as_float(m[p] << 16), r1 - __uint_as_float(m[p] & 0xffff0000u));
+            }
+          }
+          ah[i] = sbk::bf16x8_from_words(h[0], h[1], h[2], h[3]);
+          am[i] = sbk::bf16x8_from_words(m[0], m[1], m[2], m[3]);
+          al[i] = sbk::bf16x8_from_words(l[0], l[1], l[2], l[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float* wr = Ws + j * 32 * WPITCH + ((2 * gk + half) ^ wsw) * 4;
+          bh[j] = *reinterpret_cast<const sbk::bf16x8*>(wr);
+          bm[j] = *reinterpret_cast<const sbk::bf16x8*>(wr + 16);
+          bl[j] = *reinterpret_cast<const sbk::bf16x8*>(wr + 32);
+        }
+        // smallest terms first; consecutive MFMAs go to different accumulators
+        if constexpr ((MEAS & 4) == 0) {  // (measurement only, bit 2: the hi.hi products alone)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(al[i], bh[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(am[i], bm[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(am[i], bh[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(ah[i], bm[j], acc[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(ah[i], bh[j], acc[i][j]);
+      }
+      return;
+    }
     float* nbase = lds + (stage ^ 1) * STAGE + (wave * LI) * 256;
 #pragma unroll
     for (int gk = 0; gk < 4; ++gk) {
@@ -749,12 +893,12 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
     const int m0 = (tile / tiles_n) * BT, n0 = (tile % tiles_n) * BT;
     const bool interior = m0 + BT <= M && n0 + BT <= N;  // uniform: no per-element predicates
 #pragma unroll
-    for (int j = 0; j < TS; ++j) {
+    for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn0 + j * 32 + lrow;
       const bool col_ok = interior || col < N;
       const float bv = (gbias && col_ok) ? gbias[col] : 0.0f;
 #pragma unroll
-      for (int i = 0; i < TS; ++i) {
+      for (int i = 0; i < TM; ++i) {
         const int rbase = m0 + wm0 + i * 32 + 4 * half;
         float v[16];
 #pragma unroll
@@ -808,21 +952,23 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
       }
     }
   };
-  int* ticket = reinterpret_cast<int*>(lds + 2 * STAGE);
-  // a K range [kt_lo, kt_hi) of `tile` is complete in acc
-  auto finish = [&](int tile, int kt_lo, int kt_hi) SBK_INLINE_LAMBDA {
+  // a K range [kt_lo, kt_hi) of `tile` is complete in acc.  The ticket word: behind the stages, or (X3: two workgroups
+  // of 2 x 40 KB fill the CU's 160 KB) the first word of the stage that was just multiplied -- every wave is past the
+  // barrier behind its last read and the next panels go into it only after this function
+  auto finish = [&](int tile, int kt_lo, int kt_hi, int stage_done) SBK_INLINE_LAMBDA {
+    int* ticket = reinterpret_cast<int*>(lds + (X3 ? stage_done * STAGE : 2 * STAGE));
     bool store = true;
     if (kt_lo != 0 || kt_hi != KT) {  // partial: publish the slab, take a ticket; the last ticket sums the tile's slabs
       const int p_first = owner((tile - tb) * KT), p_last = owner((tile - tb + 1) * KT - 1);
       const int nseg = p_last - p_first + 1;
       float4* mine = reinterpret_cast<float4*>(slabs + (size_t)(2 * p + (kt_lo == 0 ? 1 : 0)) * (BT * BT));
 #pragma unroll
-      for (int i = 0; i < TS; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TS; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4)
-            mine[((wave * TS * TS + i * TS + j) * 4 + r4) * 64 + lane] =
+            mine[((wave * (TM * TN) + i * TN + j) * 4 + r4) * 64 + lane] =
                 make_float4(acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]);
       sbk::vm_drain();
       __syncthreads();
@@ -841,12 +987,12 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
           const float4* src =
               reinterpret_cast<const float4*>(slabs + (size_t)(2 * (x * W + p_first + sgm) + (sgm == 0 ? 1 : 0)) * (BT * BT));
 #pragma unroll
-          for (int i = 0; i < TS; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TS; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
               for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 v = src[((wave * TS * TS + i * TS + j) * 4 + r4) * 64 + lane];
+                const float4 v = src[((wave * (TM * TN) + i * TN + j) * 4 + r4) * 64 + lane];
                 acc[i][j][4 * r4] += v.x;
                 acc[i][j][4 * r4 + 1] += v.y;
                 acc[i][j][4 * r4 + 2] += v.z;
@@ -856,7 +1002,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
         if (tid == 0) sbk::atomic_store_agent(cnt + tile, 0);  // re-armed for the next launch on this stream
       }
     }
-    if (store) epilogue(tile);
+    if (store && !(noload & 8)) epilogue(tile);  // (bit 3, measurement only: no epilogue)
   };
 
   int sidx = 0, tile, lo, hi, stage = 0;
@@ -877,13 +1023,20 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
     }
     if (has_next) {  // the next unit's panels fly while this one is multiplied
       if (seg_ends) setup(ntile);
-      if (!IL && !noload) issue(nkt, stage ^ 1);
+      if constexpr (REGLD) {
+        if (!(noload & 1)) gload(nkt);
+      } else {
+        if (!IL && !(noload & 1)) issue(nkt, stage ^ 1);
+      }
     }
-    compute(stage, has_next && !noload, nkt);
+    compute(stage, has_next && !(noload & 1), nkt);
+    if constexpr (REGLD) {
+      if (has_next && !(noload & 1)) commit(stage ^ 1);  // (free: everybody passed the barrier behind its last read)
+    }
     sbk::vm_drain();   // this wave's share of the next panels has landed ...
     __syncthreads();   // ... and everybody's; every wave is done reading `stage`
     if (seg_ends) {
-      finish(tile, lo, hi);
+      finish(tile, lo, hi, stage);
       zero();
     }
     if (!has_next) break;
@@ -1589,6 +1742,8 @@ int g_sk64_units = 16;    // tuning knob (key 26): K units (64x64x32) per workgr
 int g_bf16a_stages = 2;   // tuning knob (key 27): LDS stages of gemm_nt_bf16dma_kernel (2, 3 or 4)
 int g_bf16a_grid = 0;     // tuning knob (key 28): its workgroups (0 = as many as fit: two per CU with 2 stages, one with 3 / 4)
 int g_bf16a_mode = 0;     // measurement knob (key 29)
+int g_x3_regld = 0;       // tuning knob (key 33): 1 = the split-operand kernel's panels go through registers (0: LDS-DMA)
+int g_x3_grid = 0;        // tuning knob (key 31): workgroups of the split-operand kernel (0 = two per CU from one tile per CU on)
 namespace {
 constexpr int kSkMaxGrid = 512, kSkMaxGrid64 = 1024, kSkMaxTiles = 1 << 16;  // (both grids fit the same slab area)
 int sk_cus();
@@ -1670,7 +1825,7 @@ int sk_cus() {
   return g_sk_cus;
 }
 
-int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st) {
+int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st, bool x3 = false) {
   SkArgs s;
   s.g = g;
   s.tiles_n = cdiv(g.N, bt);
@@ -1683,28 +1838,76 @@ int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st) {
   s.cnt = w.cnt;
   s.stagger = g_sk_stagger;
   s.noload = g_sk_noload;
-  const size_t lds = (size_t)(2 * 2 * bt * 32 + 4) * sizeof(float);
+  const size_t lds = x3 ? (size_t)2 * (128 * 32 + 128 * 48) * sizeof(float) : (size_t)(2 * 2 * bt * 32 + 4) * sizeof(float);
   static bool once = false;
   if (!once) {
-    (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false>), (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float));
-    (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, true>), (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float));
+    (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, false>), (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float));
+    (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, true, false>), (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float));
+    (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true>), (size_t)2 * (128 * 32 + 128 * 48) * sizeof(float));
     once = true;
   }
   const double flops = 2.0 * g.M * g.N * g.K, bytes = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
-  if (bt == 64) {
+  if (x3) {
+    // (fp32-equivalent flops: the six bf16 partial products of an element pair count as ONE multiply-add)
+    ProfScope prof("gemm_nt_f32x3", flops, bytes + 2.0 * (double)g.N * g.K, st);
+    const int meas = (g_sk_noload >> 1) & 3;
+    s.noload = g_sk_noload & 9;
+    if (meas == 0 && g_x3_regld) {
+      static bool once_r = false;
+      if (!once_r) {
+        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 0, true>), lds);
+        once_r = true;
+      }
+      SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 0, true>), dim3((unsigned)G), dim3(256), lds, st, s);
+    } else if (meas == 0) {
+      SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true>), dim3((unsigned)G), dim3(256), lds, st, s);
+    } else {
+      static bool once_meas = false;
+      if (!once_meas) {
+        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 2>), lds);
+        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 4>), lds);
+        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 6>), lds);
+        once_meas = true;
+      }
+      if (meas == 1) {
+        SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 2>), dim3((unsigned)G), dim3(256), lds, st, s);
+      } else if (meas == 2) {
+        SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 4>), dim3((unsigned)G), dim3(256), lds, st, s);
+      } else {
+        SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 6>), dim3((unsigned)G), dim3(256), lds, st, s);
+      }
+    }
+  } else if (bt == 64) {
     ProfScope prof("gemm_nt_persistent64", flops, bytes, st);
-    SBK_LAUNCH((gemm_nt_sk_kernel<64, false>), dim3((unsigned)G), dim3(256), lds, st, s);
+    SBK_LAUNCH((gemm_nt_sk_kernel<64, false, false>), dim3((unsigned)G), dim3(256), lds, st, s);
   } else {
     ProfScope prof("gemm_nt_persistent", flops, bytes, st);
     if (g_sk_interleave) {
-      SBK_LAUNCH((gemm_nt_sk_kernel<128, true>), dim3((unsigned)G), dim3(256), lds, st, s);
+      SBK_LAUNCH((gemm_nt_sk_kernel<128, true, false>), dim3((unsigned)G), dim3(256), lds, st, s);
     } else {
-      SBK_LAUNCH((gemm_nt_sk_kernel<128, false>), dim3((unsigned)G), dim3(256), lds, st, s);
+      SBK_LAUNCH((gemm_nt_sk_kernel<128, false, false>), dim3((unsigned)G), dim3(256), lds, st, s);
     }
   }
   return launch_status("sbk_gemm_nt_f32 (stream-K)");
 }
 }  // namespace
+
+// fp32 contraction with a pre-split W (sbk_split_bf16x3) on the bf16 matrix pipe; -1: no workspace for this stream
+int gemm_nt_x3(const float* A, int lda, const uint16_t* W3, const float* bias, const float* R, int ldr, float* C, int ldc,
+               int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st) {
+  if (M == 0 || N == 0) return 0;
+  GemmArgs g{A, reinterpret_cast<const float*>(W3), bias, R, C, lda, 0, ldr, ldc, M, N, K, act, alpha, seq_len,
+             rows_per_seq > 0 ? rows_per_seq : 1};
+  const long T = (long)cdiv(M, 128) * cdiv(N, 128), U = T * (K / 32);
+  const int cus = sk_cus();
+  // Measured on MI355X (tools/microbench.py --x3, profiles/r03_f32x3_sweep.log): two workgroups per CU from two tiles per
+  // CU on, one below (M = 4 032: N = 1 024 31 vs 50 us, N = 1 536 59 vs 69 us with one)
+  int G = g_x3_grid > 0 ? g_x3_grid : (T >= 2L * cus ? 2 * cus : cus);
+  if (U / g_sk_min_units < G) G = (int)(U / g_sk_min_units);  // short launches: fewer, longer ranges
+  if (G > kSkMaxGrid) G = kSkMaxGrid;
+  G = G >= 8 ? (G / 8) * 8 : 8;
+  return launch_sk(g, G, 128, st, true);
+}
 
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st) {
@@ -1829,8 +2032,37 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 27) sbk::g_bf16a_stages = value;
   if (key == 28) sbk::g_bf16a_grid = value;
   if (key == 29) sbk::g_bf16a_mode = value;
+  if (key == 31) sbk::g_x3_grid = value;
+  if (key == 33) sbk::g_x3_regld = value;
 }
 
+
+// ---- fp32 contraction on the bf16 matrix pipe (exact three-way operand split) ----------------------------------
+extern "C" int sbk_split_bf16x3(const float* W, int ldw, uint16_t* W3, int N, int K, sbk_stream_t stream) {
+  if (N == 0) return 0;
+  SBK_REQUIRE(W && W3 && N > 0 && K > 0 && K % 32 == 0 && ldw >= K, "split_bf16x3: bad arguments (K must be a multiple of 32)");
+  const long n = (long)N * K, blocks = (n + 255) / 256;
+  SBK_LAUNCH(split_bf16x3_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, sbk::as_stream(stream), W, ldw,
+             reinterpret_cast<unsigned short*>(W3), n, K);
+  return sbk::launch_status("sbk_split_bf16x3");
+}
+
+extern "C" int sbk_gemm_nt_f32x3(const float* A, int lda, const uint16_t* W3, const float* bias, const float* residual,
+                                 int ldr, float* C, int ldc, int M, int N, int K, int act, float alpha,
+                                 const int32_t* seq_len, int rows_per_seq, sbk_stream_t stream) {
+  if (M == 0 || N == 0) return 0;
+  SBK_REQUIRE(A && W3 && C, "gemm_f32x3: null operand");
+  SBK_REQUIRE(M >= 0 && N >= 0 && K >= 64 && K % 32 == 0, "gemm_f32x3: bad shape M=%d N=%d K=%d (K: a multiple of 32, >= 64)", M, N, K);
+  SBK_REQUIRE(lda > 0 && lda % 4 == 0 && ldc >= N && sbk::aligned16(A) && sbk::aligned16(W3),
+              "gemm_f32x3: operand rows must be 16-byte aligned (lda=%d)", lda);
+  SBK_REQUIRE(!residual || ldr >= N, "gemm_f32x3: residual stride");
+  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_f32x3: unknown activation %d", act);
+  SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm_f32x3: seq_len given without rows_per_seq");
+  const int rc = sbk::gemm_nt_x3(A, lda, W3, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq,
+                                 sbk::as_stream(stream));
+  if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_f32x3: no workspace for this stream (first use inside a graph capture) or too many tiles");
+  return rc;
+}
 
 // ---- bf16-operand fast entry points ---------------------------------------------------------------
 extern "C" int sbk_f32_to_bf16(const float* x, uint16_t* y, long n, sbk_stream_t stream) {

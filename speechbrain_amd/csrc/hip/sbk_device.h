@@ -42,6 +42,19 @@ __device__ __forceinline__ bf16x8 cvt_bf16x8(const float (&x)[8]) {
   return r;
 }
 
+// four 32-bit words = eight bf16 (element e in the low / high half of word e/2) -> one MFMA operand
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ bf16x8 bf16x8_from_words(unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+  u32x4 u = {w0, w1, w2, w3};
+  return __builtin_bit_cast(bf16x8, u);
+}
+// two floats -> two bf16 (round to nearest even) in one word, x0 in the low half: one v_cvt_pk_bf16_f32
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+__device__ __forceinline__ unsigned bf16_pair(float x0, float x1) {
+  bf16x2 v = {(__bf16)x0, (__bf16)x1};
+  return __builtin_bit_cast(unsigned, v);
+}
+
 // fp16 operands (same shape and lane mapping as the bf16 form), fp32 accumulate
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 __device__ __forceinline__ f32x16 mfma_32x32x16_f16(f16x8 a, f16x8 b, f32x16 acc) {
@@ -81,6 +94,19 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // Scheduling fence for the compiler: nothing is moved across it (keeps a block of loads issued ahead of
 // the arithmetic that consumes them instead of sunk next to each use).
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+// One entry of an instruction-interleave recipe: the scheduler places `SIZE` instructions of class MASK (0x008 MFMA,
+// 0x002 VALU, 0x100 LDS read, 0x020 VMEM read ...) next; a sequence of these pins the order in which the instructions
+// of a basic block are issued (an in-order wave hides a VALU instruction under its own MFMAs only if it stands between
+// them in program order).
+template <int MASK, int SIZE>
+__device__ __forceinline__ void sched_group() { __builtin_amdgcn_sched_group_barrier(MASK, SIZE, 0); }
+
+// The value is materialised in a register HERE: keeps the optimiser from sinking the arithmetic that produces it into a
+// later basic block (next to its use), i.e. out of the MFMA stream it was written to be issued under.
+__device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(f32x16& x) { asm volatile("" : "+v"(x)); }  // (an MFMA result: keeps the MFMA at this point of the stream)
 
 // x * 2^e and the exponent k of x = f * 2^k, f in [0.5,1) (0 for x = 0): single VALU instructions
 // (v_ldexp_f32 / v_frexp_exp_i32_f32) without the libm special-case wrappers.

@@ -91,6 +91,8 @@ def _declare(lib):
         "sbk_input_norm_stats_f32": ([p, p, p, p, i, i, i, i, i, f, i, p], c_int),
         "sbk_gemm_nt_f32": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_f32_to_bf16": ([p, p, ctypes.c_long, p], c_int),
+        "sbk_split_bf16x3": ([p, i, p, i, i, p], c_int),
+        "sbk_gemm_nt_f32x3": ([p, i, p, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_bf16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_f16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_bf16a": ([p, i, p, i, p, p, i, p, i, p, i, i, i, i, i, f, p], c_int),
@@ -148,7 +150,7 @@ def load(path: Optional[str] = None):
         )
     lib = ctypes.CDLL(path)
     EXPORTS = tuple(_declare(lib).keys())
-    if lib.sbk_abi_version() != 5:
+    if lib.sbk_abi_version() != 6:
         raise SbkError(f"ABI version mismatch: {lib.sbk_abi_version()}")
     _lib = lib
     return lib
@@ -212,6 +214,23 @@ def precision_scope(p):
         _tls.precision = old
 
 
+# fp32 contractions with many rows (the encoder's) run on the bf16 matrix pipe through the exact three-way operand split
+# (sbk_gemm_nt_f32x3, include/sbk.h): the same fp32 result class at 2-3x the rate of the fp32 MFMA kernels.  "0" keeps
+# every contraction on v_mfma_f32_32x32x2_f32 (A/B runs, tests of the fp32-MFMA kernels).
+F32X3 = os.environ.get("SBK_F32X3", "1") != "0"
+F32X3_MIN_ROWS = int(os.environ.get("SBK_F32X3_MIN_ROWS", "2048"))
+F32X3_MIN_TILES = int(os.environ.get("SBK_F32X3_MIN_TILES", "192"))
+
+
+def f32x3_ok(M: int, K: int, w: torch.Tensor) -> bool:
+    """Shapes routed to sbk_gemm_nt_f32x3.  Measured on MI355X (tools/microbench.py --x3, profiles/r03_f32x3_sweep.log):
+    from ~0.75 tiles of 128 x 128 per CU on the split-operand kernel wins (M = 8 000, N = 512: 38.9 vs 43.2 us); below, the
+    fp32-MFMA tile kernels do (M = 4 032, N = 512: 25.4 vs 30.6 us)."""
+    if not (F32X3 and M >= F32X3_MIN_ROWS and K % 32 == 0 and K >= 64 and w.dim() == 2 and w.is_contiguous()):
+        return False
+    return ((M + 127) // 128) * ((w.shape[0] + 127) // 128) >= F32X3_MIN_TILES
+
+
 # ------------------------------------------------------------------ ops
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None,
             seq_len=None, rows_per_seq=0):
@@ -231,6 +250,10 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_
         out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
     _dev_ok(seq_len)
+    if f32x3_ok(M, K, w):
+        _chk(lib.sbk_gemm_nt_f32x3(_p(a2), K, _p(lp_weight(w, "x3")), _p(bias), _p(r2), N, _p(out), N, M, N, K, act,
+                                   float(alpha), _p(seq_len), int(rows_per_seq), _stream(a2)), "sbk_gemm_nt_f32x3")
+        return out
     _chk(lib.sbk_gemm_nt_f32(_p(a2), K, _p(w), w.stride(0), _p(bias), _p(r2), N, _p(out), N, M, N, K, act,
                              float(alpha), _p(seq_len), int(rows_per_seq), _stream(a2)), "sbk_gemm_nt_f32")
     return out
@@ -255,6 +278,10 @@ def gemm_nt_rows(a_flat: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor
         _chk(lib.sbk_gemm_nt_bf16(_p(a_flat), int(lda), _p(bf16_weight(w)), K, _p(bias), _p(residual), N, _p(out), N, M, N, K,
                                   act, float(alpha), None, 0, _stream(a_flat)), "sbk_gemm_nt_bf16")
         return out
+    if f32x3_ok(M, K, w) and lda % 4 == 0:
+        _chk(lib.sbk_gemm_nt_f32x3(_p(a_flat), int(lda), _p(lp_weight(w, "x3")), _p(bias), _p(residual), N, _p(out), N, M, N, K,
+                                   act, float(alpha), None, 0, _stream(a_flat)), "sbk_gemm_nt_f32x3")
+        return out
     _chk(lib.sbk_gemm_nt_f32(_p(a_flat), int(lda), _p(w), w.stride(0), _p(bias), _p(residual), N, _p(out), N, M, N, K, act,
                              float(alpha), None, 0, _stream(a_flat)), "sbk_gemm_nt_f32")
     return out
@@ -265,7 +292,8 @@ _BF16_LOCK = threading.Lock()
 
 
 def lp_weight(w: torch.Tensor, kind: str = "bf16"):
-    """The reduced-precision image of a weight matrix ("bf16" / "fp16": int16 bits; "fp8": (uint8 e4m3 bits, w_scale)),
+    """The reduced-precision image of a weight matrix ("bf16" / "fp16": int16 bits; "fp8": (uint8 e4m3 bits, w_scale);
+    "x3": the exact three-piece bf16 split [N, K/32, 3, 32] of sbk_split_bf16x3 -- not reduced: the pieces sum to w),
     cached for the lifetime of THAT tensor object: the entry holds a weak reference to its source and is used only while
     ``ref() is w`` and the version counter is unchanged (a freed model's addresses are commonly handed to the next
     model of the same shapes by the caching allocator, and load_state_dict leaves ``_version`` alike -- a (data_ptr,
@@ -285,6 +313,10 @@ def lp_weight(w: torch.Tensor, kind: str = "bf16"):
         scale = max(float(w2.abs().max()), 1e-30) / 448.0  # (once per weight: a host round trip at load time)
         out = torch.empty(w2.shape, dtype=torch.uint8, device=w.device)
         _chk(lib.sbk_f32_to_fp8(_p(w2), _p(out), w2.numel(), 1.0 / scale, _stream(w2)), "sbk_f32_to_fp8")
+    elif kind == "x3":
+        N, K = w2.shape
+        out = torch.empty(N, K // 32, 3, 32, dtype=torch.int16, device=w.device)
+        _chk(lib.sbk_split_bf16x3(_p(w2), K, _p(out), N, K, _stream(w2)), "sbk_split_bf16x3")
     else:
         out = torch.empty(w2.shape, dtype=torch.int16, device=w.device)
         fn = lib.sbk_f32_to_bf16 if kind == "bf16" else lib.sbk_f32_to_f16

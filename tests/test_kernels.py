@@ -648,6 +648,96 @@ def test_gemm_stream_k(backend, M, N, K, grid, bt):
         lib.sbk_prof_set_knob(26, 16)
 
 
+@pytest.mark.parametrize("M,N,K,grid", [(700, 300, 96, 0), (1000, 130, 64, 24), (257, 128, 640, 8), (520, 260, 128, 40), (2100, 300, 64, 16),
+                                        (4100, 512, 512, 0), (130, 1030, 2048, 0), (12800, 2048, 512, 0), (4032, 512, 2048, 0),
+                                        (24000, 1536, 512, 0)])
+def test_gemm_f32x3(backend, M, N, K, grid):
+    """sbk_gemm_nt_f32x3: the fp32 contraction on the bf16 matrix pipe.  Operands are cut EXACTLY into three bf16 pieces
+    (checked bit for bit on the weight image) and six partial products are accumulated in fp32, so the result must be as
+    close to the fp64 product as the fp32-MFMA kernel's -- the same 2e-6 bound the fp32 kernels are held to, and an RMS
+    error no larger than theirs; stream-K cuts, ragged edges, every epilogue option, row masks, a sliding-window A
+    (lda < K), run-to-run bit-identical."""
+    nat, dev = backend
+    if dev.type == "cpu" and M * N * K > 6e7:
+        pytest.skip("large shape: GPU only")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01
+    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
+    a[::7] *= 1e-3  # rows of very different magnitude
+    w[::5] *= 300.0
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    lib = nat.load()
+    lib.sbk_prof_set_knob(31, grid)
+    lib.sbk_prof_set_knob(21, 1)
+    old = nat.F32X3, nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES
+    nat.F32X3, nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES = True, 1, 1
+    try:
+        ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+        w3 = nat.lp_weight(wd, "x3").cpu()
+        assert w3.shape == (N, K // 32, 3, 32)
+        pieces = (w3.view(torch.int16).to(torch.int32) << 16).view(torch.float32)  # bf16 bits -> fp32
+        assert torch.equal(pieces.double().sum(2).reshape(N, K).float(), w)  # hi + mid + lo == w exactly
+        assert nat.lp_weight(wd, "x3") is nat.lp_weight(wd, "x3")
+        big = M * N * K > 6e7
+        dd = (lambda t: t.to(dev).double()) if big else (lambda t: t.double())
+        prod = dd(a) @ dd(w).t()
+        scale = float((dd(a).abs() @ dd(w).abs().t()).max())
+        out = nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5)
+        ref = (dd(r) + 0.5 * F.silu(prod + dd(b))).float().cpu()
+        assert _md(out, ref) <= 2e-6 * scale + 1e-5
+        for _ in range(3 if dev.type == "cuda" else 1):
+            assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
+        lib.sbk_prof_set_knob(33, 1)  # the panels through registers instead of by LDS-DMA: same arithmetic
+        try:
+            assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
+        finally:
+            lib.sbk_prof_set_knob(33, 0)
+        # RMS error against fp64 next to the fp32-MFMA kernels' on the same operands.  Zero-mean operands (what LayerNorm
+        # outputs x weights are): about the same (measured on MI355X 0.85 x at K = 512, 0.87-1.22 x at K = 2 048 at the
+        # encoder's row counts, 1.6 x on a 257-row problem cut into stream-K pieces).  Operands with a
+        # strong common sign, whose partial sums grow linearly: up to 3.3 x measured (the matrix core adds the 16 products
+        # of a bf16 MFMA and the accumulator with truncation, and six MFMAs touch the accumulator per 16 k) -- still far
+        # inside the 2e-6 bound above that every fp32 kernel of the library is held to.  The emulator rounds the
+        # accumulator after every single partial product (six per k), hence its wider bounds.
+        def rms_ratio(x, y):
+            xd, yd = x.to(dev), y.to(dev)
+            exact = dd(x) @ dd(y).t()
+            got = nat.gemm_nt(xd, yd)
+            nat.F32X3 = False
+            try:
+                base = nat.gemm_nt(xd, yd)  # the fp32-MFMA kernels
+            finally:
+                nat.F32X3 = True
+            e3 = float((got.double().cpu() - exact.cpu()).pow(2).mean().sqrt())
+            e32 = float((base.double().cpu() - exact.cpu()).pow(2).mean().sqrt())
+            return e3 / max(e32, 1e-30)
+        on_gpu = dev.type == "cuda"
+        assert rms_ratio(a, w) <= (4.0 if on_gpu else 8.0)
+        assert rms_ratio(torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)) <= (2.0 if on_gpu else 8.0)
+        rows = 50 if M % 50 == 0 else M // 7
+        nseq = M // rows
+        lens = torch.tensor([(i * 13) % (rows + 1) for i in range(nseq)], dtype=torch.int32)
+        out = nat.gemm_nt(ad[: nseq * rows], wd, bd, rd[: nseq * rows], seq_len=lens.to(dev), rows_per_seq=rows)
+        keep = (torch.arange(rows)[None, :] < lens[:, None]).reshape(-1, 1)
+        ref = r[: nseq * rows] + torch.where(keep, (prod[: nseq * rows] + dd(b)).float().cpu(), torch.zeros(()))
+        assert _md(out, ref) <= 2e-6 * scale + 1e-5
+        if N == K:  # in-place residual
+            x = ad.clone()
+            out = nat.gemm_nt(x, wd, None, x)
+            assert _md(out, a + prod.float().cpu()) <= 2e-6 * scale + 1e-5
+        if K % 64 == 0 and M <= 4100:  # a window of K floats sliding by lda = K / 2 over a flat signal
+            flat = ad.reshape(-1)
+            Mw = 2 * M - 1
+            out = nat.gemm_nt_rows(flat, Mw, K, K // 2, wd, bd)
+            win = a.reshape(-1).unfold(0, K, K // 2)
+            assert win.shape[0] == Mw
+            assert _md(out, (win.double() @ w.double().t() + b).float()) <= 2e-6 * scale + 1e-5
+    finally:
+        nat.F32X3, nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES = old
+        lib.sbk_prof_set_knob(31, 0)
+        lib.sbk_prof_set_knob(21, 4)
+
+
 @pytest.mark.parametrize("d_model,nhead,B,T,beam_rows", [(128, 2, 3, 150, 4), (256, 4, 2, 75, 10), (128, 2, 1, 20, 1)])
 def test_cross_attention_lds_dma_variant(backend, d_model, nhead, B, T, beam_rows):
     """csrc/decoder.hip cross_attn_dma_kernel (head_dim 64: LDS-DMA tiles of 16 frames, transposed scores on the matrix

@@ -171,6 +171,13 @@ static inline bf16x8 cvt_bf16x8(const float (&x)[8]) {
   for (int e = 0; e < 8; ++e) r.v[e] = f32_to_bf16(x[e]);
   return r;
 }
+static inline bf16x8 bf16x8_from_words(unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+  const unsigned w[4] = {w0, w1, w2, w3};
+  bf16x8 r;
+  memcpy(r.v, w, sizeof(r.v));
+  return r;
+}
+static inline unsigned bf16_pair(float x0, float x1) { return (unsigned)f32_to_bf16(x0) | ((unsigned)f32_to_bf16(x1) << 16); }
 static inline float bf16_to_f32_(unsigned short h) {
   const unsigned u = (unsigned)h << 16;
   float f;
@@ -354,6 +361,11 @@ static inline void glds16(const float* src, float* lds_wave_base) {
   memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * sbk_emu::cur().lane, src, 16);
 }
 static inline int uniform(int v) { return v; }
+template <int MASK, int SIZE>
+static inline void sched_group() {}
+static inline void pin(unsigned&) {}
+static inline void pin(float&) {}
+static inline void pin(f32x16&) {}
 static inline void vm_drain() {}
 template <int N>
 static inline void vm_wait() {}

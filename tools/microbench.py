@@ -313,6 +313,51 @@ if __name__ == "__main__":
         for k, v in ((18, 1), (30, 0), (24, 2048), (25, 0), (26, 16)):
             nat.load().sbk_prof_set_knob(k, v)
         sys.exit(0)
+    if "--x3" in sys.argv:  # fp32 contraction on the bf16 matrix pipe (three-way operand split) vs the fp32-MFMA persistent kernel
+        def ev_time(fn, n=30):
+            fn(); fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+        shapes = [(M, N, K) for M in (4032, 8000, 12800, 24032) for (N, K) in ((2048, 512), (512, 2048), (1536, 512), (512, 512), (1024, 512))]
+        if "--x3-short" in sys.argv:
+            shapes = [(12800, 2048, 512), (12800, 512, 2048), (4032, 512, 512)]
+        grids = (0, 256, 512)
+        for (M, N, K) in shapes:
+            a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev)
+            nat.F32X3 = False
+            t32 = ev_time(lambda: nat.gemm_nt(a, w))
+            ref = nat.gemm_nt(a, w)
+            nat.F32X3, nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES = True, 1, 1
+            line = f"f32x3 M={M} N={N} K={K}: fp32-MFMA {t32:7.1f} us {2.0*M*N*K/t32/1e6:6.1f} TF/s |"
+            for grid in grids:
+                nat.load().sbk_prof_set_knob(31, grid)
+                t = ev_time(lambda: nat.gemm_nt(a, w))
+                line += f" grid {grid or 'auto'}: {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s |"
+            nat.load().sbk_prof_set_knob(31, 0)
+            if "--x3-modes" in sys.argv:  # measurement modes (wrong results): 1 no panel loads, 2 no operand split, 4 hi.hi products only
+                for grid in (512, 400, 256, 1256):
+                    nat.load().sbk_prof_set_knob(31, grid % 1000)
+                    nat.load().sbk_prof_set_knob(33, 1 if grid > 1000 else 0)  # (1xxx: panels through registers, one workgroup per CU)
+                    for mode in ((0, 1, 2, 3, 4, 6, 7, 8, 15) if grid < 1000 else (0,)):
+                        nat.load().sbk_prof_set_knob(22, mode)
+                        t = ev_time(lambda: nat.gemm_nt(a, w), n=50)
+                        line += f" g{grid} mode {mode}: {t:6.1f} |"
+                nat.load().sbk_prof_set_knob(22, 0)
+                nat.load().sbk_prof_set_knob(31, 0)
+                nat.load().sbk_prof_set_knob(33, 0)
+            out = nat.gemm_nt(a, w)
+            exact = a.double() @ w.double().t()
+            e3, e32 = float((out.double() - exact).pow(2).mean().sqrt()), float((ref.double() - exact).pow(2).mean().sqrt())
+            line += f" rms err vs fp64: x3 {e3:.3e} fp32-MFMA {e32:.3e} (output rms {float(exact.pow(2).mean().sqrt()):.1f})"
+            print(line, flush=True)
+        nat.F32X3_MIN_ROWS = 2048
+        sys.exit(0)
     if "--bf16a" in sys.argv:  # bf16 activations + weights through the LDS-DMA pipeline vs the kernel that reads fp32 activations
         def ev_time(fn, n=20):
             fn(); fn()
