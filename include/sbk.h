@@ -159,7 +159,8 @@ int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const floa
  *   sbk_split_bf16x3: W [N,K] fp32 (row stride ldw) -> W3 [N][K/32][3][32] bf16 bits (hi, mid, lo pieces; once per
  *   weight matrix, 6 bytes per element).  K % 32 == 0.
  *   sbk_gemm_nt_f32x3: C = epilogue(A . W^T) with A [M,K] fp32 in memory (cut into its pieces in registers), epilogue /
- *   lda < K / seq_len exactly as sbk_gemm_nt_f32.  K % 32 == 0, K >= 64, lda % 4 == 0, A and W3 16-byte aligned. */
+ *   lda < K / seq_len exactly as sbk_gemm_nt_f32.  K % 32 == 0, K >= 64, lda % 4 == 0, A and W3 16-byte aligned; rows of
+ *   C (and of residual / bias) are moved as 16-byte vectors: N % 4 == 0, ldc % 4 == 0, ldr % 4 == 0, 16-byte aligned. */
 int sbk_split_bf16x3(const float* W, int ldw, uint16_t* W3, int N, int K, sbk_stream_t stream);
 int sbk_gemm_nt_f32x3(const float* A, int lda, const uint16_t* W3, const float* bias, const float* residual, int ldr,
                       float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
@@ -308,6 +309,9 @@ typedef struct {
   /* optional (NULL = unused): the three LayerNorm-fed projections with gamma/beta folded in
    * (Wf = W*gamma[k], bf = b + W.beta): self-attention in_proj, cross-attention q rows, ffn.0 */
   const float *sa_in_wf, *sa_in_bf, *ca_q_wf, *ca_q_bf, *ff1_wf, *ff1_bf;
+  /* optional (NULL = unused; ABI 6): the key / value rows [2d,d] of ca_in_w as sbk_split_bf16x3 writes them -- the
+   * projection of the encoder memory (once per utterance, B*T rows) then runs as sbk_gemm_nt_f32x3 */
+  const uint16_t* ca_kv_w3;
 } sbk_decoder_layer;
 
 typedef struct {
@@ -321,6 +325,8 @@ typedef struct {
   float ln_eps;
   float emb_scale; /* multiplier of the token embedding: 0 = sqrt(d_model) (NormalizedEmbedding, nnet/embedding.py);
                       1 for the Whisper decoder, whose `pe` is its learned embed_positions table */
+  const uint16_t* seq_w3; /* optional (NULL = unused; ABI 6): seq_w as sbk_split_bf16x3 writes it -- the vocabulary
+                             projection of a step with >= 1 024 hypothesis rows then runs as sbk_gemm_nt_f32x3 */
 } sbk_decoder_weights;
 
 /* ---- a20: TransformerLM (lobes/models/transformer/TransformerLM.py:22-187; encoder-only, regularMHA,
@@ -409,6 +415,8 @@ typedef struct {
   const float* first_bias;
   int32_t probe_pos, probe_token;
   float* out_probe;
+  const uint16_t* ctc_w3; /* optional (NULL = unused; ABI 6): ctc_w as sbk_split_bf16x3 writes it (the CTC head over
+                             the B*T encoder frames, scorer.py:239-255, as sbk_gemm_nt_f32x3) */
 } sbk_search_config;
 
 /* S2STransformerBeamSearcher.forward (seq2seq.py:1632-1723, :1853-1934) with an optional full

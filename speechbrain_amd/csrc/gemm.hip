@@ -832,33 +832,36 @@ __global__ void __launch_bounds__(256, REGLD ? 1 : 2) gemm_nt_sk_kernel(SkArgs s
           bm[j] = *reinterpret_cast<const sbk::bf16x8*>(wr + 16);
           bl[j] = *reinterpret_cast<const sbk::bf16x8*>(wr + 32);
         }
-        // smallest terms first; consecutive MFMAs go to different accumulators
+        // smallest terms first; consecutive MFMAs go to different accumulators.  W is the FIRST operand: the wave
+        // computes (W tile) . (A tile)^T, so a lane owns one row m of C and registers 4g .. 4g+3 hold four consecutive
+        // columns n -- the epilogue loads residuals and stores results as 16-byte vectors (a quarter of the store
+        // instructions of the column-per-lane layout: the store tail of a tile is issue-bound, MI355X_MICROARCH.md)
         if constexpr ((MEAS & 4) == 0) {  // (measurement only, bit 2: the hi.hi products alone)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(al[i], bh[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(bh[j], al[i], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(ah[i], bl[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(bl[j], ah[i], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(am[i], bm[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(bm[j], am[i], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(am[i], bh[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(bh[j], am[i], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(ah[i], bm[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(bm[j], ah[i], acc[i][j]);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(ah[i], bh[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(bh[j], ah[i], acc[i][j]);
       }
       return;
     }
@@ -892,6 +895,61 @@ __global__ void __launch_bounds__(256, REGLD ? 1 : 2) gemm_nt_sk_kernel(SkArgs s
   auto epilogue = [&](int tile) SBK_INLINE_LAMBDA {
     const int m0 = (tile / tiles_n) * BT, n0 = (tile % tiles_n) * BT;
     const bool interior = m0 + BT <= M && n0 + BT <= N;  // uniform: no per-element predicates
+    if constexpr (X3) {  // transposed accumulators: lane = row m0 + wm0 + lrow, register 4g+e of block j = column j*32 + 8g + 4*half + e
+      const int row = m0 + wm0 + lrow, rowc = min(row, M - 1);
+      const bool row_ok = interior || row < M;
+      const bool masked = seq_len && (rowc % rows_per_seq) >= seq_len[rowc / rows_per_seq];
+      const float ra = masked ? 0.0f : alpha;
+      float* crow = gC + (size_t)rowc * ldc;
+      const float* rrow = gR ? gR + (size_t)rowc * ldr : nullptr;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float4 bv[4], rv[4];
+        bool ok[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // (N % 4 == 0: a vector is inside the matrix or outside as a whole)
+          const int col = n0 + wn0 + j * 32 + 8 * g + 4 * half;
+          ok[g] = row_ok && (interior || col < N);
+          bv[g] = (gbias && ok[g]) ? *reinterpret_cast<const float4*>(gbias + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          rv[g] = (rrow && ok[g]) ? *reinterpret_cast<const float4*>(rrow + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        float v[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          v[4 * g] = acc[0][j][4 * g] + bv[g].x;
+          v[4 * g + 1] = acc[0][j][4 * g + 1] + bv[g].y;
+          v[4 * g + 2] = acc[0][j][4 * g + 2] + bv[g].z;
+          v[4 * g + 3] = acc[0][j][4 * g + 3] + bv[g].w;
+        }
+        switch (act) {  // uniform
+          case SBK_ACT_SWISH:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+            break;
+          case SBK_ACT_GELU:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752440f));
+            break;
+          case SBK_ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
+            break;
+          case SBK_ACT_LEAKY_RELU:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.01f * v[r];
+            break;
+          default: break;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = n0 + wn0 + j * 32 + 8 * g + 4 * half;
+          const float4 o = make_float4(masked ? rv[g].x : v[4 * g] * ra + rv[g].x, masked ? rv[g].y : v[4 * g + 1] * ra + rv[g].y,
+                                       masked ? rv[g].z : v[4 * g + 2] * ra + rv[g].z, masked ? rv[g].w : v[4 * g + 3] * ra + rv[g].w);
+          if (ok[g]) *reinterpret_cast<float4*>(crow + col) = o;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn0 + j * 32 + lrow;
@@ -1892,6 +1950,13 @@ int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st, bool x3 = false)
 }
 }  // namespace
 
+// internal callers (the search's memory / CTC / vocabulary projections): from 1 024 rows and 192 tiles on (M = 1 280,
+// N = 5 000: 64.7 vs 87.9 us; M = 640: 44.9 vs 47.4, left on the tile grid)
+int g_x3_route_rows = 1024, g_x3_route_tiles = 192;  // knobs 34 / 35 (tests lower them to reach these calls with small models)
+bool x3_routed(int M, int N, int K) {
+  return M >= g_x3_route_rows && K % 32 == 0 && K >= 64 && N % 4 == 0 && (long)cdiv(M, 128) * cdiv(N, 128) >= g_x3_route_tiles;
+}
+
 // fp32 contraction with a pre-split W (sbk_split_bf16x3) on the bf16 matrix pipe; -1: no workspace for this stream
 int gemm_nt_x3(const float* A, int lda, const uint16_t* W3, const float* bias, const float* R, int ldr, float* C, int ldc,
                int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st) {
@@ -2034,6 +2099,8 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 29) sbk::g_bf16a_mode = value;
   if (key == 31) sbk::g_x3_grid = value;
   if (key == 33) sbk::g_x3_regld = value;
+  if (key == 34) sbk::g_x3_route_rows = value;
+  if (key == 35) sbk::g_x3_route_tiles = value;
 }
 
 
@@ -2055,7 +2122,9 @@ extern "C" int sbk_gemm_nt_f32x3(const float* A, int lda, const uint16_t* W3, co
   SBK_REQUIRE(M >= 0 && N >= 0 && K >= 64 && K % 32 == 0, "gemm_f32x3: bad shape M=%d N=%d K=%d (K: a multiple of 32, >= 64)", M, N, K);
   SBK_REQUIRE(lda > 0 && lda % 4 == 0 && ldc >= N && sbk::aligned16(A) && sbk::aligned16(W3),
               "gemm_f32x3: operand rows must be 16-byte aligned (lda=%d)", lda);
-  SBK_REQUIRE(!residual || ldr >= N, "gemm_f32x3: residual stride");
+  SBK_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && sbk::aligned16(C) && (!bias || sbk::aligned16(bias)),
+              "gemm_f32x3: N and ldc must be multiples of 4, C / bias 16-byte aligned (rows are stored as 16-byte vectors)");
+  SBK_REQUIRE(!residual || (ldr >= N && ldr % 4 == 0 && sbk::aligned16(residual)), "gemm_f32x3: residual stride / alignment");
   SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_f32x3: unknown activation %d", act);
   SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm_f32x3: seq_len given without rows_per_seq");
   const int rc = sbk::gemm_nt_x3(A, lda, W3, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq,

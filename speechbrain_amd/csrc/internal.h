@@ -7,6 +7,11 @@ namespace sbk {
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq,
             hipStream_t st);
+// The same contraction on the bf16 matrix pipe (csrc/gemm.hip: exact three-way operand split); W3 = sbk_split_bf16x3's
+// image of W.  x3_routed: shapes it is measured to win on (tools/microbench.py --x3 --x3-decode); -1 = no workspace.
+int gemm_nt_x3(const float* A, int lda, const uint16_t* W3, const float* bias, const float* R, int ldr, float* C, int ldc,
+               int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
+bool x3_routed(int M, int N, int K);
 // Device-resident step counter of the search running on this host thread (nullptr: the step is the
 // launch argument).  When set, every step-dependent kernel reads the step from it, so that the launches
 // of one decoding step are identical for every step and can be replayed from a captured hipGraph.

@@ -800,8 +800,14 @@ int project_memory(const sbk_decoder_weights* W, const DecoderBufs& d, const flo
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
     float* dst = d.head_major ? d.kvtmp : d.ckv[l];
-    SBK_TRY(sbk::gemm_nt(enc, dm, L.ca_in_w + (size_t)dm * dm, dm, L.ca_in_b + dm, nullptr, 0, dst, 2 * dm, B * T, 2 * dm,
-                         dm, SBK_ACT_NONE, 1.0f, nullptr, 0, st));
+    int rc = -1;
+    if (L.ca_kv_w3 && sbk::x3_routed(B * T, 2 * dm, dm))
+      rc = sbk::gemm_nt_x3(enc, dm, L.ca_kv_w3, L.ca_in_b + dm, nullptr, 0, dst, 2 * dm, B * T, 2 * dm, dm, SBK_ACT_NONE, 1.0f,
+                           nullptr, 0, st);
+    if (rc == -1)  // (not routed, or no workspace for this stream yet: first use inside a graph capture)
+      rc = sbk::gemm_nt(enc, dm, L.ca_in_w + (size_t)dm * dm, dm, L.ca_in_b + dm, nullptr, 0, dst, 2 * dm, B * T, 2 * dm, dm,
+                        SBK_ACT_NONE, 1.0f, nullptr, 0, st);
+    SBK_TRY(rc);
     if (d.head_major) SBK_TRY(sbk::kv_head_major(d.kvtmp, d.ckv[l], B, T, dm, W->nhead, st));
   }
   return 0;
@@ -860,9 +866,16 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
     if (frc != -1) return frc;
   }
   SBK_TRY(sbk::layernorm(d.x, W->final_ln_g, W->final_ln_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
-  if (want_logits)
-    SBK_TRY(sbk::gemm_nt_ws(d.h, dm, W->seq_w, dm, W->seq_b, nullptr, 0, d.logits, W->vocab, n, W->vocab, dm, SBK_ACT_NONE,
-                            1.0f, nullptr, 0, d.splitk, d.splitk_floats, st));
+  if (want_logits) {
+    int rc = -1;
+    if (W->seq_w3 && sbk::x3_routed(n, W->vocab, dm))
+      rc = sbk::gemm_nt_x3(d.h, dm, W->seq_w3, W->seq_b, nullptr, 0, d.logits, W->vocab, n, W->vocab, dm, SBK_ACT_NONE, 1.0f,
+                           nullptr, 0, st);
+    if (rc == -1)
+      rc = sbk::gemm_nt_ws(d.h, dm, W->seq_w, dm, W->seq_b, nullptr, 0, d.logits, W->vocab, n, W->vocab, dm, SBK_ACT_NONE, 1.0f,
+                           nullptr, 0, d.splitk, d.splitk_floats, st);
+    SBK_TRY(rc);
+  }
   return 0;
 }
 
@@ -1124,7 +1137,11 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
 
   SBK_TRY(project_memory(W, d, enc, B, T, st));
   if (ctc) {  // CTCScorer.reset_mem (scorer.py:239-255): log_softmax(ctc_lin(enc)), then the frame mask
-    SBK_TRY(sbk::gemm_nt(enc, dm, ctc_w, dm, ctc_b, nullptr, 0, bb.ctc_x, V, B * T, V, dm, SBK_ACT_NONE, 1.0f, nullptr, 0, st));
+    int rc = -1;
+    if (cfg->ctc_w3 && sbk::x3_routed(B * T, V, dm))
+      rc = sbk::gemm_nt_x3(enc, dm, cfg->ctc_w3, ctc_b, nullptr, 0, bb.ctc_x, V, B * T, V, dm, SBK_ACT_NONE, 1.0f, nullptr, 0, st);
+    if (rc == -1) rc = sbk::gemm_nt(enc, dm, ctc_w, dm, ctc_b, nullptr, 0, bb.ctc_x, V, B * T, V, dm, SBK_ACT_NONE, 1.0f, nullptr, 0, st);
+    SBK_TRY(rc);
     SBK_TRY(sbk::log_softmax_rows(bb.ctc_x, bb.ctc_x, B * T, V, 1.0f, 1.0f, st));
     SBK_HIP(hipMemsetAsync(bb.phi[1], 0, sbk::ctc_state_floats(B, beam, T) * sizeof(float), st));  // zero table padding
     SBK_TRY(sbk::ctc_prepare(bb.ctc_x, bb.ctc_xb, enc_len, bb.phi[0], bb.psi_prev[0], B, T, V, beam, cfg->blank, st));

@@ -33,7 +33,7 @@ class DecoderLayer(ctypes.Structure):  # sbk_decoder_layer
     _fields_ = [(n, c_void_p) for n in (
         "ln1_g", "ln1_b", "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ln2_g", "ln2_b", "ca_in_w", "ca_in_b",
         "ca_out_w", "ca_out_b", "ln3_g", "ln3_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b", "sa_in_wf", "sa_in_bf", "ca_q_wf",
-        "ca_q_bf", "ff1_wf", "ff1_bf")]
+        "ca_q_bf", "ff1_wf", "ff1_bf", "ca_kv_w3")]
 
 
 class DecoderWeights(ctypes.Structure):  # sbk_decoder_weights
@@ -41,7 +41,8 @@ class DecoderWeights(ctypes.Structure):  # sbk_decoder_weights
                 ("final_ln_b", c_void_p), ("seq_w", c_void_p), ("seq_b", c_void_p), ("seq_wf", c_void_p),
                 ("seq_bf", c_void_p), ("d_model", c_int32),
                 ("nhead", c_int32), ("d_ffn", c_int32), ("n_layers", c_int32), ("vocab", c_int32),
-                ("max_len", c_int32), ("ffn_act", c_int32), ("ln_eps", c_float), ("emb_scale", c_float)]
+                ("max_len", c_int32), ("ffn_act", c_int32), ("ln_eps", c_float), ("emb_scale", c_float),
+                ("seq_w3", c_void_p)]
 
 
 class LMLayer(ctypes.Structure):  # sbk_lm_layer
@@ -64,7 +65,8 @@ class SearchConfig(ctypes.Structure):  # sbk_search_config
                 ("lm", POINTER(LMWeights)), ("topk", c_int32), ("utt_min_steps", c_void_p),
                 ("utt_max_steps", c_void_p), ("graph_mode", c_int32), ("ctc_candidates", c_int32),
                 ("ctc_window_size", c_int32), ("prompt", c_void_p), ("prompt_len", c_int32), ("temperature_post", c_int32), ("logit_bias", c_void_p),
-                ("first_bias", c_void_p), ("probe_pos", c_int32), ("probe_token", c_int32), ("out_probe", c_void_p)]
+                ("first_bias", c_void_p), ("probe_pos", c_int32), ("probe_token", c_int32), ("out_probe", c_void_p),
+                ("ctc_w3", c_void_p)]
 
 
 def _declare(lib):
@@ -228,7 +230,7 @@ def f32x3_ok(M: int, K: int, w: torch.Tensor) -> bool:
     fp32-MFMA tile kernels do (M = 4 032, N = 512: 25.4 vs 30.6 us)."""
     if not (F32X3 and M >= F32X3_MIN_ROWS and K % 32 == 0 and K >= 64 and w.dim() == 2 and w.is_contiguous()):
         return False
-    return ((M + 127) // 128) * ((w.shape[0] + 127) // 128) >= F32X3_MIN_TILES
+    return w.shape[0] % 4 == 0 and ((M + 127) // 128) * ((w.shape[0] + 127) // 128) >= F32X3_MIN_TILES
 
 
 # ------------------------------------------------------------------ ops
@@ -715,6 +717,18 @@ class DecoderHandle:
             return t.data_ptr()
 
         dm = emb.shape[1]
+
+        def split3(w):  # sbk_split_bf16x3's image (the big contractions of the search run on the bf16 matrix pipe)
+            if not F32X3 or w.shape[1] % 32 != 0 or w.shape[1] < 64 or w.shape[0] % 4 != 0:
+                return None
+            w2 = w.detach().contiguous()
+            _dev_ok(w2)
+            _f32(w2)
+            out = torch.empty(w2.shape[0], w2.shape[1] // 32, 3, 32, dtype=torch.int16, device=w2.device)
+            _chk(load().sbk_split_bf16x3(_p(w2), w2.shape[1], _p(out), w2.shape[0], w2.shape[1], _stream(w2)), "sbk_split_bf16x3")
+            self.keep.append(out)
+            return out.data_ptr()
+
         for l, S in enumerate(layer_specs):
             o = layers[l]
             o.ln1_g, o.ln1_b = map(ptr, S["ln1"])
@@ -726,6 +740,7 @@ class DecoderHandle:
             o.ln3_g, o.ln3_b = map(ptr, S["ln3"])
             o.ff1_w, o.ff1_b = map(ptr, S["ff1"])
             o.ff2_w, o.ff2_b = map(ptr, S["ff2"])
+            o.ca_kv_w3 = split3(S["ca_in"][0][dm:])
             if fold:  # LayerNorm folded into the projection it feeds (fused kernel, csrc/gemm.hip)
                 o.sa_in_wf, o.sa_in_bf = map(ptr, _fold_ln(*S["sa_in"], *S["ln1"]))
                 o.ca_q_wf, o.ca_q_bf = map(ptr, _fold_ln(S["ca_in"][0][:dm], S["ca_in"][1][:dm], *S["ln2"]))
@@ -737,6 +752,7 @@ class DecoderHandle:
         W.final_ln_g, W.final_ln_b = map(ptr, final_ln)
         if seq is not None:
             W.seq_w, W.seq_b = map(ptr, seq)
+            W.seq_w3 = split3(seq[0])
             if fold:
                 W.seq_wf, W.seq_bf = map(ptr, _fold_ln(seq[0], seq[1], *final_ln))
         W.d_model, W.nhead = dm, nhead
@@ -873,6 +889,10 @@ def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=No
     out_longest = torch.zeros(B, dtype=torch.int32, device=dev) if want_longest else None
     flag = _host_flag(dev)
     steps = c_int32(0)
+    cfg.ctc_w3 = None
+    if ctc_w is not None and F32X3 and ctc_w.dim() == 2 and ctc_w.is_contiguous() and ctc_w.shape[1] % 32 == 0 \
+            and ctc_w.shape[1] >= 64 and ctc_w.shape[0] % 4 == 0:
+        cfg.ctc_w3 = lp_weight(ctc_w, "x3").data_ptr()  # (cached with the parameter: the CTC head over B*T frames)
     _chk(lib.sbk_beam_search_f32(ctypes.byref(handle.W), ctypes.byref(cfg), _p(enc), _p(enc_len), _p(ctc_w), _p(ctc_b),
                                  c_void_p(ws.data_ptr() + off), nbytes, _p(out_tok), _p(out_len), _p(out_score),
                                  _p(out_lp), _p(out_max), _p(out_longest), c_void_p(flag.data_ptr()),

@@ -648,8 +648,8 @@ def test_gemm_stream_k(backend, M, N, K, grid, bt):
         lib.sbk_prof_set_knob(26, 16)
 
 
-@pytest.mark.parametrize("M,N,K,grid", [(700, 300, 96, 0), (1000, 130, 64, 24), (257, 128, 640, 8), (520, 260, 128, 40), (2100, 300, 64, 16),
-                                        (4100, 512, 512, 0), (130, 1030, 2048, 0), (12800, 2048, 512, 0), (4032, 512, 2048, 0),
+@pytest.mark.parametrize("M,N,K,grid", [(700, 300, 96, 0), (1000, 132, 64, 24), (257, 128, 640, 8), (520, 260, 128, 40), (2100, 300, 64, 16),
+                                        (4100, 512, 512, 0), (130, 1032, 2048, 0), (12800, 2048, 512, 0), (4032, 512, 2048, 0),
                                         (24000, 1536, 512, 0)])
 def test_gemm_f32x3(backend, M, N, K, grid):
     """sbk_gemm_nt_f32x3: the fp32 contraction on the bf16 matrix pipe.  Operands are cut EXACTLY into three bf16 pieces

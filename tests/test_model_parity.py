@@ -767,3 +767,42 @@ def test_cross_attention_streaming_variant_matches_default(backend, variant):
     assert alt[0] == base[0]
     assert float((alt[2].cpu() - base[2].cpu()).abs().max()) <= 2e-5
     assert float((alt[3].cpu() - base[3].cpu()).abs().max()) <= 2e-5
+
+
+def test_search_projections_on_the_split_operand_kernel(backend):
+    """The search's big contractions -- cross-attention key / value rows of the encoder memory, the CTC head over the
+    B*T frames, the vocabulary projection of a step -- take sbk_gemm_nt_f32x3 (fp32 on the bf16 matrix pipe) from
+    1 024 rows / 192 tiles on.  Knobs 34 / 35 lower those thresholds so that a small model reaches them: token ids equal
+    the fp32-MFMA run's and the oracle's, scores within the fp32 tolerance; the handle carries the split images only
+    for shapes the kernel takes."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_asr, flat_state_dict
+
+    tiny = dict(d_model=64, nhead=4, d_ffn=128, n_enc=1, n_dec=2, n_fft=512, win_length=32)
+    asr = build_asr(tiny, vocab=52, seed=9, beam_size=4, ctc_weight=0.4, device=str(dev))
+    with torch.no_grad():
+        asr.mods.seq_lin.w.weight.mul_(7.0)
+        asr.mods.ctc_lin.w.weight.mul_(7.0)
+    wav = 0.1 * torch.randn(3, 9600, generator=torch.Generator().manual_seed(4))
+    lens = torch.tensor([1.0, 0.7, 0.9])
+    h = asr.mods.decoder._handle()
+    assert h.W.seq_w3 and all(h.layers[l].ca_kv_w3 for l in range(2))
+    lib = nat.load()
+    dec = asr.mods.decoder
+    enc = asr.encode_batch(wav, lens)
+    ref = dec(enc, lens.to(dev))  # thresholds at their defaults: the fp32-MFMA kernels
+    lib.sbk_prof_set_knob(34, 1)
+    lib.sbk_prof_set_knob(35, 1)
+    try:
+        got = dec(enc, lens.to(dev))
+    finally:
+        lib.sbk_prof_set_knob(34, 1024)
+        lib.sbk_prof_set_knob(35, 192)
+    assert got[0] == ref[0]
+    assert float((got[1].cpu() - ref[1].cpu()).abs().max()) <= 1e-4
+    sd = flat_state_dict(asr)
+    mc = O.ModelCfg(d_model=64, nhead=4, num_encoder_layers=1, num_decoder_layers=2, d_ffn=128, vocab=52)
+    hyps, _, _, _ = O.beam_search(enc.cpu(), lens, sd, mc, O.SearchCfg(beam=4, ctc_weight=0.4))
+    assert got[0] == hyps
+    odd = build_asr(tiny, vocab=50, seed=9, beam_size=4, ctc_weight=0.4, device=str(dev))  # 50 % 4 != 0: rows are not whole vectors
+    assert not odd.mods.decoder._handle().W.seq_w3

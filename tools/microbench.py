@@ -313,6 +313,14 @@ if __name__ == "__main__":
         for k, v in ((18, 1), (30, 0), (24, 2048), (25, 0), (26, 16)):
             nat.load().sbk_prof_set_knob(k, v)
         sys.exit(0)
+    if "--x3-pmc" in sys.argv:  # short: the split-operand kernel at a bench-sized shape for a counters pass
+        nat.F32X3, nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES = True, 1, 1
+        for (M, N, K) in [(12800, 2048, 512), (12800, 512, 2048), (24032, 1536, 512)]:
+            a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev)
+            for _ in range(6):
+                nat.gemm_nt(a, w)
+            torch.cuda.synchronize()
+        sys.exit(0)
     if "--x3" in sys.argv:  # fp32 contraction on the bf16 matrix pipe (three-way operand split) vs the fp32-MFMA persistent kernel
         def ev_time(fn, n=30):
             fn(); fn()
@@ -325,6 +333,8 @@ if __name__ == "__main__":
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) * 1e3 / n
         shapes = [(M, N, K) for M in (4032, 8000, 12800, 24032) for (N, K) in ((2048, 512), (512, 2048), (1536, 512), (512, 512), (1024, 512))]
+        if "--x3-decode" in sys.argv:  # the decoder's vocabulary projection and the memory projections (internal calls of the search)
+            shapes = [(640, 5000, 512), (1280, 5000, 512), (2560, 5000, 512), (12800, 1024, 512), (12800, 5000, 512)]
         if "--x3-short" in sys.argv:
             shapes = [(12800, 2048, 512), (12800, 512, 2048), (4032, 512, 512)]
         grids = (0, 256, 512)
@@ -340,6 +350,19 @@ if __name__ == "__main__":
                 t = ev_time(lambda: nat.gemm_nt(a, w))
                 line += f" grid {grid or 'auto'}: {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s |"
             nat.load().sbk_prof_set_knob(31, 0)
+            if "--x3-zero" in sys.argv:  # DVFS probe: the same launches on zero-filled operands (no toggling in the multipliers)
+                az, wz = torch.zeros_like(a), torch.zeros_like(w)
+                for mode in (0, 3):
+                    nat.load().sbk_prof_set_knob(22, mode)
+                    t1 = ev_time(lambda: nat.gemm_nt(a, w), n=50)
+                    t0 = ev_time(lambda: nat.gemm_nt(az, wz), n=50)
+                    line += f" mode {mode}: random {t1:6.1f} us, zeros {t0:6.1f} us |"
+                nat.load().sbk_prof_set_knob(22, 0)
+                nat.F32X3 = False
+                t1 = ev_time(lambda: nat.gemm_nt(a, w), n=50)
+                t0 = ev_time(lambda: nat.gemm_nt(az, wz), n=50)
+                nat.F32X3 = True
+                line += f" fp32-MFMA kernel: random {t1:6.1f} us, zeros {t0:6.1f} us |"
             if "--x3-modes" in sys.argv:  # measurement modes (wrong results): 1 no panel loads, 2 no operand split, 4 hi.hi products only
                 for grid in (512, 400, 256, 1256):
                     nat.load().sbk_prof_set_knob(31, grid % 1000)
