@@ -278,6 +278,7 @@ def roofline_entry(name, v, total_ms):
         e = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
              "frac": round(ach / peak, 4)}
         if name.startswith("gemm_nt_f32x3"):
+            e["frac_of_fp32_mfma_peak"] = round(ach / PEAK_MFMA_F32_TFLOPS, 4)  # what the fp32-MFMA kernel it replaced was priced against
             e["peak_note"] = ("fp32-equivalent: 2*M*N*K flops per launch; the kernel forms six bf16 partial products per multiply-add on "
                               "v_mfma_f32_32x32x16_bf16, so its ceiling is the dense bf16 MFMA peak (2 500 TF/s) / 6; "
                               f"against the fp32 MFMA peak ({PEAK_MFMA_F32_TFLOPS}) the same rate is {ach / PEAK_MFMA_F32_TFLOPS:.2f}")
@@ -425,6 +426,13 @@ def main():
 
     def timed_run(max_batch, streams, group):
         """Warm-up + the timed scatter -> transcribe -> gather of the whole job at one batch size."""
+        # every leg starts from a trimmed allocator: each leg has its own worker streams, the caching allocator keeps one
+        # pool per stream, and three legs' pools (128-utterance batches: ~2 GB of CTC emissions per grouped search) next
+        # to each other had the third leg reclaiming cached blocks inside its timed region (3 299 instead of 11 K audio-s/s)
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
         workers = ConcurrentTranscriber(asr, streams=streams, prioritise_search=not args.no_search_priority, group=group)
         workers.group_encoder = args.group_encoder
         for srch in workers.searchers:
@@ -467,6 +475,7 @@ def main():
             plan_ = st.last_plan
             info = {"n_batches": len(plan_["batches"]), "bytes_scattered": plan_["bytes_sent"], "prep_s": round(t_prep, 3),
                     "streams": workers.n, "group": workers.group,
+                    "gpu_memory_reserved_gb": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 1),
                     "per_rank_wall_s": [round(w, 4) for w in per_rank_wall],
                     "per_rank_audio_s": [round(sum(seconds[i] for b in plan_["owner"][r] for i in plan_["batches"][b]), 1)
                                          for r in range(world)],
@@ -500,6 +509,7 @@ def main():
                                       "exact three-way operand split (six bf16 partial products per multiply-add, fp32 accumulation: "
                                       "fp32-grade results, sbk_gemm_nt_f32x3)" if native.F32X3 else "fp32 throughout, fp32 MFMA contractions")
                        if args.precision == "fp32" else "opt-in bf16 operands",
+                       "gpu_memory_reserved_gb": {"after_headline_leg": info.get("gpu_memory_reserved_gb")},
                        "step": f"{UTTS_PER_STEP} utterances", "max_batch": args.max_batch,
                        "utterances_total": n_utts, "batches_total": info["n_batches"],
                        "audio_seconds_total": round(total_audio, 1), "weights": "random init, torch.manual_seed(0)",
@@ -522,6 +532,7 @@ def main():
         dt2, hyps2, _, info2 = timed_run(args.second_batch, *auto(args.second_batch))
         out[f"value_batch{args.second_batch}"] = round(total_audio / dt2, 2)
         out[f"ms_per_step_batch{args.second_batch}"] = round(1000.0 * dt2 / max(args.steps, 1), 3)
+        out["config"].setdefault("gpu_memory_reserved_gb", {})[f"after_batch{args.second_batch}_leg"] = info2.get("gpu_memory_reserved_gb")
         out["config"][f"workers_x_group_batch{args.second_batch}"] = [info2["streams"], info2["group"]]
         note(f"second run ({args.second_batch}-utterance batches): {dt2:.3f} s")
 
@@ -530,7 +541,8 @@ def main():
         from speechbrain_amd.utils.metric_stats import token_error_rate
 
         asr.eval_precision = "bf16"
-        dt3, hyps3, _, _ = timed_run(args.max_batch, *auto(args.max_batch))
+        dt3, hyps3, _, info3 = timed_run(args.max_batch, *auto(args.max_batch))
+        out["config"].setdefault("gpu_memory_reserved_gb", {})["after_bf16_leg"] = info3.get("gpu_memory_reserved_gb")
         asr.eval_precision = "fp32"
         ter = token_error_rate(hyps3, hyps)
         out["value_encoder_gemms_bf16"] = round(total_audio / dt3, 2)
