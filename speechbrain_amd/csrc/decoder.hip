@@ -208,6 +208,7 @@ struct CrossAttnArgs {
   float scale;
   int head_major;
   int fc;  // memory frames per workgroup of the frame-per-thread kernel (64, 128 or 256)
+  int32_t* cnt;  // [B] arrival tickets of the LDS-DMA kernel's runs (zero between launches), nullptr: cross_merge_kernel merges
 };
 
 // element offsets of (utterance b, head h): base of frame 0, frame stride, K -> V distance
@@ -756,11 +757,51 @@ __global__ void __launch_bounds__(1024) cross_attn_dma_kernel(CrossAttnArgs a, i
   const int klen = min(max(a.enc_len[b], 1), a.T);
   const int t0 = split * chunk, t1 = min(klen, t0 + chunk);
   float* pp = a.part ? a.part + ((((size_t)b * H + h) * a.NS + split) * nq + col) * (64 + 2) : nullptr;
+  // The partial results of an utterance's runs are merged by whichever run finishes LAST (a.cnt; round 3): publish,
+  // ticket, and the last ticket combines the NS partials in run order with cross_merge_kernel's arithmetic (bit-identical
+  // to the two-launch path), then re-arms the ticket.  One launch less per layer and step; nobody waits.
+  auto merge_if_last = [&]() SBK_INLINE_LAMBDA {
+    if (!a.cnt || a.NS == 1) return;
+    int* ticket = reinterpret_cast<int*>(lds);  // (every wave is past its last tile)
+    sbk::vm_drain();
+    __syncthreads();
+    if (tid == 0) {
+      sbk::release_agent();
+      *ticket = sbk::atomic_add_agent(a.cnt + b, 1);
+    }
+    __syncthreads();
+    const bool last = sbk::uniform(*ticket) == a.NS - 1;
+    if (!last) return;
+    if (tid == 0) {
+      sbk::acquire_agent();
+      sbk::atomic_store_agent(a.cnt + b, 0);
+    }
+    __syncthreads();
+    const int nthr = 64 * H;
+    for (int e = tid; e < nq * H * 64; e += nthr) {
+      const int j = e / (H * 64), hh = (e / 64) % H, c = e % 64;
+      const float* qq = a.part + ((((size_t)b * H + hh) * a.NS) * nq + j) * (64 + 2);
+      const size_t stride = (size_t)nq * (64 + 2);
+      float Mx = -INFINITY;
+      for (int s = 0; s < a.NS; ++s) Mx = fmaxf(Mx, qq[s * stride + 64]);
+      float num = 0.0f, den = 0.0f;
+      for (int s = 0; s < a.NS; ++s) {
+        const float l = qq[s * stride + 65];
+        if (l > 0.0f) {
+          const float w = expf(qq[s * stride + 64] - Mx);
+          num = fmaf(w, qq[s * stride + c], num);
+          den = fmaf(w, l, den);
+        }
+      }
+      a.out[((size_t)b * nq + j) * a.d + hh * 64 + c] = num / den;
+    }
+  };
   if (t0 >= t1) {  // (uniform per workgroup) nothing of this run is inside the utterance: an empty partial
     if (a.NS > 1 && g == 0 && col < nq) {
       pp[64] = -INFINITY;
       pp[65] = 0.0f;
     }
+    merge_if_last();
     return;
   }
   const float* kvb = a.kv + (size_t)b * a.T * ROW;
@@ -852,24 +893,26 @@ __global__ void __launch_bounds__(1024) cross_attn_dma_kernel(CrossAttnArgs a, i
   }
   float l_tot = l_run + sbk::shfl_xor(l_run, 16);
   l_tot += sbk::shfl_xor(l_tot, 32);
-  if (col >= nq) return;
-  if (a.NS == 1) {
-    float* op = a.out + ((size_t)b * nq + col) * a.d + h * 64;
-    const float inv = 1.0f / l_tot;
+  if (col < nq) {
+    if (a.NS == 1) {
+      float* op = a.out + ((size_t)b * nq + col) * a.d + h * 64;
+      const float inv = 1.0f / l_tot;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+      for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) op[16 * ct + 4 * g + r] = o[ct][r] * inv;
-  } else {
+        for (int r = 0; r < 4; ++r) op[16 * ct + 4 * g + r] = o[ct][r] * inv;
+    } else {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+      for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pp[16 * ct + 4 * g + r] = o[ct][r];
-    if (g == 0) {
-      pp[64] = m_run;
-      pp[65] = l_tot;
+        for (int r = 0; r < 4; ++r) pp[16 * ct + 4 * g + r] = o[ct][r];
+      if (g == 0) {
+        pp[64] = m_run;
+        pp[65] = l_tot;
+      }
     }
   }
+  merge_if_last();
 }
 
 __global__ void __launch_bounds__(256) cross_merge_kernel(const float* __restrict__ part, float* __restrict__ out,
@@ -921,6 +964,7 @@ int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
     if ((sbk::g_cross_rows == 5 || sbk::g_cross_rows == 6 || dma_auto) && !a.head_major && a.d <= 640 && a.H * 64 == a.d &&
         a.beam <= 16 && sbk::aligned16(a.kv) && (a.part || a.T <= 8)) {
       CrossAttnArgs c = a;
+      if (!sbk::g_cross_fused_merge) c.cnt = nullptr;
       const int FR = sbk::g_cross_rows == 6 ? 8 : 16;
       const int target = dma_auto ? 256 : (sbk::g_cross_fc256 == 1 ? 256 : (sbk::g_cross_fc256 == 2 ? 1024 : 512));
       int ns = sbk::cdiv(target, a.B);                          // workgroups over the batch ...
@@ -942,7 +986,7 @@ int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
         SBK_LAUNCH(cross_attn_dma_kernel<8>, dim3(c.NS, a.B), dim3(64 * a.H), lds, st, c, chunk);
       }
       int rc5 = sbk::launch_status("cross_attn_step");
-      if (rc5 || c.NS == 1) return rc5;
+      if (rc5 || c.NS == 1 || c.cnt) return rc5;  // (c.cnt: merged by the last-arriving run of every utterance)
       SBK_LAUNCH(cross_merge_kernel, dim3(a.B * a.beam), dim3(256), 0, st, (const float*)c.part, c.out, c.H, c.NS,
                  c.beam, DH, c.d);
       return sbk::launch_status("cross_merge");
@@ -1135,14 +1179,15 @@ int kv_head_major(const float* src, float* dst, int B, int T, int d, int H, hipS
   return launch_status("kv_head_major");
 }
 
+int g_cross_fused_merge = 1;  // tuning knob (key 37): the LDS-DMA cross-attention merges in its last-arriving workgroup (0: cross_merge_kernel)
 int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, float* part, int B, int T,
-                    int d, int H, int beam, hipStream_t st, int head_major) {
+                    int d, int H, int beam, hipStream_t st, int head_major, int32_t* cnt) {
   if (B == 0) return 0;
   const int Dh = d / H;
   const int fc = g_cross_rows != 0 ? kFC : (g_cross_fc256 == 1 ? 256 : (g_cross_fc256 == 2 ? 64 : kFC));
   const int NS = cdiv(T, fc);
   if (NS > 1 && !part) return fail(SBK_EINVAL, "cross_attn_step: T=%d needs a partial buffer", T);
-  CrossAttnArgs a{q, kv, enc_len, out, part, B, T, d, H, Dh, beam, NS, 1.0f / sqrtf((float)Dh), head_major, fc};
+  CrossAttnArgs a{q, kv, enc_len, out, part, B, T, d, H, Dh, beam, NS, 1.0f / sqrtf((float)Dh), head_major, fc, cnt};
   switch (Dh) {
     case 64: return launch_cross<64>(a, st);
     case 36: return launch_cross<36>(a, st);

@@ -379,7 +379,7 @@ struct PanelStage {
 };
 
 template <int BM, int BN, int BK, int WM, int WN, bool VEC>
-__device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g) {
+__device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g, int* tile_x = nullptr, int* tile_y = nullptr) {
   constexpr int WAVES_N = BN / WN;
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -402,6 +402,10 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g) {
     }
   }
   const int m0 = by * BM, n0 = bx * BN;
+  if (tile_x) {  // (the caller continues on this tile)
+    *tile_x = bx;
+    *tile_y = by;
+  }
   const int lrow = lane & 31, lk = lane >> 5;
 
   f32x16 acc[TM][TN];
@@ -497,6 +501,57 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM * WN <= 64 * 6
   g.alpha = 1.0f;
   g.seq_len = nullptr;
   gemm_nt_tile<BM, BN, BK, WM, WN, VEC>(g);
+}
+
+// ... and the reduction by whichever of a tile's K slices finishes last (round 3): every workgroup publishes its partial
+// tile (agent-scope release), takes a ticket on the tile's counter, and the last ticket sums the SK partial tiles in
+// slice order -- the order splitk_reduce_kernel uses, so the result is bit-identical to the two-launch path -- applies
+// the epilogue and re-arms the counter.  One launch less per long-K projection of a decoding step; nobody waits.
+template <int BM, int BN, int BK, int WM, int WN, bool VEC>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM * WN <= 64 * 64) ? 2 : 1) gemm_nt_splitk_fused_kernel(GemmArgs g, float* __restrict__ ws,
+                                                                                           int kper, int* __restrict__ cnt) {
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  __shared__ int ticket;
+  const int z = blockIdx.z, SK = gridDim.z;
+  GemmArgs p = g;
+  p.A += (size_t)z * kper;
+  p.W += (size_t)z * kper;
+  p.K = (g.K - z * kper) < kper ? (g.K - z * kper) : kper;
+  p.C = ws + (size_t)z * g.M * g.N;
+  p.ldc = g.N;
+  p.bias = nullptr;
+  p.R = nullptr;
+  p.act = SBK_ACT_NONE;
+  p.alpha = 1.0f;
+  p.seq_len = nullptr;
+  int bx = 0, by = 0;
+  gemm_nt_tile<BM, BN, BK, WM, WN, VEC>(p, &bx, &by);
+  sbk::vm_drain();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sbk::release_agent();
+    ticket = sbk::atomic_add_agent(cnt + by * gridDim.x + bx, 1);
+  }
+  __syncthreads();
+  if (sbk::uniform(ticket) != SK - 1) return;
+  if (threadIdx.x == 0) {
+    sbk::acquire_agent();
+    sbk::atomic_store_agent(cnt + by * gridDim.x + bx, 0);  // re-armed for the next launch on this stream
+  }
+  __syncthreads();
+  const size_t total = (size_t)g.M * g.N;
+  const int m0 = by * BM, n0 = bx * BN;
+  for (int e = threadIdx.x; e < BM * BN; e += NT) {
+    const int row = m0 + e / BN, col = n0 + e % BN;
+    if (row >= g.M || col >= g.N) continue;
+    const size_t i = (size_t)row * g.N + col;
+    float acc = ws[i];
+    for (int ks = 1; ks < SK; ++ks) acc += ws[(size_t)ks * total + i];
+    float v = apply_act(acc + (g.bias ? g.bias[col] : 0.0f), g.act) * g.alpha;
+    if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
+    if (g.R) v += g.R[(size_t)row * g.ldr + col];
+    g.C[(size_t)row * g.ldc + col] = v;
+  }
 }
 
 // Same tiling with 16-byte LDS traffic.  The two k-slices of v_mfma_f32_32x32x2 need not be neighbours in
@@ -1683,6 +1738,7 @@ int g_tiled_splitk = 256;  // tuning knob (key 14): from this many rows on, K >=
                            // 4-way K split instead of the register-operand path (0 = off).  Measured (tools/microbench.py
                            // --ffn2, N = 512, K = 2048): 160 rows 17.9 -> 21.6 us, 320: 24.2 -> 20.1, 1280: 53.0 -> 37.8,
                            // 2560: 94.4 -> 57.9; N = 768, K = 3072 at 1280 rows: 115.7 -> 63.5
+int g_splitk_fused = 1;  // tuning knob (key 36): the tiled split-K GEMM reduces in the last-arriving workgroup of a tile (0: splitk_reduce_kernel)
 int g_tiled_splitk_short = 0;  // tuning knob (key 15): K split of the same kernel for 512 <= K < 2048 (0 = not used)
 int g_skinny_reach = 0;   // tuning knob (key 12): 1 = the register-operand path also takes the mid-M shapes that go to
                           // the LDS-tiled kernels by default (M*N >= 1.9 M with K <= 1024)
@@ -1690,6 +1746,7 @@ int g_gemm_tile = 0;   // tuning knob (key 6) for the large-M path: 0 = 128x128,
                        // 2 = 128x256 (8 waves), 3 = 256x128 (4 waves of 128x64), 4 = 128x128 with 64-deep K tiles
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
+int* tile_tickets(hipStream_t st, long tiles);  // this stream's zeroed arrival counters (nullptr: none yet and the stream is capturing, or too many tiles)
 int sk_route(int M, int N, int K, int* bt = nullptr);  // workgroups (and tile edge) of the persistent kernel for this shape (0: tile-grid / register-operand paths)
 // Internal C++ entry shared with the fused pipelines (decoder step, encoder).
 // Skinny path: M <= 512 rows, K a multiple of 64, 16-byte aligned rows.  `ws` (optional) holds the
@@ -1712,6 +1769,11 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
     if ((size_t)SK * M * N <= ws_floats) {
       ProfScope prof("gemm_skinny", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
       dim3 grid(cdiv(N, 64), cdiv(M, 64), SK), block(256);
+      int* tickets = g_splitk_fused ? tile_tickets(st, (long)grid.x * grid.y) : nullptr;
+      if (tickets) {  // the reduction runs in the last-arriving K slice of every tile
+        SBK_LAUNCH((gemm_nt_splitk_fused_kernel<64, 64, 32, 32, 32, true>), grid, block, 0, st, g, ws, kper, tickets);
+        return launch_status("gemm_splitk_fused");
+      }
       SBK_LAUNCH((gemm_nt_splitk_kernel<64, 64, 32, 32, 32, true>), grid, block, 0, st, g, ws, kper);
       int rc = launch_status("gemm_splitk_tiled");
       if (rc) return rc;
@@ -1872,6 +1934,14 @@ bool sk_workspace(hipStream_t st, SkWorkspace* out) {
   *out = w;
   return true;
 }
+
+}  // namespace
+int* tile_tickets(hipStream_t st, long tiles) {
+  SkWorkspace w;
+  if (tiles > kSkMaxTiles || !sk_workspace(st, &w)) return nullptr;
+  return w.cnt;
+}
+namespace {
 
 int sk_cus() {
   if (!g_sk_cus) {
@@ -2099,6 +2169,8 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 29) sbk::g_bf16a_mode = value;
   if (key == 31) sbk::g_x3_grid = value;
   if (key == 33) sbk::g_x3_regld = value;
+  if (key == 36) sbk::g_splitk_fused = value;
+  if (key == 37) sbk::g_cross_fused_merge = value;
   if (key == 34) sbk::g_x3_route_rows = value;
   if (key == 35) sbk::g_x3_route_tiles = value;
 }

@@ -24,6 +24,7 @@ extern int g_cross_rows;
 extern int g_kv_head_major;
 extern int g_ctc_tpt;
 extern int g_cross_fc256;
+extern int g_cross_fused_merge;
 extern int g_self_group_off;
 int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
                int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, float* ws,

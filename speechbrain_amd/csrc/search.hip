@@ -69,7 +69,7 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
                    int H, int step, int nslot, int Lmax, hipStream_t st, const int32_t* key_tok = nullptr,
                    int key_stride = 0, int key_shift = 0, int key_first = 0, int pad_idx = 0, int group = 1);
 int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, float* part, int B, int T,
-                    int d, int H, int beam, hipStream_t st, int head_major);
+                    int d, int H, int beam, hipStream_t st, int head_major, int32_t* cnt = nullptr);
 int kv_head_major(const float* src, float* dst, int B, int T, int d, int H, hipStream_t st);
 size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam);
 int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st,
@@ -754,6 +754,7 @@ struct DecoderBufs {
   float* splitk;        // split-K partials of the skinny GEMMs
   size_t splitk_floats;
   float* xpart;         // cross-attention split partials
+  int32_t* xcnt;        // [B] arrival tickets of the cross-attention runs (zeroed by project_memory, re-armed by the kernel)
   float* kvtmp;         // [B,T,2d] projection output before the head-major re-layout
   int head_major;       // layout of ckv[l]: 1 = [B,H,T,2*Dh], 0 = [B,T,2d]
   float* ckv[64];
@@ -772,6 +773,7 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
   d.splitk_floats = (size_t)4 * n * (size_t)dm;  // global split-K is used for the long-K FFN2 only
   d.splitk = c.take<float>(d.splitk_floats);
   d.xpart = c.take<float>(sbk::cross_attn_partial_floats(B, T, W->nhead, dm / W->nhead, n / (B > 0 ? B : 1)) + 64);
+  d.xcnt = c.take<int32_t>((size_t)B + 16);
   d.head_major = sbk::g_kv_head_major && (dm / W->nhead) % 4 == 0;
   d.kvtmp = c.take<float>((size_t)B * T * 2 * dm);
   for (int l = 0; l < W->n_layers; ++l) {
@@ -797,6 +799,7 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
 int project_memory(const sbk_decoder_weights* W, const DecoderBufs& d, const float* enc, int B, int T,
                    hipStream_t st) {
   const int dm = W->d_model;
+  SBK_HIP(hipMemsetAsync(d.xcnt, 0, ((size_t)B + 16) * sizeof(int32_t), st));  // (once per search: the kernels leave the tickets at zero)
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
     float* dst = d.head_major ? d.kvtmp : d.ckv[l];
@@ -845,7 +848,7 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
       SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.ca_in_w, dm, L.ca_in_b, nullptr, 0, d.q, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
                               0, d.splitk, d.splitk_floats, st));
     }
-    SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, d.xpart, B, T, dm, H, beam, st, d.head_major));
+    SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, d.xpart, B, T, dm, H, beam, st, d.head_major, d.xcnt));
     SBK_TRY(sbk::gemm_nt_ws(d.ctx, dm, L.ca_out_w, dm, L.ca_out_b, d.x, dm, d.x, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
                          0, d.splitk, d.splitk_floats, st));
     frc = L.ff1_wf ? sbk::gemm_ln_nt(d.x, dm, L.ff1_wf, dm, L.ff1_bf, nullptr, 0, d.ff, W->d_ffn, n, W->d_ffn, dm, W->ln_eps,
