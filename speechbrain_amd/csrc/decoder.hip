@@ -1179,7 +1179,9 @@ int kv_head_major(const float* src, float* dst, int B, int T, int d, int H, hipS
   return launch_status("kv_head_major");
 }
 
-int g_cross_fused_merge = 1;  // tuning knob (key 37): the LDS-DMA cross-attention merges in its last-arriving workgroup (0: cross_merge_kernel)
+// tuning knob (key 37): 1 = the LDS-DMA cross-attention merges in its last-arriving workgroup.  OFF (see knob 36: the
+// per-workgroup agent-scope release costs more than the cross_merge launch it saves)
+int g_cross_fused_merge = 0;
 int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, float* part, int B, int T,
                     int d, int H, int beam, hipStream_t st, int head_major, int32_t* cnt) {
   if (B == 0) return 0;

@@ -1738,7 +1738,10 @@ int g_tiled_splitk = 256;  // tuning knob (key 14): from this many rows on, K >=
                            // 4-way K split instead of the register-operand path (0 = off).  Measured (tools/microbench.py
                            // --ffn2, N = 512, K = 2048): 160 rows 17.9 -> 21.6 us, 320: 24.2 -> 20.1, 1280: 53.0 -> 37.8,
                            // 2560: 94.4 -> 57.9; N = 768, K = 3072 at 1280 rows: 115.7 -> 63.5
-int g_splitk_fused = 1;  // tuning knob (key 36): the tiled split-K GEMM reduces in the last-arriving workgroup of a tile (0: splitk_reduce_kernel)
+// tuning knob (key 36): 1 = the tiled split-K GEMM reduces in the last-arriving workgroup of a tile.  OFF: measured slower in
+// the bench (9 815 vs 10 416 audio-s/s with knobs 36 + 37 on / off, profiles/r03_last_arriver_reductions_ab.log): the
+// agent-scope release every workgroup needs is an L2 write-back on an 8-XCD part, paid 640 times per launch here
+int g_splitk_fused = 0;
 int g_tiled_splitk_short = 0;  // tuning knob (key 15): K split of the same kernel for 512 <= K < 2048 (0 = not used)
 int g_skinny_reach = 0;   // tuning knob (key 12): 1 = the register-operand path also takes the mid-M shapes that go to
                           // the LDS-tiled kernels by default (M*N >= 1.9 M with K <= 1024)
