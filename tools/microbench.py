@@ -364,16 +364,14 @@ if __name__ == "__main__":
                 nat.F32X3 = True
                 line += f" fp32-MFMA kernel: random {t1:6.1f} us, zeros {t0:6.1f} us |"
             if "--x3-modes" in sys.argv:  # measurement modes (wrong results): 1 no panel loads, 2 no operand split, 4 hi.hi products only
-                for grid in (512, 400, 256, 1256):
-                    nat.load().sbk_prof_set_knob(31, grid % 1000)
-                    nat.load().sbk_prof_set_knob(33, 1 if grid > 1000 else 0)  # (1xxx: panels through registers, one workgroup per CU)
-                    for mode in ((0, 1, 2, 3, 4, 6, 7, 8, 15) if grid < 1000 else (0,)):
+                for grid in (512, 400, 256):
+                    nat.load().sbk_prof_set_knob(31, grid)
+                    for mode in (0, 1, 2, 3, 4, 6, 7, 8, 15):
                         nat.load().sbk_prof_set_knob(22, mode)
                         t = ev_time(lambda: nat.gemm_nt(a, w), n=50)
                         line += f" g{grid} mode {mode}: {t:6.1f} |"
                 nat.load().sbk_prof_set_knob(22, 0)
                 nat.load().sbk_prof_set_knob(31, 0)
-                nat.load().sbk_prof_set_knob(33, 0)
             out = nat.gemm_nt(a, w)
             exact = a.double() @ w.double().t()
             e3, e32 = float((out.double() - exact).pow(2).mean().sqrt()), float((ref.double() - exact).pow(2).mean().sqrt())
