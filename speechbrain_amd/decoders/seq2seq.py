@@ -256,6 +256,7 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
         lm = {}
         if self.lm is not None:
             self._lm_handle = self.lm.handle()  # keeps the pointed-to weight table alive during the call
+            self._lm_handle.ready.wait(self._lm_handle.device)  # (built on another worker's stream a moment ago?)
             lm = dict(lm=ctypes.pointer(self._lm_handle.W), lm_weight=self.lm_weight,
                       lm_temperature=self.lm_temperature)
         return native.SearchConfig(**lm, topk=self.topk if self.return_topk else 1,

@@ -289,6 +289,33 @@ def gemm_nt_rows(a_flat: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor
     return out
 
 
+class _Ready:
+    """A derived weight image (bf16 / x3 copy, LayerNorm-folded projection, a handle's tables) is produced by kernels on
+    the stream of the thread that first asked for it; the batches in flight run on other streams and may ask for it a
+    few microseconds later.  The producer records an event; a consumer on another stream waits for it (on the
+    device, not on the host) until it has completed once."""
+    __slots__ = ("ev", "sid")
+
+    def __init__(self, device):
+        self.ev, self.sid = None, 0
+        if device.type == "cuda":
+            cur = torch.cuda.current_stream(device)
+            self.ev = torch.cuda.Event()
+            self.ev.record(cur)
+            self.sid = cur.cuda_stream
+
+    def wait(self, device):
+        ev = self.ev
+        if ev is None:
+            return
+        if ev.query():
+            self.ev = None  # (benign race: the event has completed for everybody)
+            return
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream != self.sid:
+            cur.wait_event(ev)
+
+
 _BF16_WEIGHTS = {}  # (id(weight tensor), kind) -> (weakref to it, _version, reduced-precision copy[, scale])
 _BF16_LOCK = threading.Lock()
 
@@ -305,6 +332,7 @@ def lp_weight(w: torch.Tensor, kind: str = "bf16"):
     with _BF16_LOCK:
         hit = _BF16_WEIGHTS.get(key)
         if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].device == w.device:
+            hit[4].wait(w.device)  # (made on another worker's stream a moment ago?)
             return hit[2] if kind != "fp8" else (hit[2], hit[3])
     lib = load()
     w2 = w.detach().contiguous()
@@ -331,7 +359,7 @@ def lp_weight(w: torch.Tensor, kind: str = "bf16"):
                 del _BF16_WEIGHTS[key]
 
     with _BF16_LOCK:
-        _BF16_WEIGHTS[key] = (weakref.ref(w, _drop), w._version, out, scale)
+        _BF16_WEIGHTS[key] = (weakref.ref(w, _drop), w._version, out, scale, _Ready(w.device))
     return out if kind != "fp8" else (out, scale)
 
 
@@ -761,6 +789,7 @@ class DecoderHandle:
         W.max_len, W.ffn_act, W.ln_eps, W.emb_scale = pe.shape[-2], ffn_act, ln_eps, float(emb_scale)
         self.W = W
         self.device = emb.device
+        self.ready = _Ready(emb.device)  # (the folded / split tables above were written on this thread's stream)
 
     @staticmethod
     def source_key(model, seq_lin=None):
@@ -820,6 +849,7 @@ class LMHandle:
         W.normalize_before, W.pad_idx, W.ln_eps = int(enc.layers[0].normalize_before), 0, enc.norm.eps
         self.W = W
         self.device = emb.device
+        self.ready = _Ready(emb.device)
         self.key = self.source_key(lm)
 
     @staticmethod
@@ -836,6 +866,7 @@ def lm_prefix(handle: "LMHandle", tokens):
     lib = load()
     _dev_ok(tokens)
     n, L = tokens.shape
+    handle.ready.wait(tokens.device)
     nbytes = lib.sbk_lm_prefix_workspace_bytes(ctypes.byref(handle.W), n, L)
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=tokens.device)
     off = (-ws.data_ptr()) % 256
@@ -878,6 +909,7 @@ def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=No
     dev = enc.device
     L = max(int(cfg.max_steps), 1)
     K = max(int(cfg.topk), 1)  # rows per utterance (return_topk)
+    handle.ready.wait(dev)
     nbytes = lib.sbk_beam_search_workspace_bytes(ctypes.byref(handle.W), ctypes.byref(cfg), B, T)
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
@@ -910,6 +942,7 @@ def greedy_search(handle: DecoderHandle, enc, enc_len, min_steps, max_steps, bos
     B, T, _ = enc.shape
     dev = enc.device
     L = max(int(max_steps), 1)
+    handle.ready.wait(dev)
     nbytes = lib.sbk_greedy_search_workspace_bytes(ctypes.byref(handle.W), B, T, max_steps)
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
@@ -935,6 +968,7 @@ def prompted_greedy_search(handle: DecoderHandle, enc, enc_len, prompt, max_new,
     P = prompt.shape[1]
     dev = enc.device
     L = max(int(max_new), 1)
+    handle.ready.wait(enc.device)
     nbytes = lib.sbk_prompted_greedy_search_workspace_bytes(ctypes.byref(handle.W), B, T, P, int(max_new))
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
@@ -957,6 +991,7 @@ def decoder_prefix(handle: DecoderHandle, tokens, enc, enc_len):
     _dev_ok(tokens, enc, enc_len)
     n, L = tokens.shape
     T = enc.shape[1]
+    handle.ready.wait(enc.device)
     nbytes = lib.sbk_decoder_prefix_workspace_bytes(ctypes.byref(handle.W), n, T, L)
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=enc.device)
     off = (-ws.data_ptr()) % 256

@@ -841,3 +841,32 @@ def test_gemm_fp16_and_fp8_operands(backend, M, N, K):
     assert float(d8.pow(2).mean().sqrt() / ref8.double().pow(2).mean().sqrt()) <= 1e-3  # (same roundings up to stray ties)
     err = (out8.cpu().double() - (full + b)).pow(2).mean().sqrt() / full.pow(2).mean().sqrt()
     assert float(err) <= 0.045, float(err)
+
+
+def test_weight_images_made_on_another_stream_are_awaited(backend):
+    """native.lp_weight caches a weight's derived image (here the three-piece split) for every stream of the process: a
+    consumer that finds the entry a moment after ANOTHER stream's thread enqueued the kernel that writes it must wait for
+    that kernel on the device (native._Ready), not read the image early.  Stream A is kept busy so that the split kernel
+    queues behind seconds of work; the contraction issued on stream B right away must still be right."""
+    nat, dev = backend
+    if dev.type != "cuda":
+        r = nat._Ready(dev)  # host tensors (emulator): nothing to wait for
+        assert r.ev is None and r.wait(dev) is None
+        return
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(2048, 512, generator=g).to(dev)
+    a = torch.randn(4096, 512, generator=g).to(dev)
+    ref = (a.double() @ w.double().t()).float()
+    big = torch.randn(8192, 8192, device=dev)
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sa):
+        for _ in range(30):
+            big = (big @ big) * 1e-4  # ~0.2 s of queued work in front of the split kernel
+        img = nat.lp_weight(w, "x3")
+    with torch.cuda.stream(sb):
+        out = nat.gemm_nt(a, w)  # cache hit on another stream: waits for stream A's event
+    torch.cuda.synchronize()
+    assert nat.lp_weight(w, "x3") is img
+    scale = float((a.abs() @ w.abs().t()).max())
+    assert _md(out, ref) <= 2e-6 * scale + 1e-5
