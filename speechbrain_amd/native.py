@@ -233,6 +233,11 @@ def f32x3_ok(M: int, K: int, w: torch.Tensor) -> bool:
     return w.shape[0] % 4 == 0 and ((M + 127) // 128) * ((w.shape[0] + 127) // 128) >= F32X3_MIN_TILES
 
 
+def _aligned16(*ts) -> bool:
+    """(the split-operand kernel moves rows of C / residual / bias as 16-byte vectors)"""
+    return all(t is None or t.data_ptr() % 16 == 0 for t in ts)
+
+
 # ------------------------------------------------------------------ ops
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None,
             seq_len=None, rows_per_seq=0):
@@ -252,7 +257,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_
         out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
     _dev_ok(seq_len)
-    if f32x3_ok(M, K, w):
+    if f32x3_ok(M, K, w) and _aligned16(a2, out, bias, r2):
         _chk(lib.sbk_gemm_nt_f32x3(_p(a2), K, _p(lp_weight(w, "x3")), _p(bias), _p(r2), N, _p(out), N, M, N, K, act,
                                    float(alpha), _p(seq_len), int(rows_per_seq), _stream(a2)), "sbk_gemm_nt_f32x3")
         return out
@@ -280,7 +285,7 @@ def gemm_nt_rows(a_flat: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor
         _chk(lib.sbk_gemm_nt_bf16(_p(a_flat), int(lda), _p(bf16_weight(w)), K, _p(bias), _p(residual), N, _p(out), N, M, N, K,
                                   act, float(alpha), None, 0, _stream(a_flat)), "sbk_gemm_nt_bf16")
         return out
-    if f32x3_ok(M, K, w) and lda % 4 == 0:
+    if f32x3_ok(M, K, w) and lda % 4 == 0 and _aligned16(a_flat, out, bias, residual):
         _chk(lib.sbk_gemm_nt_f32x3(_p(a_flat), int(lda), _p(lp_weight(w, "x3")), _p(bias), _p(residual), N, _p(out), N, M, N, K,
                                    act, float(alpha), None, 0, _stream(a_flat)), "sbk_gemm_nt_f32x3")
         return out
