@@ -223,3 +223,19 @@ def test_wav_reader_formats(tmp_path):
         read_wav(bad)
     with pytest.raises(NotImplementedError):
         read_wav(write("adpcm.wav", 2, 4, b"\x00" * 64))
+
+
+def test_bench_roofline_entry_prices_each_kernel_against_its_own_peak():
+    """bench.py's roofline object: fp32-MFMA kernels against 157.3 TF/s, the split-operand contraction against the dense
+    bf16 MFMA peak / 6 (with the fraction of the fp32 peak beside it), memory-bound kernels against 8 TB/s."""
+    import bench
+
+    v = {"ms": 1000.0, "count": 10, "flops": 139.0e12, "bytes": 1.0e12}
+    e = bench.roofline_entry("gemm_nt_f32x3", v, 4000.0)
+    assert e["bound"] == "mfma" and abs(e["peak"] - 2500.0 / 6.0) < 0.1
+    assert abs(e["frac"] - 139.0 / (2500.0 / 6.0)) < 1e-3 and abs(e["frac_of_fp32_mfma_peak"] - 139.0 / 157.3) < 1e-3
+    assert e["launches"] == 10 and abs(e["share_of_gpu_time"] - 0.25) < 1e-9 and "peak_note" in e
+    e = bench.roofline_entry("gemm_nt_persistent", v, 4000.0)
+    assert e["peak"] == 157.3 and "frac_of_fp32_mfma_peak" not in e
+    e = bench.roofline_entry("cross_attn_step", v, 4000.0)
+    assert e["bound"] == "hbm" and e["unit"] == "GB/s" and abs(e["achieved"] - 1000.0) < 1e-6 and e["peak"] == 8000.0
