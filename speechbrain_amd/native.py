@@ -321,7 +321,7 @@ class _Ready:
             cur.wait_event(ev)
 
 
-_BF16_WEIGHTS = {}  # (id(weight tensor), kind) -> (weakref to it, _version, reduced-precision copy[, scale])
+_BF16_WEIGHTS = {}  # (id(base tensor), kind, view geometry) -> (weakref to the base, _version, image, scale, _Ready)
 _BF16_LOCK = threading.Lock()
 
 
@@ -333,10 +333,13 @@ def lp_weight(w: torch.Tensor, kind: str = "bf16"):
     model of the same shapes by the caching allocator, and load_state_dict leaves ``_version`` alike -- a (data_ptr,
     version, shape) key would then serve the OLD model's weights).  Entries die with their tensor (weakref callback);
     insert / evict under a lock (worker threads)."""
-    key = (id(w), kind)
+    # a VIEW of a parameter (conv weight [2d,d,1] reshaped to [2d,d], a slice of a stacked projection) is a new tensor object
+    # on every call: the entry belongs to the view's base and the view's geometry, so the image is made once
+    base = w._base if w._base is not None else w
+    key = (id(base), kind, w.storage_offset(), tuple(w.shape), tuple(w.stride()))
     with _BF16_LOCK:
         hit = _BF16_WEIGHTS.get(key)
-        if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].device == w.device:
+        if hit is not None and hit[0]() is base and hit[1] == w._version and hit[2].device == w.device:
             hit[4].wait(w.device)  # (made on another worker's stream a moment ago?)
             return hit[2] if kind != "fp8" else (hit[2], hit[3])
     lib = load()
@@ -364,7 +367,7 @@ def lp_weight(w: torch.Tensor, kind: str = "bf16"):
                 del _BF16_WEIGHTS[key]
 
     with _BF16_LOCK:
-        _BF16_WEIGHTS[key] = (weakref.ref(w, _drop), w._version, out, scale, _Ready(w.device))
+        _BF16_WEIGHTS[key] = (weakref.ref(base, _drop), w._version, out, scale, _Ready(w.device))
     return out if kind != "fp8" else (out, scale)
 
 

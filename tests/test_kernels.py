@@ -870,3 +870,23 @@ def test_weight_images_made_on_another_stream_are_awaited(backend):
     assert nat.lp_weight(w, "x3") is img
     scale = float((a.abs() @ w.abs().t()).max())
     assert _md(out, ref) <= 2e-6 * scale + 1e-5
+
+
+def test_weight_image_cache_follows_views_and_in_place_updates(backend):
+    """native.lp_weight: the image of a VIEW of a parameter (the pointwise-convolution weight [2d, d, 1] seen as [2d, d] is a
+    new tensor object on every call) is made once per (base tensor, geometry); an in-place update of the base (load_state_dict,
+    copy_) invalidates it; another slice of the same base has its own entry."""
+    nat, dev = backend
+    p = torch.nn.Parameter(torch.randn(128, 64, 1).to(dev))
+    with torch.no_grad():
+        img = nat.lp_weight(p.reshape(128, 64), "x3")
+        assert nat.lp_weight(p.reshape(128, 64), "x3") is img
+        assert nat.lp_weight(p.reshape(128, 64), "bf16") is nat.lp_weight(p.reshape(128, 64), "bf16")
+        half = nat.lp_weight(p.reshape(128, 64)[64:], "x3")
+        assert half is not img and half.shape[0] == 64
+        assert torch.equal(half.cpu(), img.cpu()[64:])
+        p.mul_(2.0)
+        img2 = nat.lp_weight(p.reshape(128, 64), "x3")
+        assert img2 is not img
+        pieces = (img2.cpu().view(torch.int16).to(torch.int32) << 16).view(torch.float32)
+        assert torch.equal(pieces.double().sum(2).reshape(128, 64).float(), p.detach().cpu().reshape(128, 64))
