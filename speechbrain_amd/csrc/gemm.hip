@@ -712,7 +712,10 @@ struct SkArgs {
 // instead of by LDS-DMA, whose pieces keep a wave's issue port for 60-180 cycles each.  It needs 40 staging registers: at the
 // 256-register budget of two workgroups per CU hipcc spills them, at 512 it parks the accumulators in AGPRs and copies them per
 // K tile: 415 us where the LDS-DMA kernel takes 170, profiles/r03_f32x3_sweep.log "g1256".)
-template <int BT, bool IL, bool X3, int MEAS = 0>
+// RF (X3, knob 38, prepared and not yet timed): all fourteen operand fetches of a k step stand in front of its MFMAs behind a
+// scheduling fence.  Left alone hipcc sinks every W fragment's ds_read_b128 next to the MFMA that consumes it (M D W M D W ...:
+// 20 s_waitcnt per K tile, most MFMAs wait for an LDS round trip of their own); same arithmetic, bit-identical results.
+template <int BT, bool IL, bool X3, int MEAS = 0, bool RF = false>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
   static_assert(!X3 || (BT == 128 && !IL), "the split-operand variant: 128-wide tiles, panel loads in one block");
   constexpr int BK = 32, PANEL = BT * BK, WPITCH = X3 ? 48 : BK, WPANEL = BT * WPITCH, STAGE = PANEL + WPANEL;  // floats
@@ -837,6 +840,53 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
     const float* Ws = lds + stage * STAGE + PANEL + (wn0 + lrow) * WPITCH;
     if constexpr (X3) {
       const int wsw = (lrow >> 2) & 3;
+      if constexpr (RF) {
+#pragma unroll
+        for (int gk = 0; gk < 2; ++gk) {
+          sbk::bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+          float4 xr[TM][2];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float* wr = Ws + j * 32 * WPITCH + ((2 * gk + half) ^ wsw) * 4;
+            bh[j] = *reinterpret_cast<const sbk::bf16x8*>(wr);
+            bm[j] = *reinterpret_cast<const sbk::bf16x8*>(wr + 16);
+            bl[j] = *reinterpret_cast<const sbk::bf16x8*>(wr + 32);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            xr[i][0] = *reinterpret_cast<const float4*>(As + i * 32 * BK + ((4 * gk + 2 * half) ^ sw) * 4);
+            xr[i][1] = *reinterpret_cast<const float4*>(As + i * 32 * BK + ((4 * gk + 2 * half + 1) ^ sw) * 4);
+          }
+          sbk::sched_fence();  // every fetch of the step is issued before its first MFMA
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float x[8] = {xr[i][0].x, xr[i][0].y, xr[i][0].z, xr[i][0].w, xr[i][1].x, xr[i][1].y, xr[i][1].z, xr[i][1].w};
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              h[p] = sbk::bf16_pair(x[2 * p], x[2 * p + 1]);
+              const float r0 = x[2 * p] - __uint_as_float(h[p] << 16), r1 = x[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
+              m[p] = sbk::bf16_pair(r0, r1);
+              l[p] = sbk::bf16_pair(r0 - __uint_as_float(m[p] << 16), r1 - __uint_as_float(m[p] & 0xffff0000u));
+            }
+            ah[i] = sbk::bf16x8_from_words(h[0], h[1], h[2], h[3]);
+            am[i] = sbk::bf16x8_from_words(m[0], m[1], m[2], m[3]);
+            al[i] = sbk::bf16x8_from_words(l[0], l[1], l[2], l[3]);
+          }
+#pragma unroll
+          for (int t = 0; t < 6; ++t)  // the same six partial products in the same order as below
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const sbk::bf16x8 b = (t == 1) ? bl[j] : (t == 2 || t == 4) ? bm[j] : bh[j];
+                const sbk::bf16x8 a = (t == 0) ? al[i] : (t == 2 || t == 3) ? am[i] : ah[i];
+                acc[i][j] = sbk::mfma_32x32x16_bf16(b, a, acc[i][j]);
+              }
+          sbk::sched_fence();  // (the next step's fetches stay behind this step's MFMAs: the registers are taken)
+        }
+        return;
+      }
 #pragma unroll
       for (int gk = 0; gk < 2; ++gk) {  // 16 k per step: lanes 0-31 supply k = 16 gk .. +7, lanes 32-63 the next eight
         sbk::bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
@@ -1840,6 +1890,7 @@ int g_sk64_units = 16;    // tuning knob (key 26): K units (64x64x32) per workgr
 int g_bf16a_stages = 2;   // tuning knob (key 27): LDS stages of gemm_nt_bf16dma_kernel (2, 3 or 4)
 int g_bf16a_grid = 0;     // tuning knob (key 28): its workgroups (0 = as many as fit: two per CU with 2 stages, one with 3 / 4)
 int g_bf16a_mode = 0;     // measurement knob (key 29)
+int g_x3_reads_first = 0;  // tuning knob (key 38): the split-operand kernel with a k step's operand fetches fenced in front of its MFMAs (prepared, untimed)
 int g_x3_grid = 0;        // tuning knob (key 31): workgroups of the split-operand kernel (0 = two per CU from one tile per CU on)
 namespace {
 constexpr int kSkMaxGrid = 512, kSkMaxGrid64 = 1024, kSkMaxTiles = 1 << 16;  // (both grids fit the same slab area)
@@ -1957,7 +2008,14 @@ int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st, bool x3 = false)
     ProfScope prof("gemm_nt_f32x3", flops, bytes + 2.0 * (double)g.N * g.K, st);
     const int meas = (g_sk_noload >> 1) & 3;
     s.noload = g_sk_noload & 9;
-    if (meas == 0) {
+    if (meas == 0 && g_x3_reads_first) {
+      static bool once_rf = false;
+      if (!once_rf) {
+        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 0, true>), lds);
+        once_rf = true;
+      }
+      SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 0, true>), dim3((unsigned)G), dim3(256), lds, st, s);
+    } else if (meas == 0) {
       SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true>), dim3((unsigned)G), dim3(256), lds, st, s);
     } else {
       static bool once_meas = false;
@@ -2138,6 +2196,7 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 28) sbk::g_bf16a_grid = value;
   if (key == 29) sbk::g_bf16a_mode = value;
   if (key == 31) sbk::g_x3_grid = value;
+  if (key == 38) sbk::g_x3_reads_first = value;
   if (key == 36) sbk::g_splitk_fused = value;
   if (key == 37) sbk::g_cross_fused_merge = value;
   if (key == 34) sbk::g_x3_route_rows = value;
