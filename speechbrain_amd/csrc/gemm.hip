@@ -715,7 +715,10 @@ struct SkArgs {
 // RF (X3, knob 38, prepared and not yet timed): all fourteen operand fetches of a k step stand in front of its MFMAs behind a
 // scheduling fence.  Left alone hipcc sinks every W fragment's ds_read_b128 next to the MFMA that consumes it (M D W M D W ...:
 // 20 s_waitcnt per K tile, most MFMAs wait for an LDS round trip of their own); same arithmetic, bit-identical results.
-template <int BT, bool IL, bool X3, int MEAS = 0, bool RF = false>
+// RF = 2 (knob 38 = 2, prepared, untimed): BOTH k steps' fetches and splits first, then the K tile's 48 MFMAs in one run -- the
+// two-phase shape in which the two waves of a SIMD can alternate (one in its fetch / split / LDS-DMA phase while the other
+// owns the matrix pipe: MI355X_MICROARCH.md, "Two waves per SIMD").
+template <int BT, bool IL, bool X3, int MEAS = 0, int RF = 0>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
   static_assert(!X3 || (BT == 128 && !IL), "the split-operand variant: 128-wide tiles, panel loads in one block");
   constexpr int BK = 32, PANEL = BT * BK, WPITCH = X3 ? 48 : BK, WPANEL = BT * WPITCH, STAGE = PANEL + WPANEL;  // floats
@@ -840,7 +843,63 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
     const float* Ws = lds + stage * STAGE + PANEL + (wn0 + lrow) * WPITCH;
     if constexpr (X3) {
       const int wsw = (lrow >> 2) & 3;
-      if constexpr (RF) {
+      if constexpr (RF == 2) {
+        sbk::bf16x8 ah[2][TM], am[2][TM], al[2][TM], bh[2][TN], bm[2][TN], bl[2][TN];
+        float4 xr[2][TM][2];
+#pragma unroll
+        for (int gk = 0; gk < 2; ++gk) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            xr[gk][i][0] = *reinterpret_cast<const float4*>(As + i * 32 * BK + ((4 * gk + 2 * half) ^ sw) * 4);
+            xr[gk][i][1] = *reinterpret_cast<const float4*>(As + i * 32 * BK + ((4 * gk + 2 * half + 1) ^ sw) * 4);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float* wr = Ws + j * 32 * WPITCH + ((2 * gk + half) ^ wsw) * 4;
+            bh[gk][j] = *reinterpret_cast<const sbk::bf16x8*>(wr);
+            bm[gk][j] = *reinterpret_cast<const sbk::bf16x8*>(wr + 16);
+            bl[gk][j] = *reinterpret_cast<const sbk::bf16x8*>(wr + 32);
+          }
+        }
+        sbk::sched_fence();  // every fetch of the K tile is issued ...
+#pragma unroll
+        for (int gk = 0; gk < 2; ++gk)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float4 x0 = xr[gk][i][0], x1 = xr[gk][i][1];
+            const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              h[p] = sbk::bf16_pair(x[2 * p], x[2 * p + 1]);
+              const float r0 = x[2 * p] - __uint_as_float(h[p] << 16), r1 = x[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
+              m[p] = sbk::bf16_pair(r0, r1);
+              l[p] = sbk::bf16_pair(r0 - __uint_as_float(m[p] << 16), r1 - __uint_as_float(m[p] & 0xffff0000u));
+              sbk::pin(h[p]);  // (... and every piece exists before the first MFMA: the split is not sunk between them)
+              sbk::pin(m[p]);
+              sbk::pin(l[p]);
+            }
+            ah[gk][i] = sbk::bf16x8_from_words(h[0], h[1], h[2], h[3]);
+            am[gk][i] = sbk::bf16x8_from_words(m[0], m[1], m[2], m[3]);
+            al[gk][i] = sbk::bf16x8_from_words(l[0], l[1], l[2], l[3]);
+          }
+        sbk::sched_fence();
+#pragma unroll
+        for (int gk = 0; gk < 2; ++gk)
+#pragma unroll
+          for (int t = 0; t < 6; ++t)  // the same partial products in the same order as the default path
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const sbk::bf16x8 b = (t == 1) ? bl[gk][j] : (t == 2 || t == 4) ? bm[gk][j] : bh[gk][j];
+                const sbk::bf16x8 a = (t == 0) ? al[gk][i] : (t == 2 || t == 3) ? am[gk][i] : ah[gk][i];
+                acc[i][j] = sbk::mfma_32x32x16_bf16(b, a, acc[i][j]);
+              }
+        sbk::sched_fence();
+        return;
+      }
+      if constexpr (RF == 1) {
 #pragma unroll
         for (int gk = 0; gk < 2; ++gk) {
           sbk::bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
@@ -1890,7 +1949,7 @@ int g_sk64_units = 16;    // tuning knob (key 26): K units (64x64x32) per workgr
 int g_bf16a_stages = 2;   // tuning knob (key 27): LDS stages of gemm_nt_bf16dma_kernel (2, 3 or 4)
 int g_bf16a_grid = 0;     // tuning knob (key 28): its workgroups (0 = as many as fit: two per CU with 2 stages, one with 3 / 4)
 int g_bf16a_mode = 0;     // measurement knob (key 29)
-int g_x3_reads_first = 0;  // tuning knob (key 38): the split-operand kernel with a k step's operand fetches fenced in front of its MFMAs (prepared, untimed)
+int g_x3_reads_first = 0;  // tuning knob (key 38; prepared, untimed): 1 = a k step's operand fetches fenced in front of its MFMAs; 2 = the whole K tile's fetches and splits first, then its 48 MFMAs
 int g_x3_grid = 0;        // tuning knob (key 31): workgroups of the split-operand kernel (0 = two per CU from one tile per CU on)
 namespace {
 constexpr int kSkMaxGrid = 512, kSkMaxGrid64 = 1024, kSkMaxTiles = 1 << 16;  // (both grids fit the same slab area)
@@ -2011,10 +2070,15 @@ int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st, bool x3 = false)
     if (meas == 0 && g_x3_reads_first) {
       static bool once_rf = false;
       if (!once_rf) {
-        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 0, true>), lds);
+        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 0, 1>), lds);
+        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 0, 2>), lds);
         once_rf = true;
       }
-      SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 0, true>), dim3((unsigned)G), dim3(256), lds, st, s);
+      if (g_x3_reads_first == 2) {
+        SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 0, 2>), dim3((unsigned)G), dim3(256), lds, st, s);
+      } else {
+        SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 0, 1>), dim3((unsigned)G), dim3(256), lds, st, s);
+      }
     } else if (meas == 0) {
       SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true>), dim3((unsigned)G), dim3(256), lds, st, s);
     } else {

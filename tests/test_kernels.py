@@ -701,11 +701,13 @@ def test_gemm_f32x3(backend, M, N, K, grid):
         assert _md(out, ref) <= 2e-6 * scale + 1e-5
         for _ in range(3 if dev.type == "cuda" else 1):
             assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
-        lib.sbk_prof_set_knob(38, 1)  # the prepared variant with a k step's operand fetches in front of its MFMAs: same arithmetic
-        try:
-            assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
-        finally:
-            lib.sbk_prof_set_knob(38, 0)
+        # the prepared variants (a k step's / the whole K tile's operand fetches and splits in front of the MFMAs): same arithmetic
+        for variant in (1, 2):
+            lib.sbk_prof_set_knob(38, variant)
+            try:
+                assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
+            finally:
+                lib.sbk_prof_set_knob(38, 0)
         # RMS error against fp64 next to the fp32-MFMA kernels' on the same operands.  Zero-mean operands (what LayerNorm
         # outputs x weights are): about the same (measured on MI355X 0.85 x at K = 512, 0.87-1.22 x at K = 2 048 at the
         # encoder's row counts, 1.6 x on a 257-row problem cut into stream-K pieces).  Operands with a
