@@ -843,7 +843,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
     const float* Ws = lds + stage * STAGE + PANEL + (wn0 + lrow) * WPITCH;
     if constexpr (X3) {
       const int wsw = (lrow >> 2) & 3;
-      if constexpr (RF == 2) {
+      if constexpr (RF >= 2) {  // (3: the MFMA run at raised wave priority)
         sbk::bf16x8 ah[2][TM], am[2][TM], al[2][TM], bh[2][TN], bm[2][TN], bl[2][TN];
         float4 xr[2][TM][2];
 #pragma unroll
@@ -884,6 +884,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
             al[gk][i] = sbk::bf16x8_from_words(l[0], l[1], l[2], l[3]);
           }
         sbk::sched_fence();
+        if constexpr (RF == 3) sbk::set_prio<1>();
 #pragma unroll
         for (int gk = 0; gk < 2; ++gk)
 #pragma unroll
@@ -896,6 +897,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
                 const sbk::bf16x8 a = (t == 0) ? al[gk][i] : (t == 2 || t == 3) ? am[gk][i] : ah[gk][i];
                 acc[i][j] = sbk::mfma_32x32x16_bf16(b, a, acc[i][j]);
               }
+        if constexpr (RF == 3) sbk::set_prio<0>();
         sbk::sched_fence();
         return;
       }
@@ -1949,7 +1951,7 @@ int g_sk64_units = 16;    // tuning knob (key 26): K units (64x64x32) per workgr
 int g_bf16a_stages = 2;   // tuning knob (key 27): LDS stages of gemm_nt_bf16dma_kernel (2, 3 or 4)
 int g_bf16a_grid = 0;     // tuning knob (key 28): its workgroups (0 = as many as fit: two per CU with 2 stages, one with 3 / 4)
 int g_bf16a_mode = 0;     // measurement knob (key 29)
-int g_x3_reads_first = 0;  // tuning knob (key 38; prepared, untimed): 1 = a k step's operand fetches fenced in front of its MFMAs; 2 = the whole K tile's fetches and splits first, then its 48 MFMAs
+int g_x3_reads_first = 0;  // tuning knob (key 38; prepared, untimed): 1 = a k step's operand fetches fenced in front of its MFMAs; 2 = the whole K tile's fetches and splits first, then its 48 MFMAs; 3 = 2 with the MFMA run at wave priority 1
 int g_x3_grid = 0;        // tuning knob (key 31): workgroups of the split-operand kernel (0 = two per CU from one tile per CU on)
 namespace {
 constexpr int kSkMaxGrid = 512, kSkMaxGrid64 = 1024, kSkMaxTiles = 1 << 16;  // (both grids fit the same slab area)
@@ -2072,9 +2074,12 @@ int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st, bool x3 = false)
       if (!once_rf) {
         (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 0, 1>), lds);
         (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 0, 2>), lds);
+        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 0, 3>), lds);
         once_rf = true;
       }
-      if (g_x3_reads_first == 2) {
+      if (g_x3_reads_first == 3) {
+        SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 0, 3>), dim3((unsigned)G), dim3(256), lds, st, s);
+      } else if (g_x3_reads_first == 2) {
         SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 0, 2>), dim3((unsigned)G), dim3(256), lds, st, s);
       } else {
         SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 0, 1>), dim3((unsigned)G), dim3(256), lds, st, s);

@@ -108,6 +108,10 @@ __device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(f32x16& x) { asm volatile("" : "+v"(x)); }  // (an MFMA result: keeps the MFMA at this point of the stream)
 
+// wave priority for the instruction arbiter of the SIMD (0 = default .. 3)
+template <int P>
+__device__ __forceinline__ void set_prio() { __builtin_amdgcn_s_setprio(P); }
+
 // x * 2^e and the exponent k of x = f * 2^k, f in [0.5,1) (0 for x = 0): single VALU instructions
 // (v_ldexp_f32 / v_frexp_exp_i32_f32) without the libm special-case wrappers.
 __device__ __forceinline__ float fast_ldexp(float x, int e) { return __builtin_amdgcn_ldexpf(x, e); }

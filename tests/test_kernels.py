@@ -702,7 +702,7 @@ def test_gemm_f32x3(backend, M, N, K, grid):
         for _ in range(3 if dev.type == "cuda" else 1):
             assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
         # the prepared variants (a k step's / the whole K tile's operand fetches and splits in front of the MFMAs): same arithmetic
-        for variant in (1, 2):
+        for variant in (1, 2, 3):
             lib.sbk_prof_set_knob(38, variant)
             try:
                 assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)

@@ -363,6 +363,8 @@ static inline void glds16(const float* src, float* lds_wave_base) {
 static inline int uniform(int v) { return v; }
 template <int MASK, int SIZE>
 static inline void sched_group() {}
+template <int P>
+static inline void set_prio() {}
 static inline void pin(unsigned&) {}
 static inline void pin(float&) {}
 static inline void pin(f32x16&) {}
