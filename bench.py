@@ -34,6 +34,9 @@ With --job-utts N the job is FIXED at N utterances shared by the ranks (strong s
 in the same groups run sequentially on one stream afterwards -- asserted equal.  The searches keep the product's stop
 rule (polled asynchronously every 8 steps).
 
+"value_fp32_mfma_contractions": the same job with every contraction on the fp32 MFMA instruction (the headline's large
+contractions run on the bf16 matrix pipe through the exact three-way operand split), for reference.
+
 One JSON line on rank 0: metric / value (total unpadded audio seconds / max-over-ranks wall time) plus
 "roofline" (dominant kernel; HIP-event timing of every launch during an instrumented single-stream repetition of
 the same batches), "roofline_top3", "roofline_end_to_end", "cpu_baseline" (the oracle port of the reference's
@@ -551,6 +554,23 @@ def main():
                                       "everything else fp32; token error rate of its hypotheses against the fp32 run's on the "
                                       "same utterances (random-init weights: flat posteriors amplify every perturbation)")
         note(f"bf16 encoder GEMMs: {dt3:.3f} s, token error rate vs fp32 {ter['WER']:.2f} %")
+
+    # ---- the same job with every contraction on the fp32 MFMA instruction (SBK_F32X3=0's path), for reference: the headline's
+    # large contractions run on the bf16 matrix pipe through the exact operand split
+    if world == 1 and not dist_on and not args.no_extras and args.precision == "fp32" and native.F32X3:
+        try:
+            native.F32X3 = False
+            asr.mods.decoder._dec_handle = None  # (the searchers' weight tables carry the split images: rebuilt without)
+            try:
+                dt4, _, _, _ = timed_run(args.max_batch, *auto(args.max_batch))
+            finally:
+                native.F32X3 = True
+                asr.mods.decoder._dec_handle = None
+            out["value_fp32_mfma_contractions"] = round(total_audio / dt4, 2)
+            note(f"fp32-MFMA contractions: {dt4:.3f} s")
+        except Exception as e:  # (a reference leg must never cost the headline)
+            out["value_fp32_mfma_contractions"] = None
+            out["config"]["fp32_mfma_leg_error"] = repr(e)[:200]
 
     # ---- p50 per-utterance latency (B = 1, 10 s; pinned host waveform -> token ids on the host), rank 0 only
     if rank == 0 and args.latency_runs > 0:
