@@ -663,6 +663,7 @@ def test_gemm_stream_k(backend, M, N, K, grid, bt):
 
 
 @pytest.mark.parametrize("M,N,K,grid", [(700, 300, 96, 0), (1000, 132, 64, 24), (257, 128, 640, 8), (520, 260, 128, 40), (2100, 300, 64, 16),
+                                        (1100, 520, 96, 32), (300, 132, 64, 16), (1300, 260, 160, 48),
                                         (4100, 512, 512, 0), (130, 1032, 2048, 0), (12800, 2048, 512, 0), (4032, 512, 2048, 0),
                                         (24000, 1536, 512, 0)])
 def test_gemm_f32x3(backend, M, N, K, grid):
@@ -702,10 +703,15 @@ def test_gemm_f32x3(backend, M, N, K, grid):
         for _ in range(3 if dev.type == "cuda" else 1):
             assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
         # the prepared variants (a k step's / the whole K tile's operand fetches and splits in front of the MFMAs): same arithmetic
-        for variant in (1, 2, 3):
+        for variant in (1, 2, 3, 4):  # (4: the fused-teams kernel, taken when the grid allows two teams per workgroup)
             lib.sbk_prof_set_knob(38, variant)
             try:
-                assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
+                alt = nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5)
+                if variant < 4:
+                    assert torch.equal(alt, out)
+                else:  # whole tiles only: where the shipped kernel cut a tile's K range the partial sums associate differently
+                    assert _md(alt, ref) <= 2e-6 * scale + 1e-5
+                    assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), alt)
             finally:
                 lib.sbk_prof_set_knob(38, 0)
         # RMS error against fp64 next to the fp32-MFMA kernels' on the same operands.  Zero-mean operands (what LayerNorm
