@@ -321,8 +321,10 @@ class _Ready:
             cur.wait_event(ev)
 
 
-_BF16_WEIGHTS = {}  # (id(base tensor), kind, view geometry) -> (weakref to the base, _version, image, scale, _Ready)
-_BF16_LOCK = threading.Lock()
+_BF16_WEIGHTS = {}  # (id(base tensor), kind, view geometry) -> (weakref to the base, _version, image, scale, _Ready, data_ptr)
+# re-entrant: the weak-reference callback below takes the lock too, and a cyclic-GC pass started by an allocation INSIDE a
+# locked region may run it on the thread that already holds the lock
+_BF16_LOCK = threading.RLock()
 
 
 def lp_weight(w: torch.Tensor, kind: str = "bf16"):
@@ -339,7 +341,9 @@ def lp_weight(w: torch.Tensor, kind: str = "bf16"):
     key = (id(base), kind, w.storage_offset(), tuple(w.shape), tuple(w.stride()))
     with _BF16_LOCK:
         hit = _BF16_WEIGHTS.get(key)
-        if hit is not None and hit[0]() is base and hit[1] == w._version and hit[2].device == w.device:
+        # (data_ptr: `param.data = other` -- nn.Module._apply, a manual weight swap -- keeps the object and its version)
+        if (hit is not None and hit[0]() is base and hit[1] == w._version and hit[2].device == w.device
+                and hit[5] == w.data_ptr()):
             hit[4].wait(w.device)  # (made on another worker's stream a moment ago?)
             return hit[2] if kind != "fp8" else (hit[2], hit[3])
     lib = load()
@@ -367,7 +371,7 @@ def lp_weight(w: torch.Tensor, kind: str = "bf16"):
                 del _BF16_WEIGHTS[key]
 
     with _BF16_LOCK:
-        _BF16_WEIGHTS[key] = (weakref.ref(base, _drop), w._version, out, scale, _Ready(w.device))
+        _BF16_WEIGHTS[key] = (weakref.ref(base, _drop), w._version, out, scale, _Ready(w.device), w.data_ptr())
     return out if kind != "fp8" else (out, scale)
 
 

@@ -31,15 +31,28 @@ def _oracle_cfg(size):
     return fc, mc
 
 
-@pytest.mark.parametrize("size,B,sec", [("S", 4, 10.0), ("S", 32, 10.0), ("L", 2, 6.0), ("L", 2, 22.0)])
+@pytest.mark.parametrize("size,B,sec", [("S", 4, 10.0), ("S", 32, 10.0), ("L", 2, 6.0), ("L", 2, 22.0), ("L", 12, 10.0),
+                                        ("L", 32, 8.0)])
 def test_encoder_vs_oracle(size, B, sec):
     """configs[1] (Conformer-S, 32 x 10 s -- BASELINE.json's exact shape -- and a 4-utterance cut of it) and
     Conformer-L encoders (6 s, and 22 s = T' 551: the headline's utterance lengths): Fbank within 1e-3 dB,
-    encoder output within 2e-4 absolute (fp32; oracle self-noise is 2e-6)."""
+    encoder output within 2e-4 absolute (fp32; oracle self-noise is 2e-6).
+
+    The headline's dominant kernel inside an oracle comparison: L-12-10 s has M = 3 012 rows, so
+    the contractions with N = 2 048 / 1 536 / 1 024 take the split-operand kernel (sbk_gemm_nt_f32x3) and those with
+    N = 512 the fp32-MFMA kernels -- both meet in every layer; L-32-8 s has M = 6 432 rows: EVERY contraction of the
+    layer takes it.  The routes are asserted, not assumed."""
+    from speechbrain_amd import native
     from speechbrain_amd.inference.builders import flat_state_dict
 
     asr = _asr(size)
     n = int(sec * 16000)
+    if size == "L" and B >= 12:
+        M = B * (((1 + n // 160 - 1) // 2 + 1 - 1) // 2 + 1)
+        d = 512
+        routes = {N: native.f32x3_ok(M, K, torch.empty(N, K)) for N, K in ((2048, d), (3 * d, d), (2 * d, d), (d, 2048), (d, d))}
+        assert native.F32X3 and routes[2048] and routes[3 * d] and routes[2 * d], routes
+        assert routes[d] == (B == 32), routes
     wav = 0.1 * torch.randn(B, n, generator=torch.Generator().manual_seed(1234))
     lens = torch.linspace(0.55, 1.0, B)
     for i in range(B):
