@@ -8,7 +8,8 @@
  *
  * Conventions
  *  - every pointer is DEVICE memory owned by the caller (PyTorch-allocated);
- *    the library never allocates, frees or retains pointers past the call;
+ *    the library never allocates or frees device memory and retains no pointer past the call -- with ONE
+ *    documented exception, the stream workspace below, which the caller registers and may take back;
  *  - tensors are row-major contiguous fp32 unless stated; lengths are int32;
  *  - calls are asynchronous on `stream` (a hipStream_t) and never synchronise;
  *  - return 0 on success, a negative errno-style code for bad arguments
@@ -28,12 +29,26 @@
 extern "C" {
 #endif
 
-#define SBK_ABI_VERSION 6
+#define SBK_ABI_VERSION 7
 
 typedef void* sbk_stream_t; /* hipStream_t */
 
 int sbk_abi_version(void);
 const char* sbk_last_error(void);
+
+/* ---- stream workspace (ABI 7) ------------------------------------------------------------------------------
+ * The persistent / stream-K contraction kernels (sbk_gemm_nt_f32 from ~2 048 rows on, sbk_gemm_nt_f32x3, the searches'
+ * memory / CTC / vocabulary projections) finish cut tiles through partial-tile slabs and arrival tickets in device
+ * memory.  That memory is the CALLER's: `sbk_stream_workspace_bytes()` bytes, 256-byte aligned, registered once per
+ * (current device, stream) with sbk_stream_workspace_set -- which zeroes the tickets on that stream -- and used by every
+ * later call on that stream (launches of one stream are ordered, so they share it; two streams must not share one).
+ * The pointer is retained until sbk_stream_workspace_release(stream) (or a second _set for the same stream); the caller
+ * frees the memory afterwards, once the stream has drained.  Without a registered workspace sbk_gemm_nt_f32 and the searches
+ * use their tile-grid kernels (same result class, another summation order) and sbk_gemm_nt_f32x3 returns SBK_EINVAL.
+ * speechbrain_amd.native registers one torch-allocated workspace per stream it is called on (native._stream). */
+size_t sbk_stream_workspace_bytes(void);
+int sbk_stream_workspace_set(sbk_stream_t stream, void* workspace, size_t workspace_bytes);
+int sbk_stream_workspace_release(sbk_stream_t stream);
 
 /* Per-launch timing with HIP events recorded on each launch's own stream (bench.py's roofline
  * leg).  sbk_prof_report writes "name count total_ms algorithmic_flops algorithmic_bytes" lines. */

@@ -712,13 +712,7 @@ struct SkArgs {
 // instead of by LDS-DMA, whose pieces keep a wave's issue port for 60-180 cycles each.  It needs 40 staging registers: at the
 // 256-register budget of two workgroups per CU hipcc spills them, at 512 it parks the accumulators in AGPRs and copies them per
 // K tile: 415 us where the LDS-DMA kernel takes 170, profiles/r03_f32x3_sweep.log "g1256".)
-// RF (X3, knob 38, prepared and not yet timed): all fourteen operand fetches of a k step stand in front of its MFMAs behind a
-// scheduling fence.  Left alone hipcc sinks every W fragment's ds_read_b128 next to the MFMA that consumes it (M D W M D W ...:
-// 20 s_waitcnt per K tile, most MFMAs wait for an LDS round trip of their own); same arithmetic, bit-identical results.
-// RF = 2 (knob 38 = 2, prepared, untimed): BOTH k steps' fetches and splits first, then the K tile's 48 MFMAs in one run -- the
-// two-phase shape in which the two waves of a SIMD can alternate (one in its fetch / split / LDS-DMA phase while the other
-// owns the matrix pipe: MI355X_MICROARCH.md, "Two waves per SIMD").
-template <int BT, bool IL, bool X3, int MEAS = 0, int RF = 0>
+template <int BT, bool IL, bool X3, int MEAS = 0>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
   static_assert(!X3 || (BT == 128 && !IL), "the split-operand variant: 128-wide tiles, panel loads in one block");
   constexpr int BK = 32, PANEL = BT * BK, WPITCH = X3 ? 48 : BK, WPANEL = BT * WPITCH, STAGE = PANEL + WPANEL;  // floats
@@ -843,111 +837,6 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
     const float* Ws = lds + stage * STAGE + PANEL + (wn0 + lrow) * WPITCH;
     if constexpr (X3) {
       const int wsw = (lrow >> 2) & 3;
-      if constexpr (RF >= 2) {  // (3: the MFMA run at raised wave priority)
-        sbk::bf16x8 ah[2][TM], am[2][TM], al[2][TM], bh[2][TN], bm[2][TN], bl[2][TN];
-        float4 xr[2][TM][2];
-#pragma unroll
-        for (int gk = 0; gk < 2; ++gk) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            xr[gk][i][0] = *reinterpret_cast<const float4*>(As + i * 32 * BK + ((4 * gk + 2 * half) ^ sw) * 4);
-            xr[gk][i][1] = *reinterpret_cast<const float4*>(As + i * 32 * BK + ((4 * gk + 2 * half + 1) ^ sw) * 4);
-          }
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const float* wr = Ws + j * 32 * WPITCH + ((2 * gk + half) ^ wsw) * 4;
-            bh[gk][j] = *reinterpret_cast<const sbk::bf16x8*>(wr);
-            bm[gk][j] = *reinterpret_cast<const sbk::bf16x8*>(wr + 16);
-            bl[gk][j] = *reinterpret_cast<const sbk::bf16x8*>(wr + 32);
-          }
-        }
-        sbk::sched_fence();  // every fetch of the K tile is issued ...
-#pragma unroll
-        for (int gk = 0; gk < 2; ++gk)
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const float4 x0 = xr[gk][i][0], x1 = xr[gk][i][1];
-            const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-            unsigned h[4], m[4], l[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-              h[p] = sbk::bf16_pair(x[2 * p], x[2 * p + 1]);
-              const float r0 = x[2 * p] - __uint_as_float(h[p] << 16), r1 = x[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
-              m[p] = sbk::bf16_pair(r0, r1);
-              l[p] = sbk::bf16_pair(r0 - __uint_as_float(m[p] << 16), r1 - __uint_as_float(m[p] & 0xffff0000u));
-              sbk::pin(h[p]);  // (... and every piece exists before the first MFMA: the split is not sunk between them)
-              sbk::pin(m[p]);
-              sbk::pin(l[p]);
-            }
-            ah[gk][i] = sbk::bf16x8_from_words(h[0], h[1], h[2], h[3]);
-            am[gk][i] = sbk::bf16x8_from_words(m[0], m[1], m[2], m[3]);
-            al[gk][i] = sbk::bf16x8_from_words(l[0], l[1], l[2], l[3]);
-          }
-        sbk::sched_fence();
-        if constexpr (RF == 3) sbk::set_prio<1>();
-#pragma unroll
-        for (int gk = 0; gk < 2; ++gk)
-#pragma unroll
-          for (int t = 0; t < 6; ++t)  // the same partial products in the same order as the default path
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j) {
-                const sbk::bf16x8 b = (t == 1) ? bl[gk][j] : (t == 2 || t == 4) ? bm[gk][j] : bh[gk][j];
-                const sbk::bf16x8 a = (t == 0) ? al[gk][i] : (t == 2 || t == 3) ? am[gk][i] : ah[gk][i];
-                acc[i][j] = sbk::mfma_32x32x16_bf16(b, a, acc[i][j]);
-              }
-        if constexpr (RF == 3) sbk::set_prio<0>();
-        sbk::sched_fence();
-        return;
-      }
-      if constexpr (RF == 1) {
-#pragma unroll
-        for (int gk = 0; gk < 2; ++gk) {
-          sbk::bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
-          float4 xr[TM][2];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const float* wr = Ws + j * 32 * WPITCH + ((2 * gk + half) ^ wsw) * 4;
-            bh[j] = *reinterpret_cast<const sbk::bf16x8*>(wr);
-            bm[j] = *reinterpret_cast<const sbk::bf16x8*>(wr + 16);
-            bl[j] = *reinterpret_cast<const sbk::bf16x8*>(wr + 32);
-          }
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            xr[i][0] = *reinterpret_cast<const float4*>(As + i * 32 * BK + ((4 * gk + 2 * half) ^ sw) * 4);
-            xr[i][1] = *reinterpret_cast<const float4*>(As + i * 32 * BK + ((4 * gk + 2 * half + 1) ^ sw) * 4);
-          }
-          sbk::sched_fence();  // every fetch of the step is issued before its first MFMA
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const float x[8] = {xr[i][0].x, xr[i][0].y, xr[i][0].z, xr[i][0].w, xr[i][1].x, xr[i][1].y, xr[i][1].z, xr[i][1].w};
-            unsigned h[4], m[4], l[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-              h[p] = sbk::bf16_pair(x[2 * p], x[2 * p + 1]);
-              const float r0 = x[2 * p] - __uint_as_float(h[p] << 16), r1 = x[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
-              m[p] = sbk::bf16_pair(r0, r1);
-              l[p] = sbk::bf16_pair(r0 - __uint_as_float(m[p] << 16), r1 - __uint_as_float(m[p] & 0xffff0000u));
-            }
-            ah[i] = sbk::bf16x8_from_words(h[0], h[1], h[2], h[3]);
-            am[i] = sbk::bf16x8_from_words(m[0], m[1], m[2], m[3]);
-            al[i] = sbk::bf16x8_from_words(l[0], l[1], l[2], l[3]);
-          }
-#pragma unroll
-          for (int t = 0; t < 6; ++t)  // the same six partial products in the same order as below
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j) {
-                const sbk::bf16x8 b = (t == 1) ? bl[j] : (t == 2 || t == 4) ? bm[j] : bh[j];
-                const sbk::bf16x8 a = (t == 0) ? al[i] : (t == 2 || t == 3) ? am[i] : ah[i];
-                acc[i][j] = sbk::mfma_32x32x16_bf16(b, a, acc[i][j]);
-              }
-          sbk::sched_fence();  // (the next step's fetches stay behind this step's MFMAs: the registers are taken)
-        }
-        return;
-      }
 #pragma unroll
       for (int gk = 0; gk < 2; ++gk) {  // 16 k per step: lanes 0-31 supply k = 16 gk .. +7, lanes 32-63 the next eight
         sbk::bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
@@ -1247,250 +1136,6 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
     }
     kt = nkt;
     stage ^= 1;
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Prepared, NOT yet timed (knob 38 = 4): the split-operand contraction with its two co-resident four-wave teams fused into
-// ONE 512-thread workgroup whose barriers ENFORCE the alternation that two independent workgroups only reach by chance
-// (MI355X_MICROARCH.md, "Two waves per SIMD": one wave of a SIMD in its matrix-heavy segment while its partner is in the
-// LDS / DMA segment, separated by s_barrier).  Each team owns its own stream of whole 128 x 128 tiles, its own
-// accumulators and its own two LDS stages (2 x 2 x 40 KB = the CU's 160 KB, as today); per pair of phases a team does
-//   fetch phase:  LDS-DMA pieces of the K tile after next | 28 ds_read_b128 of the next K tile | its operand split
-//   barrier
-//   MFMA phase:   the 48 MFMAs of that K tile in one run | wait for its own pieces of the following K tile
-//   barrier
-// and the two teams run the pair in opposite order, so the matrix pipe of every SIMD always has exactly one wave feeding
-// it.  The panels get two phases of flight instead of one.  No stream-K tail here (a ticketed fix-up needs team-local
-// barriers): leftover tiles are whole tiles of the teams that draw them.  Same arithmetic per tile as the shipped
-// kernel: bit-identical results.
-struct X3DuoArgs {
-  GemmArgs g;  // g.W = the pre-split matrix
-  int tiles_n, tiles, KT;
-};
-
-__global__ void __launch_bounds__(512, 1) gemm_nt_x3duo_kernel(X3DuoArgs s) {
-  constexpr int BT = 128, BK = 32, PANEL = BT * BK, WPITCH = 48, WPANEL = BT * WPITCH, STAGE = PANEL + WPANEL;  // floats
-  constexpr int LI = 4, LIW = 6, TN = 4;
-  SBK_DYN_LDS(float, lds_all);  // [2 teams][2 stages][STAGE]
-  const float* const gA = s.g.A;
-  const float* const gW = s.g.W;
-  const float* const gbias = s.g.bias;
-  const float* const gR = s.g.R;
-  float* const gC = s.g.C;
-  const int lda = s.g.lda, ldr = s.g.ldr, ldc = s.g.ldc, M = s.g.M, N = s.g.N, act = s.g.act;
-  const float alpha = s.g.alpha;
-  const int32_t* const seq_len = s.g.seq_len;
-  const int rows_per_seq = s.g.rows_per_seq;
-  const int tiles_n = s.tiles_n, KT = s.KT;
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = sbk::uniform(tid >> 6);
-  const int team = wv >> 2, wave = wv & 3;  // (waves w and w + 4 share a SIMD: one of each team)
-  float* const lds = lds_all + team * 2 * STAGE;
-  const int wm0 = wave * 32;
-  const int lrow = lane & 31, half = lane >> 5, sw = (lrow >> 1) & 7, wsw = (lrow >> 2) & 3;
-  // this team's tiles: every W-th tile of the XCD's contiguous range (W teams per XCD)
-  const int W = (gridDim.x >> 3) * 2, x = blockIdx.x & 7, j = (blockIdx.x >> 3) * 2 + team;
-  const int t0 = (int)((long)s.tiles * x / 8), t1 = (int)((long)s.tiles * (x + 1) / 8);
-  const int ntile = sbk::uniform(t0 + j < t1 ? (t1 - t0 - j + W - 1) / W : 0);
-  const int U = ntile * KT;                                                   // this team's K tiles
-  const int jo = (blockIdx.x >> 3) * 2 + (team ^ 1);
-  const int Uo = (t0 + jo < t1 ? (t1 - t0 - jo + W - 1) / W : 0) * KT;        // the other team's
-  const int Umax = U > Uo ? U : Uo;
-
-  int arw[LI], asl[LI], wrw[LIW], wsl[LIW];
-#pragma unroll
-  for (int i = 0; i < LI; ++i) {
-    arw[i] = (wave * LI + i) * 8 + (lane >> 3);
-    asl[i] = ((lane & 7) ^ ((arw[i] >> 1) & 7)) * 4;
-  }
-#pragma unroll
-  for (int i = 0; i < LIW; ++i) {
-    const int q = (wave * LIW + i) * 64 + lane;
-    wrw[i] = q / 12;
-    const int pos = q - wrw[i] * 12;
-    wsl[i] = (pos >> 2) * 16 + (((pos & 3) ^ ((wrw[i] >> 2) & 3)) * 4);
-  }
-  const float* ap[LI];
-  const float* wp[LIW];
-  auto setup = [&](int tile) SBK_INLINE_LAMBDA {
-    const int m0 = (tile / tiles_n) * BT, n0 = (tile % tiles_n) * BT;
-#pragma unroll
-    for (int i = 0; i < LI; ++i) ap[i] = gA + (size_t)min(m0 + arw[i], M - 1) * lda + asl[i];
-#pragma unroll
-    for (int i = 0; i < LIW; ++i) wp[i] = gW + (size_t)min(n0 + wrw[i], N - 1) * (KT * WPITCH) + wsl[i];
-  };
-  int i_ord = 0, i_kt = 0, issued = 0;  // the LDS-DMA cursor: K tile `issued` of this team goes into stage issued & 1
-  auto issue_next = [&]() SBK_INLINE_LAMBDA {
-    float* base = lds + (issued & 1) * STAGE + (wave * LI) * 256;
-#pragma unroll
-    for (int i = 0; i < LI; ++i) sbk::glds16(ap[i] + i_kt * BK, base + i * 256);
-    float* wbase = lds + (issued & 1) * STAGE + PANEL + (wave * LIW) * 256;
-#pragma unroll
-    for (int i = 0; i < LIW; ++i) sbk::glds16(wp[i] + i_kt * WPITCH, wbase + i * 256);
-    ++issued;
-    if (++i_kt == KT) {
-      i_kt = 0;
-      if (++i_ord < ntile) setup(t0 + j + i_ord * W);
-    }
-  };
-
-  f32x16 acc[TN];
-  auto zero = [&]() SBK_INLINE_LAMBDA {
-#pragma unroll
-    for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[jj][r] = 0.0f;
-  };
-  sbk::bf16x8 ah, am, al, bh[TN], bm[TN], bl[TN];  // the operands of one 16-deep k step (a whole K tile's would not fit 256 registers)
-  auto fetch_split = [&](int stage, int gk) SBK_INLINE_LAMBDA {
-    const float* As = lds + stage * STAGE + (wm0 + lrow) * BK;
-    const float* Ws = lds + stage * STAGE + PANEL + lrow * WPITCH + ((2 * gk + half) ^ wsw) * 4;
-    const float4 x0 = *reinterpret_cast<const float4*>(As + ((4 * gk + 2 * half) ^ sw) * 4);
-    const float4 x1 = *reinterpret_cast<const float4*>(As + ((4 * gk + 2 * half + 1) ^ sw) * 4);
-#pragma unroll
-    for (int jj = 0; jj < TN; ++jj) {
-      bh[jj] = *reinterpret_cast<const sbk::bf16x8*>(Ws + jj * 32 * WPITCH);
-      bm[jj] = *reinterpret_cast<const sbk::bf16x8*>(Ws + jj * 32 * WPITCH + 16);
-      bl[jj] = *reinterpret_cast<const sbk::bf16x8*>(Ws + jj * 32 * WPITCH + 32);
-    }
-    const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {  // x = hi + mid + lo exactly (see gemm_nt_sk_kernel)
-      h[p] = sbk::bf16_pair(xv[2 * p], xv[2 * p + 1]);
-      const float r0 = xv[2 * p] - __uint_as_float(h[p] << 16), r1 = xv[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
-      m[p] = sbk::bf16_pair(r0, r1);
-      l[p] = sbk::bf16_pair(r0 - __uint_as_float(m[p] << 16), r1 - __uint_as_float(m[p] & 0xffff0000u));
-      sbk::pin(h[p]);  // (the split belongs to THIS phase, not to the MFMA phase behind the barrier)
-      sbk::pin(m[p]);
-      sbk::pin(l[p]);
-    }
-    ah = sbk::bf16x8_from_words(h[0], h[1], h[2], h[3]);
-    am = sbk::bf16x8_from_words(m[0], m[1], m[2], m[3]);
-    al = sbk::bf16x8_from_words(l[0], l[1], l[2], l[3]);
-  };
-  auto mfma_run = [&]() SBK_INLINE_LAMBDA {  // the same six partial products in the same order as the shipped kernel
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-      for (int jj = 0; jj < TN; ++jj) {
-        const sbk::bf16x8 b = (t == 1) ? bl[jj] : (t == 2 || t == 4) ? bm[jj] : bh[jj];
-        const sbk::bf16x8 a = (t == 0) ? al : (t == 2 || t == 3) ? am : ah;
-        acc[jj] = sbk::mfma_32x32x16_bf16(b, a, acc[jj]);
-      }
-  };
-  auto epilogue = [&](int tile) SBK_INLINE_LAMBDA {  // transposed accumulators: lane = row, register quads = four columns
-    const int m0 = (tile / tiles_n) * BT, n0 = (tile % tiles_n) * BT;
-    const bool interior = m0 + BT <= M && n0 + BT <= N;
-    const int row = m0 + wm0 + lrow, rowc = min(row, M - 1);
-    const bool row_ok = interior || row < M;
-    const bool masked = seq_len && (rowc % rows_per_seq) >= seq_len[rowc / rows_per_seq];
-    const float ra = masked ? 0.0f : alpha;
-    float* crow = gC + (size_t)rowc * ldc;
-    const float* rrow = gR ? gR + (size_t)rowc * ldr : nullptr;
-#pragma unroll
-    for (int jj = 0; jj < TN; ++jj) {
-      float4 bv[4], rv[4];
-      bool ok[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = n0 + jj * 32 + 8 * g + 4 * half;
-        ok[g] = row_ok && (interior || col < N);
-        bv[g] = (gbias && ok[g]) ? *reinterpret_cast<const float4*>(gbias + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        rv[g] = (rrow && ok[g]) ? *reinterpret_cast<const float4*>(rrow + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      }
-      float v[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        v[4 * g] = acc[jj][4 * g] + bv[g].x;
-        v[4 * g + 1] = acc[jj][4 * g + 1] + bv[g].y;
-        v[4 * g + 2] = acc[jj][4 * g + 2] + bv[g].z;
-        v[4 * g + 3] = acc[jj][4 * g + 3] + bv[g].w;
-      }
-      switch (act) {  // uniform
-        case SBK_ACT_SWISH:
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
-          break;
-        case SBK_ACT_GELU:
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752440f));
-          break;
-        case SBK_ACT_RELU:
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
-          break;
-        case SBK_ACT_LEAKY_RELU:
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.01f * v[r];
-          break;
-        default: break;
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = n0 + jj * 32 + 8 * g + 4 * half;
-        const float4 o = make_float4(masked ? rv[g].x : v[4 * g] * ra + rv[g].x, masked ? rv[g].y : v[4 * g + 1] * ra + rv[g].y,
-                                     masked ? rv[g].z : v[4 * g + 2] * ra + rv[g].z, masked ? rv[g].w : v[4 * g + 3] * ra + rv[g].w);
-        if (ok[g]) *reinterpret_cast<float4*>(crow + col) = o;
-      }
-    }
-  };
-
-  // ---- prologue: this team's first two K tiles in flight, the first one landed and fetched
-  if (U > 0) {
-    setup(t0 + j);
-    issue_next();
-    if (U > 1) issue_next();
-  }
-  zero();
-  if (U > 1) {
-    sbk::vm_wait<LI + LIW>();
-  } else {
-    sbk::vm_drain();
-  }
-  __syncthreads();
-  if (U > 0 && team == 0) fetch_split(0, 0);
-  // Phases, one per 16-deep k step.  Team 0 multiplies in the even phases and fetches in the odd ones, team 1 the other way
-  // round; a team's k step v (K tile v / 2, half v % 2) is multiplied in phase 2v + team and fetched one phase earlier (k
-  // step 0 of team 0: in the prologue).  The pieces of K tile u + 1 are issued in the fetch phase of K tile u's first k
-  // step -- four phases before they are read -- and waited for behind the MFMAs of K tile u's second one.
-  // Each team runs its own straight-line loop (a common loop that branches on the team makes hipcc copy the whole operand set
-  // between the two paths in every phase).  Both loops pass the same number of barriers; k steps past a team's last one
-  // multiply stale operands into accumulators nobody stores -- in that team's own slot of the matrix pipe.
-  int c_kt = 0, c_ord = 0;
-  const int V = 2 * U, Vm = 4 * Umax / 2;  // k steps of this team / of the longer team
-  auto phase_mfma = [&](int v) SBK_INLINE_LAMBDA {
-    mfma_run();
-    if (v & 1) {  // the K tile is complete
-      if (v < V && ++c_kt == KT) {
-        epilogue(t0 + j + c_ord * W);
-        zero();
-        c_kt = 0;
-        ++c_ord;
-      }
-      sbk::vm_drain();  // this wave's pieces of the next K tile (and the epilogue's traffic) have landed
-    }
-  };
-  auto phase_fetch = [&](int v) SBK_INLINE_LAMBDA {
-    const int u = v >> 1;
-    if (!(v & 1) && u + 1 < U && issued == u + 1) issue_next();  // K tile u + 1 into the stage K tile u - 1 was fetched from
-    fetch_split(u & 1, v & 1);
-  };
-  if (team == 0) {
-    for (int v = 0; v < Vm; ++v) {
-      __syncthreads();  // (phase 2v) the other team's panels have landed; everybody is done with the stage before
-      phase_mfma(v);
-      __syncthreads();  // (phase 2v + 1)
-      phase_fetch(v + 1);
-    }
-  } else {
-    for (int v = 0; v < Vm; ++v) {
-      __syncthreads();
-      phase_fetch(v);
-      __syncthreads();
-      phase_mfma(v);
-    }
   }
 }
 
@@ -2079,7 +1724,7 @@ int g_gemm_tile = 0;   // tuning knob (key 6) for the large-M path: 0 = 128x128,
                        // 2 = 128x256 (8 waves), 3 = 256x128 (4 waves of 128x64), 4 = 128x128 with 64-deep K tiles
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
-int* tile_tickets(hipStream_t st, long tiles);  // this stream's zeroed arrival counters (nullptr: none yet and the stream is capturing, or too many tiles)
+int* tile_tickets(hipStream_t st, long tiles);  // this stream's zeroed arrival counters (nullptr: no workspace registered for the stream, or too many tiles)
 int sk_route(int M, int N, int K, int* bt = nullptr);  // workgroups (and tile edge) of the persistent kernel for this shape (0: tile-grid / register-operand paths)
 // Internal C++ entry shared with the fused pipelines (decoder step, encoder).
 // Skinny path: M <= 512 rows, K a multiple of 64, 16-byte aligned rows.  `ws` (optional) holds the
@@ -2182,7 +1827,7 @@ int gemm_ln_nt(const float* A, int lda, const float* Wf, int ldw, const float* b
   return launch_status("gemm_skinny_ln");
 }
 
-// ---- stream-K launch: per-stream workspace (slabs + tile tickets), allocated on first use and kept
+// ---- stream-K launch: per-stream workspace (slabs + tile tickets), registered by the caller (sbk_stream_workspace_set)
 int g_sk_mode = 1;        // tuning knob (key 18): 0 = tile-grid kernels only, 1 = routed by shape (sk_route), 2 = always (tests), 3 = always from 8 tiles on (A/B)
 int g_sk_grid = 0;        // tuning knob (key 19): workgroups of a stream-K launch (0 = two per CU)
 int g_sk_noload = 0;      // measurement knob (key 22)
@@ -2195,7 +1840,6 @@ int g_sk64_units = 16;    // tuning knob (key 26): K units (64x64x32) per workgr
 int g_bf16a_stages = 2;   // tuning knob (key 27): LDS stages of gemm_nt_bf16dma_kernel (2, 3 or 4)
 int g_bf16a_grid = 0;     // tuning knob (key 28): its workgroups (0 = as many as fit: two per CU with 2 stages, one with 3 / 4)
 int g_bf16a_mode = 0;     // measurement knob (key 29)
-int g_x3_reads_first = 0;  // tuning knob (key 38; prepared, untimed): 1 = a k step's operand fetches fenced in front of its MFMAs; 2 = the whole K tile's fetches and splits first, then its 48 MFMAs; 3 = 2 with the MFMA run at wave priority 1; 4 = the fused-teams kernel (gemm_nt_x3duo_kernel)
 int g_x3_grid = 0;        // tuning knob (key 31): workgroups of the split-operand kernel (0 = two per CU from one tile per CU on)
 namespace {
 constexpr int kSkMaxGrid = 512, kSkMaxGrid64 = 1024, kSkMaxTiles = 1 << 16;  // (both grids fit the same slab area)
@@ -2241,30 +1885,27 @@ struct SkWorkspace {
   float* slabs;
   int* cnt;
 };
+// Stream workspaces are CALLER-OWNED device memory (sbk_stream_workspace_set, include/sbk.h): the library allocates
+// nothing.  One per (device, stream): launches of one stream are ordered, so they can share the slabs and the tickets.
 std::mutex g_sk_mu;
-std::map<hipStream_t, SkWorkspace> g_sk_ws;
-int g_sk_cus = 0;
+std::map<std::pair<int, hipStream_t>, SkWorkspace> g_sk_ws;
+int g_sk_cus[64] = {};
 
-// the stream's workspace; false when it does not exist yet and cannot be created now (the stream is capturing)
+int cur_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev;
+}
+
+constexpr size_t kSkSlabBytes = (size_t)2 * kSkMaxGrid * 128 * 128 * sizeof(float);
+constexpr size_t kSkTicketBytes = (size_t)kSkMaxTiles * sizeof(int);
+
+// the stream's workspace; false when the caller has registered none for it (the tile-grid kernels run instead)
 bool sk_workspace(hipStream_t st, SkWorkspace* out) {
   std::lock_guard<std::mutex> lk(g_sk_mu);
-  auto it = g_sk_ws.find(st);
-  if (it != g_sk_ws.end()) {
-    *out = it->second;
-    return true;
-  }
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
-  SkWorkspace w{nullptr, nullptr};
-  if (hipMalloc(reinterpret_cast<void**>(&w.slabs), (size_t)2 * kSkMaxGrid * 128 * 128 * sizeof(float)) != hipSuccess) return false;
-  if (hipMalloc(reinterpret_cast<void**>(&w.cnt), (size_t)kSkMaxTiles * sizeof(int)) != hipSuccess) {
-    (void)hipFree(w.slabs);
-    return false;
-  }
-  // tickets start at zero (ordered before the first launch on this stream) and every launch leaves them at zero
-  if (hipMemsetAsync(w.cnt, 0, (size_t)kSkMaxTiles * sizeof(int), st) != hipSuccess) return false;
-  g_sk_ws[st] = w;
-  *out = w;
+  auto it = g_sk_ws.find(std::make_pair(cur_device(), st));
+  if (it == g_sk_ws.end()) return false;
+  *out = it->second;
   return true;
 }
 
@@ -2277,13 +1918,13 @@ int* tile_tickets(hipStream_t st, long tiles) {
 namespace {
 
 int sk_cus() {
-  if (!g_sk_cus) {
-    int dev = 0, cus = 0;
-    (void)hipGetDevice(&dev);
+  const int dev = cur_device() & 63;
+  if (!g_sk_cus[dev]) {
+    int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    g_sk_cus = cus > 0 ? cus : 256;
+    g_sk_cus[dev] = cus > 0 ? cus : 256;
   }
-  return g_sk_cus;
+  return g_sk_cus[dev];
 }
 
 int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st, bool x3 = false) {
@@ -2313,34 +1954,7 @@ int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st, bool x3 = false)
     ProfScope prof("gemm_nt_f32x3", flops, bytes + 2.0 * (double)g.N * g.K, st);
     const int meas = (g_sk_noload >> 1) & 3;
     s.noload = g_sk_noload & 9;
-    if (meas == 0 && g_x3_reads_first == 4 && G >= 16 && (G == 2 * sk_cus() || g_x3_grid > 0)) {  // the fused-teams kernel: G / 2 workgroups of 512 threads (one per CU), whole tiles
-      X3DuoArgs d;
-      d.g = g;
-      d.tiles_n = s.tiles_n;
-      d.tiles = s.tiles;
-      d.KT = s.KT;
-      static bool once_duo = false;
-      if (!once_duo) {
-        (void)SBK_ALLOW_DYN_LDS(gemm_nt_x3duo_kernel, 2 * lds);
-        once_duo = true;
-      }
-      SBK_LAUNCH(gemm_nt_x3duo_kernel, dim3((unsigned)(G / 16) * 8), dim3(512), 2 * lds, st, d);
-    } else if (meas == 0 && g_x3_reads_first) {
-      static bool once_rf = false;
-      if (!once_rf) {
-        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 0, 1>), lds);
-        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 0, 2>), lds);
-        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 0, 3>), lds);
-        once_rf = true;
-      }
-      if (g_x3_reads_first == 3) {
-        SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 0, 3>), dim3((unsigned)G), dim3(256), lds, st, s);
-      } else if (g_x3_reads_first == 2) {
-        SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 0, 2>), dim3((unsigned)G), dim3(256), lds, st, s);
-      } else {
-        SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 0, 1>), dim3((unsigned)G), dim3(256), lds, st, s);
-      }
-    } else if (meas == 0) {
+    if (meas == 0) {
       SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true>), dim3((unsigned)G), dim3(256), lds, st, s);
     } else {
       static bool once_meas = false;
@@ -2410,7 +2024,7 @@ int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
     const int G = sk_route(M, N, K, &bt);
     if (G > 0) {
       const int rc = launch_sk(g, G, bt, st);
-      if (rc != -1) return rc;  // -1: no workspace for this stream (first use inside a graph capture)
+      if (rc != -1) return rc;  // -1: the caller registered no workspace for this stream
     }
   }
   const bool big = tiles128 >= 768 || (g_gemm_tile & 16);  // +16: take the variant at any size (tests)
@@ -2423,6 +2037,29 @@ int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
   return launch_gemm<32, 64, 32, 32, 32>(g, vec, st);
 }
 }  // namespace sbk
+
+extern "C" size_t sbk_stream_workspace_bytes(void) { return sbk::kSkSlabBytes + sbk::kSkTicketBytes; }
+
+extern "C" int sbk_stream_workspace_set(sbk_stream_t stream, void* workspace, size_t workspace_bytes) {
+  SBK_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0, "stream workspace: null or not 256-byte aligned");
+  SBK_REQUIRE(workspace_bytes >= sbk_stream_workspace_bytes(), "stream workspace: %zu bytes given, %zu needed", workspace_bytes,
+              sbk_stream_workspace_bytes());
+  hipStream_t st = sbk::as_stream(stream);
+  sbk::SkWorkspace w{reinterpret_cast<float*>(workspace),
+                     reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + sbk::kSkSlabBytes)};
+  // tickets start at zero (ordered before the first launch on this stream); every launch leaves them at zero
+  const hipError_t e = hipMemsetAsync(w.cnt, 0, sbk::kSkTicketBytes, st);
+  if (e != hipSuccess) return sbk::fail((int)e, "stream workspace: memset: %s", hipGetErrorString(e));
+  std::lock_guard<std::mutex> lk(sbk::g_sk_mu);
+  sbk::g_sk_ws[std::make_pair(sbk::cur_device(), st)] = w;
+  return 0;
+}
+
+extern "C" int sbk_stream_workspace_release(sbk_stream_t stream) {
+  std::lock_guard<std::mutex> lk(sbk::g_sk_mu);
+  sbk::g_sk_ws.erase(std::make_pair(sbk::cur_device(), sbk::as_stream(stream)));
+  return 0;
+}
 
 extern "C" int sbk_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
                                const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
@@ -2521,7 +2158,6 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 28) sbk::g_bf16a_grid = value;
   if (key == 29) sbk::g_bf16a_mode = value;
   if (key == 31) sbk::g_x3_grid = value;
-  if (key == 38) sbk::g_x3_reads_first = value;
   if (key == 36) sbk::g_splitk_fused = value;
   if (key == 37) sbk::g_cross_fused_merge = value;
   if (key == 34) sbk::g_x3_route_rows = value;
@@ -2554,7 +2190,7 @@ extern "C" int sbk_gemm_nt_f32x3(const float* A, int lda, const uint16_t* W3, co
   SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm_f32x3: seq_len given without rows_per_seq");
   const int rc = sbk::gemm_nt_x3(A, lda, W3, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq,
                                  sbk::as_stream(stream));
-  if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_f32x3: no workspace for this stream (first use inside a graph capture) or too many tiles");
+  if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_f32x3: no workspace registered for this stream (sbk_stream_workspace_set) or too many tiles");
   return rc;
 }
 

@@ -74,6 +74,9 @@ def _declare(lib):
     sig = {
         "sbk_abi_version": ([], c_int),
         "sbk_last_error": ([], c_char_p),
+        "sbk_stream_workspace_bytes": ([], ctypes.c_size_t),
+        "sbk_stream_workspace_set": ([p, p, ctypes.c_size_t], c_int),
+        "sbk_stream_workspace_release": ([p], c_int),
         "sbk_prof_enable": ([i], None),
         "sbk_prof_reset": ([], None),
         "sbk_prof_report": ([ctypes.c_char_p, ctypes.c_size_t], ctypes.c_size_t),
@@ -152,7 +155,7 @@ def load(path: Optional[str] = None):
         )
     lib = ctypes.CDLL(path)
     EXPORTS = tuple(_declare(lib).keys())
-    if lib.sbk_abi_version() != 6:
+    if lib.sbk_abi_version() != 7:
         raise SbkError(f"ABI version mismatch: {lib.sbk_abi_version()}")
     _lib = lib
     return lib
@@ -180,9 +183,39 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+# The persistent / stream-K kernels need slabs and arrival tickets per stream; the library allocates nothing (include/sbk.h,
+# "stream workspace"): the binding registers ONE torch-allocated workspace per (library, device, stream) the first time an
+# op is issued on that stream, and keeps it for the life of the process (torch's streams come from a fixed pool and are
+# never destroyed).  Every op fetches its stream through _stream(), so no call can reach a kernel without one -- the same
+# kernels run on every stream, and a worker stream's first launch allocates nothing inside the library.
+_STREAM_WS = {}
+_STREAM_WS_LOCK = threading.Lock()
+
+
+def _register_workspace(key, device, handle):
+    lib = load()
+    with _STREAM_WS_LOCK:
+        if key in _STREAM_WS:
+            return
+        nbytes = lib.sbk_stream_workspace_bytes()
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        off = (-ws.data_ptr()) % 256
+        _chk(lib.sbk_stream_workspace_set(c_void_p(handle) if handle is not None else None, c_void_p(ws.data_ptr() + off), nbytes),
+             "sbk_stream_workspace_set")
+        _STREAM_WS[key] = ws
+
+
 def _stream(t: torch.Tensor):
+    lib = load()
     if t.is_cuda:
-        return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        h = torch.cuda.current_stream(t.device).cuda_stream
+        key = (id(lib), t.device.index, h)
+        if key not in _STREAM_WS:
+            _register_workspace(key, t.device, h)
+        return c_void_p(h)
+    key = (id(lib), "host", 0)  # (host tensors only reach a kernel under the test emulator: its one "stream" is NULL)
+    if key not in _STREAM_WS:
+        _register_workspace(key, t.device, None)
     return None
 
 

@@ -350,13 +350,6 @@ if __name__ == "__main__":
                 t = ev_time(lambda: nat.gemm_nt(a, w))
                 line += f" grid {grid or 'auto'}: {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s |"
             nat.load().sbk_prof_set_knob(31, 0)
-            for variant, tag in ((1, "k step's fetches first"), (2, "K tile's fetches + splits first, 48 MFMAs in one run"),
-                                 (3, "as 2, MFMA run at wave priority 1"),
-                                 (4, "fused teams: 512-thread workgroups, barrier-enforced alternation, whole tiles")):
-                nat.load().sbk_prof_set_knob(38, variant)  # prepared variants of the loop's issue order
-                t = ev_time(lambda: nat.gemm_nt(a, w))
-                nat.load().sbk_prof_set_knob(38, 0)
-                line += f" knob 38 = {variant} ({tag}): {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s |"
             if "--x3-zero" in sys.argv:  # DVFS probe: the same launches on zero-filled operands (no toggling in the multipliers)
                 az, wz = torch.zeros_like(a), torch.zeros_like(w)
                 for mode in (0, 3):
