@@ -56,7 +56,7 @@ def assign_batches(costs: Sequence[float], world: int) -> List[List[int]]:
     return out
 
 
-def pad_batch(wavs: Sequence[torch.Tensor], idx: Sequence[int], out: Optional[torch.Tensor] = None):
+def pad_batch(wavs: Sequence[torch.Tensor], idx: Sequence[int], out: Optional[torch.Tensor] = None, tails_only: bool = False):
     """batch_pad_right (utils/data_utils.py:459-519): zero right-padding, relative lengths.  Keeps the
     waveforms' dtype (float32 or int16 PCM); ``out``: optional preallocated [len(idx) * n_max] slab."""
     n = max(wavs[i].numel() for i in idx)
@@ -65,9 +65,13 @@ def pad_batch(wavs: Sequence[torch.Tensor], idx: Sequence[int], out: Optional[to
         out = torch.zeros(len(idx), n, dtype=dtype)
     else:
         out = out.view(len(idx), n)
-        out.zero_()
+        if not tails_only:
+            out.zero_()
     for r, i in enumerate(idx):
-        out[r, : wavs[i].numel()] = wavs[i]
+        m = wavs[i].numel()
+        out[r, :m] = wavs[i]
+        if tails_only and m < n:
+            out[r, m:] = 0  # (every byte of the slab is written exactly once)
     return out, torch.tensor([wavs[i].numel() / n for i in idx], dtype=torch.float32)
 
 
@@ -89,51 +93,102 @@ class ShardedTranscriber:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._copy_stream = None
         self.last_plan = None  # rank 0: {"batches": ..., "owner": ..., "bytes_sent": ...} of the last scatter
+        self._staging = None   # rank 0: the batches distribute() has announced and _stage_all() has not yet produced
 
     # -- scatter -----------------------------------------------------------------
-    def _stage(self, wavs, batches, which):
-        """One rank's batches as ONE host slab (pinned when the target is a GPU: asynchronous H2D) + metadata."""
-        dtype = wavs[batches[which[0]][0]].dtype if which else torch.float32
-        sizes = [len(batches[b]) * max(wavs[i].numel() for i in batches[b]) for b in which]
-        slab = torch.empty(sum(sizes), dtype=dtype, pin_memory=self.device.type == "cuda")
-        meta, off = [], 0
-        for b, cnt in zip(which, sizes):
-            x, lens = pad_batch(wavs, batches[b], out=slab[off: off + cnt])
-            meta.append((batches[b], tuple(x.shape), lens.tolist()))
-            off += cnt
-        return slab, meta
-
     def plan(self, wavs: Optional[Sequence[torch.Tensor]]):
-        """Rank 0 (host work only): sort by duration, bucket, assign longest-processing-time-first and pad every
-        rank's batches into one pinned host slab.  Other ranks pass None and get None."""
+        """Rank 0, metadata only (milliseconds): sort by duration, bucket, assign longest-processing-time-first, fix
+        the order every rank runs its batches in.  The padding of the batches into pinned host memory is NOT done here:
+        it is streamed batch by batch behind the first batches' compute (``distribute`` / ``run_local``).  Other ranks
+        pass None and get None."""
         if self.rank != 0:
             return None
         n = [w.numel() for w in wavs]
         batches = plan_batches(n, self.max_utts, self.max_padded)
         owner = assign_batches([batch_cost(n, b) for b in batches], self.world)
         dtype = wavs[0].dtype if len(wavs) else torch.float32
-        slabs, metas = [], []
-        def padded(b):
-            return len(batches[b]) * max(n[i] for i in batches[b])
-
+        longest = [max(n[i] for i in b) for b in batches]
+        metas = []
         for r in range(self.world):
-            owner[r].sort(key=lambda b: (-padded(b), b))  # the order the rank's workers take them in (largest first)
-            slab, meta = self._stage(wavs, batches, owner[r])
-            slabs.append(slab)
-            metas.append((str(dtype), slab.numel(), meta))
-        self.last_plan = {"batches": batches, "owner": owner,
-                          "bytes_sent": sum(s.numel() * s.element_size() for s in slabs[1:])}
-        return {"slabs": slabs, "metas": metas}
+            owner[r].sort(key=lambda b: (-len(batches[b]) * longest[b], b))  # the order the rank's workers take them in (largest first)
+            meta = [(batches[b], (len(batches[b]), longest[b]), [n[i] / longest[b] for i in batches[b]]) for b in owner[r]]
+            metas.append((str(dtype), sum(m[1][0] * m[1][1] for m in meta), meta))
+        itemsize = torch.empty(0, dtype=dtype).element_size()
+        self.last_plan = {"batches": batches, "owner": owner, "bytes_sent": sum(m[1] for m in metas[1:]) * itemsize}
+        return {"wavs": wavs, "metas": metas, "dtype": dtype}
+
+    def _pinned_slot(self, k, count, dtype):
+        """Slot k of the ring of pinned staging buffers (allocated once per transcriber: pinning memory is a driver
+        round trip per call); waits until the copy that last read the slot has finished."""
+        ring = getattr(self, "_ring", None)
+        if ring is None or ring["dtype"] != dtype or ring["count"] < count:
+            for ev in (ring["events"] if ring else []):
+                if ev is not None:
+                    ev.synchronize()
+            ring = {"dtype": dtype, "count": count, "events": [None] * 8,
+                    "bufs": [torch.empty(count, dtype=dtype, pin_memory=True) for _ in range(8)]}
+            self._ring = ring
+        k %= len(ring["bufs"])
+        if ring["events"][k] is not None:
+            ring["events"][k].synchronize()
+        return k, ring["bufs"][k][:count]
+
+    def _stage_all(self):
+        """Rank 0: pad -> (pinned ring ->) device -> (peers: exact-size point-to-point send), batch by batch, round-robin
+        over the ranks in the order the ranks run their batches.  Runs on the calling thread (every process-group call
+        of a rank stays on one thread) WHILE this rank's workers already transcribe the batches that have landed."""
+        todo, self._staging = getattr(self, "_staging", None), None
+        if not todo:
+            return
+        try:
+            self._stage(todo)
+        except BaseException as e:  # a worker blocked in ready() must not wait for a batch that will never come
+            for _, _, _, own in todo["ops"]:
+                if own is not None and not own["landed"].is_set():
+                    own["error"] = e
+                    own["landed"].set()
+            raise
+
+    def _stage(self, todo):
+        cuda = self.device.type == "cuda"
+        wavs, copy_stream = todo["wavs"], todo["copy_stream"]
+        for k, (r, ids, shape, own) in enumerate(todo["ops"]):
+            cnt = shape[0] * shape[1]
+            if cuda:
+                slot, host = self._pinned_slot(k, todo["max_count"], todo["dtype"])
+                pad_batch(wavs, ids, out=host[:cnt], tails_only=True)
+                with torch.cuda.stream(copy_stream):
+                    if r == 0:
+                        own["buf"].view(-1).copy_(host[:cnt], non_blocking=True)
+                    else:
+                        chunk = host[:cnt].to(self.device, non_blocking=True)
+                        self._pending.append((dist.isend(chunk, r, group=self.group), chunk))
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                self._ring["events"][slot] = ev
+                if r == 0:
+                    own["ev"] = ev
+            else:
+                x, _ = pad_batch(wavs, ids)
+                if r == 0:
+                    own["buf"].copy_(x)
+                else:
+                    self._pending.append((dist.isend(x, r, group=self.group), x))
+            if r == 0:
+                own["landed"].set()
 
     def distribute(self, plan):
         """The scatter proper, streamed batch by batch.  Every rank returns its local list of (global utterance ids,
         padded batch on device [B,N] in the input dtype, relative lengths [B], ready) where ``ready()`` -- called
         on the stream (and host thread) that is about to read the batch -- orders that stream after the batch's
-        arrival.  Rank 0 walks the batches round-robin over the ranks in the order the ranks will run them: one
-        host-to-device copy per batch on a copy stream, followed (for a peer's batch) by an exact-size point-to-point
-        send over that peer's xGMI link (RCCL; gloo in the CPU tests).  Nobody waits for the whole job: a rank
-        starts transcribing when its first batch has landed, and rank 0's PCIe traffic overlaps everyone's compute.
-        The per-rank metadata (pickled, small) travels first."""
+        arrival.  On rank 0 nothing has been staged when this returns: ``run_local`` starts the workers and THEN pads /
+        copies / sends the batches one by one (``_stage_all``: round-robin over the ranks in the order the ranks will
+        run them; a peer's batch is an exact-size point-to-point send over that peer's xGMI link -- RCCL; gloo in the CPU
+        tests), so nobody waits for the whole job: a rank starts transcribing when its first batch has landed, and the
+        host's padding and rank 0's PCIe traffic overlap everyone's compute.  The per-rank metadata (pickled, small)
+        travels first."""
+        import threading
+
         cuda = self.device.type == "cuda"
         if self.world == 1:
             dtype_name, count, my_meta = plan["metas"][0]
@@ -152,40 +207,39 @@ class ShardedTranscriber:
             if cuda and getattr(self, "_copy_stream", None) is None:
                 self._copy_stream = torch.cuda.Stream(self.device)  # ONE copy stream per transcriber (not per call)
             copy_stream = self._copy_stream if cuda else None
-            cursors = [0] * self.world
+            if cuda:  # (the batch buffers below come from the current stream's pool)
+                copy_stream.wait_stream(torch.cuda.current_stream(self.device))
             metas = [m[2] for m in plan["metas"]]
             order = list(range(1, self.world)) + [0]  # the peers' batches go out before rank 0 stages its own
-            for j in range(max(len(m) for m in metas)):
+            ops = []
+            for j in range(max([len(m) for m in metas] + [0])):
                 for r in order:
                     if j >= len(metas[r]):
                         continue
                     ids, shape, lens = metas[r][j]
-                    cnt = shape[0] * shape[1]
-                    host = plan["slabs"][r][cursors[r]: cursors[r] + cnt]
-                    cursors[r] += cnt
-                    if cuda:
-                        with torch.cuda.stream(copy_stream):
-                            chunk = host.to(self.device, non_blocking=True)
-                            if r != 0:
-                                self._pending.append((dist.isend(chunk, r, group=self.group), chunk))
-                            else:
-                                ev = torch.cuda.Event()
-                                ev.record(copy_stream)
-                    else:
-                        chunk = host
-                        if r != 0:
-                            self._pending.append((dist.isend(chunk, r, group=self.group), chunk))
+                    own = None
                     if r == 0:
-                        ready = None
+                        buf = torch.empty(shape, dtype=dtype, device=self.device)
                         if cuda:
-                            def ready(e=ev, c=chunk):
-                                # the consumer's stream waits for the copy AND is recorded as a user of the block, so
-                                # the caching allocator cannot hand it to a later copy while kernels still read it
+                            buf.record_stream(copy_stream)
+                        own = {"buf": buf, "ev": None, "landed": threading.Event()}
+
+                        def ready(o=own):
+                            # the batch is staged by _stage_all on another thread of control: wait for the copy to have
+                            # been ENQUEUED (host), then order the consumer's stream after it and record the stream as
+                            # a user of the block (the caching allocator must not hand it out while kernels read it)
+                            o["landed"].wait()
+                            if o.get("error") is not None:
+                                raise RuntimeError("the batch was never staged") from o["error"]
+                            if o["ev"] is not None:
                                 cur = torch.cuda.current_stream()
-                                cur.wait_event(e)
-                                c.record_stream(cur)
-                        local.append((ids, chunk.view(shape), torch.tensor(lens, dtype=torch.float32, device=self.device),
-                                      ready))
+                                cur.wait_event(o["ev"])
+                                o["buf"].record_stream(cur)
+
+                        local.append((ids, buf, torch.tensor(lens, dtype=torch.float32, device=self.device), ready))
+                    ops.append((r, ids, shape, own))
+            self._staging = {"ops": ops, "wavs": plan["wavs"], "dtype": dtype, "copy_stream": copy_stream,
+                             "max_count": max([o[2][0] * o[2][1] for o in ops] + [1])}
         else:
             for ids, shape, lens in my_meta:
                 buf = torch.empty(shape, dtype=dtype, device=self.device)
@@ -208,11 +262,17 @@ class ShardedTranscriber:
     def run_local(self, local):
         out = []
         if self.concurrent is not None and len(local) > 1:
-            hyps_per_batch = self.concurrent.transcribe_batches([(t[1], t[2]) for t in local], prepare=self.prepare,
-                                                                ready=[t[3] if len(t) > 3 else None for t in local])
+            # the workers start on whatever has landed; THIS thread then stages the rest of the job (rank 0) behind them
+            running = self.concurrent.start([(t[1], t[2]) for t in local], prepare=self.prepare,
+                                            ready=[t[3] if len(t) > 3 else None for t in local])
+            try:
+                self._stage_all()
+            finally:
+                hyps_per_batch = self.concurrent.finish(running)
             for t, hyps in zip(local, hyps_per_batch):
                 out.extend(zip(t[0], hyps))
             return out
+        self._stage_all()
         for t in local:
             ids, x, lens = t[0], t[1], t[2]
             if len(t) > 3 and t[3] is not None:
@@ -222,6 +282,7 @@ class ShardedTranscriber:
         return out
 
     def _drain_sends(self):
+        self._stage_all()  # (a rank 0 without local batches: nothing else has staged the peers' yet)
         for work, _ in getattr(self, "_pending", []):
             work.wait()
         self._pending = []

@@ -160,6 +160,20 @@ class ConcurrentTranscriber:
                            prepare: Optional[Callable] = None, ready: Optional[Sequence] = None) -> List[list]:
         """Workers pull from one queue, largest batch first, so that they finish together.  ``ready[k]`` (optional):
         called by the worker, on its stream, before it touches batch k (a batch that is still being received)."""
+        return self.finish(self.start(batches, prepare, ready))
+
+    def finish(self, running) -> List[list]:
+        futs, n = running
+        res = {}
+        for f in futs:
+            for k, toks in f.result():
+                res[k] = toks
+        return [res[k] for k in range(n)]
+
+    def start(self, batches: Sequence[Tuple[torch.Tensor, torch.Tensor]], prepare: Optional[Callable] = None,
+              ready: Optional[Sequence] = None):
+        """``transcribe_batches`` without the wait: the workers are running when this returns (``finish`` collects).
+        The caller may go on producing the batches meanwhile -- a worker blocks in ``ready[k]()`` until batch k is there."""
         if self.device.type == "cuda":
             cur = torch.cuda.current_stream(self.device)
             for s in self.enc_streams:
@@ -169,8 +183,4 @@ class ConcurrentTranscriber:
             todo.put(k)
         n_workers = min(self.n, (len(batches) + self.group - 1) // self.group)
         futs = [self.pool.submit(self._work, slot, todo, batches, prepare, ready) for slot in range(max(1, n_workers))]
-        res = {}
-        for f in futs:
-            for k, toks in f.result():
-                res[k] = toks
-        return [res[k] for k in range(len(batches))]
+        return futs, len(batches)

@@ -175,3 +175,23 @@ def test_bench_self_launch_world2():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["utterances_total"] == 256 and rec["ranks_with_work"] == 2
     assert rec["bytes_scattered"] > 0
+
+
+def test_bench_node_job_world8_launch_check():
+    """BASELINE.json configs[3] as far as a box without GPUs can take it: `bench.py --gpus 8 --job-utts 10000 --launch-check`
+    starts eight ranks (gloo), plans the 10 000-utterance job (durations scaled to a tenth), streams every batch to its
+    owner, runs the stand-in transcriber on every rank and gathers 10 000 hypotheses in input order on rank 0.  The plan
+    is the real one: 313 batches, every rank owns some, and the longest-processing-time-first assignment leaves the
+    most loaded rank within 1 % of the mean cost."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--job-utts", "10000", "--warmup", "0",
+                          "--launch-check"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 8 and rec["utterances_total"] == 10000 and rec["ranks_with_work"] == 8
+    assert rec["batches_total"] == 313 and rec["plan_max_over_mean_cost"] <= 1.01

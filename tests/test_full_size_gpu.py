@@ -508,3 +508,67 @@ def test_whisper_large_v3_shape_encoder_vs_reference_and_hf():
         got[prec] = (float(err.abs().max()), float(err.pow(2).mean().sqrt() / enc.pow(2).mean().sqrt()))
         print(f"whisper large-v3-shape encoder, {prec} GEMM operands vs fp32: max |d| {got[prec][0]:.4f}, relative RMS {got[prec][1]:.5f}")
         assert got[prec][0] <= tol_abs and got[prec][1] <= tol_rms, (prec, got[prec])
+
+
+def test_in_kernel_handoffs_under_uneven_load_conformer_l():
+    """Every in-launch hand-off of the path (stream-K partial tiles -> last-arriver fix-up in the persistent / split-operand
+    contractions, split-K tickets of the decode GEMMs, the cross-attention runs' last-arriver merge) must give
+    bit-identical results however the chip is loaded: MI355X_MICROARCH.md asks for hand-offs to be tested "under UNEVEN
+    load, consumer L1-warm, checking every word" -- an idle chip hides a missing release / acquire.  A second host thread
+    keeps a stream busy with bursts of bandwidth- and matrix-heavy launches of changing size while (a) the encoder of one
+    batch (24 x 7.5 s: GPUTEST_r03's differing batch) and (b) its beam search run again and again on another stream; every
+    word of the encoder output, every token id and every score must equal the first, unloaded, run."""
+    import threading
+
+    from speechbrain_amd import native
+
+    asr = _asr("L", beam_size=10, ctc_weight=0.4)
+    asr.mods.decoder.check_every = 0
+    n = int(7.5 * 16000)
+    wav = 0.1 * torch.randn(24, n, generator=torch.Generator().manual_seed(33))
+    lens = torch.linspace(0.6, 1.0, 24)
+    for i in range(24):
+        wav[i, int(lens[i] * n):] = 0
+    wav, lens = wav.cuda(), lens.cuda()
+    T = ((1 + n // 160 - 1) // 2 + 1 - 1) // 2 + 1
+    asr.mods.decoder.max_decode_ratio = 20.5 / T
+    enc0 = asr.encode_batch(wav, lens).clone()
+    tok0, ln0, sc0, lp0, _ = asr.mods.decoder.search_device(enc0, lens)
+    tok0, sc0, lp0 = tok0.clone(), sc0.clone(), lp0.clone()
+    torch.cuda.synchronize()
+
+    stop = threading.Event()
+
+    def load():  # bursts of different weight with pauses between them: the chip's load changes under the measured stream
+        torch.cuda.set_device(0)
+        s = torch.cuda.Stream()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        with torch.cuda.stream(s):
+            big = torch.randn(64 << 20, device="cuda", generator=g)
+            a = torch.randn(6000, 512, device="cuda", generator=g)
+            w = torch.randn(2048, 512, device="cuda", generator=g)
+            k = 0
+            while not stop.is_set():
+                k += 1
+                if k % 3 == 0:
+                    big[: (8 << 20) * (1 + k % 8)].mul_(1.0001)   # 32 .. 256 MB of HBM traffic
+                elif k % 3 == 1:
+                    for _ in range(1 + k % 5):
+                        native.gemm_nt(a[: 2048 + 512 * (k % 8)], w)  # matrix bursts (split-operand / persistent kernels)
+                else:
+                    s.synchronize()                                 # a pause: the other stream has the chip to itself
+            s.synchronize()
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        work = torch.cuda.Stream(priority=-1)
+        with torch.cuda.stream(work):
+            for rep in range(25):
+                enc = asr.encode_batch(wav, lens)
+                assert torch.equal(enc, enc0), f"encoder output differs under load (rep {rep}): {int((enc != enc0).sum())} words"
+                tok, ln, sc, lp, _ = asr.mods.decoder.search_device(enc0, lens)
+                assert torch.equal(tok, tok0) and torch.equal(sc, sc0) and torch.equal(lp, lp0), f"search differs under load (rep {rep})"
+    finally:
+        stop.set()
+        th.join()
