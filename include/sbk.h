@@ -181,6 +181,25 @@ int sbk_gemm_nt_f32x3(const float* A, int lda, const uint16_t* W3, const float* 
                       float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
                       int rows_per_seq, sbk_stream_t stream);
 
+/* The same contraction with BOTH operands pre-split and stored in PANEL layout (ABI 7; csrc/gemm_x3p.hip) -- the entry the
+ * encoder's contractions take from ~2 000 rows on.  Same arithmetic and result class as sbk_gemm_nt_f32x3 (six exact bf16
+ * partial products per element pair, fp32 accumulation); the A operand is no longer split inside the loop (once per element
+ * instead of once per column tile), and 256 x 256 tiles fed by a three-slot LDS-DMA ring keep the matrix pipe busy.
+ *   panel image of X [rows, K] (K % 16 == 0): [ceil(rows/64)][K/16][3 pieces hi|mid|lo][2 halves of 8 k][64 rows][8 k] bf16
+ *   bits, sbk_x3p_panel_bytes(rows, K) = ceil(rows/64)*64*K*6 bytes, 16-byte aligned: every 1 KB chunk is one
+ *   global_load_lds_dwordx4 and is read back as MFMA fragments without bank conflicts.
+ *   sbk_split_x3p: X [rows, K] fp32 (row stride ldx; ldx < K allowed) -> its panel image (weights: once per matrix;
+ *   activations: per call, unless the producing call wrote the image itself -- `PC` below).
+ *   sbk_gemm_nt_x3p: epilogue / seq_len exactly as sbk_gemm_nt_f32; the result goes to C (fp32, may be NULL when PC is given)
+ *   and / or to PC, the panel image of the [M, N] result (N % 16 == 0) = the A operand of the next contraction
+ *   (PositionalwiseFeedForward, nnet/attention.py:941-945: linear -> activation -> linear without an fp32 round trip).
+ *   Needs the stream workspace when the launch has more tiles than CUs. */
+size_t sbk_x3p_panel_bytes(int rows, int K);
+int sbk_split_x3p(const float* X, int ldx, uint16_t* P, int rows, int K, sbk_stream_t stream);
+int sbk_gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, const float* residual, int ldr, float* C,
+                    int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
+                    int rows_per_seq, sbk_stream_t stream);
+
 /* ---- bf16-operand fast entry points ("fp32 parity entry points plus bf16 ... fast entry points").
  * C = epilogue(bf16(A) . Wb^T) with fp32 accumulation on v_mfma_f32_32x32x16_bf16: A [M,K] stays fp32 in memory and is
  * rounded to bf16 (nearest even) inside the kernel, Wb [N,K] holds the weights as bf16 bits (sbk_f32_to_bf16, once per

@@ -1897,7 +1897,9 @@ int cur_device() {
   return dev;
 }
 
-constexpr size_t kSkSlabBytes = (size_t)2 * kSkMaxGrid * 128 * 128 * sizeof(float);
+// two partial-tile slabs per workgroup: 512 workgroups x 128 x 128 (this file's kernels) or 256 x 256 x 256 (gemm_x3p.hip)
+constexpr size_t kSkSlabBytes = (size_t)2 * 256 * 256 * 256 * sizeof(float);
+static_assert(kSkSlabBytes >= (size_t)2 * kSkMaxGrid * 128 * 128 * sizeof(float), "slab area");
 constexpr size_t kSkTicketBytes = (size_t)kSkMaxTiles * sizeof(int);
 
 // the stream's workspace; false when the caller has registered none for it (the tile-grid kernels run instead)
@@ -1915,6 +1917,13 @@ int* tile_tickets(hipStream_t st, long tiles) {
   if (tiles > kSkMaxTiles || !sk_workspace(st, &w)) return nullptr;
   return w.cnt;
 }
+bool stream_ws(hipStream_t st, float** slabs, int** cnt) {  // (gemm_x3p.hip)
+  SkWorkspace w;
+  if (!sk_workspace(st, &w)) return false;
+  *slabs = w.slabs;
+  *cnt = w.cnt;
+  return true;
+}
 namespace {
 
 int sk_cus() {
@@ -1927,6 +1936,9 @@ int sk_cus() {
   return g_sk_cus[dev];
 }
 
+}  // namespace
+int device_cus() { return sk_cus(); }
+namespace {
 int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st, bool x3 = false) {
   SkArgs s;
   s.g = g;
@@ -2158,6 +2170,7 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 28) sbk::g_bf16a_grid = value;
   if (key == 29) sbk::g_bf16a_mode = value;
   if (key == 31) sbk::g_x3_grid = value;
+  if (key == 39) sbk::g_x3p_tile = value;
   if (key == 36) sbk::g_splitk_fused = value;
   if (key == 37) sbk::g_cross_fused_merge = value;
   if (key == 34) sbk::g_x3_route_rows = value;

@@ -153,6 +153,19 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
       : "v"(src), "s"(dst)
       : "memory");
 }
+// The same with a wave-UNIFORM source chunk: `base` lives in a scalar register pair and the lanes share one 32-bit byte
+// offset register (lane * 16 for a contiguous 1 KB chunk) -- no per-piece address VGPRs in a loop that needs its vector
+// registers for accumulators and operand fragments; the per-stage address arithmetic runs on the scalar unit.
+__device__ __forceinline__ void glds16_uniform(const float* base, unsigned lane_byte_offset, float* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(
+      (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)lds_wave_base);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_byte_offset), "s"(base), "s"(dst)
+      : "memory");
+}
 // a value the caller knows to be the same in every lane, moved to a scalar register (uniform branches, scalar address math)
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // every outstanding vector-memory operation of this wave has completed (inline asm: the compiler cannot drop it)
@@ -163,6 +176,11 @@ __device__ __forceinline__ void vm_wait() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// every outstanding LDS operation of this wave has completed (reads: their data is in registers)
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// the bare workgroup barrier: no memory-counter waits are attached (a __syncthreads() drains vmcnt, i.e. every LDS-DMA in
+// flight); the caller has waited for exactly what the barrier must publish (lds_drain / vm_wait<N>)
+__device__ __forceinline__ void block_barrier_raw() { __builtin_amdgcn_s_barrier(); }
 // publish this workgroup's earlier plain stores to every CU of the device (one lane, after a __syncthreads())
 __device__ __forceinline__ void release_agent() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

@@ -12,6 +12,10 @@ int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
 int gemm_nt_x3(const float* A, int lda, const uint16_t* W3, const float* bias, const float* R, int ldr, float* C, int ldc,
                int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
 bool x3_routed(int M, int N, int K);
+// both operands as panel images (csrc/gemm_x3p.hip); PC: optional panel image of the result; -1 = no workspace
+int gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, const float* R, int ldr, float* C, int ldc,
+                uint16_t* PC, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
+extern int g_x3p_tile;
 // Device-resident step counter of the search running on this host thread (nullptr: the step is the
 // launch argument).  When set, every step-dependent kernel reads the step from it, so that the launches
 // of one decoding step are identical for every step and can be replayed from a captured hipGraph.

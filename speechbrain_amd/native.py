@@ -98,6 +98,9 @@ def _declare(lib):
         "sbk_f32_to_bf16": ([p, p, ctypes.c_long, p], c_int),
         "sbk_split_bf16x3": ([p, i, p, i, i, p], c_int),
         "sbk_gemm_nt_f32x3": ([p, i, p, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
+        "sbk_x3p_panel_bytes": ([i, i], ctypes.c_size_t),
+        "sbk_split_x3p": ([p, i, p, i, i, p], c_int),
+        "sbk_gemm_nt_x3p": ([p, p, p, p, i, p, i, p, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_bf16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_f16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_bf16a": ([p, i, p, i, p, p, i, p, i, p, i, i, i, i, i, f, p], c_int),
@@ -255,6 +258,9 @@ def precision_scope(p):
 F32X3 = os.environ.get("SBK_F32X3", "1") != "0"
 F32X3_MIN_ROWS = int(os.environ.get("SBK_F32X3_MIN_ROWS", "2048"))
 F32X3_MIN_TILES = int(os.environ.get("SBK_F32X3_MIN_TILES", "192"))
+# ... and, with the activation operand pre-split as well, through sbk_gemm_nt_x3p (csrc/gemm_x3p.hip: 256-wide tiles)
+X3P = os.environ.get("SBK_X3P", "0") != "0"  # (off until its first GPU measurement)
+X3P_MIN_TILES = int(os.environ.get("SBK_X3P_MIN_TILES", "96"))
 
 
 def f32x3_ok(M: int, K: int, w: torch.Tensor) -> bool:
@@ -290,6 +296,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_
         out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
     _dev_ok(seq_len)
+    if x3p_ok(M, K, w) and _aligned16(a2, out, bias, r2):  # both operands pre-split, 256-wide tiles (csrc/gemm_x3p.hip)
+        return gemm_nt_x3p(split_x3p(a2), w, bias, r2, act, alpha, out=out, seq_len=seq_len, rows_per_seq=rows_per_seq)
     if f32x3_ok(M, K, w) and _aligned16(a2, out, bias, r2):
         _chk(lib.sbk_gemm_nt_f32x3(_p(a2), K, _p(lp_weight(w, "x3")), _p(bias), _p(r2), N, _p(out), N, M, N, K, act,
                                    float(alpha), _p(seq_len), int(rows_per_seq), _stream(a2)), "sbk_gemm_nt_f32x3")
@@ -318,12 +326,78 @@ def gemm_nt_rows(a_flat: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor
         _chk(lib.sbk_gemm_nt_bf16(_p(a_flat), int(lda), _p(bf16_weight(w)), K, _p(bias), _p(residual), N, _p(out), N, M, N, K,
                                   act, float(alpha), None, 0, _stream(a_flat)), "sbk_gemm_nt_bf16")
         return out
+    if x3p_ok(M, K, w) and _aligned16(out, bias, residual):
+        return gemm_nt_x3p(split_x3p(a_flat, rows=M, K=K, ldx=lda), w, bias, residual, act, alpha, out=out)
     if f32x3_ok(M, K, w) and lda % 4 == 0 and _aligned16(a_flat, out, bias, residual):
         _chk(lib.sbk_gemm_nt_f32x3(_p(a_flat), int(lda), _p(lp_weight(w, "x3")), _p(bias), _p(residual), N, _p(out), N, M, N, K,
                                    act, float(alpha), None, 0, _stream(a_flat)), "sbk_gemm_nt_f32x3")
         return out
     _chk(lib.sbk_gemm_nt_f32(_p(a_flat), int(lda), _p(w), w.stride(0), _p(bias), _p(residual), N, _p(out), N, M, N, K, act,
                              float(alpha), None, 0, _stream(a_flat)), "sbk_gemm_nt_f32")
+    return out
+
+
+# ------------------------------------------------------------------ both operands pre-split, panel layout (csrc/gemm_x3p.hip)
+class Panel:
+    """The panel image (include/sbk.h, sbk_split_x3p) of an fp32 matrix [rows, K]: the A operand of sbk_gemm_nt_x3p."""
+    __slots__ = ("data", "rows", "K", "lead")
+
+    def __init__(self, data, rows, K, lead=None):
+        self.data, self.rows, self.K, self.lead = data, rows, K, lead  # lead: leading dims of the activation it stands for
+
+    @property
+    def device(self):
+        return self.data.device
+
+
+def panel_empty(rows: int, K: int, device, lead=None) -> Panel:
+    n = ((rows + 63) // 64) * 64 * K * 3  # int16 elements
+    return Panel(torch.empty(n, dtype=torch.int16, device=device), rows, K, lead)
+
+
+def split_x3p(x: torch.Tensor, rows: Optional[int] = None, K: Optional[int] = None, ldx: Optional[int] = None) -> Panel:
+    """x [..., K] fp32 (contiguous) -> its panel image; with rows / K / ldx: `rows` windows of K floats every ldx floats of
+    the flat tensor x (gemm_nt_rows' sliding-window operand)."""
+    lib = load()
+    _dev_ok(x)
+    _f32(x)
+    lead = None
+    if rows is None:
+        K = x.shape[-1]
+        lead = tuple(x.shape[:-1])
+        x = x.reshape(-1, K)
+        rows, ldx = x.shape[0], K
+    out = panel_empty(rows, K, x.device, lead)
+    _chk(lib.sbk_split_x3p(_p(x), int(ldx), _p(out.data), rows, K, _stream(x)), "sbk_split_x3p")
+    return out
+
+
+def x3p_ok(M: int, K: int, w: torch.Tensor) -> bool:
+    """Shapes routed to sbk_gemm_nt_x3p: from F32X3_MIN_ROWS rows on, K % 16 == 0, and enough 256 x 128 tiles to give most
+    CUs one (tools/microbench.py --x3p)."""
+    if not (F32X3 and X3P and M >= F32X3_MIN_ROWS and K % 16 == 0 and K >= 32 and w.dim() == 2 and w.is_contiguous()):
+        return False
+    return w.shape[0] % 4 == 0 and ((M + 255) // 256) * ((w.shape[0] + 127) // 128) >= X3P_MIN_TILES
+
+
+def gemm_nt_x3p(a: Panel, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, seq_len=None,
+                rows_per_seq=0, panel_out=False, fp32_out=True):
+    """out[M,N] = residual + alpha * act(A @ w^T + bias) with A given as its panel image.  ``panel_out``: also (or, with
+    ``fp32_out=False``, only) return the result as a Panel -- the A operand of the next contraction."""
+    lib = load()
+    M, K, N = a.rows, a.K, w.shape[0]
+    _dev_ok(a.data, w, bias, residual, seq_len)
+    wp = lp_weight(w, "x3p")
+    lead = a.lead if a.lead is not None else (M,)
+    if fp32_out and out is None:
+        out = torch.empty(*lead, N, dtype=torch.float32, device=a.device)
+    r2 = residual.reshape(-1, N) if residual is not None else None
+    pc = panel_empty(M, N, a.device, lead) if panel_out else None
+    _chk(lib.sbk_gemm_nt_x3p(_p(a.data), _p(wp), _p(bias), _p(r2), N, _p(out) if fp32_out else None, N,
+                             _p(pc.data) if pc is not None else None, M, N, K, act, float(alpha), _p(seq_len), int(rows_per_seq),
+                             _stream(a.data)), "sbk_gemm_nt_x3p")
+    if panel_out:
+        return (out, pc) if fp32_out else pc
     return out
 
 
@@ -392,6 +466,10 @@ def lp_weight(w: torch.Tensor, kind: str = "bf16"):
         N, K = w2.shape
         out = torch.empty(N, K // 32, 3, 32, dtype=torch.int16, device=w.device)
         _chk(lib.sbk_split_bf16x3(_p(w2), K, _p(out), N, K, _stream(w2)), "sbk_split_bf16x3")
+    elif kind == "x3p":
+        N, K = w2.shape
+        out = torch.empty(((N + 63) // 64) * 64 * K * 3, dtype=torch.int16, device=w.device)
+        _chk(lib.sbk_split_x3p(_p(w2), K, _p(out), N, K, _stream(w2)), "sbk_split_x3p")
     else:
         out = torch.empty(w2.shape, dtype=torch.int16, device=w.device)
         fn = lib.sbk_f32_to_bf16 if kind == "bf16" else lib.sbk_f32_to_f16

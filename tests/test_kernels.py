@@ -748,6 +748,70 @@ def test_gemm_f32x3(backend, M, N, K, grid):
         lib.sbk_prof_set_knob(21, 4)
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(300, 132, 64, 1), (300, 132, 64, 2), (700, 300, 96, 0), (1000, 520, 64, 2), (520, 260, 128, 1),
+                                        (2100, 304, 64, 2), (1300, 272, 160, 1), (4100, 512, 512, 0), (3012, 2048, 512, 0),
+                                        (12800, 2048, 512, 0), (4032, 512, 2048, 0), (24000, 1536, 512, 0), (14000, 1024, 512, 0),
+                                        (6432, 512, 512, 2), (130, 1032, 2048, 1)])
+def test_gemm_x3p(backend, M, N, K, tile):
+    """sbk_split_x3p + sbk_gemm_nt_x3p: the fp32 contraction on the bf16 matrix pipe with BOTH operands pre-split and in
+    panel layout.  The panel image is exact (hi + mid + lo == x bit for bit, padding rows zero); the result is held to the
+    bound of every fp32 kernel of the library against the fp64 product (2e-6 of the largest sum of magnitudes); both tile
+    shapes (knob 39), whole-tile and stream-K launches, ragged edges, every epilogue option, row masks; the panel-image
+    result (the next contraction's A operand) equals the fp32 result bit for bit; run-to-run bit-identical."""
+    nat, dev = backend
+    if dev.type == "cpu" and M * N * K > 6e7:
+        pytest.skip("large shape: GPU only")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01
+    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
+    a[::7] *= 1e-3  # rows of very different magnitude
+    w[::5] *= 300.0
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    lib = nat.load()
+    lib.sbk_prof_set_knob(39, tile)
+    try:
+        ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+
+        def unpanel(img, rows, cols):  # panel image -> the sum of its three pieces as fp32 [rows, cols]
+            RB, KB = (rows + 63) // 64, cols // 16
+            pieces = (img.cpu().view(torch.int16).to(torch.int32) << 16).view(torch.float32).view(RB, KB, 3, 2, 64, 8)
+            return pieces.double().sum(2).permute(0, 3, 1, 2, 4).reshape(RB * 64, cols).float()
+
+        pa = nat.split_x3p(ad)
+        full = unpanel(pa.data, M, K)
+        assert torch.equal(full[:M], a) and not full[M:].any()  # exact, padding rows zero
+        big = M * N * K > 6e7
+        dd = (lambda t: t.to(dev).double()) if big else (lambda t: t.double())
+        prod = dd(a) @ dd(w).t()
+        scale = float((dd(a).abs() @ dd(w).abs().t()).max())
+        out, pc = nat.gemm_nt_x3p(pa, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5, panel_out=N % 16 == 0) if N % 16 == 0 else \
+            (nat.gemm_nt_x3p(pa, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), None)
+        ref = (dd(r) + 0.5 * F.silu(prod + dd(b))).float().cpu()
+        assert _md(out, ref) <= 2e-6 * scale + 1e-5
+        if pc is not None:
+            assert torch.equal(unpanel(pc.data, M, N)[:M], out.cpu())
+            only = nat.gemm_nt_x3p(pa, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5, panel_out=True, fp32_out=False)
+            assert torch.equal(only.data[: pc.data.numel()].cpu()[: ((M + 63) // 64 - 1) * 64 * N * 3], pc.data.cpu()[: ((M + 63) // 64 - 1) * 64 * N * 3])
+        for _ in range(3 if dev.type == "cuda" else 1):
+            assert torch.equal(nat.gemm_nt_x3p(pa, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
+        rows = 50 if M % 50 == 0 else M // 7
+        nseq = M // rows
+        lens = torch.tensor([(i * 13) % (rows + 1) for i in range(nseq)], dtype=torch.int32)
+        pa2 = nat.split_x3p(ad[: nseq * rows])
+        out = nat.gemm_nt_x3p(pa2, wd, bd, rd[: nseq * rows], seq_len=lens.to(dev), rows_per_seq=rows)
+        keep = (torch.arange(rows)[None, :] < lens[:, None]).reshape(-1, 1)
+        ref = r[: nseq * rows] + torch.where(keep, (prod[: nseq * rows] + dd(b)).float().cpu(), torch.zeros(()))
+        assert _md(out, ref) <= 2e-6 * scale + 1e-5
+        if K % 64 == 0 and M <= 4100:  # a window of K floats sliding by lda = K / 2 over a flat signal
+            Mw = 2 * M - 1
+            pw = nat.split_x3p(ad.reshape(-1), rows=Mw, K=K, ldx=K // 2)
+            out = nat.gemm_nt_x3p(pw, wd, bd)
+            win = a.reshape(-1).unfold(0, K, K // 2)
+            assert _md(out, (win.double() @ w.double().t() + b).float()) <= 2e-6 * scale + 1e-5
+    finally:
+        lib.sbk_prof_set_knob(39, 0)
+
+
 @pytest.mark.parametrize("d_model,nhead,B,T,beam_rows", [(128, 2, 3, 150, 4), (256, 4, 2, 75, 10), (128, 2, 1, 20, 1)])
 def test_cross_attention_lds_dma_variant(backend, d_model, nhead, B, T, beam_rows):
     """csrc/decoder.hip cross_attn_dma_kernel (head_dim 64: LDS-DMA tiles of 16 frames, transposed scores on the matrix

@@ -31,6 +31,7 @@ struct int4 { int x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
@@ -360,6 +361,9 @@ static inline float group_sum(float v) {  // same lane selects as the DPP sequen
 static inline void glds16(const float* src, float* lds_wave_base) {
   memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * sbk_emu::cur().lane, src, 16);
 }
+static inline void glds16_uniform(const float* base, unsigned lane_byte_offset, float* lds_wave_base) {
+  memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * sbk_emu::cur().lane, reinterpret_cast<const char*>(base) + lane_byte_offset, 16);
+}
 static inline int uniform(int v) { return v; }
 template <int MASK, int SIZE>
 static inline void sched_group() {}
@@ -369,6 +373,8 @@ static inline void pin(unsigned&) {}
 static inline void pin(float&) {}
 static inline void pin(f32x16&) {}
 static inline void vm_drain() {}
+static inline void lds_drain() {}
+static inline void block_barrier_raw() { sbk_emu::block_barrier(); }
 template <int N>
 static inline void vm_wait() {}
 static inline void release_agent() { __atomic_thread_fence(__ATOMIC_RELEASE); }

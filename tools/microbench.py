@@ -321,6 +321,41 @@ if __name__ == "__main__":
                 nat.gemm_nt(a, w)
             torch.cuda.synchronize()
         sys.exit(0)
+    if "--x3p" in sys.argv:  # both operands pre-split, panel layout, 256-wide tiles (csrc/gemm_x3p.hip) vs the f32x3 kernel
+        def ev_time(fn, n=30):
+            fn(); fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+        shapes = [(M, N, K) for M in (4032, 8000, 14016, 24032) for (N, K) in ((2048, 512), (512, 2048), (1536, 512), (512, 512), (1024, 512))]
+        if "--x3p-short" in sys.argv:
+            shapes = [(12800, 2048, 512), (12800, 512, 2048), (14016, 1536, 512), (14016, 512, 512), (4032, 1024, 512)]
+        nat.F32X3, nat.X3P = True, False
+        for (M, N, K) in shapes:
+            a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev)
+            nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES = 1, 1
+            t3 = ev_time(lambda: nat.gemm_nt(a, w))
+            ref3 = nat.gemm_nt(a, w)
+            nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES = 2048, 192
+            tsp = ev_time(lambda: nat.split_x3p(a))
+            pa = nat.split_x3p(a)
+            line = f"x3p M={M} N={N} K={K}: f32x3 {t3:7.1f} us {2.0*M*N*K/t3/1e6:6.1f} TF/s | split A {tsp:6.1f} us {10.0*M*K/tsp/1e3:6.0f} GB/s |"
+            for tile in (1, 2):
+                nat.load().sbk_prof_set_knob(39, tile)
+                t = ev_time(lambda: nat.gemm_nt_x3p(pa, w))
+                tp = ev_time(lambda: nat.gemm_nt_x3p(pa, w, panel_out=True, fp32_out=False)) if N % 16 == 0 else float("nan")
+                line += f" tile {'256x256' if tile == 1 else '256x128'}: {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s (panel out {tp:7.1f} us) |"
+            nat.load().sbk_prof_set_knob(39, 0)
+            out = nat.gemm_nt_x3p(pa, w)
+            ref = (a.double() @ w.double().t())
+            line += f" rms err vs fp64: x3p {float((out.double() - ref).pow(2).mean().sqrt()):.3e} f32x3 {float((ref3.double() - ref).pow(2).mean().sqrt()):.3e}"
+            print(line, flush=True)
+        sys.exit(0)
     if "--x3" in sys.argv:  # fp32 contraction on the bf16 matrix pipe (three-way operand split) vs the fp32-MFMA persistent kernel
         def ev_time(fn, n=30):
             fn(); fn()
