@@ -32,7 +32,7 @@
 
 namespace {
 
-constexpr float kNeg = -1e20f;
+constexpr float kNeg = sbk::kCtcNeg;
 constexpr int kNegE = -(1 << 20);  // exponent of an exact zero
 constexpr int kHead = 24;          // head-room (bits) kept above the incoming phi term
 
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(256) ctc_combine_kernel(CtcStepArgs a, const f
   }
   if (extra) v += extra[(size_t)n * a.V + c];  // full scorers listed before "ctc" (already weighted)
   if (c == a.blank) v = kNeg;
-  comb[(size_t)n * a.V + c] = v + (psi[(size_t)n * a.V + c] - psi_prev[n]) * a.weight;
+  comb[(size_t)n * a.V + c] = fmaf(psi[(size_t)n * a.V + c] - psi_prev[n], a.weight, v);  // (what hipcc contracts v + d * w to)
 }
 
 // ---- the forward recurrence as a prefix scan ---------------------------------------------------

@@ -2171,6 +2171,7 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 29) sbk::g_bf16a_mode = value;
   if (key == 31) sbk::g_x3_grid = value;
   if (key == 39) sbk::g_x3p_tile = value;
+  if (key == 40) sbk::g_score_fused = value;
   if (key == 36) sbk::g_splitk_fused = value;
   if (key == 37) sbk::g_cross_fused_merge = value;
   if (key == 34) sbk::g_x3_route_rows = value;

@@ -30,6 +30,8 @@ extern int g_ctc_tpt;
 extern int g_cross_fc256;
 extern int g_cross_fused_merge;
 extern int g_self_group_off;
+extern int g_score_fused;  // key 40: 1 (default) = the step's scoring as one pass per hypothesis row (csrc/search.hip)
+constexpr float kCtcNeg = -1e20f;  // the CTC scorer's finite "log 0" (ctc.py:150, scorer.py:1250)
 int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
                int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, float* ws,
                size_t ws_floats, hipStream_t st);

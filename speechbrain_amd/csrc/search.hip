@@ -94,6 +94,7 @@ int am_only(const float* am, float* comb, int n_bh, int V, int eos, int eos_floo
 int row_max(const float* x, float* out, int rows, int V, hipStream_t st);
 int ctc_partial_combine(float* comb, float* thr, const float* psi, const float* psi_prev, int n_bh, int V, int k, int blank,
                         int eos, float weight, float minus_inf, hipStream_t st);
+int g_score_fused = 1;  // tuning knob (key 40): 0 = log_softmax / row_max / combine / top-k stage 1 as separate launches
 }  // namespace sbk
 
 namespace {
@@ -251,25 +252,214 @@ __global__ void __launch_bounds__(256) beam_topk_stage1_kernel(const float* __re
              });
 }
 
-// stage 2: grid (B); merge the chunk winners
+// stage 2: grid (B); merge the winners of the first `nchunks` lists (stage 1: kTopkChunks slices of beam*V; the fused
+// scoring kernel below: one list per hypothesis row)
 __global__ void __launch_bounds__(256) beam_topk_stage2_kernel(const float* __restrict__ pval,
                                                                const int32_t* __restrict__ pidx,
                                                                float* __restrict__ out_val,
                                                                int32_t* __restrict__ out_idx, int beam,
                                                                const int32_t* __restrict__ step_ptr, int step,
-                                                               const int32_t* __restrict__ utt_max) {
+                                                               const int32_t* __restrict__ utt_max, int nchunks) {
   const int b = blockIdx.x;
   if (step_ptr) step = step_ptr[0];
   if (utt_max && step >= utt_max[b]) return;
   const float* pv = pval + (size_t)b * kTopkChunks * kMaxBeam;
   const int32_t* pi = pidx + (size_t)b * kTopkChunks * kMaxBeam;
-  block_topk(kTopkChunks * kMaxBeam, beam, out_val + b * beam, out_idx + b * beam, [&](int e, float& v, int& id) {
+  block_topk(nchunks * kMaxBeam, beam, out_val + b * beam, out_idx + b * beam, [&](int e, float& v, int& id) {
     const bool ok = (e % kMaxBeam) < beam;
     v = ok ? pv[e] : -INFINITY;
     id = ok ? pi[e] : INT_MAX;
   });
   __syncthreads();
   if (threadIdx.x < beam && out_idx[b * beam + threadIdx.x] == INT_MAX) out_idx[b * beam + threadIdx.x] = 0;
+}
+
+// ---------------------------------------------------------------- one pass over a hypothesis' vocabulary row
+// The scoring of a step as ONE kernel per hypothesis row instead of four launches and five sweeps over [n_bh, V]
+// (log_softmax_row -> [row_max] -> ctc_combine / am_only -> beam_topk_stage1):  the logits row lives in registers
+// (V <= 256 * NPT), so the log-softmax, the eos rules (seq2seq.py:995-1017), the scorer combination
+// (scorer.py:1248-1253) and the candidate value seq_score + combined [/ length] (seq2seq.py:1225-1240) are applied in
+// place and the row's `beam` best candidates are selected from the registers: the top `beam` of beam * V candidates are
+// among the per-row top `beam` lists, which stage 2 merges (one list per row instead of one per slice).  Every value is
+// computed by the expressions of the kernels it replaces, in the same order (the thread <-> column mapping and the
+// reduction trees of log_softmax_row_kernel included), so candidates and scores are bit-identical to the four-launch
+// path (tests/test_model_parity.py::test_fused_scoring_equals_separate_kernels); only `am` (the pre-scorer log-probs
+// beam_update records per token) is still written out.  HBM traffic per step: logits + psi read, am written (12 B per
+// candidate) against 24 B + the top-k sweep.
+struct ScoreArgs {
+  const float* logits;   // [n_bh, V] seq_lin output
+  const float* bias;     // optional additive masks on the logits ([V]; Whisper's suppress lists)
+  const float* bias2;
+  float* am;             // [n_bh, V] out: w * log_softmax(logits / temp)
+  const float* psi;      // [n_bh, V] CTC prefix scores of the step, NULL = no CTC scorer
+  const float* psi_prev; // [n_bh]
+  const float* extra;    // [n_bh, V] weighted log-probs of the full scorers listed before "ctc" (LM), or NULL
+  const float* seq;      // [n_bh] running hypothesis scores
+  float* pval;           // [B][kTopkChunks][kMaxBeam] per-row winners for stage 2
+  int32_t* pidx;
+  const int32_t* step_ptr;
+  const int32_t* utt_min;
+  const int32_t* utt_max;
+  int V, beam, step, min_steps, eos_floor, use_thr, eos, blank;
+  float inv_temp, w, ctc_weight, thr, minus_inf, norm;
+};
+
+template <int NPT>
+__global__ void __launch_bounds__(256) score_topk_row_kernel(ScoreArgs a) {
+  __shared__ float red[4];
+  __shared__ float wv[4][kMaxBeam];
+  __shared__ int wi[4][kMaxBeam];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = a.V, b = n / a.beam, j = n % a.beam;
+  const int step = a.step_ptr ? a.step_ptr[0] : a.step;
+  if (a.utt_max && step >= a.utt_max[b]) return;  // this utterance's search has ended: nothing of the row is read again
+  float norm = a.norm;
+  if (a.step_ptr && norm > 0.0f) norm = (float)(step + 1);
+  const size_t ro = (size_t)n * V;
+  // --- log-softmax (log_softmax_row_kernel: same column mapping, same reduction order)
+  float x[NPT];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int c = tid + 256 * i;
+    x[i] = -INFINITY;
+    if (c < V) {
+      x[i] = (a.logits[ro + c] + (a.bias ? a.bias[c] : 0.0f) + (a.bias2 ? a.bias2[c] : 0.0f)) * a.inv_temp;
+      m = fmaxf(m, x[i]);
+    }
+  }
+  m = sbk::wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NPT; ++i)
+    if (tid + 256 * i < V) s += expf(x[i] - m);
+  s = sbk::wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float lse = m + logf((red[0] + red[1]) + (red[2] + red[3]));
+  __syncthreads();
+  float am_max = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int c = tid + 256 * i;
+    if (c < V) {
+      x[i] = a.w * (x[i] - lse);
+      a.am[ro + c] = x[i];
+      am_max = fmaxf(am_max, x[i]);
+    }
+  }
+  if (a.use_thr) {  // row_max_kernel
+    am_max = sbk::wave_max(am_max);
+    if (lane == 0) red[wave] = am_max;
+    __syncthreads();
+    am_max = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  }
+  // --- eos rules, scorers, candidate value (am_only_kernel / ctc_combine_kernel, the loader of beam_topk_stage1_kernel)
+  const float sq = a.seq[n];
+  const float pp = a.psi ? a.psi_prev[n] : 0.0f;
+  unsigned dead = 0;  // bit i: entry i is no candidate (past V, NaN, or already selected)
+  float bv = -INFINITY;
+  int bi = INT_MAX;
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int c = tid + 256 * i;
+    if (c >= V) {
+      dead |= 1u << i;
+      continue;
+    }
+    float v = x[i];
+    if (c == a.eos) {
+      const bool floor = a.utt_min ? step < a.utt_min[b] : (a.step_ptr ? step < a.min_steps : a.eos_floor != 0);
+      if (floor) v = a.minus_inf;
+      if (a.use_thr && !(v > a.thr * am_max)) v = a.minus_inf;
+    }
+    if (a.extra) v += a.extra[ro + c];
+    if (a.psi) {
+      if (c == a.blank) v = sbk::kCtcNeg;
+      v = fmaf(a.psi[ro + c] - pp, a.ctc_weight, v);
+    }
+    const float cand = sq + v;
+    v = norm > 0.0f ? cand / norm : cand;  // length normalisation divides, like seq2seq.py:1232-1233
+    x[i] = v;
+    if (v != v) {
+      dead |= 1u << i;
+      continue;
+    }
+    const int id = j * V + c;
+    if (better(v, id, bv, bi)) {
+      bv = v;
+      bi = id;
+    }
+  }
+  // --- the row's `beam` best: every wave selects the beam best of its lanes (beam arg-max rounds over the lanes' current
+  // best; only the winning lane rescans its registers), the first wave merges the 4 * beam wave winners
+  const int k = a.beam;
+  for (int r = 0; r < k; ++r) {
+    float v = bv;
+    int i2 = bi;
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) {
+      const float ov = sbk::shfl_xor(v, msk);
+      const int oi = sbk::shfl_xor(i2, msk);
+      if (better(ov, oi, v, i2)) {
+        v = ov;
+        i2 = oi;
+      }
+    }
+    if (lane == 0) {
+      wv[wave][r] = v;
+      wi[wave][r] = i2;
+    }
+    if (bi == i2 && i2 != INT_MAX) {  // candidate ids are unique: exactly one lane of the wave
+      dead |= 1u << ((bi - j * V - tid) >> 8);
+      bv = -INFINITY;
+      bi = INT_MAX;
+#pragma unroll
+      for (int i = 0; i < NPT; ++i) {
+        const int id = j * V + tid + 256 * i;
+        if (!((dead >> i) & 1u) && better(x[i], id, bv, bi)) {
+          bv = x[i];
+          bi = id;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float v = -INFINITY;
+    int i2 = INT_MAX;
+    if (lane < 4 * k) {
+      v = wv[lane / k][lane % k];
+      i2 = wi[lane / k][lane % k];
+    }
+    float* ov_ = a.pval + ((size_t)b * kTopkChunks + j) * kMaxBeam;
+    int32_t* oi_ = a.pidx + ((size_t)b * kTopkChunks + j) * kMaxBeam;
+    for (int r = 0; r < k; ++r) {
+      float wbv = v;
+      int wbi = i2;
+#pragma unroll
+      for (int msk = 32; msk >= 1; msk >>= 1) {
+        const float ov = sbk::shfl_xor(wbv, msk);
+        const int oi = sbk::shfl_xor(wbi, msk);
+        if (better(ov, oi, wbv, wbi)) {
+          wbv = ov;
+          wbi = oi;
+        }
+      }
+      if (lane == 0) {
+        ov_[r] = wbv;
+        oi_[r] = wbi;
+      }
+      if (i2 == wbi && wbi != INT_MAX) {
+        v = -INFINITY;
+        i2 = INT_MAX;
+      }
+    }
+  }
 }
 
 // Beams wider than the per-thread lists (the recipe's test_search uses beam 66): exact radix select.
@@ -485,11 +675,9 @@ __global__ void probe_pick_kernel(const float* __restrict__ probe, float* __rest
   if (b < B) out[b] = probe[(size_t)b * beam];
 }
 
-__global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const float* __restrict__ am, int cur, int step,
-                                                          int V, int beam, int Lmax, int eos, int length_norm,
-                                                          const int32_t* __restrict__ step_ptr,
-                                                          const int32_t* __restrict__ utt_max) {
-  if (step_ptr) step = step_ptr[0];
+__device__ __forceinline__ void beam_update_body(const BeamState& s, const float* __restrict__ am, int cur, int step, int V,
+                                                 int beam, int Lmax, int eos, int length_norm,
+                                                 const int32_t* __restrict__ utt_max) {
   __shared__ int h_src[kMaxBeamLarge];
   __shared__ int h_dst[kMaxBeamLarge];
   __shared__ int h_n;
@@ -563,6 +751,40 @@ __global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const flo
       s.fin_lp[fo + p] = p < step ? s.lp[cur][(size_t)pred * Lmax + p] : am[(size_t)pred * V + tok];
     }
   }
+}
+
+__global__ void __launch_bounds__(256) beam_update_kernel(BeamState s, const float* __restrict__ am, int cur, int step,
+                                                          int V, int beam, int Lmax, int eos, int length_norm,
+                                                          const int32_t* __restrict__ step_ptr,
+                                                          const int32_t* __restrict__ utt_max) {
+  if (step_ptr) step = step_ptr[0];
+  beam_update_body(s, am, cur, step, V, beam, Lmax, eos, length_norm, utt_max);
+}
+
+// The merge of the per-row winners (beam_topk_stage2_kernel) and the beam bookkeeping (beam_update_kernel) of an
+// utterance in one launch: both are one workgroup per utterance, and the bookkeeping reads nothing but its own
+// utterance's winners.
+__global__ void __launch_bounds__(256) beam_merge_update_kernel(BeamState s, const float* __restrict__ pval,
+                                                                const int32_t* __restrict__ pidx,
+                                                                const float* __restrict__ am, int cur, int step, int V,
+                                                                int beam, int Lmax, int eos, int length_norm,
+                                                                const int32_t* __restrict__ step_ptr,
+                                                                const int32_t* __restrict__ utt_max, int nchunks) {
+  const int b = blockIdx.x;
+  if (step_ptr) step = step_ptr[0];
+  if (!(utt_max && step >= utt_max[b])) {  // (uniform per workgroup)
+    const float* pv = pval + (size_t)b * kTopkChunks * kMaxBeam;
+    const int32_t* pi = pidx + (size_t)b * kTopkChunks * kMaxBeam;
+    block_topk(nchunks * kMaxBeam, beam, s.cand_val + b * beam, s.cand_idx + b * beam, [&](int e, float& v, int& id) {
+      const bool ok = (e % kMaxBeam) < beam;
+      v = ok ? pv[e] : -INFINITY;
+      id = ok ? pi[e] : INT_MAX;
+    });
+    __syncthreads();
+    if (threadIdx.x < beam && s.cand_idx[b * beam + threadIdx.x] == INT_MAX) s.cand_idx[b * beam + threadIdx.x] = 0;
+    __syncthreads();  // the winners (plain global stores of this workgroup) are read back by all of its threads
+  }
+  beam_update_body(s, am, cur, step, V, beam, Lmax, eos, length_norm, utt_max);
 }
 
 // Fill unfinished lists with the alive hypotheses (seq2seq.py:1600-1630) and emit the `topk` best
@@ -1198,13 +1420,17 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
       SBK_LAUNCH(softmax_prob_kernel, dim3(n), dim3(256), 0, st, (const float*)d.logits, bb.am_max, W->vocab, cfg->probe_token);
       SBK_LAUNCH(probe_pick_kernel, dim3(sbk::cdiv(B, 256)), dim3(256), 0, st, (const float*)bb.am_max, cfg->out_probe, B, beam);
     }
-    if (cfg->temperature_post)  // Whisper: log_softmax(logits + masks) / temperature (seq2seq.py:2176-2192)
-      SBK_TRY(sbk::log_softmax_rows(d.logits, bb.am, n, V, 1.0f, attn_w / cfg->temperature, st, cfg->logit_bias,
-                                    step == 0 ? cfg->first_bias : nullptr));
-    else
-      SBK_TRY(sbk::log_softmax_rows(d.logits, bb.am, n, V, cfg->temperature, attn_w, st, cfg->logit_bias,
-                                    step == 0 ? cfg->first_bias : nullptr));
-    if (cfg->using_eos_threshold) SBK_TRY(sbk::row_max(bb.am, bb.am_max, n, V, st));
+    // scoring: one fused pass per hypothesis row (score_topk_row_kernel) unless the beam / vocabulary exceed its
+    // register lists or CTC is a PARTIAL scorer (its k-th-largest mask needs the whole row first)
+    const bool fused = sbk::g_score_fused && beam <= kMaxBeam && V <= 256 * 32 && !(ctc && cfg->ctc_candidates > 0);
+    // Whisper: log_softmax(logits + masks) / temperature (seq2seq.py:2176-2192); otherwise log_softmax(logits / temperature)
+    const float ls_temp = cfg->temperature_post ? 1.0f : cfg->temperature;
+    const float ls_w = cfg->temperature_post ? attn_w / cfg->temperature : attn_w;
+    const float* first_bias = step == 0 ? cfg->first_bias : nullptr;
+    if (!fused) {
+      SBK_TRY(sbk::log_softmax_rows(d.logits, bb.am, n, V, ls_temp, ls_w, st, cfg->logit_bias, first_bias));
+      if (cfg->using_eos_threshold) SBK_TRY(sbk::row_max(bb.am, bb.am_max, n, V, st));
+    }
     const int eos_floor = step < cfg->min_steps;
     if (LM) {  // TransformerLMScorer.score (scorer.py:510-543): the prefix is the decoder's own token history
       SBK_TRY(lm_step(LM, lb, bb.s.tokens[cur], bb.s.kv_slot[cur], bb.s.seq[cur], Lmax, 1, cfg->bos, step, n, Lmax, st));
@@ -1224,7 +1450,8 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
       if (!psi_aside)
         SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[cur], bb.s.tokens[cur], enc_len, bb.psi, B, T, V, beam, step,
                                   cfg->blank, cfg->eos, st, win, window));
-      if (cfg->ctc_candidates > 0) {  // CTC as a partial scorer: only the top candidates of every hypothesis are scored
+      if (fused) {  // (combined inside score_topk_row_kernel)
+      } else if (cfg->ctc_candidates > 0) {  // CTC as a partial scorer: only the top candidates of every hypothesis are scored
         SBK_TRY(sbk::am_only(bb.am, bb.comb, n, V, cfg->eos, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
                              cfg->minus_inf, bb.am_max, extra, st, cfg->utt_min_steps, beam, step));
         SBK_TRY(sbk::ctc_partial_combine(bb.comb, bb.topk_val, bb.psi, bb.psi_prev[cur], n, V, cfg->ctc_candidates,
@@ -1234,14 +1461,27 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
                                  cfg->ctc_weight, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
                                  cfg->minus_inf, extra, st, cfg->utt_min_steps, beam, step));
       }
-    } else {
+    } else if (!fused) {
       SBK_TRY(sbk::am_only(bb.am, bb.comb, n, V, cfg->eos, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
                            cfg->minus_inf, bb.am_max, extra, st, cfg->utt_min_steps, beam, step));
     }
     const float norm = cfg->length_normalization ? (float)(step + 1) : 0.0f;
     const int32_t* sp = sbk::g_step_ptr;  // a local: launch arguments must not name the thread_local itself
     const int32_t* umax = cfg->utt_max_steps;
-    if (beam > kMaxBeam) {
+    if (fused) {
+      sbk::ProfScope prof("score_topk", 8.0 * n * V, (ctc ? 12.0 : 8.0) * n * V, st);
+      ScoreArgs a{d.logits, cfg->logit_bias, first_bias, bb.am, ctc ? bb.psi : nullptr, ctc ? bb.psi_prev[cur] : nullptr,
+                  extra, bb.s.seq_scores, bb.topk_val, bb.topk_idx, sp, cfg->utt_min_steps, umax, V, beam, step,
+                  cfg->min_steps, eos_floor, cfg->using_eos_threshold, cfg->eos, cfg->blank, 1.0f / ls_temp, ls_w,
+                  cfg->ctc_weight, cfg->eos_threshold, cfg->minus_inf, norm};
+      if (V <= 256 * 4)
+        SBK_LAUNCH(score_topk_row_kernel<4>, dim3(n), dim3(256), 0, st, a);
+      else if (V <= 256 * 20)
+        SBK_LAUNCH(score_topk_row_kernel<20>, dim3(n), dim3(256), 0, st, a);
+      else
+        SBK_LAUNCH(score_topk_row_kernel<32>, dim3(n), dim3(256), 0, st, a);
+      // (the merge of the rows' winners rides in front of the bookkeeping: beam_merge_update_kernel below)
+    } else if (beam > kMaxBeam) {
       sbk::ProfScope prof("beam_topk_large", 10.0 * n * V, 20.0 * n * V, st);
       SBK_LAUNCH(beam_topk_large_kernel, dim3(B), dim3(1024), 0, st, (const float*)bb.comb,
                  (const float*)bb.s.seq_scores, bb.s.cand_val, bb.s.cand_idx, V, beam, norm, sp, step, umax);
@@ -1250,13 +1490,18 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
       SBK_LAUNCH(beam_topk_stage1_kernel, dim3(kTopkChunks, B), dim3(256), 0, st, (const float*)bb.comb,
                  (const float*)bb.s.seq_scores, bb.topk_val, bb.topk_idx, V, beam, norm, sp, step, umax);
       SBK_LAUNCH(beam_topk_stage2_kernel, dim3(B), dim3(256), 0, st, (const float*)bb.topk_val,
-                 (const int32_t*)bb.topk_idx, bb.s.cand_val, bb.s.cand_idx, beam, sp, step, umax);
+                 (const int32_t*)bb.topk_idx, bb.s.cand_val, bb.s.cand_idx, beam, sp, step, umax, kTopkChunks);
     }
     SBK_TRY(sbk::launch_status("beam_topk"));
     {
       sbk::ProfScope prof("beam_update", 0.0, 24.0 * n * (step + 1), st);
-      SBK_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 0, st, bb.s, (const float*)bb.am, cur, step, V, beam, Lmax,
-                 cfg->eos, cfg->length_normalization, sp, umax);
+      if (fused)
+        SBK_LAUNCH(beam_merge_update_kernel, dim3(B), dim3(256), 0, st, bb.s, (const float*)bb.topk_val,
+                   (const int32_t*)bb.topk_idx, (const float*)bb.am, cur, step, V, beam, Lmax, cfg->eos,
+                   cfg->length_normalization, sp, umax, beam);
+      else
+        SBK_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 0, st, bb.s, (const float*)bb.am, cur, step, V, beam, Lmax,
+                   cfg->eos, cfg->length_normalization, sp, umax);
     }
     SBK_TRY(sbk::launch_status("beam_update"));
     // survivors' CTC state, then the next step's psi -- beside the next decoder step (with a device-side

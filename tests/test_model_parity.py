@@ -806,3 +806,90 @@ def test_search_projections_on_the_split_operand_kernel(backend):
     assert got[0] == hyps
     odd = build_asr(tiny, vocab=50, seed=9, beam_size=4, ctc_weight=0.4, device=str(dev))  # 50 % 4 != 0: rows are not whole vectors
     assert not odd.mods.decoder._handle().W.seq_w3
+
+
+@pytest.mark.parametrize("tag", ["tiny_ctc", "tiny_noctc", "tiny_lm_ctc"])
+def test_fused_scoring_equals_separate_kernels(backend, tag):
+    """The step's scoring as ONE pass per hypothesis row (csrc/search.hip:score_topk_row_kernel: log-softmax, eos rules,
+    scorer combination, candidate values and the row's top-`beam` from registers; the default) against the launches it
+    replaces (log_softmax_row / row_max / ctc_combine or am_only / beam_topk_stage1; knob 40 = 0): every expression and
+    reduction order is the same, so hypotheses, scores and per-token log-probs must be IDENTICAL, bit for bit -- with
+    the CTC scorer, with the eos threshold and without a scorer, with the LM scorer in front of CTC, for top-k lists
+    and in a grouped search with per-utterance step limits."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import (CTCScorer, S2STransformerBeamSearcher, ScorerBuilder, TransformerLMScorer)
+
+    g, mods = build(tag if tag != "tiny_lm_ctc" else "tiny_ctc", dev)
+    beam, eos_thr = int(g["cfg"][6]), bool(g["cfg"][7])
+    ctc_w, max_ratio, min_ratio = [float(v) for v in g["cfgf"]]
+    wl = torch.from_numpy(g["wav_lens"]).to(dev)
+    enc = torch.from_numpy(g["enc_out"]).to(dev)
+    full, weights = [], {}
+    if tag == "tiny_lm_ctc":
+        from speechbrain_amd.lobes.models.transformer.TransformerLM import TransformerLM
+
+        torch.manual_seed(3)
+        lm = TransformerLM(vocab=int(g["cfg"][5]), d_model=32, nhead=2, num_encoder_layers=2, num_decoder_layers=0,
+                           d_ffn=64, dropout=0.0, activation=torch.nn.GELU, normalize_before=False).to(dev).eval()
+        full.append(TransformerLMScorer(language_model=lm, temperature=1.3))
+        weights["transformerlm"] = 0.5
+    if ctc_w > 0:
+        full.append(CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2))
+        weights["ctc"] = ctc_w
+    scorer = ScorerBuilder(full_scorers=full, weights=weights) if full else None
+
+    def run(**kw):
+        bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                        min_decode_ratio=min_ratio, max_decode_ratio=max_ratio, beam_size=beam,
+                                        using_eos_threshold=eos_thr, length_normalization=True, scorer=scorer, **kw)
+        with torch.no_grad():
+            return bs(enc, wl)
+
+    lib = nat.load()
+    out = {}
+    try:
+        for fused in (1, 0):
+            lib.sbk_prof_set_knob(40, fused)
+            out[fused] = (run(), run(return_topk=True, topk=min(3, beam)), run(temperature=1.7))
+    finally:
+        lib.sbk_prof_set_knob(40, 1)
+    for a, b in zip(out[1], out[0]):
+        for x, y in zip(a, b):
+            if torch.is_tensor(x):
+                assert torch.equal(x.cpu(), y.cpu())
+            else:
+                assert x == y
+    if tag == "tiny_ctc":  # (the default path against the reference's own result)
+        assert out[1][0][0] == hyps_of(g["beam_hyps"])
+
+
+@pytest.mark.parametrize("vocab", [1300, 5300])
+def test_fused_scoring_large_vocabulary(backend, vocab):
+    """The register-list widths the recipe sizes need (20 entries per thread up to V = 5 120, 32 up to 8 192; the golden
+    models' vocabularies fit 4): beam 10 + CTC + eos threshold on a random model, fused pass against separate kernels,
+    bit for bit."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
+    from speechbrain_amd.inference.builders import build_modules
+
+    torch.manual_seed(11)
+    m = build_modules(dict(d_model=32, nhead=2, d_ffn=64, n_enc=1, n_dec=2, n_fft=512, win_length=32), vocab=vocab)
+    mods = torch.nn.ModuleDict({k: m[k] for k in ("Transformer", "seq_lin", "ctc_lin")}).to(dev).eval()
+    enc = (torch.randn(3, 24, 32, generator=torch.Generator().manual_seed(2)) * 1.5).to(dev)
+    wl = torch.tensor([1.0, 0.7, 0.9]).to(dev)
+    scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)], weights={"ctc": 0.4})
+    bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                    min_decode_ratio=0.0, max_decode_ratio=0.3, beam_size=10, using_eos_threshold=True,
+                                    length_normalization=True, scorer=scorer, return_topk=True, topk=4)
+    lib = nat.load()
+    out = {}
+    try:
+        for fused in (1, 0):
+            lib.sbk_prof_set_knob(40, fused)
+            with torch.no_grad():
+                out[fused] = bs(enc, wl)
+    finally:
+        lib.sbk_prof_set_knob(40, 1)
+    for x, y in zip(out[1], out[0]):
+        assert torch.equal(x.cpu(), y.cpu()) if torch.is_tensor(x) else x == y
+    assert int(out[1][0].max()) > 2  # (something was decoded)
