@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SBK_ABI_VERSION 7
+#define SBK_ABI_VERSION 8
 
 typedef void* sbk_stream_t; /* hipStream_t */
 
@@ -195,6 +195,12 @@ int sbk_gemm_nt_f32x3(const float* A, int lda, const uint16_t* W3, const float* 
  *   (PositionalwiseFeedForward, nnet/attention.py:941-945: linear -> activation -> linear without an fp32 round trip).
  *   Needs the stream workspace when the launch has more tiles than CUs. */
 size_t sbk_x3p_panel_bytes(int rows, int K);
+/* ABI 8: y = act(LayerNorm(x)) (nn.LayerNorm of Conformer.py:129,155,310,318 / attention.py:915) written DIRECTLY as the
+ * panel image of the [rows, d] result, i.e. as the A operand of the sbk_gemm_nt_x3p that consumes it (d % 16 == 0,
+ * d <= 2048; padding rows of the last 64-row block are written as zeros).  Same statistics as sbk_layernorm_f32 (two-pass
+ * mean / variance in fp32); split(LayerNorm) is exact, so the contraction sees the fp32 values. */
+int sbk_layernorm_x3p(const float* x, const float* gamma, const float* beta, uint16_t* P, int rows, int d, float eps,
+                      int act, sbk_stream_t stream);
 int sbk_split_x3p(const float* X, int ldx, uint16_t* P, int rows, int K, sbk_stream_t stream);
 int sbk_gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, const float* residual, int ldr, float* C,
                     int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, const int32_t* seq_len,

@@ -365,9 +365,9 @@ __global__ void __launch_bounds__(256) ctc_combine_kernel(CtcStepArgs a, const f
     if (floor) v = a.minus_inf;
     if (a.use_eos_threshold && !(v > a.eos_threshold * am_max[n])) v = a.minus_inf;
   }
-  if (extra) v += extra[(size_t)n * a.V + c];  // full scorers listed before "ctc" (already weighted)
+  if (extra) v = sbk::add_rn(v, extra[(size_t)n * a.V + c]);  // full scorers listed before "ctc" (already weighted)
   if (c == a.blank) v = kNeg;
-  comb[(size_t)n * a.V + c] = fmaf(psi[(size_t)n * a.V + c] - psi_prev[n], a.weight, v);  // (what hipcc contracts v + d * w to)
+  comb[(size_t)n * a.V + c] = sbk::score_ctc(v, psi[(size_t)n * a.V + c], psi_prev[n], a.weight);
 }
 
 // ---- the forward recurrence as a prefix scan ---------------------------------------------------
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(256) am_only_kernel(const float* __restrict__ 
     if (utt_min ? step < utt_min[n / beam] : (step_ptr ? step < min_steps : eos_floor)) v = minus_inf;
     if (use_thr && !(v > thr * am_max[n])) v = minus_inf;
   }
-  if (extra) v += extra[(size_t)n * V + c];
+  if (extra) v = sbk::add_rn(v, extra[(size_t)n * V + c]);
   comb[(size_t)n * V + c] = v;
 }
 

@@ -1103,7 +1103,7 @@ __global__ void __launch_bounds__(256) log_softmax_row_kernel(const float* __res
   const float* xr = x + (size_t)blockIdx.x * V;
   float* orow = out + (size_t)blockIdx.x * V;
   float m = -INFINITY;
-  auto at = [&](int c) SBK_INLINE_LAMBDA { return (xr[c] + (bias ? bias[c] : 0.0f) + (bias2 ? bias2[c] : 0.0f)) * inv_temp; };
+  auto at = [&](int c) SBK_INLINE_LAMBDA { return sbk::ls_logit(xr[c], bias ? bias[c] : 0.0f, bias2 ? bias2[c] : 0.0f, inv_temp); };
   for (int c = tid; c < V; c += 256) m = fmaxf(m, at(c));
   m = sbk::wave_max(m);
   if ((tid & 63) == 0) red[tid >> 6] = m;
@@ -1111,12 +1111,12 @@ __global__ void __launch_bounds__(256) log_softmax_row_kernel(const float* __res
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
   float s = 0.0f;
-  for (int c = tid; c < V; c += 256) s += expf(at(c) - m);
+  for (int c = tid; c < V; c += 256) s += expf(sbk::sub_rn(at(c), m));
   s = sbk::wave_sum(s);
   if ((tid & 63) == 0) red[tid >> 6] = s;
   __syncthreads();
   const float lse = m + logf((red[0] + red[1]) + (red[2] + red[3]));
-  for (int c = tid; c < V; c += 256) orow[c] = w * (at(c) - lse);
+  for (int c = tid; c < V; c += 256) orow[c] = sbk::ls_out(at(c), lse, w);
 }
 
 }  // namespace

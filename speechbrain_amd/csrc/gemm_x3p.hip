@@ -466,7 +466,7 @@ int launch_x3p(const X3pArgs& a0, hipStream_t st) {
 }  // namespace
 
 namespace sbk {
-int g_x3p_tile = 0;  // tuning knob (key 39): 0 = by shape, 1 = 256 x 256, 2 = 256 x 128
+int g_x3p_tile = 0;  // tuning knob (key 39): 0 / 2 = 256 x 128 (measured faster on every encoder shape: profiles/r04_d_*), 1 = 256 x 256
 
 int gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, const float* R, int ldr, float* C, int ldc,
                 uint16_t* PC, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st) {
@@ -483,7 +483,7 @@ int gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, const
   ProfScope prof("gemm_nt_x3p", flops, bytes, st);
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
   const int cus = device_cus();
-  const bool big = g_x3p_tile == 1 || (g_x3p_tile == 0 && t256 >= cus);
+  const bool big = g_x3p_tile == 1;
   if (big) return launch_x3p<4, 2, 2, 4>(a, st);
   return launch_x3p<4, 2, 2, 2>(a, st);
 }

@@ -198,6 +198,45 @@ __device__ __forceinline__ int atomic_load_agent(const int* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Products / sums / differences that the compiler must NOT contract into a fused multiply-add with a neighbouring
+// operation: two kernels that are required to produce bit-identical values (the fused scoring pass and the launches it
+// replaces) write the shared arithmetic with these, so the result does not depend on what each kernel's optimiser fuses.
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+
+// Arg-max over the wave: on return every lane holds the largest v of the wave and, among the lanes that supplied it, the
+// smallest i (candidate ids are unique, so exactly one lane recognises its own pair).  All 64 lanes must be active.  Two
+// reductions on the VALU (DPP lane selects inside each row of 16, v_readlane across the four rows) instead of 2 x 6
+// ds_bpermute round trips through the LDS crossbar per round of a selection loop.
+template <int CTRL>
+__device__ __forceinline__ int dpp_move_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float wave_max_valu(float v) {
+  v = fmaxf(v, dpp_move<0xB1>(v));
+  v = fmaxf(v, dpp_move<0x4E>(v));
+  v = fmaxf(v, dpp_move<0x141>(v));
+  v = fmaxf(v, dpp_move<0x140>(v));
+  const int b = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ int wave_min_valu(int v) {
+  v = min(v, dpp_move_i<0xB1>(v));
+  v = min(v, dpp_move_i<0x4E>(v));
+  v = min(v, dpp_move_i<0x141>(v));
+  v = min(v, dpp_move_i<0x140>(v));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+  const float m = wave_max_valu(v);
+  i = wave_min_valu(v == m ? i : 0x7fffffff);
+  v = m;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);

@@ -32,6 +32,20 @@ extern int g_cross_fused_merge;
 extern int g_self_group_off;
 extern int g_score_fused;  // key 40: 1 (default) = the step's scoring as one pass per hypothesis row (csrc/search.hip)
 constexpr float kCtcNeg = -1e20f;  // the CTC scorer's finite "log 0" (ctc.py:150, scorer.py:1250)
+// The arithmetic of a decoding step's scoring, shared by the separate kernels (log_softmax_row / ctc_combine / am_only /
+// beam_topk_stage1) and the fused pass (score_topk_row_kernel).  Written with explicitly rounded operations so that
+// the two paths cannot differ by what each kernel's optimiser contracts into a fused multiply-add.
+__device__ __forceinline__ float ls_logit(float x, float b1, float b2, float inv_temp) {  // (logit + masks) / temperature
+  return mul_rn(add_rn(add_rn(x, b1), b2), inv_temp);
+}
+__device__ __forceinline__ float ls_out(float v, float lse, float w) { return mul_rn(w, sub_rn(v, lse)); }  // w * log-softmax
+__device__ __forceinline__ float score_ctc(float v, float psi, float psi_prev, float weight) {  // scorer.py:1248-1253
+  return fmaf(sub_rn(psi, psi_prev), weight, v);
+}
+__device__ __forceinline__ float score_cand(float seq, float comb, float norm) {  // seq2seq.py:1225-1240
+  const float x = add_rn(seq, comb);
+  return norm > 0.0f ? x / norm : x;  // length normalisation divides, like seq2seq.py:1232-1233
+}
 int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
                int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, float* ws,
                size_t ws_floats, hipStream_t st);

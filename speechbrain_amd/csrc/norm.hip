@@ -75,6 +75,77 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   }
 }
 
+// y = act(LayerNorm(x)) written as the PANEL image of the [rows, d] result (csrc/gemm_x3p.hip: [rows/64][d/16][3 pieces]
+// [2 k-halves][64 rows][8 k] bf16, x = hi + mid + lo exactly): the A operand of sbk_gemm_nt_x3p made by its producer --
+// the contraction then reads 6 B per element once instead of the fp32 row being written, re-read and split by a pass of
+// its own.  A wave = one row, a lane = NV runs of 8 consecutive k (one 16-byte slot of a chunk per piece); a workgroup =
+// 8 consecutive rows, i.e. the eight 16-byte slots of every 128-byte line of the image are written by the same
+// workgroup at the same time (they merge in its XCD's L2).  Rows past `rows` up to the next multiple of 64 are written
+// as zeros (the contraction may read them).
+template <int NV>
+__global__ void __launch_bounds__(512) layernorm_x3p_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, uint4* __restrict__ P, int rows,
+                                                            int d, float eps, int act) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 6);
+  const bool live = row < rows;
+  const float* xr = x + (size_t)(live ? row : rows - 1) * d;  // padding rows shadow the last row: shuffles stay full-width
+  const int nu = d >> 3, KB = d >> 4;
+  float v[NV][8];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int u = lane + 64 * i;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (u < nu) {
+      a = *reinterpret_cast<const float4*>(xr + u * 8);
+      b = *reinterpret_cast<const float4*>(xr + u * 8 + 4);
+    }
+    v[i][0] = a.x, v[i][1] = a.y, v[i][2] = a.z, v[i][3] = a.w, v[i][4] = b.x, v[i][5] = b.y, v[i][6] = b.z, v[i][7] = b.w;
+    s += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+  }
+  const float mean = sbk::wave_sum(s) / (float)d;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nu) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = (v[i][e] - mean) * (v[i][e] - mean);
+      q += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+  const float rstd = rsqrtf(sbk::wave_sum(q) / (float)d + eps);
+  const int rb = row >> 6, rr = row & 63;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int u = lane + 64 * i;
+    if (u >= nu) continue;
+    float o[8];
+    if (live) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + u * 8), g1 = *reinterpret_cast<const float4*>(gamma + u * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(beta + u * 8), b1 = *reinterpret_cast<const float4*>(beta + u * 8 + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = act_f((v[i][e] - mean) * rstd * g[e] + bb[e], act);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = 0.0f;
+    }
+    unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {  // x = hi + mid + lo exactly (split_x3p_kernel's arithmetic)
+      hi[p] = sbk::bf16_pair(o[2 * p], o[2 * p + 1]);
+      const float r0 = o[2 * p] - __uint_as_float(hi[p] << 16), r1 = o[2 * p + 1] - __uint_as_float(hi[p] & 0xffff0000u);
+      mi[p] = sbk::bf16_pair(r0, r1);
+      lo[p] = sbk::bf16_pair(r0 - __uint_as_float(mi[p] << 16), r1 - __uint_as_float(mi[p] & 0xffff0000u));
+    }
+    uint4* dst = P + ((size_t)(rb * KB + (u >> 1)) * 6 + (u & 1)) * 64 + rr;  // chunk (rb, kb, piece 0, half), slot rr
+    dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    dst[128] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
+    dst[256] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
 // Any d (scalar loads, three passes over an L1/L2-resident row).
 __global__ void __launch_bounds__(256) layernorm_generic_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ gamma,
@@ -251,6 +322,28 @@ extern "C" int sbk_layernorm_bf16o(const float* x, const float* gamma, const flo
   SBK_REQUIRE(x && gamma && beta && y, "layernorm_bf16o: null operand");
   SBK_REQUIRE(rows >= 0 && d > 0, "layernorm_bf16o: bad shape rows=%d d=%d", rows, d);
   return sbk::layernorm_any(x, gamma, beta, nullptr, y, rows, d, eps, act, sbk::as_stream(stream));
+}
+
+extern "C" int sbk_layernorm_x3p(const float* x, const float* gamma, const float* beta, uint16_t* P, int rows, int d,
+                                 float eps, int act, sbk_stream_t stream) {
+  if (rows == 0) return 0;
+  SBK_REQUIRE(x && gamma && beta && P, "layernorm_x3p: null operand");
+  SBK_REQUIRE(rows > 0 && d >= 16 && d % 16 == 0 && d <= 2048, "layernorm_x3p: rows=%d d=%d (d %% 16 == 0, d <= 2048)", rows, d);
+  SBK_REQUIRE(sbk::aligned16(x) && sbk::aligned16(gamma) && sbk::aligned16(beta) && sbk::aligned16(P),
+              "layernorm_x3p: operands must be 16-byte aligned");
+  hipStream_t st = sbk::as_stream(stream);
+  const int rows64 = ((rows + 63) / 64) * 64;
+  sbk::ProfScope prof("layernorm_x3p", 8.0 * rows * d, (4.0 * rows + 6.0 * rows64) * d, st);
+  uint4* P4 = reinterpret_cast<uint4*>(P);
+  const dim3 grid(rows64 / 8), block(512);
+  if (d <= 512) {
+    SBK_LAUNCH(layernorm_x3p_kernel<1>, grid, block, 0, st, x, gamma, beta, P4, rows, d, eps, act);
+  } else if (d <= 1024) {
+    SBK_LAUNCH(layernorm_x3p_kernel<2>, grid, block, 0, st, x, gamma, beta, P4, rows, d, eps, act);
+  } else {
+    SBK_LAUNCH(layernorm_x3p_kernel<4>, grid, block, 0, st, x, gamma, beta, P4, rows, d, eps, act);
+  }
+  return sbk::launch_status("sbk_layernorm_x3p");
 }
 
 extern "C" size_t sbk_input_norm_stats_workspace_bytes(int B, int C) {

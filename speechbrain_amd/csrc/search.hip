@@ -180,15 +180,7 @@ __device__ __forceinline__ void block_topk(int total, int k, float* out_val, int
     float v = hp < kMaxBeam ? lv[hp][tid] : -INFINITY;
     int i = hp < kMaxBeam ? li[hp][tid] : INT_MAX;
     const int mine = i;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      const float ov = sbk::shfl_xor(v, m);
-      const int oi = sbk::shfl_xor(i, m);
-      if (better(ov, oi, v, i)) {
-        v = ov;
-        i = oi;
-      }
-    }
+    sbk::wave_argmax(v, i);
     if (lane == 0) {
       wv[wave][r] = v;
       wi[wave][r] = i;
@@ -206,15 +198,7 @@ __device__ __forceinline__ void block_topk(int total, int k, float* out_val, int
     for (int r = 0; r < k; ++r) {
       float bv = v;
       int bi = i;
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) {
-        const float ov = sbk::shfl_xor(bv, m);
-        const int oi = sbk::shfl_xor(bi, m);
-        if (better(ov, oi, bv, bi)) {
-          bv = ov;
-          bi = oi;
-        }
-      }
+      sbk::wave_argmax(bv, bi);
       if (lane == 0) {
         out_val[r] = bv;
         out_idx[r] = bi;
@@ -247,8 +231,7 @@ __global__ void __launch_bounds__(256) beam_topk_stage1_kernel(const float* __re
   block_topk(n, beam, pval + ((size_t)b * kTopkChunks + ch) * kMaxBeam, pidx + ((size_t)b * kTopkChunks + ch) * kMaxBeam,
              [&](int e, float& v, int& id) {
                id = e0 + e;
-               const float x = sq[id / V] + cb[id];
-               v = norm > 0.0f ? x / norm : x;  // length normalisation divides, like seq2seq.py:1232-1233
+               v = sbk::score_cand(sq[id / V], cb[id], norm);
              });
 }
 
@@ -324,7 +307,7 @@ __global__ void __launch_bounds__(256) score_topk_row_kernel(ScoreArgs a) {
     const int c = tid + 256 * i;
     x[i] = -INFINITY;
     if (c < V) {
-      x[i] = (a.logits[ro + c] + (a.bias ? a.bias[c] : 0.0f) + (a.bias2 ? a.bias2[c] : 0.0f)) * a.inv_temp;
+      x[i] = sbk::ls_logit(a.logits[ro + c], a.bias ? a.bias[c] : 0.0f, a.bias2 ? a.bias2[c] : 0.0f, a.inv_temp);
       m = fmaxf(m, x[i]);
     }
   }
@@ -336,7 +319,7 @@ __global__ void __launch_bounds__(256) score_topk_row_kernel(ScoreArgs a) {
   float s = 0.0f;
 #pragma unroll
   for (int i = 0; i < NPT; ++i)
-    if (tid + 256 * i < V) s += expf(x[i] - m);
+    if (tid + 256 * i < V) s += expf(sbk::sub_rn(x[i], m));
   s = sbk::wave_sum(s);
   if (lane == 0) red[wave] = s;
   __syncthreads();
@@ -347,7 +330,7 @@ __global__ void __launch_bounds__(256) score_topk_row_kernel(ScoreArgs a) {
   for (int i = 0; i < NPT; ++i) {
     const int c = tid + 256 * i;
     if (c < V) {
-      x[i] = a.w * (x[i] - lse);
+      x[i] = sbk::ls_out(x[i], lse, a.w);
       a.am[ro + c] = x[i];
       am_max = fmaxf(am_max, x[i]);
     }
@@ -377,13 +360,12 @@ __global__ void __launch_bounds__(256) score_topk_row_kernel(ScoreArgs a) {
       if (floor) v = a.minus_inf;
       if (a.use_thr && !(v > a.thr * am_max)) v = a.minus_inf;
     }
-    if (a.extra) v += a.extra[ro + c];
+    if (a.extra) v = sbk::add_rn(v, a.extra[ro + c]);
     if (a.psi) {
       if (c == a.blank) v = sbk::kCtcNeg;
-      v = fmaf(a.psi[ro + c] - pp, a.ctc_weight, v);
+      v = sbk::score_ctc(v, a.psi[ro + c], pp, a.ctc_weight);
     }
-    const float cand = sq + v;
-    v = norm > 0.0f ? cand / norm : cand;  // length normalisation divides, like seq2seq.py:1232-1233
+    v = sbk::score_cand(sq, v, norm);
     x[i] = v;
     if (v != v) {
       dead |= 1u << i;
@@ -401,15 +383,7 @@ __global__ void __launch_bounds__(256) score_topk_row_kernel(ScoreArgs a) {
   for (int r = 0; r < k; ++r) {
     float v = bv;
     int i2 = bi;
-#pragma unroll
-    for (int msk = 32; msk >= 1; msk >>= 1) {
-      const float ov = sbk::shfl_xor(v, msk);
-      const int oi = sbk::shfl_xor(i2, msk);
-      if (better(ov, oi, v, i2)) {
-        v = ov;
-        i2 = oi;
-      }
-    }
+    sbk::wave_argmax(v, i2);
     if (lane == 0) {
       wv[wave][r] = v;
       wi[wave][r] = i2;
@@ -441,15 +415,7 @@ __global__ void __launch_bounds__(256) score_topk_row_kernel(ScoreArgs a) {
     for (int r = 0; r < k; ++r) {
       float wbv = v;
       int wbi = i2;
-#pragma unroll
-      for (int msk = 32; msk >= 1; msk >>= 1) {
-        const float ov = sbk::shfl_xor(wbv, msk);
-        const int oi = sbk::shfl_xor(wbi, msk);
-        if (better(ov, oi, wbv, wbi)) {
-          wbv = ov;
-          wbi = oi;
-        }
-      }
+      sbk::wave_argmax(wbv, wbi);
       if (lane == 0) {
         ov_[r] = wbv;
         oi_[r] = wbi;

@@ -100,6 +100,7 @@ def _declare(lib):
         "sbk_gemm_nt_f32x3": ([p, i, p, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_x3p_panel_bytes": ([i, i], ctypes.c_size_t),
         "sbk_split_x3p": ([p, i, p, i, i, p], c_int),
+        "sbk_layernorm_x3p": ([p, p, p, p, i, i, f, i, p], c_int),
         "sbk_gemm_nt_x3p": ([p, p, p, p, i, p, i, p, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_bf16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_f16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
@@ -158,7 +159,7 @@ def load(path: Optional[str] = None):
         )
     lib = ctypes.CDLL(path)
     EXPORTS = tuple(_declare(lib).keys())
-    if lib.sbk_abi_version() != 7:
+    if lib.sbk_abi_version() != 8:
         raise SbkError(f"ABI version mismatch: {lib.sbk_abi_version()}")
     _lib = lib
     return lib
@@ -259,7 +260,7 @@ F32X3 = os.environ.get("SBK_F32X3", "1") != "0"
 F32X3_MIN_ROWS = int(os.environ.get("SBK_F32X3_MIN_ROWS", "2048"))
 F32X3_MIN_TILES = int(os.environ.get("SBK_F32X3_MIN_TILES", "192"))
 # ... and, with the activation operand pre-split as well, through sbk_gemm_nt_x3p (csrc/gemm_x3p.hip: 256-wide tiles)
-X3P = os.environ.get("SBK_X3P", "0") != "0"  # (off until its first GPU measurement)
+X3P = os.environ.get("SBK_X3P", "1") != "0"
 X3P_MIN_TILES = int(os.environ.get("SBK_X3P_MIN_TILES", "96"))
 
 
@@ -285,6 +286,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_
     With ``seq_len`` (int32 [batch]) rows are [batch][rows_per_seq] and the rows past each
     sequence's length contribute 0 before the residual is added."""
     lib = load()
+    if isinstance(a, Panel):  # the producer wrote the operand's panel image (layernorm_x3p, gemm_nt_x3p(panel_out=True))
+        return gemm_nt_x3p(a, w, bias, residual, act, alpha, out=out, seq_len=seq_len, rows_per_seq=rows_per_seq)
     K = a.shape[-1]
     a2 = a.reshape(-1, K)
     M, N = a2.shape[0], w.shape[0]
@@ -369,6 +372,28 @@ def split_x3p(x: torch.Tensor, rows: Optional[int] = None, K: Optional[int] = No
         rows, ldx = x.shape[0], K
     out = panel_empty(rows, K, x.device, lead)
     _chk(lib.sbk_split_x3p(_p(x), int(ldx), _p(out.data), rows, K, _stream(x)), "sbk_split_x3p")
+    return out
+
+
+def panel_for(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """True when the contraction x[..., K] @ w^T takes the both-operands-pre-split route on the fp32 path, i.e. when the
+    kernel that PRODUCES x should write it as a Panel (layernorm_x3p, gemm_nt_x3p(panel_out=True)) instead of fp32."""
+    K = x.shape[-1] if not isinstance(x, Panel) else x.K
+    M = (x.numel() // K) if not isinstance(x, Panel) else x.rows
+    return precision() == "fp32" and x3p_ok(M, K, w)
+
+
+def layernorm_x3p(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, act=ACT_NONE) -> Panel:
+    """``layernorm`` written directly as the panel image of its result (sbk_layernorm_x3p): the A operand of the
+    gemm_nt that follows, without the fp32 round trip and the split pass."""
+    lib = load()
+    d = gamma.numel()
+    x2 = x.reshape(-1, d)
+    _dev_ok(x2, gamma, beta)
+    _f32(x2)
+    out = panel_empty(x2.shape[0], d, x.device, tuple(x.shape[:-1]))
+    _chk(lib.sbk_layernorm_x3p(_p(x2), _p(gamma), _p(beta), _p(out.data), x2.shape[0], d, float(eps), act, _stream(x2)),
+         "sbk_layernorm_x3p")
     return out
 
 

@@ -812,6 +812,36 @@ def test_gemm_x3p(backend, M, N, K, tile):
         lib.sbk_prof_set_knob(39, 0)
 
 
+@pytest.mark.parametrize("rows,d,act", [(130, 512, 0), (64, 32, 1), (777, 144, 0), (300, 1024, 1), (129, 2048, 0), (5, 16, 0)])
+def test_layernorm_x3p(backend, rows, d, act):
+    """sbk_layernorm_x3p: act(LayerNorm(x)) written directly as the panel image of its result (the A operand of the
+    contraction that consumes it).  The image's three pieces must add up to the fp32 LayerNorm (same two-pass statistics;
+    the lanes hold other elements than in sbk_layernorm_f32, so sums may round differently: 2e-6 relative to the row's
+    largest magnitude), the padding rows of the last 64-row block must be zero, and the contraction fed with the image
+    must match the one fed with split(LayerNorm)."""
+    nat, dev = backend
+    g = torch.Generator().manual_seed(rows + d)
+    x = torch.randn(rows, d, generator=g) * 3.0 + torch.arange(rows)[:, None] * 0.05
+    gamma, beta = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    code = nat.ACT_SWISH if act else nat.ACT_NONE
+    pan = nat.layernorm_x3p(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5, act=code)
+    RB, KB = (rows + 63) // 64, d // 16
+    pieces = (pan.data.cpu().view(torch.int16).to(torch.int32) << 16).view(torch.float32).view(RB, KB, 3, 2, 64, 8)
+    full = pieces.double().sum(2).permute(0, 3, 1, 2, 4).reshape(RB * 64, d).float()
+    ref = F.layer_norm(x.double(), (d,), gamma.double(), beta.double(), 1e-5)
+    ref = (F.silu(ref) if act else ref).float()
+    assert not full[rows:].any()
+    assert float(((full[:rows] - ref).abs() / (ref.abs().amax(1, keepdim=True) + 1.0)).max()) <= 2e-6
+    own = nat.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5, act=code).cpu()
+    assert float(((full[:rows] - own).abs() / (own.abs().amax(1, keepdim=True) + 1.0)).max()) <= 1e-6
+    assert pan.rows == rows and pan.K == d and pan.lead == (rows,)
+    if d % 16 == 0 and d >= 32:
+        w = torch.randn(48, d, generator=g).to(dev)
+        a = nat.gemm_nt_x3p(pan, w)
+        b = nat.gemm_nt_x3p(nat.split_x3p(own.to(dev)), w)
+        assert _md(a, b.cpu()) <= 2e-5 * float(own.abs().max()) * d ** 0.5
+
+
 @pytest.mark.parametrize("d_model,nhead,B,T,beam_rows", [(128, 2, 3, 150, 4), (256, 4, 2, 75, 10), (128, 2, 1, 20, 1)])
 def test_cross_attention_lds_dma_variant(backend, d_model, nhead, B, T, beam_rows):
     """csrc/decoder.hip cross_attn_dma_kernel (head_dim 64: LDS-DMA tiles of 16 frames, transposed scores on the matrix

@@ -853,12 +853,12 @@ def test_fused_scoring_equals_separate_kernels(backend, tag):
             out[fused] = (run(), run(return_topk=True, topk=min(3, beam)), run(temperature=1.7))
     finally:
         lib.sbk_prof_set_knob(40, 1)
-    for a, b in zip(out[1], out[0]):
-        for x, y in zip(a, b):
+    for run_no, (a, b) in enumerate(zip(out[1], out[0])):
+        for out_no, (x, y) in enumerate(zip(a, b)):
             if torch.is_tensor(x):
-                assert torch.equal(x.cpu(), y.cpu())
+                assert torch.equal(x.cpu(), y.cpu()), (run_no, out_no, x.cpu(), y.cpu())
             else:
-                assert x == y
+                assert x == y, (run_no, out_no, x, y)
     if tag == "tiny_ctc":  # (the default path against the reference's own result)
         assert out[1][0][0] == hyps_of(g["beam_hyps"])
 
@@ -893,3 +893,39 @@ def test_fused_scoring_large_vocabulary(backend, vocab):
     for x, y in zip(out[1], out[0]):
         assert torch.equal(x.cpu(), y.cpu()) if torch.is_tensor(x) else x == y
     assert int(out[1][0].max()) > 2  # (something was decoded)
+
+
+@pytest.mark.parametrize("tag", ["tiny_ctc", "tiny_noctc"])
+def test_golden_encoder_on_the_panel_route(backend, tag):
+    """The encoder with every eligible contraction on the both-operands-pre-split route (csrc/gemm_x3p.hip; the routing
+    thresholds lowered so that the golden models' small shapes take it): LayerNorms write their result directly as the
+    next contraction's panel operand (sbk_layernorm_x3p), the feed-forward pair hands its hidden layer over as a panel
+    image (no fp32 round trip), the remaining operands are split by sbk_split_x3p -- against the REFERENCE's encoder
+    output, 5e-5 as on the default route."""
+    nat, dev = backend
+    g, mods = build(tag, dev)
+    feats, wl = torch.from_numpy(g["feats"]).to(dev), torch.from_numpy(g["wav_lens"]).to(dev)
+    old = nat.F32X3, nat.X3P, nat.F32X3_MIN_ROWS, nat.X3P_MIN_TILES
+    calls = {"ln": 0, "gemm": 0, "chained": 0}
+    ln0, gemm0 = nat.layernorm_x3p, nat.gemm_nt_x3p
+
+    def ln(*a, **k):
+        calls["ln"] += 1
+        return ln0(*a, **k)
+
+    def gemm(*a, **k):
+        calls["gemm"] += 1
+        calls["chained"] += bool(k.get("panel_out"))
+        return gemm0(*a, **k)
+
+    nat.F32X3, nat.X3P, nat.F32X3_MIN_ROWS, nat.X3P_MIN_TILES = True, True, 1, 1
+    nat.layernorm_x3p, nat.gemm_nt_x3p = ln, gemm
+    try:
+        with torch.no_grad():
+            enc = mods["Transformer"].encode(mods["CNN"](feats), wl)
+    finally:
+        nat.F32X3, nat.X3P, nat.F32X3_MIN_ROWS, nat.X3P_MIN_TILES = old
+        nat.layernorm_x3p, nat.gemm_nt_x3p = ln0, gemm0
+    assert float((enc.cpu() - torch.from_numpy(g["enc_out"])).abs().max()) <= 5e-5
+    n_layers = len(mods["Transformer"].encoder.layers)
+    assert calls["ln"] == 5 * n_layers and calls["chained"] == 2 * n_layers and calls["gemm"] >= 7 * n_layers

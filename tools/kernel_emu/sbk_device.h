@@ -382,6 +382,17 @@ static inline void acquire_agent() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
 static inline int atomic_add_agent(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 static inline void atomic_store_agent(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 static inline int atomic_load_agent(const int* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+static inline float mul_rn(float a, float b) { return a * b; }  // (g++ on x86-64 does not contract without -mfma)
+static inline float add_rn(float a, float b) { return a + b; }
+static inline float sub_rn(float a, float b) { return a - b; }
+static inline void wave_argmax(float& v, int& i) {  // largest v; among the lanes that hold it, the smallest i
+  float m = v;
+  for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, shfl_xor(m, k));
+  int c = v == m ? i : 0x7fffffff;
+  for (int k = 32; k >= 1; k >>= 1) c = std::min(c, shfl_xor(c, k));
+  v = m;
+  i = c;
+}
 static inline float wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
   return v;

@@ -321,6 +321,25 @@ if __name__ == "__main__":
                 nat.gemm_nt(a, w)
             torch.cuda.synchronize()
         sys.exit(0)
+    if "--ln-x3p" in sys.argv:  # LayerNorm written as the next contraction's panel operand vs LayerNorm + split pass
+        def ev_time(fn, n=30):
+            fn(); fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+        for M in (4032, 12800, 24032):
+            x = torch.randn(M, 512, device=dev); g = torch.randn(512, device=dev); b = torch.randn(512, device=dev)
+            t0 = ev_time(lambda: nat.layernorm(x, g, b, 1e-5))
+            y = nat.layernorm(x, g, b, 1e-5)
+            t1 = ev_time(lambda: nat.split_x3p(y))
+            t2 = ev_time(lambda: nat.layernorm_x3p(x, g, b, 1e-5))
+            print(f"ln-x3p M={M} d=512: layernorm {t0:6.1f} us ({8.0*M*512/t0/1e3:5.0f} GB/s) + split {t1:6.1f} us | layernorm_x3p {t2:6.1f} us ({10.0*M*512/t2/1e3:5.0f} GB/s)", flush=True)
+        sys.exit(0)
     if "--x3p" in sys.argv:  # both operands pre-split, panel layout, 256-wide tiles (csrc/gemm_x3p.hip) vs the f32x3 kernel
         def ev_time(fn, n=30):
             fn(); fn()
