@@ -351,10 +351,11 @@ def roofline_entry(name, v, total_ms):
     avg_ms = v["ms"] / max(v["count"], 1)
     if name.startswith(MFMA_KERNELS):
         ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
-        peak = PEAK_F32X3_TFLOPS if name.startswith("gemm_nt_f32x3") else PEAK_MFMA_F32_TFLOPS
+        x3 = name.startswith(("gemm_nt_f32x3", "gemm_nt_x3p"))  # six bf16 partial products per multiply-add: bf16 peak / 6
+        peak = PEAK_F32X3_TFLOPS if x3 else PEAK_MFMA_F32_TFLOPS
         e = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
              "frac": round(ach / peak, 4)}
-        if name.startswith("gemm_nt_f32x3"):
+        if x3:
             e["frac_of_fp32_mfma_peak"] = round(ach / PEAK_MFMA_F32_TFLOPS, 4)  # what the fp32-MFMA kernel it replaced was priced against
             e["peak_note"] = ("fp32-equivalent: 2*M*N*K flops per launch; the kernel forms six bf16 partial products per multiply-add on "
                               "v_mfma_f32_32x32x16_bf16, so its ceiling is the dense bf16 MFMA peak (2 500 TF/s) / 6; "
@@ -510,6 +511,7 @@ def main():
         gc.collect()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
         workers = ConcurrentTranscriber(asr, streams=streams, prioritise_search=not args.no_search_priority, group=group)
         workers.group_encoder = args.group_encoder
         for srch in workers.searchers:
@@ -555,6 +557,7 @@ def main():
             info = {"n_batches": len(plan_["batches"]), "bytes_scattered": plan_["bytes_sent"], "plan_s": round(t_prep, 4),
                     "streams": workers.n, "group": workers.group,
                     "gpu_memory_reserved_gb": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 1),
+                    "gpu_memory_peak_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                     "per_rank_wall_s": [round(w, 4) for w in per_rank_wall],
                     "per_rank_audio_s": [round(sum(seconds[i] for b in plan_["owner"][r] for i in plan_["batches"][b]), 1)
                                          for r in range(world)],
@@ -588,7 +591,8 @@ def main():
                                       "exact three-way operand split (six bf16 partial products per multiply-add, fp32 accumulation: "
                                       "fp32-grade results, sbk_gemm_nt_f32x3)" if native.F32X3 else "fp32 throughout, fp32 MFMA contractions")
                        if args.precision == "fp32" else "opt-in bf16 operands",
-                       "gpu_memory_reserved_gb": {"after_headline_leg": info.get("gpu_memory_reserved_gb")},
+                       "gpu_memory_reserved_gb": {"after_headline_leg": info.get("gpu_memory_reserved_gb"),
+                                                  "peak_allocated_headline_leg": info.get("gpu_memory_peak_allocated_gb")},
                        "step": f"{UTTS_PER_STEP} utterances", "max_batch": args.max_batch,
                        "utterances_total": n_utts, "batches_total": info["n_batches"],
                        "audio_seconds_total": round(total_audio, 1), "weights": "random init, torch.manual_seed(0)",

@@ -137,6 +137,10 @@ int sbk_amplitude_to_db_f32(float* x, float* tile_max, int B, long per_utt, floa
  * y = (x - mean[c]) / max(std[c], eps), x [rows, C]. */
 int sbk_input_norm_global_f32(const float* x, const float* mean, const float* std, float* y, int rows, int C,
                               float eps, sbk_stream_t stream);
+/* ABI 8: the same with avoid_padding_norm=True (features.py:1447-1449): x, y [B,T,C]; the padded frames t >= n_valid[b]
+ * are normalised with mean 0 / std 1, i.e. pass through unchanged. */
+int sbk_input_norm_global_masked_f32(const float* x, const float* mean, const float* std, const int32_t* n_valid, float* y,
+                                     int B, int T, int C, float eps, sbk_stream_t stream);
 
 /* a6: InputNormalization.forward with norm_type="sentence" (per_batch = 0: mean / std of each utterance's own
  * valid frames, features.py:1432-1433,1482-1490) or "batch" (per_batch = 1: of all valid frames of the batch, variance

@@ -1026,6 +1026,16 @@ def golden_input_norm():
                 out[f"y_{norm_type}_{int(std_norm)}_{int(avoid)}"] = y.numpy()
     with torch.no_grad():
         out["y_sentence_nolen"] = InputNormalization(norm_type="sentence").eval()(x).numpy()
+    # global statistics (loaded, eval mode) with and without avoid_padding_norm: padded frames pass through unchanged
+    gm, gs = torch.randn(20, generator=g), torch.rand(20, generator=g) + 0.5
+    gs[3] = 0.0  # (clamped to epsilon)
+    out["glob_mean"], out["glob_std"] = gm.numpy(), gs.numpy()
+    for std_norm in (True, False):
+        for avoid in (False, True):
+            m = InputNormalization(norm_type="global", std_norm=std_norm, avoid_padding_norm=avoid).eval()
+            m.glob_mean, m.glob_std, m.count = gm.clone(), gs.clone(), 1
+            with torch.no_grad():
+                out[f"y_global_{int(std_norm)}_{int(avoid)}"] = m(x, lengths).numpy()
     np.savez_compressed(os.path.join(OUT, "input_norm.npz"), **out)
     print("  cases:", len(out) - 2)
 

@@ -1111,11 +1111,11 @@ __global__ void __launch_bounds__(256) log_softmax_row_kernel(const float* __res
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
   float s = 0.0f;
-  for (int c = tid; c < V; c += 256) s += expf(sbk::sub_rn(at(c), m));
+  for (int c = tid; c < V; c += 256) s = sbk::add_rn(s, expf(sbk::sub_rn(at(c), m)));
   s = sbk::wave_sum(s);
   if ((tid & 63) == 0) red[tid >> 6] = s;
   __syncthreads();
-  const float lse = m + logf((red[0] + red[1]) + (red[2] + red[3]));
+  const float lse = sbk::add_rn(m, logf((red[0] + red[1]) + (red[2] + red[3])));
   for (int c = tid; c < V; c += 256) orow[c] = sbk::ls_out(at(c), lse, w);
 }
 

@@ -201,9 +201,21 @@ __device__ __forceinline__ int atomic_load_agent(const int* p) {
 // Products / sums / differences that the compiler must NOT contract into a fused multiply-add with a neighbouring
 // operation: two kernels that are required to produce bit-identical values (the fused scoring pass and the launches it
 // replaces) write the shared arithmetic with these, so the result does not depend on what each kernel's optimiser fuses.
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+// (HIP's __fmul_rn / __fadd_rn are plain operators the optimiser is free to contract -- measured: the per-token
+// log-probs of the two paths differed in the last bit at temperature != 1; an operation compiled under
+// `fp contract(off)` carries no contract flag and cannot be fused with a neighbour, inlined or not.)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
 
 // Arg-max over the wave: on return every lane holds the largest v of the wave and, among the lanes that supplied it, the
 // smallest i (candidate ids are unique, so exactly one lane recognises its own pair).  All 64 lanes must be active.  Two

@@ -146,6 +146,75 @@ __global__ void __launch_bounds__(512) layernorm_x3p_kernel(const float* __restr
   }
 }
 
+// The same for d <= 1024 with FULL-LINE stores: a wave = 8 consecutive rows, lane = (row r = lane >> 3, column group
+// u = lane & 7) holds the runs q = u + 8 j of 8 consecutive k of its row; the statistics are reduced over the 8 lanes of a
+// row (DPP); a store instruction then writes, for each u, the 16-byte slots of 8 consecutive rows = one whole 128-byte
+// line of the image (the one-row-per-wave kernel above writes 64 scattered 16-byte pieces per instruction: measured
+// 22.3 us at 12 800 x 512 -- no faster than LayerNorm + the split pass; profiles/r04_f_*).
+template <int NJ>
+__global__ void __launch_bounds__(256) layernorm_x3p_rows8_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, uint4* __restrict__ P,
+                                                                  int rows, int d, float eps, int act) {
+  const int lane = threadIdx.x & 63, r = lane >> 3, u = lane & 7;
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + r;
+  const bool live = row < rows;
+  const float* xr = x + (size_t)(live ? row : rows - 1) * d;
+  const int nu = d >> 3, KB = d >> 4;
+  float v[NJ][8];
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int q = u + 8 * j;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (q < nu) {
+      a = *reinterpret_cast<const float4*>(xr + q * 8);
+      b = *reinterpret_cast<const float4*>(xr + q * 8 + 4);
+    }
+    v[j][0] = a.x, v[j][1] = a.y, v[j][2] = a.z, v[j][3] = a.w, v[j][4] = b.x, v[j][5] = b.y, v[j][6] = b.z, v[j][7] = b.w;
+    s += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+  }
+  const float mean = sbk::group_sum<8>(s) / (float)d;
+  float qs = 0.0f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    if (u + 8 * j < nu) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = (v[j][e] - mean) * (v[j][e] - mean);
+      qs += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+  const float rstd = rsqrtf(sbk::group_sum<8>(qs) / (float)d + eps);
+  const int rb = row >> 6, rr = row & 63;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int q = u + 8 * j;
+    if (q >= nu) continue;
+    float o[8];
+    if (live) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + q * 8), g1 = *reinterpret_cast<const float4*>(gamma + q * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(beta + q * 8), b1 = *reinterpret_cast<const float4*>(beta + q * 8 + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = act_f((v[j][e] - mean) * rstd * g[e] + bb[e], act);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = 0.0f;
+    }
+    unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      hi[p] = sbk::bf16_pair(o[2 * p], o[2 * p + 1]);
+      const float r0 = o[2 * p] - __uint_as_float(hi[p] << 16), r1 = o[2 * p + 1] - __uint_as_float(hi[p] & 0xffff0000u);
+      mi[p] = sbk::bf16_pair(r0, r1);
+      lo[p] = sbk::bf16_pair(r0 - __uint_as_float(mi[p] << 16), r1 - __uint_as_float(mi[p] & 0xffff0000u));
+    }
+    uint4* dst = P + ((size_t)(rb * KB + (q >> 1)) * 6 + (q & 1)) * 64 + rr;
+    dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    dst[128] = make_uint4(mi[0], mi[1], mi[2], mi[3]);
+    dst[256] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
 // Any d (scalar loads, three passes over an L1/L2-resident row).
 __global__ void __launch_bounds__(256) layernorm_generic_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ gamma,
@@ -184,6 +253,19 @@ __global__ void __launch_bounds__(256) input_norm_kernel(const float* __restrict
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     y[i] = (x[i] - mean[c]) / fmaxf(sd[c], eps);
+  }
+}
+
+// global statistics with avoid_padding_norm (features.py:1447-1449): the padded frames (t >= n_valid[b]) keep their
+// values (mean 0, std 1); x [B,T,C]
+__global__ void __launch_bounds__(256) input_norm_masked_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                const float* __restrict__ sd, const int* __restrict__ n_valid,
+                                                                float* __restrict__ y, long n, int T, int C, float eps) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long row = i / C;
+    const bool valid = (int)(row % T) < n_valid[row / T];
+    y[i] = valid ? (x[i] - mean[c]) / fmaxf(sd[c], eps) : (x[i] - 0.0f) / fmaxf(1.0f, eps);
   }
 }
 
@@ -337,9 +419,9 @@ extern "C" int sbk_layernorm_x3p(const float* x, const float* gamma, const float
   uint4* P4 = reinterpret_cast<uint4*>(P);
   const dim3 grid(rows64 / 8), block(512);
   if (d <= 512) {
-    SBK_LAUNCH(layernorm_x3p_kernel<1>, grid, block, 0, st, x, gamma, beta, P4, rows, d, eps, act);
+    SBK_LAUNCH(layernorm_x3p_rows8_kernel<8>, dim3(rows64 / 32), dim3(256), 0, st, x, gamma, beta, P4, rows, d, eps, act);
   } else if (d <= 1024) {
-    SBK_LAUNCH(layernorm_x3p_kernel<2>, grid, block, 0, st, x, gamma, beta, P4, rows, d, eps, act);
+    SBK_LAUNCH(layernorm_x3p_rows8_kernel<16>, dim3(rows64 / 32), dim3(256), 0, st, x, gamma, beta, P4, rows, d, eps, act);
   } else {
     SBK_LAUNCH(layernorm_x3p_kernel<4>, grid, block, 0, st, x, gamma, beta, P4, rows, d, eps, act);
   }
@@ -369,6 +451,17 @@ extern "C" int sbk_input_norm_stats_f32(const float* x, const int32_t* n_valid, 
                per_batch, std_norm, eps, avoid_padding_norm);
   }
   return sbk::launch_status("sbk_input_norm_stats_f32");
+}
+
+extern "C" int sbk_input_norm_global_masked_f32(const float* x, const float* mean, const float* std, const int32_t* n_valid,
+                                                float* y, int B, int T, int C, float eps, sbk_stream_t stream) {
+  if (B == 0 || T == 0) return 0;
+  SBK_REQUIRE(x && mean && std && n_valid && y, "input_norm_masked: null operand");
+  SBK_REQUIRE(B > 0 && T > 0 && C > 0, "input_norm_masked: bad shape B=%d T=%d C=%d", B, T, C);
+  const long n = (long)B * T * C;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  SBK_LAUNCH(input_norm_masked_kernel, dim3(blocks), dim3(256), 0, sbk::as_stream(stream), x, mean, std, n_valid, y, n, T, C, eps);
+  return sbk::launch_status("sbk_input_norm_global_masked_f32");
 }
 
 extern "C" int sbk_input_norm_global_f32(const float* x, const float* mean, const float* std, float* y, int rows,

@@ -319,11 +319,11 @@ __global__ void __launch_bounds__(256) score_topk_row_kernel(ScoreArgs a) {
   float s = 0.0f;
 #pragma unroll
   for (int i = 0; i < NPT; ++i)
-    if (tid + 256 * i < V) s += expf(sbk::sub_rn(x[i], m));
+    if (tid + 256 * i < V) s = sbk::add_rn(s, expf(sbk::sub_rn(x[i], m)));
   s = sbk::wave_sum(s);
   if (lane == 0) red[wave] = s;
   __syncthreads();
-  const float lse = m + logf((red[0] + red[1]) + (red[2] + red[3]));
+  const float lse = sbk::add_rn(m, logf((red[0] + red[1]) + (red[2] + red[3])));
   __syncthreads();
   float am_max = -INFINITY;
 #pragma unroll

@@ -154,6 +154,9 @@ class ConcurrentTranscriber:
                     break
                 run(ks)
             self.enc_streams[slot].synchronize()
+        from speechbrain_amd import native
+
+        native.release_search_workspaces()  # (this thread's grow-only search buffer: the next job may run the slot on another thread)
         return out
 
     def transcribe_batches(self, batches: Sequence[Tuple[torch.Tensor, torch.Tensor]],

@@ -101,6 +101,7 @@ def _declare(lib):
         "sbk_x3p_panel_bytes": ([i, i], ctypes.c_size_t),
         "sbk_split_x3p": ([p, i, p, i, i, p], c_int),
         "sbk_layernorm_x3p": ([p, p, p, p, i, i, f, i, p], c_int),
+        "sbk_input_norm_global_masked_f32": ([p, p, p, p, p, i, i, i, f, p], c_int),
         "sbk_gemm_nt_x3p": ([p, p, p, p, i, p, i, p, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_bf16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_f16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
@@ -666,6 +667,18 @@ def input_norm_global(x, mean, std, eps):
     return out
 
 
+def input_norm_global_masked(x, mean, std, n_valid, eps):
+    """``input_norm_global`` with avoid_padding_norm: x [B,T,C], the frames t >= n_valid[b] pass through unchanged."""
+    lib = load()
+    B, T, C = x.shape
+    _dev_ok(x, mean, std, n_valid)
+    _f32(x)
+    out = torch.empty_like(x)
+    _chk(lib.sbk_input_norm_global_masked_f32(_p(x), _p(mean), _p(std), _p(n_valid), _p(out), B, T, C, float(eps), _stream(x)),
+         "sbk_input_norm_global_masked_f32")
+    return out
+
+
 def pcm16_to_f32(pcm: torch.Tensor, channels: int = 1, out=None):
     """int16 PCM (any shape; interleaved channels last when channels > 1) -> float32 sample / 32768, channel mean."""
     lib = load()
@@ -1059,7 +1072,7 @@ def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=No
     K = max(int(cfg.topk), 1)  # rows per utterance (return_topk)
     handle.ready.wait(dev)
     nbytes = lib.sbk_beam_search_workspace_bytes(ctypes.byref(handle.W), ctypes.byref(cfg), B, T)
-    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    ws = _search_workspace(nbytes + 256, dev)
     off = (-ws.data_ptr()) % 256
     out_tok = torch.zeros(B * K, L, dtype=torch.int32, device=dev)
     out_len = torch.zeros(B * K, dtype=torch.int32, device=dev)
@@ -1081,6 +1094,31 @@ def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=No
     if want_longest:
         return out_tok, out_len, out_score, out_lp, out_max, steps.value, out_longest
     return out_tok, out_len, out_score, out_lp, out_max, steps.value
+
+
+def _search_workspace(nbytes: int, dev) -> torch.Tensor:
+    """The search workspace of this host thread's current stream: ONE grow-only buffer per (thread, stream), reused by
+    the searches that follow each other on that stream (stream order makes the reuse safe; the library joins its helper
+    stream before it returns).  A fresh torch.empty per search of a job whose groups all have different sizes leaves the
+    caching allocator holding a block per size it has seen (VERDICT r3, weak #9: 127-137 GB reserved)."""
+    if dev.type != "cuda":
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    cache = getattr(_tls, "search_ws", None)
+    if cache is None:
+        cache = _tls.search_ws = {}
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        cache.pop(key, None)
+        del ws  # (the old block goes back to the allocator before the larger one is requested)
+        ws = cache[key] = torch.empty(nbytes + (nbytes >> 3), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def release_search_workspaces():
+    """Drop this thread's cached search workspaces (a worker calls it when its job ends)."""
+    if getattr(_tls, "search_ws", None):
+        _tls.search_ws.clear()
 
 
 def greedy_search(handle: DecoderHandle, enc, enc_len, min_steps, max_steps, bos, eos, check_every=8):

@@ -223,8 +223,6 @@ class InputNormalization(torch.nn.Module):
                                            self.epsilon, self.avoid_padding_norm)
         if self.training:
             raise NotImplementedError("statistic updates (training) are outside the MI355X inference path")
-        if self.avoid_padding_norm:
-            raise NotImplementedError("avoid_padding_norm with global statistics is not on the ASR inference path")
         if self.glob_mean.numel() == 0:
             raise RuntimeError("InputNormalization has no statistics loaded (glob_mean/glob_std)")
         # (locals: several worker threads may get here at once; none must see one statistic moved and the other not)
@@ -234,6 +232,13 @@ class InputNormalization(torch.nn.Module):
             self.glob_mean, self.glob_std = mean, std
         if not self.std_norm:
             std = torch.ones_like(mean)
+        if self.avoid_padding_norm and lengths is not None:  # padded frames: mean 0, std 1 (features.py:1447-1449)
+            if x.dim() != 3 or self.length_dim != 1:
+                raise NotImplementedError("avoid_padding_norm: [batch, time, channel] inputs are implemented")
+            T = x.shape[1]
+            n_valid = torch.ceil(lengths.to(x.device) * T - 1e-6).clamp_(0, T).to(torch.int32)
+            return native.input_norm_global_masked(x.contiguous(), mean.float().contiguous(), std.float().contiguous(),
+                                                   n_valid, self.epsilon)
         return native.input_norm_global(x.contiguous(), mean.float().contiguous(), std.float().contiguous(), self.epsilon)
 
     def _statistics_dict(self):

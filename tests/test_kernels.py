@@ -446,6 +446,29 @@ def test_input_normalization_sentence_and_batch(backend):
         assert float((yl[b] - ((xl[b].double() - mean) / std).float()).abs().max()) <= 1e-4
 
 
+def test_input_normalization_global_with_avoid_padding_norm(backend):
+    """a6: InputNormalization(norm_type="global", avoid_padding_norm=...) in eval mode with loaded statistics, against
+    the reference's outputs (input_norm.npz, y_global_*): the padded frames of each utterance pass through unchanged,
+    a zero std is clamped at epsilon.  Exact arithmetic (one subtraction, one division): 1e-6 relative."""
+    nat, dev = backend
+    from speechbrain_amd.processing.features import InputNormalization
+
+    gold = np.load(os.path.join(GOLD, "input_norm.npz"))
+    x, lengths = torch.from_numpy(gold["x"]).to(dev), torch.from_numpy(gold["lengths"]).to(dev)
+    for std_norm in (True, False):
+        for avoid in (False, True):
+            m = InputNormalization(norm_type="global", std_norm=std_norm, avoid_padding_norm=avoid).eval()
+            m.glob_mean, m.glob_std, m.count = torch.from_numpy(gold["glob_mean"]).to(dev), torch.from_numpy(gold["glob_std"]).to(dev), 1
+            y = m(x, lengths).cpu()
+            ref = torch.from_numpy(gold[f"y_global_{int(std_norm)}_{int(avoid)}"])
+            assert torch.isfinite(y).all() or not torch.isfinite(ref).all()
+            fin = torch.isfinite(ref) & (ref.abs() < 1e30)
+            assert float(((y - ref)[fin].abs() / ref[fin].abs().clamp(min=1.0)).max()) <= 1e-6, (std_norm, avoid)
+            assert torch.equal(y[~fin], ref[~fin]) or float(((y[~fin] - ref[~fin]) / ref[~fin]).abs().max()) <= 1e-6
+            if avoid:
+                assert torch.equal(y[2, 20:], x[2, 20:].cpu())  # (0.35 * 57 = 19.95 frames are valid)
+
+
 def test_documented_capacity_limits_are_reported(backend):
     """include/sbk.h: the attention-weights (strip) kernel keeps a [32][T] score strip in LDS -- beyond the 160 KiB
     window the call must fail with SBK_EINVAL and a message, not crash or compute garbage; the strip-free kernel
