@@ -210,6 +210,15 @@ int sbk_gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, c
                     int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
                     int rows_per_seq, sbk_stream_t stream);
 
+/* ABI 8: the same arithmetic for FEW rows -- the linear layers of a decoding step (Transformer.py:751-834: self-attention
+ * in / out projections, cross-attention query / out projections, the feed-forward pair; a few hundred to a few thousand
+ * hypothesis rows): A stays fp32 [M, K] (row stride lda) and is split in registers, PW is the panel image of W [N, K]
+ * (sbk_split_x3p), 64 x 64 tiles whose four waves split K; K % 256 == 0; K > 512 needs `workspace` (K / 512 * M * N
+ * floats) for the partial tiles of the K split, summed in a fixed order.  Epilogue as sbk_gemm_nt_f32 (no seq_len). */
+int sbk_gemm_nt_x3r(const float* A, int lda, const uint16_t* PW, const float* bias, const float* residual, int ldr, float* C,
+                    int ldc, int M, int N, int K, int act, float alpha, float* workspace, size_t workspace_floats,
+                    sbk_stream_t stream);
+
 /* ---- bf16-operand fast entry points ("fp32 parity entry points plus bf16 ... fast entry points").
  * C = epilogue(bf16(A) . Wb^T) with fp32 accumulation on v_mfma_f32_32x32x16_bf16: A [M,K] stays fp32 in memory and is
  * rounded to bf16 (nearest even) inside the kernel, Wb [N,K] holds the weights as bf16 bits (sbk_f32_to_bf16, once per
@@ -356,6 +365,10 @@ typedef struct {
   /* optional (NULL = unused; ABI 6): the key / value rows [2d,d] of ca_in_w as sbk_split_bf16x3 writes them -- the
    * projection of the encoder memory (once per utterance, B*T rows) then runs as sbk_gemm_nt_f32x3 */
   const uint16_t* ca_kv_w3;
+  /* optional (NULL = unused; ABI 8): the panel images (sbk_split_x3p) of sa_in_w [3d,d], sa_out_w, the q rows of ca_in_w
+   * [d,d], ca_out_w, ff1_w [d_ffn,d], ff2_w [d,d_ffn] -- a step with enough hypothesis rows (~200 on) then runs these
+   * projections as sbk_gemm_nt_x3r (fp32 result on the bf16 matrix pipe; LayerNorm as its own launch) */
+  const uint16_t *sa_in_wp, *sa_out_wp, *ca_q_wp, *ca_out_wp, *ff1_wp, *ff2_wp;
 } sbk_decoder_layer;
 
 typedef struct {
@@ -371,6 +384,7 @@ typedef struct {
                       1 for the Whisper decoder, whose `pe` is its learned embed_positions table */
   const uint16_t* seq_w3; /* optional (NULL = unused; ABI 6): seq_w as sbk_split_bf16x3 writes it -- the vocabulary
                              projection of a step with >= 1 024 hypothesis rows then runs as sbk_gemm_nt_f32x3 */
+  const uint16_t* seq_wp; /* optional (ABI 8): seq_w's panel image (sbk_split_x3p): the vocabulary projection as sbk_gemm_nt_x3r */
 } sbk_decoder_weights;
 
 /* ---- a20: TransformerLM (lobes/models/transformer/TransformerLM.py:22-187; encoder-only, regularMHA,

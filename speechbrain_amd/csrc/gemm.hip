@@ -1660,6 +1660,153 @@ __global__ void __launch_bounds__(256, 2) gemm_skinny_ln_kernel(GemmArgs g, floa
   tile_epilogue_32x32(g, v, mt, nt, r, half);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Few-row fp32 contraction on the bf16 matrix pipe ("x3r": the decode step's projections, 300 - 4 000 hypothesis rows).
+// A kernel trace of a decoding step (profiles/r04_g_*) shows its launches back to back (45 us of gaps in 2.1 ms): the step
+// is the sum of its kernels, and 53 % of that are the decoder layers' projections at 27 - 80 TF/s -- register-operand
+// fp32-MFMA tiles whose operands arrive as 16-byte pieces of 64 different rows per load instruction (the texture
+// path serialises them) and whose 64 x 64 x 128 wave slices cost 4 096 matrix cycles each.  Here
+//   * W arrives pre-split in PANEL layout (sbk_split_x3p: the weights' image the encoder uses): a fragment load of 32
+//     rows is two 512-byte runs, and the same three-way operand split as sbk_gemm_nt_f32x3 puts the products on
+//     v_mfma_f32_32x32x16_bf16 (6 MFMAs of 8 passes per 16 k instead of 8 MFMAs of 16 passes);
+//   * A stays fp32 [M, K] (the activations of the step: LayerNorm / attention outputs) and is cut into its three pieces
+//     in registers (a lane holds 8 consecutive k of its row per step);
+//   * tile 64 x 64, the four waves split K four ways (no LDS staging, no barrier in the loop; one LDS exchange of the
+//     partial tiles at the end, as gemm_skinny_flat64_kernel), blockIdx.y a further split of long K with the fixed-order
+//     reduce of splitk_reduce_kernel.
+// PIPE: the k steps in batches of 2 with the next batch's loads in flight under the current batch's MFMAs (fits 256
+// registers: two workgroups per CU); otherwise every load of the wave's slice is issued up front (one workgroup per CU).
+template <int NS, bool PIPE>
+__global__ void __launch_bounds__(256, PIPE ? 2 : 1) gemm_x3r_kernel(GemmArgs g, const uint4* __restrict__ PW,
+                                                                     float* __restrict__ partial, int tiles_m, int tiles_n) {
+  constexpr int SB = PIPE ? 2 : NS, NB = NS / SB;
+  static_assert(NS % SB == 0, "whole batches");
+  __shared__ float red[4][4][32][33];  // [wave][sub-tile][row][col]: partial tiles of the four K slices
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int nt, mt;
+  {
+    const int id = blockIdx.x, x = id & 7, q = id >> 3;
+    const int nt8 = (tiles_n + 7) / 8;
+    mt = q % tiles_m;
+    nt = x + 8 * (q / tiles_m);
+    if (q / tiles_m >= nt8 || nt >= tiles_n) return;
+  }
+  const int r = lane & 31, half = lane >> 5;
+  const int k_begin = (blockIdx.y * 4 + wave) * NS * 16, KB = g.K >> 4;
+  const float* arow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) arow[i] = g.A + (size_t)min(mt * 64 + i * 32 + r, g.M - 1) * g.lda + k_begin + 8 * half;
+  // chunk (row block nt, k step, piece 0, half), slot r: sub-tile j is 32 slots on, piece p two chunks (128 slots), a k step six
+  const uint4* wp = PW + ((size_t)(nt * KB + (k_begin >> 4)) * 6 + half) * 64 + r;
+  float4 av[PIPE ? 2 : 1][SB][2][2];
+  uint4 wv[PIPE ? 2 : 1][SB][2][3];
+  auto load = [&](int buf, int b) SBK_INLINE_LAMBDA {
+#pragma unroll
+    for (int s = 0; s < SB; ++s) {
+      const int st = b * SB + s;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wv[buf][s][j][p] = wp[(size_t)st * 384 + p * 128 + j * 32];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[buf][s][i][0] = *reinterpret_cast<const float4*>(arow[i] + st * 16);
+        av[buf][s][i][1] = *reinterpret_cast<const float4*>(arow[i] + st * 16 + 4);
+      }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+  auto compute = [&](int buf) SBK_INLINE_LAMBDA {
+#pragma unroll
+    for (int s = 0; s < SB; ++s) {
+      // the step's operands are materialised HERE: without the anchors hipcc hoists the split of an A fragment to its load
+      // (a wait in front of the next loads: eight serial round trips instead of one), or sinks the loads to their MFMAs
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          sbk::pin(av[buf][s][i][e].x), sbk::pin(av[buf][s][i][e].y), sbk::pin(av[buf][s][i][e].z), sbk::pin(av[buf][s][i][e].w);
+        }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          sbk::pin(wv[buf][s][j][p].x), sbk::pin(wv[buf][s][j][p].y), sbk::pin(wv[buf][s][j][p].z), sbk::pin(wv[buf][s][j][p].w);
+        }
+      sbk::bf16x8 ap[2][3], bp[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 x0 = av[buf][s][i][0], x1 = av[buf][s][i][1];
+        const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {  // x = hi + mid + lo exactly (8 significand bits each, remainders exact in fp32)
+          h[p] = sbk::bf16_pair(x[2 * p], x[2 * p + 1]);
+          const float r0 = x[2 * p] - __uint_as_float(h[p] << 16), r1 = x[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
+          m[p] = sbk::bf16_pair(r0, r1);
+          l[p] = sbk::bf16_pair(r0 - __uint_as_float(m[p] << 16), r1 - __uint_as_float(m[p] & 0xffff0000u));
+        }
+        ap[i][0] = sbk::bf16x8_from_words(h[0], h[1], h[2], h[3]);
+        ap[i][1] = sbk::bf16x8_from_words(m[0], m[1], m[2], m[3]);
+        ap[i][2] = sbk::bf16x8_from_words(l[0], l[1], l[2], l[3]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const uint4 u = wv[buf][s][j][p];
+          bp[j][p] = sbk::bf16x8_from_words(u.x, u.y, u.z, u.w);
+        }
+      // the six partial products of relative size >= 2^-17, smallest first; consecutive MFMAs go to different accumulators
+      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(ap[i][PA_[t]], bp[j][PB_[t]], acc[i][j]);
+    }
+  };
+  load(0, 0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (PIPE && b + 1 < NB) load((b + 1) & 1, b + 1);
+    sbk::sched_fence();
+    compute(PIPE ? (b & 1) : 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) red[wave][2 * i + j][(q & 3) + 8 * (q >> 2) + 4 * half][r] = acc[i][j][q];
+  __syncthreads();
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int rr = (q & 3) + 8 * (q >> 2) + 4 * half;
+    v[q] = ((red[0][wave][rr][r] + red[1][wave][rr][r]) + red[2][wave][rr][r]) + red[3][wave][rr][r];
+  }
+  const int sub_m = mt * 2 + (wave >> 1), sub_n = nt * 2 + (wave & 1);
+  if (gridDim.y > 1) {
+    float* P = partial + (size_t)blockIdx.y * g.M * g.N;
+    const int col = sub_n * 32 + r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = sub_m * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+      if (row < g.M && col < g.N) P[(size_t)row * g.N + col] = v[q];
+    }
+    return;
+  }
+  tile_epilogue_32x32(g, v, sub_m, sub_n, r, half);
+}
+
 // C = epilogue(sum_ks partial[ks]) ; fixed summation order => run-to-run deterministic.
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const float* __restrict__ partial, int SK) {
   const size_t total = (size_t)g.M * g.N;
@@ -1798,6 +1945,46 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
     SBK_LAUNCH((gemm_skinny_kernel<1>), grid, block, 0, st, g, ws, kper, tiles_m, tiles_n);
   }
   int rc = launch_status("gemm_skinny");
+  if (rc || SKg == 1) return rc;
+  const size_t total = (size_t)M * N;
+  SBK_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, g, (const float*)ws, SKg);
+  return launch_status("splitk_reduce");
+}
+
+// tuning knob (key 41): the decode step's projections on gemm_x3r_kernel: 0 = off (register-operand fp32-MFMA tiles),
+// 1 = every load of a wave's slice up front (one workgroup per CU), 2 = batches of two k steps, next batch in flight
+int g_x3r_mode = 2;
+int g_x3r_vocab = 1;      // key 43: 1 = the vocabulary projection of a step too (instead of the 128-wide persistent split-operand kernel)
+int g_x3r_min_rows = 192;  // key 42: rows from which the search routes a projection with a panel image to it
+bool x3r_routed(int M, int N, int K) { return g_x3r_mode != 0 && M >= g_x3r_min_rows && K % 256 == 0 && N % 4 == 0; }
+// -1: shape not eligible / no room for the K-split partials
+int gemm_nt_x3r(const float* A, int lda, const uint16_t* PW, const float* bias, const float* R, int ldr, float* C, int ldc,
+                int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, float* ws,
+                size_t ws_floats, hipStream_t st) {
+  if (M == 0 || N == 0) return 0;
+  if (K % 256 != 0 || lda % 4 != 0 || !aligned16(A) || !aligned16(PW)) return -1;
+  const int NS = K % 512 == 0 ? 8 : 4, SKg = K / (64 * NS);
+  if (SKg > 1 && (!ws || (size_t)SKg * M * N > ws_floats)) return -1;
+  GemmArgs g{A, nullptr, bias, R, C, lda, 0, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
+  const int tm = cdiv(M, 64), tn = cdiv(N, 64);
+  ProfScope prof("gemm_x3r", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N) + 6.0 * (double)N * K, st);
+  dim3 grid(8 * tm * cdiv(tn, 8), SKg), block(256);
+  const uint4* P4 = reinterpret_cast<const uint4*>(PW);
+  const bool pipe = g_x3r_mode != 1;
+  if (NS == 8) {
+    if (pipe) {
+      SBK_LAUNCH((gemm_x3r_kernel<8, true>), grid, block, 0, st, g, P4, ws, tm, tn);
+    } else {
+      SBK_LAUNCH((gemm_x3r_kernel<8, false>), grid, block, 0, st, g, P4, ws, tm, tn);
+    }
+  } else {
+    if (pipe) {
+      SBK_LAUNCH((gemm_x3r_kernel<4, true>), grid, block, 0, st, g, P4, ws, tm, tn);
+    } else {
+      SBK_LAUNCH((gemm_x3r_kernel<4, false>), grid, block, 0, st, g, P4, ws, tm, tn);
+    }
+  }
+  int rc = launch_status("gemm_x3r");
   if (rc || SKg == 1) return rc;
   const size_t total = (size_t)M * N;
   SBK_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, g, (const float*)ws, SKg);
@@ -2172,6 +2359,9 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 31) sbk::g_x3_grid = value;
   if (key == 39) sbk::g_x3p_tile = value;
   if (key == 40) sbk::g_score_fused = value;
+  if (key == 41) sbk::g_x3r_mode = value;
+  if (key == 42) sbk::g_x3r_min_rows = value;
+  if (key == 43) sbk::g_x3r_vocab = value;
   if (key == 36) sbk::g_splitk_fused = value;
   if (key == 37) sbk::g_cross_fused_merge = value;
   if (key == 34) sbk::g_x3_route_rows = value;
@@ -2205,6 +2395,24 @@ extern "C" int sbk_gemm_nt_f32x3(const float* A, int lda, const uint16_t* W3, co
   const int rc = sbk::gemm_nt_x3(A, lda, W3, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq,
                                  sbk::as_stream(stream));
   if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_f32x3: no workspace registered for this stream (sbk_stream_workspace_set) or too many tiles");
+  return rc;
+}
+
+extern "C" int sbk_gemm_nt_x3r(const float* A, int lda, const uint16_t* PW, const float* bias, const float* residual,
+                               int ldr, float* C, int ldc, int M, int N, int K, int act, float alpha, float* workspace,
+                               size_t workspace_floats, sbk_stream_t stream) {
+  if (M == 0 || N == 0) return 0;
+  SBK_REQUIRE(A && PW && C, "gemm_x3r: null operand");
+  SBK_REQUIRE(M >= 0 && N >= 0 && K >= 256 && K % 256 == 0, "gemm_x3r: bad shape M=%d N=%d K=%d (K: a multiple of 256)", M, N, K);
+  SBK_REQUIRE(lda >= K && lda % 4 == 0 && ldc >= N && sbk::aligned16(A) && sbk::aligned16(PW),
+              "gemm_x3r: operand rows must be 16-byte aligned (lda=%d)", lda);
+  SBK_REQUIRE(!residual || ldr >= N, "gemm_x3r: residual stride");
+  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_x3r: unknown activation %d", act);
+  SBK_REQUIRE(K <= 512 || (workspace && workspace_floats >= (size_t)(K / 512) * M * N),
+              "gemm_x3r: K = %d needs a workspace of %zu floats for the partial tiles of its K split", K, (size_t)(K / 512) * M * N);
+  const int rc = sbk::gemm_nt_x3r(A, lda, PW, bias, residual, ldr, C, ldc, M, N, K, act, alpha, nullptr, 1, workspace,
+                                  workspace_floats, sbk::as_stream(stream));
+  if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_x3r: shape not eligible");
   return rc;
 }
 

@@ -1012,8 +1012,31 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
   const int dm = W->d_model, H = W->nhead;
   const float emb_scale = W->emb_scale > 0.0f ? W->emb_scale : sqrtf((float)dm);  // NormalizedEmbedding: sqrt(d_model)
   SBK_TRY(sbk::embed_pos(tokens, W->emb, W->pe + (size_t)step * dm, d.x, n, dm, emb_scale, st));
+  // a projection with a panel image of its weights and enough hypothesis rows: sbk_gemm_nt_x3r (fp32 result on the bf16
+  // matrix pipe); -1 = not routed (the register-operand / LDS-tiled fp32-MFMA kernels below)
+  auto x3r = [&](const float* A, int lda, const uint16_t* WP, const float* b, const float* R, float* C, int N, int K,
+                 int act) -> int {
+    if (!WP || !sbk::x3r_routed(n, N, K)) return -1;
+    return sbk::gemm_nt_x3r(A, lda, WP, b, R, N, C, N, n, N, K, act, 1.0f, nullptr, 0, d.splitk, d.splitk_floats, st);
+  };
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
+    if (L.sa_in_wp && L.sa_out_wp && L.ca_q_wp && L.ca_out_wp && L.ff1_wp && L.ff2_wp && sbk::x3r_routed(n, dm, dm) &&
+        sbk::x3r_routed(n, dm, W->d_ffn) && (size_t)(W->d_ffn / 512) * n * dm <= d.splitk_floats) {
+      SBK_TRY(sbk::layernorm(d.x, L.ln1_g, L.ln1_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
+      SBK_TRY(x3r(d.h, dm, L.sa_in_wp, L.sa_in_b, nullptr, d.qkv, 3 * dm, dm, SBK_ACT_NONE));
+      SBK_TRY(sbk::self_attn_step(d.qkv, d.kcache[l], d.vcache[l], kv_slot, d.ctx, n, dm, H, step, n, Lmax, st, nullptr, 0, 0,
+                                  0, 0, beam));
+      SBK_TRY(x3r(d.ctx, dm, L.sa_out_wp, L.sa_out_b, d.x, d.x, dm, dm, SBK_ACT_NONE));
+      SBK_TRY(sbk::layernorm(d.x, L.ln2_g, L.ln2_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
+      SBK_TRY(x3r(d.h, dm, L.ca_q_wp, L.ca_in_b, nullptr, d.q, dm, dm, SBK_ACT_NONE));
+      SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, d.xpart, B, T, dm, H, beam, st, d.head_major, d.xcnt));
+      SBK_TRY(x3r(d.ctx, dm, L.ca_out_wp, L.ca_out_b, d.x, d.x, dm, dm, SBK_ACT_NONE));
+      SBK_TRY(sbk::layernorm(d.x, L.ln3_g, L.ln3_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
+      SBK_TRY(x3r(d.h, dm, L.ff1_wp, L.ff1_b, nullptr, d.ff, W->d_ffn, dm, W->ffn_act));
+      SBK_TRY(x3r(d.ff, W->d_ffn, L.ff2_wp, L.ff2_b, d.x, d.x, dm, W->d_ffn, SBK_ACT_NONE));
+      continue;
+    }
     int frc = L.sa_in_wf ? sbk::gemm_ln_nt(d.x, dm, L.sa_in_wf, dm, L.sa_in_bf, nullptr, 0, d.qkv, 3 * dm, n, 3 * dm, dm,
                                            W->ln_eps, SBK_ACT_NONE, 1.0f, st)
                          : -1;
@@ -1058,8 +1081,8 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
   }
   SBK_TRY(sbk::layernorm(d.x, W->final_ln_g, W->final_ln_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
   if (want_logits) {
-    int rc = -1;
-    if (W->seq_w3 && sbk::x3_routed(n, W->vocab, dm))
+    int rc = sbk::g_x3r_vocab ? x3r(d.h, dm, W->seq_wp, W->seq_b, nullptr, d.logits, W->vocab, dm, SBK_ACT_NONE) : -1;
+    if (rc == -1 && W->seq_w3 && sbk::x3_routed(n, W->vocab, dm))
       rc = sbk::gemm_nt_x3(d.h, dm, W->seq_w3, W->seq_b, nullptr, 0, d.logits, W->vocab, n, W->vocab, dm, SBK_ACT_NONE, 1.0f,
                            nullptr, 0, st);
     if (rc == -1)

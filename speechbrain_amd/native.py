@@ -33,7 +33,7 @@ class DecoderLayer(ctypes.Structure):  # sbk_decoder_layer
     _fields_ = [(n, c_void_p) for n in (
         "ln1_g", "ln1_b", "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ln2_g", "ln2_b", "ca_in_w", "ca_in_b",
         "ca_out_w", "ca_out_b", "ln3_g", "ln3_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b", "sa_in_wf", "sa_in_bf", "ca_q_wf",
-        "ca_q_bf", "ff1_wf", "ff1_bf", "ca_kv_w3")]
+        "ca_q_bf", "ff1_wf", "ff1_bf", "ca_kv_w3", "sa_in_wp", "sa_out_wp", "ca_q_wp", "ca_out_wp", "ff1_wp", "ff2_wp")]
 
 
 class DecoderWeights(ctypes.Structure):  # sbk_decoder_weights
@@ -42,7 +42,7 @@ class DecoderWeights(ctypes.Structure):  # sbk_decoder_weights
                 ("seq_bf", c_void_p), ("d_model", c_int32),
                 ("nhead", c_int32), ("d_ffn", c_int32), ("n_layers", c_int32), ("vocab", c_int32),
                 ("max_len", c_int32), ("ffn_act", c_int32), ("ln_eps", c_float), ("emb_scale", c_float),
-                ("seq_w3", c_void_p)]
+                ("seq_w3", c_void_p), ("seq_wp", c_void_p)]
 
 
 class LMLayer(ctypes.Structure):  # sbk_lm_layer
@@ -101,6 +101,7 @@ def _declare(lib):
         "sbk_x3p_panel_bytes": ([i, i], ctypes.c_size_t),
         "sbk_split_x3p": ([p, i, p, i, i, p], c_int),
         "sbk_layernorm_x3p": ([p, p, p, p, i, i, f, i, p], c_int),
+        "sbk_gemm_nt_x3r": ([p, i, p, p, p, i, p, i, i, i, i, i, f, p, ctypes.c_size_t, p], c_int),
         "sbk_input_norm_global_masked_f32": ([p, p, p, p, p, i, i, i, f, p], c_int),
         "sbk_gemm_nt_x3p": ([p, p, p, p, i, p, i, p, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_bf16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
@@ -262,6 +263,8 @@ F32X3_MIN_ROWS = int(os.environ.get("SBK_F32X3_MIN_ROWS", "2048"))
 F32X3_MIN_TILES = int(os.environ.get("SBK_F32X3_MIN_TILES", "192"))
 # ... and, with the activation operand pre-split as well, through sbk_gemm_nt_x3p (csrc/gemm_x3p.hip: 256-wide tiles)
 X3P = os.environ.get("SBK_X3P", "1") != "0"
+# the decode step's few-row projections on the bf16 matrix pipe (sbk_gemm_nt_x3r: panel images of the decoder's weights)
+X3R = os.environ.get("SBK_X3R", "1") != "0"
 X3P_MIN_TILES = int(os.environ.get("SBK_X3P_MIN_TILES", "96"))
 
 
@@ -424,6 +427,23 @@ def gemm_nt_x3p(a: Panel, w: torch.Tensor, bias=None, residual=None, act=ACT_NON
                              _stream(a.data)), "sbk_gemm_nt_x3p")
     if panel_out:
         return (out, pc) if fp32_out else pc
+    return out
+
+
+def gemm_nt_x3r(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0):
+    """out[M,N] = residual + alpha * act(a @ w^T + bias) for FEW rows (a decoding step's projections) on the bf16 matrix
+    pipe: a stays fp32 and is split in registers, w is used through its cached panel image (sbk_gemm_nt_x3r)."""
+    lib = load()
+    K = a.shape[-1]
+    a2 = a.reshape(-1, K)
+    M, N = a2.shape[0], w.shape[0]
+    _dev_ok(a2, w, bias, residual)
+    _f32(a2)
+    out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
+    r2 = residual.reshape(-1, N) if residual is not None else None
+    ws = torch.empty(max(1, (K // 512) * M * N if K > 512 else 1), dtype=torch.float32, device=a.device)
+    _chk(lib.sbk_gemm_nt_x3r(_p(a2), K, _p(lp_weight(w, "x3p")), _p(bias), _p(r2), N, _p(out), N, M, N, K, act, float(alpha),
+                             _p(ws), ws.numel(), _stream(a2)), "sbk_gemm_nt_x3r")
     return out
 
 
@@ -918,6 +938,18 @@ class DecoderHandle:
             self.keep.append(out)
             return out.data_ptr()
 
+        def panel(w):  # sbk_split_x3p's image: the decode step's projections as sbk_gemm_nt_x3r (csrc/gemm.hip)
+            if not (F32X3 and X3R) or w.shape[1] % 256 != 0 or w.shape[0] % 4 != 0:
+                return None
+            w2 = w.detach().contiguous()
+            _dev_ok(w2)
+            _f32(w2)
+            N, K = w2.shape
+            out = torch.empty(((N + 63) // 64) * 64 * K * 3, dtype=torch.int16, device=w2.device)
+            _chk(load().sbk_split_x3p(_p(w2), K, _p(out), N, K, _stream(w2)), "sbk_split_x3p")
+            self.keep.append(out)
+            return out.data_ptr()
+
         for l, S in enumerate(layer_specs):
             o = layers[l]
             o.ln1_g, o.ln1_b = map(ptr, S["ln1"])
@@ -930,6 +962,9 @@ class DecoderHandle:
             o.ff1_w, o.ff1_b = map(ptr, S["ff1"])
             o.ff2_w, o.ff2_b = map(ptr, S["ff2"])
             o.ca_kv_w3 = split3(S["ca_in"][0][dm:])
+            o.sa_in_wp, o.sa_out_wp = panel(S["sa_in"][0]), panel(S["sa_out"][0])
+            o.ca_q_wp, o.ca_out_wp = panel(S["ca_in"][0][:dm]), panel(S["ca_out"][0])
+            o.ff1_wp, o.ff2_wp = panel(S["ff1"][0]), panel(S["ff2"][0])
             if fold:  # LayerNorm folded into the projection it feeds (fused kernel, csrc/gemm.hip)
                 o.sa_in_wf, o.sa_in_bf = map(ptr, _fold_ln(*S["sa_in"], *S["ln1"]))
                 o.ca_q_wf, o.ca_q_bf = map(ptr, _fold_ln(S["ca_in"][0][:dm], S["ca_in"][1][:dm], *S["ln2"]))
@@ -942,6 +977,7 @@ class DecoderHandle:
         if seq is not None:
             W.seq_w, W.seq_b = map(ptr, seq)
             W.seq_w3 = split3(seq[0])
+            W.seq_wp = panel(seq[0])
             if fold:
                 W.seq_wf, W.seq_bf = map(ptr, _fold_ln(seq[0], seq[1], *final_ln))
         W.d_model, W.nhead = dm, nhead

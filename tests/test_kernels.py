@@ -835,6 +835,40 @@ def test_gemm_x3p(backend, M, N, K, tile):
         lib.sbk_prof_set_knob(39, 0)
 
 
+@pytest.mark.parametrize("M,N,K", [(1280, 512, 512), (300, 132, 256), (70, 1536, 512), (640, 512, 2048), (1280, 2048, 512),
+                                   (333, 64, 1024), (1, 40, 256), (1280, 5000, 512)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_gemm_x3r(backend, M, N, K, mode):
+    """sbk_gemm_nt_x3r: the decode step's few-row projections on the bf16 matrix pipe (fp32 A split in registers, W as its
+    panel image, 64 x 64 tiles whose four waves split K, long K split further with a fixed-order reduce).  Held to the
+    bound of every fp32 kernel of the library against the fp64 product (2e-6 of the largest sum of magnitudes); both load
+    schedules (knob 41); ragged edges; bias / activation / scaled residual; run-to-run bit-identical."""
+    nat, dev = backend
+    if dev.type == "cpu" and M * N * K > 1.2e8:
+        pytest.skip("large shape: GPU only")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01
+    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
+    a[::7] *= 1e-3
+    w[::5] *= 300.0
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    lib = nat.load()
+    lib.sbk_prof_set_knob(41, mode)
+    try:
+        ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+        prod = a.double() @ w.double().t()
+        scale = float((a.double().abs() @ w.double().abs().t()).max())
+        out = nat.gemm_nt_x3r(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5)
+        ref = (r.double() + 0.5 * F.silu(prod + b.double())).float()
+        assert _md(out, ref) <= 2e-6 * scale + 1e-5
+        for _ in range(3 if dev.type == "cuda" else 1):
+            assert torch.equal(nat.gemm_nt_x3r(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
+        plain = nat.gemm_nt_x3r(ad, wd)
+        assert _md(plain, prod.float()) <= 2e-6 * scale + 1e-5
+    finally:
+        lib.sbk_prof_set_knob(41, 2)
+
+
 @pytest.mark.parametrize("rows,d,act", [(130, 512, 0), (64, 32, 1), (777, 144, 0), (300, 1024, 1), (129, 2048, 0), (5, 16, 0)])
 def test_layernorm_x3p(backend, rows, d, act):
     """sbk_layernorm_x3p: act(LayerNorm(x)) written directly as the panel image of its result (the A operand of the

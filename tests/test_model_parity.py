@@ -247,6 +247,58 @@ def test_decoder_with_fused_layernorm_vs_oracle(backend):
     assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
 
 
+@pytest.mark.parametrize("mode", [2, 1])
+def test_decoder_on_the_x3r_route_vs_oracle(backend, mode):
+    """The decode step's projections as sbk_gemm_nt_x3r (csrc/gemm.hip: gemm_x3r_kernel -- fp32 results on the bf16
+    matrix pipe from the panel images of the decoder's weights; the route of every step with ~200 hypothesis rows or
+    more): d_model 256 / d_ffn 512 are eligible widths (K % 256 == 0), the row threshold is lowered so that this small
+    search takes it (knob 42).  Teacher-forced decoder outputs 5e-5 and a beam search with CTC (ids exact, scores 1e-4)
+    against the oracle; both load schedules (knob 41); the result does not change when the route is switched off."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
+    from speechbrain_amd.inference.builders import build_modules
+
+    m = build_modules(dict(d_model=256, nhead=4, d_ffn=512, n_enc=1, n_dec=2, n_fft=512, win_length=32), vocab=60, seed=7)
+    mods = torch.nn.ModuleDict({k: m[k] for k in ("CNN", "Transformer", "seq_lin", "ctc_lin")})
+    gen = torch.Generator().manual_seed(19)
+    with torch.no_grad():
+        for name, p in mods.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+        mods["seq_lin"].w.weight.mul_(4.0)
+        mods["ctc_lin"].w.weight.mul_(4.0)
+    sd = {k: v.detach().clone() for k, v in mods.state_dict().items()}
+    mods = mods.to(dev).eval()
+    cfg = O.ModelCfg(d_model=256, nhead=4, num_encoder_layers=1, num_decoder_layers=2, d_ffn=512, vocab=60)
+    enc = torch.randn(3, 30, 256, generator=gen)
+    wl = torch.tensor([1.0, 0.7, 0.9])
+    enc_len = torch.round(30 * wl).int()
+    tgt = torch.randint(0, 60, (3, 6), generator=gen)
+    lib = nat.load()
+    lib.sbk_prof_set_knob(41, mode)
+    lib.sbk_prof_set_knob(42, 1)
+    try:
+        h = nat.DecoderHandle(mods["Transformer"], mods["seq_lin"])
+        assert h.layers[0].sa_in_wp and h.layers[0].ff2_wp and h.W.seq_wp  # the panel images exist for these widths
+        pred = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev))
+        assert float((pred.cpu() - O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")).abs().max()) <= 5e-5
+        ratio = 8.5 / 30
+        hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=4, ctc_weight=0.4, max_decode_ratio=ratio))
+        scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)], weights={"ctc": 0.4})
+        bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
+                                        min_decode_ratio=0.0, max_decode_ratio=ratio, beam_size=4,
+                                        using_eos_threshold=False, length_normalization=True, scorer=scorer)
+        hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))
+        assert hyps == hyps_ref
+        assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
+        lib.sbk_prof_set_knob(41, 0)  # the fp32-MFMA route of the same handle
+        hyps0, _, sc0, _ = bs(enc.to(dev), wl.to(dev))
+        assert hyps0 == hyps and float((sc0 - sc).abs().max()) <= 1e-4
+    finally:
+        lib.sbk_prof_set_knob(41, 2)
+        lib.sbk_prof_set_knob(42, 192)
+
+
 def build_lm(g, dev):
     from speechbrain_amd.lobes.models.transformer.TransformerLM import TransformerLM
 

@@ -321,6 +321,33 @@ if __name__ == "__main__":
                 nat.gemm_nt(a, w)
             torch.cuda.synchronize()
         sys.exit(0)
+    if "--x3r" in sys.argv:  # the decode step's projections: fp32-MFMA default route vs sbk_gemm_nt_x3r (both load schedules)
+        def ev_time(fn, n=40):
+            fn(); fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+        lib = nat.load()
+        for M in (320, 640, 1280, 2560):
+            for (N, K) in ((512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512)):
+                a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); r = torch.randn(M, N, device=dev)
+                t0 = ev_time(lambda: nat.gemm_nt_splitk(a, w, residual=r, slices=4))  # (the search's own route: gemm_nt_ws)
+                line = f"x3r M={M} N={N} K={K}: fp32-MFMA route {t0:6.1f} us {2.0*M*N*K/t0/1e6:6.1f} TF/s |"
+                for mode in (1, 2):
+                    lib.sbk_prof_set_knob(41, mode)
+                    t = ev_time(lambda: nat.gemm_nt_x3r(a, w, residual=r))
+                    line += f" x3r mode {mode}: {t:6.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s |"
+                lib.sbk_prof_set_knob(41, 2)
+                ref = a.double() @ w.double().t() + r.double()
+                e3 = float((nat.gemm_nt_x3r(a, w, residual=r).double() - ref).pow(2).mean().sqrt())
+                e0 = float((nat.gemm_nt_splitk(a, w, residual=r, slices=4).double() - ref).pow(2).mean().sqrt())
+                print(line + f" rms err vs fp64: x3r {e3:.3e} fp32 {e0:.3e}", flush=True)
+        sys.exit(0)
     if "--ln-x3p" in sys.argv:  # LayerNorm written as the next contraction's panel operand vs LayerNorm + split pass
         def ev_time(fn, n=30):
             fn(); fn()
