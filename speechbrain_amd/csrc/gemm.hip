@@ -1661,57 +1661,77 @@ __global__ void __launch_bounds__(256, 2) gemm_skinny_ln_kernel(GemmArgs g, floa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Few-row fp32 contraction on the bf16 matrix pipe ("x3r": the decode step's projections, 300 - 4 000 hypothesis rows).
+// Few-row fp32 contraction on the bf16 matrix pipe ("x3r": the decode step's projections, 200 - 4 000 hypothesis rows).
 // A kernel trace of a decoding step (profiles/r04_g_*) shows its launches back to back (45 us of gaps in 2.1 ms): the step
-// is the sum of its kernels, and 53 % of that are the decoder layers' projections at 27 - 80 TF/s -- register-operand
+// is the sum of its kernels, and 53 % of that were the decoder layers' projections at 27 - 80 TF/s -- register-operand
 // fp32-MFMA tiles whose operands arrive as 16-byte pieces of 64 different rows per load instruction (the texture
 // path serialises them) and whose 64 x 64 x 128 wave slices cost 4 096 matrix cycles each.  Here
 //   * W arrives pre-split in PANEL layout (sbk_split_x3p: the weights' image the encoder uses): a fragment load of 32
 //     rows is two 512-byte runs, and the same three-way operand split as sbk_gemm_nt_f32x3 puts the products on
 //     v_mfma_f32_32x32x16_bf16 (6 MFMAs of 8 passes per 16 k instead of 8 MFMAs of 16 passes);
-//   * A stays fp32 [M, K] (the activations of the step: LayerNorm / attention outputs) and is cut into its three pieces
-//     in registers (a lane holds 8 consecutive k of its row per step);
+//   * A is either fp32 [M, K] (cut into its three pieces in registers: a lane holds 8 consecutive k of its row per step)
+//     or -- APAN -- its panel image written by the kernel that produced it (LayerNorm, the previous projection's
+//     epilogue, sbk_split_x3p): coalesced fragment loads like W's, no VALU work in the loop;
 //   * tile 64 x 64, the four waves split K four ways (no LDS staging, no barrier in the loop; one LDS exchange of the
-//     partial tiles at the end, as gemm_skinny_flat64_kernel), blockIdx.y a further split of long K with the fixed-order
-//     reduce of splitk_reduce_kernel.
-// PIPE: the k steps in batches of 2 with the next batch's loads in flight under the current batch's MFMAs (fits 256
-// registers: two workgroups per CU); otherwise every load of the wave's slice is issued up front (one workgroup per CU).
-template <int NS, bool PIPE>
-__global__ void __launch_bounds__(256, PIPE ? 2 : 1) gemm_x3r_kernel(GemmArgs g, const uint4* __restrict__ PW,
-                                                                     float* __restrict__ partial, int tiles_m, int tiles_n) {
-  constexpr int SB = PIPE ? 2 : NS, NB = NS / SB;
-  static_assert(NS % SB == 0, "whole batches");
-  __shared__ float red[4][4][32][33];  // [wave][sub-tile][row][col]: partial tiles of the four K slices
+//     partial tiles at the end), blockIdx.y a further split of long K with the fixed-order reduce of
+//     splitk_reduce_kernel;
+//   * the k steps run through a ring of DEPTH single-step operand buffers: the loads of step s + DEPTH - 1 are in
+//     flight under the MFMAs of step s (<= 224 registers: two workgroups per CU).  The operands of a step are
+//     materialised by empty asm anchors where they are used -- without them hipcc hoists the split of an A fragment to
+//     its load (a wait in front of the next loads) or sinks the loads to their MFMAs;
+//   * W is the FIRST MFMA operand (the wave computes (W tile) . (A tile)^T): a lane owns one row m of C and register
+//     quads hold four consecutive columns -- bias / residual / result move as 16-byte vectors, and the result can be
+//     written as the panel image of the next projection's A operand (PC: the feed-forward pair's hidden layer).
+struct X3rArgs {
+  const float* A;    // fp32 [M, K], row stride lda (when PA is null)
+  const uint4* PA;   // or the panel image of A
+  const uint4* PW;   // panel image of W [N, K]
+  const float* bias;
+  const float* R;
+  float* C;          // fp32 result (may be null when PC is given)
+  uint2* PC;         // optional: the result as the panel image of a [M, N] matrix
+  float* partial;    // [gridDim.y][M][N] partial tiles of a long-K split
+  int lda, ldr, ldc, M, N, K, act, tiles_m, tiles_n;
+  float alpha;
+};
+
+template <int NS, bool APAN>
+__global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
+  constexpr int DEPTH = APAN ? 3 : 4;
+  __shared__ float4 red[4][4][4][64];  // [wave][sub-tile][register quad][lane]: partial tiles of the four K slices (64 KB)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int nt, mt;
-  {
+  {  // XCD-aware tile order: workgroup id = 8 q + x runs on XCD x; give it the column tiles nt = x (mod 8)
     const int id = blockIdx.x, x = id & 7, q = id >> 3;
-    const int nt8 = (tiles_n + 7) / 8;
-    mt = q % tiles_m;
-    nt = x + 8 * (q / tiles_m);
-    if (q / tiles_m >= nt8 || nt >= tiles_n) return;
+    const int nt8 = (g.tiles_n + 7) / 8;
+    mt = q % g.tiles_m;
+    nt = x + 8 * (q / g.tiles_m);
+    if (q / g.tiles_m >= nt8 || nt >= g.tiles_n) return;
   }
   const int r = lane & 31, half = lane >> 5;
   const int k_begin = (blockIdx.y * 4 + wave) * NS * 16, KB = g.K >> 4;
   const float* arow[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) arow[i] = g.A + (size_t)min(mt * 64 + i * 32 + r, g.M - 1) * g.lda + k_begin + 8 * half;
-  // chunk (row block nt, k step, piece 0, half), slot r: sub-tile j is 32 slots on, piece p two chunks (128 slots), a k step six
-  const uint4* wp = PW + ((size_t)(nt * KB + (k_begin >> 4)) * 6 + half) * 64 + r;
-  float4 av[PIPE ? 2 : 1][SB][2][2];
-  uint4 wv[PIPE ? 2 : 1][SB][2][3];
-  auto load = [&](int buf, int b) SBK_INLINE_LAMBDA {
+  // chunk (row block, k step, piece 0, half), slot r: sub-tile i / j is 32 slots on, piece p two chunks (128 slots), a k step six
+  const uint4* wp = g.PW + ((size_t)(nt * KB + (k_begin >> 4)) * 6 + half) * 64 + r;
+  const uint4* pa = g.PA + ((size_t)(mt * KB + (k_begin >> 4)) * 6 + half) * 64 + r;
+  float4 av[APAN ? 1 : DEPTH][2][2];
+  uint4 ap4[APAN ? DEPTH : 1][2][3];
+  uint4 wv[DEPTH][2][3];
+  auto load = [&](int buf, int st) SBK_INLINE_LAMBDA {
 #pragma unroll
-    for (int s = 0; s < SB; ++s) {
-      const int st = b * SB + s;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int p = 0; p < 3; ++p) wv[buf][j][p] = wp[(size_t)st * 384 + p * 128 + j * 32];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wv[buf][s][j][p] = wp[(size_t)st * 384 + p * 128 + j * 32];
+    for (int i = 0; i < 2; ++i) {
+      if constexpr (APAN) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        av[buf][s][i][0] = *reinterpret_cast<const float4*>(arow[i] + st * 16);
-        av[buf][s][i][1] = *reinterpret_cast<const float4*>(arow[i] + st * 16 + 4);
+        for (int p = 0; p < 3; ++p) ap4[buf][i][p] = pa[(size_t)st * 384 + p * 128 + i * 32];
+      } else {
+        av[buf][i][0] = *reinterpret_cast<const float4*>(arow[i] + st * 16);
+        av[buf][i][1] = *reinterpret_cast<const float4*>(arow[i] + st * 16 + 4);
       }
     }
   };
@@ -1723,26 +1743,30 @@ __global__ void __launch_bounds__(256, PIPE ? 2 : 1) gemm_x3r_kernel(GemmArgs g,
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
   auto compute = [&](int buf) SBK_INLINE_LAMBDA {
+    sbk::bf16x8 ap[2][3], bp[2][3];
 #pragma unroll
-    for (int s = 0; s < SB; ++s) {
-      // the step's operands are materialised HERE: without the anchors hipcc hoists the split of an A fragment to its load
-      // (a wait in front of the next loads: eight serial round trips instead of one), or sinks the loads to their MFMAs
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int p = 0; p < 3; ++p) {
+        sbk::pin(wv[buf][j][p].x), sbk::pin(wv[buf][j][p].y), sbk::pin(wv[buf][j][p].z), sbk::pin(wv[buf][j][p].w);
+        const uint4 u = wv[buf][j][p];
+        bp[j][p] = sbk::bf16x8_from_words(u.x, u.y, u.z, u.w);
+      }
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          sbk::pin(av[buf][s][i][e].x), sbk::pin(av[buf][s][i][e].y), sbk::pin(av[buf][s][i][e].z), sbk::pin(av[buf][s][i][e].w);
-        }
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 2; ++i) {
+      if constexpr (APAN) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          sbk::pin(wv[buf][s][j][p].x), sbk::pin(wv[buf][s][j][p].y), sbk::pin(wv[buf][s][j][p].z), sbk::pin(wv[buf][s][j][p].w);
+          sbk::pin(ap4[buf][i][p].x), sbk::pin(ap4[buf][i][p].y), sbk::pin(ap4[buf][i][p].z), sbk::pin(ap4[buf][i][p].w);
+          const uint4 u = ap4[buf][i][p];
+          ap[i][p] = sbk::bf16x8_from_words(u.x, u.y, u.z, u.w);
         }
-      sbk::bf16x8 ap[2][3], bp[2][3];
+      } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float4 x0 = av[buf][s][i][0], x1 = av[buf][s][i][1];
+        for (int e = 0; e < 2; ++e) {
+          sbk::pin(av[buf][i][e].x), sbk::pin(av[buf][i][e].y), sbk::pin(av[buf][i][e].z), sbk::pin(av[buf][i][e].w);
+        }
+        const float4 x0 = av[buf][i][0], x1 = av[buf][i][1];
         const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
         unsigned h[4], m[4], l[4];
 #pragma unroll
@@ -1756,55 +1780,108 @@ __global__ void __launch_bounds__(256, PIPE ? 2 : 1) gemm_x3r_kernel(GemmArgs g,
         ap[i][1] = sbk::bf16x8_from_words(m[0], m[1], m[2], m[3]);
         ap[i][2] = sbk::bf16x8_from_words(l[0], l[1], l[2], l[3]);
       }
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const uint4 u = wv[buf][s][j][p];
-          bp[j][p] = sbk::bf16x8_from_words(u.x, u.y, u.z, u.w);
-        }
-      // the six partial products of relative size >= 2^-17, smallest first; consecutive MFMAs go to different accumulators
-      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(ap[i][PA_[t]], bp[j][PB_[t]], acc[i][j]);
     }
-  };
-  load(0, 0);
+    // the six partial products of relative size >= 2^-17, smallest first; consecutive MFMAs go to different accumulators
+    constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    if (PIPE && b + 1 < NB) load((b + 1) & 1, b + 1);
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(bp[j][PB_[t]], ap[i][PA_[t]], acc[i][j]);
+  };
+#pragma unroll
+  for (int st = 0; st < DEPTH - 1 && st < NS; ++st) load(st, st);
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    if (st + DEPTH - 1 < NS) load((st + DEPTH - 1) % DEPTH, st + DEPTH - 1);
     sbk::sched_fence();
-    compute(PIPE ? (b & 1) : 0);
+    compute(st % DEPTH);
   }
+  // every wave publishes its four partial sub-tiles; wave s then owns sub-tile s = 2 i + j (fixed summation order)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) red[wave][2 * i + j][(q & 3) + 8 * (q >> 2) + 4 * half][r] = acc[i][j][q];
+      for (int q4 = 0; q4 < 4; ++q4)
+        red[wave][2 * i + j][q4][lane] = make_float4(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]);
   __syncthreads();
-  float v[16];
+  // lane = row (sub_m * 32 + r), register quad q4 = columns sub_n * 32 + 8 q4 + 4 half .. +3
+  const int row = (mt * 2 + (wave >> 1)) * 32 + r, col0 = (nt * 2 + (wave & 1)) * 32 + 4 * half;
+  const bool row_ok = row < g.M;
+  float4 v[4];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int rr = (q & 3) + 8 * (q >> 2) + 4 * half;
-    v[q] = ((red[0][wave][rr][r] + red[1][wave][rr][r]) + red[2][wave][rr][r]) + red[3][wave][rr][r];
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const float4 a0 = red[0][wave][q4][lane], a1 = red[1][wave][q4][lane], a2 = red[2][wave][q4][lane], a3 = red[3][wave][q4][lane];
+    v[q4] = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z,
+                        ((a0.w + a1.w) + a2.w) + a3.w);
   }
-  const int sub_m = mt * 2 + (wave >> 1), sub_n = nt * 2 + (wave & 1);
-  if (gridDim.y > 1) {
-    float* P = partial + (size_t)blockIdx.y * g.M * g.N;
-    const int col = sub_n * 32 + r;
+  if (gridDim.y > 1) {  // partial tile of a long-K split: combined (with the epilogue) by splitk_reduce_kernel
+    float* P = g.partial + ((size_t)blockIdx.y * g.M + (row_ok ? row : 0)) * g.N;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = sub_m * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-      if (row < g.M && col < g.N) P[(size_t)row * g.N + col] = v[q];
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int col = col0 + 8 * q4;
+      if (row_ok && col < g.N) *reinterpret_cast<float4*>(P + col) = v[q4];
     }
     return;
   }
-  tile_epilogue_32x32(g, v, sub_m, sub_n, r, half);
+  const float* rrow = g.R ? g.R + (size_t)(row_ok ? row : 0) * g.ldr : nullptr;
+  float4 bv[4], rv[4];
+  bool ok[4];
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {  // (N % 4 == 0: a vector is inside the matrix or outside as a whole)
+    const int col = col0 + 8 * q4;
+    ok[q4] = row_ok && col < g.N;
+    bv[q4] = (g.bias && ok[q4]) ? *reinterpret_cast<const float4*>(g.bias + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    rv[q4] = (rrow && ok[q4]) ? *reinterpret_cast<const float4*>(rrow + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  float o[16];
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    o[4 * q4] = v[q4].x + bv[q4].x, o[4 * q4 + 1] = v[q4].y + bv[q4].y, o[4 * q4 + 2] = v[q4].z + bv[q4].z, o[4 * q4 + 3] = v[q4].w + bv[q4].w;
+  }
+  switch (g.act) {  // uniform
+    case SBK_ACT_SWISH:
+#pragma unroll
+      for (int q = 0; q < 16; ++q) o[q] = o[q] / (1.0f + expf(-o[q]));
+      break;
+    case SBK_ACT_GELU:
+#pragma unroll
+      for (int q = 0; q < 16; ++q) o[q] = 0.5f * o[q] * (1.0f + erff(o[q] * 0.70710678118654752440f));
+      break;
+    case SBK_ACT_RELU:
+#pragma unroll
+      for (int q = 0; q < 16; ++q) o[q] = o[q] > 0.0f ? o[q] : 0.0f;
+      break;
+    case SBK_ACT_LEAKY_RELU:
+#pragma unroll
+      for (int q = 0; q < 16; ++q) o[q] = o[q] > 0.0f ? o[q] : 0.01f * o[q];
+      break;
+    default: break;
+  }
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const int col = col0 + 8 * q4;
+    const float o0 = o[4 * q4] * g.alpha + rv[q4].x, o1 = o[4 * q4 + 1] * g.alpha + rv[q4].y;
+    const float o2 = o[4 * q4 + 2] * g.alpha + rv[q4].z, o3 = o[4 * q4 + 3] * g.alpha + rv[q4].w;
+    if (!ok[q4]) continue;
+    if (g.C) *reinterpret_cast<float4*>(g.C + (size_t)row * g.ldc + col) = make_float4(o0, o1, o2, o3);
+    if (g.PC) {
+      // the result as the NEXT projection's A operand (its K = this N): columns col .. col+3 are k = col .. col+3 of row
+      // `row`: chunk (row / 64, col / 16, piece, (col % 16) / 8), slot row % 64, bytes (col % 8) * 2 .. +8
+      const unsigned h0 = sbk::bf16_pair(o0, o1), h1 = sbk::bf16_pair(o2, o3);
+      const float r0 = o0 - __uint_as_float(h0 << 16), r1 = o1 - __uint_as_float(h0 & 0xffff0000u);
+      const float r2 = o2 - __uint_as_float(h1 << 16), r3 = o3 - __uint_as_float(h1 & 0xffff0000u);
+      const unsigned m0 = sbk::bf16_pair(r0, r1), m1 = sbk::bf16_pair(r2, r3);
+      const unsigned l0 = sbk::bf16_pair(r0 - __uint_as_float(m0 << 16), r1 - __uint_as_float(m0 & 0xffff0000u));
+      const unsigned l1 = sbk::bf16_pair(r2 - __uint_as_float(m1 << 16), r3 - __uint_as_float(m1 & 0xffff0000u));
+      uint2* d = g.PC + (((size_t)(row >> 6) * (g.N >> 4) + (col >> 4)) * 6 + ((col >> 3) & 1)) * 128 + (row & 63) * 2 + ((col >> 2) & 1);
+      d[0] = make_uint2(h0, h1);
+      d[256] = make_uint2(m0, m1);
+      d[512] = make_uint2(l0, l1);
+    }
+  }
 }
 
 // C = epilogue(sum_ks partial[ks]) ; fixed summation order => run-to-run deterministic.
@@ -1952,40 +2029,49 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
 }
 
 // tuning knob (key 41): the decode step's projections on gemm_x3r_kernel: 0 = off (register-operand fp32-MFMA tiles),
-// 1 = every load of a wave's slice up front (one workgroup per CU), 2 = batches of two k steps, next batch in flight
+// otherwise on; key 44: 1 = their A operands as panel images too (LayerNorm -> panel, attention context through
+// sbk_split_x3p, the feed-forward hidden layer by the first projection's epilogue), 0 = fp32 A split in registers
 int g_x3r_mode = 2;
+int g_x3r_apanel = 1;
 int g_x3r_vocab = 1;      // key 43: 1 = the vocabulary projection of a step too (instead of the 128-wide persistent split-operand kernel)
 int g_x3r_min_rows = 192;  // key 42: rows from which the search routes a projection with a panel image to it
 bool x3r_routed(int M, int N, int K) { return g_x3r_mode != 0 && M >= g_x3r_min_rows && K % 256 == 0 && N % 4 == 0; }
-// -1: shape not eligible / no room for the K-split partials
-int gemm_nt_x3r(const float* A, int lda, const uint16_t* PW, const float* bias, const float* R, int ldr, float* C, int ldc,
-                int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, float* ws,
-                size_t ws_floats, hipStream_t st) {
+// A fp32 [M, K] (row stride lda) or PA = its panel image; C fp32 and / or PC = the result's panel image (N % 16 == 0, no
+// long-K split).  -1: shape not eligible / no room for the K-split partials
+int gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW, const float* bias, const float* R, int ldr,
+                float* C, int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, float* ws, size_t ws_floats,
+                hipStream_t st) {
   if (M == 0 || N == 0) return 0;
-  if (K % 256 != 0 || lda % 4 != 0 || !aligned16(A) || !aligned16(PW)) return -1;
+  if (K % 256 != 0 || N % 4 != 0 || !aligned16(PW) || (!A && !PA) || (!C && !PC)) return -1;
+  if (!PA && (lda % 4 != 0 || !aligned16(A))) return -1;
+  if ((PA && !aligned16(PA)) || (C && (ldc % 4 != 0 || !aligned16(C))) || (R && (ldr % 4 != 0 || !aligned16(R))) ||
+      (bias && !aligned16(bias)))
+    return -1;
   const int NS = K % 512 == 0 ? 8 : 4, SKg = K / (64 * NS);
-  if (SKg > 1 && (!ws || (size_t)SKg * M * N > ws_floats)) return -1;
-  GemmArgs g{A, nullptr, bias, R, C, lda, 0, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
+  if (SKg > 1 && (PC || !C || !ws || (size_t)SKg * M * N > ws_floats)) return -1;
+  if (PC && N % 16 != 0) return -1;
   const int tm = cdiv(M, 64), tn = cdiv(N, 64);
-  ProfScope prof("gemm_x3r", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N) + 6.0 * (double)N * K, st);
+  X3rArgs a{A, reinterpret_cast<const uint4*>(PA), reinterpret_cast<const uint4*>(PW), bias, R, C, reinterpret_cast<uint2*>(PC),
+            ws, lda, ldr, ldc, M, N, K, act, tm, tn, alpha};
+  ProfScope prof("gemm_x3r", 2.0 * M * N * K,
+                 (PA ? 6.0 : 4.0) * M * (double)K + 6.0 * (double)N * K + ((C ? 4.0 : 0.0) + (PC ? 6.0 : 0.0) + (R ? 4.0 : 0.0)) * M * (double)N, st);
   dim3 grid(8 * tm * cdiv(tn, 8), SKg), block(256);
-  const uint4* P4 = reinterpret_cast<const uint4*>(PW);
-  const bool pipe = g_x3r_mode != 1;
   if (NS == 8) {
-    if (pipe) {
-      SBK_LAUNCH((gemm_x3r_kernel<8, true>), grid, block, 0, st, g, P4, ws, tm, tn);
+    if (PA) {
+      SBK_LAUNCH((gemm_x3r_kernel<8, true>), grid, block, 0, st, a);
     } else {
-      SBK_LAUNCH((gemm_x3r_kernel<8, false>), grid, block, 0, st, g, P4, ws, tm, tn);
+      SBK_LAUNCH((gemm_x3r_kernel<8, false>), grid, block, 0, st, a);
     }
   } else {
-    if (pipe) {
-      SBK_LAUNCH((gemm_x3r_kernel<4, true>), grid, block, 0, st, g, P4, ws, tm, tn);
+    if (PA) {
+      SBK_LAUNCH((gemm_x3r_kernel<4, true>), grid, block, 0, st, a);
     } else {
-      SBK_LAUNCH((gemm_x3r_kernel<4, false>), grid, block, 0, st, g, P4, ws, tm, tn);
+      SBK_LAUNCH((gemm_x3r_kernel<4, false>), grid, block, 0, st, a);
     }
   }
   int rc = launch_status("gemm_x3r");
   if (rc || SKg == 1) return rc;
+  GemmArgs g{A, nullptr, bias, R, C, lda, 0, ldr, ldc, M, N, K, act, alpha, nullptr, 1};
   const size_t total = (size_t)M * N;
   SBK_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, g, (const float*)ws, SKg);
   return launch_status("splitk_reduce");
@@ -2362,6 +2448,7 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 41) sbk::g_x3r_mode = value;
   if (key == 42) sbk::g_x3r_min_rows = value;
   if (key == 43) sbk::g_x3r_vocab = value;
+  if (key == 44) sbk::g_x3r_apanel = value;
   if (key == 36) sbk::g_splitk_fused = value;
   if (key == 37) sbk::g_cross_fused_merge = value;
   if (key == 34) sbk::g_x3_route_rows = value;
@@ -2398,19 +2485,24 @@ extern "C" int sbk_gemm_nt_f32x3(const float* A, int lda, const uint16_t* W3, co
   return rc;
 }
 
-extern "C" int sbk_gemm_nt_x3r(const float* A, int lda, const uint16_t* PW, const float* bias, const float* residual,
-                               int ldr, float* C, int ldc, int M, int N, int K, int act, float alpha, float* workspace,
-                               size_t workspace_floats, sbk_stream_t stream) {
+extern "C" int sbk_gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW, const float* bias,
+                               const float* residual, int ldr, float* C, int ldc, uint16_t* PC, int M, int N, int K, int act,
+                               float alpha, float* workspace, size_t workspace_floats, sbk_stream_t stream) {
   if (M == 0 || N == 0) return 0;
-  SBK_REQUIRE(A && PW && C, "gemm_x3r: null operand");
-  SBK_REQUIRE(M >= 0 && N >= 0 && K >= 256 && K % 256 == 0, "gemm_x3r: bad shape M=%d N=%d K=%d (K: a multiple of 256)", M, N, K);
-  SBK_REQUIRE(lda >= K && lda % 4 == 0 && ldc >= N && sbk::aligned16(A) && sbk::aligned16(PW),
-              "gemm_x3r: operand rows must be 16-byte aligned (lda=%d)", lda);
-  SBK_REQUIRE(!residual || ldr >= N, "gemm_x3r: residual stride");
+  SBK_REQUIRE((A || PA) && PW && (C || PC), "gemm_x3r: null operand");
+  SBK_REQUIRE(M >= 0 && N >= 0 && N % 4 == 0 && K >= 256 && K % 256 == 0,
+              "gemm_x3r: bad shape M=%d N=%d K=%d (N: a multiple of 4, K: a multiple of 256)", M, N, K);
+  SBK_REQUIRE(PA || (lda >= K && lda % 4 == 0 && sbk::aligned16(A)), "gemm_x3r: rows of A must be 16-byte aligned (lda=%d)", lda);
+  SBK_REQUIRE(sbk::aligned16(PW) && (!PA || sbk::aligned16(PA)) && (!PC || (sbk::aligned16(PC) && N % 16 == 0)),
+              "gemm_x3r: panel images must be 16-byte aligned (a panel result needs N %% 16 == 0)");
+  SBK_REQUIRE(!C || (ldc >= N && ldc % 4 == 0 && sbk::aligned16(C)), "gemm_x3r: C rows are stored as 16-byte vectors (ldc=%d)", ldc);
+  SBK_REQUIRE(!residual || (ldr >= N && ldr % 4 == 0 && sbk::aligned16(residual)), "gemm_x3r: residual stride / alignment");
+  SBK_REQUIRE(!bias || sbk::aligned16(bias), "gemm_x3r: bias alignment");
   SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_x3r: unknown activation %d", act);
-  SBK_REQUIRE(K <= 512 || (workspace && workspace_floats >= (size_t)(K / 512) * M * N),
-              "gemm_x3r: K = %d needs a workspace of %zu floats for the partial tiles of its K split", K, (size_t)(K / 512) * M * N);
-  const int rc = sbk::gemm_nt_x3r(A, lda, PW, bias, residual, ldr, C, ldc, M, N, K, act, alpha, nullptr, 1, workspace,
+  SBK_REQUIRE(K <= 512 || (C && !PC && workspace && workspace_floats >= (size_t)(K / 512) * M * N),
+              "gemm_x3r: K = %d needs an fp32 result and a workspace of %zu floats for the partial tiles of its K split", K,
+              (size_t)(K / 512) * M * N);
+  const int rc = sbk::gemm_nt_x3r(A, lda, PA, PW, bias, residual, ldr, C, ldc, PC, M, N, K, act, alpha, workspace,
                                   workspace_floats, sbk::as_stream(stream));
   if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_x3r: shape not eligible");
   return rc;

@@ -939,6 +939,8 @@ struct Carver {
 
 struct DecoderBufs {
   float *x, *h, *qkv, *ctx, *q, *ff, *logits;
+  uint16_t *hp, *ctxp, *ffp;  // panel images (sbk_split_x3p layout) of the LayerNorm output / attention context / feed-forward
+                              // hidden layer: the A operands of the step's projections on sbk_gemm_nt_x3r
   float* splitk;        // split-K partials of the skinny GEMMs
   size_t splitk_floats;
   float* xpart;         // cross-attention split partials
@@ -958,6 +960,10 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
   d.q = c.take<float>((size_t)n * dm);
   d.ff = c.take<float>((size_t)n * W->d_ffn);
   d.logits = c.take<float>((size_t)n * W->vocab);
+  const size_t n64 = ((size_t)n + 63) / 64 * 64;
+  d.hp = c.take<uint16_t>(n64 * dm * 3);
+  d.ctxp = c.take<uint16_t>(n64 * dm * 3);
+  d.ffp = c.take<uint16_t>(n64 * W->d_ffn * 3);
   d.splitk_floats = (size_t)4 * n * (size_t)dm;  // global split-K is used for the long-K FFN2 only
   d.splitk = c.take<float>(d.splitk_floats);
   d.xpart = c.take<float>(sbk::cross_attn_partial_floats(B, T, W->nhead, dm / W->nhead, n / (B > 0 ? B : 1)) + 64);
@@ -1014,27 +1020,38 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
   SBK_TRY(sbk::embed_pos(tokens, W->emb, W->pe + (size_t)step * dm, d.x, n, dm, emb_scale, st));
   // a projection with a panel image of its weights and enough hypothesis rows: sbk_gemm_nt_x3r (fp32 result on the bf16
   // matrix pipe); -1 = not routed (the register-operand / LDS-tiled fp32-MFMA kernels below)
-  auto x3r = [&](const float* A, int lda, const uint16_t* WP, const float* b, const float* R, float* C, int N, int K,
-                 int act) -> int {
+  auto x3r = [&](const float* A, int lda, const uint16_t* PA, const uint16_t* WP, const float* b, const float* R, float* C,
+                 uint16_t* PC, int N, int K, int act) -> int {
     if (!WP || !sbk::x3r_routed(n, N, K)) return -1;
-    return sbk::gemm_nt_x3r(A, lda, WP, b, R, N, C, N, n, N, K, act, 1.0f, nullptr, 0, d.splitk, d.splitk_floats, st);
+    return sbk::gemm_nt_x3r(A, lda, PA, WP, b, R, N, C, N, PC, n, N, K, act, 1.0f, d.splitk, d.splitk_floats, st);
+  };
+  const bool apan = sbk::g_x3r_apanel && dm % 16 == 0 && dm <= 2048 && W->d_ffn % 16 == 0;
+  // LayerNorm of the residual stream as the next projection's operand: its panel image (apan) or fp32 rows
+  auto norm = [&](const float* g_, const float* b_) -> int {
+    if (apan) return sbk_layernorm_x3p(d.x, g_, b_, d.hp, n, dm, W->ln_eps, SBK_ACT_NONE, st);
+    return sbk::layernorm(d.x, g_, b_, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st);
   };
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
     if (L.sa_in_wp && L.sa_out_wp && L.ca_q_wp && L.ca_out_wp && L.ff1_wp && L.ff2_wp && sbk::x3r_routed(n, dm, dm) &&
         sbk::x3r_routed(n, dm, W->d_ffn) && (size_t)(W->d_ffn / 512) * n * dm <= d.splitk_floats) {
-      SBK_TRY(sbk::layernorm(d.x, L.ln1_g, L.ln1_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
-      SBK_TRY(x3r(d.h, dm, L.sa_in_wp, L.sa_in_b, nullptr, d.qkv, 3 * dm, dm, SBK_ACT_NONE));
+      const float* hA = apan ? nullptr : d.h;
+      const uint16_t* hP = apan ? d.hp : nullptr;
+      SBK_TRY(norm(L.ln1_g, L.ln1_b));
+      SBK_TRY(x3r(hA, dm, hP, L.sa_in_wp, L.sa_in_b, nullptr, d.qkv, nullptr, 3 * dm, dm, SBK_ACT_NONE));
       SBK_TRY(sbk::self_attn_step(d.qkv, d.kcache[l], d.vcache[l], kv_slot, d.ctx, n, dm, H, step, n, Lmax, st, nullptr, 0, 0,
                                   0, 0, beam));
-      SBK_TRY(x3r(d.ctx, dm, L.sa_out_wp, L.sa_out_b, d.x, d.x, dm, dm, SBK_ACT_NONE));
-      SBK_TRY(sbk::layernorm(d.x, L.ln2_g, L.ln2_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
-      SBK_TRY(x3r(d.h, dm, L.ca_q_wp, L.ca_in_b, nullptr, d.q, dm, dm, SBK_ACT_NONE));
+      if (apan) SBK_TRY(sbk_split_x3p(d.ctx, dm, d.ctxp, n, dm, st));
+      SBK_TRY(x3r(apan ? nullptr : d.ctx, dm, apan ? d.ctxp : nullptr, L.sa_out_wp, L.sa_out_b, d.x, d.x, nullptr, dm, dm, SBK_ACT_NONE));
+      SBK_TRY(norm(L.ln2_g, L.ln2_b));
+      SBK_TRY(x3r(hA, dm, hP, L.ca_q_wp, L.ca_in_b, nullptr, d.q, nullptr, dm, dm, SBK_ACT_NONE));
       SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, d.xpart, B, T, dm, H, beam, st, d.head_major, d.xcnt));
-      SBK_TRY(x3r(d.ctx, dm, L.ca_out_wp, L.ca_out_b, d.x, d.x, dm, dm, SBK_ACT_NONE));
-      SBK_TRY(sbk::layernorm(d.x, L.ln3_g, L.ln3_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
-      SBK_TRY(x3r(d.h, dm, L.ff1_wp, L.ff1_b, nullptr, d.ff, W->d_ffn, dm, W->ffn_act));
-      SBK_TRY(x3r(d.ff, W->d_ffn, L.ff2_wp, L.ff2_b, d.x, d.x, dm, W->d_ffn, SBK_ACT_NONE));
+      if (apan) SBK_TRY(sbk_split_x3p(d.ctx, dm, d.ctxp, n, dm, st));
+      SBK_TRY(x3r(apan ? nullptr : d.ctx, dm, apan ? d.ctxp : nullptr, L.ca_out_wp, L.ca_out_b, d.x, d.x, nullptr, dm, dm, SBK_ACT_NONE));
+      SBK_TRY(norm(L.ln3_g, L.ln3_b));
+      // the feed-forward pair: the hidden layer goes from the first projection's epilogue to the second as a panel image
+      SBK_TRY(x3r(hA, dm, hP, L.ff1_wp, L.ff1_b, nullptr, apan ? nullptr : d.ff, apan ? d.ffp : nullptr, W->d_ffn, dm, W->ffn_act));
+      SBK_TRY(x3r(apan ? nullptr : d.ff, W->d_ffn, apan ? d.ffp : nullptr, L.ff2_wp, L.ff2_b, d.x, d.x, nullptr, dm, W->d_ffn, SBK_ACT_NONE));
       continue;
     }
     int frc = L.sa_in_wf ? sbk::gemm_ln_nt(d.x, dm, L.sa_in_wf, dm, L.sa_in_bf, nullptr, 0, d.qkv, 3 * dm, n, 3 * dm, dm,
@@ -1081,7 +1098,7 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
   }
   SBK_TRY(sbk::layernorm(d.x, W->final_ln_g, W->final_ln_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
   if (want_logits) {
-    int rc = sbk::g_x3r_vocab ? x3r(d.h, dm, W->seq_wp, W->seq_b, nullptr, d.logits, W->vocab, dm, SBK_ACT_NONE) : -1;
+    int rc = sbk::g_x3r_vocab ? x3r(d.h, dm, nullptr, W->seq_wp, W->seq_b, nullptr, d.logits, nullptr, W->vocab, dm, SBK_ACT_NONE) : -1;
     if (rc == -1 && W->seq_w3 && sbk::x3_routed(n, W->vocab, dm))
       rc = sbk::gemm_nt_x3(d.h, dm, W->seq_w3, W->seq_b, nullptr, 0, d.logits, W->vocab, n, W->vocab, dm, SBK_ACT_NONE, 1.0f,
                            nullptr, 0, st);

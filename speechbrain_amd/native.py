@@ -101,7 +101,7 @@ def _declare(lib):
         "sbk_x3p_panel_bytes": ([i, i], ctypes.c_size_t),
         "sbk_split_x3p": ([p, i, p, i, i, p], c_int),
         "sbk_layernorm_x3p": ([p, p, p, p, i, i, f, i, p], c_int),
-        "sbk_gemm_nt_x3r": ([p, i, p, p, p, i, p, i, i, i, i, i, f, p, ctypes.c_size_t, p], c_int),
+        "sbk_gemm_nt_x3r": ([p, i, p, p, p, p, i, p, i, p, i, i, i, i, f, p, ctypes.c_size_t, p], c_int),
         "sbk_input_norm_global_masked_f32": ([p, p, p, p, p, i, i, i, f, p], c_int),
         "sbk_gemm_nt_x3p": ([p, p, p, p, i, p, i, p, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_bf16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
@@ -430,20 +430,31 @@ def gemm_nt_x3p(a: Panel, w: torch.Tensor, bias=None, residual=None, act=ACT_NON
     return out
 
 
-def gemm_nt_x3r(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0):
+def gemm_nt_x3r(a, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, panel_out=False, fp32_out=True):
     """out[M,N] = residual + alpha * act(a @ w^T + bias) for FEW rows (a decoding step's projections) on the bf16 matrix
-    pipe: a stays fp32 and is split in registers, w is used through its cached panel image (sbk_gemm_nt_x3r)."""
+    pipe (sbk_gemm_nt_x3r): ``a`` is an fp32 tensor (split in registers) or a Panel, ``w`` is used through its cached panel
+    image; ``panel_out``: also (or, with ``fp32_out=False``, only) return the result as a Panel."""
     lib = load()
-    K = a.shape[-1]
-    a2 = a.reshape(-1, K)
-    M, N = a2.shape[0], w.shape[0]
-    _dev_ok(a2, w, bias, residual)
-    _f32(a2)
-    out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
+    if isinstance(a, Panel):
+        M, K, lead, a2, dev = a.rows, a.K, (a.lead if a.lead is not None else (a.rows,)), None, a.device
+        _dev_ok(a.data)
+    else:
+        K = a.shape[-1]
+        a2 = a.reshape(-1, K)
+        M, lead, dev = a2.shape[0], tuple(a.shape[:-1]), a.device
+        _dev_ok(a2)
+        _f32(a2)
+    N = w.shape[0]
+    _dev_ok(w, bias, residual)
+    out = torch.empty(*lead, N, dtype=torch.float32, device=dev) if fp32_out else None
+    pc = panel_empty(M, N, dev, lead) if panel_out else None
     r2 = residual.reshape(-1, N) if residual is not None else None
-    ws = torch.empty(max(1, (K // 512) * M * N if K > 512 else 1), dtype=torch.float32, device=a.device)
-    _chk(lib.sbk_gemm_nt_x3r(_p(a2), K, _p(lp_weight(w, "x3p")), _p(bias), _p(r2), N, _p(out), N, M, N, K, act, float(alpha),
-                             _p(ws), ws.numel(), _stream(a2)), "sbk_gemm_nt_x3r")
+    ws = torch.empty(max(1, (K // 512) * M * N if K > 512 else 1), dtype=torch.float32, device=dev)
+    _chk(lib.sbk_gemm_nt_x3r(_p(a2), K, _p(a.data) if a2 is None else None, _p(lp_weight(w, "x3p")), _p(bias), _p(r2), N,
+                             _p(out), N, _p(pc.data) if pc is not None else None, M, N, K, act, float(alpha), _p(ws),
+                             ws.numel(), _stream(ws)), "sbk_gemm_nt_x3r")
+    if panel_out:
+        return (out, pc) if fp32_out else pc
     return out
 
 

@@ -837,12 +837,14 @@ def test_gemm_x3p(backend, M, N, K, tile):
 
 @pytest.mark.parametrize("M,N,K", [(1280, 512, 512), (300, 132, 256), (70, 1536, 512), (640, 512, 2048), (1280, 2048, 512),
                                    (333, 64, 1024), (1, 40, 256), (1280, 5000, 512)])
-@pytest.mark.parametrize("mode", [1, 2])
-def test_gemm_x3r(backend, M, N, K, mode):
-    """sbk_gemm_nt_x3r: the decode step's few-row projections on the bf16 matrix pipe (fp32 A split in registers, W as its
-    panel image, 64 x 64 tiles whose four waves split K, long K split further with a fixed-order reduce).  Held to the
-    bound of every fp32 kernel of the library against the fp64 product (2e-6 of the largest sum of magnitudes); both load
-    schedules (knob 41); ragged edges; bias / activation / scaled residual; run-to-run bit-identical."""
+@pytest.mark.parametrize("a_panel", [False, True])
+def test_gemm_x3r(backend, M, N, K, a_panel):
+    """sbk_gemm_nt_x3r: the decode step's few-row projections on the bf16 matrix pipe (W as its panel image; A fp32 and
+    split in registers, or as its panel image too; 64 x 64 tiles whose four waves split K, long K split further with a
+    fixed-order reduce).  Held to the bound of every fp32 kernel of the library against the fp64 product (2e-6 of the
+    largest sum of magnitudes); ragged edges; bias / activation / scaled residual; the panel-image result (the next
+    projection's A operand) equals the fp32 result bit for bit; both forms of A give the SAME bits (the split is exact);
+    run-to-run bit-identical."""
     nat, dev = backend
     if dev.type == "cpu" and M * N * K > 1.2e8:
         pytest.skip("large shape: GPU only")
@@ -852,21 +854,30 @@ def test_gemm_x3r(backend, M, N, K, mode):
     a[::7] *= 1e-3
     w[::5] *= 300.0
     b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
-    lib = nat.load()
-    lib.sbk_prof_set_knob(41, mode)
-    try:
-        ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
-        prod = a.double() @ w.double().t()
-        scale = float((a.double().abs() @ w.double().abs().t()).max())
-        out = nat.gemm_nt_x3r(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5)
-        ref = (r.double() + 0.5 * F.silu(prod + b.double())).float()
-        assert _md(out, ref) <= 2e-6 * scale + 1e-5
-        for _ in range(3 if dev.type == "cuda" else 1):
-            assert torch.equal(nat.gemm_nt_x3r(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
-        plain = nat.gemm_nt_x3r(ad, wd)
-        assert _md(plain, prod.float()) <= 2e-6 * scale + 1e-5
-    finally:
-        lib.sbk_prof_set_knob(41, 2)
+    ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    op = nat.split_x3p(ad) if a_panel else ad
+    prod = a.double() @ w.double().t()
+    scale = float((a.double().abs() @ w.double().abs().t()).max())
+    out = nat.gemm_nt_x3r(op, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5)
+    ref = (r.double() + 0.5 * F.silu(prod + b.double())).float()
+    assert _md(out, ref) <= 2e-6 * scale + 1e-5
+    for _ in range(3 if dev.type == "cuda" else 1):
+        assert torch.equal(nat.gemm_nt_x3r(op, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
+    if a_panel:
+        assert torch.equal(out, nat.gemm_nt_x3r(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5))
+    plain = nat.gemm_nt_x3r(op, wd)
+    assert _md(plain, prod.float()) <= 2e-6 * scale + 1e-5
+    if N % 16 == 0 and K <= 512:
+        both, pc = nat.gemm_nt_x3r(op, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5, panel_out=True)
+        RB, KBn = (M + 63) // 64, N // 16
+        pieces = (pc.data.cpu().view(torch.int16).to(torch.int32) << 16).view(torch.float32).view(RB, KBn, 3, 2, 64, 8)
+        full = pieces.double().sum(2).permute(0, 3, 1, 2, 4).reshape(RB * 64, N).float()
+        assert torch.equal(both, out) and torch.equal(full[:M], out.cpu())
+        only = nat.gemm_nt_x3r(op, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5, panel_out=True, fp32_out=False)
+        # (the hand-over: a second projection fed with the panel image equals the one fed with the fp32 result)
+        w2 = torch.randn(64, N, generator=g).to(dev)
+        if N % 256 == 0:
+            assert torch.equal(nat.gemm_nt_x3r(only, w2), nat.gemm_nt_x3r(out, w2))
 
 
 @pytest.mark.parametrize("rows,d,act", [(130, 512, 0), (64, 32, 1), (777, 144, 0), (300, 1024, 1), (129, 2048, 0), (5, 16, 0)])

@@ -338,11 +338,15 @@ if __name__ == "__main__":
                 a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); r = torch.randn(M, N, device=dev)
                 t0 = ev_time(lambda: nat.gemm_nt_splitk(a, w, residual=r, slices=4))  # (the search's own route: gemm_nt_ws)
                 line = f"x3r M={M} N={N} K={K}: fp32-MFMA route {t0:6.1f} us {2.0*M*N*K/t0/1e6:6.1f} TF/s |"
-                for mode in (1, 2):
-                    lib.sbk_prof_set_knob(41, mode)
-                    t = ev_time(lambda: nat.gemm_nt_x3r(a, w, residual=r))
-                    line += f" x3r mode {mode}: {t:6.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s |"
-                lib.sbk_prof_set_knob(41, 2)
+                t = ev_time(lambda: nat.gemm_nt_x3r(a, w, residual=r))
+                line += f" x3r, A fp32: {t:6.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s |"
+                pa = nat.split_x3p(a)
+                t = ev_time(lambda: nat.gemm_nt_x3r(pa, w, residual=r))
+                tsp = ev_time(lambda: nat.split_x3p(a))
+                line += f" A panel: {t:6.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s (split pass {tsp:4.1f} us) |"
+                if K <= 512 and N % 16 == 0:
+                    t = ev_time(lambda: nat.gemm_nt_x3r(pa, w, act=nat.ACT_GELU, panel_out=True, fp32_out=False))
+                    line += f" panel out: {t:6.1f} us |"
                 ref = a.double() @ w.double().t() + r.double()
                 e3 = float((nat.gemm_nt_x3r(a, w, residual=r).double() - ref).pow(2).mean().sqrt())
                 e0 = float((nat.gemm_nt_splitk(a, w, residual=r, slices=4).double() - ref).pow(2).mean().sqrt())
