@@ -2030,9 +2030,10 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
 
 // tuning knob (key 41): the decode step's projections on gemm_x3r_kernel: 0 = off (register-operand fp32-MFMA tiles),
 // otherwise on; key 44: 1 = their A operands as panel images too (LayerNorm -> panel, attention context through
-// sbk_split_x3p, the feed-forward hidden layer by the first projection's epilogue), 0 = fp32 A split in registers
+// sbk_split_x3p, the feed-forward hidden layer by the first projection's epilogue), 0 (default) = fp32 A split in registers
 int g_x3r_mode = 2;
-int g_x3r_apanel = 1;
+int g_x3r_apanel = 0;  // (measured, profiles/r04_i_*: panel A operands are no faster inside the contraction -- 12.9 vs 14.2 us at 1 280 x
+                       // 512 x 512, 20.6 vs 18.6 at N = 1 536 -- and their producers cost more than they save at 1 280 rows)
 int g_x3r_vocab = 1;      // key 43: 1 = the vocabulary projection of a step too (instead of the 128-wide persistent split-operand kernel)
 int g_x3r_min_rows = 192;  // key 42: rows from which the search routes a projection with a panel image to it
 bool x3r_routed(int M, int N, int K) { return g_x3r_mode != 0 && M >= g_x3r_min_rows && K % 256 == 0 && N % 4 == 0; }

@@ -418,10 +418,16 @@ extern "C" int sbk_layernorm_x3p(const float* x, const float* gamma, const float
   sbk::ProfScope prof("layernorm_x3p", 8.0 * rows * d, (4.0 * rows + 6.0 * rows64) * d, st);
   uint4* P4 = reinterpret_cast<uint4*>(P);
   const dim3 grid(rows64 / 8), block(512);
-  if (d <= 512) {
+  // (few rows: the 8-rows-per-wave kernel leaves the chip empty -- 32 us at 1 280 x 512, 40 workgroups -- so the
+  // row-per-wave kernel takes them; profiles/r04_i_*)
+  if (d <= 512 && rows >= 4096) {
     SBK_LAUNCH(layernorm_x3p_rows8_kernel<8>, dim3(rows64 / 32), dim3(256), 0, st, x, gamma, beta, P4, rows, d, eps, act);
-  } else if (d <= 1024) {
+  } else if (d > 512 && d <= 1024 && rows >= 4096) {
     SBK_LAUNCH(layernorm_x3p_rows8_kernel<16>, dim3(rows64 / 32), dim3(256), 0, st, x, gamma, beta, P4, rows, d, eps, act);
+  } else if (d <= 512) {
+    SBK_LAUNCH(layernorm_x3p_kernel<1>, grid, block, 0, st, x, gamma, beta, P4, rows, d, eps, act);
+  } else if (d <= 1024) {
+    SBK_LAUNCH(layernorm_x3p_kernel<2>, grid, block, 0, st, x, gamma, beta, P4, rows, d, eps, act);
   } else {
     SBK_LAUNCH(layernorm_x3p_kernel<4>, grid, block, 0, st, x, gamma, beta, P4, rows, d, eps, act);
   }

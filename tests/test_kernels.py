@@ -880,7 +880,8 @@ def test_gemm_x3r(backend, M, N, K, a_panel):
             assert torch.equal(nat.gemm_nt_x3r(only, w2), nat.gemm_nt_x3r(out, w2))
 
 
-@pytest.mark.parametrize("rows,d,act", [(130, 512, 0), (64, 32, 1), (777, 144, 0), (300, 1024, 1), (129, 2048, 0), (5, 16, 0)])
+@pytest.mark.parametrize("rows,d,act", [(130, 512, 0), (64, 32, 1), (777, 144, 0), (300, 1024, 1), (129, 2048, 0), (5, 16, 0),
+                                        (4100, 512, 1), (4097, 1024, 0)])
 def test_layernorm_x3p(backend, rows, d, act):
     """sbk_layernorm_x3p: act(LayerNorm(x)) written directly as the panel image of its result (the A operand of the
     contraction that consumes it).  The image's three pieces must add up to the fp32 LayerNorm (same two-pass statistics;
@@ -889,7 +890,7 @@ def test_layernorm_x3p(backend, rows, d, act):
     must match the one fed with split(LayerNorm)."""
     nat, dev = backend
     g = torch.Generator().manual_seed(rows + d)
-    x = torch.randn(rows, d, generator=g) * 3.0 + torch.arange(rows)[:, None] * 0.05
+    x = torch.randn(rows, d, generator=g) * 3.0 + torch.arange(rows)[:, None] * (0.05 if rows < 1000 else 0.002)  # (row means up to ~40)
     gamma, beta = torch.randn(d, generator=g), torch.randn(d, generator=g)
     code = nat.ACT_SWISH if act else nat.ACT_NONE
     pan = nat.layernorm_x3p(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5, act=code)

@@ -254,8 +254,8 @@ def test_decoder_on_the_x3r_route_vs_oracle(backend, mode):
     more): d_model 256 / d_ffn 512 are eligible widths (K % 256 == 0), the row threshold is lowered so that this small
     search takes it (knob 42).  Teacher-forced decoder outputs 5e-5 and a beam search with CTC (ids exact, scores 1e-4)
     against the oracle; with the A operands as panel images too (LayerNorm written as a panel, attention context through
-    sbk_split_x3p, the feed-forward hidden layer handed over by the first projection's epilogue: knob 44 = 1, the default)
-    and as fp32 rows split in registers (0); the result does not change when the route is switched off."""
+    sbk_split_x3p, the feed-forward hidden layer handed over by the first projection's epilogue: knob 44 = 1) and as fp32
+    rows split in registers (0, the default); the result does not change when the route is switched off."""
     nat, dev = backend
     from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
     from speechbrain_amd.inference.builders import build_modules
@@ -298,7 +298,7 @@ def test_decoder_on_the_x3r_route_vs_oracle(backend, mode):
         assert hyps0 == hyps and float((sc0 - sc).abs().max()) <= 1e-4
     finally:
         lib.sbk_prof_set_knob(41, 2)
-        lib.sbk_prof_set_knob(44, 1)
+        lib.sbk_prof_set_knob(44, 0)
         lib.sbk_prof_set_knob(42, 192)
 
 
