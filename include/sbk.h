@@ -215,11 +215,10 @@ int sbk_gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, c
  * hypothesis rows).  A is given either as fp32 [M, K] (row stride lda; split in registers) or as its panel image PA (A may
  * then be NULL); PW is the panel image of W [N, K] (sbk_split_x3p); 64 x 64 tiles whose four waves split K; N % 4 == 0,
  * K % 256 == 0.  The result goes to C (fp32) and / or PC, the panel image of the [M, N] result (N % 16 == 0) = the A
- * operand of the next projection.  K > 512 needs an fp32 result and `workspace` (K / 512 * M * N floats) for the partial
- * tiles of the K split, summed in a fixed order.  Epilogue: residual + alpha * act(. + bias). */
+ * operand of the next projection.  Epilogue: residual + alpha * act(. + bias).  No workspace: K is never split across
+ * workgroups (fixed summation order: the four waves' K quarters in order). */
 int sbk_gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW, const float* bias, const float* residual,
-                    int ldr, float* C, int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, float* workspace,
-                    size_t workspace_floats, sbk_stream_t stream);
+                    int ldr, float* C, int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, sbk_stream_t stream);
 
 /* ---- bf16-operand fast entry points ("fp32 parity entry points plus bf16 ... fast entry points").
  * C = epilogue(bf16(A) . Wb^T) with fp32 accumulation on v_mfma_f32_32x32x16_bf16: A [M,K] stays fp32 in memory and is

@@ -1672,11 +1672,13 @@ __global__ void __launch_bounds__(256, 2) gemm_skinny_ln_kernel(GemmArgs g, floa
 //   * A is either fp32 [M, K] (cut into its three pieces in registers: a lane holds 8 consecutive k of its row per step)
 //     or -- APAN -- its panel image written by the kernel that produced it (LayerNorm, the previous projection's
 //     epilogue, sbk_split_x3p): coalesced fragment loads like W's, no VALU work in the loop;
-//   * tile 64 x 64, the four waves split K four ways (no LDS staging, no barrier in the loop; one LDS exchange of the
-//     partial tiles at the end), blockIdx.y a further split of long K with the fixed-order reduce of
-//     splitk_reduce_kernel;
-//   * the k steps run through a ring of DEPTH single-step operand buffers: the loads of step s + DEPTH - 1 are in
-//     flight under the MFMAs of step s (<= 224 registers: two workgroups per CU).  The operands of a step are
+//   * tile 64 x 64, the four waves split K four ways -- each takes K / 64 steps of 16 k, however long K is: no LDS
+//     staging, no barrier in the loop, one LDS exchange of the partial tiles at the end.  (The fp32-MFMA kernels split a
+//     long K across workgroups as well, to fill the chip, and pay a reduce launch: on the bf16 pipe the 2 048-deep
+//     feed-forward projection of 1 280 rows is 10 us of matrix time per workgroup on 160 CUs);
+//   * the k steps run through a ring of four single-step operand buffers (two with panel A): the loads of step s + 3
+//     (s + 1) are in flight under the MFMAs of step s (<= 256 registers: two workgroups per CU); the step loop is rolled
+//     over the ring (K / 64 steps per wave: 8 at K = 512, 32 at 2 048).  The operands of a step are
 //     materialised by empty asm anchors where they are used -- without them hipcc hoists the split of an A fragment to
 //     its load (a wait in front of the next loads) or sinks the loads to their MFMAs;
 //   * W is the FIRST MFMA operand (the wave computes (W tile) . (A tile)^T): a lane owns one row m of C and register
@@ -1690,14 +1692,14 @@ struct X3rArgs {
   const float* R;
   float* C;          // fp32 result (may be null when PC is given)
   uint2* PC;         // optional: the result as the panel image of a [M, N] matrix
-  float* partial;    // [gridDim.y][M][N] partial tiles of a long-K split
+  int ns;            // k steps (of 16) per wave: K / 64, a multiple of 4
   int lda, ldr, ldc, M, N, K, act, tiles_m, tiles_n;
   float alpha;
 };
 
-template <int NS, bool APAN>
+template <bool APAN>
 __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
-  constexpr int DEPTH = APAN ? 3 : 4;
+  constexpr int DEPTH = APAN ? 2 : 4, PD = APAN ? 1 : 3;  // ring size (= the unrolled body of the step loop), prefetch distance (registers)
   __shared__ float4 red[4][4][4][64];  // [wave][sub-tile][register quad][lane]: partial tiles of the four K slices (64 KB)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int nt, mt;
@@ -1709,7 +1711,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
     if (q / g.tiles_m >= nt8 || nt >= g.tiles_n) return;
   }
   const int r = lane & 31, half = lane >> 5;
-  const int k_begin = (blockIdx.y * 4 + wave) * NS * 16, KB = g.K >> 4;
+  const int ns = g.ns, k_begin = wave * ns * 16, KB = g.K >> 4;
   const float* arow[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) arow[i] = g.A + (size_t)min(mt * 64 + i * 32 + r, g.M - 1) * g.lda + k_begin + 8 * half;
@@ -1791,12 +1793,15 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
         for (int j = 0; j < 2; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(bp[j][PB_[t]], ap[i][PA_[t]], acc[i][j]);
   };
 #pragma unroll
-  for (int st = 0; st < DEPTH - 1 && st < NS; ++st) load(st, st);
+  for (int st = 0; st < PD; ++st) load(st, st);  // (ns >= 4 > PD)
+#pragma unroll 1
+  for (int s0 = 0; s0 < ns; s0 += DEPTH) {
 #pragma unroll
-  for (int st = 0; st < NS; ++st) {
-    if (st + DEPTH - 1 < NS) load((st + DEPTH - 1) % DEPTH, st + DEPTH - 1);
-    sbk::sched_fence();
-    compute(st % DEPTH);
+    for (int j = 0; j < DEPTH; ++j) {
+      if (s0 + j + PD < ns) load((j + PD) % DEPTH, s0 + j + PD);  // (uniform)
+      sbk::sched_fence();
+      compute(j);
+    }
   }
   // every wave publishes its four partial sub-tiles; wave s then owns sub-tile s = 2 i + j (fixed summation order)
 #pragma unroll
@@ -1816,15 +1821,6 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
     const float4 a0 = red[0][wave][q4][lane], a1 = red[1][wave][q4][lane], a2 = red[2][wave][q4][lane], a3 = red[3][wave][q4][lane];
     v[q4] = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z,
                         ((a0.w + a1.w) + a2.w) + a3.w);
-  }
-  if (gridDim.y > 1) {  // partial tile of a long-K split: combined (with the epilogue) by splitk_reduce_kernel
-    float* P = g.partial + ((size_t)blockIdx.y * g.M + (row_ok ? row : 0)) * g.N;
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const int col = col0 + 8 * q4;
-      if (row_ok && col < g.N) *reinterpret_cast<float4*>(P + col) = v[q4];
-    }
-    return;
   }
   const float* rrow = g.R ? g.R + (size_t)(row_ok ? row : 0) * g.ldr : nullptr;
   float4 bv[4], rv[4];
@@ -2037,45 +2033,28 @@ int g_x3r_apanel = 0;  // (measured, profiles/r04_i_*: panel A operands are no f
 int g_x3r_vocab = 1;      // key 43: 1 = the vocabulary projection of a step too (instead of the 128-wide persistent split-operand kernel)
 int g_x3r_min_rows = 192;  // key 42: rows from which the search routes a projection with a panel image to it
 bool x3r_routed(int M, int N, int K) { return g_x3r_mode != 0 && M >= g_x3r_min_rows && K % 256 == 0 && N % 4 == 0; }
-// A fp32 [M, K] (row stride lda) or PA = its panel image; C fp32 and / or PC = the result's panel image (N % 16 == 0, no
-// long-K split).  -1: shape not eligible / no room for the K-split partials
+// A fp32 [M, K] (row stride lda) or PA = its panel image; C fp32 and / or PC = the result's panel image (N % 16 == 0).
+// -1: shape not eligible
 int gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW, const float* bias, const float* R, int ldr,
-                float* C, int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, float* ws, size_t ws_floats,
-                hipStream_t st) {
+                float* C, int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, hipStream_t st) {
   if (M == 0 || N == 0) return 0;
   if (K % 256 != 0 || N % 4 != 0 || !aligned16(PW) || (!A && !PA) || (!C && !PC)) return -1;
   if (!PA && (lda % 4 != 0 || !aligned16(A))) return -1;
   if ((PA && !aligned16(PA)) || (C && (ldc % 4 != 0 || !aligned16(C))) || (R && (ldr % 4 != 0 || !aligned16(R))) ||
-      (bias && !aligned16(bias)))
+      (bias && !aligned16(bias)) || (PC && N % 16 != 0))
     return -1;
-  const int NS = K % 512 == 0 ? 8 : 4, SKg = K / (64 * NS);
-  if (SKg > 1 && (PC || !C || !ws || (size_t)SKg * M * N > ws_floats)) return -1;
-  if (PC && N % 16 != 0) return -1;
   const int tm = cdiv(M, 64), tn = cdiv(N, 64);
   X3rArgs a{A, reinterpret_cast<const uint4*>(PA), reinterpret_cast<const uint4*>(PW), bias, R, C, reinterpret_cast<uint2*>(PC),
-            ws, lda, ldr, ldc, M, N, K, act, tm, tn, alpha};
+            K / 64, lda, ldr, ldc, M, N, K, act, tm, tn, alpha};
   ProfScope prof("gemm_x3r", 2.0 * M * N * K,
                  (PA ? 6.0 : 4.0) * M * (double)K + 6.0 * (double)N * K + ((C ? 4.0 : 0.0) + (PC ? 6.0 : 0.0) + (R ? 4.0 : 0.0)) * M * (double)N, st);
-  dim3 grid(8 * tm * cdiv(tn, 8), SKg), block(256);
-  if (NS == 8) {
-    if (PA) {
-      SBK_LAUNCH((gemm_x3r_kernel<8, true>), grid, block, 0, st, a);
-    } else {
-      SBK_LAUNCH((gemm_x3r_kernel<8, false>), grid, block, 0, st, a);
-    }
+  dim3 grid(8 * tm * cdiv(tn, 8)), block(256);
+  if (PA) {
+    SBK_LAUNCH((gemm_x3r_kernel<true>), grid, block, 0, st, a);
   } else {
-    if (PA) {
-      SBK_LAUNCH((gemm_x3r_kernel<4, true>), grid, block, 0, st, a);
-    } else {
-      SBK_LAUNCH((gemm_x3r_kernel<4, false>), grid, block, 0, st, a);
-    }
+    SBK_LAUNCH((gemm_x3r_kernel<false>), grid, block, 0, st, a);
   }
-  int rc = launch_status("gemm_x3r");
-  if (rc || SKg == 1) return rc;
-  GemmArgs g{A, nullptr, bias, R, C, lda, 0, ldr, ldc, M, N, K, act, alpha, nullptr, 1};
-  const size_t total = (size_t)M * N;
-  SBK_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, g, (const float*)ws, SKg);
-  return launch_status("splitk_reduce");
+  return launch_status("gemm_x3r");
 }
 
 // C = epilogue(LN(A) . Wf^T + bf) with gamma/beta pre-folded into (Wf, bf); returns -1 when the shape is
@@ -2488,7 +2467,7 @@ extern "C" int sbk_gemm_nt_f32x3(const float* A, int lda, const uint16_t* W3, co
 
 extern "C" int sbk_gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW, const float* bias,
                                const float* residual, int ldr, float* C, int ldc, uint16_t* PC, int M, int N, int K, int act,
-                               float alpha, float* workspace, size_t workspace_floats, sbk_stream_t stream) {
+                               float alpha, sbk_stream_t stream) {
   if (M == 0 || N == 0) return 0;
   SBK_REQUIRE((A || PA) && PW && (C || PC), "gemm_x3r: null operand");
   SBK_REQUIRE(M >= 0 && N >= 0 && N % 4 == 0 && K >= 256 && K % 256 == 0,
@@ -2500,11 +2479,7 @@ extern "C" int sbk_gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, cons
   SBK_REQUIRE(!residual || (ldr >= N && ldr % 4 == 0 && sbk::aligned16(residual)), "gemm_x3r: residual stride / alignment");
   SBK_REQUIRE(!bias || sbk::aligned16(bias), "gemm_x3r: bias alignment");
   SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_x3r: unknown activation %d", act);
-  SBK_REQUIRE(K <= 512 || (C && !PC && workspace && workspace_floats >= (size_t)(K / 512) * M * N),
-              "gemm_x3r: K = %d needs an fp32 result and a workspace of %zu floats for the partial tiles of its K split", K,
-              (size_t)(K / 512) * M * N);
-  const int rc = sbk::gemm_nt_x3r(A, lda, PA, PW, bias, residual, ldr, C, ldc, PC, M, N, K, act, alpha, workspace,
-                                  workspace_floats, sbk::as_stream(stream));
+  const int rc = sbk::gemm_nt_x3r(A, lda, PA, PW, bias, residual, ldr, C, ldc, PC, M, N, K, act, alpha, sbk::as_stream(stream));
   if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_x3r: shape not eligible");
   return rc;
 }

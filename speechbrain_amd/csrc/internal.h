@@ -17,11 +17,9 @@ int gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, const
                 uint16_t* PC, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
 extern int g_x3p_tile;
 // few-row contraction on the bf16 matrix pipe (csrc/gemm.hip: gemm_x3r_kernel): A fp32 [M, K] or PA = its panel image,
-// PW = the panel image of W (sbk_split_x3p); C fp32 and / or PC = the result's panel image; ws: room for the partial tiles
-// of a long-K split; -1 = shape not eligible
+// PW = the panel image of W (sbk_split_x3p); C fp32 and / or PC = the result's panel image; -1 = shape not eligible
 int gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW, const float* bias, const float* R, int ldr,
-                float* C, int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, float* ws, size_t ws_floats,
-                hipStream_t st);
+                float* C, int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, hipStream_t st);
 bool x3r_routed(int M, int N, int K);
 extern int g_x3r_mode, g_x3r_min_rows, g_x3r_vocab, g_x3r_apanel;
 // Device-resident step counter of the search running on this host thread (nullptr: the step is the

@@ -1023,7 +1023,7 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
   auto x3r = [&](const float* A, int lda, const uint16_t* PA, const uint16_t* WP, const float* b, const float* R, float* C,
                  uint16_t* PC, int N, int K, int act) -> int {
     if (!WP || !sbk::x3r_routed(n, N, K)) return -1;
-    return sbk::gemm_nt_x3r(A, lda, PA, WP, b, R, N, C, N, PC, n, N, K, act, 1.0f, d.splitk, d.splitk_floats, st);
+    return sbk::gemm_nt_x3r(A, lda, PA, WP, b, R, N, C, N, PC, n, N, K, act, 1.0f, st);
   };
   const bool apan = sbk::g_x3r_apanel && dm % 16 == 0 && dm <= 2048 && W->d_ffn % 16 == 0;
   // LayerNorm of the residual stream as the next projection's operand: its panel image (apan) or fp32 rows
@@ -1034,7 +1034,7 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
     if (L.sa_in_wp && L.sa_out_wp && L.ca_q_wp && L.ca_out_wp && L.ff1_wp && L.ff2_wp && sbk::x3r_routed(n, dm, dm) &&
-        sbk::x3r_routed(n, dm, W->d_ffn) && (size_t)(W->d_ffn / 512) * n * dm <= d.splitk_floats) {
+        sbk::x3r_routed(n, dm, W->d_ffn)) {
       const float* hA = apan ? nullptr : d.h;
       const uint16_t* hP = apan ? d.hp : nullptr;
       SBK_TRY(norm(L.ln1_g, L.ln1_b));

@@ -101,7 +101,7 @@ def _declare(lib):
         "sbk_x3p_panel_bytes": ([i, i], ctypes.c_size_t),
         "sbk_split_x3p": ([p, i, p, i, i, p], c_int),
         "sbk_layernorm_x3p": ([p, p, p, p, i, i, f, i, p], c_int),
-        "sbk_gemm_nt_x3r": ([p, i, p, p, p, p, i, p, i, p, i, i, i, i, f, p, ctypes.c_size_t, p], c_int),
+        "sbk_gemm_nt_x3r": ([p, i, p, p, p, p, i, p, i, p, i, i, i, i, f, p], c_int),
         "sbk_input_norm_global_masked_f32": ([p, p, p, p, p, i, i, i, f, p], c_int),
         "sbk_gemm_nt_x3p": ([p, p, p, p, i, p, i, p, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_bf16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
@@ -449,10 +449,9 @@ def gemm_nt_x3r(a, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alph
     out = torch.empty(*lead, N, dtype=torch.float32, device=dev) if fp32_out else None
     pc = panel_empty(M, N, dev, lead) if panel_out else None
     r2 = residual.reshape(-1, N) if residual is not None else None
-    ws = torch.empty(max(1, (K // 512) * M * N if K > 512 else 1), dtype=torch.float32, device=dev)
     _chk(lib.sbk_gemm_nt_x3r(_p(a2), K, _p(a.data) if a2 is None else None, _p(lp_weight(w, "x3p")), _p(bias), _p(r2), N,
-                             _p(out), N, _p(pc.data) if pc is not None else None, M, N, K, act, float(alpha), _p(ws),
-                             ws.numel(), _stream(ws)), "sbk_gemm_nt_x3r")
+                             _p(out), N, _p(pc.data) if pc is not None else None, M, N, K, act, float(alpha),
+                             _stream(w)), "sbk_gemm_nt_x3r")
     if panel_out:
         return (out, pc) if fp32_out else pc
     return out
