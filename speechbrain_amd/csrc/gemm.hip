@@ -1697,7 +1697,10 @@ struct X3rArgs {
   float alpha;
 };
 
-template <bool APAN>
+// NS > 0: the wave's NS steps fully unrolled (K = 64 NS; measured faster for K = 512 with N >= 1 024: 18.6 / 25.3 / 51.5 us
+// against 21.0 / 27.0 / 58.1 rolled at N = 1 536 / 2 048 / 5 000, profiles/r04_i_*, r04_k_*); NS = 0: the loop rolled
+// over the ring (any K; faster for N = 512: 12.4 vs 14.2 us, and the only form for long K)
+template <bool APAN, int NS>
 __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
   constexpr int DEPTH = APAN ? 2 : 4, PD = APAN ? 1 : 3;  // ring size (= the unrolled body of the step loop), prefetch distance (registers)
   __shared__ float4 red[4][4][4][64];  // [wave][sub-tile][register quad][lane]: partial tiles of the four K slices (64 KB)
@@ -1711,7 +1714,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
     if (q / g.tiles_m >= nt8 || nt >= g.tiles_n) return;
   }
   const int r = lane & 31, half = lane >> 5;
-  const int ns = g.ns, k_begin = wave * ns * 16, KB = g.K >> 4;
+  const int ns = NS > 0 ? NS : g.ns, k_begin = wave * ns * 16, KB = g.K >> 4;
   const float* arow[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) arow[i] = g.A + (size_t)min(mt * 64 + i * 32 + r, g.M - 1) * g.lda + k_begin + 8 * half;
@@ -1794,13 +1797,22 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
   };
 #pragma unroll
   for (int st = 0; st < PD; ++st) load(st, st);  // (ns >= 4 > PD)
-#pragma unroll 1
-  for (int s0 = 0; s0 < ns; s0 += DEPTH) {
+  if constexpr (NS > 0) {
 #pragma unroll
-    for (int j = 0; j < DEPTH; ++j) {
-      if (s0 + j + PD < ns) load((j + PD) % DEPTH, s0 + j + PD);  // (uniform)
+    for (int st = 0; st < NS; ++st) {
+      if (st + PD < NS) load((st + PD) % DEPTH, st + PD);
       sbk::sched_fence();
-      compute(j);
+      compute(st % DEPTH);
+    }
+  } else {
+#pragma unroll 1
+    for (int s0 = 0; s0 < ns; s0 += DEPTH) {
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        if (s0 + j + PD < ns) load((j + PD) % DEPTH, s0 + j + PD);  // (uniform)
+        sbk::sched_fence();
+        compute(j);
+      }
     }
   }
   // every wave publishes its four partial sub-tiles; wave s then owns sub-tile s = 2 i + j (fixed summation order)
@@ -2025,7 +2037,7 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
 }
 
 // tuning knob (key 41): the decode step's projections on gemm_x3r_kernel: 0 = off (register-operand fp32-MFMA tiles),
-// otherwise on; key 44: 1 = their A operands as panel images too (LayerNorm -> panel, attention context through
+// otherwise on (3 = always the rolled step loop); key 44: 1 = their A operands as panel images too (LayerNorm -> panel, attention context through
 // sbk_split_x3p, the feed-forward hidden layer by the first projection's epilogue), 0 (default) = fp32 A split in registers
 int g_x3r_mode = 2;
 int g_x3r_apanel = 0;  // (measured, profiles/r04_i_*: panel A operands are no faster inside the contraction -- 12.9 vs 14.2 us at 1 280 x
@@ -2050,9 +2062,11 @@ int gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW,
                  (PA ? 6.0 : 4.0) * M * (double)K + 6.0 * (double)N * K + ((C ? 4.0 : 0.0) + (PC ? 6.0 : 0.0) + (R ? 4.0 : 0.0)) * M * (double)N, st);
   dim3 grid(8 * tm * cdiv(tn, 8)), block(256);
   if (PA) {
-    SBK_LAUNCH((gemm_x3r_kernel<true>), grid, block, 0, st, a);
+    SBK_LAUNCH((gemm_x3r_kernel<true, 0>), grid, block, 0, st, a);
+  } else if (K == 512 && N >= 1024 && g_x3r_mode != 3) {
+    SBK_LAUNCH((gemm_x3r_kernel<false, 8>), grid, block, 0, st, a);
   } else {
-    SBK_LAUNCH((gemm_x3r_kernel<false>), grid, block, 0, st, a);
+    SBK_LAUNCH((gemm_x3r_kernel<false, 0>), grid, block, 0, st, a);
   }
   return launch_status("gemm_x3r");
 }
