@@ -351,7 +351,7 @@ def roofline_entry(name, v, total_ms):
     avg_ms = v["ms"] / max(v["count"], 1)
     if name.startswith(MFMA_KERNELS):
         ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
-        x3 = name.startswith(("gemm_nt_f32x3", "gemm_nt_x3p"))  # six bf16 partial products per multiply-add: bf16 peak / 6
+        x3 = name.startswith(("gemm_nt_f32x3", "gemm_nt_x3p", "gemm_x3r"))  # six bf16 partial products per multiply-add: bf16 peak / 6
         peak = PEAK_F32X3_TFLOPS if x3 else PEAK_MFMA_F32_TFLOPS
         e = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
              "frac": round(ach / peak, 4)}
@@ -587,9 +587,10 @@ def main():
                                    + (" + TransformerLM 12x768 scorer 0.6" if args.lm else "")
                                    + "; 16 kHz 0.1*randn 16-bit PCM, durations U(5,30) s; duration-sorted batches of "
                                    f"<= {args.max_batch} utterances; decode steps = round(4 tok/s * seconds)",
-                       "arithmetic": ("fp32 throughout; encoder contractions with >= 192 tiles of 128 x 128 on the bf16 matrix pipe by the "
-                                      "exact three-way operand split (six bf16 partial products per multiply-add, fp32 accumulation: "
-                                      "fp32-grade results, sbk_gemm_nt_f32x3)" if native.F32X3 else "fp32 throughout, fp32 MFMA contractions")
+                       "arithmetic": ("fp32 throughout; the encoder's large contractions (sbk_gemm_nt_x3p / _f32x3) and the decode step's "
+                                      "projections from ~200 hypothesis rows on (sbk_gemm_nt_x3r) on the bf16 matrix pipe by the exact "
+                                      "three-way operand split (six bf16 partial products per multiply-add, fp32 accumulation: "
+                                      "fp32-grade results)" if native.F32X3 else "fp32 throughout, fp32 MFMA contractions")
                        if args.precision == "fp32" else "opt-in bf16 operands",
                        "gpu_memory_reserved_gb": {"after_headline_leg": info.get("gpu_memory_reserved_gb"),
                                                   "peak_allocated_headline_leg": info.get("gpu_memory_peak_allocated_gb")},

@@ -235,8 +235,9 @@ def test_bench_roofline_entry_prices_each_kernel_against_its_own_peak():
     assert e["bound"] == "mfma" and abs(e["peak"] - 2500.0 / 6.0) < 0.1
     assert abs(e["frac"] - 139.0 / (2500.0 / 6.0)) < 1e-3 and abs(e["frac_of_fp32_mfma_peak"] - 139.0 / 157.3) < 1e-3
     assert e["launches"] == 10 and abs(e["share_of_gpu_time"] - 0.25) < 1e-9 and "peak_note" in e
-    e = bench.roofline_entry("gemm_nt_x3p", v, 4000.0)  # (both operands pre-split: the same six bf16 products per multiply-add)
-    assert abs(e["peak"] - 2500.0 / 6.0) < 0.1 and abs(e["frac"] - 139.0 / (2500.0 / 6.0)) < 1e-3
+    for name in ("gemm_nt_x3p", "gemm_x3r"):  # (pre-split operands / the decode step's few-row projections: the same six bf16 products)
+        e = bench.roofline_entry(name, v, 4000.0)
+        assert abs(e["peak"] - 2500.0 / 6.0) < 0.1 and abs(e["frac"] - 139.0 / (2500.0 / 6.0)) < 1e-3
     e = bench.roofline_entry("gemm_nt_persistent", v, 4000.0)
     assert e["peak"] == 157.3 and "frac_of_fp32_mfma_peak" not in e
     e = bench.roofline_entry("cross_attn_step", v, 4000.0)
