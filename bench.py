@@ -824,8 +824,13 @@ def main():
                 for h in heads:
                     h.mul_(8.0)
             try:
+                # (12 utterances x beam 10 = 120 hypothesis rows: the decode step's projections take sbk_gemm_nt_x3r from
+                # ~200 rows on -- the headline's grouped searches have 1 280 -- so the row threshold is lowered for this
+                # sample: the kernel the headline's decode loop runs is the one compared with the oracle)
+                native.load().sbk_prof_set_knob(42, 1)
                 got12 = run_step(asr, w12.to(dev), l12.to(dev))
             finally:
+                native.load().sbk_prof_set_knob(42, 192)
                 with torch.no_grad():
                     for h in heads:
                         h.div_(8.0)
@@ -834,9 +839,10 @@ def main():
             out["token_error_rate_vs_oracle_12x10s_peaked_heads"] = {
                 "WER_percent": round(wer12["WER"], 3), "tokens": wer12["num_scored_tokens"], "utterances": len(ref12),
                 "ids_equal": [list(a) for a in got12] == [list(b) for b in ref12],
-                "note": "12 x 10 s (3 012 encoder rows: FFN / QKV / pointwise-conv contractions on sbk_gemm_nt_f32x3), relative "
-                        "lengths 0.6-1, output heads x8 on both sides so that fp32 reassociation cannot flip a near-tie; "
-                        "oracle = oracle/sb_oracle.py (the port)"}
+                "note": "12 x 10 s (3 012 encoder rows: FFN / QKV / pointwise-conv contractions on sbk_gemm_nt_x3p with the "
+                        "LayerNorm -> panel / hidden-layer hand-over chain; the decode step's projections on sbk_gemm_nt_x3r), "
+                        "relative lengths 0.6-1, output heads x8 on both sides so that fp32 reassociation cannot flip a "
+                        "near-tie; oracle = oracle/sb_oracle.py (the port)"}
         if ref_tokens:  # the same batch on the HIP path, scored against the oracle's tokens
             from speechbrain_amd.utils.metric_stats import token_error_rate
 

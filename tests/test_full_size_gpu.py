@@ -38,10 +38,11 @@ def test_encoder_vs_oracle(size, B, sec):
     Conformer-L encoders (6 s, and 22 s = T' 551: the headline's utterance lengths): Fbank within 1e-3 dB,
     encoder output within 2e-4 absolute (fp32; oracle self-noise is 2e-6).
 
-    The headline's dominant kernel inside an oracle comparison: L-12-10 s has M = 3 012 rows, so
-    the contractions with N = 2 048 / 1 536 / 1 024 take the split-operand kernel (sbk_gemm_nt_f32x3) and those with
-    N = 512 the fp32-MFMA kernels -- both meet in every layer; L-32-8 s has M = 6 432 rows: EVERY contraction of the
-    layer takes it.  The routes are asserted, not assumed."""
+    The encoder's dominant kernel inside an oracle comparison: L-12-10 s has M = 3 012 rows, so
+    the contractions with N = 2 048 / 1 536 / 1 024 take the split-operand route (round 4: sbk_gemm_nt_x3p, both
+    operands pre-split -- LayerNorm writes the panel operand, the feed-forward hidden layer is handed over as a panel
+    image; sbk_gemm_nt_f32x3 with SBK_X3P=0) and those with N = 512 the fp32-MFMA kernels -- both meet in every layer;
+    L-32-8 s has M = 6 432 rows: EVERY contraction of the layer takes it.  The routes are asserted, not assumed."""
     from speechbrain_amd import native
     from speechbrain_amd.inference.builders import flat_state_dict
 
@@ -53,6 +54,9 @@ def test_encoder_vs_oracle(size, B, sec):
         routes = {N: native.f32x3_ok(M, K, torch.empty(N, K)) for N, K in ((2048, d), (3 * d, d), (2 * d, d), (d, 2048), (d, d))}
         assert native.F32X3 and routes[2048] and routes[3 * d] and routes[2 * d], routes
         assert routes[d] == (B == 32), routes
+        if native.X3P:  # (the default: the same shapes on the both-operands-pre-split kernel)
+            proutes = {N: native.x3p_ok(M, K, torch.empty(N, K)) for N, K in ((2048, d), (3 * d, d), (2 * d, d), (d, 2048), (d, d))}
+            assert proutes[2048] and proutes[3 * d] and proutes[2 * d] and proutes[d] == (B == 32), proutes
     wav = 0.1 * torch.randn(B, n, generator=torch.Generator().manual_seed(1234))
     lens = torch.linspace(0.55, 1.0, B)
     for i in range(B):
@@ -123,6 +127,22 @@ def test_conformer_l_decoder_logprobs_and_search_vs_oracle():
                                                O.SearchCfg(beam=10, ctc_weight=0.4, max_decode_ratio=12.5 / T), trace=tr)
     assert hyps == hyps_ref
     assert float((scores.cpu() - scores_ref).abs().max()) <= 1e-3
+    # the same with the step's projections on sbk_gemm_nt_x3r (round 4: the route of every step with ~200 hypothesis rows
+    # or more -- the bench's grouped searches; this search has 20 rows, so the row threshold is lowered, knob 42): the
+    # kernel the headline's decode loop spends its time in, inside the oracle comparison at Conformer-L size
+    lib = native.load()
+    lib.sbk_prof_set_knob(42, 1)
+    try:
+        assert h.layers[0].sa_in_wp and h.layers[0].ff2_wp and h.W.seq_wp
+        pred3 = native.decoder_prefix(h, tgt.int().cuda(), enc_ref.cuda(), enc_lens.cuda())
+        lp3 = native.log_softmax(native.gemm_nt(pred3, asr.mods.seq_lin.w.weight, asr.mods.seq_lin.w.bias))
+        assert float((lp3.cpu() - lp_ref).abs().max()) <= 1e-3
+        assert not torch.equal(pred3, pred)  # (another kernel did run)
+        hyps3, _, scores3, _ = asr.mods.decoder(enc_ref.cuda(), lens.cuda())
+        assert hyps3 == hyps_ref
+        assert float((scores3.cpu() - scores_ref).abs().max()) <= 1e-3
+    finally:
+        lib.sbk_prof_set_knob(42, 192)
 
 
 def test_recipe_lm_scorer_search_vs_oracle():

@@ -880,6 +880,39 @@ def test_gemm_x3r(backend, M, N, K, a_panel):
             assert torch.equal(nat.gemm_nt_x3r(only, w2), nat.gemm_nt_x3r(out, w2))
 
 
+def test_no_stream_workspace_is_an_error_not_an_allocation(backend):
+    """include/sbk.h, "stream workspace" (ABI 7): the library allocates no device memory.  A stream-K launch of the
+    split-operand contraction on a stream whose workspace the caller has NOT registered must fail with SBK_EINVAL and a
+    message (round 3's library called hipMalloc there, in the middle of other streams' kernels: DESIGN section 3); after
+    sbk_stream_workspace_set the same call succeeds."""
+    import ctypes
+
+    nat, dev = backend
+    lib = nat.load()
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 12800 if dev.type == "cuda" else 1100, 2048 if dev.type == "cuda" else 640, 64
+    a, w = torch.randn(M, K, generator=g).to(dev), torch.randn(N, K, generator=g).to(dev)
+    out = torch.empty(M, N, device=dev)
+    w3 = nat.lp_weight(w, "x3")
+    handle = nat._stream(a)  # (registers this stream's workspace: the binding never lets a call through without one)
+    key = [k for k in nat._STREAM_WS if k[0] == id(lib) and (k[2] == (handle.value or 0) if dev.type == "cuda" else k[1] == "host")][0]
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    lib.sbk_last_error.restype = ctypes.c_char_p
+    call = lambda: lib.sbk_gemm_nt_f32x3(nat._p(a), K, nat._p(w3), None, None, 0, nat._p(out), N, M, N, K, 0, ctypes.c_float(1.0),
+                                         None, 0, handle)
+    assert lib.sbk_stream_workspace_release(handle) == 0
+    try:
+        assert call() == -22 and b"workspace" in lib.sbk_last_error()
+    finally:
+        with nat._STREAM_WS_LOCK:
+            ws = nat._STREAM_WS.pop(key)
+        del ws
+        nat._stream(a)  # registered again
+    assert call() == 0
+    assert _md(out, (a.double().cpu() @ w.double().cpu().t()).float()) <= 2e-6 * float((a.abs().double().cpu() @ w.abs().double().cpu().t()).max()) + 1e-5
+
+
 @pytest.mark.parametrize("rows,d,act", [(130, 512, 0), (64, 32, 1), (777, 144, 0), (300, 1024, 1), (129, 2048, 0), (5, 16, 0),
                                         (4100, 512, 1), (4097, 1024, 0)])
 def test_layernorm_x3p(backend, rows, d, act):
