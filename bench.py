@@ -372,7 +372,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16, help="steps per GPU; one step = 128 utterances")
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=4,
+                    help="untimed steps through the same path before the clock starts (communicators, allocator pools, and the "
+                         "box itself: the first bench process on a fresh box measured 5-7 %% below the following ones with one "
+                         "warm-up step, profiles/r04_j_*, r04_k_*, r04_l_*)")
     ap.add_argument("--max-batch", type=int, default=32, help="utterances per batch of the headline run (32 = recipe-sized)")
     ap.add_argument("--second-batch", type=int, default=128, help="batch size of the second timed run (0: skip; N = 1 only)")
     ap.add_argument("--streams", type=int, default=0, help="worker threads per GPU, each with a batch (or a group of batches) in flight (0: automatic)")

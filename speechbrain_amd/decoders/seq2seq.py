@@ -249,7 +249,12 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
                         raise NotImplementedError("CTC as a partial scorer needs scorer_beam_scale >= 1 "
                                                   "(int(beam_size * scorer_beam_scale) candidates >= beam_size)")
         if self.attn_weight <= 0:
-            raise NotImplementedError("pure-CTC beam search (ctc_weight = 1) is not implemented")
+            # the reference skips forward_step when attn_weight = 0 and then carries the PREVIOUS step's combined score
+            # matrix -- rows still in the previous step's hypothesis order -- into the next step as its "log_probs"
+            # (seq2seq.py:916-921 with :1540-1545, :1590-1592): scores accumulate over steps, unpermuted.  Checked against
+            # the reference itself (round 4): a plain "CTC scores only" search gives other hypotheses.  Not reproduced.
+            raise NotImplementedError("pure-CTC beam search (ctc_weight = 1): the reference's behaviour there is an "
+                                      "accumulation quirk of its step loop, not reproduced")
 
     def config(self, T):
         mn, mx = self._steps(T)

@@ -321,6 +321,20 @@ if __name__ == "__main__":
                 nat.gemm_nt(a, w)
             torch.cuda.synchronize()
         sys.exit(0)
+    if "--r4-pmc" in sys.argv:  # short: round 4's two contraction kernels at bench-sized shapes for the counters passes
+        nat.F32X3, nat.X3P = True, True
+        for (M, N, K) in [(1280, 512, 512), (1280, 2048, 512), (1280, 512, 2048), (1280, 5000, 512)]:  # gemm_x3r_kernel
+            a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); r = torch.randn(M, N, device=dev)
+            for _ in range(6):
+                nat.gemm_nt_x3r(a, w, residual=r)
+            torch.cuda.synchronize()
+        for (M, N, K) in [(12800, 2048, 512), (12800, 512, 2048), (24032, 1536, 512)]:  # gemm_nt_x3p_kernel (A panel made once)
+            a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev)
+            pa = nat.split_x3p(a)
+            for _ in range(6):
+                nat.gemm_nt_x3p(pa, w)
+            torch.cuda.synchronize()
+        sys.exit(0)
     if "--x3r" in sys.argv:  # the decode step's projections: fp32-MFMA default route vs sbk_gemm_nt_x3r (both load schedules)
         def ev_time(fn, n=40):
             fn(); fn()
