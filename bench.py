@@ -288,12 +288,16 @@ def whisper_encoder_leg(dev, B=8, reps=3):
     res = {"workload": f"log-mel + Whisper large-v3 encoder forward, {B} x 30 s, random weights, one stream",
            "precisions": "operand type of the GEMMs (fp32 accumulation everywhere): fp32 = parity path; bf16 = bf16 activations "
                          "between the contractions (LayerNorm / attention / GELU epilogue write bf16, LDS-DMA bf16 GEMM, "
-                         "attention with K / V^T tiles shared through LDS; residual stream fp32); fp16 and fp8 (e4m3, per-tensor "
-                         "scales, activation max |x| found on the device per GEMM) read fp32 activations and round them on load"}
+                         "attention with K / V^T tiles shared through LDS; residual stream fp32); fp8 = e4m3 activations between the "
+                         "contractions too (round 4: LayerNorm writes fp8 rows with one scale per row, weights with one scale per "
+                         "output channel, q/k/v projection and the feed-forward pair on v_mfma_f32_32x32x64_f8f6f4 -- the 2 x-rate fp8 "
+                         "instruction -- attention and its out-projection on bf16 rows); fp16 reads fp32 activations and rounds them "
+                         "on load; fp8_fp32_activations = the round-3 fp8 path (per-tensor scales, activation max |x| per GEMM)"}
     flops = B * 32 * (1500 * 2.0 * (4 * 1280 * 1280 + 2 * 1280 * 5120) + 4.0 * 1500 * 1500 * 1280) \
         + B * 2.0 * (3000 * 1280 * 384 + 1500 * 1280 * 3840)
-    for prec in ("fp32", "bf16", "fp16", "fp8"):
-        with native.precision_scope(prec):
+    for prec in ("fp32", "bf16", "fp16", "fp8", "fp8_fp32_activations"):
+        native.FP8_ACTIVATIONS = prec != "fp8_fp32_activations"
+        with native.precision_scope(prec.split("_")[0]):
             w.forward_encoder(w._get_mel(wav))
             torch.cuda.synchronize()
             t = time.perf_counter()
@@ -303,6 +307,7 @@ def whisper_encoder_leg(dev, B=8, reps=3):
             dt = (time.perf_counter() - t) / reps
         res[prec] = {"ms_per_batch": round(1000.0 * dt, 2), "audio_sec_per_s": round(B * 30.0 / dt, 1),
                      "tflops": round(flops / dt / 1e12, 1)}
+    native.FP8_ACTIVATIONS = True
     del w
     torch.cuda.empty_cache()
     return res

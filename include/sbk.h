@@ -388,6 +388,27 @@ typedef struct {
   const uint16_t* seq_wp; /* optional (ABI 8): seq_w's panel image (sbk_split_x3p): the vocabulary projection as sbk_gemm_nt_x3r */
 } sbk_decoder_weights;
 
+/* ---- ABI 8: fp8 (OCP e4m3) activations AND weights on the 2 x-rate fp8 matrix instruction (configs[4]: "fp8 MFMA on CDNA4";
+ * the Whisper encoder layer, integrations/huggingface/whisper.py:318-353, under run_opts precision "fp8").  Operands are
+ * byte matrices with ONE fp32 scale per row (value = scale[row] * e4m3):
+ *   sbk_quant_rows_fp8:   x [rows, d] fp32 (row stride ldx) -> q, scale[r] = max |x[r,:]| / 448 (weights: per output channel,
+ *                         once per matrix);
+ *   sbk_layernorm_fp8o:   act(LayerNorm(x)) written in that form (the next contraction's A operand, no fp32 round trip);
+ *   sbk_gemm_nt_fp8a:     C = residual + alpha * act(a_scale[m] w_scale[n] (A8 . W8^T) + bias), fp32 accumulation on
+ *                         v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; K % 128 == 0; a_scale / w_scale may be
+ *                         NULL (= 1); outputs: C fp32 and / or Cb bf16 and / or C8 = e4m3(result / c8_scale) with a FIXED
+ *                         scale (the hidden layer of a feed-forward pair, whose row maxima are unknown before the last
+ *                         column tile: with c8_scale = 1 it is the A operand of the next call with a_scale = NULL).
+ * Not a parity path: e4m3 keeps 3 significand bits (tolerances in tests/test_whisper.py). */
+int sbk_quant_rows_fp8(const float* x, int ldx, uint8_t* q, float* scale, int rows, int d, sbk_stream_t stream);
+/* the same from bf16 rows (the bf16 attention kernel's context -> the out-projection's fp8 operand); ldx in elements */
+int sbk_quant_rows_bf16_fp8(const uint16_t* xb, int ldx, uint8_t* q, float* scale, int rows, int d, sbk_stream_t stream);
+int sbk_layernorm_fp8o(const float* x, const float* gamma, const float* beta, uint8_t* q, float* scale, int rows, int d,
+                       float eps, int act, sbk_stream_t stream);
+int sbk_gemm_nt_fp8a(const uint8_t* A8, int lda, const float* a_scale, const uint8_t* W8, int ldw, const float* w_scale,
+                     const float* bias, const float* residual, int ldr, float* C, int ldc, uint16_t* Cb, int ldcb, uint8_t* C8,
+                     int ldc8, float c8_scale, int M, int N, int K, int act, float alpha, sbk_stream_t stream);
+
 /* ---- a20: TransformerLM (lobes/models/transformer/TransformerLM.py:22-187; encoder-only, regularMHA,
  * fixed_abs_sine positions, no embedding_proj) used as a full scorer (decoders/scorer.py:413-577).
  * By the reference's state_dict names (device pointers, fp32):

@@ -66,6 +66,19 @@ using fp8x8 = long;
 __device__ __forceinline__ f32x16 mfma_32x32x16_fp8(fp8x8 a, fp8x8 b, f32x16 acc) {
   return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, acc, 0, 0, 0);
 }
+// OCP e4m3 operands, 32 per lane (8 VGPRs): D(32x32) += A(32x64) * B(64x32), fp32 accumulate, on
+// v_mfma_scale_f32_32x32x64_f8f6f4 with UNIT block scales (scale operands 0 = E8M0 127: measured exact,
+// tools/mx_probe.hip).  Lane l supplies row / column l & 31 and 32 bytes of k block l >> 5 (the order of the k inside
+// the instruction does not matter to a contraction as long as A and B use the same one).  Measured from registers:
+// 4 267 TF/s, 2.06 x v_mfma_f32_32x32x16_bf16 (profiles/r04_m2_*).
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+__device__ __forceinline__ f32x16 mfma_32x32x64_fp8(i32x8 a, i32x8 b, f32x16 acc) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, 0, 0, 0);
+}
+__device__ __forceinline__ i32x8 i32x8_from_u4(uint4 lo, uint4 hi) {
+  i32x8 r = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+  return r;
+}
 // two floats -> two e4m3 bytes (low byte = a), round to nearest even, saturating at +-448 (v_cvt_pk_fp8_f32)
 __device__ __forceinline__ unsigned short f32x2_to_fp8(float a, float b) {
   a = fminf(fmaxf(a, -448.0f), 448.0f);

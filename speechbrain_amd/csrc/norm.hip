@@ -215,6 +215,76 @@ __global__ void __launch_bounds__(256) layernorm_x3p_rows8_kernel(const float* _
   }
 }
 
+// ---- fp8 (OCP e4m3) rows with one fp32 scale per row: q[r][c] = e4m3(v[r][c] / scale[r]), scale[r] = max_c |v[r][c]| / 448
+// (1 for an all-zero row) -- the operand format of sbk_gemm_nt_fp8a.  LN = true: v = act(LayerNorm(x)) (the row is in
+// registers anyway: the maximum is one more wave reduction); LN = false: v = x (weights: one scale per output channel).
+// One wave per row, d % 4 == 0, d <= 256 * MAXV.
+// BF16IN: x holds bf16 rows (the attention kernel's context), ldx in bf16 elements
+template <int MAXV, bool LN, bool BF16IN = false>
+__global__ void __launch_bounds__(256) rows_fp8_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, unsigned char* __restrict__ q,
+                                                       float* __restrict__ scale, int rows, int d, int ldx, float eps, int act) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool live = row < rows;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)(live ? row : rows - 1) * ldx);
+  const uint2* xb = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + (size_t)(live ? row : rows - 1) * ldx);
+  const int nv = d >> 2;
+  float4 v[MAXV];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if constexpr (BF16IN) {
+      const uint2 u = c < nv ? xb[c] : make_uint2(0u, 0u);
+      v[i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                         __uint_as_float(u.y & 0xffff0000u));
+    } else {
+      v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  if constexpr (LN) {  // (layernorm_kernel's arithmetic)
+    const float mean = sbk::wave_sum(s) / (float)d;
+    float qs = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (lane + i * 64 < nv) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+        qs += (a * a + b * b) + (cc * cc + dd * dd);
+      }
+    const float rstd = rsqrtf(sbk::wave_sum(qs) / (float)d + eps);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        const float4 g = g4[c], b = b4[c];
+        v[i].x = act_f((v[i].x - mean) * rstd * g.x + b.x, act);
+        v[i].y = act_f((v[i].y - mean) * rstd * g.y + b.y, act);
+        v[i].z = act_f((v[i].z - mean) * rstd * g.z + b.z, act);
+        v[i].w = act_f((v[i].w - mean) * rstd * g.w + b.w, act);
+      }
+    }
+  }
+  float m = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (lane + i * 64 < nv) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+  m = sbk::wave_max(m);
+  const float sc = m > 0.0f ? m / 448.0f : 1.0f, inv = 1.0f / sc;
+  if (!live) return;
+  if (lane == 0) scale[row] = sc;
+  unsigned* qr = reinterpret_cast<unsigned*>(q + (size_t)row * d);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv)
+      qr[c] = (unsigned)sbk::f32x2_to_fp8(v[i].x * inv, v[i].y * inv) | ((unsigned)sbk::f32x2_to_fp8(v[i].z * inv, v[i].w * inv) << 16);
+  }
+}
+
 // Any d (scalar loads, three passes over an L1/L2-resident row).
 __global__ void __launch_bounds__(256) layernorm_generic_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ gamma,
@@ -404,6 +474,68 @@ extern "C" int sbk_layernorm_bf16o(const float* x, const float* gamma, const flo
   SBK_REQUIRE(x && gamma && beta && y, "layernorm_bf16o: null operand");
   SBK_REQUIRE(rows >= 0 && d > 0, "layernorm_bf16o: bad shape rows=%d d=%d", rows, d);
   return sbk::layernorm_any(x, gamma, beta, nullptr, y, rows, d, eps, act, sbk::as_stream(stream));
+}
+
+namespace {
+template <bool LN>
+int launch_rows_fp8(const float* x, int ldx, const float* gamma, const float* beta, unsigned char* q, float* scale, int rows, int d,
+                    float eps, int act, hipStream_t st) {
+  dim3 grid(sbk::cdiv(rows, 4)), block(256);
+  sbk::ProfScope prof(LN ? "layernorm_fp8" : "quant_rows_fp8", 8.0 * rows * d, 5.0 * rows * d, st);
+  if (d <= 256) {
+    SBK_LAUNCH((rows_fp8_kernel<1, LN>), grid, block, 0, st, x, gamma, beta, q, scale, rows, d, ldx, eps, act);
+  } else if (d <= 512) {
+    SBK_LAUNCH((rows_fp8_kernel<2, LN>), grid, block, 0, st, x, gamma, beta, q, scale, rows, d, ldx, eps, act);
+  } else if (d <= 1024) {
+    SBK_LAUNCH((rows_fp8_kernel<4, LN>), grid, block, 0, st, x, gamma, beta, q, scale, rows, d, ldx, eps, act);
+  } else if (d <= 1280) {
+    SBK_LAUNCH((rows_fp8_kernel<5, LN>), grid, block, 0, st, x, gamma, beta, q, scale, rows, d, ldx, eps, act);
+  } else if (d <= 2048) {
+    SBK_LAUNCH((rows_fp8_kernel<8, LN>), grid, block, 0, st, x, gamma, beta, q, scale, rows, d, ldx, eps, act);
+  } else {
+    SBK_LAUNCH((rows_fp8_kernel<20, LN>), grid, block, 0, st, x, gamma, beta, q, scale, rows, d, ldx, eps, act);
+  }
+  return sbk::launch_status(LN ? "sbk_layernorm_fp8o" : "sbk_quant_rows_fp8");
+}
+}  // namespace
+
+extern "C" int sbk_layernorm_fp8o(const float* x, const float* gamma, const float* beta, uint8_t* q, float* scale, int rows,
+                                  int d, float eps, int act, sbk_stream_t stream) {
+  if (rows == 0) return 0;
+  SBK_REQUIRE(x && gamma && beta && q && scale, "layernorm_fp8o: null operand");
+  SBK_REQUIRE(rows > 0 && d >= 4 && d % 4 == 0 && d <= 5120, "layernorm_fp8o: rows=%d d=%d (d %% 4 == 0, d <= 5120)", rows, d);
+  SBK_REQUIRE(sbk::aligned16(x) && sbk::aligned16(gamma) && sbk::aligned16(beta) && (reinterpret_cast<uintptr_t>(q) & 3) == 0,
+              "layernorm_fp8o: operand alignment");
+  return launch_rows_fp8<true>(x, d, gamma, beta, q, scale, rows, d, eps, act, sbk::as_stream(stream));
+}
+
+extern "C" int sbk_quant_rows_bf16_fp8(const uint16_t* xb, int ldx, uint8_t* q, float* scale, int rows, int d, sbk_stream_t stream) {
+  if (rows == 0) return 0;
+  SBK_REQUIRE(xb && q && scale, "quant_rows_bf16_fp8: null operand");
+  SBK_REQUIRE(rows > 0 && d >= 4 && d % 4 == 0 && d <= 2048 && ldx >= d && ldx % 4 == 0,
+              "quant_rows_bf16_fp8: rows=%d d=%d ldx=%d (d %% 4 == 0, d <= 2048)", rows, d, ldx);
+  SBK_REQUIRE((reinterpret_cast<uintptr_t>(xb) & 7) == 0 && (reinterpret_cast<uintptr_t>(q) & 3) == 0, "quant_rows_bf16_fp8: operand alignment");
+  hipStream_t st = sbk::as_stream(stream);
+  const float* x = reinterpret_cast<const float*>(xb);
+  dim3 grid(sbk::cdiv(rows, 4)), block(256);
+  sbk::ProfScope prof("quant_rows_fp8", 2.0 * rows * d, 3.0 * rows * d, st);
+  if (d <= 512) {
+    SBK_LAUNCH((rows_fp8_kernel<2, false, true>), grid, block, 0, st, x, nullptr, nullptr, q, scale, rows, d, ldx, 0.0f, 0);
+  } else if (d <= 1280) {
+    SBK_LAUNCH((rows_fp8_kernel<5, false, true>), grid, block, 0, st, x, nullptr, nullptr, q, scale, rows, d, ldx, 0.0f, 0);
+  } else {
+    SBK_LAUNCH((rows_fp8_kernel<8, false, true>), grid, block, 0, st, x, nullptr, nullptr, q, scale, rows, d, ldx, 0.0f, 0);
+  }
+  return sbk::launch_status("sbk_quant_rows_bf16_fp8");
+}
+
+extern "C" int sbk_quant_rows_fp8(const float* x, int ldx, uint8_t* q, float* scale, int rows, int d, sbk_stream_t stream) {
+  if (rows == 0) return 0;
+  SBK_REQUIRE(x && q && scale, "quant_rows_fp8: null operand");
+  SBK_REQUIRE(rows > 0 && d >= 4 && d % 4 == 0 && d <= 5120 && ldx >= d && ldx % 4 == 0,
+              "quant_rows_fp8: rows=%d d=%d ldx=%d (d %% 4 == 0, d <= 5120)", rows, d, ldx);
+  SBK_REQUIRE(sbk::aligned16(x) && (reinterpret_cast<uintptr_t>(q) & 3) == 0, "quant_rows_fp8: operand alignment");
+  return launch_rows_fp8<false>(x, ldx, nullptr, nullptr, q, scale, rows, d, 0.0f, 0, sbk::as_stream(stream));
 }
 
 extern "C" int sbk_layernorm_x3p(const float* x, const float* gamma, const float* beta, uint16_t* P, int rows, int d,

@@ -226,10 +226,28 @@ class WhisperEncoder(nn.Module):
         # kernels, at the points where those round on load.
         bf16a = (native.precision() == "bf16" and native.BF16_ACTIVATIONS and att_ok(self.layers) and native.bf16a_ok(d)
                  and native.bf16a_ok(self.layers[0].fc1.out_features))
+        # precision "fp8" (BASELINE configs[4]): the same pipeline with e4m3 operands on the 2 x-rate fp8 matrix instruction
+        # for the four contractions of a layer -- LayerNorm writes fp8 rows with one scale per row, the weights carry one
+        # scale per output channel, the feed-forward hidden layer is written as fp8 by the first contraction's GELU
+        # epilogue; the attention runs on bf16 rows as above and its context is quantised row by row for the out-projection
+        fp8a = (native.precision() == "fp8" and native.FP8_ACTIVATIONS and att_ok(self.layers) and native.fp8a_ok(d)
+                and native.fp8a_ok(self.layers[0].fc1.out_features) and B * Tq >= 256)
         for layer in self.layers:
             att = layer.self_attn
             ln = layer.self_attn_layer_norm
             w_in, b_in = att.stacked(interleave_heads=True)
+            if fp8a:
+                h = native.layernorm_fp8(x, ln.weight, ln.bias, ln.eps)
+                qkv = native.gemm_nt_fp8a(h, w_in, b_in, out_dtype=torch.bfloat16)
+                ctx = native.attention_bf16(qkv, None, att.num_heads, att.head_dim ** -0.5)
+                x = native.gemm_nt_fp8a(native.quant_rows_fp8(ctx), att.out_proj.weight, att.out_proj.bias, residual=x)
+                ln = layer.final_layer_norm
+                h = native.layernorm_fp8(x, ln.weight, ln.bias, ln.eps)
+                h = native.gemm_nt_fp8a(h, layer.fc1.weight, layer.fc1.bias, act=native.ACT_GELU, out_dtype="fp8")
+                x = native.gemm_nt_fp8a(h, layer.fc2.weight, layer.fc2.bias, residual=x)
+                if hidden is not None:
+                    hidden.append(x)
+                continue
             if bf16a:
                 h = native.layernorm_bf16(x, ln.weight, ln.bias, ln.eps)
                 qkv = native.gemm_nt_bf16a(h, w_in, b_in, out_dtype=torch.bfloat16)

@@ -102,6 +102,10 @@ def _declare(lib):
         "sbk_split_x3p": ([p, i, p, i, i, p], c_int),
         "sbk_layernorm_x3p": ([p, p, p, p, i, i, f, i, p], c_int),
         "sbk_gemm_nt_x3r": ([p, i, p, p, p, p, i, p, i, p, i, i, i, i, f, p], c_int),
+        "sbk_quant_rows_fp8": ([p, i, p, p, i, i, p], c_int),
+        "sbk_quant_rows_bf16_fp8": ([p, i, p, p, i, i, p], c_int),
+        "sbk_layernorm_fp8o": ([p, p, p, p, p, i, i, f, i, p], c_int),
+        "sbk_gemm_nt_fp8a": ([p, i, p, p, i, p, p, p, i, p, i, p, i, p, i, f, i, i, i, i, f, p], c_int),
         "sbk_input_norm_global_masked_f32": ([p, p, p, p, p, i, i, i, f, p], c_int),
         "sbk_gemm_nt_x3p": ([p, p, p, p, i, p, i, p, i, i, i, i, f, p, i, p], c_int),
         "sbk_gemm_nt_bf16": ([p, i, p, i, p, p, i, p, i, i, i, i, i, f, p, i, p], c_int),
@@ -329,7 +333,9 @@ def gemm_nt_rows(a_flat: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor
     _f32(a_flat), _f32(w)
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a_flat.device)
-    if precision() == "bf16" and M >= 256 and K % 8 == 0 and lda % 4 == 0:
+    # (precision "fp8" with fp8 activations: the sliding-window operand stays fp32 in memory, so the two convolutions of the
+    # Whisper front-end take the bf16-operand kernel there too -- 2 % of the encoder's flops)
+    if (precision() == "bf16" or (precision() == "fp8" and FP8_ACTIVATIONS)) and M >= 256 and K % 8 == 0 and lda % 4 == 0:
         _chk(lib.sbk_gemm_nt_bf16(_p(a_flat), int(lda), _p(bf16_weight(w)), K, _p(bias), _p(residual), N, _p(out), N, M, N, K,
                                   act, float(alpha), None, 0, _stream(a_flat)), "sbk_gemm_nt_bf16")
         return out
@@ -508,7 +514,7 @@ def lp_weight(w: torch.Tensor, kind: str = "bf16"):
         if (hit is not None and hit[0]() is base and hit[1] == w._version and hit[2].device == w.device
                 and hit[5] == w.data_ptr()):
             hit[4].wait(w.device)  # (made on another worker's stream a moment ago?)
-            return hit[2] if kind != "fp8" else (hit[2], hit[3])
+            return hit[2] if kind not in ("fp8", "fp8r") else (hit[2], hit[3])
     lib = load()
     w2 = w.detach().contiguous()
     _dev_ok(w2)
@@ -518,6 +524,10 @@ def lp_weight(w: torch.Tensor, kind: str = "bf16"):
         scale = max(float(w2.abs().max()), 1e-30) / 448.0  # (once per weight: a host round trip at load time)
         out = torch.empty(w2.shape, dtype=torch.uint8, device=w.device)
         _chk(lib.sbk_f32_to_fp8(_p(w2), _p(out), w2.numel(), 1.0 / scale, _stream(w2)), "sbk_f32_to_fp8")
+    elif kind == "fp8r":  # e4m3 with one scale per output channel (sbk_quant_rows_fp8): the W operand of gemm_nt_fp8a
+        out = torch.empty(w2.shape, dtype=torch.uint8, device=w.device)
+        scale = torch.empty(w2.shape[0], dtype=torch.float32, device=w.device)
+        _chk(lib.sbk_quant_rows_fp8(_p(w2), w2.shape[1], _p(out), _p(scale), w2.shape[0], w2.shape[1], _stream(w2)), "sbk_quant_rows_fp8")
     elif kind == "x3":
         N, K = w2.shape
         out = torch.empty(N, K // 32, 3, 32, dtype=torch.int16, device=w.device)
@@ -539,7 +549,7 @@ def lp_weight(w: torch.Tensor, kind: str = "bf16"):
 
     with _BF16_LOCK:
         _BF16_WEIGHTS[key] = (weakref.ref(base, _drop), w._version, out, scale, _Ready(w.device), w.data_ptr())
-    return out if kind != "fp8" else (out, scale)
+    return out if kind not in ("fp8", "fp8r") else (out, scale)
 
 
 def bf16_weight(w: torch.Tensor) -> torch.Tensor:
@@ -626,6 +636,85 @@ def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps
     _chk(lib.sbk_layernorm_bf16o(_p(x2), _p(gamma), _p(beta), _p(out), x2.shape[0], d, float(eps), act, _stream(x2)),
          "sbk_layernorm_bf16o")
     return out
+
+
+# precision "fp8": fp8 (e4m3) activations between the contractions of the Whisper encoder, one fp32 scale per row, on the
+# 2 x-rate fp8 matrix instruction (sbk_gemm_nt_fp8a); False = the round-3 path (fp32 activations, per-tensor scales)
+FP8_ACTIVATIONS = os.environ.get("SBK_FP8_ACTIVATIONS", "1") != "0"
+
+
+class Fp8Rows:
+    """An activation as e4m3 bytes with one fp32 scale per row (scale None: 1): value = scale[row] * e4m3."""
+    __slots__ = ("q", "scale")
+
+    def __init__(self, q, scale):
+        self.q, self.scale = q, scale
+
+    @property
+    def shape(self):
+        return self.q.shape
+
+
+def fp8a_ok(K: int) -> bool:
+    """Shapes the fp8-activation contraction (sbk_gemm_nt_fp8a) takes: K a multiple of its 128-deep K tile."""
+    return K % 128 == 0
+
+
+def layernorm_fp8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, act=ACT_NONE) -> Fp8Rows:
+    """``layernorm`` written as e4m3 rows with one scale per row (row maximum / 448): the operand of gemm_nt_fp8a."""
+    lib = load()
+    d = gamma.numel()
+    x2 = x.reshape(-1, d)
+    _dev_ok(x2, gamma, beta)
+    _f32(x2)
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+    _chk(lib.sbk_layernorm_fp8o(_p(x2), _p(gamma), _p(beta), _p(q), _p(scale), x2.shape[0], d, float(eps), act, _stream(x2)),
+         "sbk_layernorm_fp8o")
+    return Fp8Rows(q, scale)
+
+
+def quant_rows_fp8(x: torch.Tensor) -> Fp8Rows:
+    """x [..., d] fp32 or bf16 -> e4m3 rows with one scale per row."""
+    lib = load()
+    d = x.shape[-1]
+    x2 = x.reshape(-1, d).contiguous()
+    _dev_ok(x2)
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+    if x2.dtype == torch.bfloat16:
+        _chk(lib.sbk_quant_rows_bf16_fp8(_p(x2), d, _p(q), _p(scale), x2.shape[0], d, _stream(x2)), "sbk_quant_rows_bf16_fp8")
+    else:
+        _f32(x2)
+        _chk(lib.sbk_quant_rows_fp8(_p(x2), d, _p(q), _p(scale), x2.shape[0], d, _stream(x2)), "sbk_quant_rows_fp8")
+    return Fp8Rows(q, scale)
+
+
+def gemm_nt_fp8a(a: Fp8Rows, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out_dtype=torch.float32):
+    """epilogue(a . w^T) with ``a`` ALREADY fp8 in memory (layernorm_fp8 / quant_rows_fp8 / a previous call's fp8 output) and
+    the cached per-channel-scaled e4m3 image of the fp32 parameter ``w``; fp32 accumulation, fp32 residual.  The result is
+    fp32, torch.bfloat16 (the attention kernel's operand) or -- ``out_dtype="fp8"`` -- e4m3 at scale 1 (an Fp8Rows
+    without scales: the hidden layer of a feed-forward pair)."""
+    lib = load()
+    K = a.q.shape[-1]
+    a2 = a.q.reshape(-1, K)
+    M, N = a2.shape[0], w.shape[0]
+    _dev_ok(a2, a.scale, bias, residual)
+    wq, w_scale = lp_weight(w, "fp8r")
+    r2 = residual.reshape(-1, N) if residual is not None else None
+    lead = tuple(a.q.shape[:-1])
+    c = cb = c8 = None
+    if out_dtype == "fp8":
+        c8 = torch.empty(*lead, N, dtype=torch.uint8, device=a2.device)
+    elif out_dtype == torch.bfloat16:
+        cb = torch.empty(*lead, N, dtype=torch.bfloat16, device=a2.device)
+    else:
+        c = torch.empty(*lead, N, dtype=torch.float32, device=a2.device)
+    _chk(lib.sbk_gemm_nt_fp8a(_p(a2), K, _p(a.scale), _p(wq), K, _p(w_scale), _p(bias), _p(r2), N, _p(c), N, _p(cb), N,
+                              _p(c8), N, 1.0, M, N, K, act, float(alpha), _stream(a2)), "sbk_gemm_nt_fp8a")
+    if c8 is not None:
+        return Fp8Rows(c8, None)
+    return cb if cb is not None else c
 
 
 def gemm_nt_splitk(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, slices=8):

@@ -880,6 +880,81 @@ def test_gemm_x3r(backend, M, N, K, a_panel):
             assert torch.equal(nat.gemm_nt_x3r(only, w2), nat.gemm_nt_x3r(out, w2))
 
 
+def _e4m3(q):  # uint8 e4m3 bits -> float32 (torch's own decoder)
+    return q.cpu().view(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("rows,d,act", [(70, 1280, 0), (33, 256, 1), (9, 5120, 0), (130, 512, 0)])
+def test_layernorm_and_row_quantisation_to_fp8(backend, rows, d, act):
+    """sbk_layernorm_fp8o / sbk_quant_rows_fp8: e4m3 rows with one fp32 scale per row.  scale = row maximum / 448 (the largest
+    element maps to +-448 exactly), every element is the e4m3 rounding of value / scale (at most half an e4m3 step: 2^-4
+    relative, plus the subnormal step), an all-zero row gets scale 1."""
+    nat, dev = backend
+    g = torch.Generator().manual_seed(rows + d)
+    x = torch.randn(rows, d, generator=g) * 2.5 + 0.3
+    x[1] = 0.0
+    gamma, beta = torch.randn(d, generator=g), torch.randn(d, generator=g) * 0.2
+    code = nat.ACT_SWISH if act else nat.ACT_NONE
+    ref = nat.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5, act=code).cpu()
+    for name, got, want in (("ln", nat.layernorm_fp8(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5, act=code), ref),
+                            ("plain", nat.quant_rows_fp8(x.to(dev)), x)):
+        sc = got.scale.cpu()
+        amax = want.abs().amax(1)
+        assert torch.allclose(sc, torch.where(amax > 0, amax / 448.0, torch.ones(())), rtol=1e-6, atol=0), name
+        deq = _e4m3(got.q).view(rows, d) * sc[:, None]
+        assert float(((deq - want).abs() - (want.abs() * 2.0 ** -4 + sc[:, None] * 2.0 ** -10)).max()) <= 0.0, name
+        assert float(_e4m3(got.q).abs().max()) == 448.0
+    if d <= 2048:  # bf16 rows in (the attention context): the same scales and bytes as from the widened values
+        xb = x.to(torch.bfloat16)
+        a, b2 = nat.quant_rows_fp8(xb.to(dev)), nat.quant_rows_fp8(xb.float().to(dev))
+        assert torch.equal(a.q.cpu(), b2.q.cpu()) and torch.equal(a.scale.cpu(), b2.scale.cpu())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 260, 256), (128, 128, 128), (1000, 1536, 1280), (130, 5120, 1280), (257, 1280, 5120)])
+def test_gemm_fp8a(backend, M, N, K):
+    """sbk_gemm_nt_fp8a: e4m3 activations x e4m3 weights (one fp32 scale per row each) on the 2 x-rate fp8 matrix instruction,
+    fp32 accumulation.  Against the product of the DEQUANTISED operands the kernel is an fp32 GEMM (products of two e4m3
+    numbers are exact in fp32): 5e-6 of the largest sum of magnitudes (the instruction adds its 64 products and the
+    accumulator with truncation: measured 2.03e-6 at K = 256); against the unquantised product it carries the
+    operands' rounding (3 significand bits each): relative RMS <= 4 %.  Bias / GELU / scaled residual; fp32, bf16 and
+    fp8 (scale 1) outputs; ragged edges; run-to-run bit-identical."""
+    nat, dev = backend
+    if dev.type == "cpu" and M * N * K > 1.5e8:
+        pytest.skip("large shape: GPU only")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * (1.0 + torch.arange(M)[:, None] * 0.01)
+    w = torch.randn(N, K, generator=g) * 0.05
+    w[::5] *= 30.0
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    aq = nat.quant_rows_fp8(ad)
+    wq, ws = nat.lp_weight(wd, "fp8r")
+    adq = (_e4m3(aq.q).view(M, K) * aq.scale.cpu()[:, None]).double()
+    wdq = (_e4m3(wq).view(N, K) * ws.cpu()[:, None]).double()
+    prod_q, prod = adq @ wdq.t(), a.double() @ w.double().t()
+    scale = float((adq.abs() @ wdq.abs().t()).max())
+    out = nat.gemm_nt_fp8a(aq, wd, bd, rd, act=nat.ACT_GELU, alpha=0.5)
+    ref_q = (r.double() + 0.5 * F.gelu(prod_q + b.double())).float()
+    assert _md(out, ref_q) <= 5e-6 * scale + 1e-5
+    for _ in range(3 if dev.type == "cuda" else 1):
+        assert torch.equal(nat.gemm_nt_fp8a(aq, wd, bd, rd, act=nat.ACT_GELU, alpha=0.5), out)
+    plain = nat.gemm_nt_fp8a(aq, wd)
+    assert _md(plain, prod_q.float()) <= 5e-6 * scale + 1e-5
+    rms = float((plain.cpu().double() - prod).pow(2).mean().sqrt() / prod.pow(2).mean().sqrt())
+    assert rms <= 4e-2, rms
+    ob = nat.gemm_nt_fp8a(aq, wd, bd, out_dtype=torch.bfloat16)
+    assert torch.equal(ob.cpu(), nat.gemm_nt_fp8a(aq, wd, bd).cpu().to(torch.bfloat16))
+    o8 = nat.gemm_nt_fp8a(aq, wd, bd, act=nat.ACT_GELU, out_dtype="fp8")
+    want8 = nat.gemm_nt_fp8a(aq, wd, bd, act=nat.ACT_GELU).cpu().clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    assert o8.scale is None and torch.equal(_e4m3(o8.q).view(M, N), want8)
+    if N % 128 == 0:  # the hand-over: the fp8 result as the next contraction's operand
+        w2 = torch.randn(64, N, generator=g).to(dev) * 0.1
+        nxt = nat.gemm_nt_fp8a(o8, w2)
+        w2q, w2s = nat.lp_weight(w2, "fp8r")
+        ref2 = want8.double() @ (_e4m3(w2q).view(64, N) * w2s.cpu()[:, None]).double().t()
+        assert _md(nxt, ref2.float()) <= 5e-6 * float((want8.abs().double() @ (_e4m3(w2q).view(64, N).abs() * w2s.cpu()[:, None]).double().t()).max()) + 1e-5
+
+
 def test_no_stream_workspace_is_an_error_not_an_allocation(backend):
     """include/sbk.h, "stream workspace" (ABI 7): the library allocates no device memory.  A stream-K launch of the
     split-operand contraction on a stream whose workspace the caller has NOT registered must fail with SBK_EINVAL and a

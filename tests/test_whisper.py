@@ -297,3 +297,47 @@ def test_whisper_encoder_bf16_activation_pipeline(backend):
         err = (got - ref).float()
         assert float(err.abs().max()) <= 0.15 and float(err.pow(2).mean().sqrt()) <= 1e-2 * rms
     assert float((got_a - got_f).pow(2).mean().sqrt()) <= 3e-3 * rms
+
+
+def test_whisper_encoder_fp8_activation_pipeline(backend):
+    """precision "fp8" (BASELINE configs[4]): LayerNorm writes e4m3 rows with one scale per row, the weights carry one
+    scale per output channel, the four contractions of a layer run on the 2 x-rate fp8 matrix instruction
+    (native.gemm_nt_fp8a; hidden layer handed over as e4m3; attention on bf16 rows, its context quantised row by row).  Against
+    the fp32 encoder: e4m3 keeps 3 significand bits -- absolute 1.0, relative RMS 8 % (the tolerance of the round-3 fp8
+    path with fp32 activations and per-tensor scales, which must hold too, and be no tighter than the new one)."""
+    nat, dev = backend
+    from speechbrain_amd.integrations.huggingface.whisper import Whisper
+
+    cfg = dict(num_mel_bins=80, d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256,
+               max_source_positions=160, decoder_layers=0, decoder_attention_heads=2, decoder_ffn_dim=256,
+               vocab_size=100, max_target_positions=16)
+    w = Whisper.from_config(cfg, encoder_only=True, seed=4).to(dev).eval()
+    mel = torch.randn(2, 80, 320, generator=torch.Generator().manual_seed(5)).to(dev)  # 2 x 160 frames = 320 rows
+    calls = {"fp8a": 0}
+    g0 = nat.gemm_nt_fp8a
+
+    def counted(*a, **k):
+        calls["fp8a"] += 1
+        return g0(*a, **k)
+
+    nat.gemm_nt_fp8a = counted
+    try:
+        with torch.no_grad():
+            ref = w.model.encoder(mel)
+            with nat.precision_scope("fp8"):
+                got_a = w.model.encoder(mel)
+                nat.FP8_ACTIVATIONS = False
+                try:
+                    got_t = w.model.encoder(mel)
+                finally:
+                    nat.FP8_ACTIVATIONS = True
+    finally:
+        nat.gemm_nt_fp8a = g0
+    assert calls["fp8a"] == 4 * 2  # the four contractions of a layer on the fp8 instruction
+    rms = float(ref.pow(2).mean().sqrt())
+    errs = []
+    for got in (got_a, got_t):
+        err = (got - ref).float()
+        errs.append(float(err.pow(2).mean().sqrt()) / rms)
+        assert float(err.abs().max()) <= 1.0 and errs[-1] <= 8e-2, errs
+    assert errs[0] <= 1.25 * errs[1] + 1e-3, errs  # per-row / per-channel scales: no worse than per-tensor scaling

@@ -307,6 +307,26 @@ static inline f32x16 mfma_32x32x16_fp8(fp8x8 a, fp8x8 b, f32x16 acc) {
   }
   return mfma_32x32x16_generic_(av, bv, acc, 0);
 }
+struct i32x8 {
+  int v[8];
+  int& operator[](int i) { return v[i]; }
+  const int& operator[](int i) const { return v[i]; }
+};
+static inline i32x8 i32x8_from_u4(uint4 lo, uint4 hi) {
+  return i32x8{{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w}};
+}
+// e4m3 operands, 32 per lane: four passes of the 8-per-lane contraction over the lane's bytes 8q .. 8q+7
+static inline f32x16 mfma_32x32x64_fp8(i32x8 a, i32x8 b, f32x16 acc) {
+  for (int q = 0; q < 4; ++q) {
+    float av[8], bv[8];
+    for (int e = 0; e < 8; ++e) {
+      av[e] = fp8_to_f32_((unsigned char)((unsigned)a.v[2 * q + e / 4] >> (8 * (e % 4))));
+      bv[e] = fp8_to_f32_((unsigned char)((unsigned)b.v[2 * q + e / 4] >> (8 * (e % 4))));
+    }
+    acc = mfma_32x32x16_generic_(av, bv, acc, 0);
+  }
+  return acc;
+}
 static inline f32x4 mfma_16x16x4(float a, float b, f32x4 acc) {
   const int l = sbk_emu::cur().lane;
   float* A = sbk_emu::wave_buf(0);
