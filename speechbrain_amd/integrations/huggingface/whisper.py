@@ -137,7 +137,11 @@ class _Attention(nn.Module):
                     w = w.view(3, H, Dh, d).permute(1, 0, 2, 3)
                     b = b.view(3, H, Dh).permute(1, 0, 2)
                 self._stack = (w.reshape(3 * self.embed_dim, self.embed_dim).contiguous(), b.reshape(-1).contiguous())
+            # (built by kernels on THIS thread's stream; a batch in flight on another stream may ask for it a moment later:
+            # the consumer waits for the producer's event on the device, as for every derived weight image -- ADVICE r3)
+            self._stack_ready = native._Ready(self.q_proj.weight.device)
             self._stack_key = key
+        self._stack_ready.wait(self.q_proj.weight.device)
         return self._stack
 
 
@@ -190,7 +194,9 @@ class WhisperEncoder(nn.Module):
         if getattr(conv, "_gemm_key", None) != key:
             with torch.no_grad():
                 conv._gemm_w = conv.weight.permute(0, 2, 1).reshape(conv.weight.shape[0], -1).contiguous()
+            conv._gemm_ready = native._Ready(conv.weight.device)  # (see _Attention.stacked)
             conv._gemm_key = key
+        conv._gemm_ready.wait(conv.weight.device)
         return conv._gemm_w
 
     def forward(self, input_features, output_hidden_states=False):
