@@ -19,5 +19,6 @@ except Exception as e: print('no result', e)"; }
   f=$(find /tmp/dtr -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/decode_trace.py "$f" 32 | head -16
   for rep in 1 2; do for k in 0 1 3; do echo "== bench 8 x 4, knob 45 = $k (run $rep)"; bench --knob 45=$k; done; done
   for k in 0 3; do echo "== bench 4 x 8, knob 45 = $k"; bench --streams 4 --group 8 --knob 45=$k; done
+  for k in 0 3; do echo "== bench 8 x 4, knob 45 = $k, one cross-attention run per utterance (4 = 5, 8 = 3)"; bench --knob 45=$k --knob 4=5 --knob 8=3; done
   echo "== microbench"; timeout 60 python tools/microbench.py --x3r-ln 2>&1 | grep "x3r-ln" | head -12
 } 2>&1 | tee gpurun_out/r5_a.log
