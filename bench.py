@@ -420,6 +420,11 @@ def main():
                     help="no GPU work: launch the N ranks exactly as a measurement would (gloo instead of RCCL), push the "
                          "synthetic job through plan -> streamed scatter -> a stand-in transcriber -> gather and print the "
                          "line with n_gpus = N.  What tests/test_distributed.py runs on CPU")
+    ap.add_argument("--prof-concurrent", action="store_true",
+                    help="measurement runs only (the value is then that of an INSTRUMENTED run): HIP events around every launch "
+                         "of the timed region itself -- per kernel class the time its launches took with the other workers' "
+                         "kernels co-resident, and the mean number of kernels in flight (sum of those times / wall clock); "
+                         "rocprofv3 serialises the launch path of several threads and cannot show this regime (DESIGN.md section 6)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -544,6 +549,9 @@ def main():
         # the clock starts with the waveforms in (pageable) host memory and stops with the token-id lists on the host
         # (SURVEY 8d): planning -- duration sort, buckets, LPT assignment -- and the padding of every batch into pinned
         # staging memory are INSIDE it; the padding / H2D / sends are streamed behind the first batches' compute
+        if args.prof_concurrent:
+            native.prof_reset()
+            native.prof_enable(True)
         t0 = time.perf_counter()
         plan = st.plan(job)
         t_prep = time.perf_counter() - t0
@@ -552,6 +560,11 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         trace_mark()
+        conc = None
+        if args.prof_concurrent:
+            native.prof_enable(False)
+            conc = native.prof_report()
+            native.prof_reset()
         per_rank_wall = [dt]
         if dist_on:  # every rank's own wall time (audit of a scaling run), MAX over ranks = the job's time
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -560,16 +573,25 @@ def main():
             per_rank_wall = [float(w[0]) for w in walls]
             dt = max(per_rank_wall)
         info = {}
+        if rank == 0 and conc:
+            tot = sum(v["ms"] for v in conc.values())
+            top = sorted(conc.items(), key=lambda kv: -kv[1]["ms"])[:16]
+            info["concurrent_kernels"] = {
+                "instrumented": True, "launches": sum(v["count"] for v in conc.values()),
+                "kernel_ms_sum": round(tot, 1), "wall_ms": round(1000.0 * dt, 1),
+                "mean_kernels_in_flight": round(tot / (1000.0 * dt), 2),
+                "by_class": {k: {"launches": v["count"], "ms": round(v["ms"], 1), "us_each": round(1000.0 * v["ms"] / max(v["count"], 1), 1)}
+                             for k, v in top}}
         if rank == 0:
             plan_ = st.last_plan
-            info = {"n_batches": len(plan_["batches"]), "bytes_scattered": plan_["bytes_sent"], "plan_s": round(t_prep, 4),
+            info.update({"n_batches": len(plan_["batches"]), "bytes_scattered": plan_["bytes_sent"], "plan_s": round(t_prep, 4),
                     "streams": workers.n, "group": workers.group,
                     "gpu_memory_reserved_gb": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 1),
                     "gpu_memory_peak_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                     "per_rank_wall_s": [round(w, 4) for w in per_rank_wall],
                     "per_rank_audio_s": [round(sum(seconds[i] for b in plan_["owner"][r] for i in plan_["batches"][b]), 1)
                                          for r in range(world)],
-                    "per_rank_batches": [len(plan_["owner"][r]) for r in range(world)]}
+                    "per_rank_batches": [len(plan_["owner"][r]) for r in range(world)]})
         workers.pool.shutdown(wait=True)
         return dt, hyps, local, info
 
@@ -618,6 +640,7 @@ def main():
                                     if asr.mods.decoder.check_every > 0 else "not polled (check_every = 0)"},
             "rccl_world": world if dist_on else 0,
             "per_rank": {"wall_s": info["per_rank_wall_s"], "audio_s": info["per_rank_audio_s"], "batches": info["per_rank_batches"]},
+            **({"concurrent_kernels": info["concurrent_kernels"]} if "concurrent_kernels" in info else {}),
         }
 
     # ---- the same utterances as 128-utterance batches (N = 1)

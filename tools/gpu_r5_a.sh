@@ -17,6 +17,7 @@ except Exception as e: print('no result', e)"; }
   echo "== decode trace, knob 45 = 3"
   (cd /tmp && rm -rf /tmp/dtr && timeout 60 rocprofv3 --kernel-trace --output-format csv -d /tmp/dtr -o t -- python $R/tools/decode_probe.py --steps 16 --reps 2 --knob 45=3 2>&1 | grep "decode probe")
   f=$(find /tmp/dtr -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/decode_trace.py "$f" 32 | head -16
+  echo "== the eight-worker regime from HIP events (instrumented run, 4 steps)"; timeout 80 python bench.py --steps 4 --prof-concurrent --no-extras --no-roofline --no-cpu-baseline --latency-runs 0 2>>gpurun_out/r5a.err | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print(d[\"value\"], json.dumps(d.get(\"concurrent_kernels\")))"
   for rep in 1 2; do for k in 0 1 3; do echo "== bench 8 x 4, knob 45 = $k (run $rep)"; bench --knob 45=$k; done; done
   for k in 0 3; do echo "== bench 4 x 8, knob 45 = $k"; bench --streams 4 --group 8 --knob 45=$k; done
   for k in 0 3; do echo "== bench 8 x 4, knob 45 = $k, one cross-attention run per utterance (4 = 5, 8 = 3)"; bench --knob 45=$k --knob 4=5 --knob 8=3; done
