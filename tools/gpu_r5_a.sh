@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, first visit -- AFTER `git apply staging/r5_decoder_layernorm_in_projections.patch`, both libraries rebuilt and the
+# Round 5, first visit -- AFTER `git apply` of the two patches of staging/ (in order), both libraries rebuilt and the
 # CPU suite green here.  Full GPU suite at the patched tree, then what the patch buys: the decoder's LayerNorms as launches
 # (knob 45 = 0), inside the projections from a pre-pass (1) and from handed-over block statistics (3) -- the decoding step
 # on one stream (probe + kernel trace) and the headline under the two schedules that measured best (8 x 4, 4 x 8).
@@ -21,5 +21,7 @@ except Exception as e: print('no result', e)"; }
   for rep in 1 2; do for k in 0 1 3; do echo "== bench 8 x 4, knob 45 = $k (run $rep)"; bench --knob 45=$k; done; done
   for k in 0 3; do echo "== bench 4 x 8, knob 45 = $k"; bench --streams 4 --group 8 --knob 45=$k; done
   for k in 0 3; do echo "== bench 8 x 4, knob 45 = $k, one cross-attention run per utterance (4 = 5, 8 = 3)"; bench --knob 45=$k --knob 4=5 --knob 8=3; done
+  echo "== RelPosMHAXL on split operands (second staged patch)"; timeout 90 python tools/microbench.py --relpos-x3 2>&1 | grep "relpos attention"
+  for v in 0 1; do echo "== bench 8 x 4, SBK_RELPOS_X3=$v"; SBK_RELPOS_X3=$v bench; done
   echo "== microbench"; timeout 60 python tools/microbench.py --x3r-ln 2>&1 | grep "x3r-ln" | head -12
 } 2>&1 | tee gpurun_out/r5_a.log
