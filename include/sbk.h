@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SBK_ABI_VERSION 8
+#define SBK_ABI_VERSION 9
 
 typedef void* sbk_stream_t; /* hipStream_t */
 
@@ -219,6 +219,27 @@ int sbk_gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, c
  * workgroups (fixed summation order: the four waves' K quarters in order). */
 int sbk_gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW, const float* bias, const float* residual,
                     int ldr, float* C, int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, sbk_stream_t stream);
+/* ABI 9: the LayerNorm in front of such a projection (Transformer.py:751-834 with normalize_before: norm1 -> self-attention
+ * in_proj, norm2 -> cross-attention query rows, norm3 -> ffn.0; decoder.norm -> seq_lin) inside the projection's launch:
+ * C = residual + alpha * act(LayerNorm(A) . W^T + b) with the affine folded into the operands exactly as for
+ * sbk_gemm_ln_nt_f32 -- PWf = panel image (sbk_split_x3p) of Wf[n,k] = W[n,k] gamma[k], bf[n] = b[n] + sum_k W[n,k] beta[k].
+ * Row statistics in the two-pass form of sbk_layernorm_f32 (biased variance, eps inside the root), computed by the
+ * workgroup for its 64 rows while its first operand loads are in flight; x - mean is split, rstd scales the finished
+ * tile.  A fp32 [M, K], lda % 4 == 0; K = 256, 512, 1 024 or 1 280; N % 4 == 0. */
+int sbk_gemm_ln_nt_x3r(const float* A, int lda, const uint16_t* PWf, const float* bf, const float* residual, int ldr, float* C,
+                       int ldc, uint16_t* PC, int M, int N, int K, float eps, int act, float alpha, sbk_stream_t stream);
+/* ABI 9: the same without a pass over the rows -- the row statistics travel with the rows.  stats_out (N % 64 == 0): the
+ * launch is a plain sbk_gemm_nt_x3r (fp32 A) whose epilogue also writes, per row and 32-column block of its result, the
+ * block's mean and sum of squared deviations (float pairs, [M][N / 32]); stats_in ([M][K / 32], from such a launch or
+ * from sbk_row_block_stats_f32): the launch is C = residual + alpha * act(LayerNorm(A) . W^T + b) with PW / bias the
+ * FOLDED operands of sbk_gemm_ln_nt_x3r, a lane folding the blocks of its own rows (pairwise update of Chan, Golub &
+ * LeVeque; any K % 256 == 0).  One of the two per launch.  The decode step's residual stream: embed_pos and the three
+ * projections that add to it hand their statistics to the projection behind the next LayerNorm. */
+int sbk_gemm_nt_x3r_stats(const float* A, int lda, const float* stats_in, const uint16_t* PW, const float* bias,
+                          const float* residual, int ldr, float* C, int ldc, float* stats_out, int M, int N, int K, float eps,
+                          int act, float alpha, sbk_stream_t stream);
+/* block statistics of fp32 rows x [rows, d] (d % 32 == 0), as above: stats [rows][d / 32] float pairs */
+int sbk_row_block_stats_f32(const float* x, int ldx, float* stats, int rows, int d, sbk_stream_t stream);
 
 /* ---- bf16-operand fast entry points ("fp32 parity entry points plus bf16 ... fast entry points").
  * C = epilogue(bf16(A) . Wb^T) with fp32 accumulation on v_mfma_f32_32x32x16_bf16: A [M,K] stays fp32 in memory and is
@@ -319,6 +340,15 @@ int sbk_conv_block_f32(const float* x, const float* wt, const float* bias, const
 int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                              const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,
                              float scale, int chunk_size, int left_chunks, sbk_stream_t stream);
+/* ABI 9: the same context (no attention-weights output; head_dim 64) with the three products of a tile -- Q K^T, the
+ * position term, P V -- on the bf16 matrix pipe by the exact three-way operand split of sbk_gemm_nt_f32x3 (fp32 accumulation,
+ * fp32-grade results: the tolerances of sbk_relpos_attention_f32 hold).  Keys, values (transposed) and the position rows
+ * are split once per call into bf16 piece images in `workspace` (>= sbk_relpos_x3_workspace_bytes(B, T, H) bytes, 16-byte
+ * aligned, caller-owned; the library allocates nothing); queries and probabilities are split in registers. */
+size_t sbk_relpos_x3_workspace_bytes(int B, int T, int H);
+int sbk_relpos_attention_x3_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
+                                const int32_t* key_len, float* out, void* workspace, size_t workspace_bytes, int B, int T, int H,
+                                int Dh, float scale, int chunk_size, int left_chunks, sbk_stream_t stream);
 
 /* ---- RoPEMHA core (nnet/attention.py:1167-1392): what sits between in_proj and out_proj.
  *   out = softmax( rot(q) rot(k)^T scale , keys < key_len ) v,  scale = 1/sqrt(embed_dim) (:1272)
@@ -370,6 +400,9 @@ typedef struct {
    * [d,d], ca_out_w, ff1_w [d_ffn,d], ff2_w [d,d_ffn] -- a step with enough hypothesis rows (~200 on) then runs these
    * projections as sbk_gemm_nt_x3r (fp32 result on the bf16 matrix pipe; LayerNorm as its own launch) */
   const uint16_t *sa_in_wp, *sa_out_wp, *ca_q_wp, *ca_out_wp, *ff1_wp, *ff2_wp;
+  /* optional (NULL = unused; ABI 9): the panel images of the FOLDED matrices sa_in_wf, ca_q_wf, ff1_wf -- with them (and the
+   * folded biases above) a routed step runs norm1 / norm2 / norm3 inside the projection they feed (sbk_gemm_ln_nt_x3r) */
+  const uint16_t *sa_in_wfp, *ca_q_wfp, *ff1_wfp;
 } sbk_decoder_layer;
 
 typedef struct {
@@ -386,6 +419,7 @@ typedef struct {
   const uint16_t* seq_w3; /* optional (NULL = unused; ABI 6): seq_w as sbk_split_bf16x3 writes it -- the vocabulary
                              projection of a step with >= 1 024 hypothesis rows then runs as sbk_gemm_nt_f32x3 */
   const uint16_t* seq_wp; /* optional (ABI 8): seq_w's panel image (sbk_split_x3p): the vocabulary projection as sbk_gemm_nt_x3r */
+  const uint16_t* seq_wfp; /* optional (ABI 9): seq_wf's panel image: decoder.norm inside the vocabulary projection (sbk_gemm_ln_nt_x3r) */
 } sbk_decoder_weights;
 
 /* ---- ABI 8: fp8 (OCP e4m3) activations AND weights on the 2 x-rate fp8 matrix instruction (configs[4]: "fp8 MFMA on CDNA4";

@@ -33,7 +33,8 @@ class DecoderLayer(ctypes.Structure):  # sbk_decoder_layer
     _fields_ = [(n, c_void_p) for n in (
         "ln1_g", "ln1_b", "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ln2_g", "ln2_b", "ca_in_w", "ca_in_b",
         "ca_out_w", "ca_out_b", "ln3_g", "ln3_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b", "sa_in_wf", "sa_in_bf", "ca_q_wf",
-        "ca_q_bf", "ff1_wf", "ff1_bf", "ca_kv_w3", "sa_in_wp", "sa_out_wp", "ca_q_wp", "ca_out_wp", "ff1_wp", "ff2_wp")]
+        "ca_q_bf", "ff1_wf", "ff1_bf", "ca_kv_w3", "sa_in_wp", "sa_out_wp", "ca_q_wp", "ca_out_wp", "ff1_wp", "ff2_wp",
+        "sa_in_wfp", "ca_q_wfp", "ff1_wfp")]
 
 
 class DecoderWeights(ctypes.Structure):  # sbk_decoder_weights
@@ -42,7 +43,7 @@ class DecoderWeights(ctypes.Structure):  # sbk_decoder_weights
                 ("seq_bf", c_void_p), ("d_model", c_int32),
                 ("nhead", c_int32), ("d_ffn", c_int32), ("n_layers", c_int32), ("vocab", c_int32),
                 ("max_len", c_int32), ("ffn_act", c_int32), ("ln_eps", c_float), ("emb_scale", c_float),
-                ("seq_w3", c_void_p), ("seq_wp", c_void_p)]
+                ("seq_w3", c_void_p), ("seq_wp", c_void_p), ("seq_wfp", c_void_p)]
 
 
 class LMLayer(ctypes.Structure):  # sbk_lm_layer
@@ -102,6 +103,11 @@ def _declare(lib):
         "sbk_split_x3p": ([p, i, p, i, i, p], c_int),
         "sbk_layernorm_x3p": ([p, p, p, p, i, i, f, i, p], c_int),
         "sbk_gemm_nt_x3r": ([p, i, p, p, p, p, i, p, i, p, i, i, i, i, f, p], c_int),
+        "sbk_gemm_ln_nt_x3r": ([p, i, p, p, p, i, p, i, p, i, i, i, f, i, f, p], c_int),
+        "sbk_gemm_nt_x3r_stats": ([p, i, p, p, p, p, i, p, i, p, i, i, i, f, i, f, p], c_int),
+        "sbk_relpos_x3_workspace_bytes": ([i, i, i], ctypes.c_size_t),
+        "sbk_relpos_attention_x3_f32": ([p, p, p, p, p, p, p, ctypes.c_size_t, i, i, i, i, f, i, i, p], c_int),
+        "sbk_row_block_stats_f32": ([p, i, p, i, i, p], c_int),
         "sbk_quant_rows_fp8": ([p, i, p, p, i, i, p], c_int),
         "sbk_quant_rows_bf16_fp8": ([p, i, p, p, i, i, p], c_int),
         "sbk_layernorm_fp8o": ([p, p, p, p, p, i, i, f, i, p], c_int),
@@ -165,7 +171,7 @@ def load(path: Optional[str] = None):
         )
     lib = ctypes.CDLL(path)
     EXPORTS = tuple(_declare(lib).keys())
-    if lib.sbk_abi_version() != 8:
+    if lib.sbk_abi_version() != 9:
         raise SbkError(f"ABI version mismatch: {lib.sbk_abi_version()}")
     _lib = lib
     return lib
@@ -269,6 +275,8 @@ F32X3_MIN_TILES = int(os.environ.get("SBK_F32X3_MIN_TILES", "192"))
 X3P = os.environ.get("SBK_X3P", "1") != "0"
 # the decode step's few-row projections on the bf16 matrix pipe (sbk_gemm_nt_x3r: panel images of the decoder's weights)
 X3R = os.environ.get("SBK_X3R", "1") != "0"
+# RelPosMHAXL's tile products on the bf16 matrix pipe (sbk_relpos_attention_x3_f32; SBK_RELPOS_X3=1 to route -- untimed: off)
+RELPOS_X3 = os.environ.get("SBK_RELPOS_X3", "0") != "0"
 X3P_MIN_TILES = int(os.environ.get("SBK_X3P_MIN_TILES", "96"))
 
 
@@ -461,6 +469,54 @@ def gemm_nt_x3r(a, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alph
     if panel_out:
         return (out, pc) if fp32_out else pc
     return out
+
+
+def gemm_ln_nt_x3r(a: torch.Tensor, wf: torch.Tensor, bf, eps, residual=None, act=ACT_NONE, alpha=1.0):
+    """residual + alpha * act(LN(a) @ W^T + b) for FEW rows on the bf16 matrix pipe, the LayerNorm in the projection's
+    prologue (sbk_gemm_ln_nt_x3r): gamma / beta pre-folded into (wf, bf) as for ``gemm_ln_nt``; ``wf`` is used through its
+    cached panel image.  K = 256, 512, 1024 or 1280."""
+    lib = load()
+    K = a.shape[-1]
+    a2 = a.reshape(-1, K)
+    M, N = a2.shape[0], wf.shape[0]
+    _dev_ok(a2, wf, bf, residual)
+    _f32(a2)
+    out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
+    r2 = residual.reshape(-1, N) if residual is not None else None
+    _chk(lib.sbk_gemm_ln_nt_x3r(_p(a2), K, _p(lp_weight(wf, "x3p")), _p(bf), _p(r2), N, _p(out), N, None, M, N, K,
+                                float(eps), act, float(alpha), _stream(wf)), "sbk_gemm_ln_nt_x3r")
+    return out
+
+
+def row_block_stats(x: torch.Tensor):
+    """[rows, d / 32, 2]: mean and sum of squared deviations of every 32-column block of the rows of ``x`` (d % 32 == 0) --
+    what the kernels that write a residual stream hand to the LayerNorm behind it (sbk_row_block_stats_f32)."""
+    d = x.shape[-1]
+    x2 = x.reshape(-1, d)
+    _dev_ok(x2)
+    _f32(x2)
+    out = torch.empty(x2.shape[0], d // 32, 2, dtype=torch.float32, device=x.device)
+    _chk(load().sbk_row_block_stats_f32(_p(x2), x2.stride(0), _p(out), x2.shape[0], d, _stream(x2)), "sbk_row_block_stats_f32")
+    return out
+
+
+def gemm_nt_x3r_stats(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, stats_in=None,
+                      eps=0.0, stats_out=False):
+    """sbk_gemm_nt_x3r_stats: with ``stats_out`` the plain few-row projection, also returning the block statistics of its
+    result's rows (N % 64 == 0); with ``stats_in`` (the block statistics of the rows of ``a``) the projection of
+    LayerNorm(a) -- ``w`` / ``bias`` are then the FOLDED operands of ``gemm_ln_nt_x3r``."""
+    lib = load()
+    K = a.shape[-1]
+    a2 = a.reshape(-1, K)
+    M, N = a2.shape[0], w.shape[0]
+    _dev_ok(a2, w, bias, residual, stats_in)
+    _f32(a2)
+    out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
+    so = torch.empty(M, N // 32, 2, dtype=torch.float32, device=a.device) if stats_out else None
+    r2 = residual.reshape(-1, N) if residual is not None else None
+    _chk(lib.sbk_gemm_nt_x3r_stats(_p(a2), K, _p(stats_in), _p(lp_weight(w, "x3p")), _p(bias), _p(r2), N, _p(out), N, _p(so),
+                                   M, N, K, float(eps), act, float(alpha), _stream(w)), "sbk_gemm_nt_x3r_stats")
+    return (out, so) if stats_out else out
 
 
 class _Ready:
@@ -907,6 +963,13 @@ def relpos_attention(qkv, pos, bias_u, bias_v, key_len, H, scale, want_attn=Fals
     d = d3 // 3
     if out is None:
         out = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
+    if RELPOS_X3 and not want_attn and d // H == 64:  # the tile products on the bf16 matrix pipe (split operands, fp32-grade)
+        nbytes = lib.sbk_relpos_x3_workspace_bytes(B, T, H)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)  # (caching allocator: stream-ordered reuse)
+        _chk(lib.sbk_relpos_attention_x3_f32(_p(qkv), _p(pos), _p(bias_u), _p(bias_v), _p(key_len), _p(out), _p(ws), nbytes,
+                                             B, T, H, 64, float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
+             "sbk_relpos_attention_x3_f32")
+        return out, None
     attn = torch.empty(B, H, T, T, dtype=torch.float32, device=qkv.device) if want_attn else None
     _chk(lib.sbk_relpos_attention_f32(_p(qkv), _p(pos), _p(bias_u), _p(bias_v), _p(key_len), _p(out), _p(attn), B, T,
                                       H, d // H, float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
@@ -1064,10 +1127,13 @@ class DecoderHandle:
             o.sa_in_wp, o.sa_out_wp = panel(S["sa_in"][0]), panel(S["sa_out"][0])
             o.ca_q_wp, o.ca_out_wp = panel(S["ca_in"][0][:dm]), panel(S["ca_out"][0])
             o.ff1_wp, o.ff2_wp = panel(S["ff1"][0]), panel(S["ff2"][0])
-            if fold:  # LayerNorm folded into the projection it feeds (fused kernel, csrc/gemm.hip)
-                o.sa_in_wf, o.sa_in_bf = map(ptr, _fold_ln(*S["sa_in"], *S["ln1"]))
-                o.ca_q_wf, o.ca_q_bf = map(ptr, _fold_ln(S["ca_in"][0][:dm], S["ca_in"][1][:dm], *S["ln2"]))
-                o.ff1_wf, o.ff1_bf = map(ptr, _fold_ln(*S["ff1"], *S["ln3"]))
+            if fold:  # LayerNorm folded into the projection it feeds (fused kernels, csrc/gemm.hip)
+                for name, (wf, bf) in (("sa_in", _fold_ln(*S["sa_in"], *S["ln1"])),
+                                       ("ca_q", _fold_ln(S["ca_in"][0][:dm], S["ca_in"][1][:dm], *S["ln2"])),
+                                       ("ff1", _fold_ln(*S["ff1"], *S["ln3"]))):
+                    setattr(o, name + "_wf", ptr(wf))
+                    setattr(o, name + "_bf", ptr(bf))
+                    setattr(o, name + "_wfp", panel(wf))  # (ABI 9: the same fold for the rows sbk_gemm_ln_nt_x3r takes)
         self.layers = layers
         W = DecoderWeights()
         W.layers = ctypes.cast(layers, POINTER(DecoderLayer))
@@ -1078,7 +1144,8 @@ class DecoderHandle:
             W.seq_w3 = split3(seq[0])
             W.seq_wp = panel(seq[0])
             if fold:
-                W.seq_wf, W.seq_bf = map(ptr, _fold_ln(seq[0], seq[1], *final_ln))
+                wf, bf = _fold_ln(seq[0], seq[1], *final_ln)
+                W.seq_wf, W.seq_bf, W.seq_wfp = ptr(wf), ptr(bf), panel(wf)
         W.d_model, W.nhead = dm, nhead
         W.d_ffn, W.n_layers = layer_specs[0]["ff1"][0].shape[0], len(layer_specs)
         W.vocab = seq[0].shape[0] if seq is not None else emb.shape[0]

@@ -248,6 +248,49 @@ def test_relpos_transposed_flash_variant(backend, B, T, H, Dh, lens, chunk):
         assert _md(new, O.relpos_mha(x, pos, sd, "", H, kp)) <= 5e-6
 
 
+@pytest.mark.parametrize("B,T,H,lens,chunk", [(2, 133, 2, [133, 20], (0, -1)), (1, 33, 1, None, (0, -1)), (2, 251, 2, [251, 129], (16, 2)),
+                                              (1, 97, 3, [97], (8, -1)), (3, 64, 2, [64, 1, 40], (0, -1))])
+def test_relpos_attention_on_the_bf16_pipe_with_split_operands(backend, monkeypatch, B, T, H, lens, chunk):
+    """sbk_relpos_attention_x3_f32 (csrc/relpos_attn.hip: relpos_flash_x3_kernel, head_dim 64): RelPosMHAXL's Q K^T, position
+    term and P V on v_mfma_f32_32x32x16_bf16 with every operand cut into its three bf16 pieces (keys, transposed values and
+    position rows split once per call into a caller-owned workspace; queries and probabilities in registers).  fp32-grade:
+    the tolerance of the fp32-MFMA kernel against the oracle, and against that kernel itself -- key padding (down to one
+    key), Dynamic Chunk masks, ragged last tiles, T = a multiple of the tile and one more than it; run-to-run identical."""
+    nat, dev = backend
+    Dh = 64
+    d = H * Dh
+    g = torch.Generator().manual_seed(T + H)
+    x = torch.randn(B, T, d, generator=g)
+    sd = {"in_proj_weight": torch.randn(3 * d, d, generator=g) / math.sqrt(d),
+          "pos_bias_u": torch.randn(Dh, H, generator=g) * 0.3, "pos_bias_v": torch.randn(Dh, H, generator=g) * 0.3,
+          "linear_pos.weight": torch.randn(d, d, generator=g) / math.sqrt(d), "out_proj.weight": torch.eye(d),
+          "out_proj.bias": torch.zeros(d)}
+    pos = O.relpos_table(T, d)
+    kl = None if lens is None else torch.tensor(lens, dtype=torch.int32)
+    qkv = nat.gemm_nt(x.to(dev), sd["in_proj_weight"].to(dev))
+    P = nat.gemm_nt(pos.to(dev), sd["linear_pos.weight"].to(dev))
+    args = (qkv, P, sd["pos_bias_u"].reshape(-1).contiguous().to(dev), sd["pos_bias_v"].reshape(-1).contiguous().to(dev),
+            None if kl is None else kl.to(dev), H, 1 / math.sqrt(d), False, chunk[0], chunk[1])
+    base, _ = nat.relpos_attention(*args)
+    monkeypatch.setattr(nat, "RELPOS_X3", True)
+    nat.prof_reset()
+    nat.prof_enable(True)
+    try:
+        new, none = nat.relpos_attention(*args)
+        again, _ = nat.relpos_attention(*args)
+    finally:
+        nat.prof_enable(False)
+    assert none is None and "relpos_attention_x3" in nat.prof_report()
+    assert torch.equal(new, again)
+    assert _md(new, base.cpu()) <= 5e-6
+    if chunk[0] == 0:
+        kp = None if kl is None else ~O.length_to_mask(kl, T)
+        assert _md(new, O.relpos_mha(x, pos, sd, "", H, kp)) <= 5e-6
+    # the weights output still comes from the fp32 kernel (the route is not taken with want_attn)
+    _, attn = nat.relpos_attention(*args[:7], True, chunk[0], chunk[1])
+    assert attn is not None
+
+
 @pytest.mark.parametrize("prefetch", [0, 1, 4, 5])
 @pytest.mark.parametrize("B,T,H,Dh,lens", [(2, 45, 4, 8, [45, 30]), (1, 70, 2, 36, [70]), (2, 133, 2, 64, [133, 20]),
                                            (1, 300, 1, 32, None)])
@@ -880,6 +923,98 @@ def test_gemm_x3r(backend, M, N, K, a_panel):
             assert torch.equal(nat.gemm_nt_x3r(only, w2), nat.gemm_nt_x3r(out, w2))
 
 
+@pytest.mark.parametrize("M,N,K", [(1280, 512, 512), (300, 132, 512), (70, 1536, 512), (1280, 2048, 512), (1, 40, 512),
+                                   (333, 64, 1024), (200, 260, 1280), (130, 768, 256), (1280, 5000, 512)])
+def test_gemm_ln_x3r(backend, M, N, K):
+    """sbk_gemm_ln_nt_x3r: the LayerNorm in front of a decode-step projection inside the projection's launch (row statistics
+    by the workgroup for its 64 rows, x - mean split in front of the matrix instruction, rstd on the finished tile; gamma /
+    beta folded into the weight's panel image and the bias).  Against LayerNorm + Linear in fp64 at the bound of the
+    library's fp32 kernels (rows with an offset of several standard deviations and rows of tiny magnitude included);
+    against the two launches it replaces (sbk_layernorm_f32 + sbk_gemm_nt_x3r) at the same bound; ragged edges; bias /
+    activation / scaled residual; run-to-run bit-identical."""
+    nat, dev = backend
+    if dev.type == "cpu" and M * N * K > 1.2e8:
+        pytest.skip("large shape: GPU only")
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    a = torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 3.0) + torch.randn(M, 1, generator=g) * 4.0
+    a[::7] *= 1e-3
+    a[:, ::5] *= 3.0  # (a few loud channels, as residual streams have)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    w[::5] *= 30.0
+    gamma, beta = 1.0 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    eps = 1e-5
+    wf, bf = nat._fold_ln(w, b, gamma, beta)
+    ad, wd, bd, rd, gd, btd, wfd, bfd = (t.to(dev) for t in (a, w, b, r, gamma, beta, wf, bf))
+    ln64 = F.layer_norm(a.double(), (K,), gamma.double(), beta.double(), eps)
+    prod = ln64 @ w.double().t()
+    scale = float((ln64.abs() @ w.double().abs().t()).max())
+    out = nat.gemm_ln_nt_x3r(ad, wfd, bfd, eps, residual=rd, act=nat.ACT_SWISH, alpha=0.5)
+    ref = (r.double() + 0.5 * F.silu(prod + b.double())).float()
+    assert _md(out, ref) <= 2e-6 * scale + 1e-5
+    for _ in range(3 if dev.type == "cuda" else 1):
+        assert torch.equal(nat.gemm_ln_nt_x3r(ad, wfd, bfd, eps, residual=rd, act=nat.ACT_SWISH, alpha=0.5), out)
+    plain = nat.gemm_ln_nt_x3r(ad, wfd, bfd, eps)
+    assert _md(plain, (prod + b.double()).float()) <= 2e-6 * scale + 1e-5
+    if K % 256 == 0:
+        two = nat.gemm_nt_x3r(nat.layernorm(ad, gd, btd, eps), wd, bd)
+        assert _md(plain, two) <= 2e-6 * scale + 1e-5
+    # constant rows (variance 0: rstd = 1 / sqrt(eps), x - mean = 0 exactly) give the folded bias
+    const = torch.full((3, K), 2.5).to(dev)
+    assert _md(nat.gemm_ln_nt_x3r(const, wfd, bfd, eps), bf.expand(3, N)) <= 1e-6 * float(bf.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("M,dm,N", [(1280, 512, 1536), (300, 512, 132), (70, 512, 512), (45, 1280, 260), (130, 256, 768),
+                                    (1280, 512, 5000)])
+def test_gemm_x3r_layernorm_from_handed_over_block_statistics(backend, M, dm, N):
+    """The LayerNorm of a decode-step projection WITHOUT a pass over its rows (sbk_gemm_nt_x3r_stats): the projection that
+    writes the residual stream (x = residual + ctx . Wo^T + b, N = d_model) also writes, per row and 32-column block, the
+    block's mean and sum of squared deviations; the projection behind the LayerNorm folds the blocks of its rows (pairwise
+    update with equal block sizes) and runs on x - mean, rstd on the finished tile.  The handed-over statistics equal the
+    blocks' two-pass statistics of the written rows (1e-6 relative to the row's scale) and sbk_row_block_stats_f32's bit
+    for bit (embed_pos uses that arithmetic); the LayerNorm-projection against LayerNorm + Linear in fp64 at the bound of
+    the library's fp32 kernels and against the pre-pass form (sbk_gemm_ln_nt_x3r); run-to-run bit-identical."""
+    nat, dev = backend
+    if dev.type == "cpu" and M * N * dm > 1.2e8:
+        pytest.skip("large shape: GPU only")
+    g = torch.Generator().manual_seed(M + N + dm + 2)
+    ctx = torch.randn(M, dm, generator=g)
+    wo, bo = torch.randn(dm, dm, generator=g) / dm ** 0.5, torch.randn(dm, generator=g)
+    x0 = torch.randn(M, dm, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 3.0) + torch.randn(M, 1, generator=g) * 4.0
+    x0[::7] *= 1e-3
+    x0[:, ::5] *= 3.0
+    w = torch.randn(N, dm, generator=g) / dm ** 0.5
+    w[::5] *= 30.0
+    gamma, beta, b = 1.0 + 0.3 * torch.randn(dm, generator=g), 0.2 * torch.randn(dm, generator=g), torch.randn(N, generator=g)
+    eps = 1e-5
+    wf, bf = nat._fold_ln(w, b, gamma, beta)
+    ctxd, wod, bod, x0d, wfd, bfd = (t.to(dev) for t in (ctx, wo, bo, x0, wf, bf))
+    x, st = nat.gemm_nt_x3r_stats(ctxd, wod, bod, residual=x0d, stats_out=True)
+    assert torch.equal(x, nat.gemm_nt_x3r(ctxd, wod, bod, x0d))  # the rows themselves: the plain projection's
+    blocks = x.cpu().double().view(M, dm // 32, 32)
+    mb = blocks.mean(-1)
+    m2 = ((blocks - mb[..., None]) ** 2).sum(-1)
+    rowscale = x.cpu().double().abs().amax(-1, keepdim=True)
+    assert float(((st[..., 0].cpu().double() - mb).abs() / rowscale).max()) <= 1e-6
+    assert float(((st[..., 1].cpu().double() - m2).abs() / (32 * rowscale ** 2)).max()) <= 1e-6
+    st2 = nat.row_block_stats(x)
+    assert float(((st2[..., 0].cpu().double() - mb).abs() / rowscale).max()) <= 1e-6
+    assert float(((st2[..., 1].cpu().double() - m2).abs() / (32 * rowscale ** 2)).max()) <= 1e-6
+    ln64 = F.layer_norm(x.cpu().double(), (dm,), gamma.double(), beta.double(), eps)
+    prod = ln64 @ w.double().t() + b.double()
+    scale = float((ln64.abs() @ w.double().abs().t()).max())
+    for stats in (st, st2):
+        out = nat.gemm_nt_x3r_stats(x, wfd, bfd, stats_in=stats, eps=eps)
+        assert _md(out, prod.float()) <= 2e-6 * scale + 1e-5
+    for _ in range(3 if dev.type == "cuda" else 1):
+        assert torch.equal(nat.gemm_nt_x3r_stats(x, wfd, bfd, stats_in=st2, eps=eps), out)
+    if dm in (256, 512, 1024, 1280):
+        assert _md(out, nat.gemm_ln_nt_x3r(x, wfd, bfd, eps)) <= 2e-6 * scale + 1e-5
+    r = torch.randn(M, N, generator=g)
+    out2 = nat.gemm_nt_x3r_stats(x, wfd, bfd, residual=r.to(dev), act=nat.ACT_SWISH, alpha=0.5, stats_in=st, eps=eps)
+    assert _md(out2, (r.double() + 0.5 * F.silu(prod)).float()) <= 2e-6 * scale + 1e-5
+
+
 def _e4m3(q):  # uint8 e4m3 bits -> float32 (torch's own decoder)
     return q.cpu().view(torch.float8_e4m3fn).float()
 
@@ -1053,6 +1188,16 @@ def test_cross_attention_lds_dma_variant(backend, d_model, nhead, B, T, beam_row
     assert float((outs[0] - ref).abs().max()) <= 5e-5
     assert float((outs[5] - ref).abs().max()) <= 5e-5
     assert float((outs[6] - ref).abs().max()) <= 5e-5
+    # one run per utterance (knob 8 = 3: the workgroup walks the whole memory and writes the context itself -- no partials,
+    # no merge launch)
+    nat.load().sbk_prof_set_knob(4, 5)
+    nat.load().sbk_prof_set_knob(8, 3)
+    try:
+        one = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev)).cpu()
+    finally:
+        nat.load().sbk_prof_set_knob(4, 7)
+        nat.load().sbk_prof_set_knob(8, 0)
+    assert float((one - ref).abs().max()) <= 5e-5
     # the merge of an utterance's runs by its last-arriving workgroup (knob 37 = 1; measured slower, off) against the separate
     # cross_merge launch: same partials, same arithmetic -> the same bits, also over repeated calls (tickets re-armed)
     for knob in (5, 6):

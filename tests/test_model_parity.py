@@ -247,15 +247,18 @@ def test_decoder_with_fused_layernorm_vs_oracle(backend):
     assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
 
 
-@pytest.mark.parametrize("mode", [1, 0])
-def test_decoder_on_the_x3r_route_vs_oracle(backend, mode):
+@pytest.mark.parametrize("mode,ln", [(1, 1), (0, 1), (0, 3), (0, 0)])
+def test_decoder_on_the_x3r_route_vs_oracle(backend, mode, ln):
     """The decode step's projections as sbk_gemm_nt_x3r (csrc/gemm.hip: gemm_x3r_kernel -- fp32 results on the bf16
     matrix pipe from the panel images of the decoder's weights; the route of every step with ~200 hypothesis rows or
     more): d_model 256 / d_ffn 512 are eligible widths (K % 256 == 0), the row threshold is lowered so that this small
     search takes it (knob 42).  Teacher-forced decoder outputs 5e-5 and a beam search with CTC (ids exact, scores 1e-4)
     against the oracle; with the A operands as panel images too (LayerNorm written as a panel, attention context through
     sbk_split_x3p, the feed-forward hidden layer handed over by the first projection's epilogue: knob 44 = 1) and as fp32
-    rows split in registers (0, the default); the result does not change when the route is switched off."""
+    rows split in registers (0, the default); with norm1 / norm2 / norm3 and decoder.norm inside the projections they feed
+    (sbk_gemm_ln_nt_x3r, knob 45 = 1: the default with fp32 operands -- the profiler's launch names show which route ran),
+    with their row statistics handed over by the kernels that write the residual stream (3: embed_pos and the three
+    projections that add to it) and as launches of their own (0); the result does not change when the route is switched off."""
     nat, dev = backend
     from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
     from speechbrain_amd.inference.builders import build_modules
@@ -278,11 +281,22 @@ def test_decoder_on_the_x3r_route_vs_oracle(backend, mode):
     tgt = torch.randint(0, 60, (3, 6), generator=gen)
     lib = nat.load()
     lib.sbk_prof_set_knob(44, mode)
+    lib.sbk_prof_set_knob(45, ln)
     lib.sbk_prof_set_knob(42, 1)
     try:
         h = nat.DecoderHandle(mods["Transformer"], mods["seq_lin"])
         assert h.layers[0].sa_in_wp and h.layers[0].ff2_wp and h.W.seq_wp  # the panel images exist for these widths
+        assert h.layers[0].sa_in_wfp and h.layers[0].ca_q_wfp and h.layers[0].ff1_wfp and h.W.seq_wfp  # and the folded ones
+        nat.prof_reset()
+        nat.prof_enable(True)
         pred = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev))
+        nat.prof_enable(False)
+        rep = nat.prof_report()
+        fused = rep.get("gemm_lns_x3r" if ln == 3 else "gemm_ln_x3r", {}).get("count", 0)
+        assert ("gemm_ln_x3r" in rep) == (ln == 1 and not mode) and ("gemm_lns_x3r" in rep) == (ln == 3 and not mode), sorted(rep)
+        # fused: three per layer and position; the LayerNorm launches left are decoder.norm, whose rows are this entry's result
+        norms = rep.get("layernorm", {}).get("count", 0)
+        assert (fused == 6 * tgt.shape[1] and norms == tgt.shape[1]) if (ln and not mode) else fused == 0, (fused, norms)
         assert float((pred.cpu() - O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")).abs().max()) <= 5e-5
         ratio = 8.5 / 30
         hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=4, ctc_weight=0.4, max_decode_ratio=ratio))
@@ -290,16 +304,70 @@ def test_decoder_on_the_x3r_route_vs_oracle(backend, mode):
         bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
                                         min_decode_ratio=0.0, max_decode_ratio=ratio, beam_size=4,
                                         using_eos_threshold=False, length_normalization=True, scorer=scorer)
+        nat.prof_reset()
+        nat.prof_enable(True)
         hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))
+        nat.prof_enable(False)
+        rep = nat.prof_report()
+        if ln and not mode:  # a search step: every LayerNorm of the decoder, decoder.norm included, inside a projection
+            assert rep["gemm_lns_x3r" if ln == 3 else "gemm_ln_x3r"]["count"] % 6 == 0 and "layernorm" not in rep, sorted(rep)  # (decoder.norm: the few-row fused kernel at 12 rows)
         assert hyps == hyps_ref
         assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
+        if ln and not mode:
+            # decoder.norm inside the vocabulary projection as well: at bench sizes (1 280 rows x 5 000 tokens) the few-row
+            # fused kernel does not take that shape; here it is switched off (knob 2) so that this small search takes the route
+            lib.sbk_prof_set_knob(2, 1)
+            try:
+                nat.prof_reset()
+                nat.prof_enable(True)
+                hyps_v, _, sc_v, _ = bs(enc.to(dev), wl.to(dev))
+                nat.prof_enable(False)
+                rep = nat.prof_report()
+            finally:
+                lib.sbk_prof_set_knob(2, 0)
+            assert rep["gemm_lns_x3r" if ln == 3 else "gemm_ln_x3r"]["count"] % 7 == 0 and "layernorm" not in rep, sorted(rep)
+            assert hyps_v == hyps_ref and float((sc_v.cpu() - sc_ref).abs().max()) <= 1e-4
         lib.sbk_prof_set_knob(41, 0)  # the fp32-MFMA route of the same handle
         hyps0, _, sc0, _ = bs(enc.to(dev), wl.to(dev))
         assert hyps0 == hyps and float((sc0 - sc).abs().max()) <= 1e-4
     finally:
+        nat.prof_enable(False)
         lib.sbk_prof_set_knob(41, 2)
         lib.sbk_prof_set_knob(44, 0)
+        lib.sbk_prof_set_knob(45, 1)
         lib.sbk_prof_set_knob(42, 192)
+
+
+def test_encoder_with_relpos_attention_on_split_operands_vs_oracle(backend, monkeypatch):
+    """A Conformer encoder whose RelPosMHAXL layers run on sbk_relpos_attention_x3_f32 (head_dim 64: the route's condition;
+    csrc/relpos_attn.hip: relpos_flash_x3_kernel) against the oracle's encoder on the same weights, ragged lengths included:
+    the tolerance of the default route.  The profiler's launch names show that the route ran in every layer."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_modules
+
+    m = build_modules(dict(d_model=128, nhead=2, d_ffn=256, n_enc=2, n_dec=1, n_fft=400, win_length=25), vocab=50, seed=5)
+    mods = torch.nn.ModuleDict({k: m[k] for k in ("CNN", "Transformer")})
+    sd = {k: v.detach().clone() for k, v in mods.state_dict().items()}
+    mods = mods.to(dev).eval()
+    cfg = O.ModelCfg(d_model=128, nhead=2, num_encoder_layers=2, num_decoder_layers=1, d_ffn=256, vocab=50)
+    gen = torch.Generator().manual_seed(23)
+    feats = torch.randn(3, 150, 80, generator=gen)
+    wl = torch.tensor([1.0, 0.6, 0.83])
+    with torch.no_grad():
+        cnn = mods["CNN"](feats.to(dev))
+        base = mods["Transformer"].encode(cnn, wl.to(dev)).cpu()
+        monkeypatch.setattr(nat, "RELPOS_X3", True)
+        nat.prof_reset()
+        nat.prof_enable(True)
+        try:
+            enc = mods["Transformer"].encode(cnn, wl.to(dev)).cpu()
+        finally:
+            nat.prof_enable(False)
+    rep = nat.prof_report()
+    assert rep["relpos_attention_x3"]["count"] == 2 and "relpos_attention" not in rep, sorted(rep)
+    ref = O.encode(cnn.cpu(), wl, sd, cfg, "Transformer.")
+    assert float((base - ref).abs().max()) <= 5e-5
+    assert float((enc - ref).abs().max()) <= 5e-5
 
 
 def build_lm(g, dev):

@@ -145,6 +145,25 @@ if __name__ == "__main__":
             nat.load().sbk_prof_set_knob(17, 1)
             print(f"relpos attention B={B} T={T} H={H}:", res, "max|diff|", float((outs["lds-tile"] - outs["transposed"]).abs().max()), flush=True)
         sys.exit(0)
+    if "--relpos-x3" in sys.argv:  # RelPosMHAXL: fp32-MFMA transposed-score kernel vs the split-operand kernel on the bf16 pipe
+        import math
+        for (B, T, H) in [(32, 251, 8), (32, 440, 8), (32, 750, 8), (8, 750, 8)]:
+            Dh, d = 64, 8 * 64
+            qkv = torch.randn(B, T, 3 * d, device=dev)
+            P = torch.randn(2 * T - 1, d, device=dev)
+            u, v = torch.randn(d, device=dev) * 0.3, torch.randn(d, device=dev) * 0.3
+            kl = torch.full((B,), T, dtype=torch.int32, device=dev)
+            fl = 6.0 * B * H * T * T * Dh
+            res, outs = {}, {}
+            for tag, on in (("fp32 MFMA", False), ("split operands", True)):
+                nat.RELPOS_X3 = on
+                outs[tag] = nat.relpos_attention(qkv, P, u, v, kl, H, 1 / math.sqrt(d))[0]
+                t = timeit(lambda: nat.relpos_attention(qkv, P, u, v, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
+                res[tag] = f"{t:8.1f} us {fl / t / 1e6:6.1f} TF/s"
+            nat.RELPOS_X3 = False
+            print(f"relpos attention B={B} T={T} H={H}:", res, "(split passes included) max|diff|",
+                  float((outs["fp32 MFMA"] - outs["split operands"]).abs().max()), flush=True)
+        sys.exit(0)
     if "--attn2" in sys.argv:  # RoPE / plain attention: LDS-tile flash kernel vs transposed-score kernel vs its bf16 variant
         import math
         from speechbrain_amd.nnet.attention import PrecomputedRoPESinusoids
@@ -365,6 +384,42 @@ if __name__ == "__main__":
                 e3 = float((nat.gemm_nt_x3r(a, w, residual=r).double() - ref).pow(2).mean().sqrt())
                 e0 = float((nat.gemm_nt_splitk(a, w, residual=r, slices=4).double() - ref).pow(2).mean().sqrt())
                 print(line + f" rms err vs fp64: x3r {e3:.3e} fp32 {e0:.3e}", flush=True)
+        sys.exit(0)
+    if "--x3r-ln" in sys.argv:  # LayerNorm + sbk_gemm_nt_x3r (two launches) vs sbk_gemm_ln_nt_x3r (the LayerNorm in the prologue)
+        def ev_time(fn, n=40):
+            fn(); fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+        K = 512
+        for M in (640, 1280, 2560):
+            for N in (512, 1536, 2048, 5000):
+                a = torch.randn(M, K, device=dev) * 2 + 0.5; w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
+                g = 1 + 0.1 * torch.randn(K, device=dev); bt = 0.1 * torch.randn(K, device=dev)
+                wf, bf = nat._fold_ln(w, b, g, bt)
+                h = torch.empty_like(a)
+                t_ln = ev_time(lambda: nat.layernorm(a, g, bt, 1e-5, out=h))
+                t_g = ev_time(lambda: nat.gemm_nt_x3r(h, w, b))
+                t2 = ev_time(lambda: nat.gemm_nt_x3r(nat.layernorm(a, g, bt, 1e-5, out=h), w, b))
+                t1 = ev_time(lambda: nat.gemm_ln_nt_x3r(a, wf, bf, 1e-5))
+                ref = torch.nn.functional.layer_norm(a.double(), (K,), g.double(), bt.double(), 1e-5) @ w.double().t() + b.double()
+                e1 = float((nat.gemm_ln_nt_x3r(a, wf, bf, 1e-5).double() - ref).abs().max())
+                e2 = float((nat.gemm_nt_x3r(nat.layernorm(a, g, bt, 1e-5), w, b).double() - ref).abs().max())
+                st = nat.row_block_stats(a)
+                t3 = ev_time(lambda: nat.gemm_nt_x3r_stats(a, wf, bf, stats_in=st, eps=1e-5))
+                e3 = float((nat.gemm_nt_x3r_stats(a, wf, bf, stats_in=st, eps=1e-5).double() - ref).abs().max())
+                print(f"x3r-ln M={M} N={N}: layernorm {t_ln:5.1f} us + x3r {t_g:5.1f} us, back to back {t2:5.1f} us | pre-pass {t1:5.1f} us "
+                      f"({2.0*M*N*K/t1/1e6:5.1f} TF/s) | handed-over statistics {t3:5.1f} us | max err vs fp64: {e1:.2e} / {e3:.2e}, two launches {e2:.2e}", flush=True)
+            # the producing side: a projection that writes the residual stream, with and without the block statistics of its result
+            ctx = torch.randn(M, K, device=dev); wo = torch.randn(K, K, device=dev); x0 = torch.randn(M, K, device=dev)
+            tp0 = ev_time(lambda: nat.gemm_nt_x3r(ctx, wo, residual=x0))
+            tp1 = ev_time(lambda: nat.gemm_nt_x3r_stats(ctx, wo, residual=x0, stats_out=True))
+            print(f"x3r-ln M={M}: out-projection {K} -> {K} + residual {tp0:5.1f} us, also writing block statistics {tp1:5.1f} us", flush=True)
         sys.exit(0)
     if "--ln-x3p" in sys.argv:  # LayerNorm written as the next contraction's panel operand vs LayerNorm + split pass
         def ev_time(fn, n=30):
