@@ -100,15 +100,25 @@ class WhisperASR(Pretrained):
         super().__init__(*args, **kwargs)
         self.tokenizer = self.hparams.whisper.tokenizer
 
+    # ---- the encoder under the interface's precision (inference/interfaces.py:295-298: every forward of a Pretrained
+    # runs inside the context built from run_opts; here that context is native.precision_scope) -----------------------
+    def _mel(self, wavs):
+        return self.mods.whisper._get_mel(wavs.to(device=self.device, dtype=torch.float32))
+
+    def _encode_mel(self, mel):
+        from speechbrain_amd import native
+
+        with native.precision_scope(self.eval_precision):
+            return self.mods.whisper.forward_encoder(mel)
+
     def encode_batch(self, wavs, wav_lens):
-        wavs = wavs.to(device=self.device, dtype=torch.float32)
-        return self.mods.whisper.forward_encoder(self.mods.whisper._get_mel(wavs))
+        return self._encode_mel(self._mel(wavs))
 
     @torch.no_grad()
     def transcribe_batch(self, wavs, wav_lens):
         wav_lens = wav_lens.float().to(self.device)
         predicted_tokens, _, _, _ = self.mods.decoder(self.encode_batch(wavs, wav_lens), wav_lens)
-        predicted_words = [self.tokenizer.decode(t, skip_special_tokens=True).strip() for t in predicted_tokens]
+        predicted_words = [self._text(t) for t in predicted_tokens]
         if getattr(self.hparams, "normalized_transcripts", False):
             predicted_words = [self.tokenizer.normalize(text).split(" ") for text in predicted_words]
         return predicted_words, predicted_tokens
@@ -116,30 +126,38 @@ class WhisperASR(Pretrained):
     def forward(self, wavs, wav_lens):
         return self.transcribe_batch(wavs, wav_lens)
 
+    def _text(self, tokens):
+        return self.tokenizer.decode(tokens, skip_special_tokens=True).strip()
+
     # ---- language identification (inference/ASR.py:475-560) --------------------------------------------------------
     @torch.no_grad()
     def detect_language_file(self, path: str):
         """Language of an audio file of 30 seconds or less: (language tokens [1], [{code: probability}])."""
-        wavs = self.load_audio(path).float().to(self.device).unsqueeze(0)
-        return self.mods.whisper.detect_language(self.mods.whisper._get_mel(wavs))
+        return self.mods.whisper.detect_language(self._mel(self.load_audio(path).unsqueeze(0)))
 
     @torch.no_grad()
     def detect_language_batch(self, wav):
-        return self.mods.whisper.detect_language(self.mods.whisper._get_mel(wav.to(device=self.device, dtype=torch.float32)))
+        return self.mods.whisper.detect_language(self._mel(wav))
 
-    @torch.no_grad()
-    def _detect_language(self, mel, task):
-        """:541-560: the configured language, or -- when none is set or the task is lang_id -- the detected one, which
-        is also handed to the searcher as the language token of every utterance."""
-        languages = [self.mods.whisper.language] * mel.shape[0]
-        lang_probs = None
-        if self.mods.whisper.language is None or task == "lang_id":
-            lang_tokens, lang_probs = self.mods.whisper.detect_language(mel)
-            languages = [max(probs, key=probs.get) for probs in lang_probs]
-            self.mods.decoder.set_lang_tokens(lang_tokens)
-        return languages, lang_probs
+    def _segment_languages(self, mel, task):
+        """The language code of every item of ``mel``: the model's configured language, unless none is configured or the
+        task is language identification -- then the most probable detected one, whose tokens also become the
+        searcher's language tokens (inference/ASR.py:541-560)."""
+        whisper = self.mods.whisper
+        if whisper.language is not None and task != "lang_id":
+            return [whisper.language] * mel.shape[0]
+        lang_tokens, lang_probs = whisper.detect_language(mel)
+        self.mods.decoder.set_lang_tokens(lang_tokens)
+        return [max(probs, key=probs.get) for probs in lang_probs]
 
     # ---- long-form transcription (inference/ASR.py:622-840) ------------------------------------------------------
+    def _file_segments(self, path, chunk_size, **kwargs):
+        """(start_s, end_s, samples [1, n]) for consecutive ``chunk_size``-second pieces of the file."""
+        audio = self.load_audio(path, **kwargs).unsqueeze(0)
+        pieces = split_fixed_chunks(audio, chunk_size * self.hparams.sample_rate)
+        for k, piece in enumerate(pieces):
+            yield k * chunk_size, (k + 1) * chunk_size, piece.to(self.device)
+
     @torch.no_grad()
     def transcribe_file_streaming(self, path, task=None, initial_prompt=None, logprob_threshold=-1.0,
                                   no_speech_threshold=0.6, condition_on_previous_text=False, verbose=False,
@@ -151,46 +169,34 @@ class WhisperASR(Pretrained):
         of this package; the segments and therefore the results are the same)."""
         if use_torchaudio_streaming:
             raise NotImplementedError("torchaudio.io.StreamReader (ffmpeg) streaming: pass use_torchaudio_streaming=False")
-        if task is not None:
-            if task not in self.TASKS:
-                raise ValueError(f"Task {task} not supported. Supported tasks are {self.TASKS}")
-            if task != "lang_id":
-                self.mods.decoder.set_task(task)
-        num_frames_per_chunk = chunk_size * self.hparams.sample_rate
-        segments = split_fixed_chunks(self.load_audio(path, **kwargs).unsqueeze(0), num_frames_per_chunk)
-        rel_length = torch.tensor([1.0])
-        all_tokens, prompt_reset_since = [], 0
-        if initial_prompt is not None:
-            all_tokens.extend(self.tokenizer.encode(" " + initial_prompt.strip()))
-        for i, segment in enumerate(segments):
-            segment = segment.to(self.device)
-            mel_segment = self.mods.whisper._get_mel(segment)
-            start, end = i * chunk_size, (i + 1) * chunk_size
-            encoder_out = self.mods.whisper.forward_encoder(mel_segment)
-            languages, _ = self._detect_language(mel_segment, task)
+        if task is not None and task not in self.TASKS:
+            raise ValueError(f"Task {task} not supported. Supported tasks are {self.TASKS}")
+        searcher = self.mods.decoder
+        if task in ("transcribe", "translate"):
+            searcher.set_task(task)
+        history = _PromptHistory(self.tokenizer, initial_prompt,
+                                 carry_over=lambda: condition_on_previous_text and searcher.temperature <= 0.5)
+        whole = torch.tensor([1.0])
+        for start, end, samples in self._file_segments(path, chunk_size, **kwargs):
+            mel = self._mel(samples)
+            memory = self._encode_mel(mel)
+            lang = self._segment_languages(mel, task)[0]
+            seg = ASRWhisperSegment(start=start, end=end, chunk=samples, lang_id=lang)
             if task == "lang_id":
-                yield ASRWhisperSegment(start=start, end=end, chunk=segment, lang_id=languages[0])
+                yield seg
                 continue
-            prompt = all_tokens[prompt_reset_since:]
-            self.mods.decoder.set_prompt(prompt)
-            predicted_tokens, _, scores, _ = self.mods.decoder(encoder_out, rel_length)
-            avg_log_probs = scores.sum() / (len(predicted_tokens[0]) + 1)
-            no_speech_prob = self.mods.decoder.no_speech_probs[0]
-            if no_speech_threshold is not None:
-                should_skip = no_speech_prob > no_speech_threshold
-                if logprob_threshold is not None and avg_log_probs > logprob_threshold:
-                    should_skip = False  # confident enough despite the no-speech probability
-                if should_skip:
-                    yield ASRWhisperSegment(start=start, end=end, chunk=segment, lang_id=languages[0], words="", tokens=[],
-                                            prompt=prompt, avg_log_probs=avg_log_probs.item(), no_speech_prob=no_speech_prob)
-                    continue
-            words = [self.tokenizer.decode(t, skip_special_tokens=True).strip() for t in predicted_tokens]
-            yield ASRWhisperSegment(start=start, end=end, chunk=segment, lang_id=languages[0], words=words[0],
-                                    tokens=predicted_tokens[0], prompt=prompt, avg_log_probs=avg_log_probs.item(),
-                                    no_speech_prob=no_speech_prob)
-            all_tokens.extend(predicted_tokens[0])
-            if not condition_on_previous_text or self.mods.decoder.temperature > 0.5:
-                prompt_reset_since = len(all_tokens)
+            seg.prompt = history.current()
+            searcher.set_prompt(seg.prompt)
+            hyps, _, scores, _ = searcher(memory, whole)
+            seg.avg_log_probs = float(scores.sum() / (len(hyps[0]) + 1))
+            seg.no_speech_prob = searcher.no_speech_probs[0]
+            if _is_silence(seg.no_speech_prob, seg.avg_log_probs, no_speech_threshold, logprob_threshold):
+                seg.words, seg.tokens = "", []
+                yield seg
+                continue
+            seg.words, seg.tokens = self._text(hyps[0]), hyps[0]
+            yield seg
+            history.append(hyps[0])
 
     def transcribe_file(self, path, task=None, initial_prompt=None, logprob_threshold=-1.0, no_speech_threshold=0.6,
                         condition_on_previous_text=False, verbose=False, use_torchaudio_streaming=False, chunk_size=30,
@@ -205,6 +211,32 @@ class WhisperASR(Pretrained):
             if verbose:
                 print(f"[{seg.start}s --> {seg.end}s] {seg.words if task != 'lang_id' else seg.lang_id}")
         return results
+
+
+def _is_silence(no_speech_prob, avg_log_prob, no_speech_threshold, logprob_threshold):
+    """The segment skip rule of long-form Whisper decoding (inference/ASR.py:742-757): a segment is dropped when the
+    no-speech probability exceeds its threshold -- unless the hypothesis' average log-probability clears its own."""
+    if no_speech_threshold is None or not no_speech_prob > no_speech_threshold:
+        return False
+    return logprob_threshold is None or not avg_log_prob > logprob_threshold
+
+
+class _PromptHistory:
+    """The token history that conditions the next segment's search (inference/ASR.py:690-700, 775-787): everything decoded
+    so far (after an optional initial prompt), of which only the part behind ``mark`` is shown to the searcher.  Unless
+    ``carry_over()`` holds after a segment, the mark moves to the end, i.e. the next segment starts from an empty prompt."""
+
+    def __init__(self, tokenizer, initial_prompt, carry_over):
+        self.tokens = list(tokenizer.encode(" " + initial_prompt.strip())) if initial_prompt is not None else []
+        self.mark, self.carry_over = 0, carry_over
+
+    def current(self):
+        return self.tokens[self.mark:]
+
+    def append(self, hyp):
+        self.tokens.extend(hyp)
+        if not self.carry_over():
+            self.mark = len(self.tokens)
 
 
 # ---------------------------------------------------------------------------------------------- streaming

@@ -87,12 +87,15 @@ class Pretrained(torch.nn.Module):
         if device is None:
             device = "cuda:0" if torch.cuda.is_available() else "cpu"
         self.device = torch.device(device)
-        # run_opts precision / eval_precision (utils/run_opts.py:114-115): "fp32" = the parity path; "bf16" = bf16
-        # operands with fp32 accumulation in the encoder's large GEMMs (Fbank and everything else stay fp32, as the
-        # reference's autocast keeps them, utils/autocast.py:167)
+        # run_opts precision / eval_precision (utils/run_opts.py:114-115; the reference turns it into the autocast
+        # context every forward runs in, inference/interfaces.py:295-298): "fp32" = the parity path; "bf16" / "fp16" =
+        # operands of that type with fp32 accumulation in the encoder's large contractions (Fbank and everything else
+        # stay fp32, as the reference's autocast keeps them, utils/autocast.py:167); "fp8" = the e4m3 activation pipeline
+        # of the Whisper encoder (BASELINE configs[4]; native.precision_scope).  Every forward of an interface runs inside
+        # native.precision_scope(self.eval_precision).
         self.eval_precision = run_opts.get("eval_precision") or run_opts.get("precision") or "fp32"
-        if self.eval_precision not in ("fp32", "bf16"):
-            raise NotImplementedError(f"precision {self.eval_precision!r}: 'fp32' and 'bf16' are implemented")
+        if self.eval_precision not in ("fp32", "bf16", "fp16", "fp8"):
+            raise NotImplementedError(f"precision {self.eval_precision!r}: 'fp32' (parity), 'bf16', 'fp16' and 'fp8' are implemented")
         self.mods = torch.nn.ModuleDict(modules or {})
         for m in self.mods.values():
             if m is not None:

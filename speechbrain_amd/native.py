@@ -370,6 +370,19 @@ class Panel:
     def device(self):
         return self.data.device
 
+    # what a consumer written for the fp32 activation asks of its operand (RoPEMHA.core / the *_group cores: ADVICE r4)
+    @property
+    def shape(self):
+        return torch.Size((tuple(self.lead) if self.lead is not None else (self.rows,)) + (self.K,))
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    def new_empty_rows(self) -> torch.Tensor:
+        """An fp32 tensor of the shape of the activation this image stands for (``torch.empty_like`` of a tensor operand)."""
+        return torch.empty(self.shape, dtype=torch.float32, device=self.data.device)
+
 
 def panel_empty(rows: int, K: int, device, lead=None) -> Panel:
     n = ((rows + 63) // 64) * 64 * K * 3  # int16 elements
@@ -436,9 +449,22 @@ def gemm_nt_x3p(a: Panel, w: torch.Tensor, bias=None, residual=None, act=ACT_NON
         out = torch.empty(*lead, N, dtype=torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
     pc = panel_empty(M, N, a.device, lead) if panel_out else None
+    # The kernel moves rows of C / residual / bias as 16-byte vectors.  A tensor operand falls back to another kernel in
+    # gemm_nt; a Panel operand has no fp32 form to fall back with, so unaligned views go through aligned temporaries
+    # (fresh torch allocations are 512-byte aligned) -- ADVICE r4
+    user_out = None
+    if bias is not None and bias.data_ptr() % 16:
+        bias = bias.clone()
+    if r2 is not None and r2.data_ptr() % 16:
+        r2 = r2.clone()
+    if fp32_out and out.data_ptr() % 16:
+        user_out, out = out, torch.empty(out.shape, dtype=torch.float32, device=out.device)
     _chk(lib.sbk_gemm_nt_x3p(_p(a.data), _p(wp), _p(bias), _p(r2), N, _p(out) if fp32_out else None, N,
                              _p(pc.data) if pc is not None else None, M, N, K, act, float(alpha), _p(seq_len), int(rows_per_seq),
                              _stream(a.data)), "sbk_gemm_nt_x3p")
+    if user_out is not None:
+        user_out.copy_(out)
+        out = user_out
     if panel_out:
         return (out, pc) if fp32_out else pc
     return out

@@ -833,6 +833,46 @@ def test_grouped_encoder_equals_batch_by_batch(backend, attention):
     assert got == seq
 
 
+@pytest.mark.parametrize("attention", ["RelPosMHAXL", "RoPEMHA"])
+def test_panel_route_serves_both_attention_types_and_the_grouped_encoder(backend, attention):
+    """with the both-operands-pre-split route on (the default fp32 path from 2 048 rows on; here the
+    thresholds are lowered so that the tiny model takes it) a LayerNorm hands its consumer a native.Panel, not a tensor.
+    RoPEMHA.core / core_group and RelPosMHAXL.core_group must accept it: encode_batch and encode_group on the panel route
+    against the same model on the fp32-tensor route (2e-5: same products, another summation order)."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_asr
+
+    tiny = dict(d_model=32, nhead=4, d_ffn=64, n_enc=2, n_dec=1, n_fft=512, win_length=32)
+    asr = build_asr(tiny, vocab=30, seed=23, beam_size=2, ctc_weight=0.3, device=str(dev), attention_type=attention)
+    g = torch.Generator().manual_seed(3)
+    batches = [(0.1 * torch.randn(B, N, generator=g), torch.linspace(0.6, 1.0, B) if B > 1 else torch.ones(1))
+               for B, N in [(3, 9600), (2, 5120), (1, 12800)]]
+    with torch.no_grad():
+        plain = [asr.encode_batch(w, l) for w, l in batches]
+    old = nat.F32X3, nat.X3P, nat.F32X3_MIN_ROWS, nat.X3P_MIN_TILES
+    calls = {"ln": 0}
+    ln0 = nat.layernorm_x3p
+
+    def ln(*a, **k):
+        calls["ln"] += 1
+        return ln0(*a, **k)
+
+    nat.F32X3, nat.X3P, nat.F32X3_MIN_ROWS, nat.X3P_MIN_TILES = True, True, 1, 1
+    nat.layernorm_x3p = ln
+    try:
+        with torch.no_grad():
+            one_by_one = [asr.encode_batch(w, l) for w, l in batches]
+            n_single = calls["ln"]
+            together = asr.encode_group(batches)
+    finally:
+        nat.F32X3, nat.X3P, nat.F32X3_MIN_ROWS, nat.X3P_MIN_TILES = old
+        nat.layernorm_x3p = ln0
+    assert n_single > 0 and calls["ln"] > n_single  # (both entry points handed panels to their attention layers)
+    for a, b, c in zip(one_by_one, together, plain):
+        assert a.shape == c.shape and b.shape == c.shape
+        assert float((a - c).abs().max()) <= 2e-5 and float((b - c).abs().max()) <= 2e-5
+
+
 def test_bf16_precision_is_opt_in_and_close(backend):
     """run_opts precision="bf16": the encoder's large GEMMs take bf16 operands (fp32 accumulation); the default stays
     the fp32 parity path bit for bit.  Stated tolerance for this tiny model: encoder output within 5e-2 absolute of

@@ -192,6 +192,52 @@ def test_whisper_asr_interface(backend):
     assert float((enc.cpu() - torch.from_numpy(g["enc"])).abs().max()) <= 1e-3
 
 
+def test_whisper_asr_run_opts_precision_reaches_the_fp8_pipeline(backend):
+    """BASELINE configs[4] "via speechbrain.inference, fp8 MFMA": WhisperASR(run_opts={"precision": "fp8"}) runs its encoder
+    inside native.precision_scope("fp8") (the reference builds the inference context of every forward from run_opts,
+    inference/interfaces.py:295-298) -- the layer's four contractions take native.gemm_nt_fp8a (encode_batch here; transcribe_batch
+    and transcribe_file_streaming go through the same WhisperASR._encode_mel); the default interface stays on fp32 and takes none; fp16 / bf16 are
+    accepted, anything else is refused by name."""
+    nat, dev = backend
+    from speechbrain_amd.inference.ASR import WhisperASR
+    from speechbrain_amd.integrations.huggingface.whisper import Whisper
+
+    cfg = dict(num_mel_bins=80, d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256,
+               max_source_positions=160, decoder_layers=1, decoder_attention_heads=2, decoder_ffn_dim=256,
+               vocab_size=100, max_target_positions=16)
+    w = Whisper.from_config(cfg, seed=4).to(dev).eval()
+    w._get_mel = lambda wav: w.log_mel_spectrogram(w.pad_or_trim(wav, 51200))  # 320 frames -> 160 encoder positions
+    hp = {"language": "en", "sample_rate": 16000, "whisper": w, "normalized_transcripts": False}
+    wav = 0.1 * torch.randn(2, 51200, generator=torch.Generator().manual_seed(9))
+    calls = {"fp8a": 0}
+    g0 = nat.gemm_nt_fp8a
+
+    def counted(*a, **k):
+        calls["fp8a"] += 1
+        return g0(*a, **k)
+
+    nat.gemm_nt_fp8a = counted
+    try:
+        with torch.no_grad():
+            a32 = WhisperASR(modules={"whisper": w, "decoder": torch.nn.Identity()}, hparams=hp, run_opts={"device": str(dev)})
+            ref = a32.encode_batch(wav, torch.ones(2))
+            assert calls["fp8a"] == 0 and a32.eval_precision == "fp32"
+            a8 = WhisperASR(modules={"whisper": w, "decoder": torch.nn.Identity()}, hparams=hp,
+                            run_opts={"device": str(dev), "precision": "fp8"})
+            got = a8.encode_batch(wav, torch.ones(2))
+            assert calls["fp8a"] == 4 * 2  # the four contractions of each of the two layers
+            assert nat.precision() == "fp32"  # (the scope ends with the forward)
+    finally:
+        nat.gemm_nt_fp8a = g0
+    rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert 0.0 < rel <= 8e-2, rel  # e4m3 operands: the tolerance of test_whisper_encoder_fp8_activation_pipeline
+    for p in ("bf16", "fp16"):
+        assert WhisperASR(modules={"whisper": w, "decoder": torch.nn.Identity()}, hparams=hp,
+                          run_opts={"device": str(dev), "eval_precision": p}).eval_precision == p
+    with pytest.raises(NotImplementedError):
+        WhisperASR(modules={"whisper": w, "decoder": torch.nn.Identity()}, hparams=hp, run_opts={"device": str(dev), "precision": "int4"})
+
+
 def test_whisper_beam_searcher_matches_reference_golden(backend):
     """S2SWhisperBeamSearcher (seq2seq.py:1937-2206) on the device search: prompt priming of every hypothesis' KV cache,
     per-utterance language tokens, suppression masks, log_softmax / temperature, eos rules, return_topk -- token ids
