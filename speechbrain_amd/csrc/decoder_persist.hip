@@ -1,0 +1,515 @@
+// The decoding step of a FEW hypothesis rows as ONE cooperative launch (reference: TransformerDecoderLayer.forward,
+// lobes/models/transformer/Transformer.py:751-834, driven by S2STransformerBeamSearcher.forward_step,
+// decoders/seq2seq.py:1632-1723 -- the single-utterance regime, beam <= 16 rows).
+//
+// Why: at 10 rows a step of the launch-per-operation path is ~70 dependent launches of ~9 us (p50 27 ms for a 10-s
+// utterance, three rounds flat), although its work is streaming ~100 MB of weights once.  Here the whole decoder stack of a
+// step is one kernel whose G workgroups stay resident and meet at grid barriers between sub-layers:
+//
+//   embed | per layer: [norm1 + in_proj] | self-attention | [out_proj + x] | [norm2 + q proj] | cross-attention |
+//   [out_proj + x] | [norm3 + ffn.0 + act] | [ffn.3 + x] | ... | [decoder.norm + seq_lin]
+//
+// * projections: weight-stationary -- a workgroup owns 16 output columns (its 16 x K weight slice, 32 KB at K = 512) for
+//   ALL rows; the four waves split K, 16 x 16 x 4 fp32 MFMAs, fixed-order LDS reduction.  The rows (16 x K fp32) are staged
+//   into LDS by every workgroup, LayerNorm statistics included (gamma / beta are folded into the weights, sbk.h).
+//   The first weight loads of the NEXT projection are issued before the barrier wait: weights do not depend on activations,
+//   so their HBM latency hides behind the barrier.
+// * activations between workgroups travel through agent-scope (sc1) accesses, never through L2 write-back / invalidate
+//   (hip/sbk_device.h: ld_agent / st_agent / grid_arrive / grid_wait; tools/persist_probe.hip measured both).
+// * self-attention: one wave per (row, head) over the KV cache (the layout and arithmetic of self_attn_step_kernel);
+//   cross-attention: one workgroup per (utterance, head), the four waves walk the memory in 64-frame runs with all K / V rows
+//   of a run in flight, online softmax per wave, merge through LDS.
+// Results: same algorithm, another summation order than the launch-per-operation kernels (tests: ids equal, 1e-4).
+#include <math.h>
+
+#include "internal.h"
+
+namespace {
+
+constexpr int kPRows = 16;        // hypothesis rows a launch serves (the MFMA tile height)
+constexpr int kMaxPLayers = 16;   // (kernel arguments are passed by value: 16 x 15 pointers)
+
+struct PLayer {
+  const float *sa_in_wf, *sa_in_bf, *sa_out_w, *sa_out_b, *ca_q_wf, *ca_q_bf, *ca_out_w, *ca_out_b, *ff1_wf, *ff1_bf, *ff2_w, *ff2_b;
+  float *kcache, *vcache;  // [slot][Lmax][d]
+  const float* ckv;        // [B][T][2d]: K (d) then V (d) per frame
+};
+
+struct PStepArgs {
+  PLayer L[kMaxPLayers];
+  const int32_t *tok, *kv_slot, *enc_len;
+  const float *emb, *pe_row;
+  float *x, *qkv, *ctx, *q, *ff, *h, *logits;
+  const float *fin_g, *fin_b, *seq_wf, *seq_bf;
+  int* bar;      // arrival counter of the grid barriers (monotonic over the launches of a search)
+  int bar_base;  // its value when this launch starts
+  int n, B, T, beam, d, H, dffn, V, nl, step, Lmax, act, want_logits;
+  float eps, emb_scale, attn_scale;
+};
+
+struct WPref {  // the first operand loads of this wave's first tile of the NEXT projection
+  float4 w[8];
+};
+
+__device__ __forceinline__ float act_of(float v, int act) {
+  switch (act) {
+    case SBK_ACT_SWISH: return v / (1.0f + expf(-v));
+    case SBK_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case SBK_ACT_RELU: return v > 0.0f ? v : 0.0f;
+    case SBK_ACT_LEAKY_RELU: return v > 0.0f ? v : 0.01f * v;
+    default: return v;
+  }
+}
+
+// address of this lane's first operand of tile `tile` (16 columns from tile * 16; rows past N re-read row N - 1)
+__device__ __forceinline__ const float* w_lane_ptr(const float* W, int K, int N, int tile) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int col = tile * 16 + (lane & 15);
+  col = col < N ? col : N - 1;
+  return W + (size_t)col * K + wave * (K >> 2) + 4 * (lane >> 4);
+}
+
+__device__ __forceinline__ void prefetch_w(WPref& pf, const float* W, int K, int N) {
+  if ((int)blockIdx.x * 16 >= N) return;
+  const float* wp = w_lane_ptr(W, K, N, blockIdx.x);
+  const int nb = K >> 6;  // 16-deep operand groups of this wave's K quarter
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (j < nb) pf.w[j] = *reinterpret_cast<const float4*>(wp + 16 * j);
+}
+
+// rows of X [n][K] (written by other workgroups of this launch) -> xs [16][K + 4] in LDS, rows >= n zero; LN: normalised
+template <bool LN>
+__device__ __forceinline__ void stage_rows(const PStepArgs& a, float* xs, const float* X, int K) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, KP = K + 4;
+  __syncthreads();  // (the previous user of this LDS region is done)
+  for (int idx = 2 * tid; idx < kPRows * K; idx += 512) {
+    const int row = idx / K, c = idx - row * K;
+    float2 v = make_float2(0.0f, 0.0f);
+    if (row < a.n) v = sbk::ld_agent2(X + (size_t)row * K + c);
+    xs[row * KP + c] = v.x;
+    xs[row * KP + c + 1] = v.y;
+  }
+  __syncthreads();
+  if (LN) {
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 4 + r;
+      if (row >= a.n) continue;  // (uniform per wave)
+      float* xr = xs + row * KP;
+      float s = 0.0f;
+      for (int c = lane; c < K; c += 64) s += xr[c];
+      const float mean = sbk::wave_sum(s) / (float)K;
+      float qs = 0.0f;
+      for (int c = lane; c < K; c += 64) {
+        const float dv = xr[c] - mean;
+        qs += dv * dv;
+      }
+      const float rstd = rsqrtf(sbk::wave_sum(qs) / (float)K + a.eps);
+      for (int c = lane; c < K; c += 64) xr[c] = (xr[c] - mean) * rstd;
+    }
+    __syncthreads();
+  }
+}
+
+// C[n][N] (+ R) = act(xs . W^T + bias) for this workgroup's column tiles; xs staged by stage_rows.  K % 64 == 0.
+__device__ __forceinline__ void tiles_gemm(const PStepArgs& a, const float* xs, float* red, int K, const float* W, const float* bias,
+                                           const float* R, float* C, int N, int act, const WPref& pf) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, KP = K + 4, G = gridDim.x;
+  const int ntiles = (N + 15) >> 4, nb = K >> 6;
+  const float* xa = xs + (lane & 15) * KP + wave * (K >> 2) + 4 * (lane >> 4);
+  for (int tile = blockIdx.x; tile < ntiles; tile += G) {
+    const float* wp = w_lane_ptr(W, K, N, tile);
+    sbk::f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int jb = 0; jb < nb; jb += 8) {
+      float4 w[8];
+      if (jb == 0 && tile == (int)blockIdx.x) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = pf.w[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (jb + j < nb) w[j] = *reinterpret_cast<const float4*>(wp + 16 * (jb + j));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (jb + j < nb) {
+          const float4 x4 = *reinterpret_cast<const float4*>(xa + 16 * (jb + j));
+          acc = sbk::mfma_16x16x4(x4.x, w[j].x, acc);
+          acc = sbk::mfma_16x16x4(x4.y, w[j].y, acc);
+          acc = sbk::mfma_16x16x4(x4.z, w[j].z, acc);
+          acc = sbk::mfma_16x16x4(x4.w, w[j].w, acc);
+        }
+      }
+    }
+    __syncthreads();  // (red free again)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+    __syncthreads();
+    const int row = tid >> 4, col = tile * 16 + (tid & 15);
+    if (row < a.n && col < N) {
+      float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+      v = act_of(v + (bias ? bias[col] : 0.0f), act);
+      if (R) v += sbk::ld_agent(R + (size_t)row * N + col);
+      sbk::st_agent(C + (size_t)row * N + col, v);
+    }
+  }
+}
+
+// one wave: hypothesis row i, head h (head_dim 64) over the KV cache -- self_attn_step_kernel's walk with coherent I/O
+__device__ __forceinline__ void self_attn_item(const PStepArgs& a, const PLayer& L, float* prob, int* slot, int i, int h) {
+  const int lane = threadIdx.x & 63, pg = lane >> 4, cq = lane & 15, d = a.d, step = a.step, len = step + 1;
+  const float* qp = a.qkv + (size_t)i * 3 * d + h * 64 + cq * 4;
+  float4 q4, kn, vn;
+  {
+    const float2 q0 = sbk::ld_agent2(qp), q1 = sbk::ld_agent2(qp + 2);
+    const float2 k0 = sbk::ld_agent2(qp + d), k1 = sbk::ld_agent2(qp + d + 2);
+    const float2 v0 = sbk::ld_agent2(qp + 2 * d), v1 = sbk::ld_agent2(qp + 2 * d + 2);
+    q4 = make_float4(q0.x * a.attn_scale, q0.y * a.attn_scale, q1.x * a.attn_scale, q1.y * a.attn_scale);
+    kn = make_float4(k0.x, k0.y, k1.x, k1.y);
+    vn = make_float4(v0.x, v0.y, v1.x, v1.y);
+  }
+  if (pg == 0) {  // append this token's K / V head slice (slot = hypothesis index); read by LATER launches only
+    const size_t o = ((size_t)i * a.Lmax + step) * d + h * 64 + cq * 4;
+    *reinterpret_cast<float4*>(L.kcache + o) = kn;
+    *reinterpret_cast<float4*>(L.vcache + o) = vn;
+  }
+  for (int p = lane; p < step; p += 64) slot[p] = a.kv_slot[(size_t)i * a.Lmax + p];
+  sbk::wave_sync();
+  const size_t hoff = (size_t)h * 64 + cq * 4;
+  for (int p0 = 0; p0 < len; p0 += 16) {
+    float4 kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + 4 * u + pg;
+      kv[u] = p < step ? *reinterpret_cast<const float4*>(L.kcache + ((size_t)slot[p] * a.Lmax + p) * d + hoff) : kn;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float s = (q4.x * kv[u].x + q4.y * kv[u].y) + (q4.z * kv[u].z + q4.w * kv[u].w);
+      s += sbk::shfl_xor(s, 1);
+      s += sbk::shfl_xor(s, 2);
+      s += sbk::shfl_xor(s, 4);
+      s += sbk::shfl_xor(s, 8);
+      const int p = p0 + 4 * u + pg;
+      if (p < len && cq == 0) prob[p] = s;
+    }
+  }
+  sbk::wave_sync();
+  float m = -INFINITY;
+  for (int p = lane; p < len; p += 64) m = fmaxf(m, prob[p]);
+  m = sbk::wave_max(m);
+  float sum = 0.0f;
+  for (int p = lane; p < len; p += 64) {
+    const float e = expf(prob[p] - m);
+    prob[p] = e;
+    sum += e;
+  }
+  sum = sbk::wave_sum(sum);
+  for (int p = lane; p < len; p += 64) prob[p] = prob[p] / sum;
+  sbk::wave_sync();
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p0 = 0; p0 < len; p0 += 16) {
+    float4 vv[4];
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + 4 * u + pg;
+      vv[u] = p < step ? *reinterpret_cast<const float4*>(L.vcache + ((size_t)slot[p] * a.Lmax + p) * d + hoff) : vn;
+      w[u] = p < len ? prob[p] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc.x = fmaf(w[u], vv[u].x, acc.x);
+      acc.y = fmaf(w[u], vv[u].y, acc.y);
+      acc.z = fmaf(w[u], vv[u].z, acc.z);
+      acc.w = fmaf(w[u], vv[u].w, acc.w);
+    }
+  }
+  float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] += sbk::shfl_xor(o[e], 16);
+    o[e] += sbk::shfl_xor(o[e], 32);
+  }
+  if (pg == 0) {
+    float* op = a.ctx + (size_t)i * d + hoff;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sbk::st_agent(op + e, o[e]);
+  }
+  sbk::wave_sync();  // (prob / slot are reused by this wave's next item)
+}
+
+// one workgroup: the beam rows of utterance u, head h (head_dim 64) over the utterance's memory
+__device__ __forceinline__ void cross_attn_item(const PStepArgs& a, const PLayer& L, float* lds, int u, int h) {
+  float* qs = lds;           // [16][64] scaled queries
+  float* wm = qs + 1024;     // [4][16] running maxima of the waves
+  float* wl = wm + 64;       // [4][16] their sums
+  float* wacc = wl + 64;     // [4][16][64] their un-normalised contexts
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pg = lane >> 4, cq = lane & 15;
+  const int d = a.d, nq = a.beam;
+  int klen = a.enc_len[u];
+  klen = klen < 1 ? 1 : (klen > a.T ? a.T : klen);
+  __syncthreads();
+  for (int idx = tid; idx < kPRows * 64; idx += 256) {
+    const int j = idx >> 6, c = idx & 63;
+    qs[idx] = j < nq ? sbk::ld_agent(a.q + ((size_t)u * a.beam + j) * d + h * 64 + c) * a.attn_scale : 0.0f;
+  }
+  __syncthreads();
+  const float* kvb = L.ckv + (size_t)u * a.T * 2 * d + h * 64 + cq * 4;
+  float m[kPRows], l[kPRows];
+  float4 acc[kPRows];
+#pragma unroll
+  for (int j = 0; j < kPRows; ++j) {
+    m[j] = -INFINITY;
+    l[j] = 0.0f;
+    acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int t0 = wave * 64; t0 < klen; t0 += 256) {
+    float4 kk[16], vv[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {  // every K and V row of the run in flight before any arithmetic
+      const int t = t0 + 4 * g + pg;
+      const bool ok = t < klen;
+      const float* rp = kvb + (size_t)(ok ? t : t0) * 2 * d;
+      kk[g] = *reinterpret_cast<const float4*>(rp);
+      vv[g] = *reinterpret_cast<const float4*>(rp + d);
+    }
+#pragma unroll
+    for (int j = 0; j < kPRows; ++j) {
+      if (j < nq) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qs + j * 64 + cq * 4);
+        float s[16];
+        float cm = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          float sv = (q4.x * kk[g].x + q4.y * kk[g].y) + (q4.z * kk[g].z + q4.w * kk[g].w);
+          sv += sbk::shfl_xor(sv, 1);
+          sv += sbk::shfl_xor(sv, 2);
+          sv += sbk::shfl_xor(sv, 4);
+          sv += sbk::shfl_xor(sv, 8);
+          s[g] = (t0 + 4 * g + pg) < klen ? sv : -INFINITY;
+          cm = fmaxf(cm, s[g]);
+        }
+        cm = fmaxf(cm, sbk::shfl_xor(cm, 16));
+        cm = fmaxf(cm, sbk::shfl_xor(cm, 32));  // (finite: frame t0 of this run is inside the memory)
+        const float mn = fmaxf(m[j], cm);
+        const float corr = expf(m[j] - mn);
+        float lj = l[j] * corr;
+        float4 aj = make_float4(acc[j].x * corr, acc[j].y * corr, acc[j].z * corr, acc[j].w * corr);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const float p = expf(s[g] - mn);
+          lj += p;
+          aj.x = fmaf(p, vv[g].x, aj.x);
+          aj.y = fmaf(p, vv[g].y, aj.y);
+          aj.z = fmaf(p, vv[g].z, aj.z);
+          aj.w = fmaf(p, vv[g].w, aj.w);
+        }
+        m[j] = mn;
+        l[j] = lj;
+        acc[j] = aj;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kPRows; ++j) {
+    if (j < nq) {
+      float lj = l[j];
+      lj += sbk::shfl_xor(lj, 16);
+      lj += sbk::shfl_xor(lj, 32);
+      float o[4] = {acc[j].x, acc[j].y, acc[j].z, acc[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] += sbk::shfl_xor(o[e], 16);
+        o[e] += sbk::shfl_xor(o[e], 32);
+      }
+      if (pg == 0) {
+        *reinterpret_cast<float4*>(wacc + (wave * kPRows + j) * 64 + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        if (cq == 0) {
+          wm[wave * kPRows + j] = m[j];
+          wl[wave * kPRows + j] = lj;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int j = tid >> 4, c4 = (tid & 15) * 4;
+    if (j < nq) {
+      float M = fmaxf(fmaxf(wm[j], wm[kPRows + j]), fmaxf(wm[2 * kPRows + j], wm[3 * kPRows + j]));
+      float den = 0.0f;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float e = expf(wm[w * kPRows + j] - M);  // (a wave without frames: exp(-inf) = 0)
+        den = fmaf(wl[w * kPRows + j], e, den);
+        const float4 v = *reinterpret_cast<const float4*>(wacc + (w * kPRows + j) * 64 + c4);
+        o.x = fmaf(v.x, e, o.x);
+        o.y = fmaf(v.y, e, o.y);
+        o.z = fmaf(v.z, e, o.z);
+        o.w = fmaf(v.w, e, o.w);
+      }
+      float* op = a.ctx + ((size_t)u * a.beam + j) * d + h * 64 + c4;
+      sbk::st_agent(op, o.x / den);
+      sbk::st_agent(op + 1, o.y / den);
+      sbk::st_agent(op + 2, o.z / den);
+      sbk::st_agent(op + 3, o.w / den);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) decoder_step_persist_kernel(PStepArgs a) {
+  SBK_DYN_LDS(float, lds);
+  const int tid = threadIdx.x, wave = tid >> 6, G = gridDim.x;
+  const int d = a.d, Kmax = d > a.dffn ? d : a.dffn;
+  float* xs = lds;                                  // [16][K + 4] staged rows; the attention phases' scratch
+  float* red = lds + (size_t)kPRows * (Kmax + 4);   // [4][256] K-split partial tiles
+  int bar = a.bar_base;
+  WPref pf;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pf.w[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // barrier in two halves: the next projection's first weight loads are issued between arrival and wait
+#define SBK_PSTEP_BARRIER(W_, K_, N_)            \
+  do {                                           \
+    bar += G;                                    \
+    sbk::grid_arrive(a.bar);                     \
+    if ((W_) != nullptr) prefetch_w(pf, (W_), (K_), (N_)); \
+    sbk::grid_wait(a.bar, bar);                  \
+  } while (0)
+
+  // embedding + position (NormalizedEmbedding, PositionalEncoding): x = emb[tok] * scale + pe[pos]
+  for (int i = blockIdx.x; i < a.n; i += G) {
+    const float* e = a.emb + (size_t)a.tok[i] * d;
+    for (int c = tid; c < d; c += 256) sbk::st_agent(a.x + (size_t)i * d + c, e[c] * a.emb_scale + a.pe_row[c]);
+  }
+  SBK_PSTEP_BARRIER(a.L[0].sa_in_wf, d, 3 * d);
+  for (int l = 0; l < a.nl; ++l) {
+    const PLayer& L = a.L[l];
+    // norm1 + self-attention in_proj
+    stage_rows<true>(a, xs, a.x, d);
+    tiles_gemm(a, xs, red, d, L.sa_in_wf, L.sa_in_bf, nullptr, a.qkv, 3 * d, SBK_ACT_NONE, pf);
+    SBK_PSTEP_BARRIER(L.sa_out_w, d, d);
+    {  // self-attention over the KV cache: a wave per (row, head)
+      const int lpad = ((a.Lmax + 63) >> 6) << 6;
+      float* prob = xs + (size_t)wave * 2 * lpad;
+      int* slot = reinterpret_cast<int*>(prob + lpad);
+      for (int item = blockIdx.x * 4 + wave; item < a.n * a.H; item += G * 4) self_attn_item(a, L, prob, slot, item / a.H, item % a.H);
+    }
+    SBK_PSTEP_BARRIER((const float*)nullptr, 0, 0);
+    stage_rows<false>(a, xs, a.ctx, d);
+    tiles_gemm(a, xs, red, d, L.sa_out_w, L.sa_out_b, a.x, a.x, d, SBK_ACT_NONE, pf);
+    SBK_PSTEP_BARRIER(L.ca_q_wf, d, d);
+    // norm2 + the query rows of the cross-attention in_proj
+    stage_rows<true>(a, xs, a.x, d);
+    tiles_gemm(a, xs, red, d, L.ca_q_wf, L.ca_q_bf, nullptr, a.q, d, SBK_ACT_NONE, pf);
+    SBK_PSTEP_BARRIER(L.ca_out_w, d, d);
+    for (int it = blockIdx.x; it < a.B * a.H; it += G) cross_attn_item(a, L, xs, it / a.H, it % a.H);
+    SBK_PSTEP_BARRIER((const float*)nullptr, 0, 0);
+    stage_rows<false>(a, xs, a.ctx, d);
+    tiles_gemm(a, xs, red, d, L.ca_out_w, L.ca_out_b, a.x, a.x, d, SBK_ACT_NONE, pf);
+    SBK_PSTEP_BARRIER(L.ff1_wf, d, a.dffn);
+    // norm3 + the feed-forward pair
+    stage_rows<true>(a, xs, a.x, d);
+    tiles_gemm(a, xs, red, d, L.ff1_wf, L.ff1_bf, nullptr, a.ff, a.dffn, a.act, pf);
+    SBK_PSTEP_BARRIER(L.ff2_w, a.dffn, d);
+    stage_rows<false>(a, xs, a.ff, a.dffn);
+    tiles_gemm(a, xs, red, a.dffn, L.ff2_w, L.ff2_b, a.x, a.x, d, SBK_ACT_NONE, pf);
+    if (l + 1 < a.nl) {
+      SBK_PSTEP_BARRIER(a.L[l + 1].sa_in_wf, d, 3 * d);
+    } else if (a.want_logits) {
+      SBK_PSTEP_BARRIER(a.seq_wf, d, a.V);
+    } else {
+      SBK_PSTEP_BARRIER((const float*)nullptr, 0, 0);
+    }
+  }
+#undef SBK_PSTEP_BARRIER
+  // decoder.norm (+ seq_lin): every workgroup normalises the rows for its column tiles; workgroup 0 also writes h
+  stage_rows<true>(a, xs, a.x, d);
+  if (blockIdx.x == 0 && a.h) {
+    for (int idx = tid; idx < a.n * d; idx += 256) {
+      const int row = idx / d, c = idx - row * d;
+      a.h[idx] = xs[row * (d + 4) + c] * a.fin_g[c] + a.fin_b[c];
+    }
+  }
+  if (a.want_logits) tiles_gemm(a, xs, red, d, a.seq_wf, a.seq_bf, nullptr, a.logits, a.V, SBK_ACT_NONE, pf);
+}
+
+}  // namespace
+
+namespace sbk {
+
+int g_persist = 1;        // tuning knob (key 47): 0 = off; 1 = the persistent step for <= 16 hypothesis rows
+int g_persist_grid = 128; // tuning knob (key 48): workgroups of the cooperative launch (clamped to what the device holds)
+
+// grid barriers of one launch: 1 (embedding) + 8 per layer
+int persist_barriers(int n_layers) { return 1 + 8 * n_layers; }
+
+bool persist_eligible(const sbk_decoder_weights* W, int n, int B, int beam, int Lmax) {
+  if (!g_persist || n < 1 || n > kPRows || beam < 1 || beam > kPRows || B * beam != n) return false;
+  const int d = W->d_model;
+  if (W->n_layers < 1 || W->n_layers > kMaxPLayers || W->nhead < 1 || d != W->nhead * 64 || d % 64 != 0 || W->d_ffn % 64 != 0) return false;
+  if (!W->emb || !W->pe || !W->final_ln_g || !W->final_ln_b) return false;
+  if (W->seq_w && !(W->seq_wf && W->seq_bf && aligned16(W->seq_wf))) return false;
+  for (int l = 0; l < W->n_layers; ++l) {
+    const sbk_decoder_layer& L = W->layers[l];
+    if (!(L.sa_in_wf && L.sa_in_bf && L.ca_q_wf && L.ca_q_bf && L.ff1_wf && L.ff1_bf && L.sa_out_w && L.ca_out_w && L.ff2_w)) return false;
+    if (!(aligned16(L.sa_in_wf) && aligned16(L.ca_q_wf) && aligned16(L.ff1_wf) && aligned16(L.sa_out_w) && aligned16(L.ca_out_w) &&
+          aligned16(L.ff2_w)))
+      return false;
+  }
+  const size_t lpad = (size_t)((Lmax + 63) / 64) * 64;
+  return 8 * lpad * sizeof(float) <= 64 * 1024;
+}
+
+// One decoder step for n <= 16 hypothesis rows (n = B * beam) at position `step`: d.x .. d.logits as decoder_step leaves
+// them (the final LayerNorm output in h, the seq_lin logits when want_logits).  bar / bar_seq: the search's barrier counter
+// (zero when the search starts) and the number of persistent launches issued on it so far.
+int decoder_step_persist(const sbk_decoder_weights* W, const int32_t* tokens, const int32_t* kv_slot, const int32_t* enc_len,
+                         float* x, float* qkv, float* ctx, float* q, float* ff, float* h, float* logits, float* const* kcache,
+                         float* const* vcache, float* const* ckv, int* bar, int bar_seq, int step, int n, int B, int T, int beam,
+                         int Lmax, bool want_logits, hipStream_t st) {
+  PStepArgs a;
+  const int d = W->d_model;
+  for (int l = 0; l < W->n_layers; ++l) {
+    const sbk_decoder_layer& L = W->layers[l];
+    a.L[l] = PLayer{L.sa_in_wf, L.sa_in_bf, L.sa_out_w, L.sa_out_b, L.ca_q_wf, L.ca_q_bf, L.ca_out_w, L.ca_out_b,
+                    L.ff1_wf, L.ff1_bf, L.ff2_w, L.ff2_b, kcache[l], vcache[l], ckv[l]};
+  }
+  a.tok = tokens; a.kv_slot = kv_slot; a.enc_len = enc_len;
+  a.emb = W->emb; a.pe_row = W->pe + (size_t)step * d;
+  a.x = x; a.qkv = qkv; a.ctx = ctx; a.q = q; a.ff = ff; a.h = h; a.logits = logits;
+  a.fin_g = W->final_ln_g; a.fin_b = W->final_ln_b; a.seq_wf = W->seq_wf; a.seq_bf = W->seq_bf;
+  a.bar = bar;
+  a.n = n; a.B = B; a.T = T; a.beam = beam; a.d = d; a.H = W->nhead; a.dffn = W->d_ffn; a.V = W->vocab; a.nl = W->n_layers;
+  a.step = step; a.Lmax = Lmax; a.act = W->ffn_act; a.want_logits = want_logits && W->seq_wf ? 1 : 0;
+  a.eps = W->ln_eps; a.emb_scale = W->emb_scale > 0.0f ? W->emb_scale : sqrtf((float)d);
+  a.attn_scale = 1.0f / sqrtf(64.0f);
+  const int Kmax = d > W->d_ffn ? d : W->d_ffn;
+  size_t region = (size_t)kPRows * (Kmax + 4);
+  const size_t attn = 1024 + 128 + (size_t)4 * kPRows * 64, self = (size_t)8 * (((Lmax + 63) / 64) * 64);
+  if (region < attn) region = attn;
+  if (region < self) region = self;
+  // (the region is sized for the rows AND the attention scratch; red follows the rows' extent)
+  const size_t lds = (region + 1024 + 64) * sizeof(float);
+  if (lds > 160 * 1024 - 512) return -1;
+  static bool allowed = false;
+  if (!allowed) {
+    if (SBK_ALLOW_DYN_LDS(decoder_step_persist_kernel, 160 * 1024 - 512) != hipSuccess) return -1;
+    allowed = true;
+  }
+  int maxg = 0;
+  if (SBK_COOP_MAX_GRID(decoder_step_persist_kernel, 256, lds, maxg) != hipSuccess || maxg < 1) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  int G = g_persist_grid < 1 ? 1 : g_persist_grid;
+  if (G > maxg) G = maxg;
+  a.bar_base = bar_seq * persist_barriers(W->n_layers) * G;
+  ProfScope prof("decoder_step_persist", 2.0 * n * (double)(W->n_layers * (4.0 * d * d + 2.0 * d * W->d_ffn) + (want_logits ? (double)d * W->vocab : 0.0)),
+                 4.0 * (W->n_layers * (4.0 * d * d + 2.0 * d * W->d_ffn) + (want_logits ? (double)d * W->vocab : 0.0)), st);
+  const hipError_t e = SBK_LAUNCH_COOP(decoder_step_persist_kernel, dim3(G), dim3(256), lds, st, a);
+  if (e != hipSuccess) return fail((int)e, "decoder_step_persist: cooperative launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace sbk

@@ -211,6 +211,38 @@ __device__ __forceinline__ int atomic_load_agent(const int* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- data handed from one workgroup to another INSIDE a launch (the persistent few-row decoding step, csrc/decoder_persist.hip).
+// An MI355X has eight XCDs with private, mutually non-coherent L2s: a plain store may sit in the writer's L2 and a plain load
+// may hit a stale line of the reader's.  Agent-scope relaxed atomics compile to sc1 accesses that are served at the
+// device-coherent level, so no L2 write-back / invalidate (buffer_wbl2 / buffer_inv: 2-10 us per barrier on this part,
+// tools/persist_probe.hip) is ever needed for such data; a writer only has to drain its own stores (vm_drain) before it
+// signals.  Checked on the box: 0 mismatches over 500 rounds of all-to-all hand-over (profiles/r05_a_*).
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ float2 ld_agent2(const float* p) {  // 8-byte aligned
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__builtin_bit_cast(float, (unsigned)(u & 0xffffffffull)), __builtin_bit_cast(float, (unsigned)(u >> 32)));
+}
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Barrier among the G co-resident workgroups of a cooperative launch: `ctr` counts arrivals monotonically (the caller passes
+// the value it must reach); every lane first drains its own sc1 stores, one ticket per workgroup.  1.3 us at G = 64, 2.0 at 128.
+// In two halves, so that loads which do not depend on the other workgroups (the next projection's weights) can be issued
+// between the arrival and the wait and fly while the barrier completes.
+__device__ __forceinline__ void grid_arrive(int* ctr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void grid_wait(int* ctr, int target) {
+  if (threadIdx.x == 0) {
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+
 // Products / sums / differences that the compiler must NOT contract into a fused multiply-add with a neighbouring
 // operation: two kernels that are required to produce bit-identical values (the fused scoring pass and the launches it
 // replaces) write the shared arithmetic with these, so the result does not depend on what each kernel's optimiser fuses.
@@ -283,6 +315,17 @@ __device__ __forceinline__ float wave_max(float v) {
 // Raise a kernel's dynamic-LDS window above the 64 KiB default (gfx950 has 160 KiB per CU).
 #define SBK_ALLOW_DYN_LDS(kernel, bytes) \
   hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+
+// Cooperative launch (every workgroup resident at once: the kernel may use sbk::grid_barrier): ONE by-value argument struct;
+// evaluates to the hipError_t of the launch.  SBK_COOP_MAX_GRID: the largest grid the device can hold for this kernel.
+#define SBK_LAUNCH_COOP(kernel, grid, block, lds_bytes, stream, arg_struct) \
+  ([&]() -> hipError_t { void* p__[] = {(void*)&(arg_struct)};               \
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&kernel), grid, block, p__, lds_bytes, stream); }())
+#define SBK_COOP_MAX_GRID(kernel, block_threads, lds_bytes, out_int)                                                   \
+  ([&]() -> hipError_t { int dev__ = 0, cus__ = 0, per__ = 0; hipError_t e__ = hipGetDevice(&dev__);                    \
+    if (e__ == hipSuccess) e__ = hipDeviceGetAttribute(&cus__, hipDeviceAttributeMultiprocessorCount, dev__);         \
+    if (e__ == hipSuccess) e__ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per__, kernel, block_threads, lds_bytes); \
+    (out_int) = cus__ * per__; return e__; }())
 
 // kernel<<<grid, block, lds_bytes, stream>>>(args...)
 #define SBK_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \

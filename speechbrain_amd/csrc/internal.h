@@ -31,6 +31,16 @@ int gemm_ln_nt_x3r(const float* A, int lda, const float2* stats_in, const uint16
 bool x3r_ln_routed(int K);
 extern int g_x3r_mode, g_x3r_min_rows, g_x3r_vocab, g_x3r_apanel, g_x3r_ln;
 extern int g_relpos_x3;  // key 46 (csrc/relpos_attn.hip)
+// The decoding step of <= 16 hypothesis rows as ONE cooperative launch (csrc/decoder_persist.hip; keys 47 / 48).
+// persist_eligible: shapes / weights it takes (head_dim 64, folded LayerNorm weights present, <= 16 layers); decoder_step_persist
+// returns -1 when the launch cannot be made (the caller then issues the launch-per-operation step).
+bool persist_eligible(const sbk_decoder_weights* W, int n, int B, int beam, int Lmax);
+int persist_barriers(int n_layers);
+int decoder_step_persist(const sbk_decoder_weights* W, const int32_t* tokens, const int32_t* kv_slot, const int32_t* enc_len,
+                         float* x, float* qkv, float* ctx, float* q, float* ff, float* h, float* logits, float* const* kcache,
+                         float* const* vcache, float* const* ckv, int* bar, int bar_seq, int step, int n, int B, int T, int beam,
+                         int Lmax, bool want_logits, hipStream_t st);
+extern int g_persist, g_persist_grid;
 // Device-resident step counter of the search running on this host thread (nullptr: the step is the
 // launch argument).  When set, every step-dependent kernel reads the step from it, so that the launches
 // of one decoding step are identical for every step and can be replayed from a captured hipGraph.

@@ -948,6 +948,8 @@ struct DecoderBufs {
   float* xpart;         // cross-attention split partials
   int32_t* xcnt;        // [B] arrival tickets of the cross-attention runs (zeroed by project_memory, re-armed by the kernel)
   float* kvtmp;         // [B,T,2d] projection output before the head-major re-layout
+  int32_t* pbar;        // arrival counter of the persistent few-row step's grid barriers (zeroed by project_memory)
+  mutable int pseq;     // persistent launches issued on it since
   int head_major;       // layout of ckv[l]: 1 = [B,H,T,2*Dh], 0 = [B,T,2d]
   float* ckv[64];
   float *kcache[64], *vcache[64];
@@ -971,6 +973,8 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
   d.splitk = c.take<float>(d.splitk_floats);
   d.xpart = c.take<float>(sbk::cross_attn_partial_floats(B, T, W->nhead, dm / W->nhead, n / (B > 0 ? B : 1)) + 64);
   d.xcnt = c.take<int32_t>((size_t)B + 16);
+  d.pbar = c.take<int32_t>(64);
+  d.pseq = 0;
   d.head_major = sbk::g_kv_head_major && (dm / W->nhead) % 4 == 0;
   d.kvtmp = c.take<float>((size_t)B * T * 2 * dm);
   for (int l = 0; l < W->n_layers; ++l) {
@@ -997,6 +1001,8 @@ int project_memory(const sbk_decoder_weights* W, const DecoderBufs& d, const flo
                    hipStream_t st) {
   const int dm = W->d_model;
   SBK_HIP(hipMemsetAsync(d.xcnt, 0, ((size_t)B + 16) * sizeof(int32_t), st));  // (once per search: the kernels leave the tickets at zero)
+  SBK_HIP(hipMemsetAsync(d.pbar, 0, 64 * sizeof(int32_t), st));
+  d.pseq = 0;
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
     float* dst = d.head_major ? d.kvtmp : d.ckv[l];
@@ -1019,6 +1025,16 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
                  const int32_t* enc_len, int step, int n, int B, int T, int beam, int Lmax, bool want_logits,
                  hipStream_t st) {
   const int dm = W->d_model, H = W->nhead;
+  // a beam's worth of rows (<= 16): the whole stack of the step as ONE cooperative launch (csrc/decoder_persist.hip)
+  if (!d.head_major && !sbk::g_step_ptr && sbk::persist_eligible(W, n, B, beam, Lmax)) {
+    const int rc = sbk::decoder_step_persist(W, tokens, kv_slot, enc_len, d.x, d.qkv, d.ctx, d.q, d.ff, d.h, d.logits, d.kcache,
+                                             d.vcache, d.ckv, d.pbar, d.pseq, step, n, B, T, beam, Lmax, want_logits, st);
+    if (rc == 0) {
+      ++d.pseq;
+      return 0;
+    }
+    if (rc != -1) return rc;
+  }
   const float emb_scale = W->emb_scale > 0.0f ? W->emb_scale : sqrtf((float)dm);  // NormalizedEmbedding: sqrt(d_model)
   const bool apan = sbk::g_x3r_apanel && dm % 16 == 0 && dm <= 2048 && W->d_ffn % 16 == 0;
   // knob 45 = 3: every LayerNorm of the step takes its row statistics from the kernel that wrote the residual stream
@@ -1581,6 +1597,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   // into a hipGraph and replayed; 2: the same device-side step counter with plain launches (tests, fallback).
   int graph_mode = cfg->graph_mode;
   if (graph_mode && (side || sbk::prof_enabled() || T > 900 || cfg->max_steps < 2 || pos_off > 0 || cfg->first_bias || window > 0)) graph_mode = 0;
+  if (graph_mode && !d.head_major && sbk::persist_eligible(W, n, B, beam, Lmax)) graph_mode = 0;  // (a cooperative launch is not captured)
   if (graph_mode) {
     struct Scope {  // the step source is per host thread; never leave it set
       ~Scope() {

@@ -160,6 +160,7 @@ def test_conformer_l_decoder_logprobs_and_search_vs_oracle():
     # kernel the headline's decode loop spends its time in, inside the oracle comparison at Conformer-L size
     lib = native.load()
     lib.sbk_prof_set_knob(42, 1)
+    lib.sbk_prof_set_knob(47, 0)  # (the 2-row prefix above ran as the persistent few-row step, csrc/decoder_persist.hip; here the x3r route is wanted)
     try:
         assert h.layers[0].sa_in_wp and h.layers[0].ff2_wp and h.W.seq_wp
         pred3 = native.decoder_prefix(h, tgt.int().cuda(), enc_ref.cuda(), enc_lens.cuda())
@@ -171,6 +172,7 @@ def test_conformer_l_decoder_logprobs_and_search_vs_oracle():
         assert float((scores3.cpu() - scores_ref).abs().max()) <= 1e-3
     finally:
         lib.sbk_prof_set_knob(42, 192)
+        lib.sbk_prof_set_knob(47, 1)
 
 
 def test_recipe_lm_scorer_search_vs_oracle():

@@ -247,6 +247,104 @@ def test_decoder_with_fused_layernorm_vs_oracle(backend):
     assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
 
 
+def _persist_model(dev, d_model, nhead, d_ffn, n_dec, vocab, seed):
+    from speechbrain_amd.inference.builders import build_modules
+
+    m = build_modules(dict(d_model=d_model, nhead=nhead, d_ffn=d_ffn, n_enc=1, n_dec=n_dec, n_fft=512, win_length=32), vocab=vocab, seed=seed)
+    mods = torch.nn.ModuleDict({k: m[k] for k in ("CNN", "Transformer", "seq_lin", "ctc_lin")})
+    gen = torch.Generator().manual_seed(seed + 12)
+    with torch.no_grad():
+        for name, p in mods.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+        mods["seq_lin"].w.weight.mul_(4.0)
+        mods["ctc_lin"].w.weight.mul_(4.0)
+    sd = {k: v.detach().clone() for k, v in mods.state_dict().items()}
+    cfg = O.ModelCfg(d_model=d_model, nhead=nhead, num_encoder_layers=1, num_decoder_layers=n_dec, d_ffn=d_ffn, vocab=vocab)
+    return mods.to(dev).eval(), sd, cfg, gen
+
+
+@pytest.mark.parametrize("shape", ["d128", "d512"])
+def test_persistent_few_row_decoding_step_vs_oracle_and_the_launch_per_operation_path(backend, shape):
+    """csrc/decoder_persist.hip: the decoder stack of a step with <= 16 hypothesis rows (one utterance's beam -- the
+    single-utterance latency regime) as ONE cooperative launch with grid barriers between sub-layers and agent-scope
+    hand-over of the activations.  Against the oracle: teacher-forced decoder outputs 5e-5 (3 rows, beam 1), beam search
+    with CTC for one utterance at beam 10 and beam 16 (the full 16-row tile) and three utterances at beam 4 (12 rows, ragged
+    memory lengths), a 300-frame memory (several 256-frame runs per wave in the cross-attention), the greedy searcher --
+    token ids exact, scores 1e-4; and against the launch-per-operation path of the same library (knob 47 = 0): ids equal,
+    scores 2e-5.  The profiler's launch names show which path ran; with another grid (knob 48) the result is the same."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, S2STransformerGreedySearcher, ScorerBuilder
+
+    dm, H, dffn = (128, 2, 256) if shape == "d128" else (512, 8, 2048)
+    mods, sd, cfg, gen = _persist_model(dev, dm, H, dffn, 2, 60, 7 if shape == "d128" else 9)
+    lib = nat.load()
+
+    def searcher(beam, ratio, ctc=0.4):
+        scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)], weights={"ctc": ctc})
+        return S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=0.0,
+                                          max_decode_ratio=ratio, beam_size=beam, using_eos_threshold=False,
+                                          length_normalization=True, scorer=scorer)
+
+    def run(fn):
+        nat.prof_reset()
+        nat.prof_enable(True)
+        try:
+            out = fn()
+        finally:
+            nat.prof_enable(False)
+        return out, nat.prof_report()
+
+    try:
+        enc = torch.randn(3, 30, dm, generator=gen)
+        wl = torch.tensor([1.0, 0.7, 0.9])
+        enc_len = torch.round(30 * wl).int()
+        tgt = torch.randint(0, 60, (3, 6), generator=gen)
+        h = nat.DecoderHandle(mods["Transformer"], mods["seq_lin"])
+        pred, rep = run(lambda: nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev)))
+        assert rep.get("decoder_step_persist", {}).get("count", 0) == tgt.shape[1] and "self_attn_step" not in rep, sorted(rep)
+        assert float((pred.cpu() - O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")).abs().max()) <= 5e-5
+        cases = [("one utterance, beam 10", enc[:1], wl[:1], 10, 8.5 / 30), ("three utterances, beam 4", enc, wl, 4, 8.5 / 30)]
+        if shape == "d128":
+            long_enc = torch.randn(1, 300, dm, generator=gen)
+            cases += [("one utterance, beam 16", enc[1:2], torch.ones(1), 16, 6.5 / 30),
+                      ("300-frame memory", long_enc, torch.tensor([0.93]), 10, 6.5 / 300)]
+        for tag, e, w, beam, ratio in cases:
+            ref_h, _, ref_s, _ = O.beam_search(e, w, sd, cfg, O.SearchCfg(beam=beam, ctc_weight=0.4, max_decode_ratio=ratio))
+            bs = searcher(beam, ratio)
+            (hyps, _, sc, _), rep = run(lambda: bs(e.to(dev), w.to(dev)))
+            assert rep.get("decoder_step_persist", {}).get("count", 0) >= 1 and "cross_attn_step" not in rep and "gemm_skinny_ln" not in rep, (tag, sorted(rep))
+            assert hyps == ref_h, tag
+            assert float((sc.cpu() - ref_s).abs().max()) <= 1e-4, tag
+            lib.sbk_prof_set_knob(47, 0)
+            try:
+                (hyps0, _, sc0, _), rep0 = run(lambda: bs(e.to(dev), w.to(dev)))
+            finally:
+                lib.sbk_prof_set_knob(47, 1)
+            assert "decoder_step_persist" not in rep0 and "self_attn_step" in rep0, (tag, sorted(rep0))
+            assert hyps0 == hyps and float((sc0 - sc).abs().max()) <= 2e-5, tag
+        # another grid: fewer workgroups than column tiles / attention items (every loop over tiles and items runs more than once)
+        e, w = enc[:1], wl[:1]
+        bs = searcher(10, 8.5 / 30)
+        base = bs(e.to(dev), w.to(dev))
+        for grid in (3, 1000):
+            lib.sbk_prof_set_knob(48, grid)
+            try:
+                got = bs(e.to(dev), w.to(dev))
+            finally:
+                lib.sbk_prof_set_knob(48, 128)
+            assert got[0] == base[0] and torch.equal(got[2], base[2]), grid  # (the arithmetic does not depend on the grid)
+        gs = S2STransformerGreedySearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=0.0,
+                                          max_decode_ratio=8.5 / 30)
+        (g_h, _, g_s, _), rep = run(lambda: gs(enc.to(dev), wl.to(dev)))
+        assert rep.get("decoder_step_persist", {}).get("count", 0) >= 1, sorted(rep)
+        ref_g = O.greedy_search(enc, wl, sd, cfg, O.SearchCfg(beam=1, max_decode_ratio=8.5 / 30))
+        assert g_h == ref_g[0]
+    finally:
+        lib.sbk_prof_set_knob(47, 1)
+        lib.sbk_prof_set_knob(48, 128)
+
+
 @pytest.mark.parametrize("mode,ln", [(1, 1), (0, 1), (0, 3), (0, 0)])
 def test_decoder_on_the_x3r_route_vs_oracle(backend, mode, ln):
     """The decode step's projections as sbk_gemm_nt_x3r (csrc/gemm.hip: gemm_x3r_kernel -- fp32 results on the bf16
@@ -283,6 +381,7 @@ def test_decoder_on_the_x3r_route_vs_oracle(backend, mode, ln):
     lib.sbk_prof_set_knob(44, mode)
     lib.sbk_prof_set_knob(45, ln)
     lib.sbk_prof_set_knob(42, 1)
+    lib.sbk_prof_set_knob(47, 0)  # (12 rows: without it the step would be the persistent few-row launch, csrc/decoder_persist.hip)
     try:
         h = nat.DecoderHandle(mods["Transformer"], mods["seq_lin"])
         assert h.layers[0].sa_in_wp and h.layers[0].ff2_wp and h.W.seq_wp  # the panel images exist for these widths
@@ -336,6 +435,7 @@ def test_decoder_on_the_x3r_route_vs_oracle(backend, mode, ln):
         lib.sbk_prof_set_knob(44, 0)
         lib.sbk_prof_set_knob(45, 1)
         lib.sbk_prof_set_knob(42, 192)
+        lib.sbk_prof_set_knob(47, 1)
 
 
 def test_encoder_with_relpos_attention_on_split_operands_vs_oracle(backend, monkeypatch):
@@ -907,7 +1007,8 @@ def test_bf16_precision_is_opt_in_and_close(backend):
     assert float((e32 - e16f).abs().max()) <= 5e-2 and float((e16 - e16f).abs().max()) <= 2e-2
     with pytest.raises(NotImplementedError):
         build_asr(tiny, vocab=30, seed=2, device=str(dev)).__class__(modules=dict(a32.mods), hparams={"tokenizer": None},
-                                                                     run_opts={"device": str(dev), "precision": "fp8"})
+                                                                     run_opts={"device": str(dev), "precision": "int4"})
+    # (fp16 / fp8 are accepted since round 5: inference/interfaces.py, tests/test_whisper.py)
 
 
 @pytest.mark.parametrize("variant", [3, 4])

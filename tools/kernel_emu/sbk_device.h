@@ -94,6 +94,9 @@ void wave_barrier();
 float* wave_buf(int which);  // 64-float exchange buffers of the current wave (which = 0,1)
 void* dyn_lds();
 void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds_bytes);
+// every workgroup of the grid on an OS thread of its own, all running at once (a cooperative launch: grid barriers work)
+void launch_coop(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds_bytes);
+void grid_barrier_wait(int* ctr, int target);
 }  // namespace sbk_emu
 
 #define threadIdx (sbk_emu::cur().tid)
@@ -402,6 +405,20 @@ static inline void acquire_agent() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
 static inline int atomic_add_agent(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 static inline void atomic_store_agent(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 static inline int atomic_load_agent(const int* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+static inline float ld_agent(const float* p) { unsigned u = __atomic_load_n(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED); float f; memcpy(&f, &u, 4); return f; }
+static inline float2 ld_agent2(const float* p) { return float2{ld_agent(p), ld_agent(p + 1)}; }
+static inline void st_agent(float* p, float v) { unsigned u; memcpy(&u, &v, 4); __atomic_store_n(reinterpret_cast<unsigned*>(p), u, __ATOMIC_RELAXED); }
+static inline void grid_arrive(int* ctr) {  // (every fiber calls it; fiber 0 of the workgroup takes the ticket)
+  sbk_emu::block_barrier();
+  if (sbk_emu::cur().lin == 0) {
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    __atomic_fetch_add(ctr, 1, __ATOMIC_SEQ_CST);
+  }
+}
+static inline void grid_wait(int* ctr, int target) {
+  if (sbk_emu::cur().lin == 0) sbk_emu::grid_barrier_wait(ctr, target);
+  sbk_emu::block_barrier();
+}
 static inline float mul_rn(float a, float b) { return a * b; }  // (g++ on x86-64 does not contract without -mfma)
 static inline float add_rn(float a, float b) { return a + b; }
 static inline float sub_rn(float a, float b) { return a - b; }
@@ -429,3 +446,6 @@ static inline float wave_max(float v) {
 #define SBK_ALLOW_DYN_LDS(kernel, bytes) ((void)(bytes), 0)
 #define SBK_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \
   sbk_emu::launch([=]() { kernel(__VA_ARGS__); }, grid, block, lds_bytes)
+#define SBK_LAUNCH_COOP(kernel, grid, block, lds_bytes, stream, arg_struct) \
+  (sbk_emu::launch_coop([=]() { kernel(arg_struct); }, grid, block, lds_bytes), 0)
+#define SBK_COOP_MAX_GRID(kernel, block_threads, lds_bytes, out_int) ((out_int) = 6, 0)

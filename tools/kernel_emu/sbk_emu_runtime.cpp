@@ -276,4 +276,30 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds
   pool->run(body, grid, block, lds_bytes, nblocks, nworkers);
 }
 
+// A cooperative launch: one OS thread per workgroup, all alive together, so that a workgroup may wait for the others.
+void launch_coop(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds_bytes) {
+  const long nblocks = (long)grid.x * grid.y * grid.z;
+  const int nthreads_blk = block.x * block.y * block.z;
+  if (nblocks <= 0 || nthreads_blk <= 0) return;
+  if (nthreads_blk > kMaxThreads || nblocks > 64) {
+    fprintf(stderr, "sbk_emu: cooperative launch of %ld blocks x %d threads\n", nblocks, nthreads_blk);
+    abort();
+  }
+  std::vector<std::thread> ts;
+  for (long b = 0; b < nblocks; ++b) {
+    ts.emplace_back([&, b] {
+      BlockRun* run = new BlockRun();  // (not the pool's thread_local: this thread dies with the launch)
+      dim3 bid(b % grid.x, (b / grid.x) % grid.y, b / ((long)grid.x * grid.y));
+      run_block(*run, bid, grid, block, body, lds_bytes);
+      delete run;
+    });
+  }
+  for (auto& t : ts) t.join();
+}
+
+void grid_barrier_wait(int* ctr, int target) {
+  while (__atomic_load_n(ctr, __ATOMIC_SEQ_CST) - target < 0) std::this_thread::yield();
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+}
+
 }  // namespace sbk_emu
