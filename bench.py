@@ -693,19 +693,28 @@ def main():
         lat_stream = torch.cuda.Stream(dev)  # (the legacy default stream cannot be captured into a graph)
         dec = asr.mods.decoder
         saved = (dec.overlap_ctc, dec.graph_mode)
-        # two ways to run a single search: CTC scorer on a helper stream beside the decoder step, or the
-        # decoding steps replayed from a captured hipGraph (device-side step counter); report the better one
-        for mode, (ov, gm) in (("helper_stream", (3, 0)), ("hipgraph", (0, 1))):
+        # ways to run a single search.  Round 5 (the default): the decoder stack of a step as ONE cooperative launch
+        # (csrc/decoder_persist.hip, knob 47), alone or with the CTC scorer on a helper stream beside it; before: a launch
+        # per operation with the CTC scorer on a helper stream, or replayed from a captured hipGraph.  Report the best
+        from speechbrain_amd import native as _nat
+
+        lib = _nat.load()
+        for mode, (ov, gm, persist) in (("persistent_step", (0, 0, 1)), ("persistent_step_helper_stream", (3, 0, 1)),
+                                        ("helper_stream", (3, 0, 0)), ("hipgraph", (0, 1, 0))):
             dec.overlap_ctc, dec.graph_mode = ov, gm
+            lib.sbk_prof_set_knob(47, persist)
             lat = []
-            with torch.cuda.stream(lat_stream):
-                run_step(asr, w1, l1)
-                for _ in range(args.latency_runs):
-                    torch.cuda.synchronize()
-                    t = time.perf_counter()
+            try:
+                with torch.cuda.stream(lat_stream):
                     run_step(asr, w1, l1)
-                    torch.cuda.synchronize()
-                    lat.append(time.perf_counter() - t)
+                    for _ in range(args.latency_runs):
+                        torch.cuda.synchronize()
+                        t = time.perf_counter()
+                        run_step(asr, w1, l1)
+                        torch.cuda.synchronize()
+                        lat.append(time.perf_counter() - t)
+            finally:
+                lib.sbk_prof_set_knob(47, 1)
             lat.sort()
             by_mode[mode] = round(1000.0 * lat[len(lat) // 2], 2)
         dec.overlap_ctc, dec.graph_mode = saved

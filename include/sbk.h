@@ -340,15 +340,6 @@ int sbk_conv_block_f32(const float* x, const float* wt, const float* bias, const
 int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                              const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh,
                              float scale, int chunk_size, int left_chunks, sbk_stream_t stream);
-/* ABI 9: the same context (no attention-weights output; head_dim 64) with the three products of a tile -- Q K^T, the
- * position term, P V -- on the bf16 matrix pipe by the exact three-way operand split of sbk_gemm_nt_f32x3 (fp32 accumulation,
- * fp32-grade results: the tolerances of sbk_relpos_attention_f32 hold).  Keys, values (transposed) and the position rows
- * are split once per call into bf16 piece images in `workspace` (>= sbk_relpos_x3_workspace_bytes(B, T, H) bytes, 16-byte
- * aligned, caller-owned; the library allocates nothing); queries and probabilities are split in registers. */
-size_t sbk_relpos_x3_workspace_bytes(int B, int T, int H);
-int sbk_relpos_attention_x3_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
-                                const int32_t* key_len, float* out, void* workspace, size_t workspace_bytes, int B, int T, int H,
-                                int Dh, float scale, int chunk_size, int left_chunks, sbk_stream_t stream);
 
 /* ---- RoPEMHA core (nnet/attention.py:1167-1392): what sits between in_proj and out_proj.
  *   out = softmax( rot(q) rot(k)^T scale , keys < key_len ) v,  scale = 1/sqrt(embed_dim) (:1272)

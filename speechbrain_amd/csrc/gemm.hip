@@ -2818,7 +2818,6 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 43) sbk::g_x3r_vocab = value;
   if (key == 44) sbk::g_x3r_apanel = value;
   if (key == 45) sbk::g_x3r_ln = value;
-  if (key == 46) sbk::g_relpos_x3 = value;
   if (key == 47) sbk::g_persist = value;
   if (key == 48) sbk::g_persist_grid = value;
   if (key == 36) sbk::g_splitk_fused = value;

@@ -30,7 +30,6 @@ int gemm_ln_nt_x3r(const float* A, int lda, const float2* stats_in, const uint16
                    float* C, int ldc, uint16_t* PC, int M, int N, int K, float eps, int act, float alpha, hipStream_t st);
 bool x3r_ln_routed(int K);
 extern int g_x3r_mode, g_x3r_min_rows, g_x3r_vocab, g_x3r_apanel, g_x3r_ln;
-extern int g_relpos_x3;  // key 46 (csrc/relpos_attn.hip)
 // The decoding step of <= 16 hypothesis rows as ONE cooperative launch (csrc/decoder_persist.hip; keys 47 / 48).
 // persist_eligible: shapes / weights it takes (head_dim 64, folded LayerNorm weights present, <= 16 layers); decoder_step_persist
 // returns -1 when the launch cannot be made (the caller then issues the launch-per-operation step).
@@ -64,8 +63,10 @@ __device__ __forceinline__ float ls_logit(float x, float b1, float b2, float inv
   return mul_rn(add_rn(add_rn(x, b1), b2), inv_temp);
 }
 __device__ __forceinline__ float ls_out(float v, float lse, float w) { return mul_rn(w, sub_rn(v, lse)); }  // w * log-softmax
-__device__ __forceinline__ float score_ctc(float v, float psi, float psi_prev, float weight) {  // scorer.py:1248-1253
-  return fmaf(sub_rn(psi, psi_prev), weight, v);
+// log_probs += score * weight with score = psi - psi_prev (scorer.py:1248-1253, ctc.py:259-262): the reference rounds the
+// difference, the product and the sum separately (three torch operations), so no fused multiply-add here
+__device__ __forceinline__ float score_ctc(float v, float psi, float psi_prev, float weight) {
+  return add_rn(v, mul_rn(sub_rn(psi, psi_prev), weight));
 }
 __device__ __forceinline__ float score_cand(float seq, float comb, float norm) {  // seq2seq.py:1225-1240
   const float x = add_rn(seq, comb);

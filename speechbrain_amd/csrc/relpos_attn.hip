@@ -878,254 +878,6 @@ __global__ void __launch_bounds__(256, 2) rope_flash_t_bf16_kernel(AttnArgs a) {
   }
 }
 
-// ---- RelPosMHAXL on the bf16 matrix pipe with fp32-grade results (head_dim 64; sbk_relpos_attention_x3_f32) ----------------
-// relpos_flash_t_kernel spends its matrix time on v_mfma_f32_32x32x2_f32 (96 instructions of 16 passes per 32 x 32 tile:
-// QK^T, the position term, P V) and runs at about half of that pipe's peak.  The same three products with every operand cut
-// into its three bf16 pieces (x = hi + mid + lo exactly; the six partial products of relative size >= 2^-17, smallest first,
-// fp32 accumulation: the arithmetic of sbk_gemm_nt_f32x3 / _x3p) are 72 instructions of 8 passes.  Keys, values and the
-// position table are split ONCE per layer into piece images (every query tile of a head would otherwise split the same
-// rows again, T / 32 times over):
-//   K3   [(b, h)][T][3 pieces][64 channels]            a lane's MFMA operand = 16 bytes (8 consecutive channels of its key row)
-//   P3   [h][2T-1][3][64]                              the same for the rows of linear_pos(RelPosEncXL table)
-//   V3T  [(b, h)][3][64 channels][Tp keys]             transposed, zero padded to Tp = T rounded up to 32: the 8 keys of a
-//        context-update step are two runs of four consecutive keys (8 bytes each) in the accumulator's key order
-// in a workspace the CALLER provides (sbk_relpos_x3_workspace_bytes).  The queries ((q + u) s, (q + v) s) are split in
-// registers once per wave; the probabilities per tile.  Everything else -- transposed scores, lane-local softmax
-// statistics, the G^T ring through LDS for the relative shift -- is relpos_flash_t_kernel's walk.
-constexpr int kX3Pa[6] = {2, 0, 1, 1, 0, 0}, kX3Pb[6] = {0, 2, 1, 0, 1, 0};
-
-// 8 floats -> their three bf16 piece vectors
-__device__ __forceinline__ void split3_x8(const float (&x)[8], sbk::bf16x8 (&out)[3]) {
-  unsigned h[4], m[4], l[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    h[p] = sbk::bf16_pair(x[2 * p], x[2 * p + 1]);
-    const float r0 = x[2 * p] - __uint_as_float(h[p] << 16), r1 = x[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
-    m[p] = sbk::bf16_pair(r0, r1);
-    l[p] = sbk::bf16_pair(r0 - __uint_as_float(m[p] << 16), r1 - __uint_as_float(m[p] & 0xffff0000u));
-  }
-  out[0] = sbk::bf16x8_from_words(h[0], h[1], h[2], h[3]);
-  out[1] = sbk::bf16x8_from_words(m[0], m[1], m[2], m[3]);
-  out[2] = sbk::bf16x8_from_words(l[0], l[1], l[2], l[3]);
-}
-
-// rows of 64 channels -> [row][3][64] bf16 pieces.  src element (o, r, c) at src + (o / inner) * s1 + (o % inner) * s2 +
-// r * row_stride + c; dst row index o * rows + r.  One thread = four channels of a row.
-__global__ void __launch_bounds__(256) split_rows64_x3_kernel(const float* __restrict__ src, int inner, size_t s1, size_t s2,
-                                                              size_t row_stride, uint2* __restrict__ dst, int rows, long total4) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
-    const int c4 = (int)(i & 15);
-    const long rr = i >> 4;
-    const long o = rr / rows, r = rr - o * rows;
-    const float4 v = *reinterpret_cast<const float4*>(src + (o / inner) * s1 + (o % inner) * s2 + r * row_stride + 4 * c4);
-    const unsigned h0 = sbk::bf16_pair(v.x, v.y), h1 = sbk::bf16_pair(v.z, v.w);
-    const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xffff0000u);
-    const float r2 = v.z - __uint_as_float(h1 << 16), r3 = v.w - __uint_as_float(h1 & 0xffff0000u);
-    const unsigned m0 = sbk::bf16_pair(r0, r1), m1 = sbk::bf16_pair(r2, r3);
-    const unsigned l0 = sbk::bf16_pair(r0 - __uint_as_float(m0 << 16), r1 - __uint_as_float(m0 & 0xffff0000u));
-    const unsigned l1 = sbk::bf16_pair(r2 - __uint_as_float(m1 << 16), r3 - __uint_as_float(m1 & 0xffff0000u));
-    uint2* d = dst + (size_t)rr * 48 + c4;  // 3 pieces x 16 quads per row
-    d[0] = make_uint2(h0, h1);
-    d[16] = make_uint2(m0, m1);
-    d[32] = make_uint2(l0, l1);
-  }
-}
-
-// values [B,T,H,(q|k|v)] -> V3T [(b, h)][3][64][Tp]: a workgroup transposes 64 keys x 64 channels through LDS
-__global__ void __launch_bounds__(256) split_vt_x3_kernel(const float* __restrict__ qkv, uint2* __restrict__ dst, int T, int Tp, int H) {
-  __shared__ float tile[64][65];
-  const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-  const size_t row3 = (size_t)3 * H * 64;
-  const float* vb = qkv + (size_t)b * T * row3 + (size_t)h * 192 + 128;
-  for (int i = threadIdx.x; i < 64 * 16; i += 256) {  // 16 float4 per key row
-    const int t = i >> 4, c4 = i & 15;
-    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (t0 + t < T) v = *reinterpret_cast<const float4*>(vb + (size_t)(t0 + t) * row3 + 4 * c4);
-    tile[t][4 * c4] = v.x, tile[t][4 * c4 + 1] = v.y, tile[t][4 * c4 + 2] = v.z, tile[t][4 * c4 + 3] = v.w;
-  }
-  __syncthreads();
-  const size_t bh = (size_t)b * H + h;
-  for (int i = threadIdx.x; i < 64 * 16; i += 256) {  // channel c, keys t0 + 4 q .. + 3
-    const int c = i >> 4, q = i & 15;
-    if (t0 + 4 * q >= Tp) continue;
-    const float x0 = tile[4 * q][c], x1 = tile[4 * q + 1][c], x2 = tile[4 * q + 2][c], x3 = tile[4 * q + 3][c];
-    const unsigned h0 = sbk::bf16_pair(x0, x1), h1 = sbk::bf16_pair(x2, x3);
-    const float r0 = x0 - __uint_as_float(h0 << 16), r1 = x1 - __uint_as_float(h0 & 0xffff0000u);
-    const float r2 = x2 - __uint_as_float(h1 << 16), r3 = x3 - __uint_as_float(h1 & 0xffff0000u);
-    const unsigned m0 = sbk::bf16_pair(r0, r1), m1 = sbk::bf16_pair(r2, r3);
-    const unsigned l0 = sbk::bf16_pair(r0 - __uint_as_float(m0 << 16), r1 - __uint_as_float(m0 & 0xffff0000u));
-    const unsigned l1 = sbk::bf16_pair(r2 - __uint_as_float(m1 << 16), r3 - __uint_as_float(m1 & 0xffff0000u));
-    const size_t plane = (size_t)64 * Tp / 4;  // uint2 (four keys) per piece plane
-    uint2* d = dst + (bh * 3 * 64 + c) * (size_t)(Tp / 4) + (t0 / 4 + q);
-    d[0] = make_uint2(h0, h1);
-    d[plane] = make_uint2(m0, m1);
-    d[2 * plane] = make_uint2(l0, l1);
-  }
-}
-
-struct AttnX3Args {
-  AttnArgs a;
-  const uint4* K3;   // [(b, h)][T][3][64] bf16: 8 uint4 per (row, piece)
-  const uint4* P3;   // [h][2T-1][3][64]
-  const uint2* V3T;  // [(b, h)][3][64][Tp]: Tp / 4 uint2 per (piece, channel)
-  int Tp;
-};
-
-__global__ void __launch_bounds__(256, 2) relpos_flash_x3_kernel(AttnX3Args x) {
-  constexpr int DH = 64;
-  using sbk::bf16x8;
-  const AttnArgs& a = x.a;
-  __shared__ float Gs[4][64][32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int jl = lane & 31, half = lane >> 5;
-  const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
-  const int T = a.T, d = a.H * DH;
-  if (i0 >= T) return;
-  const size_t row3 = (size_t)3 * d;
-  const float* qkv_b = a.qkv + (size_t)b * T * row3 + (size_t)h * 3 * DH;
-  const int qrow = min(i0 + jl, T - 1);
-  float (*G)[32] = Gs[wave];
-  const size_t bh = (size_t)b * a.H + h;
-
-  // (q + u) s and (q + v) s, chunk t = channels 16 t + 8 half .. + 7, cut into their pieces once
-  bf16x8 qu[3][4], qv[3][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int c0 = 16 * t + 8 * half;
-    float qr[8], bu[8], bv[8], xu[8], xv[8];
-    load_run<8>(qr, qkv_b + (size_t)qrow * row3 + c0);
-    load_run<8>(bu, a.bias_u + h * DH + c0);
-    load_run<8>(bv, a.bias_v + h * DH + c0);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      xu[e] = (qr[e] + bu[e]) * a.scale;
-      xv[e] = (qr[e] + bv[e]) * a.scale;
-    }
-    bf16x8 pu[3], pv[3];
-    split3_x8(xu, pu);
-    split3_x8(xv, pv);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) qu[p][t] = pu[p], qv[p][t] = pv[p];
-  }
-  int klen = T;
-  if (a.key_len) klen = min(max(a.key_len[b], 1), T);
-  const int nkt = (klen + 31) / 32;
-  int lo, hi;
-  key_range(a, qrow, klen, lo, hi);
-  int kt_begin = 0, kt_end = nkt;
-  if (a.chunk > 0) {
-    kt_end = min(nkt, ((min(i0 + 31, T - 1) / a.chunk + 1) * a.chunk + 31) / 32);
-    if (a.left >= 0) kt_begin = max(0, (i0 / a.chunk - a.left) * a.chunk) / 32;
-  }
-  float m_run = -INFINITY, l_run = 0.0f;
-  f32x16 o[2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[ct][r] = 0.0f;
-
-  // (rows of a piece image) x (query pieces) -> a 32 x 32 tile: row = image row of lane jl, column = query jl
-  auto tile_x3 = [&](const uint4* rowp, const bf16x8 (&q)[3][4]) SBK_INLINE_LAMBDA {
-    bf16x8 kb[3][4];
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const uint4 u = rowp[p * 8 + 2 * t + half];
-        kb[p][t] = sbk::bf16x8_from_words(u.x, u.y, u.z, u.w);
-      }
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc = sbk::mfma_32x32x16_bf16(kb[kX3Pa[pr]][t], q[kX3Pb[pr]][t], acc);
-    return acc;
-  };
-  const uint4* P3h = x.P3 + (size_t)h * (2 * T - 1) * 24;
-  auto g_block = [&](int first_row, int slot) SBK_INLINE_LAMBDA {
-    const int prow = min(max(first_row + jl, 0), 2 * T - 2);
-    const f32x16 g = tile_x3(P3h + (size_t)prow * 24, qv);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) G[slot * 32 + (r & 3) + 8 * (r >> 2) + 4 * half][jl] = g[r];
-  };
-  const uint4* K3b = x.K3 + bh * (size_t)T * 24;
-  const uint2* V3b = x.V3T + bh * 3 * 64 * (size_t)(x.Tp / 4);
-  const size_t vplane = (size_t)64 * (x.Tp / 4);
-  g_block((T - 1) - i0 - 31 + 32 * kt_begin, kt_begin & 1);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int j0 = kt * 32;
-    const int rbase = (T - 1) - i0 - 31 + j0;
-    f32x16 acc = tile_x3(K3b + (size_t)min(j0 + jl, T - 1) * 24, qu);
-    g_block(rbase + 32, (kt + 1) & 1);
-    sbk::wave_sync();
-    float mx = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int jc = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int rr = 31 - jl + jc;
-      acc[r] += G[(((kt & 1) + (rr >> 5)) & 1) * 32 + (rr & 31)][jl];
-      const int key = j0 + jc;
-      if (!(key >= lo && key < hi)) acc[r] = -INFINITY;
-      mx = fmaxf(mx, acc[r]);
-    }
-    sbk::wave_sync();
-    mx = fmaxf(mx, sbk::shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = m_new == -INFINITY ? 1.0f : expf(m_run - m_new);
-    float sum = 0.0f;
-    bf16x8 pb[3][2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float pe[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int r = 8 * s + e;
-        pe[e] = acc[r] == -INFINITY ? 0.0f : expf(acc[r] - m_new);
-        sum += pe[e];
-      }
-      bf16x8 pp[3];
-      split3_x8(pe, pp);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) pb[p][s] = pp[p];
-    }
-    sum += sbk::shfl_xor(sum, 32);
-    l_run = l_run * alpha + sum;
-    m_run = m_new;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
-    // O^T[channel][query] += V^T P^T: step s contracts the keys of accumulator registers 8 s .. 8 s + 7 of this half-wave =
-    // j0 + 16 s + 4 half + {0..3} and j0 + 16 s + 8 + 4 half + {0..3}
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        bf16x8 vb[3];
-        const uint2* vp = V3b + (size_t)(ct * 32 + jl) * (x.Tp / 4) + ((j0 + 16 * s + 4 * half) >> 2);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const uint2 u0 = vp[p * vplane], u1 = vp[p * vplane + 2];
-          vb[p] = sbk::bf16x8_from_words(u0.x, u0.y, u1.x, u1.y);
-        }
-#pragma unroll
-        for (int pr = 0; pr < 6; ++pr) o[ct] = sbk::mfma_32x32x16_bf16(vb[kX3Pa[pr]], pb[kX3Pb[pr]][s], o[ct]);
-      }
-  }
-  if (i0 + jl < T) {
-    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
-    float* orow = a.out + ((size_t)b * T + i0 + jl) * d + h * DH;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4)
-        *reinterpret_cast<float4*>(orow + ct * 32 + 8 * q4 + 4 * half) =
-            make_float4(o[ct][4 * q4] * inv, o[ct][4 * q4 + 1] * inv, o[ct][4 * q4 + 2] * inv, o[ct][4 * q4 + 3] * inv);
-  }
-}
-
 // ---- plain attention on bf16 q / k / v rows shared through LDS (the Whisper encoder under precision "bf16") ------------
 // qkv [B,T,H,3,64] bf16 as written by the bf16-activation QKV contraction; vT [B,H,64,Tp] bf16 = the values transposed
 // (v_transpose_bf16_kernel, Tp = T rounded up to 64, zero padded).  A workgroup = one (utterance, head) and 128 queries
@@ -1455,57 +1207,6 @@ extern "C" int sbk_attention_bf16io(const uint16_t* qkv, const int32_t* key_len,
   const size_t lds = (size_t)2 * 2 * 64 * 32 * sizeof(float);
   SBK_LAUNCH(attn_lds_bf16_kernel, dim3((T + 127) / 128, H, B), dim3(256), lds, st, a);
   return sbk::launch_status("sbk_attention_bf16io");
-}
-
-namespace sbk {
-int g_relpos_x3 = 0;  // tuning knob (key 46): 1 = the binding routes RelPosMHAXL (head_dim 64, no attention-weights output) to relpos_flash_x3_kernel
-size_t relpos_x3_workspace_bytes(int B, int T, int H) {
-  const size_t Tp = ((size_t)T + 31) / 32 * 32;
-  return (size_t)B * H * T * 384 + (size_t)H * (2 * (size_t)T - 1) * 384 + (size_t)B * H * 384 * Tp + 1024;
-}
-int relpos_attention_x3(const float* qkv, const float* pos, const float* bias_u, const float* bias_v, const int32_t* key_len,
-                        float* out, void* workspace, size_t workspace_bytes, int B, int T, int H, float scale, int chunk, int left,
-                        hipStream_t st) {
-  if (B == 0 || T == 0) return 0;
-  if (workspace_bytes < relpos_x3_workspace_bytes(B, T, H)) return fail(SBK_EINVAL, "relpos_attention_x3: workspace too small");
-  const int Tp = (T + 31) / 32 * 32, d = H * 64;
-  char* w = static_cast<char*>(workspace);
-  uint4* K3 = reinterpret_cast<uint4*>(w);
-  w += ((size_t)B * H * T * 384 + 255) & ~(size_t)255;
-  uint4* P3 = reinterpret_cast<uint4*>(w);
-  w += ((size_t)H * (2 * (size_t)T - 1) * 384 + 255) & ~(size_t)255;
-  uint2* V3T = reinterpret_cast<uint2*>(w);
-  ProfScope prof("relpos_attention_x3", 2.0 * 3 * B * H * (double)T * T * 64, 4.0 * 4 * B * (double)T * d + 6.0 * 2 * B * (double)T * d, st);
-  {
-    const long tk = (long)B * H * T * 16, tp = (long)H * (2 * T - 1) * 16;
-    SBK_LAUNCH(split_rows64_x3_kernel, dim3((unsigned)((tk + 255) / 256 < 65535 ? (tk + 255) / 256 : 65535)), dim3(256), 0, st, qkv + 64, H,
-               (size_t)T * 3 * d, (size_t)192, (size_t)3 * d, reinterpret_cast<uint2*>(K3), T, tk);
-    SBK_LAUNCH(split_rows64_x3_kernel, dim3((unsigned)((tp + 255) / 256 < 65535 ? (tp + 255) / 256 : 65535)), dim3(256), 0, st, pos, 1, (size_t)64,
-               (size_t)0, (size_t)d, reinterpret_cast<uint2*>(P3), 2 * T - 1, tp);
-    SBK_LAUNCH(split_vt_x3_kernel, dim3((Tp + 63) / 64, H, B), dim3(256), 0, st, qkv, V3T, T, Tp, H);
-    int rc = launch_status("relpos_attention_x3 (split)");
-    if (rc) return rc;
-  }
-  AttnX3Args x{AttnArgs{qkv, pos, bias_u, bias_v, key_len, out, nullptr, B, T, H, 0, scale, chunk, left, 0}, K3, P3, V3T, Tp};
-  SBK_LAUNCH(relpos_flash_x3_kernel, dim3((T + 127) / 128, H, B), dim3(256), 0, st, x);
-  return launch_status("relpos_attention_x3");
-}
-}  // namespace sbk
-
-extern "C" size_t sbk_relpos_x3_workspace_bytes(int B, int T, int H) { return sbk::relpos_x3_workspace_bytes(B, T, H); }
-extern "C" int sbk_relpos_attention_x3_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
-                                           const int32_t* key_len, float* out, void* workspace, size_t workspace_bytes, int B,
-                                           int T, int H, int Dh, float scale, int chunk_size, int left_chunks,
-                                           sbk_stream_t stream) {
-  if (B == 0 || T == 0) return 0;
-  SBK_REQUIRE(qkv && pos && bias_u && bias_v && out && workspace, "relpos_attention_x3: null pointer");
-  SBK_REQUIRE(B > 0 && T > 0 && H > 0 && Dh == 64, "relpos_attention_x3: head_dim must be 64 (B=%d T=%d H=%d Dh=%d)", B, T, H, Dh);
-  SBK_REQUIRE(chunk_size >= 0, "relpos_attention_x3: chunk_size must be >= 0");
-  SBK_REQUIRE(sbk::aligned16(qkv) && sbk::aligned16(pos) && sbk::aligned16(out) && sbk::aligned16(workspace) &&
-                  sbk::aligned16(bias_u) && sbk::aligned16(bias_v),
-              "relpos_attention_x3: operands must be 16-byte aligned");
-  return sbk::relpos_attention_x3(qkv, pos, bias_u, bias_v, key_len, out, workspace, workspace_bytes, B, T, H, scale, chunk_size,
-                                  left_chunks, sbk::as_stream(stream));
 }
 
 extern "C" int sbk_relpos_attention_f32(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,

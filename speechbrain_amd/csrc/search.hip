@@ -1045,7 +1045,9 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
   for (int l = 0; hand_over && l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
     hand_over = L.sa_in_wp && L.sa_out_wp && L.ca_q_wp && L.ca_out_wp && L.ff1_wp && L.ff2_wp && L.sa_in_wfp && L.sa_in_bf &&
-                L.ca_q_wfp && L.ca_q_bf && L.ff1_wfp && L.ff1_bf;
+                L.ca_q_wfp && L.ca_q_bf && L.ff1_wfp && L.ff1_bf && sbk::aligned16(L.sa_in_b) && sbk::aligned16(L.sa_out_b) &&
+                sbk::aligned16(L.ca_in_b) && sbk::aligned16(L.ca_out_b) && sbk::aligned16(L.ff1_b) && sbk::aligned16(L.ff2_b) &&
+                sbk::aligned16(L.sa_in_bf) && sbk::aligned16(L.ca_q_bf) && sbk::aligned16(L.ff1_bf);
   }
   float2* const xs = hand_over ? d.xstat : nullptr;
   SBK_TRY(sbk::embed_pos(tokens, W->emb, W->pe + (size_t)step * dm, d.x, n, dm, emb_scale, st, xs));
@@ -1061,10 +1063,17 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
     if (apan) return sbk_layernorm_x3p(d.x, g_, b_, d.hp, n, dm, W->ln_eps, SBK_ACT_NONE, st);
     return sbk::layernorm(d.x, g_, b_, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st);
   };
+  // the routed kernels move bias rows as 16-byte vectors: a layer with an unaligned bias view takes the fp32 kernels below
+  // instead of failing inside the route
+  auto biases_aligned = [](const sbk_decoder_layer& L) {
+    return sbk::aligned16(L.sa_in_b) && sbk::aligned16(L.sa_out_b) && sbk::aligned16(L.ca_in_b) && sbk::aligned16(L.ca_out_b) &&
+           sbk::aligned16(L.ff1_b) && sbk::aligned16(L.ff2_b) && sbk::aligned16(L.sa_in_bf) && sbk::aligned16(L.ca_q_bf) &&
+           sbk::aligned16(L.ff1_bf);
+  };
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
     if (L.sa_in_wp && L.sa_out_wp && L.ca_q_wp && L.ca_out_wp && L.ff1_wp && L.ff2_wp && sbk::x3r_routed(n, dm, dm) &&
-        sbk::x3r_routed(n, dm, W->d_ffn)) {
+        sbk::x3r_routed(n, dm, W->d_ffn) && biases_aligned(L)) {
       const float* hA = apan ? nullptr : d.h;
       const uint16_t* hP = apan ? d.hp : nullptr;
       // norm1 / norm2 / norm3 inside the projection they feed (folded panel images, ABI 9; knob 45)

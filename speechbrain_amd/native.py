@@ -105,8 +105,6 @@ def _declare(lib):
         "sbk_gemm_nt_x3r": ([p, i, p, p, p, p, i, p, i, p, i, i, i, i, f, p], c_int),
         "sbk_gemm_ln_nt_x3r": ([p, i, p, p, p, i, p, i, p, i, i, i, f, i, f, p], c_int),
         "sbk_gemm_nt_x3r_stats": ([p, i, p, p, p, p, i, p, i, p, i, i, i, f, i, f, p], c_int),
-        "sbk_relpos_x3_workspace_bytes": ([i, i, i], ctypes.c_size_t),
-        "sbk_relpos_attention_x3_f32": ([p, p, p, p, p, p, p, ctypes.c_size_t, i, i, i, i, f, i, i, p], c_int),
         "sbk_row_block_stats_f32": ([p, i, p, i, i, p], c_int),
         "sbk_quant_rows_fp8": ([p, i, p, p, i, i, p], c_int),
         "sbk_quant_rows_bf16_fp8": ([p, i, p, p, i, i, p], c_int),
@@ -275,8 +273,6 @@ F32X3_MIN_TILES = int(os.environ.get("SBK_F32X3_MIN_TILES", "192"))
 X3P = os.environ.get("SBK_X3P", "1") != "0"
 # the decode step's few-row projections on the bf16 matrix pipe (sbk_gemm_nt_x3r: panel images of the decoder's weights)
 X3R = os.environ.get("SBK_X3R", "1") != "0"
-# RelPosMHAXL's tile products on the bf16 matrix pipe (sbk_relpos_attention_x3_f32; SBK_RELPOS_X3=1 to route -- untimed: off)
-RELPOS_X3 = os.environ.get("SBK_RELPOS_X3", "0") != "0"
 X3P_MIN_TILES = int(os.environ.get("SBK_X3P_MIN_TILES", "96"))
 
 
@@ -989,13 +985,6 @@ def relpos_attention(qkv, pos, bias_u, bias_v, key_len, H, scale, want_attn=Fals
     d = d3 // 3
     if out is None:
         out = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
-    if RELPOS_X3 and not want_attn and d // H == 64:  # the tile products on the bf16 matrix pipe (split operands, fp32-grade)
-        nbytes = lib.sbk_relpos_x3_workspace_bytes(B, T, H)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)  # (caching allocator: stream-ordered reuse)
-        _chk(lib.sbk_relpos_attention_x3_f32(_p(qkv), _p(pos), _p(bias_u), _p(bias_v), _p(key_len), _p(out), _p(ws), nbytes,
-                                             B, T, H, 64, float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),
-             "sbk_relpos_attention_x3_f32")
-        return out, None
     attn = torch.empty(B, H, T, T, dtype=torch.float32, device=qkv.device) if want_attn else None
     _chk(lib.sbk_relpos_attention_f32(_p(qkv), _p(pos), _p(bias_u), _p(bias_v), _p(key_len), _p(out), _p(attn), B, T,
                                       H, d // H, float(scale), int(chunk_size), int(left_chunks), _stream(qkv)),

@@ -91,34 +91,6 @@ def test_rope_conformer_l_encoder_vs_oracle():
     assert float((enc - ref).abs().max()) <= 2e-4
 
 
-def test_conformer_l_encoder_with_relpos_attention_on_split_operands_vs_oracle(monkeypatch):
-    """Conformer-L (RelPosMHAXL, 8 heads of 64) with the attention's tile products on the bf16 matrix pipe
-    (sbk_relpos_attention_x3_f32: keys / values / position rows split once per call, fp32-grade results): encoder output
-    within 2e-4 of the oracle, with padding -- the bound of the default route; every layer takes the route."""
-    from speechbrain_amd import native
-    from speechbrain_amd.inference.builders import flat_state_dict
-
-    asr = _asr("L")
-    n = 6 * 16000
-    wav = 0.1 * torch.randn(3, n, generator=torch.Generator().manual_seed(4321))
-    lens = torch.tensor([1.0, 0.55, 0.8])
-    wav[1, int(0.55 * n):] = 0
-    wav[2, int(0.8 * n):] = 0
-    fc, mc = _oracle_cfg("L")
-    sd = flat_state_dict(asr)
-    monkeypatch.setattr(native, "RELPOS_X3", True)
-    native.prof_reset()
-    native.prof_enable(True)
-    try:
-        enc = asr.encode_batch(wav, lens).cpu()
-    finally:
-        native.prof_enable(False)
-    rep = native.prof_report()
-    assert rep["relpos_attention_x3"]["count"] == 12 and "relpos_attention" not in rep, sorted(rep)
-    ref = O.encode_batch(wav, lens, sd, fc, mc, torch.zeros(80), torch.ones(80))
-    assert float((enc - ref).abs().max()) <= 2e-4
-
-
 def test_conformer_l_decoder_logprobs_and_search_vs_oracle():
     """Conformer-L, beam 10 + CTC 0.4: first-step log-probs within 1e-4, then (with peaked output
     heads so that fp32 noise cannot flip a near-tie, SURVEY 7 hard-part 1) bit-exact token ids and

@@ -248,49 +248,6 @@ def test_relpos_transposed_flash_variant(backend, B, T, H, Dh, lens, chunk):
         assert _md(new, O.relpos_mha(x, pos, sd, "", H, kp)) <= 5e-6
 
 
-@pytest.mark.parametrize("B,T,H,lens,chunk", [(2, 133, 2, [133, 20], (0, -1)), (1, 33, 1, None, (0, -1)), (2, 251, 2, [251, 129], (16, 2)),
-                                              (1, 97, 3, [97], (8, -1)), (3, 64, 2, [64, 1, 40], (0, -1))])
-def test_relpos_attention_on_the_bf16_pipe_with_split_operands(backend, monkeypatch, B, T, H, lens, chunk):
-    """sbk_relpos_attention_x3_f32 (csrc/relpos_attn.hip: relpos_flash_x3_kernel, head_dim 64): RelPosMHAXL's Q K^T, position
-    term and P V on v_mfma_f32_32x32x16_bf16 with every operand cut into its three bf16 pieces (keys, transposed values and
-    position rows split once per call into a caller-owned workspace; queries and probabilities in registers).  fp32-grade:
-    the tolerance of the fp32-MFMA kernel against the oracle, and against that kernel itself -- key padding (down to one
-    key), Dynamic Chunk masks, ragged last tiles, T = a multiple of the tile and one more than it; run-to-run identical."""
-    nat, dev = backend
-    Dh = 64
-    d = H * Dh
-    g = torch.Generator().manual_seed(T + H)
-    x = torch.randn(B, T, d, generator=g)
-    sd = {"in_proj_weight": torch.randn(3 * d, d, generator=g) / math.sqrt(d),
-          "pos_bias_u": torch.randn(Dh, H, generator=g) * 0.3, "pos_bias_v": torch.randn(Dh, H, generator=g) * 0.3,
-          "linear_pos.weight": torch.randn(d, d, generator=g) / math.sqrt(d), "out_proj.weight": torch.eye(d),
-          "out_proj.bias": torch.zeros(d)}
-    pos = O.relpos_table(T, d)
-    kl = None if lens is None else torch.tensor(lens, dtype=torch.int32)
-    qkv = nat.gemm_nt(x.to(dev), sd["in_proj_weight"].to(dev))
-    P = nat.gemm_nt(pos.to(dev), sd["linear_pos.weight"].to(dev))
-    args = (qkv, P, sd["pos_bias_u"].reshape(-1).contiguous().to(dev), sd["pos_bias_v"].reshape(-1).contiguous().to(dev),
-            None if kl is None else kl.to(dev), H, 1 / math.sqrt(d), False, chunk[0], chunk[1])
-    base, _ = nat.relpos_attention(*args)
-    monkeypatch.setattr(nat, "RELPOS_X3", True)
-    nat.prof_reset()
-    nat.prof_enable(True)
-    try:
-        new, none = nat.relpos_attention(*args)
-        again, _ = nat.relpos_attention(*args)
-    finally:
-        nat.prof_enable(False)
-    assert none is None and "relpos_attention_x3" in nat.prof_report()
-    assert torch.equal(new, again)
-    assert _md(new, base.cpu()) <= 5e-6
-    if chunk[0] == 0:
-        kp = None if kl is None else ~O.length_to_mask(kl, T)
-        assert _md(new, O.relpos_mha(x, pos, sd, "", H, kp)) <= 5e-6
-    # the weights output still comes from the fp32 kernel (the route is not taken with want_attn)
-    _, attn = nat.relpos_attention(*args[:7], True, chunk[0], chunk[1])
-    assert attn is not None
-
-
 @pytest.mark.parametrize("prefetch", [0, 1, 4, 5])
 @pytest.mark.parametrize("B,T,H,Dh,lens", [(2, 45, 4, 8, [45, 30]), (1, 70, 2, 36, [70]), (2, 133, 2, 64, [133, 20]),
                                            (1, 300, 1, 32, None)])

@@ -438,38 +438,6 @@ def test_decoder_on_the_x3r_route_vs_oracle(backend, mode, ln):
         lib.sbk_prof_set_knob(47, 1)
 
 
-def test_encoder_with_relpos_attention_on_split_operands_vs_oracle(backend, monkeypatch):
-    """A Conformer encoder whose RelPosMHAXL layers run on sbk_relpos_attention_x3_f32 (head_dim 64: the route's condition;
-    csrc/relpos_attn.hip: relpos_flash_x3_kernel) against the oracle's encoder on the same weights, ragged lengths included:
-    the tolerance of the default route.  The profiler's launch names show that the route ran in every layer."""
-    nat, dev = backend
-    from speechbrain_amd.inference.builders import build_modules
-
-    m = build_modules(dict(d_model=128, nhead=2, d_ffn=256, n_enc=2, n_dec=1, n_fft=400, win_length=25), vocab=50, seed=5)
-    mods = torch.nn.ModuleDict({k: m[k] for k in ("CNN", "Transformer")})
-    sd = {k: v.detach().clone() for k, v in mods.state_dict().items()}
-    mods = mods.to(dev).eval()
-    cfg = O.ModelCfg(d_model=128, nhead=2, num_encoder_layers=2, num_decoder_layers=1, d_ffn=256, vocab=50)
-    gen = torch.Generator().manual_seed(23)
-    feats = torch.randn(3, 150, 80, generator=gen)
-    wl = torch.tensor([1.0, 0.6, 0.83])
-    with torch.no_grad():
-        cnn = mods["CNN"](feats.to(dev))
-        base = mods["Transformer"].encode(cnn, wl.to(dev)).cpu()
-        monkeypatch.setattr(nat, "RELPOS_X3", True)
-        nat.prof_reset()
-        nat.prof_enable(True)
-        try:
-            enc = mods["Transformer"].encode(cnn, wl.to(dev)).cpu()
-        finally:
-            nat.prof_enable(False)
-    rep = nat.prof_report()
-    assert rep["relpos_attention_x3"]["count"] == 2 and "relpos_attention" not in rep, sorted(rep)
-    ref = O.encode(cnn.cpu(), wl, sd, cfg, "Transformer.")
-    assert float((base - ref).abs().max()) <= 5e-5
-    assert float((enc - ref).abs().max()) <= 5e-5
-
-
 def build_lm(g, dev):
     from speechbrain_amd.lobes.models.transformer.TransformerLM import TransformerLM
 

@@ -145,25 +145,6 @@ if __name__ == "__main__":
             nat.load().sbk_prof_set_knob(17, 1)
             print(f"relpos attention B={B} T={T} H={H}:", res, "max|diff|", float((outs["lds-tile"] - outs["transposed"]).abs().max()), flush=True)
         sys.exit(0)
-    if "--relpos-x3" in sys.argv:  # RelPosMHAXL: fp32-MFMA transposed-score kernel vs the split-operand kernel on the bf16 pipe
-        import math
-        for (B, T, H) in [(32, 251, 8), (32, 440, 8), (32, 750, 8), (8, 750, 8)]:
-            Dh, d = 64, 8 * 64
-            qkv = torch.randn(B, T, 3 * d, device=dev)
-            P = torch.randn(2 * T - 1, d, device=dev)
-            u, v = torch.randn(d, device=dev) * 0.3, torch.randn(d, device=dev) * 0.3
-            kl = torch.full((B,), T, dtype=torch.int32, device=dev)
-            fl = 6.0 * B * H * T * T * Dh
-            res, outs = {}, {}
-            for tag, on in (("fp32 MFMA", False), ("split operands", True)):
-                nat.RELPOS_X3 = on
-                outs[tag] = nat.relpos_attention(qkv, P, u, v, kl, H, 1 / math.sqrt(d))[0]
-                t = timeit(lambda: nat.relpos_attention(qkv, P, u, v, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
-                res[tag] = f"{t:8.1f} us {fl / t / 1e6:6.1f} TF/s"
-            nat.RELPOS_X3 = False
-            print(f"relpos attention B={B} T={T} H={H}:", res, "(split passes included) max|diff|",
-                  float((outs["fp32 MFMA"] - outs["split operands"]).abs().max()), flush=True)
-        sys.exit(0)
     if "--attn2" in sys.argv:  # RoPE / plain attention: LDS-tile flash kernel vs transposed-score kernel vs its bf16 variant
         import math
         from speechbrain_amd.nnet.attention import PrecomputedRoPESinusoids
