@@ -108,6 +108,44 @@ def run_step(asr, wav, lens):
     return asr.transcribe_batch(wav, lens)[1]
 
 
+def decode_step_probe(asr, dev, frames=430, batches=4, steps=(16, 32)):
+    """The decoding step at the headline's shape -- ONE grouped search of `batches` x 32 utterances (T' = 430, 420, ...; beam 10 +
+    CTC) from a random encoder output, on one stream: milliseconds and launches per step as the difference of a 32- and a 16-step
+    search (the per-search set-up -- memory projection, CTC emissions -- cancels).  Launch counts from the library's per-launch
+    profiler (sbk_prof_*), times from the wall clock around synchronised searches without it.  (tools/decode_probe.py is the
+    same search for rocprofv3 passes.)"""
+    from speechbrain_amd import native
+
+    dec = asr.mods.decoder
+    g = torch.Generator().manual_seed(3)
+    items = [(torch.randn(32, frames - 10 * k, 512, generator=g).to(dev), torch.linspace(0.85, 1.0, 32).to(dev)) for k in range(batches)]
+    res = {}
+    with torch.no_grad():
+        for n in steps:
+            ratios = [(0.0, (n + 0.5) / it[0].shape[1]) for it in items]
+            dec.forward_group(items, ratios)  # warm-up (workspaces)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                dec.forward_group(items, ratios)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / 3
+            native.prof_reset()
+            native.prof_enable(True)
+            dec.forward_group(items, ratios)
+            torch.cuda.synchronize()
+            native.prof_enable(False)
+            rep = native.prof_report()
+            native.prof_reset()
+            res[n] = (ms, sum(v["count"] for v in rep.values()), {k: v["count"] for k, v in rep.items()})
+    a, b = steps
+    per = {k: round((res[b][2].get(k, 0) - res[a][2].get(k, 0)) / (b - a), 2) for k in res[b][2]}
+    return {"decode_step_ms": round((res[b][0] - res[a][0]) / (b - a), 4),
+            "launches_per_decode_step": round((res[b][1] - res[a][1]) / (b - a), 2),
+            "launches_per_decode_step_by_kernel": {k: v for k, v in sorted(per.items(), key=lambda kv: -kv[1]) if v > 0},
+            "shape": f"{batches} x 32 utterances, T' {frames}..{frames - 10 * (batches - 1)}, beam 10 + CTC, one stream; difference of a {b}- and a {a}-step search"}
+
+
 # ------------------------------------------------------------------ CPU leg (oracle port)
 def cpu_threads():
     """Host threads for the CPU leg: the cores this process may run on, capped at 32 (the port's
@@ -395,6 +433,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip configs[1] (Conformer-S encoder) and the second run")
     ap.add_argument("--latency-runs", type=int, default=5)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--leg", default="", choices=["", "batch128", "bf16", "fp32mfma"], help=argparse.SUPPRESS)  # child process of a secondary leg
+    ap.add_argument("--leg-out", default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample", default="4x10s", choices=["4x10s", "2shortest"], help=argparse.SUPPRESS)
     ap.add_argument("--job-utts", type=int, default=0,
                     help="STRONG scaling: a fixed job of this many utterances shared by all the ranks (BASELINE.json "
@@ -592,12 +632,30 @@ def main():
                     "per_rank_audio_s": [round(sum(seconds[i] for b in plan_["owner"][r] for i in plan_["batches"][b]), 1)
                                          for r in range(world)],
                     "per_rank_batches": [len(plan_["owner"][r]) for r in range(world)]})
-        workers.pool.shutdown(wait=True)
+        workers.close()
         return dt, hyps, local, info
 
     def auto(max_batch):
         # measured (tools/ab_cases.txt sweeps, profiles/r02_*): 8 workers; 4 recipe-sized batches per grouped search
         return args.streams or 8, args.group or max(1, 128 // max_batch)
+
+    if args.leg:  # ---- this process IS such a child: run the one leg, write its result, leave
+        if args.leg == "batch128":
+            dt2, hyps2, _, info2 = timed_run(args.second_batch, *auto(args.second_batch))
+        elif args.leg == "bf16":
+            asr.eval_precision = "bf16"
+            dt2, hyps2, _, info2 = timed_run(args.max_batch, *auto(args.max_batch))
+        else:
+            native.F32X3 = False
+            asr.mods.decoder._dec_handle = None  # (the searchers' weight tables carry the split images: rebuilt without)
+            dt2, hyps2, _, info2 = timed_run(args.max_batch, *auto(args.max_batch))
+        res = {"leg": args.leg, "dt": dt2, "value": round(total_audio / dt2, 2), "ms_per_step": round(1000.0 * dt2 / max(args.steps, 1), 3),
+               "reserved_gb": info2.get("gpu_memory_reserved_gb"), "peak_allocated_gb": info2.get("gpu_memory_peak_allocated_gb"),
+               "workers_x_group": [info2["streams"], info2["group"]],
+               "hyps": [[int(v) for v in h] for h in hyps2] if args.leg == "bf16" else None}
+        with open(args.leg_out, "w") as f:
+            json.dump(res, f)
+        return
 
     dt, hyps, local_batches, info = timed_run(args.max_batch, *auto(args.max_batch))
     note(f"timed region done: {dt:.3f} s")
@@ -643,47 +701,75 @@ def main():
             **({"concurrent_kernels": info["concurrent_kernels"]} if "concurrent_kernels" in info else {}),
         }
 
-    # ---- the same utterances as 128-utterance batches (N = 1)
-    if world == 1 and not dist_on and args.second_batch > 0 and not args.no_extras:
-        dt2, hyps2, _, info2 = timed_run(args.second_batch, *auto(args.second_batch))
-        out[f"value_batch{args.second_batch}"] = round(total_audio / dt2, 2)
-        out[f"ms_per_step_batch{args.second_batch}"] = round(1000.0 * dt2 / max(args.steps, 1), 3)
-        out["config"].setdefault("gpu_memory_reserved_gb", {})[f"after_batch{args.second_batch}_leg"] = info2.get("gpu_memory_reserved_gb")
-        out["config"][f"workers_x_group_batch{args.second_batch}"] = [info2["streams"], info2["group"]]
-        note(f"second run ({args.second_batch}-utterance batches): {dt2:.3f} s")
+    # ---- secondary legs (N = 1), EACH IN A PROCESS OF ITS OWN (the legs used to share the parent's caching-allocator
+    # pools -- one per worker stream -- and the third leg measured 8.3 K where the same leg alone gives 11-12 K): the same
+    # utterances as 128-utterance batches; the opt-in bf16 encoder GEMMs + token agreement with the fp32 run; every contraction
+    # on the fp32 MFMA instruction (SBK_F32X3=0's path: the headline's large contractions run on the bf16 pipe)
+    def child_leg(name):
+        import gc
+        import subprocess
+        import tempfile
 
-    # ---- the opt-in bf16 encoder GEMMs on the same job + token agreement with the fp32 run (N = 1)
-    if world == 1 and not dist_on and not args.no_extras and args.precision == "fp32":
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()  # (the child needs the HBM the parent's pools still hold)
+        fd, path = tempfile.mkstemp(suffix=".json", prefix=f"sbk_leg_{name}_")
+        os.close(fd)
+        cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--leg-out", path, "--steps", str(args.steps), "--warmup",
+               str(args.warmup), "--max-batch", str(args.max_batch), "--second-batch", str(args.second_batch), "--attention",
+               args.attention, "--check-every", str(args.check_every), "--streams", str(args.streams), "--group", str(args.group),
+               "--graph-mode", str(args.graph_mode), "--overlap-ctc", str(args.overlap_ctc)]
+        cmd += [x for kv in args.knob for x in ("--knob", kv)]
+        cmd += (["--lm"] if args.lm else []) + (["--group-encoder"] if args.group_encoder else []) + (
+            ["--no-search-priority"] if args.no_search_priority else [])
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            if r.returncode != 0:
+                return {"error": f"rc {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"}
+            with open(path) as f:
+                return json.load(f)
+        except Exception as e:  # (a secondary leg must never cost the headline)
+            return {"error": repr(e)[:300]}
+        finally:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+
+    extras = world == 1 and not dist_on and not args.no_extras
+    if extras:
+        out["config"]["secondary_legs"] = "each in a process of its own (own allocator pools, worker streams and weight images)"
+    if extras and args.second_batch > 0:
+        r2 = child_leg("batch128")
+        out[f"value_batch{args.second_batch}"] = r2.get("value")
+        if "error" in r2:
+            out["config"][f"batch{args.second_batch}_leg_error"] = r2["error"]
+        else:
+            out[f"ms_per_step_batch{args.second_batch}"] = r2["ms_per_step"]
+            out["config"].setdefault("gpu_memory_reserved_gb", {})[f"batch{args.second_batch}_leg_own_process"] = r2["reserved_gb"]
+            out["config"][f"workers_x_group_batch{args.second_batch}"] = r2["workers_x_group"]
+        note(f"second run ({args.second_batch}-utterance batches): {r2.get('value')}")
+    if extras and args.precision == "fp32":
         from speechbrain_amd.utils.metric_stats import token_error_rate
 
-        asr.eval_precision = "bf16"
-        dt3, hyps3, _, info3 = timed_run(args.max_batch, *auto(args.max_batch))
-        out["config"].setdefault("gpu_memory_reserved_gb", {})["after_bf16_leg"] = info3.get("gpu_memory_reserved_gb")
-        asr.eval_precision = "fp32"
-        ter = token_error_rate(hyps3, hyps)
-        out["value_encoder_gemms_bf16"] = round(total_audio / dt3, 2)
-        out["bf16_vs_fp32_token_error_rate_percent"] = round(ter["WER"], 3)
+        r3 = child_leg("bf16")
+        out["value_encoder_gemms_bf16"] = r3.get("value")
+        if "error" in r3:
+            out["config"]["bf16_leg_error"] = r3["error"]
+        else:
+            ter = token_error_rate(r3["hyps"], hyps)
+            out["bf16_vs_fp32_token_error_rate_percent"] = round(ter["WER"], 3)
+            out["config"].setdefault("gpu_memory_reserved_gb", {})["bf16_leg_own_process"] = r3["reserved_gb"]
         out["config"]["bf16_note"] = ("opt-in (run_opts precision='bf16'): encoder GEMM operands rounded to bf16, fp32 accumulation, "
                                       "everything else fp32; token error rate of its hypotheses against the fp32 run's on the "
                                       "same utterances (random-init weights: flat posteriors amplify every perturbation)")
-        note(f"bf16 encoder GEMMs: {dt3:.3f} s, token error rate vs fp32 {ter['WER']:.2f} %")
-
-    # ---- the same job with every contraction on the fp32 MFMA instruction (SBK_F32X3=0's path), for reference: the headline's
-    # large contractions run on the bf16 matrix pipe through the exact operand split
-    if world == 1 and not dist_on and not args.no_extras and args.precision == "fp32" and native.F32X3:
-        try:
-            native.F32X3 = False
-            asr.mods.decoder._dec_handle = None  # (the searchers' weight tables carry the split images: rebuilt without)
-            try:
-                dt4, _, _, _ = timed_run(args.max_batch, *auto(args.max_batch))
-            finally:
-                native.F32X3 = True
-                asr.mods.decoder._dec_handle = None
-            out["value_fp32_mfma_contractions"] = round(total_audio / dt4, 2)
-            note(f"fp32-MFMA contractions: {dt4:.3f} s")
-        except Exception as e:  # (a reference leg must never cost the headline)
-            out["value_fp32_mfma_contractions"] = None
-            out["config"]["fp32_mfma_leg_error"] = repr(e)[:200]
+        note(f"bf16 encoder GEMMs: {r3.get('value')}")
+    if extras and args.precision == "fp32" and native.F32X3:
+        r4 = child_leg("fp32mfma")
+        out["value_fp32_mfma_contractions"] = r4.get("value")
+        if "error" in r4:
+            out["config"]["fp32_mfma_leg_error"] = r4["error"]
+        note(f"fp32-MFMA contractions: {r4.get('value')}")
 
     # ---- p50 per-utterance latency (B = 1, 10 s; pinned host waveform -> token ids on the host), rank 0 only
     if rank == 0 and args.latency_runs > 0:
@@ -740,7 +826,7 @@ def main():
         one.group_encoder = args.group_encoder
         one.plan_workers = auto(args.max_batch)[0]  # the same groups as the eight workers formed
         seq_out = one.transcribe_batches([(t[1], t[2]) for t in local_batches], prepare=fixed_decode_length)
-        one.pool.shutdown(wait=True)
+        one.close()
         # determinism of the headline's execution mode: the same batches, in the same groups, one after the other on ONE
         # stream give exactly the token ids the eight concurrent workers produced inside the timed region (NOT a parity
         # statement: both sides are the worker machinery -- the comparison with plain transcribe_batch follows below)
@@ -793,6 +879,13 @@ def main():
             "frac_of_hbm_peak": round(mb_per_s * out["value"] / world / 1e3 / PEAK_HBM_GBS, 4),
             "single_stream_kernel_ms_per_audio_sec": round(total_ms / max(rep_audio, 1e-9), 4)}
         out["kernel_breakdown_ms"] = {k: round(v["ms"], 2) for k, v in ranked}
+        try:  # the decoding step of the headline's grouped searches, on one stream (on the line, not only in profiles/)
+            probe = decode_step_probe(asr, dev)
+            out["decode_step_ms"] = probe.pop("decode_step_ms")
+            out["launches_per_decode_step"] = probe.pop("launches_per_decode_step")
+            out["decode_step_probe"] = probe
+        except Exception as e:
+            out["decode_step_probe"] = {"error": repr(e)[:200]}
 
     # ---- parity of the headline's execution mode against the PLAIN path: >= 256 utterances of the job through the eight
     # concurrent workers with grouped searches vs main-thread, one-stream, ungrouped asr.transcribe_batch calls on the same
@@ -813,7 +906,7 @@ def main():
         try:
             par = ConcurrentTranscriber(asr, streams=auto(args.max_batch)[0], group=auto(args.max_batch)[1])
             got = par.transcribe_batches([(t[1], t[2]) for t in sub], prepare=fixed_decode_length)
-            par.pool.shutdown(wait=True)
+            par.close()
             n_bad = 0
             for t, per_batch in zip(sub, got):
                 plain = run_step(asr, t[1], t[2])

@@ -999,9 +999,13 @@ int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
       CrossAttnArgs c = a;
       if (!sbk::g_cross_fused_merge) c.cnt = nullptr;
       const int FR = sbk::g_cross_rows == 6 ? 8 : 16;
-      // (knob 8 = 3, either route: ONE run per utterance -- no partials, no merge launch; B workgroups walk their whole memory.
-      //  An A/B for groups of ~128 utterances whose co-resident streams fill the other CUs: DESIGN.md section 8)
-      const int target = sbk::g_cross_fc256 == 3 ? a.B : dma_auto ? 256 : (sbk::g_cross_fc256 == 1 ? 256 : (sbk::g_cross_fc256 == 2 ? 1024 : 512));
+      // ONE run per utterance from ~100 utterances per search on (round 5 default; knob 8 = 3 forces it, 4 = round 4's 256
+      // workgroups): no partials, no merge launch, B workgroups walk their whole memory.  On one stream it is slower (2.20 vs
+      // 2.03 ms per step: half of the CUs idle), under the eight workers it is +1.8 % on the headline in three paired runs
+      // (11 925 / 11 870 / 11 901 against 11 725 / 11 648 / 11 681, profiles/r05_b_*): the co-resident streams use the other CUs
+      // and six merge launches per step are gone.
+      const bool one_run = sbk::g_cross_fc256 == 3 || (dma_auto && a.B >= 96 && sbk::g_cross_fc256 != 4);
+      const int target = one_run ? a.B : dma_auto ? 256 : (sbk::g_cross_fc256 == 1 ? 256 : (sbk::g_cross_fc256 == 2 ? 1024 : 512));
       int ns = sbk::cdiv(target, a.B);                          // workgroups over the batch ...
       if (ns > sbk::cdiv(a.T, FR)) ns = sbk::cdiv(a.T, FR);    // ... of at least one tile
       if (ns > sbk::cdiv(a.T, 16)) ns = sbk::cdiv(a.T, 16);    // (the partial buffer is sized for 16-frame runs)

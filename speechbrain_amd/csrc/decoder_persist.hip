@@ -47,8 +47,9 @@ struct PStepArgs {
   float eps, emb_scale, attn_scale;
 };
 
-struct WPref {  // the first operand loads of this wave's first tile of the NEXT projection
-  float4 w[8];
+constexpr int kWB = 16;  // operand loads (16 bytes each, 16 k apart) a wave keeps in flight per block: 256 k of its K quarter
+struct WPref {           // the first block of this wave's first tile of the NEXT projection
+  float4 w[kWB];
 };
 
 __device__ __forceinline__ float act_of(float v, int act) {
@@ -74,38 +75,66 @@ __device__ __forceinline__ void prefetch_w(WPref& pf, const float* W, int K, int
   const float* wp = w_lane_ptr(W, K, N, blockIdx.x);
   const int nb = K >> 6;  // 16-deep operand groups of this wave's K quarter
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < kWB; ++j)
     if (j < nb) pf.w[j] = *reinterpret_cast<const float4*>(wp + 16 * j);
 }
 
 // rows of X [n][K] (written by other workgroups of this launch) -> xs [16][K + 4] in LDS, rows >= n zero; LN: normalised
+// (K <= 1 024 then).  A lane owns column pairs c = 2 tid + 512 j of EVERY row: 32 eight-byte agent-scope loads in flight per
+// lane and pass (one pass for K <= 1 024).  Issued one by one they cost a round trip each -- the first version of this kernel
+// spent most of its 800 us per step there (profiles/r05_b_*).
 template <bool LN>
 __device__ __forceinline__ void stage_rows(const PStepArgs& a, float* xs, const float* X, int K) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, KP = K + 4;
   __syncthreads();  // (the previous user of this LDS region is done)
-  for (int idx = 2 * tid; idx < kPRows * K; idx += 512) {
-    const int row = idx / K, c = idx - row * K;
-    float2 v = make_float2(0.0f, 0.0f);
-    if (row < a.n) v = sbk::ld_agent2(X + (size_t)row * K + c);
-    xs[row * KP + c] = v.x;
-    xs[row * KP + c + 1] = v.y;
+  for (int c0 = 2 * tid; c0 < K; c0 += 1024) {
+    float2 v[2][kPRows];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + 512 * j;
+#pragma unroll
+      for (int r = 0; r < kPRows; ++r) {
+        v[j][r] = make_float2(0.0f, 0.0f);
+        if (c < K && r < a.n) v[j][r] = sbk::ld_agent2(X + (size_t)r * K + c);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + 512 * j;
+      if (c < K) {
+#pragma unroll
+        for (int r = 0; r < kPRows; ++r) {
+          xs[r * KP + c] = v[j][r].x;
+          xs[r * KP + c + 1] = v[j][r].y;
+        }
+      }
+    }
   }
   __syncthreads();
-  if (LN) {
-    for (int r = 0; r < 4; ++r) {
-      const int row = wave * 4 + r;
-      if (row >= a.n) continue;  // (uniform per wave)
+  if (LN) {  // rows wave, wave + 4, ...: the row in registers (K / 64 <= 16 values per lane), two-pass statistics
+    for (int row = wave; row < a.n; row += 4) {
       float* xr = xs + row * KP;
-      float s = 0.0f;
-      for (int c = lane; c < K; c += 64) s += xr[c];
-      const float mean = sbk::wave_sum(s) / (float)K;
+      float xv[16];
+      float sm = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int c = lane + 64 * e;
+        xv[e] = c < K ? xr[c] : 0.0f;
+        sm += xv[e];
+      }
+      const float mean = sbk::wave_sum(sm) / (float)K;
       float qs = 0.0f;
-      for (int c = lane; c < K; c += 64) {
-        const float dv = xr[c] - mean;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float dv = (lane + 64 * e) < K ? xv[e] - mean : 0.0f;
         qs += dv * dv;
       }
       const float rstd = rsqrtf(sbk::wave_sum(qs) / (float)K + a.eps);
-      for (int c = lane; c < K; c += 64) xr[c] = (xr[c] - mean) * rstd;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int c = lane + 64 * e;
+        if (c < K) xr[c] = (xv[e] - mean) * rstd;
+      }
     }
     __syncthreads();
   }
@@ -119,44 +148,60 @@ __device__ __forceinline__ void tiles_gemm(const PStepArgs& a, const float* xs, 
   const float* xa = xs + (lane & 15) * KP + wave * (K >> 2) + 4 * (lane >> 4);
   for (int tile = blockIdx.x; tile < ntiles; tile += G) {
     const float* wp = w_lane_ptr(W, K, N, tile);
-    sbk::f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int jb = 0; jb < nb; jb += 8) {
-      float4 w[8];
-      if (jb == 0 && tile == (int)blockIdx.x) {
+    const int row = tid >> 4, col = tile * 16 + (tid & 15);
+    const bool out_ok = row < a.n && col < N;
+    float rv = 0.0f;
+    if (R && out_ok) rv = sbk::ld_agent(R + (size_t)row * N + col);  // (in flight under the products)
+    float4 wc[kWB];
+    if (tile == (int)blockIdx.x) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = pf.w[j];
-      } else {
+      for (int j = 0; j < kWB; ++j) wc[j] = pf.w[j];
+    } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (jb + j < nb) w[j] = *reinterpret_cast<const float4*>(wp + 16 * (jb + j));
+      for (int j = 0; j < kWB; ++j)
+        if (j < nb) wc[j] = *reinterpret_cast<const float4*>(wp + 16 * j);
+    }
+    // four independent accumulation chains (one per element of the 16-byte operands): a single chain would serialise
+    // K / 16 dependent MFMAs per wave
+    sbk::f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
+    for (int jb = 0; jb < nb; jb += kWB) {
+      float4 wn[kWB];
+      if (jb + kWB < nb) {  // the next block's operands fly under this block's products
+#pragma unroll
+        for (int j = 0; j < kWB; ++j)
+          if (jb + kWB + j < nb) wn[j] = *reinterpret_cast<const float4*>(wp + 16 * (jb + kWB + j));
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < kWB; ++j) {
         if (jb + j < nb) {
           const float4 x4 = *reinterpret_cast<const float4*>(xa + 16 * (jb + j));
-          acc = sbk::mfma_16x16x4(x4.x, w[j].x, acc);
-          acc = sbk::mfma_16x16x4(x4.y, w[j].y, acc);
-          acc = sbk::mfma_16x16x4(x4.z, w[j].z, acc);
-          acc = sbk::mfma_16x16x4(x4.w, w[j].w, acc);
+          a0 = sbk::mfma_16x16x4(x4.x, wc[j].x, a0);
+          a1 = sbk::mfma_16x16x4(x4.y, wc[j].y, a1);
+          a2 = sbk::mfma_16x16x4(x4.z, wc[j].z, a2);
+          a3 = sbk::mfma_16x16x4(x4.w, wc[j].w, a3);
         }
+      }
+      if (jb + kWB < nb) {
+#pragma unroll
+        for (int j = 0; j < kWB; ++j) wc[j] = wn[j];
       }
     }
     __syncthreads();  // (red free again)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+    for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = (a0[r] + a1[r]) + (a2[r] + a3[r]);
     __syncthreads();
-    const int row = tid >> 4, col = tile * 16 + (tid & 15);
-    if (row < a.n && col < N) {
+    if (out_ok) {
       float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
-      v = act_of(v + (bias ? bias[col] : 0.0f), act);
-      if (R) v += sbk::ld_agent(R + (size_t)row * N + col);
+      v = act_of(v + (bias ? bias[col] : 0.0f), act) + rv;
       sbk::st_agent(C + (size_t)row * N + col, v);
     }
   }
 }
 
-// one wave: hypothesis row i, head h (head_dim 64) over the KV cache -- self_attn_step_kernel's walk with coherent I/O
-__device__ __forceinline__ void self_attn_item(const PStepArgs& a, const PLayer& L, float* prob, int* slot, int i, int h) {
+// one wave: hypothesis row i, head h (head_dim 64) over the KV cache (layout of self_attn_step_kernel: rows [slot][pos][d],
+// ancestry table kv_slot[hyp][pos]).  64 positions per pass with every K and V row of the pass in flight at once (4 position
+// groups x 16 lanes x 16-byte pieces), softmax carried across passes as a running (max, sum, context).
+__device__ __forceinline__ void self_attn_item(const PStepArgs& a, const PLayer& L, int* slot, int i, int h) {
   const int lane = threadIdx.x & 63, pg = lane >> 4, cq = lane & 15, d = a.d, step = a.step, len = step + 1;
   const float* qp = a.qkv + (size_t)i * 3 * d + h * 64 + cq * 4;
   float4 q4, kn, vn;
@@ -168,63 +213,56 @@ __device__ __forceinline__ void self_attn_item(const PStepArgs& a, const PLayer&
     kn = make_float4(k0.x, k0.y, k1.x, k1.y);
     vn = make_float4(v0.x, v0.y, v1.x, v1.y);
   }
+  for (int p = lane; p < step; p += 64) slot[p] = a.kv_slot[(size_t)i * a.Lmax + p];
   if (pg == 0) {  // append this token's K / V head slice (slot = hypothesis index); read by LATER launches only
     const size_t o = ((size_t)i * a.Lmax + step) * d + h * 64 + cq * 4;
     *reinterpret_cast<float4*>(L.kcache + o) = kn;
     *reinterpret_cast<float4*>(L.vcache + o) = vn;
   }
-  for (int p = lane; p < step; p += 64) slot[p] = a.kv_slot[(size_t)i * a.Lmax + p];
   sbk::wave_sync();
   const size_t hoff = (size_t)h * 64 + cq * 4;
-  for (int p0 = 0; p0 < len; p0 += 16) {
-    float4 kv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int p = p0 + 4 * u + pg;
-      kv[u] = p < step ? *reinterpret_cast<const float4*>(L.kcache + ((size_t)slot[p] * a.Lmax + p) * d + hoff) : kn;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float s = (q4.x * kv[u].x + q4.y * kv[u].y) + (q4.z * kv[u].z + q4.w * kv[u].w);
-      s += sbk::shfl_xor(s, 1);
-      s += sbk::shfl_xor(s, 2);
-      s += sbk::shfl_xor(s, 4);
-      s += sbk::shfl_xor(s, 8);
-      const int p = p0 + 4 * u + pg;
-      if (p < len && cq == 0) prob[p] = s;
-    }
-  }
-  sbk::wave_sync();
-  float m = -INFINITY;
-  for (int p = lane; p < len; p += 64) m = fmaxf(m, prob[p]);
-  m = sbk::wave_max(m);
-  float sum = 0.0f;
-  for (int p = lane; p < len; p += 64) {
-    const float e = expf(prob[p] - m);
-    prob[p] = e;
-    sum += e;
-  }
-  sum = sbk::wave_sum(sum);
-  for (int p = lane; p < len; p += 64) prob[p] = prob[p] / sum;
-  sbk::wave_sync();
+  float m = -INFINITY, l = 0.0f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int p0 = 0; p0 < len; p0 += 16) {
-    float4 vv[4];
-    float w[4];
+  for (int c0 = 0; c0 < len; c0 += 64) {
+    float4 kk[16], vv[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int p = p0 + 4 * u + pg;
-      vv[u] = p < step ? *reinterpret_cast<const float4*>(L.vcache + ((size_t)slot[p] * a.Lmax + p) * d + hoff) : vn;
-      w[u] = p < len ? prob[p] : 0.0f;
+    for (int g = 0; g < 16; ++g) {
+      const int p = c0 + 4 * g + pg;
+      kk[g] = kn;
+      vv[g] = vn;
+      if (p < step) {
+        const size_t o = ((size_t)slot[p] * a.Lmax + p) * d + hoff;
+        kk[g] = *reinterpret_cast<const float4*>(L.kcache + o);
+        vv[g] = *reinterpret_cast<const float4*>(L.vcache + o);
+      }
     }
+    float s[16];
+    float cm = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc.x = fmaf(w[u], vv[u].x, acc.x);
-      acc.y = fmaf(w[u], vv[u].y, acc.y);
-      acc.z = fmaf(w[u], vv[u].z, acc.z);
-      acc.w = fmaf(w[u], vv[u].w, acc.w);
+    for (int g = 0; g < 16; ++g) {
+      float sv = (q4.x * kk[g].x + q4.y * kk[g].y) + (q4.z * kk[g].z + q4.w * kk[g].w);
+      sv = sbk::group_sum<16>(sv);
+      s[g] = (c0 + 4 * g + pg) < len ? sv : -INFINITY;
+      cm = fmaxf(cm, s[g]);
     }
+    cm = fmaxf(cm, sbk::shfl_xor(cm, 16));
+    cm = fmaxf(cm, sbk::shfl_xor(cm, 32));  // (finite: position c0 < len is in this pass)
+    const float mn = fmaxf(m, cm), corr = expf(m - mn);
+    l *= corr;
+    acc.x *= corr; acc.y *= corr; acc.z *= corr; acc.w *= corr;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const float p = expf(s[g] - mn);
+      l += p;
+      acc.x = fmaf(p, vv[g].x, acc.x);
+      acc.y = fmaf(p, vv[g].y, acc.y);
+      acc.z = fmaf(p, vv[g].z, acc.z);
+      acc.w = fmaf(p, vv[g].w, acc.w);
+    }
+    m = mn;
   }
+  l += sbk::shfl_xor(l, 16);
+  l += sbk::shfl_xor(l, 32);
   float o[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -234,9 +272,9 @@ __device__ __forceinline__ void self_attn_item(const PStepArgs& a, const PLayer&
   if (pg == 0) {
     float* op = a.ctx + (size_t)i * d + hoff;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sbk::st_agent(op + e, o[e]);
+    for (int e = 0; e < 4; ++e) sbk::st_agent(op + e, o[e] / l);
   }
-  sbk::wave_sync();  // (prob / slot are reused by this wave's next item)
+  sbk::wave_sync();  // (slot is reused by this wave's next item)
 }
 
 // one workgroup: the beam rows of utterance u, head h (head_dim 64) over the utterance's memory
@@ -250,9 +288,15 @@ __device__ __forceinline__ void cross_attn_item(const PStepArgs& a, const PLayer
   int klen = a.enc_len[u];
   klen = klen < 1 ? 1 : (klen > a.T ? a.T : klen);
   __syncthreads();
-  for (int idx = tid; idx < kPRows * 64; idx += 256) {
-    const int j = idx >> 6, c = idx & 63;
-    qs[idx] = j < nq ? sbk::ld_agent(a.q + ((size_t)u * a.beam + j) * d + h * 64 + c) * a.attn_scale : 0.0f;
+  {
+    float qv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // (all four loads of a lane in flight)
+      const int idx = tid + 256 * r, j = idx >> 6, c = idx & 63;
+      qv[r] = j < nq ? sbk::ld_agent(a.q + ((size_t)u * a.beam + j) * d + h * 64 + c) * a.attn_scale : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) qs[tid + 256 * r] = qv[r];
   }
   __syncthreads();
   const float* kvb = L.ckv + (size_t)u * a.T * 2 * d + h * 64 + cq * 4;
@@ -283,10 +327,7 @@ __device__ __forceinline__ void cross_attn_item(const PStepArgs& a, const PLayer
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
           float sv = (q4.x * kk[g].x + q4.y * kk[g].y) + (q4.z * kk[g].z + q4.w * kk[g].w);
-          sv += sbk::shfl_xor(sv, 1);
-          sv += sbk::shfl_xor(sv, 2);
-          sv += sbk::shfl_xor(sv, 4);
-          sv += sbk::shfl_xor(sv, 8);
+          sv = sbk::group_sum<16>(sv);  // (DPP on the VALU: 160 of these per run and beam set)
           s[g] = (t0 + 4 * g + pg) < klen ? sv : -INFINITY;
           cm = fmaxf(cm, s[g]);
         }
@@ -367,7 +408,7 @@ __global__ void __launch_bounds__(256) decoder_step_persist_kernel(PStepArgs a) 
   int bar = a.bar_base;
   WPref pf;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) pf.w[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = 0; j < kWB; ++j) pf.w[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   // barrier in two halves: the next projection's first weight loads are issued between arrival and wait
 #define SBK_PSTEP_BARRIER(W_, K_, N_)            \
   do {                                           \
@@ -391,9 +432,8 @@ __global__ void __launch_bounds__(256) decoder_step_persist_kernel(PStepArgs a) 
     SBK_PSTEP_BARRIER(L.sa_out_w, d, d);
     {  // self-attention over the KV cache: a wave per (row, head)
       const int lpad = ((a.Lmax + 63) >> 6) << 6;
-      float* prob = xs + (size_t)wave * 2 * lpad;
-      int* slot = reinterpret_cast<int*>(prob + lpad);
-      for (int item = blockIdx.x * 4 + wave; item < a.n * a.H; item += G * 4) self_attn_item(a, L, prob, slot, item / a.H, item % a.H);
+      int* slot = reinterpret_cast<int*>(xs) + (size_t)wave * lpad;
+      for (int item = blockIdx.x * 4 + wave; item < a.n * a.H; item += G * 4) self_attn_item(a, L, slot, item / a.H, item % a.H);
     }
     SBK_PSTEP_BARRIER((const float*)nullptr, 0, 0);
     stage_rows<false>(a, xs, a.ctx, d);
@@ -447,7 +487,7 @@ int persist_barriers(int n_layers) { return 1 + 8 * n_layers; }
 bool persist_eligible(const sbk_decoder_weights* W, int n, int B, int beam, int Lmax) {
   if (!g_persist || n < 1 || n > kPRows || beam < 1 || beam > kPRows || B * beam != n) return false;
   const int d = W->d_model;
-  if (W->n_layers < 1 || W->n_layers > kMaxPLayers || W->nhead < 1 || d != W->nhead * 64 || d % 64 != 0 || W->d_ffn % 64 != 0) return false;
+  if (W->n_layers < 1 || W->n_layers > kMaxPLayers || W->nhead < 1 || d != W->nhead * 64 || d > 1024 || W->d_ffn % 64 != 0) return false;
   if (!W->emb || !W->pe || !W->final_ln_g || !W->final_ln_b) return false;
   if (W->seq_w && !(W->seq_wf && W->seq_bf && aligned16(W->seq_wf))) return false;
   for (int l = 0; l < W->n_layers; ++l) {

@@ -224,10 +224,14 @@ class ShardedTranscriber:
                             buf.record_stream(copy_stream)
                         own = {"buf": buf, "ev": None, "landed": threading.Event()}
 
-                        def ready(o=own):
+                        def ready(o=own, staging_thread=threading.get_ident()):
                             # the batch is staged by _stage_all on another thread of control: wait for the copy to have
                             # been ENQUEUED (host), then order the consumer's stream after it and record the stream as
-                            # a user of the block (the caching allocator must not hand it out while kernels read it)
+                            # a user of the block (the caching allocator must not hand it out while kernels read it).
+                            # A caller that consumes the local list itself, without run_local, calls ready() on the very
+                            # thread that would have staged: stage now instead of waiting for nobody
+                            if not o["landed"].is_set() and threading.get_ident() == staging_thread and getattr(self, "_staging", None):
+                                self._stage_all()
                             o["landed"].wait()
                             if o.get("error") is not None:
                                 raise RuntimeError("the batch was never staged") from o["error"]

@@ -47,6 +47,16 @@ class ConcurrentTranscriber:
         self.balance_tail = True
         self.plan_workers = self.n  # workers the group sizes are planned for (a one-worker replay of an eight-worker job sets 8)
 
+    def close(self):
+        """Stop the worker threads and return what the streams of this transcriber pinned in the library (one registered
+        workspace per stream that issued an op: native.release_stream_workspace).  The object must not be used afterwards."""
+        self.pool.shutdown(wait=True)
+        if self.device.type == "cuda":
+            from speechbrain_amd import native
+
+            for st in list(self.enc_streams) + [d for d in self.dec_streams if d is not None]:
+                native.release_stream_workspace(st)
+
     def _one(self, slot: int, wavs, wav_lens, prepare: Optional[Callable], ready: Optional[Callable] = None):
         searcher = self.searchers[slot]
         if prepare is not None:
@@ -146,17 +156,21 @@ class ConcurrentTranscriber:
                 if not ks:
                     return out
                 run(ks)
-        torch.cuda.set_device(self.device)  # the current device is per host thread
-        with torch.cuda.stream(self.enc_streams[slot]):
-            while True:
-                ks = take()
-                if not ks:
-                    break
-                run(ks)
-            self.enc_streams[slot].synchronize()
         from speechbrain_amd import native
 
-        native.release_search_workspaces()  # (this thread's grow-only search buffer: the next job may run the slot on another thread)
+        torch.cuda.set_device(self.device)  # the current device is per host thread
+        try:
+            with torch.cuda.stream(self.enc_streams[slot]):
+                while True:
+                    ks = take()
+                    if not ks:
+                        break
+                    run(ks)
+                self.enc_streams[slot].synchronize()
+        finally:
+            # this thread's grow-only search buffer: the next job may run the slot on another thread -- also when a batch raised
+            # (a failing worker kept its multi-GB buffer)
+            native.release_search_workspaces()
         return out
 
     def transcribe_batches(self, batches: Sequence[Tuple[torch.Tensor, torch.Tensor]],

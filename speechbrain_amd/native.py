@@ -214,9 +214,28 @@ def _register_workspace(key, device, handle):
         nbytes = lib.sbk_stream_workspace_bytes()
         ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
         off = (-ws.data_ptr()) % 256
-        _chk(lib.sbk_stream_workspace_set(c_void_p(handle) if handle is not None else None, c_void_p(ws.data_ptr() + off), nbytes),
-             "sbk_stream_workspace_set")
+        # the library keys its table on hipGetDevice(): make the tensor's device the current one for the call
+        ctx = torch.cuda.device(device) if getattr(device, "type", None) == "cuda" else contextlib.nullcontext()
+        with ctx:
+            _chk(lib.sbk_stream_workspace_set(c_void_p(handle) if handle is not None else None, c_void_p(ws.data_ptr() + off), nbytes),
+                 "sbk_stream_workspace_set")
         _STREAM_WS[key] = ws
+
+
+def release_stream_workspace(stream) -> bool:
+    """Give back the workspace registered for a ``torch.cuda.Stream`` that will not be used again (a worker stream of a
+    ConcurrentTranscriber that is being closed): sbk_stream_workspace_release, then the ~134 MB return to torch's allocator once
+    the stream has drained.  Streams that never issued an op have none (False)."""
+    lib = load()
+    key = (id(lib), stream.device.index, stream.cuda_stream)
+    with _STREAM_WS_LOCK:
+        ws = _STREAM_WS.pop(key, None)
+        if ws is None:
+            return False
+        stream.synchronize()
+        with torch.cuda.device(stream.device):
+            _chk(lib.sbk_stream_workspace_release(c_void_p(stream.cuda_stream)), "sbk_stream_workspace_release")
+    return True
 
 
 def _stream(t: torch.Tensor):

@@ -65,6 +65,70 @@ def test_scatter_gather_world2(tmp_path, world):
     assert sum(counts.values()) == 23 and min(counts.values()) >= 4  # every rank did real work
 
 
+def _worker_variant(rank, world, tmpdir, q, variant):
+    import speechbrain_amd.inference.sharded as sharded
+
+    os.environ["RANK"], os.environ["LOCAL_RANK"], os.environ["WORLD_SIZE"] = str(rank), str(rank), str(world)
+    dist.init_process_group("gloo", init_method=f"file://{tmpdir}/sync", rank=rank, world_size=world)
+    try:
+        wavs = make_job() if rank == 0 else None
+        if variant == "rank0_idle":  # the plan gives rank 0 NO batch: it only stages and sends (from gather's drain)
+            lpt = sharded.assign_batches
+
+            def peers_only(costs, w):
+                out = lpt(costs, w - 1)
+                return [[]] + out
+
+            sharded.assign_batches = peers_only
+        st = ShardedTranscriber(fake_transcribe, "cpu", max_utts=4)
+        local = st.scatter(wavs)
+        n_local = sum(len(t[0]) for t in local)
+        if variant == "last_first" and rank != 0:
+            # a consumer that asks for the batch that arrives LAST first (a worker pool is free to): every receive was posted
+            # in distribute(), so waiting out of order must neither deadlock nor mix the buffers up
+            results = []
+            for t in reversed(local):
+                t[3]()
+                results.extend(zip(t[0], fake_transcribe(t[1], t[2])))
+            hyps = st.gather(results)
+        elif variant == "last_first":
+            # rank 0 consumes its own list directly, without run_local: ready() stages on the calling thread
+            results = []
+            for t in reversed(local):
+                t[3]()
+                results.extend(zip(t[0], fake_transcribe(t[1], t[2])))
+            hyps = st.gather(results)
+        else:
+            hyps = st.gather(st.run_local(local))
+        if rank == 0:
+            q.put(("hyps", hyps))
+        q.put(("count", rank, n_local))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant", ["rank0_idle", "last_first"])
+def test_scatter_edge_cases_world3(tmp_path, variant):
+    """(a) rank 0 owns no local batch -- it pads and sends everyone else's while idle itself; (b) consumers
+    take their batches in the reverse of the arrival order, rank 0 directly from distribute()'s list without run_local."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_variant, args=(r, world, str(tmp_path), q, variant)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world + 1)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    hyps = [g[1] for g in got if g[0] == "hyps"][0]
+    counts = {g[1]: g[2] for g in got if g[0] == "count"}
+    assert hyps == expected(make_job())
+    assert sum(counts.values()) == 23
+    if variant == "rank0_idle":
+        assert counts[0] == 0 and min(counts[1], counts[2]) >= 4
+
+
 def test_single_process_path():
     st = ShardedTranscriber(fake_transcribe, "cpu", max_utts=5)
     wavs = make_job(11, seed=9)

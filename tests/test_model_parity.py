@@ -693,8 +693,17 @@ def test_concurrent_transcriber_matches_sequential(backend):
             wav[i, int(lens[i] * n):] = 0
         batches.append((wav.to(dev), lens.to(dev)))
     ref = [asr.transcribe_batch(w, l)[1] for w, l in batches]
-    got = ConcurrentTranscriber(asr, streams=3).transcribe_batches(batches)
+    ct = ConcurrentTranscriber(asr, streams=3)
+    got = ct.transcribe_batches(batches)
     assert got == ref
+    if dev.type == "cuda":  # close(): the workers' streams give their registered library workspaces back
+        keys = [(id(nat.load()), s.device.index, s.cuda_stream) for s in ct.enc_streams + [d for d in ct.dec_streams if d is not None]]
+        assert any(k in nat._STREAM_WS for k in keys)
+        ct.close()
+        assert not any(k in nat._STREAM_WS for k in keys)
+        assert ConcurrentTranscriber(asr, streams=3).transcribe_batches(batches) == ref  # (fresh streams register again)
+    else:
+        ct.close()
     seen = []
     got2 = ConcurrentTranscriber(asr, streams=2, prioritise_search=False).transcribe_batches(
         batches, prepare=lambda searcher, wavs: seen.append(wavs.shape[1]))
