@@ -320,10 +320,18 @@ def whisper_encoder_leg(dev, B=8, reps=3):
     cfg = dict(num_mel_bins=128, d_model=1280, encoder_layers=32, encoder_attention_heads=20, encoder_ffn_dim=5120,
                max_source_positions=1500, decoder_layers=0, decoder_attention_heads=20, decoder_ffn_dim=5120,
                vocab_size=51866, max_target_positions=448)
+    from speechbrain_amd.inference.ASR import WhisperASR
+
     w = Whisper.from_config(cfg, encoder_only=True).to(dev).eval()
     wav = 0.1 * torch.randn(B, 480000, generator=torch.Generator().manual_seed(3))
     wav = wav.to(dev)
-    res = {"workload": f"log-mel + Whisper large-v3 encoder forward, {B} x 30 s, random weights, one stream",
+    lens = torch.ones(B)
+
+    def interface(prec):  # BASELINE configs[4] "via speechbrain.inference": the precision is the interface's run_opts
+        return WhisperASR(modules={"whisper": w, "decoder": torch.nn.Identity()},
+                          hparams={"language": "en", "sample_rate": 16000, "whisper": w}, run_opts={"device": str(dev), "precision": prec})
+
+    res = {"workload": f"WhisperASR(run_opts precision=...).encode_batch = log-mel + Whisper large-v3 encoder forward, {B} x 30 s, random weights, one stream",
            "precisions": "operand type of the GEMMs (fp32 accumulation everywhere): fp32 = parity path; bf16 = bf16 activations "
                          "between the contractions (LayerNorm / attention / GELU epilogue write bf16, LDS-DMA bf16 GEMM, "
                          "attention with K / V^T tiles shared through LDS; residual stream fp32); fp8 = e4m3 activations between the "
@@ -333,19 +341,27 @@ def whisper_encoder_leg(dev, B=8, reps=3):
                          "on load; fp8_fp32_activations = the round-3 fp8 path (per-tensor scales, activation max |x| per GEMM)"}
     flops = B * 32 * (1500 * 2.0 * (4 * 1280 * 1280 + 2 * 1280 * 5120) + 4.0 * 1500 * 1500 * 1280) \
         + B * 2.0 * (3000 * 1280 * 384 + 1500 * 1280 * 3840)
+    ref = None
     for prec in ("fp32", "bf16", "fp16", "fp8", "fp8_fp32_activations"):
         native.FP8_ACTIVATIONS = prec != "fp8_fp32_activations"
-        with native.precision_scope(prec.split("_")[0]):
-            w.forward_encoder(w._get_mel(wav))
+        asr_w = interface(prec.split("_")[0])
+        with torch.no_grad():
+            out = asr_w.encode_batch(wav, lens)
             torch.cuda.synchronize()
             t = time.perf_counter()
             for _ in range(reps):
-                w.forward_encoder(w._get_mel(wav))
+                asr_w.encode_batch(wav, lens)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t) / reps
         res[prec] = {"ms_per_batch": round(1000.0 * dt, 2), "audio_sec_per_s": round(B * 30.0 / dt, 1),
                      "tflops": round(flops / dt / 1e12, 1)}
+        if ref is None:
+            ref = out
+        else:  # (32 layers: the tolerance tests/test_full_size_gpu.py asserts at this depth)
+            res[prec]["relative_rms_vs_fp32"] = round(float((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()), 5)
+        del out
     native.FP8_ACTIVATIONS = True
+    del ref
     del w
     torch.cuda.empty_cache()
     return res

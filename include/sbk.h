@@ -60,6 +60,11 @@ size_t sbk_prof_report(char* buf, size_t cap);
 int sbk_prof_gemm_repeat_f32(const float* A, const float* W, float* C, int M, int N, int K, float* workspace,
                              size_t workspace_floats, int iters, float* us_per_launch, sbk_stream_t stream);
 
+/* Measurement: phase time stamps (100 MHz ticks) of the most recent persistent few-row decoding step launched with knob 49 set
+ * (csrc/decoder_persist.hip): [start, (end of phase, end of barrier) x barriers, end] of workgroup 0.  Synchronises the device;
+ * returns the number of stamps written to the HOST array `out`.  tools/latency_probe.py --stamps prints them. */
+int sbk_prof_persist_stamps(long long* out, int cap);
+
 /* tuning knobs for experiments (key 1: K chunks per fetch batch of the skinny GEMM, 0 = automatic) */
 void sbk_prof_set_knob(int key, int value);
 /* HBM calibration (SURVEY 8d "measure achievable with a copy kernel first"): hand-written float4 streaming kernels.

@@ -41,6 +41,7 @@ struct PStepArgs {
   const float *emb, *pe_row;
   float *x, *qkv, *ctx, *q, *ff, *h, *logits;
   const float *fin_g, *fin_b, *seq_wf, *seq_bf;
+  long long* stamps;  // optional (knob 49): workgroup 0 writes the 100 MHz wall clock at the end of every phase and barrier
   int* bar;      // arrival counter of the grid barriers (monotonic over the launches of a search)
   int bar_base;  // its value when this launch starts
   int n, B, T, beam, d, H, dffn, V, nl, step, Lmax, act, want_logits;
@@ -111,30 +112,36 @@ __device__ __forceinline__ void stage_rows(const PStepArgs& a, float* xs, const 
     }
   }
   __syncthreads();
-  if (LN) {  // rows wave, wave + 4, ...: the row in registers (K / 64 <= 16 values per lane), two-pass statistics
-    for (int row = wave; row < a.n; row += 4) {
-      float* xr = xs + row * KP;
-      float xv[16];
-      float sm = 0.0f;
+  if (LN) {
+    // a row per 16-lane group (wave w, group g: row 4 w + g), 16-byte pieces c = 4 cq + 64 e in registers, sums over the group on
+    // the VALU (DPP): all sixteen rows at once.  (A row per wave with wave-wide reductions took ~6 us of dependent latency per
+    // phase at one wave per SIMD: profiles/r05_d_*.)
+    const int row = 4 * wave + (lane >> 4), cq = lane & 15;
+    float* xr = xs + row * KP + 4 * cq;
+    float4 xv[16];
+    float sm = 0.0f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int c = lane + 64 * e;
-        xv[e] = c < K ? xr[c] : 0.0f;
-        sm += xv[e];
-      }
-      const float mean = sbk::wave_sum(sm) / (float)K;
-      float qs = 0.0f;
+    for (int e = 0; e < 16; ++e) {
+      xv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (64 * e < K) xv[e] = *reinterpret_cast<const float4*>(xr + 64 * e);
+      sm += (xv[e].x + xv[e].y) + (xv[e].z + xv[e].w);
+    }
+    const float mean = sbk::group_sum<16>(sm) / (float)K;
+    float qs = 0.0f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float dv = (lane + 64 * e) < K ? xv[e] - mean : 0.0f;
-        qs += dv * dv;
+    for (int e = 0; e < 16; ++e) {
+      if (64 * e < K) {
+        const float d0 = xv[e].x - mean, d1 = xv[e].y - mean, d2 = xv[e].z - mean, d3 = xv[e].w - mean;
+        qs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       }
-      const float rstd = rsqrtf(sbk::wave_sum(qs) / (float)K + a.eps);
+    }
+    const float rstd = rsqrtf(sbk::group_sum<16>(qs) / (float)K + a.eps);
+    if (row < a.n) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int c = lane + 64 * e;
-        if (c < K) xr[c] = (xv[e] - mean) * rstd;
-      }
+      for (int e = 0; e < 16; ++e)
+        if (64 * e < K)
+          *reinterpret_cast<float4*>(xr + 64 * e) = make_float4((xv[e].x - mean) * rstd, (xv[e].y - mean) * rstd, (xv[e].z - mean) * rstd,
+                                                                (xv[e].w - mean) * rstd);
     }
     __syncthreads();
   }
@@ -146,21 +153,17 @@ __device__ __forceinline__ void tiles_gemm(const PStepArgs& a, const float* xs, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, KP = K + 4, G = gridDim.x;
   const int ntiles = (N + 15) >> 4, nb = K >> 6;
   const float* xa = xs + (lane & 15) * KP + wave * (K >> 2) + 4 * (lane >> 4);
+  float4 wc[kWB];
   for (int tile = blockIdx.x; tile < ntiles; tile += G) {
     const float* wp = w_lane_ptr(W, K, N, tile);
     const int row = tid >> 4, col = tile * 16 + (tid & 15);
     const bool out_ok = row < a.n && col < N;
     float rv = 0.0f;
     if (R && out_ok) rv = sbk::ld_agent(R + (size_t)row * N + col);  // (in flight under the products)
-    float4 wc[kWB];
     if (tile == (int)blockIdx.x) {
 #pragma unroll
       for (int j = 0; j < kWB; ++j) wc[j] = pf.w[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < kWB; ++j)
-        if (j < nb) wc[j] = *reinterpret_cast<const float4*>(wp + 16 * j);
-    }
+    }  // (a later tile: wc was loaded under the previous tile's reduction, below)
     // four independent accumulation chains (one per element of the 16-byte operands): a single chain would serialise
     // K / 16 dependent MFMAs per wave
     sbk::f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
@@ -186,6 +189,12 @@ __device__ __forceinline__ void tiles_gemm(const PStepArgs& a, const float* xs, 
         for (int j = 0; j < kWB; ++j) wc[j] = wn[j];
       }
     }
+    if (tile + G < ntiles) {  // the next tile's first block flies under this tile's reduction and stores
+      const float* wq = w_lane_ptr(W, K, N, tile + G);
+#pragma unroll
+      for (int j = 0; j < kWB; ++j)
+        if (j < nb) wc[j] = *reinterpret_cast<const float4*>(wq + 16 * j);
+    }
     __syncthreads();  // (red free again)
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = (a0[r] + a1[r]) + (a2[r] + a3[r]);
@@ -198,60 +207,89 @@ __device__ __forceinline__ void tiles_gemm(const PStepArgs& a, const float* xs, 
   }
 }
 
-// one wave: hypothesis row i, head h (head_dim 64) over the KV cache (layout of self_attn_step_kernel: rows [slot][pos][d],
-// ancestry table kv_slot[hyp][pos]).  64 positions per pass with every K and V row of the pass in flight at once (4 position
-// groups x 16 lanes x 16-byte pieces), softmax carried across passes as a running (max, sum, context).
-__device__ __forceinline__ void self_attn_item(const PStepArgs& a, const PLayer& L, int* slot, int i, int h) {
-  const int lane = threadIdx.x & 63, pg = lane >> 4, cq = lane & 15, d = a.d, step = a.step, len = step + 1;
-  const float* qp = a.qkv + (size_t)i * 3 * d + h * 64 + cq * 4;
-  float4 q4, kn, vn;
-  {
+// One workgroup: hypothesis row i, head h (head_dim 64).  SELF: over the KV cache (layout of self_attn_step_kernel: rows
+// [slot][pos][d], ancestry table kv_slot[hyp][pos]; the new token's K / V come from qkv and are appended), 64 positions per pass;
+// otherwise over the utterance's encoder memory ([T][2d]: K then V), 256 frames per pass.  A pass is split over the four waves,
+// a wave's lanes are 4 position groups x 16 lanes x 16-byte pieces of the head row, and EVERY K and V row of the pass is in
+// flight before any arithmetic.  Softmax as a running (max, sum, context) per wave, the four waves merged through LDS.
+// (One wave per item with all beams took 27 us per cross-attention phase -- a lone wave issues an instruction every four cycles:
+// profiles/r05_d_*; spreading rows x heads over the workgroups divides the instruction stream of a wave by ~20.)
+template <bool SELF>
+__device__ __forceinline__ void attn_item(const PStepArgs& a, const PLayer& L, float* lds, int i, int h) {
+  constexpr int GPW = SELF ? 4 : 16;            // position groups of four per wave and pass
+  constexpr int PASS = 4 * 4 * GPW;              // positions per pass of the workgroup
+  float* wm = lds;                               // [4] running maxima of the waves
+  float* wl = lds + 4;                           // [4] their sums
+  float* wacc = lds + 8;                         // [4][64] their un-normalised contexts
+  int* slot = reinterpret_cast<int*>(lds + 8 + 256);  // SELF: [step] cache slots of this row's prefix
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pg = lane >> 4, cq = lane & 15, d = a.d;
+  const size_t hoff = (size_t)h * 64 + cq * 4;
+  float4 q4, kn = make_float4(0.f, 0.f, 0.f, 0.f), vn = kn;
+  int len;
+  const float* mem = nullptr;
+  __syncthreads();  // (the previous item's merge has read the LDS)
+  if (SELF) {
+    const float* qp = a.qkv + (size_t)i * 3 * d + hoff;
     const float2 q0 = sbk::ld_agent2(qp), q1 = sbk::ld_agent2(qp + 2);
     const float2 k0 = sbk::ld_agent2(qp + d), k1 = sbk::ld_agent2(qp + d + 2);
     const float2 v0 = sbk::ld_agent2(qp + 2 * d), v1 = sbk::ld_agent2(qp + 2 * d + 2);
+    for (int p = tid; p < a.step; p += 256) slot[p] = a.kv_slot[(size_t)i * a.Lmax + p];
     q4 = make_float4(q0.x * a.attn_scale, q0.y * a.attn_scale, q1.x * a.attn_scale, q1.y * a.attn_scale);
     kn = make_float4(k0.x, k0.y, k1.x, k1.y);
     vn = make_float4(v0.x, v0.y, v1.x, v1.y);
+    len = a.step + 1;
+    if (wave == 0 && pg == 0) {  // append this token's K / V head slice (slot = hypothesis index); read by LATER launches only
+      const size_t o = ((size_t)i * a.Lmax + a.step) * d + hoff;
+      *reinterpret_cast<float4*>(L.kcache + o) = kn;
+      *reinterpret_cast<float4*>(L.vcache + o) = vn;
+    }
+    __syncthreads();
+  } else {
+    const float* qp = a.q + (size_t)i * d + hoff;
+    const float2 q0 = sbk::ld_agent2(qp), q1 = sbk::ld_agent2(qp + 2);
+    q4 = make_float4(q0.x * a.attn_scale, q0.y * a.attn_scale, q1.x * a.attn_scale, q1.y * a.attn_scale);
+    const int u = i / a.beam;
+    int klen = a.enc_len[u];
+    len = klen < 1 ? 1 : (klen > a.T ? a.T : klen);
+    mem = L.ckv + (size_t)u * a.T * 2 * d + hoff;
   }
-  for (int p = lane; p < step; p += 64) slot[p] = a.kv_slot[(size_t)i * a.Lmax + p];
-  if (pg == 0) {  // append this token's K / V head slice (slot = hypothesis index); read by LATER launches only
-    const size_t o = ((size_t)i * a.Lmax + step) * d + h * 64 + cq * 4;
-    *reinterpret_cast<float4*>(L.kcache + o) = kn;
-    *reinterpret_cast<float4*>(L.vcache + o) = vn;
-  }
-  sbk::wave_sync();
-  const size_t hoff = (size_t)h * 64 + cq * 4;
   float m = -INFINITY, l = 0.0f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int c0 = 0; c0 < len; c0 += 64) {
-    float4 kk[16], vv[16];
+  for (int c0 = wave * 4 * GPW; c0 < len; c0 += PASS) {
+    float4 kk[GPW], vv[GPW];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < GPW; ++g) {
       const int p = c0 + 4 * g + pg;
-      kk[g] = kn;
-      vv[g] = vn;
-      if (p < step) {
-        const size_t o = ((size_t)slot[p] * a.Lmax + p) * d + hoff;
-        kk[g] = *reinterpret_cast<const float4*>(L.kcache + o);
-        vv[g] = *reinterpret_cast<const float4*>(L.vcache + o);
+      if (SELF) {
+        kk[g] = kn;
+        vv[g] = vn;
+        if (p < a.step) {
+          const size_t o = ((size_t)slot[p] * a.Lmax + p) * d + hoff;
+          kk[g] = *reinterpret_cast<const float4*>(L.kcache + o);
+          vv[g] = *reinterpret_cast<const float4*>(L.vcache + o);
+        }
+      } else {
+        const float* rp = mem + (size_t)(p < len ? p : c0) * 2 * d;
+        kk[g] = *reinterpret_cast<const float4*>(rp);
+        vv[g] = *reinterpret_cast<const float4*>(rp + d);
       }
     }
-    float s[16];
+    float s[GPW];
     float cm = -INFINITY;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < GPW; ++g) {
       float sv = (q4.x * kk[g].x + q4.y * kk[g].y) + (q4.z * kk[g].z + q4.w * kk[g].w);
       sv = sbk::group_sum<16>(sv);
       s[g] = (c0 + 4 * g + pg) < len ? sv : -INFINITY;
       cm = fmaxf(cm, s[g]);
     }
     cm = fmaxf(cm, sbk::shfl_xor(cm, 16));
-    cm = fmaxf(cm, sbk::shfl_xor(cm, 32));  // (finite: position c0 < len is in this pass)
+    cm = fmaxf(cm, sbk::shfl_xor(cm, 32));  // (finite: position c0 < len belongs to this wave's share of the pass)
     const float mn = fmaxf(m, cm), corr = expf(m - mn);
     l *= corr;
     acc.x *= corr; acc.y *= corr; acc.z *= corr; acc.w *= corr;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < GPW; ++g) {
       const float p = expf(s[g] - mn);
       l += p;
       acc.x = fmaf(p, vv[g].x, acc.x);
@@ -270,138 +308,38 @@ __device__ __forceinline__ void self_attn_item(const PStepArgs& a, const PLayer&
     o[e] += sbk::shfl_xor(o[e], 32);
   }
   if (pg == 0) {
-    float* op = a.ctx + (size_t)i * d + hoff;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) sbk::st_agent(op + e, o[e] / l);
-  }
-  sbk::wave_sync();  // (slot is reused by this wave's next item)
-}
-
-// one workgroup: the beam rows of utterance u, head h (head_dim 64) over the utterance's memory
-__device__ __forceinline__ void cross_attn_item(const PStepArgs& a, const PLayer& L, float* lds, int u, int h) {
-  float* qs = lds;           // [16][64] scaled queries
-  float* wm = qs + 1024;     // [4][16] running maxima of the waves
-  float* wl = wm + 64;       // [4][16] their sums
-  float* wacc = wl + 64;     // [4][16][64] their un-normalised contexts
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pg = lane >> 4, cq = lane & 15;
-  const int d = a.d, nq = a.beam;
-  int klen = a.enc_len[u];
-  klen = klen < 1 ? 1 : (klen > a.T ? a.T : klen);
-  __syncthreads();
-  {
-    float qv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {  // (all four loads of a lane in flight)
-      const int idx = tid + 256 * r, j = idx >> 6, c = idx & 63;
-      qv[r] = j < nq ? sbk::ld_agent(a.q + ((size_t)u * a.beam + j) * d + h * 64 + c) * a.attn_scale : 0.0f;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) qs[tid + 256 * r] = qv[r];
-  }
-  __syncthreads();
-  const float* kvb = L.ckv + (size_t)u * a.T * 2 * d + h * 64 + cq * 4;
-  float m[kPRows], l[kPRows];
-  float4 acc[kPRows];
-#pragma unroll
-  for (int j = 0; j < kPRows; ++j) {
-    m[j] = -INFINITY;
-    l[j] = 0.0f;
-    acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  for (int t0 = wave * 64; t0 < klen; t0 += 256) {
-    float4 kk[16], vv[16];
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {  // every K and V row of the run in flight before any arithmetic
-      const int t = t0 + 4 * g + pg;
-      const bool ok = t < klen;
-      const float* rp = kvb + (size_t)(ok ? t : t0) * 2 * d;
-      kk[g] = *reinterpret_cast<const float4*>(rp);
-      vv[g] = *reinterpret_cast<const float4*>(rp + d);
-    }
-#pragma unroll
-    for (int j = 0; j < kPRows; ++j) {
-      if (j < nq) {
-        const float4 q4 = *reinterpret_cast<const float4*>(qs + j * 64 + cq * 4);
-        float s[16];
-        float cm = -INFINITY;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          float sv = (q4.x * kk[g].x + q4.y * kk[g].y) + (q4.z * kk[g].z + q4.w * kk[g].w);
-          sv = sbk::group_sum<16>(sv);  // (DPP on the VALU: 160 of these per run and beam set)
-          s[g] = (t0 + 4 * g + pg) < klen ? sv : -INFINITY;
-          cm = fmaxf(cm, s[g]);
-        }
-        cm = fmaxf(cm, sbk::shfl_xor(cm, 16));
-        cm = fmaxf(cm, sbk::shfl_xor(cm, 32));  // (finite: frame t0 of this run is inside the memory)
-        const float mn = fmaxf(m[j], cm);
-        const float corr = expf(m[j] - mn);
-        float lj = l[j] * corr;
-        float4 aj = make_float4(acc[j].x * corr, acc[j].y * corr, acc[j].z * corr, acc[j].w * corr);
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const float p = expf(s[g] - mn);
-          lj += p;
-          aj.x = fmaf(p, vv[g].x, aj.x);
-          aj.y = fmaf(p, vv[g].y, aj.y);
-          aj.z = fmaf(p, vv[g].z, aj.z);
-          aj.w = fmaf(p, vv[g].w, aj.w);
-        }
-        m[j] = mn;
-        l[j] = lj;
-        acc[j] = aj;
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < kPRows; ++j) {
-    if (j < nq) {
-      float lj = l[j];
-      lj += sbk::shfl_xor(lj, 16);
-      lj += sbk::shfl_xor(lj, 32);
-      float o[4] = {acc[j].x, acc[j].y, acc[j].z, acc[j].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] += sbk::shfl_xor(o[e], 16);
-        o[e] += sbk::shfl_xor(o[e], 32);
-      }
-      if (pg == 0) {
-        *reinterpret_cast<float4*>(wacc + (wave * kPRows + j) * 64 + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
-        if (cq == 0) {
-          wm[wave * kPRows + j] = m[j];
-          wl[wave * kPRows + j] = lj;
-        }
-      }
+    *reinterpret_cast<float4*>(wacc + wave * 64 + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    if (cq == 0) {
+      wm[wave] = m;
+      wl[wave] = l;
     }
   }
   __syncthreads();
-  {
-    const int j = tid >> 4, c4 = (tid & 15) * 4;
-    if (j < nq) {
-      float M = fmaxf(fmaxf(wm[j], wm[kPRows + j]), fmaxf(wm[2 * kPRows + j], wm[3 * kPRows + j]));
-      float den = 0.0f;
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 16) {  // merge of the four waves (a wave without positions: max -inf, sum 0 -> weight exp(-inf) = 0)
+    const float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    float den = 0.0f;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const float e = expf(wm[w * kPRows + j] - M);  // (a wave without frames: exp(-inf) = 0)
-        den = fmaf(wl[w * kPRows + j], e, den);
-        const float4 v = *reinterpret_cast<const float4*>(wacc + (w * kPRows + j) * 64 + c4);
-        o.x = fmaf(v.x, e, o.x);
-        o.y = fmaf(v.y, e, o.y);
-        o.z = fmaf(v.z, e, o.z);
-        o.w = fmaf(v.w, e, o.w);
-      }
-      float* op = a.ctx + ((size_t)u * a.beam + j) * d + h * 64 + c4;
-      sbk::st_agent(op, o.x / den);
-      sbk::st_agent(op + 1, o.y / den);
-      sbk::st_agent(op + 2, o.z / den);
-      sbk::st_agent(op + 3, o.w / den);
+    for (int w = 0; w < 4; ++w) {
+      const float e = expf(wm[w] - M);
+      den = fmaf(wl[w], e, den);
+      const float4 v = *reinterpret_cast<const float4*>(wacc + w * 64 + tid * 4);
+      r.x = fmaf(v.x, e, r.x);
+      r.y = fmaf(v.y, e, r.y);
+      r.z = fmaf(v.z, e, r.z);
+      r.w = fmaf(v.w, e, r.w);
     }
+    float* op = a.ctx + (size_t)i * d + (size_t)h * 64 + tid * 4;
+    sbk::st_agent(op, r.x / den);
+    sbk::st_agent(op + 1, r.y / den);
+    sbk::st_agent(op + 2, r.z / den);
+    sbk::st_agent(op + 3, r.w / den);
   }
 }
 
 __global__ void __launch_bounds__(256) decoder_step_persist_kernel(PStepArgs a) {
   SBK_DYN_LDS(float, lds);
-  const int tid = threadIdx.x, wave = tid >> 6, G = gridDim.x;
+  const int tid = threadIdx.x, G = gridDim.x;
   const int d = a.d, Kmax = d > a.dffn ? d : a.dffn;
   float* xs = lds;                                  // [16][K + 4] staged rows; the attention phases' scratch
   float* red = lds + (size_t)kPRows * (Kmax + 4);   // [4][256] K-split partial tiles
@@ -410,13 +348,22 @@ __global__ void __launch_bounds__(256) decoder_step_persist_kernel(PStepArgs a) 
 #pragma unroll
   for (int j = 0; j < kWB; ++j) pf.w[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   // barrier in two halves: the next projection's first weight loads are issued between arrival and wait
+  int n_stamp = 0;
+#define SBK_PSTEP_STAMP()                                                                  \
+  do {                                                                                     \
+    if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[n_stamp] = sbk::wall_clock();     \
+    ++n_stamp;                                                                             \
+  } while (0)
 #define SBK_PSTEP_BARRIER(W_, K_, N_)            \
   do {                                           \
     bar += G;                                    \
+    SBK_PSTEP_STAMP();                           \
     sbk::grid_arrive(a.bar);                     \
     if ((W_) != nullptr) prefetch_w(pf, (W_), (K_), (N_)); \
     sbk::grid_wait(a.bar, bar);                  \
+    SBK_PSTEP_STAMP();                           \
   } while (0)
+  SBK_PSTEP_STAMP();
 
   // embedding + position (NormalizedEmbedding, PositionalEncoding): x = emb[tok] * scale + pe[pos]
   for (int i = blockIdx.x; i < a.n; i += G) {
@@ -430,11 +377,8 @@ __global__ void __launch_bounds__(256) decoder_step_persist_kernel(PStepArgs a) 
     stage_rows<true>(a, xs, a.x, d);
     tiles_gemm(a, xs, red, d, L.sa_in_wf, L.sa_in_bf, nullptr, a.qkv, 3 * d, SBK_ACT_NONE, pf);
     SBK_PSTEP_BARRIER(L.sa_out_w, d, d);
-    {  // self-attention over the KV cache: a wave per (row, head)
-      const int lpad = ((a.Lmax + 63) >> 6) << 6;
-      int* slot = reinterpret_cast<int*>(xs) + (size_t)wave * lpad;
-      for (int item = blockIdx.x * 4 + wave; item < a.n * a.H; item += G * 4) self_attn_item(a, L, slot, item / a.H, item % a.H);
-    }
+    // self-attention over the KV cache: a workgroup per (row, head)
+    for (int it = blockIdx.x; it < a.n * a.H; it += G) attn_item<true>(a, L, xs, it / a.H, it % a.H);
     SBK_PSTEP_BARRIER((const float*)nullptr, 0, 0);
     stage_rows<false>(a, xs, a.ctx, d);
     tiles_gemm(a, xs, red, d, L.sa_out_w, L.sa_out_b, a.x, a.x, d, SBK_ACT_NONE, pf);
@@ -443,7 +387,7 @@ __global__ void __launch_bounds__(256) decoder_step_persist_kernel(PStepArgs a) 
     stage_rows<true>(a, xs, a.x, d);
     tiles_gemm(a, xs, red, d, L.ca_q_wf, L.ca_q_bf, nullptr, a.q, d, SBK_ACT_NONE, pf);
     SBK_PSTEP_BARRIER(L.ca_out_w, d, d);
-    for (int it = blockIdx.x; it < a.B * a.H; it += G) cross_attn_item(a, L, xs, it / a.H, it % a.H);
+    for (int it = blockIdx.x; it < a.n * a.H; it += G) attn_item<false>(a, L, xs, it / a.H, it % a.H);
     SBK_PSTEP_BARRIER((const float*)nullptr, 0, 0);
     stage_rows<false>(a, xs, a.ctx, d);
     tiles_gemm(a, xs, red, d, L.ca_out_w, L.ca_out_b, a.x, a.x, d, SBK_ACT_NONE, pf);
@@ -472,6 +416,8 @@ __global__ void __launch_bounds__(256) decoder_step_persist_kernel(PStepArgs a) 
     }
   }
   if (a.want_logits) tiles_gemm(a, xs, red, d, a.seq_wf, a.seq_bf, nullptr, a.logits, a.V, SBK_ACT_NONE, pf);
+  SBK_PSTEP_STAMP();
+#undef SBK_PSTEP_STAMP
 }
 
 }  // namespace
@@ -480,6 +426,9 @@ namespace sbk {
 
 int g_persist = 1;        // tuning knob (key 47): 0 = off; 1 = the persistent step for <= 16 hypothesis rows
 int g_persist_grid = 128; // tuning knob (key 48): workgroups of the cooperative launch (clamped to what the device holds)
+int g_persist_stamps = 0; // measurement knob (key 49): phase time stamps of the launches (sbk_prof_persist_stamps reads the last launch's)
+static long long* g_last_stamps = nullptr;  // device buffer of the most recent stamped launch (the caller's workspace)
+static int g_last_stamp_count = 0;
 
 // grid barriers of one launch: 1 (embedding) + 8 per layer
 int persist_barriers(int n_layers) { return 1 + 8 * n_layers; }
@@ -497,8 +446,7 @@ bool persist_eligible(const sbk_decoder_weights* W, int n, int B, int beam, int 
           aligned16(L.ff2_w)))
       return false;
   }
-  const size_t lpad = (size_t)((Lmax + 63) / 64) * 64;
-  return 8 * lpad * sizeof(float) <= 64 * 1024;
+  return Lmax <= 16384;
 }
 
 // One decoder step for n <= 16 hypothesis rows (n = B * beam) at position `step`: d.x .. d.logits as decoder_step leaves
@@ -509,6 +457,12 @@ int decoder_step_persist(const sbk_decoder_weights* W, const int32_t* tokens, co
                          float* const* vcache, float* const* ckv, int* bar, int bar_seq, int step, int n, int B, int T, int beam,
                          int Lmax, bool want_logits, hipStream_t st) {
   PStepArgs a;
+  // (bar points at 64 ints; the stamps live behind them in the same carve: 256 x 8 bytes)
+  a.stamps = g_persist_stamps ? reinterpret_cast<long long*>(bar + 64) : nullptr;
+  if (a.stamps) {
+    g_last_stamps = a.stamps;
+    g_last_stamp_count = 2 + 2 * persist_barriers(W->n_layers);
+  }
   const int d = W->d_model;
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
@@ -526,9 +480,8 @@ int decoder_step_persist(const sbk_decoder_weights* W, const int32_t* tokens, co
   a.attn_scale = 1.0f / sqrtf(64.0f);
   const int Kmax = d > W->d_ffn ? d : W->d_ffn;
   size_t region = (size_t)kPRows * (Kmax + 4);
-  const size_t attn = 1024 + 128 + (size_t)4 * kPRows * 64, self = (size_t)8 * (((Lmax + 63) / 64) * 64);
+  const size_t attn = 8 + 256 + (size_t)Lmax + 64;  // attn_item: wave maxima / sums / contexts + the row's cache slots
   if (region < attn) region = attn;
-  if (region < self) region = self;
   // (the region is sized for the rows AND the attention scratch; red follows the rows' extent)
   const size_t lds = (region + 1024 + 64) * sizeof(float);
   if (lds > 160 * 1024 - 512) return -1;
@@ -553,3 +506,13 @@ int decoder_step_persist(const sbk_decoder_weights* W, const int32_t* tokens, co
 }
 
 }  // namespace sbk
+
+// Measurement: the phase time stamps (100 MHz wall clock ticks) workgroup 0 wrote during the most recent stamped launch
+// (knob 49): [start, (end of phase, end of barrier) x barriers, end].  Synchronises the device.  Returns the count.
+extern "C" int sbk_prof_persist_stamps(long long* out, int cap) {
+  if (!sbk::g_last_stamps || !out || cap <= 0) return 0;
+  const int n = sbk::g_last_stamp_count < cap ? sbk::g_last_stamp_count : cap;
+  if (hipDeviceSynchronize() != hipSuccess) return 0;
+  if (hipMemcpy(out, sbk::g_last_stamps, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return n;
+}

@@ -2820,6 +2820,7 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 45) sbk::g_x3r_ln = value;
   if (key == 47) sbk::g_persist = value;
   if (key == 48) sbk::g_persist_grid = value;
+  if (key == 49) sbk::g_persist_stamps = value;
   if (key == 36) sbk::g_splitk_fused = value;
   if (key == 37) sbk::g_cross_fused_merge = value;
   if (key == 34) sbk::g_x3_route_rows = value;

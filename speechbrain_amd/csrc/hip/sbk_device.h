@@ -229,6 +229,8 @@ __device__ __forceinline__ void st_agent(float* p, float v) {
 }
 // Barrier among the G co-resident workgroups of a cooperative launch: `ctr` counts arrivals monotonically (the caller passes
 // the value it must reach); every lane first drains its own sc1 stores, one ticket per workgroup.  1.3 us at G = 64, 2.0 at 128.
+// 100 MHz wall clock shared by every CU (measurement only)
+__device__ __forceinline__ long long wall_clock() { return (long long)wall_clock64(); }
 // In two halves, so that loads which do not depend on the other workgroups (the next projection's weights) can be issued
 // between the arrival and the wait and fly while the barrier completes.
 __device__ __forceinline__ void grid_arrive(int* ctr) {

@@ -973,7 +973,7 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
   d.splitk = c.take<float>(d.splitk_floats);
   d.xpart = c.take<float>(sbk::cross_attn_partial_floats(B, T, W->nhead, dm / W->nhead, n / (B > 0 ? B : 1)) + 64);
   d.xcnt = c.take<int32_t>((size_t)B + 16);
-  d.pbar = c.take<int32_t>(64);
+  d.pbar = c.take<int32_t>(64 + 512);  // (+ 256 eight-byte phase stamps of the measurement knob 49)
   d.pseq = 0;
   d.head_major = sbk::g_kv_head_major && (dm / W->nhead) % 4 == 0;
   d.kvtmp = c.take<float>((size_t)B * T * 2 * dm);

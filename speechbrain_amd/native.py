@@ -83,6 +83,7 @@ def _declare(lib):
         "sbk_prof_report": ([ctypes.c_char_p, ctypes.c_size_t], ctypes.c_size_t),
         "sbk_prof_ctc_psi_repeat_f32": ([p, p, p, p, p, i, i, i, i, i, i, POINTER(c_float), p], c_int),
         "sbk_prof_set_knob": ([i, i], None),
+        "sbk_prof_persist_stamps": ([p, i], c_int),
         "sbk_prof_mfma_peak_f32": ([p, i, i, i, POINTER(c_float), p], c_int),
         "sbk_prof_stream_f32": ([p, p, ctypes.c_long, i, i, POINTER(c_float), p], c_int),
         "sbk_prof_gemm_repeat_f32": ([p, p, p, i, i, i, p, ctypes.c_size_t, i, POINTER(c_float), p], c_int),

@@ -45,6 +45,8 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 enum { hipMemcpyDeviceToDevice = 3, hipMemcpyDeviceToHost = 2, hipMemcpyHostToDevice = 1 };
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipDeviceSynchronize() { return 0; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : 2; }
 static inline hipError_t hipFree(void* p) { free(p); return 0; }
 enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
@@ -408,6 +410,7 @@ static inline int atomic_load_agent(const int* p) { return __atomic_load_n(p, __
 static inline float ld_agent(const float* p) { unsigned u = __atomic_load_n(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED); float f; memcpy(&f, &u, 4); return f; }
 static inline float2 ld_agent2(const float* p) { return float2{ld_agent(p), ld_agent(p + 1)}; }
 static inline void st_agent(float* p, float v) { unsigned u; memcpy(&u, &v, 4); __atomic_store_n(reinterpret_cast<unsigned*>(p), u, __ATOMIC_RELAXED); }
+static inline long long wall_clock() { return 0; }
 static inline void grid_arrive(int* ctr) {  // (every fiber calls it; fiber 0 of the workgroup takes the ticket)
   sbk_emu::block_barrier();
   if (sbk_emu::cur().lin == 0) {

@@ -21,6 +21,7 @@ ap.add_argument("--seconds", type=float, default=10.0)
 ap.add_argument("--overlap", type=int, default=0)
 ap.add_argument("--graph", type=int, default=0)
 ap.add_argument("--report", action="store_true")
+ap.add_argument("--stamps", action="store_true", help="phase times of the last persistent step of a search (knob 49)")
 ap.add_argument("--knob", action="append", default=[])
 args = ap.parse_args()
 
@@ -68,3 +69,28 @@ with torch.no_grad(), torch.cuda.stream(st):
         tot = sum(v["ms"] for v in rep.values())
         for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
             print(f"  {k:24s} {v['count']:6d} launches {1e3 * v['ms'] / v['count']:8.1f} us each {100 * v['ms'] / tot:5.1f} %")
+    if args.stamps:
+        import ctypes
+
+        lib.sbk_prof_set_knob(49, 1)
+        dec(enc, ldev)
+        torch.cuda.synchronize()
+        lib.sbk_prof_set_knob(49, 0)
+        buf = (ctypes.c_longlong * 256)()
+        n = lib.sbk_prof_persist_stamps(buf, 256)
+        t = [buf[i] * 0.01 for i in range(n)]  # 100 MHz ticks -> us
+        names = ["embed"]
+        for l in range(6):
+            names += [f"L{l} norm1+in_proj", f"L{l} self-attn", f"L{l} out_proj", f"L{l} norm2+q", f"L{l} cross-attn", f"L{l} out_proj2", f"L{l} norm3+ffn0", f"L{l} ffn3"]
+        print(f"  persistent step (last of the search): {t[-1] - t[0]:.1f} us, {n} stamps")
+        work = {}
+        bars = 0.0
+        for k, name in enumerate(names):
+            w, b = t[1 + 2 * k] - t[2 * k], t[2 + 2 * k] - t[1 + 2 * k]
+            key = name.split(" ", 1)[-1] if name != "embed" else name
+            work.setdefault(key, []).append(w)
+            bars += b
+        for key, v in work.items():
+            print(f"    {key:16s} {sum(v) / len(v):7.2f} us each x {len(v)}")
+        print(f"    barriers        {bars / len(names):7.2f} us each x {len(names)} (arrival .. release, workgroup 0)")
+        print(f"    norm+seq_lin    {t[-1] - t[-2]:7.2f} us")
