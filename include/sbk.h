@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SBK_ABI_VERSION 9
+#define SBK_ABI_VERSION 10
 
 typedef void* sbk_stream_t; /* hipStream_t */
 
@@ -215,36 +215,25 @@ int sbk_gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, c
                     int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, const int32_t* seq_len,
                     int rows_per_seq, sbk_stream_t stream);
 
-/* ABI 8: the same arithmetic for FEW rows -- the linear layers of a decoding step (Transformer.py:751-834: self-attention
- * in / out projections, cross-attention query / out projections, the feed-forward pair; a few hundred to a few thousand
- * hypothesis rows).  A is given either as fp32 [M, K] (row stride lda; split in registers) or as its panel image PA (A may
- * then be NULL); PW is the panel image of W [N, K] (sbk_split_x3p); 64 x 64 tiles whose four waves split K; N % 4 == 0,
- * K % 256 == 0.  The result goes to C (fp32) and / or PC, the panel image of the [M, N] result (N % 16 == 0) = the A
- * operand of the next projection.  Epilogue: residual + alpha * act(. + bias).  No workspace: K is never split across
- * workgroups (fixed summation order: the four waves' K quarters in order). */
-int sbk_gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW, const float* bias, const float* residual,
-                    int ldr, float* C, int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, sbk_stream_t stream);
-/* ABI 9: the LayerNorm in front of such a projection (Transformer.py:751-834 with normalize_before: norm1 -> self-attention
- * in_proj, norm2 -> cross-attention query rows, norm3 -> ffn.0; decoder.norm -> seq_lin) inside the projection's launch:
- * C = residual + alpha * act(LayerNorm(A) . W^T + b) with the affine folded into the operands exactly as for
- * sbk_gemm_ln_nt_f32 -- PWf = panel image (sbk_split_x3p) of Wf[n,k] = W[n,k] gamma[k], bf[n] = b[n] + sum_k W[n,k] beta[k].
+/* ABI 8 (signature of ABI 10): the same arithmetic for FEW rows -- the linear layers of a decoding step (Transformer.py:751-834:
+ * self-attention in / out projections, cross-attention query / out projections, the feed-forward pair; a few hundred to a few
+ * thousand hypothesis rows).  A fp32 [M, K] (row stride lda; split in registers), PW the panel image of W [N, K]
+ * (sbk_split_x3p); 64 x 64 tiles whose four waves split K; N % 4 == 0, K % 256 == 0.  Epilogue: residual + alpha * act(. + bias).
+ * No workspace: K is never split across workgroups (fixed summation order: the four waves' K quarters in order).
+ * (ABI 8-9 also took A as a panel image and could write the result as one: measured no faster and removed in ABI 10.) */
+int sbk_gemm_nt_x3r(const float* A, int lda, const uint16_t* PW, const float* bias, const float* residual, int ldr, float* C,
+                    int ldc, int M, int N, int K, int act, float alpha, sbk_stream_t stream);
+/* ABI 9 (signature of ABI 10): the LayerNorm in front of such a projection (Transformer.py:751-834 with normalize_before:
+ * norm1 -> self-attention in_proj, norm2 -> cross-attention query rows, norm3 -> ffn.0; decoder.norm -> seq_lin) inside the
+ * projection's launch: C = residual + alpha * act(LayerNorm(A) . W^T + b) with the affine folded into the operands exactly as
+ * for sbk_gemm_ln_nt_f32 -- PWf = panel image (sbk_split_x3p) of Wf[n,k] = W[n,k] gamma[k], bf[n] = b[n] + sum_k W[n,k] beta[k].
  * Row statistics in the two-pass form of sbk_layernorm_f32 (biased variance, eps inside the root), computed by the
  * workgroup for its 64 rows while its first operand loads are in flight; x - mean is split, rstd scales the finished
- * tile.  A fp32 [M, K], lda % 4 == 0; K = 256, 512, 1 024 or 1 280; N % 4 == 0. */
+ * tile.  A fp32 [M, K], lda % 4 == 0; K = 256, 512, 1 024 or 1 280; N % 4 == 0.
+ * (ABI 9's sbk_gemm_nt_x3r_stats / sbk_row_block_stats_f32 -- row statistics handed over by the kernels that write the rows --
+ * measured equal to this pre-pass on the GPU and were removed in ABI 10: profiles/r05_a_*.) */
 int sbk_gemm_ln_nt_x3r(const float* A, int lda, const uint16_t* PWf, const float* bf, const float* residual, int ldr, float* C,
-                       int ldc, uint16_t* PC, int M, int N, int K, float eps, int act, float alpha, sbk_stream_t stream);
-/* ABI 9: the same without a pass over the rows -- the row statistics travel with the rows.  stats_out (N % 64 == 0): the
- * launch is a plain sbk_gemm_nt_x3r (fp32 A) whose epilogue also writes, per row and 32-column block of its result, the
- * block's mean and sum of squared deviations (float pairs, [M][N / 32]); stats_in ([M][K / 32], from such a launch or
- * from sbk_row_block_stats_f32): the launch is C = residual + alpha * act(LayerNorm(A) . W^T + b) with PW / bias the
- * FOLDED operands of sbk_gemm_ln_nt_x3r, a lane folding the blocks of its own rows (pairwise update of Chan, Golub &
- * LeVeque; any K % 256 == 0).  One of the two per launch.  The decode step's residual stream: embed_pos and the three
- * projections that add to it hand their statistics to the projection behind the next LayerNorm. */
-int sbk_gemm_nt_x3r_stats(const float* A, int lda, const float* stats_in, const uint16_t* PW, const float* bias,
-                          const float* residual, int ldr, float* C, int ldc, float* stats_out, int M, int N, int K, float eps,
-                          int act, float alpha, sbk_stream_t stream);
-/* block statistics of fp32 rows x [rows, d] (d % 32 == 0), as above: stats [rows][d / 32] float pairs */
-int sbk_row_block_stats_f32(const float* x, int ldx, float* stats, int rows, int d, sbk_stream_t stream);
+                       int ldc, int M, int N, int K, float eps, int act, float alpha, sbk_stream_t stream);
 
 /* ---- bf16-operand fast entry points ("fp32 parity entry points plus bf16 ... fast entry points").
  * C = epilogue(bf16(A) . Wb^T) with fp32 accumulation on v_mfma_f32_32x32x16_bf16: A [M,K] stays fp32 in memory and is

@@ -21,47 +21,13 @@
 namespace {
 
 // ---------------------------------------------------------------- embedding
-// (mean, sum of squared deviations) of the 32-column block a half-wave holds one value each of (d % 32 == 0: a half-wave is
-// inside the row or outside as a whole; every lane takes part in the lane exchanges) -> stats[row][c / 32]
-__device__ __forceinline__ void block_stats_32(float v, bool ok, int c, float2* __restrict__ srow) {
-  float sm = sbk::group_sum<16>(v);
-  sm += sbk::shfl_xor(sm, 16);
-  const float mb = sm * (1.0f / 32.0f);
-  const float dv = v - mb;
-  float qs = sbk::group_sum<16>(dv * dv);
-  qs += sbk::shfl_xor(qs, 16);
-  if (ok && (c & 31) == 0) srow[c >> 5] = make_float2(mb, qs);
-}
-
-// stats (optional): the rows' block statistics for the LayerNorm of the first decoder layer (gemm.hip: gemm_x3r_kernel, LNQ < 0)
 __global__ void __launch_bounds__(256) embed_pos_kernel(const int32_t* __restrict__ tok, const float* __restrict__ emb,
                                                         const float* __restrict__ pe_row, float* __restrict__ x,
-                                                        int n, int d, float scale,
-                                                        const int32_t* __restrict__ step_ptr, float2* __restrict__ stats) {
+                                                        int n, int d, float scale, const int32_t* __restrict__ step_ptr) {
   const int i = blockIdx.x;
   if (step_ptr) pe_row += (size_t)step_ptr[0] * d;  // pe_row = row 0 of the table in that mode
   const float* e = emb + (size_t)tok[i] * d;
-  if (!stats) {  // (uniform)
-    for (int c = threadIdx.x; c < d; c += 256) x[(size_t)i * d + c] = e[c] * scale + pe_row[c];
-    return;
-  }
-  for (int c0 = 0; c0 < d; c0 += 256) {
-    const int c = c0 + threadIdx.x;
-    const bool ok = c < d;
-    const float v = ok ? e[c] * scale + pe_row[c] : 0.0f;
-    if (ok) x[(size_t)i * d + c] = v;
-    block_stats_32(v, ok, c, stats + (size_t)i * (d >> 5));
-  }
-}
-
-__global__ void __launch_bounds__(256) row_block_stats_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ stats,
-                                                              int d) {
-  const int i = blockIdx.x;
-  for (int c0 = 0; c0 < d; c0 += 256) {
-    const int c = c0 + threadIdx.x;
-    const bool ok = c < d;
-    block_stats_32(ok ? x[(size_t)i * ldx + c] : 0.0f, ok, c, stats + (size_t)i * (d >> 5));
-  }
+  for (int c = threadIdx.x; c < d; c += 256) x[(size_t)i * d + c] = e[c] * scale + pe_row[c];
 }
 
 // ---------------------------------------------------------------- self attention, one new token
@@ -1173,19 +1139,12 @@ int g_cross_rows = 7;     // key 4: 7 (default) = LDS-DMA / MFMA kernel for larg
 int g_kv_head_major = 0;  // key 5: cross K/V stored [B,H,T,2*Dh] instead of [B,T,2d]
 
 int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,
-              hipStream_t st, float2* stats) {
+              hipStream_t st) {
   if (n == 0) return 0;
-  if (stats && d % 32 != 0) return fail(SBK_EINVAL, "embed_pos: block statistics need d %% 32 == 0 (d=%d)", d);
   ProfScope prof("embed_pos", 2.0 * n * d, 8.0 * n * d, st);
   const int32_t* sp = g_step_ptr;  // a local: launch arguments must not name the thread_local itself
-  SBK_LAUNCH(embed_pos_kernel, dim3(n), dim3(256), 0, st, tok, emb, pe_row, x, n, d, scale, sp, stats);
+  SBK_LAUNCH(embed_pos_kernel, dim3(n), dim3(256), 0, st, tok, emb, pe_row, x, n, d, scale, sp);
   return launch_status("embed_pos");
-}
-int row_block_stats(const float* x, int ldx, float2* stats, int rows, int d, hipStream_t st) {
-  if (rows == 0) return 0;
-  ProfScope prof("row_block_stats", 3.0 * rows * d, 4.0 * rows * d, st);
-  SBK_LAUNCH(row_block_stats_kernel, dim3(rows), dim3(256), 0, st, x, ldx, stats, d);
-  return launch_status("row_block_stats");
 }
 
 int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t* kv_slot, float* out, int n, int d,
@@ -1266,12 +1225,6 @@ int log_softmax_rows(const float* x, float* out, int rows, int V, float temperat
 }
 
 }  // namespace sbk
-
-extern "C" int sbk_row_block_stats_f32(const float* x, int ldx, float* stats, int rows, int d, sbk_stream_t stream) {
-  if (rows == 0) return 0;
-  SBK_REQUIRE(x && stats && rows > 0 && d > 0 && d % 32 == 0 && ldx >= d, "row_block_stats: bad arguments (d %% 32 == 0)");
-  return sbk::row_block_stats(x, ldx, reinterpret_cast<float2*>(stats), rows, d, sbk::as_stream(stream));
-}
 
 extern "C" int sbk_log_softmax_f32(const float* x, float* out, int rows, int V, float temperature, float weight,
                                    sbk_stream_t stream) {

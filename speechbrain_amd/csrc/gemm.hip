@@ -1854,371 +1854,6 @@ __global__ void __launch_bounds__(256, 2) gemm_skinny_ln_kernel(GemmArgs g, floa
   tile_epilogue_32x32(g, v, mt, nt, r, half);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Few-row fp32 contraction on the bf16 matrix pipe ("x3r": the decode step's projections, 200 - 4 000 hypothesis rows).
-// A kernel trace of a decoding step (profiles/r04_g_*) shows its launches back to back (45 us of gaps in 2.1 ms): the step
-// is the sum of its kernels, and 53 % of that were the decoder layers' projections at 27 - 80 TF/s -- register-operand
-// fp32-MFMA tiles whose operands arrive as 16-byte pieces of 64 different rows per load instruction (the texture
-// path serialises them) and whose 64 x 64 x 128 wave slices cost 4 096 matrix cycles each.  Here
-//   * W arrives pre-split in PANEL layout (sbk_split_x3p: the weights' image the encoder uses): a fragment load of 32
-//     rows is two 512-byte runs, and the same three-way operand split as sbk_gemm_nt_f32x3 puts the products on
-//     v_mfma_f32_32x32x16_bf16 (6 MFMAs of 8 passes per 16 k instead of 8 MFMAs of 16 passes);
-//   * A is either fp32 [M, K] (cut into its three pieces in registers: a lane holds 8 consecutive k of its row per step)
-//     or -- APAN -- its panel image written by the kernel that produced it (LayerNorm, the previous projection's
-//     epilogue, sbk_split_x3p): coalesced fragment loads like W's, no VALU work in the loop;
-//   * tile 64 x 64, the four waves split K four ways -- each takes K / 64 steps of 16 k, however long K is: no LDS
-//     staging, no barrier in the loop, one LDS exchange of the partial tiles at the end.  (The fp32-MFMA kernels split a
-//     long K across workgroups as well, to fill the chip, and pay a reduce launch: on the bf16 pipe the 2 048-deep
-//     feed-forward projection of 1 280 rows is 10 us of matrix time per workgroup on 160 CUs);
-//   * the k steps run through a ring of four single-step operand buffers (two with panel A): the loads of step s + 3
-//     (s + 1) are in flight under the MFMAs of step s (<= 256 registers: two workgroups per CU); the step loop is rolled
-//     over the ring (K / 64 steps per wave: 8 at K = 512, 32 at 2 048).  The operands of a step are
-//     materialised by empty asm anchors where they are used -- without them hipcc hoists the split of an A fragment to
-//     its load (a wait in front of the next loads) or sinks the loads to their MFMAs;
-//   * W is the FIRST MFMA operand (the wave computes (W tile) . (A tile)^T): a lane owns one row m of C and register
-//     quads hold four consecutive columns -- bias / residual / result move as 16-byte vectors, and the result can be
-//     written as the panel image of the next projection's A operand (PC: the feed-forward pair's hidden layer).
-struct X3rArgs {
-  const float* A;    // fp32 [M, K], row stride lda (when PA is null)
-  const uint4* PA;   // or the panel image of A
-  const uint4* PW;   // panel image of W [N, K]
-  const float* bias;
-  const float* R;
-  float* C;          // fp32 result (may be null when PC is given)
-  uint2* PC;         // optional: the result as the panel image of a [M, N] matrix
-  int ns;            // k steps (of 16) per wave: K / 64, a multiple of 4
-  int lda, ldr, ldc, M, N, K, act, tiles_m, tiles_n;
-  float alpha;
-  float ln_eps;      // LNQ != 0: A is the residual stream, the operand is its LayerNorm (affine folded into PW / bias)
-  const float2* st_in;  // LNQ < 0: (mean, sum of squared deviations) of every 32-column block of A's rows, [M][K / 32]
-  float2* st_out;       // STO: the same for the result's rows, [M][N / 32] (N % 64 == 0) -- written by the epilogue
-};
-
-// NS > 0: the wave's NS steps fully unrolled (K = 64 NS; measured faster for K = 512 with N >= 1 024: 18.6 / 25.3 / 51.5 us
-// against 21.0 / 27.0 / 58.1 rolled at N = 1 536 / 2 048 / 5 000, profiles/r04_i_*, r04_k_*); NS = 0: the loop rolled
-// over the ring (any K; faster for N = 512: 12.4 vs 14.2 us, and the only form for long K)
-//
-// LNQ > 0 (= K / 256; fp32 A only): the LayerNorm in front of the projection runs in its prologue.  gamma / beta are folded
-// into the operands by the caller (PW = panel image of W[n,k] gamma[k], bias[n] + sum_k W[n,k] beta[k]: sbk_gemm_ln_nt_f32's
-// convention), so  LN(x) . W^T + b = rstd * ((x - mean) . Wf^T) + bf.  Row statistics: wave w takes rows 16 w .. 16 w + 15 of
-// the tile, a row per 16 lanes, in the two-pass form of csrc/norm.hip (mean, then the sum of squared deviations) while the
-// first operand loads of the step loop are already in flight; x - mean is formed in front of the split (one subtraction
-// per element), rstd multiplies the finished tile in the epilogue (a lane owns one row there).  The rows are re-read by
-// the step loop through L1 / L2 (the kernel that wrote them ran just before).
-//
-// LNQ < 0: the same with the row statistics HANDED OVER by the kernel that wrote the rows (STO: the epilogue of the
-// projection that produced the residual stream, or embed_pos): per row and 32-column block the block's mean and its sum of
-// squared deviations (a lane of the epilogue holds 16 of the 32 values, its partner 32 lanes on the other 16), which a
-// lane of the consumer folds block by block for its two operand rows (Chan et al.'s pairwise update with equal block
-// sizes: 5 operations per block; 128 B per row instead of the row itself, no LDS, no barrier: every lane needs exactly
-// the rows it computes for, in the loop and in the epilogue).  Measured with the pre-pass form (profiles/r04_u_*): in a
-// decoding step the pre-pass costs a projection 7.8 us -- more than the LayerNorm launch it replaces (5.8).
-template <bool APAN, int NS, int LNQ = 0, bool STO = false>
-__global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
-  static_assert(!(APAN && LNQ != 0), "gemm_x3r: the LayerNorm prologue reads fp32 rows");
-  constexpr int DEPTH = APAN ? 2 : 4, PD = APAN ? 1 : 3;  // ring size (= the unrolled body of the step loop), prefetch distance (registers)
-  __shared__ float4 red[4][4][4][64];  // [wave][sub-tile][register quad][lane]: partial tiles of the four K slices (64 KB)
-  __shared__ float2 stat[LNQ > 0 ? 64 : 1];  // (mean, rstd) of the tile's rows
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int nt, mt;
-  {  // XCD-aware tile order: workgroup id = 8 q + x runs on XCD x; give it the column tiles nt = x (mod 8)
-    const int id = blockIdx.x, x = id & 7, q = id >> 3;
-    const int nt8 = (g.tiles_n + 7) / 8;
-    mt = q % g.tiles_m;
-    nt = x + 8 * (q / g.tiles_m);
-    if (q / g.tiles_m >= nt8 || nt >= g.tiles_n) return;
-  }
-  const int r = lane & 31, half = lane >> 5;
-  const int ns = NS > 0 ? NS : g.ns, k_begin = wave * ns * 16, KB = g.K >> 4;
-  const float* arow[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) arow[i] = g.A + (size_t)min(mt * 64 + i * 32 + r, g.M - 1) * g.lda + k_begin + 8 * half;
-  // chunk (row block, k step, piece 0, half), slot r: sub-tile i / j is 32 slots on, piece p two chunks (128 slots), a k step six
-  const uint4* wp = g.PW + ((size_t)(nt * KB + (k_begin >> 4)) * 6 + half) * 64 + r;
-  const uint4* pa = g.PA + ((size_t)(mt * KB + (k_begin >> 4)) * 6 + half) * 64 + r;
-  float4 av[APAN ? 1 : DEPTH][2][2];
-  uint4 ap4[APAN ? DEPTH : 1][2][3];
-  uint4 wv[DEPTH][2][3];
-  auto load = [&](int buf, int st) SBK_INLINE_LAMBDA {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) wv[buf][j][p] = wp[(size_t)st * 384 + p * 128 + j * 32];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if constexpr (APAN) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) ap4[buf][i][p] = pa[(size_t)st * 384 + p * 128 + i * 32];
-      } else {
-        av[buf][i][0] = *reinterpret_cast<const float4*>(arow[i] + st * 16);
-        av[buf][i][1] = *reinterpret_cast<const float4*>(arow[i] + st * 16 + 4);
-      }
-    }
-  };
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
-  float mean[2] = {0.0f, 0.0f}, rstd2[2] = {1.0f, 1.0f};  // (LNQ != 0) of this lane's two operand rows
-  auto compute = [&](int buf) SBK_INLINE_LAMBDA {
-    sbk::bf16x8 ap[2][3], bp[2][3];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        sbk::pin(wv[buf][j][p].x), sbk::pin(wv[buf][j][p].y), sbk::pin(wv[buf][j][p].z), sbk::pin(wv[buf][j][p].w);
-        const uint4 u = wv[buf][j][p];
-        bp[j][p] = sbk::bf16x8_from_words(u.x, u.y, u.z, u.w);
-      }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if constexpr (APAN) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          sbk::pin(ap4[buf][i][p].x), sbk::pin(ap4[buf][i][p].y), sbk::pin(ap4[buf][i][p].z), sbk::pin(ap4[buf][i][p].w);
-          const uint4 u = ap4[buf][i][p];
-          ap[i][p] = sbk::bf16x8_from_words(u.x, u.y, u.z, u.w);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          sbk::pin(av[buf][i][e].x), sbk::pin(av[buf][i][e].y), sbk::pin(av[buf][i][e].z), sbk::pin(av[buf][i][e].w);
-        }
-        const float4 x0 = av[buf][i][0], x1 = av[buf][i][1];
-        float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-        if constexpr (LNQ != 0) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] -= mean[i];
-        }
-        unsigned h[4], m[4], l[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {  // x = hi + mid + lo exactly (8 significand bits each, remainders exact in fp32)
-          h[p] = sbk::bf16_pair(x[2 * p], x[2 * p + 1]);
-          const float r0 = x[2 * p] - __uint_as_float(h[p] << 16), r1 = x[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
-          m[p] = sbk::bf16_pair(r0, r1);
-          l[p] = sbk::bf16_pair(r0 - __uint_as_float(m[p] << 16), r1 - __uint_as_float(m[p] & 0xffff0000u));
-        }
-        ap[i][0] = sbk::bf16x8_from_words(h[0], h[1], h[2], h[3]);
-        ap[i][1] = sbk::bf16x8_from_words(m[0], m[1], m[2], m[3]);
-        ap[i][2] = sbk::bf16x8_from_words(l[0], l[1], l[2], l[3]);
-      }
-    }
-    // the six partial products of relative size >= 2^-17, smallest first; consecutive MFMAs go to different accumulators
-    constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(bp[j][PB_[t]], ap[i][PA_[t]], acc[i][j]);
-  };
-#pragma unroll
-  for (int st = 0; st < PD; ++st) load(st, st);  // (ns >= 4 > PD)
-  if constexpr (LNQ > 0) {
-    // a row per 16 lanes (four rows per pass, four passes): 16-byte loads 256 B apart, both sums by DPP inside the row of lanes
-    const float inv_k = 1.0f / (float)g.K;
-    const int grp = lane >> 4, t = lane & 15;
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int rl = wave * 16 + ps * 4 + grp;
-      const float4* xr = reinterpret_cast<const float4*>(g.A + (size_t)min(mt * 64 + rl, g.M - 1) * g.lda);
-      float4 xs[4 * LNQ];
-#pragma unroll
-      for (int j = 0; j < 4 * LNQ; ++j) xs[j] = xr[t + 16 * j];
-      float sm = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 4 * LNQ; ++j) sm += (xs[j].x + xs[j].y) + (xs[j].z + xs[j].w);
-      const float mu = sbk::group_sum<16>(sm) * inv_k;
-      float qs = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 4 * LNQ; ++j) {
-        const float a = xs[j].x - mu, b = xs[j].y - mu, c = xs[j].z - mu, d = xs[j].w - mu;
-        qs += (a * a + b * b) + (c * c + d * d);
-      }
-      const float rs = rsqrtf(sbk::group_sum<16>(qs) * inv_k + g.ln_eps);
-      if (t == 0) stat[rl] = make_float2(mu, rs);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) mean[i] = stat[i * 32 + r].x;
-  }
-  if constexpr (LNQ < 0) {
-    // every load of the statistics first (K / 64 16-byte vectors per row: independent of each other and of the operand
-    // loads already in flight), then the fold -- block k joins the k blocks in front of it:
-    //   d = mean_k - mean;  mean += d / (k + 1);  m2 += m2_k + d^2 * 32 k / (k + 1)
-    auto fold = [](float& ma, float& m2, float mk, float qk, int k) SBK_INLINE_LAMBDA {
-      const float kf = (float)k, d = mk - ma;
-      ma += d / (kf + 1.0f);
-      m2 += qk + d * d * (32.0f * kf / (kf + 1.0f));
-    };
-    const float4* sp[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      sp[i] = reinterpret_cast<const float4*>(g.st_in + (size_t)min(mt * 64 + i * 32 + r, g.M - 1) * (g.K >> 5));
-    float ma[2], m2[2];
-    if constexpr (NS > 0) {  // K = 64 NS: NS vectors per row, all in flight at once
-      float4 sv[2][NS];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) sv[i][j] = sp[i][j];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ma[i] = sv[i][0].x, m2[i] = sv[i][0].y;
-        fold(ma[i], m2[i], sv[i][0].z, sv[i][0].w, 1);
-#pragma unroll
-        for (int j = 1; j < NS; ++j) {
-          fold(ma[i], m2[i], sv[i][j].x, sv[i][j].y, 2 * j);
-          fold(ma[i], m2[i], sv[i][j].z, sv[i][j].w, 2 * j + 1);
-        }
-      }
-    } else {  // any K % 256 == 0: four vectors per row and pass
-      const int nv = g.K >> 6;
-#pragma unroll 1
-      for (int j0 = 0; j0 < nv; j0 += 4) {
-        float4 sv[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) sv[i][j] = sp[i][j0 + j];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j0 + j == 0) {
-              ma[i] = sv[i][0].x, m2[i] = sv[i][0].y;
-            } else {
-              fold(ma[i], m2[i], sv[i][j].x, sv[i][j].y, 2 * (j0 + j));
-            }
-            fold(ma[i], m2[i], sv[i][j].z, sv[i][j].w, 2 * (j0 + j) + 1);
-          }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      mean[i] = ma[i];
-      rstd2[i] = rsqrtf(m2[i] / (float)g.K + g.ln_eps);
-    }
-  }
-  if constexpr (NS > 0) {
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
-      if (st + PD < NS) load((st + PD) % DEPTH, st + PD);
-      sbk::sched_fence();
-      compute(st % DEPTH);
-    }
-  } else {
-#pragma unroll 1
-    for (int s0 = 0; s0 < ns; s0 += DEPTH) {
-#pragma unroll
-      for (int j = 0; j < DEPTH; ++j) {
-        if (s0 + j + PD < ns) load((j + PD) % DEPTH, s0 + j + PD);  // (uniform)
-        sbk::sched_fence();
-        compute(j);
-      }
-    }
-  }
-  // every wave publishes its four partial sub-tiles; wave s then owns sub-tile s = 2 i + j (fixed summation order)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4)
-        red[wave][2 * i + j][q4][lane] = make_float4(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]);
-  __syncthreads();
-  // lane = row (sub_m * 32 + r), register quad q4 = columns sub_n * 32 + 8 q4 + 4 half .. +3
-  const int row = (mt * 2 + (wave >> 1)) * 32 + r, col0 = (nt * 2 + (wave & 1)) * 32 + 4 * half;
-  const bool row_ok = row < g.M;
-  float4 v[4];
-#pragma unroll
-  for (int q4 = 0; q4 < 4; ++q4) {
-    const float4 a0 = red[0][wave][q4][lane], a1 = red[1][wave][q4][lane], a2 = red[2][wave][q4][lane], a3 = red[3][wave][q4][lane];
-    v[q4] = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z,
-                        ((a0.w + a1.w) + a2.w) + a3.w);
-  }
-  if constexpr (LNQ != 0) {
-    const float rs = LNQ > 0 ? stat[(wave >> 1) * 32 + r].y : ((wave >> 1) ? rstd2[1] : rstd2[0]);
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) v[q4].x *= rs, v[q4].y *= rs, v[q4].z *= rs, v[q4].w *= rs;
-  }
-  const float* rrow = g.R ? g.R + (size_t)(row_ok ? row : 0) * g.ldr : nullptr;
-  float4 bv[4], rv[4];
-  bool ok[4];
-#pragma unroll
-  for (int q4 = 0; q4 < 4; ++q4) {  // (N % 4 == 0: a vector is inside the matrix or outside as a whole)
-    const int col = col0 + 8 * q4;
-    ok[q4] = row_ok && col < g.N;
-    bv[q4] = (g.bias && ok[q4]) ? *reinterpret_cast<const float4*>(g.bias + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    rv[q4] = (rrow && ok[q4]) ? *reinterpret_cast<const float4*>(rrow + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  }
-  float o[16];
-#pragma unroll
-  for (int q4 = 0; q4 < 4; ++q4) {
-    o[4 * q4] = v[q4].x + bv[q4].x, o[4 * q4 + 1] = v[q4].y + bv[q4].y, o[4 * q4 + 2] = v[q4].z + bv[q4].z, o[4 * q4 + 3] = v[q4].w + bv[q4].w;
-  }
-  switch (g.act) {  // uniform
-    case SBK_ACT_SWISH:
-#pragma unroll
-      for (int q = 0; q < 16; ++q) o[q] = o[q] / (1.0f + expf(-o[q]));
-      break;
-    case SBK_ACT_GELU:
-#pragma unroll
-      for (int q = 0; q < 16; ++q) o[q] = 0.5f * o[q] * (1.0f + erff(o[q] * 0.70710678118654752440f));
-      break;
-    case SBK_ACT_RELU:
-#pragma unroll
-      for (int q = 0; q < 16; ++q) o[q] = o[q] > 0.0f ? o[q] : 0.0f;
-      break;
-    case SBK_ACT_LEAKY_RELU:
-#pragma unroll
-      for (int q = 0; q < 16; ++q) o[q] = o[q] > 0.0f ? o[q] : 0.01f * o[q];
-      break;
-    default: break;
-  }
-  if constexpr (STO) {  // (N % 64 == 0: every column of the sub-tile is inside the matrix)
-    float f[16], sm = 0.0f;
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      f[4 * q4] = o[4 * q4] * g.alpha + rv[q4].x, f[4 * q4 + 1] = o[4 * q4 + 1] * g.alpha + rv[q4].y;
-      f[4 * q4 + 2] = o[4 * q4 + 2] * g.alpha + rv[q4].z, f[4 * q4 + 3] = o[4 * q4 + 3] * g.alpha + rv[q4].w;
-      sm += (f[4 * q4] + f[4 * q4 + 1]) + (f[4 * q4 + 2] + f[4 * q4 + 3]);
-    }
-    sm += sbk::shfl_xor(sm, 32);
-    const float mb = sm * (1.0f / 32.0f);
-    float qs = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) qs += (f[e] - mb) * (f[e] - mb);
-    qs += sbk::shfl_xor(qs, 32);
-    if (half == 0 && row_ok) g.st_out[(size_t)row * (g.N >> 5) + (col0 >> 5)] = make_float2(mb, qs);
-  }
-#pragma unroll
-  for (int q4 = 0; q4 < 4; ++q4) {
-    const int col = col0 + 8 * q4;
-    const float o0 = o[4 * q4] * g.alpha + rv[q4].x, o1 = o[4 * q4 + 1] * g.alpha + rv[q4].y;
-    const float o2 = o[4 * q4 + 2] * g.alpha + rv[q4].z, o3 = o[4 * q4 + 3] * g.alpha + rv[q4].w;
-    if (!ok[q4]) continue;
-    if (g.C) *reinterpret_cast<float4*>(g.C + (size_t)row * g.ldc + col) = make_float4(o0, o1, o2, o3);
-    if (g.PC) {
-      // the result as the NEXT projection's A operand (its K = this N): columns col .. col+3 are k = col .. col+3 of row
-      // `row`: chunk (row / 64, col / 16, piece, (col % 16) / 8), slot row % 64, bytes (col % 8) * 2 .. +8
-      const unsigned h0 = sbk::bf16_pair(o0, o1), h1 = sbk::bf16_pair(o2, o3);
-      const float r0 = o0 - __uint_as_float(h0 << 16), r1 = o1 - __uint_as_float(h0 & 0xffff0000u);
-      const float r2 = o2 - __uint_as_float(h1 << 16), r3 = o3 - __uint_as_float(h1 & 0xffff0000u);
-      const unsigned m0 = sbk::bf16_pair(r0, r1), m1 = sbk::bf16_pair(r2, r3);
-      const unsigned l0 = sbk::bf16_pair(r0 - __uint_as_float(m0 << 16), r1 - __uint_as_float(m0 & 0xffff0000u));
-      const unsigned l1 = sbk::bf16_pair(r2 - __uint_as_float(m1 << 16), r3 - __uint_as_float(m1 & 0xffff0000u));
-      uint2* d = g.PC + (((size_t)(row >> 6) * (g.N >> 4) + (col >> 4)) * 6 + ((col >> 3) & 1)) * 128 + (row & 63) * 2 + ((col >> 2) & 1);
-      d[0] = make_uint2(h0, h1);
-      d[256] = make_uint2(m0, m1);
-      d[512] = make_uint2(l0, l1);
-    }
-  }
-}
-
 // C = epilogue(sum_ks partial[ks]) ; fixed summation order => run-to-run deterministic.
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const float* __restrict__ partial, int SK) {
   const size_t total = (size_t)g.M * g.N;
@@ -2362,88 +1997,6 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   SBK_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, g, (const float*)ws, SKg);
   return launch_status("splitk_reduce");
 }
-
-// tuning knob (key 41): the decode step's projections on gemm_x3r_kernel: 0 = off (register-operand fp32-MFMA tiles),
-// otherwise on (3 = always the rolled step loop); key 44: 1 = their A operands as panel images too (LayerNorm -> panel, attention context through
-// sbk_split_x3p, the feed-forward hidden layer by the first projection's epilogue), 0 (default) = fp32 A split in registers
-int g_x3r_mode = 2;
-int g_x3r_apanel = 0;  // (measured, profiles/r04_i_*: panel A operands are no faster inside the contraction -- 12.9 vs 14.2 us at 1 280 x
-                       // 512 x 512, 20.6 vs 18.6 at N = 1 536 -- and their producers cost more than they save at 1 280 rows)
-int g_x3r_vocab = 1;      // key 43: 1 = the vocabulary projection of a step too (instead of the 128-wide persistent split-operand kernel)
-int g_x3r_min_rows = 192;  // key 42: rows from which the search routes a projection with a panel image to it
-bool x3r_routed(int M, int N, int K) { return g_x3r_mode != 0 && M >= g_x3r_min_rows && K % 256 == 0 && N % 4 == 0; }
-// key 45: the LayerNorm in front of a routed projection of the search: 0 = a launch of its own; 1 = in the projection's prologue
-// from a pre-pass over the rows (gemm_ln_nt_x3r; the vocabulary projection only below 4 096 columns), 2 = the same, wide
-// vocabularies included; 3 = from block statistics handed over by the kernel that wrote the rows (gemm_lns_nt_x3r)
-int g_x3r_ln = 1;
-// A fp32 [M, K] (row stride lda) or PA = its panel image; C fp32 and / or PC = the result's panel image (N % 16 == 0).
-// ln_eps >= 0: the operand is LayerNorm(A) over K with the affine folded into (PW, bias): row statistics by a pre-pass
-// (st_in null; fp32 A, K = 256 / 512 / 1 024 / 1 280) or from st_in [M][K / 32] (any K % 256 == 0).  st_out: block statistics
-// of the result's rows [M][N / 32] (fp32 A without LayerNorm, N % 64 == 0).
-// -1: shape not eligible
-static int launch_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW, const float* bias, const float* R, int ldr,
-                      float* C, int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, float ln_eps,
-                      const float2* st_in, float2* st_out, hipStream_t st) {
-  if (M == 0 || N == 0) return 0;
-  const bool ln = ln_eps >= 0.0f;
-  if (K % 256 != 0 || N % 4 != 0 || !aligned16(PW) || (!A && !PA) || (!C && !PC)) return -1;
-  if (!PA && (lda % 4 != 0 || !aligned16(A))) return -1;
-  if ((PA && !aligned16(PA)) || (C && (ldc % 4 != 0 || !aligned16(C))) || (R && (ldr % 4 != 0 || !aligned16(R))) ||
-      (bias && !aligned16(bias)) || (PC && N % 16 != 0))
-    return -1;
-  if (ln && (PA || st_out || (!st_in && !(K == 256 || K == 512 || K == 1024 || K == 1280)) || (st_in && !aligned16(st_in)))) return -1;
-  if (!ln && st_in) return -1;
-  if (st_out && (PA || N % 64 != 0 || !C)) return -1;
-  const int tm = cdiv(M, 64), tn = cdiv(N, 64);
-  X3rArgs a{A, reinterpret_cast<const uint4*>(PA), reinterpret_cast<const uint4*>(PW), bias, R, C, reinterpret_cast<uint2*>(PC),
-            K / 64, lda, ldr, ldc, M, N, K, act, tm, tn, alpha, ln_eps, st_in, st_out};
-  ProfScope prof(ln ? (st_in ? "gemm_lns_x3r" : "gemm_ln_x3r") : "gemm_x3r", 2.0 * M * N * K,
-                 (PA ? 6.0 : 4.0) * M * (double)K + 6.0 * (double)N * K + ((C ? 4.0 : 0.0) + (PC ? 6.0 : 0.0) + (R ? 4.0 : 0.0)) * M * (double)N, st);
-  dim3 grid(8 * tm * cdiv(tn, 8)), block(256);
-  if (ln && st_in) {
-    if (K == 512) {
-      SBK_LAUNCH((gemm_x3r_kernel<false, 8, -1>), grid, block, 0, st, a);
-    } else {
-      SBK_LAUNCH((gemm_x3r_kernel<false, 0, -1>), grid, block, 0, st, a);
-    }
-    return launch_status("gemm_lns_x3r");
-  }
-  if (ln) {
-    if (K == 512) {  // (the unrolled step loop for every N: the rolled one is at the register limit without the row means)
-      SBK_LAUNCH((gemm_x3r_kernel<false, 8, 2>), grid, block, 0, st, a);
-    } else if (K == 256) {
-      SBK_LAUNCH((gemm_x3r_kernel<false, 4, 1>), grid, block, 0, st, a);
-    } else if (K == 1024) {
-      SBK_LAUNCH((gemm_x3r_kernel<false, 0, 4>), grid, block, 0, st, a);
-    } else {
-      SBK_LAUNCH((gemm_x3r_kernel<false, 0, 5>), grid, block, 0, st, a);
-    }
-    return launch_status("gemm_ln_x3r");
-  }
-  if (st_out) {  // (the projections that write the residual stream: N = d_model)
-    SBK_LAUNCH((gemm_x3r_kernel<false, 0, 0, true>), grid, block, 0, st, a);
-  } else if (PA) {
-    SBK_LAUNCH((gemm_x3r_kernel<true, 0>), grid, block, 0, st, a);
-  } else if (K == 512 && N >= 1024 && g_x3r_mode != 3) {
-    SBK_LAUNCH((gemm_x3r_kernel<false, 8>), grid, block, 0, st, a);
-  } else {
-    SBK_LAUNCH((gemm_x3r_kernel<false, 0>), grid, block, 0, st, a);
-  }
-  return launch_status("gemm_x3r");
-}
-int gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW, const float* bias, const float* R, int ldr,
-                float* C, int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, hipStream_t st, float2* stats_out) {
-  return launch_x3r(A, lda, PA, PW, bias, R, ldr, C, ldc, PC, M, N, K, act, alpha, -1.0f, nullptr, stats_out, st);
-}
-// C = epilogue(LN(A) . W^T + b) for the rows the search routes to gemm_x3r: PWf = panel image of W[n,k] gamma[k],
-// bf[n] = b[n] + sum_k W[n,k] beta[k] (gemm_ln_nt's convention).  stats_in: the rows' block statistics (written by
-// embed_pos / a gemm_nt_x3r with stats_out), null = a pre-pass over the rows.  -1: shape not eligible
-int gemm_ln_nt_x3r(const float* A, int lda, const float2* stats_in, const uint16_t* PWf, const float* bf, const float* R, int ldr,
-                   float* C, int ldc, uint16_t* PC, int M, int N, int K, float eps, int act, float alpha, hipStream_t st) {
-  if (!(eps >= 0.0f)) return -1;
-  return launch_x3r(A, lda, nullptr, PWf, bf, R, ldr, C, ldc, PC, M, N, K, act, alpha, eps, stats_in, nullptr, st);
-}
-bool x3r_ln_routed(int K) { return g_x3r_ln != 0 && (K == 256 || K == 512 || K == 1024 || K == 1280); }  // (the pre-pass form)
 
 // C = epilogue(LN(A) . Wf^T + bf) with gamma/beta pre-folded into (Wf, bf); returns -1 when the shape is
 // not eligible (the caller then runs LayerNorm + gemm_nt_ws with the unfolded weights).
@@ -2815,8 +2368,6 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 40) sbk::g_score_fused = value;
   if (key == 41) sbk::g_x3r_mode = value;
   if (key == 42) sbk::g_x3r_min_rows = value;
-  if (key == 43) sbk::g_x3r_vocab = value;
-  if (key == 44) sbk::g_x3r_apanel = value;
   if (key == 45) sbk::g_x3r_ln = value;
   if (key == 47) sbk::g_persist = value;
   if (key == 48) sbk::g_persist_grid = value;
@@ -2854,70 +2405,6 @@ extern "C" int sbk_gemm_nt_f32x3(const float* A, int lda, const uint16_t* W3, co
   const int rc = sbk::gemm_nt_x3(A, lda, W3, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq,
                                  sbk::as_stream(stream));
   if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_f32x3: no workspace registered for this stream (sbk_stream_workspace_set) or too many tiles");
-  return rc;
-}
-
-extern "C" int sbk_gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW, const float* bias,
-                               const float* residual, int ldr, float* C, int ldc, uint16_t* PC, int M, int N, int K, int act,
-                               float alpha, sbk_stream_t stream) {
-  if (M == 0 || N == 0) return 0;
-  SBK_REQUIRE((A || PA) && PW && (C || PC), "gemm_x3r: null operand");
-  SBK_REQUIRE(M >= 0 && N >= 0 && N % 4 == 0 && K >= 256 && K % 256 == 0,
-              "gemm_x3r: bad shape M=%d N=%d K=%d (N: a multiple of 4, K: a multiple of 256)", M, N, K);
-  SBK_REQUIRE(PA || (lda >= K && lda % 4 == 0 && sbk::aligned16(A)), "gemm_x3r: rows of A must be 16-byte aligned (lda=%d)", lda);
-  SBK_REQUIRE(sbk::aligned16(PW) && (!PA || sbk::aligned16(PA)) && (!PC || (sbk::aligned16(PC) && N % 16 == 0)),
-              "gemm_x3r: panel images must be 16-byte aligned (a panel result needs N %% 16 == 0)");
-  SBK_REQUIRE(!C || (ldc >= N && ldc % 4 == 0 && sbk::aligned16(C)), "gemm_x3r: C rows are stored as 16-byte vectors (ldc=%d)", ldc);
-  SBK_REQUIRE(!residual || (ldr >= N && ldr % 4 == 0 && sbk::aligned16(residual)), "gemm_x3r: residual stride / alignment");
-  SBK_REQUIRE(!bias || sbk::aligned16(bias), "gemm_x3r: bias alignment");
-  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_x3r: unknown activation %d", act);
-  const int rc = sbk::gemm_nt_x3r(A, lda, PA, PW, bias, residual, ldr, C, ldc, PC, M, N, K, act, alpha, sbk::as_stream(stream));
-  if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_x3r: shape not eligible");
-  return rc;
-}
-
-extern "C" int sbk_gemm_ln_nt_x3r(const float* A, int lda, const uint16_t* PWf, const float* bf, const float* residual, int ldr,
-                                  float* C, int ldc, uint16_t* PC, int M, int N, int K, float eps, int act, float alpha,
-                                  sbk_stream_t stream) {
-  if (M == 0 || N == 0) return 0;
-  SBK_REQUIRE(A && PWf && (C || PC), "gemm_ln_x3r: null operand");
-  SBK_REQUIRE(M >= 0 && N >= 0 && N % 4 == 0 && (K == 256 || K == 512 || K == 1024 || K == 1280),
-              "gemm_ln_x3r: bad shape M=%d N=%d K=%d (N: a multiple of 4, K: 256, 512, 1024 or 1280)", M, N, K);
-  SBK_REQUIRE(eps >= 0.0f, "gemm_ln_x3r: eps must be >= 0");
-  SBK_REQUIRE(lda >= K && lda % 4 == 0 && sbk::aligned16(A), "gemm_ln_x3r: rows of A must be 16-byte aligned (lda=%d)", lda);
-  SBK_REQUIRE(sbk::aligned16(PWf) && (!PC || (sbk::aligned16(PC) && N % 16 == 0)),
-              "gemm_ln_x3r: panel images must be 16-byte aligned (a panel result needs N %% 16 == 0)");
-  SBK_REQUIRE(!C || (ldc >= N && ldc % 4 == 0 && sbk::aligned16(C)), "gemm_ln_x3r: C rows are stored as 16-byte vectors (ldc=%d)", ldc);
-  SBK_REQUIRE(!residual || (ldr >= N && ldr % 4 == 0 && sbk::aligned16(residual)), "gemm_ln_x3r: residual stride / alignment");
-  SBK_REQUIRE(!bf || sbk::aligned16(bf), "gemm_ln_x3r: bias alignment");
-  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_ln_x3r: unknown activation %d", act);
-  const int rc = sbk::gemm_ln_nt_x3r(A, lda, nullptr, PWf, bf, residual, ldr, C, ldc, PC, M, N, K, eps, act, alpha, sbk::as_stream(stream));
-  if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_ln_x3r: shape not eligible");
-  return rc;
-}
-
-extern "C" int sbk_gemm_nt_x3r_stats(const float* A, int lda, const float* stats_in, const uint16_t* PW, const float* bias,
-                                     const float* residual, int ldr, float* C, int ldc, float* stats_out, int M, int N, int K,
-                                     float eps, int act, float alpha, sbk_stream_t stream) {
-  if (M == 0 || N == 0) return 0;
-  SBK_REQUIRE(A && PW && C, "gemm_x3r_stats: null operand");
-  SBK_REQUIRE(M >= 0 && N >= 0 && N % 4 == 0 && K >= 256 && K % 256 == 0,
-              "gemm_x3r_stats: bad shape M=%d N=%d K=%d (N: a multiple of 4, K: a multiple of 256)", M, N, K);
-  SBK_REQUIRE(!stats_in || eps >= 0.0f, "gemm_x3r_stats: eps must be >= 0");
-  SBK_REQUIRE(!stats_out || N % 64 == 0, "gemm_x3r_stats: block statistics of the result need N %% 64 == 0 (N=%d)", N);
-  SBK_REQUIRE(!(stats_in && stats_out), "gemm_x3r_stats: a launch either consumes or produces block statistics");
-  SBK_REQUIRE(lda >= K && lda % 4 == 0 && sbk::aligned16(A), "gemm_x3r_stats: rows of A must be 16-byte aligned (lda=%d)", lda);
-  SBK_REQUIRE(sbk::aligned16(PW) && (!stats_in || sbk::aligned16(stats_in)) && (!stats_out || sbk::aligned16(stats_out)),
-              "gemm_x3r_stats: panel image / statistics must be 16-byte aligned");
-  SBK_REQUIRE(ldc >= N && ldc % 4 == 0 && sbk::aligned16(C), "gemm_x3r_stats: C rows are stored as 16-byte vectors (ldc=%d)", ldc);
-  SBK_REQUIRE(!residual || (ldr >= N && ldr % 4 == 0 && sbk::aligned16(residual)), "gemm_x3r_stats: residual stride / alignment");
-  SBK_REQUIRE(!bias || sbk::aligned16(bias), "gemm_x3r_stats: bias alignment");
-  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_x3r_stats: unknown activation %d", act);
-  const int rc = stats_in ? sbk::gemm_ln_nt_x3r(A, lda, reinterpret_cast<const float2*>(stats_in), PW, bias, residual, ldr, C, ldc,
-                                                nullptr, M, N, K, eps, act, alpha, sbk::as_stream(stream))
-                          : sbk::gemm_nt_x3r(A, lda, nullptr, PW, bias, residual, ldr, C, ldc, nullptr, M, N, K, act, alpha,
-                                             sbk::as_stream(stream), reinterpret_cast<float2*>(stats_out));
-  if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_x3r_stats: shape not eligible");
   return rc;
 }
 

@@ -16,20 +16,17 @@ bool x3_routed(int M, int N, int K);
 int gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, const float* R, int ldr, float* C, int ldc,
                 uint16_t* PC, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
 extern int g_x3p_tile;
-// few-row contraction on the bf16 matrix pipe (csrc/gemm.hip: gemm_x3r_kernel): A fp32 [M, K] or PA = its panel image,
-// PW = the panel image of W (sbk_split_x3p); C fp32 and / or PC = the result's panel image; -1 = shape not eligible
-// stats_out (optional, fp32 A, N % 64 == 0): per row and 32-column block of the result its mean and sum of squared
-// deviations, [M][N / 32] -- what a LayerNorm over those rows needs (gemm_ln_nt_x3r's stats_in)
-int gemm_nt_x3r(const float* A, int lda, const uint16_t* PA, const uint16_t* PW, const float* bias, const float* R, int ldr,
-                float* C, int ldc, uint16_t* PC, int M, int N, int K, int act, float alpha, hipStream_t st,
-                float2* stats_out = nullptr);
+// few-row contraction on the bf16 matrix pipe (csrc/gemm_x3r.hip): A fp32 [M, K], PW = the panel image of W (sbk_split_x3p);
+// -1 = shape not eligible
+int gemm_nt_x3r(const float* A, int lda, const uint16_t* PW, const float* bias, const float* R, int ldr, float* C, int ldc, int M,
+                int N, int K, int act, float alpha, hipStream_t st);
 bool x3r_routed(int M, int N, int K);
-// the same with the LayerNorm over K in its prologue (affine folded into PWf / bf; stats_in: the rows' block statistics,
-// null = a pre-pass over the rows); x3r_ln_routed: knob 45 and a K the pre-pass takes
-int gemm_ln_nt_x3r(const float* A, int lda, const float2* stats_in, const uint16_t* PWf, const float* bf, const float* R, int ldr,
-                   float* C, int ldc, uint16_t* PC, int M, int N, int K, float eps, int act, float alpha, hipStream_t st);
+// the same with the LayerNorm over K in its prologue (affine folded into PWf / bf; row statistics by a pre-pass over the rows);
+// x3r_ln_routed: knob 45 and a K the pre-pass takes
+int gemm_ln_nt_x3r(const float* A, int lda, const uint16_t* PWf, const float* bf, const float* R, int ldr, float* C, int ldc, int M,
+                   int N, int K, float eps, int act, float alpha, hipStream_t st);
 bool x3r_ln_routed(int K);
-extern int g_x3r_mode, g_x3r_min_rows, g_x3r_vocab, g_x3r_apanel, g_x3r_ln;
+extern int g_x3r_mode, g_x3r_min_rows, g_x3r_ln;
 // The decoding step of <= 16 hypothesis rows as ONE cooperative launch (csrc/decoder_persist.hip; keys 47 / 48).
 // persist_eligible: shapes / weights it takes (head_dim 64, folded LayerNorm weights present, <= 16 layers); decoder_step_persist
 // returns -1 when the launch cannot be made (the caller then issues the launch-per-operation step).

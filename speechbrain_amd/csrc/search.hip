@@ -64,7 +64,7 @@ thread_local AsyncPoll g_poll;
 namespace sbk {
 // decoder.hip / ctc_prefix.hip
 int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,
-              hipStream_t st, float2* stats = nullptr);
+              hipStream_t st);
 int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t* kv_slot, float* out, int n, int d,
                    int H, int step, int nslot, int Lmax, hipStream_t st, const int32_t* key_tok = nullptr,
                    int key_stride = 0, int key_shift = 0, int key_first = 0, int pad_idx = 0, int group = 1);
@@ -939,10 +939,6 @@ struct Carver {
 
 struct DecoderBufs {
   float *x, *h, *qkv, *ctx, *q, *ff, *logits;
-  uint16_t *hp, *ctxp, *ffp;  // panel images (sbk_split_x3p layout) of the LayerNorm output / attention context / feed-forward
-                              // hidden layer: the A operands of the step's projections on sbk_gemm_nt_x3r
-  float2* xstat;        // [n][d_model / 32] block statistics of the residual stream x (knob 45 = 3: the LayerNorms of a routed
-                        // step take their row statistics from the kernel that wrote the rows)
   float* splitk;        // split-K partials of the skinny GEMMs
   size_t splitk_floats;
   float* xpart;         // cross-attention split partials
@@ -964,11 +960,6 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
   d.q = c.take<float>((size_t)n * dm);
   d.ff = c.take<float>((size_t)n * W->d_ffn);
   d.logits = c.take<float>((size_t)n * W->vocab);
-  const size_t n64 = ((size_t)n + 63) / 64 * 64;
-  d.hp = c.take<uint16_t>(n64 * dm * 3);
-  d.ctxp = c.take<uint16_t>(n64 * dm * 3);
-  d.ffp = c.take<uint16_t>(n64 * W->d_ffn * 3);
-  d.xstat = c.take<float2>((size_t)n * (dm / 32 + 1));
   d.splitk_floats = (size_t)4 * n * (size_t)dm;  // global split-K is used for the long-K FFN2 only
   d.splitk = c.take<float>(d.splitk_floats);
   d.xpart = c.take<float>(sbk::cross_attn_partial_floats(B, T, W->nhead, dm / W->nhead, n / (B > 0 ? B : 1)) + 64);
@@ -1036,32 +1027,12 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
     if (rc != -1) return rc;
   }
   const float emb_scale = W->emb_scale > 0.0f ? W->emb_scale : sqrtf((float)dm);  // NormalizedEmbedding: sqrt(d_model)
-  const bool apan = sbk::g_x3r_apanel && dm % 16 == 0 && dm <= 2048 && W->d_ffn % 16 == 0;
-  // knob 45 = 3: every LayerNorm of the step takes its row statistics from the kernel that wrote the residual stream
-  // (embed_pos, the self-attention / cross-attention out-projections, the second feed-forward projection) -- needs every
-  // layer on the x3r route with the folded panel images (d_model a multiple of 256, as the route itself asks)
-  bool hand_over = sbk::g_x3r_ln == 3 && !apan && dm % 256 == 0 && sbk::x3r_routed(n, dm, dm) &&
-                   sbk::x3r_routed(n, dm, W->d_ffn) && sbk::x3r_routed(n, W->d_ffn, dm);
-  for (int l = 0; hand_over && l < W->n_layers; ++l) {
-    const sbk_decoder_layer& L = W->layers[l];
-    hand_over = L.sa_in_wp && L.sa_out_wp && L.ca_q_wp && L.ca_out_wp && L.ff1_wp && L.ff2_wp && L.sa_in_wfp && L.sa_in_bf &&
-                L.ca_q_wfp && L.ca_q_bf && L.ff1_wfp && L.ff1_bf && sbk::aligned16(L.sa_in_b) && sbk::aligned16(L.sa_out_b) &&
-                sbk::aligned16(L.ca_in_b) && sbk::aligned16(L.ca_out_b) && sbk::aligned16(L.ff1_b) && sbk::aligned16(L.ff2_b) &&
-                sbk::aligned16(L.sa_in_bf) && sbk::aligned16(L.ca_q_bf) && sbk::aligned16(L.ff1_bf);
-  }
-  float2* const xs = hand_over ? d.xstat : nullptr;
-  SBK_TRY(sbk::embed_pos(tokens, W->emb, W->pe + (size_t)step * dm, d.x, n, dm, emb_scale, st, xs));
+  SBK_TRY(sbk::embed_pos(tokens, W->emb, W->pe + (size_t)step * dm, d.x, n, dm, emb_scale, st));
   // a projection with a panel image of its weights and enough hypothesis rows: sbk_gemm_nt_x3r (fp32 result on the bf16
-  // matrix pipe); -1 = not routed (the register-operand / LDS-tiled fp32-MFMA kernels below).  so: block statistics of the result
-  auto x3r = [&](const float* A, int lda, const uint16_t* PA, const uint16_t* WP, const float* b, const float* R, float* C,
-                 uint16_t* PC, int N, int K, int act, float2* so = nullptr) -> int {
+  // matrix pipe); -1 = not routed (the register-operand / LDS-tiled fp32-MFMA kernels below)
+  auto x3r = [&](const float* A, int lda, const uint16_t* WP, const float* b, const float* R, float* C, int N, int K, int act) -> int {
     if (!WP || !sbk::x3r_routed(n, N, K)) return -1;
-    return sbk::gemm_nt_x3r(A, lda, PA, WP, b, R, N, C, N, PC, n, N, K, act, 1.0f, st, so);
-  };
-  // LayerNorm of the residual stream as the next projection's operand: its panel image (apan) or fp32 rows
-  auto norm = [&](const float* g_, const float* b_) -> int {
-    if (apan) return sbk_layernorm_x3p(d.x, g_, b_, d.hp, n, dm, W->ln_eps, SBK_ACT_NONE, st);
-    return sbk::layernorm(d.x, g_, b_, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st);
+    return sbk::gemm_nt_x3r(A, lda, WP, b, R, N, C, N, n, N, K, act, 1.0f, st);
   };
   // the routed kernels move bias rows as 16-byte vectors: a layer with an unaligned bias view takes the fp32 kernels below
   // instead of failing inside the route
@@ -1074,40 +1045,23 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
     const sbk_decoder_layer& L = W->layers[l];
     if (L.sa_in_wp && L.sa_out_wp && L.ca_q_wp && L.ca_out_wp && L.ff1_wp && L.ff2_wp && sbk::x3r_routed(n, dm, dm) &&
         sbk::x3r_routed(n, dm, W->d_ffn) && biases_aligned(L)) {
-      const float* hA = apan ? nullptr : d.h;
-      const uint16_t* hP = apan ? d.hp : nullptr;
-      // norm1 / norm2 / norm3 inside the projection they feed (folded panel images, ABI 9; knob 45)
-      const bool lnf = !apan && (xs || sbk::x3r_ln_routed(dm)) && L.sa_in_wfp && L.sa_in_bf && L.ca_q_wfp && L.ca_q_bf && L.ff1_wfp && L.ff1_bf;
-      auto x3rln = [&](const uint16_t* WFP, const float* bfold, float* C, int N, int act) -> int {
-        return sbk::gemm_ln_nt_x3r(d.x, dm, xs, WFP, bfold, nullptr, 0, C, N, nullptr, n, N, dm, W->ln_eps, act, 1.0f, st);
+      // norm1 / norm2 / norm3 inside the projection they feed (folded panel images, ABI 9; knob 45), else as launches
+      const bool lnf = sbk::x3r_ln_routed(dm) && L.sa_in_wfp && L.sa_in_bf && L.ca_q_wfp && L.ca_q_bf && L.ff1_wfp && L.ff1_bf;
+      auto ln_proj = [&](const float* g_, const float* b_, const uint16_t* WFP, const float* bfold, const uint16_t* WP, const float* bias,
+                         float* C, int N, int act) -> int {
+        if (lnf) return sbk::gemm_ln_nt_x3r(d.x, dm, WFP, bfold, nullptr, 0, C, N, n, N, dm, W->ln_eps, act, 1.0f, st);
+        SBK_TRY(sbk::layernorm(d.x, g_, b_, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
+        return x3r(d.h, dm, WP, bias, nullptr, C, N, dm, act);
       };
-      if (lnf) {
-        SBK_TRY(x3rln(L.sa_in_wfp, L.sa_in_bf, d.qkv, 3 * dm, SBK_ACT_NONE));
-      } else {
-        SBK_TRY(norm(L.ln1_g, L.ln1_b));
-        SBK_TRY(x3r(hA, dm, hP, L.sa_in_wp, L.sa_in_b, nullptr, d.qkv, nullptr, 3 * dm, dm, SBK_ACT_NONE));
-      }
+      SBK_TRY(ln_proj(L.ln1_g, L.ln1_b, L.sa_in_wfp, L.sa_in_bf, L.sa_in_wp, L.sa_in_b, d.qkv, 3 * dm, SBK_ACT_NONE));
       SBK_TRY(sbk::self_attn_step(d.qkv, d.kcache[l], d.vcache[l], kv_slot, d.ctx, n, dm, H, step, n, Lmax, st, nullptr, 0, 0,
                                   0, 0, beam));
-      if (apan) SBK_TRY(sbk_split_x3p(d.ctx, dm, d.ctxp, n, dm, st));
-      SBK_TRY(x3r(apan ? nullptr : d.ctx, dm, apan ? d.ctxp : nullptr, L.sa_out_wp, L.sa_out_b, d.x, d.x, nullptr, dm, dm, SBK_ACT_NONE, xs));
-      if (lnf) {
-        SBK_TRY(x3rln(L.ca_q_wfp, L.ca_q_bf, d.q, dm, SBK_ACT_NONE));
-      } else {
-        SBK_TRY(norm(L.ln2_g, L.ln2_b));
-        SBK_TRY(x3r(hA, dm, hP, L.ca_q_wp, L.ca_in_b, nullptr, d.q, nullptr, dm, dm, SBK_ACT_NONE));
-      }
+      SBK_TRY(x3r(d.ctx, dm, L.sa_out_wp, L.sa_out_b, d.x, d.x, dm, dm, SBK_ACT_NONE));
+      SBK_TRY(ln_proj(L.ln2_g, L.ln2_b, L.ca_q_wfp, L.ca_q_bf, L.ca_q_wp, L.ca_in_b, d.q, dm, SBK_ACT_NONE));
       SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, d.xpart, B, T, dm, H, beam, st, d.head_major, d.xcnt));
-      if (apan) SBK_TRY(sbk_split_x3p(d.ctx, dm, d.ctxp, n, dm, st));
-      SBK_TRY(x3r(apan ? nullptr : d.ctx, dm, apan ? d.ctxp : nullptr, L.ca_out_wp, L.ca_out_b, d.x, d.x, nullptr, dm, dm, SBK_ACT_NONE, xs));
-      if (lnf) {
-        SBK_TRY(x3rln(L.ff1_wfp, L.ff1_bf, d.ff, W->d_ffn, W->ffn_act));
-      } else {
-        SBK_TRY(norm(L.ln3_g, L.ln3_b));
-        // the feed-forward pair: the hidden layer goes from the first projection's epilogue to the second as a panel image
-        SBK_TRY(x3r(hA, dm, hP, L.ff1_wp, L.ff1_b, nullptr, apan ? nullptr : d.ff, apan ? d.ffp : nullptr, W->d_ffn, dm, W->ffn_act));
-      }
-      SBK_TRY(x3r(apan ? nullptr : d.ff, W->d_ffn, apan ? d.ffp : nullptr, L.ff2_wp, L.ff2_b, d.x, d.x, nullptr, dm, W->d_ffn, SBK_ACT_NONE, xs));
+      SBK_TRY(x3r(d.ctx, dm, L.ca_out_wp, L.ca_out_b, d.x, d.x, dm, dm, SBK_ACT_NONE));
+      SBK_TRY(ln_proj(L.ln3_g, L.ln3_b, L.ff1_wfp, L.ff1_bf, L.ff1_wp, L.ff1_b, d.ff, W->d_ffn, W->ffn_act));
+      SBK_TRY(x3r(d.ff, W->d_ffn, L.ff2_wp, L.ff2_b, d.x, d.x, dm, W->d_ffn, SBK_ACT_NONE));
       continue;
     }
     int frc = L.sa_in_wf ? sbk::gemm_ln_nt(d.x, dm, L.sa_in_wf, dm, L.sa_in_bf, nullptr, 0, d.qkv, 3 * dm, n, 3 * dm, dm,
@@ -1155,15 +1109,15 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
   // decoder.norm inside the vocabulary projection -- for narrow vocabularies only: every column tile's workgroup repeats the
   // row statistics, which at V = 5 000 (79 column tiles) costs what the LayerNorm launch does (58.6 vs 59.0 us at 1 280 rows,
   // 105 vs 117 at 2 560: profiles/r04_s_*); knob 45 = 2 forces it; with handed-over statistics (3) the prologue reads 128 B per row
-  if (want_logits && sbk::g_x3r_vocab && W->seq_wfp && W->seq_bf && (xs || sbk::x3r_ln_routed(dm)) && sbk::x3r_routed(n, W->vocab, dm) &&
-      (W->vocab < 4096 || sbk::g_x3r_ln == 2 || xs)) {
-    const int rc = sbk::gemm_ln_nt_x3r(d.x, dm, xs, W->seq_wfp, W->seq_bf, nullptr, 0, d.logits, W->vocab, nullptr, n, W->vocab, dm,
-                                       W->ln_eps, SBK_ACT_NONE, 1.0f, st);
+  if (want_logits && W->seq_wfp && W->seq_bf && sbk::x3r_ln_routed(dm) && sbk::x3r_routed(n, W->vocab, dm) &&
+      (W->vocab < 4096 || sbk::g_x3r_ln == 2)) {
+    const int rc = sbk::gemm_ln_nt_x3r(d.x, dm, W->seq_wfp, W->seq_bf, nullptr, 0, d.logits, W->vocab, n, W->vocab, dm, W->ln_eps,
+                                       SBK_ACT_NONE, 1.0f, st);
     if (rc != -1) return rc;
   }
   SBK_TRY(sbk::layernorm(d.x, W->final_ln_g, W->final_ln_b, d.h, n, dm, W->ln_eps, SBK_ACT_NONE, st));
   if (want_logits) {
-    int rc = sbk::g_x3r_vocab ? x3r(d.h, dm, nullptr, W->seq_wp, W->seq_b, nullptr, d.logits, nullptr, W->vocab, dm, SBK_ACT_NONE) : -1;
+    int rc = x3r(d.h, dm, W->seq_wp, W->seq_b, nullptr, d.logits, W->vocab, dm, SBK_ACT_NONE);
     if (rc == -1 && W->seq_w3 && sbk::x3_routed(n, W->vocab, dm))
       rc = sbk::gemm_nt_x3(d.h, dm, W->seq_w3, W->seq_b, nullptr, 0, d.logits, W->vocab, n, W->vocab, dm, SBK_ACT_NONE, 1.0f,
                            nullptr, 0, st);

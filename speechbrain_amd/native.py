@@ -103,10 +103,8 @@ def _declare(lib):
         "sbk_x3p_panel_bytes": ([i, i], ctypes.c_size_t),
         "sbk_split_x3p": ([p, i, p, i, i, p], c_int),
         "sbk_layernorm_x3p": ([p, p, p, p, i, i, f, i, p], c_int),
-        "sbk_gemm_nt_x3r": ([p, i, p, p, p, p, i, p, i, p, i, i, i, i, f, p], c_int),
-        "sbk_gemm_ln_nt_x3r": ([p, i, p, p, p, i, p, i, p, i, i, i, f, i, f, p], c_int),
-        "sbk_gemm_nt_x3r_stats": ([p, i, p, p, p, p, i, p, i, p, i, i, i, f, i, f, p], c_int),
-        "sbk_row_block_stats_f32": ([p, i, p, i, i, p], c_int),
+        "sbk_gemm_nt_x3r": ([p, i, p, p, p, i, p, i, i, i, i, i, f, p], c_int),
+        "sbk_gemm_ln_nt_x3r": ([p, i, p, p, p, i, p, i, i, i, i, f, i, f, p], c_int),
         "sbk_quant_rows_fp8": ([p, i, p, p, i, i, p], c_int),
         "sbk_quant_rows_bf16_fp8": ([p, i, p, p, i, i, p], c_int),
         "sbk_layernorm_fp8o": ([p, p, p, p, p, i, i, f, i, p], c_int),
@@ -170,7 +168,7 @@ def load(path: Optional[str] = None):
         )
     lib = ctypes.CDLL(path)
     EXPORTS = tuple(_declare(lib).keys())
-    if lib.sbk_abi_version() != 9:
+    if lib.sbk_abi_version() != 10:
         raise SbkError(f"ABI version mismatch: {lib.sbk_abi_version()}")
     _lib = lib
     return lib
@@ -486,30 +484,19 @@ def gemm_nt_x3p(a: Panel, w: torch.Tensor, bias=None, residual=None, act=ACT_NON
     return out
 
 
-def gemm_nt_x3r(a, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, panel_out=False, fp32_out=True):
+def gemm_nt_x3r(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0):
     """out[M,N] = residual + alpha * act(a @ w^T + bias) for FEW rows (a decoding step's projections) on the bf16 matrix
-    pipe (sbk_gemm_nt_x3r): ``a`` is an fp32 tensor (split in registers) or a Panel, ``w`` is used through its cached panel
-    image; ``panel_out``: also (or, with ``fp32_out=False``, only) return the result as a Panel."""
+    pipe (sbk_gemm_nt_x3r): ``a`` fp32 (split in registers), ``w`` is used through its cached panel image."""
     lib = load()
-    if isinstance(a, Panel):
-        M, K, lead, a2, dev = a.rows, a.K, (a.lead if a.lead is not None else (a.rows,)), None, a.device
-        _dev_ok(a.data)
-    else:
-        K = a.shape[-1]
-        a2 = a.reshape(-1, K)
-        M, lead, dev = a2.shape[0], tuple(a.shape[:-1]), a.device
-        _dev_ok(a2)
-        _f32(a2)
-    N = w.shape[0]
-    _dev_ok(w, bias, residual)
-    out = torch.empty(*lead, N, dtype=torch.float32, device=dev) if fp32_out else None
-    pc = panel_empty(M, N, dev, lead) if panel_out else None
+    K = a.shape[-1]
+    a2 = a.reshape(-1, K)
+    M, N = a2.shape[0], w.shape[0]
+    _dev_ok(a2, w, bias, residual)
+    _f32(a2)
+    out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
-    _chk(lib.sbk_gemm_nt_x3r(_p(a2), K, _p(a.data) if a2 is None else None, _p(lp_weight(w, "x3p")), _p(bias), _p(r2), N,
-                             _p(out), N, _p(pc.data) if pc is not None else None, M, N, K, act, float(alpha),
+    _chk(lib.sbk_gemm_nt_x3r(_p(a2), K, _p(lp_weight(w, "x3p")), _p(bias), _p(r2), N, _p(out), N, M, N, K, act, float(alpha),
                              _stream(w)), "sbk_gemm_nt_x3r")
-    if panel_out:
-        return (out, pc) if fp32_out else pc
     return out
 
 
@@ -525,40 +512,9 @@ def gemm_ln_nt_x3r(a: torch.Tensor, wf: torch.Tensor, bf, eps, residual=None, ac
     _f32(a2)
     out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
     r2 = residual.reshape(-1, N) if residual is not None else None
-    _chk(lib.sbk_gemm_ln_nt_x3r(_p(a2), K, _p(lp_weight(wf, "x3p")), _p(bf), _p(r2), N, _p(out), N, None, M, N, K,
+    _chk(lib.sbk_gemm_ln_nt_x3r(_p(a2), K, _p(lp_weight(wf, "x3p")), _p(bf), _p(r2), N, _p(out), N, M, N, K,
                                 float(eps), act, float(alpha), _stream(wf)), "sbk_gemm_ln_nt_x3r")
     return out
-
-
-def row_block_stats(x: torch.Tensor):
-    """[rows, d / 32, 2]: mean and sum of squared deviations of every 32-column block of the rows of ``x`` (d % 32 == 0) --
-    what the kernels that write a residual stream hand to the LayerNorm behind it (sbk_row_block_stats_f32)."""
-    d = x.shape[-1]
-    x2 = x.reshape(-1, d)
-    _dev_ok(x2)
-    _f32(x2)
-    out = torch.empty(x2.shape[0], d // 32, 2, dtype=torch.float32, device=x.device)
-    _chk(load().sbk_row_block_stats_f32(_p(x2), x2.stride(0), _p(out), x2.shape[0], d, _stream(x2)), "sbk_row_block_stats_f32")
-    return out
-
-
-def gemm_nt_x3r_stats(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act=ACT_NONE, alpha=1.0, stats_in=None,
-                      eps=0.0, stats_out=False):
-    """sbk_gemm_nt_x3r_stats: with ``stats_out`` the plain few-row projection, also returning the block statistics of its
-    result's rows (N % 64 == 0); with ``stats_in`` (the block statistics of the rows of ``a``) the projection of
-    LayerNorm(a) -- ``w`` / ``bias`` are then the FOLDED operands of ``gemm_ln_nt_x3r``."""
-    lib = load()
-    K = a.shape[-1]
-    a2 = a.reshape(-1, K)
-    M, N = a2.shape[0], w.shape[0]
-    _dev_ok(a2, w, bias, residual, stats_in)
-    _f32(a2)
-    out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
-    so = torch.empty(M, N // 32, 2, dtype=torch.float32, device=a.device) if stats_out else None
-    r2 = residual.reshape(-1, N) if residual is not None else None
-    _chk(lib.sbk_gemm_nt_x3r_stats(_p(a2), K, _p(stats_in), _p(lp_weight(w, "x3p")), _p(bias), _p(r2), N, _p(out), N, _p(so),
-                                   M, N, K, float(eps), act, float(alpha), _stream(w)), "sbk_gemm_nt_x3r_stats")
-    return (out, so) if stats_out else out
 
 
 class _Ready:

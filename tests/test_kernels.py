@@ -837,14 +837,11 @@ def test_gemm_x3p(backend, M, N, K, tile):
 
 @pytest.mark.parametrize("M,N,K", [(1280, 512, 512), (300, 132, 256), (70, 1536, 512), (640, 512, 2048), (1280, 2048, 512),
                                    (333, 64, 1024), (1, 40, 256), (1280, 5000, 512)])
-@pytest.mark.parametrize("a_panel", [False, True])
-def test_gemm_x3r(backend, M, N, K, a_panel):
+def test_gemm_x3r(backend, M, N, K):
     """sbk_gemm_nt_x3r: the decode step's few-row projections on the bf16 matrix pipe (W as its panel image; A fp32 and
-    split in registers, or as its panel image too; 64 x 64 tiles whose four waves split K, long K split further with a
-    fixed-order reduce).  Held to the bound of every fp32 kernel of the library against the fp64 product (2e-6 of the
-    largest sum of magnitudes); ragged edges; bias / activation / scaled residual; the panel-image result (the next
-    projection's A operand) equals the fp32 result bit for bit; both forms of A give the SAME bits (the split is exact);
-    run-to-run bit-identical."""
+    split in registers; 64 x 64 tiles whose four waves split K however long it is).  Held to the bound of every fp32 kernel
+    of the library against the fp64 product (2e-6 of the largest sum of magnitudes); ragged edges; bias / activation /
+    scaled residual; run-to-run bit-identical."""
     nat, dev = backend
     if dev.type == "cpu" and M * N * K > 1.2e8:
         pytest.skip("large shape: GPU only")
@@ -855,29 +852,15 @@ def test_gemm_x3r(backend, M, N, K, a_panel):
     w[::5] *= 300.0
     b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
     ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
-    op = nat.split_x3p(ad) if a_panel else ad
     prod = a.double() @ w.double().t()
     scale = float((a.double().abs() @ w.double().abs().t()).max())
-    out = nat.gemm_nt_x3r(op, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5)
+    out = nat.gemm_nt_x3r(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5)
     ref = (r.double() + 0.5 * F.silu(prod + b.double())).float()
     assert _md(out, ref) <= 2e-6 * scale + 1e-5
     for _ in range(3 if dev.type == "cuda" else 1):
-        assert torch.equal(nat.gemm_nt_x3r(op, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
-    if a_panel:
-        assert torch.equal(out, nat.gemm_nt_x3r(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5))
-    plain = nat.gemm_nt_x3r(op, wd)
+        assert torch.equal(nat.gemm_nt_x3r(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
+    plain = nat.gemm_nt_x3r(ad, wd)
     assert _md(plain, prod.float()) <= 2e-6 * scale + 1e-5
-    if N % 16 == 0:
-        both, pc = nat.gemm_nt_x3r(op, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5, panel_out=True)
-        RB, KBn = (M + 63) // 64, N // 16
-        pieces = (pc.data.cpu().view(torch.int16).to(torch.int32) << 16).view(torch.float32).view(RB, KBn, 3, 2, 64, 8)
-        full = pieces.double().sum(2).permute(0, 3, 1, 2, 4).reshape(RB * 64, N).float()
-        assert torch.equal(both, out) and torch.equal(full[:M], out.cpu())
-        only = nat.gemm_nt_x3r(op, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5, panel_out=True, fp32_out=False)
-        # (the hand-over: a second projection fed with the panel image equals the one fed with the fp32 result)
-        w2 = torch.randn(64, N, generator=g).to(dev)
-        if N % 256 == 0:
-            assert torch.equal(nat.gemm_nt_x3r(only, w2), nat.gemm_nt_x3r(out, w2))
 
 
 @pytest.mark.parametrize("M,N,K", [(1280, 512, 512), (300, 132, 512), (70, 1536, 512), (1280, 2048, 512), (1, 40, 512),
@@ -919,57 +902,6 @@ def test_gemm_ln_x3r(backend, M, N, K):
     # constant rows (variance 0: rstd = 1 / sqrt(eps), x - mean = 0 exactly) give the folded bias
     const = torch.full((3, K), 2.5).to(dev)
     assert _md(nat.gemm_ln_nt_x3r(const, wfd, bfd, eps), bf.expand(3, N)) <= 1e-6 * float(bf.abs().max()) + 1e-6
-
-
-@pytest.mark.parametrize("M,dm,N", [(1280, 512, 1536), (300, 512, 132), (70, 512, 512), (45, 1280, 260), (130, 256, 768),
-                                    (1280, 512, 5000)])
-def test_gemm_x3r_layernorm_from_handed_over_block_statistics(backend, M, dm, N):
-    """The LayerNorm of a decode-step projection WITHOUT a pass over its rows (sbk_gemm_nt_x3r_stats): the projection that
-    writes the residual stream (x = residual + ctx . Wo^T + b, N = d_model) also writes, per row and 32-column block, the
-    block's mean and sum of squared deviations; the projection behind the LayerNorm folds the blocks of its rows (pairwise
-    update with equal block sizes) and runs on x - mean, rstd on the finished tile.  The handed-over statistics equal the
-    blocks' two-pass statistics of the written rows (1e-6 relative to the row's scale) and sbk_row_block_stats_f32's bit
-    for bit (embed_pos uses that arithmetic); the LayerNorm-projection against LayerNorm + Linear in fp64 at the bound of
-    the library's fp32 kernels and against the pre-pass form (sbk_gemm_ln_nt_x3r); run-to-run bit-identical."""
-    nat, dev = backend
-    if dev.type == "cpu" and M * N * dm > 1.2e8:
-        pytest.skip("large shape: GPU only")
-    g = torch.Generator().manual_seed(M + N + dm + 2)
-    ctx = torch.randn(M, dm, generator=g)
-    wo, bo = torch.randn(dm, dm, generator=g) / dm ** 0.5, torch.randn(dm, generator=g)
-    x0 = torch.randn(M, dm, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 3.0) + torch.randn(M, 1, generator=g) * 4.0
-    x0[::7] *= 1e-3
-    x0[:, ::5] *= 3.0
-    w = torch.randn(N, dm, generator=g) / dm ** 0.5
-    w[::5] *= 30.0
-    gamma, beta, b = 1.0 + 0.3 * torch.randn(dm, generator=g), 0.2 * torch.randn(dm, generator=g), torch.randn(N, generator=g)
-    eps = 1e-5
-    wf, bf = nat._fold_ln(w, b, gamma, beta)
-    ctxd, wod, bod, x0d, wfd, bfd = (t.to(dev) for t in (ctx, wo, bo, x0, wf, bf))
-    x, st = nat.gemm_nt_x3r_stats(ctxd, wod, bod, residual=x0d, stats_out=True)
-    assert torch.equal(x, nat.gemm_nt_x3r(ctxd, wod, bod, x0d))  # the rows themselves: the plain projection's
-    blocks = x.cpu().double().view(M, dm // 32, 32)
-    mb = blocks.mean(-1)
-    m2 = ((blocks - mb[..., None]) ** 2).sum(-1)
-    rowscale = x.cpu().double().abs().amax(-1, keepdim=True)
-    assert float(((st[..., 0].cpu().double() - mb).abs() / rowscale).max()) <= 1e-6
-    assert float(((st[..., 1].cpu().double() - m2).abs() / (32 * rowscale ** 2)).max()) <= 1e-6
-    st2 = nat.row_block_stats(x)
-    assert float(((st2[..., 0].cpu().double() - mb).abs() / rowscale).max()) <= 1e-6
-    assert float(((st2[..., 1].cpu().double() - m2).abs() / (32 * rowscale ** 2)).max()) <= 1e-6
-    ln64 = F.layer_norm(x.cpu().double(), (dm,), gamma.double(), beta.double(), eps)
-    prod = ln64 @ w.double().t() + b.double()
-    scale = float((ln64.abs() @ w.double().abs().t()).max())
-    for stats in (st, st2):
-        out = nat.gemm_nt_x3r_stats(x, wfd, bfd, stats_in=stats, eps=eps)
-        assert _md(out, prod.float()) <= 2e-6 * scale + 1e-5
-    for _ in range(3 if dev.type == "cuda" else 1):
-        assert torch.equal(nat.gemm_nt_x3r_stats(x, wfd, bfd, stats_in=st2, eps=eps), out)
-    if dm in (256, 512, 1024, 1280):
-        assert _md(out, nat.gemm_ln_nt_x3r(x, wfd, bfd, eps)) <= 2e-6 * scale + 1e-5
-    r = torch.randn(M, N, generator=g)
-    out2 = nat.gemm_nt_x3r_stats(x, wfd, bfd, residual=r.to(dev), act=nat.ACT_SWISH, alpha=0.5, stats_in=st, eps=eps)
-    assert _md(out2, (r.double() + 0.5 * F.silu(prod)).float()) <= 2e-6 * scale + 1e-5
 
 
 def _e4m3(q):  # uint8 e4m3 bits -> float32 (torch's own decoder)

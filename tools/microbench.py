@@ -354,13 +354,6 @@ if __name__ == "__main__":
                 line = f"x3r M={M} N={N} K={K}: fp32-MFMA route {t0:6.1f} us {2.0*M*N*K/t0/1e6:6.1f} TF/s |"
                 t = ev_time(lambda: nat.gemm_nt_x3r(a, w, residual=r))
                 line += f" x3r, A fp32: {t:6.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s |"
-                pa = nat.split_x3p(a)
-                t = ev_time(lambda: nat.gemm_nt_x3r(pa, w, residual=r))
-                tsp = ev_time(lambda: nat.split_x3p(a))
-                line += f" A panel: {t:6.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s (split pass {tsp:4.1f} us) |"
-                if N % 16 == 0:
-                    t = ev_time(lambda: nat.gemm_nt_x3r(pa, w, act=nat.ACT_GELU, panel_out=True, fp32_out=False))
-                    line += f" panel out: {t:6.1f} us |"
                 ref = a.double() @ w.double().t() + r.double()
                 e3 = float((nat.gemm_nt_x3r(a, w, residual=r).double() - ref).pow(2).mean().sqrt())
                 e0 = float((nat.gemm_nt_splitk(a, w, residual=r, slices=4).double() - ref).pow(2).mean().sqrt())
@@ -391,16 +384,8 @@ if __name__ == "__main__":
                 ref = torch.nn.functional.layer_norm(a.double(), (K,), g.double(), bt.double(), 1e-5) @ w.double().t() + b.double()
                 e1 = float((nat.gemm_ln_nt_x3r(a, wf, bf, 1e-5).double() - ref).abs().max())
                 e2 = float((nat.gemm_nt_x3r(nat.layernorm(a, g, bt, 1e-5), w, b).double() - ref).abs().max())
-                st = nat.row_block_stats(a)
-                t3 = ev_time(lambda: nat.gemm_nt_x3r_stats(a, wf, bf, stats_in=st, eps=1e-5))
-                e3 = float((nat.gemm_nt_x3r_stats(a, wf, bf, stats_in=st, eps=1e-5).double() - ref).abs().max())
                 print(f"x3r-ln M={M} N={N}: layernorm {t_ln:5.1f} us + x3r {t_g:5.1f} us, back to back {t2:5.1f} us | pre-pass {t1:5.1f} us "
-                      f"({2.0*M*N*K/t1/1e6:5.1f} TF/s) | handed-over statistics {t3:5.1f} us | max err vs fp64: {e1:.2e} / {e3:.2e}, two launches {e2:.2e}", flush=True)
-            # the producing side: a projection that writes the residual stream, with and without the block statistics of its result
-            ctx = torch.randn(M, K, device=dev); wo = torch.randn(K, K, device=dev); x0 = torch.randn(M, K, device=dev)
-            tp0 = ev_time(lambda: nat.gemm_nt_x3r(ctx, wo, residual=x0))
-            tp1 = ev_time(lambda: nat.gemm_nt_x3r_stats(ctx, wo, residual=x0, stats_out=True))
-            print(f"x3r-ln M={M}: out-projection {K} -> {K} + residual {tp0:5.1f} us, also writing block statistics {tp1:5.1f} us", flush=True)
+                      f"({2.0*M*N*K/t1/1e6:5.1f} TF/s) | max err vs fp64: {e1:.2e}, two launches {e2:.2e}", flush=True)
         sys.exit(0)
     if "--ln-x3p" in sys.argv:  # LayerNorm written as the next contraction's panel operand vs LayerNorm + split pass
         def ev_time(fn, n=30):
