@@ -20,27 +20,7 @@ namespace {
 
 using sbk::f32x16;
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-  switch (act) {
-    case SBK_ACT_SWISH: return v / (1.0f + expf(-v));
-    case SBK_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    case SBK_ACT_RELU: return v > 0.0f ? v : 0.0f;
-    case SBK_ACT_LEAKY_RELU: return v > 0.0f ? v : 0.01f * v;
-    default: return v;
-  }
-}
-
-struct GemmArgs {
-  const float* A;
-  const float* W;
-  const float* bias;
-  const float* R;
-  float* C;
-  int lda, ldw, ldr, ldc, M, N, K, act;
-  float alpha;
-  const int32_t* seq_len;  // optional: rows are [batch][rows_per_seq]; rows >= seq_len[batch] produce v = 0
-  int rows_per_seq;
-};
+#include "gemm_common.h"
 
 // Epilogue of a 32x32 register tile held by ONE wave (lane: column r, rows (q&3) + 8*(q>>2) + 4*half): straight-line
 // code -- the residual rows / sequence lengths are requested together, the activation is chosen by ONE uniform
@@ -100,188 +80,6 @@ __device__ __forceinline__ void tile_epilogue_32x32(const GemmArgs& g, float (&v
   }
 }
 
-// ---------------------------------------------------------------------------
-// bf16-operand fast path (sbk_gemm_nt_bf16, SURVEY 8b "fast entry points"): C = epilogue(bf16(A) . Wb^T) with fp32
-// accumulation on v_mfma_f32_32x32x16_bf16 (16x the f32 matrix rate).  A stays fp32 in HBM -- every kernel around
-// the contraction (LayerNorm, attention, GLU/conv, residual stream) is the fp32 one -- and is rounded to bf16 (RNE) on
-// its way into LDS; Wb is the weight matrix converted once by the caller.  Same 128x128 tiling, XCD-aware order and
-// epilogue as the f32 kernel; LDS rows are 32 bf16 + 8 pad (80 B: the 16-lane groups of a ds_read_b128 hit 16
-// distinct 4-bank groups), each operand fragment is one ds_read_b128 of 8 consecutive k.  With the MFMA work cut
-// 16x the kernel is bound by the fp32 A / C traffic (4 B per element each), not by the matrix pipe.
-struct GemmBf16Args {
-  const float* A;
-  const void* W;  // [N,K] reduced-precision bits: bf16 / fp16 (2 bytes) or fp8 e4m3 (1 byte)
-  const float* bias;
-  const float* R;
-  float* C;
-  int lda, ldw, ldr, ldc, M, N, K, act;
-  float alpha;
-  const int32_t* seq_len;
-  int rows_per_seq;
-  // fp8 only: A is multiplied by 448 / a_absmax[0] (device scalar) before it is rounded to e4m3, the accumulators by
-  // a_absmax[0] / 448 * w_scale afterwards (w_scale = the weight's own absmax / 448, applied when it was quantised)
-  const float* a_absmax;
-  float w_scale;
-};
-
-// DT: 0 = bf16, 1 = fp16 (operands 8 x 16 bit per lane), 2 = fp8 e4m3 (8 x 8 bit per lane); all on the
-// 32x32x16 matrix-core shape with fp32 accumulation.
-template <int BM, int BN, int DT>
-__global__ void __launch_bounds__(256, 2) gemm_nt_lp_kernel(GemmBf16Args g) {
-  using Elem = typename std::conditional<DT == 2, unsigned char, unsigned short>::type;
-  constexpr int ES = (int)sizeof(Elem);
-  constexpr int BK = 32, PITCH = BK + 16 / ES;  // elements per LDS row: 16 bytes of padding
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int APER = BM * BK / 4 / 256;          // float4 slots of the A panel per thread
-  constexpr int WV = 16 / ES;                      // W elements per 16-byte load
-  constexpr int WSLOTS = BN * BK / WV;             // 16-byte slots of the W panel
-  constexpr int WPER = (WSLOTS + 255) / 256;
-  static_assert(APER >= 1, "tile too small for 256 threads");
-  __shared__ __attribute__((aligned(16))) Elem As[BM][PITCH];
-  __shared__ __attribute__((aligned(16))) Elem Ws[BN][PITCH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
-    const int id = by * gx + bx;
-    if (nwg % 8 == 0) {
-      const int swz = (id % 8) * (nwg / 8) + id / 8;
-      bx = swz % gx;
-      by = swz / gx;
-    }
-  }
-  const int m0 = by * BM, n0 = bx * BN;
-  const int lrow = lane & 31, kh = lane >> 5;
-  float a_mul = 1.0f, out_mul = 1.0f;
-  if constexpr (DT == 2) {
-    const float amax = fmaxf(g.a_absmax ? g.a_absmax[0] : 448.0f, 1e-30f);
-    a_mul = 448.0f / amax;
-    out_mul = amax / 448.0f * g.w_scale;
-  }
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  float4 ra[APER];
-  uint4 rw[WPER];
-  const Elem* Wp = reinterpret_cast<const Elem*>(g.W);
-  const bool interior = m0 + BM <= g.M && n0 + BN <= g.N && (g.K % BK) == 0;  // uniform: unpredicated panel loads
-  auto fetch = [&](int k0) SBK_INLINE_LAMBDA {
-#pragma unroll
-    for (int i = 0; i < APER; ++i) {
-      const int s = tid + i * 256, rr = s / (BK / 4), c = (s % (BK / 4)) * 4;
-      const int gr = m0 + rr, gk = k0 + c;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (interior || (gr < g.M && gk < g.K)) v = *reinterpret_cast<const float4*>(g.A + (size_t)gr * g.lda + gk);  // K % 8 == 0
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < WPER; ++i) {
-      const int s = tid + i * 256, rr = s / (BK / WV), c = (s % (BK / WV)) * WV;
-      const int gr = n0 + rr, gk = k0 + c;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (s < WSLOTS && (interior || (gr < g.N && gk < g.K))) v = *reinterpret_cast<const uint4*>(Wp + (size_t)gr * g.ldw + gk);
-      rw[i] = v;
-    }
-  };
-  auto commit = [&]() SBK_INLINE_LAMBDA {
-#pragma unroll
-    for (int i = 0; i < APER; ++i) {
-      const int s = tid + i * 256, rr = s / (BK / 4), c = (s % (BK / 4)) * 4;
-      if constexpr (DT == 0) {
-        uint2 p;
-        p.x = (unsigned)sbk::f32_to_bf16(ra[i].x) | ((unsigned)sbk::f32_to_bf16(ra[i].y) << 16);
-        p.y = (unsigned)sbk::f32_to_bf16(ra[i].z) | ((unsigned)sbk::f32_to_bf16(ra[i].w) << 16);
-        *reinterpret_cast<uint2*>(&As[rr][c]) = p;
-      } else if constexpr (DT == 1) {
-        uint2 p;
-        p.x = (unsigned)sbk::f32_to_f16(ra[i].x) | ((unsigned)sbk::f32_to_f16(ra[i].y) << 16);
-        p.y = (unsigned)sbk::f32_to_f16(ra[i].z) | ((unsigned)sbk::f32_to_f16(ra[i].w) << 16);
-        *reinterpret_cast<uint2*>(&As[rr][c]) = p;
-      } else {
-        const unsigned p = (unsigned)sbk::f32x2_to_fp8(ra[i].x * a_mul, ra[i].y * a_mul) |
-                           ((unsigned)sbk::f32x2_to_fp8(ra[i].z * a_mul, ra[i].w * a_mul) << 16);
-        *reinterpret_cast<unsigned*>(&As[rr][c]) = p;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < WPER; ++i) {
-      const int s = tid + i * 256, rr = s / (BK / WV), c = (s % (BK / WV)) * WV;
-      if (s < WSLOTS) *reinterpret_cast<uint4*>(&Ws[rr][c]) = rw[i];
-    }
-  };
-  fetch(0);
-  for (int k0 = 0; k0 < g.K; k0 += BK) {
-    commit();
-    __syncthreads();
-    if (k0 + BK < g.K) fetch(k0 + BK);
-#pragma unroll
-    for (int ks = 0; ks < BK; ks += 16) {
-      if constexpr (DT == 2) {
-        sbk::fp8x8 a[TM], b[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const sbk::fp8x8*>(&As[wm0 + i * 32 + lrow][ks + kh * 8]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const sbk::fp8x8*>(&Ws[wn0 + j * 32 + lrow][ks + kh * 8]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_fp8(a[i], b[j], acc[i][j]);
-      } else if constexpr (DT == 1) {
-        sbk::f16x8 a[TM], b[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const sbk::f16x8*>(&As[wm0 + i * 32 + lrow][ks + kh * 8]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const sbk::f16x8*>(&Ws[wn0 + j * 32 + lrow][ks + kh * 8]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_f16(a[i], b[j], acc[i][j]);
-      } else {
-        sbk::bf16x8 a[TM], b[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const sbk::bf16x8*>(&As[wm0 + i * 32 + lrow][ks + kh * 8]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const sbk::bf16x8*>(&Ws[wn0 + j * 32 + lrow][ks + kh * 8]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(a[i], b[j], acc[i][j]);
-      }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn0 + j * 32 + lrow;
-    if (col >= g.N) continue;
-    const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (row >= g.M) continue;
-        float v = apply_act(acc[i][j][r] * out_mul + bv, g.act) * g.alpha;
-        if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
-        if (g.R) v += g.R[(size_t)row * g.ldr + col];
-        g.C[(size_t)row * g.ldc + col] = v;
-      }
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = sbk::f32_to_bf16(x[i]);
-}
-__global__ void __launch_bounds__(256) f32_to_f16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = sbk::f32_to_f16(x[i]);
-}
 // W [N][K] fp32 -> [N][K/32][3][32] bf16: the three exact pieces of every element (hi = bf16(x), mid = bf16(x - hi),
 // lo = x - hi - mid, round to nearest even), one 192-byte record per row and 32-deep K tile -- the W operand of gemm_nt_sk_kernel<.., X3>
 __global__ void __launch_bounds__(256) split_bf16x3_kernel(const float* __restrict__ W, int ldw, unsigned short* __restrict__ out,
@@ -300,20 +98,6 @@ __global__ void __launch_bounds__(256) split_bf16x3_kernel(const float* __restri
     o[64] = sbk::f32_to_bf16(q);
   }
 }
-// y = e4m3(x * mul), two values per thread (n even)
-__global__ void __launch_bounds__(256) f32_to_fp8_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n2,
-                                                         float mul) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256)
-    y[i] = sbk::f32x2_to_fp8(x[2 * i] * mul, x[2 * i + 1] * mul);
-}
-// out[0] = max |x| (non-negative floats order like their bit patterns: atomicMax on the int image; out zeroed by the caller)
-__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int* __restrict__ out, long n) {
-  float m = 0.0f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
-  m = sbk::wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(out, (int)__float_as_uint(m));
-}
-
 // Register-staged panel: global -> registers (issued early, in flight under the MFMAs of the previous
 // K tile) -> LDS [rows][BK+1].
 template <int ROWS, int BK, int NT>
@@ -507,149 +291,6 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM * WN <= 64 * 6
 // tile (agent-scope release), takes a ticket on the tile's counter, and the last ticket sums the SK partial tiles in
 // slice order -- the order splitk_reduce_kernel uses, so the result is bit-identical to the two-launch path -- applies
 // the epilogue and re-arms the counter.  One launch less per long-K projection of a decoding step; nobody waits.
-template <int BM, int BN, int BK, int WM, int WN, bool VEC>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM * WN <= 64 * 64) ? 2 : 1) gemm_nt_splitk_fused_kernel(GemmArgs g, float* __restrict__ ws,
-                                                                                           int kper, int* __restrict__ cnt) {
-  constexpr int NT = (BM / WM) * (BN / WN) * 64;
-  __shared__ int ticket;
-  const int z = blockIdx.z, SK = gridDim.z;
-  GemmArgs p = g;
-  p.A += (size_t)z * kper;
-  p.W += (size_t)z * kper;
-  p.K = (g.K - z * kper) < kper ? (g.K - z * kper) : kper;
-  p.C = ws + (size_t)z * g.M * g.N;
-  p.ldc = g.N;
-  p.bias = nullptr;
-  p.R = nullptr;
-  p.act = SBK_ACT_NONE;
-  p.alpha = 1.0f;
-  p.seq_len = nullptr;
-  int bx = 0, by = 0;
-  gemm_nt_tile<BM, BN, BK, WM, WN, VEC>(p, &bx, &by);
-  sbk::vm_drain();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    sbk::release_agent();
-    ticket = sbk::atomic_add_agent(cnt + by * gridDim.x + bx, 1);
-  }
-  __syncthreads();
-  if (sbk::uniform(ticket) != SK - 1) return;
-  if (threadIdx.x == 0) {
-    sbk::acquire_agent();
-    sbk::atomic_store_agent(cnt + by * gridDim.x + bx, 0);  // re-armed for the next launch on this stream
-  }
-  __syncthreads();
-  const size_t total = (size_t)g.M * g.N;
-  const int m0 = by * BM, n0 = bx * BN;
-  for (int e = threadIdx.x; e < BM * BN; e += NT) {
-    const int row = m0 + e / BN, col = n0 + e % BN;
-    if (row >= g.M || col >= g.N) continue;
-    const size_t i = (size_t)row * g.N + col;
-    float acc = ws[i];
-    for (int ks = 1; ks < SK; ++ks) acc += ws[(size_t)ks * total + i];
-    float v = apply_act(acc + (g.bias ? g.bias[col] : 0.0f), g.act) * g.alpha;
-    if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
-    if (g.R) v += g.R[(size_t)row * g.ldr + col];
-    g.C[(size_t)row * g.ldc + col] = v;
-  }
-}
-
-// Same tiling with 16-byte LDS traffic.  The two k-slices of v_mfma_f32_32x32x2 need not be neighbours in
-// memory: any pairing of k values is a valid contraction as long as A and W use the same one.  Lane half
-// `lk` therefore owns the contiguous run [lk*BK/2, (lk+1)*BK/2) of a K tile and MFMA number j multiplies
-// k = j (lanes 0-31) with k = BK/2 + j (lanes 32-63): every operand fetch is a ds_read_b128 of four
-// consecutive k (4x fewer LDS instructions than scalar reads at pitch BK+1) and every panel store a
-// ds_write_b128.  Pitch BK+4 floats: the 16-lane groups of a b128 read (MI355X_MICROARCH.md, LDS table) land
-// on 16 distinct 4-bank groups because (BK+4)/4 is odd; the 8-lane groups of a b128 write cover one row.
-template <int BM, int BN, int BK, int WM, int WN, bool VEC>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM * WN <= 64 * 64) ? 2 : 1) gemm_nt_v4_kernel(GemmArgs g) {
-  constexpr int WAVES_N = BN / WN;
-  constexpr int NT = (BM / WM) * (BN / WN) * 64;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  static_assert(((BK + 4) / 4) % 2 == 1 && BK % 8 == 0, "pitch (BK+4)/4 must be odd");
-  __shared__ __attribute__((aligned(16))) float As[BM][BK + 4];
-  __shared__ __attribute__((aligned(16))) float Ws[BN][BK + 4];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-  int bx = blockIdx.x, by = blockIdx.y;
-  {  // XCD-aware tile order, as in gemm_nt_kernel
-    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
-    const int id = by * gx + bx;
-    if (nwg % 8 == 0) {
-      const int swz = (id % 8) * (nwg / 8) + id / 8;
-      bx = swz % gx;
-      by = swz / gx;
-    }
-  }
-  const int m0 = by * BM, n0 = bx * BN;
-  const int lrow = lane & 31, lk = lane >> 5;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  PanelStage<BM, BK, NT> pa;
-  PanelStage<BN, BK, NT> pw;
-  pa.template fetch<VEC>(g.A, g.lda, m0, g.M, 0, g.K, tid);
-  pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, 0, g.K, tid);
-  for (int k0 = 0; k0 < g.K; k0 += BK) {
-    pa.commit_vec(As, tid);
-    pw.commit_vec(Ws, tid);
-    __syncthreads();
-    if (k0 + BK < g.K) {  // next K tile: loads fly while this tile is multiplied
-      pa.template fetch<VEC>(g.A, g.lda, m0, g.M, k0 + BK, g.K, tid);
-      pw.template fetch<VEC>(g.W, g.ldw, n0, g.N, k0 + BK, g.K, tid);
-    }
-#pragma unroll
-    for (int kv = 0; kv < BK / 2; kv += 4) {
-      float4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(&As[wm0 + i * 32 + lrow][lk * (BK / 2) + kv]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(&Ws[wn0 + j * 32 + lrow][lk * (BK / 2) + kv]);
-      // k-major order: consecutive MFMAs go to DIFFERENT accumulators (a same-accumulator pair with anything
-      // scheduled in between stalls, MI355X_MICROARCH.md per-instruction table)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const float av = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
-            const float bw = e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w;
-            acc[i][j] = sbk::mfma_32x32x2(av, bw, acc[i][j]);
-          }
-    }
-    __syncthreads();
-  }
-
-  // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn0 + j * 32 + lrow;
-    if (col >= g.N) continue;
-    const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= g.M) continue;
-        float v = apply_act(acc[i][j][r] + bv, g.act) * g.alpha;
-        if (g.seq_len && (row % g.rows_per_seq) >= g.seq_len[row / g.rows_per_seq]) v = 0.0f;
-        if (g.R) v += g.R[(size_t)row * g.ldr + col];
-        g.C[(size_t)row * g.ldc + col] = v;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
 // Persistent GEMM on LDS-DMA panels with a stream-K tail (the encoder's contractions: M = frames of a batch, 4-24 K
 // rows, i.e. 100-3000 tiles of 128x128 -- tile counts that fill 256 CUs badly when every workgroup takes whole tiles).
@@ -681,8 +322,6 @@ struct SkArgs {
   float* slabs;  // [2 * G][128 * 128] partial tiles (slot 0: the workgroup's segment that does not start a tile; 1: the one that does)
   int* cnt;      // [tiles] arrival tickets, zero between launches
   int tiles_n, tiles, KT;
-  int stagger;   // upper half of each XCD's workgroups runs the tail share first
-  int noload;    // measurement only (knob 22): panels are loaded once per workgroup (wrong results, MFMA/LDS ceiling)
 };
 
 // BT: tile edge (128: four waves of 64x64, the encoder shapes; 64: four waves of 32x32, 32 KB of LDS -- the decode-step
@@ -712,9 +351,9 @@ struct SkArgs {
 // instead of by LDS-DMA, whose pieces keep a wave's issue port for 60-180 cycles each.  It needs 40 staging registers: at the
 // 256-register budget of two workgroups per CU hipcc spills them, at 512 it parks the accumulators in AGPRs and copies them per
 // K tile: 415 us where the LDS-DMA kernel takes 170, profiles/r03_f32x3_sweep.log "g1256".)
-template <int BT, bool IL, bool X3, int MEAS = 0>
+template <int BT, bool X3>
 __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
-  static_assert(!X3 || (BT == 128 && !IL), "the split-operand variant: 128-wide tiles, panel loads in one block");
+  static_assert(BT == 128, "128-wide tiles (the 64-wide instantiation of round 3 -- knobs 25 / 26 -- never won a shape and is gone)");
   constexpr int BK = 32, PANEL = BT * BK, WPITCH = X3 ? 48 : BK, WPANEL = BT * WPITCH, STAGE = PANEL + WPANEL;  // floats
   constexpr int TS = BT / 64, WT = BT / 2, LI = BT / 32;      // 32x32 sub-tiles per wave and dimension, wave tile edge, loader instructions per wave and panel
   // the wave's sub-tiles: TM x TN of 32 x 32.  X3: one row block x four column blocks (a wave = 32 rows of the tile, all
@@ -734,7 +373,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
   const int rows_per_seq = s.g.rows_per_seq;
   float* const slabs = s.slabs;
   int* const cnt = s.cnt;
-  const int tiles_n = s.tiles_n, KT = s.KT, noload = s.noload;
+  const int tiles_n = s.tiles_n, KT = s.KT;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = sbk::uniform(tid >> 6);
   const int wm0 = X3 ? wave * 32 : (wave >> 1) * WT, wn0 = X3 ? 0 : (wave & 1) * WT;
@@ -756,7 +395,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
   }
   const int nseg_wg = nfull + nt;
   if (nseg_wg == 0) return;
-  const bool tail_first = s.stagger && j >= (W >> 1);
+  const bool tail_first = j >= (W >> 1);
   auto seg_get = [&](int sidx, int& tile, int& lo, int& hi) SBK_INLINE_LAMBDA {
     const int d = tail_first ? sidx - nt : sidx;
     if (d >= 0 && d < nfull) {
@@ -846,17 +485,12 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
           const float4 x1 = *reinterpret_cast<const float4*>(As + i * 32 * BK + ((4 * gk + 2 * half + 1) ^ sw) * 4);
           const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
           unsigned h[4], m[4], l[4];
-          if constexpr ((MEAS & 2) != 0) {  // measurement only: no operand split (wrong results)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) h[p] = m[p] = l[p] = __float_as_uint(x[2 * p]) ^ __float_as_uint(x[2 * p + 1]);
-          } else {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {  // x = hi + mid + lo exactly: 8 significand bits each, remainders exact in fp32
-              h[p] = sbk::bf16_pair(x[2 * p], x[2 * p + 1]);
-              const float r0 = x[2 * p] - __uint_as_float(h[p] << 16), r1 = x[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
-              m[p] = sbk::bf16_pair(r0, r1);
-              l[p] = sbk::bf16_pair(r0 - __uint_as_float(m[p] << 16), r1 - __uint_as_float(m[p] & 0xffff0000u));
-            }
+          for (int p = 0; p < 4; ++p) {  // x = hi + mid + lo exactly: 8 significand bits each, remainders exact in fp32
+            h[p] = sbk::bf16_pair(x[2 * p], x[2 * p + 1]);
+            const float r0 = x[2 * p] - __uint_as_float(h[p] << 16), r1 = x[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
+            m[p] = sbk::bf16_pair(r0, r1);
+            l[p] = sbk::bf16_pair(r0 - __uint_as_float(m[p] << 16), r1 - __uint_as_float(m[p] & 0xffff0000u));
           }
           ah[i] = sbk::bf16x8_from_words(h[0], h[1], h[2], h[3]);
           am[i] = sbk::bf16x8_from_words(m[0], m[1], m[2], m[3]);
@@ -873,7 +507,6 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
         // computes (W tile) . (A tile)^T, so a lane owns one row m of C and registers 4g .. 4g+3 hold four consecutive
         // columns n -- the epilogue loads residuals and stores results as 16-byte vectors (a quarter of the store
         // instructions of the column-per-lane layout: the store tail of a tile is issue-bound, MI355X_MICROARCH.md)
-        if constexpr ((MEAS & 4) == 0) {  // (measurement only, bit 2: the hi.hi products alone)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -894,7 +527,6 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(bm[j], ah[i], acc[i][j]);
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -902,7 +534,6 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
       }
       return;
     }
-    float* nbase = lds + (stage ^ 1) * STAGE + (wave * LI) * 256;
 #pragma unroll
     for (int gk = 0; gk < 4; ++gk) {
       const int slot = ((2 * gk + half) ^ sw) * 4;
@@ -921,12 +552,6 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
             const float bw = e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w;
             acc[i][j] = sbk::mfma_32x32x2(av, bw, acc[i][j]);
           }
-      if constexpr (IL) {
-        if (fly && gk < LI) {  // (uniform) behind this group's MFMAs
-          sbk::glds16(ap[gk] + nkt * BK, nbase + gk * 256);
-          sbk::glds16(wp[gk] + nkt * BK, nbase + PANEL + gk * 256);
-        }
-      }
     }
   };
   auto epilogue = [&](int tile) SBK_INLINE_LAMBDA {
@@ -1097,7 +722,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
         if (tid == 0) sbk::atomic_store_agent(cnt + tile, 0);  // re-armed for the next launch on this stream
       }
     }
-    if (store && !(noload & 8)) epilogue(tile);  // (bit 3, measurement only: no epilogue)
+    if (store) epilogue(tile);
   };
 
   int sidx = 0, tile, lo, hi, stage = 0;
@@ -1118,9 +743,9 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
     }
     if (has_next) {  // the next unit's panels fly while this one is multiplied
       if (seg_ends) setup(ntile);
-      if (!IL && !(noload & 1)) issue(nkt, stage ^ 1);
+      issue(nkt, stage ^ 1);
     }
-    compute(stage, has_next && !(noload & 1), nkt);
+    compute(stage, has_next, nkt);
     sbk::vm_drain();   // this wave's share of the next panels has landed ...
     __syncthreads();   // ... and everybody's; every wave is done reading `stage`
     if (seg_ends) {
@@ -1151,387 +776,6 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_sk_kernel(SkArgs s) {
 // applies the epilogue (fixed summation order => run-to-run deterministic).
 // For long K (FFN2) gridDim.y adds a second, global split whose partial tiles
 // are combined by splitk_reduce_kernel.
-// ---------------------------------------------------------------------------
-// bf16 activations AND bf16 weights (sbk_gemm_nt_bf16a): C = epilogue(A . W^T) with A [M,K] and W [N,K] both bf16 in
-// HBM, fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 and / or bf16 output.  With the operands already rounded
-// the panels go global -> LDS by LDS-DMA exactly like the fp32 persistent kernel's: a 128-byte LDS row is 64 bf16 (a
-// K tile of 64) instead of 32 floats, the same source-side slot swizzle makes the ds_read_b128 operand fetch (8
-// consecutive k of one row = one MFMA operand) conflict-free.  The matrix pipe needs a K tile every 512 cycles per
-// wave (16x the fp32 rate): NS stages (NS - 1 K tiles in flight, s_waitcnt vmcnt(8 x tiles issued after the one needed)
-// -- loads retire in order), one barrier per K tile; default NS = 2 with two workgroups per CU (see launch_bf16dma).
-// 256-register budget: with 512 the compiler keeps the accumulators in AGPRs and copies all 64 in and out of VGPRs
-// every K tile.  Persistent over whole tiles (XCD-contiguous ranges, the K pipeline runs on across
-// tile boundaries and under the epilogue); no K split -- the shapes that take this path have thousands of tiles.
-struct Bf16DmaArgs {
-  const unsigned short* A;
-  const unsigned short* W;
-  const float* bias;
-  const float* R;      // fp32 residual (optional)
-  float* C;            // fp32 output (optional)
-  unsigned short* Cb;  // bf16 output (optional): the next contraction's operand
-  int lda, ldw, ldr, ldc, ldcb, M, N, K, act;
-  float alpha;
-  int tiles_n, tiles, KT;
-  int mode;  // measurement only (knob 29): 1 = no MFMA work, 2 = no panel loads after the prologue (wrong results)
-};
-
-template <int NS>
-__global__ void __launch_bounds__(256, 2) gemm_nt_bf16dma_kernel(Bf16DmaArgs s) {
-  constexpr int BKF = 32, PANEL = 128 * BKF, STAGE = 2 * PANEL;  // float units (one unit = two bf16)
-  SBK_DYN_LDS(float, lds);  // [NS][A 128 rows | W 128 rows][64 bf16]
-  const unsigned short* const gA = s.A;
-  const unsigned short* const gW = s.W;
-  const float* const gbias = s.bias;
-  const float* const gR = s.R;
-  float* const gC = s.C;
-  unsigned short* const gCb = s.Cb;
-  const int lda = s.lda, ldw = s.ldw, ldr = s.ldr, ldc = s.ldc, ldcb = s.ldcb, M = s.M, N = s.N, act = s.act;
-  const float alpha = s.alpha;
-  const int tiles_n = s.tiles_n, KT = s.KT, mode = s.mode;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = sbk::uniform(tid >> 6);
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-  const int lrow = lane & 31, half = lane >> 5, sw = (lrow >> 1) & 7;
-  // this workgroup's tiles: every W-th tile of the XCD's contiguous range
-  const int W = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;  // gridDim.x is a multiple of 8
-  const int t0 = (int)((long)s.tiles * x / 8), t1 = (int)((long)s.tiles * (x + 1) / 8);
-  const int ntile = sbk::uniform(t0 + j < t1 ? (t1 - t0 - j + W - 1) / W : 0);
-  if (ntile == 0) return;
-  const int U = ntile * KT;
-
-  int lrw[4], lsl[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    lrw[i] = (wave * 4 + i) * 8 + (lane >> 3);
-    lsl[i] = ((lane & 7) ^ ((lrw[i] >> 1) & 7)) * 8;  // source k offset (bf16 elements) of the 16-byte slot this lane fills
-  }
-  const unsigned short* ap[4];
-  const unsigned short* wp[4];
-  auto setup = [&](int tile) SBK_INLINE_LAMBDA {
-    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {  // rows past the matrix re-read its last row (their outputs are never stored)
-      ap[i] = gA + (size_t)min(m0 + lrw[i], M - 1) * lda + lsl[i];
-      wp[i] = gW + (size_t)min(n0 + lrw[i], N - 1) * ldw + lsl[i];
-    }
-  };
-  auto issue = [&](int kt, int stage) SBK_INLINE_LAMBDA {
-    float* base = lds + stage * STAGE + (wave * 4) * 256;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sbk::glds16(reinterpret_cast<const float*>(ap[i] + kt * 64), base + i * 256);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sbk::glds16(reinterpret_cast<const float*>(wp[i] + kt * 64), base + PANEL + i * 256);
-  };
-  f32x16 acc[2][2];
-  auto zero = [&]() SBK_INLINE_LAMBDA {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
-  };
-  auto compute = [&](int stage) SBK_INLINE_LAMBDA {
-    const float* As = lds + stage * STAGE + (wm0 + lrow) * BKF;
-    const float* Ws = lds + stage * STAGE + PANEL + (wn0 + lrow) * BKF;
-#pragma unroll
-    for (int gk = 0; gk < 4; ++gk) {  // 16 k per step: lanes 0-31 supply k = 16 gk .. +7, lanes 32-63 the next eight
-      const int slot = ((2 * gk + half) ^ sw) * 4;
-      sbk::bf16x8 a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const sbk::bf16x8*>(As + i * 32 * BKF + slot);
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) b[jj] = *reinterpret_cast<const sbk::bf16x8*>(Ws + jj * 32 * BKF + slot);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) acc[i][jj] = sbk::mfma_32x32x16_bf16(a[i], b[jj], acc[i][jj]);
-    }
-  };
-  auto epilogue = [&](int tile) SBK_INLINE_LAMBDA {
-    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
-    const bool interior = m0 + 128 <= M && n0 + 128 <= N;  // uniform: no per-element predicates
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      const int col = n0 + wn0 + jj * 32 + lrow;
-      const bool col_ok = interior || col < N;
-      const float bv = (gbias && col_ok) ? gbias[col] : 0.0f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rbase = m0 + wm0 + i * 32 + 4 * half;
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc[i][jj][r] + bv;
-        switch (act) {  // uniform
-          case SBK_ACT_SWISH:
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
-            break;
-          case SBK_ACT_GELU:
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752440f));
-            break;
-          case SBK_ACT_RELU:
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
-            break;
-          case SBK_ACT_LEAKY_RELU:
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.01f * v[r];
-            break;
-          default: break;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (interior || (col_ok && row < M)) {
-            float o = v[r] * alpha;
-            if (gR) o += gR[(size_t)row * ldr + col];
-            if (gC) gC[(size_t)row * ldc + col] = o;
-            if (gCb) gCb[(size_t)row * ldcb + col] = sbk::f32_to_bf16(o);
-          }
-        }
-      }
-    }
-  };
-
-  // ---- the K pipeline over this workgroup's units (tile ordinal, K tile): `issued` units are in flight or landed
-  int i_ord = 0, i_kt = 0, issued = 0;
-  setup(t0 + j);
-  auto issue_next = [&]() SBK_INLINE_LAMBDA {
-    if (!(mode & 2) || issued < NS - 1) issue(i_kt, issued % NS);
-    ++issued;
-    if (++i_kt == KT) {
-      i_kt = 0;
-      if (++i_ord < ntile) setup(t0 + j + i_ord * W);
-    }
-  };
-  for (int pre = 0; pre < NS - 1 && issued < U; ++pre) issue_next();
-  zero();
-  int landed = -1, c_ord = 0, c_kt = 0;
-  for (int n = 0; n < U; ++n) {
-    if (n > landed) {  // unit n's panels: everything this wave issued up to it has landed once at most 8 x (units issued after it) loads are in flight
-      const int newer = sbk::uniform(issued - 1 - n);
-      if (newer <= 0) {
-        sbk::vm_drain();
-      } else if (newer == 1) {
-        sbk::vm_wait<8>();
-      } else if (newer == 2) {
-        sbk::vm_wait<16>();
-      } else {
-        sbk::vm_wait<24>();
-      }
-      landed = n;
-    }
-    __syncthreads();  // ... and everybody's share of it; every wave is done with the stage of unit n - 1
-    if (issued < U) issue_next();  // into the stage unit n - 1 occupied
-    if (!(mode & 1)) compute(n % NS);
-    if (++c_kt == KT) {
-      epilogue(t0 + j + c_ord * W);
-      zero();
-      c_kt = 0;
-      ++c_ord;
-      // the epilogue's own loads / stores are younger than every K tile in flight: the next wait is a full one, after
-      // which all of them have landed
-      landed = n;
-    }
-  }
-}
-
-// fp8 (OCP e4m3) activations AND weights (sbk_gemm_nt_fp8a), each with one fp32 scale per row: C = epilogue(sa[m] sw[n]
-// (A8 . W8^T)) with fp32 accumulation on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales: the 2 x-rate fp8 MFMA of
-// gfx950, measured 4 267 TF/s from registers against 2 074 for the bf16 form).  The pipeline is gemm_nt_bf16dma_kernel's
-// with bytes for elements: a 128-byte LDS row is 128 fp8 (a K tile of 128), panels by LDS-DMA with the same source-side
-// slot swizzle, a lane's MFMA operand (32 consecutive bytes of its row: k block `half` of a 64-deep step) is two
-// ds_read_b128 of neighbouring slots -- the same bank behaviour as the bf16 fetch; per K tile and wave 8 MFMAs of 64
-// cycles where the bf16 kernel has 16 of 32: the same cadence for twice the K, i.e. half the panel bytes per flop.
-// The scales are applied to the accumulators in the epilogue (rows of A: per activation row, written by
-// sbk_layernorm_fp8o or a previous call's fp8 output; rows of W: per output channel, sbk_quant_rows_fp8 once per
-// weight), so no element inside a row shares its scale with another row -- finer than per-tensor scaling, and free.
-// Outputs: fp32 and / or bf16 (the attention kernel's operand) and / or fp8 with a FIXED scale (c8_scale: the hidden
-// layer of a feed-forward pair, whose row maxima are not known before the last column tile; e4m3's 2^-9 .. 448 range
-// at scale 1 covers GELU / Swish outputs of normalised inputs).
-struct Fp8DmaArgs {
-  const unsigned char* A;
-  const unsigned char* W;
-  const float* sa;     // [M] scale of each row of A (null: 1)
-  const float* sw;     // [N] scale of each row of W (null: 1)
-  const float* bias;
-  const float* R;      // fp32 residual (optional)
-  float* C;            // fp32 output (optional)
-  unsigned short* Cb;  // bf16 output (optional)
-  unsigned char* C8;   // fp8 output (optional): e4m3(o / c8_scale)
-  float c8_scale;
-  int lda, ldw, ldr, ldc, ldcb, ldc8, M, N, K, act;
-  float alpha;
-  int tiles_n, tiles, KT;
-};
-
-__global__ void __launch_bounds__(256, 2) gemm_nt_fp8dma_kernel(Fp8DmaArgs s) {
-  constexpr int NS = 2, BKF = 32, PANEL = 128 * BKF, STAGE = 2 * PANEL;  // float units (one unit = four fp8)
-  SBK_DYN_LDS(float, lds);  // [NS][A 128 rows | W 128 rows][128 fp8]
-  const unsigned char* const gA = s.A;
-  const unsigned char* const gW = s.W;
-  const float* const gsa = s.sa;
-  const float* const gsw = s.sw;
-  const float* const gbias = s.bias;
-  const float* const gR = s.R;
-  float* const gC = s.C;
-  unsigned short* const gCb = s.Cb;
-  unsigned char* const gC8 = s.C8;
-  const int lda = s.lda, ldw = s.ldw, ldr = s.ldr, ldc = s.ldc, ldcb = s.ldcb, ldc8 = s.ldc8, M = s.M, N = s.N, act = s.act;
-  const float alpha = s.alpha, c8_inv = 1.0f / s.c8_scale;
-  const int tiles_n = s.tiles_n, KT = s.KT;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = sbk::uniform(tid >> 6);
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-  const int lrow = lane & 31, half = lane >> 5, sw = (lrow >> 1) & 7;
-  const int W = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;  // gridDim.x is a multiple of 8
-  const int t0 = (int)((long)s.tiles * x / 8), t1 = (int)((long)s.tiles * (x + 1) / 8);
-  const int ntile = sbk::uniform(t0 + j < t1 ? (t1 - t0 - j + W - 1) / W : 0);
-  if (ntile == 0) return;
-  const int U = ntile * KT;
-
-  int lrw[4], lsl[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    lrw[i] = (wave * 4 + i) * 8 + (lane >> 3);
-    lsl[i] = ((lane & 7) ^ ((lrw[i] >> 1) & 7)) * 16;  // source k offset (bytes) of the 16-byte slot this lane fills
-  }
-  const unsigned char* ap[4];
-  const unsigned char* wp[4];
-  auto setup = [&](int tile) SBK_INLINE_LAMBDA {
-    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {  // rows past the matrix re-read its last row (their outputs are never stored)
-      ap[i] = gA + (size_t)min(m0 + lrw[i], M - 1) * lda + lsl[i];
-      wp[i] = gW + (size_t)min(n0 + lrw[i], N - 1) * ldw + lsl[i];
-    }
-  };
-  auto issue = [&](int kt, int stage) SBK_INLINE_LAMBDA {
-    float* base = lds + stage * STAGE + (wave * 4) * 256;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sbk::glds16(reinterpret_cast<const float*>(ap[i] + kt * 128), base + i * 256);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sbk::glds16(reinterpret_cast<const float*>(wp[i] + kt * 128), base + PANEL + i * 256);
-  };
-  f32x16 acc[2][2];
-  auto zero = [&]() SBK_INLINE_LAMBDA {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
-  };
-  auto compute = [&](int stage) SBK_INLINE_LAMBDA {
-    const float* As = lds + stage * STAGE + (wm0 + lrow) * BKF;
-    const float* Ws = lds + stage * STAGE + PANEL + (wn0 + lrow) * BKF;
-#pragma unroll
-    for (int gk = 0; gk < 2; ++gk) {  // 64 k per step: lanes 0-31 supply bytes 64 gk .. +31 of their row, lanes 32-63 the next 32
-      const int s0 = ((4 * gk + 2 * half) ^ sw) * 4, s1 = ((4 * gk + 2 * half + 1) ^ sw) * 4;
-      sbk::i32x8 a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        a[i] = sbk::i32x8_from_u4(*reinterpret_cast<const uint4*>(As + i * 32 * BKF + s0), *reinterpret_cast<const uint4*>(As + i * 32 * BKF + s1));
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-        b[jj] = sbk::i32x8_from_u4(*reinterpret_cast<const uint4*>(Ws + jj * 32 * BKF + s0), *reinterpret_cast<const uint4*>(Ws + jj * 32 * BKF + s1));
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) acc[i][jj] = sbk::mfma_32x32x64_fp8(a[i], b[jj], acc[i][jj]);
-    }
-  };
-  auto epilogue = [&](int tile) SBK_INLINE_LAMBDA {
-    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
-    const bool interior = m0 + 128 <= M && n0 + 128 <= N;  // uniform: no per-element predicates
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rbase = m0 + wm0 + i * 32 + 4 * half;
-      float rs[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rs[r] = gsa ? gsa[min(rbase + (r & 3) + 8 * (r >> 2), M - 1)] : 1.0f;
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int col = n0 + wn0 + jj * 32 + lrow;
-        const bool col_ok = interior || col < N;
-        const float bv = (gbias && col_ok) ? gbias[col] : 0.0f;
-        const float cs = (gsw && col_ok) ? gsw[col] : 1.0f;
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc[i][jj][r] * (rs[r] * cs) + bv;
-        switch (act) {  // uniform
-          case SBK_ACT_SWISH:
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
-            break;
-          case SBK_ACT_GELU:
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752440f));
-            break;
-          case SBK_ACT_RELU:
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
-            break;
-          case SBK_ACT_LEAKY_RELU:
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.01f * v[r];
-            break;
-          default: break;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (interior || (col_ok && row < M)) {
-            float o = v[r] * alpha;
-            if (gR) o += gR[(size_t)row * ldr + col];
-            if (gC) gC[(size_t)row * ldc + col] = o;
-            if (gCb) gCb[(size_t)row * ldcb + col] = sbk::f32_to_bf16(o);
-            if (gC8) gC8[(size_t)row * ldc8 + col] = (unsigned char)(sbk::f32x2_to_fp8(o * c8_inv, 0.0f) & 0xff);
-          }
-        }
-      }
-    }
-  };
-
-  // ---- the K pipeline over this workgroup's units (tile ordinal, K tile), as gemm_nt_bf16dma_kernel<2>
-  int i_ord = 0, i_kt = 0, issued = 0;
-  setup(t0 + j);
-  auto issue_next = [&]() SBK_INLINE_LAMBDA {
-    issue(i_kt, issued % NS);
-    ++issued;
-    if (++i_kt == KT) {
-      i_kt = 0;
-      if (++i_ord < ntile) setup(t0 + j + i_ord * W);
-    }
-  };
-  for (int pre = 0; pre < NS - 1 && issued < U; ++pre) issue_next();
-  zero();
-  int landed = -1, c_ord = 0, c_kt = 0;
-  for (int n = 0; n < U; ++n) {
-    if (n > landed) {
-      const int newer = sbk::uniform(issued - 1 - n);
-      if (newer <= 0) {
-        sbk::vm_drain();
-      } else {
-        sbk::vm_wait<8>();
-      }
-      landed = n;
-    }
-    __syncthreads();
-    if (issued < U) issue_next();
-    compute(n % NS);
-    if (++c_kt == KT) {
-      epilogue(t0 + j + c_ord * W);
-      zero();
-      c_kt = 0;
-      ++c_ord;
-      landed = n;
-    }
-  }
-}
-
 template <int NCH>  // 32-float K chunks fetched per batch (all of them in flight together)
 __global__ void __launch_bounds__(256, 2) gemm_skinny_kernel(GemmArgs g, float* __restrict__ partial, int kper,
                                                           int tiles_m, int tiles_n) {
@@ -1683,89 +927,6 @@ __global__ void __launch_bounds__(256, 2) gemm_skinny_flat_kernel(GemmArgs g, fl
 // owns a 2 x 2 block of 32x32 accumulators.  Per MFMA that halves the bytes pulled from L2 (the 32x32 kernel moves
 // 128 KB per workgroup for 64 MFMAs per wave and is bound by that traffic from ~500 workgroups on: measured 2.2 us
 // per extra 100 workgroups), and the four accumulator chains are independent, so no MFMA waits on its predecessor.
-template <int NCH>
-__global__ void __launch_bounds__(256) gemm_skinny_flat64_kernel(GemmArgs g, float* __restrict__ partial, int tiles_m,
-                                                                 int tiles_n) {
-  constexpr int KC = 32;
-  __shared__ float red[4][4][32][33];  // [wave][sub-tile][row][col]: partial tiles of the four K slices
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int nt, mt;
-  {
-    const int id = blockIdx.x, x = id & 7, q = id >> 3;
-    const int nt8 = (tiles_n + 7) / 8;
-    mt = q % tiles_m;
-    nt = x + 8 * (q / tiles_m);
-    if (q / tiles_m >= nt8 || nt >= tiles_n) return;
-  }
-  const int r = lane & 31, half = lane >> 5;
-  const int k_begin = (blockIdx.y * 4 + wave) * NCH * KC;
-  const float* arow[2];
-  const float* wrow[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    arow[i] = g.A + (size_t)min(mt * 64 + i * 32 + r, g.M - 1) * g.lda + half * (KC / 2) + k_begin;
-    wrow[i] = g.W + (size_t)min(nt * 64 + i * 32 + r, g.N - 1) * g.ldw + half * (KC / 2) + k_begin;
-  }
-  float4 a[2][NCH][4], w[2][NCH][4];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) w[i][c][v] = *reinterpret_cast<const float4*>(wrow[i] + c * KC + 4 * v);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) a[i][c][v] = *reinterpret_cast<const float4*>(arow[i] + c * KC + 4 * v);
-    }
-  sbk::sched_fence();
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
-#pragma unroll
-  for (int c = 0; c < NCH; ++c)
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const float av = e == 0 ? a[i][c][v].x : e == 1 ? a[i][c][v].y : e == 2 ? a[i][c][v].z : a[i][c][v].w;
-            const float wv = e == 0 ? w[j][c][v].x : e == 1 ? w[j][c][v].y : e == 2 ? w[j][c][v].z : w[j][c][v].w;
-            acc[i][j] = sbk::mfma_32x32x2(av, wv, acc[i][j]);
-          }
-  // every wave publishes its four partial sub-tiles; wave s then owns sub-tile s = 2*i + j (fixed summation order)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) red[wave][2 * i + j][(q & 3) + 8 * (q >> 2) + 4 * half][r] = acc[i][j][q];
-  __syncthreads();
-  float v[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int rr = (q & 3) + 8 * (q >> 2) + 4 * half;
-    v[q] = ((red[0][wave][rr][r] + red[1][wave][rr][r]) + red[2][wave][rr][r]) + red[3][wave][rr][r];
-  }
-  const int sub_m = mt * 2 + (wave >> 1), sub_n = nt * 2 + (wave & 1);  // this wave's 32x32 tile in 32-row/col units
-  if (gridDim.y > 1) {
-    float* P = partial + (size_t)blockIdx.y * g.M * g.N;
-    const int col = sub_n * 32 + r;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = sub_m * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-      if (row < g.M && col < g.N) P[(size_t)row * g.N + col] = v[q];
-    }
-    return;
-  }
-  tile_epilogue_32x32(g, v, sub_m, sub_n, r, half);
-}
-
 // LayerNorm fused into the skinny GEMM:  C = epilogue( LN(A) . W^T ) for K = NCH*128 (one fetch batch
 // per wave, so the workgroup's four waves hold complete rows of A in registers).  gamma/beta are
 // pre-folded into the operands by the caller:  Wf[n,k] = W[n,k]*gamma[k],  bf[n] = b[n] + sum_k W[n,k]*beta[k],
@@ -1869,9 +1030,6 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const fl
 }
 
 }  // namespace
-namespace sbk {
-int g_gemm_vec_lds = 0;  // tuning knob (key 9): 1 = the 16-byte LDS operand variant (gemm_nt_v4_kernel)
-}
 namespace {
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
@@ -1881,16 +1039,10 @@ int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
                              : (BM == 128 && BN == 256) ? "gemm_nt_128x256"
                              : BM == 128 ? "gemm_nt_128x128" : (BM == 64 ? "gemm_nt_64x64" : "gemm_nt_32x64");
   sbk::ProfScope prof(kName, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N), st);
-  if (!sbk::g_gemm_vec_lds) {  // default: scalar LDS operand reads at pitch BK+1 (measured faster)
-    if (vec) {
-      SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, true>), grid, block, 0, st, g);
-    } else {
-      SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, false>), grid, block, 0, st, g);
-    }
-  } else if (vec) {
-    SBK_LAUNCH((gemm_nt_v4_kernel<BM, BN, BK, WM, WN, true>), grid, block, 0, st, g);
+  if (vec) {  // scalar LDS operand reads at pitch BK+1 (a 16-byte LDS operand variant was knob 9 in rounds 1-4: measured slower, removed)
+    SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, true>), grid, block, 0, st, g);
   } else {
-    SBK_LAUNCH((gemm_nt_v4_kernel<BM, BN, BK, WM, WN, false>), grid, block, 0, st, g);
+    SBK_LAUNCH((gemm_nt_kernel<BM, BN, BK, WM, WN, false>), grid, block, 0, st, g);
   }
   return sbk::launch_status("sbk_gemm_nt_f32");
 }
@@ -1898,22 +1050,15 @@ int launch_gemm(const GemmArgs& g, bool vec, hipStream_t st) {
 }  // namespace
 
 namespace sbk {
-int g_skinny_nch = 0;  // tuning knob (0 = automatic): K chunks fetched per batch by the skinny kernel
 int g_skinny_off = 0;  // tuning knob: 1 = route few-row GEMMs to the LDS-tiled kernels
-int g_skinny_looped = 0;  // tuning knob (key 10): 1 = always the looped skinny kernel (the round-1 schedule)
-int g_flat64_min_rows = 1 << 30;  // tuning knob (key 11): from this many rows on the register-operand path uses 64x64 tiles
-                                  // (off by default: measured slower in situ, 29 vs 23 us at M = 1280)
 int g_tiled_splitk = 256;  // tuning knob (key 14): from this many rows on, K >= 2048 shapes take 64x64 LDS tiles with a
                            // 4-way K split instead of the register-operand path (0 = off).  Measured (tools/microbench.py
                            // --ffn2, N = 512, K = 2048): 160 rows 17.9 -> 21.6 us, 320: 24.2 -> 20.1, 1280: 53.0 -> 37.8,
                            // 2560: 94.4 -> 57.9; N = 768, K = 3072 at 1280 rows: 115.7 -> 63.5
-// tuning knob (key 36): 1 = the tiled split-K GEMM reduces in the last-arriving workgroup of a tile.  OFF: measured slower in
-// the bench (9 815 vs 10 416 audio-s/s with knobs 36 + 37 on / off, profiles/r03_last_arriver_reductions_ab.log): the
-// agent-scope release every workgroup needs is an L2 write-back on an 8-XCD part, paid 640 times per launch here
-int g_splitk_fused = 0;
-int g_tiled_splitk_short = 0;  // tuning knob (key 15): K split of the same kernel for 512 <= K < 2048 (0 = not used)
-int g_skinny_reach = 0;   // tuning knob (key 12): 1 = the register-operand path also takes the mid-M shapes that go to
-                          // the LDS-tiled kernels by default (M*N >= 1.9 M with K <= 1024)
+// (Removed in round 5 with their kernels -- measured and lost, logs under profiles/: the reduction of the tiled split-K GEMM in
+// its last-arriving workgroup (knob 36: 9 815 vs 10 416 audio-s/s, r03_last_arriver_reductions_ab.log -- an agent-scope
+// release is an L2 write-back on an 8-XCD part), 64 x 64 register-operand tiles (knob 11: 29 vs 23 us in situ), the looped
+// skinny schedule of round 1 (knob 10), the wider reach of the register-operand path (knob 12), other K splits (knob 15).)
 int g_gemm_tile = 0;   // tuning knob (key 6) for the large-M path: 0 = 128x128, 1 = 256x128 (8 waves of 64x64),
                        // 2 = 128x256 (8 waves), 3 = 256x128 (4 waves of 128x64), 4 = 128x128 with 64-deep K tiles
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
@@ -1929,23 +1074,18 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   if (M == 0 || N == 0) return 0;
   // (measured, tools/microbench.py --attn --gemm: from ~1.9 M outputs with a short K the LDS-tiled kernels win:
   //  M=1280 N=1536 41.6 -> 27.6 us, M=640 N=5000 63 -> 46 us; a long K still needs the split of the skinny path)
-  const bool big_short = !g_skinny_reach && (long)M * N >= 1900000 && K <= 1024;  // (K = 768: the TransformerLM scorer's projections)
-  const bool skinny_ok = !big_short && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < (g_skinny_reach ? 2048 : 256)) && M <= (g_skinny_reach ? 8192 : 4096) && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
+  const bool big_short = (long)M * N >= 1900000 && K <= 1024;  // (K = 768: the TransformerLM scorer's projections)
+  const bool skinny_ok = !big_short && (M <= 512 || (long)cdiv(M, 128) * cdiv(N, 128) < 256) && M <= 4096 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
   if (!skinny_ok || g_skinny_off || (aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && sk_route(M, N, K) > 0))
     return gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, st);
   GemmArgs g{A, W, bias, R, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1};
   // (K = 768, the TransformerLM scorer's projections: 2-way split, 34.4 -> 24.6 us at 1280 rows; K = 512: no gain)
-  const int short_sk = K < 2048 && (long)M * N < 1900000 ? (g_tiled_splitk_short ? (K >= 512 ? g_tiled_splitk_short : 0) : (K >= 768 && M >= 1024 ? 2 : 0)) : 0;
+  const int short_sk = K < 2048 && (long)M * N < 1900000 && K >= 768 && M >= 1024 ? 2 : 0;
   if (g_tiled_splitk && ws && M >= g_tiled_splitk && (K >= 2048 || short_sk) && K % 128 == 0) {  // long K at ~1 K rows: 64x64 LDS tiles, K split 4-way
     const int SK = short_sk ? short_sk : 4, kper = K / SK;
     if ((size_t)SK * M * N <= ws_floats) {
       ProfScope prof("gemm_skinny", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
       dim3 grid(cdiv(N, 64), cdiv(M, 64), SK), block(256);
-      int* tickets = g_splitk_fused ? tile_tickets(st, (long)grid.x * grid.y) : nullptr;
-      if (tickets) {  // the reduction runs in the last-arriving K slice of every tile
-        SBK_LAUNCH((gemm_nt_splitk_fused_kernel<64, 64, 32, 32, 32, true>), grid, block, 0, st, g, ws, kper, tickets);
-        return launch_status("gemm_splitk_fused");
-      }
       SBK_LAUNCH((gemm_nt_splitk_kernel<64, 64, 32, 32, 32, true>), grid, block, 0, st, g, ws, kper);
       int rc = launch_status("gemm_splitk_tiled");
       if (rc) return rc;
@@ -1966,17 +1106,9 @@ int gemm_nt_ws(const float* A, int lda, const float* W, int ldw, const float* bi
   const int kper = cdiv(cdiv(K, 4 * SKg), 32) * 32;
   ProfScope prof("gemm_skinny", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
   dim3 grid(8 * tiles_m * cdiv(tiles_n, 8), SKg), block(256);
-  const int nch = g_skinny_nch ? g_skinny_nch : (kper >= 128 ? 4 : (kper >= 64 ? 2 : 1));
-  const bool flat = !g_skinny_looped && K == 4 * SKg * kper && (kper == 128 || kper == 64 || kper == 32);
-  if (flat && (kper == 128 || kper == 64) && M >= g_flat64_min_rows) {  // 2 x 2 accumulators per wave (see the kernel)
-    const int tm64 = cdiv(M, 64), tn64 = cdiv(N, 64);
-    dim3 grid64(8 * tm64 * cdiv(tn64, 8), SKg);
-    if (kper == 128) {
-      SBK_LAUNCH((gemm_skinny_flat64_kernel<4>), grid64, block, 0, st, g, ws, tm64, tn64);
-    } else {
-      SBK_LAUNCH((gemm_skinny_flat64_kernel<2>), grid64, block, 0, st, g, ws, tm64, tn64);
-    }
-  } else if (flat) {  // one fetch batch per wave: every load in flight before the first MFMA
+  const int nch = kper >= 128 ? 4 : (kper >= 64 ? 2 : 1);
+  const bool flat = K == 4 * SKg * kper && (kper == 128 || kper == 64 || kper == 32);
+  if (flat) {  // one fetch batch per wave: every load in flight before the first MFMA
     if (kper == 128) {
       SBK_LAUNCH((gemm_skinny_flat_kernel<4>), grid, block, 0, st, g, ws, tiles_m, tiles_n);
     } else if (kper == 64) {
@@ -2023,20 +1155,12 @@ int gemm_ln_nt(const float* A, int lda, const float* Wf, int ldw, const float* b
 
 // ---- stream-K launch: per-stream workspace (slabs + tile tickets), registered by the caller (sbk_stream_workspace_set)
 int g_sk_mode = 1;        // tuning knob (key 18): 0 = tile-grid kernels only, 1 = routed by shape (sk_route), 2 = always (tests), 3 = always from 8 tiles on (A/B)
-int g_sk_grid = 0;        // tuning knob (key 19): workgroups of a stream-K launch (0 = two per CU)
-int g_sk_noload = 0;      // measurement knob (key 22)
-int g_sk_stagger = 1;     // tuning knob (key 23): upper half of each XCD's workgroups runs its tail share first
 int g_sk_min_rows = 2048;  // tuning knob (key 24): fewer rows than this never take the persistent kernel in routed mode
-int g_sk_min_units = 4;   // tuning knob (key 21): fewer units per workgroup than this shrinks the grid
-int g_sk_interleave = 0;  // tuning knob (key 30): 1 = the next K tile's LDS-DMA pieces are issued between the MFMA groups
-int g_sk64_min_rows = 0;  // tuning knob (key 25): from this many rows on (and below g_sk_min_rows) the 64x64-tile persistent kernel; 0 = off
-int g_sk64_units = 16;    // tuning knob (key 26): K units (64x64x32) per workgroup the 64-tile grid is sized for
-int g_bf16a_stages = 2;   // tuning knob (key 27): LDS stages of gemm_nt_bf16dma_kernel (2, 3 or 4)
-int g_bf16a_grid = 0;     // tuning knob (key 28): its workgroups (0 = as many as fit: two per CU with 2 stages, one with 3 / 4)
-int g_bf16a_mode = 0;     // measurement knob (key 29)
-int g_x3_grid = 0;        // tuning knob (key 31): workgroups of the split-operand kernel (0 = two per CU from one tile per CU on)
+// (Knobs 19 / 21 / 22 / 23 / 25 / 26 / 30 / 31 of rounds 3-4 -- grid size, units per workgroup, the measurement builds, the
+// tail-first stagger switch, 64-wide persistent tiles, panel pieces interleaved with the MFMA groups, the split-operand
+// kernel's grid -- are gone: their measured values are the constants below, their logs profiles/r03_*.)
 namespace {
-constexpr int kSkMaxGrid = 512, kSkMaxGrid64 = 1024, kSkMaxTiles = 1 << 16;  // (both grids fit the same slab area)
+constexpr int kSkMaxGrid = 512, kSkMaxTiles = 1 << 16;
 int sk_cus();
 }
 // Workgroups of the persistent kernel for this shape, 0 = the tile-grid kernels.  Measured on MI355X (tools/microbench.py
@@ -2052,24 +1176,16 @@ int sk_route(int M, int N, int K, int* bt) {
   if (!g_sk_mode || K % 32 != 0 || K < 64) return 0;
   const long T = (long)cdiv(M, 128) * cdiv(N, 128), U = T * (K / 32);
   const int cus = sk_cus();
-  int G = g_sk_grid;
-  if (g_sk_mode == 1 && M < g_sk_min_rows) {
-    // decode-step shapes (a few hundred to ~1 300 rows): 64x64 tiles, one workgroup per g_sk64_units K units -- a whole
-    // tile at K = 512, a quarter of one at K = 2 048 (split K through the slabs, reduced by the last arriver)
-    if (!g_sk64_min_rows || M < g_sk64_min_rows) return 0;
-    *bt = 64;
-    const long U64 = (long)cdiv(M, 64) * cdiv(N, 64) * (K / 32);
-    if (!G) G = (int)std::min<long>(kSkMaxGrid64, U64 / std::max(1, g_sk64_units));
-    return G >= 8 ? (G / 8) * 8 : 0;
-  }
+  int G = 0;
+  if (g_sk_mode == 1 && M < g_sk_min_rows) return 0;  // (decode-step shapes: the register-operand / split-operand few-row kernels)
   if (g_sk_mode == 1) {
     const bool narrow_short = N <= 512 && K <= 512;
     if (narrow_short ? 2 * T < 3L * cus : U < 16L * cus) return 0;
-    if (!G) G = U >= 32L * cus ? 2 * cus : cus;
+    G = U >= 32L * cus ? 2 * cus : cus;
   } else {
     if (g_sk_mode == 3 && T < 8) return 0;
-    if (!G) G = 2 * cus;
-    if (U / g_sk_min_units < G) G = (int)(U / g_sk_min_units);  // short launches: fewer, longer ranges
+    G = 2 * cus;
+    if (U / 4 < G) G = (int)(U / 4);  // short launches: fewer, longer ranges (>= 4 units per workgroup)
   }
   if (G > kSkMaxGrid) G = kSkMaxGrid;
   return G >= 8 ? (G / 8) * 8 : 8;  // W workgroups on each of the 8 XCDs
@@ -2144,50 +1260,21 @@ int launch_sk(const GemmArgs& g, int G, int bt, hipStream_t st, bool x3 = false)
   if (!sk_workspace(st, &w)) return -1;
   s.slabs = w.slabs;
   s.cnt = w.cnt;
-  s.stagger = g_sk_stagger;
-  s.noload = g_sk_noload;
   const size_t lds = x3 ? (size_t)2 * (128 * 32 + 128 * 48) * sizeof(float) : (size_t)(2 * 2 * bt * 32 + 4) * sizeof(float);
   static bool once = false;
   if (!once) {
-    (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, false>), (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float));
-    (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, true, false>), (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float));
-    (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true>), (size_t)2 * (128 * 32 + 128 * 48) * sizeof(float));
+    (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false>), (size_t)(2 * 2 * 128 * 32 + 4) * sizeof(float));
+    (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, true>), (size_t)2 * (128 * 32 + 128 * 48) * sizeof(float));
     once = true;
   }
   const double flops = 2.0 * g.M * g.N * g.K, bytes = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
   if (x3) {
     // (fp32-equivalent flops: the six bf16 partial products of an element pair count as ONE multiply-add)
     ProfScope prof("gemm_nt_f32x3", flops, bytes + 2.0 * (double)g.N * g.K, st);
-    const int meas = (g_sk_noload >> 1) & 3;
-    s.noload = g_sk_noload & 9;
-    if (meas == 0) {
-      SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true>), dim3((unsigned)G), dim3(256), lds, st, s);
-    } else {
-      static bool once_meas = false;
-      if (!once_meas) {
-        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 2>), lds);
-        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 4>), lds);
-        (void)SBK_ALLOW_DYN_LDS((gemm_nt_sk_kernel<128, false, true, 6>), lds);
-        once_meas = true;
-      }
-      if (meas == 1) {
-        SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 2>), dim3((unsigned)G), dim3(256), lds, st, s);
-      } else if (meas == 2) {
-        SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 4>), dim3((unsigned)G), dim3(256), lds, st, s);
-      } else {
-        SBK_LAUNCH((gemm_nt_sk_kernel<128, false, true, 6>), dim3((unsigned)G), dim3(256), lds, st, s);
-      }
-    }
-  } else if (bt == 64) {
-    ProfScope prof("gemm_nt_persistent64", flops, bytes, st);
-    SBK_LAUNCH((gemm_nt_sk_kernel<64, false, false>), dim3((unsigned)G), dim3(256), lds, st, s);
+    SBK_LAUNCH((gemm_nt_sk_kernel<128, true>), dim3((unsigned)G), dim3(256), lds, st, s);
   } else {
     ProfScope prof("gemm_nt_persistent", flops, bytes, st);
-    if (g_sk_interleave) {
-      SBK_LAUNCH((gemm_nt_sk_kernel<128, true, false>), dim3((unsigned)G), dim3(256), lds, st, s);
-    } else {
-      SBK_LAUNCH((gemm_nt_sk_kernel<128, false, false>), dim3((unsigned)G), dim3(256), lds, st, s);
-    }
+    SBK_LAUNCH((gemm_nt_sk_kernel<128, false>), dim3((unsigned)G), dim3(256), lds, st, s);
   }
   return launch_status("sbk_gemm_nt_f32 (stream-K)");
 }
@@ -2210,8 +1297,8 @@ int gemm_nt_x3(const float* A, int lda, const uint16_t* W3, const float* bias, c
   const int cus = sk_cus();
   // Measured on MI355X (tools/microbench.py --x3, profiles/r03_f32x3_sweep.log): two workgroups per CU from two tiles per
   // CU on, one below (M = 4 032: N = 1 024 31 vs 50 us, N = 1 536 59 vs 69 us with one)
-  int G = g_x3_grid > 0 ? g_x3_grid : (T >= 2L * cus ? 2 * cus : cus);
-  if (U / g_sk_min_units < G) G = (int)(U / g_sk_min_units);  // short launches: fewer, longer ranges
+  int G = T >= 2L * cus ? 2 * cus : cus;
+  if (U / 4 < G) G = (int)(U / 4);  // short launches: fewer, longer ranges
   if (G > kSkMaxGrid) G = kSkMaxGrid;
   G = G >= 8 ? (G / 8) * 8 : 8;
   return launch_sk(g, G, 128, st, true);
@@ -2334,36 +1421,17 @@ extern "C" int sbk_prof_gemm_repeat_f32(const float* A, const float* W, float* C
 }
 
 extern "C" void sbk_prof_set_knob(int key, int value) {
-  if (key == 1) sbk::g_skinny_nch = value;
   if (key == 2) sbk::g_skinny_off = value;
   if (key == 3) sbk::g_attn_prefetch = value;
   if (key == 16) sbk::g_rope_flash_lds = value;
   if (key == 17) sbk::g_relpos_flash_t = value;
   if (key == 4) sbk::g_cross_rows = value;
-  if (key == 5) sbk::g_kv_head_major = value;
   if (key == 6) sbk::g_gemm_tile = value;
   if (key == 7) sbk::g_ctc_tpt = value;
   if (key == 8) sbk::g_cross_fc256 = value;
-  if (key == 9) sbk::g_gemm_vec_lds = value;
-  if (key == 10) sbk::g_skinny_looped = value;
-  if (key == 11) sbk::g_flat64_min_rows = value;
-  if (key == 12) sbk::g_skinny_reach = value;
   if (key == 14) sbk::g_tiled_splitk = value;
-  if (key == 15) sbk::g_tiled_splitk_short = value;
-  if (key == 13) sbk::g_self_group_off = value;
   if (key == 18) sbk::g_sk_mode = value;
-  if (key == 19) sbk::g_sk_grid = value;
-  if (key == 21) sbk::g_sk_min_units = value > 0 ? value : 1;
-  if (key == 22) sbk::g_sk_noload = value;
-  if (key == 23) sbk::g_sk_stagger = value;
   if (key == 24) sbk::g_sk_min_rows = value;
-  if (key == 25) sbk::g_sk64_min_rows = value;
-  if (key == 30) sbk::g_sk_interleave = value;
-  if (key == 26) sbk::g_sk64_units = value > 0 ? value : 1;
-  if (key == 27) sbk::g_bf16a_stages = value;
-  if (key == 28) sbk::g_bf16a_grid = value;
-  if (key == 29) sbk::g_bf16a_mode = value;
-  if (key == 31) sbk::g_x3_grid = value;
   if (key == 39) sbk::g_x3p_tile = value;
   if (key == 40) sbk::g_score_fused = value;
   if (key == 41) sbk::g_x3r_mode = value;
@@ -2372,8 +1440,6 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 47) sbk::g_persist = value;
   if (key == 48) sbk::g_persist_grid = value;
   if (key == 49) sbk::g_persist_stamps = value;
-  if (key == 36) sbk::g_splitk_fused = value;
-  if (key == 37) sbk::g_cross_fused_merge = value;
   if (key == 34) sbk::g_x3_route_rows = value;
   if (key == 35) sbk::g_x3_route_tiles = value;
 }
@@ -2406,206 +1472,4 @@ extern "C" int sbk_gemm_nt_f32x3(const float* A, int lda, const uint16_t* W3, co
                                  sbk::as_stream(stream));
   if (rc == -1) return sbk::fail(SBK_EINVAL, "gemm_f32x3: no workspace registered for this stream (sbk_stream_workspace_set) or too many tiles");
   return rc;
-}
-
-// ---- bf16-operand fast entry points ---------------------------------------------------------------
-extern "C" int sbk_f32_to_bf16(const float* x, uint16_t* y, long n, sbk_stream_t stream) {
-  if (n == 0) return 0;
-  SBK_REQUIRE(x && y && n > 0, "f32_to_bf16: bad arguments");
-  const long blocks = (n + 255) / 256;
-  SBK_LAUNCH(f32_to_bf16_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, sbk::as_stream(stream), x,
-             reinterpret_cast<unsigned short*>(y), n);
-  return sbk::launch_status("sbk_f32_to_bf16");
-}
-
-namespace {
-int launch_bf16dma(const Bf16DmaArgs& a0, hipStream_t st) {
-  Bf16DmaArgs a = a0;
-  a.tiles_n = sbk::cdiv(a.N, 128);
-  a.tiles = sbk::cdiv(a.M, 128) * a.tiles_n;
-  a.KT = a.K / 64;
-  a.mode = sbk::g_bf16a_mode;
-  int dev = 0, cus = 0;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (cus <= 0) cus = 256;
-  // Measured on MI355X (tools/microbench.py --bf16a, profiles/r03_bf16_activation_gemm.log): two stages and two
-  // workgroups per CU (634-827 TF/s at 12 000 rows) beat three / four stages with one (460-630): a second workgroup's
-  // MFMAs cover the ~100-cycle issue of each LDS-DMA piece better than a deeper pipeline of one wave per SIMD does
-  const int ns = sbk::g_bf16a_stages == 3 ? 3 : (sbk::g_bf16a_stages == 4 ? 4 : 2);
-  int G = sbk::g_bf16a_grid > 0 ? sbk::g_bf16a_grid : (ns == 2 ? 2 * cus : cus);
-  if (G > a.tiles) G = a.tiles;
-  G = G >= 8 ? (G / 8) * 8 : 8;
-  const size_t lds = (size_t)ns * 2 * 128 * 32 * sizeof(float);
-  static bool once = false;
-  if (!once) {
-    (void)SBK_ALLOW_DYN_LDS(gemm_nt_bf16dma_kernel<2>, (size_t)2 * 2 * 128 * 32 * sizeof(float));
-    (void)SBK_ALLOW_DYN_LDS(gemm_nt_bf16dma_kernel<3>, (size_t)3 * 2 * 128 * 32 * sizeof(float));
-    (void)SBK_ALLOW_DYN_LDS(gemm_nt_bf16dma_kernel<4>, (size_t)4 * 2 * 128 * 32 * sizeof(float));
-    once = true;
-  }
-  sbk::ProfScope prof("gemm_nt_bf16a", 2.0 * a.M * a.N * a.K,
-                      2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.C ? 4.0 : 0.0) * a.M * a.N + (a.Cb ? 2.0 : 0.0) * a.M * a.N +
-                          (a.R ? 4.0 : 0.0) * a.M * a.N, st);
-  if (ns == 2) {
-    SBK_LAUNCH(gemm_nt_bf16dma_kernel<2>, dim3((unsigned)G), dim3(256), lds, st, a);
-  } else if (ns == 3) {
-    SBK_LAUNCH(gemm_nt_bf16dma_kernel<3>, dim3((unsigned)G), dim3(256), lds, st, a);
-  } else {
-    SBK_LAUNCH(gemm_nt_bf16dma_kernel<4>, dim3((unsigned)G), dim3(256), lds, st, a);
-  }
-  return sbk::launch_status("sbk_gemm_nt_bf16a");
-}
-
-int launch_lp(int dt, const float* A, int lda, const void* Wq, int ldw, const float* bias, const float* residual, int ldr,
-              float* C, int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq,
-              const float* a_absmax, float w_scale, hipStream_t st) {
-  GemmBf16Args g{A, Wq, bias, residual, C, lda, ldw, ldr, ldc, M, N, K, act, alpha, seq_len, rows_per_seq > 0 ? rows_per_seq : 1,
-                 a_absmax, w_scale};
-  const long tiles128 = (long)sbk::cdiv(M, 128) * sbk::cdiv(N, 128);
-  const char* name = dt == 0 ? "gemm_nt_bf16" : (dt == 1 ? "gemm_nt_f16" : "gemm_nt_fp8");
-  sbk::ProfScope prof(name, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N) + (dt == 2 ? 1.0 : 2.0) * (double)N * K, st);
-  const dim3 g128(sbk::cdiv(N, 128), sbk::cdiv(M, 128)), g64(sbk::cdiv(N, 64), sbk::cdiv(M, 64)), block(256);
-#define SBK_LP(DT)                                                           \
-  if (tiles128 >= 256) {                                                     \
-    SBK_LAUNCH((gemm_nt_lp_kernel<128, 128, DT>), g128, block, 0, st, g);    \
-  } else {                                                                   \
-    SBK_LAUNCH((gemm_nt_lp_kernel<64, 64, DT>), g64, block, 0, st, g);       \
-  }
-  if (dt == 0) {
-    SBK_LP(0)
-  } else if (dt == 1) {
-    SBK_LP(1)
-  } else {
-    SBK_LP(2)
-  }
-#undef SBK_LP
-  return sbk::launch_status(name);
-}
-}  // namespace
-
-extern "C" int sbk_gemm_nt_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, const float* bias,
-                                const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
-                                float alpha, const int32_t* seq_len, int rows_per_seq, sbk_stream_t stream) {
-  if (M == 0 || N == 0) return 0;
-  SBK_REQUIRE(A && Wb && C, "gemm_bf16: null operand");
-  SBK_REQUIRE(M >= 0 && N >= 0 && K > 0 && K % 8 == 0, "gemm_bf16: bad shape M=%d N=%d K=%d (K must be a multiple of 8)", M, N, K);
-  SBK_REQUIRE(lda > 0 && ldw >= K && ldc >= N && lda % 4 == 0 && ldw % 8 == 0, "gemm_bf16: leading dimensions");
-  SBK_REQUIRE(sbk::aligned16(A) && sbk::aligned16(Wb), "gemm_bf16: operands must be 16-byte aligned");
-  SBK_REQUIRE(!residual || ldr >= N, "gemm_bf16: residual stride");
-  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_bf16: unknown activation %d", act);
-  SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm_bf16: seq_len given without rows_per_seq");
-  return launch_lp(0, A, lda, Wb, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, nullptr, 1.0f,
-                   sbk::as_stream(stream));
-}
-
-extern "C" int sbk_gemm_nt_bf16a(const uint16_t* A, int lda, const uint16_t* Wb, int ldw, const float* bias,
-                                 const float* residual, int ldr, float* C, int ldc, uint16_t* Cb, int ldcb, int M, int N,
-                                 int K, int act, float alpha, sbk_stream_t stream) {
-  if (M == 0 || N == 0) return 0;
-  SBK_REQUIRE(A && Wb && (C || Cb), "gemm_bf16a: null operand");
-  SBK_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_bf16a: K must be a multiple of 64 (M=%d N=%d K=%d)", M, N, K);
-  SBK_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && sbk::aligned16(A) && sbk::aligned16(Wb),
-              "gemm_bf16a: operand rows must be 16-byte aligned (lda=%d ldw=%d)", lda, ldw);
-  SBK_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N) && (!residual || ldr >= N), "gemm_bf16a: leading dimension smaller than the row");
-  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_bf16a: unknown activation %d", act);
-  Bf16DmaArgs a{A, Wb, bias, residual, C, Cb, lda, ldw, ldr, ldc, ldcb, M, N, K, act, alpha, 0, 0, 0, 0};
-  return launch_bf16dma(a, sbk::as_stream(stream));
-}
-
-extern "C" int sbk_gemm_nt_fp8a(const uint8_t* A8, int lda, const float* a_scale, const uint8_t* W8, int ldw, const float* w_scale,
-                                const float* bias, const float* residual, int ldr, float* C, int ldc, uint16_t* Cb, int ldcb,
-                                uint8_t* C8, int ldc8, float c8_scale, int M, int N, int K, int act, float alpha,
-                                sbk_stream_t stream) {
-  if (M == 0 || N == 0) return 0;
-  SBK_REQUIRE(A8 && W8 && (C || Cb || C8), "gemm_fp8a: null operand");
-  SBK_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0, "gemm_fp8a: K must be a multiple of 128 (M=%d N=%d K=%d)", M, N, K);
-  SBK_REQUIRE(lda >= K && ldw >= K && lda % 16 == 0 && ldw % 16 == 0 && sbk::aligned16(A8) && sbk::aligned16(W8),
-              "gemm_fp8a: operand rows must be 16-byte aligned (lda=%d ldw=%d)", lda, ldw);
-  SBK_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N) && (!C8 || (ldc8 >= N && c8_scale > 0.0f)) && (!residual || ldr >= N),
-              "gemm_fp8a: leading dimension smaller than the row / non-positive fp8 output scale");
-  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_fp8a: unknown activation %d", act);
-  Fp8DmaArgs a{A8, W8, a_scale, w_scale, bias, residual, C, Cb, C8, C8 ? c8_scale : 1.0f, lda, ldw, ldr, ldc, ldcb, ldc8,
-               M, N, K, act, alpha, 0, 0, 0};
-  a.tiles_n = sbk::cdiv(N, 128);
-  a.tiles = sbk::cdiv(M, 128) * a.tiles_n;
-  a.KT = K / 128;
-  int dev = 0, cus = 0;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (cus <= 0) cus = 256;
-  int G = 2 * cus;  // two stages, two workgroups per CU (launch_bf16dma's measured choice)
-  if (G > a.tiles) G = a.tiles;
-  G = G >= 8 ? (G / 8) * 8 : 8;
-  const size_t lds = (size_t)2 * 2 * 128 * 32 * sizeof(float);
-  static bool once = false;
-  if (!once) {
-    (void)SBK_ALLOW_DYN_LDS(gemm_nt_fp8dma_kernel, lds);
-    once = true;
-  }
-  hipStream_t st = sbk::as_stream(stream);
-  sbk::ProfScope prof("gemm_nt_fp8a", 2.0 * M * (double)N * K,
-                      1.0 * ((double)M * K + (double)N * K) + ((C ? 4.0 : 0.0) + (Cb ? 2.0 : 0.0) + (C8 ? 1.0 : 0.0) + (residual ? 4.0 : 0.0)) * M * (double)N, st);
-  SBK_LAUNCH(gemm_nt_fp8dma_kernel, dim3((unsigned)G), dim3(256), lds, st, a);
-  return sbk::launch_status("sbk_gemm_nt_fp8a");
-}
-
-extern "C" int sbk_gemm_nt_f16(const float* A, int lda, const uint16_t* Wh, int ldw, const float* bias,
-                               const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int act,
-                               float alpha, const int32_t* seq_len, int rows_per_seq, sbk_stream_t stream) {
-  if (M == 0 || N == 0) return 0;
-  SBK_REQUIRE(A && Wh && C, "gemm_f16: null operand");
-  SBK_REQUIRE(M >= 0 && N >= 0 && K > 0 && K % 8 == 0, "gemm_f16: bad shape M=%d N=%d K=%d (K must be a multiple of 8)", M, N, K);
-  SBK_REQUIRE(lda > 0 && ldw >= K && ldc >= N && lda % 4 == 0 && ldw % 8 == 0, "gemm_f16: leading dimensions");
-  SBK_REQUIRE(sbk::aligned16(A) && sbk::aligned16(Wh), "gemm_f16: operands must be 16-byte aligned");
-  SBK_REQUIRE(!residual || ldr >= N, "gemm_f16: residual stride");
-  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_f16: unknown activation %d", act);
-  SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm_f16: seq_len given without rows_per_seq");
-  return launch_lp(1, A, lda, Wh, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, nullptr, 1.0f,
-                   sbk::as_stream(stream));
-}
-
-extern "C" int sbk_gemm_nt_fp8(const float* A, int lda, const float* a_absmax, const uint8_t* Wq, int ldw, float w_scale,
-                               const float* bias, const float* residual, int ldr, float* C, int ldc, int M, int N, int K,
-                               int act, float alpha, const int32_t* seq_len, int rows_per_seq, sbk_stream_t stream) {
-  if (M == 0 || N == 0) return 0;
-  SBK_REQUIRE(A && Wq && C && a_absmax, "gemm_fp8: null operand");
-  SBK_REQUIRE(M >= 0 && N >= 0 && K > 0 && K % 16 == 0, "gemm_fp8: bad shape M=%d N=%d K=%d (K must be a multiple of 16)", M, N, K);
-  SBK_REQUIRE(lda > 0 && ldw >= K && ldc >= N && lda % 4 == 0 && ldw % 16 == 0, "gemm_fp8: leading dimensions");
-  SBK_REQUIRE(sbk::aligned16(A) && sbk::aligned16(Wq), "gemm_fp8: operands must be 16-byte aligned");
-  SBK_REQUIRE(!residual || ldr >= N, "gemm_fp8: residual stride");
-  SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_fp8: unknown activation %d", act);
-  SBK_REQUIRE(!seq_len || rows_per_seq > 0, "gemm_fp8: seq_len given without rows_per_seq");
-  SBK_REQUIRE(w_scale > 0.0f, "gemm_fp8: w_scale must be positive");
-  return launch_lp(2, A, lda, Wq, ldw, bias, residual, ldr, C, ldc, M, N, K, act, alpha, seq_len, rows_per_seq, a_absmax, w_scale,
-                   sbk::as_stream(stream));
-}
-
-extern "C" int sbk_f32_to_f16(const float* x, uint16_t* y, long n, sbk_stream_t stream) {
-  if (n == 0) return 0;
-  SBK_REQUIRE(x && y && n > 0, "f32_to_f16: bad arguments");
-  const long blocks = (n + 255) / 256;
-  SBK_LAUNCH(f32_to_f16_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, sbk::as_stream(stream), x,
-             reinterpret_cast<unsigned short*>(y), n);
-  return sbk::launch_status("sbk_f32_to_f16");
-}
-
-// y = e4m3(x * mul) (OCP e4m3fn, round to nearest even, saturating at +-448); n even
-extern "C" int sbk_f32_to_fp8(const float* x, uint8_t* y, long n, float mul, sbk_stream_t stream) {
-  if (n == 0) return 0;
-  SBK_REQUIRE(x && y && n > 0 && n % 2 == 0, "f32_to_fp8: bad arguments (n must be even)");
-  const long blocks = (n / 2 + 255) / 256;
-  SBK_LAUNCH(f32_to_fp8_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, sbk::as_stream(stream), x,
-             reinterpret_cast<unsigned short*>(y), n / 2, mul);
-  return sbk::launch_status("sbk_f32_to_fp8");
-}
-
-// out[0] = max |x[i]| (device float; the activation scale of sbk_gemm_nt_fp8)
-extern "C" int sbk_absmax_f32(const float* x, long n, float* out, sbk_stream_t stream) {
-  SBK_REQUIRE(x && out && n > 0, "absmax: bad arguments");
-  hipStream_t st = sbk::as_stream(stream);
-  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return sbk::fail(1, "absmax: memset");
-  const long blocks = (n + 255) / 256;
-  SBK_LAUNCH(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, x, reinterpret_cast<int*>(out), n);
-  return sbk::launch_status("sbk_absmax_f32");
 }

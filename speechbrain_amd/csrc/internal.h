@@ -46,11 +46,8 @@ extern int g_attn_prefetch;
 extern int g_rope_flash_lds;
 extern int g_relpos_flash_t;
 extern int g_cross_rows;
-extern int g_kv_head_major;
 extern int g_ctc_tpt;
 extern int g_cross_fc256;
-extern int g_cross_fused_merge;
-extern int g_self_group_off;
 extern int g_score_fused;  // key 40: 1 (default) = the step's scoring as one pass per hypothesis row (csrc/search.hip)
 constexpr float kCtcNeg = -1e20f;  // the CTC scorer's finite "log 0" (ctc.py:150, scorer.py:1250)
 // The arithmetic of a decoding step's scoring, shared by the separate kernels (log_softmax_row / ctc_combine / am_only /

@@ -69,8 +69,7 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
                    int H, int step, int nslot, int Lmax, hipStream_t st, const int32_t* key_tok = nullptr,
                    int key_stride = 0, int key_shift = 0, int key_first = 0, int pad_idx = 0, int group = 1);
 int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, float* out, float* part, int B, int T,
-                    int d, int H, int beam, hipStream_t st, int head_major, int32_t* cnt = nullptr);
-int kv_head_major(const float* src, float* dst, int B, int T, int d, int H, hipStream_t st);
+                    int d, int H, int beam, hipStream_t st);
 size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam);
 int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st,
                      const float* bias = nullptr, const float* bias2 = nullptr);
@@ -942,11 +941,8 @@ struct DecoderBufs {
   float* splitk;        // split-K partials of the skinny GEMMs
   size_t splitk_floats;
   float* xpart;         // cross-attention split partials
-  int32_t* xcnt;        // [B] arrival tickets of the cross-attention runs (zeroed by project_memory, re-armed by the kernel)
-  float* kvtmp;         // [B,T,2d] projection output before the head-major re-layout
   int32_t* pbar;        // arrival counter of the persistent few-row step's grid barriers (zeroed by project_memory)
   mutable int pseq;     // persistent launches issued on it since
-  int head_major;       // layout of ckv[l]: 1 = [B,H,T,2*Dh], 0 = [B,T,2d]
   float* ckv[64];
   float *kcache[64], *vcache[64];
 };
@@ -963,11 +959,8 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
   d.splitk_floats = (size_t)4 * n * (size_t)dm;  // global split-K is used for the long-K FFN2 only
   d.splitk = c.take<float>(d.splitk_floats);
   d.xpart = c.take<float>(sbk::cross_attn_partial_floats(B, T, W->nhead, dm / W->nhead, n / (B > 0 ? B : 1)) + 64);
-  d.xcnt = c.take<int32_t>((size_t)B + 16);
   d.pbar = c.take<int32_t>(64 + 512);  // (+ 256 eight-byte phase stamps of the measurement knob 49)
   d.pseq = 0;
-  d.head_major = sbk::g_kv_head_major && (dm / W->nhead) % 4 == 0;
-  d.kvtmp = c.take<float>((size_t)B * T * 2 * dm);
   for (int l = 0; l < W->n_layers; ++l) {
     d.ckv[l] = c.take<float>((size_t)B * T * 2 * dm);
     d.kcache[l] = c.take<float>((size_t)Lmax * n * dm);
@@ -991,12 +984,11 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
 int project_memory(const sbk_decoder_weights* W, const DecoderBufs& d, const float* enc, int B, int T,
                    hipStream_t st) {
   const int dm = W->d_model;
-  SBK_HIP(hipMemsetAsync(d.xcnt, 0, ((size_t)B + 16) * sizeof(int32_t), st));  // (once per search: the kernels leave the tickets at zero)
   SBK_HIP(hipMemsetAsync(d.pbar, 0, 64 * sizeof(int32_t), st));
   d.pseq = 0;
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
-    float* dst = d.head_major ? d.kvtmp : d.ckv[l];
+    float* dst = d.ckv[l];
     int rc = -1;
     if (L.ca_kv_w3 && sbk::x3_routed(B * T, 2 * dm, dm))
       rc = sbk::gemm_nt_x3(enc, dm, L.ca_kv_w3, L.ca_in_b + dm, nullptr, 0, dst, 2 * dm, B * T, 2 * dm, dm, SBK_ACT_NONE, 1.0f,
@@ -1005,7 +997,6 @@ int project_memory(const sbk_decoder_weights* W, const DecoderBufs& d, const flo
       rc = sbk::gemm_nt(enc, dm, L.ca_in_w + (size_t)dm * dm, dm, L.ca_in_b + dm, nullptr, 0, dst, 2 * dm, B * T, 2 * dm, dm,
                         SBK_ACT_NONE, 1.0f, nullptr, 0, st);
     SBK_TRY(rc);
-    if (d.head_major) SBK_TRY(sbk::kv_head_major(d.kvtmp, d.ckv[l], B, T, dm, W->nhead, st));
   }
   return 0;
 }
@@ -1017,7 +1008,7 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
                  hipStream_t st) {
   const int dm = W->d_model, H = W->nhead;
   // a beam's worth of rows (<= 16): the whole stack of the step as ONE cooperative launch (csrc/decoder_persist.hip)
-  if (!d.head_major && !sbk::g_step_ptr && sbk::persist_eligible(W, n, B, beam, Lmax)) {
+  if (!sbk::g_step_ptr && sbk::persist_eligible(W, n, B, beam, Lmax)) {
     const int rc = sbk::decoder_step_persist(W, tokens, kv_slot, enc_len, d.x, d.qkv, d.ctx, d.q, d.ff, d.h, d.logits, d.kcache,
                                              d.vcache, d.ckv, d.pbar, d.pseq, step, n, B, T, beam, Lmax, want_logits, st);
     if (rc == 0) {
@@ -1058,7 +1049,7 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
                                   0, 0, beam));
       SBK_TRY(x3r(d.ctx, dm, L.sa_out_wp, L.sa_out_b, d.x, d.x, dm, dm, SBK_ACT_NONE));
       SBK_TRY(ln_proj(L.ln2_g, L.ln2_b, L.ca_q_wfp, L.ca_q_bf, L.ca_q_wp, L.ca_in_b, d.q, dm, SBK_ACT_NONE));
-      SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, d.xpart, B, T, dm, H, beam, st, d.head_major, d.xcnt));
+      SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, d.xpart, B, T, dm, H, beam, st));
       SBK_TRY(x3r(d.ctx, dm, L.ca_out_wp, L.ca_out_b, d.x, d.x, dm, dm, SBK_ACT_NONE));
       SBK_TRY(ln_proj(L.ln3_g, L.ln3_b, L.ff1_wfp, L.ff1_bf, L.ff1_wp, L.ff1_b, d.ff, W->d_ffn, W->ffn_act));
       SBK_TRY(x3r(d.ff, W->d_ffn, L.ff2_wp, L.ff2_b, d.x, d.x, dm, W->d_ffn, SBK_ACT_NONE));
@@ -1086,7 +1077,7 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
       SBK_TRY(sbk::gemm_nt_ws(d.h, dm, L.ca_in_w, dm, L.ca_in_b, nullptr, 0, d.q, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
                               0, d.splitk, d.splitk_floats, st));
     }
-    SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, d.xpart, B, T, dm, H, beam, st, d.head_major, d.xcnt));
+    SBK_TRY(sbk::cross_attn_step(d.q, d.ckv[l], enc_len, d.ctx, d.xpart, B, T, dm, H, beam, st));
     SBK_TRY(sbk::gemm_nt_ws(d.ctx, dm, L.ca_out_w, dm, L.ca_out_b, d.x, dm, d.x, dm, n, dm, dm, SBK_ACT_NONE, 1.0f, nullptr,
                          0, d.splitk, d.splitk_floats, st));
     frc = L.ff1_wf ? sbk::gemm_ln_nt(d.x, dm, L.ff1_wf, dm, L.ff1_bf, nullptr, 0, d.ff, W->d_ffn, n, W->d_ffn, dm, W->ln_eps,
@@ -1415,7 +1406,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   }
 
   const int window = ctc ? cfg->ctc_window_size : 0;
-  SBK_REQUIRE(window >= 0 && (window == 0 || (!cfg->utt_max_steps && !cfg->utt_min_steps && !d.head_major)),
+  SBK_REQUIRE(window >= 0 && (window == 0 || (!cfg->utt_max_steps && !cfg->utt_min_steps)),
               "beam_search: ctc_window_size excludes the grouped search");
   if (window > 0) {
     SBK_LAUNCH(win_init_kernel, dim3(sbk::cdiv(Lmax, 256)), dim3(256), 0, st, bb.win, Lmax);
@@ -1560,7 +1551,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   // into a hipGraph and replayed; 2: the same device-side step counter with plain launches (tests, fallback).
   int graph_mode = cfg->graph_mode;
   if (graph_mode && (side || sbk::prof_enabled() || T > 900 || cfg->max_steps < 2 || pos_off > 0 || cfg->first_bias || window > 0)) graph_mode = 0;
-  if (graph_mode && !d.head_major && sbk::persist_eligible(W, n, B, beam, Lmax)) graph_mode = 0;  // (a cooperative launch is not captured)
+  if (graph_mode && sbk::persist_eligible(W, n, B, beam, Lmax)) graph_mode = 0;  // (a cooperative launch is not captured)
   if (graph_mode) {
     struct Scope {  // the step source is per host thread; never leave it set
       ~Scope() {

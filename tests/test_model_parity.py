@@ -520,11 +520,11 @@ def test_golden_rope_conformer(backend, tag):
 
 
 @pytest.mark.parametrize("nhead", [2, 4, 8])
-@pytest.mark.parametrize("rows,head_major", [(2, 0), (2, 1), (1, 1), (0, 1), (1, 0), (0, 0), (3, 0), (4, 0)])
-def test_cross_attention_kernel_variants(backend, nhead, rows, head_major):
-    """The three cross-attention kernels (2: MFMA for head_dim 64/32, 1: row-coalesced for 64/32/16, 0:
-    frame-per-thread) and both K/V layouts over a memory of several splits with ragged lengths, through
-    the KV-cached decoder and a 5-beam search vs the oracle."""
+@pytest.mark.parametrize("rows", [0, 3, 4])
+def test_cross_attention_kernel_variants(backend, nhead, rows):
+    """The frame-per-thread cross-attention kernel (head_dim 64 / 32 / 16) with 128-, 256- and 64-frame splits of a memory
+    with ragged lengths (several partial results merged per utterance), through the KV-cached decoder and a 5-beam search
+    vs the oracle.  (The LDS-DMA kernel: tests/test_kernels.py::test_cross_attention_lds_dma_variant.)"""
     nat, dev = backend
     from speechbrain_amd.inference.builders import build_modules
 
@@ -548,17 +548,17 @@ def test_cross_attention_kernel_variants(backend, nhead, rows, head_major):
     bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
                                     min_decode_ratio=0.0, max_decode_ratio=ratio, beam_size=5,
                                     using_eos_threshold=False, length_normalization=True)
-    nat.load().sbk_prof_set_knob(4, rows if rows < 3 else 0)  # 3 / 4 = the frame-per-thread kernel with 256- / 64-frame splits
-    nat.load().sbk_prof_set_knob(8, {3: 1, 4: 2}.get(rows, 0))
-    nat.load().sbk_prof_set_knob(5, head_major)  # cross K/V as [B,H,T,2*Dh] or as the projection wrote them
+    nat.load().sbk_prof_set_knob(4, 0)
+    nat.load().sbk_prof_set_knob(8, {3: 1, 4: 2}.get(rows, 0))  # 3 / 4 = 256- / 64-frame splits
+    nat.load().sbk_prof_set_knob(47, 0)  # (15 rows: not the persistent few-row step, which has its own attention)
     try:
         h = nat.DecoderHandle(mods["Transformer"], mods["seq_lin"])
         pred = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev))
         hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))  # several beams per (utterance, head) workgroup
     finally:
         nat.load().sbk_prof_set_knob(4, 7)
-        nat.load().sbk_prof_set_knob(5, 0)
         nat.load().sbk_prof_set_knob(8, 0)
+        nat.load().sbk_prof_set_knob(47, 1)
     assert float((pred.cpu() - O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")).abs().max()) <= 5e-5
     hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=5, max_decode_ratio=ratio))
     assert hyps == hyps_ref
@@ -981,32 +981,6 @@ def test_bf16_precision_is_opt_in_and_close(backend):
         build_asr(tiny, vocab=30, seed=2, device=str(dev)).__class__(modules=dict(a32.mods), hparams={"tokenizer": None},
                                                                      run_opts={"device": str(dev), "precision": "int4"})
     # (fp16 / fp8 are accepted since round 5: inference/interfaces.py, tests/test_whisper.py)
-
-
-@pytest.mark.parametrize("variant", [3, 4])
-def test_cross_attention_streaming_variant_matches_default(backend, variant):
-    """csrc/decoder.hip cross_attn_stream_kernel (tuning knob 4 = 3; d_model = 512 only): one wave per run of memory
-    frames with an online softmax must give the search the default kernel gives (ragged lengths, several splits)."""
-    nat, dev = backend
-    from speechbrain_amd.inference.builders import build_asr
-
-    cfg = dict(d_model=512, nhead=8, d_ffn=64, n_enc=1, n_dec=1, n_fft=512, win_length=32)
-    asr = build_asr(cfg, vocab=24, seed=13, beam_size=3, ctc_weight=0.0, device=str(dev), max_decode_ratio=0.12)
-    with torch.no_grad():
-        asr.mods.seq_lin.w.weight.mul_(8.0)
-    wav = 0.1 * torch.randn(2, 28800, generator=torch.Generator().manual_seed(2))  # 46 frames after the front-end
-    lens = torch.tensor([1.0, 0.62])
-    enc = asr.encode_batch(wav, lens)
-    dec = asr.mods.decoder
-    base = dec(enc, lens.to(dev))
-    nat.load().sbk_prof_set_knob(4, variant)
-    try:
-        alt = dec(enc, lens.to(dev))
-    finally:
-        nat.load().sbk_prof_set_knob(4, 7)
-    assert alt[0] == base[0]
-    assert float((alt[2].cpu() - base[2].cpu()).abs().max()) <= 2e-5
-    assert float((alt[3].cpu() - base[3].cpu()).abs().max()) <= 2e-5
 
 
 def test_search_projections_on_the_split_operand_kernel(backend):

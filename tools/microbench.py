@@ -88,46 +88,16 @@ if __name__ == "__main__":
         nat.load().sbk_prof_set_knob(2, 0)
         sys.exit(0)
     if "--enc-gemm" in sys.argv:  # encoder GEMM shapes (M = B*T'), tile variants of the large-M path
-        for tile, vec in ((0, 0), (0, 1), (4, 1)):
+        for tile in (0, 4):
             nat.load().sbk_prof_set_knob(6, tile)
-            nat.load().sbk_prof_set_knob(9, vec)
-            print("tile variant", tile, "16-byte LDS operands" if vec else "scalar LDS operands")
+            print("tile variant", tile)
             for (M, N, K) in [(16384, 2048, 512), (16384, 512, 2048), (56064, 2048, 512), (56064, 512, 2048),
                               (56064, 1536, 512), (56064, 512, 512), (56064, 1024, 512)]:
                 gemm_case(M, N, K, 0)
         nat.load().sbk_prof_set_knob(6, 0)
-        print("decode-step shapes through the tiled kernels (knob 2 = 1), scalar vs 16-byte LDS operands")
-        nat.load().sbk_prof_set_knob(2, 1)
-        for vec in (0, 1):
-            nat.load().sbk_prof_set_knob(9, vec)
-            for M in (320, 1280):
-                for (N, K) in [(512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512)]:
-                    gemm_case(M, N, K, 0)
-        nat.load().sbk_prof_set_knob(2, 0)
-        nat.load().sbk_prof_set_knob(9, 0)
         sys.exit(0)
-    if "--pmc-decode" in sys.argv:  # short: the decode-step GEMM variants whose wave-level counters are read from PMC passes
-        for (knobs, tag) in (((12, 1, 11, 100000), "flat32"), ((12, 1, 11, 600), "flat64"), ((2, 1, 12, 0), "tiled")):
-            for i in range(0, len(knobs), 2):
-                nat.load().sbk_prof_set_knob(knobs[i], knobs[i + 1])
-            print("variant", tag)
-            for (M, N, K) in [(320, 512, 512), (1280, 512, 512), (1280, 2048, 512), (2560, 512, 512)]:
-                gemm_case(M, N, K, 8, iters=5)
-            nat.load().sbk_prof_set_knob(2, 0)
-        nat.load().sbk_prof_set_knob(11, 1 << 30)
-        nat.load().sbk_prof_set_knob(12, 0)
-        sys.exit(0)
-    if "--flat64" in sys.argv:  # register-operand path: 32x32 tiles vs 64x64 tiles (2x2 accumulators), reach on
-        nat.load().sbk_prof_set_knob(12, 1)
-        for min_rows in (100000, 600):
-            nat.load().sbk_prof_set_knob(11, min_rows)
-            print("register-operand path,", "32x32 tiles" if min_rows > 10000 else "64x64 tiles from 600 rows")
-            for M in (640, 1280, 2560, 5120):
-                for (N, K) in [(512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512)]:
-                    gemm_case(M, N, K, 8)
-        nat.load().sbk_prof_set_knob(11, 1 << 30)
-        nat.load().sbk_prof_set_knob(12, 0)
-        sys.exit(0)
+    # (--pmc-decode / --flat64 and the 16-byte-LDS-operand columns measured kernels that round 5 removed: their logs are
+    #  profiles/r02_microbench_decode_gemm_variants.log and r02_pmc_decode_gemm_wave_counters.csv)
     if "--relpos-t" in sys.argv:  # RelPosMHAXL flash kernel: default (score tile through LDS) vs transposed scores (knob 17)
         import math
         for (B, T, H) in [(64, 440, 8), (32, 750, 8)]:
