@@ -311,109 +311,9 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   }
 }
 
-// The same score on the matrix cores (knob 7 = 8).  Counters of the VALU kernel above (profiles/r03_decode_step_*): it is
-// bound by the broadcast reads of the phi table from LDS (three ds_read_b128 per frame and wave for ten FMAs per lane)
-// and runs at 3.7 TB/s.  The product is a [16 beams x frames] . [frames x tokens] contraction per utterance:
-// v_mfma_f32_16x16x4_f32 with i = beam, k = frame, j = token slot.  A lane loads four CONSECUTIVE tokens of frame
-// u + 1 + (lane >> 4) as one 16-byte vector (a wave: 4 frames x 64 tokens = 1 KB of the emission matrix per
-// instruction) and feeds component m to MFMA m (accumulator m <-> tokens c0 + 4 j + m); the phi operand is one 4-byte
-// load of the [frame][16 beams] table (64 consecutive floats per wave): no LDS, no barrier.  The f32 MFMA is an fmaf
-// chain in k order, i.e. the same sequence of roundings as the VALU kernel's frame loop: results are bit-identical
-// (tests/test_model_parity.py::test_ctc_score_tokens_per_thread[8]).  One segment (32 frames, 8 k steps, 32 MFMAs) per
-// fold into the block-float sums, as above.
-__global__ void __launch_bounds__(256) ctc_score_mfma_kernel(CtcStepArgs a, const float* __restrict__ P,
-                                                             const BF* __restrict__ st, const float* __restrict__ sg,
-                                                             const int* __restrict__ se, float* __restrict__ psi_out) {
-  if (a.step_ptr) a.prefix_len = a.step_ptr[0];
-  const int b = blockIdx.y, j0 = blockIdx.z * 16, bp = beam_pitch(a.beam);
-  const int T = a.T, V = a.V, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lk = lane >> 4;
-  const int cw = (blockIdx.x * 4 + wave) * 64;  // this wave's 64 tokens
-  if (cw >= V) return;                           // (wave-uniform; the kernel has no barrier)
-  const int c0 = cw + 4 * li;                    // this lane's four tokens (V % 4 == 0: all inside or all outside)
-  const bool c_ok = c0 < V;
-  const int cc = c_ok ? c0 : V - 4;
-  const int nseg = nseg_of(T);
-  int start, end;
-  ctc_frame_range(a.prefix_len, T, a.win, a.window, &start, &end);
-  const int u_begin = start - 1, u_end = end - 1;
-  const float* Pb = P + (size_t)b * T * V;
-  const float* tab = sg + (size_t)b * T * bp + j0 + li;              // phi of beam j0 + li (the A operand's row)
-  const int* seg_e = se + (size_t)b * nseg * bp + j0 + 4 * lk;       // exponents of this lane's result rows: beams j0 + 4 lk + r
-  float mps[4][4];
-  int Eps[4][4];
-  {
-    const float4 p0 = *reinterpret_cast<const float4*>(Pb + cc);
-    const float p0v[4] = {p0.x, p0.y, p0.z, p0.w};
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {  // psi_init = r[start-1][nb]: x[0] (non-blank) at the very first step (ctc.py:168-172,212)
-        const bool first = a.prefix_len == 0 && start == 1 && p0v[m] > 0.0f;
-        mps[m][r] = first ? p0v[m] : 0.0f;
-        Eps[m][r] = first ? 0 : kNegE;
-      }
-  }
-  for (int seg = u_begin / kSeg; seg * kSeg < u_end; ++seg) {
-    float av[8];
-    float4 pv[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int u = seg * kSeg + 4 * ks + lk;
-      const bool ok = u >= u_begin && u < u_end;
-      av[ks] = tab[(size_t)min(max(u, 0), T - 1) * bp];
-      if (!ok) av[ks] = 0.0f;
-      pv[ks] = *reinterpret_cast<const float4*>(Pb + (size_t)min(u + 1, T - 1) * V + cc);
-    }
-    sbk::sched_fence();
-    sbk::f32x4 acc[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = sbk::f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      sbk::pin(av[ks]), sbk::pin(pv[ks].x), sbk::pin(pv[ks].y), sbk::pin(pv[ks].z), sbk::pin(pv[ks].w);
-      acc[0] = sbk::mfma_16x16x4(av[ks], pv[ks].x, acc[0]);
-      acc[1] = sbk::mfma_16x16x4(av[ks], pv[ks].y, acc[1]);
-      acc[2] = sbk::mfma_16x16x4(av[ks], pv[ks].z, acc[2]);
-      acc[3] = sbk::mfma_16x16x4(av[ks], pv[ks].w, acc[3]);
-    }
-    // end of the scale segment: fold into the block-float sums (the arithmetic of ctc_score_step_kernel)
-    const int4 es4 = *reinterpret_cast<const int4*>(seg_e + (size_t)seg * bp);
-    const int es[4] = {es4.x, es4.y, es4.z, es4.w};
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float part = acc[m][r];
-        const int kx = sbk::frexp_exp(part);
-        const int ep = part > 0.0f ? es[r] + kx : kNegE;
-        const float mp = sbk::fast_ldexp(part, -kx);
-        const int P2 = max(Eps[m][r], ep);
-        mps[m][r] = sbk::fast_ldexp(mps[m][r], Eps[m][r] - P2) + sbk::fast_ldexp(mp, ep - P2);
-        Eps[m][r] = P2;
-      }
-  }
-  if (!c_ok) return;
-  const int last_frame = a.enc_len[b] - 1;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int jb = j0 + 4 * lk + r;
-    if (jb >= a.beam) continue;
-    const int n = b * a.beam + jb;
-    float o[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      o[m] = bf_log(mps[m][r], Eps[m][r]);
-      if (c0 + m == a.eos) {  // psi[eos] = log-sum of the prefix' own variables at the last frame (ctc.py:232-235)
-        const BF s = st[(size_t)n * T + last_frame];
-        o[m] = bf_log(s.mg, s.eg);
-      }
-      if (c0 + m == a.blank && a.eos != a.blank) o[m] = kNeg;
-    }
-    *reinterpret_cast<float4*>(psi_out + (size_t)n * V + c0) = make_float4(o[0], o[1], o[2], o[3]);
-  }
-}
-
+// (The same score on v_mfma_f32_16x16x4_f32 -- knob 7 = 8 of round 4 -- was bit-identical and no faster: 255 vs 252-269 us, the
+// kernel is bound by its HBM stream at 3.7-4 TB/s, not by the LDS broadcast reads the counters had pointed at; two and four
+// tokens per thread -- knob 7 = 2 / 4 -- were within noise: profiles/r04_i_*.  Both removed in round 5.)
 // The one token per hypothesis that repeats the prefix' last token uses phi = beta instead of
 // gamma (ctc.py:175-186): recompute that entry.  One wave per hypothesis, lanes over frames.
 __global__ void __launch_bounds__(64) ctc_same_token_kernel(CtcStepArgs a, const float* __restrict__ P,
@@ -759,7 +659,6 @@ __global__ void __launch_bounds__(256) row_max_kernel(const float* __restrict__ 
 }  // namespace
 
 namespace sbk {
-int g_ctc_tpt = 1;  // tuning knob (sbk_prof_set_knob key 7): vocabulary entries per thread in ctc_score_step (1, 2, 4)
 
 namespace {
 struct StateView {
@@ -810,15 +709,7 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
   a.window = window;
   const StateView v = view(const_cast<float*>(state), B, beam, T);
   ProfScope prof("ctc_score_step", 2.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 4.0 * B * beam * V, st);
-  if (g_ctc_tpt == 8 && V % 4 == 0 && aligned16(P) && aligned16(psi)) {  // on the matrix cores (no LDS)
-    dim3 grid(cdiv(V, 256), B, beam_pitch(beam) / 16), block(256);
-    SBK_LAUNCH(ctc_score_mfma_kernel, grid, block, 0, st, a, P, (const BF*)v.st, (const float*)v.sg, (const int*)v.se, psi);
-    int rc = launch_status("ctc_score_step");
-    if (rc) return rc;
-    SBK_LAUNCH(ctc_same_token_kernel, dim3(B * beam), dim3(64), 0, st, a, P, (const float*)v.sb, (const int*)v.se, psi);
-    return launch_status("ctc_same_token");
-  }
-  const int tpt = (g_ctc_tpt == 4 && (V % 4 != 0 || !aligned16(P))) ? 1 : (g_ctc_tpt == 8 ? 1 : g_ctc_tpt);
+  constexpr int tpt = 1;
   dim3 grid(cdiv(V, 256 * tpt), B, beam_pitch(beam) / 16), block(256);  // z: tiles of 16 beams (P is re-read per tile)
   const size_t lds = ((size_t)T * 16 + (size_t)((T + kSeg - 1) / kSeg) * 16) * sizeof(float);
   if (lds > 160 * 1024) return fail(SBK_EINVAL, "ctc_psi_step: T=%d frames need %zu B of LDS (max 160 KiB)", T, lds);
@@ -830,16 +721,7 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
     SBK_LAUNCH((ctc_score_step_kernel<NB, TP>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg,        \
                (const int*)v.se, psi);                                                                                  \
   } while (0)
-#define SBK_CTC_LAUNCH(NB)                                                                                              \
-  do {                                                                                                                  \
-    if (tpt == 4) {                                                                                                     \
-      SBK_CTC_LAUNCH_ONE(NB, 4);                                                                                        \
-    } else if (tpt == 2) {                                                                                              \
-      SBK_CTC_LAUNCH_ONE(NB, 2);                                                                                        \
-    } else {                                                                                                            \
-      SBK_CTC_LAUNCH_ONE(NB, 1);                                                                                        \
-    }                                                                                                                   \
-  } while (0)
+#define SBK_CTC_LAUNCH(NB) SBK_CTC_LAUNCH_ONE(NB, 1)
   if (beam == 1) {
     SBK_CTC_LAUNCH(1);
   } else if (beam <= 4) {

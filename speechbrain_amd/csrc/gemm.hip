@@ -1059,8 +1059,6 @@ int g_tiled_splitk = 256;  // tuning knob (key 14): from this many rows on, K >=
 // its last-arriving workgroup (knob 36: 9 815 vs 10 416 audio-s/s, r03_last_arriver_reductions_ab.log -- an agent-scope
 // release is an L2 write-back on an 8-XCD part), 64 x 64 register-operand tiles (knob 11: 29 vs 23 us in situ), the looped
 // skinny schedule of round 1 (knob 10), the wider reach of the register-operand path (knob 12), other K splits (knob 15).)
-int g_gemm_tile = 0;   // tuning knob (key 6) for the large-M path: 0 = 128x128, 1 = 256x128 (8 waves of 64x64),
-                       // 2 = 128x256 (8 waves), 3 = 256x128 (4 waves of 128x64), 4 = 128x128 with 64-deep K tiles
 int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
             int ldc, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
 int* tile_tickets(hipStream_t st, long tiles);  // this stream's zeroed arrival counters (nullptr: no workspace registered for the stream, or too many tiles)
@@ -1320,11 +1318,7 @@ int gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
       if (rc != -1) return rc;  // -1: the caller registered no workspace for this stream
     }
   }
-  const bool big = tiles128 >= 768 || (g_gemm_tile & 16);  // +16: take the variant at any size (tests)
-  if (big && (g_gemm_tile & 15) == 1) return launch_gemm<256, 128, 32, 64, 64>(g, vec, st);
-  if (big && (g_gemm_tile & 15) == 2) return launch_gemm<128, 256, 32, 64, 64>(g, vec, st);
-  if (big && (g_gemm_tile & 15) == 3) return launch_gemm<256, 128, 32, 128, 64>(g, vec, st);
-  if (big && (g_gemm_tile & 15) == 4) return launch_gemm<128, 128, 64, 64, 64>(g, vec, st);  // one barrier pair per 128 MFMAs
+  // (256 x 128, 128 x 256 and 64-deep-K variants of the 128 x 128 tile -- knob 6 of rounds 1-2 -- never beat it: removed in round 5)
   if (tiles128 >= 384) return launch_gemm<128, 128, 32, 64, 64>(g, vec, st);
   if (tiles64 >= 256 || M > 256) return launch_gemm<64, 64, 32, 32, 32>(g, vec, st);
   return launch_gemm<32, 64, 32, 32, 32>(g, vec, st);
@@ -1422,17 +1416,11 @@ extern "C" int sbk_prof_gemm_repeat_f32(const float* A, const float* W, float* C
 
 extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 2) sbk::g_skinny_off = value;
-  if (key == 3) sbk::g_attn_prefetch = value;
-  if (key == 16) sbk::g_rope_flash_lds = value;
-  if (key == 17) sbk::g_relpos_flash_t = value;
   if (key == 4) sbk::g_cross_rows = value;
-  if (key == 6) sbk::g_gemm_tile = value;
-  if (key == 7) sbk::g_ctc_tpt = value;
   if (key == 8) sbk::g_cross_fc256 = value;
   if (key == 14) sbk::g_tiled_splitk = value;
   if (key == 18) sbk::g_sk_mode = value;
   if (key == 24) sbk::g_sk_min_rows = value;
-  if (key == 39) sbk::g_x3p_tile = value;
   if (key == 40) sbk::g_score_fused = value;
   if (key == 41) sbk::g_x3r_mode = value;
   if (key == 42) sbk::g_x3r_min_rows = value;

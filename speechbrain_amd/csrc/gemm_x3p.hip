@@ -466,7 +466,8 @@ int launch_x3p(const X3pArgs& a0, hipStream_t st) {
 }  // namespace
 
 namespace sbk {
-int g_x3p_tile = 0;  // tuning knob (key 39): 0 / 2 = 256 x 128 (measured faster on every encoder shape: profiles/r04_d_*), 1 = 256 x 256
+// (256 x 256 tiles -- knob 39 of round 4 -- were slower than 256 x 128 on every encoder shape, e.g. 179 vs 155 us at N = 2 048:
+// profiles/r04_d_*; instantiation and knob removed in round 5)
 
 int gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, const float* R, int ldr, float* C, int ldc,
                 uint16_t* PC, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st) {
@@ -481,10 +482,6 @@ int gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, const
   // algorithmic bytes: both operand images once (6 B per element) + the result (+ the residual)
   const double bytes = 6.0 * ((double)M * K + (double)N * K) + (C ? 4.0 : 0.0) * M * N + (PC ? 6.0 : 0.0) * M * N + (R ? 4.0 : 0.0) * M * N;
   ProfScope prof("gemm_nt_x3p", flops, bytes, st);
-  const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-  const int cus = device_cus();
-  const bool big = g_x3p_tile == 1;
-  if (big) return launch_x3p<4, 2, 2, 4>(a, st);
   return launch_x3p<4, 2, 2, 2>(a, st);
 }
 }  // namespace sbk

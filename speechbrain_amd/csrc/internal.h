@@ -15,7 +15,6 @@ bool x3_routed(int M, int N, int K);
 // both operands as panel images (csrc/gemm_x3p.hip); PC: optional panel image of the result; -1 = no workspace
 int gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, const float* R, int ldr, float* C, int ldc,
                 uint16_t* PC, int M, int N, int K, int act, float alpha, const int32_t* seq_len, int rows_per_seq, hipStream_t st);
-extern int g_x3p_tile;
 // few-row contraction on the bf16 matrix pipe (csrc/gemm_x3r.hip): A fp32 [M, K], PW = the panel image of W (sbk_split_x3p);
 // -1 = shape not eligible
 int gemm_nt_x3r(const float* A, int lda, const uint16_t* PW, const float* bias, const float* R, int ldr, float* C, int ldc, int M,
@@ -42,11 +41,7 @@ extern int g_persist, g_persist_grid, g_persist_stamps;
 // of one decoding step are identical for every step and can be replayed from a captured hipGraph.
 extern thread_local const int32_t* g_step_ptr;
 extern thread_local int g_step_min_steps;  // min_decode_steps of that search (eos floor: step < min_steps)
-extern int g_attn_prefetch;
-extern int g_rope_flash_lds;
-extern int g_relpos_flash_t;
 extern int g_cross_rows;
-extern int g_ctc_tpt;
 extern int g_cross_fc256;
 extern int g_score_fused;  // key 40: 1 (default) = the step's scoring as one pass per hypothesis row (csrc/search.hip)
 constexpr float kCtcNeg = -1e20f;  // the CTC scorer's finite "log 0" (ctc.py:150, scorer.py:1250)

@@ -278,198 +278,9 @@ __global__ void __launch_bounds__(NW * 64) relpos_attn_kernel(AttnArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Strip-free variant (no attention-weights output): one WAVE owns a 32-query tile and walks the key
-// tiles with an online softmax, so the only LDS is a 32x33 score/probability tile per wave and the
-// occupancy is set by registers (2 waves per SIMD) instead of by a [32][T'] strip (1 workgroup per CU
-// for T' > ~350).  Q (+u, +v) lives in registers in the same half-split layout as the K / P runs.
-// Per key tile: AC and the two skewed BD products land in the wave's LDS tile, each lane updates the
-// running max / sum of its row (16 columns per half-wave, halves combined by one shuffle), the
-// accumulated context is rescaled by exp(m_old - m_new) and P.V is added with V read straight from
-// L2 (128-byte rows per half-wave).  No workgroup barrier anywhere: the 4 waves of a workgroup are
-// independent query tiles sharing K/V through L2.
-template <int DH, bool ROPE>
-__global__ void __launch_bounds__(256, 2) relpos_flash_kernel(AttnArgs a) {
-  constexpr int DH2 = DH / 2;
-  constexpr int NC = (DH + 31) / 32;
-  __shared__ float Ssc[4][32][33];
-  __shared__ float rowv[4][32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int jl = lane & 31, half = lane >> 5;
-  const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
-  const int T = a.T, d = a.H * DH;
-  if (i0 >= T) return;  // whole wave: nothing below synchronises across waves
-  const size_t row3 = (size_t)3 * d;
-  const float* qkv_b = a.qkv + (size_t)b * T * row3 + (size_t)h * 3 * DH;
-  float (*S)[33] = Ssc[wave];
-  float* rv = rowv[wave];
-
-  float qu[DH2], qv[DH2];
-  {
-    const int row = min(i0 + jl, T - 1);
-    float qr[DH2];
-    load_run<DH2>(qr, qkv_b + (size_t)row * row3 + half * DH2);
-    if constexpr (ROPE) {
-      float cs[DH2], sn[DH2];
-      load_run<DH2>(cs, a.pos + (size_t)row * DH + half * DH2);
-      load_run<DH2>(sn, a.bias_u + (size_t)row * DH + half * DH2);
-#pragma unroll
-      for (int s2 = 0; s2 < DH2; s2 += 2) {
-        qu[s2] = (qr[s2] * cs[s2] + qr[s2 + 1] * sn[s2]) * a.scale;
-        qu[s2 + 1] = (qr[s2 + 1] * cs[s2 + 1] + qr[s2] * sn[s2 + 1]) * a.scale;
-      }
-    } else {
-      float bu[DH2], bv[DH2];
-      load_run<DH2>(bu, a.bias_u + h * DH + half * DH2);
-      load_run<DH2>(bv, a.bias_v + h * DH + half * DH2);
-#pragma unroll
-      for (int s = 0; s < DH2; ++s) {
-        qu[s] = (qr[s] + bu[s]) * a.scale;
-        qv[s] = (qr[s] + bv[s]) * a.scale;
-      }
-    }
-  }
-  int klen = T;
-  if (a.key_len) klen = min(max(a.key_len[b], 1), T);
-  const int nkt = (klen + 31) / 32;
-  int lo_row, hi_row;  // allowed keys of query row jl
-  key_range(a, min(i0 + jl, T - 1), klen, lo_row, hi_row);
-  int kt_begin = 0, kt_end = nkt;  // key tiles any row of this query tile may see
-  if (a.chunk > 0) {
-    kt_end = min(nkt, ((min(i0 + 31, T - 1) / a.chunk + 1) * a.chunk + 31) / 32);
-    if (a.left >= 0) kt_begin = max(0, (i0 / a.chunk - a.left) * a.chunk) / 32;
-  }
-  float m_run = -INFINITY, l_run = 0.0f;  // of query row jl (both half-waves carry the same values)
-  f32x16 o[NC];
-#pragma unroll
-  for (int ct = 0; ct < NC; ++ct)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[ct][r] = 0.0f;
-
-  // The position rows a key tile needs are r = rbase .. rbase+63 with rbase = T-1-i0-31+j0, so the upper
-  // half of one tile's rows is the lower half of the next tile's: G = (Q+v) P[rbase+32 ..]^T is computed
-  // ONCE and carried in registers to the next tile (one new 32-MFMA chain and one new P run per tile).
-  f32x16 gprev;
-  if constexpr (!ROPE) {
-    float p0reg[DH2];
-    const int prow0 = min(max((T - 1) - i0 - 31 + kt_begin * 32 + jl, 0), 2 * T - 2);
-    load_run<DH2>(p0reg, a.pos + (size_t)prow0 * d + h * DH + half * DH2);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) gprev[r] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < DH2; ++s) gprev = sbk::mfma_32x32x2(qv[s], p0reg[s], gprev);
-  }
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int j0 = kt * 32;
-    float kreg[DH2], p1reg[DH2];
-    {
-      const int krow = min(j0 + jl, T - 1);
-      load_run<DH2>(kreg, qkv_b + (size_t)krow * row3 + DH + half * DH2);
-      if constexpr (ROPE) {
-        float csreg[DH2];
-        load_run<DH2>(csreg, a.pos + (size_t)krow * DH + half * DH2);
-        load_run<DH2>(p1reg, a.bias_u + (size_t)krow * DH + half * DH2);
-#pragma unroll
-        for (int s2 = 0; s2 < DH2; s2 += 2) {
-          const float k0 = kreg[s2], k1 = kreg[s2 + 1];
-          kreg[s2] = k0 * csreg[s2] + k1 * p1reg[s2];
-          kreg[s2 + 1] = k1 * csreg[s2 + 1] + k0 * p1reg[s2 + 1];
-        }
-      } else {
-        const int rbase = (T - 1) - i0 - 31 + j0;
-        const int prow1 = min(max(rbase + 32 + jl, 0), 2 * T - 2);
-        load_run<DH2>(p1reg, a.pos + (size_t)prow1 * d + h * DH + half * DH2);
-      }
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < DH2; ++s) acc = sbk::mfma_32x32x2(qu[s], kreg[s], acc);
-    // V of this key tile: requested now, consumed after the softmax update (kreg is dead from here on)
-    float vv[NC][16];
-#pragma unroll
-    for (int ct = 0; ct < NC; ++ct) {
-      const int col = ct * 32 + jl;
-      const float* vbase = qkv_b + 2 * DH + (col < DH ? col : 0);
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int t = min(j0 + 2 * u + half, T - 1);
-        vv[ct][u] = col < DH ? vbase[(size_t)t * row3] : 0.0f;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S[(r & 3) + 8 * (r >> 2) + 4 * half][jl] = acc[r];
-    sbk::wave_sync();
-    if constexpr (!ROPE) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-      for (int s = 0; s < DH2; ++s) acc = sbk::mfma_32x32x2(qv[s], p1reg[s], acc);
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {  // lower rows: carried from the previous tile; upper rows: just computed
-        const int rl = pt * 32 + jl;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const int jloc = rl + i - 31;
-          if (jloc >= 0 && jloc < 32) S[i][jloc] += pt == 0 ? gprev[r] : acc[r];
-        }
-      }
-      gprev = acc;
-      sbk::wave_sync();
-    }
-    // online softmax: lane = (row jl, columns half*16 .. half*16+15)
-    float sv[16];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int c = half * 16 + q;
-      sv[q] = (j0 + c >= lo_row && j0 + c < hi_row) ? S[jl][c] : -INFINITY;
-      mx = fmaxf(mx, sv[q]);
-    }
-    mx = fmaxf(mx, sbk::shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);  // -inf while the row has not met an allowed key yet (chunk mask)
-    const float alpha = m_new == -INFINITY ? 1.0f : expf(m_run - m_new);
-    float sum = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float pq = sv[q] == -INFINITY ? 0.0f : expf(sv[q] - m_new);
-      S[jl][half * 16 + q] = pq;
-      sum += pq;
-    }
-    sum += sbk::shfl_xor(sum, 32);
-    l_run = l_run * alpha + sum;
-    m_run = m_new;
-    if (half == 0) rv[jl] = alpha;
-    sbk::wave_sync();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float al = rv[(r & 3) + 8 * (r >> 2) + 4 * half];
-#pragma unroll
-      for (int ct = 0; ct < NC; ++ct) o[ct][r] *= al;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const float pa = S[jl][2 * u + half];
-#pragma unroll
-      for (int ct = 0; ct < NC; ++ct) o[ct] = sbk::mfma_32x32x2(pa, vv[ct][u], o[ct]);
-    }
-    sbk::wave_sync();  // the next tile overwrites S and rv
-  }
-  if (half == 0) rv[jl] = l_run;
-  sbk::wave_sync();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-    const float inv = rv[i] > 0.0f ? 1.0f / rv[i] : 0.0f;  // no allowed key at all: zero context (attention.py:713-728)
-#pragma unroll
-    for (int ct = 0; ct < NC; ++ct) {
-      const int col = ct * 32 + jl;
-      if (col < DH && i0 + i < T) a.out[((size_t)b * T + i0 + i) * d + h * DH + col] = o[ct][r] * inv;
-    }
-  }
-}
+// (The first strip-free kernel -- one wave per 32-query tile with a 32 x 33 LDS score tile, rounds 1-2, later knobs 16 / 17 -- was
+// replaced by the transposed-score kernels below in round 3: 608 -> 491 us at B = 64, T' = 440; 777 -> 617 us at B = 32, T' = 750
+// (profiles/r03_stream_calibration_and_streamk_v1_sweep.log).  Removed in round 5.)
 
 // ---------------------------------------------------------------------------------------------
 // Attention without a position-score term (RoPEMHA; plain MHA = an identity rotation table), transposed scores.
@@ -1046,20 +857,13 @@ template <int DH, bool ROPE>
 int launch_flash(const AttnArgs& a, hipStream_t st) {
   sbk::ProfScope prof(ROPE ? "rope_attention" : "relpos_attention", (ROPE ? 4.0 : 6.0) * a.B * a.H * (double)a.T * a.T * DH,
                       4.0 * a.B * a.T * (4.0 * a.H * DH) + 4.0 * (2.0 * a.T - 1) * a.H * DH, st);
-  if constexpr (ROPE) {
-    if (!sbk::g_rope_flash_lds || !a.pos) {  // default: transposed scores, no LDS (knob 16 = 1 keeps the LDS-tile kernel for A/B)
-      SBK_LAUNCH((rope_flash_t_kernel<DH>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
-      return sbk::launch_status("sbk_rope_attention_f32");
-    }
+  if constexpr (ROPE) {  // transposed scores, no LDS
+    SBK_LAUNCH((rope_flash_t_kernel<DH>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+    return sbk::launch_status("sbk_rope_attention_f32");
+  } else {  // transposed scores, position term through a 64-row LDS ring
+    SBK_LAUNCH((relpos_flash_t_kernel<DH>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+    return sbk::launch_status("sbk_relpos_attention_f32");
   }
-  if constexpr (!ROPE) {
-    if (sbk::g_relpos_flash_t) {  // default: transposed scores, position term through a 64-row LDS ring (knob 17 = 0: LDS-tile kernel)
-      SBK_LAUNCH((relpos_flash_t_kernel<DH>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
-      return sbk::launch_status("sbk_relpos_attention_f32");
-    }
-  }
-  SBK_LAUNCH((relpos_flash_kernel<DH, ROPE>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
-  return sbk::launch_status(ROPE ? "sbk_rope_attention_f32" : "sbk_relpos_attention_f32");
 }
 
 template <int DH, bool ROPE, bool PF, int NW>
@@ -1070,12 +874,10 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
   // Schedule (measured on MI355X, tools/microbench.py --attn, B=64 T'=440 Dh=64): once the score strip
   // pins one workgroup per CU (> 80 KB of LDS), 8 waves per workgroup are 1.43x (RelPos) / 1.28x (RoPE)
   // faster than 4; prefetching the next key tile's operands helps only RoPE (1.18x more; RelPos spills).
-  // sbk_prof_set_knob key 3 overrides: bit 0 prefetch on, bit 1 force 4 waves, bit 2 force 8 waves.
-  const int k = sbk::g_attn_prefetch;
-  if (!a.attn && !(k & 8)) return launch_flash<DH, ROPE>(a, st);  // bit 3 (8): keep the strip kernel (A/B, tests)
+  if (!a.attn) return launch_flash<DH, ROPE>(a, st);  // (the strip kernel below serves the attention-weights output)
   const size_t lds4 = ((size_t)2 * 32 * (DH + 1) + 3 * 32 * 33 + (size_t)32 * a.SP) * sizeof(float);
-  const bool eight = (k & 4) ? true : ((k & 2) ? false : lds4 > 80 * 1024);
-  const bool pf = k ? (k & 1) : (ROPE && eight);
+  const bool eight = lds4 > 80 * 1024;
+  const bool pf = ROPE && eight;
   if (eight) return pf ? launch_attn_pf<DH, ROPE, true, 8>(a, st) : launch_attn_pf<DH, ROPE, false, 8>(a, st);
   return pf ? launch_attn_pf<DH, ROPE, true, 4>(a, st) : launch_attn_pf<DH, ROPE, false, 4>(a, st);
 }
@@ -1098,10 +900,6 @@ int launch_attn_pf(const AttnArgs& a, hipStream_t st) {
 }  // namespace
 
 namespace sbk {
-int g_relpos_flash_t = 1;  // tuning knob (key 17): 1 (default since round 3) = RelPosMHAXL through the transposed-score flash
-                           // kernel; 0 = the LDS-tile flash kernel (kept for A/B and as the second implementation in tests)
-int g_rope_flash_lds = 0;  // tuning knob (key 16): 1 = RoPE / plain attention through the LDS-tile flash kernel (round-2 first half)
-int g_attn_prefetch = 0;  // tuning knob (sbk_prof_set_knob key 3): phase 1 prefetches the next key tile's operands
 
 int relpos_attention(const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                      const int32_t* key_len, float* out, float* attn, int B, int T, int H, int Dh, float scale,

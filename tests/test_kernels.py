@@ -37,25 +37,6 @@ def test_gemm_bias_act_residual(backend, M, N, K):
         assert _md(out, ref) <= 2e-6 * scale + 1e-5
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
-def test_gemm_large_tile_variants(backend, tile):
-    """The 256x128 / 128x256 tilings of the large-M path (tuning knob 6), forced at a small ragged shape."""
-    nat, dev = backend
-    M, N, K = 5000, 300, 72  # > 4096 rows: past the skinny path; ragged in every dimension
-    g = torch.Generator().manual_seed(tile)
-    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.001
-    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
-    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
-    ref = r + 0.5 * F.silu(a.double() @ w.double().t() + b).float()
-    scale = float((a.abs() @ w.abs().t()).max())
-    nat.load().sbk_prof_set_knob(6, 16 + tile)
-    try:
-        out = nat.gemm_nt(a.to(dev), w.to(dev), b.to(dev), r.to(dev), act=nat.ACT_SWISH, alpha=0.5)
-    finally:
-        nat.load().sbk_prof_set_knob(6, 0)
-    assert _md(out, ref) <= 2e-6 * scale + 1e-5
-
-
 @pytest.mark.parametrize("M,N,K", [(320, 96, 128), (40, 70, 64), (512, 33, 192), (20, 130, 512), (320, 512, 2048)])
 def test_gemm_skinny_splitk(backend, M, N, K):
     """Decoder-step shapes: register-fed skinny kernel, with and without split-K partials."""
@@ -174,10 +155,8 @@ def test_conv_frontend_golden(backend):
 
 @pytest.mark.parametrize("B,T,H,Dh,lens", [(2, 45, 4, 8, [45, 30]), (1, 70, 2, 36, [70]), (2, 33, 2, 64, [33, 20]),
                                            (1, 100, 1, 16, None), (1, 40, 2, 32, [17]), (2, 251, 2, 64, [251, 129])])
-@pytest.mark.parametrize("prefetch", [0, 1, 4, 5])
-def test_relpos_attention(backend, B, T, H, Dh, lens, prefetch):
+def test_relpos_attention(backend, B, T, H, Dh, lens):
     nat, dev = backend
-    nat.load().sbk_prof_set_knob(3, prefetch)  # both schedules of phase 1 (operand prefetch off / on)
     d = H * Dh
     g = torch.Generator().manual_seed(T + Dh)
     x = torch.randn(B, T, d, generator=g)
@@ -206,16 +185,15 @@ def test_relpos_attention(backend, B, T, H, Dh, lens, prefetch):
     if lens is not None:  # masked keys carry exactly zero weight
         for b, n in enumerate(lens):
             assert float(attn[b, :, :, n:].abs().max()) == 0.0 if n < T else True
-    nat.load().sbk_prof_set_knob(3, 0)
 
 
 @pytest.mark.parametrize("B,T,H,Dh,lens,chunk", [(2, 45, 4, 8, [45, 30], (0, -1)), (1, 70, 2, 36, [70], (0, -1)),
                                                  (2, 133, 2, 64, [133, 20], (0, -1)), (1, 100, 1, 16, None, (0, -1)),
                                                  (2, 251, 2, 64, [251, 129], (16, 2)), (1, 97, 2, 32, [97], (8, -1))])
 def test_relpos_transposed_flash_variant(backend, B, T, H, Dh, lens, chunk):
-    """csrc/relpos_attn.hip relpos_flash_t_kernel (the default since round 3; knob 17 = 0 selects the LDS-tile flash
-    kernel it replaced): transposed scores with the position term gathered from a 64-row LDS ring must reproduce the
-    LDS-tile kernel and the oracle -- key padding, Dynamic Chunk masks, ragged tiles, every instantiated head size."""
+    """csrc/relpos_attn.hip relpos_flash_t_kernel (the default since round 3): transposed scores with the position term
+    gathered from a 64-row LDS ring must reproduce the strip kernel (the second implementation: the one that also writes the
+    attention weights) and the oracle -- key padding, Dynamic Chunk masks, ragged tiles, every instantiated head size."""
     nat, dev = backend
     d = H * Dh
     g = torch.Generator().manual_seed(T + Dh)
@@ -230,11 +208,7 @@ def test_relpos_transposed_flash_variant(backend, B, T, H, Dh, lens, chunk):
     P = nat.gemm_nt(pos.to(dev), sd["linear_pos.weight"].to(dev))
     args = (qkv, P, sd["pos_bias_u"].reshape(-1).contiguous().to(dev), sd["pos_bias_v"].reshape(-1).contiguous().to(dev),
             None if kl is None else kl.to(dev), H, 1 / math.sqrt(d), False, chunk[0], chunk[1])
-    nat.load().sbk_prof_set_knob(17, 0)
-    try:
-        base, _ = nat.relpos_attention(*args)
-    finally:
-        nat.load().sbk_prof_set_knob(17, 1)
+    base, _ = nat.relpos_attention(*(args[:7] + (True,) + args[8:]))  # want_attn: the strip kernel
     new, _ = nat.relpos_attention(*args)
     assert _md(new, base.cpu()) <= 5e-6
     if chunk[0] == 0:
@@ -242,15 +216,13 @@ def test_relpos_transposed_flash_variant(backend, B, T, H, Dh, lens, chunk):
         assert _md(new, O.relpos_mha(x, pos, sd, "", H, kp)) <= 5e-6
 
 
-@pytest.mark.parametrize("prefetch", [0, 1, 4, 5])
 @pytest.mark.parametrize("B,T,H,Dh,lens", [(2, 45, 4, 8, [45, 30]), (1, 70, 2, 36, [70]), (2, 133, 2, 64, [133, 20]),
                                            (1, 300, 1, 32, None)])
-def test_rope_attention(backend, B, T, H, Dh, lens, prefetch):
+def test_rope_attention(backend, B, T, H, Dh, lens):
     """RoPEMHA (nnet/attention.py:1191-1392) vs the oracle restatement, with key padding."""
     nat, dev = backend
     from speechbrain_amd.nnet.attention import PrecomputedRoPESinusoids
 
-    nat.load().sbk_prof_set_knob(3, prefetch)
     d = H * Dh
     g = torch.Generator().manual_seed(T + Dh)
     x = torch.randn(B, T, d, generator=g)
@@ -269,7 +241,6 @@ def test_rope_attention(backend, B, T, H, Dh, lens, prefetch):
                                    1 / math.sqrt(d), want_attn=True)
     out2, _ = nat.rope_attention(qkv, tab.cosines.to(dev), tab.sines.to(dev), None if kl is None else kl.to(dev), H,
                                  1 / math.sqrt(d), want_attn=False)  # strip-free kernel
-    nat.load().sbk_prof_set_knob(3, 0)
     assert _md(out, ref) <= 5e-6
     assert _md(out2, ref) <= 5e-6
     assert float((attn.sum(-1) - 1).abs().max()) <= 1e-5
@@ -277,8 +248,7 @@ def test_rope_attention(backend, B, T, H, Dh, lens, prefetch):
 
 @pytest.mark.parametrize("T,lens,chunk", [(45, None, (0, -1)), (70, [70, 33], (0, -1)), (100, [100, 61], (16, 1))])
 def test_rope_attention_kernel_variants(backend, T, lens, chunk):
-    """The transposed-score flash kernel (default; no LDS) against the LDS-tile flash kernel (knob 16) and the strip
-    kernel, and the bf16 matrix-core variant (precision scope "bf16", head_dim 64) against the fp32 result: key padding,
+    """The transposed-score flash kernel (default; no LDS) against the strip kernel, and the bf16 matrix-core variant (precision scope "bf16", head_dim 64) against the fp32 result: key padding,
     Dynamic Chunk mask, ragged last tiles.  bf16 tolerance 3e-2 absolute on contexts of unit scale (8-bit mantissas
     of q, k, v and the probabilities)."""
     nat, dev = backend
@@ -295,12 +265,7 @@ def test_rope_attention_kernel_variants(backend, T, lens, chunk):
     scale = 1 / math.sqrt(Dh)
     new, _ = nat.rope_attention(qkv, cos, sin, kl, H, scale, False, chunk[0], chunk[1])
     strip, _ = nat.rope_attention(qkv, cos, sin, kl, H, scale, True, chunk[0], chunk[1])
-    nat.load().sbk_prof_set_knob(16, 1)
-    try:
-        old, _ = nat.rope_attention(qkv, cos, sin, kl, H, scale, False, chunk[0], chunk[1])
-    finally:
-        nat.load().sbk_prof_set_knob(16, 0)
-    assert _md(new, old.cpu()) <= 5e-6 and _md(new, strip.cpu()) <= 5e-6
+    assert _md(new, strip.cpu()) <= 5e-6
     with nat.precision_scope("bf16"):
         low, none = nat.rope_attention(qkv, cos, sin, kl, H, scale, False, chunk[0], chunk[1])
     assert none is None
@@ -710,15 +675,14 @@ def test_gemm_f32x3(backend, M, N, K):
         nat.F32X3, nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES = old
 
 
-@pytest.mark.parametrize("M,N,K,tile", [(300, 132, 64, 1), (300, 132, 64, 2), (700, 300, 96, 0), (1000, 520, 64, 2), (520, 260, 128, 1),
-                                        (2100, 304, 64, 2), (1300, 272, 160, 1), (4100, 512, 512, 0), (3012, 2048, 512, 0),
-                                        (12800, 2048, 512, 0), (4032, 512, 2048, 0), (24000, 1536, 512, 0), (14000, 1024, 512, 0),
-                                        (6432, 512, 512, 2), (130, 1032, 2048, 1)])
-def test_gemm_x3p(backend, M, N, K, tile):
+@pytest.mark.parametrize("M,N,K", [(300, 132, 64), (700, 300, 96), (1000, 520, 64), (520, 260, 128), (2100, 304, 64), (1300, 272, 160),
+                                   (4100, 512, 512), (3012, 2048, 512), (12800, 2048, 512), (4032, 512, 2048), (24000, 1536, 512),
+                                   (14000, 1024, 512), (6432, 512, 512), (130, 1032, 2048)])
+def test_gemm_x3p(backend, M, N, K):
     """sbk_split_x3p + sbk_gemm_nt_x3p: the fp32 contraction on the bf16 matrix pipe with BOTH operands pre-split and in
     panel layout.  The panel image is exact (hi + mid + lo == x bit for bit, padding rows zero); the result is held to the
-    bound of every fp32 kernel of the library against the fp64 product (2e-6 of the largest sum of magnitudes); both tile
-    shapes (knob 39), whole-tile and stream-K launches, ragged edges, every epilogue option, row masks; the panel-image
+    bound of every fp32 kernel of the library against the fp64 product (2e-6 of the largest sum of magnitudes);
+    whole-tile and stream-K launches, ragged edges, every epilogue option, row masks; the panel-image
     result (the next contraction's A operand) equals the fp32 result bit for bit; run-to-run bit-identical."""
     nat, dev = backend
     if dev.type == "cpu" and M * N * K > 6e7:
@@ -730,7 +694,6 @@ def test_gemm_x3p(backend, M, N, K, tile):
     w[::5] *= 300.0
     b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
     lib = nat.load()
-    lib.sbk_prof_set_knob(39, tile)
     try:
         ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
 
@@ -771,7 +734,7 @@ def test_gemm_x3p(backend, M, N, K, tile):
             win = a.reshape(-1).unfold(0, K, K // 2)
             assert _md(out, (win.double() @ w.double().t() + b).float()) <= 2e-6 * scale + 1e-5
     finally:
-        lib.sbk_prof_set_knob(39, 0)
+        pass
 
 
 @pytest.mark.parametrize("M,N,K", [(1280, 512, 512), (300, 132, 256), (70, 1536, 512), (640, 512, 2048), (1280, 2048, 512),

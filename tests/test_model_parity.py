@@ -616,32 +616,6 @@ def test_from_hparams_local_model_directory(backend):
         EncoderDecoderASR.from_hparams(source="speechbrain/asr-conformer-transformerlm-librispeech")
 
 
-@pytest.mark.parametrize("tpt", [1, 2, 4, 8])
-def test_ctc_score_tokens_per_thread(backend, tpt):
-    """ctc_score_step with 1, 2 and 4 (float4 loads) vocabulary entries per thread (tuning knob 7); 8 = the matrix-core
-    formulation (ctc_score_mfma_kernel: beams x frames x tokens on v_mfma_f32_16x16x4_f32, no LDS)."""
-    nat, dev = backend
-    from speechbrain_amd.decoders import CTCScorer, S2STransformerBeamSearcher, ScorerBuilder
-
-    g, mods = build("tiny_ctc", dev)
-    beam, ctc_w = int(g["cfg"][6]), float(g["cfgf"][0])
-    scorer = ScorerBuilder(full_scorers=[CTCScorer(ctc_fc=mods["ctc_lin"], blank_index=0, eos_index=2)],
-                           weights={"ctc": ctc_w})
-    bs = S2STransformerBeamSearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2,
-                                    min_decode_ratio=0.0, max_decode_ratio=1.0, beam_size=beam,
-                                    using_eos_threshold=False, length_normalization=True, scorer=scorer)
-    nat.load().sbk_prof_set_knob(7, tpt)
-    try:
-        hyps, _, scores, _ = bs(torch.from_numpy(g["enc_out"]).to(dev), torch.from_numpy(g["wav_lens"]).to(dev))
-    finally:
-        nat.load().sbk_prof_set_knob(7, 1)
-    assert hyps == hyps_of(g["beam_hyps"])
-    assert float((scores.cpu() - torch.from_numpy(g["beam_scores"])).abs().max()) <= 1e-4
-    if tpt == 8:  # the f32 MFMA is an fmaf chain in frame order: the same roundings as the VALU kernel's frame loop
-        base = bs(torch.from_numpy(g["enc_out"]).to(dev), torch.from_numpy(g["wav_lens"]).to(dev))
-        assert base[0] == hyps and torch.equal(base[2], scores)
-
-
 def test_long_utterance_search_vs_oracle(backend):
     """A 44 s utterance (T' = 1100 encoder frames): CTC tables beyond the default 64 KiB LDS window,
     9 cross-attention splits -- beam search + CTC vs the oracle."""
