@@ -861,6 +861,12 @@ def main():
         native.prof_enable(False)
         rep = native.prof_report()
         native.prof_reset()
+        # one kernel, two profiler names: gemm_x3r_kernel with and without the LayerNorm in its prologue (csrc/gemm_x3r.hip)
+        if "gemm_ln_x3r" in rep:
+            fam = rep.setdefault("gemm_x3r", {"ms": 0.0, "count": 0, "flops": 0.0, "bytes": 0.0})
+            ln = rep.pop("gemm_ln_x3r")
+            for k in ("ms", "count", "flops", "bytes"):
+                fam[k] = fam[k] + ln[k]
         total_ms = sum(v["ms"] for v in rep.values()) or 1.0
         ranked = sorted(rep.items(), key=lambda kv: -kv[1]["ms"])
         roof = roofline_entry(ranked[0][0], ranked[0][1], total_ms)
@@ -869,7 +875,7 @@ def main():
         try:  # HBM bytes per launch from the PMC counters, collected in their own rocprofv3 --pmc passes (tools/run_pmc.sh)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             key = next((k for k in pmc if not k.startswith("_") and name.startswith(k)), None)
-            if key and pmc[key].get("round") == 4:  # (a row collected on an earlier round's kernel is not this kernel's traffic)
+            if key and pmc[key].get("round") == 5:  # (a row collected on an earlier round's kernel is not this kernel's traffic)
                 traffic = pmc[key]["bytes_per_launch"]
                 roof["traffic_note"] = f"{pmc[key]['note']}; algorithmic {pmc[key]['algorithmic_bytes_per_launch']} B/launch"
                 roof["traffic_provenance"] = {"source": "profiles/pmc_traffic.json: rocprofv3 --pmc passes of THIS round's kernel in their own runs "
@@ -877,7 +883,7 @@ def main():
                                               "commit": pmc[key].get("commit"), "shape": pmc[key].get("shape"),
                                               "collected": pmc[key].get("collected")}
             busy = {k: v["mfma_busy"] for k, v in pmc.get("_mfma_busy", {}).items()
-                    if not k.startswith("_") and k.startswith(name) and v.get("round") == 4}
+                    if not k.startswith("_") and k.startswith(name) and v.get("round") == 5}
             if busy:  # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x active cycles), from its own --pmc pass
                 roof["mfma_busy_pmc"] = busy
         except Exception:
