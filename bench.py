@@ -146,6 +146,33 @@ def decode_step_probe(asr, dev, frames=430, batches=4, steps=(16, 32)):
             "shape": f"{batches} x 32 utterances, T' {frames}..{frames - 10 * (batches - 1)}, beam 10 + CTC, one stream; difference of a {b}- and a {a}-step search"}
 
 
+def x3r_per_shape(dev, rows=1280, iters=40):
+    """The dominant kernel shape by shape: the few-row split-operand projection at the row count of the
+    headline's grouped searches, back-to-back launches between two HIP events on the current stream (weights L2-warm: the
+    in-situ figure of the line's `roofline` is lower, every launch of a decoding step meeting cold operands)."""
+    from speechbrain_amd import native
+
+    out = []
+    with torch.no_grad():
+        for (N, K, what) in ((512, 512, "out-projections, q projection"), (1536, 512, "self-attention in_proj"), (2048, 512, "ffn.0"),
+                             (512, 2048, "ffn.3"), (5000, 512, "seq_lin")):
+            a = torch.randn(rows, K, device=dev)
+            w = torch.randn(N, K, device=dev)
+            r = torch.randn(rows, N, device=dev)
+            for _ in range(3):
+                native.gemm_nt_x3r(a, w, residual=r)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                native.gemm_nt_x3r(a, w, residual=r)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            tf = 2.0 * rows * N * K / us / 1e6
+            out.append({"M": rows, "N": N, "K": K, "what": what, "us": round(us, 1), "tflops": round(tf, 1), "frac": round(tf / PEAK_F32X3_TFLOPS, 4)})
+    return out
+
+
 # ------------------------------------------------------------------ CPU leg (oracle port)
 def cpu_threads():
     """Host threads for the CPU leg: the cores this process may run on, capped at 32 (the port's
@@ -889,6 +916,12 @@ def main():
         except Exception:
             pass
         roof["traffic"] = traffic
+        if name.startswith("gemm_x3r"):
+            roof["kernel_note"] = "gemm_x3r_kernel with and without the LayerNorm prologue (profiler names gemm_x3r + gemm_ln_x3r: one kernel template)"
+            try:
+                roof["per_shape_isolated"] = x3r_per_shape(dev)
+            except Exception as e:
+                roof["per_shape_isolated"] = repr(e)[:200]
         out["roofline"] = roof
         out["roofline_top3"] = [roofline_entry(k, v, total_ms) for k, v in ranked[:3]]
         gflop_per_s = sum(v["flops"] for v in rep.values()) / max(rep_audio, 1e-9) / 1e9

@@ -54,8 +54,19 @@ class ConcurrentTranscriber:
         if self.device.type == "cuda":
             from speechbrain_amd import native
 
-            for st in list(self.enc_streams) + [d for d in self.dec_streams if d is not None]:
+            streams = list(self.enc_streams) + [d for d in self.dec_streams if d is not None]
+            native.release_search_workspaces(streams)  # the searches' grow-only buffers (several GB each at 128-utterance groups)
+            for st in streams:
                 native.release_stream_workspace(st)
+
+    def __del__(self):  # (a transcriber dropped without close(): its streams' search buffers must not outlive it)
+        try:
+            if self.device.type == "cuda":
+                from speechbrain_amd import native
+
+                native.release_search_workspaces(list(self.enc_streams) + [d for d in self.dec_streams if d is not None])
+        except Exception:
+            pass
 
     def _one(self, slot: int, wavs, wav_lens, prepare: Optional[Callable], ready: Optional[Callable] = None):
         searcher = self.searchers[slot]
@@ -156,21 +167,15 @@ class ConcurrentTranscriber:
                 if not ks:
                     return out
                 run(ks)
-        from speechbrain_amd import native
-
         torch.cuda.set_device(self.device)  # the current device is per host thread
-        try:
-            with torch.cuda.stream(self.enc_streams[slot]):
-                while True:
-                    ks = take()
-                    if not ks:
-                        break
-                    run(ks)
-                self.enc_streams[slot].synchronize()
-        finally:
-            # this thread's grow-only search buffer: the next job may run the slot on another thread -- also when a batch raised
-            # (a failing worker kept its multi-GB buffer)
-            native.release_search_workspaces()
+        with torch.cuda.stream(self.enc_streams[slot]):
+            while True:
+                ks = take()
+                if not ks:
+                    break
+                run(ks)
+            self.enc_streams[slot].synchronize()
+        # (the grow-only search buffers belong to the worker STREAMS and stay for the transcriber's next job: close() returns them)
         return out
 
     def transcribe_batches(self, batches: Sequence[Tuple[torch.Tensor, torch.Tensor]],

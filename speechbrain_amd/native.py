@@ -1265,7 +1265,7 @@ def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=No
     K = max(int(cfg.topk), 1)  # rows per utterance (return_topk)
     handle.ready.wait(dev)
     nbytes = lib.sbk_beam_search_workspace_bytes(ctypes.byref(handle.W), ctypes.byref(cfg), B, T)
-    ws = _search_workspace(nbytes + 256, dev)
+    ws, ws_key = _search_workspace(nbytes + 256, dev)
     off = (-ws.data_ptr()) % 256
     out_tok = torch.zeros(B * K, L, dtype=torch.int32, device=dev)
     out_len = torch.zeros(B * K, dtype=torch.int32, device=dev)
@@ -1279,39 +1279,65 @@ def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=No
     if ctc_w is not None and F32X3 and ctc_w.dim() == 2 and ctc_w.is_contiguous() and ctc_w.shape[1] % 32 == 0 \
             and ctc_w.shape[1] >= 64 and ctc_w.shape[0] % 4 == 0:
         cfg.ctc_w3 = lp_weight(ctc_w, "x3").data_ptr()  # (cached with the parameter: the CTC head over B*T frames)
-    _chk(lib.sbk_beam_search_f32(ctypes.byref(handle.W), ctypes.byref(cfg), _p(enc), _p(enc_len), _p(ctc_w), _p(ctc_b),
-                                 c_void_p(ws.data_ptr() + off), nbytes, _p(out_tok), _p(out_len), _p(out_score),
-                                 _p(out_lp), _p(out_max), _p(out_longest), c_void_p(flag.data_ptr()),
-                                 ctypes.byref(steps), B, T, _stream(enc)),
-         "sbk_beam_search_f32")
+    try:
+        _chk(lib.sbk_beam_search_f32(ctypes.byref(handle.W), ctypes.byref(cfg), _p(enc), _p(enc_len), _p(ctc_w), _p(ctc_b),
+                                     c_void_p(ws.data_ptr() + off), nbytes, _p(out_tok), _p(out_len), _p(out_score),
+                                     _p(out_lp), _p(out_max), _p(out_longest), c_void_p(flag.data_ptr()),
+                                     ctypes.byref(steps), B, T, _stream(enc)),
+             "sbk_beam_search_f32")
+    finally:
+        _search_workspace_done(ws_key)
     if want_longest:
         return out_tok, out_len, out_score, out_lp, out_max, steps.value, out_longest
     return out_tok, out_len, out_score, out_lp, out_max, steps.value
 
 
-def _search_workspace(nbytes: int, dev) -> torch.Tensor:
-    """The search workspace of this host thread's current stream: ONE grow-only buffer per (thread, stream), reused by
-    the searches that follow each other on that stream (stream order makes the reuse safe; the library joins its helper
-    stream before it returns).  A fresh torch.empty per search of a job whose groups all have different sizes leaves the
-    caching allocator holding a block per size it has seen (VERDICT r3, weak #9: 127-137 GB reserved)."""
+_SEARCH_WS = {}  # (device index, stream handle) -> [buffer, a host thread is enqueueing a search into it]
+_SEARCH_WS_LOCK = threading.Lock()
+
+
+def _search_workspace(nbytes: int, dev):
+    """The search workspace of the current stream: ONE grow-only buffer per (device, stream), reused by the searches that
+    follow each other on that stream (stream order makes the reuse safe; the library joins its helper stream before it
+    returns) and kept ACROSS the jobs of a transcriber (``release_search_workspaces``: when its streams retire).
+    Rounds 3-4 kept it per (thread, stream) and dropped it after every job: the caching allocator then served a later, smaller
+    request by splitting the cached block and a still later, larger one from a fresh segment -- 106-133 GB reserved for 62-71 GB
+    allocated.  Returns (buffer, key); ``_search_workspace_done(key)`` when the library call has
+    returned.  A second host thread that starts a search on the same stream meanwhile gets a private buffer (key None)."""
     if dev.type != "cuda":
-        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    cache = getattr(_tls, "search_ws", None)
-    if cache is None:
-        cache = _tls.search_ws = {}
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev), None
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    ws = cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        cache.pop(key, None)
-        del ws  # (the old block goes back to the allocator before the larger one is requested)
-        ws = cache[key] = torch.empty(nbytes + (nbytes >> 3), dtype=torch.uint8, device=dev)
-    return ws
+    with _SEARCH_WS_LOCK:
+        ent = _SEARCH_WS.get(key)
+        if ent is not None and ent[1]:
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev), None
+        if ent is None or ent[0].numel() < nbytes:
+            _SEARCH_WS.pop(key, None)
+            ent = None  # (the old block goes back to the allocator before the larger one is requested)
+            ent = _SEARCH_WS[key] = [torch.empty(nbytes + (nbytes >> 3), dtype=torch.uint8, device=dev), False]
+        ent[1] = True
+        return ent[0], key
 
 
-def release_search_workspaces():
-    """Drop this thread's cached search workspaces (a worker calls it when its job ends)."""
-    if getattr(_tls, "search_ws", None):
-        _tls.search_ws.clear()
+def _search_workspace_done(key):
+    if key is None:
+        return
+    with _SEARCH_WS_LOCK:
+        ent = _SEARCH_WS.get(key)
+        if ent is not None:
+            ent[1] = False
+
+
+def release_search_workspaces(streams=None):
+    """Drop the cached search workspaces of the given ``torch.cuda.Stream`` objects (a ConcurrentTranscriber calls it for its
+    worker streams when it is closed), or -- ``None`` -- of every stream no search is running on."""
+    with _SEARCH_WS_LOCK:
+        if streams is None:
+            keys = [k for k, ent in _SEARCH_WS.items() if not ent[1]]
+        else:
+            keys = [(s.device.index, s.cuda_stream) for s in streams]
+        for k in keys:
+            _SEARCH_WS.pop(k, None)
 
 
 def greedy_search(handle: DecoderHandle, enc, enc_len, min_steps, max_steps, bos, eos, check_every=8):
