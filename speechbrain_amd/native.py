@@ -1312,8 +1312,15 @@ def _search_workspace(nbytes: int, dev):
         if ent is not None and ent[1]:
             return torch.empty(nbytes, dtype=torch.uint8, device=dev), None
         if ent is None or ent[0].numel() < nbytes:
+            grown = ent is not None and ent[0].numel() >= (256 << 20)
             _SEARCH_WS.pop(key, None)
             ent = None  # (the old block goes back to the allocator before the larger one is requested)
+            if grown:
+                # a multi-GB block that has just been outgrown would sit in this stream's pool for good (no later request
+                # of the pool is that large, and another stream's pool cannot take it): hand the cached blocks back to
+                # the driver.  Rare -- a stream's buffer grows a few times in its life -- and visit I of round 5 counted
+                # 36 GB of such blocks (eight worker streams x one outgrown buffer) in the bench's 100 GB reserved
+                torch.cuda.empty_cache()
             ent = _SEARCH_WS[key] = [torch.empty(nbytes + (nbytes >> 3), dtype=torch.uint8, device=dev), False]
         ent[1] = True
         return ent[0], key
