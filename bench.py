@@ -622,10 +622,15 @@ def main():
             longest = sorted(range(n_utts), key=lambda i: -job[i].numel())
             warm = [job[i] for i in longest[: max(1, args.warmup) * UTTS_PER_STEP * world]]
         local = st.scatter(warm)
-        st.gather(st.run_local(local))
         if local:
+            # FIRST the largest batch as a full group on every worker: each worker stream sizes its search buffer once, at its
+            # maximum (a buffer that is outgrown later goes back to the driver together with every cached block -- native.
+            # _search_workspace -- which must not happen right in front of the timed region); then the warm job itself
             big = max(local, key=lambda t: t[1].numel())
+            if len(big) > 3 and big[3] is not None:
+                big[3]()  # (rank 0: stages the warm job on this thread; a peer: waits for its receive)
             workers.transcribe_batches([(big[1], big[2])] * (workers.n * workers.group), prepare=fixed_decode_length)
+        st.gather(st.run_local(local))
         note(f"batch {max_batch}: warm-up done; timed region")
         barrier()
         trace_mark()
