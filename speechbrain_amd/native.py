@@ -1292,6 +1292,7 @@ def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=No
     return out_tok, out_len, out_score, out_lp, out_max, steps.value
 
 
+WS_TRIM = os.environ.get("SBK_WS_TRIM", "1") != "0"  # (A/B switch of the trim below)
 _SEARCH_WS = {}  # (device index, stream handle) -> [buffer, a host thread is enqueueing a search into it]
 _SEARCH_WS_LOCK = threading.Lock()
 
@@ -1312,7 +1313,7 @@ def _search_workspace(nbytes: int, dev):
         if ent is not None and ent[1]:
             return torch.empty(nbytes, dtype=torch.uint8, device=dev), None
         if ent is None or ent[0].numel() < nbytes:
-            grown = ent is not None and ent[0].numel() >= (256 << 20)
+            grown = WS_TRIM and ent is not None and ent[0].numel() >= (256 << 20)
             _SEARCH_WS.pop(key, None)
             ent = None  # (the old block goes back to the allocator before the larger one is requested)
             if grown:
