@@ -1292,7 +1292,10 @@ def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=No
     return out_tok, out_len, out_score, out_lp, out_max, steps.value
 
 
-WS_TRIM = os.environ.get("SBK_WS_TRIM", "1") != "0"  # (A/B switch of the trim below)
+# SBK_WS_TRIM=1: an outgrown multi-GB search buffer is handed back to the driver (torch.cuda.empty_cache) instead of staying in
+# its stream's pool.  OFF by default: on one box (profiles/r05_i_*) it took the bench's reserved memory from 81.5 to 67 GB but
+# the headline from 11.7 K to 8.7-11.1 K audio-s/s -- the emptied pools are refilled by hipMalloc inside the next job.
+WS_TRIM = os.environ.get("SBK_WS_TRIM", "0") != "0"
 _SEARCH_WS = {}  # (device index, stream handle) -> [buffer, a host thread is enqueueing a search into it]
 _SEARCH_WS_LOCK = threading.Lock()
 
@@ -1317,10 +1320,8 @@ def _search_workspace(nbytes: int, dev):
             _SEARCH_WS.pop(key, None)
             ent = None  # (the old block goes back to the allocator before the larger one is requested)
             if grown:
-                # a multi-GB block that has just been outgrown would sit in this stream's pool for good (no later request
-                # of the pool is that large, and another stream's pool cannot take it): hand the cached blocks back to
-                # the driver.  Rare -- a stream's buffer grows a few times in its life -- and visit I of round 5 counted
-                # 36 GB of such blocks (eight worker streams x one outgrown buffer) in the bench's 100 GB reserved
+                # (opt-in, see WS_TRIM: a multi-GB block that has just been outgrown sits in this stream's pool for good -- no
+                #  later request of the pool is that large, and another stream's pool cannot take it)
                 torch.cuda.empty_cache()
             ent = _SEARCH_WS[key] = [torch.empty(nbytes + (nbytes >> 3), dtype=torch.uint8, device=dev), False]
         ent[1] = True
