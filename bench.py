@@ -476,7 +476,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip configs[1] (Conformer-S encoder) and the second run")
     ap.add_argument("--latency-runs", type=int, default=5)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--leg", default="", choices=["", "batch128", "bf16", "fp32mfma"], help=argparse.SUPPRESS)  # child process of a secondary leg
+    ap.add_argument("--leg", default="", choices=["", "batch128", "bf16", "fp32mfma", "latency"], help=argparse.SUPPRESS)  # child process of a secondary leg
     ap.add_argument("--leg-out", default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample", default="4x10s", choices=["4x10s", "2shortest"], help=argparse.SUPPRESS)
     ap.add_argument("--job-utts", type=int, default=0,
@@ -687,7 +687,76 @@ def main():
         # measured (tools/ab_cases.txt sweeps, profiles/r02_*): 8 workers; 4 recipe-sized batches per grouped search
         return args.streams or 8, args.group or max(1, 128 // max_batch)
 
+    def child_leg(name):
+        import gc
+        import subprocess
+        import tempfile
+
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()  # (the child needs the HBM the parent's pools still hold)
+        fd, path = tempfile.mkstemp(suffix=".json", prefix=f"sbk_leg_{name}_")
+        os.close(fd)
+        cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--leg-out", path, "--steps", str(args.steps), "--warmup",
+               str(args.warmup), "--max-batch", str(args.max_batch), "--second-batch", str(args.second_batch), "--attention",
+               args.attention, "--check-every", str(args.check_every), "--streams", str(args.streams), "--group", str(args.group),
+               "--graph-mode", str(args.graph_mode), "--overlap-ctc", str(args.overlap_ctc), "--latency-runs", str(args.latency_runs)]
+        cmd += [x for kv in args.knob for x in ("--knob", kv)]
+        cmd += (["--lm"] if args.lm else []) + (["--group-encoder"] if args.group_encoder else []) + (
+            ["--no-search-priority"] if args.no_search_priority else [])
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            if r.returncode != 0:
+                return {"error": f"rc {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"}
+            with open(path) as f:
+                return json.load(f)
+        except Exception as e:  # (a secondary leg must never cost the headline)
+            return {"error": repr(e)[:300]}
+        finally:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+
+    def latency_modes():
+        """p50 of a single 10-s utterance, pinned host waveform -> token ids on the host, for the ways to run a single search.
+        Round 5 (the default): the decoder stack of a step as ONE cooperative launch (csrc/decoder_persist.hip, knob 47), alone or
+        with the CTC scorer on a helper stream beside it; before: a launch per operation with the CTC scorer on a helper stream,
+        or replayed from a captured hipGraph."""
+        w1 = (0.1 * torch.randn(1, 160000, generator=torch.Generator().manual_seed(5))).pin_memory()
+        l1 = torch.ones(1)
+        by_mode = {}
+        lat_stream = torch.cuda.Stream(dev)  # (the legacy default stream cannot be captured into a graph)
+        dec = asr.mods.decoder
+        saved = (dec.overlap_ctc, dec.graph_mode)
+        lib = native.load()
+        for mode, (ov, gm, persist) in (("persistent_step", (0, 0, 1)), ("persistent_step_helper_stream", (3, 0, 1)),
+                                        ("helper_stream", (3, 0, 0)), ("hipgraph", (0, 1, 0))):
+            dec.overlap_ctc, dec.graph_mode = ov, gm
+            lib.sbk_prof_set_knob(47, persist)
+            lat = []
+            try:
+                with torch.cuda.stream(lat_stream):
+                    run_step(asr, w1, l1)
+                    run_step(asr, w1, l1)
+                    for _ in range(max(args.latency_runs, 1)):
+                        torch.cuda.synchronize()
+                        t = time.perf_counter()
+                        run_step(asr, w1, l1)
+                        torch.cuda.synchronize()
+                        lat.append(time.perf_counter() - t)
+            finally:
+                lib.sbk_prof_set_knob(47, 1)
+            lat.sort()
+            by_mode[mode] = round(1000.0 * lat[len(lat) // 2], 2)
+        dec.overlap_ctc, dec.graph_mode = saved
+        return by_mode
+
     if args.leg:  # ---- this process IS such a child: run the one leg, write its result, leave
+        if args.leg == "latency":
+            with open(args.leg_out, "w") as f:
+                json.dump({"leg": "latency", "by_mode": latency_modes()}, f)
+            return
         if args.leg == "batch128":
             dt2, hyps2, _, info2 = timed_run(args.second_batch, *auto(args.second_batch))
         elif args.leg == "bf16":
@@ -753,37 +822,6 @@ def main():
     # pools -- one per worker stream -- and the third leg measured 8.3 K where the same leg alone gives 11-12 K): the same
     # utterances as 128-utterance batches; the opt-in bf16 encoder GEMMs + token agreement with the fp32 run; every contraction
     # on the fp32 MFMA instruction (SBK_F32X3=0's path: the headline's large contractions run on the bf16 pipe)
-    def child_leg(name):
-        import gc
-        import subprocess
-        import tempfile
-
-        gc.collect()
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()  # (the child needs the HBM the parent's pools still hold)
-        fd, path = tempfile.mkstemp(suffix=".json", prefix=f"sbk_leg_{name}_")
-        os.close(fd)
-        cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--leg-out", path, "--steps", str(args.steps), "--warmup",
-               str(args.warmup), "--max-batch", str(args.max_batch), "--second-batch", str(args.second_batch), "--attention",
-               args.attention, "--check-every", str(args.check_every), "--streams", str(args.streams), "--group", str(args.group),
-               "--graph-mode", str(args.graph_mode), "--overlap-ctc", str(args.overlap_ctc)]
-        cmd += [x for kv in args.knob for x in ("--knob", kv)]
-        cmd += (["--lm"] if args.lm else []) + (["--group-encoder"] if args.group_encoder else []) + (
-            ["--no-search-priority"] if args.no_search_priority else [])
-        try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-            if r.returncode != 0:
-                return {"error": f"rc {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"}
-            with open(path) as f:
-                return json.load(f)
-        except Exception as e:  # (a secondary leg must never cost the headline)
-            return {"error": repr(e)[:300]}
-        finally:
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
-
     extras = world == 1 and not dist_on and not args.no_extras
     if extras:
         out["config"]["secondary_legs"] = "each in a process of its own (own allocator pools, worker streams and weight images)"
@@ -819,39 +857,21 @@ def main():
             out["config"]["fp32_mfma_leg_error"] = r4["error"]
         note(f"fp32-MFMA contractions: {r4.get('value')}")
 
-    # ---- p50 per-utterance latency (B = 1, 10 s; pinned host waveform -> token ids on the host), rank 0 only
+    # ---- p50 per-utterance latency (B = 1, 10 s; pinned host waveform -> token ids on the host), rank 0 only.  In a process of
+    # its own like the other secondary legs: measured inside this one -- 100 GB of cached blocks mapped, sixteen retired worker
+    # streams -- every mode read 3-4 ms more than in a fresh process (27.5 against 22.9 ms for the persistent step,
+    # profiles/r05_final_bench_first.json against profiles/r05_g_*.log)
     if rank == 0 and args.latency_runs > 0:
-        w1 = (0.1 * torch.randn(1, 160000, generator=torch.Generator().manual_seed(5))).pin_memory()
-        l1 = torch.ones(1)
-        by_mode = {}
-        lat_stream = torch.cuda.Stream(dev)  # (the legacy default stream cannot be captured into a graph)
-        dec = asr.mods.decoder
-        saved = (dec.overlap_ctc, dec.graph_mode)
-        # ways to run a single search.  Round 5 (the default): the decoder stack of a step as ONE cooperative launch
-        # (csrc/decoder_persist.hip, knob 47), alone or with the CTC scorer on a helper stream beside it; before: a launch
-        # per operation with the CTC scorer on a helper stream, or replayed from a captured hipGraph.  Report the best
-        from speechbrain_amd import native as _nat
-
-        lib = _nat.load()
-        for mode, (ov, gm, persist) in (("persistent_step", (0, 0, 1)), ("persistent_step_helper_stream", (3, 0, 1)),
-                                        ("helper_stream", (3, 0, 0)), ("hipgraph", (0, 1, 0))):
-            dec.overlap_ctc, dec.graph_mode = ov, gm
-            lib.sbk_prof_set_knob(47, persist)
-            lat = []
-            try:
-                with torch.cuda.stream(lat_stream):
-                    run_step(asr, w1, l1)
-                    for _ in range(args.latency_runs):
-                        torch.cuda.synchronize()
-                        t = time.perf_counter()
-                        run_step(asr, w1, l1)
-                        torch.cuda.synchronize()
-                        lat.append(time.perf_counter() - t)
-            finally:
-                lib.sbk_prof_set_knob(47, 1)
-            lat.sort()
-            by_mode[mode] = round(1000.0 * lat[len(lat) // 2], 2)
-        dec.overlap_ctc, dec.graph_mode = saved
+        by_mode = None
+        if world == 1 and not dist_on:
+            r5 = child_leg("latency")
+            by_mode = r5.get("by_mode")
+            if by_mode is None:
+                out["config"]["latency_leg_error"] = r5.get("error", "no result")
+            else:
+                out["config"]["latency_leg"] = "own process"
+        if by_mode is None:
+            by_mode = latency_modes()
         out["p50_latency_ms"] = min(by_mode.values())
         out["p50_latency_ms_by_mode"] = by_mode
         out["config"]["latency_case"] = "B=1, 10 s utterance, 40 decode steps"
