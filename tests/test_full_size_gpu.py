@@ -571,6 +571,65 @@ def test_whisper_large_v3_full_depth_reduced_precision_through_the_interface():
     assert torch.isfinite(out["fp8"]).all() and 0.0 < rel["bf16"] <= 1e-2 and 0.0 < rel["fp8"] <= 8e-2, rel
 
 
+@pytest.mark.timeout(300)
+def test_persistent_step_from_several_threads_at_once_conformer_l():
+    """The persistent few-row decoding step is a COOPERATIVE launch whose workgroups wait for each other at grid barriers:
+    four host threads, each on its own stream, run single-utterance searches (beam 10 + CTC, Conformer-L) at the same time while
+    a fifth keeps the chip busy with large contractions -- every result must equal the sequential one and nothing may hang
+    (tools/coop_concurrency_check.py is the same check as a script; profiles/r05_j_*: 4 and 8 threads, 0 differing results)."""
+    import threading
+
+    from speechbrain_amd import native
+
+    asr = _asr("L", beam_size=10, ctc_weight=0.4)
+    with torch.no_grad():
+        asr.mods.seq_lin.w.weight.mul_(8.0)
+        asr.mods.ctc_lin.w.weight.mul_(8.0)
+    dec = asr.mods.decoder
+    dec.max_decode_ratio = 0.1
+    g = torch.Generator().manual_seed(1)
+    encs = [(torch.randn(1, 120 + 17 * k, 512, generator=g).cuda(), torch.ones(1).cuda()) for k in range(4)]
+    native.prof_reset()
+    native.prof_enable(True)
+    with torch.no_grad():
+        ref = [dec(e, l)[0] for e, l in encs]
+    native.prof_enable(False)
+    assert "decoder_step_persist" in native.prof_report()
+    torch.cuda.synchronize()
+    stop, bad = threading.Event(), []
+
+    def load():
+        torch.cuda.set_device(0)
+        s = torch.cuda.Stream()
+        a, w = torch.randn(8192, 512, device="cuda"), torch.randn(2048, 512, device="cuda")
+        with torch.cuda.stream(s), torch.no_grad():
+            while not stop.is_set():
+                for _ in range(4):
+                    native.gemm_nt(a, w)
+                s.synchronize()
+
+    def worker(k):
+        torch.cuda.set_device(0)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s), torch.no_grad():
+            for r in range(6):
+                if dec(*encs[k])[0] != ref[k]:
+                    bad.append((k, r))
+            s.synchronize()
+
+    lt = threading.Thread(target=load)
+    lt.start()
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    stop.set()
+    lt.join()
+    torch.cuda.synchronize()
+    assert not bad, bad
+
+
 def test_in_kernel_handoffs_under_uneven_load_conformer_l():
     """Every in-launch hand-off of the path (stream-K partial tiles -> last-arriver fix-up in the persistent / split-operand
     contractions, split-K tickets of the decode GEMMs, the cross-attention runs' last-arriver merge) must give
