@@ -191,6 +191,132 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
   }
 }
 
+// The same step with the whole prefix requested at once (head_dim a multiple of 4, <= 64): a pass covers 4 NT positions -- NT
+// 16-byte loads per lane for the K rows and, in the first pass, NT more for the V rows, ALL issued before the first score is
+// formed (the kernel above asks for 16 positions, waits, asks for the next 16 ... and starts on V after the softmax: two
+// dependent round trips per 16 positions of prefix, ~8 at 60 tokens).  Loads are unconditional on clamped positions (a load
+// under a lane mask is a branch and a full wait each); surplus positions carry weight 0.  Same summation order as the kernel
+// above: bit-identical results.
+template <int NT>
+__global__ void __launch_bounds__(256) self_attn_wide_kernel(SelfAttnArgs a) {
+  SBK_DYN_LDS(float, lds);  // [4 waves][2][Lmax_pad]: probabilities, slots
+  if (a.step_ptr) a.step = a.step_ptr[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = blockIdx.x * 4 + wave;
+  const bool live = item < a.n * a.H;
+  int i = live ? item / a.H : 0, h = live ? item % a.H : 0;
+  if (live && a.group > 1) {  // item = ((utterance * H + head) * group + beam)
+    const int per = a.H * a.group, u = item / per, rem = item % per;
+    h = rem / a.group;
+    i = u * a.group + rem % a.group;
+  }
+  const int d = a.d, Dh = a.Dh, L = a.step + 1;
+  const int lpad = ((a.Lmax + 63) / 64) * 64;
+  float* prob = lds + wave * 2 * lpad;
+  int* slot = reinterpret_cast<int*>(prob + lpad);
+  const float* q = a.qkv + (size_t)i * 3 * d + h * Dh;
+  const float* knew = q + d;
+  const float* vnew = q + 2 * d;
+  const int pg = lane >> 4, cq = lane & 15;  // position group, 16-byte piece of the head row
+  const bool piece = cq * 4 < Dh;
+  const int co = piece ? cq * 4 : 0;
+  if (live) {  // append this token's K/V head slice to the cache (slot = hypothesis index)
+    for (int c = lane; c < Dh; c += 64) {
+      const size_t o = ((size_t)i * a.Lmax + a.step) * d + h * Dh + c;
+      a.kcache[o] = knew[c];
+      a.vcache[o] = vnew[c];
+    }
+  }
+  for (int p = lane; p < a.step; p += 64) slot[p] = a.kv_slot[(size_t)i * a.Lmax + p];
+  sbk::wave_sync();
+  // the rows of a pass: the ancestry slots of its 4 NT (clamped) positions are read from LDS FIRST, all together, and held by
+  // an empty asm anchor -- otherwise the select between the new token's row and the cache row becomes a branch around each slot
+  // read, one LDS round trip in front of every load
+  const int ps_max = max(a.step - 1, 0);
+  const size_t head_off = (size_t)h * Dh;
+  auto rows = [&](float4(&dst)[NT], int pb, const float* cache, const float* fresh) SBK_INLINE_LAMBDA {
+    unsigned sl[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sl[t] = (unsigned)slot[min(min(pb + 4 * t + pg, L - 1), ps_max)];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sbk::pin(sl[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int p = min(pb + 4 * t + pg, L - 1);
+      const float* c = cache + ((size_t)sl[t] * a.Lmax + p) * d + head_off;
+      dst[t] = *reinterpret_cast<const float4*>((p == a.step ? fresh : c) + co);
+    }
+  };
+  float4 q4 = *reinterpret_cast<const float4*>(q + co);
+  const float qs = piece ? a.scale : 0.0f;
+  q4.x *= qs; q4.y *= qs; q4.z *= qs; q4.w *= qs;
+  float4 kv[NT], vpre[NT];
+  auto scores = [&](int pb) SBK_INLINE_LAMBDA {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float s = (q4.x * kv[t].x + q4.y * kv[t].y) + (q4.z * kv[t].z + q4.w * kv[t].w);
+      s += sbk::shfl_xor(s, 1);
+      s += sbk::shfl_xor(s, 2);
+      s += sbk::shfl_xor(s, 4);
+      s += sbk::shfl_xor(s, 8);
+      const int p = pb + 4 * t + pg;
+      if (p < L && cq == 0) {
+        if (a.key_tok) {
+          const int tk = p < a.key_shift ? a.key_first : a.key_tok[(size_t)i * a.key_stride + p - a.key_shift];
+          if (tk == a.pad_idx) s = -INFINITY;
+        }
+        prob[p] = s;
+      }
+    }
+  };
+  // first pass: K and V rows of positions 0 .. 4 NT - 1 in flight together
+  rows(kv, 0, a.kcache, knew);
+  rows(vpre, 0, a.vcache, vnew);
+  scores(0);
+  for (int pb = 4 * NT; pb < L; pb += 4 * NT) {
+    rows(kv, pb, a.kcache, knew);
+    scores(pb);
+  }
+  sbk::wave_sync();
+  float m = -INFINITY;
+  for (int p = lane; p < L; p += 64) m = fmaxf(m, prob[p]);
+  m = sbk::wave_max(m);
+  float sum = 0.0f;
+  for (int p = lane; p < L; p += 64) {
+    const float e = expf(prob[p] - m);
+    prob[p] = e;
+    sum += e;
+  }
+  sum = sbk::wave_sum(sum);
+  for (int p = lane; p < L; p += 64) prob[p] = prob[p] / sum;
+  sbk::wave_sync();
+  // context: each position group accumulates its positions (ascending), then the 4 groups are summed
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto context = [&](const float4(&vv)[NT], int pb) SBK_INLINE_LAMBDA {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int p = pb + 4 * t + pg;
+      const float w = (p < L && piece) ? prob[p] : 0.0f;
+      acc.x = fmaf(w, vv[t].x, acc.x);
+      acc.y = fmaf(w, vv[t].y, acc.y);
+      acc.z = fmaf(w, vv[t].z, acc.z);
+      acc.w = fmaf(w, vv[t].w, acc.w);
+    }
+  };
+  context(vpre, 0);
+  for (int pb = 4 * NT; pb < L; pb += 4 * NT) {
+    rows(kv, pb, a.vcache, vnew);
+    context(kv, pb);
+  }
+  float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] += sbk::shfl_xor(o[e], 16);
+    o[e] += sbk::shfl_xor(o[e], 32);
+  }
+  if (live && pg == 0 && piece) *reinterpret_cast<float4*>(a.out + (size_t)i * d + head_off + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // ---------------------------------------------------------------- cross attention, all beams of an utterance
 constexpr int kQT = 16;   // queries (beams) served per workgroup
 constexpr int kFC = 128;  // memory frames per workgroup (flash-decoding style split of the memory)
@@ -325,55 +451,67 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
   }
 }
 
-// ---- cross-attention step on LDS-DMA tiles and the matrix cores (head_dim 64, d <= 640, beam <= 16, row-major K/V).
-// A workgroup = one utterance x one run of frames, ALL heads (wave w = head w): the K|V rows of 16 frames (16 x 8d
-// bytes, contiguous in HBM: one fully sequential stream per workgroup instead of 256-byte pieces 8d bytes apart) go
-// straight into a double-buffered LDS image by global_load_lds_dwordx4 while the previous tile is consumed -- no
-// staging registers, 16 x 8d bytes in flight per CU at all times.  Per tile and head, transposed scores
-// S^T[frame][beam] = K Q^T on v_mfma_f32_16x16x4_f32 (beams padded to 16): in the result layout a lane owns one beam
-// and four frames, so the online-softmax statistics need two cross-lane steps, the probabilities ARE the B operand of
-// O^T[channel][beam] += V^T P^T (k slot g of MFMA i <-> frame 4g+i, V^T read in that order), and the running rescale
-// is one scalar per lane.  LDS image: the 16-byte slot s of frame row R lands in slot s ^ R ^ ((R & 4) << 1) within
-// its 256-byte head segment (swizzle on the global SOURCE address, the image of an LDS-DMA being lane-linear): the
-// ds_read_b128 of the K operand and the ds_read_b32 of the V operand are both conflict-free (checked exhaustively,
-// DESIGN.md).  Partial (context, max, sum) per run of frames -> cross_merge_kernel, as for the other variants.
-// FR = frames per LDS tile: 16, or 8 (half of the MFMA rows idle, half the LDS: two workgroups per CU whose load
-// and compute phases interleave).
-template <int FR>
-__global__ void __launch_bounds__(1024) cross_attn_dma_kernel(CrossAttnArgs a, int chunk) {
-  SBK_DYN_LDS(float, lds);  // [2 stages][FR frames][2d]
-  const int ROW = 2 * a.d, TILE = FR * ROW, H = a.H;
-  const int tid = threadIdx.x, lane = tid & 63, h = sbk::uniform(tid >> 6);  // wave = head
-  const int split = blockIdx.x, b = blockIdx.y;
-  const int nq = a.beam, col = lane & 15, g = lane >> 4;
+// ---- cross-attention step on a REGISTER ring and the matrix cores (head_dim 64, beam <= 16, row-major K/V): a WAVE = one
+// (utterance, head) x one run of frames -- no LDS, no barrier, nothing shared between the waves of a workgroup.  Each wave streams
+// its own 256-byte head segments of the K|V rows straight into MFMA operand registers, D tiles of 16 frames deep (D x 8 KB per
+// wave, 4 waves per CU), transposed scores and context on v_mfma_f32_16x16x4_f32 (beams padded to 16), online softmax:
+//   scores  S^T[frame][beam] = K Q^T:  A[m = frame][k slot g] of MFMA (jq, e) = K[frame][16 jq + 4 g + e] -- the lane's float4
+//           load jq covers 64 contiguous bytes of each of the tile's 16 rows across g; in the result a lane owns one beam and the
+//           four frames 4 g .. 4 g + 3, so the softmax statistics need two cross-lane steps and the rescale is one scalar per lane;
+//   context O^T[channel][beam] += V^T P^T:  k slot g of MFMA (ct, i) <-> frame 4 g + i (the frames whose probabilities the lane
+//           holds: P IS the B operand), A[m][g] = V[frame 4g + i][4 m + ct] -- the lane's float4 load i covers the 256 contiguous
+//           bytes of four rows; result row m of block ct is channel 4 m + ct, so a lane ends with the 16 CONSECUTIVE channels
+//           16 g .. 16 g + 15 of its beam (four float4 stores).
+// Frames past the run re-read the utterance's last row and are masked to -inf before the softmax (probability exactly 0).
+// History: round 3's LDS-DMA kernel (a workgroup = one utterance, wave = head, a double-buffered 16-frame
+// K|V image in LDS) kept ONE 64 KB tile in flight per CU behind a workgroup barrier -- two fp32 tiles are all that fit in 160 KB --
+// and its tile period was the latency of one burst (3.4 us: 92 us per launch at 128 utterances x 430 frames, 2.4 TB/s); the ring
+// has 2 x 8 KB x 4 waves in flight per CU with no barrier: 46 us, 4.8 TB/s (profiles/r05_m_*, r05_n_*).  Partial (context, max,
+// sum) per run of frames -> cross_merge_kernel when an utterance is split into runs.
+template <int D>
+__global__ void __launch_bounds__(256) cross_attn_ring_kernel(CrossAttnArgs a, int chunk) {
+  const int lane = threadIdx.x & 63, wave = sbk::uniform(threadIdx.x >> 6);
+  const int split = blockIdx.x, gw = sbk::uniform(blockIdx.y * 4 + wave);
+  if (gw >= a.B * a.H) return;  // (no barrier anywhere below)
+  const int b = gw / a.H, h = gw - b * a.H;
+  const int ROW = 2 * a.d, nq = a.beam, col = lane & 15, g = lane >> 4;
   const int klen = min(max(a.enc_len[b], 1), a.T);
   const int t0 = split * chunk, t1 = min(klen, t0 + chunk);
-  float* pp = a.part ? a.part + ((((size_t)b * H + h) * a.NS + split) * nq + col) * (64 + 2) : nullptr;
-  if (t0 >= t1) {  // (uniform per workgroup) nothing of this run is inside the utterance: an empty partial
+  float* pp = a.part ? a.part + ((((size_t)b * a.H + h) * a.NS + split) * nq + col) * (64 + 2) : nullptr;
+  if (t0 >= t1) {
     if (a.NS > 1 && g == 0 && col < nq) {
       pp[64] = -INFINITY;
       pp[65] = 0.0f;
     }
     return;
   }
-  const float* kvb = a.kv + (size_t)b * a.T * ROW;
   float qf[16];
+  {  // unconditional loads of a clamped row (a load under a lane mask is a branch + a full wait each: 16 round trips in a row)
+    const float* qp = a.q + ((size_t)b * nq + min(col, nq - 1)) * a.d + h * 64 + 4 * g;
+    const float qs = col < nq ? a.scale : 0.0f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
-    qf[i] = col < nq ? a.q[((size_t)b * nq + col) * a.d + h * 64 + 16 * g + i] * a.scale : 0.0f;
-
-  // loader: the H waves share the 16 frame rows of a tile; one wave-instruction moves 1 KB = 4 head segments of a row
-  const int per_row = ROW / 256;             // wave-instructions per frame row
-  const int pieces = FR * per_row;           // per tile
-  const int seg = lane >> 4, slot = lane & 15;
-  auto issue = [&](int tile, int stage) SBK_INLINE_LAMBDA {
-    for (int pc = h; pc < pieces; pc += H) {
-      const int R = pc / per_row, qd = pc - R * per_row;
-      const int frame = min(t0 + tile * FR + R, klen - 1);  // rows past the run re-read a valid row (masked below)
-      const int fsw = R ^ ((R & 4) << 1);
-      sbk::glds16(kvb + (size_t)frame * ROW + (qd * 4 + seg) * 64 + ((slot ^ fsw) & 15) * 4,
-                  lds + stage * TILE + R * ROW + qd * 256);
+    for (int jq = 0; jq < 4; ++jq) {
+      const float4 t = *reinterpret_cast<const float4*>(qp + 16 * jq);
+      qf[4 * jq] = t.x * qs;
+      qf[4 * jq + 1] = t.y * qs;
+      qf[4 * jq + 2] = t.z * qs;
+      qf[4 * jq + 3] = t.w * qs;
     }
+  }
+  const float* kb = a.kv + (size_t)b * a.T * ROW + h * 64 + 4 * g;  // + row * ROW + 16 jq
+  const float* vb = a.kv + (size_t)b * a.T * ROW + a.d + h * 64 + 4 * col;  // + row * ROW
+  const int ntiles = (t1 - t0 + 15) / 16;
+  float4 kr[D][4], vr[D][4];
+  auto fetch = [&](float4(&kk)[4], float4(&vv)[4], int tile) SBK_INLINE_LAMBDA {
+    // unconditional (tiles past the run fetch the utterance's last row again: cache hits) -- straight-line code between the
+    // fetch of tile k + D - 1 and the use of tile k is what lets the compiler count the loads in between (s_waitcnt vmcnt(8 (D - 1)
+    // + ...)); behind a branch it falls back to waiting for everything in flight
+    const float* kp = kb + (size_t)min(t0 + tile * 16 + col, klen - 1) * ROW;
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) kk[jq] = *reinterpret_cast<const float4*>(kp + 16 * jq);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      vv[i] = *reinterpret_cast<const float4*>(vb + (size_t)min(t0 + tile * 16 + 4 * g + i, klen - 1) * ROW);
   };
   sbk::f32x4 o[4];
 #pragma unroll
@@ -381,41 +519,27 @@ __global__ void __launch_bounds__(1024) cross_attn_dma_kernel(CrossAttnArgs a, i
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[ct][r] = 0.0f;
   float m_run = -INFINITY, l_run = 0.0f;
-  const int ntiles = (t1 - t0 + FR - 1) / FR;
-  const int krow = col & (FR - 1);  // (FR = 8: MFMA rows 8-15 repeat rows 0-7 and are masked out of the softmax)
-  const int ksw = krow ^ ((krow & 4) << 1);  // swizzle of this lane's K row
-  issue(0, 0);
-  sbk::vm_drain();
-  __syncthreads();
-  int stage = 0;
-  for (int k = 0; k < ntiles; ++k) {
-    if (k + 1 < ntiles) issue(k + 1, stage ^ 1);
-    const float* Kt = lds + stage * TILE + h * 64;
-    const float* Vt = Kt + a.d;
-    float4 kq[4];
-#pragma unroll
-    for (int jq = 0; jq < 4; ++jq) kq[jq] = *reinterpret_cast<const float4*>(Kt + krow * ROW + (((4 * g + jq) ^ ksw) & 15) * 4);
+  auto consume = [&](const float4(&kk)[4], const float4(&vv)[4], int tile) SBK_INLINE_LAMBDA {
     sbk::f32x4 sc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) sc[r] = 0.0f;
 #pragma unroll
     for (int jq = 0; jq < 4; ++jq) {
-      sc = sbk::mfma_16x16x4(kq[jq].x, qf[4 * jq], sc);
-      sc = sbk::mfma_16x16x4(kq[jq].y, qf[4 * jq + 1], sc);
-      sc = sbk::mfma_16x16x4(kq[jq].z, qf[4 * jq + 2], sc);
-      sc = sbk::mfma_16x16x4(kq[jq].w, qf[4 * jq + 3], sc);
+      sc = sbk::mfma_16x16x4(kk[jq].x, qf[4 * jq], sc);
+      sc = sbk::mfma_16x16x4(kk[jq].y, qf[4 * jq + 1], sc);
+      sc = sbk::mfma_16x16x4(kk[jq].z, qf[4 * jq + 2], sc);
+      sc = sbk::mfma_16x16x4(kk[jq].w, qf[4 * jq + 3], sc);
     }
-    // sc[r] = score of (frame t0 + FR k + 4g + r, beam col)
-    const int fb = t0 + k * FR + 4 * g;
+    const int fb = t0 + tile * 16 + 4 * g;  // sc[r] = score of (frame fb + r, beam col)
     float mt = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (fb + r >= t1 || 4 * g + r >= FR) sc[r] = -INFINITY;
+      if (fb + r >= t1) sc[r] = -INFINITY;
       mt = fmaxf(mt, sc[r]);
     }
     mt = fmaxf(mt, sbk::shfl_xor(mt, 16));
     mt = fmaxf(mt, sbk::shfl_xor(mt, 32));
-    const float m_new = fmaxf(m_run, mt);  // finite: frame t0 + 16k is inside the run
+    const float m_new = fmaxf(m_run, mt);  // finite: the tile's first frame is inside the run
     const float alpha = expf(m_run - m_new);
     float p[4], ps = 0.0f;
 #pragma unroll
@@ -429,35 +553,43 @@ __global__ void __launch_bounds__(1024) cross_attn_dma_kernel(CrossAttnArgs a, i
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[ct][r] *= alpha;
-    // O^T[channel 16ct + 4g' + r][beam] += V^T P^T: k slot g of MFMA i <-> frame row 4g + i
-    const int vsw = (g & 1) << 3;  // (R & 4) << 1 of R = 4g + i (mod FR); the R part of the swizzle is XORed below
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int i = 0; i < 4; ++i) {
+      o[0] = sbk::mfma_16x16x4(vv[i].x, p[i], o[0]);
+      o[1] = sbk::mfma_16x16x4(vv[i].y, p[i], o[1]);
+      o[2] = sbk::mfma_16x16x4(vv[i].z, p[i], o[2]);
+      o[3] = sbk::mfma_16x16x4(vv[i].w, p[i], o[3]);
+    }
+  };
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int R = (4 * g + i) & (FR - 1);
-        const float va = Vt[R * ROW + ((((4 * ct + (col >> 2)) ^ R ^ vsw) & 15) << 2) + (col & 3)];
-        o[ct] = sbk::mfma_16x16x4(va, p[i], o[ct]);
-      }
-    sbk::vm_drain();   // this wave's pieces of the next tile have landed ...
-    __syncthreads();   // ... and everybody's; every wave is done with `stage`
-    stage ^= 1;
+  for (int s = 0; s < D - 1; ++s) fetch(kr[s], vr[s], s);
+  int k0 = 0;
+  for (; k0 + D <= ntiles; k0 += D) {  // whole rounds of the ring: straight-line code
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      fetch(kr[(s + D - 1) % D], vr[(s + D - 1) % D], k0 + s + D - 1);
+      sbk::sched_fence();
+      consume(kr[s], vr[s], k0 + s);
+      sbk::sched_fence();
+    }
   }
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s)  // the last < D tiles are in flight already (slots 0 ..)
+    if (k0 + s < ntiles) consume(kr[s], vr[s], k0 + s);
   float l_tot = l_run + sbk::shfl_xor(l_run, 16);
   l_tot += sbk::shfl_xor(l_tot, 32);
   if (col < nq) {
     if (a.NS == 1) {
-      float* op = a.out + ((size_t)b * nq + col) * a.d + h * 64;
+      float* op = a.out + ((size_t)b * nq + col) * a.d + h * 64 + 16 * g;
       const float inv = 1.0f / l_tot;
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) op[16 * ct + 4 * g + r] = o[ct][r] * inv;
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float4*>(op + 4 * r) = make_float4(o[0][r] * inv, o[1][r] * inv, o[2][r] * inv, o[3][r] * inv);
     } else {
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pp[16 * ct + 4 * g + r] = o[ct][r];
+        for (int r = 0; r < 4; ++r) pp[16 * g + 4 * r + ct] = o[ct][r];
       if (g == 0) {
         pp[64] = m_run;
         pp[65] = l_tot;
@@ -505,37 +637,23 @@ int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
   const int qtiles = (a.beam + kQT - 1) / kQT;
   sbk::ProfScope prof("cross_attn_step", 4.0 * a.B * a.beam * (double)a.T * a.d, 8.0 * a.B * (double)a.T * a.d, st);
   if constexpr (DH == 64) {
-    // LDS-DMA tiles + matrix cores (all heads of an utterance per workgroup, sequential HBM stream).
-    // Measured (tools/decode_probe.py, profiles/r03_cross_attention_dma_sweep.log): with four recipe-sized batches per
-    // search (128 utterances x 430 frames) it runs the step in 64 us against 92 for the frame-per-thread kernel (3.5 vs
-    // 2.45 TB/s incl. the merge); for a single 32-utterance batch the frame-per-thread kernel wins (38 vs 52 us): the
-    // default (knob 4 = 7) takes the LDS-DMA kernel from ~40 K memory frames per search on; 5 = always; 0 = never.
-    // (Measured and removed in round 5: 8-frame tiles, the row-coalesced / fp32-MFMA / wave-streaming kernels -- knob 4 =
-    //  1 .. 4, 6: all within +-5 % of the frame-per-thread kernel or slower, DESIGN.md section 5 -- and the merge by the
-    //  last-arriving run, knob 37: slower, profiles/r03_last_arriver_reductions_ab.log.)
-    const bool dma_auto = sbk::g_cross_rows == 7 && (long)a.B * a.T >= 40000;
-    if ((sbk::g_cross_rows == 5 || dma_auto) && a.d <= 640 && a.H * 64 == a.d && a.beam <= 16 && sbk::aligned16(a.kv) &&
-        (a.part || a.T <= 16)) {
+    // The register-ring / MFMA kernel from 128 (utterance, head) pairs on (knob 4 = 7, default; 5 = always, 0 = never): measured
+    // per launch at T' 430, d 512, beam 10 (tools/decode_probe.py, profiles/r05_o_*): 16 utterances 25.1 us against 30.0 for the
+    // frame-per-thread kernel, 32: 28.6 / 38.1, 64: 35.4 / 55.9, 128: 46.5 / (LDS-DMA kernel) 92.7, 256: 81.0 / 95.9; at 2 and 8
+    // utterances the frame-per-thread kernel wins (25.3 / 45.5, 26.9 / 25.6-31.5: an utterance would be cut into 16-frame runs).
+    // Runs per utterance: ~1 024 waves (one 4-wave workgroup per CU) but runs of >= 100 frames -- every further run is a partial
+    // to write and merge (128 utterances: 46.5 us as one run, 65.2 as two); knob 8 = 3 forces ONE run.
+    // (Measured and removed: the LDS-DMA kernel with 16- / 8-frame tiles, the row-coalesced / fp32-MFMA / VALU wave-streaming
+    //  kernels, the merge by the last-arriving run: DESIGN.md section 5.)
+    const int uh = a.B * a.H;
+    if ((sbk::g_cross_rows == 5 || (sbk::g_cross_rows == 7 && uh >= 128)) && a.beam <= 16 && a.H * 64 == a.d &&
+        sbk::aligned16(a.kv) && sbk::aligned16(a.q) && sbk::aligned16(a.out) && (a.part || a.T <= 16)) {
       CrossAttnArgs c = a;
-      // ONE run per utterance from ~100 utterances per search on (round 5 default; knob 8 = 3 forces it, 4 = round 4's 256
-      // workgroups): no partials, no merge launch, B workgroups walk their whole memory.  On one stream it is slower (2.20 vs
-      // 2.03 ms per step: half of the CUs idle), under the eight workers it is +1.8 % on the headline in three paired runs
-      // (11 925 / 11 870 / 11 901 against 11 725 / 11 648 / 11 681, profiles/r05_b_*): the co-resident streams use the other CUs
-      // and six merge launches per step are gone.
-      const bool one_run = sbk::g_cross_fc256 == 3 || (dma_auto && a.B >= 96 && sbk::g_cross_fc256 != 4);
-      const int target = one_run ? a.B : dma_auto ? 256 : 512;
-      int ns = sbk::cdiv(target, a.B);                          // workgroups over the batch ...
-      if (ns > sbk::cdiv(a.T, 16)) ns = sbk::cdiv(a.T, 16);    // ... of at least one 16-frame tile (the partial buffer's size)
-      if (ns < 1) ns = 1;
+      int ns = sbk::g_cross_fc256 == 3 ? 1 : std::min(sbk::cdiv(1024, uh), std::max(1, a.T / 100));
+      if (ns > sbk::cdiv(a.T, 16)) ns = sbk::cdiv(a.T, 16);  // (the partial buffer is sized for 16-frame runs)
       const int chunk = sbk::cdiv(sbk::cdiv(a.T, ns), 16) * 16;
       c.NS = sbk::cdiv(a.T, chunk);
-      const size_t lds = (size_t)2 * 16 * 2 * a.d * sizeof(float);
-      static bool once = false;
-      if (!once) {
-        (void)SBK_ALLOW_DYN_LDS(cross_attn_dma_kernel<16>, 160 * 1024);
-        once = true;
-      }
-      SBK_LAUNCH(cross_attn_dma_kernel<16>, dim3(c.NS, a.B), dim3(64 * a.H), lds, st, c, chunk);
+      SBK_LAUNCH(cross_attn_ring_kernel<3>, dim3(c.NS, sbk::cdiv(uh, 4)), dim3(256), 0, st, c, chunk);
       int rc5 = sbk::launch_status("cross_attn_step");
       if (rc5 || c.NS == 1) return rc5;
       SBK_LAUNCH(cross_merge_kernel, dim3(a.B * a.beam), dim3(256), 0, st, (const float*)c.part, c.out, c.H, c.NS,
@@ -634,8 +752,8 @@ thread_local int g_step_min_steps = 0;
 // Measured alternatives kept behind sbk_prof_set_knob (Conformer-L, B=64, MI355X; cross_attn_step total per
 // 8 batches): frame-per-thread kernel 247 ms with either layout; row-coalesced kernel 336 ms on [B,T,2d],
 // 306 ms on head-major [B,H,T,2*Dh]; at B=128 the MFMA formulation takes 315 ms vs 303 ms.  The defaults stay 0.
-int g_cross_rows = 7;     // key 4: 7 (default) = LDS-DMA / MFMA kernel for large grouped searches, else frame-per-thread;
-                          // 0 = the frame-per-thread kernel always, 5 = the LDS-DMA kernel always
+int g_cross_rows = 7;     // key 4: 7 (default) = the register-ring / MFMA kernel from 128 (utterance, head) pairs on, else frame-per-thread;
+                          // 0 = the frame-per-thread kernel always, 5 = the ring kernel always
 
 int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* x, int n, int d, float scale,
               hipStream_t st) {
@@ -646,6 +764,7 @@ int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* 
   return launch_status("embed_pos");
 }
 
+int g_self_wide = 0;  // key 50
 int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t* kv_slot, float* out, int n, int d,
                    int H, int step, int nslot, int Lmax, hipStream_t st, const int32_t* key_tok, int key_stride,
                    int key_shift, int key_first, int pad_idx, int group) {
@@ -656,13 +775,23 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
   const size_t lds = (size_t)8 * (((Lmax + 63) / 64) * 64) * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "self_attn_step: Lmax=%d too long for the LDS window", Lmax);
   ProfScope prof("self_attn_step", 4.0 * n * d * (step + 1), 8.0 * n * d * (step + 1), st);
-  SBK_LAUNCH(self_attn_step_kernel, dim3(cdiv(n * H, 4)), dim3(256), lds, st, a);
+  // key 50: 0 = 16 positions per pass (the general kernel), 8 / 16 = the whole-prefix kernel with 32 / 64 positions per pass
+  const bool wide_ok = (a.Dh % 4) == 0 && a.Dh <= 64 && d % 4 == 0 && aligned16(qkv) && aligned16(kcache) && aligned16(vcache) && aligned16(out);
+  if (g_self_wide == 16 && wide_ok) {
+    SBK_LAUNCH(self_attn_wide_kernel<16>, dim3(cdiv(n * H, 4)), dim3(256), lds, st, a);
+  } else if (g_self_wide == 8 && wide_ok) {
+    SBK_LAUNCH(self_attn_wide_kernel<8>, dim3(cdiv(n * H, 4)), dim3(256), lds, st, a);
+  } else if (g_self_wide == 4 && wide_ok) {
+    SBK_LAUNCH(self_attn_wide_kernel<4>, dim3(cdiv(n * H, 4)), dim3(256), lds, st, a);
+  } else {
+    SBK_LAUNCH(self_attn_step_kernel, dim3(cdiv(n * H, 4)), dim3(256), lds, st, a);
+  }
   return launch_status("self_attn_step");
 }
 
 // Number of memory splits used for T frames and floats of partial storage they need.
-int g_cross_fc256 = 0;  // tuning knob (key 8): frame-per-thread kernel: 1 = 256, 2 = 64 memory frames per workgroup (0 = 128); LDS-DMA kernel: 3 = one run
-                        // per utterance always, 4 = never (0 = from ~100 utterances per search on)
+int g_cross_fc256 = 0;  // tuning knob (key 8): frame-per-thread kernel: 1 = 256, 2 = 64 memory frames per workgroup (0 = 128); ring kernel: 3 = one run
+                        // per utterance always
 int cross_attn_splits(int T) { return cdiv(T, 16); }  // sizes the partial buffer for the finest split (16-frame runs)
 size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam) {
   const int ns = cross_attn_splits(T);

@@ -41,6 +41,7 @@ struct X3rArgs {
   int lda, ldr, ldc, M, N, K, act, tiles_m, tiles_n;
   float alpha;
   float ln_eps;      // LNQ > 0: A is the residual stream, the operand is its LayerNorm (affine folded into PW / bias)
+  int early;         // key 46: bias / residual loads in front of the exchange of the partial tiles
 };
 
 // NS > 0: the wave's NS steps fully unrolled (K = 64 NS; measured faster for K = 512 with N >= 1 024: 18.6 / 25.3 / 51.5 us
@@ -192,6 +193,22 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
       }
     }
   }
+  // lane = row (sub_m * 32 + r), register quad q4 = columns sub_n * 32 + 8 q4 + 4 half .. +3
+  const int row = (mt * 2 + (wave >> 1)) * 32 + r, col0 = (nt * 2 + (wave & 1)) * 32 + 4 * half;
+  const bool row_ok = row < g.M;
+  const float* rrow = g.R ? g.R + (size_t)(row_ok ? row : 0) * g.ldr : nullptr;
+  float4 bv[4], rv[4];
+  bool ok[4];
+  auto side_loads = [&]() SBK_INLINE_LAMBDA {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {  // (N % 4 == 0: a vector is inside the matrix or outside as a whole)
+      const int col = col0 + 8 * q4;
+      ok[q4] = row_ok && col < g.N;
+      bv[q4] = (g.bias && ok[q4]) ? *reinterpret_cast<const float4*>(g.bias + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      rv[q4] = (rrow && ok[q4]) ? *reinterpret_cast<const float4*>(rrow + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+  };
+  if (g.early) side_loads();  // bias / residual requested under the exchange of the partial tiles (the ring's registers are free)
   // every wave publishes its four partial sub-tiles; wave s then owns sub-tile s = 2 i + j (fixed summation order)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -201,9 +218,6 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
       for (int q4 = 0; q4 < 4; ++q4)
         red[wave][2 * i + j][q4][lane] = make_float4(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]);
   __syncthreads();
-  // lane = row (sub_m * 32 + r), register quad q4 = columns sub_n * 32 + 8 q4 + 4 half .. +3
-  const int row = (mt * 2 + (wave >> 1)) * 32 + r, col0 = (nt * 2 + (wave & 1)) * 32 + 4 * half;
-  const bool row_ok = row < g.M;
   float4 v[4];
 #pragma unroll
   for (int q4 = 0; q4 < 4; ++q4) {
@@ -216,16 +230,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) v[q4].x *= rs, v[q4].y *= rs, v[q4].z *= rs, v[q4].w *= rs;
   }
-  const float* rrow = g.R ? g.R + (size_t)(row_ok ? row : 0) * g.ldr : nullptr;
-  float4 bv[4], rv[4];
-  bool ok[4];
-#pragma unroll
-  for (int q4 = 0; q4 < 4; ++q4) {  // (N % 4 == 0: a vector is inside the matrix or outside as a whole)
-    const int col = col0 + 8 * q4;
-    ok[q4] = row_ok && col < g.N;
-    bv[q4] = (g.bias && ok[q4]) ? *reinterpret_cast<const float4*>(g.bias + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    rv[q4] = (rrow && ok[q4]) ? *reinterpret_cast<const float4*>(rrow + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  }
+  if (!g.early) side_loads();
   float o[16];
 #pragma unroll
   for (int q4 = 0; q4 < 4; ++q4) {
@@ -273,6 +278,7 @@ bool x3r_routed(int M, int N, int K) { return g_x3r_mode != 0 && M >= g_x3r_min_
 // prologue from a pre-pass over the rows (gemm_ln_nt_x3r; the vocabulary projection only below 4 096 columns: every column
 // tile repeats the statistics), 2 = the same, wide vocabularies included
 int g_x3r_ln = 1;
+int g_x3r_early = 0;  // key 46
 
 // A fp32 [M, K] (row stride lda); ln_eps >= 0: the operand is LayerNorm(A) over K with the affine folded into (PW, bias), row
 // statistics by a pre-pass (K = 256 / 512 / 1 024 / 1 280).  -1: shape not eligible
@@ -284,7 +290,7 @@ static int launch_x3r(const float* A, int lda, const uint16_t* PW, const float* 
   if (ldc % 4 != 0 || !aligned16(C) || (R && (ldr % 4 != 0 || !aligned16(R))) || (bias && !aligned16(bias))) return -1;
   if (ln && !(K == 256 || K == 512 || K == 1024 || K == 1280)) return -1;
   const int tm = cdiv(M, 64), tn = cdiv(N, 64);
-  X3rArgs a{A, reinterpret_cast<const uint4*>(PW), bias, R, C, K / 64, lda, ldr, ldc, M, N, K, act, tm, tn, alpha, ln_eps};
+  X3rArgs a{A, reinterpret_cast<const uint4*>(PW), bias, R, C, K / 64, lda, ldr, ldc, M, N, K, act, tm, tn, alpha, ln_eps, g_x3r_early};
   ProfScope prof(ln ? "gemm_ln_x3r" : "gemm_x3r", 2.0 * M * N * K,
                  4.0 * M * (double)K + 6.0 * (double)N * K + (4.0 + (R ? 4.0 : 0.0)) * M * (double)N, st);
   dim3 grid(8 * tm * cdiv(tn, 8)), block(256);

@@ -32,10 +32,14 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   const int nv = d >> 2;
   float4 v[MAXV];
   float s = 0.0f;
+  // the whole row requested first: unconditional loads of clamped slots (a load under a lane mask is a branch and a full wait each;
+  // in source order load / use / load / use the compiler keeps that order); slots past the row are zeros
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) v[i] = xr[min(lane + i * 64, nv - 1)];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + i * 64;
-    v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c >= nv) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   const float mean = sbk::wave_sum(s) / (float)d;
@@ -56,8 +60,8 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + i * 64;
+    const float4 g = g4[min(c, nv - 1)], b = b4[min(c, nv - 1)];
     if (c < nv) {
-      const float4 g = g4[c], b = b4[c];
       float4 o;
       o.x = act_f((v[i].x - mean) * rstd * g.x + b.x, act);
       o.y = act_f((v[i].y - mean) * rstd * g.y + b.y, act);
@@ -93,14 +97,18 @@ __global__ void __launch_bounds__(512) layernorm_x3p_kernel(const float* __restr
   const int nu = d >> 3, KB = d >> 4;
   float v[NV][8];
   float s = 0.0f;
+  float4 xa[NV], xb[NV];  // (the whole row requested first, unconditionally, on clamped runs: see layernorm_kernel)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int uc = min(lane + 64 * i, nu - 1);
+    xa[i] = *reinterpret_cast<const float4*>(xr + uc * 8);
+    xb[i] = *reinterpret_cast<const float4*>(xr + uc * 8 + 4);
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int u = lane + 64 * i;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (u < nu) {
-      a = *reinterpret_cast<const float4*>(xr + u * 8);
-      b = *reinterpret_cast<const float4*>(xr + u * 8 + 4);
-    }
+    float4 a = xa[i], b = xb[i];
+    if (u >= nu) a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     v[i][0] = a.x, v[i][1] = a.y, v[i][2] = a.z, v[i][3] = a.w, v[i][4] = b.x, v[i][5] = b.y, v[i][6] = b.z, v[i][7] = b.w;
     s += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
   }
@@ -118,18 +126,15 @@ __global__ void __launch_bounds__(512) layernorm_x3p_kernel(const float* __restr
   const int rb = row >> 6, rr = row & 63;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int u = lane + 64 * i;
+    const int u = lane + 64 * i, uc = min(u, nu - 1);
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + uc * 8), g1 = *reinterpret_cast<const float4*>(gamma + uc * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + uc * 8), b1 = *reinterpret_cast<const float4*>(beta + uc * 8 + 4);
     if (u >= nu) continue;
     float o[8];
-    if (live) {
-      const float4 g0 = *reinterpret_cast<const float4*>(gamma + u * 8), g1 = *reinterpret_cast<const float4*>(gamma + u * 8 + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(beta + u * 8), b1 = *reinterpret_cast<const float4*>(beta + u * 8 + 4);
+    {
       const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = act_f((v[i][e] - mean) * rstd * g[e] + bb[e], act);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = 0.0f;
+      for (int e = 0; e < 8; ++e) o[e] = live ? act_f((v[i][e] - mean) * rstd * g[e] + bb[e], act) : 0.0f;
     }
     unsigned hi[4], mi[4], lo[4];
 #pragma unroll
@@ -162,14 +167,20 @@ __global__ void __launch_bounds__(256) layernorm_x3p_rows8_kernel(const float* _
   const int nu = d >> 3, KB = d >> 4;
   float v[NJ][8];
   float s = 0.0f;
+  // the whole row requested first: unconditional loads of clamped pieces (a load under a lane mask is a branch and a full wait
+  // each, NJ round trips in a row; and in source order load / use / load / use the compiler keeps that order)
+  float4 xa[NJ], xb[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int qc = min(u + 8 * j, nu - 1);
+    xa[j] = *reinterpret_cast<const float4*>(xr + qc * 8);
+    xb[j] = *reinterpret_cast<const float4*>(xr + qc * 8 + 4);
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int q = u + 8 * j;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (q < nu) {
-      a = *reinterpret_cast<const float4*>(xr + q * 8);
-      b = *reinterpret_cast<const float4*>(xr + q * 8 + 4);
-    }
+    float4 a = xa[j], b = xb[j];
+    if (q >= nu) a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     v[j][0] = a.x, v[j][1] = a.y, v[j][2] = a.z, v[j][3] = a.w, v[j][4] = b.x, v[j][5] = b.y, v[j][6] = b.z, v[j][7] = b.w;
     s += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
   }
@@ -187,18 +198,15 @@ __global__ void __launch_bounds__(256) layernorm_x3p_rows8_kernel(const float* _
   const int rb = row >> 6, rr = row & 63;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int q = u + 8 * j;
+    const int q = u + 8 * j, qc = min(q, nu - 1);
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + qc * 8), g1 = *reinterpret_cast<const float4*>(gamma + qc * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + qc * 8), b1 = *reinterpret_cast<const float4*>(beta + qc * 8 + 4);
     if (q >= nu) continue;
     float o[8];
-    if (live) {
-      const float4 g0 = *reinterpret_cast<const float4*>(gamma + q * 8), g1 = *reinterpret_cast<const float4*>(gamma + q * 8 + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(beta + q * 8), b1 = *reinterpret_cast<const float4*>(beta + q * 8 + 4);
+    {
       const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = act_f((v[j][e] - mean) * rstd * g[e] + bb[e], act);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = 0.0f;
+      for (int e = 0; e < 8; ++e) o[e] = live ? act_f((v[j][e] - mean) * rstd * g[e] + bb[e], act) : 0.0f;
     }
     unsigned hi[4], mi[4], lo[4];
 #pragma unroll
@@ -232,15 +240,26 @@ __global__ void __launch_bounds__(256) rows_fp8_kernel(const float* __restrict__
   const int nv = d >> 2;
   float4 v[MAXV];
   float s = 0.0f;
+  uint2 ub[BF16IN ? MAXV : 1];  // (the whole row requested first, unconditionally, on clamped slots: see layernorm_kernel)
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int cl = min(lane + i * 64, nv - 1);
+    if constexpr (BF16IN) {
+      ub[i] = xb[cl];
+    } else {
+      v[i] = xr[cl];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + i * 64;
     if constexpr (BF16IN) {
-      const uint2 u = c < nv ? xb[c] : make_uint2(0u, 0u);
+      uint2 u = ub[i];
+      if (c >= nv) u = make_uint2(0u, 0u);
       v[i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
                          __uint_as_float(u.y & 0xffff0000u));
     } else {
-      v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c >= nv) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
@@ -259,8 +278,8 @@ __global__ void __launch_bounds__(256) rows_fp8_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = lane + i * 64;
+      const float4 g = g4[min(c, nv - 1)], b = b4[min(c, nv - 1)];
       if (c < nv) {
-        const float4 g = g4[c], b = b4[c];
         v[i].x = act_f((v[i].x - mean) * rstd * g.x + b.x, act);
         v[i].y = act_f((v[i].y - mean) * rstd * g.y + b.y, act);
         v[i].z = act_f((v[i].z - mean) * rstd * g.z + b.z, act);

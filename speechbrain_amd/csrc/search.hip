@@ -299,16 +299,26 @@ __global__ void __launch_bounds__(256) score_topk_row_kernel(ScoreArgs a) {
   if (a.step_ptr && norm > 0.0f) norm = (float)(step + 1);
   const size_t ro = (size_t)n * V;
   // --- log-softmax (log_softmax_row_kernel: same column mapping, same reduction order)
-  float x[NPT];
+  // every global operand of the row is requested up front, unconditionally, on a clamped column (a load under a lane mask is
+  // a branch and a full wait each: NPT round trips in a row); columns past V are discarded below
+  float x[NPT], ps[NPT], ex[NPT];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) x[i] = a.logits[ro + min(tid + 256 * i, V - 1)];
+  if (a.psi) {  // (uniform)
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) ps[i] = a.psi[ro + min(tid + 256 * i, V - 1)];
+  }
+  if (a.extra) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) ex[i] = a.extra[ro + min(tid + 256 * i, V - 1)];
+  }
   float m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < NPT; ++i) {
-    const int c = tid + 256 * i;
-    x[i] = -INFINITY;
-    if (c < V) {
-      x[i] = sbk::ls_logit(a.logits[ro + c], a.bias ? a.bias[c] : 0.0f, a.bias2 ? a.bias2[c] : 0.0f, a.inv_temp);
-      m = fmaxf(m, x[i]);
-    }
+    const int c = tid + 256 * i, cl = min(c, V - 1);
+    const float v = sbk::ls_logit(x[i], a.bias ? a.bias[cl] : 0.0f, a.bias2 ? a.bias2[cl] : 0.0f, a.inv_temp);
+    x[i] = c < V ? v : -INFINITY;
+    if (c < V) m = fmaxf(m, v);
   }
   m = sbk::wave_max(m);
   if (lane == 0) red[wave] = m;
@@ -359,10 +369,10 @@ __global__ void __launch_bounds__(256) score_topk_row_kernel(ScoreArgs a) {
       if (floor) v = a.minus_inf;
       if (a.use_thr && !(v > a.thr * am_max)) v = a.minus_inf;
     }
-    if (a.extra) v = sbk::add_rn(v, a.extra[ro + c]);
+    if (a.extra) v = sbk::add_rn(v, ex[i]);
     if (a.psi) {
       if (c == a.blank) v = sbk::kCtcNeg;
-      v = sbk::score_ctc(v, a.psi[ro + c], pp, a.ctc_weight);
+      v = sbk::score_ctc(v, ps[i], pp, a.ctc_weight);
     }
     v = sbk::score_cand(sq, v, norm);
     x[i] = v;

@@ -948,11 +948,12 @@ def test_layernorm_x3p(backend, rows, d, act):
 
 
 @pytest.mark.parametrize("d_model,nhead,B,T,beam_rows", [(128, 2, 3, 150, 4), (256, 4, 2, 75, 10), (128, 2, 1, 20, 1)])
-def test_cross_attention_lds_dma_variant(backend, d_model, nhead, B, T, beam_rows):
-    """csrc/decoder.hip cross_attn_dma_kernel (head_dim 64: LDS-DMA tiles of 16 frames, transposed scores on the matrix
-    cores, online softmax over the runs of the memory) through the KV-cached decoder: teacher-forced decoder outputs
-    must match the frame-per-thread kernel (knob 4 = 0) and the oracle's full-prefix decode -- ragged memory lengths
-    (partial last tile, empty runs past a short utterance), several hypotheses per utterance, a 1-frame-tile memory."""
+def test_cross_attention_register_ring_kernel(backend, d_model, nhead, B, T, beam_rows):
+    """csrc/decoder.hip cross_attn_ring_kernel (head_dim 64: a wave per (utterance, head, run of frames), 16-frame K / V tiles
+    straight into MFMA operand registers three tiles deep, transposed scores and context on the matrix cores, online softmax
+    over the runs of the memory) through the KV-cached decoder: teacher-forced decoder outputs must match the frame-per-thread
+    kernel (knob 4 = 0) and the oracle's full-prefix decode -- ragged memory lengths (partial last tile, runs past a short
+    utterance's end, fewer tiles than the ring is deep), several hypotheses per utterance, a 20-frame memory."""
     nat, dev = backend
     from speechbrain_amd.inference.builders import build_modules, flat_state_dict
 
@@ -980,8 +981,8 @@ def test_cross_attention_lds_dma_variant(backend, d_model, nhead, B, T, beam_row
                 nat.load().sbk_prof_set_knob(4, 7)
         assert float((outs[0] - ref).abs().max()) <= 5e-5
         assert float((outs[5] - ref).abs().max()) <= 5e-5
-        # one run per utterance (knob 8 = 3: the workgroup walks the whole memory and writes the context itself -- no partials,
-        # no merge launch: the default from ~100 utterances per search on)
+        # one run per utterance (knob 8 = 3: the wave walks the whole memory and writes the context itself -- no partials, no
+        # merge launch: what a search of >= 128 utterances x 8 heads gets by default)
         nat.load().sbk_prof_set_knob(4, 5)
         nat.load().sbk_prof_set_knob(8, 3)
         try:
@@ -1013,6 +1014,55 @@ def test_cross_attention_lds_dma_variant(backend, d_model, nhead, B, T, beam_row
         nat.load().sbk_prof_set_knob(4, 7)
     assert hyps == hyps_ref
     assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("d_model,nhead,L", [(128, 2, 70), (64, 4, 21)])
+def test_self_attention_whole_prefix_kernel(backend, d_model, nhead, L):
+    """csrc/decoder.hip self_attn_wide_kernel (knob 50 = 4 / 8 / 16: the K and V rows of 16 / 32 / 64 positions of the prefix
+    requested at once, unconditional loads on clamped positions) against the 16-positions-per-pass kernel: the same summation
+    order, so the teacher-forced decoder outputs are bit-identical at every prefix length up to L (one, two and several
+    passes; head_dim 64 and 16), and a beam search (hypotheses reading their ancestors' cache slots) returns the same
+    hypotheses and scores; both against the oracle."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import S2STransformerBeamSearcher
+    from speechbrain_amd.inference.builders import build_modules
+
+    mods = build_modules(dict(d_model=d_model, nhead=nhead, d_ffn=128, n_enc=1, n_dec=2, n_fft=400, win_length=25), vocab=40, seed=5)
+    tr, seq = mods["Transformer"].to(dev).eval(), mods["seq_lin"].to(dev).eval()
+    sd = {"Transformer." + k: v.detach().cpu() for k, v in tr.state_dict().items()}
+    cfg = O.ModelCfg(d_model=d_model, nhead=nhead, num_encoder_layers=1, num_decoder_layers=2, d_ffn=128, vocab=40)
+    gen = torch.Generator().manual_seed(L)
+    enc = torch.randn(3, 24, d_model, generator=gen)
+    enc_len = torch.tensor([24, 17, 9], dtype=torch.int32)
+    tgt = torch.randint(0, 40, (3, L), generator=gen)
+    h = nat.DecoderHandle(tr, seq)
+    lib = nat.load()
+    lib.sbk_prof_set_knob(47, 0)  # (3 rows: not the persistent few-row step, which has its own attention)
+    outs = {}
+    try:
+        for knob in (0, 4, 8, 16):
+            lib.sbk_prof_set_knob(50, knob)
+            outs[knob] = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev)).cpu()
+        assert float((outs[0] - O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")).abs().max()) <= 5e-5
+        for knob in (4, 8, 16):
+            assert torch.equal(outs[knob], outs[0]), knob
+        sd["seq_lin.w.weight"], sd["seq_lin.w.bias"] = seq.w.weight.detach().cpu() * 4.0, seq.w.bias.detach().cpu()
+        with torch.no_grad():
+            seq.w.weight.mul_(4.0)
+        wl, ratio = enc_len.float() / 24, 20.5 / 24
+        bs = S2STransformerBeamSearcher(modules=[tr, seq], bos_index=1, eos_index=2, min_decode_ratio=0.0, max_decode_ratio=ratio,
+                                        beam_size=5, using_eos_threshold=False, length_normalization=True)
+        res = {}
+        for knob in (0, 8):
+            lib.sbk_prof_set_knob(50, knob)
+            hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))
+            res[knob] = (hyps, sc.cpu())
+        assert res[0][0] == res[8][0] and torch.equal(res[0][1], res[8][1])
+        hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=5, ctc_weight=0.0, max_decode_ratio=ratio))
+        assert res[8][0] == hyps_ref and float((res[8][1] - sc_ref).abs().max()) <= 1e-4
+    finally:
+        lib.sbk_prof_set_knob(50, 0)
+        lib.sbk_prof_set_knob(47, 1)
 
 
 @pytest.mark.parametrize("M,N,K", [(70, 50, 48), (300, 130, 64), (5000, 300, 80)])

@@ -524,7 +524,7 @@ def test_golden_rope_conformer(backend, tag):
 def test_cross_attention_kernel_variants(backend, nhead, rows):
     """The frame-per-thread cross-attention kernel (head_dim 64 / 32 / 16) with 128-, 256- and 64-frame splits of a memory
     with ragged lengths (several partial results merged per utterance), through the KV-cached decoder and a 5-beam search
-    vs the oracle.  (The LDS-DMA kernel: tests/test_kernels.py::test_cross_attention_lds_dma_variant.)"""
+    vs the oracle.  (The register-ring kernel: tests/test_kernels.py::test_cross_attention_register_ring_kernel.)"""
     nat, dev = backend
     from speechbrain_amd.inference.builders import build_modules
 

@@ -19,6 +19,7 @@ ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--reps", type=int, default=1)
 ap.add_argument("--frames", type=int, default=430)
 ap.add_argument("--batches", type=int, default=4)
+ap.add_argument("--utts", type=int, default=32, help="utterances per batch")
 ap.add_argument("--report", action="store_true", help="HIP-event time per kernel class (sbk_prof_*)")
 ap.add_argument("--knob", action="append", default=[])
 args = ap.parse_args()
@@ -33,8 +34,8 @@ g = torch.Generator().manual_seed(3)
 items, ratios = [], []
 for k in range(args.batches):
     T = args.frames - 10 * k
-    enc = torch.randn(32, T, 512, generator=g).to(dev)
-    lens = torch.linspace(0.85, 1.0, 32).to(dev)
+    enc = torch.randn(args.utts, T, 512, generator=g).to(dev)
+    lens = torch.linspace(0.85, 1.0, args.utts).to(dev)
     items.append((enc, lens))
     ratios.append((0.0, (args.steps + 0.5) / T))
 with torch.no_grad():
@@ -48,7 +49,7 @@ with torch.no_grad():
         dec.forward_group(items, ratios)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-print(f"decode probe: {args.batches} x 32 utterances, T' {args.frames}, {args.steps} steps: {1e3 * dt / args.reps / args.steps:.3f} ms per step", flush=True)
+print(f"decode probe: {args.batches} x {args.utts} utterances, T' {args.frames}, {args.steps} steps: {1e3 * dt / args.reps / args.steps:.3f} ms per step", flush=True)
 if args.report:
     native.prof_enable(False)
     rep = native.prof_report()
