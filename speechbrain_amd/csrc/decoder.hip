@@ -55,7 +55,11 @@ struct SelfAttnArgs {
 // lanes read one K (or V) head row as 16-byte pieces (a 256-byte row per load instruction and
 // group, fully coalesced).  The ancestry slots are fetched once into LDS, and rows are requested
 // four position-quads at a time, so the walk over the prefix costs a few dependent round trips
-// instead of two per position.
+// instead of two per position.  (Round 5 measured the whole prefix requested at once -- the K and V rows of 16 / 32 / 64
+// positions in flight per wave before the first score, unconditional loads on clamped positions, bit-identical results: 41.7 /
+// 55.5 / 73.2 us per launch against 43.3 at 1 280 rows and prefixes of 1 .. 60 tokens, profiles/r05_p_*: the kernel is bound
+// by the number of row requests it issues, not by their latency -- every surplus (clamped) request and every wave lost to
+// the 112 / 188 registers costs more than the shorter chain returns.  Removed.)
 __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
   SBK_DYN_LDS(float, lds);  // [4 waves][2][Lmax_pad]: probabilities, slots
   if (a.step_ptr) a.step = a.step_ptr[0];
@@ -189,132 +193,6 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
       if (live && pg == 0 && c < Dh) a.out[(size_t)i * d + head_off + c] = acc;
     }
   }
-}
-
-// The same step with the whole prefix requested at once (head_dim a multiple of 4, <= 64): a pass covers 4 NT positions -- NT
-// 16-byte loads per lane for the K rows and, in the first pass, NT more for the V rows, ALL issued before the first score is
-// formed (the kernel above asks for 16 positions, waits, asks for the next 16 ... and starts on V after the softmax: two
-// dependent round trips per 16 positions of prefix, ~8 at 60 tokens).  Loads are unconditional on clamped positions (a load
-// under a lane mask is a branch and a full wait each); surplus positions carry weight 0.  Same summation order as the kernel
-// above: bit-identical results.
-template <int NT>
-__global__ void __launch_bounds__(256) self_attn_wide_kernel(SelfAttnArgs a) {
-  SBK_DYN_LDS(float, lds);  // [4 waves][2][Lmax_pad]: probabilities, slots
-  if (a.step_ptr) a.step = a.step_ptr[0];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = blockIdx.x * 4 + wave;
-  const bool live = item < a.n * a.H;
-  int i = live ? item / a.H : 0, h = live ? item % a.H : 0;
-  if (live && a.group > 1) {  // item = ((utterance * H + head) * group + beam)
-    const int per = a.H * a.group, u = item / per, rem = item % per;
-    h = rem / a.group;
-    i = u * a.group + rem % a.group;
-  }
-  const int d = a.d, Dh = a.Dh, L = a.step + 1;
-  const int lpad = ((a.Lmax + 63) / 64) * 64;
-  float* prob = lds + wave * 2 * lpad;
-  int* slot = reinterpret_cast<int*>(prob + lpad);
-  const float* q = a.qkv + (size_t)i * 3 * d + h * Dh;
-  const float* knew = q + d;
-  const float* vnew = q + 2 * d;
-  const int pg = lane >> 4, cq = lane & 15;  // position group, 16-byte piece of the head row
-  const bool piece = cq * 4 < Dh;
-  const int co = piece ? cq * 4 : 0;
-  if (live) {  // append this token's K/V head slice to the cache (slot = hypothesis index)
-    for (int c = lane; c < Dh; c += 64) {
-      const size_t o = ((size_t)i * a.Lmax + a.step) * d + h * Dh + c;
-      a.kcache[o] = knew[c];
-      a.vcache[o] = vnew[c];
-    }
-  }
-  for (int p = lane; p < a.step; p += 64) slot[p] = a.kv_slot[(size_t)i * a.Lmax + p];
-  sbk::wave_sync();
-  // the rows of a pass: the ancestry slots of its 4 NT (clamped) positions are read from LDS FIRST, all together, and held by
-  // an empty asm anchor -- otherwise the select between the new token's row and the cache row becomes a branch around each slot
-  // read, one LDS round trip in front of every load
-  const int ps_max = max(a.step - 1, 0);
-  const size_t head_off = (size_t)h * Dh;
-  auto rows = [&](float4(&dst)[NT], int pb, const float* cache, const float* fresh) SBK_INLINE_LAMBDA {
-    unsigned sl[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) sl[t] = (unsigned)slot[min(min(pb + 4 * t + pg, L - 1), ps_max)];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) sbk::pin(sl[t]);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int p = min(pb + 4 * t + pg, L - 1);
-      const float* c = cache + ((size_t)sl[t] * a.Lmax + p) * d + head_off;
-      dst[t] = *reinterpret_cast<const float4*>((p == a.step ? fresh : c) + co);
-    }
-  };
-  float4 q4 = *reinterpret_cast<const float4*>(q + co);
-  const float qs = piece ? a.scale : 0.0f;
-  q4.x *= qs; q4.y *= qs; q4.z *= qs; q4.w *= qs;
-  float4 kv[NT], vpre[NT];
-  auto scores = [&](int pb) SBK_INLINE_LAMBDA {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float s = (q4.x * kv[t].x + q4.y * kv[t].y) + (q4.z * kv[t].z + q4.w * kv[t].w);
-      s += sbk::shfl_xor(s, 1);
-      s += sbk::shfl_xor(s, 2);
-      s += sbk::shfl_xor(s, 4);
-      s += sbk::shfl_xor(s, 8);
-      const int p = pb + 4 * t + pg;
-      if (p < L && cq == 0) {
-        if (a.key_tok) {
-          const int tk = p < a.key_shift ? a.key_first : a.key_tok[(size_t)i * a.key_stride + p - a.key_shift];
-          if (tk == a.pad_idx) s = -INFINITY;
-        }
-        prob[p] = s;
-      }
-    }
-  };
-  // first pass: K and V rows of positions 0 .. 4 NT - 1 in flight together
-  rows(kv, 0, a.kcache, knew);
-  rows(vpre, 0, a.vcache, vnew);
-  scores(0);
-  for (int pb = 4 * NT; pb < L; pb += 4 * NT) {
-    rows(kv, pb, a.kcache, knew);
-    scores(pb);
-  }
-  sbk::wave_sync();
-  float m = -INFINITY;
-  for (int p = lane; p < L; p += 64) m = fmaxf(m, prob[p]);
-  m = sbk::wave_max(m);
-  float sum = 0.0f;
-  for (int p = lane; p < L; p += 64) {
-    const float e = expf(prob[p] - m);
-    prob[p] = e;
-    sum += e;
-  }
-  sum = sbk::wave_sum(sum);
-  for (int p = lane; p < L; p += 64) prob[p] = prob[p] / sum;
-  sbk::wave_sync();
-  // context: each position group accumulates its positions (ascending), then the 4 groups are summed
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto context = [&](const float4(&vv)[NT], int pb) SBK_INLINE_LAMBDA {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int p = pb + 4 * t + pg;
-      const float w = (p < L && piece) ? prob[p] : 0.0f;
-      acc.x = fmaf(w, vv[t].x, acc.x);
-      acc.y = fmaf(w, vv[t].y, acc.y);
-      acc.z = fmaf(w, vv[t].z, acc.z);
-      acc.w = fmaf(w, vv[t].w, acc.w);
-    }
-  };
-  context(vpre, 0);
-  for (int pb = 4 * NT; pb < L; pb += 4 * NT) {
-    rows(kv, pb, a.vcache, vnew);
-    context(kv, pb);
-  }
-  float o[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    o[e] += sbk::shfl_xor(o[e], 16);
-    o[e] += sbk::shfl_xor(o[e], 32);
-  }
-  if (live && pg == 0 && piece) *reinterpret_cast<float4*>(a.out + (size_t)i * d + head_off + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // ---------------------------------------------------------------- cross attention, all beams of an utterance
@@ -764,7 +642,6 @@ int embed_pos(const int32_t* tok, const float* emb, const float* pe_row, float* 
   return launch_status("embed_pos");
 }
 
-int g_self_wide = 0;  // key 50
 int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t* kv_slot, float* out, int n, int d,
                    int H, int step, int nslot, int Lmax, hipStream_t st, const int32_t* key_tok, int key_stride,
                    int key_shift, int key_first, int pad_idx, int group) {
@@ -775,17 +652,7 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
   const size_t lds = (size_t)8 * (((Lmax + 63) / 64) * 64) * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "self_attn_step: Lmax=%d too long for the LDS window", Lmax);
   ProfScope prof("self_attn_step", 4.0 * n * d * (step + 1), 8.0 * n * d * (step + 1), st);
-  // key 50: 0 = 16 positions per pass (the general kernel), 8 / 16 = the whole-prefix kernel with 32 / 64 positions per pass
-  const bool wide_ok = (a.Dh % 4) == 0 && a.Dh <= 64 && d % 4 == 0 && aligned16(qkv) && aligned16(kcache) && aligned16(vcache) && aligned16(out);
-  if (g_self_wide == 16 && wide_ok) {
-    SBK_LAUNCH(self_attn_wide_kernel<16>, dim3(cdiv(n * H, 4)), dim3(256), lds, st, a);
-  } else if (g_self_wide == 8 && wide_ok) {
-    SBK_LAUNCH(self_attn_wide_kernel<8>, dim3(cdiv(n * H, 4)), dim3(256), lds, st, a);
-  } else if (g_self_wide == 4 && wide_ok) {
-    SBK_LAUNCH(self_attn_wide_kernel<4>, dim3(cdiv(n * H, 4)), dim3(256), lds, st, a);
-  } else {
-    SBK_LAUNCH(self_attn_step_kernel, dim3(cdiv(n * H, 4)), dim3(256), lds, st, a);
-  }
+  SBK_LAUNCH(self_attn_step_kernel, dim3(cdiv(n * H, 4)), dim3(256), lds, st, a);
   return launch_status("self_attn_step");
 }
 

@@ -25,7 +25,10 @@
 //     (MI355X_MICROARCH.md, "Two waves per SIMD": complementary phases, separated by s_barrier).
 // Tiles are scheduled like gemm_nt_sk_kernel's: a fixed grid, XCD x owns a contiguous range of tiles, its workgroups take
 // whole tiles round-robin and share the leftover tiles stream-K style (partial tiles through slabs, last arriver sums in K
-// order: run-to-run deterministic, nobody waits).
+// order: run-to-run deterministic, nobody waits).  (Round 5 measured the tile space cut into 2 / 4 column groups, so that an
+// XCD's eighth of the tile indices is a block of rows x one column group and its L2 keeps that group's W panels: 155.6 / 160.9 us
+// against 156.3 at (12 800, 2 048, 512), 135.5 / 136.0 against 135.0 at (14 016, 1 536, 512), 101.3 / 102.2 against 99.6 at
+// (14 016, 1 024, 512), profiles/r05_q_*: the kernel is not bound by what crosses the fabric.  Not kept.)
 #include "common.h"
 #include "internal.h"
 

@@ -41,7 +41,7 @@ struct X3rArgs {
   int lda, ldr, ldc, M, N, K, act, tiles_m, tiles_n;
   float alpha;
   float ln_eps;      // LNQ > 0: A is the residual stream, the operand is its LayerNorm (affine folded into PW / bias)
-  int early;         // key 46: bias / residual loads in front of the exchange of the partial tiles
+  int xc;            // column groups of the tile space among the 8 XCDs (1, 2, 4 or 8; 8 / xc row groups)
 };
 
 // NS > 0: the wave's NS steps fully unrolled (K = 64 NS; measured faster for K = 512 with N >= 1 024: 18.6 / 25.3 / 51.5 us
@@ -67,12 +67,15 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
   __shared__ float2 stat[LNQ > 0 ? 64 : 1];  // (mean, rstd) of the tile's rows
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int nt, mt;
-  {  // XCD-aware tile order: workgroup id = 8 q + x runs on XCD x; give it the column tiles nt = x (mod 8)
+  {  // XCD-aware tile order: workgroup id = 8 q + x runs on XCD x (observed placement, speed only).  The XCDs own the tile
+     // space as xc column groups x 8 / xc row groups: XCD x takes the column tiles nt = x % xc (mod xc) of the row tiles mt =
+     // x / xc (mod 8 / xc), so an XCD's L2 fetches 1 / (8 / xc) of A and 1 / xc of W -- xc * |A| + (8 / xc) * |W| bytes cross the
+     // fabric per launch (xc = 8, rounds 4-5a: every XCD fetched all of A)
     const int id = blockIdx.x, x = id & 7, q = id >> 3;
-    const int nt8 = (g.tiles_n + 7) / 8;
-    mt = q % g.tiles_m;
-    nt = x + 8 * (q / g.tiles_m);
-    if (q / g.tiles_m >= nt8 || nt >= g.tiles_n) return;
+    const int c = g.xc, r = 8 / c, rm = (g.tiles_m + r - 1) / r;
+    mt = x / c + r * (q % rm);
+    nt = x % c + c * (q / rm);
+    if (mt >= g.tiles_m || nt >= g.tiles_n) return;
   }
   const int r = lane & 31, half = lane >> 5;
   const int ns = NS > 0 ? NS : g.ns, k_begin = wave * ns * 16, KB = g.K >> 4;
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
       rv[q4] = (rrow && ok[q4]) ? *reinterpret_cast<const float4*>(rrow + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
   };
-  if (g.early) side_loads();  // bias / residual requested under the exchange of the partial tiles (the ring's registers are free)
+  side_loads();  // bias / residual requested under the exchange of the partial tiles (the ring's registers are free: -1.2 % per launch, profiles/r05_p_*)
   // every wave publishes its four partial sub-tiles; wave s then owns sub-tile s = 2 i + j (fixed summation order)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -230,7 +233,6 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) v[q4].x *= rs, v[q4].y *= rs, v[q4].z *= rs, v[q4].w *= rs;
   }
-  if (!g.early) side_loads();
   float o[16];
 #pragma unroll
   for (int q4 = 0; q4 < 4; ++q4) {
@@ -278,7 +280,7 @@ bool x3r_routed(int M, int N, int K) { return g_x3r_mode != 0 && M >= g_x3r_min_
 // prologue from a pre-pass over the rows (gemm_ln_nt_x3r; the vocabulary projection only below 4 096 columns: every column
 // tile repeats the statistics), 2 = the same, wide vocabularies included
 int g_x3r_ln = 1;
-int g_x3r_early = 0;  // key 46
+int g_x3r_xc = 0;  // key 51: column groups among the XCDs (1 / 2 / 4 / 8; 0 = the count that minimises the fabric traffic)
 
 // A fp32 [M, K] (row stride lda); ln_eps >= 0: the operand is LayerNorm(A) over K with the affine folded into (PW, bias), row
 // statistics by a pre-pass (K = 256 / 512 / 1 024 / 1 280).  -1: shape not eligible
@@ -290,10 +292,17 @@ static int launch_x3r(const float* A, int lda, const uint16_t* PW, const float* 
   if (ldc % 4 != 0 || !aligned16(C) || (R && (ldr % 4 != 0 || !aligned16(R))) || (bias && !aligned16(bias))) return -1;
   if (ln && !(K == 256 || K == 512 || K == 1024 || K == 1280)) return -1;
   const int tm = cdiv(M, 64), tn = cdiv(N, 64);
-  X3rArgs a{A, reinterpret_cast<const uint4*>(PW), bias, R, C, K / 64, lda, ldr, ldc, M, N, K, act, tm, tn, alpha, ln_eps, g_x3r_early};
+  int xc = g_x3r_xc;
+  if (!(xc == 1 || xc == 2 || xc == 4 || xc == 8)) {  // fewest bytes across the fabric: xc |A| + (8 / xc) |W|
+    const double ab = 4.0 * M * (double)K, wb = 6.0 * N * (double)K;
+    xc = 8;
+    for (int c = 4; c >= 1; c >>= 1)
+      if (c * ab + (8 / c) * wb < xc * ab + (8 / xc) * wb) xc = c;
+  }
+  X3rArgs a{A, reinterpret_cast<const uint4*>(PW), bias, R, C, K / 64, lda, ldr, ldc, M, N, K, act, tm, tn, alpha, ln_eps, xc};
   ProfScope prof(ln ? "gemm_ln_x3r" : "gemm_x3r", 2.0 * M * N * K,
                  4.0 * M * (double)K + 6.0 * (double)N * K + (4.0 + (R ? 4.0 : 0.0)) * M * (double)N, st);
-  dim3 grid(8 * tm * cdiv(tn, 8)), block(256);
+  dim3 grid(8 * cdiv(tm, 8 / xc) * cdiv(tn, xc)), block(256);
   if (ln) {
     if (K == 512) {  // (the unrolled step loop for every N: the rolled one is at the register limit without the row means)
       SBK_LAUNCH((gemm_x3r_kernel<8, 2>), grid, block, 0, st, a);

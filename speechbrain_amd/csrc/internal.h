@@ -43,8 +43,7 @@ extern thread_local const int32_t* g_step_ptr;
 extern thread_local int g_step_min_steps;  // min_decode_steps of that search (eos floor: step < min_steps)
 extern int g_cross_rows;
 extern int g_cross_fc256;
-extern int g_self_wide;
-extern int g_x3r_early;
+extern int g_x3r_xc;
 extern int g_score_fused;  // key 40: 1 (default) = the step's scoring as one pass per hypothesis row (csrc/search.hip)
 constexpr float kCtcNeg = -1e20f;  // the CTC scorer's finite "log 0" (ctc.py:150, scorer.py:1250)
 // The arithmetic of a decoding step's scoring, shared by the separate kernels (log_softmax_row / ctc_combine / am_only /
