@@ -433,6 +433,32 @@ def launch_check(args, rank, world):
         dist.destroy_process_group()
 
 
+def pmc_traffic(name, roof, path=None):
+    """HBM bytes per launch of kernel class `name` from the PMC counters, collected in their own rocprofv3 --pmc passes
+    (tools/run_pmc_r5.sh -> profiles/pmc_traffic.json); fills roof's traffic_note / traffic_provenance / mfma_busy_pmc.  None when
+    there is no row of THIS round's kernel, or when the row was counted before a later change of the kernel's schedule (then the
+    note quotes it)."""
+    pmc = json.load(open(path or os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    traffic = None
+    key = next((k for k in pmc if not k.startswith("_") and name.startswith(k)), None)
+    if key and pmc[key].get("round") == 5:  # (a row collected on an earlier round's kernel is not this kernel's traffic)
+        if pmc[key].get("superseded"):
+            roof["traffic_note"] = (f"not measured for the kernel as shipped -- {pmc[key]['superseded']}; the superseded row: "
+                                    f"{pmc[key]['bytes_per_launch']} B/launch against {pmc[key]['algorithmic_bytes_per_launch']} algorithmic")
+        else:
+            traffic = pmc[key]["bytes_per_launch"]
+            roof["traffic_note"] = f"{pmc[key]['note']}; algorithmic {pmc[key]['algorithmic_bytes_per_launch']} B/launch"
+        roof["traffic_provenance"] = {"source": "profiles/pmc_traffic.json: rocprofv3 --pmc passes of THIS round's kernel in their own runs "
+                                                "(counters cannot be read inside a timing run; tools/run_pmc_r5.sh)",
+                                      "commit": pmc[key].get("commit"), "shape": pmc[key].get("shape"),
+                                      "collected": pmc[key].get("collected")}
+    busy = {k: v["mfma_busy"] for k, v in pmc.get("_mfma_busy", {}).items()
+            if not k.startswith("_") and k.startswith(name) and v.get("round") == 5}
+    if busy:  # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x active cycles), from its own --pmc pass
+        roof["mfma_busy_pmc"] = busy
+    return traffic
+
+
 def roofline_entry(name, v, total_ms):
     avg_ms = v["ms"] / max(v["count"], 1)
     if name.startswith(MFMA_KERNELS):
@@ -924,20 +950,8 @@ def main():
         roof = roofline_entry(ranked[0][0], ranked[0][1], total_ms)
         name = roof["kernel"]
         traffic = None
-        try:  # HBM bytes per launch from the PMC counters, collected in their own rocprofv3 --pmc passes (tools/run_pmc.sh)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = next((k for k in pmc if not k.startswith("_") and name.startswith(k)), None)
-            if key and pmc[key].get("round") == 5:  # (a row collected on an earlier round's kernel is not this kernel's traffic)
-                traffic = pmc[key]["bytes_per_launch"]
-                roof["traffic_note"] = f"{pmc[key]['note']}; algorithmic {pmc[key]['algorithmic_bytes_per_launch']} B/launch"
-                roof["traffic_provenance"] = {"source": "profiles/pmc_traffic.json: rocprofv3 --pmc passes of THIS round's kernel in their own runs "
-                                                        "(counters cannot be read inside a timing run; tools/run_pmc_x3.sh)",
-                                              "commit": pmc[key].get("commit"), "shape": pmc[key].get("shape"),
-                                              "collected": pmc[key].get("collected")}
-            busy = {k: v["mfma_busy"] for k, v in pmc.get("_mfma_busy", {}).items()
-                    if not k.startswith("_") and k.startswith(name) and v.get("round") == 5}
-            if busy:  # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x active cycles), from its own --pmc pass
-                roof["mfma_busy_pmc"] = busy
+        try:
+            traffic = pmc_traffic(name, roof)
         except Exception:
             pass
         roof["traffic"] = traffic

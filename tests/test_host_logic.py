@@ -242,3 +242,32 @@ def test_bench_roofline_entry_prices_each_kernel_against_its_own_peak():
     assert e["peak"] == 157.3 and "frac_of_fp32_mfma_peak" not in e
     e = bench.roofline_entry("cross_attn_step", v, 4000.0)
     assert e["bound"] == "hbm" and e["unit"] == "GB/s" and abs(e["achieved"] - 1000.0) < 1e-6 and e["peak"] == 8000.0
+
+
+def test_bench_traffic_rows_of_this_rounds_kernels_only(tmp_path):
+    """bench.pmc_traffic: the `traffic` field of the roofline object is the PMC figure of THIS round's kernel as shipped or null --
+    a row of an earlier round, and a row counted before a later change of the kernel's schedule ("superseded"), are quoted in
+    the note, never reported; the committed profiles/pmc_traffic.json parses and yields a note for the dominant kernel."""
+    import json
+
+    import bench
+
+    rows = {"_source": "test", "gemm_x3r": {"round": 5, "bytes_per_launch": 100, "algorithmic_bytes_per_launch": 40, "note": "n", "commit": "c"},
+            "gemm_nt_x3p": {"round": 4, "bytes_per_launch": 7, "algorithmic_bytes_per_launch": 3, "note": "old"},
+            "_mfma_busy": {"gemm_x3r M=1": {"round": 5, "mfma_busy": 0.25}, "gemm_x3r M=2": {"round": 4, "mfma_busy": 0.5}}}
+    f = tmp_path / "pmc.json"
+    f.write_text(json.dumps(rows))
+    roof = {}
+    assert bench.pmc_traffic("gemm_x3r", roof, str(f)) == 100
+    assert "algorithmic 40" in roof["traffic_note"] and roof["traffic_provenance"]["commit"] == "c" and roof["mfma_busy_pmc"] == {"gemm_x3r M=1": 0.25}
+    roof = {}
+    assert bench.pmc_traffic("gemm_nt_x3p", roof, str(f)) is None and "traffic_note" not in roof  # an earlier round's row
+    rows["gemm_x3r"]["superseded"] = "counted before the tile order changed"
+    f.write_text(json.dumps(rows))
+    roof = {}
+    assert bench.pmc_traffic("gemm_x3r", roof, str(f)) is None
+    assert "not measured for the kernel as shipped" in roof["traffic_note"] and "100 B/launch" in roof["traffic_note"]
+    roof = {}
+    bench.pmc_traffic("gemm_x3r", roof)  # the committed file
+    assert "traffic_note" in roof and "traffic_provenance" in roof
+

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Fabric traffic of the memory-bound decode-step kernels (cross_attn_dma, ctc_score_step, self_attn_step) at the headline's
+# Fabric traffic of the memory-bound decode-step kernels (cross_attn_ring, ctc_score_step, self_attn_step) at the headline's
 # decode shape (tools/decode_probe.py: 4 x 32 utterances, T' 430, beam 10 + CTC), FETCH_SIZE and WRITE_SIZE in separate --pmc
 # passes beside --kernel-trace only (MI355X_MICROARCH.md).  Output: gpurun_out/pmc_r5_decode_{fetch,write}.csv + a summary.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
@@ -13,10 +13,11 @@ for SET in "FETCH_SIZE" "WRITE_SIZE"; do
 done
 python - <<'PY'
 import csv, collections
-# algorithmic bytes per launch at this shape: cross K/V 8 T' d per utterance (T' 430..400, 128 utterances, one layer);
+# algorithmic bytes per launch at this shape: cross K/V 8 len d per utterance (T' 430..400, 128 utterances, one layer);
 # CTC posteriors 4 T' V per utterance; self-attention cache 8 d (step + 1) per hypothesis row (1 280 rows), mean over the steps run
 T = [430, 420, 410, 400]
-alg = {"cross_attn_dma_kernel": sum(32 * t for t in T) * 8 * 512, "ctc_score_step_kernel": sum(32 * t for t in T) * 4 * 5000,
+# (lengths 0.85 .. 1.0 of T' within a batch: mean 0.925)
+alg = {"cross_attn_ring_kernel": int(0.925 * sum(32 * t for t in T)) * 8 * 512, "ctc_score_step_kernel": int(0.925 * sum(32 * t for t in T)) * 4 * 5000,
        "self_attn_step_kernel": None}
 vals = {}
 for tag in ("fetch", "write"):
