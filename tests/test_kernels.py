@@ -1172,6 +1172,63 @@ def test_cross_attention_register_ring_kernel(backend, d_model, nhead, B, T, bea
     assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
 
 
+@pytest.mark.parametrize("d_model,nhead,B,T,beam", [(192, 3, 3, 33, 16), (128, 2, 5, 49, 3), (256, 4, 1, 17, 16), (128, 2, 2, 230, 3), (128, 2, 3, 330, 2)])
+def test_cross_attention_register_ring_kernel_edge_shapes(backend, d_model, nhead, B, T, beam):
+    """cross_attn_ring_kernel at the edges of its index arithmetic (logic check on the emulator; the GPU cases are
+    test_cross_attention_register_ring_kernel -- these shapes were added after the round's last GPU visit): a number of (utterance,
+    head) pairs that does not fill the last workgroup (9, 10, 4 waves), a full 16-beam tile and a 3-beam one, memories of 16 k + 1
+    frames (a last tile of one frame), utterances shorter than one tile and shorter than the first run (an EMPTY partial for the
+    later runs), one run per utterance and two / three runs of >= 100 frames merged by cross_merge (memories of 230 / 330 frames:
+    the default run rule cuts a memory only from 200 frames on).  Teacher-forced decoder outputs vs the oracle and the frame-per-thread kernel, then the beam search vs the
+    oracle's."""
+    nat, dev = backend
+    if dev.type == "cuda":
+        pytest.skip("emulator-only cases (added after the last GPU visit of round 5)")
+    from speechbrain_amd.decoders import S2STransformerBeamSearcher
+    from speechbrain_amd.inference.builders import build_modules
+
+    mods = build_modules(dict(d_model=d_model, nhead=nhead, d_ffn=128, n_enc=1, n_dec=2, n_fft=400, win_length=25), vocab=40, seed=beam)
+    tr, seq = mods["Transformer"].to(dev).eval(), mods["seq_lin"].to(dev).eval()
+    sd = {"Transformer." + k: v.detach().cpu() for k, v in tr.state_dict().items()}
+    cfg = O.ModelCfg(d_model=d_model, nhead=nhead, num_encoder_layers=1, num_decoder_layers=2, d_ffn=128, vocab=40)
+    gen = torch.Generator().manual_seed(T + beam)
+    enc = torch.randn(B, T, d_model, generator=gen) * 1.5
+    enc_len = torch.tensor([T, 17, 3, T - 1, 16][:B], dtype=torch.int32).clamp(max=T)
+    tgt = torch.randint(0, 40, (B, 5), generator=gen)
+    ref = O.decode(tgt, enc, enc_len, sd, cfg, "Transformer.")
+    h = nat.DecoderHandle(tr, seq)
+    lib = nat.load()
+    lib.sbk_prof_set_knob(47, 0)  # (not the persistent few-row step, which has its own attention)
+    try:
+        outs = {}
+        for rows, one_run in ((0, 0), (5, 0), (5, 3)):
+            lib.sbk_prof_set_knob(4, rows)
+            lib.sbk_prof_set_knob(8, one_run)
+            outs[(rows, one_run)] = nat.decoder_prefix(h, tgt.int().to(dev), enc.to(dev), enc_len.to(dev)).cpu()
+        for k, v in outs.items():
+            assert float((v - ref).abs().max()) <= 5e-5, k
+        # from 200 frames on the default rule cuts the memory into runs (partials + cross_merge: another summation order than
+        # one run per utterance); below, both settings are the same launch
+        assert torch.equal(outs[(5, 0)], outs[(5, 3)]) == (T < 200)
+        sd["seq_lin.w.weight"], sd["seq_lin.w.bias"] = seq.w.weight.detach().cpu() * 4.0, seq.w.bias.detach().cpu()
+        with torch.no_grad():
+            seq.w.weight.mul_(4.0)
+        wl, ratio = enc_len.float() / T, 6.5 / T
+        hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=beam, ctc_weight=0.0, max_decode_ratio=ratio))
+        bs = S2STransformerBeamSearcher(modules=[tr, seq], bos_index=1, eos_index=2, min_decode_ratio=0.0, max_decode_ratio=ratio,
+                                        beam_size=beam, using_eos_threshold=False, length_normalization=True)
+        for one_run in (0, 3):
+            lib.sbk_prof_set_knob(4, 5)
+            lib.sbk_prof_set_knob(8, one_run)
+            hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))
+            assert hyps == hyps_ref, one_run
+            assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4
+    finally:
+        lib.sbk_prof_set_knob(4, 7)
+        lib.sbk_prof_set_knob(8, 0)
+        lib.sbk_prof_set_knob(47, 1)
+
+
 @pytest.mark.parametrize("M,N,K", [(70, 50, 48), (300, 130, 64), (5000, 300, 80)])
 def test_gemm_fp16_and_fp8_operands(backend, M, N, K):
     """sbk_gemm_nt_f16 / sbk_gemm_nt_fp8 (SURVEY 8b "fp16 / fp8 fast entry points"): the kernels must equal the fp32
