@@ -58,7 +58,7 @@ if __name__ == "__main__":
             gemm_case(M, N, K, 8, iters=20)
         ctc_case(128, 440, 5000, 10, 5)
         sys.exit(0)
-    if "--attn" in sys.argv:  # encoder attention, both schedules of phase 1
+    if "--attn" in sys.argv:  # encoder attention kernels (RelPosMHAXL / RoPE) in isolation
         import math
         from speechbrain_amd.nnet.attention import PrecomputedRoPESinusoids
         H, Dh = 8, 64
@@ -69,13 +69,10 @@ if __name__ == "__main__":
             P = torch.randn(2 * T - 1, d, device=dev)
             u = torch.randn(d, device=dev) * 0.1
             kl = torch.full((B,), T, dtype=torch.int32, device=dev)
-            for pf in (0, 8):  # 0: strip-free online-softmax kernel; 8: score-strip kernel (default schedule)
-                nat.load().sbk_prof_set_knob(3, pf)
-                t_rel = timeit(lambda: nat.relpos_attention(qkv, P, u, u, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
-                t_rope = timeit(lambda: nat.rope_attention(qkv, tab.cosines, tab.sines, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
-                fl = B * H * T * T * Dh
-                print(f"attn B={B} T={T} knob={pf}: relpos {t_rel:8.1f} us {6.0*fl/t_rel/1e6:6.1f} TF/s | rope {t_rope:8.1f} us {4.0*fl/t_rope/1e6:6.1f} TF/s", flush=True)
-        nat.load().sbk_prof_set_knob(3, 0)
+            t_rel = timeit(lambda: nat.relpos_attention(qkv, P, u, u, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
+            t_rope = timeit(lambda: nat.rope_attention(qkv, tab.cosines, tab.sines, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
+            fl = B * H * T * T * Dh
+            print(f"attn B={B} T={T}: relpos {t_rel:8.1f} us {6.0*fl/t_rel/1e6:6.1f} TF/s | rope {t_rope:8.1f} us {4.0*fl/t_rope/1e6:6.1f} TF/s", flush=True)
         if "--gemm" not in sys.argv:
             sys.exit(0)
         print("decode-step GEMMs: register-operand 32x32 tiles (skinny) vs LDS-tiled")
@@ -87,51 +84,9 @@ if __name__ == "__main__":
                 gemm_case(M, N, K, 8)
         nat.load().sbk_prof_set_knob(2, 0)
         sys.exit(0)
-    if "--enc-gemm" in sys.argv:  # encoder GEMM shapes (M = B*T'), tile variants of the large-M path
-        for tile in (0, 4):
-            nat.load().sbk_prof_set_knob(6, tile)
-            print("tile variant", tile)
-            for (M, N, K) in [(16384, 2048, 512), (16384, 512, 2048), (56064, 2048, 512), (56064, 512, 2048),
-                              (56064, 1536, 512), (56064, 512, 512), (56064, 1024, 512)]:
-                gemm_case(M, N, K, 0)
-        nat.load().sbk_prof_set_knob(6, 0)
-        sys.exit(0)
-    # (--pmc-decode / --flat64 and the 16-byte-LDS-operand columns measured kernels that round 5 removed: their logs are
-    #  profiles/r02_microbench_decode_gemm_variants.log and r02_pmc_decode_gemm_wave_counters.csv)
-    if "--relpos-t" in sys.argv:  # RelPosMHAXL flash kernel: default (score tile through LDS) vs transposed scores (knob 17)
-        import math
-        for (B, T, H) in [(64, 440, 8), (32, 750, 8)]:
-            Dh, d = 64, 8 * 64
-            qkv = torch.randn(B, T, 3 * d, device=dev)
-            P = torch.randn(2 * T - 1, d, device=dev)
-            u, v = torch.randn(d, device=dev) * 0.3, torch.randn(d, device=dev) * 0.3
-            fl = 6.0 * B * H * T * T * Dh
-            res, outs = {}, {}
-            for tag, knob in (("lds-tile", 0), ("transposed", 1)):
-                nat.load().sbk_prof_set_knob(17, knob)
-                outs[tag] = nat.relpos_attention(qkv, P, u, v, None, H, 1 / math.sqrt(d))[0]
-                t = timeit(lambda: nat.relpos_attention(qkv, P, u, v, None, H, 1 / math.sqrt(d)), n=20, warm=3)
-                res[tag] = f"{t:8.1f} us {fl / t / 1e6:6.1f} TF/s"
-            nat.load().sbk_prof_set_knob(17, 1)
-            print(f"relpos attention B={B} T={T} H={H}:", res, "max|diff|", float((outs["lds-tile"] - outs["transposed"]).abs().max()), flush=True)
-        sys.exit(0)
-    if "--attn2" in sys.argv:  # RoPE / plain attention: LDS-tile flash kernel vs transposed-score kernel vs its bf16 variant
-        import math
-        from speechbrain_amd.nnet.attention import PrecomputedRoPESinusoids
-        for (B, T, H) in [(64, 440, 8), (32, 750, 8), (8, 1500, 20)]:
-            Dh = 64
-            qkv = torch.randn(B, T, 3 * H * Dh, device=dev)
-            tab = PrecomputedRoPESinusoids(2048, Dh, torch.float32, dev)
-            fl = 4.0 * B * H * T * T * Dh
-            res = {}
-            for tag, knob, prec in (("lds-tile", 1, "fp32"), ("transposed", 0, "fp32"), ("transposed bf16", 0, "bf16")):
-                nat.load().sbk_prof_set_knob(16, knob)
-                with nat.precision_scope(prec):
-                    t = timeit(lambda: nat.rope_attention(qkv, tab.cosines, tab.sines, None, H, 0.125), n=20, warm=3)
-                res[tag] = f"{t:8.1f} us {fl / t / 1e6:6.1f} TF/s"
-            nat.load().sbk_prof_set_knob(16, 0)
-            print(f"rope attention B={B} T={T} H={H}:", res, flush=True)
-        sys.exit(0)
+    # (Modes that toggled knobs removed in round 5 -- --enc-gemm, --relpos-t, --attn2, --k512, --skinny, --sk, --sk64, --pmc-decode,
+    #  --flat64, the tile / grid / measurement-mode columns of --x3p / --x3 / --bf16a -- went with the kernels they compared: their
+    #  logs are under profiles/r02_* .. r04_*.)
     if "--ffn2" in sys.argv:  # few rows, K = 2048: register-operand split-K (default) vs 64x64 LDS tiles with a 4-way K split
         for knob in (0, 1):
             nat.load().sbk_prof_set_knob(14, knob)
@@ -140,24 +95,6 @@ if __name__ == "__main__":
                 gemm_case(M, 512, 2048, 8)
             gemm_case(1280, 768, 3072, 8)
         nat.load().sbk_prof_set_knob(14, 0)
-        sys.exit(0)
-    if "--k512" in sys.argv:  # K = 512 decode shapes: register-operand flat schedule vs 64x64 LDS tiles with a 2- / 4-way K split
-        for sk in (0, 2, 4):
-            nat.load().sbk_prof_set_knob(15, sk)
-            print("K = 512 path:", f"64x64 LDS tiles, {sk}-way K split" if sk else "default")
-            for M in (320, 640, 1280, 2560):
-                gemm_case(M, 512, 512, 8)
-            gemm_case(1280, 768, 768, 8)
-        nat.load().sbk_prof_set_knob(15, 0)
-        sys.exit(0)
-    if "--skinny" in sys.argv:  # decode-step GEMMs on the register-operand path: looped (round 1) vs flat schedule
-        for looped in (1, 0):
-            nat.load().sbk_prof_set_knob(10, looped)
-            print("skinny schedule:", "looped" if looped else "flat (all loads up front)")
-            for M in (320, 640, 1280):
-                for (N, K) in [(512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512)]:
-                    gemm_case(M, N, K, 8)
-        nat.load().sbk_prof_set_knob(10, 0)
         sys.exit(0)
     if "--stream" in sys.argv:  # hand-written float4 streaming kernels of the library (sbk_prof_stream_f32): the HBM calibration
         for mb in (64, 256, 1024, 4096):
@@ -175,7 +112,7 @@ if __name__ == "__main__":
     if "--enc-layer" in sys.argv:  # the Conformer-L encoder in situ (32 utterances x 5 / 10 / 20 / 30 s): per-kernel event times by GEMM routing
         from speechbrain_amd.inference.builders import build_asr
         asr = build_asr("L", vocab=5000, seed=0, device="cuda:0")
-        variants = (("tile grid", {18: 0}), ("persistent G=512", {18: 3, 19: 512}), ("persistent G=256", {18: 3, 19: 256}), ("routed (default)", {18: 1, 19: 0}))
+        variants = (("tile grid", {18: 0}), ("routed (default)", {18: 1}))
         for sec in (5, 10, 20, 30):
             wav = (0.1 * torch.randn(32, sec * 16000, generator=torch.Generator().manual_seed(sec))).to(dev)
             lens = torch.ones(32, device=dev)
@@ -197,7 +134,7 @@ if __name__ == "__main__":
                 gms, gfl = sum(v["ms"] for v in gem.values()), sum(v["flops"] for v in gem.values())
                 print(f"enc 32x{sec}s {tag:18s}: all kernels {tot / 3:8.2f} ms | GEMMs {gms / 3:8.2f} ms {gfl / gms / 1e9:6.1f} TF/s |",
                       {k: (round(v["ms"] / 3, 2), round(v["flops"] / v["ms"] / 1e9, 1)) for k, v in gem.items()}, flush=True)
-        nat.load().sbk_prof_set_knob(18, 1); nat.load().sbk_prof_set_knob(19, 0)
+        nat.load().sbk_prof_set_knob(18, 1)
         sys.exit(0)
     if "--enc-bf16" in sys.argv:  # Conformer-L encoder under precision bf16: bf16 activations in memory (feed-forward pairs) vs fp32 activations rounded on load
         from speechbrain_amd.inference.builders import build_asr
@@ -236,14 +173,12 @@ if __name__ == "__main__":
                 rc = nat.load().sbk_prof_mfma_peak_f32(nat._p(sink), wgs, 20000, rnd, ctypes.byref(tf), nat._stream(sink))
                 assert rc == 0
                 print(f"mfma peak: {wgs} workgroups x 4 waves, {'random' if rnd else 'zero'} operands: {tf.value:7.1f} TFLOP/s", flush=True)
-        for tag, knobs in (("stream-K", {18: 1, 22: 0}), ("stream-K, panel loads off (ceiling of the LDS/MFMA loop)", {18: 1, 22: 1}),
-                           ("tile grid", {18: 0, 22: 0})):
+        for tag, knobs in (("stream-K", {18: 1}), ("tile grid", {18: 0})):
             for k, v in knobs.items():
                 nat.load().sbk_prof_set_knob(k, v)
             print("variant:", tag, flush=True)
             for (M, N, K) in [(56064, 2048, 512), (56064, 512, 2048), (56064, 512, 512)]:
                 gemm_case(M, N, K, 0, iters=30)
-        nat.load().sbk_prof_set_knob(22, 0)
         nat.load().sbk_prof_set_knob(18, 1)
         print("zero-filled operands (DVFS give-back), stream-K then tile grid")
         for mode in (1, 0):
@@ -262,26 +197,6 @@ if __name__ == "__main__":
             for (M, N, K) in [(56064, 2048, 512), (56064, 512, 2048), (12800, 2048, 512)]:
                 gemm_case(M, N, K, 0, iters=5)
         nat.load().sbk_prof_set_knob(18, 1)
-        sys.exit(0)
-    if "--sk" in sys.argv:  # encoder GEMM shapes of the bench (M = 32 utterances x T' frames): tile grid vs stream-K
-        shapes = [(M, N, K) for M in (4032, 8000, 12800, 16000, 24032, 56064)
-                  for (N, K) in ((512, 512), (1536, 512), (2048, 512), (512, 2048), (1024, 512))]
-        variants = (("persistent (routed), pieces in front", {18: 1, 30: 0}), ("persistent (routed), pieces interleaved", {18: 1, 30: 1}))
-        if "--sk-narrow" in sys.argv:  # the narrow short-K shapes on 64-wide persistent tiles
-            shapes = [(M, N, K) for M in (4032, 8000, 12800, 16000, 24032) for (N, K) in ((512, 512), (1024, 512))]
-            variants = (("routed (128-wide tiles / tile grid)", {24: 2048, 25: 0}), ("64-wide tiles, 16 K units per workgroup", {24: 1 << 30, 25: 1, 26: 16}),
-                        ("64-wide tiles, 32 units", {24: 1 << 30, 25: 1, 26: 32}), ("64-wide tiles, 48 units", {24: 1 << 30, 25: 1, 26: 48}))
-        for tag, knobs in variants:
-            for k, v in knobs.items():
-                nat.load().sbk_prof_set_knob(k, v)
-            print("variant:", tag, flush=True)
-            for (M, N, K) in shapes:
-                gemm_case(M, N, K, 0, iters=50)
-            nat.load().sbk_prof_set_knob(19, 0)
-            nat.load().sbk_prof_set_knob(21, 4)
-            nat.load().sbk_prof_set_knob(23, 1)
-        for k, v in ((18, 1), (30, 0), (24, 2048), (25, 0), (26, 16)):
-            nat.load().sbk_prof_set_knob(k, v)
         sys.exit(0)
     if "--x3-pmc" in sys.argv:  # short: the split-operand kernel at a bench-sized shape for a counters pass
         nat.F32X3, nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES = True, 1, 1
@@ -400,12 +315,9 @@ if __name__ == "__main__":
             tsp = ev_time(lambda: nat.split_x3p(a))
             pa = nat.split_x3p(a)
             line = f"x3p M={M} N={N} K={K}: f32x3 {t3:7.1f} us {2.0*M*N*K/t3/1e6:6.1f} TF/s | split A {tsp:6.1f} us {10.0*M*K/tsp/1e3:6.0f} GB/s |"
-            for tile in (1, 2):
-                nat.load().sbk_prof_set_knob(39, tile)
-                t = ev_time(lambda: nat.gemm_nt_x3p(pa, w))
-                tp = ev_time(lambda: nat.gemm_nt_x3p(pa, w, panel_out=True, fp32_out=False)) if N % 16 == 0 else float("nan")
-                line += f" tile {'256x256' if tile == 1 else '256x128'}: {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s (panel out {tp:7.1f} us) |"
-            nat.load().sbk_prof_set_knob(39, 0)
+            t = ev_time(lambda: nat.gemm_nt_x3p(pa, w))
+            tp = ev_time(lambda: nat.gemm_nt_x3p(pa, w, panel_out=True, fp32_out=False)) if N % 16 == 0 else float("nan")
+            line += f" x3p (256x128 tiles): {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s (panel out {tp:7.1f} us) |"
             out = nat.gemm_nt_x3p(pa, w)
             ref = (a.double() @ w.double().t())
             line += f" rms err vs fp64: x3p {float((out.double() - ref).pow(2).mean().sqrt()):.3e} f32x3 {float((ref3.double() - ref).pow(2).mean().sqrt()):.3e}"
@@ -427,41 +339,19 @@ if __name__ == "__main__":
             shapes = [(640, 5000, 512), (1280, 5000, 512), (2560, 5000, 512), (12800, 1024, 512), (12800, 5000, 512)]
         if "--x3-short" in sys.argv:
             shapes = [(12800, 2048, 512), (12800, 512, 2048), (4032, 512, 512)]
-        grids = (0, 256, 512)
         for (M, N, K) in shapes:
             a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev)
             nat.F32X3 = False
             t32 = ev_time(lambda: nat.gemm_nt(a, w))
             ref = nat.gemm_nt(a, w)
             nat.F32X3, nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES = True, 1, 1
-            line = f"f32x3 M={M} N={N} K={K}: fp32-MFMA {t32:7.1f} us {2.0*M*N*K/t32/1e6:6.1f} TF/s |"
-            for grid in grids:
-                nat.load().sbk_prof_set_knob(31, grid)
-                t = ev_time(lambda: nat.gemm_nt(a, w))
-                line += f" grid {grid or 'auto'}: {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s |"
-            nat.load().sbk_prof_set_knob(31, 0)
+            t = ev_time(lambda: nat.gemm_nt(a, w))
+            line = f"f32x3 M={M} N={N} K={K}: fp32-MFMA {t32:7.1f} us {2.0*M*N*K/t32/1e6:6.1f} TF/s | f32x3 {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF/s |"
             if "--x3-zero" in sys.argv:  # DVFS probe: the same launches on zero-filled operands (no toggling in the multipliers)
                 az, wz = torch.zeros_like(a), torch.zeros_like(w)
-                for mode in (0, 3):
-                    nat.load().sbk_prof_set_knob(22, mode)
-                    t1 = ev_time(lambda: nat.gemm_nt(a, w), n=50)
-                    t0 = ev_time(lambda: nat.gemm_nt(az, wz), n=50)
-                    line += f" mode {mode}: random {t1:6.1f} us, zeros {t0:6.1f} us |"
-                nat.load().sbk_prof_set_knob(22, 0)
-                nat.F32X3 = False
                 t1 = ev_time(lambda: nat.gemm_nt(a, w), n=50)
                 t0 = ev_time(lambda: nat.gemm_nt(az, wz), n=50)
-                nat.F32X3 = True
-                line += f" fp32-MFMA kernel: random {t1:6.1f} us, zeros {t0:6.1f} us |"
-            if "--x3-modes" in sys.argv:  # measurement modes (wrong results): 1 no panel loads, 2 no operand split, 4 hi.hi products only
-                for grid in (512, 400, 256):
-                    nat.load().sbk_prof_set_knob(31, grid)
-                    for mode in (0, 1, 2, 3, 4, 6, 7, 8, 15):
-                        nat.load().sbk_prof_set_knob(22, mode)
-                        t = ev_time(lambda: nat.gemm_nt(a, w), n=50)
-                        line += f" g{grid} mode {mode}: {t:6.1f} |"
-                nat.load().sbk_prof_set_knob(22, 0)
-                nat.load().sbk_prof_set_knob(31, 0)
+                line += f" random {t1:6.1f} us, zeros {t0:6.1f} us |"
             out = nat.gemm_nt(a, w)
             exact = a.double() @ w.double().t()
             e3, e32 = float((out.double() - exact).pow(2).mean().sqrt()), float((ref.double() - exact).pow(2).mean().sqrt())
@@ -485,26 +375,9 @@ if __name__ == "__main__":
             a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); ab = a.bfloat16()
             t_old = ev_time(lambda: nat.gemm_nt_bf16(a, w))
             line = f"bf16 gemm M={M} N={N} K={K}: fp32-A kernel {t_old:7.1f} us {2.0*M*N*K/t_old/1e6:7.1f} TF/s |"
-            for st, grid, mode in ((4, 0, 0), (2, 512, 0), (2, 768, 0), (4, 0, 1), (4, 0, 2), (2, 512, 1), (2, 512, 2)):
-                for k, v in ((27, st), (28, grid), (29, mode)):
-                    nat.load().sbk_prof_set_knob(k, v)
-                t32 = ev_time(lambda: nat.gemm_nt_bf16a(ab, w))
-                line += f" {st} stages grid {grid or 'cus'} mode {mode}: {t32:7.1f} us {2.0*M*N*K/t32/1e6:7.1f} TF/s |"
-            for k, v in ((27, 2), (28, 0), (29, 0)):
-                nat.load().sbk_prof_set_knob(k, v)
+            t32 = ev_time(lambda: nat.gemm_nt_bf16a(ab, w))
+            line += f" bf16-A LDS-DMA kernel: {t32:7.1f} us {2.0*M*N*K/t32/1e6:7.1f} TF/s |"
             print(line, flush=True)
-        sys.exit(0)
-    if "--sk64" in sys.argv:  # decode-step GEMM shapes (rows = hypotheses in flight): today's paths vs the 64-wide persistent tiles
-        shapes = [(M, N, K) for M in (320, 640, 1280) for (N, K) in ((512, 512), (1536, 512), (2048, 512), (512, 2048), (5000, 512))]
-        for tag, knobs in (("today (skinny / split-K / tile grid)", {25: 0}), ("persistent 64x64, 16 units per workgroup", {25: 1, 26: 16}),
-                           ("persistent 64x64, 8 units", {25: 1, 26: 8}), ("persistent 64x64, 32 units", {25: 1, 26: 32})):
-            for k, v in knobs.items():
-                nat.load().sbk_prof_set_knob(k, v)
-            print("variant:", tag, flush=True)
-            for (M, N, K) in shapes:
-                gemm_case(M, N, K, 8, iters=100)
-        nat.load().sbk_prof_set_knob(25, 0)
-        nat.load().sbk_prof_set_knob(26, 16)
         sys.exit(0)
     if "--copy" in sys.argv:  # what a plain streaming kernel reaches on this box (calibrates the HBM rooflines)
         for mb in (256, 1024, 4096):
@@ -522,19 +395,11 @@ if __name__ == "__main__":
     print("launch overhead (empty-ish layernorm 4 rows):", end=" ")
     x = torch.randn(4, 512, device=dev); g = torch.ones(512, device=dev); bb = torch.zeros(512, device=dev)
     print(f"{timeit(lambda: nat.layernorm(x, g, bb, 1e-5)):.2f} us")
-    for nch in (2,):
-        print("skinny chunks per batch =", nch)
-        nat.load().sbk_prof_set_knob(1, nch)
-        for (M, N, K) in [(320, 512, 512), (320, 1536, 512), (320, 2048, 512), (320, 512, 2048), (320, 5000, 512)]:
-            gemm_case(M, N, K, 8)
-    nat.load().sbk_prof_set_knob(1, 0)
-    print("LDS-tiled kernels for the same shapes")
+    print("decode-step shapes at 320 rows: register-operand (skinny) kernels, then the LDS-tiled ones (knob 2 = 1)")
+    for (M, N, K) in [(320, 512, 512), (320, 1536, 512), (320, 2048, 512), (320, 512, 2048), (320, 5000, 512)]:
+        gemm_case(M, N, K, 8)
     nat.load().sbk_prof_set_knob(2, 1)
     for (M, N, K) in [(320, 512, 512), (320, 1536, 512), (320, 2048, 512), (320, 512, 2048), (320, 5000, 512), (640, 2048, 512), (640, 5000, 512)]:
         gemm_case(M, N, K, 8)
     nat.load().sbk_prof_set_knob(2, 0)
-    for (M, N, K) in [(640, 2048, 512), (640, 5000, 512)]:
-        gemm_case(M, N, K, 8)
     sys.exit(0)
-    for (M, N, K) in [(8032, 512, 512), (8032, 2048, 512), (8032, 512, 2048), (24032, 2048, 512), (24032, 5000, 512)]:
-        gemm_case(M, N, K, 0)
