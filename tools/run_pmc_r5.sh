@@ -4,12 +4,14 @@
 # prescribes) and MFMA busy / clock (one pass).  --pmc only with --kernel-trace.  Output: gpurun_out/pmc_r5_{fetch,write,mfma}.csv
 # + a per-shape summary on stdout.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+# (90 s per pass: a healthy pass takes 10-25 s; in visit R rocprofv3 died at start-up and sat in its signal handler until the
+#  timeout -- two 300-second waits were the round's last GPU minutes, profiles/r05_r_*)
 CMD="python $PWD/tools/microbench.py --r4-pmc"
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   i=$((i+1)); tag=$(echo fetch write mfma | cut -d' ' -f$i)
   [ $i -gt ${PMC_PASSES:-3} ] && break  # (PMC_PASSES=2: the two traffic passes only)
-  (cd /tmp && rm -rf /tmp/pmcx5 && timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pmcx5 -o x -- $CMD > $OLDPWD/gpurun_out/pmc_r5_$tag.log 2>&1)
+  (cd /tmp && rm -rf /tmp/pmcx5 && timeout 90 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pmcx5 -o x -- $CMD > $OLDPWD/gpurun_out/pmc_r5_$tag.log 2>&1)
   f=$(find /tmp/pmcx5 -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/pmc_r5_$tag.csv
 done

@@ -3,11 +3,13 @@
 # decode shape (tools/decode_probe.py: 4 x 32 utterances, T' 430, beam 10 + CTC), FETCH_SIZE and WRITE_SIZE in separate --pmc
 # passes beside --kernel-trace only (MI355X_MICROARCH.md).  Output: gpurun_out/pmc_r5_decode_{fetch,write}.csv + a summary.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+# (90 s per pass: a healthy pass takes 10-25 s; in visit R rocprofv3 died at start-up and sat in its signal handler until the
+#  timeout -- two 300-second waits were the round's last GPU minutes, profiles/r05_r_*)
 CMD="python $PWD/tools/decode_probe.py --steps 8 --reps 1"
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1)); tag=$(echo fetch write | cut -d' ' -f$i)
-  (cd /tmp && rm -rf /tmp/pmcd && timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pmcd -o x -- $CMD > $OLDPWD/gpurun_out/pmc_r5_decode_$tag.log 2>&1)
+  (cd /tmp && rm -rf /tmp/pmcd && timeout 90 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pmcd -o x -- $CMD > $OLDPWD/gpurun_out/pmc_r5_decode_$tag.log 2>&1)
   f=$(find /tmp/pmcd -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/pmc_r5_decode_$tag.csv
 done
