@@ -175,7 +175,7 @@ __device__ __forceinline__ void ctc_frame_range(int prefix_len, int T, const int
 // (already * attn weight); outputs comb = am' + w * (psi - psi_prev) and psi, both [n_bh,V].
 // TPT = 4 takes FOUR CONSECUTIVE vocabulary entries per thread and reads the emissions as float4 (needs V % 4 == 0);
 // TPT = 1 / 2 take entries 256 apart with scalar loads.
-template <int NB, int TPT>  // beams per tile in registers; tokens per thread (each table read feeds NB*TPT FMAs)
+template <int NB, int TPT, bool NT>  // beams per tile in registers; tokens per thread (each table read feeds NB*TPT FMAs); NT: non-temporal loads of P
 __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, const float* __restrict__ P,
                                                              const BF* __restrict__ st, const float* __restrict__ sg,
                                                              const int* __restrict__ se,
@@ -244,11 +244,11 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
       const bool ok = u >= u_begin && u < u_end;
       if constexpr (TPT == 4) {
         float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v4 = *reinterpret_cast<const float4*>(Pb + (size_t)(u + 1) * V + c4);
+        if (ok) v4 = sbk::ld16<NT>(Pb + (size_t)(u + 1) * V + c4);
         buf[0][q] = v4.x; buf[1][q] = v4.y; buf[2][q] = v4.z; buf[3][q] = v4.w;
       } else {
 #pragma unroll
-        for (int k = 0; k < TPT; ++k) buf[k][q] = ok ? Pb[(size_t)(u + 1) * V + cc[k]] : 0.0f;
+        for (int k = 0; k < TPT; ++k) buf[k][q] = ok ? sbk::ld4<NT>(Pb + (size_t)(u + 1) * V + cc[k]) : 0.0f;
       }
     }
   };
@@ -714,12 +714,19 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
   const size_t lds = ((size_t)T * 16 + (size_t)((T + kSeg - 1) / kSeg) * 16) * sizeof(float);
   if (lds > 160 * 1024) return fail(SBK_EINVAL, "ctc_psi_step: T=%d frames need %zu B of LDS (max 160 KiB)", T, lds);
   // utterances beyond ~39 s (T' > 990) need more than the default 64 KiB dynamic-LDS window
+#define SBK_CTC_LAUNCH_NT(NB, TP, NT)                                                                                   \
+  do {                                                                                                                  \
+    if (lds > 64 * 1024 && SBK_ALLOW_DYN_LDS((ctc_score_step_kernel<NB, TP, NT>), lds) != hipSuccess)                    \
+      return fail(SBK_EINVAL, "ctc_psi_step: cannot raise the LDS window to %zu B", lds);                               \
+    SBK_LAUNCH((ctc_score_step_kernel<NB, TP, NT>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg,    \
+               (const int*)v.se, psi);                                                                                  \
+  } while (0)
 #define SBK_CTC_LAUNCH_ONE(NB, TP)                                                                                      \
   do {                                                                                                                  \
-    if (lds > 64 * 1024 && SBK_ALLOW_DYN_LDS((ctc_score_step_kernel<NB, TP>), lds) != hipSuccess)                        \
-      return fail(SBK_EINVAL, "ctc_psi_step: cannot raise the LDS window to %zu B", lds);                               \
-    SBK_LAUNCH((ctc_score_step_kernel<NB, TP>), grid, block, lds, st, a, P, (const BF*)v.st, (const float*)v.sg,        \
-               (const int*)v.se, psi);                                                                                  \
+    if (g_nt_mask & 4)                                                                                                  \
+      SBK_CTC_LAUNCH_NT(NB, TP, true);                                                                                  \
+    else                                                                                                                \
+      SBK_CTC_LAUNCH_NT(NB, TP, false);                                                                                 \
   } while (0)
 #define SBK_CTC_LAUNCH(NB) SBK_CTC_LAUNCH_ONE(NB, 1)
   if (beam == 1) {
@@ -733,6 +740,7 @@ int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, co
   }
 #undef SBK_CTC_LAUNCH
 #undef SBK_CTC_LAUNCH_ONE
+#undef SBK_CTC_LAUNCH_NT
   int rc = launch_status("ctc_score_step");
   if (rc) return rc;
   SBK_LAUNCH(ctc_same_token_kernel, dim3(B * beam), dim3(64), 0, st, a, P, (const float*)v.sb, (const int*)v.se, psi);

@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) cross_attn_step_kernel(CrossAttnArgs a) {
 // and its tile period was the latency of one burst (3.4 us: 92 us per launch at 128 utterances x 430 frames, 2.4 TB/s); the ring
 // has 2 x 8 KB x 4 waves in flight per CU with no barrier: 46 us, 4.8 TB/s (profiles/r05_m_*, r05_n_*).  Partial (context, max,
 // sum) per run of frames -> cross_merge_kernel when an utterance is split into runs.
-template <int D>
+template <int D, bool KNT, bool VNT>  // KNT / VNT: non-temporal loads of the K / V tiles (knob 53, bits 1 / 2)
 __global__ void __launch_bounds__(256) cross_attn_ring_kernel(CrossAttnArgs a, int chunk) {
   const int lane = threadIdx.x & 63, wave = sbk::uniform(threadIdx.x >> 6);
   const int split = blockIdx.x, gw = sbk::uniform(blockIdx.y * 4 + wave);
@@ -386,10 +386,9 @@ __global__ void __launch_bounds__(256) cross_attn_ring_kernel(CrossAttnArgs a, i
     // + ...)); behind a branch it falls back to waiting for everything in flight
     const float* kp = kb + (size_t)min(t0 + tile * 16 + col, klen - 1) * ROW;
 #pragma unroll
-    for (int jq = 0; jq < 4; ++jq) kk[jq] = *reinterpret_cast<const float4*>(kp + 16 * jq);
+    for (int jq = 0; jq < 4; ++jq) kk[jq] = sbk::ld16<KNT>(kp + 16 * jq);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      vv[i] = *reinterpret_cast<const float4*>(vb + (size_t)min(t0 + tile * 16 + 4 * g + i, klen - 1) * ROW);
+    for (int i = 0; i < 4; ++i) vv[i] = sbk::ld16<VNT>(vb + (size_t)min(t0 + tile * 16 + 4 * g + i, klen - 1) * ROW);
   };
   sbk::f32x4 o[4];
 #pragma unroll
@@ -513,7 +512,14 @@ void launch_frames(const CrossAttnArgs& a, int qtiles, hipStream_t st) {
 template <int DH>
 int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
   const int qtiles = (a.beam + kQT - 1) / kQT;
-  sbk::ProfScope prof("cross_attn_step", 4.0 * a.B * a.beam * (double)a.T * a.d, 8.0 * a.B * (double)a.T * a.d, st);
+  // profiler names: "cross_attn_ring" = the register-ring kernel, "cross_attn_step" = the frame-per-thread kernel (a test or the
+  // bench can tell from the report which one a search ran), "cross_merge" = the merge of the runs' partials (a launch of its own)
+  const double pflops = 4.0 * a.B * a.beam * (double)a.T * a.d, pbytes = 8.0 * a.B * (double)a.T * a.d;
+  auto merge = [&](const CrossAttnArgs& c) {
+    sbk::ProfScope pm("cross_merge", 0.0, 4.0 * c.B * c.beam * (double)c.d * (c.NS + 1.0), st);
+    SBK_LAUNCH(cross_merge_kernel, dim3(c.B * c.beam), dim3(256), 0, st, (const float*)c.part, c.out, c.H, c.NS, c.beam, DH, c.d);
+    return sbk::launch_status("cross_merge");
+  };
   if constexpr (DH == 64) {
     // The register-ring / MFMA kernel from 128 (utterance, head) pairs on (knob 4 = 7, default; 5 = always, 0 = never): measured
     // per launch at T' 430, d 512, beam 10 (tools/decode_probe.py, profiles/r05_o_*): 16 utterances 25.1 us against 30.0 for the
@@ -531,20 +537,30 @@ int launch_cross(const CrossAttnArgs& a, hipStream_t st) {
       if (ns > sbk::cdiv(a.T, 16)) ns = sbk::cdiv(a.T, 16);  // (the partial buffer is sized for 16-frame runs)
       const int chunk = sbk::cdiv(sbk::cdiv(a.T, ns), 16) * 16;
       c.NS = sbk::cdiv(a.T, chunk);
-      SBK_LAUNCH(cross_attn_ring_kernel<3>, dim3(c.NS, sbk::cdiv(uh, 4)), dim3(256), 0, st, c, chunk);
-      int rc5 = sbk::launch_status("cross_attn_step");
+      int rc5;
+      {
+        sbk::ProfScope prof("cross_attn_ring", pflops, pbytes, st);
+        const dim3 grid(c.NS, sbk::cdiv(uh, 4));
+        switch (sbk::g_nt_mask & 3) {
+          case 0: SBK_LAUNCH((cross_attn_ring_kernel<3, false, false>), grid, dim3(256), 0, st, c, chunk); break;
+          case 1: SBK_LAUNCH((cross_attn_ring_kernel<3, true, false>), grid, dim3(256), 0, st, c, chunk); break;
+          case 2: SBK_LAUNCH((cross_attn_ring_kernel<3, false, true>), grid, dim3(256), 0, st, c, chunk); break;
+          default: SBK_LAUNCH((cross_attn_ring_kernel<3, true, true>), grid, dim3(256), 0, st, c, chunk); break;
+        }
+        rc5 = sbk::launch_status("cross_attn_ring");
+      }
       if (rc5 || c.NS == 1) return rc5;
-      SBK_LAUNCH(cross_merge_kernel, dim3(a.B * a.beam), dim3(256), 0, st, (const float*)c.part, c.out, c.H, c.NS,
-                 c.beam, DH, c.d);
-      return sbk::launch_status("cross_merge");
+      return merge(c);
     }
   }
-  launch_frames<DH>(a, qtiles, st);
-  int rc = sbk::launch_status("cross_attn_step");
+  int rc;
+  {
+    sbk::ProfScope prof("cross_attn_step", pflops, pbytes, st);
+    launch_frames<DH>(a, qtiles, st);
+    rc = sbk::launch_status("cross_attn_step");
+  }
   if (rc || a.NS == 1) return rc;
-  SBK_LAUNCH(cross_merge_kernel, dim3(a.B * a.beam), dim3(256), 0, st, (const float*)a.part, a.out, a.H, a.NS, a.beam,
-             DH, a.d);
-  return sbk::launch_status("cross_merge");
+  return merge(a);
 }
 
 // ---- head-averaged cross-attention probabilities of ONE decoder layer for the current position: what
@@ -630,6 +646,7 @@ thread_local int g_step_min_steps = 0;
 // Measured alternatives kept behind sbk_prof_set_knob (Conformer-L, B=64, MI355X; cross_attn_step total per
 // 8 batches): frame-per-thread kernel 247 ms with either layout; row-coalesced kernel 336 ms on [B,T,2d],
 // 306 ms on head-major [B,H,T,2*Dh]; at B=128 the MFMA formulation takes 315 ms vs 303 ms.  The defaults stay 0.
+int g_nt_mask = 0;        // key 53: non-temporal loads of streamed-once data: 1 = ring K tiles, 2 = ring V tiles, 4 = CTC posteriors
 int g_cross_rows = 7;     // key 4: 7 (default) = the register-ring / MFMA kernel from 128 (utterance, head) pairs on, else frame-per-thread;
                           // 0 = the frame-per-thread kernel always, 5 = the ring kernel always
 

@@ -179,6 +179,24 @@ __device__ __forceinline__ void glds16_uniform(const float* base, unsigned lane_
       : "v"(lane_byte_offset), "s"(base), "s"(dst)
       : "memory");
 }
+// Loads of data a kernel streams ONCE (the K/V memory of a cross-attention step, the CTC posteriors): NT = the non-temporal cache
+// policy (global_load_dword[x4] ... nt: the line is not kept in the CU's vector L1 and is marked for early eviction in L2 / the
+// Infinity Cache, so that operands other kernels re-use -- weight panels, the residual stream -- survive the stream);
+// false = the default policy.  A template parameter, not a run-time branch: the policy is part of the instruction.
+template <bool NT>
+__device__ __forceinline__ float4 ld16(const float* p) {
+  if constexpr (NT) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    return *reinterpret_cast<const float4*>(p);
+  }
+}
+template <bool NT>
+__device__ __forceinline__ float ld4(const float* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
 // a value the caller knows to be the same in every lane, moved to a scalar register (uniform branches, scalar address math)
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // every outstanding vector-memory operation of this wave has completed (inline asm: the compiler cannot drop it)

@@ -42,6 +42,7 @@ extern int g_persist, g_persist_grid, g_persist_stamps;
 extern thread_local const int32_t* g_step_ptr;
 extern thread_local int g_step_min_steps;  // min_decode_steps of that search (eos floor: step < min_steps)
 extern int g_cross_rows;
+extern int g_nt_mask;
 extern int g_cross_fc256;
 extern int g_x3r_xc;
 extern int g_score_fused;  // key 40: 1 (default) = the step's scoring as one pass per hypothesis row (csrc/search.hip)

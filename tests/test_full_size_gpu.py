@@ -147,6 +147,65 @@ def test_conformer_l_decoder_logprobs_and_search_vs_oracle():
         lib.sbk_prof_set_knob(47, 1)
 
 
+def test_ring_cross_attention_conformer_l_geometry_default_knobs_vs_oracle():
+    """csrc/decoder.hip cross_attn_ring_kernel at the geometry and under the knobs it SHIPS with, inside an
+    oracle comparison on the GPU.  Conformer-L decoder (d 512, 8 heads of 64, 6 layers), 16 utterances = 128 (utterance, head)
+    pairs -- the default routing's threshold (knob 4 = 7) --, memories of T' = 420 frames with lengths 0.45 .. 1 of that, so the
+    default run rule cuts each memory into 4 runs of 112 frames (partials, cross_merge; the short utterances leave EMPTY later
+    runs, the last run of the longest holds 84 frames = 5 tiles + a 4-frame tile), beam 10 (a 16-column MFMA tile with six
+    padding columns), no CTC (the oracle's Python-loop scorer would take minutes).  Then 32 utterances (256 pairs: the other
+    side of the run rule, ns = 4 again but two waves' worth of workgroups per run).  Token ids exact (heads x8), scores 1e-3,
+    teacher-forced decoder outputs 2e-4 -- and the profiler must show that the ring kernel and the merge are what ran."""
+    from speechbrain_amd import native
+
+    asr = _asr("L", beam_size=10, ctc_weight=0.0)
+    _, mc = _oracle_cfg("L")
+    with torch.no_grad():
+        asr.mods.seq_lin.w.weight.mul_(8.0)
+    from speechbrain_amd.inference.builders import flat_state_dict
+
+    sd = flat_state_dict(asr)
+    T = 420
+    for B, steps in ((16, 10), (32, 4)):
+        g = torch.Generator().manual_seed(100 + B)
+        enc = torch.randn(B, T, 512, generator=g)
+        lens = torch.linspace(0.45, 1.0, B)
+        enc_lens = torch.round(T * lens).int()
+        ratio = (steps + 0.5) / T
+        asr.mods.decoder.max_decode_ratio = ratio
+        native.prof_reset()
+        native.prof_enable(True)
+        try:
+            hyps, _, scores, _ = asr.mods.decoder(enc.cuda(), lens.cuda())
+        finally:
+            native.prof_enable(False)
+        rep = native.prof_report()
+        native.prof_reset()
+        assert rep.get("cross_attn_ring", {}).get("count", 0) >= 6 * steps and "cross_attn_step" not in rep, sorted(rep)
+        assert rep.get("cross_merge", {}).get("count", 0) == rep["cross_attn_ring"]["count"], sorted(rep)  # (4 runs per memory: merged)
+        hyps_ref, _, scores_ref, _ = O.beam_search(enc, lens, sd, mc, O.SearchCfg(beam=10, ctc_weight=0.0, max_decode_ratio=ratio))
+        assert hyps == hyps_ref, B
+        L = min(len(h) for h in hyps)
+        assert L >= 3  # (a degenerate hypothesis would make the comparison vacuous)
+        assert float((scores.cpu() - scores_ref).abs().max()) <= 1e-3
+        if B == 16:  # teacher-forced decoder outputs on the search's own best hypotheses (one hypothesis row per memory: 16 x 8 pairs)
+            tgt = torch.tensor([[1] + list(h[: L - 1]) for h in hyps])
+            h = native.DecoderHandle(asr.mods.transformer, asr.mods.seq_lin)
+            lib = native.load()
+            lib.sbk_prof_set_knob(47, 0)  # (16 rows would otherwise run as the persistent few-row step, which has its own attention)
+            native.prof_enable(True)
+            try:
+                pred = native.decoder_prefix(h, tgt.int().cuda(), enc.cuda(), enc_lens.cuda())
+            finally:
+                native.prof_enable(False)
+                lib.sbk_prof_set_knob(47, 1)
+            rep = native.prof_report()
+            native.prof_reset()
+            assert rep.get("cross_attn_ring", {}).get("count", 0) > 0 and rep.get("cross_merge", {}).get("count", 0) > 0, sorted(rep)
+            ref = O.decode(tgt, enc, enc_lens, sd, mc, "Transformer.")
+            assert float((pred.cpu() - ref).abs().max()) <= 2e-4
+
+
 def test_recipe_lm_scorer_search_vs_oracle():
     """a20 at recipe size: Conformer-L + TransformerLM (12 x 768, 12 heads, d_ffn 3072, GELU, post-norm,
     LM temperature 1.15, lm_weight 0.6) + CTC 0.4 (conformer_large.yaml:166-223 ``test_search`` scorers,

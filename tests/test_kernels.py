@@ -1174,16 +1174,13 @@ def test_cross_attention_register_ring_kernel(backend, d_model, nhead, B, T, bea
 
 @pytest.mark.parametrize("d_model,nhead,B,T,beam", [(192, 3, 3, 33, 16), (128, 2, 5, 49, 3), (256, 4, 1, 17, 16), (128, 2, 2, 230, 3), (128, 2, 3, 330, 2)])
 def test_cross_attention_register_ring_kernel_edge_shapes(backend, d_model, nhead, B, T, beam):
-    """cross_attn_ring_kernel at the edges of its index arithmetic (logic check on the emulator; the GPU cases are
-    test_cross_attention_register_ring_kernel -- these shapes were added after the round's last GPU visit): a number of (utterance,
+    """cross_attn_ring_kernel at the edges of its index arithmetic (emulator and GPU): a number of (utterance,
     head) pairs that does not fill the last workgroup (9, 10, 4 waves), a full 16-beam tile and a 3-beam one, memories of 16 k + 1
     frames (a last tile of one frame), utterances shorter than one tile and shorter than the first run (an EMPTY partial for the
     later runs), one run per utterance and two / three runs of >= 100 frames merged by cross_merge (memories of 230 / 330 frames:
     the default run rule cuts a memory only from 200 frames on).  Teacher-forced decoder outputs vs the oracle and the frame-per-thread kernel, then the beam search vs the
     oracle's."""
     nat, dev = backend
-    if dev.type == "cuda":
-        pytest.skip("emulator-only cases (added after the last GPU visit of round 5)")
     from speechbrain_amd.decoders import S2STransformerBeamSearcher
     from speechbrain_amd.inference.builders import build_modules
 

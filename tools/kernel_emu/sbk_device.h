@@ -390,6 +390,10 @@ static inline void glds16_uniform(const float* base, unsigned lane_byte_offset, 
   memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * sbk_emu::cur().lane, reinterpret_cast<const char*>(base) + lane_byte_offset, 16);
 }
 static inline int uniform(int v) { return v; }
+template <bool NT>
+static inline float4 ld16(const float* p) { return *reinterpret_cast<const float4*>(p); }  // (the cache policy has no host meaning)
+template <bool NT>
+static inline float ld4(const float* p) { return *p; }
 template <int MASK, int SIZE>
 static inline void sched_group() {}
 template <int P>
