@@ -195,6 +195,186 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
   }
 }
 
+// ---- self-attention of the new token over SHARED ANCESTRY (head_dim 64, 2 .. 16 beams per utterance, no key mask): a WAVE = one
+// (utterance, head) and ALL of its beams.  The beams of an utterance descend from few common ancestors: at position p their `beam`
+// ancestry slots kv_slot[.][p] name 1 .. beam DISTINCT cache rows (one or two for all but the newest positions), and the kernel
+// above asks for every one of them once per beam (5.2 MB of row requests per prefix token and launch at 1 280 hypotheses:
+// it is bound by the number of requests it issues).  Here the wave first lists the distinct (slot, position)
+// rows of its utterance -- a lane per position compares the beams' slots, a wave scan packs the list into LDS together with a
+// 16-bit mask of the beams that descend from each row; the new token's own K / V rows (one per beam, read from qkv) close the
+// list --, then walks the list exactly like cross_attn_ring_kernel walks a run of memory frames: tiles of 16 rows straight into
+// MFMA operand registers D tiles deep, transposed scores S^T[row][beam] = K Q^T and context O^T += V^T P^T on
+// v_mfma_f32_16x16x4_f32, online softmax -- a (row, beam) pair whose beam does not descend from the row is masked to -inf
+// (probability exactly 0), so every beam's softmax runs over exactly its own prefix.  Each distinct row is fetched ONCE.
+// The wave also appends the new token's K / V head slices to the cache (slot = hypothesis index), as the kernel above does.
+template <int D>
+__global__ void __launch_bounds__(256) self_attn_anc_kernel(SelfAttnArgs a, int cap) {
+  SBK_DYN_LDS(float, lds);  // [4 waves][cap] x int2 {packed row, beam mask}
+  if (a.step_ptr) a.step = a.step_ptr[0];
+  const int lane = threadIdx.x & 63, wave = sbk::uniform(threadIdx.x >> 6);
+  const int beam = a.group, U = a.n / beam, gw = sbk::uniform(blockIdx.x * 4 + wave);
+  if (gw >= U * a.H) return;  // (no workgroup barrier anywhere below)
+  const int u = gw / a.H, h = gw - u * a.H;
+  const int d = a.d, step = a.step, Lmax = a.Lmax;
+  int2* rows = reinterpret_cast<int2*>(lds) + (size_t)wave * cap;
+  const int col = lane & 15, g = lane >> 4;
+  const size_t hoff = (size_t)h * 64;
+  // the new token's K / V head slices -> cache rows [hypothesis][step]
+  for (int j = 0; j < beam; ++j) {
+    const size_t i = (size_t)u * beam + j;
+    const float* src = a.qkv + i * 3 * d + d + hoff;
+    const size_t o = (i * Lmax + step) * d + hoff + lane;
+    a.kcache[o] = src[lane];
+    a.vcache[o] = src[d + lane];
+  }
+  // distinct (slot, position) rows of the utterance's prefixes, in position order
+  int nrows = 0;
+  for (int p0 = 0; p0 < step; p0 += 64) {
+    const int p = p0 + lane;
+    const bool act = p < step;
+    int sl[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sl[j] = (act && j < beam) ? a.kv_slot[((size_t)u * beam + j) * Lmax + p] : -1 - j;
+    unsigned msk[16];
+    unsigned first = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      unsigned m = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) m |= (sl[k] == sl[j]) ? (1u << k) : 0u;
+      msk[j] = m;
+      if (act && j < beam && (m & ((1u << j) - 1u)) == 0u) first |= 1u << j;  // no earlier beam names the same row
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cnt += (first >> j) & 1;
+    int incl = cnt;  // inclusive scan over the lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = sbk::shfl(incl, lane >= off ? lane - off : lane);
+      if (lane >= off) incl += t;
+    }
+    int w = nrows + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if ((first >> j) & 1) rows[w++] = make_int2((sl[j] << 12) | p, (int)msk[j]);
+    nrows += sbk::shfl(incl, 63);
+  }
+  if (lane < beam) rows[nrows + lane] = make_int2((lane << 12) | step, 1 << lane);  // the new token itself: qkv row of beam `lane`
+  nrows += beam;
+  sbk::wave_sync();
+  // row record -> address of the row's K head slice (V: the same offset in vcache, or + d inside qkv)
+  auto kaddr = [&](int rec, const float*& kp, const float*& vp) SBK_INLINE_LAMBDA {
+    const int pos = rec & 4095, slot = rec >> 12;
+    if (pos == step) {
+      kp = a.qkv + ((size_t)u * beam + slot) * 3 * d + d + hoff;
+      vp = kp + d;
+    } else {
+      const size_t o = ((size_t)slot * Lmax + pos) * d + hoff;
+      kp = a.kcache + o;
+      vp = a.vcache + o;
+    }
+  };
+  float qf[16];
+  {
+    const float* qp = a.qkv + ((size_t)u * beam + min(col, beam - 1)) * 3 * d + hoff + 4 * g;
+    const float qs = col < beam ? a.scale : 0.0f;
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {
+      const float4 t = *reinterpret_cast<const float4*>(qp + 16 * jq);
+      qf[4 * jq] = t.x * qs, qf[4 * jq + 1] = t.y * qs, qf[4 * jq + 2] = t.z * qs, qf[4 * jq + 3] = t.w * qs;
+    }
+  }
+  const int ntiles = (nrows + 15) / 16;
+  float4 kr[D][4], vr[D][4];
+  int vm[D][4];  // beam masks of the rows 4 g + i of the tile (0 past the list)
+  auto fetch = [&](float4(&kk)[4], float4(&vv)[4], int(&mm)[4], int tile) SBK_INLINE_LAMBDA {
+    const float *kp, *vp;
+    kaddr(rows[min(tile * 16 + col, nrows - 1)].x, kp, vp);
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) kk[jq] = *reinterpret_cast<const float4*>(kp + 4 * g + 16 * jq);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = tile * 16 + 4 * g + i;
+      const int2 rec = rows[min(r, nrows - 1)];
+      kaddr(rec.x, kp, vp);
+      vv[i] = *reinterpret_cast<const float4*>(vp + 4 * col);
+      mm[i] = r < nrows ? rec.y : 0;
+    }
+  };
+  sbk::f32x4 o[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[ct][r] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+  auto consume = [&](const float4(&kk)[4], const float4(&vv)[4], const int(&mm)[4]) SBK_INLINE_LAMBDA {
+    sbk::f32x4 sc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc[r] = 0.0f;
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {
+      sc = sbk::mfma_16x16x4(kk[jq].x, qf[4 * jq], sc);
+      sc = sbk::mfma_16x16x4(kk[jq].y, qf[4 * jq + 1], sc);
+      sc = sbk::mfma_16x16x4(kk[jq].z, qf[4 * jq + 2], sc);
+      sc = sbk::mfma_16x16x4(kk[jq].w, qf[4 * jq + 3], sc);
+    }
+    float mt = -INFINITY;  // sc[r] = score of (row 4 g + r of the tile, beam col)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (!((mm[r] >> col) & 1)) sc[r] = -INFINITY;
+      mt = fmaxf(mt, sc[r]);
+    }
+    mt = fmaxf(mt, sbk::shfl_xor(mt, 16));
+    mt = fmaxf(mt, sbk::shfl_xor(mt, 32));
+    const float m_new = fmaxf(m_run, mt);  // -inf while the beam has met none of its rows (a tile of other beams' rows)
+    const float alpha = m_new == -INFINITY ? 1.0f : expf(m_run - m_new);
+    float pr[4], ps = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pr[r] = sc[r] == -INFINITY ? 0.0f : expf(sc[r] - m_new);
+      ps += pr[r];
+    }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[ct][r] *= alpha;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[0] = sbk::mfma_16x16x4(vv[i].x, pr[i], o[0]);
+      o[1] = sbk::mfma_16x16x4(vv[i].y, pr[i], o[1]);
+      o[2] = sbk::mfma_16x16x4(vv[i].z, pr[i], o[2]);
+      o[3] = sbk::mfma_16x16x4(vv[i].w, pr[i], o[3]);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s) fetch(kr[s], vr[s], vm[s], s);  // (tiles past the list re-read its last row, masks 0)
+  int k0 = 0;
+  for (; k0 + D <= ntiles; k0 += D) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      fetch(kr[(s + D - 1) % D], vr[(s + D - 1) % D], vm[(s + D - 1) % D], k0 + s + D - 1);
+      sbk::sched_fence();
+      consume(kr[s], vr[s], vm[s]);
+      sbk::sched_fence();
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s)
+    if (k0 + s < ntiles) consume(kr[s], vr[s], vm[s]);
+  float l_tot = l_run + sbk::shfl_xor(l_run, 16);
+  l_tot += sbk::shfl_xor(l_tot, 32);
+  if (col < beam) {
+    float* op = a.out + ((size_t)u * beam + col) * d + hoff + 16 * g;
+    const float inv = 1.0f / l_tot;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<float4*>(op + 4 * r) = make_float4(o[0][r] * inv, o[1][r] * inv, o[2][r] * inv, o[3][r] * inv);
+  }
+}
+
 // ---------------------------------------------------------------- cross attention, all beams of an utterance
 constexpr int kQT = 16;   // queries (beams) served per workgroup
 constexpr int kFC = 128;  // memory frames per workgroup (flash-decoding style split of the memory)
@@ -646,7 +826,8 @@ thread_local int g_step_min_steps = 0;
 // Measured alternatives kept behind sbk_prof_set_knob (Conformer-L, B=64, MI355X; cross_attn_step total per
 // 8 batches): frame-per-thread kernel 247 ms with either layout; row-coalesced kernel 336 ms on [B,T,2d],
 // 306 ms on head-major [B,H,T,2*Dh]; at B=128 the MFMA formulation takes 315 ms vs 303 ms.  The defaults stay 0.
-int g_nt_mask = 0;        // key 53: non-temporal loads of streamed-once data: 1 = ring K tiles, 2 = ring V tiles, 4 = CTC posteriors
+int g_self_anc = 1;       // key 55: 1 (default) = self-attention of a decoding step over shared ancestry (self_attn_anc_kernel), 0 = a wave per (hypothesis, head)
+int g_nt_mask = 7;        // key 53: non-temporal loads of streamed-once data: 1 = ring K tiles, 2 = ring V tiles, 4 = CTC posteriors
 int g_cross_rows = 7;     // key 4: 7 (default) = the register-ring / MFMA kernel from 128 (utterance, head) pairs on, else frame-per-thread;
                           // 0 = the frame-per-thread kernel always, 5 = the ring kernel always
 
@@ -666,6 +847,17 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
   if (group < 1 || n % group != 0) group = 1;
   SelfAttnArgs a{qkv, kcache, vcache, kv_slot, out, n, d, H, d / H, step, nslot, Lmax, 1.0f / sqrtf((float)(d / H)),
                  g_step_ptr, key_tok, key_stride, key_shift, key_first, pad_idx, group};
+  // beams of an utterance share their ancestry: each distinct cache row fetched once per (utterance, head) (knob 55, default on)
+  if (g_self_anc && group >= 2 && group <= 16 && d == H * 64 && !key_tok && nslot < (1 << 19) && Lmax < 4096 && aligned16(qkv) &&
+      aligned16(kcache) && aligned16(vcache) && aligned16(out) && d % 4 == 0) {
+    const int cap = (Lmax + 1) * group;  // every row distinct
+    const size_t lds_anc = (size_t)4 * cap * sizeof(int2);
+    if (lds_anc <= 64 * 1024) {
+      ProfScope prof("self_attn_anc", 4.0 * n * d * (step + 1), 8.0 * n * d * (step + 1), st);
+      SBK_LAUNCH(self_attn_anc_kernel<3>, dim3(cdiv((n / group) * H, 4)), dim3(256), lds_anc, st, a, cap);
+      return launch_status("self_attn_anc");
+    }
+  }
   const size_t lds = (size_t)8 * (((Lmax + 63) / 64) * 64) * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "self_attn_step: Lmax=%d too long for the LDS window", Lmax);
   ProfScope prof("self_attn_step", 4.0 * n * d * (step + 1), 8.0 * n * d * (step + 1), st);

@@ -1419,6 +1419,8 @@ extern "C" void sbk_prof_set_knob(int key, int value) {
   if (key == 4) sbk::g_cross_rows = value;
   if (key == 8) sbk::g_cross_fc256 = value;
   if (key == 53) sbk::g_nt_mask = value;
+  if (key == 54) sbk::g_x3r_probe = value;
+  if (key == 55) sbk::g_self_anc = value;
   if (key == 51) sbk::g_x3r_xc = value;
   if (key == 14) sbk::g_tiled_splitk = value;
   if (key == 18) sbk::g_sk_mode = value;

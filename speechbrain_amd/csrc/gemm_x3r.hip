@@ -267,6 +267,19 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
   }
 }
 
+// MEASUREMENT ONLY (knob 54 = 2 / 3): every XCD reads the whole buffer once (workgroup b runs on XCD b % 8 and takes slice b / 8
+// of 32), so that the launch behind it finds the operand in its XCD's L2 -- prices what a projection loses to cold operands
+// inside a decoding step (profiles/r06_b_*).  `sink` is never written (the sum of finite values is not NaN-compared true).
+__global__ void __launch_bounds__(256) x3r_touch_kernel(const uint4* __restrict__ p, size_t n16, unsigned* __restrict__ sink) {
+  const size_t per = (n16 + 31) / 32, b0 = (size_t)(blockIdx.x >> 3) * per, b1 = b0 + per < n16 ? b0 + per : n16;
+  unsigned acc = 0;
+  for (size_t i = b0 + threadIdx.x; i < b1; i += 256) {
+    const uint4 v = p[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9e3779b9u && n16 == 1) *sink = acc;
+}
+
 }  // namespace
 
 namespace sbk {
@@ -280,6 +293,9 @@ bool x3r_routed(int M, int N, int K) { return g_x3r_mode != 0 && M >= g_x3r_min_
 // prologue from a pre-pass over the rows (gemm_ln_nt_x3r; the vocabulary projection only below 4 096 columns: every column
 // tile repeats the statistics), 2 = the same, wide vocabularies included
 int g_x3r_ln = 1;
+int g_x3r_probe = 0;  // key 54, MEASUREMENT ONLY (results of in-place launches are wrong with 1): 1 = every launch is issued twice, the second under the
+                      // profiler name *_rep (its operands are where the first left them); 2 = the weight panel is read into every XCD's L2 by a
+                      // launch in front ("x3r_touch"); 3 = the panel and the A rows
 int g_x3r_xc = 0;  // key 51: column groups among the XCDs (1 / 2 / 4 / 8; 0 = the count that minimises the fabric traffic)
 
 // A fp32 [M, K] (row stride lda); ln_eps >= 0: the operand is LayerNorm(A) over K with the affine folded into (PW, bias), row
@@ -300,7 +316,16 @@ static int launch_x3r(const float* A, int lda, const uint16_t* PW, const float* 
       if (c * ab + (8 / c) * wb < xc * ab + (8 / xc) * wb) xc = c;
   }
   X3rArgs a{A, reinterpret_cast<const uint4*>(PW), bias, R, C, K / 64, lda, ldr, ldc, M, N, K, act, tm, tn, alpha, ln_eps, xc};
-  ProfScope prof(ln ? "gemm_ln_x3r" : "gemm_x3r", 2.0 * M * N * K,
+  if (g_x3r_probe >= 2) {
+    ProfScope pt("x3r_touch", 0.0, 8.0 * 6.0 * (double)N * K, st);
+    SBK_LAUNCH(x3r_touch_kernel, dim3(256), dim3(256), 0, st, reinterpret_cast<const uint4*>(PW), (size_t)N * K * 6 / 16, (unsigned*)nullptr);
+    if (g_x3r_probe == 3 && lda == K)
+      SBK_LAUNCH(x3r_touch_kernel, dim3(256), dim3(256), 0, st, reinterpret_cast<const uint4*>(A), (size_t)M * K * 4 / 16, (unsigned*)nullptr);
+  }
+  const int reps = g_x3r_probe == 1 ? 2 : 1;
+  int rc_last = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+  ProfScope prof(rep ? (ln ? "gemm_ln_x3r_rep" : "gemm_x3r_rep") : (ln ? "gemm_ln_x3r" : "gemm_x3r"), 2.0 * M * N * K,
                  4.0 * M * (double)K + 6.0 * (double)N * K + (4.0 + (R ? 4.0 : 0.0)) * M * (double)N, st);
   dim3 grid(8 * cdiv(tm, 8 / xc) * cdiv(tn, xc)), block(256);
   if (ln) {
@@ -313,14 +338,18 @@ static int launch_x3r(const float* A, int lda, const uint16_t* PW, const float* 
     } else {
       SBK_LAUNCH((gemm_x3r_kernel<0, 5>), grid, block, 0, st, a);
     }
-    return launch_status("gemm_ln_x3r");
-  }
-  if (K == 512 && N >= 1024 && g_x3r_mode != 3) {
-    SBK_LAUNCH((gemm_x3r_kernel<8>), grid, block, 0, st, a);
+    rc_last = launch_status("gemm_ln_x3r");
   } else {
-    SBK_LAUNCH((gemm_x3r_kernel<0>), grid, block, 0, st, a);
+    if (K == 512 && N >= 1024 && g_x3r_mode != 3) {
+      SBK_LAUNCH((gemm_x3r_kernel<8>), grid, block, 0, st, a);
+    } else {
+      SBK_LAUNCH((gemm_x3r_kernel<0>), grid, block, 0, st, a);
+    }
+    rc_last = launch_status("gemm_x3r");
   }
-  return launch_status("gemm_x3r");
+  if (rc_last) return rc_last;
+  }
+  return rc_last;
 }
 int gemm_nt_x3r(const float* A, int lda, const uint16_t* PW, const float* bias, const float* R, int ldr, float* C, int ldc, int M,
                 int N, int K, int act, float alpha, hipStream_t st) {

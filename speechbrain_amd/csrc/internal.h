@@ -25,7 +25,7 @@ bool x3r_routed(int M, int N, int K);
 int gemm_ln_nt_x3r(const float* A, int lda, const uint16_t* PWf, const float* bf, const float* R, int ldr, float* C, int ldc, int M,
                    int N, int K, float eps, int act, float alpha, hipStream_t st);
 bool x3r_ln_routed(int K);
-extern int g_x3r_mode, g_x3r_min_rows, g_x3r_ln;
+extern int g_x3r_mode, g_x3r_min_rows, g_x3r_ln, g_x3r_probe;
 // The decoding step of <= 16 hypothesis rows as ONE cooperative launch (csrc/decoder_persist.hip; keys 47 / 48).
 // persist_eligible: shapes / weights it takes (head_dim 64, folded LayerNorm weights present, <= 16 layers); decoder_step_persist
 // returns -1 when the launch cannot be made (the caller then issues the launch-per-operation step).
@@ -43,6 +43,7 @@ extern thread_local const int32_t* g_step_ptr;
 extern thread_local int g_step_min_steps;  // min_decode_steps of that search (eos floor: step < min_steps)
 extern int g_cross_rows;
 extern int g_nt_mask;
+extern int g_self_anc;
 extern int g_cross_fc256;
 extern int g_x3r_xc;
 extern int g_score_fused;  // key 40: 1 (default) = the step's scoring as one pass per hypothesis row (csrc/search.hip)

@@ -252,9 +252,10 @@ def test_bench_traffic_rows_of_this_rounds_kernels_only(tmp_path):
 
     import bench
 
-    rows = {"_source": "test", "gemm_x3r": {"round": 5, "bytes_per_launch": 100, "algorithmic_bytes_per_launch": 40, "note": "n", "commit": "c"},
-            "gemm_nt_x3p": {"round": 4, "bytes_per_launch": 7, "algorithmic_bytes_per_launch": 3, "note": "old"},
-            "_mfma_busy": {"gemm_x3r M=1": {"round": 5, "mfma_busy": 0.25}, "gemm_x3r M=2": {"round": 4, "mfma_busy": 0.5}}}
+    now = bench.PMC_ROUND
+    rows = {"_source": "test", "gemm_x3r": {"round": now, "bytes_per_launch": 100, "algorithmic_bytes_per_launch": 40, "note": "n", "commit": "c"},
+            "gemm_nt_x3p": {"round": now - 1, "bytes_per_launch": 7, "algorithmic_bytes_per_launch": 3, "note": "old"},
+            "_mfma_busy": {"gemm_x3r M=1": {"round": now, "mfma_busy": 0.25}, "gemm_x3r M=2": {"round": now - 1, "mfma_busy": 0.5}}}
     f = tmp_path / "pmc.json"
     f.write_text(json.dumps(rows))
     roof = {}
@@ -268,6 +269,6 @@ def test_bench_traffic_rows_of_this_rounds_kernels_only(tmp_path):
     assert bench.pmc_traffic("gemm_x3r", roof, str(f)) is None
     assert "not measured for the kernel as shipped" in roof["traffic_note"] and "100 B/launch" in roof["traffic_note"]
     roof = {}
-    bench.pmc_traffic("gemm_x3r", roof)  # the committed file
-    assert "traffic_note" in roof and "traffic_provenance" in roof
+    t = bench.pmc_traffic("gemm_x3r", roof)  # the committed file: this round's row of the kernel as shipped
+    assert "traffic_note" in roof and "traffic_provenance" in roof and t and t > 9437184 and roof["mfma_busy_pmc"]
 

@@ -1226,6 +1226,59 @@ def test_cross_attention_register_ring_kernel_edge_shapes(backend, d_model, nhea
         lib.sbk_prof_set_knob(47, 1)
 
 
+@pytest.mark.parametrize("d_model,nhead,B,beam,steps", [(128, 2, 3, 10, 70), (128, 2, 2, 16, 40), (192, 3, 5, 2, 20), (128, 2, 1, 3, 130)])
+def test_self_attention_over_shared_ancestry(backend, d_model, nhead, B, beam, steps):
+    """csrc/decoder.hip self_attn_anc_kernel (head_dim 64, 2 .. 16 beams: a wave per (utterance, head) lists the DISTINCT (slot,
+    position) cache rows of its beams' prefixes with a mask of the beams descending from each, fetches every row once and scores
+    it against all beams on the matrix cores; a (row, beam) pair outside the beam's ancestry is masked to probability 0) through the
+    beam search: token ids and scores against the oracle's full-prefix search and against the wave-per-(hypothesis, head) kernel
+    (knob 55 = 0) -- prefixes longer than 64 positions (two passes of the list builder, > 3 tiles: whole rounds of the register
+    ring), a full 16-beam tile, 2 and 3 beams (masks with few bits), 5 utterances x 3 heads = 15 waves (a partial last workgroup),
+    130 steps with 3 beams (rows of other beams fill whole tiles: the -inf guard of the online softmax)."""
+    nat, dev = backend
+    from speechbrain_amd.decoders import S2STransformerBeamSearcher
+    from speechbrain_amd.inference.builders import build_modules
+
+    mods = build_modules(dict(d_model=d_model, nhead=nhead, d_ffn=128, n_enc=1, n_dec=2, n_fft=400, win_length=25), vocab=40, seed=beam)
+    tr, seq = mods["Transformer"].to(dev).eval(), mods["seq_lin"].to(dev).eval()
+    with torch.no_grad():
+        seq.w.weight.mul_(4.0)
+    sd = {"Transformer." + k: v.detach().cpu() for k, v in tr.state_dict().items()}
+    sd["seq_lin.w.weight"], sd["seq_lin.w.bias"] = seq.w.weight.detach().cpu(), seq.w.bias.detach().cpu()
+    cfg = O.ModelCfg(d_model=d_model, nhead=nhead, num_encoder_layers=1, num_decoder_layers=2, d_ffn=128, vocab=40)
+    gen = torch.Generator().manual_seed(steps + beam)
+    T = 24
+    enc = torch.randn(B, T, d_model, generator=gen) * 1.5
+    wl = torch.tensor([1.0, 0.7, 0.9, 0.5, 0.8][:B])
+    ratio, min_ratio = (steps + 0.5) / T, (steps - 4.5) / T  # (<eos> is barred until the last steps: every prefix grows to ~steps tokens)
+    hyps_ref, _, sc_ref, _ = O.beam_search(enc, wl, sd, cfg, O.SearchCfg(beam=beam, ctc_weight=0.0, max_decode_ratio=ratio, min_decode_ratio=min_ratio))
+    bs = S2STransformerBeamSearcher(modules=[tr, seq], bos_index=1, eos_index=2, min_decode_ratio=min_ratio, max_decode_ratio=ratio,
+                                    beam_size=beam, using_eos_threshold=False, length_normalization=True)
+    lib = nat.load()
+    lib.sbk_prof_set_knob(47, 0)  # (not the persistent few-row step, which has its own attention)
+    try:
+        got = {}
+        for anc in (1, 0):
+            lib.sbk_prof_set_knob(55, anc)
+            nat.prof_reset()
+            nat.prof_enable(True)
+            try:
+                hyps, _, sc, _ = bs(enc.to(dev), wl.to(dev))
+            finally:
+                nat.prof_enable(False)
+            rep = nat.prof_report()
+            nat.prof_reset()
+            assert ("self_attn_anc" in rep) == (anc == 1) and ("self_attn_step" in rep) == (anc == 0), sorted(rep)
+            got[anc] = (hyps, sc.cpu())
+            assert hyps == hyps_ref, anc
+            assert float((sc.cpu() - sc_ref).abs().max()) <= 1e-4, anc
+        assert min(len(h) for h in got[1][0]) >= steps - 6  # (long prefixes were actually decoded)
+        assert float((got[1][1] - got[0][1]).abs().max()) <= 2e-5
+    finally:
+        lib.sbk_prof_set_knob(55, 1)
+        lib.sbk_prof_set_knob(47, 1)
+
+
 @pytest.mark.parametrize("M,N,K", [(70, 50, 48), (300, 130, 64), (5000, 300, 80)])
 def test_gemm_fp16_and_fp8_operands(backend, M, N, K):
     """sbk_gemm_nt_f16 / sbk_gemm_nt_fp8 (SURVEY 8b "fp16 / fp8 fast entry points"): the kernels must equal the fp32

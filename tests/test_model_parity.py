@@ -321,7 +321,7 @@ def test_persistent_few_row_decoding_step_vs_oracle_and_the_launch_per_operation
                 (hyps0, _, sc0, _), rep0 = run(lambda: bs(e.to(dev), w.to(dev)))
             finally:
                 lib.sbk_prof_set_knob(47, 1)
-            assert "decoder_step_persist" not in rep0 and "self_attn_step" in rep0, (tag, sorted(rep0))
+            assert "decoder_step_persist" not in rep0 and ("self_attn_step" in rep0 or "self_attn_anc" in rep0), (tag, sorted(rep0))
             assert hyps0 == hyps and float((sc0 - sc).abs().max()) <= 2e-5, tag
         # another grid: fewer workgroups than column tiles / attention items (every loop over tiles and items runs more than once)
         e, w = enc[:1], wl[:1]

@@ -32,6 +32,7 @@ struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
