@@ -947,6 +947,12 @@ def main():
         one = ConcurrentTranscriber(asr, streams=1, prioritise_search=False, group=auto(args.max_batch)[1])
         one.group_encoder = args.group_encoder
         one.plan_workers = auto(args.max_batch)[0]  # the same groups as the eight workers formed
+        # every launch ALONE between its two events: a single worker would otherwise run the CTC scorer on a helper stream
+        # (overlap_ctc = 3), and the layer-0 launches that co-run with the 250-us ctc_score_step were counted at 100-200 us each
+        # -- rounds 4-5 reported gemm_x3r at 27-28 us per launch for what the device timeline shows at 13-35 us
+        # (profiles/r06_c_*).  The timed region's workers run with overlap_ctc = 0 as well.
+        for srch in one.searchers:
+            srch.overlap_ctc = 0 if args.overlap_ctc < 0 else args.overlap_ctc
         seq_out = one.transcribe_batches([(t[1], t[2]) for t in local_batches], prepare=fixed_decode_length)
         one.close()
         # determinism of the headline's execution mode: the same batches, in the same groups, one after the other on ONE

@@ -169,6 +169,11 @@ __device__ __forceinline__ void ctc_frame_range(int prefix_len, int T, const int
     *end = min(T, win[1] + window);
   }
 }
+// The frames of an utterance past its own length hold P = 1 for token 0 and EXACTLY 0 for every other token (ctc_emissions_kernel:
+// the reference's frame mask), so they add exact zeros to the score of every token but 0 -- and when token 0 is the blank, its
+// score is overwritten in any case (the blank column / the <eos> rule).  The frame loops of the score kernels therefore stop at
+// the utterance's own length: bit-identical results, fewer bytes for the shorter utterances of a padded batch.
+__device__ __forceinline__ int ctc_clip_to_length(int end, int blank, int len) { return blank == 0 ? min(end, max(len, 1)) : end; }
 
 // P [B,T,V] masked linear posteriors; sg [n_bh,T] / se [n_bh,nseg] segment-scaled gamma tables
 // (uniform per workgroup: fetched through the scalar cache); am [n_bh,V] acoustic log-probs
@@ -199,6 +204,7 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   const int nseg = nseg_of(T);
   int start, end;
   ctc_frame_range(a.prefix_len, T, a.win, a.window, &start, &end);
+  end = ctc_clip_to_length(end, a.blank, a.enc_len[b]);
   const float* Pb = P + (size_t)b * T * V;
   const int last_frame = a.enc_len[b] - 1;
   // the utterance's scaled gamma table [T][16] and segment exponents [nseg][16] -> LDS (coalesced copy);
@@ -326,6 +332,7 @@ __global__ void __launch_bounds__(64) ctc_same_token_kernel(CtcStepArgs a, const
   if (c == a.eos || c == a.blank || c < 0 || c >= V) return;  // those entries are overridden anyway
   int start, end;
   ctc_frame_range(a.prefix_len, T, a.win, a.window, &start, &end);
+  end = ctc_clip_to_length(end, a.blank, a.enc_len[b]);
   const float* Pb = P + (size_t)b * T * V;
   // per-lane block-float partial over its frames, then a wave reduction on a common exponent
   float m = 0.0f;

@@ -24,6 +24,11 @@
 
 #include "internal.h"
 
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
 namespace {
 
 constexpr int kPRows = 16;        // hypothesis rows a launch serves (the MFMA tile height)
@@ -433,6 +438,53 @@ static int g_last_stamp_count = 0;
 // grid barriers of one launch: 1 (embedding) + 8 per layer
 int persist_barriers(int n_layers) { return 1 + 8 * n_layers; }
 
+// What a launch of this model needs and whether this device can make it: dynamic LDS of a workgroup, the LDS window raised, the
+// largest co-resident grid, the architecture the hand-over protocol was validated on.  Cached per (device, LDS bytes): the graph
+// decision of a search (persist_eligible) and every step (decoder_step_persist) read the SAME answer, and the occupancy query
+// runs once, not per step.
+struct PersistPlan {
+  int dev;
+  size_t lds;
+  int maxg;  // 0 = not feasible on this device
+};
+static std::mutex g_plan_mu;
+static std::vector<PersistPlan> g_plans;
+
+static size_t persist_lds_bytes(const sbk_decoder_weights* W, int Lmax) {
+  const int d = W->d_model, Kmax = d > W->d_ffn ? d : W->d_ffn;
+  size_t region = (size_t)kPRows * (Kmax + 4);
+  const size_t attn = 8 + 256 + (size_t)Lmax + 64;  // attn_item: wave maxima / sums / contexts + the row's cache slots
+  if (region < attn) region = attn;
+  // (the region is sized for the rows AND the attention scratch; red follows the rows' extent)
+  return (region + 1024 + 64) * sizeof(float);
+}
+
+static int persist_max_grid(const sbk_decoder_weights* W, int Lmax, size_t* lds_out) {
+  const size_t lds = persist_lds_bytes(W, Lmax);
+  if (lds_out) *lds_out = lds;
+  if (lds > 160 * 1024 - 512) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  for (const PersistPlan& p : g_plans)
+    if (p.dev == dev && p.lds == lds) return p.maxg;
+  PersistPlan p{dev, lds, 0};
+  hipDeviceProp_t prop;
+  // agent-scope relaxed accesses + a drained vmcnt as the hand-over between workgroups is outside the HIP memory model: it is
+  // what gfx950 does (tools/persist_probe.hip, profiles/r05_a_*), so the path is offered on that architecture only
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0 &&
+      SBK_ALLOW_DYN_LDS(decoder_step_persist_kernel, 160 * 1024 - 512) == hipSuccess) {
+    int maxg = 0;
+    if (SBK_COOP_MAX_GRID(decoder_step_persist_kernel, 256, lds, maxg) == hipSuccess && maxg >= 1) p.maxg = maxg;
+  }
+  if (p.maxg == 0) (void)hipGetLastError();  // (a failed query must not surface in the next launch_status())
+  g_plans.push_back(p);
+  return p.maxg;
+}
+
 bool persist_eligible(const sbk_decoder_weights* W, int n, int B, int beam, int Lmax) {
   if (!g_persist || n < 1 || n > kPRows || beam < 1 || beam > kPRows || B * beam != n) return false;
   const int d = W->d_model;
@@ -446,16 +498,19 @@ bool persist_eligible(const sbk_decoder_weights* W, int n, int B, int beam, int 
           aligned16(L.ff2_w)))
       return false;
   }
-  return Lmax <= 16384;
+  return Lmax <= 16384 && persist_max_grid(W, Lmax, nullptr) >= 1;
 }
 
 // One decoder step for n <= 16 hypothesis rows (n = B * beam) at position `step`: d.x .. d.logits as decoder_step leaves
 // them (the final LayerNorm output in h, the seq_lin logits when want_logits).  bar / bar_seq: the search's barrier counter
-// (zero when the search starts) and the number of persistent launches issued on it so far.
+// (zero when the search starts) and the number of persistent launches issued on it so far.  grid_io: the search's grid (0 = not
+// chosen yet): chosen by the FIRST launch of a search and kept for all of them -- the barrier targets are bar_seq * barriers * G,
+// so a grid that changed between two launches (knob 48, another occupancy answer) would leave the counter past every target and
+// every barrier would fall through.
 int decoder_step_persist(const sbk_decoder_weights* W, const int32_t* tokens, const int32_t* kv_slot, const int32_t* enc_len,
                          float* x, float* qkv, float* ctx, float* q, float* ff, float* h, float* logits, float* const* kcache,
-                         float* const* vcache, float* const* ckv, int* bar, int bar_seq, int step, int n, int B, int T, int beam,
-                         int Lmax, bool want_logits, hipStream_t st) {
+                         float* const* vcache, float* const* ckv, int* bar, int bar_seq, int* grid_io, int step, int n, int B, int T,
+                         int beam, int Lmax, bool want_logits, hipStream_t st) {
   PStepArgs a;
   // (bar points at 64 ints; the stamps live behind them in the same carve: 256 x 8 bytes)
   a.stamps = g_persist_stamps ? reinterpret_cast<long long*>(bar + 64) : nullptr;
@@ -478,25 +533,15 @@ int decoder_step_persist(const sbk_decoder_weights* W, const int32_t* tokens, co
   a.step = step; a.Lmax = Lmax; a.act = W->ffn_act; a.want_logits = want_logits && W->seq_wf ? 1 : 0;
   a.eps = W->ln_eps; a.emb_scale = W->emb_scale > 0.0f ? W->emb_scale : sqrtf((float)d);
   a.attn_scale = 1.0f / sqrtf(64.0f);
-  const int Kmax = d > W->d_ffn ? d : W->d_ffn;
-  size_t region = (size_t)kPRows * (Kmax + 4);
-  const size_t attn = 8 + 256 + (size_t)Lmax + 64;  // attn_item: wave maxima / sums / contexts + the row's cache slots
-  if (region < attn) region = attn;
-  // (the region is sized for the rows AND the attention scratch; red follows the rows' extent)
-  const size_t lds = (region + 1024 + 64) * sizeof(float);
-  if (lds > 160 * 1024 - 512) return -1;
-  static bool allowed = false;
-  if (!allowed) {
-    if (SBK_ALLOW_DYN_LDS(decoder_step_persist_kernel, 160 * 1024 - 512) != hipSuccess) return -1;
-    allowed = true;
+  size_t lds = 0;
+  const int maxg = persist_max_grid(W, Lmax, &lds);
+  if (maxg < 1) return -1;
+  int G = grid_io && *grid_io > 0 ? *grid_io : (g_persist_grid < 1 ? 1 : g_persist_grid);
+  if (G > maxg) {
+    if (grid_io && *grid_io > 0) return fail(SBK_EINVAL, "decoder_step_persist: the search's grid (%d) no longer fits the device (%d)", G, maxg);
+    G = maxg;
   }
-  int maxg = 0;
-  if (SBK_COOP_MAX_GRID(decoder_step_persist_kernel, 256, lds, maxg) != hipSuccess || maxg < 1) {
-    (void)hipGetLastError();
-    return -1;
-  }
-  int G = g_persist_grid < 1 ? 1 : g_persist_grid;
-  if (G > maxg) G = maxg;
+  if (grid_io) *grid_io = G;
   a.bar_base = bar_seq * persist_barriers(W->n_layers) * G;
   ProfScope prof("decoder_step_persist", 2.0 * n * (double)(W->n_layers * (4.0 * d * d + 2.0 * d * W->d_ffn) + (want_logits ? (double)d * W->vocab : 0.0)),
                  4.0 * (W->n_layers * (4.0 * d * d + 2.0 * d * W->d_ffn) + (want_logits ? (double)d * W->vocab : 0.0)), st);

@@ -33,8 +33,8 @@ bool persist_eligible(const sbk_decoder_weights* W, int n, int B, int beam, int 
 int persist_barriers(int n_layers);
 int decoder_step_persist(const sbk_decoder_weights* W, const int32_t* tokens, const int32_t* kv_slot, const int32_t* enc_len,
                          float* x, float* qkv, float* ctx, float* q, float* ff, float* h, float* logits, float* const* kcache,
-                         float* const* vcache, float* const* ckv, int* bar, int bar_seq, int step, int n, int B, int T, int beam,
-                         int Lmax, bool want_logits, hipStream_t st);
+                         float* const* vcache, float* const* ckv, int* bar, int bar_seq, int* grid_io, int step, int n, int B, int T,
+                         int beam, int Lmax, bool want_logits, hipStream_t st);
 extern int g_persist, g_persist_grid, g_persist_stamps;
 // Device-resident step counter of the search running on this host thread (nullptr: the step is the
 // launch argument).  When set, every step-dependent kernel reads the step from it, so that the launches

@@ -953,6 +953,7 @@ struct DecoderBufs {
   float* xpart;         // cross-attention split partials
   int32_t* pbar;        // arrival counter of the persistent few-row step's grid barriers (zeroed by project_memory)
   mutable int pseq;     // persistent launches issued on it since
+  mutable int pgrid;    // workgroups of this search's persistent launches (0 until the first one chooses)
   float* ckv[64];
   float *kcache[64], *vcache[64];
 };
@@ -971,6 +972,7 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
   d.xpart = c.take<float>(sbk::cross_attn_partial_floats(B, T, W->nhead, dm / W->nhead, n / (B > 0 ? B : 1)) + 64);
   d.pbar = c.take<int32_t>(64 + 512);  // (+ 256 eight-byte phase stamps of the measurement knob 49)
   d.pseq = 0;
+  d.pgrid = 0;
   for (int l = 0; l < W->n_layers; ++l) {
     d.ckv[l] = c.take<float>((size_t)B * T * 2 * dm);
     d.kcache[l] = c.take<float>((size_t)Lmax * n * dm);
@@ -996,6 +998,7 @@ int project_memory(const sbk_decoder_weights* W, const DecoderBufs& d, const flo
   const int dm = W->d_model;
   SBK_HIP(hipMemsetAsync(d.pbar, 0, 64 * sizeof(int32_t), st));
   d.pseq = 0;
+  d.pgrid = 0;
   for (int l = 0; l < W->n_layers; ++l) {
     const sbk_decoder_layer& L = W->layers[l];
     float* dst = d.ckv[l];
@@ -1020,7 +1023,7 @@ int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32
   // a beam's worth of rows (<= 16): the whole stack of the step as ONE cooperative launch (csrc/decoder_persist.hip)
   if (!sbk::g_step_ptr && sbk::persist_eligible(W, n, B, beam, Lmax)) {
     const int rc = sbk::decoder_step_persist(W, tokens, kv_slot, enc_len, d.x, d.qkv, d.ctx, d.q, d.ff, d.h, d.logits, d.kcache,
-                                             d.vcache, d.ckv, d.pbar, d.pseq, step, n, B, T, beam, Lmax, want_logits, st);
+                                             d.vcache, d.ckv, d.pbar, d.pseq, &d.pgrid, step, n, B, T, beam, Lmax, want_logits, st);
     if (rc == 0) {
       ++d.pseq;
       return 0;

@@ -55,6 +55,8 @@ static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatu
 enum { hipDeviceAttributeMultiprocessorCount = 1 };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 16; return 0; }
+struct hipDeviceProp_t { char gcnArchName[256]; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { strcpy(p->gcnArchName, "gfx950:emu"); return 0; }
 typedef void* hipEvent_t;
 // hipGraph: not emulated -- capture reports failure, the callers fall back to plain launches
 typedef void* hipGraph_t;
