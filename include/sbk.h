@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SBK_ABI_VERSION 10
+#define SBK_ABI_VERSION 11
 
 typedef void* sbk_stream_t; /* hipStream_t */
 
@@ -67,6 +67,8 @@ int sbk_prof_persist_stamps(long long* out, int cap);
 
 /* tuning knobs for experiments (key 1: K chunks per fetch batch of the skinny GEMM, 0 = automatic) */
 void sbk_prof_set_knob(int key, int value);
+/* ABI 11: the current value of a switch (INT_MIN for an unknown key), so that an experiment or a test can restore what it found */
+int sbk_prof_get_knob(int key);
 /* HBM calibration (SURVEY 8d "measure achievable with a copy kernel first"): hand-written float4 streaming kernels.
  * mode 0 = copy src -> dst (2 * 4 * n bytes per launch), mode 1 = read src (4 * n bytes; dst is a sink of >= 2048
  * floats).  n % 4 == 0, 16-byte aligned.  Mean time of `iters` back-to-back launches in *us_per_launch (HOST). */
@@ -517,6 +519,30 @@ typedef struct {
   const uint16_t* ctc_w3; /* optional (NULL = unused; ABI 6): ctc_w as sbk_split_bf16x3 writes it (the CTC head over
                              the B*T encoder frames, scorer.py:239-255, as sbk_gemm_nt_f32x3) */
 } sbk_search_config;
+
+/* ---- the CTC prefix scorer as a per-step API (ABI 11) -----------------------------------------------------------------------
+ * replaces: decoders/scorer.py:108-255 CTCScorer.reset_mem / score / permute_mem = decoders/ctc.py:79-295
+ * CTCPrefixScore.__init__ / forward_step / permute_mem -- what a searcher written against the reference's ScorerBuilder
+ * (scorer.py:1221-1315) calls once per decoding step.  (sbk_beam_search_f32 drives the same kernels itself.)  The caller owns the
+ * state: `x` [B,T,V] and a workspace of sbk_ctc_scorer_workspace_bytes(B, T, V, beam) bytes, both 16-byte aligned device memory.
+ *   reset   x = log_softmax(ctc_fc(enc)) on entry; converted IN PLACE to the masked linear posteriors the scorer reads from then
+ *           on (frames past enc_len[b]: 1 for token 0, else 0 -- the reference's mask); initial state for `beam` hypotheses per
+ *           utterance (ctc.py:103-124).
+ *   score   step = number of tokens decoded so far (0 at <bos>); inp_tokens [B*beam] = the last token of every hypothesis;
+ *           scores [B*beam, V] = psi - psi_prev (ctc.py:262): psi[eos] = the prefix's own end probability, psi[blank] = -1e20.
+ *           ctc_window_size > 0: attn_window = device {min, max} of the attention peaks of this step (ctc.py:189-200).
+ *   permute after the beam update of the same step: hypothesis row n of the NEW beam extends row parent[n] (0 .. B*beam-1) of
+ *           the old one by token[n]; parent_last_tok = the inp_tokens passed to score().  (ctc.py:243-295 selects the same
+ *           states by flat candidate indices.) */
+size_t sbk_ctc_scorer_workspace_bytes(int B, int T, int V, int beam);
+int sbk_ctc_scorer_reset_f32(float* x, const int32_t* enc_len, void* workspace, size_t workspace_bytes, int B, int T, int V,
+                             int beam, int blank, sbk_stream_t stream);
+int sbk_ctc_scorer_score_f32(const float* x, const int32_t* enc_len, void* workspace, size_t workspace_bytes,
+                             const int32_t* inp_tokens, int step, const int32_t* attn_window, int ctc_window_size, float* scores,
+                             int B, int T, int V, int beam, int blank, int eos, sbk_stream_t stream);
+int sbk_ctc_scorer_permute_f32(const float* x, void* workspace, size_t workspace_bytes, const int32_t* parent,
+                               const int32_t* token, const int32_t* parent_last_tok, int step, const int32_t* attn_window,
+                               int ctc_window_size, int B, int T, int V, int beam, int blank, sbk_stream_t stream);
 
 /* S2STransformerBeamSearcher.forward (seq2seq.py:1632-1723, :1853-1934) with an optional full
  * CTC scorer (scorer.py:108-255,1221-1315; ctc.py:26-295).

@@ -806,6 +806,88 @@ int row_max(const float* x, float* out, int rows, int V, hipStream_t st) {
 
 // Measurement helper (tools/microbench.py): `iters` back-to-back ctc_psi_step launches on a freshly
 // initialised state; mean microseconds per launch.  `work` >= ctc_state_floats + B*T + n_bh floats.
+// ---- the CTC prefix scorer as a per-step API (decoders/scorer.py:108-255 CTCScorer.reset_mem / score / permute_mem, i.e.
+// decoders/ctc.py:79-295 CTCPrefixScore.forward_step / permute_mem): what a searcher written against the reference's
+// ScorerBuilder calls once per decoding step.  The fused search (sbk_beam_search_f32) drives the same kernels itself.
+namespace {
+__global__ void __launch_bounds__(256) ctc_score_delta_kernel(const float* __restrict__ psi, const float* __restrict__ psi_prev,
+                                                              float* __restrict__ out, int V) {
+  const int n = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c < V) out[(size_t)n * V + c] = sbk::sub_rn(psi[(size_t)n * V + c], psi_prev[n]);  // ctc.py:262 (psi - psi_prev)
+}
+struct ScorerWs {
+  float* phi[2];
+  float* psi;
+  float* psi_prev[2];
+  float* xb;
+};
+size_t scorer_ws_floats(int B, int T, int V, int beam) {
+  auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+  return 2 * up(sbk::ctc_state_floats(B, beam, T)) + up((size_t)B * beam * V) + 2 * up((size_t)B * beam) + up((size_t)B * T);
+}
+ScorerWs carve_scorer(void* ws, int B, int T, int V, int beam) {
+  auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+  float* p = static_cast<float*>(ws);
+  ScorerWs w;
+  w.phi[0] = p, p += up(sbk::ctc_state_floats(B, beam, T));
+  w.phi[1] = p, p += up(sbk::ctc_state_floats(B, beam, T));
+  w.psi = p, p += up((size_t)B * beam * V);
+  w.psi_prev[0] = p, p += up((size_t)B * beam);
+  w.psi_prev[1] = p, p += up((size_t)B * beam);
+  w.xb = p;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t sbk_ctc_scorer_workspace_bytes(int B, int T, int V, int beam) {
+  if (B <= 0 || T <= 0 || V <= 0 || beam <= 0) return 0;
+  return scorer_ws_floats(B, T, V, beam) * sizeof(float);
+}
+
+extern "C" int sbk_ctc_scorer_reset_f32(float* x, const int32_t* enc_len, void* ws, size_t ws_bytes, int B, int T, int V, int beam,
+                                        int blank, sbk_stream_t stream) {
+  if (B == 0) return 0;
+  SBK_REQUIRE(x && enc_len && ws && B > 0 && T > 0 && V > 0 && beam > 0 && blank >= 0 && blank < V, "ctc_scorer_reset: bad arguments");
+  SBK_REQUIRE(ws_bytes >= sbk_ctc_scorer_workspace_bytes(B, T, V, beam) && sbk::aligned16(ws) && sbk::aligned16(x),
+              "ctc_scorer_reset: workspace too small (%zu B) or unaligned", ws_bytes);
+  hipStream_t st = sbk::as_stream(stream);
+  const ScorerWs w = carve_scorer(ws, B, T, V, beam);
+  if (hipMemsetAsync(w.phi[1], 0, sbk::ctc_state_floats(B, beam, T) * sizeof(float), st) != hipSuccess)  // (table padding reads as zero)
+    return sbk::fail(1, "ctc_scorer_reset: memset");
+  return sbk::ctc_prepare(x, w.xb, enc_len, w.phi[0], w.psi_prev[0], B, T, V, beam, blank, st);
+}
+
+extern "C" int sbk_ctc_scorer_score_f32(const float* x, const int32_t* enc_len, void* ws, size_t ws_bytes, const int32_t* inp_tokens,
+                                        int step, const int32_t* attn_window, int ctc_window_size, float* scores, int B, int T, int V,
+                                        int beam, int blank, int eos, sbk_stream_t stream) {
+  if (B == 0) return 0;
+  SBK_REQUIRE(x && enc_len && ws && inp_tokens && scores && B > 0 && T > 0 && V > 0 && beam > 0 && step >= 0, "ctc_scorer_score: bad arguments");
+  SBK_REQUIRE(ws_bytes >= sbk_ctc_scorer_workspace_bytes(B, T, V, beam), "ctc_scorer_score: workspace too small");
+  SBK_REQUIRE(ctc_window_size >= 0 && (ctc_window_size == 0 || attn_window), "ctc_scorer_score: a window needs the {min, max} attention peaks");
+  hipStream_t st = sbk::as_stream(stream);
+  const ScorerWs w = carve_scorer(ws, B, T, V, beam);
+  const int cur = step & 1;
+  const int32_t* win = ctc_window_size > 0 ? attn_window : nullptr;
+  int rc = sbk::ctc_psi_step(x, w.phi[cur], inp_tokens, enc_len, w.psi, B, T, V, beam, step, blank, eos, st, win, ctc_window_size);
+  if (rc) return rc;
+  SBK_LAUNCH(ctc_score_delta_kernel, dim3(sbk::cdiv(V, 256), B * beam), dim3(256), 0, st, (const float*)w.psi,
+             (const float*)w.psi_prev[cur], scores, V);
+  return sbk::launch_status("ctc_score_delta");
+}
+
+extern "C" int sbk_ctc_scorer_permute_f32(const float* x, void* ws, size_t ws_bytes, const int32_t* parent, const int32_t* token,
+                                          const int32_t* parent_last_tok, int step, const int32_t* attn_window, int ctc_window_size,
+                                          int B, int T, int V, int beam, int blank, sbk_stream_t stream) {
+  if (B == 0) return 0;
+  SBK_REQUIRE(x && ws && parent && token && parent_last_tok && B > 0 && T > 0 && V > 0 && beam > 0 && step >= 0, "ctc_scorer_permute: bad arguments");
+  SBK_REQUIRE(ws_bytes >= sbk_ctc_scorer_workspace_bytes(B, T, V, beam), "ctc_scorer_permute: workspace too small");
+  SBK_REQUIRE(ctc_window_size >= 0 && (ctc_window_size == 0 || attn_window), "ctc_scorer_permute: a window needs the {min, max} attention peaks");
+  const ScorerWs w = carve_scorer(ws, B, T, V, beam);
+  const int cur = step & 1;
+  return sbk::ctc_advance(x, w.phi[cur], w.psi, parent, token, parent_last_tok, w.phi[cur ^ 1], w.psi_prev[cur ^ 1], B * beam, T, V,
+                          beam, step, blank, sbk::as_stream(stream), ctc_window_size > 0 ? attn_window : nullptr, ctc_window_size);
+}
+
 extern "C" int sbk_prof_ctc_psi_repeat_f32(float* P_logsoftmax, const int32_t* enc_len, const int32_t* last_tok,
                                            float* psi, float* work, int B, int T, int V, int beam, int prefix_len,
                                            int iters, float* us_per_launch, sbk_stream_t stream) {

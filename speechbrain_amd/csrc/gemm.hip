@@ -1414,26 +1414,38 @@ extern "C" int sbk_prof_gemm_repeat_f32(const float* A, const float* W, float* C
   return rc;
 }
 
+// the tuning / measurement switch behind a key (nullptr: no such key)
+static int* knob_slot(int key) {
+  switch (key) {
+    case 2: return &sbk::g_skinny_off;
+    case 4: return &sbk::g_cross_rows;
+    case 8: return &sbk::g_cross_fc256;
+    case 14: return &sbk::g_tiled_splitk;
+    case 18: return &sbk::g_sk_mode;
+    case 24: return &sbk::g_sk_min_rows;
+    case 34: return &sbk::g_x3_route_rows;
+    case 35: return &sbk::g_x3_route_tiles;
+    case 40: return &sbk::g_score_fused;
+    case 41: return &sbk::g_x3r_mode;
+    case 42: return &sbk::g_x3r_min_rows;
+    case 45: return &sbk::g_x3r_ln;
+    case 47: return &sbk::g_persist;
+    case 48: return &sbk::g_persist_grid;
+    case 49: return &sbk::g_persist_stamps;
+    case 51: return &sbk::g_x3r_xc;
+    case 53: return &sbk::g_nt_mask;
+    case 54: return &sbk::g_x3r_probe;
+    case 55: return &sbk::g_self_anc;
+    default: return nullptr;
+  }
+}
 extern "C" void sbk_prof_set_knob(int key, int value) {
-  if (key == 2) sbk::g_skinny_off = value;
-  if (key == 4) sbk::g_cross_rows = value;
-  if (key == 8) sbk::g_cross_fc256 = value;
-  if (key == 53) sbk::g_nt_mask = value;
-  if (key == 54) sbk::g_x3r_probe = value;
-  if (key == 55) sbk::g_self_anc = value;
-  if (key == 51) sbk::g_x3r_xc = value;
-  if (key == 14) sbk::g_tiled_splitk = value;
-  if (key == 18) sbk::g_sk_mode = value;
-  if (key == 24) sbk::g_sk_min_rows = value;
-  if (key == 40) sbk::g_score_fused = value;
-  if (key == 41) sbk::g_x3r_mode = value;
-  if (key == 42) sbk::g_x3r_min_rows = value;
-  if (key == 45) sbk::g_x3r_ln = value;
-  if (key == 47) sbk::g_persist = value;
-  if (key == 48) sbk::g_persist_grid = value;
-  if (key == 49) sbk::g_persist_stamps = value;
-  if (key == 34) sbk::g_x3_route_rows = value;
-  if (key == 35) sbk::g_x3_route_tiles = value;
+  if (int* p = knob_slot(key)) *p = value;
+}
+// current value of a switch (a test restores what it found); INT_MIN for an unknown key
+extern "C" int sbk_prof_get_knob(int key) {
+  const int* p = knob_slot(key);
+  return p ? *p : (-2147483647 - 1);
 }
 
 

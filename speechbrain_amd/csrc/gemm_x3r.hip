@@ -267,6 +267,12 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
   }
 }
 
+// (Round 6 built the same contraction on 128 x 64 tiles -- a W fragment serving four row sub-tiles: 0.29 instead of 0.42 KB of
+// operands per MFMA, half the workgroups, 128 accumulator registers at one wave per SIMD -- bit-identical results, and measured it
+// on the GPU: 15.9 against 12.6 us at (1 280, 512, 512), 45.4 against 29.5 at K = 2 048, the decoding step 1.98 against 1.67 ms;
+// only from 2 560 rows on does it win (16.6 / 46.0 against 20.0 / 56.5 us), and the 8-worker headline is the same either way
+// (12 145 / 12 184 against 12 139 / 12 324): a launch of this size is ~10 us of fixed latency -- launch, first operand round trip,
+// exchange, stores -- plus its MFMA chain, and halving the waves doubles the chain.  Removed; profiles/r06_e_*.)
 // MEASUREMENT ONLY (knob 54 = 2 / 3): every XCD reads the whole buffer once (workgroup b runs on XCD b % 8 and takes slice b / 8
 // of 32), so that the launch behind it finds the operand in its XCD's L2 -- prices what a projection loses to cold operands
 // inside a decoding step (profiles/r06_b_*).  `sink` is never written (the sum of finite values is not NaN-compared true).

@@ -1014,8 +1014,9 @@ int project_memory(const sbk_decoder_weights* W, const DecoderBufs& d, const flo
   return 0;
 }
 
-// One decoder step for n = B*beam hypotheses at position `step`; leaves the final-LayerNorm
-// output in d.h and (when want_logits) seq_lin logits in d.logits.
+// One decoder step for n = B*beam hypotheses at position `step`.  With want_logits: the seq_lin logits in d.logits (d.h is then
+// NOT defined: the routes that run decoder.norm inside the vocabulary projection -- sbk_gemm_ln_nt_f32 / _x3r -- never write it);
+// without: the final-LayerNorm output in d.h (sbk_decoder_prefix_f32 reads it).
 int decoder_step(const sbk_decoder_weights* W, const DecoderBufs& d, const int32_t* tokens, const int32_t* kv_slot,
                  const int32_t* enc_len, int step, int n, int B, int T, int beam, int Lmax, bool want_logits,
                  hipStream_t st) {

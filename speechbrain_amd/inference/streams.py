@@ -42,6 +42,11 @@ class ConcurrentTranscriber:
             self.enc_streams = [torch.cuda.Stream(self.device) for _ in range(self.n)]
             self.dec_streams = [torch.cuda.Stream(self.device, priority=-1) if (prioritise_search and self.n > 1) else None
                                 for _ in range(self.n)]
+            from speechbrain_amd import native
+
+            for st in list(self.enc_streams) + [d for d in self.dec_streams if d is not None]:
+                native.retain_stream_workspace(st)  # (released in close(); pooled handles may be shared with another owner)
+        self._closed = False
         self.pool = ThreadPoolExecutor(self.n)
         self._take_lock = threading.Lock()
         self.balance_tail = True
@@ -51,7 +56,8 @@ class ConcurrentTranscriber:
         """Stop the worker threads and return what the streams of this transcriber pinned in the library (one registered
         workspace per stream that issued an op: native.release_stream_workspace).  The object must not be used afterwards."""
         self.pool.shutdown(wait=True)
-        if self.device.type == "cuda":
+        if self.device.type == "cuda" and not self._closed:
+            self._closed = True
             from speechbrain_amd import native
 
             streams = list(self.enc_streams) + [d for d in self.dec_streams if d is not None]

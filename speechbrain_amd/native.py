@@ -83,6 +83,11 @@ def _declare(lib):
         "sbk_prof_report": ([ctypes.c_char_p, ctypes.c_size_t], ctypes.c_size_t),
         "sbk_prof_ctc_psi_repeat_f32": ([p, p, p, p, p, i, i, i, i, i, i, POINTER(c_float), p], c_int),
         "sbk_prof_set_knob": ([i, i], None),
+        "sbk_prof_get_knob": ([i], c_int),
+        "sbk_ctc_scorer_workspace_bytes": ([i, i, i, i], ctypes.c_size_t),
+        "sbk_ctc_scorer_reset_f32": ([p, p, p, ctypes.c_size_t, i, i, i, i, i, p], c_int),
+        "sbk_ctc_scorer_score_f32": ([p, p, p, ctypes.c_size_t, p, i, p, i, p, i, i, i, i, i, i, p], c_int),
+        "sbk_ctc_scorer_permute_f32": ([p, p, ctypes.c_size_t, p, p, p, i, p, i, i, i, i, i, i, p], c_int),
         "sbk_prof_persist_stamps": ([p, i], c_int),
         "sbk_prof_mfma_peak_f32": ([p, i, i, i, POINTER(c_float), p], c_int),
         "sbk_prof_stream_f32": ([p, p, ctypes.c_long, i, i, POINTER(c_float), p], c_int),
@@ -168,7 +173,7 @@ def load(path: Optional[str] = None):
         )
     lib = ctypes.CDLL(path)
     EXPORTS = tuple(_declare(lib).keys())
-    if lib.sbk_abi_version() != 10:
+    if lib.sbk_abi_version() != 11:
         raise SbkError(f"ABI version mismatch: {lib.sbk_abi_version()}")
     _lib = lib
     return lib
@@ -202,7 +207,18 @@ def _p(t: Optional[torch.Tensor]):
 # never destroyed).  Every op fetches its stream through _stream(), so no call can reach a kernel without one -- the same
 # kernels run on every stream, and a worker stream's first launch allocates nothing inside the library.
 _STREAM_WS = {}
-_STREAM_WS_LOCK = threading.Lock()
+_STREAM_WS_LOCK = threading.RLock()
+# torch hands out stream HANDLES from a pool (32 per priority): two live Stream objects -- of two transcribers, or a
+# transcriber's and ShardedTranscriber's copy stream -- can be the same handle.  An owner that means to release a stream's
+# workspace when it retires first RETAINS it; the workspace goes back only when its last owner has released it.
+_STREAM_WS_REFS = {}
+
+
+def retain_stream_workspace(stream):
+    """Declare an owner of the (device, handle) of ``stream`` (a ConcurrentTranscriber for each of its worker streams)."""
+    key = (id(load()), stream.device.index, stream.cuda_stream)
+    with _STREAM_WS_LOCK:
+        _STREAM_WS_REFS[key] = _STREAM_WS_REFS.get(key, 0) + 1
 
 
 def _register_workspace(key, device, handle):
@@ -228,10 +244,20 @@ def release_stream_workspace(stream) -> bool:
     lib = load()
     key = (id(lib), stream.device.index, stream.cuda_stream)
     with _STREAM_WS_LOCK:
+        left = _STREAM_WS_REFS.get(key, 0) - 1
+        if left > 0:  # another live owner of the same pooled handle: it keeps the workspace
+            _STREAM_WS_REFS[key] = left
+            return False
+        _STREAM_WS_REFS.pop(key, None)
+        if key not in _STREAM_WS:
+            return False
+    stream.synchronize()  # (outside the lock: other streams' first launches register their workspaces meanwhile)
+    with _STREAM_WS_LOCK:
+        if _STREAM_WS_REFS.get(key, 0) > 0:  # (retained again while the stream drained)
+            return False
         ws = _STREAM_WS.pop(key, None)
         if ws is None:
             return False
-        stream.synchronize()
         with torch.cuda.device(stream.device):
             _chk(lib.sbk_stream_workspace_release(c_void_p(stream.cuda_stream)), "sbk_stream_workspace_release")
     return True
@@ -1297,7 +1323,7 @@ def beam_search(handle: DecoderHandle, cfg: SearchConfig, enc, enc_len, ctc_w=No
 # the headline from 11.7 K to 8.7-11.1 K audio-s/s -- the emptied pools are refilled by hipMalloc inside the next job.
 WS_TRIM = os.environ.get("SBK_WS_TRIM", "0") != "0"
 _SEARCH_WS = {}  # (device index, stream handle) -> [buffer, a host thread is enqueueing a search into it]
-_SEARCH_WS_LOCK = threading.Lock()
+_SEARCH_WS_LOCK = threading.RLock()  # (re-entrant: a transcriber finalised by the cyclic GC inside an allocation made under the lock)
 
 
 def _search_workspace(nbytes: int, dev):
@@ -1346,7 +1372,9 @@ def release_search_workspaces(streams=None):
         else:
             keys = [(s.device.index, s.cuda_stream) for s in streams]
         for k in keys:
-            _SEARCH_WS.pop(k, None)
+            ent = _SEARCH_WS.get(k)
+            if ent is not None and not ent[1]:  # (a search of another owner of the same pooled handle is running on it: kept)
+                _SEARCH_WS.pop(k, None)
 
 
 def greedy_search(handle: DecoderHandle, enc, enc_len, min_steps, max_steps, bos, eos, check_every=8):
@@ -1414,6 +1442,52 @@ def decoder_prefix(handle: DecoderHandle, tokens, enc, enc_len):
                                     c_void_p(ws.data_ptr() + off), nbytes, _p(pred), n, T, L, _stream(enc)),
          "sbk_decoder_prefix_f32")
     return pred
+
+
+class CTCStepScorer:
+    """The CTC prefix scorer as a per-step object (sbk_ctc_scorer_*: decoders/ctc.py:79-295 CTCPrefixScore).  ``log_probs``
+    [B,T,V] = log_softmax(ctc_fc(enc)) -- the scorer takes ownership and converts it in place --, ``enc_len`` [B] int32 absolute
+    lengths.  ``score(inp_tokens, step)`` -> psi - psi_prev [B*beam, V]; ``permute(parent, token, inp_tokens, step)`` moves the
+    state to the hypotheses chosen by the beam update.  The beam width is fixed by the first ``score`` call."""
+
+    def __init__(self, log_probs, enc_len, blank, eos, ctc_window_size=0):
+        _dev_ok(log_probs, enc_len)
+        _f32(log_probs)
+        self.x, self.enc_len = log_probs, enc_len.to(torch.int32)
+        self.B, self.T, self.V = log_probs.shape
+        self.blank, self.eos, self.window = int(blank), int(eos), int(ctc_window_size)
+        self.beam, self.ws, self.nbytes = 0, None, 0
+
+    def _ready(self, beam):
+        if self.beam == beam:
+            return
+        if self.beam:
+            raise SbkError(f"CTCStepScorer: the beam width changed from {self.beam} to {beam} inside one utterance batch")
+        lib = load()
+        self.beam = beam
+        self.nbytes = lib.sbk_ctc_scorer_workspace_bytes(self.B, self.T, self.V, beam)
+        self.ws = torch.empty(self.nbytes + 256, dtype=torch.uint8, device=self.x.device)
+        self._off = (-self.ws.data_ptr()) % 256
+        _chk(lib.sbk_ctc_scorer_reset_f32(_p(self.x), _p(self.enc_len), c_void_p(self.ws.data_ptr() + self._off), self.nbytes, self.B,
+                                          self.T, self.V, beam, self.blank, _stream(self.x)), "sbk_ctc_scorer_reset_f32")
+
+    def score(self, inp_tokens, step, attn_window=None):
+        n = inp_tokens.shape[0]
+        if n % self.B:
+            raise SbkError(f"CTCStepScorer: {n} hypotheses for {self.B} utterances")
+        self._ready(n // self.B)
+        tok = inp_tokens.to(torch.int32).contiguous()
+        out = torch.empty(n, self.V, dtype=torch.float32, device=self.x.device)
+        _chk(load().sbk_ctc_scorer_score_f32(_p(self.x), _p(self.enc_len), c_void_p(self.ws.data_ptr() + self._off), self.nbytes, _p(tok),
+                                             int(step), _p(attn_window), self.window if attn_window is not None else 0, _p(out), self.B,
+                                             self.T, self.V, self.beam, self.blank, self.eos, _stream(self.x)), "sbk_ctc_scorer_score_f32")
+        return out
+
+    def permute(self, parent, token, parent_last_tok, step, attn_window=None):
+        par, tk, last = (t.to(torch.int32).contiguous() for t in (parent, token, parent_last_tok))
+        _chk(load().sbk_ctc_scorer_permute_f32(_p(self.x), c_void_p(self.ws.data_ptr() + self._off), self.nbytes, _p(par), _p(tk), _p(last),
+                                               int(step), _p(attn_window), self.window if attn_window is not None else 0, self.B, self.T,
+                                               self.V, self.beam, self.blank, _stream(self.x)), "sbk_ctc_scorer_permute_f32")
 
 
 def log_softmax(x, temperature=1.0, weight=1.0):

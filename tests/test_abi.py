@@ -29,7 +29,7 @@ def test_header_symbols_exported(lib_path):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sbk.h but not exported"
     lib.sbk_abi_version.restype = ctypes.c_int
-    assert lib.sbk_abi_version() == 10
+    assert lib.sbk_abi_version() == 11
 
 
 def test_binding_covers_header(lib_path):

@@ -722,154 +722,6 @@ def test_gemm_x3p(backend, M, N, K):
         rows = 50 if M % 50 == 0 else M // 7
         nseq = M // rows
         lens = torch.tensor([(i * 13) % (rows + 1) for i in range(nseq)], dtype=torch.int32)
-        out = nat.gemm_nt(ad[: nseq * rows], wd, bd, rd[: nseq * rows], seq_len=lens.to(dev), rows_per_seq=rows)
-        keep = (torch.arange(rows)[None, :] < lens[:, None]).reshape(-1, 1)
-        ref = r[: nseq * rows] + torch.where(keep, (a[: nseq * rows].double() @ w.double().t() + b).float(), torch.zeros(()))
-        assert _md(out, ref) <= 2e-6 * scale + 1e-5
-        x = ad[:, :K].clone()
-        if N == K:  # in-place residual
-            out = nat.gemm_nt(x, wd, None, x)
-            assert _md(out, a + (a.double() @ w.double().t()).float()) <= 2e-6 * scale + 1e-5
-    finally:
-        lib.sbk_prof_set_knob(18, 1)
-
-
-@pytest.mark.parametrize("M,N,K", [(700, 300, 96), (1000, 132, 64), (257, 128, 640), (520, 260, 128), (2100, 300, 64), (1100, 520, 96),
-                                   (300, 132, 64), (1300, 260, 160), (4100, 512, 512), (130, 1032, 2048), (12800, 2048, 512),
-                                   (4032, 512, 2048), (24000, 1536, 512)])
-def test_gemm_f32x3(backend, M, N, K):
-    """sbk_gemm_nt_f32x3: the fp32 contraction on the bf16 matrix pipe.  Operands are cut EXACTLY into three bf16 pieces
-    (checked bit for bit on the weight image) and six partial products are accumulated in fp32, so the result must be as
-    close to the fp64 product as the fp32-MFMA kernel's -- the same 2e-6 bound the fp32 kernels are held to, and an RMS
-    error no larger than theirs; stream-K cuts, ragged edges, every epilogue option, row masks, a sliding-window A
-    (lda < K), run-to-run bit-identical."""
-    nat, dev = backend
-    if dev.type == "cpu" and M * N * K > 6e7:
-        pytest.skip("large shape: GPU only")
-    g = torch.Generator().manual_seed(M + N + K)
-    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01
-    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
-    a[::7] *= 1e-3  # rows of very different magnitude
-    w[::5] *= 300.0
-    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
-    lib = nat.load()
-    old = nat.F32X3, nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES
-    nat.F32X3, nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES = True, 1, 1
-    try:
-        ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
-        w3 = nat.lp_weight(wd, "x3").cpu()
-        assert w3.shape == (N, K // 32, 3, 32)
-        pieces = (w3.view(torch.int16).to(torch.int32) << 16).view(torch.float32)  # bf16 bits -> fp32
-        assert torch.equal(pieces.double().sum(2).reshape(N, K).float(), w)  # hi + mid + lo == w exactly
-        assert nat.lp_weight(wd, "x3") is nat.lp_weight(wd, "x3")
-        big = M * N * K > 6e7
-        dd = (lambda t: t.to(dev).double()) if big else (lambda t: t.double())
-        prod = dd(a) @ dd(w).t()
-        scale = float((dd(a).abs() @ dd(w).abs().t()).max())
-        out = nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5)
-        ref = (dd(r) + 0.5 * F.silu(prod + dd(b))).float().cpu()
-        assert _md(out, ref) <= 2e-6 * scale + 1e-5
-        for _ in range(3 if dev.type == "cuda" else 1):
-            assert torch.equal(nat.gemm_nt(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
-        # RMS error against fp64 next to the fp32-MFMA kernels' on the same operands.  Zero-mean operands (what LayerNorm
-        # outputs x weights are): about the same (measured on MI355X 0.85 x at K = 512, 0.87-1.22 x at K = 2 048 at the
-        # encoder's row counts, 1.6 x on a 257-row problem cut into stream-K pieces).  Operands with a
-        # strong common sign, whose partial sums grow linearly: up to 3.3 x measured (the matrix core adds the 16 products
-        # of a bf16 MFMA and the accumulator with truncation, and six MFMAs touch the accumulator per 16 k) -- still far
-        # inside the 2e-6 bound above that every fp32 kernel of the library is held to.  The emulator rounds the
-        # accumulator after every single partial product (six per k), hence its wider bounds.
-        def rms_ratio(x, y):
-            xd, yd = x.to(dev), y.to(dev)
-            exact = dd(x) @ dd(y).t()
-            got = nat.gemm_nt(xd, yd)
-            nat.F32X3 = False
-            try:
-                base = nat.gemm_nt(xd, yd)  # the fp32-MFMA kernels
-            finally:
-                nat.F32X3 = True
-            e3 = float((got.double().cpu() - exact.cpu()).pow(2).mean().sqrt())
-            e32 = float((base.double().cpu() - exact.cpu()).pow(2).mean().sqrt())
-            return e3 / max(e32, 1e-30)
-        on_gpu = dev.type == "cuda"
-        assert rms_ratio(a, w) <= (4.0 if on_gpu else 8.0)
-        assert rms_ratio(torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)) <= (2.0 if on_gpu else 8.0)
-        rows = 50 if M % 50 == 0 else M // 7
-        nseq = M // rows
-        lens = torch.tensor([(i * 13) % (rows + 1) for i in range(nseq)], dtype=torch.int32)
-        out = nat.gemm_nt(ad[: nseq * rows], wd, bd, rd[: nseq * rows], seq_len=lens.to(dev), rows_per_seq=rows)
-        keep = (torch.arange(rows)[None, :] < lens[:, None]).reshape(-1, 1)
-        ref = r[: nseq * rows] + torch.where(keep, (prod[: nseq * rows] + dd(b)).float().cpu(), torch.zeros(()))
-        assert _md(out, ref) <= 2e-6 * scale + 1e-5
-        if N == K:  # in-place residual
-            x = ad.clone()
-            out = nat.gemm_nt(x, wd, None, x)
-            assert _md(out, a + prod.float().cpu()) <= 2e-6 * scale + 1e-5
-        if K % 64 == 0 and M <= 4100:  # a window of K floats sliding by lda = K / 2 over a flat signal
-            flat = ad.reshape(-1)
-            Mw = 2 * M - 1
-            out = nat.gemm_nt_rows(flat, Mw, K, K // 2, wd, bd)
-            win = a.reshape(-1).unfold(0, K, K // 2)
-            assert win.shape[0] == Mw
-            assert _md(out, (win.double() @ w.double().t() + b).float()) <= 2e-6 * scale + 1e-5
-    finally:
-        nat.F32X3, nat.F32X3_MIN_ROWS, nat.F32X3_MIN_TILES = old
-
-
-@pytest.mark.parametrize("M,N,K", [(300, 132, 64), (700, 300, 96), (1000, 520, 64), (520, 260, 128), (2100, 304, 64), (1300, 272, 160),
-                                   (4100, 512, 512), (3012, 2048, 512), (12800, 2048, 512), (4032, 512, 2048), (24000, 1536, 512),
-                                   (14000, 1024, 512), (6432, 512, 512), (130, 1032, 2048)])
-def test_gemm_x3p(backend, M, N, K):
-    """sbk_split_x3p + sbk_gemm_nt_x3p: the fp32 contraction on the bf16 matrix pipe with BOTH operands pre-split and in
-    panel layout.  The panel image is exact (hi + mid + lo == x bit for bit, padding rows zero); the result is held to the
-    bound of every fp32 kernel of the library against the fp64 product (2e-6 of the largest sum of magnitudes);
-    whole-tile and stream-K launches, ragged edges, every epilogue option, row masks; the panel-image
-    result (the next contraction's A operand) equals the fp32 result bit for bit; run-to-run bit-identical."""
-    nat, dev = backend
-    if dev.type == "cpu" and M * N * K > 6e7:
-        pytest.skip("large shape: GPU only")
-    g = torch.Generator().manual_seed(M + N + K)
-    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01
-    w = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.02
-    a[::7] *= 1e-3  # rows of very different magnitude
-    w[::5] *= 300.0
-    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
-    lib = nat.load()
-    try:
-        ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
-
-        def unpanel(img, rows, cols):  # panel image -> the sum of its three pieces as fp32 [rows, cols]
-            RB, KB = (rows + 63) // 64, cols // 16
-            pieces = (img.cpu().view(torch.int16).to(torch.int32) << 16).view(torch.float32).view(RB, KB, 3, 2, 64, 8)
-            return pieces.double().sum(2).permute(0, 3, 1, 2, 4).reshape(RB * 64, cols).float()
-
-        pa = nat.split_x3p(ad)
-        full = unpanel(pa.data, M, K)
-        assert torch.equal(full[:M], a) and not full[M:].any()  # exact, padding rows zero
-        big = M * N * K > 6e7
-        dd = (lambda t: t.to(dev).double()) if big else (lambda t: t.double())
-        prod = dd(a) @ dd(w).t()
-        scale = float((dd(a).abs() @ dd(w).abs().t()).max())
-        out, pc = nat.gemm_nt_x3p(pa, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5, panel_out=N % 16 == 0) if N % 16 == 0 else \
-            (nat.gemm_nt_x3p(pa, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), None)
-        ref = (dd(r) + 0.5 * F.silu(prod + dd(b))).float().cpu()
-        assert _md(out, ref) <= 2e-6 * scale + 1e-5
-        if pc is not None:
-            assert torch.equal(unpanel(pc.data, M, N)[:M], out.cpu())
-            only = nat.gemm_nt_x3p(pa, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5, panel_out=True, fp32_out=False)
-            assert torch.equal(only.data[: pc.data.numel()].cpu()[: ((M + 63) // 64 - 1) * 64 * N * 3], pc.data.cpu()[: ((M + 63) // 64 - 1) * 64 * N * 3])
-        for _ in range(3 if dev.type == "cuda" else 1):
-            assert torch.equal(nat.gemm_nt_x3p(pa, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out)
-        # the tile order (column groups of the tile space, knob 52: which tiles an XCD's workgroups share) permutes the tiles
-        # among the workgroups and nothing else: every tile once, the same bits (stream-K leftovers included)
-        try:
-            for cg in (1, 2, 4):
-                lib.sbk_prof_set_knob(52, cg)
-                assert torch.equal(nat.gemm_nt_x3p(pa, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out), cg
-        finally:
-            lib.sbk_prof_set_knob(52, 0)
-        rows = 50 if M % 50 == 0 else M // 7
-        nseq = M // rows
-        lens = torch.tensor([(i * 13) % (rows + 1) for i in range(nseq)], dtype=torch.int32)
         pa2 = nat.split_x3p(ad[: nseq * rows])
         out = nat.gemm_nt_x3p(pa2, wd, bd, rd[: nseq * rows], seq_len=lens.to(dev), rows_per_seq=rows)
         keep = (torch.arange(rows)[None, :] < lens[:, None]).reshape(-1, 1)
@@ -889,8 +741,8 @@ def test_gemm_x3p(backend, M, N, K):
                                    (333, 64, 1024), (1, 40, 256), (1280, 5000, 512)])
 def test_gemm_x3r(backend, M, N, K):
     """sbk_gemm_nt_x3r: the decode step's few-row projections on the bf16 matrix pipe (W as its panel image; A fp32 and
-    split in registers; 64 x 64 tiles whose four waves split K however long it is).  Held to the bound of every fp32 kernel
-    of the library against the fp64 product (2e-6 of the largest sum of magnitudes); ragged edges; bias / activation /
+    split in registers; 64 x 64 tiles whose four waves split K however long it is).  Held to the bound of every fp32
+    kernel of the library against the fp64 product (2e-6 of the largest sum of magnitudes); ragged edges; bias / activation /
     scaled residual; run-to-run bit-identical."""
     nat, dev = backend
     if dev.type == "cpu" and M * N * K > 1.2e8:
