@@ -207,31 +207,39 @@ __global__ void __launch_bounds__(256) self_attn_step_kernel(SelfAttnArgs a) {
 // v_mfma_f32_16x16x4_f32, online softmax -- a (row, beam) pair whose beam does not descend from the row is masked to -inf
 // (probability exactly 0), so every beam's softmax runs over exactly its own prefix.  Each distinct row is fetched ONCE.
 // The wave also appends the new token's K / V head slices to the cache (slot = hypothesis index), as the kernel above does.
+// A WORKGROUP = one (utterance, head); its four waves take a quarter of the prefix positions each (their own list, their own walk:
+// nothing shared until the end) and the four partial (context, max, sum) triples are merged through LDS by wave 0 -- the
+// flash-decoding split of cross_attn_ring_kernel inside a workgroup.  (Round 6 first built it as one wave per (utterance, head):
+// a tenth of the row requests, but a 3-4 x longer dependent chain per wave -- 55-60 against 36-43 us per launch on one stream,
+// +1-2 % under the eight workers; profiles/r06_d_*.)
 template <int D>
 __global__ void __launch_bounds__(256) self_attn_anc_kernel(SelfAttnArgs a, int cap) {
-  SBK_DYN_LDS(float, lds);  // [4 waves][cap] x int2 {packed row, beam mask}
+  SBK_DYN_LDS(float, lds);  // [4 waves][cap] x int2 {packed row, beam mask} | [4 waves][64 lanes][18] partials
   if (a.step_ptr) a.step = a.step_ptr[0];
   const int lane = threadIdx.x & 63, wave = sbk::uniform(threadIdx.x >> 6);
-  const int beam = a.group, U = a.n / beam, gw = sbk::uniform(blockIdx.x * 4 + wave);
-  if (gw >= U * a.H) return;  // (no workgroup barrier anywhere below)
+  const int beam = a.group, gw = blockIdx.x;  // (utterance, head)
   const int u = gw / a.H, h = gw - u * a.H;
   const int d = a.d, step = a.step, Lmax = a.Lmax;
   int2* rows = reinterpret_cast<int2*>(lds) + (size_t)wave * cap;
+  float* part = lds + (size_t)8 * cap;  // behind the four lists (2 floats per record)
   const int col = lane & 15, g = lane >> 4;
   const size_t hoff = (size_t)h * 64;
-  // the new token's K / V head slices -> cache rows [hypothesis][step]
-  for (int j = 0; j < beam; ++j) {
+  // the new token's K / V head slices -> cache rows [hypothesis][step] (beam j by wave j mod 4)
+  for (int j = wave; j < beam; j += 4) {
     const size_t i = (size_t)u * beam + j;
     const float* src = a.qkv + i * 3 * d + d + hoff;
     const size_t o = (i * Lmax + step) * d + hoff + lane;
     a.kcache[o] = src[lane];
     a.vcache[o] = src[d + lane];
   }
-  // distinct (slot, position) rows of the utterance's prefixes, in position order
+  // this wave's positions [p_lo, p_hi): a quarter of the prefix, in whole lanes' worth of 16
+  const int per = ((step + 63) / 64) * 16;
+  const int p_lo = min(wave * per, step), p_hi = min(p_lo + per, step);
+  // distinct (slot, position) rows of the utterance's prefixes over these positions, in position order
   int nrows = 0;
-  for (int p0 = 0; p0 < step; p0 += 64) {
+  for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
     const int p = p0 + lane;
-    const bool act = p < step;
+    const bool act = p < p_hi;
     int sl[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) sl[j] = (act && j < beam) ? a.kv_slot[((size_t)u * beam + j) * Lmax + p] : -1 - j;
@@ -260,8 +268,12 @@ __global__ void __launch_bounds__(256) self_attn_anc_kernel(SelfAttnArgs a, int 
       if ((first >> j) & 1) rows[w++] = make_int2((sl[j] << 12) | p, (int)msk[j]);
     nrows += sbk::shfl(incl, 63);
   }
-  if (lane < beam) rows[nrows + lane] = make_int2((lane << 12) | step, 1 << lane);  // the new token itself: qkv row of beam `lane`
-  nrows += beam;
+  // the new token itself (qkv row of beam j): beam j by wave j mod 4, like the cache append
+  {
+    const int mine = beam > wave ? (beam - wave + 3) / 4 : 0;
+    if (lane < mine) rows[nrows + lane] = make_int2(((wave + 4 * lane) << 12) | step, 1 << (wave + 4 * lane));
+    nrows += mine;
+  }
   sbk::wave_sync();
   // row record -> address of the row's K head slice (V: the same offset in vcache, or + d inside qkv)
   auto kaddr = [&](int rec, const float*& kp, const float*& vp) SBK_INLINE_LAMBDA {
@@ -275,103 +287,131 @@ __global__ void __launch_bounds__(256) self_attn_anc_kernel(SelfAttnArgs a, int 
       vp = a.vcache + o;
     }
   };
-  float qf[16];
-  {
-    const float* qp = a.qkv + ((size_t)u * beam + min(col, beam - 1)) * 3 * d + hoff + 4 * g;
-    const float qs = col < beam ? a.scale : 0.0f;
-#pragma unroll
-    for (int jq = 0; jq < 4; ++jq) {
-      const float4 t = *reinterpret_cast<const float4*>(qp + 16 * jq);
-      qf[4 * jq] = t.x * qs, qf[4 * jq + 1] = t.y * qs, qf[4 * jq + 2] = t.z * qs, qf[4 * jq + 3] = t.w * qs;
-    }
-  }
-  const int ntiles = (nrows + 15) / 16;
-  float4 kr[D][4], vr[D][4];
-  int vm[D][4];  // beam masks of the rows 4 g + i of the tile (0 past the list)
-  auto fetch = [&](float4(&kk)[4], float4(&vv)[4], int(&mm)[4], int tile) SBK_INLINE_LAMBDA {
-    const float *kp, *vp;
-    kaddr(rows[min(tile * 16 + col, nrows - 1)].x, kp, vp);
-#pragma unroll
-    for (int jq = 0; jq < 4; ++jq) kk[jq] = *reinterpret_cast<const float4*>(kp + 4 * g + 16 * jq);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = tile * 16 + 4 * g + i;
-      const int2 rec = rows[min(r, nrows - 1)];
-      kaddr(rec.x, kp, vp);
-      vv[i] = *reinterpret_cast<const float4*>(vp + 4 * col);
-      mm[i] = r < nrows ? rec.y : 0;
-    }
-  };
   sbk::f32x4 o[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[ct][r] = 0.0f;
   float m_run = -INFINITY, l_run = 0.0f;
-  auto consume = [&](const float4(&kk)[4], const float4(&vv)[4], const int(&mm)[4]) SBK_INLINE_LAMBDA {
-    sbk::f32x4 sc;
+  if (nrows > 0) {  // (uniform; a wave without rows -- a prefix shorter than four positions -- hands over an empty partial)
+    float qf[16];
+    {
+      const float* qp = a.qkv + ((size_t)u * beam + min(col, beam - 1)) * 3 * d + hoff + 4 * g;
+      const float qs = col < beam ? a.scale : 0.0f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sc[r] = 0.0f;
-#pragma unroll
-    for (int jq = 0; jq < 4; ++jq) {
-      sc = sbk::mfma_16x16x4(kk[jq].x, qf[4 * jq], sc);
-      sc = sbk::mfma_16x16x4(kk[jq].y, qf[4 * jq + 1], sc);
-      sc = sbk::mfma_16x16x4(kk[jq].z, qf[4 * jq + 2], sc);
-      sc = sbk::mfma_16x16x4(kk[jq].w, qf[4 * jq + 3], sc);
+      for (int jq = 0; jq < 4; ++jq) {
+        const float4 t = *reinterpret_cast<const float4*>(qp + 16 * jq);
+        qf[4 * jq] = t.x * qs, qf[4 * jq + 1] = t.y * qs, qf[4 * jq + 2] = t.z * qs, qf[4 * jq + 3] = t.w * qs;
+      }
     }
-    float mt = -INFINITY;  // sc[r] = score of (row 4 g + r of the tile, beam col)
+    const int ntiles = (nrows + 15) / 16;
+    float4 kr[D][4], vr[D][4];
+    int vm[D][4];  // beam masks of the rows 4 g + i of the tile (0 past the list)
+    auto fetch = [&](float4(&kk)[4], float4(&vv)[4], int(&mm)[4], int tile) SBK_INLINE_LAMBDA {
+      const float *kp, *vp;
+      kaddr(rows[min(tile * 16 + col, nrows - 1)].x, kp, vp);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (!((mm[r] >> col) & 1)) sc[r] = -INFINITY;
-      mt = fmaxf(mt, sc[r]);
-    }
-    mt = fmaxf(mt, sbk::shfl_xor(mt, 16));
-    mt = fmaxf(mt, sbk::shfl_xor(mt, 32));
-    const float m_new = fmaxf(m_run, mt);  // -inf while the beam has met none of its rows (a tile of other beams' rows)
-    const float alpha = m_new == -INFINITY ? 1.0f : expf(m_run - m_new);
-    float pr[4], ps = 0.0f;
+      for (int jq = 0; jq < 4; ++jq) kk[jq] = *reinterpret_cast<const float4*>(kp + 4 * g + 16 * jq);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      pr[r] = sc[r] == -INFINITY ? 0.0f : expf(sc[r] - m_new);
-      ps += pr[r];
+      for (int i = 0; i < 4; ++i) {
+        const int r = tile * 16 + 4 * g + i;
+        const int2 rec = rows[min(r, nrows - 1)];
+        kaddr(rec.x, kp, vp);
+        vv[i] = *reinterpret_cast<const float4*>(vp + 4 * col);
+        mm[i] = r < nrows ? rec.y : 0;
+      }
+    };
+    auto consume = [&](const float4(&kk)[4], const float4(&vv)[4], const int(&mm)[4]) SBK_INLINE_LAMBDA {
+      sbk::f32x4 sc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[r] = 0.0f;
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) {
+        sc = sbk::mfma_16x16x4(kk[jq].x, qf[4 * jq], sc);
+        sc = sbk::mfma_16x16x4(kk[jq].y, qf[4 * jq + 1], sc);
+        sc = sbk::mfma_16x16x4(kk[jq].z, qf[4 * jq + 2], sc);
+        sc = sbk::mfma_16x16x4(kk[jq].w, qf[4 * jq + 3], sc);
+      }
+      float mt = -INFINITY;  // sc[r] = score of (row 4 g + r of the tile, beam col)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (!((mm[r] >> col) & 1)) sc[r] = -INFINITY;
+        mt = fmaxf(mt, sc[r]);
+      }
+      mt = fmaxf(mt, sbk::shfl_xor(mt, 16));
+      mt = fmaxf(mt, sbk::shfl_xor(mt, 32));
+      const float m_new = fmaxf(m_run, mt);  // -inf while the beam has met none of its rows (a tile of other beams' rows)
+      const float alpha = m_new == -INFINITY ? 1.0f : expf(m_run - m_new);
+      float pr[4], ps = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[r] = sc[r] == -INFINITY ? 0.0f : expf(sc[r] - m_new);
+        ps += pr[r];
+      }
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[ct][r] *= alpha;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[0] = sbk::mfma_16x16x4(vv[i].x, pr[i], o[0]);
+        o[1] = sbk::mfma_16x16x4(vv[i].y, pr[i], o[1]);
+        o[2] = sbk::mfma_16x16x4(vv[i].z, pr[i], o[2]);
+        o[3] = sbk::mfma_16x16x4(vv[i].w, pr[i], o[3]);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) fetch(kr[s], vr[s], vm[s], s);  // (tiles past the list re-read its last row, masks 0)
+    int k0 = 0;
+    for (; k0 + D <= ntiles; k0 += D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        fetch(kr[(s + D - 1) % D], vr[(s + D - 1) % D], vm[(s + D - 1) % D], k0 + s + D - 1);
+        sbk::sched_fence();
+        consume(kr[s], vr[s], vm[s]);
+        sbk::sched_fence();
+      }
     }
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s)
+      if (k0 + s < ntiles) consume(kr[s], vr[s], vm[s]);
+  }
+  float l_tot = l_run + sbk::shfl_xor(l_run, 16);
+  l_tot += sbk::shfl_xor(l_tot, 32);
+  // hand the partial over: [wave][lane][16 context values | max | sum]
+  {
+    float* pp = part + ((size_t)wave * 64 + lane) * 18;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[ct][r] *= alpha;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      o[0] = sbk::mfma_16x16x4(vv[i].x, pr[i], o[0]);
-      o[1] = sbk::mfma_16x16x4(vv[i].y, pr[i], o[1]);
-      o[2] = sbk::mfma_16x16x4(vv[i].z, pr[i], o[2]);
-      o[3] = sbk::mfma_16x16x4(vv[i].w, pr[i], o[3]);
-    }
-  };
-#pragma unroll
-  for (int s = 0; s < D - 1; ++s) fetch(kr[s], vr[s], vm[s], s);  // (tiles past the list re-read its last row, masks 0)
-  int k0 = 0;
-  for (; k0 + D <= ntiles; k0 += D) {
-#pragma unroll
-    for (int s = 0; s < D; ++s) {
-      fetch(kr[(s + D - 1) % D], vr[(s + D - 1) % D], vm[(s + D - 1) % D], k0 + s + D - 1);
-      sbk::sched_fence();
-      consume(kr[s], vr[s], vm[s]);
-      sbk::sched_fence();
-    }
+      for (int r = 0; r < 4; ++r) pp[4 * ct + r] = o[ct][r];
+    pp[16] = m_run;
+    pp[17] = l_tot;
   }
+  __syncthreads();
+  if (wave == 0 && col < beam) {  // (every beam owns a new-token row, so the merged maximum is finite)
+    float M = -INFINITY;
 #pragma unroll
-  for (int s = 0; s < D - 1; ++s)
-    if (k0 + s < ntiles) consume(kr[s], vr[s], vm[s]);
-  float l_tot = l_run + sbk::shfl_xor(l_run, 16);
-  l_tot += sbk::shfl_xor(l_tot, 32);
-  if (col < beam) {
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, part[((size_t)w * 64 + lane) * 18 + 16]);
+    float acc[16], den = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {  // fixed order: the result does not depend on which wave finished first
+      const float* pp = part + ((size_t)w * 64 + lane) * 18;
+      const float mw = pp[16];
+      const float sc = mw == -INFINITY ? 0.0f : expf(mw - M);
+      den = fmaf(sc, pp[17], den);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = fmaf(sc, pp[e], acc[e]);
+    }
     float* op = a.out + ((size_t)u * beam + col) * d + hoff + 16 * g;
-    const float inv = 1.0f / l_tot;
+    const float inv = 1.0f / den;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      *reinterpret_cast<float4*>(op + 4 * r) = make_float4(o[0][r] * inv, o[1][r] * inv, o[2][r] * inv, o[3][r] * inv);
+      *reinterpret_cast<float4*>(op + 4 * r) = make_float4(acc[r] * inv, acc[4 + r] * inv, acc[8 + r] * inv, acc[12 + r] * inv);
   }
 }
 
@@ -850,11 +890,12 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
   // beams of an utterance share their ancestry: each distinct cache row fetched once per (utterance, head) (knob 55, default on)
   if (g_self_anc && group >= 2 && group <= 16 && d == H * 64 && !key_tok && nslot < (1 << 19) && Lmax < 4096 && aligned16(qkv) &&
       aligned16(kcache) && aligned16(vcache) && aligned16(out) && d % 4 == 0) {
-    const int cap = (Lmax + 1) * group;  // every row distinct
-    const size_t lds_anc = (size_t)4 * cap * sizeof(int2);
+    // list capacity of a wave: its quarter of the positions (16-position granules) with every row distinct + its new-token rows
+    const int cap = ((((Lmax + 63) / 64) * 16) + 4) * group;
+    const size_t lds_anc = (size_t)4 * cap * sizeof(int2) + (size_t)4 * 64 * 18 * sizeof(float);
     if (lds_anc <= 64 * 1024) {
       ProfScope prof("self_attn_anc", 4.0 * n * d * (step + 1), 8.0 * n * d * (step + 1), st);
-      SBK_LAUNCH(self_attn_anc_kernel<3>, dim3(cdiv((n / group) * H, 4)), dim3(256), lds_anc, st, a, cap);
+      SBK_LAUNCH(self_attn_anc_kernel<3>, dim3((n / group) * H), dim3(256), lds_anc, st, a, cap);
       return launch_status("self_attn_anc");
     }
   }

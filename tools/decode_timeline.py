@@ -1,7 +1,7 @@
 """The launches of ONE decoding step in issue order, from a rocprofv3 --kernel-trace CSV of tools/decode_probe.py: per position in the
 step the kernel, its mean duration over the traced steps and the mean gap in front of it (device timestamps; no HIP events in the stream).
 
-    python tools/decode_timeline.py <kernel_trace.csv> [steps]
+    python tools/decode_timeline.py <kernel_trace.csv> [steps] [anchor kernel: embed_pos (default) | decoder_step_persist ...]
 """
 import csv
 import sys
@@ -14,7 +14,7 @@ def short(k):
     return head[-46:]
 
 
-def main(path, steps=24):
+def main(path, steps=24, anchor="embed_pos"):
     rows = []
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
@@ -24,7 +24,7 @@ def main(path, steps=24):
             except (KeyError, ValueError):
                 continue
     rows.sort()
-    idx = [i for i, r in enumerate(rows) if "embed_pos" in r[2]]
+    idx = [i for i, r in enumerate(rows) if anchor in r[2]]
     idx = idx[-(steps + 1):]
     seqs = [rows[a:b] for a, b in zip(idx[:-1], idx[1:])]
     n = Counter(len(s) for s in seqs).most_common(1)[0][0]
@@ -40,4 +40,4 @@ def main(path, steps=24):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], *(int(v) for v in sys.argv[2:3]))
+    main(sys.argv[1], *(int(v) for v in sys.argv[2:3]), *sys.argv[3:4])
