@@ -273,6 +273,11 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
 // only from 2 560 rows on does it win (16.6 / 46.0 against 20.0 / 56.5 us), and the 8-worker headline is the same either way
 // (12 145 / 12 184 against 12 139 / 12 324): a launch of this size is ~10 us of fixed latency -- launch, first operand round trip,
 // exchange, stores -- plus its MFMA chain, and halving the waves doubles the chain.  Removed; profiles/r06_e_*.)
+// (Also round 6: EIGHT waves per workgroup cutting K eight ways -- a wave's chain of dependent k steps halves, two waves per SIMD, the
+// partial tiles met in two stages through the same 64 KB of LDS.  In the device timeline of a decoding step at 1 280 rows: 12.1 against
+// 13.3 us at N = K = 512, 13.9 against 13.1 with the LayerNorm prologue, 33.8 against 34.8 at K = 2 048 -- the long-K projection is not
+// waiting for its chain: 160 workgroups pull 205 MB of operand fragments out of L2 in 34 us, 6 TB/s --, 41.5 against 30.9 at N = 2 048;
+// the step 1.72 ms either way with N <= 512 routed to it, the headline 11.8-11.9 against 12.0 K.  Removed; profiles/r06_k_*.)
 // MEASUREMENT ONLY (knob 54 = 2 / 3): every XCD reads the whole buffer once (workgroup b runs on XCD b % 8 and takes slice b / 8
 // of 32), so that the launch behind it finds the operand in its XCD's L2 -- prices what a projection loses to cold operands
 // inside a decoding step (profiles/r06_b_*).  `sink` is never written (the sum of finite values is not NaN-compared true).
