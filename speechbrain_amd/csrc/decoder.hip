@@ -866,7 +866,11 @@ thread_local int g_step_min_steps = 0;
 // Measured alternatives kept behind sbk_prof_set_knob (Conformer-L, B=64, MI355X; cross_attn_step total per
 // 8 batches): frame-per-thread kernel 247 ms with either layout; row-coalesced kernel 336 ms on [B,T,2d],
 // 306 ms on head-major [B,H,T,2*Dh]; at B=128 the MFMA formulation takes 315 ms vs 303 ms.  The defaults stay 0.
-int g_self_anc = 1;       // key 55: 1 (default) = self-attention of a decoding step over shared ancestry (self_attn_anc_kernel), 0 = a wave per (hypothesis, head)
+int g_self_anc = 0;       // key 55: 1 = self-attention of a decoding step over shared ancestry (self_attn_anc_kernel), 0 (default) = a wave per
+                          // (hypothesis, head).  The shared-ancestry kernel fetches each distinct cache row once -- with the bench's random-init
+                          // weights (flat posteriors: the beams of an utterance diverge early) that is 0.55 x the L2 misses and 0.83 x the requests of
+                          // the default, and 34.0 against 28.2 us per launch at 60 steps, 31 against 16 at 24 (profiles/r06_i_*, r06_l_*): off.
+                          // The beams of a trained model share all but their last tokens; there it walks ~L + beam rows instead of L x beam.
 int g_nt_mask = 7;        // key 53: non-temporal loads of streamed-once data: 1 = ring K tiles, 2 = ring V tiles, 4 = CTC posteriors
 int g_cross_rows = 7;     // key 4: 7 (default) = the register-ring / MFMA kernel from 128 (utterance, head) pairs on, else frame-per-thread;
                           // 0 = the frame-per-thread kernel always, 5 = the ring kernel always
@@ -887,7 +891,7 @@ int self_attn_step(const float* qkv, float* kcache, float* vcache, const int32_t
   if (group < 1 || n % group != 0) group = 1;
   SelfAttnArgs a{qkv, kcache, vcache, kv_slot, out, n, d, H, d / H, step, nslot, Lmax, 1.0f / sqrtf((float)(d / H)),
                  g_step_ptr, key_tok, key_stride, key_shift, key_first, pad_idx, group};
-  // beams of an utterance share their ancestry: each distinct cache row fetched once per (utterance, head) (knob 55, default on)
+  // beams of an utterance share their ancestry: each distinct cache row fetched once per (utterance, head) (knob 55, see g_self_anc)
   if (g_self_anc && group >= 2 && group <= 16 && d == H * 64 && !key_tok && nslot < (1 << 19) && Lmax < 4096 && aligned16(qkv) &&
       aligned16(kcache) && aligned16(vcache) && aligned16(out) && d % 4 == 0) {
     // list capacity of a wave: its quarter of the positions (16-position granules) with every row distinct + its new-token rows

@@ -1436,6 +1436,7 @@ static int* knob_slot(int key) {
     case 53: return &sbk::g_nt_mask;
     case 54: return &sbk::g_x3r_probe;
     case 55: return &sbk::g_self_anc;
+    case 58: return &sbk::g_x3r_pair;
     default: return nullptr;
   }
 }

@@ -60,7 +60,11 @@ struct X3rArgs {
 // residual stream -- per-block mean / M2 in the producers' epilogues, folded by the consumer, no pass over the rows -- ran the
 // decoding step in 2.03 ms against 2.02 for this pre-pass and 2.06 for LayerNorm launches, 11.5-11.6 K audio-s/s either way:
 // profiles/r05_a_*.)
-template <int NS, int LNQ = 0>
+// PAIR (round 6, knob 58): the operand loads of TWO consecutive k steps are issued together.  A lane reads 32 bytes of its A row per
+// step, so a 128-byte line is touched by two steps -- issued one compute step apart (the rolling schedule below) the line has left
+// the 32 KB vector L1 in between (four waves x three steps x 8 KB of lines in flight) and comes from L2 twice; issued back to back
+// the second access merges with the first.
+template <int NS, int LNQ = 0, bool PAIR = false>
 __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
   constexpr int DEPTH = 4, PD = 3;  // ring size (= the unrolled body of the step loop), prefetch distance (registers)
   __shared__ float4 red[4][4][4][64];  // [wave][sub-tile][register quad][lane]: partial tiles of the four K slices (64 KB)
@@ -149,7 +153,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
         for (int j = 0; j < 2; ++j) acc[i][j] = sbk::mfma_32x32x16_bf16(bp[j][PB_[t]], ap[i][PA_[t]], acc[i][j]);
   };
 #pragma unroll
-  for (int st = 0; st < PD; ++st) load(st, st);  // (ns >= 4 > PD)
+  for (int st = 0; st < (PAIR ? DEPTH : PD); ++st) load(st, st);  // (ns >= 4 > PD)
   if constexpr (LNQ > 0) {
     // a row per 16 lanes (four rows per pass, four passes): 16-byte loads 256 B apart, both sums by DPP inside the row of lanes
     const float inv_k = 1.0f / (float)g.K;
@@ -178,7 +182,34 @@ __global__ void __launch_bounds__(256, 2) gemm_x3r_kernel(X3rArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) mean[i] = stat[i * 32 + r].x;
   }
-  if constexpr (NS > 0) {
+  if constexpr (PAIR && NS > 0) {
+#pragma unroll
+    for (int st = 0; st < NS; st += 2) {
+      compute(st % DEPTH);
+      compute((st + 1) % DEPTH);
+      sbk::sched_fence();
+      if (st + DEPTH < NS) {
+        load(st % DEPTH, st + DEPTH);
+        load((st + 1) % DEPTH, st + DEPTH + 1);
+      }
+      sbk::sched_fence();
+    }
+  } else if constexpr (PAIR) {
+#pragma unroll 1
+    for (int s0 = 0; s0 < ns; s0 += DEPTH) {  // (ns is a multiple of 4)
+#pragma unroll
+      for (int j = 0; j < DEPTH; j += 2) {
+        compute(j);
+        compute(j + 1);
+        sbk::sched_fence();
+        if (s0 + j + DEPTH < ns) {  // (uniform)
+          load(j, s0 + j + DEPTH);
+          load(j + 1, s0 + j + DEPTH + 1);
+        }
+        sbk::sched_fence();
+      }
+    }
+  } else if constexpr (NS > 0) {
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
       if (st + PD < NS) load((st + PD) % DEPTH, st + PD);
@@ -304,6 +335,9 @@ bool x3r_routed(int M, int N, int K) { return g_x3r_mode != 0 && M >= g_x3r_min_
 // prologue from a pre-pass over the rows (gemm_ln_nt_x3r; the vocabulary projection only below 4 096 columns: every column
 // tile repeats the statistics), 2 = the same, wide vocabularies included
 int g_x3r_ln = 1;
+int g_x3r_pair = 1;   // key 58: operand loads of two k steps issued together (bit 0: plain kernel -- the default: 31.0 against 34.8 us at K = 2 048,
+                      // 13.0-13.2 against 13.3 at N = K = 512 in the step's device timeline; bit 1: with the LayerNorm prologue -- off: 32.6 /
+                      // 22.7 / 14.4 against 31.5 / 21.8 / 13.0 us, its rows are in the L1 / L2 from the statistics pre-pass; profiles/r06_l_*)
 int g_x3r_probe = 0;  // key 54, MEASUREMENT ONLY (results of in-place launches are wrong with 1): 1 = every launch is issued twice, the second under the
                       // profiler name *_rep (its operands are where the first left them); 2 = the weight panel is read into every XCD's L2 by a
                       // launch in front ("x3r_touch"); 3 = the panel and the A rows
@@ -339,9 +373,11 @@ static int launch_x3r(const float* A, int lda, const uint16_t* PW, const float* 
   ProfScope prof(rep ? (ln ? "gemm_ln_x3r_rep" : "gemm_x3r_rep") : (ln ? "gemm_ln_x3r" : "gemm_x3r"), 2.0 * M * N * K,
                  4.0 * M * (double)K + 6.0 * (double)N * K + (4.0 + (R ? 4.0 : 0.0)) * M * (double)N, st);
   dim3 grid(8 * cdiv(tm, 8 / xc) * cdiv(tn, xc)), block(256);
+  const int pair = g_x3r_pair;  // bit 0: the plain kernel, bit 1: the LayerNorm-prologue kernel
   if (ln) {
     if (K == 512) {  // (the unrolled step loop for every N: the rolled one is at the register limit without the row means)
-      SBK_LAUNCH((gemm_x3r_kernel<8, 2>), grid, block, 0, st, a);
+      if (pair & 2) SBK_LAUNCH((gemm_x3r_kernel<8, 2, true>), grid, block, 0, st, a);
+      else SBK_LAUNCH((gemm_x3r_kernel<8, 2>), grid, block, 0, st, a);
     } else if (K == 256) {
       SBK_LAUNCH((gemm_x3r_kernel<4, 1>), grid, block, 0, st, a);
     } else if (K == 1024) {
@@ -352,9 +388,11 @@ static int launch_x3r(const float* A, int lda, const uint16_t* PW, const float* 
     rc_last = launch_status("gemm_ln_x3r");
   } else {
     if (K == 512 && N >= 1024 && g_x3r_mode != 3) {
-      SBK_LAUNCH((gemm_x3r_kernel<8>), grid, block, 0, st, a);
+      if (pair & 1) SBK_LAUNCH((gemm_x3r_kernel<8, 0, true>), grid, block, 0, st, a);
+      else SBK_LAUNCH((gemm_x3r_kernel<8>), grid, block, 0, st, a);
     } else {
-      SBK_LAUNCH((gemm_x3r_kernel<0>), grid, block, 0, st, a);
+      if (pair & 1) SBK_LAUNCH((gemm_x3r_kernel<0, 0, true>), grid, block, 0, st, a);
+      else SBK_LAUNCH((gemm_x3r_kernel<0>), grid, block, 0, st, a);
     }
     rc_last = launch_status("gemm_x3r");
   }

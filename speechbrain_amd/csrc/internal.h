@@ -25,7 +25,7 @@ bool x3r_routed(int M, int N, int K);
 int gemm_ln_nt_x3r(const float* A, int lda, const uint16_t* PWf, const float* bf, const float* R, int ldr, float* C, int ldc, int M,
                    int N, int K, float eps, int act, float alpha, hipStream_t st);
 bool x3r_ln_routed(int K);
-extern int g_x3r_mode, g_x3r_min_rows, g_x3r_ln, g_x3r_probe;
+extern int g_x3r_mode, g_x3r_min_rows, g_x3r_ln, g_x3r_probe, g_x3r_pair;
 // The decoding step of <= 16 hypothesis rows as ONE cooperative launch (csrc/decoder_persist.hip; keys 47 / 48).
 // persist_eligible: shapes / weights it takes (head_dim 64, folded LayerNorm weights present, <= 16 layers); decoder_step_persist
 // returns -1 when the launch cannot be made (the caller then issues the launch-per-operation step).

@@ -771,6 +771,14 @@ def test_gemm_x3r(backend, M, N, K):
             assert torch.equal(nat.gemm_nt_x3r(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out), xc
     finally:
         nat.load().sbk_prof_set_knob(51, 0)
+    # the order in which the operand loads are issued (knob 58: two k steps together) changes no bit
+    keep = nat.load().sbk_prof_get_knob(58)
+    try:
+        for sched in (0, 3):
+            nat.load().sbk_prof_set_knob(58, sched)
+            assert torch.equal(nat.gemm_nt_x3r(ad, wd, bd, rd, act=nat.ACT_SWISH, alpha=0.5), out), sched
+    finally:
+        nat.load().sbk_prof_set_knob(58, keep)
 
 
 @pytest.mark.parametrize("M,N,K", [(1280, 512, 512), (300, 132, 512), (70, 1536, 512), (1280, 2048, 512), (1, 40, 512),
@@ -806,6 +814,13 @@ def test_gemm_ln_x3r(backend, M, N, K):
         assert torch.equal(nat.gemm_ln_nt_x3r(ad, wfd, bfd, eps, residual=rd, act=nat.ACT_SWISH, alpha=0.5), out)
     plain = nat.gemm_ln_nt_x3r(ad, wfd, bfd, eps)
     assert _md(plain, (prod + b.double()).float()) <= 2e-6 * scale + 1e-5
+    keep = nat.load().sbk_prof_get_knob(58)
+    try:
+        for sched in (0, 3):  # (the issue order of the operand loads changes no bit)
+            nat.load().sbk_prof_set_knob(58, sched)
+            assert torch.equal(nat.gemm_ln_nt_x3r(ad, wfd, bfd, eps), plain), sched
+    finally:
+        nat.load().sbk_prof_set_knob(58, keep)
     if K % 256 == 0:
         two = nat.gemm_nt_x3r(nat.layernorm(ad, gd, btd, eps), wd, bd)
         assert _md(plain, two) <= 2e-6 * scale + 1e-5
@@ -1080,9 +1095,10 @@ def test_cross_attention_register_ring_kernel_edge_shapes(backend, d_model, nhea
 
 @pytest.mark.parametrize("d_model,nhead,B,beam,steps", [(128, 2, 3, 10, 70), (128, 2, 2, 16, 40), (192, 3, 5, 2, 20), (128, 2, 1, 3, 130)])
 def test_self_attention_over_shared_ancestry(backend, d_model, nhead, B, beam, steps):
-    """csrc/decoder.hip self_attn_anc_kernel (head_dim 64, 2 .. 16 beams: a wave per (utterance, head) lists the DISTINCT (slot,
-    position) cache rows of its beams' prefixes with a mask of the beams descending from each, fetches every row once and scores
-    it against all beams on the matrix cores; a (row, beam) pair outside the beam's ancestry is masked to probability 0) through the
+    """csrc/decoder.hip self_attn_anc_kernel (knob 55 = 1; head_dim 64, 2 .. 16 beams: a workgroup per (utterance, head) whose four
+    waves each list the DISTINCT (slot, position) cache rows of the beams' prefixes over a quarter of the positions, with a mask of
+    the beams descending from each row, fetch every row once and score it against all beams on the matrix cores -- a (row, beam) pair
+    outside the beam's ancestry is masked to probability 0 -- and merge their partial softmaxes through LDS) through the
     beam search: token ids and scores against the oracle's full-prefix search and against the wave-per-(hypothesis, head) kernel
     (knob 55 = 0) -- prefixes longer than 64 positions (two passes of the list builder, > 3 tiles: whole rounds of the register
     ring), a full 16-beam tile, 2 and 3 beams (masks with few bits), 5 utterances x 3 heads = 15 waves (a partial last workgroup),
@@ -1107,6 +1123,7 @@ def test_self_attention_over_shared_ancestry(backend, d_model, nhead, B, beam, s
     bs = S2STransformerBeamSearcher(modules=[tr, seq], bos_index=1, eos_index=2, min_decode_ratio=min_ratio, max_decode_ratio=ratio,
                                     beam_size=beam, using_eos_threshold=False, length_normalization=True)
     lib = nat.load()
+    keep55 = lib.sbk_prof_get_knob(55)
     lib.sbk_prof_set_knob(47, 0)  # (not the persistent few-row step, which has its own attention)
     try:
         got = {}
@@ -1127,7 +1144,7 @@ def test_self_attention_over_shared_ancestry(backend, d_model, nhead, B, beam, s
         assert min(len(h) for h in got[1][0]) >= steps - 6  # (long prefixes were actually decoded)
         assert float((got[1][1] - got[0][1]).abs().max()) <= 2e-5
     finally:
-        lib.sbk_prof_set_knob(55, 1)
+        lib.sbk_prof_set_knob(55, keep55)
         lib.sbk_prof_set_knob(47, 1)
 
 
