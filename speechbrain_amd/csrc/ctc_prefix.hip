@@ -94,9 +94,9 @@ __device__ __forceinline__ void build_segment_tables(Row row, int T, int lane, f
 
 // ---- emissions: log_softmax rows -> linear probabilities with the reference's frame mask
 __global__ void __launch_bounds__(256) ctc_emissions_kernel(float* __restrict__ x, float* __restrict__ xb_log,
-                                                            const int32_t* __restrict__ enc_len, int T, int V, int blank) {
+                                                            const int32_t* __restrict__ enc_len, int T, int V, int blank, int ldp) {
   const int b = blockIdx.y, t = blockIdx.x;
-  float* row = x + ((size_t)b * T + t) * V;
+  float* row = x + ((size_t)b * T + t) * ldp;
   const bool pad = t >= enc_len[b];
   if (threadIdx.x == 0) xb_log[b * T + t] = pad ? (blank == 0 ? 0.0f : kNeg) : row[blank];
   __syncthreads();
@@ -159,6 +159,8 @@ struct CtcStepArgs {
   // (device memory), frames [max(start, win[0] - window), min(T, win[1] + window)) are scored; NULL = every frame
   const int32_t* win;
   int window;
+  int ldp;  // row pitch of P in floats (>= V; the search pads it to whole 128-byte lines: a workgroup's 1 KB segment of a frame row
+            // then is 8 lines instead of 9 -- 20 000-byte rows at V = 5 000 are not line-aligned)
 };
 // scored frame range [start, end) of a step (ctc.py:187-200)
 __device__ __forceinline__ void ctc_frame_range(int prefix_len, int T, const int32_t* win, int window, int* start, int* end) {
@@ -205,7 +207,8 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
   int start, end;
   ctc_frame_range(a.prefix_len, T, a.win, a.window, &start, &end);
   end = ctc_clip_to_length(end, a.blank, a.enc_len[b]);
-  const float* Pb = P + (size_t)b * T * V;
+  const int ldp = a.ldp;
+  const float* Pb = P + (size_t)b * T * ldp;
   const int last_frame = a.enc_len[b] - 1;
   // the utterance's scaled gamma table [T][16] and segment exponents [nseg][16] -> LDS (coalesced copy);
   // every lane then reads the same address per frame (broadcast, conflict-free)
@@ -250,11 +253,11 @@ __global__ void __launch_bounds__(256) ctc_score_step_kernel(CtcStepArgs a, cons
       const bool ok = u >= u_begin && u < u_end;
       if constexpr (TPT == 4) {
         float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v4 = sbk::ld16<NT>(Pb + (size_t)(u + 1) * V + c4);
+        if (ok) v4 = sbk::ld16<NT>(Pb + (size_t)(u + 1) * ldp + c4);
         buf[0][q] = v4.x; buf[1][q] = v4.y; buf[2][q] = v4.z; buf[3][q] = v4.w;
       } else {
 #pragma unroll
-        for (int k = 0; k < TPT; ++k) buf[k][q] = ok ? sbk::ld4<NT>(Pb + (size_t)(u + 1) * V + cc[k]) : 0.0f;
+        for (int k = 0; k < TPT; ++k) buf[k][q] = ok ? sbk::ld4<NT>(Pb + (size_t)(u + 1) * ldp + cc[k]) : 0.0f;
       }
     }
   };
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(64) ctc_same_token_kernel(CtcStepArgs a, const
   int start, end;
   ctc_frame_range(a.prefix_len, T, a.win, a.window, &start, &end);
   end = ctc_clip_to_length(end, a.blank, a.enc_len[b]);
-  const float* Pb = P + (size_t)b * T * V;
+  const float* Pb = P + (size_t)b * T * a.ldp;
   // per-lane block-float partial over its frames, then a wave reduction on a common exponent
   float m = 0.0f;
   int E = kNegE;
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(64) ctc_same_token_kernel(CtcStepArgs a, const
     E = 0;
   }
   for (int u = start - 1 + lane; u < end - 1; u += 64) {
-    const float term = sb[(size_t)n * T + u] * Pb[(size_t)(u + 1) * V + c];
+    const float term = sb[(size_t)n * T + u] * Pb[(size_t)(u + 1) * a.ldp + c];
     const int k = sbk::frexp_exp(term);
     const int et = term > 0.0f ? se[((size_t)b * nseg + u / kSeg) * beam_pitch(a.beam) + n % a.beam] + k : kNegE;
     const float mt = sbk::fast_ldexp(term, -k);
@@ -483,6 +486,7 @@ struct CtcAdvArgs {
   const int32_t* step_ptr;
   const int32_t* win;  // attention window of this step (see CtcStepArgs)
   int window;
+  int ldp;             // row pitch of P in floats
 };
 
 __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
@@ -499,15 +503,15 @@ __global__ void __launch_bounds__(64) ctc_advance_kernel(CtcAdvArgs a) {
   const int n = blockIdx.x, lane = threadIdx.x;
   const int b = n / a.beam, p = a.parent[n], c = a.token[n];
   const bool same = a.parent_last_tok[p] == c;
-  const float* Pb = a.P + (size_t)b * T * a.V;
+  const float* Pb = a.P + (size_t)b * T * a.ldp;
   for (int tb = 0; tb < T; tb += 256) {  // 4 frames per lane per round: 12 loads in flight per lane
     float vpc[4], vpb[4];
     BF vs[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int t = min(tb + u * 64 + lane, T - 1);
-      vpc[u] = Pb[(size_t)t * a.V + c];
-      vpb[u] = Pb[(size_t)t * a.V + a.blank];
+      vpc[u] = Pb[(size_t)t * a.ldp + c];
+      vpb[u] = Pb[(size_t)t * a.ldp + a.blank];
       vs[u] = a.st_old[(size_t)p * T + t];
     }
 #pragma unroll
@@ -687,7 +691,7 @@ StateView view(float* base, int B, int beam, int T) {
 
 // floats of one CTC state buffer: BF rows + the two segment-scaled tables + segment exponents
 int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, const int32_t* enc_len, float* psi, int B,
-                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st, const int32_t* win, int window);
+                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st, const int32_t* win, int window, int ldp);
 
 size_t ctc_state_floats(int B, int beam, int T) {
   const size_t n_bh = (size_t)B * beam, bp = beam_pitch(beam);
@@ -696,8 +700,9 @@ size_t ctc_state_floats(int B, int beam, int T) {
 
 // x: [B,T,V] log_softmax(ctc_lin(enc)) on entry, linear masked posteriors on exit.
 int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, float* psi_prev, int B, int T, int V,
-                int beam, int blank, hipStream_t st) {
-  SBK_LAUNCH(ctc_emissions_kernel, dim3(T, B), dim3(256), 0, st, x, xb_log, enc_len, T, V, blank);
+                int beam, int blank, hipStream_t st, int ldp) {
+  if (ldp < V) ldp = V;
+  SBK_LAUNCH(ctc_emissions_kernel, dim3(T, B), dim3(256), 0, st, x, xb_log, enc_len, T, V, blank, ldp);
   int rc = launch_status("ctc_emissions");
   if (rc) return rc;
   StateView v = view(state, B, beam, T);
@@ -710,10 +715,11 @@ int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, f
 
 // psi[n,c] for every hypothesis / token (needs only the CTC state: can run beside the decoder step)
 int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, const int32_t* enc_len, float* psi, int B,
-                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st, const int32_t* win, int window) {
+                 int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st, const int32_t* win, int window, int ldp) {
   CtcStepArgs a{last_tok, enc_len, B, T, V, beam, prefix_len, blank, eos, 0.0f, 0, 0, 0.0f, 0.0f, g_step_ptr, 0};
   a.win = win;
   a.window = window;
+  a.ldp = ldp < V ? V : ldp;
   const StateView v = view(const_cast<float*>(state), B, beam, T);
   ProfScope prof("ctc_score_step", 2.0 * B * beam * (double)T * V, 4.0 * B * (double)T * V + 4.0 * B * beam * V, st);
   constexpr int tpt = 1;
@@ -765,11 +771,11 @@ int ctc_combine(const float* am, const float* am_max, const float* psi, const fl
 
 int ctc_advance(const float* P, const float* state_old, const float* psi, const int32_t* parent, const int32_t* token,
                 const int32_t* parent_last_tok, float* state_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
-                int prefix_len, int blank, hipStream_t st, const int32_t* win, int window) {
+                int prefix_len, int blank, hipStream_t st, const int32_t* win, int window, int ldp) {
   const StateView vo = view(const_cast<float*>(state_old), n_bh / beam, beam, T);
   const StateView vn = view(state_new, n_bh / beam, beam, T);
   CtcAdvArgs a{P, vo.st, psi, parent, token, parent_last_tok, vn.st, vn.sg, vn.sb, vn.se, psi_prev_new, n_bh, T, V, beam,
-               prefix_len, blank, g_step_ptr, win, window};
+               prefix_len, blank, g_step_ptr, win, window, ldp < V ? V : ldp};
   const size_t lds = (size_t)7 * T * sizeof(float);
   if (lds > 64 * 1024) return fail(SBK_EINVAL, "ctc_advance: T=%d too long for the LDS window", T);
   ProfScope prof("ctc_advance", 14.0 * n_bh * T, 64.0 * n_bh * T, st);
@@ -854,7 +860,7 @@ extern "C" int sbk_ctc_scorer_reset_f32(float* x, const int32_t* enc_len, void* 
   const ScorerWs w = carve_scorer(ws, B, T, V, beam);
   if (hipMemsetAsync(w.phi[1], 0, sbk::ctc_state_floats(B, beam, T) * sizeof(float), st) != hipSuccess)  // (table padding reads as zero)
     return sbk::fail(1, "ctc_scorer_reset: memset");
-  return sbk::ctc_prepare(x, w.xb, enc_len, w.phi[0], w.psi_prev[0], B, T, V, beam, blank, st);
+  return sbk::ctc_prepare(x, w.xb, enc_len, w.phi[0], w.psi_prev[0], B, T, V, beam, blank, st, V);
 }
 
 extern "C" int sbk_ctc_scorer_score_f32(const float* x, const int32_t* enc_len, void* ws, size_t ws_bytes, const int32_t* inp_tokens,
@@ -868,7 +874,7 @@ extern "C" int sbk_ctc_scorer_score_f32(const float* x, const int32_t* enc_len, 
   const ScorerWs w = carve_scorer(ws, B, T, V, beam);
   const int cur = step & 1;
   const int32_t* win = ctc_window_size > 0 ? attn_window : nullptr;
-  int rc = sbk::ctc_psi_step(x, w.phi[cur], inp_tokens, enc_len, w.psi, B, T, V, beam, step, blank, eos, st, win, ctc_window_size);
+  int rc = sbk::ctc_psi_step(x, w.phi[cur], inp_tokens, enc_len, w.psi, B, T, V, beam, step, blank, eos, st, win, ctc_window_size, V);
   if (rc) return rc;
   SBK_LAUNCH(ctc_score_delta_kernel, dim3(sbk::cdiv(V, 256), B * beam), dim3(256), 0, st, (const float*)w.psi,
              (const float*)w.psi_prev[cur], scores, V);
@@ -885,7 +891,7 @@ extern "C" int sbk_ctc_scorer_permute_f32(const float* x, void* ws, size_t ws_by
   const ScorerWs w = carve_scorer(ws, B, T, V, beam);
   const int cur = step & 1;
   return sbk::ctc_advance(x, w.phi[cur], w.psi, parent, token, parent_last_tok, w.phi[cur ^ 1], w.psi_prev[cur ^ 1], B * beam, T, V,
-                          beam, step, blank, sbk::as_stream(stream), ctc_window_size > 0 ? attn_window : nullptr, ctc_window_size);
+                          beam, step, blank, sbk::as_stream(stream), ctc_window_size > 0 ? attn_window : nullptr, ctc_window_size, V);
 }
 
 extern "C" int sbk_prof_ctc_psi_repeat_f32(float* P_logsoftmax, const int32_t* enc_len, const int32_t* last_tok,
@@ -896,14 +902,14 @@ extern "C" int sbk_prof_ctc_psi_repeat_f32(float* P_logsoftmax, const int32_t* e
   float* state = work;
   float* xb = work + sbk::ctc_state_floats(B, beam, T);
   float* psi_prev = xb + (size_t)B * T;
-  int rc = sbk::ctc_prepare(P_logsoftmax, xb, enc_len, state, psi_prev, B, T, V, beam, 0, st);
+  int rc = sbk::ctc_prepare(P_logsoftmax, xb, enc_len, state, psi_prev, B, T, V, beam, 0, st, V);
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return sbk::fail(1, "event create");
   for (int i = 0; i < 2 && !rc; ++i)
-    rc = sbk::ctc_psi_step(P_logsoftmax, state, last_tok, enc_len, psi, B, T, V, beam, prefix_len, 0, 2, st, nullptr, 0);
+    rc = sbk::ctc_psi_step(P_logsoftmax, state, last_tok, enc_len, psi, B, T, V, beam, prefix_len, 0, 2, st, nullptr, 0, V);
   (void)hipEventRecord(e0, st);
   for (int i = 0; i < iters && !rc; ++i)
-    rc = sbk::ctc_psi_step(P_logsoftmax, state, last_tok, enc_len, psi, B, T, V, beam, prefix_len, 0, 2, st, nullptr, 0);
+    rc = sbk::ctc_psi_step(P_logsoftmax, state, last_tok, enc_len, psi, B, T, V, beam, prefix_len, 0, 2, st, nullptr, 0, V);
   (void)hipEventRecord(e1, st);
   (void)hipEventSynchronize(e1);
   float ms = 0.0f;

@@ -835,11 +835,11 @@ __global__ void __launch_bounds__(256) cross_attn_avg_probs_kernel(const float* 
 __global__ void __launch_bounds__(256) log_softmax_row_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                               int V, float inv_temp, float w,
                                                               const float* __restrict__ bias,
-                                                              const float* __restrict__ bias2) {
+                                                              const float* __restrict__ bias2, int ld) {
   __shared__ float red[4];
   const int tid = threadIdx.x;
-  const float* xr = x + (size_t)blockIdx.x * V;
-  float* orow = out + (size_t)blockIdx.x * V;
+  const float* xr = x + (size_t)blockIdx.x * ld;
+  float* orow = out + (size_t)blockIdx.x * ld;
   float m = -INFINITY;
   auto at = [&](int c) SBK_INLINE_LAMBDA { return sbk::ls_logit(xr[c], bias ? bias[c] : 0.0f, bias2 ? bias2[c] : 0.0f, inv_temp); };
   for (int c = tid; c < V; c += 256) m = fmaxf(m, at(c));
@@ -949,10 +949,10 @@ int cross_attn_avg_probs(const float* q, const float* kv, const int32_t* enc_len
 }
 
 int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st,
-                     const float* bias, const float* bias2) {
+                     const float* bias, const float* bias2, int ld) {
   if (rows == 0) return 0;
   ProfScope prof("log_softmax", 4.0 * rows * V, 8.0 * rows * V, st);
-  SBK_LAUNCH(log_softmax_row_kernel, dim3(rows), dim3(256), 0, st, x, out, V, 1.0f / temperature, weight, bias, bias2);
+  SBK_LAUNCH(log_softmax_row_kernel, dim3(rows), dim3(256), 0, st, x, out, V, 1.0f / temperature, weight, bias, bias2, ld < V ? V : ld);
   return launch_status("log_softmax_rows");
 }
 
@@ -962,5 +962,5 @@ extern "C" int sbk_log_softmax_f32(const float* x, float* out, int rows, int V, 
                                    sbk_stream_t stream) {
   if (rows == 0) return 0;  // empty batch: nothing to launch, the data pointers may be NULL
   SBK_REQUIRE(x && out && rows >= 0 && V > 0 && temperature > 0.0f, "log_softmax: bad arguments");
-  return sbk::log_softmax_rows(x, out, rows, V, temperature, weight, sbk::as_stream(stream), nullptr, nullptr);
+  return sbk::log_softmax_rows(x, out, rows, V, temperature, weight, sbk::as_stream(stream), nullptr, nullptr, V);
 }

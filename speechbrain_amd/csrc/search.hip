@@ -72,13 +72,13 @@ int cross_attn_step(const float* q, const float* kv, const int32_t* enc_len, flo
                     int d, int H, int beam, hipStream_t st);
 size_t cross_attn_partial_floats(int B, int T, int H, int Dh, int beam);
 int log_softmax_rows(const float* x, float* out, int rows, int V, float temperature, float weight, hipStream_t st,
-                     const float* bias = nullptr, const float* bias2 = nullptr);
+                     const float* bias = nullptr, const float* bias2 = nullptr, int ld = 0);
 int ctc_prepare(float* x, float* xb_log, const int32_t* enc_len, float* state, float* psi_prev, int B, int T, int V,
-                int beam, int blank, hipStream_t st);
+                int beam, int blank, hipStream_t st, int ldp = 0);
 size_t ctc_state_floats(int B, int beam, int T);
 int ctc_psi_step(const float* P, const float* state, const int32_t* last_tok, const int32_t* enc_len, float* psi, int B,
                  int T, int V, int beam, int prefix_len, int blank, int eos, hipStream_t st, const int32_t* win = nullptr,
-                 int window = 0);
+                 int window = 0, int ldp = 0);
 int cross_attn_avg_probs(const float* q, const float* kv, const int32_t* enc_len, float* out, int n, int T, int d, int H,
                          int beam, hipStream_t st);
 int ctc_combine(const float* am, const float* am_max, const float* psi, const float* psi_prev, float* comb, int n_bh,
@@ -86,7 +86,7 @@ int ctc_combine(const float* am, const float* am_max, const float* psi, const fl
                 const float* extra, hipStream_t st, const int32_t* utt_min = nullptr, int beam = 1, int step = 0);
 int ctc_advance(const float* x, const float* phi_old, const float* psi, const int32_t* parent, const int32_t* token,
                 const int32_t* parent_last_tok, float* phi_new, float* psi_prev_new, int n_bh, int T, int V, int beam,
-                int prefix_len, int blank, hipStream_t st, const int32_t* win = nullptr, int window = 0);
+                int prefix_len, int blank, hipStream_t st, const int32_t* win = nullptr, int window = 0, int ldp = 0);
 int am_only(const float* am, float* comb, int n_bh, int V, int eos, int eos_floor, int use_thr, float thr,
             float minus_inf, const float* am_max, const float* extra, hipStream_t st, const int32_t* utt_min = nullptr,
             int beam = 1, int step = 0);
@@ -986,6 +986,10 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
     if (e__ != hipSuccess) return sbk::fail((int)e__, "%s: %s", #expr, hipGetErrorString(e__)); \
   } while (0)
 
+// row pitch (floats) of the CTC posteriors the search keeps: whole 128-byte lines, so that a score workgroup's 1 KB segment of a
+// frame row is 8 lines (20 000-byte rows at V = 5 000 are not line-aligned: 9 lines, 1.25 x the bytes at the fabric counter)
+static inline int ctc_pitch(int V) { return (V + 31) & ~31; }
+
 #define SBK_TRY(expr)        \
   do {                       \
     int rc__ = (expr);       \
@@ -1303,7 +1307,7 @@ void carve_beam(Carver& c, BeamBufs& b, int B, int beam, int T, int V, int Lmax,
   b.topk_idx = c.take<int32_t>((size_t)B * kTopkChunks * kMaxBeam);
   if (ctc) {
     b.psi = c.take<float>(n * V);
-    b.ctc_x = c.take<float>((size_t)B * T * V);
+    b.ctc_x = c.take<float>((size_t)B * T * ctc_pitch(V));  // frame rows padded to whole 128-byte lines
     b.ctc_xb = c.take<float>((size_t)B * T);
     for (int k = 0; k < 2; ++k) {
       b.phi[k] = c.take<float>(sbk::ctc_state_floats(B, beam, T));
@@ -1390,16 +1394,17 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
   }
   const float* extra = LM ? lb.logits : nullptr;  // weighted LM log-probs of the step
 
+  const int Vp = ctc_pitch(V);  // row pitch of the CTC posteriors
   SBK_TRY(project_memory(W, d, enc, B, T, st));
   if (ctc) {  // CTCScorer.reset_mem (scorer.py:239-255): log_softmax(ctc_lin(enc)), then the frame mask
     int rc = -1;
     if (cfg->ctc_w3 && sbk::x3_routed(B * T, V, dm))
-      rc = sbk::gemm_nt_x3(enc, dm, cfg->ctc_w3, ctc_b, nullptr, 0, bb.ctc_x, V, B * T, V, dm, SBK_ACT_NONE, 1.0f, nullptr, 0, st);
-    if (rc == -1) rc = sbk::gemm_nt(enc, dm, ctc_w, dm, ctc_b, nullptr, 0, bb.ctc_x, V, B * T, V, dm, SBK_ACT_NONE, 1.0f, nullptr, 0, st);
+      rc = sbk::gemm_nt_x3(enc, dm, cfg->ctc_w3, ctc_b, nullptr, 0, bb.ctc_x, Vp, B * T, V, dm, SBK_ACT_NONE, 1.0f, nullptr, 0, st);
+    if (rc == -1) rc = sbk::gemm_nt(enc, dm, ctc_w, dm, ctc_b, nullptr, 0, bb.ctc_x, Vp, B * T, V, dm, SBK_ACT_NONE, 1.0f, nullptr, 0, st);
     SBK_TRY(rc);
-    SBK_TRY(sbk::log_softmax_rows(bb.ctc_x, bb.ctc_x, B * T, V, 1.0f, 1.0f, st));
+    SBK_TRY(sbk::log_softmax_rows(bb.ctc_x, bb.ctc_x, B * T, V, 1.0f, 1.0f, st, nullptr, nullptr, Vp));
     SBK_HIP(hipMemsetAsync(bb.phi[1], 0, sbk::ctc_state_floats(B, beam, T) * sizeof(float), st));  // zero table padding
-    SBK_TRY(sbk::ctc_prepare(bb.ctc_x, bb.ctc_xb, enc_len, bb.phi[0], bb.psi_prev[0], B, T, V, beam, cfg->blank, st));
+    SBK_TRY(sbk::ctc_prepare(bb.ctc_x, bb.ctc_xb, enc_len, bb.phi[0], bb.psi_prev[0], B, T, V, beam, cfg->blank, st, Vp));
   }
   bb.s.pos_off = pos_off;
   SBK_LAUNCH(beam_init_kernel, dim3(sbk::cdiv(n > B ? n : B, 256)), dim3(256), 0, st, bb.s, B, beam, cfg->bos);
@@ -1437,7 +1442,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
     SBK_HIP(hipEventRecord(side->fork, st));
     SBK_HIP(hipStreamWaitEvent(cst, side->fork, 0));
     SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[0], bb.s.tokens[0], enc_len, bb.psi, B, T, V, beam, 0, cfg->blank,
-                              cfg->eos, pst));
+                              cfg->eos, pst, nullptr, 0, Vp));
     SBK_HIP(hipEventRecord(side->join, cst));
   }
   // One decoding step as a list of launches.  `counter` = true: the step number lives in device memory
@@ -1479,7 +1484,7 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
       if (side && (psi_aside || step > 0)) SBK_HIP(hipStreamWaitEvent(st, side->join, 0));  // helper-stream work done
       if (!psi_aside)
         SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[cur], bb.s.tokens[cur], enc_len, bb.psi, B, T, V, beam, step,
-                                  cfg->blank, cfg->eos, st, win, window));
+                                  cfg->blank, cfg->eos, st, win, window, Vp));
       if (fused) {  // (combined inside score_topk_row_kernel)
       } else if (cfg->ctc_candidates > 0) {  // CTC as a partial scorer: only the top candidates of every hypothesis are scored
         SBK_TRY(sbk::am_only(bb.am, bb.comb, n, V, cfg->eos, eos_floor, cfg->using_eos_threshold, cfg->eos_threshold,
@@ -1542,10 +1547,10 @@ extern "C" int sbk_beam_search_f32(const sbk_decoder_weights* W, const sbk_searc
         SBK_HIP(hipStreamWaitEvent(cst, side->fork, 0));
       }
       SBK_TRY(sbk::ctc_advance(bb.ctc_x, bb.phi[cur], bb.psi, bb.s.parent, bb.s.tokens[cur ^ 1], bb.s.tokens[cur],
-                               bb.phi[cur ^ 1], bb.psi_prev[cur ^ 1], n, T, V, beam, step, cfg->blank, cst, win, window));
+                               bb.phi[cur ^ 1], bb.psi_prev[cur ^ 1], n, T, V, beam, step, cfg->blank, cst, win, window, Vp));
       if (psi_aside)
         SBK_TRY(sbk::ctc_psi_step(bb.ctc_x, bb.phi[cur ^ 1], bb.s.tokens[cur ^ 1], enc_len, bb.psi, B, T, V, beam,
-                                  step + 1, cfg->blank, cfg->eos, pst));
+                                  step + 1, cfg->blank, cfg->eos, pst, nullptr, 0, Vp));
       if (side) SBK_HIP(hipEventRecord(side->join, cst));
     }
     if (counter) {
