@@ -545,6 +545,13 @@ int decoder_step_persist(const sbk_decoder_weights* W, const int32_t* tokens, co
   a.bar_base = bar_seq * persist_barriers(W->n_layers) * G;
   ProfScope prof("decoder_step_persist", 2.0 * n * (double)(W->n_layers * (4.0 * d * d + 2.0 * d * W->d_ffn) + (want_logits ? (double)d * W->vocab : 0.0)),
                  4.0 * (W->n_layers * (4.0 * d * d + 2.0 * d * W->d_ffn) + (want_logits ? (double)d * W->vocab : 0.0)), st);
+  if (g_persist == 2) {
+    // MEASUREMENT (knob 47 = 2): the same grid as a PLAIN launch.  MI355X_MICROARCH.md: plain, cooperative and graph launches give
+    // identical residency; what the cooperative launch adds is the check of the grid against the occupancy query (done above:
+    // G <= maxg) -- and, measured in the B = 1 timeline, an ~11-us gap on either side of the kernel (profiles/r06_h_*)
+    SBK_LAUNCH(decoder_step_persist_kernel, dim3(G), dim3(256), lds, st, a);
+    return launch_status("decoder_step_persist");
+  }
   const hipError_t e = SBK_LAUNCH_COOP(decoder_step_persist_kernel, dim3(G), dim3(256), lds, st, a);
   if (e != hipSuccess) return fail((int)e, "decoder_step_persist: cooperative launch: %s", hipGetErrorString(e));
   return 0;
