@@ -779,7 +779,11 @@ def main():
         dec = asr.mods.decoder
         saved = (dec.overlap_ctc, dec.graph_mode)
         lib = native.load()
+        # (round 6: "..._plain_launch_single_search_only" = the same kernel and grid as a PLAIN launch, knob 47 = 2: no 11-us gap on
+        #  either side of it -- but several searches at once could then each hold part of the chip and wait for the rest forever; the
+        #  cooperative launch queue runs such kernels one at a time.  Reported, never the product default, not in p50_latency_ms.)
         for mode, (ov, gm, persist) in (("persistent_step", (0, 0, 1)), ("persistent_step_helper_stream", (3, 0, 1)),
+                                        ("persistent_step_helper_stream_plain_launch_single_search_only", (3, 0, 2)),
                                         ("helper_stream", (3, 0, 0)), ("hipgraph", (0, 1, 0))):
             dec.overlap_ctc, dec.graph_mode = ov, gm
             lib.sbk_prof_set_knob(47, persist)
@@ -926,7 +930,7 @@ def main():
                 out["config"]["latency_leg"] = "own process"
         if by_mode is None:
             by_mode = latency_modes()
-        out["p50_latency_ms"] = min(by_mode.values())
+        out["p50_latency_ms"] = min(v for k, v in by_mode.items() if "single_search_only" not in k)
         out["p50_latency_ms_by_mode"] = by_mode
         out["config"]["latency_case"] = "B=1, 10 s utterance, 40 decode steps"
 

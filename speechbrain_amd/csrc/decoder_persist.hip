@@ -49,6 +49,11 @@ struct PStepArgs {
   long long* stamps;  // optional (knob 49): workgroup 0 writes the 100 MHz wall clock at the end of every phase and barrier
   int* bar;      // arrival counter of the grid barriers (monotonic over the launches of a search)
   int bar_base;  // its value when this launch starts
+  // two-level arrival (knob 59): workgroup b arrives at sub-counter b % 8 (its own 128-byte line); the arrival that completes a
+  // sub-counter's round arrives at `bar`.  G atomics on ONE address are served one after the other (~25 ns each: 3.4-3.8 us of a
+  // barrier among 128 workgroups); eight lines take them side by side.  ord_base: barriers passed before this launch.
+  int* sub;
+  int tree, ord_base;
   int n, B, T, beam, d, H, dffn, V, nl, step, Lmax, act, want_logits;
   float eps, emb_scale, attn_scale;
 };
@@ -349,6 +354,10 @@ __global__ void __launch_bounds__(256) decoder_step_persist_kernel(PStepArgs a) 
   float* xs = lds;                                  // [16][K + 4] staged rows; the attention phases' scratch
   float* red = lds + (size_t)kPRows * (Kmax + 4);   // [4][256] K-split partial tiles
   int bar = a.bar_base;
+  int ord = a.ord_base;                                             // barriers of this search passed so far
+  const int nsub = G < 8 ? G : 8, sub_k = (int)blockIdx.x & 7;
+  const int cnt_k = (G - sub_k + 7) >> 3;                           // workgroups that arrive at this sub-counter
+  int* const subp = a.sub + 32 * sub_k;
   WPref pf;
 #pragma unroll
   for (int j = 0; j < kWB; ++j) pf.w[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -362,10 +371,15 @@ __global__ void __launch_bounds__(256) decoder_step_persist_kernel(PStepArgs a) 
 #define SBK_PSTEP_BARRIER(W_, K_, N_)            \
   do {                                           \
     bar += G;                                    \
+    ++ord;                                       \
     SBK_PSTEP_STAMP();                           \
-    sbk::grid_arrive(a.bar);                     \
+    if (a.tree) {                                \
+      sbk::grid_arrive_tree(subp, ord * cnt_k, a.bar); \
+    } else {                                     \
+      sbk::grid_arrive(a.bar);                   \
+    }                                            \
     if ((W_) != nullptr) prefetch_w(pf, (W_), (K_), (N_)); \
-    sbk::grid_wait(a.bar, bar);                  \
+    sbk::grid_wait(a.bar, a.tree ? ord * nsub : bar); \
     SBK_PSTEP_STAMP();                           \
   } while (0)
   SBK_PSTEP_STAMP();
@@ -429,8 +443,13 @@ __global__ void __launch_bounds__(256) decoder_step_persist_kernel(PStepArgs a) 
 
 namespace sbk {
 
-int g_persist = 1;        // tuning knob (key 47): 0 = off; 1 = the persistent step for <= 16 hypothesis rows
+int g_persist = 1;        // tuning knob (key 47): 0 = off; 1 = the persistent step for <= 16 hypothesis rows; 2 = the same as a PLAIN launch
+                          // (18.9 against 19.7 ms per 10-s utterance: no ~11-us gaps around the kernel -- but ONLY safe while one search at a
+                          // time uses the device: the cooperative queue runs such kernels one after the other, plain launches of several
+                          // searches could each keep part of the CUs and spin on the rest)
 int g_persist_grid = 128; // tuning knob (key 48): workgroups of the cooperative launch (clamped to what the device holds)
+int g_persist_tree = 1;   // key 59: 1 (default) = the grid barriers count arrivals on eight sub-counters + a top counter (0 = one counter):
+                          // the persistent step 324 against 395 us, a 10-s utterance 19.7 against 22.6 ms (profiles/r06_o_*)
 int g_persist_stamps = 0; // measurement knob (key 49): phase time stamps of the launches (sbk_prof_persist_stamps reads the last launch's)
 static long long* g_last_stamps = nullptr;  // device buffer of the most recent stamped launch (the caller's workspace)
 static int g_last_stamp_count = 0;
@@ -536,19 +555,25 @@ int decoder_step_persist(const sbk_decoder_weights* W, const int32_t* tokens, co
   size_t lds = 0;
   const int maxg = persist_max_grid(W, Lmax, &lds);
   if (maxg < 1) return -1;
-  int G = grid_io && *grid_io > 0 ? *grid_io : (g_persist_grid < 1 ? 1 : g_persist_grid);
+  int G = grid_io && *grid_io > 0 ? (*grid_io & 0xffff) : (g_persist_grid < 1 ? 1 : g_persist_grid);
+  if (G > 0xffff) G = 0xffff;
   if (G > maxg) {
     if (grid_io && *grid_io > 0) return fail(SBK_EINVAL, "decoder_step_persist: the search's grid (%d) no longer fits the device (%d)", G, maxg);
     G = maxg;
   }
-  if (grid_io) *grid_io = G;
+  const int tree = grid_io && *grid_io > 0 ? (*grid_io >> 16) & 1 : (g_persist_tree != 0);  // (fixed per search, like the grid)
+  if (grid_io) *grid_io = G | (tree << 16);
+  a.sub = bar + 64 + 512;  // (behind the flat counter's line and the stamps: carve_decoder)
+  a.tree = tree;
+  a.ord_base = bar_seq * persist_barriers(W->n_layers);
   a.bar_base = bar_seq * persist_barriers(W->n_layers) * G;
   ProfScope prof("decoder_step_persist", 2.0 * n * (double)(W->n_layers * (4.0 * d * d + 2.0 * d * W->d_ffn) + (want_logits ? (double)d * W->vocab : 0.0)),
                  4.0 * (W->n_layers * (4.0 * d * d + 2.0 * d * W->d_ffn) + (want_logits ? (double)d * W->vocab : 0.0)), st);
   if (g_persist == 2) {
-    // MEASUREMENT (knob 47 = 2): the same grid as a PLAIN launch.  MI355X_MICROARCH.md: plain, cooperative and graph launches give
-    // identical residency; what the cooperative launch adds is the check of the grid against the occupancy query (done above:
-    // G <= maxg) -- and, measured in the B = 1 timeline, an ~11-us gap on either side of the kernel (profiles/r06_h_*)
+    // OPT-IN (knob 47 = 2; one search per device at a time): the same grid as a PLAIN launch.  MI355X_MICROARCH.md: plain, cooperative
+    // and graph launches give identical residency; the cooperative launch adds the check of the grid against the occupancy query
+    // (done above: G <= maxg), an ~11-us gap on either side of the kernel in the B = 1 timeline (profiles/r06_h_*, r06_o_*) -- and
+    // mutual exclusion among cooperative kernels, which is what makes several concurrent searches safe
     SBK_LAUNCH(decoder_step_persist_kernel, dim3(G), dim3(256), lds, st, a);
     return launch_status("decoder_step_persist");
   }

@@ -1437,6 +1437,7 @@ static int* knob_slot(int key) {
     case 54: return &sbk::g_x3r_probe;
     case 55: return &sbk::g_self_anc;
     case 58: return &sbk::g_x3r_pair;
+    case 59: return &sbk::g_persist_tree;
     default: return nullptr;
   }
 }

@@ -256,6 +256,18 @@ __device__ __forceinline__ void grid_arrive(int* ctr) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The same arrival on a two-level counter: this workgroup's sub-counter `sub` (one of up to eight, each on its own 128-byte line) and,
+// from the arrival that completes the sub-counter's round (`sub_target` = rounds x its member count), the top counter `top` the
+// waiters poll.  Atomics on one address are totally ordered, so the completing arrival is ordered after every other member's --
+// and each of those after its workgroup's drained stores: a waiter that sees the top target sees all of them.
+__device__ __forceinline__ void grid_arrive_tree(int* sub, int sub_target, int* top) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(sub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == sub_target) __hip_atomic_fetch_add(top, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 __device__ __forceinline__ void grid_wait(int* ctr, int target) {
   if (threadIdx.x == 0) {
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0) __builtin_amdgcn_s_sleep(1);

@@ -35,7 +35,7 @@ int decoder_step_persist(const sbk_decoder_weights* W, const int32_t* tokens, co
                          float* x, float* qkv, float* ctx, float* q, float* ff, float* h, float* logits, float* const* kcache,
                          float* const* vcache, float* const* ckv, int* bar, int bar_seq, int* grid_io, int step, int n, int B, int T,
                          int beam, int Lmax, bool want_logits, hipStream_t st);
-extern int g_persist, g_persist_grid, g_persist_stamps;
+extern int g_persist, g_persist_grid, g_persist_stamps, g_persist_tree;
 // Device-resident step counter of the search running on this host thread (nullptr: the step is the
 // launch argument).  When set, every step-dependent kernel reads the step from it, so that the launches
 // of one decoding step are identical for every step and can be replayed from a captured hipGraph.

@@ -970,7 +970,8 @@ void carve_decoder(Carver& c, DecoderBufs& d, const sbk_decoder_weights* W, int 
   d.splitk_floats = (size_t)4 * n * (size_t)dm;  // global split-K is used for the long-K FFN2 only
   d.splitk = c.take<float>(d.splitk_floats);
   d.xpart = c.take<float>(sbk::cross_attn_partial_floats(B, T, W->nhead, dm / W->nhead, n / (B > 0 ? B : 1)) + 64);
-  d.pbar = c.take<int32_t>(64 + 512);  // (+ 256 eight-byte phase stamps of the measurement knob 49)
+  d.pbar = c.take<int32_t>(64 + 512 + 256);  // (+ 256 eight-byte phase stamps of the measurement knob 49, + eight sub-counters of the
+                                             //  two-level grid barrier, a 128-byte line each)
   d.pseq = 0;
   d.pgrid = 0;
   for (int l = 0; l < W->n_layers; ++l) {
@@ -1000,7 +1001,7 @@ static inline int ctc_pitch(int V) { return (V + 31) & ~31; }
 int project_memory(const sbk_decoder_weights* W, const DecoderBufs& d, const float* enc, int B, int T,
                    hipStream_t st) {
   const int dm = W->d_model;
-  SBK_HIP(hipMemsetAsync(d.pbar, 0, 64 * sizeof(int32_t), st));
+  SBK_HIP(hipMemsetAsync(d.pbar, 0, (64 + 512 + 256) * sizeof(int32_t), st));
   d.pseq = 0;
   d.pgrid = 0;
   for (int l = 0; l < W->n_layers; ++l) {

@@ -334,6 +334,17 @@ def test_persistent_few_row_decoding_step_vs_oracle_and_the_launch_per_operation
             finally:
                 lib.sbk_prof_set_knob(48, 128)
             assert got[0] == base[0] and torch.equal(got[2], base[2]), grid  # (the arithmetic does not depend on the grid)
+        # the grid barriers on a two-level arrival counter (knob 59): the same results, grid sizes with full, ragged and single sub-counters
+        keep59 = lib.sbk_prof_get_knob(59)
+        try:
+            lib.sbk_prof_set_knob(59, 1)
+            for grid in (128, 3, 13, 1000):
+                lib.sbk_prof_set_knob(48, grid)
+                got = bs(e.to(dev), w.to(dev))
+                assert got[0] == base[0] and torch.equal(got[2], base[2]), ("tree", grid)
+        finally:
+            lib.sbk_prof_set_knob(59, keep59)
+            lib.sbk_prof_set_knob(48, 128)
         gs = S2STransformerGreedySearcher(modules=[mods["Transformer"], mods["seq_lin"]], bos_index=1, eos_index=2, min_decode_ratio=0.0,
                                           max_decode_ratio=8.5 / 30)
         (g_h, _, g_s, _), rep = run(lambda: gs(enc.to(dev), wl.to(dev)))

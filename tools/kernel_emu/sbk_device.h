@@ -425,6 +425,14 @@ static inline void grid_arrive(int* ctr) {  // (every fiber calls it; fiber 0 of
     __atomic_fetch_add(ctr, 1, __ATOMIC_SEQ_CST);
   }
 }
+static inline void grid_arrive_tree(int* sub, int sub_target, int* top) {
+  sbk_emu::block_barrier();
+  if (sbk_emu::cur().lin == 0) {
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    const int old = __atomic_fetch_add(sub, 1, __ATOMIC_SEQ_CST);
+    if (old + 1 == sub_target) __atomic_fetch_add(top, 1, __ATOMIC_SEQ_CST);
+  }
+}
 static inline void grid_wait(int* ctr, int target) {
   if (sbk_emu::cur().lin == 0) sbk_emu::grid_barrier_wait(ctr, target);
   sbk_emu::block_barrier();
