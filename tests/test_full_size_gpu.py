@@ -433,8 +433,8 @@ def _headline_job(durations, seed):
 
 def test_headline_shape_beam10_ctc_vs_oracle_end_to_end():
     """the headline's own shape -- Conformer-L, beam 10 + CTC 0.4, utterances of 15-16 s (T' 401,
-    64 decoding steps at 4 tokens/s, the bench's rule; the same test passed at 24 s / 16 s, T' 601, 96 steps -- the
-    oracle's Python-loop CTC scorer needs ~14 min for that, so the committed size is the smaller one) -- END TO END (waveform -> token ids: Fbank, CNN, encoder,
+    the first 40 of their 64 decoding steps; the same test passed at 64 steps in rounds 2-6 and at 24 s / 16 s, T' 601, 96 steps --
+    the oracle's Python-loop CTC scorer needs 6 and 14 min for those, so the committed size is the smaller one) -- END TO END (waveform -> token ids: Fbank, CNN, encoder,
     CTC emissions, grouped-search kernels at their long-memory sizes) against the oracle (waveform -> O.encode_batch ->
     O.beam_search).  Peaked output heads (x8) so that fp32 reassociation cannot flip a near-tie:
     token ids exact, scores within 2e-3."""
@@ -447,8 +447,10 @@ def test_headline_shape_beam10_ctc_vs_oracle_end_to_end():
         asr.mods.ctc_lin.w.weight.mul_(8.0)
     wav, lens = _headline_job([16.0, 15.0], seed=41)
     T = ((1 + wav.shape[1] // 160 - 1) // 2 + 1 - 1) // 2 + 1
-    steps = int(round(4.0 * wav.shape[1] / 16000.0))
-    assert T >= 400 and steps >= 64
+    # (40 of the 64 steps the bench's rule -- 4 tokens/s -- gives these utterances: the oracle's Python-loop CTC scorer takes 5-9 s per
+    #  step at this shape on the box's host cores, and the driver's GPU tier has a 1 200-s limit for the whole suite)
+    steps = 40
+    assert T >= 400 and steps <= int(round(4.0 * wav.shape[1] / 16000.0))
     ratio = (steps + 0.5) / T
     asr.mods.decoder.max_decode_ratio = ratio
     sd = flat_state_dict(asr)
