@@ -292,12 +292,10 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
 
         ``items``: list of (enc_states [B_g,T_g,d], wav_len [B_g]); ``ratios`` (optional): per batch
         (min_decode_ratio, max_decode_ratio), default the searcher's own.  Returns the list of ``forward`` results,
-        one per batch.  Every batch keeps its own semantics -- its own padded length T_g, hence its own step limits
+        one per batch (with ``return_topk`` the padded top-k tensors of each batch).  Every batch keeps its own semantics -- its own padded length T_g, hence its own step limits
         int(T_g * ratio) (seq2seq.py:1336-1338) and its own length normaliser for ``best_lens`` -- but the decoder
         step runs over the rows of all batches at once (csrc/search.hip, ``utt_max_steps``): with recipe-sized
         batches the per-step GEMMs otherwise see a few hundred rows and cannot fill the chip."""
-        if self.return_topk:
-            raise NotImplementedError("forward_group returns the best hypothesis per utterance (return_topk = False)")
         if self.ctc_window_size and len(items) > 1:
             raise NotImplementedError("the CTC attention window takes its frame range over the whole batch: no grouped search")
         if len(items) == 1 and ratios is None:
@@ -326,6 +324,16 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
                                                             utt_min_steps=limits[0].contiguous(),
                                                             utt_max_steps=limits[1].contiguous(), want_longest=True)
         n, L = tok.shape
+        if self.return_topk:  # every batch as forward() returns it: padded [B_g, topk, max_len_g] tensors (seq2seq.py:1712-1713)
+            K, longest_h = self.topk, longest.cpu()  # (the call's one sync; rows are utterance-major, topk per utterance)
+            out, off = [], 0
+            for B in Bs:
+                max_len = max(int(longest_h[off: off + B].max()), 1)  # this batch's pad width (seq2seq.py:1461)
+                rows = slice(off * K, (off + B) * K)
+                out.append((tok[rows, :max_len].reshape(B, K, max_len).long(), ln[rows].float().reshape(B, K) / max_len,
+                            sc[rows].reshape(B, K), lp[rows, :max_len].reshape(B, K, max_len)))
+                off += B
+            return out
         packed = torch.cat([tok.reshape(-1), ln, longest]).cpu()  # one device->host copy
         tok_h, ln_h, longest_h = packed[: n * L].reshape(n, L), packed[n * L: n * L + n], packed[n * L + n:]
         out, off = [], 0

@@ -919,6 +919,20 @@ def test_grouped_search_equals_separate_searches(backend, ctc_weight):
         assert p_g.shape == p_s.shape and float((p_g.cpu() - p_s.cpu()).abs().max()) <= 2e-5
     early = [len(h) < int(items[i][0].shape[1] * ratios[i][1]) - 1 for i, res in enumerate(separate) for h in res[0]]
     assert any(early), "the case should contain hypotheses that end through EOS before the step limit"
+    # return_topk (seq2seq.py:757-760, :1712-1713): every batch's padded [B, topk, max_len] tensors, grouped == separate
+    keep_topk = (dec.return_topk, dec.topk)
+    dec.return_topk, dec.topk = True, 3
+    try:
+        sep3 = []
+        for (enc, wl), (r_min, r_max) in zip(items, ratios):
+            dec.min_decode_ratio, dec.max_decode_ratio = r_min, r_max
+            sep3.append(dec(enc, wl))
+        for (h_g, l_g, s_g, p_g), (h_s, l_s, s_s, p_s) in zip(dec.forward_group(items, ratios), sep3):
+            assert h_g.shape == h_s.shape and torch.equal(h_g.cpu(), h_s.cpu())
+            assert float((l_g.cpu() - l_s.cpu()).abs().max()) <= 1e-6 and float((s_g.cpu() - s_s.cpu()).abs().max()) <= 2e-5
+            assert p_g.shape == p_s.shape and float((p_g.cpu() - p_s.cpu()).abs().max()) <= 2e-5
+    finally:
+        dec.return_topk, dec.topk = keep_topk
     # the same grouped search with the step number in device memory (2) and replayed from a captured hipGraph (1: on
     # the GPU, from a real stream; the emulator falls back to 2): per-utterance limits are compared against *step_ptr
     import contextlib
