@@ -67,10 +67,13 @@ class ConcurrentTranscriber:
 
     def __del__(self):  # (a transcriber dropped without close(): its streams' search buffers must not outlive it)
         try:
-            if self.device.type == "cuda":
+            if self.device.type == "cuda" and not self._closed:
                 from speechbrain_amd import native
 
-                native.release_search_workspaces(list(self.enc_streams) + [d for d in self.dec_streams if d is not None])
+                streams = list(self.enc_streams) + [d for d in self.dec_streams if d is not None]
+                native.release_search_workspaces(streams)
+                for st in streams:
+                    native.forget_stream_owner(st)  # (no synchronisation in a finaliser: the claim goes, the workspace stays)
         except Exception:
             pass
 

@@ -237,6 +237,18 @@ def _register_workspace(key, device, handle):
         _STREAM_WS[key] = ws
 
 
+def forget_stream_owner(stream):
+    """An owner of ``stream`` went away WITHOUT releasing (a transcriber dropped without ``close()``): its claim is withdrawn, the
+    workspace stays registered -- the handle's next owner releases it, or it lives as long as the process (one per pooled handle)."""
+    key = (id(load()), stream.device.index, stream.cuda_stream)
+    with _STREAM_WS_LOCK:
+        left = _STREAM_WS_REFS.get(key, 0) - 1
+        if left > 0:
+            _STREAM_WS_REFS[key] = left
+        else:
+            _STREAM_WS_REFS.pop(key, None)
+
+
 def release_stream_workspace(stream) -> bool:
     """Give back the workspace registered for a ``torch.cuda.Stream`` that will not be used again (a worker stream of a
     ConcurrentTranscriber that is being closed): sbk_stream_workspace_release, then the ~134 MB return to torch's allocator once
