@@ -69,6 +69,7 @@ MFMA_KERNELS = ("gemm", "relpos_attention", "rope_attention")
 TOKENS_PER_SECOND = 4.0
 SR = 16000
 UTTS_PER_STEP = 128
+GROUP_ENCODER_DEFAULT = 1000  # batches per encoder pass of a worker's group (0 = one pass per batch, 1000 = the whole group = the product's default)
 PMC_ROUND = 6  # the round whose rocprofv3 --pmc rows in profiles/pmc_traffic.json describe the kernels as shipped
 
 
@@ -537,8 +538,9 @@ def main():
                     help="encoder attention (RelPosMHAXL = BASELINE.json's config; RoPEMHA = the in-tree recipe)")
     ap.add_argument("--lm", action="store_true",
                     help="add the recipe's TransformerLM scorer (12 x 768, weight 0.6, T=1.15): test_search at beam 10")
-    ap.add_argument("--group-encoder", action="store_true",
-                    help="one encoder pass over the rows of all the batches of a group instead of one per batch (A/B)")
+    ap.add_argument("--group-encoder", type=int, default=-1, nargs="?", const=1000, metavar="BATCHES",
+                    help="one encoder pass over the rows of up to BATCHES batches of a group (no value: all of them) instead of one "
+                         "per batch; 0: one pass per batch; default: GROUP_ENCODER_DEFAULT)")
     ap.add_argument("--overlap-ctc", type=int, default=-1,
                     help="A/B: overlap_ctc bit mask of the workers' searches (default: 0 with several workers)")
     ap.add_argument("--graph-mode", type=int, default=0, choices=[0, 1, 2],
@@ -658,7 +660,7 @@ def main():
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats(dev)
         workers = ConcurrentTranscriber(asr, streams=streams, prioritise_search=not args.no_search_priority, group=group)
-        workers.group_encoder = args.group_encoder
+        workers.group_encoder = group_encoder_setting()
         for srch in workers.searchers:
             srch.graph_mode = args.graph_mode
             if args.overlap_ctc >= 0:
@@ -732,9 +734,18 @@ def main():
         workers.close()
         return dt, hyps, local, info
 
+    def group_encoder_setting():
+        """ConcurrentTranscriber.group_encoder of the timed region: False = one encoder pass per batch, True = one over the rows of all
+        the batches of a group, n = over n batches at a time.  Default (round 6, profiles/r06_r_*, r06_s_*): see GROUP_ENCODER_DEFAULT."""
+        v = GROUP_ENCODER_DEFAULT if args.group_encoder < 0 else args.group_encoder
+        return False if v == 0 else (True if v >= 1000 else v)
+
     def auto(max_batch):
-        # measured (tools/ab_cases.txt sweeps, profiles/r02_*): 8 workers; 4 recipe-sized batches per grouped search
-        return args.streams or 8, args.group or max(1, 128 // max_batch)
+        # 4 recipe-sized batches per grouped search (profiles/r02_* ... r06_d_*); workers: rounds 2-5 ran 8 -- with the group encoder
+        # (round 6) 4 / 5 / 6 / 8 workers read 12 629 / 12 594 / 12 612 / 12 516 and 12 559 / 12 577 / 12 533 / 12 491 at 12 steps,
+        # 12 861 / -- / 13 042 / 12 978 at the driver's 20 + 5 steps, with 78 / -- / 100 / 125 GB reserved (profiles/r06_u_*): from two
+        # workers on every further one only stretches the others' kernels (DESIGN.md section 6), so 6 -- the memory of six
+        return args.streams or 6, args.group or max(1, 128 // max_batch)
 
     def child_leg(name):
         import gc
@@ -751,7 +762,7 @@ def main():
                args.attention, "--check-every", str(args.check_every), "--streams", str(args.streams), "--group", str(args.group),
                "--graph-mode", str(args.graph_mode), "--overlap-ctc", str(args.overlap_ctc), "--latency-runs", str(args.latency_runs)]
         cmd += [x for kv in args.knob for x in ("--knob", kv)]
-        cmd += (["--lm"] if args.lm else []) + (["--group-encoder"] if args.group_encoder else []) + (
+        cmd += (["--lm"] if args.lm else []) + ["--group-encoder", str(args.group_encoder)] + (
             ["--no-search-priority"] if args.no_search_priority else [])
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
@@ -949,7 +960,7 @@ def main():
         native.prof_enable(True)
         # the same batches, grouped as in the timed region, on ONE worker stream (every launch between two events)
         one = ConcurrentTranscriber(asr, streams=1, prioritise_search=False, group=auto(args.max_batch)[1])
-        one.group_encoder = args.group_encoder
+        one.group_encoder = group_encoder_setting()
         one.plan_workers = auto(args.max_batch)[0]  # the same groups as the eight workers formed
         # every launch ALONE between its two events: a single worker would otherwise run the CTC scorer on a helper stream
         # (overlap_ctc = 3), and the layer-0 launches that co-run with the 250-us ctc_score_step were counted at 100-200 us each
@@ -1037,6 +1048,7 @@ def main():
                 h.mul_(8.0)
         try:
             par = ConcurrentTranscriber(asr, streams=auto(args.max_batch)[0], group=auto(args.max_batch)[1])
+            par.group_encoder = group_encoder_setting()
             got = par.transcribe_batches([(t[1], t[2]) for t in sub], prepare=fixed_decode_length)
             par.close()
             n_bad = 0

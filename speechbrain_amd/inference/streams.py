@@ -28,10 +28,12 @@ class ConcurrentTranscriber:
         batch keeps its own padding and step limits, the decoder step sees the rows of all of them."""
         self.asr, self.n, self.device = asr, max(1, int(streams)), asr.device
         self.group = max(1, int(group))
-        # True: a group's batches also share one encoder pass (EncoderDecoderASR.encode_group).  Measured on MI355X
-        # (profiles/r02_group_encoder_ab.jsonl): the large GEMM kernel runs 103 instead of 92 TF/s, the total kernel time
-        # is the same and 8 workers finish 1 % later (coarser interleaving) -- so it is off unless asked for
-        self.group_encoder = False
+        # True: a group's batches also share one encoder pass (EncoderDecoderASR.encode_group); an int: that many batches per pass.
+        # Round 2 (profiles/r02_group_encoder_ab.jsonl, the fp32-MFMA contractions of the time): 1 % slower.  Round 6, with the
+        # split-operand contractions (profiles/r06_r_*, r06_s_*): +1.5 % at 12 steps (12 379 / 12 376 / 12 528 / 12 291 against 12 199 /
+        # 12 148 / 12 255 / 12 169), +2.7 % at the driver's 20 steps (12 986 against 12 648; two batches per pass: 12 744) -- and 16-19 GB
+        # more reserved memory (the pools of eight encoder streams sized for 4 x the activations): on.
+        self.group_encoder = True
         if self.device.type != "cuda":
             self.n = 1
         self.searchers = [copy.copy(asr.mods.decoder) for _ in range(self.n)]
@@ -125,7 +127,11 @@ class ConcurrentTranscriber:
                     wavs = native.pcm16_to_f32(wavs)
                 dev_batches.append((wavs, wav_lens))
             if self.group_encoder and hasattr(self.asr, "encode_group"):
-                encs = self.asr.encode_group(dev_batches)  # one encoder pass over the rows of all the batches
+                # one encoder pass over the rows of several batches (True: all of the group's; an int: that many at a time)
+                per = len(dev_batches) if self.group_encoder is True else max(1, int(self.group_encoder))
+                encs = []
+                for i in range(0, len(dev_batches), per):
+                    encs += self.asr.encode_group(dev_batches[i: i + per])
             else:
                 encs = [self.asr.encode_batch(w, l) for w, l in dev_batches]
             items = [(e, l) for e, (_, l) in zip(encs, dev_batches)]
