@@ -744,8 +744,11 @@ def main():
         # 4 recipe-sized batches per grouped search (profiles/r02_* ... r06_d_*); workers: rounds 2-5 ran 8 -- with the group encoder
         # (round 6) 4 / 5 / 6 / 8 workers read 12 629 / 12 594 / 12 612 / 12 516 and 12 559 / 12 577 / 12 533 / 12 491 at 12 steps,
         # 12 861 / -- / 13 042 / 12 978 at the driver's 20 + 5 steps, with 78 / -- / 100 / 125 GB reserved (profiles/r06_u_*): from two
-        # workers on every further one only stretches the others' kernels, so 6 -- the memory of six
-        return args.streams or 6, args.group or max(1, 128 // max_batch)
+        # workers on every further one only stretches the others' kernels.  At 20 + 5 steps twice more
+        # (profiles/r06_v_*): 4 workers 12 953 / 12 939 at 78 GB reserved, 5: 13 042 / 12 950 at 82 GB, 6: 13 050 / 13 027 at 100 GB -> 5.
+        # (128-utterance batches are searched one per worker: eight of them, as before.)
+        group = args.group or max(1, 128 // max_batch)
+        return args.streams or (5 if group > 1 else 8), group
 
     def child_leg(name):
         import gc
