@@ -1,12 +1,12 @@
 #!/bin/bash
 # Round 6, visit Q: the single-utterance encoder (3.05 ms for ~200 launches issued from Python): its device-side kernel sum (timeline) and
-# the feasibility of replaying it from a captured graph (tools/latency_probe.py --graph-encoder).
+# the feasibility of replaying it from a captured graph (tools/latency_probe.py).
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$PWD
 {
-  timeout 200 python tools/latency_probe.py --runs 9 --overlap 3 --graph-encoder 2>&1 | grep -E "latency probe|graphed"
-  timeout 200 python tools/latency_probe.py --runs 9 --overlap 3 --graph-encoder --seconds 20 2>&1 | grep -E "latency probe|graphed"
+  timeout 200 python tools/latency_probe.py --runs 9 --overlap 3 2>&1 | grep -E "latency probe|graphed"
+  timeout 200 python tools/latency_probe.py --runs 9 --overlap 3 --seconds 20 2>&1 | grep -E "latency probe|graphed"
   (cd /tmp && rm -rf /tmp/tq && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tq -o t -- python $R/tools/latency_probe.py --runs 3 --overlap 3 2>&1 | grep "latency probe")
   f=$(find /tmp/tq -name "*kernel_trace.csv" | head -1)
   [ -n "$f" ] && python - "$f" <<'PY'

@@ -23,8 +23,6 @@ ap.add_argument("--graph", type=int, default=0)
 ap.add_argument("--report", action="store_true")
 ap.add_argument("--stamps", action="store_true", help="phase times of the last persistent step of a search (knob 49)")
 ap.add_argument("--knob", action="append", default=[])
-ap.add_argument("--graph-encoder", action="store_true", help="feasibility probe: the encoder forward of this utterance shape captured once "
-                "into a graph (torch.cuda.CUDAGraph around asr.encode_batch) and replayed")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -59,29 +57,6 @@ with torch.no_grad(), torch.cuda.stream(st):
     ldev = lens.to(dev)
     enc_ms = med(lambda: asr.encode_batch(wav.to(dev, non_blocking=True), lens))
     search = med(lambda: dec(enc, ldev))
-    if args.graph_encoder:
-        wdev = wav.to(dev)
-        static_in = wdev.clone()
-        for _ in range(3):  # (workspaces of the capture stream, weight images: everything that allocates or registers, outside the capture)
-            asr.encode_batch(static_in, lens)
-        torch.cuda.synchronize()
-        gph = torch.cuda.CUDAGraph()
-        try:
-            with torch.cuda.graph(gph, stream=st):
-                static_out = asr.encode_batch(static_in, lens)
-            torch.cuda.synchronize()
-
-            def replay():
-                static_in.copy_(wav, non_blocking=True)
-                gph.replay()
-                return static_out
-
-            err = float((replay() - enc).abs().max())
-            genc = med(replay)
-            gwhole = med(lambda: dec(replay(), ldev))
-            print(f"  graphed encoder: {genc:.2f} ms per replay (max |d| vs eager {err:.1e}); graphed encoder + search {gwhole:.2f} ms", flush=True)
-        except Exception as e:
-            print(f"  graphed encoder: capture failed: {type(e).__name__}: {str(e)[:300]}", flush=True)
     print(f"latency probe: {args.seconds:g} s utterance, {steps} steps: transcribe_batch {whole:.2f} ms = encoder {enc_ms:.2f} + search {search:.2f} "
           f"({1e3 * search / steps:.1f} us per step); knobs {args.knob}, overlap_ctc {args.overlap}, graph {args.graph}", flush=True)
     if args.report:
