@@ -1438,6 +1438,7 @@ static int* knob_slot(int key) {
     case 55: return &sbk::g_self_anc;
     case 58: return &sbk::g_x3r_pair;
     case 59: return &sbk::g_persist_tree;
+    case 60: return &sbk::g_attn_exp2;
     default: return nullptr;
   }
 }

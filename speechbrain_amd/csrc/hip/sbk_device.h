@@ -121,6 +121,10 @@ __device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(f32x16& x) { asm volatile("" : "+v"(x)); }  // (an MFMA result: keeps the MFMA at this point of the stream)
 
+// 2^x as ONE v_exp_f32 (no range fix-ups: fine for softmax weights, x <= 0 or -inf; libm's exp2f / expf add a scaling and its undo);
+// wave_any: the predicate holds in at least one lane (wave-uniform result)
+__device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 // wave priority for the instruction arbiter of the SIMD (0 = default .. 3)
 template <int P>
 __device__ __forceinline__ void set_prio() { __builtin_amdgcn_s_setprio(P); }

@@ -44,6 +44,7 @@ extern thread_local int g_step_min_steps;  // min_decode_steps of that search (e
 extern int g_cross_rows;
 extern int g_nt_mask;
 extern int g_self_anc;
+extern int g_attn_exp2;
 extern int g_cross_fc256;
 extern int g_x3r_xc;
 extern int g_score_fused;  // key 40: 1 (default) = the step's scoring as one pass per hypothesis row (csrc/search.hip)

@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256, 2) rope_flash_t_kernel(AttnArgs a) {
 // ring in LDS (each key tile adds the 32 rows the previous one did not have; 16 stores per lane) and every lane
 // gathers its 16 entries back (pitch 32: the 32 lanes of a half-wave hit 32 different banks).  Scores, softmax,
 // probabilities and the context product are those of rope_flash_t_kernel.
-template <int DH>
+template <int DH, bool E2 = true>  // E2: the softmax weights as 2^(.) on one v_exp_f32 (false: libm's expf -- the A/B of knob 60)
 __global__ void __launch_bounds__(256, 2) relpos_flash_t_kernel(AttnArgs a) {
   constexpr int DH2 = DH / 2;
   constexpr int NC = (DH + 31) / 32;
@@ -511,20 +511,36 @@ __global__ void __launch_bounds__(256, 2) relpos_flash_t_kernel(AttnArgs a) {
     sbk::wave_sync();  // everybody has read the lower block before the next tile overwrites its slot
     mx = fmaxf(mx, sbk::shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = m_new == -INFINITY ? 1.0f : expf(m_run - m_new);
-    float sum = 0.0f;
+    // e^(s - m) as 2^(s log2(e) - m log2(e)): one FMA + one v_exp_f32 per score (libm's expf: a scaling, the instruction and its range
+    // fix-ups); a masked score (-inf) gives exactly 0; a row whose keys are all masked so far keeps m = -inf: guarded
+    constexpr float kL2E = 1.44269504088896340736f;
+    const bool none = m_new == -INFINITY;
+    const float nm = none ? 0.0f : -m_new * kL2E;
+    float alpha, sum = 0.0f;
+    if constexpr (E2) {
+      alpha = none ? 1.0f : sbk::exp2_raw(fmaf(m_run, kL2E, nm));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc[r] = acc[r] == -INFINITY ? 0.0f : expf(acc[r] - m_new);
-      sum += acc[r];
+      for (int r = 0; r < 16; ++r) {
+        acc[r] = none ? 0.0f : sbk::exp2_raw(fmaf(acc[r], kL2E, nm));
+        sum += acc[r];
+      }
+    } else {
+      alpha = none ? 1.0f : expf(m_run - m_new);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[r] = acc[r] == -INFINITY ? 0.0f : expf(acc[r] - m_new);
+        sum += acc[r];
+      }
     }
     sum += sbk::shfl_xor(sum, 32);
     l_run = l_run * alpha + sum;
     m_run = m_new;
+    if (sbk::wave_any(alpha != 1.0f)) {  // (a new maximum is rare after the first tiles)
 #pragma unroll
-    for (int ct = 0; ct < NC; ++ct)
+      for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -789,21 +805,26 @@ __global__ void __launch_bounds__(256, 2) attn_lds_bf16_kernel(AttnLdsArgs a) {
         acc[u] = sbk::mfma_32x32x16_bf16(kb, qb[t], acc[u]);
       }
     }
-    // acc[u][r]: key 64 kt + 32u + 16 (r>>3) + 8 half + (r&7), query jl
+    // acc[u][r]: key 64 kt + 32u + 16 (r>>3) + 8 half + (r&7), query jl.  The softmax runs on the RAW scores in base 2 (round 6):
+    // p = 2^((s - m) c) with c = scale * log2(e) is one FMA + one v_exp_f32 per score where expf((s * scale) - m) was a multiply, a
+    // subtraction and libm's exp (a scaling, the instruction and its range fix-ups); the running maximum m is kept in raw units.
     float mx = -INFINITY;
     const bool tail = (kt + 1) * 64 > klen;  // uniform: only the last tile has keys to mask
+    if (tail) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * 64 + 32 * u + 16 * (r >> 3) + 8 * half + (r & 7) >= klen) acc[u][r] = -INFINITY;
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[u][r] * a.scale;
-        if (tail && kt * 64 + 32 * u + 16 * (r >> 3) + 8 * half + (r & 7) >= klen) v = -INFINITY;
-        acc[u][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[u][r]);
     mx = fmaxf(mx, sbk::shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);  // finite: key 64 kt is inside the utterance
-    const float alpha = expf(m_run - m_new);
+    const float c2 = a.scale * 1.44269504088896340736f, mc = -m_new * c2;
+    const float alpha = sbk::exp2_raw((m_run - m_new) * c2);  // (2^-inf = 0 at the first tile)
     float sum = 0.0f;
     bf16x8 pb[2][2];
 #pragma unroll
@@ -813,7 +834,7 @@ __global__ void __launch_bounds__(256, 2) attn_lds_bf16_kernel(AttnLdsArgs a) {
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          x[e] = expf(acc[u][8 * s2 + e] - m_new);
+          x[e] = sbk::exp2_raw(fmaf(acc[u][8 * s2 + e], c2, mc));
           sum += x[e];
         }
         pb[u][s2] = sbk::cvt_bf16x8(x);
@@ -821,10 +842,12 @@ __global__ void __launch_bounds__(256, 2) attn_lds_bf16_kernel(AttnLdsArgs a) {
     sum += sbk::shfl_xor(sum, 32);
     l_run = l_run * alpha + sum;
     m_run = m_new;
+    if (sbk::wave_any(alpha != 1.0f)) {  // (after the first tiles a new maximum is rare: most tiles skip the 32 rescaling multiplies)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[c][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[c][r] *= alpha;
+    }
     // O^T[channel 32c + row][query] += V^T[channel][keys 32u + 16s + 8 half .. +7] . P^T
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -853,6 +876,11 @@ __global__ void __launch_bounds__(256, 2) attn_lds_bf16_kernel(AttnLdsArgs a) {
   }
 }
 
+}  // namespace
+namespace sbk {
+int g_attn_exp2 = 1;  // key 60: 1 (default) = relpos_flash_t_kernel computes its softmax weights as 2^(.) on v_exp_f32, 0 = libm expf
+}
+namespace {
 template <int DH, bool ROPE>
 int launch_flash(const AttnArgs& a, hipStream_t st) {
   sbk::ProfScope prof(ROPE ? "rope_attention" : "relpos_attention", (ROPE ? 4.0 : 6.0) * a.B * a.H * (double)a.T * a.T * DH,
@@ -861,7 +889,11 @@ int launch_flash(const AttnArgs& a, hipStream_t st) {
     SBK_LAUNCH((rope_flash_t_kernel<DH>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
     return sbk::launch_status("sbk_rope_attention_f32");
   } else {  // transposed scores, position term through a 64-row LDS ring
-    SBK_LAUNCH((relpos_flash_t_kernel<DH>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+    if (sbk::g_attn_exp2) {
+      SBK_LAUNCH((relpos_flash_t_kernel<DH, true>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+    } else {
+      SBK_LAUNCH((relpos_flash_t_kernel<DH, false>), dim3((a.T + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+    }
     return sbk::launch_status("sbk_relpos_attention_f32");
   }
 }

@@ -393,6 +393,12 @@ static inline void glds16_uniform(const float* base, unsigned lane_byte_offset, 
   memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * sbk_emu::cur().lane, reinterpret_cast<const char*>(base) + lane_byte_offset, 16);
 }
 static inline int uniform(int v) { return v; }
+static inline float exp2_raw(float x) { return exp2f(x); }
+static inline bool wave_any(bool p) {  // (every fiber of the wave calls it)
+  int v = p ? 1 : 0;
+  for (int k = 32; k >= 1; k >>= 1) v |= shfl_idx_(v, sbk_emu::cur().lane ^ k);
+  return v != 0;
+}
 template <bool NT>
 static inline float4 ld16(const float* p) { return *reinterpret_cast<const float4*>(p); }  // (the cache policy has no host meaning)
 template <bool NT>

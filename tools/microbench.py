@@ -69,10 +69,13 @@ if __name__ == "__main__":
             P = torch.randn(2 * T - 1, d, device=dev)
             u = torch.randn(d, device=dev) * 0.1
             kl = torch.full((B,), T, dtype=torch.int32, device=dev)
+            nat.load().sbk_prof_set_knob(60, 0)  # softmax weights through libm's expf (before round 6)
+            t_rel0 = timeit(lambda: nat.relpos_attention(qkv, P, u, u, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
+            nat.load().sbk_prof_set_knob(60, 1)  # 2^(.) on one v_exp_f32 + the rescale skipped when no lane has a new maximum (default)
             t_rel = timeit(lambda: nat.relpos_attention(qkv, P, u, u, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
             t_rope = timeit(lambda: nat.rope_attention(qkv, tab.cosines, tab.sines, kl, H, 1 / math.sqrt(d)), n=20, warm=3)
             fl = B * H * T * T * Dh
-            print(f"attn B={B} T={T}: relpos {t_rel:8.1f} us {6.0*fl/t_rel/1e6:6.1f} TF/s | rope {t_rope:8.1f} us {4.0*fl/t_rope/1e6:6.1f} TF/s", flush=True)
+            print(f"attn B={B} T={T}: relpos {t_rel:8.1f} us {6.0*fl/t_rel/1e6:6.1f} TF/s (expf form {t_rel0:8.1f} us) | rope {t_rope:8.1f} us {4.0*fl/t_rope/1e6:6.1f} TF/s", flush=True)
         if "--gemm" not in sys.argv:
             sys.exit(0)
         print("decode-step GEMMs: register-operand 32x32 tiles (skinny) vs LDS-tiled")
