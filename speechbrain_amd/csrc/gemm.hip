@@ -1439,6 +1439,7 @@ static int* knob_slot(int key) {
     case 58: return &sbk::g_x3r_pair;
     case 59: return &sbk::g_persist_tree;
     case 60: return &sbk::g_attn_exp2;
+    case 61: return &sbk::g_lp256;
     default: return nullptr;
   }
 }

@@ -46,6 +46,27 @@ extern int g_nt_mask;
 extern int g_self_anc;
 extern int g_attn_exp2;
 extern int g_cross_fc256;
+// bf16 x bf16 / e4m3 x e4m3 contraction on 256 x 256 tiles (csrc/gemm_lp256.hip): the large shapes of sbk_gemm_nt_bf16a / _fp8a.
+// lda / ldw in BYTES; KT = bytes of a row of K / 128; sa / sw / C8 only with fp8 operands.  lp256_routed: key 61 and the shape.
+struct Lp256Args {
+  const unsigned char* A;
+  const unsigned char* W;
+  const float* sa;
+  const float* sw;
+  const float* bias;
+  const float* R;
+  float* C;
+  unsigned short* Cb;
+  unsigned char* C8;
+  float c8_scale;
+  long lda, ldw;
+  int ldr, ldc, ldcb, ldc8, M, N, act;
+  float alpha;
+  int KT, tiles_m, tiles_n, tiles, whole;
+};
+bool lp256_routed(int M, int N, long k_bytes);
+int gemm_nt_lp256(const Lp256Args& a, bool fp8, hipStream_t st);
+extern int g_lp256;
 extern int g_x3r_xc;
 extern int g_score_fused;  // key 40: 1 (default) = the step's scoring as one pass per hypothesis row (csrc/search.hip)
 constexpr float kCtcNeg = -1e20f;  // the CTC scorer's finite "log 0" (ctc.py:150, scorer.py:1250)

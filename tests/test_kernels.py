@@ -906,6 +906,48 @@ def test_gemm_fp8a(backend, M, N, K):
         assert _md(nxt, ref2.float()) <= 1e-4 * float((want8.abs().double() @ (_e4m3(w2q).view(64, N).abs() * w2s.cpu()[:, None]).double().t()).max()) + 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 260, 256), (520, 300, 384), (256, 512, 128), (1100, 700, 640), (1300, 1100, 256), (12000, 1280, 1280),
+                                   (12000, 3840, 1280), (4100, 1280, 5120)])
+def test_gemm_lp256_tiles_equal_the_128_tile_kernels(backend, M, N, K):
+    """csrc/gemm_lp256.hip (256 x 256 tiles, eight waves in two groups half a step apart, a ring of two 64 KB K tiles; key 61): the
+    large shapes of sbk_gemm_nt_bf16a / sbk_gemm_nt_fp8a.  It forms the same sums in the same order as the 128 x 128 kernels (K
+    ascending, one accumulator per output element, the same MFMA instruction), so every output of every form -- fp32 with bias /
+    GELU / alpha / residual, bf16, e4m3 -- must be bit-identical between the two routes; ragged last tiles in both dimensions, one
+    tile per workgroup and several, K tiles 1 ... 40; run-to-run bit-identical.  (The 128 x 128 kernels are checked against the exact
+    products in test_gemm_bf16_activation_operands / test_gemm_fp8a.)"""
+    nat, dev = backend
+    if dev.type == "cpu" and M * N * K > 5e8:
+        pytest.skip("large shape: GPU only")
+    lib = nat.load()
+    keep = lib.sbk_prof_get_knob(61)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * (1.0 + torch.arange(M)[:, None] * 0.01)
+    w = torch.randn(N, K, generator=g) * 0.05
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    ab = ad.bfloat16()
+    aq = nat.quant_rows_fp8(ad)
+
+    def forms():
+        out = [nat.gemm_nt_bf16a(ab, wd, bd, rd, act=nat.ACT_GELU, alpha=0.5), nat.gemm_nt_bf16a(ab, wd, None, None),
+               nat.gemm_nt_bf16a(ab, wd, bd, None, out_dtype=torch.bfloat16)]
+        if K % 128 == 0:
+            out += [nat.gemm_nt_fp8a(aq, wd, bd, rd, act=nat.ACT_GELU, alpha=0.5), nat.gemm_nt_fp8a(aq, wd),
+                    nat.gemm_nt_fp8a(aq, wd, bd, out_dtype=torch.bfloat16), nat.gemm_nt_fp8a(aq, wd, bd, act=nat.ACT_GELU, out_dtype="fp8").q]
+        return [o.cpu() for o in out]
+
+    try:
+        lib.sbk_prof_set_knob(61, 0)
+        want = forms()
+        lib.sbk_prof_set_knob(61, 2)
+        for _ in range(3 if dev.type == "cuda" else 1):
+            got = forms()
+            for i, (x, y) in enumerate(zip(got, want)):
+                assert torch.equal(x, y), (i, float((x.float() - y.float()).abs().max()))
+    finally:
+        lib.sbk_prof_set_knob(61, keep)
+
+
 def test_no_stream_workspace_is_an_error_not_an_allocation(backend):
     """include/sbk.h, "stream workspace" (ABI 7): the library allocates no device memory.  A stream-K launch of the
     split-operand contraction on a stream whose workspace the caller has NOT registered must fail with SBK_EINVAL and a

@@ -382,6 +382,37 @@ if __name__ == "__main__":
             line += f" bf16-A LDS-DMA kernel: {t32:7.1f} us {2.0*M*N*K/t32/1e6:7.1f} TF/s |"
             print(line, flush=True)
         sys.exit(0)
+    if "--lp256" in sys.argv:  # bf16 / e4m3 activation x weight contractions: 128 x 128 tiles (key 61 = 0) vs 256 x 256 (csrc/gemm_lp256.hip)
+        def ev_time(fn, n=20):
+            fn(); fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+        lib = nat.load()
+        # (rows, N, K, activation, output): the four projections of a Whisper large-v3 encoder layer at 8 x 30 s, then Conformer-L's
+        shapes = [(12000, 3840, 1280, nat.ACT_NONE, torch.bfloat16), (12000, 1280, 1280, nat.ACT_NONE, torch.float32),
+                  (12000, 5120, 1280, nat.ACT_GELU, "hidden"), (12000, 1280, 5120, nat.ACT_NONE, torch.float32),
+                  (12000, 5120, 1280, nat.ACT_NONE, "hidden"), (48000, 1280, 1280, nat.ACT_NONE, torch.float32),
+                  (14016, 2048, 512, nat.ACT_SWISH, torch.bfloat16), (14016, 512, 2048, nat.ACT_NONE, torch.float32)]
+        for (M, N, K, act, od) in shapes:
+            a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.05; ab = a.bfloat16(); aq = nat.quant_rows_fp8(a)
+            b = torch.randn(N, device=dev); r = torch.randn(M, N, device=dev) if od is torch.float32 else None
+            line = f"M={M} N={N} K={K} act={act} out={'fp8/bf16' if od == 'hidden' else str(od).replace('torch.', '')}:"
+            for name, fn in (("bf16a", lambda: nat.gemm_nt_bf16a(ab, w, b, r, act=act, out_dtype=torch.bfloat16 if od == "hidden" else od)),
+                             ("fp8a", lambda: nat.gemm_nt_fp8a(aq, w, b, r, act=act, out_dtype="fp8" if od == "hidden" else od))):
+                ts = []
+                for knob in (0, 2):
+                    lib.sbk_prof_set_knob(61, knob)
+                    ts.append(ev_time(fn))
+                line += f"  {name} 128^2 {ts[0]:7.1f} us {2.0*M*N*K/ts[0]/1e6:7.1f} TF/s | 256^2 {ts[1]:7.1f} us {2.0*M*N*K/ts[1]/1e6:7.1f} TF/s;"
+            lib.sbk_prof_set_knob(61, 1)
+            print(line, flush=True)
+        sys.exit(0)
     if "--copy" in sys.argv:  # what a plain streaming kernel reaches on this box (calibrates the HBM rooflines)
         for mb in (256, 1024, 4096):
             x = torch.empty(mb * 1024 * 1024 // 4, device=dev).normal_()

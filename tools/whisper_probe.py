@@ -17,8 +17,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--layers", type=int, default=4)
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--prec", default="fp32,bf16")
+ap.add_argument("--knob", action="append", default=[], metavar="KEY=VALUE")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
+for kv in args.knob:
+    native.load().sbk_prof_set_knob(*[int(v) for v in kv.split("=")])
 cfg = dict(num_mel_bins=128, d_model=1280, encoder_layers=args.layers, encoder_attention_heads=20, encoder_ffn_dim=5120,
            max_source_positions=1500, decoder_layers=0, decoder_attention_heads=20, decoder_ffn_dim=5120,
            vocab_size=51866, max_target_positions=448)
