@@ -1440,6 +1440,7 @@ static int* knob_slot(int key) {
     case 59: return &sbk::g_persist_tree;
     case 60: return &sbk::g_attn_exp2;
     case 61: return &sbk::g_lp256;
+    case 62: return &sbk::g_lp256_mode;
     default: return nullptr;
   }
 }

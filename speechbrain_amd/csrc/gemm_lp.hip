@@ -681,13 +681,15 @@ extern "C" int sbk_gemm_nt_bf16a(const uint16_t* A, int lda, const uint16_t* Wb,
               "gemm_bf16a: operand rows must be 16-byte aligned (lda=%d ldw=%d)", lda, ldw);
   SBK_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N) && (!residual || ldr >= N), "gemm_bf16a: leading dimension smaller than the row");
   SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_bf16a: unknown activation %d", act);
-  if (sbk::lp256_routed(M, N, 2L * K)) {  // the large shapes: 256 x 256 tiles (csrc/gemm_lp256.hip), the same sums in the same order
-    hipStream_t st = sbk::as_stream(stream);
-    sbk::ProfScope prof("gemm_nt_bf16a", 2.0 * M * (double)N * K,
-                        2.0 * ((double)M * K + (double)N * K) + ((C ? 4.0 : 0.0) + (Cb ? 2.0 : 0.0) + (residual ? 4.0 : 0.0)) * M * (double)N, st);
-    sbk::Lp256Args a{reinterpret_cast<const unsigned char*>(A), reinterpret_cast<const unsigned char*>(Wb), nullptr, nullptr, bias, residual,
-                     C, Cb, nullptr, 1.0f, 2L * lda, 2L * ldw, ldr, ldc, ldcb, 0, M, N, act, alpha, K / 64, 0, 0, 0, 0};
-    return sbk::gemm_nt_lp256(a, false, st);
+  {  // the large shapes: 256 x 256 tiles (csrc/gemm_lp256.hip), the same sums in the same order
+    const sbk::Lp256Args a{reinterpret_cast<const unsigned char*>(A), reinterpret_cast<const unsigned char*>(Wb), nullptr, nullptr, bias,
+                           residual, C, Cb, nullptr, 1.0f, 2L * lda, 2L * ldw, ldr, ldc, ldcb, 0, M, N, act, alpha, K / 64, 0, 0, 0, 0};
+    if (sbk::lp256_routed(a)) {
+      hipStream_t st = sbk::as_stream(stream);
+      sbk::ProfScope prof("gemm_nt_bf16a", 2.0 * M * (double)N * K,
+                          2.0 * ((double)M * K + (double)N * K) + ((C ? 4.0 : 0.0) + (Cb ? 2.0 : 0.0) + (residual ? 4.0 : 0.0)) * M * (double)N, st);
+      return sbk::gemm_nt_lp256(a, false, st);
+    }
   }
   Bf16DmaArgs a{A, Wb, bias, residual, C, Cb, lda, ldw, ldr, ldc, ldcb, M, N, K, act, alpha, 0, 0, 0};
   return launch_bf16dma(a, sbk::as_stream(stream));
@@ -705,13 +707,15 @@ extern "C" int sbk_gemm_nt_fp8a(const uint8_t* A8, int lda, const float* a_scale
   SBK_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N) && (!C8 || (ldc8 >= N && c8_scale > 0.0f)) && (!residual || ldr >= N),
               "gemm_fp8a: leading dimension smaller than the row / non-positive fp8 output scale");
   SBK_REQUIRE(act >= SBK_ACT_NONE && act <= SBK_ACT_LEAKY_RELU, "gemm_fp8a: unknown activation %d", act);
-  if (sbk::lp256_routed(M, N, (long)K)) {  // the large shapes: 256 x 256 tiles (csrc/gemm_lp256.hip), the same sums in the same order
-    hipStream_t st = sbk::as_stream(stream);
-    sbk::ProfScope prof("gemm_nt_fp8a", 2.0 * M * (double)N * K,
-                        1.0 * ((double)M * K + (double)N * K) + ((C ? 4.0 : 0.0) + (Cb ? 2.0 : 0.0) + (C8 ? 1.0 : 0.0) + (residual ? 4.0 : 0.0)) * M * (double)N, st);
-    sbk::Lp256Args a{A8, W8, a_scale, w_scale, bias, residual, C, Cb, C8, C8 ? c8_scale : 1.0f, (long)lda, (long)ldw, ldr, ldc, ldcb, ldc8,
-                     M, N, act, alpha, K / 128, 0, 0, 0, 0};
-    return sbk::gemm_nt_lp256(a, true, st);
+  {  // the large shapes: 256 x 256 tiles (csrc/gemm_lp256.hip), the same sums in the same order
+    const sbk::Lp256Args a{A8, W8, a_scale, w_scale, bias, residual, C, Cb, C8, C8 ? c8_scale : 1.0f, (long)lda, (long)ldw, ldr, ldc, ldcb, ldc8,
+                           M, N, act, alpha, K / 128, 0, 0, 0, 0};
+    if (sbk::lp256_routed(a)) {
+      hipStream_t st = sbk::as_stream(stream);
+      sbk::ProfScope prof("gemm_nt_fp8a", 2.0 * M * (double)N * K,
+                          1.0 * ((double)M * K + (double)N * K) + ((C ? 4.0 : 0.0) + (Cb ? 2.0 : 0.0) + (C8 ? 1.0 : 0.0) + (residual ? 4.0 : 0.0)) * M * (double)N, st);
+      return sbk::gemm_nt_lp256(a, true, st);
+    }
   }
   Fp8DmaArgs a{A8, W8, a_scale, w_scale, bias, residual, C, Cb, C8, C8 ? c8_scale : 1.0f, lda, ldw, ldr, ldc, ldcb, ldc8,
                M, N, K, act, alpha, 0, 0, 0};

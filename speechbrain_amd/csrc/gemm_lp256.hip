@@ -21,7 +21,8 @@
 //   * tiles in bands of eight tile rows, column-major inside a band, XCD x owns a contiguous range and its workgroups take
 //     consecutive tiles round by round: the 32 tiles an XCD works on at a time are 8 x 4 -- 12 operand blocks in its L2 instead
 //     of the 2 + tiles_n of a row-major order;
-//   * persistent over whole tiles, the next tile's first two K tiles issued before this tile's epilogue.
+//   * persistent over whole tiles, the next tile's first K tile issued before this tile's epilogue; the epilogue turns the
+//     accumulators through LDS and writes whole lines (see there).
 // Arithmetic, epilogue and outputs are gemm_nt_bf16dma_kernel's / gemm_nt_fp8dma_kernel's (fp32 accumulation; per-row scales of
 // both fp8 operands applied to the accumulators; bias, activation, alpha, fp32 residual; fp32 / bf16 / e4m3 outputs): the same sums
 // in the same order per output element (K ascending, one accumulator), so the two kernels agree bit for bit.
@@ -50,10 +51,18 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr int kRowF = 32;                 // floats per 128-byte LDS row
 constexpr int kPanelF = 256 * kRowF;      // one operand's 256 rows of a K tile
 constexpr int kSlotF = 2 * kPanelF;       // A panel | W panel: 64 KB
+constexpr int kStgPitch = 72, kStgF = 16 * kStgPitch;  // a wave's epilogue staging: 16 rows x 64 columns fp32, pitch 72 floats (8 x 4.5 KB: inside slot 1)
+static_assert(8 * kStgF <= kSlotF, "the staging area is slot 1");
 constexpr size_t kLdsBytes = (size_t)2 * kSlotF * sizeof(float);
 
-template <bool FP8>
+// MODE: 0 = the kernel.  Measurement builds (key 62, tools/microbench.py --lp256-modes; results are garbage, timings are what they are
+// for): bit 0 = no LDS-DMA after a tile's first two K tiles, 1 = no MFMAs, 2 = no epilogue, 3 = no fragment fetches.  Schedule variants
+// (same results): bit 4 = the wave raises its priority for its MFMA phase, bit 5 = the LDS reads are awaited AFTER the phase barrier
+// (group 1 in the second half of a K tile keeps the early wait: those reads are the last ones of the slot the other group refills
+// behind that barrier).
+template <bool FP8, int MODE>
 __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s) {
+  constexpr bool kNoDma = MODE & 1, kNoMfma = MODE & 2, kNoEpi = MODE & 4, kNoFetch = MODE & 8, kPrio = MODE & 16, kLateDrain = MODE & 32;
   SBK_DYN_LDS(float, lds);  // [2 slots][A 256 rows | W 256 rows][128 bytes]  (ONE LDS object)
   const unsigned char* const gA = s.A;
   const unsigned char* const gW = s.W;
@@ -134,6 +143,15 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
   // ---- fragments of one step (64 bytes of every row of the wave's 128 + 64 rows): 12 ds_read_b128, 48 registers
   using Frag = std::conditional_t<FP8, uint4, sbk::bf16x8>;
   Frag fa[2][4], fw[2][2];  // [16-byte piece][sub-tile]: bf16 = k step (8 k per lane), fp8 = low / high half of the lane's 32 bytes
+  if constexpr (kNoFetch) {  // (defined operands the optimiser cannot see through)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[p][i] = sbk::opaque_zero<Frag>();
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) fw[p][jj] = sbk::opaque_zero<Frag>();
+    }
+  }
   auto fetch = [&](int slot, int h) SBK_INLINE_LAMBDA {
     const float* sa = lds + slot * kSlotF + (wrow0 + lrow) * kRowF;
     const float* sb = lds + slot * kSlotF + kPanelF + (wcol0 + lrow) * kRowF;
@@ -149,7 +167,15 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
     }
   };
   auto multiply = [&]() SBK_INLINE_LAMBDA {
-    if constexpr (FP8) {
+    if constexpr (kNoMfma) {  // (the fetched fragments stay live)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sbk::keep(fa[p][i]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) sbk::keep(fw[p][jj]);
+      }
+    } else if constexpr (FP8) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -165,66 +191,95 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
     }
   };
 
-  // acc[i][jj][r]: row m0 + wrow0 + 32 i + (r & 3) + 8 (r >> 2) + 4 half, column n0 + wcol0 + 32 jj + lrow
+  // acc[i][jj][r]: row m0 + wrow0 + 32 i + (r & 3) + 8 (r >> 2) + 4 half, column n0 + wcol0 + 32 jj + lrow.  Written from that layout
+  // (a lane = a column) the result leaves as 4-byte / 2-byte stores and the residual arrives as 4-byte loads, eight-odd dependent
+  // batches per tile with the matrix pipe idle: measured 41-48 us of a 138 / 80-us launch (profiles/r06_z_*).  So a wave turns each
+  // 16 x 64 block through its own 4.5 KB of LDS (slot 1 is idle between two tiles; pitch 72 floats: the two
+  // half-waves of a ds_write_b32 land 32 banks apart) and handles it by rows: a lane owns four consecutive columns -- 16-byte
+  // residual loads, one block ahead of the block being written, and 16 / 8 / 4-byte stores that complete whole 128-byte lines.
+  // The arithmetic per element is the 128 x 128 kernels': (acc * (row scale * column scale) + bias) -> activation -> * alpha -> + residual.
   auto epilogue = [&](int t) SBK_INLINE_LAMBDA {
     int m0, n0;
     tile_origin(t, m0, n0);
-    const bool interior = m0 + 256 <= M && n0 + 256 <= N;  // uniform: no per-element predicates
-    static_for<0, 4>([&](auto ic) SBK_INLINE_LAMBDA {  // (a compile-time i: left to `#pragma unroll` the compiler kept this loop rolled
-      constexpr int i = decltype(ic)::value;           //  in the fp8 instantiation and moved the accumulators to scratch memory)
-      const int rbase = m0 + wrow0 + i * 32 + 4 * half;
-      float rs[16];
-      if constexpr (FP8) {
+    float* const stg = lds + kSlotF + wave * kStgF;
+    const int rq = lane >> 4, c4 = (lane & 15) * 4;
+    const int col = n0 + wcol0 + c4;
+    const bool col_ok = col < N;  // (N % 4 == 0: a vector is inside the matrix or outside as a whole)
+    const float4 bv4 = (gbias && col_ok) ? *reinterpret_cast<const float4*>(gbias + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 cs4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if constexpr (FP8) {
+      if (gsw && col_ok) cs4 = *reinterpret_cast<const float4*>(gsw + col);
+    }
+    float4 rv[2][4];
+    auto load_r = [&](int u, float4 (&dst)[4]) SBK_INLINE_LAMBDA {  // unit u: rows 16 u .. 16 u + 15 of the wave's 128
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rs[r] = gsa ? gsa[min(rbase + (r & 3) + 8 * (r >> 2), M - 1)] : 1.0f;
+      for (int it = 0; it < 4; ++it) {
+        const int row = m0 + wrow0 + 16 * u + 4 * it + rq;
+        dst[it] = (gR && col_ok && row < M) ? *reinterpret_cast<const float4*>(gR + (size_t)row * ldr + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
+    };
+    load_r(0, rv[0]);
+    static_for<0, 8>([&](auto uc) SBK_INLINE_LAMBDA {  // (compile-time indices: the accumulators stay in registers)
+      constexpr int u = decltype(uc)::value, i = u >> 1, hh = u & 1;
+      if constexpr (u + 1 < 8) load_r(u + 1, rv[(u + 1) & 1]);
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int col = n0 + wcol0 + jj * 32 + lrow;
-        const bool col_ok = interior || col < N;
-        const float bv = (gbias && col_ok) ? gbias[col] : 0.0f;
-        float v[16];
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8)  // registers 8 hh .. 8 hh + 7: rows 16 hh + (r & 3) + 8 ((r >> 2) & 1) + 4 half of the block
+          stg[((r8 & 3) + 8 * (r8 >> 2) + 4 * half) * kStgPitch + jj * 32 + lrow] = acc[i][jj][8 * hh + r8];
+      sbk::wave_sync();  // (a wave's LDS operations execute in order)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rl = 4 * it + rq, row = m0 + wrow0 + 16 * u + rl;
+        const float4 a4 = *reinterpret_cast<const float4*>(stg + rl * kStgPitch + c4);
+        const float4 r4 = rv[u & 1][it];
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+        const float bvv[4] = {bv4.x, bv4.y, bv4.z, bv4.w}, csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
+        float v[4];
         if constexpr (FP8) {
-          const float cs = (gsw && col_ok) ? gsw[col] : 1.0f;
+          const float rs = gsa ? gsa[min(row, M - 1)] : 1.0f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = acc[i][jj][r] * (rs[r] * cs) + bv;
+          for (int e = 0; e < 4; ++e) v[e] = av[e] * (rs * csv[e]) + bvv[e];
         } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = acc[i][jj][r] + bv;
+          for (int e = 0; e < 4; ++e) v[e] = av[e] + bvv[e];
         }
         switch (act) {  // uniform
           case SBK_ACT_SWISH:
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+            for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
             break;
           case SBK_ACT_GELU:
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752440f));
+            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
             break;
           case SBK_ACT_RELU:
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
             break;
           case SBK_ACT_LEAKY_RELU:
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.01f * v[r];
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.01f * v[e];
             break;
           default: break;
         }
+        if (col_ok && row < M) {
+          float o[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (interior || (col_ok && row < M)) {
-            float o = v[r] * alpha;
-            if (gR) o += gR[(size_t)row * ldr + col];
-            if (gC) gC[(size_t)row * ldc + col] = o;
-            if (gCb) gCb[(size_t)row * ldcb + col] = sbk::f32_to_bf16(o);
-            if constexpr (FP8) {
-              if (gC8) gC8[(size_t)row * ldc8 + col] = (unsigned char)(sbk::f32x2_to_fp8(o * c8_inv, 0.0f) & 0xff);
-            }
+          for (int e = 0; e < 4; ++e) {
+            o[e] = v[e] * alpha;
+            if (gR) o[e] += rr[e];
+          }
+          if (gC) *reinterpret_cast<float4*>(gC + (size_t)row * ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
+          if (gCb) *reinterpret_cast<uint2*>(gCb + (size_t)row * ldcb + col) = make_uint2(sbk::bf16_pair(o[0], o[1]), sbk::bf16_pair(o[2], o[3]));
+          if constexpr (FP8) {
+            if (gC8)
+              *reinterpret_cast<unsigned*>(gC8 + (size_t)row * ldc8 + col) =
+                  (unsigned)sbk::f32x2_to_fp8(o[0] * c8_inv, o[1] * c8_inv) | ((unsigned)sbk::f32x2_to_fp8(o[2] * c8_inv, o[3] * c8_inv) << 16);
           }
         }
       }
+      sbk::wave_sync();
     });
   };
 
@@ -236,17 +291,17 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
     sbk::sched_fence();
   };
 
-  // ---- main loop.  Per tile: K tiles 0 and 1 are in flight on entry.  Step (m, h): [issue K tile m + 1 at h = 0, m >= 1 -- its slot's
-  // previous tenant m - 1 was last fetched in step (m - 1, 1), which ended two physical barriers ago for this group and one for the
-  // other] fetch; drain the LDS reads; [h = 1: this wave's share of K tile m + 1 has landed -- read two program barriers later, i.e. at
-  // least one physical barrier after the OTHER group's wait]; barrier; MFMAs; barrier.
+  // ---- main loop.  Per tile: K tile 0 is in flight (slot 0) on entry.  Step (m, h): [issue K tile m + 1 at h = 0 -- its slot's previous
+  // tenant m - 1 was last fetched in step (m - 1, 1), which ended two physical barriers ago for this group and one for the other; at
+  // m = 0 the slot was the epilogue's staging area, done with before the tile's first barrier] fetch; drain the LDS reads; [h = 1: this
+  // wave's share of K tile m + 1 has landed -- read two program barriers later, i.e. at least one physical barrier after the OTHER
+  // group's wait]; barrier; MFMAs; barrier.
   setup(t_first);
   issue(0, 0);
-  if (KT > 1) issue(1, 1);
   zero();
   for (int ord = 0; ord < ntile; ++ord) {
     const int t = t_first + ord * t_stride;
-    sbk::vm_drain();           // K tiles 0 and 1 of this tile (and the previous tile's stores)
+    sbk::vm_drain();           // K tile 0 of this tile (and the previous tile's stores)
     sbk::block_barrier_raw();  // ... everybody's
     if (group == 1) sbk::block_barrier_raw();
 #pragma unroll 1
@@ -254,28 +309,40 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
       const int slot = m & 1;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        if (h == 0 && m >= 1 && m + 1 < KT) issue(m + 1, slot ^ 1);
-        fetch(slot, h);
-        sbk::lds_drain();
+        if constexpr (!kNoDma) {
+          if (h == 0 && m + 1 < KT) issue(m + 1, slot ^ 1);
+        }
+        if constexpr (!kNoFetch) fetch(slot, h);
+        const bool early = !kLateDrain || (h == 1 && group == 1);  // (uniform)
+        if (early) sbk::lds_drain();
         if (h == 1) sbk::vm_drain();
         phase_barrier();
+        if (!early) sbk::lds_drain();
+        if constexpr (kPrio) sbk::set_prio<1>();
         multiply();
+        if constexpr (kPrio) sbk::set_prio<0>();
         phase_barrier();
       }
     }
     if (group == 0) sbk::block_barrier_raw();
-    // both groups aligned, nobody reads LDS: the next tile's first two K tiles fly during this one's epilogue
+    // both groups aligned, nobody reads LDS: the next tile's first K tile flies (into slot 0) during this one's epilogue
     if (ord + 1 < ntile) {
       setup(t + t_stride);
-      issue(0, 0);
-      if (KT > 1) issue(1, 1);
+      if constexpr (!kNoDma) issue(0, 0);
     }
-    epilogue(t);
+    if constexpr (kNoEpi) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) sbk::pin(acc[i][jj]);
+    } else {
+      epilogue(t);
+    }
     zero();
   }
 }
 
-template <bool FP8>
+template <bool FP8, int MODE>
 int launch_lp256(const sbk::Lp256Args& a0, hipStream_t st) {
   sbk::Lp256Args a = a0;
   a.tiles_m = sbk::cdiv(a.M, 256);
@@ -292,22 +359,40 @@ int launch_lp256(const sbk::Lp256Args& a0, hipStream_t st) {
   }
   static bool once = false;
   if (!once) {
-    (void)SBK_ALLOW_DYN_LDS(gemm_nt_lp256_kernel<FP8>, kLdsBytes);
+    (void)SBK_ALLOW_DYN_LDS((gemm_nt_lp256_kernel<FP8, MODE>), kLdsBytes);
     once = true;
   }
-  SBK_LAUNCH(gemm_nt_lp256_kernel<FP8>, dim3((unsigned)G), dim3(512), kLdsBytes, st, a);
+  SBK_LAUNCH((gemm_nt_lp256_kernel<FP8, MODE>), dim3((unsigned)G), dim3(512), kLdsBytes, st, a);
   return sbk::launch_status(FP8 ? "sbk_gemm_nt_fp8a" : "sbk_gemm_nt_bf16a");
 }
 
 }  // namespace
 
 namespace sbk {
-bool lp256_routed(int M, int N, long k_bytes) {
-  if (g_lp256 == 0 || k_bytes < 256 || k_bytes % 128 != 0) return false;
+bool lp256_routed(const Lp256Args& a) {
+  const long k_bytes = 128L * a.KT;
+  if (g_lp256 == 0 || a.KT < 2) return false;
+  // the epilogue's vectors: four consecutive columns per lane
+  const auto al = [](const void* p, uintptr_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
+  if (a.N % 4 != 0 || !al(a.bias, 16) || !al(a.sw, 16) || (a.R && (a.ldr % 4 != 0 || !al(a.R, 16))) || (a.C && (a.ldc % 4 != 0 || !al(a.C, 16))) ||
+      (a.Cb && (a.ldcb % 4 != 0 || !al(a.Cb, 8))) || (a.C8 && (a.ldc8 % 4 != 0 || !al(a.C8, 4))))
+    return false;
+  (void)k_bytes;
   if (g_lp256 == 2) return true;
-  return (long)cdiv(M, 256) * cdiv(N, 256) >= 128;
+  return (long)cdiv(a.M, 256) * cdiv(a.N, 256) >= 128;
 }
+int g_lp256_mode = 0;  // key 62: MODE of gemm_nt_lp256_kernel (bf16 operands only; measurement builds 1 / 2 / 4 / 8, schedule variants 16 / 32 / 48)
 int gemm_nt_lp256(const Lp256Args& a, bool fp8, hipStream_t st) {
-  return fp8 ? launch_lp256<true>(a, st) : launch_lp256<false>(a, st);
+  if (fp8) return launch_lp256<true, 0>(a, st);
+  switch (g_lp256_mode) {
+    case 1: return launch_lp256<false, 1>(a, st);
+    case 2: return launch_lp256<false, 2>(a, st);
+    case 4: return launch_lp256<false, 4>(a, st);
+    case 8: return launch_lp256<false, 8>(a, st);
+    case 16: return launch_lp256<false, 16>(a, st);
+    case 32: return launch_lp256<false, 32>(a, st);
+    case 48: return launch_lp256<false, 48>(a, st);
+    default: return launch_lp256<false, 0>(a, st);
+  }
 }
 }  // namespace sbk

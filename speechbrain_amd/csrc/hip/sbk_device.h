@@ -125,6 +125,20 @@ __device__ __forceinline__ void pin(f32x16& x) { asm volatile("" : "+v"(x)); }  
 // wave_any: the predicate holds in at least one lane (wave-uniform result)
 __device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+// measurement builds: a 16-byte value stays live up to this point / an all-zero 16-byte value the optimiser cannot see through
+template <class T>
+__device__ __forceinline__ void keep(const T& x) {
+  static_assert(sizeof(T) == 16, "keep: one register quad");
+  const u32x4 u = __builtin_bit_cast(u32x4, x);
+  asm volatile("" ::"v"(u));
+}
+template <class T>
+__device__ __forceinline__ T opaque_zero() {
+  static_assert(sizeof(T) == 16, "opaque_zero: one register quad");
+  u32x4 u = {0u, 0u, 0u, 0u};
+  asm volatile("" : "+v"(u));
+  return __builtin_bit_cast(T, u);
+}
 // wave priority for the instruction arbiter of the SIMD (0 = default .. 3)
 template <int P>
 __device__ __forceinline__ void set_prio() { __builtin_amdgcn_s_setprio(P); }

@@ -393,6 +393,10 @@ static inline void glds16_uniform(const float* base, unsigned lane_byte_offset, 
   memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * sbk_emu::cur().lane, reinterpret_cast<const char*>(base) + lane_byte_offset, 16);
 }
 static inline int uniform(int v) { return v; }
+template <class T>
+static inline void keep(const T&) {}
+template <class T>
+static inline T opaque_zero() { T t; memset(&t, 0, sizeof(T)); return t; }
 static inline float exp2_raw(float x) { return exp2f(x); }
 static inline bool wave_any(bool p) {  // (every fiber of the wave calls it)
   int v = p ? 1 : 0;

@@ -382,6 +382,36 @@ if __name__ == "__main__":
             line += f" bf16-A LDS-DMA kernel: {t32:7.1f} us {2.0*M*N*K/t32/1e6:7.1f} TF/s |"
             print(line, flush=True)
         sys.exit(0)
+    if "--lp256-modes" in sys.argv:  # measurement builds / schedule variants of gemm_nt_lp256_kernel (key 62), bf16 operands
+        def ev_time(fn, n=20):
+            fn(); fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+        lib = nat.load()
+        names = {0: "kernel", 1: "no LDS-DMA in the loop", 2: "no MFMAs", 4: "no epilogue", 8: "no fragment fetches", 16: "MFMA phase at priority 1",
+                 32: "LDS reads awaited behind the barrier", 48: "both"}
+        for (M, N, K, od, res) in [(12000, 3840, 1280, torch.bfloat16, False), (12000, 1280, 5120, torch.float32, True),
+                                   (12000, 1280, 1280, torch.float32, True), (8192, 8192, 8192, torch.bfloat16, False)]:
+            a = torch.randn(M, K, device=dev).bfloat16(); w = torch.randn(N, K, device=dev) * 0.05
+            b = torch.randn(N, device=dev); r = torch.randn(M, N, device=dev) if res else None
+            fn = lambda: nat.gemm_nt_bf16a(a, w, b, r, out_dtype=od)
+            lib.sbk_prof_set_knob(61, 0)
+            t = ev_time(fn)
+            print(f"M={M} N={N} K={K} out={str(od).replace('torch.', '')}{' + residual' if res else ''}: 128^2 kernel {t:7.1f} us {2.0*M*N*K/t/1e6:7.1f} TF/s", flush=True)
+            lib.sbk_prof_set_knob(61, 2)
+            for mode in (0, 1, 2, 4, 8, 16, 32, 48, 0):
+                lib.sbk_prof_set_knob(62, mode)
+                t = ev_time(fn)
+                print(f"    mode {mode:2d} ({names[mode]}): {t:7.1f} us {2.0*M*N*K/t/1e6:7.1f} TF/s", flush=True)
+            lib.sbk_prof_set_knob(62, 0)
+            lib.sbk_prof_set_knob(61, 1)
+        sys.exit(0)
     if "--lp256" in sys.argv:  # bf16 / e4m3 activation x weight contractions: 128 x 128 tiles (key 61 = 0) vs 256 x 256 (csrc/gemm_lp256.hip)
         def ev_time(fn, n=20):
             fn(); fn()
