@@ -21,7 +21,8 @@
 //   * tiles in bands of eight tile rows, column-major inside a band, XCD x owns a contiguous range and its workgroups take
 //     consecutive tiles round by round: the 32 tiles an XCD works on at a time are 8 x 4 -- 12 operand blocks in its L2 instead
 //     of the 2 + tiles_n of a row-major order;
-//   * persistent over whole tiles, the next tile's first K tile issued before this tile's epilogue; the epilogue turns the
+//   * persistent over whole tiles, the K tiles of consecutive output tiles one stream through the ring (the next tile's first K tile
+//     lands under this tile's last steps; nothing waits for an epilogue's stores at a tile's start); the epilogue turns the
 //     accumulators through LDS and writes whole lines (see there).
 // Arithmetic, epilogue and outputs are gemm_nt_bf16dma_kernel's / gemm_nt_fp8dma_kernel's (fp32 accumulation; per-row scales of
 // both fp8 operands applied to the accumulators; bias, activation, alpha, fp32 residual; fp32 / bf16 / e4m3 outputs): the same sums
@@ -52,7 +53,7 @@ constexpr int kRowF = 32;                 // floats per 128-byte LDS row
 constexpr int kPanelF = 256 * kRowF;      // one operand's 256 rows of a K tile
 constexpr int kSlotF = 2 * kPanelF;       // A panel | W panel: 64 KB
 constexpr int kStgPitch = 72, kStgF = 16 * kStgPitch;  // a wave's epilogue staging: 16 rows x 64 columns fp32, pitch 72 floats (8 x 4.5 KB: inside slot 1)
-static_assert(8 * kStgF <= kSlotF, "the staging area is slot 1");
+static_assert(8 * kStgF <= kSlotF, "the staging area is one slot");
 constexpr size_t kLdsBytes = (size_t)2 * kSlotF * sizeof(float);
 
 // MODE: 0 = the kernel.  Measurement builds (key 62, tools/microbench.py --lp256-modes; results are garbage, timings are what they are
@@ -60,7 +61,7 @@ constexpr size_t kLdsBytes = (size_t)2 * kSlotF * sizeof(float);
 // (same results): bit 4 = the wave raises its priority for its MFMA phase, bit 5 = the LDS reads are awaited AFTER the phase barrier
 // (group 1 in the second half of a K tile keeps the early wait: those reads are the last ones of the slot the other group refills
 // behind that barrier).
-template <bool FP8, int MODE>
+template <bool FP8, int MODE, int ACT>
 __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s) {
   constexpr bool kNoDma = MODE & 1, kNoMfma = MODE & 2, kNoEpi = MODE & 4, kNoFetch = MODE & 8, kPrio = MODE & 16, kLateDrain = MODE & 32;
   SBK_DYN_LDS(float, lds);  // [2 slots][A 256 rows | W 256 rows][128 bytes]  (ONE LDS object)
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
   float* const gC = s.C;
   unsigned short* const gCb = s.Cb;
   unsigned char* const gC8 = s.C8;
-  const int ldr = s.ldr, ldc = s.ldc, ldcb = s.ldcb, ldc8 = s.ldc8, M = s.M, N = s.N, act = s.act;
+  const int ldr = s.ldr, ldc = s.ldc, ldcb = s.ldcb, ldc8 = s.ldc8, M = s.M, N = s.N;
   const long lda = s.lda, ldw = s.ldw;  // bytes
   const float alpha = s.alpha, c8_inv = 1.0f / s.c8_scale;
   const int tiles_m = s.tiles_m, tiles_n = s.tiles_n, KT = s.KT;
@@ -194,28 +195,36 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
   // acc[i][jj][r]: row m0 + wrow0 + 32 i + (r & 3) + 8 (r >> 2) + 4 half, column n0 + wcol0 + 32 jj + lrow.  Written from that layout
   // (a lane = a column) the result leaves as 4-byte / 2-byte stores and the residual arrives as 4-byte loads, eight-odd dependent
   // batches per tile with the matrix pipe idle: measured 41-48 us of a 138 / 80-us launch (profiles/r06_z_*).  So a wave turns each
-  // 16 x 64 block through its own 4.5 KB of LDS (slot 1 is idle between two tiles; pitch 72 floats: the two
+  // 16 x 64 block through its own 4.5 KB of LDS (the slot of the tile's last K tile; pitch 72 floats: the two
   // half-waves of a ds_write_b32 land 32 banks apart) and handles it by rows: a lane owns four consecutive columns -- 16-byte
   // residual loads, one block ahead of the block being written, and 16 / 8 / 4-byte stores that complete whole 128-byte lines.
   // The arithmetic per element is the 128 x 128 kernels': (acc * (row scale * column scale) + bias) -> activation -> * alpha -> + residual.
-  auto epilogue = [&](int t) SBK_INLINE_LAMBDA {
+  // Straight-line code: the activation is a template parameter, interior tiles carry no per-lane predicates, the residual's loads are
+  // unconditional on clamped addresses and the four LDS reads of a unit are issued together -- the first form of this epilogue had a
+  // run-time switch and exec-mask branches around every load and store, and the compiler serialised it into 32 dependent
+  // read -> wait -> store round trips per wave (12 us per tile).
+  auto epilogue_tile = [&](int t, int stg_slot, auto edge_c, auto res_c) SBK_INLINE_LAMBDA {
+    constexpr bool EDGE = decltype(edge_c)::value, HAS_R = decltype(res_c)::value;
     int m0, n0;
     tile_origin(t, m0, n0);
-    float* const stg = lds + kSlotF + wave * kStgF;
+    float* const stg = lds + stg_slot * kSlotF + wave * kStgF;
     const int rq = lane >> 4, c4 = (lane & 15) * 4;
     const int col = n0 + wcol0 + c4;
-    const bool col_ok = col < N;  // (N % 4 == 0: a vector is inside the matrix or outside as a whole)
-    const float4 bv4 = (gbias && col_ok) ? *reinterpret_cast<const float4*>(gbias + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float4 cs4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    const bool col_ok = !EDGE || col < N;        // (N % 4 == 0: a vector is inside the matrix or outside as a whole)
+    const int colc = EDGE ? min(col, N - 4) : col;  // an address inside the matrix for the lanes past its edge
+    float4 bv4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), cs4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (gbias) bv4 = *reinterpret_cast<const float4*>(gbias + colc);
     if constexpr (FP8) {
-      if (gsw && col_ok) cs4 = *reinterpret_cast<const float4*>(gsw + col);
+      if (gsw) cs4 = *reinterpret_cast<const float4*>(gsw + colc);
     }
     float4 rv[2][4];
     auto load_r = [&](int u, float4 (&dst)[4]) SBK_INLINE_LAMBDA {  // unit u: rows 16 u .. 16 u + 15 of the wave's 128
+      if constexpr (HAS_R) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = m0 + wrow0 + 16 * u + 4 * it + rq;
-        dst[it] = (gR && col_ok && row < M) ? *reinterpret_cast<const float4*>(gR + (size_t)row * ldr + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int it = 0; it < 4; ++it) {
+          const int row = m0 + wrow0 + 16 * u + 4 * it + rq;
+          dst[it] = *reinterpret_cast<const float4*>(gR + (size_t)(EDGE ? min(row, M - 1) : row) * ldr + colc);
+        }
       }
     };
     load_r(0, rv[0]);
@@ -228,48 +237,48 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
         for (int r8 = 0; r8 < 8; ++r8)  // registers 8 hh .. 8 hh + 7: rows 16 hh + (r & 3) + 8 ((r >> 2) & 1) + 4 half of the block
           stg[((r8 & 3) + 8 * (r8 >> 2) + 4 * half) * kStgPitch + jj * 32 + lrow] = acc[i][jj][8 * hh + r8];
       sbk::wave_sync();  // (a wave's LDS operations execute in order)
+      float4 a4[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) a4[it] = *reinterpret_cast<const float4*>(stg + (4 * it + rq) * kStgPitch + c4);
+      sbk::wave_sync();
+      float rs4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+      if constexpr (FP8) {
+        if (gsa) {  // (uniform)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) rs4[it] = gsa[min(m0 + wrow0 + 16 * u + 4 * it + rq, M - 1)];
+        }
+      }
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int rl = 4 * it + rq, row = m0 + wrow0 + 16 * u + rl;
-        const float4 a4 = *reinterpret_cast<const float4*>(stg + rl * kStgPitch + c4);
+        const int row = m0 + wrow0 + 16 * u + 4 * it + rq;
         const float4 r4 = rv[u & 1][it];
-        const float av[4] = {a4.x, a4.y, a4.z, a4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+        const float av[4] = {a4[it].x, a4[it].y, a4[it].z, a4[it].w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+        (void)rr;
         const float bvv[4] = {bv4.x, bv4.y, bv4.z, bv4.w}, csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
         float v[4];
         if constexpr (FP8) {
-          const float rs = gsa ? gsa[min(row, M - 1)] : 1.0f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = av[e] * (rs * csv[e]) + bvv[e];
+          for (int e = 0; e < 4; ++e) v[e] = av[e] * (rs4[it] * csv[e]) + bvv[e];
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = av[e] + bvv[e];
         }
-        switch (act) {  // uniform
-          case SBK_ACT_SWISH:
+        if constexpr (ACT == SBK_ACT_SWISH) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
-            break;
-          case SBK_ACT_GELU:
+          for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+        } else if constexpr (ACT == SBK_ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-            break;
-          case SBK_ACT_RELU:
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-            break;
-          case SBK_ACT_LEAKY_RELU:
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.01f * v[e];
-            break;
-          default: break;
+          for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        } else {
+          static_assert(ACT == SBK_ACT_NONE, "lp256: activation not instantiated");
         }
-        if (col_ok && row < M) {
-          float o[4];
+        float o[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = v[e] * alpha;
-            if (gR) o[e] += rr[e];
-          }
+        for (int e = 0; e < 4; ++e) {
+          o[e] = v[e] * alpha;
+          if constexpr (HAS_R) o[e] += rr[e];
+        }
+        if (!EDGE || (col_ok && row < M)) {
           if (gC) *reinterpret_cast<float4*>(gC + (size_t)row * ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
           if (gCb) *reinterpret_cast<uint2*>(gCb + (size_t)row * ldcb + col) = make_uint2(sbk::bf16_pair(o[0], o[1]), sbk::bf16_pair(o[2], o[3]));
           if constexpr (FP8) {
@@ -279,8 +288,29 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
           }
         }
       }
-      sbk::wave_sync();
     });
+  };
+  auto epilogue = [&](int t, int stg_slot) SBK_INLINE_LAMBDA {
+    int m0, n0;
+    tile_origin(t, m0, n0);
+    // (four straight-line variants.  With the residual behind a run-time `if (gR)` the compiler saw a path on which its loads are
+    // requested and never consumed, and -- their registers being the main loop's fragment registers -- put an s_waitcnt vmcnt(0) in
+    // front of the loop's first ds_read: every K tile then waited for the LDS-DMA issued just before it; bf16 1 290 -> 820 TF/s at
+    // 8 192^3, profiles/r06_ac_*)
+    const bool interior = m0 + 256 <= M && n0 + 256 <= N;  // (uniform)
+    if (gR) {
+      if (interior) {
+        epilogue_tile(t, stg_slot, std::false_type{}, std::true_type{});
+      } else {
+        epilogue_tile(t, stg_slot, std::true_type{}, std::true_type{});
+      }
+    } else {
+      if (interior) {
+        epilogue_tile(t, stg_slot, std::false_type{}, std::false_type{});
+      } else {
+        epilogue_tile(t, stg_slot, std::true_type{}, std::false_type{});
+      }
+    }
   };
 
   // the barrier between two phases, pinned by scheduling fences (gemm_nt_x3p_kernel: MFMAs touch no memory, the scheduler would
@@ -291,26 +321,36 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
     sbk::sched_fence();
   };
 
-  // ---- main loop.  Per tile: K tile 0 is in flight (slot 0) on entry.  Step (m, h): [issue K tile m + 1 at h = 0 -- its slot's previous
-  // tenant m - 1 was last fetched in step (m - 1, 1), which ended two physical barriers ago for this group and one for the other; at
-  // m = 0 the slot was the epilogue's staging area, done with before the tile's first barrier] fetch; drain the LDS reads; [h = 1: this
-  // wave's share of K tile m + 1 has landed -- read two program barriers later, i.e. at least one physical barrier after the OTHER
-  // group's wait]; barrier; MFMAs; barrier.
+  // ---- main loop.  The K tiles of this workgroup's tiles form ONE stream n = 0, 1, ... through the two slots (slot n & 1): the first K
+  // tile of the next output tile is just the next K tile.  Step (n, h): [at h = 0 issue K tile n + 1 into the other slot -- its previous
+  // tenant n - 1 was last fetched in step (n - 1, 1), which ended two physical barriers ago for this group and one for the other; behind
+  // an output tile's end the slot was that tile's epilogue staging area, released by the barrier after the epilogue] fetch; drain
+  // the LDS reads; [h = 1: this wave's share of K tile n + 1 has landed -- read two program barriers later, i.e. at least one physical
+  // barrier after the OTHER group's wait]; barrier; MFMAs; barrier.  Nothing waits for an epilogue's stores at a tile's start: they are
+  // first waited for half a K tile into the next tile, together with that tile's second K tile.
   setup(t_first);
   issue(0, 0);
   zero();
+  sbk::vm_drain();           // K tile 0
+  sbk::block_barrier_raw();  // ... everybody's share of it
+  if (group == 1) sbk::block_barrier_raw();
+  int n = 0;  // K tiles consumed so far (uniform)
   for (int ord = 0; ord < ntile; ++ord) {
     const int t = t_first + ord * t_stride;
-    sbk::vm_drain();           // K tile 0 of this tile (and the previous tile's stores)
-    sbk::block_barrier_raw();  // ... everybody's
-    if (group == 1) sbk::block_barrier_raw();
 #pragma unroll 1
-    for (int m = 0; m < KT; ++m) {
-      const int slot = m & 1;
+    for (int m = 0; m < KT; ++m, ++n) {
+      const int slot = n & 1;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if constexpr (!kNoDma) {
-          if (h == 0 && m + 1 < KT) issue(m + 1, slot ^ 1);
+          if (h == 0) {
+            if (m + 1 < KT) {
+              issue(m + 1, slot ^ 1);
+            } else if (ord + 1 < ntile) {  // (this tile's last K tile was issued a K tile ago: the loader moves on to the next tile)
+              setup(t + t_stride);
+              issue(0, slot ^ 1);
+            }
+          }
         }
         if constexpr (!kNoFetch) fetch(slot, h);
         const bool early = !kLateDrain || (h == 1 && group == 1);  // (uniform)
@@ -325,24 +365,29 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
       }
     }
     if (group == 0) sbk::block_barrier_raw();
-    // both groups aligned, nobody reads LDS: the next tile's first K tile flies (into slot 0) during this one's epilogue
-    if (ord + 1 < ntile) {
-      setup(t + t_stride);
-      if constexpr (!kNoDma) issue(0, 0);
-    }
+    // both groups aligned, nobody reads the slot of this tile's last K tile any more: it is the epilogue's staging area (the other slot
+    // holds the next tile's first K tile, landed and published above)
     if constexpr (kNoEpi) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) sbk::pin(acc[i][jj]);
     } else {
-      epilogue(t);
+      epilogue(t, (n - 1) & 1);
+      // (the epilogue's stores retired in the compiler's books too: see vm_drain_visible.  The next tile's first K tile landed before
+      // the epilogue; what this waits for is the stores' acknowledgement -- measured neutral against not waiting, visits AA / AB)
+      sbk::vm_drain_visible();
     }
     zero();
+    if (ord + 1 < ntile) {
+      sbk::lds_drain();
+      sbk::block_barrier_raw();  // every wave is done with the staging area: the next tile's second K tile may land there
+      if (group == 1) sbk::block_barrier_raw();
+    }
   }
 }
 
-template <bool FP8, int MODE>
+template <bool FP8, int MODE, int ACT>
 int launch_lp256(const sbk::Lp256Args& a0, hipStream_t st) {
   sbk::Lp256Args a = a0;
   a.tiles_m = sbk::cdiv(a.M, 256);
@@ -359,10 +404,10 @@ int launch_lp256(const sbk::Lp256Args& a0, hipStream_t st) {
   }
   static bool once = false;
   if (!once) {
-    (void)SBK_ALLOW_DYN_LDS((gemm_nt_lp256_kernel<FP8, MODE>), kLdsBytes);
+    (void)SBK_ALLOW_DYN_LDS((gemm_nt_lp256_kernel<FP8, MODE, ACT>), kLdsBytes);
     once = true;
   }
-  SBK_LAUNCH((gemm_nt_lp256_kernel<FP8, MODE>), dim3((unsigned)G), dim3(512), kLdsBytes, st, a);
+  SBK_LAUNCH((gemm_nt_lp256_kernel<FP8, MODE, ACT>), dim3((unsigned)G), dim3(512), kLdsBytes, st, a);
   return sbk::launch_status(FP8 ? "sbk_gemm_nt_fp8a" : "sbk_gemm_nt_bf16a");
 }
 
@@ -372,6 +417,7 @@ namespace sbk {
 bool lp256_routed(const Lp256Args& a) {
   const long k_bytes = 128L * a.KT;
   if (g_lp256 == 0 || a.KT < 2) return false;
+  if (a.act != SBK_ACT_NONE && a.act != SBK_ACT_GELU && a.act != SBK_ACT_SWISH) return false;  // (the instantiated epilogues)
   // the epilogue's vectors: four consecutive columns per lane
   const auto al = [](const void* p, uintptr_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
   if (a.N % 4 != 0 || !al(a.bias, 16) || !al(a.sw, 16) || (a.R && (a.ldr % 4 != 0 || !al(a.R, 16))) || (a.C && (a.ldc % 4 != 0 || !al(a.C, 16))) ||
@@ -383,16 +429,24 @@ bool lp256_routed(const Lp256Args& a) {
 }
 int g_lp256_mode = 0;  // key 62: MODE of gemm_nt_lp256_kernel (bf16 operands only; measurement builds 1 / 2 / 4 / 8, schedule variants 16 / 32 / 48)
 int gemm_nt_lp256(const Lp256Args& a, bool fp8, hipStream_t st) {
-  if (fp8) return launch_lp256<true, 0>(a, st);
+  if (fp8) {
+    switch (a.act) {
+      case SBK_ACT_GELU: return launch_lp256<true, 0, SBK_ACT_GELU>(a, st);
+      case SBK_ACT_SWISH: return launch_lp256<true, 0, SBK_ACT_SWISH>(a, st);
+      default: return launch_lp256<true, 0, SBK_ACT_NONE>(a, st);
+    }
+  }
+  if (a.act == SBK_ACT_GELU) return launch_lp256<false, 0, SBK_ACT_GELU>(a, st);
+  if (a.act == SBK_ACT_SWISH) return launch_lp256<false, 0, SBK_ACT_SWISH>(a, st);
   switch (g_lp256_mode) {
-    case 1: return launch_lp256<false, 1>(a, st);
-    case 2: return launch_lp256<false, 2>(a, st);
-    case 4: return launch_lp256<false, 4>(a, st);
-    case 8: return launch_lp256<false, 8>(a, st);
-    case 16: return launch_lp256<false, 16>(a, st);
-    case 32: return launch_lp256<false, 32>(a, st);
-    case 48: return launch_lp256<false, 48>(a, st);
-    default: return launch_lp256<false, 0>(a, st);
+    case 1: return launch_lp256<false, 1, SBK_ACT_NONE>(a, st);
+    case 2: return launch_lp256<false, 2, SBK_ACT_NONE>(a, st);
+    case 4: return launch_lp256<false, 4, SBK_ACT_NONE>(a, st);
+    case 8: return launch_lp256<false, 8, SBK_ACT_NONE>(a, st);
+    case 16: return launch_lp256<false, 16, SBK_ACT_NONE>(a, st);
+    case 32: return launch_lp256<false, 32, SBK_ACT_NONE>(a, st);
+    case 48: return launch_lp256<false, 48, SBK_ACT_NONE>(a, st);
+    default: return launch_lp256<false, 0, SBK_ACT_NONE>(a, st);
   }
 }
 }  // namespace sbk

@@ -219,6 +219,11 @@ __device__ __forceinline__ float ld4(const float* p) {
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // every outstanding vector-memory operation of this wave has completed (inline asm: the compiler cannot drop it)
 __device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The same wait as an instruction the compiler's own counter bookkeeping SEES (gfx9 encoding: vmcnt 0, expcnt / lgkmcnt untouched).
+// For the end of an epilogue in a kernel whose loop issues its LDS-DMA from inline asm: with stores still "in flight" in the compiler's
+// books it places its own s_waitcnt vmcnt(0) in front of the first instruction of the loop that overwrites one of their registers --
+// wherever that is, e.g. right behind the asm LDS-DMA of every K tile (csrc/gemm_lp256.hip, profiles/r06_ac_*).
+__device__ __forceinline__ void vm_drain_visible() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 // at most N of this wave's vector-memory operations still in flight (they retire in issue order)
 template <int N>
 __device__ __forceinline__ void vm_wait() {

@@ -930,7 +930,8 @@ def test_gemm_lp256_tiles_equal_the_128_tile_kernels(backend, M, N, K):
 
     def forms():
         out = [nat.gemm_nt_bf16a(ab, wd, bd, rd, act=nat.ACT_GELU, alpha=0.5), nat.gemm_nt_bf16a(ab, wd, None, None),
-               nat.gemm_nt_bf16a(ab, wd, bd, None, out_dtype=torch.bfloat16)]
+               nat.gemm_nt_bf16a(ab, wd, bd, None, out_dtype=torch.bfloat16), nat.gemm_nt_bf16a(ab, wd, bd, rd, act=nat.ACT_SWISH),
+               nat.gemm_nt_bf16a(ab, wd, bd, None, act=nat.ACT_RELU)]  # (an activation the 256 x 256 kernel does not instantiate: both routes are the 128 x 128 kernel)
         if K % 128 == 0:
             out += [nat.gemm_nt_fp8a(aq, wd, bd, rd, act=nat.ACT_GELU, alpha=0.5), nat.gemm_nt_fp8a(aq, wd),
                     nat.gemm_nt_fp8a(aq, wd, bd, out_dtype=torch.bfloat16), nat.gemm_nt_fp8a(aq, wd, bd, act=nat.ACT_GELU, out_dtype="fp8").q]

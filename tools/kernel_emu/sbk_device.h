@@ -415,6 +415,7 @@ static inline void pin(unsigned&) {}
 static inline void pin(float&) {}
 static inline void pin(f32x16&) {}
 static inline void vm_drain() {}
+static inline void vm_drain_visible() {}
 static inline void lds_drain() {}
 static inline void block_barrier_raw() { sbk_emu::block_barrier(); }
 template <int N>
