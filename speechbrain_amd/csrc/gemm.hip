@@ -1441,6 +1441,8 @@ static int* knob_slot(int key) {
     case 60: return &sbk::g_attn_exp2;
     case 61: return &sbk::g_lp256;
     case 62: return &sbk::g_lp256_mode;
+    case 63: return &sbk::g_x3p_fast_epi;
+    case 64: return &sbk::g_x3p_mode;
     default: return nullptr;
   }
 }

@@ -33,11 +33,14 @@
 #include "internal.h"
 
 #include <algorithm>
+#include <type_traits>
 
 using sbk::cdiv;
 using sbk::f32x16;
 
 namespace sbk {
+int g_x3p_fast_epi = 1;  // key 63
+int g_x3p_mode = 0;  // key 64
 // csrc/gemm.hip: the caller-registered stream workspace (slabs of kX3pSlabFloats floats each, tile tickets)
 bool stream_ws(hipStream_t st, float** slabs, int** cnt);
 int device_cus();
@@ -106,11 +109,15 @@ struct X3pArgs {
   int* cnt;
   int tiles_n, tiles, KT;  // KT = K / 16 stages per tile
   int whole;               // 1: gridDim.x == tiles, workgroup b runs tile b (no stream-K)
+  int fast_epi;            // key 63: 1 (default) = the hot epilogue forms as straight-line code, 0 = the generic form always
 };
 
 // WM x WN waves (= 8), each TM x TN sub-tiles of 32 x 32.
-template <int WM, int WN, int TM, int TN>
+// MODE: 0 = the kernel; measurement builds (key 64, tools/microbench.py --x3p-modes; garbage results): bit 0 = no LDS-DMA after a
+// segment's first two stages, 1 = no MFMAs, 2 = no epilogue, 3 = no fragment fetches.
+template <int WM, int WN, int TM, int TN, int MODE>
 __global__ void __launch_bounds__(512, 2) gemm_nt_x3p_kernel(X3pArgs s) {
+  constexpr bool kNoDma = MODE & 1, kNoMfma = MODE & 2, kNoEpi = MODE & 4, kNoFetch = MODE & 8;
   static_assert(WM * WN == 8, "eight waves: two per SIMD, half a stage apart");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int RBA = BM / 64, RBW = BN / 64;            // row blocks (chunks of 64 rows) of the A / W panels of a tile
@@ -236,6 +243,15 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_x3p_kernel(X3pArgs s) {
   const int wbase = (NPA + (wcol0 >> 6) * 6 + half) * kChunkFloats + lrow * 4;
 
   sbk::bf16x8 af[3][TM], wf[3][TN];
+  if constexpr (kNoFetch) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[p][i] = sbk::opaque_zero<sbk::bf16x8>();
+#pragma unroll
+      for (int jj = 0; jj < TN; ++jj) wf[p][jj] = sbk::opaque_zero<sbk::bf16x8>();
+    }
+  }
   auto fetch = [&](int slot) SBK_INLINE_LAMBDA {
     const float* sa = lds + slot * STAGE + abase;
     const float* sw = lds + slot * STAGE + wbase;
@@ -252,6 +268,16 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_x3p_kernel(X3pArgs s) {
     // smallest terms first; consecutive MFMAs go to different accumulators.  W is the FIRST operand: a lane owns one row m
     // of C and registers 4g .. 4g+3 hold four consecutive columns (16-byte epilogue vectors), as in gemm_nt_sk_kernel<X3>
     constexpr int PW_[6] = {0, 2, 1, 0, 1, 0}, PA_[6] = {2, 0, 1, 1, 0, 0};  // (W piece, A piece): hi.lo lo.hi mid.mid hi.mid mid.hi hi.hi
+    if constexpr (kNoMfma) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) sbk::keep(af[p][i]);
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) sbk::keep(wf[p][jj]);
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -260,7 +286,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_x3p_kernel(X3pArgs s) {
         for (int jj = 0; jj < TN; ++jj) acc[i][jj] = sbk::mfma_32x32x16_bf16(wf[PW_[t]][jj], af[PA_[t]][i], acc[i][jj]);
   };
 
-  auto epilogue = [&](int tile) SBK_INLINE_LAMBDA {
+  auto epilogue_generic = [&](int tile) SBK_INLINE_LAMBDA {
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const bool interior = m0 + BM <= M && n0 + BN <= N;  // uniform: no per-element predicates
 #pragma unroll
@@ -335,6 +361,120 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_x3p_kernel(X3pArgs s) {
     }
   };
 
+  // The hot forms of the epilogue as straight-line code (round 6): activation, residual, outputs and the edge predicates are compile-time,
+  // the bias vectors and the wave's whole residual block are requested before the first sub-tile is touched.  The generic form above has a
+  // run-time switch and exec-mask branches around every load and store; the compiler serialises it into dependent request -> wait ->
+  // store round trips (189 branches, 13 full s_waitcnt vmcnt(0) per tile): 28-36 % of the launch at K = 512 (profiles/r06_ae_*).
+  // The arithmetic per element is the generic form's, operation for operation (unmasked rows: v * alpha + residual, residual 0 when absent).
+  auto epilogue_fast = [&](int tile, auto act_c, auto r_c, auto c_c, auto pc_c, auto edge_c) SBK_INLINE_LAMBDA {
+    constexpr int ACT = decltype(act_c)::value;
+    constexpr bool HAS_R = decltype(r_c)::value, HAS_C = decltype(c_c)::value, HAS_PC = decltype(pc_c)::value, EDGE = decltype(edge_c)::value;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    float4 bv[TN][4];
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bv[jj][g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (gbias) {  // (uniform; the vectors are used unconditionally)
+#pragma unroll
+      for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = n0 + wcol0 + jj * 32 + 8 * g + 4 * half;
+          bv[jj][g] = *reinterpret_cast<const float4*>(gbias + (EDGE ? min(col, N - 4) : col));
+        }
+    }
+    float4 rv[TM][TN][4];
+    if constexpr (HAS_R) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wrow0 + i * 32 + lrow;
+        const float* rrow = gR + (size_t)(EDGE ? min(row, M - 1) : row) * ldr;
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int col = n0 + wcol0 + jj * 32 + 8 * g + 4 * half;
+            rv[i][jj][g] = *reinterpret_cast<const float4*>(rrow + (EDGE ? min(col, N - 4) : col));
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = m0 + wrow0 + i * 32 + lrow;
+      const bool row_ok = !EDGE || row < M;
+#pragma unroll
+      for (int jj = 0; jj < TN; ++jj) {
+        float v[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          v[4 * g] = acc[i][jj][4 * g] + bv[jj][g].x;
+          v[4 * g + 1] = acc[i][jj][4 * g + 1] + bv[jj][g].y;
+          v[4 * g + 2] = acc[i][jj][4 * g + 2] + bv[jj][g].z;
+          v[4 * g + 3] = acc[i][jj][4 * g + 3] + bv[jj][g].w;
+        }
+        if constexpr (ACT == SBK_ACT_SWISH) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+        } else {
+          static_assert(ACT == SBK_ACT_NONE, "x3p: activation not instantiated in the straight-line epilogue");
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = n0 + wcol0 + jj * 32 + 8 * g + 4 * half;
+          float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if constexpr (HAS_R) r4 = rv[i][jj][g];
+          const float o0 = v[4 * g] * alpha + r4.x, o1 = v[4 * g + 1] * alpha + r4.y;
+          const float o2 = v[4 * g + 2] * alpha + r4.z, o3 = v[4 * g + 3] * alpha + r4.w;
+          if (!EDGE || (row_ok && col < N)) {
+            if constexpr (HAS_C) *reinterpret_cast<float4*>(gC + (size_t)row * ldc + col) = make_float4(o0, o1, o2, o3);
+            if constexpr (HAS_PC) {  // (the panel image of the result: see the generic form)
+              const unsigned h0 = sbk::bf16_pair(o0, o1), h1 = sbk::bf16_pair(o2, o3);
+              const float r0 = o0 - __uint_as_float(h0 << 16), r1 = o1 - __uint_as_float(h0 & 0xffff0000u);
+              const float r2 = o2 - __uint_as_float(h1 << 16), r3 = o3 - __uint_as_float(h1 & 0xffff0000u);
+              const unsigned m0_ = sbk::bf16_pair(r0, r1), m1_ = sbk::bf16_pair(r2, r3);
+              const unsigned l0 = sbk::bf16_pair(r0 - __uint_as_float(m0_ << 16), r1 - __uint_as_float(m0_ & 0xffff0000u));
+              const unsigned l1 = sbk::bf16_pair(r2 - __uint_as_float(m1_ << 16), r3 - __uint_as_float(m1_ & 0xffff0000u));
+              const int KBn = N >> 4;
+              uint2* d = gPC + (((size_t)(row >> 6) * KBn + (col >> 4)) * 6 + ((col >> 3) & 1)) * 128 + (row & 63) * 2 + ((col >> 2) & 1);
+              d[0] = make_uint2(h0, h1);
+              d[256] = make_uint2(m0_, m1_);
+              d[512] = make_uint2(l0, l1);
+            }
+          }
+        }
+      }
+    }
+  };
+  auto epilogue = [&](int tile) SBK_INLINE_LAMBDA {
+    using std::integral_constant;
+    using T = std::true_type;
+    using F = std::false_type;
+    if (s.fast_epi && !seq_len) {  // (uniform)
+      const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+      const bool edge = !(m0 + BM <= M && n0 + BN <= N);
+      constexpr integral_constant<int, SBK_ACT_NONE> kNone{};
+      constexpr integral_constant<int, SBK_ACT_SWISH> kSwish{};
+      if (act == SBK_ACT_SWISH && !gR && !gC && gPC) {  // first feed-forward projection -> the second one's panel operand
+        if (edge) epilogue_fast(tile, kSwish, F{}, F{}, T{}, T{}); else epilogue_fast(tile, kSwish, F{}, F{}, T{}, F{});
+        return;
+      }
+      if (act == SBK_ACT_NONE && gR && gC && !gPC) {  // out-projection, second feed-forward projection, second pointwise convolution
+        if (edge) epilogue_fast(tile, kNone, T{}, T{}, F{}, T{}); else epilogue_fast(tile, kNone, T{}, T{}, F{}, F{});
+        return;
+      }
+      if (act == SBK_ACT_NONE && !gR && gC && !gPC) {  // q/k/v projection, first pointwise convolution
+        if (edge) epilogue_fast(tile, kNone, F{}, T{}, F{}, T{}); else epilogue_fast(tile, kNone, F{}, T{}, F{}, F{});
+        return;
+      }
+      if (act == SBK_ACT_SWISH && !gR && gC && !gPC) {
+        if (edge) epilogue_fast(tile, kSwish, F{}, T{}, F{}, T{}); else epilogue_fast(tile, kSwish, F{}, T{}, F{}, F{});
+        return;
+      }
+    }
+    epilogue_generic(tile);
+  };
+
   // a K range [lo, hi) of `tile` is complete in acc (every wave of the workgroup is here, both groups aligned)
   auto finish = [&](int tile, int lo, int hi) SBK_INLINE_LAMBDA {
     int* ticket = reinterpret_cast<int*>(lds + 2 * STAGE);  // slot 2 is idle between two segments
@@ -383,7 +523,17 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_x3p_kernel(X3pArgs s) {
         if (tid == 0) sbk::atomic_store_agent(cnt + tile, 0);  // re-armed for the next launch on this stream
       }
     }
-    if (store) epilogue(tile);
+    if constexpr (kNoEpi) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) sbk::pin(acc[i][jj]);
+    } else {
+      if (store) epilogue(tile);
+      // (the epilogue's stores retired in the compiler's books as well: with stores "in flight" it put an s_waitcnt vmcnt(0) of its own
+      // behind the LDS-DMA issue of every stage -- sbk::vm_drain_visible; the segment start waits for everything anyway)
+      sbk::vm_drain_visible();
+    }
   };
 
   // the barrier between two phases.  The scheduling fences pin it: MFMAs touch no memory, so the scheduler would otherwise
@@ -410,10 +560,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_x3p_kernel(X3pArgs s) {
     for (int n = 0; n < ns; ++n) {
       // ---- fetch phase (the SIMD's other wave multiplies meanwhile)
       const int slot = n % 3;
-      if (n + 2 < ns) issue(lo + n + 2, (n + 2) % 3);  // its slot was last read in stage n - 1: two barriers ago for both groups
-      fetch(slot);
+      if constexpr (!kNoDma) {
+        if (n + 2 < ns) issue(lo + n + 2, (n + 2) % 3);  // its slot was last read in stage n - 1: two barriers ago for both groups
+      }
+      if constexpr (!kNoFetch) fetch(slot);
       sbk::lds_drain();
-      if (n + 2 < ns) {
+      if (!kNoDma && n + 2 < ns) {
         wait_keep_one_stage();  // this wave's share of stage n + 1 has landed (stage n + 2 may fly on)
       } else {
         sbk::vm_drain();
@@ -438,11 +590,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_x3p_kernel(X3pArgs s) {
   }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int MODE>
 int launch_x3p(const X3pArgs& a0, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t lds = (size_t)3 * ((BM / 64 + BN / 64) * 6) * kChunk;
   X3pArgs a = a0;
+  a.fast_epi = sbk::g_x3p_fast_epi;
   a.tiles_n = cdiv(a.N, BN);
   a.tiles = cdiv(a.M, BM) * a.tiles_n;
   a.KT = a.K / 16;
@@ -459,10 +612,10 @@ int launch_x3p(const X3pArgs& a0, hipStream_t st) {
   }
   static bool once = false;
   if (!once) {
-    (void)SBK_ALLOW_DYN_LDS((gemm_nt_x3p_kernel<WM, WN, TM, TN>), lds);
+    (void)SBK_ALLOW_DYN_LDS((gemm_nt_x3p_kernel<WM, WN, TM, TN, MODE>), lds);
     once = true;
   }
-  SBK_LAUNCH((gemm_nt_x3p_kernel<WM, WN, TM, TN>), dim3((unsigned)G), dim3(512), lds, st, a);
+  SBK_LAUNCH((gemm_nt_x3p_kernel<WM, WN, TM, TN, MODE>), dim3((unsigned)G), dim3(512), lds, st, a);
   return sbk::launch_status("sbk_gemm_nt_x3p");
 }
 
@@ -485,7 +638,13 @@ int gemm_nt_x3p(const uint16_t* PA, const uint16_t* PW, const float* bias, const
   // algorithmic bytes: both operand images once (6 B per element) + the result (+ the residual)
   const double bytes = 6.0 * ((double)M * K + (double)N * K) + (C ? 4.0 : 0.0) * M * N + (PC ? 6.0 : 0.0) * M * N + (R ? 4.0 : 0.0) * M * N;
   ProfScope prof("gemm_nt_x3p", flops, bytes, st);
-  return launch_x3p<4, 2, 2, 2>(a, st);
+  switch (g_x3p_mode) {  // key 64: measurement builds
+    case 1: return launch_x3p<4, 2, 2, 2, 1>(a, st);
+    case 2: return launch_x3p<4, 2, 2, 2, 2>(a, st);
+    case 4: return launch_x3p<4, 2, 2, 2, 4>(a, st);
+    case 8: return launch_x3p<4, 2, 2, 2, 8>(a, st);
+    default: return launch_x3p<4, 2, 2, 2, 0>(a, st);
+  }
 }
 }  // namespace sbk
 

@@ -66,7 +66,7 @@ struct Lp256Args {
 };
 bool lp256_routed(const Lp256Args& a);
 int gemm_nt_lp256(const Lp256Args& a, bool fp8, hipStream_t st);
-extern int g_lp256, g_lp256_mode;
+extern int g_lp256, g_lp256_mode, g_x3p_mode, g_x3p_fast_epi;
 extern int g_x3r_xc;
 extern int g_score_fused;  // key 40: 1 (default) = the step's scoring as one pass per hypothesis row (csrc/search.hip)
 constexpr float kCtcNeg = -1e20f;  // the CTC scorer's finite "log 0" (ctc.py:150, scorer.py:1250)

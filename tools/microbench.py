@@ -294,6 +294,45 @@ if __name__ == "__main__":
             t2 = ev_time(lambda: nat.layernorm_x3p(x, g, b, 1e-5))
             print(f"ln-x3p M={M} d=512: layernorm {t0:6.1f} us ({8.0*M*512/t0/1e3:5.0f} GB/s) + split {t1:6.1f} us | layernorm_x3p {t2:6.1f} us ({10.0*M*512/t2/1e3:5.0f} GB/s)", flush=True)
         sys.exit(0)
+    if "--x3p-modes" in sys.argv:  # measurement builds of gemm_nt_x3p_kernel (key 64) at the encoder's shapes
+        def ev_time(fn, n=20):
+            fn(); fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+        lib = nat.load()
+        names = {0: "kernel", 1: "no LDS-DMA in the loop", 2: "no MFMAs", 4: "no epilogue", 8: "no fragment fetches"}
+        for (M, N, K, act, res, pout) in [(56064, 2048, 512, nat.ACT_SWISH, False, True), (56064, 512, 2048, nat.ACT_NONE, True, False),
+                                          (56064, 1536, 512, nat.ACT_NONE, False, False), (56064, 512, 512, nat.ACT_NONE, True, False),
+                                          (14016, 2048, 512, nat.ACT_SWISH, False, True), (14016, 512, 2048, nat.ACT_NONE, True, False)]:
+            a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
+            r = torch.randn(M, N, device=dev) if res else None
+            pa = nat.split_x3p(a)
+            fn = (lambda: nat.gemm_nt_x3p(pa, w, b, r, act=act, alpha=0.5, panel_out=True, fp32_out=False)) if pout else \
+                 (lambda: nat.gemm_nt_x3p(pa, w, b, r, act=act, alpha=0.5))
+            line = f"x3p M={M} N={N} K={K} act={act}{' + residual' if res else ''}{' -> panel' if pout else ''}:"
+            modes = (0, 0) if "--x3p-epi" in sys.argv else (0, 1, 2, 4, 8, 0)
+            outs = []
+            for fe in ((0, 1, 0, 1) if "--x3p-epi" in sys.argv else (1,)):  # key 63: the generic epilogue / the straight-line forms
+                lib.sbk_prof_set_knob(63, fe)
+                if "--x3p-epi" in sys.argv:
+                    line += f"  | key 63 = {fe}:"
+                    o = fn()
+                    outs.append(o.data.clone() if hasattr(o, "data") and not torch.is_tensor(o) else o.clone())
+                for mode in modes:
+                    lib.sbk_prof_set_knob(64, mode)
+                    t = ev_time(fn)
+                    line += f"  [{names[mode]}] {t:6.1f} us"
+            lib.sbk_prof_set_knob(64, 0)
+            lib.sbk_prof_set_knob(63, 1)
+            same = f"  identical: {bool(torch.equal(outs[0], outs[1]))}" if outs else ""
+            print(line + f"  ({2.0*M*N*K/t/1e6:5.1f} TF/s){same}", flush=True)
+        sys.exit(0)
     if "--x3p" in sys.argv:  # both operands pre-split, panel layout, 256-wide tiles (csrc/gemm_x3p.hip) vs the f32x3 kernel
         def ev_time(fn, n=30):
             fn(); fn()
