@@ -22,7 +22,7 @@
 //     consecutive tiles round by round: the 32 tiles an XCD works on at a time are 8 x 4 -- 12 operand blocks in its L2 instead
 //     of the 2 + tiles_n of a row-major order;
 //   * persistent over whole tiles, the K tiles of consecutive output tiles one stream through the ring (the next tile's first K tile
-//     lands under this tile's last steps; nothing waits for an epilogue's stores at a tile's start); the epilogue turns the
+//     lands under this tile's last steps); the epilogue turns the
 //     accumulators through LDS and writes whole lines (see there).
 // Arithmetic, epilogue and outputs are gemm_nt_bf16dma_kernel's / gemm_nt_fp8dma_kernel's (fp32 accumulation; per-row scales of
 // both fp8 operands applied to the accumulators; bias, activation, alpha, fp32 residual; fp32 / bf16 / e4m3 outputs): the same sums
@@ -326,8 +326,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
   // tenant n - 1 was last fetched in step (n - 1, 1), which ended two physical barriers ago for this group and one for the other; behind
   // an output tile's end the slot was that tile's epilogue staging area, released by the barrier after the epilogue] fetch; drain
   // the LDS reads; [h = 1: this wave's share of K tile n + 1 has landed -- read two program barriers later, i.e. at least one physical
-  // barrier after the OTHER group's wait]; barrier; MFMAs; barrier.  Nothing waits for an epilogue's stores at a tile's start: they are
-  // first waited for half a K tile into the next tile, together with that tile's second K tile.
+  // barrier after the OTHER group's wait]; barrier; MFMAs; barrier.
   setup(t_first);
   issue(0, 0);
   zero();
@@ -415,7 +414,6 @@ int launch_lp256(const sbk::Lp256Args& a0, hipStream_t st) {
 
 namespace sbk {
 bool lp256_routed(const Lp256Args& a) {
-  const long k_bytes = 128L * a.KT;
   if (g_lp256 == 0 || a.KT < 2) return false;
   if (a.act != SBK_ACT_NONE && a.act != SBK_ACT_GELU && a.act != SBK_ACT_SWISH) return false;  // (the instantiated epilogues)
   // the epilogue's vectors: four consecutive columns per lane
@@ -423,7 +421,6 @@ bool lp256_routed(const Lp256Args& a) {
   if (a.N % 4 != 0 || !al(a.bias, 16) || !al(a.sw, 16) || (a.R && (a.ldr % 4 != 0 || !al(a.R, 16))) || (a.C && (a.ldc % 4 != 0 || !al(a.C, 16))) ||
       (a.Cb && (a.ldcb % 4 != 0 || !al(a.Cb, 8))) || (a.C8 && (a.ldc8 % 4 != 0 || !al(a.C8, 4))))
     return false;
-  (void)k_bytes;
   if (g_lp256 == 2) return true;
   return (long)cdiv(a.M, 256) * cdiv(a.N, 256) >= 128;
 }
