@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_bf16dma_kernel(Bf16DmaArgs s) 
             break;
           case SBK_ACT_GELU:
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752440f));
+            for (int r = 0; r < 16; ++r) v[r] = sbk::gelu_erfc(v[r]);
             break;
           case SBK_ACT_RELU:
 #pragma unroll
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fp8dma_kernel(Fp8DmaArgs s) {
             break;
           case SBK_ACT_GELU:
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752440f));
+            for (int r = 0; r < 16; ++r) v[r] = sbk::gelu_erfc(v[r]);
             break;
           case SBK_ACT_RELU:
 #pragma unroll

@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_lp256_kernel(sbk::Lp256Args s)
           for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
         } else if constexpr (ACT == SBK_ACT_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+          for (int e = 0; e < 4; ++e) v[e] = sbk::gelu_erfc(v[e]);
         } else {
           static_assert(ACT == SBK_ACT_NONE, "lp256: activation not instantiated");
         }

@@ -139,6 +139,25 @@ __device__ __forceinline__ T opaque_zero() {
   asm volatile("" : "+v"(u));
   return __builtin_bit_cast(T, u);
 }
+// GELU (erf form) for the epilogues of the REDUCED-PRECISION contractions (bf16 / e4m3 activations: csrc/gemm_lp.hip, gemm_lp256.hip;
+// the fp32 parity path keeps libm's erff).  1 + erf(x / sqrt 2) = 2 - erfc(z) for x >= 0 and erfc(z) for x < 0, z = |x| / sqrt 2, with
+// erfc by Abramowitz & Stegun 7.1.26 (absolute error <= 1.5e-7: below half an ulp of the bf16 / e4m3 value it is rounded to, and the
+// negative tail keeps its RELATIVE accuracy because erfc is formed directly, not as 1 - erf) on one v_rcp_f32 and one v_exp_f32: about 17
+// instructions where libm's erff is ~35 with both of its branches taken in a wave -- the first feed-forward projection of a Whisper
+// large-v3 layer evaluates it 61 M times per launch (54 of its 146 us, profiles/r06_ad_*).
+// Compiled under `fp contract(off)` with its fused operations written out: two kernels that must agree bit for bit (the 128 x 128 and
+// the 256 x 256 contraction, tests/test_kernels.py) inline it, and what each kernel's optimiser would contract differs (seen on the GPU).
+__device__ __forceinline__ float gelu_erfc(float x) {
+#pragma clang fp contract(off)
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float q = (p * t) * exp2_raw(-1.44269504088896340736f * (z * z));  // erfc(z)
+  return (0.5f * x) * (x >= 0.0f ? 2.0f - q : q);
+}
 // wave priority for the instruction arbiter of the SIMD (0 = default .. 3)
 template <int P>
 __device__ __forceinline__ void set_prio() { __builtin_amdgcn_s_setprio(P); }

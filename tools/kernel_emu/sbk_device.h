@@ -393,6 +393,16 @@ static inline void glds16_uniform(const float* base, unsigned lane_byte_offset, 
   memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * sbk_emu::cur().lane, reinterpret_cast<const char*>(base) + lane_byte_offset, 16);
 }
 static inline int uniform(int v) { return v; }
+static inline float gelu_erfc(float x) {  // (the device version's formula; its v_rcp_f32 / v_exp_f32 are a true quotient / exp2f here)
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = 1.0f / fmaf(0.3275911f, z, 1.0f);
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float q = (p * t) * exp2f(-1.44269504088896340736f * (z * z));
+  return (0.5f * x) * (x >= 0.0f ? 2.0f - q : q);
+}
 template <class T>
 static inline void keep(const T&) {}
 template <class T>
