@@ -367,7 +367,10 @@ def whisper_encoder_leg(dev, B=8, reps=3):
                          "contractions too (round 4: LayerNorm writes fp8 rows with one scale per row, weights with one scale per "
                          "output channel, q/k/v projection and the feed-forward pair on v_mfma_f32_32x32x64_f8f6f4 -- the 2 x-rate fp8 "
                          "instruction -- attention and its out-projection on bf16 rows); fp16 reads fp32 activations and rounds them "
-                         "on load; fp8_fp32_activations = the round-3 fp8 path (per-tensor scales, activation max |x| per GEMM)"}
+                         "on load; fp8_fp32_activations = the round-3 fp8 path (per-tensor scales, activation max |x| per GEMM).  Round 6: the bf16 / fp8 "
+                         "contractions at these shapes run on 256 x 256 tiles (csrc/gemm_lp256.hip: bit-identical to the 128 x 128 kernels), "
+                         "the bf16 attention computes its softmax in base 2 on one v_exp_f32 per score, the GELU of the reduced-precision "
+                         "epilogues is erfc by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7; the fp32 path keeps libm's erff)"}
     flops = B * 32 * (1500 * 2.0 * (4 * 1280 * 1280 + 2 * 1280 * 5120) + 4.0 * 1500 * 1500 * 1280) \
         + B * 2.0 * (3000 * 1280 * 384 + 1500 * 1280 * 3840)
     ref = None
