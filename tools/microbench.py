@@ -464,14 +464,18 @@ if __name__ == "__main__":
             return e0.elapsed_time(e1) * 1e3 / n
         lib = nat.load()
         # (rows, N, K, activation, output): the four projections of a Whisper large-v3 encoder layer at 8 x 30 s, then Conformer-L's
+        if "--lp256-small" in sys.argv:  # where the 256 x 256 route starts to pay: 36 ... 360 tiles (1 / 2 / 4 / 8 x 30 s of Whisper rows)
+            small = [(M, N, K, nat.ACT_NONE, od) for M in (1500, 3000, 6000) for (N, K, od) in ((3840, 1280, torch.bfloat16), (1280, 1280, torch.float32), (5120, 1280, "hidden"), (1280, 5120, torch.float32))]
         shapes = [(12000, 3840, 1280, nat.ACT_NONE, torch.bfloat16), (12000, 1280, 1280, nat.ACT_NONE, torch.float32),
                   (12000, 5120, 1280, nat.ACT_GELU, "hidden"), (12000, 1280, 5120, nat.ACT_NONE, torch.float32),
                   (12000, 5120, 1280, nat.ACT_NONE, "hidden"), (48000, 1280, 1280, nat.ACT_NONE, torch.float32),
                   (14016, 2048, 512, nat.ACT_SWISH, torch.bfloat16), (14016, 512, 2048, nat.ACT_NONE, torch.float32)]
+        if "--lp256-small" in sys.argv:
+            shapes = small
         for (M, N, K, act, od) in shapes:
             a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.05; ab = a.bfloat16(); aq = nat.quant_rows_fp8(a)
             b = torch.randn(N, device=dev); r = torch.randn(M, N, device=dev) if od is torch.float32 else None
-            line = f"M={M} N={N} K={K} act={act} out={'fp8/bf16' if od == 'hidden' else str(od).replace('torch.', '')}:"
+            line = f"M={M} N={N} K={K} ({-(-M // 256) * -(-N // 256)} tiles) act={act} out={'fp8/bf16' if od == 'hidden' else str(od).replace('torch.', '')}:"
             for name, fn in (("bf16a", lambda: nat.gemm_nt_bf16a(ab, w, b, r, act=act, out_dtype=torch.bfloat16 if od == "hidden" else od)),
                              ("fp8a", lambda: nat.gemm_nt_fp8a(aq, w, b, r, act=act, out_dtype="fp8" if od == "hidden" else od))):
                 ts = []
