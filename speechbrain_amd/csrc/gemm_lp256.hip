@@ -36,7 +36,7 @@ using sbk::f32x16;
 
 namespace sbk {
 int device_cus();
-int g_lp256 = 1;  // key 61: 1 (default) = shapes with >= 128 tiles of 256 x 256 take this kernel, 0 = never, 2 = always (tests)
+int g_lp256 = 1;  // key 61: 1 (default) = shapes with >= 128 (96: fp32 result + residual) tiles of 256 x 256 take this kernel, 0 = never, 2 = always (tests)
 }  // namespace sbk
 
 namespace {
@@ -422,7 +422,10 @@ bool lp256_routed(const Lp256Args& a) {
       (a.Cb && (a.ldcb % 4 != 0 || !al(a.Cb, 8))) || (a.C8 && (a.ldc8 % 4 != 0 || !al(a.C8, 4))))
     return false;
   if (g_lp256 == 2) return true;
-  return (long)cdiv(a.M, 256) * cdiv(a.N, 256) >= 128;
+  // from how many tiles on (profiles/r06_ai_*: 36 ... 480 tiles): 128 in general -- below, the 128 x 128 kernels' four times as many
+  // workgroups fill the chip better --, 96 for an fp32 result with a residual, whose rows the 128 x 128 kernels move as 4-byte accesses
+  // (6 000 x 1 280 x 1 280, 120 tiles: 41 against 80 us)
+  return (long)cdiv(a.M, 256) * cdiv(a.N, 256) >= ((a.C && a.R) ? 96 : 128);
 }
 int g_lp256_mode = 0;  // key 62: MODE of gemm_nt_lp256_kernel (bf16 operands only; measurement builds 1 / 2 / 4 / 8, schedule variants 16 / 32 / 48)
 int gemm_nt_lp256(const Lp256Args& a, bool fp8, hipStream_t st) {
