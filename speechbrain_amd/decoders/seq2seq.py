@@ -286,6 +286,19 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
                                                          enc_lens, cw, cb)
         return tok, ln, sc, lp, mxl
 
+    def _forward_each(self, items, ratios=None):
+        """``forward`` batch by batch under each batch's own decode ratios (the fallback of ``forward_group``)."""
+        keep = (self.min_decode_ratio, self.max_decode_ratio)
+        out = []
+        try:
+            for i, (enc, wl) in enumerate(items):
+                if ratios is not None:
+                    self.min_decode_ratio, self.max_decode_ratio = ratios[i]
+                out.append(self.forward(enc, wl))
+        finally:
+            self.min_decode_ratio, self.max_decode_ratio = keep
+        return out
+
     @torch.no_grad()
     def forward_group(self, items, ratios=None):
         """Several independent batches in ONE device search.
@@ -297,7 +310,9 @@ class S2STransformerBeamSearcher(S2SBaseSearcher):
         step runs over the rows of all batches at once (csrc/search.hip, ``utt_max_steps``): with recipe-sized
         batches the per-step GEMMs otherwise see a few hundred rows and cannot fill the chip."""
         if self.ctc_window_size and len(items) > 1:
-            raise NotImplementedError("the CTC attention window takes its frame range over the whole batch: no grouped search")
+            # the CTC attention window takes its frame range over the whole batch of a search (ctc.py:189-200): the batches keep their
+            # own searches -- what the reference, which has no grouped search, does with them
+            return self._forward_each(items, ratios)
         if len(items) == 1 and ratios is None:
             return [self.forward(*items[0])]
         dev = items[0][0].device
@@ -430,4 +445,5 @@ class S2SWhisperBeamSearcher(_WhisperPrompting, S2STransformerBeamSearcher):
         return S2STransformerBeamSearcher.forward(self, enc_states, wav_len)
 
     def forward_group(self, items, ratios=None):
-        raise NotImplementedError("grouped search with a token prompt")
+        # a token prompt primes every hypothesis' cache at its own decoder positions: the batches keep their own searches
+        return self._forward_each(items, ratios)

@@ -951,6 +951,36 @@ def test_grouped_search_equals_separate_searches(backend, ctc_weight):
         dec.overlap_ctc, dec.graph_mode = saved
 
 
+def test_grouped_search_with_a_ctc_attention_window_runs_batch_by_batch(backend):
+    """forward_group with CTCScorer(ctc_window_size > 0) (scorer.py:183-187, ctc.py:189-200): the window's frame range is taken over
+    the whole batch of a search, so the batches of a group keep their own searches (what the reference, which has no grouped search,
+    does) -- every batch gets exactly what forward gives it under its own decode ratios, and the searcher's own ratios are restored."""
+    nat, dev = backend
+    from speechbrain_amd.inference.builders import build_asr
+
+    tiny = dict(d_model=32, nhead=4, d_ffn=64, n_enc=1, n_dec=2, n_fft=512, win_length=32)
+    asr = build_asr(tiny, vocab=30, seed=23, beam_size=4, ctc_weight=0.4, device=str(dev), using_eos_threshold=True)
+    dec = asr.mods.decoder
+    dec.ctc_window_size = 6
+    g = torch.Generator().manual_seed(5)
+    items, ratios = [], [(0.0, 0.5), (0.1, 0.8), (0.0, 0.3)]
+    for B, N in [(2, 9600), (3, 6400), (1, 12800)]:
+        wav = 0.1 * torch.randn(B, N, generator=g)
+        lens = torch.linspace(0.8, 1.0, B)
+        items.append((asr.encode_batch(wav, lens), lens.to(dev)))
+    keep = (dec.min_decode_ratio, dec.max_decode_ratio)
+    separate = []
+    for (enc, wl), r in zip(items, ratios):
+        dec.min_decode_ratio, dec.max_decode_ratio = r
+        separate.append(dec(enc, wl))
+    dec.min_decode_ratio, dec.max_decode_ratio = keep
+    grouped = dec.forward_group(items, ratios)
+    assert (dec.min_decode_ratio, dec.max_decode_ratio) == keep
+    assert len(grouped) == len(separate)
+    for (h_g, l_g, s_g, p_g), (h_s, l_s, s_s, p_s) in zip(grouped, separate):
+        assert h_g == h_s and torch.equal(s_g.cpu(), s_s.cpu()) and torch.equal(p_g.cpu(), p_s.cpu())
+
+
 @pytest.mark.parametrize("attention", ["RelPosMHAXL", "RoPEMHA"])
 def test_grouped_encoder_equals_batch_by_batch(backend, attention):
     """encode_group: the Conformer encoder over the rows of several independently padded batches laid end to end (one

@@ -263,6 +263,12 @@ def test_whisper_beam_searcher_matches_reference_golden(backend):
         assert np.abs(np.array(s.no_speech_probs) - g[f"beam_{tag}_no_speech"][::4]).max() <= 1e-5, tag
         s.set_lang_tokens(torch.tensor([4, 5, 6]))  # one per utterance gives the same search
         assert s(enc, torch.ones(3))[0] == hyps
+    # forward_group: a token prompt primes every hypothesis' cache at its own decoder positions, so the batches of a group keep
+    # their own searches (two copies of the batch give the golden hypotheses twice)
+    s = S2SWhisperBeamSearcher(module=[w], **{**base, "temperature": 1.0})
+    s.set_lang_tokens(torch.tensor([4, 5, 6]))
+    both = s.forward_group([(enc, torch.ones(3)), (enc, torch.ones(3))])
+    assert len(both) == 2 and both[0][0] == both[1][0] == [[int(t) for t in row if t >= 0] for row in g["beam_t10_hyps"]]
     s = S2SWhisperBeamSearcher(module=[w], **{**base, "temperature": 1.0, "return_topk": True, "topk": 3})
     s.set_lang_tokens(torch.tensor([4, 5, 6]))
     k_hyps, k_lens, k_scores, _ = s(enc, torch.ones(3))
