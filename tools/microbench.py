@@ -451,6 +451,22 @@ if __name__ == "__main__":
             lib.sbk_prof_set_knob(62, 0)
             lib.sbk_prof_set_knob(61, 1)
         sys.exit(0)
+    if "--lp256-pmc" in sys.argv:  # short: the Whisper layer's four contractions on the 256 x 256 kernel, 6 launches each, for the counters passes
+        shapes = [(12000, 3840, 1280, nat.ACT_NONE, torch.bfloat16), (12000, 1280, 1280, nat.ACT_NONE, torch.float32),
+                  (12000, 5120, 1280, nat.ACT_GELU, "hidden"), (12000, 1280, 5120, nat.ACT_NONE, torch.float32)]
+        for fp8 in (False, True):
+            for (M, N, K, act, od) in shapes:
+                a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.05; ab = a.bfloat16(); aq = nat.quant_rows_fp8(a)
+                b = torch.randn(N, device=dev); r = torch.randn(M, N, device=dev) if od is torch.float32 else None
+                nat.gemm_nt_fp8a(aq, w, b, r) if fp8 else nat.gemm_nt_bf16a(ab, w, b, r)  # (weight images cached before the counted launches)
+                torch.cuda.synchronize()
+                for _ in range(6):
+                    if fp8:
+                        nat.gemm_nt_fp8a(aq, w, b, r, act=act, out_dtype="fp8" if od == "hidden" else od)
+                    else:
+                        nat.gemm_nt_bf16a(ab, w, b, r, act=act, out_dtype=torch.bfloat16 if od == "hidden" else od)
+                torch.cuda.synchronize()
+        sys.exit(0)
     if "--lp256" in sys.argv:  # bf16 / e4m3 activation x weight contractions: 128 x 128 tiles (key 61 = 0) vs 256 x 256 (csrc/gemm_lp256.hip)
         def ev_time(fn, n=20):
             fn(); fn()
