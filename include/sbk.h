@@ -255,7 +255,9 @@ int sbk_gemm_nt_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, const
  * fp32 (C) and / or as bf16 (Cb: the next contraction's operand, rounded to nearest even -- the same value the fp32-A
  * kernel above would round on its way into LDS, so the two paths differ by summation order only).
  * sbk_layernorm_bf16o / sbk_rope_attention_bf16o are the producers of such operands: LayerNorm / attention context
- * written as bf16. */
+ * written as bf16.  Round 6: from 128 tiles of 256 x 256 on (96 for an fp32 result with a residual; 16-byte aligned rows of
+ * C / residual / bias, N % 4 == 0) this entry and sbk_gemm_nt_fp8a run csrc/gemm_lp256.hip -- the same sums in the same order,
+ * bit-identical results; the GELU of these two entries is erfc by Abramowitz-Stegun 7.1.26 (|error| <= 4.2e-7 in fp32). */
 int sbk_gemm_nt_bf16a(const uint16_t* A, int lda, const uint16_t* Wb, int ldw, const float* bias, const float* residual,
                       int ldr, float* C, int ldc, uint16_t* Cb, int ldcb, int M, int N, int K, int act, float alpha,
                       sbk_stream_t stream);
